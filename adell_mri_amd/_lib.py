@@ -1,0 +1,87 @@
+"""ctypes binding of ``libadellhip.so`` (C ABI: ``include/adell_hip.h``).
+
+The library is the product: there is no CPU or eager-torch fallback. A missing
+library, or a kernel call on a non-CUDA tensor, raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libadellhip.so")
+
+_lib = None
+
+OK = 0
+E_BADARG, E_UNSUPPORTED, E_HIP, E_NOMEM = -1, -2, -3, -4
+
+ACT_IDS = {
+    "identity": 0, "swish": 1, "silu": 1, "relu": 2, "leaky_relu": 3, "prelu": 4,
+    "gelu": 5, "sigmoid": 6, "tanh": 7, "elu": 8,
+}
+
+
+class AdellHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "D", "H", "W", "C0", "C1", "Cout", "KD", "KH", "KW", "SD", "SH", "SW",
+        "PD", "PH", "PW", "Do", "Ho", "Wo")]
+
+
+class NormActDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", ctypes.c_int64), ("V", ctypes.c_int64), ("C", ctypes.c_int32),
+        ("stats_per_item", ctypes.c_int32), ("act", ctypes.c_int32),
+        ("act_w_n", ctypes.c_int32), ("act_p", ctypes.c_float),
+        ("drop_p", ctypes.c_float), ("seed", ctypes.c_uint64),
+        ("rng_offset", ctypes.c_uint32),
+    ]
+
+
+_vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> (restype, argtypes); every symbol include/adell_hip.h declares.
+SIGNATURES = {
+    "adell_abi_version": (_i, []),
+    "adell_last_error": (ctypes.c_char_p, []),
+    "adell_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "adell_conv3d_fwd_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "adell_conv3d_bwd_data": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "adell_convtranspose3d_k2s2_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "adell_convtranspose3d_k2s2_bwd_data": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "adell_stats_finalize": (_i, [_vp, _i, _i, _i, _l, _f, _vp, _vp, _vp]),
+    "adell_channel_partials_ntiles": (_i, [_l]),
+    "adell_channel_partials": (_i, [_vp, _i, _l, _i, _vp, _vp]),
+    "adell_norm_act_fwd": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "adell_debug_force_conv_cfg": (None, [_i]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdellHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C adell_mri_amd/csrc`). adell_mri_amd has no fallback path."
+            )
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = lib().adell_last_error().decode("utf-8", "replace")
+        kind = {E_BADARG: "bad argument", E_UNSUPPORTED: "unsupported", E_HIP: "HIP error",
+                E_NOMEM: "out of memory"}.get(rc, f"error {rc}")
+        raise AdellHipError(f"libadellhip: {kind}: {msg}")
+    return rc

@@ -1,0 +1,75 @@
+// Shared helpers for the adell HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/adell_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ADELL_WAVE 64
+
+void adell_set_error(const char* fmt, ...);
+
+#define ADELL_CHECK_HIP(expr)                                                  \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      adell_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,            \
+                      hipGetErrorString(_e));                                  \
+      return ADELL_E_HIP;                                                      \
+    }                                                                          \
+  } while (0)
+
+#define ADELL_REQUIRE(cond, ...)                                               \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      adell_set_error(__VA_ARGS__);                                            \
+      return ADELL_E_BADARG;                                                   \
+    }                                                                          \
+  } while (0)
+
+static inline int adell_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int adell_ilog2(int v) {
+  int r = 0;
+  while ((1 << r) < v) ++r;
+  return r;
+}
+static inline bool adell_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float adell_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double adell_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Activation ids shared with the host side (adell_hip.h: ADELL_ACT_*).
+__device__ __forceinline__ float adell_sigmoidf(float x) {
+  return 1.0f / (1.0f + expf(-x));
+}
+
+// Philox-4x32-10 counter RNG: one call -> 4 uniform 32-bit words. The dropout
+// mask of element e of a tensor is a pure function of (seed, offset, e), so
+// forward and backward regenerate it instead of storing it.
+__device__ __forceinline__ uint4 adell_philox4(uint32_t c0, uint32_t c1,
+                                               uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}

@@ -1,0 +1,303 @@
+// Host launchers + C-ABI for the 3D convolution family (see conv_igemm.h for
+// the kernel). Everything here is NDHWC fp32 on raw device pointers.
+#include "conv_igemm.h"
+
+// ---------------------------------------------------------------------------
+// Tile selection. BM voxels are laid out as a TX x TY x TZ brick (powers of 2).
+// ---------------------------------------------------------------------------
+struct ConvTile {
+  int cfg;  // 0: 256x64, 1: 256x32, 2: 64x64, 3: 128x32
+  int BM, BN;
+  int lTX, lTY, lTZ;
+};
+
+static void adell_shape_brick(int BM, int Wo, int Ho, int Do, int* lx, int* ly,
+                              int* lz) {
+  // Spread log2(BM) bits over x,y,z (x first) without exceeding the padded
+  // extent of each dim; leftover bits go to x.
+  int bits = adell_ilog2(BM);
+  int cap[3] = {adell_ilog2(Wo), adell_ilog2(Ho), adell_ilog2(Do)};
+  int l[3] = {0, 0, 0};
+  int pref[3] = {3, 3, 2};  // 8 x 8 x 4
+  for (int pass = 0; pass < 2 && bits > 0; ++pass) {
+    bool progress = true;
+    while (bits > 0 && progress) {
+      progress = false;
+      for (int d = 0; d < 3 && bits > 0; ++d) {
+        const int lim = pass == 0 ? (cap[d] < pref[d] ? cap[d] : pref[d]) : cap[d];
+        if (l[d] < lim) {
+          ++l[d];
+          --bits;
+          progress = true;
+        }
+      }
+    }
+  }
+  l[0] += bits;
+  *lx = l[0];
+  *ly = l[1];
+  *lz = l[2];
+}
+
+static ConvTile adell_pick_tile(int N, int Do, int Ho, int Wo, int Cout,
+                                int force_cfg) {
+  ConvTile t;
+  const long vox = (long)N * Do * Ho * Wo;
+  const bool wide = Cout > 32;
+  const bool big = vox * (wide ? adell_cdiv(Cout, 64) : 1) >= 256L * 256;
+  if (force_cfg >= 0)
+    t.cfg = force_cfg;
+  else if (big)
+    t.cfg = wide ? 0 : 1;
+  else
+    t.cfg = wide ? 2 : 3;
+  switch (t.cfg) {
+    case 0: t.BM = 256; t.BN = 64; break;
+    case 1: t.BM = 256; t.BN = 32; break;
+    case 2: t.BM = 64; t.BN = 64; break;
+    default: t.BM = 128; t.BN = 32; break;
+  }
+  adell_shape_brick(t.BM, Wo, Ho, Do, &t.lTX, &t.lTY, &t.lTZ);
+  return t;
+}
+
+static int g_conv_force_cfg = -1;
+extern "C" void adell_debug_force_conv_cfg(int cfg) { g_conv_force_cfg = cfg; }
+
+template <int MT, int NT, int WM, int WN>
+static int adell_launch_conv(const ConvArgs& a, dim3 grid, size_t lds,
+                             hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = adell_conv_igemm_kernel<MT, NT, WM, WN>;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(kern),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// Generic launcher. `a` must have everything but the tile fields filled in.
+static int adell_conv_dispatch(ConvArgs a, int N, hipStream_t st) {
+  const ConvTile t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, g_conv_force_cfg);
+  a.lTX = t.lTX;
+  a.lTY = t.lTY;
+  a.lTZ = t.lTZ;
+  const int TX = 1 << t.lTX, TY = 1 << t.lTY, TZ = 1 << t.lTZ;
+  a.ntx = adell_cdiv(a.Wo, TX);
+  a.nty = adell_cdiv(a.Ho, TY);
+  a.ntz = adell_cdiv(a.Do, TZ);
+  a.HX = (TX - 1) * a.SW + a.KW;
+  a.HY = (TY - 1) * a.SH + a.KH;
+  a.HZ = (TZ - 1) * a.SD + a.KD;
+  a.VP = a.HX * a.HY * a.HZ;
+  if ((a.VP & 1) == 0) a.VP += 1;
+  const int ntap = a.KD * a.KH * a.KW;
+  size_t lds = ((size_t)8 * a.VP + (size_t)ntap * 8 * t.BN) * sizeof(float);
+  const size_t red = (size_t)4 * t.BN * 2 * sizeof(float);
+  if (lds < red) lds = red;
+  if (lds > 160 * 1024) {
+    adell_set_error("conv: LDS need %zu B exceeds 160 KiB (halo %dx%dx%d)", lds,
+                    a.HX, a.HY, a.HZ);
+    return ADELL_E_UNSUPPORTED;
+  }
+  a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) &&
+           (((uintptr_t)a.x0 & 15) == 0) && (((uintptr_t)a.x1 & 15) == 0);
+  a.vecw = (a.Cout % 4 == 0) && (((uintptr_t)a.w & 15) == 0);
+  const long nsp = (long)a.ntx * a.nty * a.ntz;
+  if (nsp > 0x7fffffffL || N > 65535) {
+    adell_set_error("conv: grid too large");
+    return ADELL_E_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)nsp, (unsigned)adell_cdiv(a.Cout, t.BN), (unsigned)N);
+  switch (t.cfg) {
+    case 0: return adell_launch_conv<2, 2, 4, 1>(a, grid, lds, st);
+    case 1: return adell_launch_conv<2, 1, 4, 1>(a, grid, lds, st);
+    case 2: return adell_launch_conv<1, 1, 2, 2>(a, grid, lds, st);
+    default: return adell_launch_conv<1, 1, 4, 1>(a, grid, lds, st);
+  }
+}
+
+static int adell_check_desc(const adell_conv3d_desc* d) {
+  ADELL_REQUIRE(d != nullptr, "conv: null descriptor");
+  ADELL_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, "conv: bad input dims");
+  ADELL_REQUIRE(d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad channel counts");
+  ADELL_REQUIRE(d->KD >= 1 && d->KD <= 3 && d->KH >= 1 && d->KH <= 3 && d->KW >= 1 &&
+                    d->KW <= 3,
+                "conv: kernel size must be 1..3 per dim");
+  ADELL_REQUIRE(d->SD >= 1 && d->SD <= 2 && d->SH >= 1 && d->SH <= 2 && d->SW >= 1 &&
+                    d->SW <= 2,
+                "conv: stride must be 1..2 per dim");
+  ADELL_REQUIRE(d->PD >= 0 && d->PH >= 0 && d->PW >= 0, "conv: negative padding");
+  ADELL_REQUIRE(d->Do == (d->D + 2 * d->PD - d->KD) / d->SD + 1 &&
+                    d->Ho == (d->H + 2 * d->PH - d->KH) / d->SH + 1 &&
+                    d->Wo == (d->W + 2 * d->PW - d->KW) / d->SW + 1,
+                "conv: output dims do not match input/kernel/stride/pad");
+  ADELL_REQUIRE(d->Do > 0 && d->Ho > 0 && d->Wo > 0, "conv: empty output");
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv3d_fwd_ntiles(const adell_conv3d_desc* d) {
+  if (adell_check_desc(d) != ADELL_OK) return ADELL_E_BADARG;
+  const ConvTile t = adell_pick_tile(d->N, d->Do, d->Ho, d->Wo, d->Cout, g_conv_force_cfg);
+  return adell_cdiv(d->Wo, 1 << t.lTX) * adell_cdiv(d->Ho, 1 << t.lTY) *
+         adell_cdiv(d->Do, 1 << t.lTZ);
+}
+
+extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
+                                const float* x1, const float* w_packed,
+                                const float* bias, const float* residual,
+                                float* y, float* stat_partials, void* stream) {
+  int rc = adell_check_desc(d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(x0 && w_packed && y, "conv_fwd: null pointer");
+  ADELL_REQUIRE(d->C1 == 0 || x1, "conv_fwd: C1 > 0 needs x1");
+  ConvArgs a = {};
+  a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.res = residual;
+  a.y0 = y; a.y1 = nullptr; a.part = stat_partials;
+  a.D = d->D; a.H = d->H; a.W = d->W;
+  a.C0 = d->C0; a.C1 = d->C1; a.Cin = d->C0 + d->C1; a.Cout = d->Cout;
+  a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
+  a.SD = d->SD; a.SH = d->SH; a.SW = d->SW;
+  a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
+  a.UPS = 1;
+  a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.ysplit = d->Cout; a.shuffle = 0; a.Cs = d->Cout;
+  return adell_conv_dispatch(a, d->N, (hipStream_t)stream);
+}
+
+// dX = conv_stride1(zero_insert(dY, S), flip(W)^T, pad = K-1-P), written to the
+// two sources of the forward's virtual concat. Needs equal strides in all dims
+// when any stride is 2 (UPS is one factor); w_packed_bwd is
+// [flipped tap][Cout][Cin] (adell_pack_weight mode 1).
+extern "C" int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
+                                     const float* w_packed_bwd, float* dx0,
+                                     float* dx1, void* stream) {
+  int rc = adell_check_desc(d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(dy && w_packed_bwd && dx0, "conv_bwd_data: null pointer");
+  ADELL_REQUIRE(d->C1 == 0 || dx1, "conv_bwd_data: C1 > 0 needs dx1");
+  if (!(d->SD == d->SH && d->SH == d->SW)) {
+    adell_set_error("conv_bwd_data: anisotropic strides unsupported");
+    return ADELL_E_UNSUPPORTED;
+  }
+  if (d->PD > d->KD - 1 || d->PH > d->KH - 1 || d->PW > d->KW - 1) {
+    adell_set_error("conv_bwd_data: pad > k-1 unsupported");
+    return ADELL_E_UNSUPPORTED;
+  }
+  ConvArgs a = {};
+  a.x0 = dy; a.x1 = nullptr; a.w = w_packed_bwd; a.bias = nullptr; a.res = nullptr;
+  a.y0 = dx0; a.y1 = dx1; a.part = nullptr;
+  a.D = d->Do; a.H = d->Ho; a.W = d->Wo;
+  a.C0 = d->Cout; a.C1 = 0; a.Cin = d->Cout; a.Cout = d->C0 + d->C1;
+  a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
+  a.SD = a.SH = a.SW = 1;
+  a.PD = d->KD - 1 - d->PD; a.PH = d->KH - 1 - d->PH; a.PW = d->KW - 1 - d->PW;
+  a.UPS = d->SD;
+  a.Do = d->D; a.Ho = d->H; a.Wo = d->W;
+  a.ysplit = d->C0; a.shuffle = 0; a.Cs = a.Cout;
+  return adell_conv_dispatch(a, d->N, (hipStream_t)stream);
+}
+
+// ConvTranspose3d with kernel = stride = 2, padding 0: a per-voxel GEMM
+// [Cin] -> [8*Cout] whose columns scatter to the 2x2x2 children of the voxel.
+// w_packed is [Cin][8][Cout] (adell_pack_weight mode 2).
+extern "C" int adell_convtranspose3d_k2s2_fwd(int N, int D, int H, int W, int Cin,
+                                              int Cout, const float* x,
+                                              const float* w_packed,
+                                              const float* bias, float* y,
+                                              void* stream) {
+  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0,
+                "convT_fwd: bad dims");
+  ADELL_REQUIRE(x && w_packed && y, "convT_fwd: null pointer");
+  ConvArgs a = {};
+  a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.res = nullptr;
+  a.y0 = y; a.y1 = nullptr; a.part = nullptr;
+  a.D = D; a.H = H; a.W = W;
+  a.C0 = Cin; a.C1 = 0; a.Cin = Cin; a.Cout = 8 * Cout;
+  a.KD = a.KH = a.KW = 1;
+  a.SD = a.SH = a.SW = 1;
+  a.PD = a.PH = a.PW = 0;
+  a.UPS = 1;
+  a.Do = D; a.Ho = H; a.Wo = W;
+  a.ysplit = a.Cout; a.shuffle = 1; a.Cs = Cout;
+  return adell_conv_dispatch(a, N, (hipStream_t)stream);
+}
+
+// dX of the k=s=2 transposed conv = a k=2, s=2, p=0 convolution of dY
+// ([N,2D,2H,2W,Cout]) with w_packed_bwd [8 taps][Cout][Cin] (pack mode 3).
+extern "C" int adell_convtranspose3d_k2s2_bwd_data(int N, int D, int H, int W,
+                                                   int Cin, int Cout,
+                                                   const float* dy,
+                                                   const float* w_packed_bwd,
+                                                   float* dx, void* stream) {
+  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0,
+                "convT_bwd_data: bad dims");
+  ADELL_REQUIRE(dy && w_packed_bwd && dx, "convT_bwd_data: null pointer");
+  ConvArgs a = {};
+  a.x0 = dy; a.x1 = nullptr; a.w = w_packed_bwd; a.bias = nullptr; a.res = nullptr;
+  a.y0 = dx; a.y1 = nullptr; a.part = nullptr;
+  a.D = 2 * D; a.H = 2 * H; a.W = 2 * W;
+  a.C0 = Cout; a.C1 = 0; a.Cin = Cout; a.Cout = Cin;
+  a.KD = a.KH = a.KW = 2;
+  a.SD = a.SH = a.SW = 2;
+  a.PD = a.PH = a.PW = 0;
+  a.UPS = 1;
+  a.Do = D; a.Ho = H; a.Wo = W;
+  a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
+  return adell_conv_dispatch(a, N, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// Weight repacking (canonical torch layouts -> GEMM-B layouts), run once per
+// optimiser step on ~8M floats: HBM-trivial.
+// ---------------------------------------------------------------------------
+__global__ void adell_pack_weight_kernel(const float* __restrict__ w,
+                                         float* __restrict__ out, int mode, int A,
+                                         int B, int KD, int KH, int KW) {
+  // conv:  w[A=Cout][B=Cin][taps];  convT: w[A=Cin][B=Cout][taps]
+  const int taps = KD * KH * KW;
+  const long total = (long)A * B * taps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    long o = i;  // index into `out`
+    int tap, ia, ib;
+    long src;
+    switch (mode) {
+      case 0:  // out[tap][Cin][Cout]
+        ia = o % A; o /= A; ib = o % B; tap = o / B;
+        src = ((long)ia * B + ib) * taps + tap;
+        break;
+      case 1:  // out[flipped tap][Cout][Cin]
+        ib = o % B; o /= B; ia = o % A; tap = o / A;
+        src = ((long)ia * B + ib) * taps + (taps - 1 - tap);
+        break;
+      case 2:  // convT fwd: out[Cin][tap][Cout]
+        ib = o % B; o /= B; tap = o % taps; ia = o / taps;
+        src = ((long)ia * B + ib) * taps + tap;
+        break;
+      default:  // 3, convT bwd-data: out[tap][Cout][Cin]
+        ia = o % A; o /= A; ib = o % B; tap = o / B;
+        src = ((long)ia * B + ib) * taps + tap;
+        break;
+    }
+    out[i] = w[src];
+  }
+}
+
+extern "C" int adell_pack_weight(const float* w, float* out, int mode, int dim0,
+                                 int dim1, int KD, int KH, int KW, void* stream) {
+  ADELL_REQUIRE(w && out, "pack_weight: null pointer");
+  ADELL_REQUIRE(mode >= 0 && mode <= 3, "pack_weight: mode must be 0..3");
+  ADELL_REQUIRE(dim0 > 0 && dim1 > 0 && KD > 0 && KH > 0 && KW > 0, "pack_weight: bad dims");
+  const long total = (long)dim0 * dim1 * KD * KH * KW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adell_pack_weight_kernel, dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, w, out, mode, dim0, dim1, KD, KH, KW);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

@@ -1,0 +1,289 @@
+// Normalisation statistics + fused Norm -> Dropout -> Activation ("NDA", the
+// ordering UNet.adn_fn uses: reference adell_mri/modules/segmentation/unet.py:697-714,
+// adell_mri/modules/layers/adn_fn.py:140-152). HBM-bound elementwise work on
+// NDHWC fp32; reductions use wavefront shuffles and fixed-order fp64 combines.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// Per-(n,c) statistics from per-block partials [N][ntiles][C][2] (sum, sumsq)
+// written by the conv epilogue or by adell_channel_partials_kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_stats_finalize_kernel(
+    const float* __restrict__ part, int ntiles, int C, double count, float eps,
+    float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double sh[8][32][2];
+  const int n = blockIdx.y;
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int t = sl; t < ntiles; t += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(
+          part + (((size_t)n * ntiles + t) * C + c) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  }
+  sh[sl][cl][0] = s1;
+  sh[sl][cl][1] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a += sh[k][cl][0];
+      b += sh[k][cl][1];
+    }
+    const double m = a / count;
+    double var = b / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[(size_t)n * C + c] = (float)m;
+    rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+extern "C" int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
+                                    long count, float eps, float* mean, float* rstd,
+                                    void* stream) {
+  ADELL_REQUIRE(partials && mean && rstd, "stats_finalize: null pointer");
+  ADELL_REQUIRE(N > 0 && ntiles > 0 && C > 0 && count > 0, "stats_finalize: bad dims");
+  hipLaunchKernelGGL(adell_stats_finalize_kernel, dim3(adell_cdiv(C, 32), N), dim3(256),
+                     0, (hipStream_t)stream, partials, ntiles, C, (double)count, eps,
+                     mean, rstd);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// Partials of a tensor that did not come out of the conv epilogue. Each block
+// reduces a slab of ADELL_STATS_SLAB voxels; thread (vl, c) walks voxels
+// vl, vl+VL, ... of the slab.
+#define ADELL_STATS_SLAB 1024
+__global__ __launch_bounds__(256) void adell_channel_partials_kernel(
+    const float* __restrict__ x, long V, int C, float* __restrict__ part,
+    int ntiles) {
+  __shared__ float sh[256][2];
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const long v0 = (long)tile * ADELL_STATS_SLAB;
+  long v1 = v0 + ADELL_STATS_SLAB;
+  if (v1 > V) v1 = V;
+  const int CG = C < 256 ? C : 256;
+  const int VL = 256 / CG;
+  const int cl = threadIdx.x % CG, vl = threadIdx.x / CG;
+  for (int cb = 0; cb < C; cb += CG) {
+    const int c = cb + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (vl < VL && c < C) {
+      const float* p = x + ((size_t)n * V) * C + c;
+      for (long v = v0 + vl; v < v1; v += VL) {
+        const float t = p[v * C];
+        s1 += t;
+        s2 += t * t;
+      }
+    }
+    sh[threadIdx.x][0] = s1;
+    sh[threadIdx.x][1] = s2;
+    __syncthreads();
+    if (vl == 0 && c < C) {
+      float a = 0.f, b = 0.f;
+      for (int k = 0; k < VL; ++k) {
+        a += sh[k * CG + cl][0];
+        b += sh[k * CG + cl][1];
+      }
+      float* o = part + (((size_t)n * ntiles + tile) * C + c) * 2;
+      o[0] = a;
+      o[1] = b;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int adell_channel_partials_ntiles(long V) {
+  return (int)((V + ADELL_STATS_SLAB - 1) / ADELL_STATS_SLAB);
+}
+
+extern "C" int adell_channel_partials(const float* x, int N, long V, int C,
+                                      float* partials, void* stream) {
+  ADELL_REQUIRE(x && partials, "channel_partials: null pointer");
+  ADELL_REQUIRE(N > 0 && V > 0 && C > 0, "channel_partials: bad dims");
+  const int nt = adell_channel_partials_ntiles(V);
+  hipLaunchKernelGGL(adell_channel_partials_kernel, dim3(nt, N), dim3(256), 0,
+                     (hipStream_t)stream, x, V, C, partials, nt);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Activations
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float adell_act_fwd(int act, float x, float p) {
+  switch (act) {
+    case ADELL_ACT_SILU: return x * adell_sigmoidf(x);
+    case ADELL_ACT_RELU: return x > 0.f ? x : 0.f;
+    case ADELL_ACT_LEAKY_RELU: return x > 0.f ? x : p * x;
+    case ADELL_ACT_PRELU: return x > 0.f ? x : p * x;
+    case ADELL_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case ADELL_ACT_SIGMOID: return adell_sigmoidf(x);
+    case ADELL_ACT_TANH: return tanhf(x);
+    case ADELL_ACT_ELU: return x > 0.f ? x : p * (expf(x) - 1.0f);
+    default: return x;
+  }
+}
+// d act(x) / dx
+__device__ __forceinline__ float adell_act_grad(int act, float x, float p) {
+  switch (act) {
+    case ADELL_ACT_SILU: {
+      const float s = adell_sigmoidf(x);
+      return s * (1.0f + x * (1.0f - s));
+    }
+    case ADELL_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ADELL_ACT_LEAKY_RELU: return x > 0.f ? 1.f : p;
+    case ADELL_ACT_PRELU: return x > 0.f ? 1.f : p;
+    case ADELL_ACT_GELU: {
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case ADELL_ACT_SIGMOID: {
+      const float s = adell_sigmoidf(x);
+      return s * (1.0f - s);
+    }
+    case ADELL_ACT_TANH: {
+      const float t = tanhf(x);
+      return 1.0f - t * t;
+    }
+    case ADELL_ACT_ELU: return x > 0.f ? 1.f : p * expf(x);
+    default: return 1.f;
+  }
+}
+
+struct NormActArgs {
+  const float* x;
+  const float* mean;   // [N*C] (instance) or [C] (batch) or null (no norm)
+  const float* rstd;
+  const float* gamma;  // [C] or null
+  const float* beta;   // [C] or null
+  const float* act_w;  // PReLU weight: [1] or [C]; null otherwise
+  float* out;
+  long VC;             // voxels-per-item * C
+  long total;          // N * VC
+  int C;
+  int stat_stride_n;   // C for instance statistics, 0 for batch statistics
+  int act;
+  int act_w_n;         // number of PReLU weights (1 or C)
+  float act_p;         // leaky slope / elu alpha
+  float drop_p;        // 0 disables dropout
+  uint32_t seed_lo, seed_hi;
+  uint32_t rng_offset;
+  int vec;             // C % 4 == 0: float4 path covers everything
+};
+
+// hat = (x-mean)*rstd*gamma+beta ; u = dropout(hat) ; out = act(u)
+__global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) {
+  const long n4 = a.vec ? (a.total >> 2) : 0;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4;
+       i += (long)gridDim.x * blockDim.x) {
+    const long e = i << 2;
+    const int c = (int)(e % a.C);
+    const long nidx = e / a.VC;
+    float4 v = reinterpret_cast<const float4*>(a.x)[i];
+    float h[4] = {v.x, v.y, v.z, v.w};
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (a.drop_p > 0.f)
+      r = adell_philox4((uint32_t)i, (uint32_t)(i >> 32), a.rng_offset, 0u, a.seed_lo,
+                        a.seed_hi);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cj = c + j;
+      float t = h[j];
+      if (a.mean) {
+        const long si = nidx * a.stat_stride_n + cj;
+        t = (t - a.mean[si]) * a.rstd[si];
+      }
+      if (a.gamma) t = t * a.gamma[cj];
+      if (a.beta) t = t + a.beta[cj];
+      if (a.drop_p > 0.f) {
+        const float u = (float)(rr[j] >> 8) * (1.0f / 16777216.0f);
+        t = (u >= a.drop_p) ? t * keep_scale : 0.f;
+      }
+      float p = a.act_p;
+      if (a.act_w) p = a.act_w[a.act_w_n > 1 ? cj : 0];
+      h[j] = adell_act_fwd(a.act, t, p);
+    }
+    reinterpret_cast<float4*>(a.out)[i] = make_float4(h[0], h[1], h[2], h[3]);
+  }
+  // scalar tail (total not a multiple of 4 only when C is not)
+  const long tail0 = n4 << 2;
+  for (long e = tail0 + blockIdx.x * (long)blockDim.x + threadIdx.x; e < a.total;
+       e += (long)gridDim.x * blockDim.x) {
+    const int cj = (int)(e % a.C);
+    const long nidx = e / a.VC;
+    float t = a.x[e];
+    if (a.mean) {
+      const long si = nidx * a.stat_stride_n + cj;
+      t = (t - a.mean[si]) * a.rstd[si];
+    }
+    if (a.gamma) t = t * a.gamma[cj];
+    if (a.beta) t = t + a.beta[cj];
+    if (a.drop_p > 0.f) {
+      const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34),
+                                    a.rng_offset, 0u, a.seed_lo, a.seed_hi);
+      const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+      const float u = (float)(rr[e & 3] >> 8) * (1.0f / 16777216.0f);
+      t = (u >= a.drop_p) ? t * keep_scale : 0.f;
+    }
+    float p = a.act_p;
+    if (a.act_w) p = a.act_w[a.act_w_n > 1 ? cj : 0];
+    a.out[e] = adell_act_fwd(a.act, t, p);
+  }
+}
+
+static int adell_na_fill(NormActArgs* a, const adell_norm_act_desc* d) {
+  ADELL_REQUIRE(d != nullptr, "norm_act: null descriptor");
+  ADELL_REQUIRE(d->N > 0 && d->V > 0 && d->C > 0, "norm_act: bad dims");
+  ADELL_REQUIRE(d->act >= 0 && d->act <= ADELL_ACT_ELU, "norm_act: unknown activation");
+  ADELL_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "norm_act: dropout p must be in [0,1)");
+  ADELL_REQUIRE(d->stats_per_item == 0 || d->stats_per_item == 1,
+                "norm_act: stats_per_item must be 0/1");
+  a->VC = d->V * d->C;
+  a->total = d->N * a->VC;
+  a->C = d->C;
+  a->stat_stride_n = d->stats_per_item ? d->C : 0;
+  a->act = d->act;
+  a->act_w_n = d->act_w_n;
+  a->act_p = d->act_p;
+  a->drop_p = d->drop_p;
+  a->seed_lo = (uint32_t)(d->seed & 0xffffffffu);
+  a->seed_hi = (uint32_t)(d->seed >> 32);
+  a->rng_offset = d->rng_offset;
+  return ADELL_OK;
+}
+
+static int adell_ew_blocks(long n4) {
+  long b = (n4 + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
+                                  const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta,
+                                  const float* act_w, float* out, void* stream) {
+  NormActArgs a = {};
+  int rc = adell_na_fill(&a, d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(x && out, "norm_act_fwd: null pointer");
+  ADELL_REQUIRE((mean == nullptr) == (rstd == nullptr), "norm_act_fwd: mean/rstd mismatch");
+  ADELL_REQUIRE(d->C % 4 == 0 || a.total < (1L << 31),
+                "norm_act_fwd: C %% 4 != 0 needs < 2^31 elements");
+  a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
+  a.act_w = act_w; a.out = out;
+  a.vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0);
+  hipLaunchKernelGGL(adell_norm_act_fwd_kernel,
+                     dim3(adell_ew_blocks(a.vec ? (a.total >> 2) : a.total)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

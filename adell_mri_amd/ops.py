@@ -1,0 +1,188 @@
+"""Raw (non-autograd) Python front-ends of the HIP kernels.
+
+Activations are torch CUDA tensors of logical shape ``[N, C, D, H, W]`` whose
+memory is dense NDHWC (``torch.channels_last_3d``); ``ndhwc()`` / ``new_act()``
+are the only places that care about strides. Everything is enqueued on
+``torch.cuda.current_stream()``; PyTorch only provides memory and streams.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_IDS, ConvDesc, NormActDesc, check
+
+
+def _triple(v):
+    if isinstance(v, (int,)):
+        return (int(v),) * 3
+    v = tuple(int(i) for i in v)
+    if len(v) == 1:
+        return v * 3
+    assert len(v) == 3, v
+    return v
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.AdellHipError(
+                "adell_mri_amd kernels run on MI355X only: got a CPU tensor (no CPU fallback)")
+        if t is not None and t.dtype != torch.float32:
+            raise _lib.AdellHipError(f"adell_mri_amd kernels are fp32; got {t.dtype}")
+
+
+def ndhwc(x):
+    """Return a tensor sharing x's logical NCDHW shape whose memory is dense NDHWC."""
+    if x.dim() != 5:
+        raise _lib.AdellHipError(f"expected a 5-D [N,C,D,H,W] tensor, got {tuple(x.shape)}")
+    xp = x.permute(0, 2, 3, 4, 1)
+    if not xp.is_contiguous():
+        xp = xp.contiguous()
+    return xp.permute(0, 4, 1, 2, 3)
+
+
+def new_act(N, C, D, H, W, device):
+    return torch.empty((N, D, H, W, C), device=device, dtype=torch.float32).permute(0, 4, 1, 2, 3)
+
+
+def conv_out_size(size, k, s, p):
+    return tuple((d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip(size, k, s, p))
+
+
+def make_conv_desc(N, size, C0, C1, Cout, k, s, p):
+    k, s, p = _triple(k), _triple(s), _triple(p)
+    o = conv_out_size(size, k, s, p)
+    return ConvDesc(N, *size, C0, C1, Cout, *k, *s, *p, *o)
+
+
+def pack_weight(w, mode):
+    """mode 0/1: conv weight [Cout,Cin,k,k,k]; mode 2/3: convT weight [Cin,Cout,2,2,2]."""
+    _require_cuda(w)
+    w = w.contiguous()
+    out = torch.empty(w.numel(), device=w.device, dtype=torch.float32)
+    d0, d1, kd, kh, kw = w.shape
+    check(_lib.lib().adell_pack_weight(_ptr(w), _ptr(out), mode, d0, d1, kd, kh, kw, _stream()))
+    return out
+
+
+def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, residual=None,
+               want_stats=False):
+    """y = conv(cat(x0, x1)) + bias + residual ; optional (sum, sumsq) partials."""
+    _require_cuda(x0, x1, w_packed, bias, residual)
+    x0 = ndhwc(x0)
+    N, C0, D, H, W = x0.shape
+    C1 = 0
+    if x1 is not None:
+        x1 = ndhwc(x1)
+        assert x1.shape[0] == N and tuple(x1.shape[2:]) == (D, H, W)
+        C1 = x1.shape[1]
+    d = make_conv_desc(N, (D, H, W), C0, C1, Cout, kernel, stride, padding)
+    y = new_act(N, Cout, d.Do, d.Ho, d.Wo, x0.device)
+    if residual is not None:
+        residual = ndhwc(residual)
+        assert tuple(residual.shape) == tuple(y.shape)
+    part = None
+    if want_stats:
+        nt = _lib.lib().adell_conv3d_fwd_ntiles(ctypes.byref(d))
+        if nt < 0:
+            check(nt)
+        part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
+    check(_lib.lib().adell_conv3d_fwd(ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed),
+                                      _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
+                                      _stream()))
+    return y, part
+
+
+def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding):
+    _require_cuda(dy, w_packed_bwd)
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    d = make_conv_desc(N, tuple(in_size), C0, C1, Cout, kernel, stride, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    dx0 = new_act(N, C0, *in_size, dy.device)
+    dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
+    check(_lib.lib().adell_conv3d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd),
+                                           _ptr(dx0), _ptr(dx1), _stream()))
+    return dx0, dx1
+
+
+def convtranspose3d_k2s2_fwd(x, w_packed, bias, Cout):
+    _require_cuda(x, w_packed, bias)
+    x = ndhwc(x)
+    N, Cin, D, H, W = x.shape
+    y = new_act(N, Cout, 2 * D, 2 * H, 2 * W, x.device)
+    check(_lib.lib().adell_convtranspose3d_k2s2_fwd(N, D, H, W, Cin, Cout, _ptr(x),
+                                                    _ptr(w_packed), _ptr(bias), _ptr(y),
+                                                    _stream()))
+    return y
+
+
+def convtranspose3d_k2s2_bwd_data(dy, w_packed_bwd, Cin):
+    _require_cuda(dy, w_packed_bwd)
+    dy = ndhwc(dy)
+    N, Cout, D2, H2, W2 = dy.shape
+    D, H, W = D2 // 2, H2 // 2, W2 // 2
+    dx = new_act(N, Cin, D, H, W, dy.device)
+    check(_lib.lib().adell_convtranspose3d_k2s2_bwd_data(N, D, H, W, Cin, Cout, _ptr(dy),
+                                                         _ptr(w_packed_bwd), _ptr(dx),
+                                                         _stream()))
+    return dx
+
+
+def stats_finalize(partials, count, eps):
+    N, nt, C, _ = partials.shape
+    mean = torch.empty((N, C), device=partials.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(_lib.lib().adell_stats_finalize(_ptr(partials), N, nt, C, int(count), float(eps),
+                                          _ptr(mean), _ptr(rstd), _stream()))
+    return mean, rstd
+
+
+def channel_partials(x):
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    V = x.shape[2] * x.shape[3] * x.shape[4]
+    nt = _lib.lib().adell_channel_partials_ntiles(V)
+    part = torch.empty((N, nt, C, 2), device=x.device, dtype=torch.float32)
+    check(_lib.lib().adell_channel_partials(_ptr(x), N, V, C, _ptr(part), _stream()))
+    return part
+
+
+def instance_stats(x, eps=1e-5, partials=None):
+    """(mean, rstd) of shape [N, C] over the spatial dims of x."""
+    if partials is None:
+        partials = channel_partials(x)
+    V = x.shape[2] * x.shape[3] * x.shape[4]
+    return stats_finalize(partials, V, eps)
+
+
+def make_na_desc(x, act, stats_per_item=1, act_p=0.0, act_w_n=0, drop_p=0.0, seed=0,
+                 rng_offset=0):
+    N, C = x.shape[:2]
+    V = x.shape[2] * x.shape[3] * x.shape[4]
+    act_id = ACT_IDS[act] if isinstance(act, str) else int(act)
+    return NormActDesc(N, V, C, stats_per_item, act_id, act_w_n, float(act_p), float(drop_p),
+                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_offset) & 0xFFFFFFFF)
+
+
+def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.0,
+                 stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0):
+    _require_cuda(x, mean, rstd, gamma, beta, act_w)
+    x = ndhwc(x)
+    d = make_na_desc(x, act, stats_per_item, act_p, 0 if act_w is None else act_w.numel(),
+                     drop_p, seed, rng_offset)
+    out = new_act(*x.shape, x.device)
+    check(_lib.lib().adell_norm_act_fwd(ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd),
+                                        _ptr(gamma), _ptr(beta), _ptr(act_w), _ptr(out),
+                                        _stream()))
+    return out

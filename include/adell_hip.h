@@ -1,0 +1,150 @@
+/*
+ * adell_hip.h -- C ABI of libadellhip.so, the MI355X (gfx950) kernel library
+ * behind the adell_mri U-Net / UNETR forward-backward path.
+ *
+ * The reference (CCIG-Champalimaud/adell-mri) is pure Python on torch and has
+ * no FFI boundary of its own: the operators on its hot path are stock
+ * torch.nn calls at the call sites cited on each entry point below (paths are
+ * relative to the reference root). This header is the boundary a maintainer
+ * binds instead of those calls (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *  - all tensors are fp32, dense, NDHWC ("channels_last_3d": the memory a
+ *    torch tensor of logical shape [N,C,D,H,W] has after
+ *    .contiguous(memory_format=torch.channels_last_3d));
+ *  - pointers are device pointers unless stated; `stream` is a hipStream_t
+ *    (NULL = default stream); nothing synchronises the host;
+ *  - every function returns ADELL_OK or a negative ADELL_E_* code and never
+ *    throws; adell_last_error() gives the message of the calling thread's
+ *    last failure.
+ */
+#ifndef ADELL_HIP_H
+#define ADELL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADELL_OK 0
+#define ADELL_E_BADARG (-1)
+#define ADELL_E_UNSUPPORTED (-2)
+#define ADELL_E_HIP (-3)
+#define ADELL_E_NOMEM (-4)
+
+#define ADELL_ABI_VERSION 1
+
+/* activation ids (reference: adell_mri/modules/activations.py:6-31) */
+enum {
+  ADELL_ACT_IDENTITY = 0,
+  ADELL_ACT_SILU = 1, /* "swish" */
+  ADELL_ACT_RELU = 2,
+  ADELL_ACT_LEAKY_RELU = 3,
+  ADELL_ACT_PRELU = 4,
+  ADELL_ACT_GELU = 5,
+  ADELL_ACT_SIGMOID = 6,
+  ADELL_ACT_TANH = 7,
+  ADELL_ACT_ELU = 8
+};
+
+int adell_abi_version(void);
+const char* adell_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * 3D convolution. Replaces torch.nn.Conv3d at unet.py:260-273 (conv_block_3d),
+ * res_blocks.py:150-178 (ResidualBlock3d), unet.py:641-655 (final layer); the
+ * two sources x0/x1 are the operands of torch.concat at unet.py:817 (never
+ * materialised); `residual` is the "+ X" of res_blocks.py:192.
+ * ---------------------------------------------------------------------- */
+typedef struct adell_conv3d_desc {
+  int32_t N, D, H, W; /* input batch / spatial size */
+  int32_t C0, C1;     /* channels of source 0 and source 1 (C1 may be 0) */
+  int32_t Cout;
+  int32_t KD, KH, KW; /* 1..3 */
+  int32_t SD, SH, SW; /* 1..2 */
+  int32_t PD, PH, PW;
+  int32_t Do, Ho, Wo; /* must equal (D + 2P - K) / S + 1 */
+} adell_conv3d_desc;
+
+/* Repack weights from the torch layout into the GEMM-B layouts the kernels
+ * read. mode 0: conv [Cout=dim0][Cin=dim1][taps] -> [tap][Cin][Cout] (forward);
+ * mode 1: same source -> [flipped tap][Cout][Cin] (backward-data);
+ * mode 2: convT [Cin=dim0][Cout=dim1][8] -> [Cin][8][Cout] (forward);
+ * mode 3: same source -> [tap][Cout][Cin] (backward-data). */
+int adell_pack_weight(const float* w, float* out, int mode, int dim0, int dim1,
+                      int KD, int KH, int KW, void* stream);
+
+/* Rows of the statistics-partials buffer adell_conv3d_fwd writes per batch
+ * item (buffer shape [N][ntiles][Cout][2] floats), or a negative error. */
+int adell_conv3d_fwd_ntiles(const adell_conv3d_desc* d);
+
+/* y = conv(concat(x0,x1), w) + bias + residual.  bias, residual, x1 and
+ * stat_partials may be NULL. When stat_partials is given, per-block
+ * per-channel (sum, sum of squares) of y are written for adell_stats_finalize
+ * (InstanceNorm3d / BatchNorm3d statistics without re-reading y). */
+int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                     const float* w_packed, const float* bias,
+                     const float* residual, float* y, float* stat_partials,
+                     void* stream);
+
+/* dX of the convolution above (autograd mirror of the same call sites).
+ * dx0 receives channels [0,C0), dx1 channels [C0,C0+C1). */
+int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
+                          const float* w_packed_bwd, float* dx0, float* dx1,
+                          void* stream);
+
+/* ------------------------------------------------------------------------
+ * ConvTranspose3d(kernel=2, stride=2, padding=0): unet.py:445-458
+ * (init_upscale_ops, upscale_type="transpose"), unetr.py:286-308.
+ * x [N,D,H,W,Cin] -> y [N,2D,2H,2W,Cout].
+ * ---------------------------------------------------------------------- */
+int adell_convtranspose3d_k2s2_fwd(int N, int D, int H, int W, int Cin, int Cout,
+                                   const float* x, const float* w_packed,
+                                   const float* bias, float* y, void* stream);
+int adell_convtranspose3d_k2s2_bwd_data(int N, int D, int H, int W, int Cin,
+                                        int Cout, const float* dy,
+                                        const float* w_packed_bwd, float* dx,
+                                        void* stream);
+
+/* ------------------------------------------------------------------------
+ * Normalisation statistics and the fused Norm -> Dropout -> Activation of
+ * ActDropNorm with ordering "NDA" (adn_fn.py:56-152; unet.py:697-714).
+ * ---------------------------------------------------------------------- */
+/* mean / rstd [N][C] from partials [N][ntiles][C][2]; count = voxels per item;
+ * biased variance, rstd = 1/sqrt(var+eps) (torch.nn.InstanceNorm3d). */
+int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
+                         long count, float eps, float* mean, float* rstd,
+                         void* stream);
+/* Partials of an arbitrary tensor x [N][V][C] (same buffer format). */
+int adell_channel_partials_ntiles(long V);
+int adell_channel_partials(const float* x, int N, long V, int C, float* partials,
+                           void* stream);
+
+typedef struct adell_norm_act_desc {
+  int64_t N, V;           /* batch items, voxels per item */
+  int32_t C;
+  int32_t stats_per_item; /* 1: mean/rstd are [N][C] (instance); 0: [C] (batch) */
+  int32_t act;            /* ADELL_ACT_* */
+  int32_t act_w_n;        /* PReLU weight count (1 or C) when act_w != NULL */
+  float act_p;            /* LeakyReLU slope / ELU alpha */
+  float drop_p;           /* dropout probability, 0 = off (eval) */
+  uint64_t seed;          /* Philox key; mask is a function of (seed, offset, index) */
+  uint32_t rng_offset;    /* distinguishes ADN sites sharing one seed */
+} adell_norm_act_desc;
+
+/* out = act(dropout((x - mean) * rstd * gamma + beta)); mean/rstd, gamma, beta,
+ * act_w may be NULL. */
+int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
+                       const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* act_w, float* out,
+                       void* stream);
+
+/* test hook: force one conv tile configuration (0..3), -1 = heuristic */
+void adell_debug_force_conv_cfg(int cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADELL_HIP_H */

@@ -1,0 +1,172 @@
+"""Op-level parity of the HIP kernels against the plain-C oracle (oracle/c),
+called through the C ABI. Tolerances are written per test; fp32 everywhere."""
+import numpy as np
+import pytest
+import torch
+
+from adell_mri_amd import _lib, ops
+from oracle import cops
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def _cl(a, device):
+    """numpy NCDHW -> cuda tensor, logical NCDHW, NDHWC memory."""
+    return ops.ndhwc(_dev(a, device))
+
+
+def _np(t):
+    return t.detach().contiguous().cpu().numpy()
+
+
+def _relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+CONV_CASES = [
+    # N, Cin, size, Cout, k, s, p, cfg
+    (1, 32, (16, 16, 16), 32, 3, 1, 1, -1),
+    (2, 2, (12, 10, 9), 32, 3, 1, 1, -1),
+    (1, 2, (9, 9, 9), 2, 3, 1, 1, -1),
+    (1, 64, (8, 8, 8), 64, 3, 1, 1, -1),
+    (1, 32, (16, 16, 16), 32, 3, 2, 1, -1),
+    (1, 16, (17, 15, 13), 48, 3, 2, 1, -1),
+    (1, 32, (8, 8, 8), 1, 1, 1, 0, -1),
+    (1, 40, (8, 8, 8), 72, 3, 1, 1, -1),
+    (1, 32, (16, 16, 16), 64, 3, 1, 1, 0),
+    (1, 32, (16, 16, 16), 32, 3, 1, 1, 1),
+    (1, 32, (16, 16, 16), 64, 3, 1, 1, 2),
+    (1, 32, (16, 16, 16), 32, 3, 1, 1, 3),
+    (1, 8, (6, 6, 6), 8, (3, 3, 1), (2, 2, 1), (1, 1, 0), -1),
+    (1, 8, (10, 10, 10), 8, 3, 1, 0, -1),
+]
+
+
+@pytest.mark.parametrize("N,Cin,size,Cout,k,s,p,cfg", CONV_CASES)
+def test_conv3d_fwd_matches_oracle(cuda, N, Cin, size, Cout, k, s, p, cfg):
+    rng = np.random.default_rng(1234)
+    k3 = ops._triple(k)
+    x = rng.standard_normal((N, Cin, *size)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, *k3)) / np.sqrt(Cin * np.prod(k3))).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = cops.conv3d(x, w, b, s, p)
+    _lib.lib().adell_debug_force_conv_cfg(cfg)
+    try:
+        wp = ops.pack_weight(_dev(w, cuda), 0)
+        y, part = ops.conv3d_fwd(_cl(x, cuda), wp, _dev(b, cuda), Cout, k, s, p, want_stats=True)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().adell_debug_force_conv_cfg(-1)
+    got = _np(y)
+    assert got.shape == ref.shape
+    # fp32 MFMA k-ordered fma chain vs fp64-accumulated oracle
+    assert _relerr(got, ref) < 2e-6 * np.sqrt(Cin * np.prod(k3)) + 1e-6
+    # fused statistics epilogue
+    V = np.prod(ref.shape[2:])
+    mean, rstd = ops.stats_finalize(part, V, 1e-5)
+    m_ref = ref.reshape(N, Cout, -1).mean(-1)
+    r_ref = 1.0 / np.sqrt(ref.reshape(N, Cout, -1).var(-1) + 1e-5)
+    np.testing.assert_allclose(_np(mean), m_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(_np(rstd), r_ref, rtol=1e-4)
+
+
+def test_conv3d_virtual_concat_and_residual(cuda):
+    rng = np.random.default_rng(7)
+    xa = rng.standard_normal((1, 32, 8, 8, 8)).astype(np.float32)
+    xb = rng.standard_normal((1, 32, 8, 8, 8)).astype(np.float32)
+    w = (rng.standard_normal((64, 64, 3, 3, 3)) * 0.03).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    res = rng.standard_normal((1, 64, 8, 8, 8)).astype(np.float32)
+    ref = cops.conv3d(np.concatenate([xa, xb], 1), w, b, 1, 1) + res
+    wp = ops.pack_weight(_dev(w, cuda), 0)
+    y, _ = ops.conv3d_fwd(_cl(xa, cuda), wp, _dev(b, cuda), 64, 3, 1, 1, x1=_cl(xb, cuda),
+                          residual=_cl(res, cuda))
+    assert _relerr(_np(y), ref) < 1e-4
+
+
+BWD_CASES = [
+    (1, 32, (8, 8, 8), 32, 3, 1, 1),
+    (1, 16, (16, 16, 16), 24, 3, 2, 1),
+    (1, 8, (9, 9, 9), 8, 3, 2, 1),
+    (2, 2, (8, 8, 8), 32, 3, 1, 1),
+    (1, 32, (8, 8, 8), 1, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("N,Cin,size,Cout,k,s,p", BWD_CASES)
+def test_conv3d_bwd_data_matches_oracle(cuda, N, Cin, size, Cout, k, s, p):
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((N, Cin, *size)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k, k)) / np.sqrt(Cout * k ** 3)).astype(np.float32)
+    osz = ops.conv_out_size(size, (k,) * 3, (s,) * 3, (p,) * 3)
+    dy = rng.standard_normal((N, Cout, *osz)).astype(np.float32)
+    dx_ref, _, _ = cops.conv3d_bwd(x, w, dy, s, p)
+    wpb = ops.pack_weight(_dev(w, cuda), 1)
+    dx0, dx1 = ops.conv3d_bwd_data(_cl(dy, cuda), wpb, size, Cin, 0, k, s, p)
+    assert dx1 is None
+    assert _relerr(_np(dx0), dx_ref) < 1e-4
+
+
+def test_conv3d_bwd_data_splits_concat_sources(cuda):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((1, 48, 8, 8, 8)).astype(np.float32)
+    w = (rng.standard_normal((32, 48, 3, 3, 3)) * 0.03).astype(np.float32)
+    dy = rng.standard_normal((1, 32, 8, 8, 8)).astype(np.float32)
+    dx_ref, _, _ = cops.conv3d_bwd(x, w, dy, 1, 1)
+    wpb = ops.pack_weight(_dev(w, cuda), 1)
+    dx0, dx1 = ops.conv3d_bwd_data(_cl(dy, cuda), wpb, (8, 8, 8), 32, 16, 3, 1, 1)
+    assert _relerr(_np(dx0), dx_ref[:, :32]) < 1e-4
+    assert _relerr(_np(dx1), dx_ref[:, 32:]) < 1e-4
+
+
+@pytest.mark.parametrize("Cin,Cout,size", [(32, 16, (4, 4, 4)), (64, 32, (8, 8, 8)), (8, 3, (5, 3, 2))])
+def test_convtranspose_k2s2_fwd_and_bwd_data(cuda, Cin, Cout, size):
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, Cin, *size)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout, 2, 2, 2)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = cops.conv_transpose3d(x, w, b, 2, 0)
+    wp = ops.pack_weight(_dev(w, cuda), 2)
+    y = ops.convtranspose3d_k2s2_fwd(_cl(x, cuda), wp, _dev(b, cuda), Cout)
+    assert _np(y).shape == ref.shape
+    assert _relerr(_np(y), ref) < 1e-5
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    dx_ref, _, _ = cops.conv_transpose3d_bwd(x, w, dy)
+    wpb = ops.pack_weight(_dev(w, cuda), 3)
+    dx = ops.convtranspose3d_k2s2_bwd_data(_cl(dy, cuda), wpb, Cin)
+    assert _relerr(_np(dx), dx_ref) < 1e-5
+
+
+@pytest.mark.parametrize("act", ["swish", "relu", "gelu", "identity", "sigmoid", "tanh"])
+@pytest.mark.parametrize("C,size", [(32, (8, 8, 8)), (2, (9, 7, 5)), (3, (4, 4, 4))])
+def test_instance_norm_act_fwd(cuda, act, C, size):
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((2, C, *size)) * 3 + 1.5).astype(np.float32)
+    ref = cops.norm_act(x, True, 1e-5, act)
+    xd = _cl(x, cuda)
+    mean, rstd = ops.instance_stats(xd, 1e-5)
+    out = ops.norm_act_fwd(xd, mean, rstd, act)
+    np.testing.assert_allclose(_np(out), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_dropout_mask_statistics_and_determinism(cuda):
+    x = torch.ones((1, 32, 16, 16, 16), device=cuda)
+    xd = ops.ndhwc(x)
+    a = ops.norm_act_fwd(xd, None, None, "identity", drop_p=0.15, seed=42, rng_offset=3)
+    b = ops.norm_act_fwd(xd, None, None, "identity", drop_p=0.15, seed=42, rng_offset=3)
+    c = ops.norm_act_fwd(xd, None, None, "identity", drop_p=0.15, seed=42, rng_offset=4)
+    assert torch.equal(a, b)
+    assert not torch.equal(a, c)
+    kept = (a != 0).float().mean().item()
+    assert abs(kept - 0.85) < 0.01
+    vals = torch.unique(a)
+    assert torch.allclose(vals, torch.tensor([0.0, 1.0 / 0.85], device=cuda))
+
+
+def test_cpu_tensor_is_refused():
+    with pytest.raises(_lib.AdellHipError):
+        ops.norm_act_fwd(torch.zeros(1, 4, 2, 2, 2), None, None, "relu")
