@@ -1,0 +1,425 @@
+// Backward-weight of the 3D convolution family on the fp32 MFMA.
+//
+//   dW[tap][ci][co] = sum_{n,v} X[n, S*v + tap - P][ci] * dY[n, v][co]
+//
+// GEMM view: M = ci (A rows), N = co (B cols), K = output voxels. Both operands
+// are staged in their natural NDHWC layout (rows = voxels, channels inner), so
+// the 32 lanes of an MFMA row/column group read 32 consecutive channels of one
+// voxel (conflict-free ds_read_b32).
+//
+// Work split: blockIdx.x = region (an interleaved subset of the spatial bricks,
+// split-K), blockIdx.y = (ci tile, co tile), blockIdx.z = tap group. A wave
+// owns up to MAXJ "jobs" = (tap, 32x32 channel sub-tile) accumulators. Every
+// region writes its partial dW slab to the workspace; a second kernel reduces
+// the slabs in fixed order (deterministic) straight into torch's canonical
+// [Cout][Cin][kD][kH][kW] layout.
+#include "common.h"
+
+struct WgradArgs {
+  const float* x0;
+  const float* x1;
+  const float* dy;
+  float* ws;          // [R][ntap][Cin][Cout]
+  int N, D, H, W;     // X dims
+  int C0, C1, Cin, Cout;
+  int KD, KH, KW, SD, SH, SW, PD, PH, PW;
+  int Do, Ho, Wo;     // dY dims
+  int lTX, lTY, lTZ;
+  int ntx, nty, ntz;  // bricks per dim (per batch item)
+  int HX, HY, HZ;     // halo brick of X for one tap group
+  int TCI, TCO;       // channel tile (32 or 64)
+  int nci, nco;       // channel tiles
+  int KDg;            // kz planes per tap group (1 or KD)
+  int R;              // regions
+  int vecx, vecy;
+};
+
+template <int MAXJ>
+__global__ __launch_bounds__(256) void adell_conv_wgrad_kernel(WgradArgs a) {
+  extern __shared__ float smem[];
+  const int TV = 1 << (a.lTX + a.lTY + a.lTZ);
+  const int HV = a.HX * a.HY * a.HZ;
+  float* sX = smem;                  // [HV][TCI]
+  float* sY = smem + HV * a.TCI;     // [TV][TCO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int region = blockIdx.x;
+  const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
+  const int ci0 = cit * a.TCI, co0 = cot * a.TCO;
+  const int grp = blockIdx.z;
+  const int kz0 = grp * a.KDg;
+  const int tapsg = a.KDg * a.KH * a.KW;
+  const int sci = a.TCI >> 5;
+  const int nsub = sci * (a.TCO >> 5);
+  const int J = tapsg * nsub;
+
+  // job table of this wave: j = wave + 4q
+  int aoffj[MAXJ], boffj[MAXJ];
+  bool jok[MAXJ];
+#pragma unroll
+  for (int q = 0; q < MAXJ; ++q) {
+    const int j = wave + 4 * q;
+    jok[q] = j < J;
+    const int sub = j % nsub, tl = j / nsub;
+    const int cis = sub % sci, cos = sub / sci;
+    const int kx = tl % a.KW, ky = (tl / a.KW) % a.KH, kz = tl / (a.KW * a.KH);
+    aoffj[q] = ((kz * a.HY + ky) * a.HX + kx) * a.TCI + cis * 32;
+    boffj[q] = cos * 32;
+  }
+
+  f32x16 acc[MAXJ];
+#pragma unroll
+  for (int q = 0; q < MAXJ; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int TX = 1 << a.lTX, TY = 1 << a.lTY;
+  const long tiles_per_item = (long)a.ntx * a.nty * a.ntz;
+  const long ntiles = tiles_per_item * a.N;
+  const int HXY = a.HX * a.HY;
+  const int c4x = a.TCI >> 2, c4y = a.TCO >> 2;
+
+  for (long tile = region; tile < ntiles; tile += a.R) {
+    long t = tile;
+    const int tx = (int)(t % a.ntx); t /= a.ntx;
+    const int ty = (int)(t % a.nty); t /= a.nty;
+    const int tz = (int)(t % a.ntz);
+    const int nb = (int)(t / a.ntz);
+    const int ox0 = tx << a.lTX, oy0 = ty << a.lTY, oz0 = tz << a.lTZ;
+    const int lx0 = ox0 * a.SW - a.PW, ly0 = oy0 * a.SH - a.PH,
+              lz0 = oz0 * a.SD - a.PD + kz0;
+    __syncthreads();
+    // ---- stage X halo brick [HV][TCI] -------------------------------------
+    for (int it = tid; it < HV * c4x; it += 256) {
+      const int c4 = it % c4x, hv = it / c4x;
+      const int hz = hv / HXY;
+      const int rem = hv - hz * HXY;
+      const int hy = rem / a.HX, hx = rem - hy * a.HX;
+      const int rx = lx0 + hx, ry = ly0 + hy, rz = lz0 + hz;
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rx >= 0 && ry >= 0 && rz >= 0 && rx < a.W && ry < a.H && rz < a.D) {
+        const size_t gv = ((size_t)(nb * a.D + rz) * a.H + ry) * a.W + rx;
+        const int c = ci0 + 4 * c4;
+        if (a.vecx) {
+          if (c < a.C0)
+            f = *reinterpret_cast<const float4*>(a.x0 + gv * a.C0 + c);
+          else if (c < a.Cin)
+            f = *reinterpret_cast<const float4*>(a.x1 + gv * a.C1 + (c - a.C0));
+        } else {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int cc = c + j;
+            v[j] = cc < a.C0 ? a.x0[gv * a.C0 + cc]
+                             : (cc < a.Cin ? a.x1[gv * a.C1 + (cc - a.C0)] : 0.f);
+          }
+          f = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      *reinterpret_cast<float4*>(&sX[hv * a.TCI + 4 * c4]) = f;
+    }
+    // ---- stage dY brick [TV][TCO] -----------------------------------------
+    for (int it = tid; it < TV * c4y; it += 256) {
+      const int c4 = it % c4y, v = it / c4y;
+      const int x = ox0 + (v & (TX - 1));
+      const int y = oy0 + ((v >> a.lTX) & (TY - 1));
+      const int z = oz0 + (v >> (a.lTX + a.lTY));
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x < a.Wo && y < a.Ho && z < a.Do) {
+        const size_t gv = ((size_t)(nb * a.Do + z) * a.Ho + y) * a.Wo + x;
+        const int c = co0 + 4 * c4;
+        const float* p = a.dy + gv * a.Cout + c;
+        if (a.vecy) {
+          if (c < a.Cout) f = *reinterpret_cast<const float4*>(p);
+        } else {
+          if (c + 0 < a.Cout) f.x = p[0];
+          if (c + 1 < a.Cout) f.y = p[1];
+          if (c + 2 < a.Cout) f.z = p[2];
+          if (c + 3 < a.Cout) f.w = p[3];
+        }
+      }
+      *reinterpret_cast<float4*>(&sY[v * a.TCO + 4 * c4]) = f;
+    }
+    __syncthreads();
+    // ---- K loop over the brick's voxels, two per MFMA ---------------------
+    const int rows = TV >> a.lTX;
+    for (int r = 0; r < rows; ++r) {
+      const int y = r & (TY - 1), z = r >> a.lTY;
+      const int arow = ((z * a.SD) * a.HY + y * a.SH) * a.HX;
+      for (int xp = 0; xp < TX; xp += 2) {
+        const int abase = (arow + (xp + lh) * a.SW) * a.TCI + li;
+        const int bbase = (r * TX + xp + lh) * a.TCO + li;
+#pragma unroll
+        for (int q = 0; q < MAXJ; ++q) {
+          if (jok[q]) {
+            const float av = sX[abase + aoffj[q]];
+            const float bv = sY[bbase + boffj[q]];
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write this region's partial slab ------------------------------------
+  const int ntap = a.KD * a.KH * a.KW;
+#pragma unroll
+  for (int q = 0; q < MAXJ; ++q) {
+    if (!jok[q]) continue;
+    const int j = wave + 4 * q;
+    const int sub = j % nsub, tl = j / nsub;
+    const int cis = sub % sci, cos = sub / sci;
+    const int tap = kz0 * a.KH * a.KW + tl;
+    const int co = co0 + cos * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int ci = ci0 + cis * 32 + row;
+      if (ci < a.Cin && co < a.Cout)
+        a.ws[(((size_t)region * ntap + tap) * a.Cin + ci) * a.Cout + co] = acc[q][r];
+    }
+  }
+}
+
+// out[(co*Cin + ci)*ntap + tap] = sum_r ws[r][tap][ci][co]
+__global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
+    const float* __restrict__ ws, float* __restrict__ out, int R, int ntap, int Cin,
+    int Cout) {
+  const long total = (long)ntap * Cin * Cout;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const long rest = i / Cout;
+    const int ci = (int)(rest % Cin);
+    const int tap = (int)(rest / Cin);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += ws[(size_t)r * total + i];
+    out[((size_t)co * Cin + ci) * ntap + tap] = s;
+  }
+}
+
+struct WgradPlan {
+  int lTX, lTY, lTZ, HX, HY, HZ, TCI, TCO, nci, nco, KDg, ngrp, R, maxj;
+  size_t lds;
+  long ntiles;
+};
+
+static int adell_wgrad_plan(int N, int Cin, int Cout, int KD, int KH, int KW, int SD,
+                            int SH, int SW, int Do, int Ho, int Wo, WgradPlan* p) {
+  p->TCI = Cin > 32 ? 64 : 32;
+  p->TCO = Cout > 32 ? 64 : 32;
+  p->nci = adell_cdiv(Cin, p->TCI);
+  p->nco = adell_cdiv(Cout, p->TCO);
+  const int nsub = (p->TCI / 32) * (p->TCO / 32);
+  p->KDg = (nsub >= 2 && KD > 1) ? 1 : KD;
+  p->ngrp = KD / p->KDg;
+  const int J = p->KDg * KH * KW * nsub;
+  p->maxj = adell_cdiv(J, 4);
+  if (p->maxj > 9) {
+    adell_set_error("wgrad: %d jobs per wave unsupported", p->maxj);
+    return ADELL_E_UNSUPPORTED;
+  }
+  // brick: start from 8x8x2 and shrink until the LDS budget (<= 80 KiB, two
+  // blocks per CU) is met; x extent stays >= 2 (two voxels per MFMA).
+  int l[3] = {3, 3, 1};
+  const int cap[3] = {adell_ilog2(Wo) < 1 ? 1 : adell_ilog2(Wo), adell_ilog2(Ho),
+                      adell_ilog2(Do)};
+  for (int d = 0; d < 3; ++d)
+    if (l[d] > cap[d]) l[d] = cap[d];
+  for (;;) {
+    const int TX = 1 << l[0], TY = 1 << l[1], TZ = 1 << l[2];
+    p->HX = (TX - 1) * SW + KW;
+    p->HY = (TY - 1) * SH + KH;
+    p->HZ = (TZ - 1) * SD + p->KDg;
+    p->lds = ((size_t)p->HX * p->HY * p->HZ * p->TCI + (size_t)TX * TY * TZ * p->TCO) *
+             sizeof(float);
+    if (p->lds <= 80 * 1024) break;
+    // shrink the largest dim (prefer z, then y, then x)
+    int d = 2;
+    if (l[1] > l[d]) d = 1;
+    if (l[0] > l[d] && l[0] > 1) d = 0;
+    if (l[d] == 0 || (d == 0 && l[0] == 1)) {
+      if (p->lds <= 160 * 1024) break;
+      adell_set_error("wgrad: cannot fit LDS");
+      return ADELL_E_UNSUPPORTED;
+    }
+    --l[d];
+  }
+  p->lTX = l[0]; p->lTY = l[1]; p->lTZ = l[2];
+  p->ntiles = (long)N * adell_cdiv(Wo, 1 << l[0]) * adell_cdiv(Ho, 1 << l[1]) *
+              adell_cdiv(Do, 1 << l[2]);
+  const long chan_blocks = (long)p->nci * p->nco * p->ngrp;
+  long R = adell_cdiv(768, (int)chan_blocks);
+  if (R > p->ntiles) R = p->ntiles;
+  if (R < 1) R = 1;
+  p->R = (int)R;
+  return ADELL_OK;
+}
+
+static size_t adell_wgrad_ws_bytes(const WgradPlan& p, int ntap, int Cin, int Cout) {
+  return (size_t)p.R * ntap * Cin * Cout * sizeof(float);
+}
+
+template <int MAXJ>
+static int adell_launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = adell_conv_wgrad_kernel<MAXJ>;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// Core: X is the strided/haloed operand (its channels index dW's "Cin" axis), dY
+// the dense one. out is [CoutY][CinX][ntap].
+static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const float* x0,
+                            const float* x1, int Cout, int Do, int Ho, int Wo,
+                            const float* dy, int KD, int KH, int KW, int SD, int SH,
+                            int SW, int PD, int PH, int PW, float* out, void* ws,
+                            size_t ws_bytes, hipStream_t st) {
+  const int Cin = C0 + C1;
+  WgradPlan p;
+  int rc = adell_wgrad_plan(N, Cin, Cout, KD, KH, KW, SD, SH, SW, Do, Ho, Wo, &p);
+  if (rc != ADELL_OK) return rc;
+  const int ntap = KD * KH * KW;
+  const size_t need = adell_wgrad_ws_bytes(p, ntap, Cin, Cout);
+  ADELL_REQUIRE(ws != nullptr && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu)",
+                ws_bytes, need);
+  WgradArgs a = {};
+  a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = (float*)ws;
+  a.N = N; a.D = D; a.H = H; a.W = W;
+  a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout;
+  a.KD = KD; a.KH = KH; a.KW = KW; a.SD = SD; a.SH = SH; a.SW = SW;
+  a.PD = PD; a.PH = PH; a.PW = PW;
+  a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+  a.lTX = p.lTX; a.lTY = p.lTY; a.lTZ = p.lTZ;
+  a.ntx = adell_cdiv(Wo, 1 << p.lTX);
+  a.nty = adell_cdiv(Ho, 1 << p.lTY);
+  a.ntz = adell_cdiv(Do, 1 << p.lTZ);
+  a.HX = p.HX; a.HY = p.HY; a.HZ = p.HZ;
+  a.TCI = p.TCI; a.TCO = p.TCO; a.nci = p.nci; a.nco = p.nco;
+  a.KDg = p.KDg; a.R = p.R;
+  a.vecx = (C0 % 4 == 0) && (C1 % 4 == 0) && (((uintptr_t)x0 & 15) == 0) &&
+           (((uintptr_t)x1 & 15) == 0);
+  a.vecy = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
+  dim3 grid((unsigned)p.R, (unsigned)(p.nci * p.nco), (unsigned)p.ngrp);
+  if (p.maxj <= 2)
+    rc = adell_launch_wgrad<2>(a, grid, p.lds, st);
+  else if (p.maxj <= 5)
+    rc = adell_launch_wgrad<5>(a, grid, p.lds, st);
+  else if (p.maxj <= 7)
+    rc = adell_launch_wgrad<7>(a, grid, p.lds, st);
+  else
+    rc = adell_launch_wgrad<9>(a, grid, p.lds, st);
+  if (rc != ADELL_OK) return rc;
+  const long total = (long)ntap * Cin * Cout;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st,
+                     (const float*)ws, out, p.R, ntap, Cin, Cout);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" long adell_conv3d_bwd_weight_workspace(const adell_conv3d_desc* d) {
+  if (!d) return ADELL_E_BADARG;
+  WgradPlan p;
+  const int Cin = d->C0 + d->C1;
+  if (adell_wgrad_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->Do,
+                       d->Ho, d->Wo, &p) != ADELL_OK)
+    return ADELL_E_UNSUPPORTED;
+  return (long)adell_wgrad_ws_bytes(p, d->KD * d->KH * d->KW, Cin, d->Cout);
+}
+
+extern "C" int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* x0,
+                                       const float* x1, const float* dy, float* dw,
+                                       void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight: null pointer");
+  ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight: C1 > 0 needs x1");
+  return adell_wgrad_core(d->N, d->D, d->H, d->W, d->C0, d->C1, x0, x1, d->Cout, d->Do,
+                          d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
+                          d->PH, d->PW, dw, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// dW[ci][co][tap] = sum_v x[v][ci] * dy[2v+tap][co]: the same GEMM with the roles
+// swapped (dy is the strided operand, x the dense one).
+extern "C" long adell_convtranspose3d_k2s2_bwd_weight_workspace(int N, int D, int H, int W,
+                                                                int Cin, int Cout) {
+  WgradPlan p;
+  if (adell_wgrad_plan(N, Cout, Cin, 2, 2, 2, 2, 2, 2, D, H, W, &p) != ADELL_OK)
+    return ADELL_E_UNSUPPORTED;
+  return (long)adell_wgrad_ws_bytes(p, 8, Cout, Cin);
+}
+
+extern "C" int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W, int Cin,
+                                                     int Cout, const float* x,
+                                                     const float* dy, float* dw,
+                                                     void* workspace, size_t workspace_bytes,
+                                                     void* stream) {
+  ADELL_REQUIRE(x && dy && dw, "convT_bwd_weight: null pointer");
+  return adell_wgrad_core(N, 2 * D, 2 * H, 2 * W, Cout, 0, dy, nullptr, Cin, D, H, W, x, 2, 2,
+                          2, 2, 2, 2, 0, 0, 0, dw, workspace, workspace_bytes,
+                          (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// Bias gradient: column sums of dy [rows][C], two deterministic phases.
+// ---------------------------------------------------------------------------
+#define ADELL_BG_ROWS 2048
+__global__ __launch_bounds__(256) void adell_colsum_partial_kernel(
+    const float* __restrict__ dy, long rows, int C, float* __restrict__ part) {
+  __shared__ float sh[256];
+  const long r0 = (long)blockIdx.x * ADELL_BG_ROWS;
+  long r1 = r0 + ADELL_BG_ROWS;
+  if (r1 > rows) r1 = rows;
+  const int CG = C < 256 ? C : 256;
+  const int VL = 256 / CG;
+  const int cl = threadIdx.x % CG, vl = threadIdx.x / CG;
+  for (int cb = 0; cb < C; cb += CG) {
+    const int c = cb + cl;
+    float s = 0.f;
+    if (vl < VL && c < C)
+      for (long r = r0 + vl; r < r1; r += VL) s += dy[r * C + c];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (vl == 0 && c < C) {
+      float t = 0.f;
+      for (int k = 0; k < VL; ++k) t += sh[k * CG + cl];
+      part[(size_t)blockIdx.x * C + c] = t;
+    }
+    __syncthreads();
+  }
+}
+__global__ void adell_colsum_final_kernel(const float* __restrict__ part, int nb, int C,
+                                          float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += (double)part[(size_t)b * C + c];
+  out[c] = (float)s;
+}
+
+extern "C" long adell_bias_grad_workspace(long rows, int C) {
+  return (long)((rows + ADELL_BG_ROWS - 1) / ADELL_BG_ROWS) * C * (long)sizeof(float);
+}
+
+extern "C" int adell_bias_grad(const float* dy, long rows, int C, float* db, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(dy && db && workspace, "bias_grad: null pointer");
+  ADELL_REQUIRE(rows > 0 && C > 0, "bias_grad: bad dims");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_bias_grad_workspace(rows, C),
+                "bias_grad: workspace too small");
+  const int nb = (int)((rows + ADELL_BG_ROWS - 1) / ADELL_BG_ROWS);
+  hipLaunchKernelGGL(adell_colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                     dy, rows, C, (float*)workspace);
+  hipLaunchKernelGGL(adell_colsum_final_kernel, dim3(adell_cdiv(C, 64)), dim3(64), 0,
+                     (hipStream_t)stream, (const float*)workspace, nb, C, db);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

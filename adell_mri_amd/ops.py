@@ -115,6 +115,62 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding):
     return dx0, dx1
 
 
+def _workspace(nbytes, device):
+    return torch.empty((max(int(nbytes), 4) + 3) // 4, device=device, dtype=torch.float32)
+
+
+def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None):
+    """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout."""
+    _require_cuda(x0, x1, dy)
+    x0, dy = ndhwc(x0), ndhwc(dy)
+    N, C0, D, H, W = x0.shape
+    C1 = 0
+    if x1 is not None:
+        x1 = ndhwc(x1)
+        C1 = x1.shape[1]
+    Cout = dy.shape[1]
+    k = _triple(kernel)
+    d = make_conv_desc(N, (D, H, W), C0, C1, Cout, kernel, stride, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    nbytes = _lib.lib().adell_conv3d_bwd_weight_workspace(ctypes.byref(d))
+    if nbytes < 0:
+        check(int(nbytes))
+    ws = _workspace(nbytes, x0.device)
+    dw = torch.empty((Cout, C0 + C1, *k), device=x0.device, dtype=torch.float32)
+    check(_lib.lib().adell_conv3d_bwd_weight(ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy),
+                                             _ptr(dw), _ptr(ws), ws.numel() * 4, _stream()))
+    return dw
+
+
+def bias_grad(dy):
+    _require_cuda(dy)
+    dy = ndhwc(dy)
+    C = dy.shape[1]
+    rows = dy.numel() // C
+    nbytes = _lib.lib().adell_bias_grad_workspace(rows, C)
+    ws = _workspace(nbytes, dy.device)
+    db = torch.empty((C,), device=dy.device, dtype=torch.float32)
+    check(_lib.lib().adell_bias_grad(_ptr(dy), rows, C, _ptr(db), _ptr(ws), ws.numel() * 4,
+                                     _stream()))
+    return db
+
+
+def convtranspose3d_k2s2_bwd_weight(x, dy):
+    """dW in torch's canonical [Cin, Cout, 2, 2, 2] layout."""
+    _require_cuda(x, dy)
+    x, dy = ndhwc(x), ndhwc(dy)
+    N, Cin, D, H, W = x.shape
+    Cout = dy.shape[1]
+    nbytes = _lib.lib().adell_convtranspose3d_k2s2_bwd_weight_workspace(N, D, H, W, Cin, Cout)
+    if nbytes < 0:
+        check(int(nbytes))
+    ws = _workspace(nbytes, x.device)
+    dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
+    check(_lib.lib().adell_convtranspose3d_k2s2_bwd_weight(
+        N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, _stream()))
+    return dw
+
+
 def convtranspose3d_k2s2_fwd(x, w_packed, bias, Cout):
     _require_cuda(x, w_packed, bias)
     x = ndhwc(x)

@@ -95,6 +95,20 @@ int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
                           const float* w_packed_bwd, float* dx0, float* dx1,
                           void* stream);
 
+/* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
+ * bricks, fixed-order reduction: deterministic). workspace: device scratch of
+ * at least adell_conv3d_bwd_weight_workspace(d) bytes. */
+long adell_conv3d_bwd_weight_workspace(const adell_conv3d_desc* d);
+int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* x0,
+                            const float* x1, const float* dy, float* dw,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* db[c] = sum over rows of dy[rows][C] (torch's bias gradient of Conv3d /
+ * ConvTranspose3d). workspace >= adell_bias_grad_workspace(rows, C) bytes. */
+long adell_bias_grad_workspace(long rows, int C);
+int adell_bias_grad(const float* dy, long rows, int C, float* db, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * ConvTranspose3d(kernel=2, stride=2, padding=0): unet.py:445-458
  * (init_upscale_ops, upscale_type="transpose"), unetr.py:286-308.
@@ -107,6 +121,13 @@ int adell_convtranspose3d_k2s2_bwd_data(int N, int D, int H, int W, int Cin,
                                         int Cout, const float* dy,
                                         const float* w_packed_bwd, float* dx,
                                         void* stream);
+/* dw in torch's canonical [Cin][Cout][2][2][2] layout. */
+long adell_convtranspose3d_k2s2_bwd_weight_workspace(int N, int D, int H, int W,
+                                                     int Cin, int Cout);
+int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W, int Cin,
+                                          int Cout, const float* x, const float* dy,
+                                          float* dw, void* workspace,
+                                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Normalisation statistics and the fused Norm -> Dropout -> Activation of

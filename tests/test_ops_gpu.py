@@ -123,6 +123,51 @@ def test_conv3d_bwd_data_splits_concat_sources(cuda):
     assert _relerr(_np(dx1), dx_ref[:, 32:]) < 1e-4
 
 
+WGRAD_CASES = [
+    # N, C0, C1, size, Cout, k, s, p
+    (1, 32, 0, (8, 8, 8), 32, 3, 1, 1),
+    (2, 64, 0, (8, 8, 8), 64, 3, 1, 1),
+    (1, 32, 32, (8, 8, 8), 32, 3, 1, 1),
+    (1, 64, 0, (8, 8, 8), 32, 3, 1, 1),
+    (1, 32, 0, (16, 16, 16), 32, 3, 2, 1),
+    (1, 64, 0, (9, 9, 9), 64, 3, 2, 1),
+    (2, 2, 0, (10, 9, 7), 32, 3, 1, 1),
+    (1, 2, 0, (8, 8, 8), 2, 3, 1, 1),
+    (1, 32, 0, (8, 8, 8), 1, 1, 1, 0),
+    (1, 128, 0, (4, 4, 4), 72, 3, 1, 1),
+    (1, 40, 0, (6, 6, 6), 24, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,size,Cout,k,s,p", WGRAD_CASES)
+def test_conv3d_bwd_weight_and_bias_match_oracle(cuda, N, C0, C1, size, Cout, k, s, p):
+    rng = np.random.default_rng(21)
+    Cin = C0 + C1
+    x = rng.standard_normal((N, Cin, *size)).astype(np.float32)
+    w = np.zeros((Cout, Cin, k, k, k), np.float32)
+    osz = ops.conv_out_size(size, (k,) * 3, (s,) * 3, (p,) * 3)
+    dy = rng.standard_normal((N, Cout, *osz)).astype(np.float32)
+    _, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, s, p)
+    x0 = _cl(x[:, :C0], cuda)
+    x1 = _cl(x[:, C0:], cuda) if C1 else None
+    dyd = _cl(dy, cuda)
+    dw = ops.conv3d_bwd_weight(x0, dyd, k, s, p, x1=x1)
+    assert _relerr(_np(dw), dw_ref) < 2e-5
+    db = ops.bias_grad(dyd)
+    assert _relerr(_np(db), db_ref) < 2e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,size", [(32, 16, (4, 4, 4)), (64, 32, (8, 8, 8)), (8, 3, (5, 3, 2))])
+def test_convtranspose_k2s2_bwd_weight(cuda, Cin, Cout, size):
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((2, Cin, *size)).astype(np.float32)
+    w = np.zeros((Cin, Cout, 2, 2, 2), np.float32)
+    dy = rng.standard_normal((2, Cout, *[2 * s for s in size])).astype(np.float32)
+    _, dw_ref, _ = cops.conv_transpose3d_bwd(x, w, dy)
+    dw = ops.convtranspose3d_k2s2_bwd_weight(_cl(x, cuda), _cl(dy, cuda))
+    assert _relerr(_np(dw), dw_ref) < 2e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,size", [(32, 16, (4, 4, 4)), (64, 32, (8, 8, 8)), (8, 3, (5, 3, 2))])
 def test_convtranspose_k2s2_fwd_and_bwd_data(cuda, Cin, Cout, size):
     rng = np.random.default_rng(11)
