@@ -58,10 +58,12 @@ SIGNATURES = {
     "adell_convtranspose3d_k2s2_bwd_weight": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_k2s2_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "adell_convtranspose3d_k2s2_bwd_data": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "adell_stats_finalize": (_i, [_vp, _i, _i, _i, _l, _f, _vp, _vp, _vp]),
+    "adell_stats_finalize": (_i, [_vp, _i, _i, _i, _l, _f, _i, _vp, _vp, _vp]),
     "adell_channel_partials_ntiles": (_i, [_l]),
     "adell_channel_partials": (_i, [_vp, _i, _l, _i, _vp, _vp]),
     "adell_norm_act_fwd": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "adell_norm_act_bwd_workspace": (_l, [ctypes.POINTER(NormActDesc)]),
+    "adell_norm_act_bwd": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 11 + [ctypes.c_size_t, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),
 }
 

@@ -9,20 +9,21 @@
 // written by the conv epilogue or by adell_channel_partials_kernel.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adell_stats_finalize_kernel(
-    const float* __restrict__ part, int ntiles, int C, double count, float eps,
-    float* __restrict__ mean, float* __restrict__ rstd) {
+    const float* __restrict__ part, int N, int ntiles, int C, double count, float eps,
+    int per_item, float* __restrict__ mean, float* __restrict__ rstd) {
   __shared__ double sh[8][32][2];
-  const int n = blockIdx.y;
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
+  const int nbeg = per_item ? blockIdx.y : 0, nend = per_item ? blockIdx.y + 1 : N;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int t = sl; t < ntiles; t += 8) {
-      const float2 v = *reinterpret_cast<const float2*>(
-          part + (((size_t)n * ntiles + t) * C + c) * 2);
-      s1 += (double)v.x;
-      s2 += (double)v.y;
-    }
+    for (int n = nbeg; n < nend; ++n)
+      for (int t = sl; t < ntiles; t += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(
+            part + (((size_t)n * ntiles + t) * C + c) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+      }
   }
   sh[sl][cl][0] = s1;
   sh[sl][cl][1] = s2;
@@ -34,22 +35,24 @@ __global__ __launch_bounds__(256) void adell_stats_finalize_kernel(
       a += sh[k][cl][0];
       b += sh[k][cl][1];
     }
-    const double m = a / count;
-    double var = b / count - m * m;
+    const double cnt = per_item ? count : count * N;
+    const double m = a / cnt;
+    double var = b / cnt - m * m;
     if (var < 0.0) var = 0.0;
-    mean[(size_t)n * C + c] = (float)m;
-    rstd[(size_t)n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    const size_t o = per_item ? (size_t)blockIdx.y * C + c : (size_t)c;
+    mean[o] = (float)m;
+    rstd[o] = (float)(1.0 / sqrt(var + (double)eps));
   }
 }
 
 extern "C" int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
-                                    long count, float eps, float* mean, float* rstd,
-                                    void* stream) {
+                                    long count, float eps, int per_item, float* mean,
+                                    float* rstd, void* stream) {
   ADELL_REQUIRE(partials && mean && rstd, "stats_finalize: null pointer");
   ADELL_REQUIRE(N > 0 && ntiles > 0 && C > 0 && count > 0, "stats_finalize: bad dims");
-  hipLaunchKernelGGL(adell_stats_finalize_kernel, dim3(adell_cdiv(C, 32), N), dim3(256),
-                     0, (hipStream_t)stream, partials, ntiles, C, (double)count, eps,
-                     mean, rstd);
+  hipLaunchKernelGGL(adell_stats_finalize_kernel, dim3(adell_cdiv(C, 32), per_item ? N : 1),
+                     dim3(256), 0, (hipStream_t)stream, partials, N, ntiles, C, (double)count,
+                     eps, per_item, mean, rstd);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
@@ -284,6 +287,293 @@ extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
   hipLaunchKernelGGL(adell_norm_act_fwd_kernel,
                      dim3(adell_ew_blocks(a.vec ? (a.total >> 2) : a.total)), dim3(256), 0,
                      (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Backward of out = act(dropout(hn * gamma + beta)), hn = (x - mean) * rstd.
+//   dt  = dout * act'(u) * mask / (1-p)
+//   dx  = rstd * (gamma*dt - c1 - hn*c2),  c1 = mean(gamma*dt), c2 = mean(gamma*dt*hn)
+// Pass 1 writes per-slab partials (sum dt, sum dt*hn); the finalize kernel
+// turns them into c1/c2 (and dgamma/dbeta); pass 2 is elementwise.
+// ---------------------------------------------------------------------------
+struct NormActBwdArgs {
+  const float* x;
+  const float* dout;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* beta;
+  const float* act_w;
+  const float* c1;   // [N*C] or [C]
+  const float* c2;
+  float* dx;
+  float* part;       // [N][ntiles][C][2]
+  long V;            // voxels per item
+  long VC, total;
+  int C, stat_stride_n, act, act_w_n, ntiles;
+  float act_p, drop_p;
+  uint32_t seed_lo, seed_hi, rng_offset;
+};
+
+__device__ __forceinline__ void adell_na_bwd_elem(const NormActBwdArgs& a, float x, float dout,
+                                                  long nidx, int c, bool keep,
+                                                  float keep_scale, float* dt, float* hn) {
+  float h = x;
+  if (a.mean) {
+    const long si = nidx * a.stat_stride_n + c;
+    h = (x - a.mean[si]) * a.rstd[si];
+  }
+  float t = h;
+  if (a.gamma) t *= a.gamma[c];
+  if (a.beta) t += a.beta[c];
+  const float u = keep ? t * keep_scale : 0.f;
+  float p = a.act_p;
+  if (a.act_w) p = a.act_w[a.act_w_n > 1 ? c : 0];
+  const float du = dout * adell_act_grad(a.act, u, p);
+  *dt = keep ? du * keep_scale : 0.f;
+  *hn = h;
+}
+
+__device__ __forceinline__ void adell_na_keep4(const NormActBwdArgs& a, long e4, bool keep[4]) {
+  keep[0] = keep[1] = keep[2] = keep[3] = true;
+  if (a.drop_p > 0.f) {
+    const uint4 r = adell_philox4((uint32_t)e4, (uint32_t)(e4 >> 32), a.rng_offset, 0u,
+                                  a.seed_lo, a.seed_hi);
+    const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      keep[j] = (float)(rr[j] >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
+  }
+}
+
+// grid (ntiles, N); each block reduces ADELL_STATS_SLAB voxels. VEC: C % 4 == 0.
+template <bool VEC>
+__global__ __launch_bounds__(256) void adell_na_bwd_partials_kernel(NormActBwdArgs a) {
+  __shared__ float sh[256][2][VEC ? 4 : 1];
+  constexpr int W = VEC ? 4 : 1;
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const long v0 = (long)tile * ADELL_STATS_SLAB;
+  long v1 = v0 + ADELL_STATS_SLAB;
+  if (v1 > a.V) v1 = a.V;
+  const int CW = a.C / W;  // thread columns
+  const int CG = CW < 256 ? CW : 256;
+  const int VL = 256 / CG;
+  const int cl = threadIdx.x % CG, vl = threadIdx.x / CG;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  for (int cb = 0; cb < CW; cb += CG) {
+    const int cw = cb + cl;
+    float A[W], B[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) A[j] = B[j] = 0.f;
+    if (vl < VL && cw < CW) {
+      for (long v = v0 + vl; v < v1; v += VL) {
+        const long e = ((long)n * a.V + v) * a.C + (long)cw * W;
+        if constexpr (VEC) {
+          const float4 xv = *reinterpret_cast<const float4*>(a.x + e);
+          const float4 gv = *reinterpret_cast<const float4*>(a.dout + e);
+          const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+          bool keep[4];
+          adell_na_keep4(a, e >> 2, keep);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float dt, hn;
+            adell_na_bwd_elem(a, xs[j], gs[j], n, cw * 4 + j, keep[j], keep_scale, &dt, &hn);
+            A[j] += dt;
+            B[j] += dt * hn;
+          }
+        } else {
+          bool keep[4];
+          adell_na_keep4(a, e >> 2, keep);
+          float dt, hn;
+          adell_na_bwd_elem(a, a.x[e], a.dout[e], n, cw, keep[e & 3], keep_scale, &dt, &hn);
+          A[0] += dt;
+          B[0] += dt * hn;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      sh[threadIdx.x][0][j] = A[j];
+      sh[threadIdx.x][1][j] = B[j];
+    }
+    __syncthreads();
+    if (vl == 0 && cw < CW) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < VL; ++k) {
+          s1 += sh[k * CG + cl][0][j];
+          s2 += sh[k * CG + cl][1][j];
+        }
+        float* o = a.part + (((size_t)n * a.ntiles + tile) * a.C + cw * W + j) * 2;
+        o[0] = s1;
+        o[1] = s2;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// c1/c2 [N][C] (per_item) or [C]; dgamma/dbeta [C] (optional).
+__global__ __launch_bounds__(256) void adell_na_bwd_finalize_kernel(
+    const float* __restrict__ part, int N, int ntiles, int C, double count, int per_item,
+    const float* __restrict__ gamma, float* __restrict__ c1, float* __restrict__ c2,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[8][32][2];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double accA = 0.0, accB = 0.0;  // over all items (batch statistics / dgamma)
+  for (int n = 0; n < N; ++n) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+      for (int t = sl; t < ntiles; t += 8) {
+        const float2 v =
+            *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+      }
+    sh[sl][cl][0] = s1;
+    sh[sl][cl][1] = s2;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      double A = 0.0, B = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        A += sh[k][cl][0];
+        B += sh[k][cl][1];
+      }
+      accA += A;
+      accB += B;
+      if (per_item) {
+        const double g = gamma ? (double)gamma[c] : 1.0;
+        c1[(size_t)n * C + c] = (float)(g * A / count);
+        c2[(size_t)n * C + c] = (float)(g * B / count);
+      }
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && c < C) {
+    if (!per_item) {
+      const double g = gamma ? (double)gamma[c] : 1.0;
+      c1[c] = (float)(g * accA / (count * N));
+      c2[c] = (float)(g * accB / (count * N));
+    }
+    if (dgamma) dgamma[c] = (float)accB;
+    if (dbeta) dbeta[c] = (float)accA;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs a) {
+  constexpr int W = VEC ? 4 : 1;
+  const long nw = a.total / W;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nw;
+       i += (long)gridDim.x * blockDim.x) {
+    const long e = i * W;
+    const int c = (int)(e % a.C);
+    const long nidx = e / a.VC;
+    bool keep[4];
+    adell_na_keep4(a, e >> 2, keep);
+    float xs[W], gs[W], out[W];
+    if constexpr (VEC) {
+      const float4 xv = *reinterpret_cast<const float4*>(a.x + e);
+      const float4 gv = *reinterpret_cast<const float4*>(a.dout + e);
+      xs[0] = xv.x; xs[1] = xv.y; xs[2] = xv.z; xs[3] = xv.w;
+      gs[0] = gv.x; gs[1] = gv.y; gs[2] = gv.z; gs[3] = gv.w;
+    } else {
+      xs[0] = a.x[e];
+      gs[0] = a.dout[e];
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int cj = c + j;
+      float dt, hn;
+      adell_na_bwd_elem(a, xs[j], gs[j], nidx, cj, VEC ? keep[j] : keep[e & 3], keep_scale,
+                        &dt, &hn);
+      float r = dt;
+      if (a.gamma) r *= a.gamma[cj];
+      if (a.mean) {
+        const long si = nidx * a.stat_stride_n + cj;
+        r = a.rstd[si] * (r - a.c1[si] - hn * a.c2[si]);
+      }
+      out[j] = r;
+    }
+    if constexpr (VEC)
+      *reinterpret_cast<float4*>(a.dx + e) = make_float4(out[0], out[1], out[2], out[3]);
+    else
+      a.dx[e] = out[0];
+  }
+}
+
+static int adell_nab_fill(NormActBwdArgs* a, const adell_norm_act_desc* d) {
+  ADELL_REQUIRE(d != nullptr, "norm_act_bwd: null descriptor");
+  ADELL_REQUIRE(d->N > 0 && d->V > 0 && d->C > 0, "norm_act_bwd: bad dims");
+  ADELL_REQUIRE(d->act >= 0 && d->act <= ADELL_ACT_ELU, "norm_act_bwd: unknown activation");
+  ADELL_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "norm_act_bwd: dropout p must be in [0,1)");
+  a->V = d->V;
+  a->VC = d->V * d->C;
+  a->total = d->N * a->VC;
+  a->C = d->C;
+  a->stat_stride_n = d->stats_per_item ? d->C : 0;
+  a->act = d->act;
+  a->act_w_n = d->act_w_n;
+  a->act_p = d->act_p;
+  a->drop_p = d->drop_p;
+  a->seed_lo = (uint32_t)(d->seed & 0xffffffffu);
+  a->seed_hi = (uint32_t)(d->seed >> 32);
+  a->rng_offset = d->rng_offset;
+  a->ntiles = adell_channel_partials_ntiles(d->V);
+  return ADELL_OK;
+}
+
+// workspace floats: partials [N][ntiles][C][2] + c1 [N][C] + c2 [N][C]
+extern "C" long adell_norm_act_bwd_workspace(const adell_norm_act_desc* d) {
+  if (!d || d->N <= 0 || d->V <= 0 || d->C <= 0) return ADELL_E_BADARG;
+  const long nt = adell_channel_partials_ntiles(d->V);
+  return (long)sizeof(float) * (d->N * nt * d->C * 2 + 2 * d->N * d->C);
+}
+
+extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
+                                  const float* dout, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, const float* act_w,
+                                  float* dx, float* dgamma, float* dbeta, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  NormActBwdArgs a = {};
+  int rc = adell_nab_fill(&a, d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(x && dout && dx, "norm_act_bwd: null pointer");
+  ADELL_REQUIRE((mean == nullptr) == (rstd == nullptr), "norm_act_bwd: mean/rstd mismatch");
+  hipStream_t st = (hipStream_t)stream;
+  a.x = x; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
+  a.act_w = act_w; a.dx = dx;
+  const bool vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
+                   (((uintptr_t)dout & 15) == 0) && (((uintptr_t)dx & 15) == 0);
+  if (mean || dgamma || dbeta) {
+    ADELL_REQUIRE(workspace && (long)workspace_bytes >= adell_norm_act_bwd_workspace(d),
+                  "norm_act_bwd: workspace too small");
+    float* part = (float*)workspace;
+    float* c1 = part + (size_t)d->N * a.ntiles * d->C * 2;
+    float* c2 = c1 + (size_t)d->N * d->C;
+    a.part = part; a.c1 = c1; a.c2 = c2;
+    dim3 grid(a.ntiles, (unsigned)d->N);
+    if (vec)
+      hipLaunchKernelGGL(adell_na_bwd_partials_kernel<true>, grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(adell_na_bwd_partials_kernel<false>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(adell_na_bwd_finalize_kernel, dim3(adell_cdiv(d->C, 32)), dim3(256), 0,
+                       st, (const float*)part, (int)d->N, a.ntiles, d->C, (double)d->V,
+                       d->stats_per_item, gamma, c1, c2, dgamma, dbeta);
+  }
+  const long nw = vec ? a.total / 4 : a.total;
+  if (vec)
+    hipLaunchKernelGGL(adell_na_bwd_apply_kernel<true>, dim3(adell_ew_blocks(nw)), dim3(256), 0,
+                       st, a);
+  else
+    hipLaunchKernelGGL(adell_na_bwd_apply_kernel<false>, dim3(adell_ew_blocks(nw)), dim3(256),
+                       0, st, a);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

@@ -1,0 +1,183 @@
+"""torch.autograd glue over the HIP kernels (``ops.py``).
+
+Each Function is one fused site of the reference's hot path:
+
+* ``conv3d``            Conv3d (+ virtual concat of two sources, + residual add,
+                        + per-channel statistics for the norm that follows)
+* ``conv_transpose3d_k2s2``  ConvTranspose3d(k=2, s=2)
+* ``norm_drop_act``     Norm -> Dropout -> Activation of ActDropNorm ("NDA")
+
+Statistics produced by the conv epilogue ride on the output tensor as
+``y._adell_partials`` so that the following ``norm_drop_act`` does not re-read
+``y``; they are dropped by any other consumer.
+"""
+import itertools
+
+import torch
+
+from . import ops
+
+_PACK_CACHE = {}
+_dropout_counter = itertools.count(1)
+
+
+def _packed(w, mode):
+    """Repacked copy of a weight, cached until the parameter is modified in place."""
+    key = (w.data_ptr(), mode)
+    ver = w._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[1].device == w.device and hit[2] == tuple(w.shape):
+        return hit[1]
+    p = ops.pack_weight(w.detach(), mode)
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (ver, p, tuple(w.shape))
+    return p
+
+
+class _Conv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, residual, stride, padding, want_stats):
+        k = tuple(weight.shape[2:])
+        wp = _packed(weight, 0)
+        y, part = ops.conv3d_fwd(x0, wp, bias, weight.shape[0], k, stride, padding, x1=x1,
+                                 residual=residual, want_stats=want_stats)
+        ctx.save_for_backward(x0, x1, weight)
+        ctx.conf = (k, stride, padding, bias is not None, residual is not None)
+        if part is None:
+            part = y.new_empty(0)
+        ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, dy, _dpart):
+        x0, x1, weight = ctx.saved_tensors
+        k, stride, padding, has_bias, has_res = ctx.conf
+        need = ctx.needs_input_grad
+        dy = ops.ndhwc(dy)
+        dx0 = dx1 = dw = db = dres = None
+        C0 = x0.shape[1]
+        C1 = 0 if x1 is None else x1.shape[1]
+        if need[0] or (x1 is not None and need[1]):
+            dx0, dx1 = ops.conv3d_bwd_data(dy, _packed(weight, 1), tuple(x0.shape[2:]), C0, C1, k,
+                                           stride, padding)
+            if not need[0]:
+                dx0 = None
+            if x1 is None or not need[1]:
+                dx1 = None
+        if need[2]:
+            dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1)
+        if has_bias and need[3]:
+            db = ops.bias_grad(dy)
+        if has_res and need[4]:
+            dres = dy
+        return dx0, dx1, dw, db, dres, None, None, None
+
+
+def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True):
+    """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual)."""
+    stride, padding = ops._triple(stride), ops._triple(padding)
+    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual, stride, padding, want_stats)
+    if want_stats and part.numel() > 0:
+        y._adell_partials = part
+    return y
+
+
+class _ConvT3dK2S2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.convtranspose3d_k2s2_fwd(x, _packed(weight, 2), bias, weight.shape[1])
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dy = ops.ndhwc(dy)
+        dx = dw = db = None
+        if need[0]:
+            dx = ops.convtranspose3d_k2s2_bwd_data(dy, _packed(weight, 3), weight.shape[0])
+        if need[1]:
+            dw = ops.convtranspose3d_k2s2_bwd_weight(x, dy)
+        if ctx.has_bias and need[2]:
+            db = ops.bias_grad(dy)
+        return dx, dw, db
+
+
+def conv_transpose3d_k2s2(x, weight, bias=None):
+    return _ConvT3dK2S2Fn.apply(x, weight, bias)
+
+
+class _NormDropActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, rstd, gamma, beta, act_w, conf):
+        act, act_p, per_item, drop_p, seed, offset = conf
+        out = ops.norm_act_fwd(x, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w,
+                               act_p=act_p, stats_per_item=per_item, drop_p=drop_p, seed=seed,
+                               rng_offset=offset)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta, act_w)
+        ctx.conf = conf
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mean, rstd, gamma, beta, act_w = ctx.saved_tensors
+        act, act_p, per_item, drop_p, seed, offset = ctx.conf
+        if act_w is not None and ctx.needs_input_grad[5]:
+            raise NotImplementedError("PReLU weight gradient is not implemented yet")
+        want_affine = gamma is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        dx, dgamma, dbeta = ops.norm_act_bwd(
+            x, dout, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w, act_p=act_p,
+            stats_per_item=per_item, drop_p=drop_p, seed=seed, rng_offset=offset,
+            want_affine_grads=want_affine)
+        return dx, None, None, dgamma, dbeta, None, None
+
+
+def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=None,
+                  momentum=0.1, act="identity", act_p=0.0, act_w=None, drop_p=0.0,
+                  training=False):
+    """Fused Norm -> Dropout -> Activation.
+
+    norm: "none" | "instance" | "batch". ``running`` = (running_mean, running_var,
+    num_batches_tracked) buffers of a BatchNorm module (updated in training).
+    """
+    part = getattr(x, "_adell_partials", None)
+    x = ops.ndhwc(x)
+    N, C = x.shape[:2]
+    V = x.shape[2] * x.shape[3] * x.shape[4]
+    mean = rstd = None
+    per_item = 1
+    if norm == "instance":
+        if part is None:
+            part = ops.channel_partials(x.detach())
+        mean, rstd = ops.stats_finalize(part, V, eps, per_item=True)
+    elif norm == "batch":
+        per_item = 0
+        if training or running is None or running[0] is None:
+            if part is None:
+                part = ops.channel_partials(x.detach())
+            mean, rstd = ops.stats_finalize(part, V, eps, per_item=False)
+            if training and running is not None and running[0] is not None:
+                with torch.no_grad():
+                    rm, rv, nbt = running
+                    n = N * V
+                    var = (1.0 / (rstd * rstd) - eps) * (n / max(n - 1, 1))
+                    if nbt is not None:
+                        nbt += 1
+                    mom = momentum if momentum is not None else 1.0 / float(nbt)
+                    rm.mul_(1 - mom).add_(mean, alpha=mom)
+                    rv.mul_(1 - mom).add_(var, alpha=mom)
+        else:
+            mean = running[0]
+            rstd = torch.rsqrt(running[1] + eps)
+    elif norm != "none":
+        raise NotImplementedError(f"norm {norm!r} has no HIP kernel yet")
+    p = float(drop_p) if training else 0.0
+    seed, offset = 0, 0
+    if p > 0.0:
+        seed = torch.initial_seed()
+        offset = next(_dropout_counter)
+    conf = (act, float(act_p), per_item, p, seed, offset)
+    return _NormDropActFn.apply(x, mean, rstd, gamma, beta, act_w, conf)

@@ -1,0 +1,63 @@
+"""Convolution leaves. They subclass the stock ``torch.nn`` modules so that
+parameter shapes, initialisation and ``state_dict`` keys are those of the
+reference's ``torch.nn.Conv3d`` / ``ConvTranspose3d`` call sites
+(adell_mri/modules/segmentation/unet.py:260-273, :445-458), but ``forward`` runs
+the MI355X kernels and never ``F.conv3d``."""
+import torch
+
+from ... import functional as HF
+from ..._lib import AdellHipError
+
+
+def _resolve_padding(padding, kernel_size, stride, dilation):
+    if isinstance(padding, str):
+        if padding == "valid":
+            return (0,) * len(kernel_size)
+        if padding == "same":
+            if any(k % 2 == 0 for k in kernel_size):
+                raise AdellHipError("padding='same' needs odd kernel sizes on the HIP path")
+            return tuple(d * (k - 1) // 2 for k, d in zip(kernel_size, dilation))
+        raise ValueError(padding)
+    return tuple(padding)
+
+
+class Conv3d(torch.nn.Conv3d):
+    def _check(self):
+        if self.groups != 1 or any(d != 1 for d in self.dilation) or self.padding_mode != "zeros":
+            raise AdellHipError("HIP Conv3d supports groups=1, dilation=1, zero padding only")
+
+    def forward(self, X, X_cat=None, residual=None):
+        """``X_cat``: second source of a virtual channel concat; ``residual``: tensor
+        added to the output inside the kernel epilogue."""
+        self._check()
+        pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
+        return HF.conv3d(X, self.weight, self.bias, self.stride, pad, x1=X_cat, residual=residual)
+
+
+class Conv2d(torch.nn.Conv2d):
+    """2-D convolution run as a depth-1 3-D convolution."""
+
+    def forward(self, X, X_cat=None, residual=None):
+        if self.groups != 1 or any(d != 1 for d in self.dilation) or self.padding_mode != "zeros":
+            raise AdellHipError("HIP Conv2d supports groups=1, dilation=1, zero padding only")
+        pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
+        un = lambda t: None if t is None else t.unsqueeze(2)  # noqa: E731
+        y = HF.conv3d(un(X), self.weight.unsqueeze(2), self.bias, (1, *self.stride), (0, *pad),
+                      x1=un(X_cat), residual=un(residual))
+        part = getattr(y, "_adell_partials", None)
+        y = y.squeeze(2)
+        if part is not None:
+            y._adell_partials = part
+        return y
+
+
+class ConvTranspose3d(torch.nn.ConvTranspose3d):
+    def forward(self, X, output_size=None):
+        ok = (tuple(self.kernel_size) == (2, 2, 2) and tuple(self.stride) == (2, 2, 2)
+              and tuple(self.padding) == (0, 0, 0) and tuple(self.output_padding) == (0, 0, 0)
+              and self.groups == 1 and tuple(self.dilation) == (1, 1, 1) and output_size is None)
+        if not ok:
+            raise AdellHipError(
+                "HIP ConvTranspose3d implements kernel=stride=2, padding=0 (the U-Net decoder "
+                f"upscaling); got k={self.kernel_size} s={self.stride} p={self.padding}")
+        return HF.conv_transpose3d_k2s2(X, self.weight, self.bias)

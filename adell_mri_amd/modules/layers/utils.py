@@ -1,0 +1,17 @@
+"""Small tensor helpers (mirror of adell_mri/modules/layers/utils.py)."""
+from typing import List
+
+import torch
+
+
+def crop_to_size(X: torch.Tensor, output_size: List[int]) -> torch.Tensor:
+    """Centre-crop the spatial dims of ``X`` ([N, C, ...]) to ``output_size``.
+
+    Same window as adell_mri/modules/layers/utils.py:30-52 (offset ``diff // 2``),
+    expressed as a strided view instead of ``index_select`` copies.
+    """
+    sl = [slice(None), slice(None)]
+    for cur, out in zip(X.shape[2:], output_size):
+        a = (cur - out) // 2
+        sl.append(slice(a, a + out))
+    return X[tuple(sl)]

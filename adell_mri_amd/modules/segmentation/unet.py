@@ -1,0 +1,353 @@
+"""U-Net on the MI355X kernels: drop-in mirror of
+``adell_mri.modules.segmentation.unet.UNet`` (reference: adell_mri/modules/
+segmentation/unet.py:31-843) for the 3-D training path.
+
+What is kept verbatim from the reference: the constructor signature and
+defaults (unet.py:43-68), attribute names, the module tree / ``state_dict``
+keys (``encoding_operations.L.{0,1}...``, ``link_ops``, ``upscale_ops``,
+``decoding_operations``, ``final_layer``), and ``forward``'s arguments and
+return tuples (unet.py:751-843).
+
+What is different underneath: every Conv3d / ConvTranspose3d / ActDropNorm is a
+HIP-kernel leaf; ``torch.concat((upsampled, skip))`` (unet.py:817) is never
+materialised -- the decoder's first convolution reads both tensors as one
+virtual channel range; residual adds live in conv epilogues; activations stay
+NDHWC between layers.
+"""
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from ..._lib import AdellHipError
+from ..layers.adn_fn import ActDropNorm, norm_fn_dict
+from ..layers.conv import Conv2d, Conv3d, ConvTranspose3d
+from ..layers.regularization import UOut
+from ..layers.res_blocks import ResidualBlock3d
+from ..layers.utils import crop_to_size
+
+
+def _per_dim(v, n):
+    return [v for _ in range(n)] if isinstance(v, int) else list(v)
+
+
+class ConcatConvBlock(torch.nn.Sequential):
+    """``Sequential(conv, adn, conv)`` whose first conv can take the two halves
+    of a channel concat separately (same children / keys as the Sequential built
+    by the reference's ``conv_block_3d``, unet.py:260-273)."""
+
+    def forward(self, X, X_cat=None):
+        mods = list(self)
+        h = mods[0](X, X_cat=X_cat) if X_cat is not None else mods[0](X)
+        for mod in mods[1:]:
+            h = mod(h)
+        return h
+
+
+class _DecoderOp(torch.nn.Sequential):
+    """``Sequential(conv_block, adn)`` forwarding the concat operand."""
+
+    def forward(self, X, X_cat=None):
+        mods = list(self)
+        if X_cat is not None and isinstance(mods[0], ConcatConvBlock):
+            h = mods[0](X, X_cat=X_cat)
+        else:
+            h = mods[0](X if X_cat is None else torch.cat((X, X_cat), 1))
+        for mod in mods[1:]:
+            h = mod(h)
+        return h
+
+
+class UNet(torch.nn.Module):
+    def __init__(
+        self,
+        spatial_dimensions: int = 2,
+        encoding_operations: List[torch.nn.ModuleList] = None,
+        conv_type: str = "regular",
+        link_type: str = "identity",
+        upscale_type: str = "upsample",
+        interpolation: str = "bilinear",
+        norm_type: str = "batch",
+        dropout_type: str = "dropout",
+        padding: str = "same",
+        dropout_param: float = 0.1,
+        activation_fn: torch.nn.Module = torch.nn.PReLU,
+        in_channels: int = 1,
+        n_classes: int = 2,
+        depth: list = [16, 32, 64],
+        kernel_sizes: list = [3, 3, 3],
+        strides: list = [2, 2, 2],
+        bottleneck_classification: bool = False,
+        skip_conditioning: int = None,
+        feature_conditioning: int = None,
+        feature_conditioning_params: Dict[str, torch.Tensor] = None,
+        deep_supervision: bool = False,
+        parent_class: bool = False,
+        encoder_only: bool = False,
+    ):
+        super().__init__()
+        self.spatial_dimensions = spatial_dimensions
+        self.encoding_operations = encoding_operations
+        self.conv_type = conv_type
+        self.link_type = link_type
+        self.upscale_type = upscale_type
+        self.interpolation = interpolation
+        self.norm_type = norm_type
+        self.dropout_type = dropout_type
+        self.padding = padding
+        self.dropout_param = dropout_param
+        self.activation_fn = activation_fn
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.depth = depth
+        self.kernel_sizes = kernel_sizes
+        self.strides = strides
+        self.bottleneck_classification = bottleneck_classification
+        self.skip_conditioning = skip_conditioning
+        self.feature_conditioning = feature_conditioning
+        self.feature_conditioning_params = feature_conditioning_params
+        self.deep_supervision = deep_supervision
+        self.encoder_only = encoder_only
+
+        if self.encoder_only is True or parent_class is False:
+            self.get_norm_op()
+            self.get_drop_op()
+            self.get_conv_op()
+            if self.encoding_operations is None:
+                self.init_encoder()
+            else:
+                self.init_encoder_backbone()
+        if self.encoder_only is not True and parent_class is False:
+            self.init_upscale_ops()
+            self.init_link_ops()
+            self.init_decoder()
+            self.init_final_layer()
+            if self.bottleneck_classification is True:
+                self.init_bottleneck_classifier()
+            if self.feature_conditioning == 0:
+                self.feature_conditioning = None
+            if self.feature_conditioning is not None:
+                raise NotImplementedError(
+                    "feature_conditioning is outside the HIP path built so far")
+
+    # ---- operator selection ------------------------------------------------
+    def get_norm_op(self):
+        if self.norm_type is None:
+            self.norm_op = torch.nn.Identity
+            return
+        self.norm_op = norm_fn_dict[self.norm_type][self.spatial_dimensions]
+
+    def get_drop_op(self):
+        if self.dropout_type is None:
+            self.drop_op = torch.nn.Identity
+        elif self.dropout_type == "dropout":
+            self.drop_op = torch.nn.Dropout
+        elif self.dropout_type == "uout":
+            self.drop_op = UOut
+
+    def get_conv_op(self):
+        if self.spatial_dimensions not in (2, 3):
+            raise ValueError("spatial_dimensions must be 2 or 3")
+        if self.conv_type == "regular":
+            self.conv_op_enc = self.conv_block
+            self.conv_op_dec = self.conv_block
+        elif self.conv_type == "resnet" and self.spatial_dimensions == 3:
+            self.conv_op_enc = self.res_block_conv_3d
+            self.conv_op_dec = self.conv_block
+        else:
+            raise NotImplementedError(
+                f"conv_type={self.conv_type!r} (spatial_dimensions={self.spatial_dimensions}) "
+                "is outside the HIP path built so far")
+
+    @property
+    def _conv(self):
+        return Conv3d if self.spatial_dimensions == 3 else Conv2d
+
+    def conv_block(self, in_d, out_d, kernel_size, stride=None, padding=None):
+        """conv(in->in, k, stride) -> ADN(in) -> conv(in->out, k): unet.py:245-273."""
+        padding = 0 if padding is None else padding
+        stride = 1 if stride is None else stride
+        return ConcatConvBlock(
+            self._conv(in_d, in_d, kernel_size, stride, padding),
+            self.adn_fn(in_d),
+            self._conv(in_d, out_d, kernel_size, 1, padding),
+        )
+
+    # the reference names (unet.py:245,260) stay available
+    conv_block_2d = conv_block
+    conv_block_3d = conv_block
+
+    def res_block_conv_3d(self, in_d, out_d, kernel_size, stride=None, padding=None):
+        """ResidualBlock3d (+ MaxPool3d when strided): unet.py:344-379."""
+        inter_d = int(in_d) if in_d > 32 else None
+        stride = _per_dim(1 if stride is None else stride, 3)
+        if any(s > 1 for s in stride):
+            raise NotImplementedError("conv_type='resnet' with stride > 1 needs the MaxPool3d "
+                                      "kernel (next row)")
+        return ResidualBlock3d(in_d, kernel_size, inter_d, out_d, adn_fn=self.adn_fn)
+
+    def adn_fn(self, s: int) -> torch.nn.Module:
+        return ActDropNorm(in_channels=s, ordering="NDA", norm_fn=self.norm_op,
+                           act_fn=self.activation_fn, dropout_fn=self.drop_op,
+                           dropout_param=self.dropout_param)
+
+    # ---- builders (same trees as unet.py:415-655) ----------------------------
+    def init_upscale_ops(self):
+        depths_a = self.depth[:0:-1]
+        depths_b = self.depth[-2::-1]
+        ops_ = []
+        if self.upscale_type != "transpose":
+            raise NotImplementedError("upscale_type='upsample' is outside the HIP path built so "
+                                      "far (all BASELINE configs use 'transpose')")
+        if self.spatial_dimensions != 3:
+            raise NotImplementedError("2-D transposed convolution has no HIP kernel yet")
+        for d1, d2, s in zip(depths_a, depths_b, self.strides[::-1][1:]):
+            s = _per_dim(s, self.spatial_dimensions)
+            p = [int(np.maximum(i - 2, 0)) for i in s]
+            ops_.append(ConvTranspose3d(d1, d2, s, stride=s, padding=p))
+        self.upscale_ops = torch.nn.ModuleList(ops_)
+
+    def init_link_ops(self):
+        ex = self.skip_conditioning if self.skip_conditioning is not None else 0
+        rev_depth = self.depth[-2::-1]
+        if self.link_type == "identity":
+            self.link_ops = torch.nn.ModuleList([torch.nn.Identity() for _ in self.depth[:-1]])
+        elif self.link_type == "conv":
+            self.link_ops = torch.nn.ModuleList([
+                torch.nn.Sequential(self._conv(d + ex, d, 3, padding=self.padding), self.adn_fn(d))
+                for d in rev_depth])
+        elif self.link_type == "residual":
+            if self.spatial_dimensions != 3:
+                raise NotImplementedError("2-D residual links are outside the HIP path so far")
+            self.link_ops = torch.nn.ModuleList([
+                ResidualBlock3d(d + ex, 3, out_channels=d, adn_fn=self.adn_fn) for d in rev_depth])
+        else:
+            raise NotImplementedError(f"link_type={self.link_type!r} is outside the HIP path")
+
+    def init_encoder(self):
+        self.encoding_operations = torch.nn.ModuleList([])
+        previous_d = self.in_channels
+        nd = self.spatial_dimensions
+        k = None
+        for i in range(len(self.depth) - 1):
+            d = self.depth[i]
+            k = _per_dim(self.kernel_sizes[i], nd)
+            s = _per_dim(self.strides[i], nd)
+            p = [int(j // 2) for j in k]
+            op = torch.nn.Sequential(
+                self.conv_op_enc(previous_d, d, kernel_size=k, stride=1, padding=self.padding),
+                self.adn_fn(d))
+            op_downsample = torch.nn.Sequential(
+                self.conv_op_enc(d, d, kernel_size=k, stride=s, padding=p), self.adn_fn(d))
+            self.encoding_operations.append(torch.nn.ModuleList([op, op_downsample]))
+            previous_d = d
+        op = torch.nn.Sequential(
+            self.conv_op_enc(self.depth[-2], self.depth[-1], kernel_size=k, stride=1,
+                             padding=self.padding),
+            self.adn_fn(self.depth[-1]))
+        self.encoding_operations.append(torch.nn.ModuleList([op, torch.nn.Identity()]))
+
+    def init_encoder_backbone(self):
+        raise NotImplementedError("backbone encoders need the MaxPool3d kernel (next row)")
+
+    def init_decoder(self):
+        self.decoding_operations = torch.nn.ModuleList([])
+        depths = self.depth[-2::-1]
+        kernel_sizes = self.kernel_sizes[-2::-1]
+        self.deep_supervision_ops = torch.nn.ModuleList([])
+        for d, k in zip(depths, kernel_sizes):
+            k = _per_dim(k, self.spatial_dimensions)
+            op = _DecoderOp(
+                self.conv_op_dec(d * 2, d, kernel_size=k, stride=1, padding=self.padding),
+                self.adn_fn(d))
+            self.decoding_operations.append(op)
+            if self.deep_supervision is True:
+                self.deep_supervision_ops.append(self.get_ds_final_layer(d))
+
+    def _head(self, d, padding):
+        last = torch.nn.Softmax(dim=1) if self.n_classes > 2 else torch.nn.Sigmoid()
+        nc = self.n_classes if self.n_classes > 2 else 1
+        return torch.nn.Sequential(self._conv(d, d, 3, padding=padding), self.adn_fn(d),
+                                   self._conv(d, nc, 1), last)
+
+    def get_final_layer(self, d: int) -> torch.nn.Module:
+        return self._head(d, "same")
+
+    def get_ds_final_layer(self, d: int) -> torch.nn.Module:
+        return self._head(d, 0)
+
+    def init_final_layer(self):
+        self.final_layer = self.get_final_layer(self.depth[0])
+
+    def init_bottleneck_classifier(self):
+        nc = self.n_classes if self.n_classes > 2 else 1
+        self.bottleneck_classifier = torch.nn.Linear(self.depth[-1], nc)
+
+    # ---- forward (unet.py:751-843) --------------------------------------------
+    def _final(self, layer, X, return_logits):
+        mods = list(layer)
+        for mod in mods[:-1]:
+            X = mod(X)
+        if return_logits is True:
+            return X
+        # Sigmoid / Softmax over one small [B, n_classes, ...] tensor
+        return mods[-1](X)
+
+    def forward(self, X: torch.Tensor, X_skip_layer: torch.Tensor = None,
+                X_feature_conditioning: torch.Tensor = None, return_features=False,
+                return_bottleneck=False, return_logits=False):
+        if not X.is_cuda:
+            raise AdellHipError("adell_mri_amd.UNet runs on MI355X only (no CPU fallback)")
+        if X_feature_conditioning is not None:
+            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
+        if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
+            X_skip_layer = X_skip_layer.unsqueeze(1)
+
+        encoding_out = []
+        curr = X
+        for op, op_ds in self.encoding_operations:
+            curr = op(curr)
+            encoding_out.append(curr)
+            curr = op_ds(curr)
+        bottleneck = curr
+        if return_bottleneck is True:
+            return None, None, bottleneck
+        elif self.encoder_only is True:
+            return bottleneck
+
+        deep_outputs = []
+        for i in range(len(self.decoding_operations)):
+            op = self.decoding_operations[i]
+            link_op = self.link_ops[i]
+            up = self.upscale_ops[i]
+            link_in = encoding_out[-i - 2]
+            if X_skip_layer is not None:
+                S = link_in.shape[2:]
+                xfl = torch.nn.functional.interpolate(X_skip_layer, S, mode="nearest")
+                link_in = torch.cat([link_in, xfl], axis=1)
+            encoded = link_op(link_in)
+            curr = up(curr)
+            sh, sh2 = list(curr.shape)[2:], list(encoded.shape)[2:]
+            if np.prod(sh) < np.prod(sh2):
+                encoded = crop_to_size(encoded, sh)
+            if np.prod(sh) > np.prod(sh2):
+                curr = crop_to_size(curr, sh2)
+            curr = op(curr, X_cat=encoded)  # virtual concat (curr, encoded)
+            deep_outputs.append(curr)
+
+        final_features = curr
+        curr = self._final(self.final_layer, curr, return_logits)
+        if return_features is True:
+            return curr, final_features, bottleneck
+
+        if self.bottleneck_classification is True:
+            pooled = bottleneck.flatten(start_dim=2).max(-1).values
+            bn_out = self.bottleneck_classifier(pooled)
+        else:
+            bn_out = None
+
+        if self.deep_supervision is True:
+            for i in range(len(deep_outputs)):
+                deep_outputs[i] = self._final(self.deep_supervision_ops[i], deep_outputs[i], False)
+            return curr, bn_out, deep_outputs
+        return curr, bn_out

@@ -194,12 +194,14 @@ def convtranspose3d_k2s2_bwd_data(dy, w_packed_bwd, Cin):
     return dx
 
 
-def stats_finalize(partials, count, eps):
+def stats_finalize(partials, count, eps, per_item=True):
+    """(mean, rstd): [N, C] per item (instance norm) or [C] over the batch (batch norm)."""
     N, nt, C, _ = partials.shape
-    mean = torch.empty((N, C), device=partials.device, dtype=torch.float32)
+    mean = torch.empty((N, C) if per_item else (C,), device=partials.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     check(_lib.lib().adell_stats_finalize(_ptr(partials), N, nt, C, int(count), float(eps),
-                                          _ptr(mean), _ptr(rstd), _stream()))
+                                          1 if per_item else 0, _ptr(mean), _ptr(rstd),
+                                          _stream()))
     return mean, rstd
 
 
@@ -242,3 +244,25 @@ def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.
                                         _ptr(gamma), _ptr(beta), _ptr(act_w), _ptr(out),
                                         _stream()))
     return out
+
+
+def norm_act_bwd(x, dout, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.0,
+                 stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0, want_affine_grads=False):
+    """dx (and dgamma, dbeta when want_affine_grads) of norm_act_fwd."""
+    _require_cuda(x, dout, mean, rstd, gamma, beta, act_w)
+    x, dout = ndhwc(x), ndhwc(dout)
+    d = make_na_desc(x, act, stats_per_item, act_p, 0 if act_w is None else act_w.numel(),
+                     drop_p, seed, rng_offset)
+    dx = new_act(*x.shape, x.device)
+    dgamma = dbeta = None
+    if want_affine_grads:
+        dgamma = torch.empty((x.shape[1],), device=x.device, dtype=torch.float32)
+        dbeta = torch.empty_like(dgamma)
+    ws = None
+    if mean is not None or want_affine_grads:
+        ws = _workspace(_lib.lib().adell_norm_act_bwd_workspace(ctypes.byref(d)), x.device)
+    check(_lib.lib().adell_norm_act_bwd(
+        ctypes.byref(d), _ptr(x), _ptr(dout), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+        _ptr(act_w), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+        0 if ws is None else ws.numel() * 4, _stream()))
+    return dx, dgamma, dbeta

@@ -133,11 +133,12 @@ int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W, int Cin,
  * Normalisation statistics and the fused Norm -> Dropout -> Activation of
  * ActDropNorm with ordering "NDA" (adn_fn.py:56-152; unet.py:697-714).
  * ---------------------------------------------------------------------- */
-/* mean / rstd [N][C] from partials [N][ntiles][C][2]; count = voxels per item;
- * biased variance, rstd = 1/sqrt(var+eps) (torch.nn.InstanceNorm3d). */
+/* mean / rstd from partials [N][ntiles][C][2]; count = voxels per item; biased
+ * variance, rstd = 1/sqrt(var+eps). per_item=1: [N][C] (torch.nn.InstanceNorm3d);
+ * per_item=0: [C] over the whole batch (torch.nn.BatchNorm3d in training). */
 int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
-                         long count, float eps, float* mean, float* rstd,
-                         void* stream);
+                         long count, float eps, int per_item, float* mean,
+                         float* rstd, void* stream);
 /* Partials of an arbitrary tensor x [N][V][C] (same buffer format). */
 int adell_channel_partials_ntiles(long V);
 int adell_channel_partials(const float* x, int N, long V, int C, float* partials,
@@ -160,6 +161,17 @@ typedef struct adell_norm_act_desc {
 int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
                        const float* mean, const float* rstd, const float* gamma,
                        const float* beta, const float* act_w, float* out,
+                       void* stream);
+
+/* dx (and optionally dgamma / dbeta [C]) of adell_norm_act_fwd; the dropout
+ * mask is regenerated from (seed, rng_offset). workspace >=
+ * adell_norm_act_bwd_workspace(d) bytes (needed when a norm or affine grad is
+ * involved). */
+long adell_norm_act_bwd_workspace(const adell_norm_act_desc* d);
+int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x, const float* dout,
+                       const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* act_w, float* dx, float* dgamma,
+                       float* dbeta, void* workspace, size_t workspace_bytes,
                        void* stream);
 
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */

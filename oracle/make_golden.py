@@ -1,0 +1,142 @@
+"""Generate tests/golden/*.npz from the REAL reference (run in the build
+container only; /root/reference never travels to the GPU box).
+
+Import recipe: the reference's package __init__ files pull
+in monai/lightning, which are not installed, so empty package stubs with the
+right __path__ are registered first and the leaf modules are imported directly.
+
+    python oracle/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REF = os.environ.get("ADELL_REFERENCE", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+for name, path in [
+    ("adell_mri", "adell_mri"), ("adell_mri.modules", "adell_mri/modules"),
+    ("adell_mri.modules.layers", "adell_mri/modules/layers"),
+    ("adell_mri.modules.segmentation", "adell_mri/modules/segmentation"),
+    ("adell_mri.utils", "adell_mri/utils"),
+]:
+    m = types.ModuleType(name)
+    m.__path__ = [os.path.join(REF, path)]
+    sys.modules[name] = m
+import einops.layers.torch  # noqa: E402,F401  (the reference uses it via bare `import einops`)
+import torch  # noqa: E402
+
+from adell_mri.modules.activations import activation_factory  # noqa: E402
+from adell_mri.modules.layers.adn_fn import get_adn_fn  # noqa: E402
+from adell_mri.modules.layers.res_blocks import ResidualBlock3d  # noqa: E402
+from adell_mri.modules.segmentation.losses import (  # noqa: E402
+    binary_focal_loss, binary_generalized_dice_loss)
+from adell_mri.modules.segmentation.unet import UNet  # noqa: E402
+
+from oracle.weights import fill_state_dict  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+UNET_CASES = {
+    # name: (constructor kwargs, input shape, input distribution)
+    "unet3d_cfg2_tiny": (dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                              upscale_type="transpose", norm_type="instance", padding=1,
+                              dropout_param=0.15, activation_fn="swish", in_channels=2,
+                              n_classes=2, depth=[4, 4, 8, 16, 32], kernel_sizes=[3] * 5,
+                              strides=[2] * 5), (1, 2, 32, 32, 32), "uniform"),
+    "unet3d_cfg2_small": (dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                               upscale_type="transpose", norm_type="instance", padding=1,
+                               dropout_param=0.15, activation_fn="swish", in_channels=2,
+                               n_classes=2, depth=[8, 8, 16], kernel_sizes=[3] * 3,
+                               strides=[2] * 3), (2, 2, 16, 16, 16), "normal"),
+    "unet3d_identity_links_relu": (dict(spatial_dimensions=3, conv_type="regular",
+                                        link_type="identity", upscale_type="transpose",
+                                        norm_type="instance", padding=1, dropout_param=0.0,
+                                        activation_fn="relu", in_channels=1, n_classes=2,
+                                        depth=[8, 16, 32], kernel_sizes=[3] * 3,
+                                        strides=[2] * 3), (1, 1, 16, 16, 16), "uniform"),
+    "unet3d_conv_links_gelu": (dict(spatial_dimensions=3, conv_type="regular", link_type="conv",
+                                    upscale_type="transpose", norm_type="instance", padding=1,
+                                    dropout_param=0.0, activation_fn="gelu", in_channels=3,
+                                    n_classes=2, depth=[8, 16, 32], kernel_sizes=[3] * 3,
+                                    strides=[2] * 3), (1, 3, 16, 16, 16), "normal"),
+}
+
+
+def make_unet(kw):
+    kw = dict(kw)
+    kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+    net = UNet(**kw)
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    return net
+
+
+def gen_unet(name, kw, shape, dist):
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.rand(shape, generator=g) if dist == "uniform" else torch.randn(shape, generator=g)
+    y = (torch.rand((shape[0], 1, *shape[2:]), generator=g) > 0.9).float()
+    net = make_unet(kw).eval()  # eval(): dropout off, instance norm unaffected
+    out = {"x": x.numpy(), "y": y.numpy()}
+    # forward parity target: logits (north_star: within 1e-4 rel)
+    logits, _ = net(x, return_logits=True)
+    out["logits"] = logits.detach().numpy()
+    prob, _ = net(x)
+    out["prob"] = prob.detach().numpy()
+    # training-step arithmetic (segmentation/pl.py:218-222,284-317): dice + focal
+    d = binary_generalized_dice_loss(prob, y, smooth=1e-5, eps=1e-6)
+    f = binary_focal_loss(prob, y, gamma=1.0, eps=1e-6)
+    loss = torch.stack([d.mean(), f.mean()]).mean()
+    out["dice"] = d.detach().numpy()
+    out["focal"] = f.detach().numpy()
+    out["loss"] = loss.detach().numpy()
+    net.zero_grad()
+    loss.backward()
+    sd_keys = [k for k, _ in net.named_parameters()]
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy().copy()
+    # one and two SGD-Nesterov steps as configured at segmentation/pl.py:563-569
+    opt = torch.optim.SGD(net.parameters(), lr=5e-4, momentum=0.99, weight_decay=5e-3,
+                          nesterov=True)
+    opt.step()
+    for k, p in net.named_parameters():
+        out["step1:" + k] = p.detach().numpy().copy()
+    out["param_keys"] = np.array(sd_keys)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "params", sum(p.numel() for p in net.parameters()), "loss", float(loss))
+
+
+def gen_blocks():
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    x = torch.randn((2, 8, 8, 8, 8), generator=g)
+    adn = get_adn_fn(3, "instance", "swish", 0.0)
+    blk = ResidualBlock3d(8, 3, out_channels=8, adn_fn=adn).eval()
+    blk.load_state_dict(fill_state_dict(blk.state_dict()))
+    out["res_x"] = x.numpy()
+    out["res_y"] = blk(x).detach().numpy()
+    blk2 = ResidualBlock3d(8, 3, inter_channels=4, out_channels=6, adn_fn=adn).eval()
+    blk2.load_state_dict(fill_state_dict(blk2.state_dict()))
+    out["res2_y"] = blk2(x).detach().numpy()
+    for act in ["swish", "relu", "gelu", "leaky_relu", "sigmoid", "tanh", "elu"]:
+        m = get_adn_fn(3, "instance", act, 0.0)(8).eval()
+        out["adn_" + act] = m(x).detach().numpy()
+    p = torch.rand((2, 1, 8, 8, 8), generator=g)
+    t = (torch.rand((2, 1, 8, 8, 8), generator=g) > 0.7).float()
+    out["loss_p"], out["loss_t"] = p.numpy(), t.numpy()
+    out["loss_dice"] = binary_generalized_dice_loss(p, t, smooth=1e-5, eps=1e-6).numpy()
+    out["loss_focal"] = binary_focal_loss(p, t, gamma=1.0, eps=1e-6).numpy()
+    out["loss_focal_g2"] = binary_focal_loss(p, t, gamma=2.0, eps=1e-6).numpy()
+    np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
+    print("blocks ok")
+
+
+if __name__ == "__main__":
+    for name, (kw, shape, dist) in UNET_CASES.items():
+        gen_unet(name, kw, shape, dist)
+    gen_blocks()

@@ -1,0 +1,32 @@
+"""Name-keyed deterministic parameter values (TEST INFRASTRUCTURE ONLY).
+
+A parameter's values depend only on its ``state_dict`` key and shape, never on
+module construction order, so the real reference (in oracle/make_golden.py), the
+torch oracle and the HIP product can all be loaded with identical weights
+without shipping them.
+"""
+import zlib
+
+import numpy as np
+
+
+def tensor_for(name, shape, scale=None):
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    shape = tuple(int(s) for s in shape)
+    if scale is None:
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 16
+        scale = 1.0 / np.sqrt(max(fan_in, 1))
+    return rng.uniform(-scale, scale, size=shape).astype(np.float32)
+
+
+def fill_state_dict(sd):
+    """In-place: every floating-point entry of a torch state_dict gets tensor_for(key)."""
+    import torch
+
+    out = {}
+    for k, v in sd.items():
+        if v.is_floating_point() and v.numel() > 0 and "running_" not in k:
+            out[k] = torch.from_numpy(tensor_for(k, v.shape)).to(v.dtype)
+        else:
+            out[k] = v.clone()
+    return out

@@ -1,0 +1,30 @@
+"""Constructor kwargs of the golden U-Net cases (same as oracle/make_golden.py)."""
+UNET_CASES = {
+    "unet3d_cfg2_tiny": dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                             upscale_type="transpose", norm_type="instance", padding=1,
+                             dropout_param=0.15, activation_fn="swish", in_channels=2,
+                             n_classes=2, depth=[4, 4, 8, 16, 32], kernel_sizes=[3] * 5,
+                             strides=[2] * 5),
+    "unet3d_cfg2_small": dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                              upscale_type="transpose", norm_type="instance", padding=1,
+                              dropout_param=0.15, activation_fn="swish", in_channels=2,
+                              n_classes=2, depth=[8, 8, 16], kernel_sizes=[3] * 3,
+                              strides=[2] * 3),
+    "unet3d_identity_links_relu": dict(spatial_dimensions=3, conv_type="regular",
+                                       link_type="identity", upscale_type="transpose",
+                                       norm_type="instance", padding=1, dropout_param=0.0,
+                                       activation_fn="relu", in_channels=1, n_classes=2,
+                                       depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+    "unet3d_conv_links_gelu": dict(spatial_dimensions=3, conv_type="regular", link_type="conv",
+                                   upscale_type="transpose", norm_type="instance", padding=1,
+                                   dropout_param=0.0, activation_fn="gelu", in_channels=3,
+                                   n_classes=2, depth=[8, 16, 32], kernel_sizes=[3] * 3,
+                                   strides=[2] * 3),
+}
+
+
+def oracle_cfg(kw):
+    return dict(depth=kw["depth"], kernel_sizes=kw["kernel_sizes"], strides=kw["strides"],
+                padding=kw["padding"], norm_type=kw["norm_type"], activation=kw["activation_fn"],
+                link_type=kw["link_type"], n_classes=kw["n_classes"],
+                dropout_param=kw["dropout_param"])

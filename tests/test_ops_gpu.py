@@ -198,6 +198,30 @@ def test_instance_norm_act_fwd(cuda, act, C, size):
     np.testing.assert_allclose(_np(out), ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("act", ["swish", "relu", "gelu", "identity"])
+@pytest.mark.parametrize("C,size", [(32, (8, 8, 8)), (2, (9, 7, 5)), (64, (12, 12, 12))])
+def test_instance_norm_act_bwd(cuda, act, C, size):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((2, C, *size)) * 2 + 0.5).astype(np.float32)
+    g = rng.standard_normal(x.shape).astype(np.float32)
+    ref = cops.norm_act_bwd(x, g, True, 1e-5, act)
+    xd, gd = _cl(x, cuda), _cl(g, cuda)
+    mean, rstd = ops.instance_stats(xd, 1e-5)
+    dx, _, _ = ops.norm_act_bwd(xd, gd, mean, rstd, act)
+    assert _relerr(_np(dx), ref) < 5e-5
+
+
+def test_norm_act_bwd_with_dropout_matches_forward_mask(cuda):
+    # d/dx of sum(out * g) by finite structure: with act=identity and no norm,
+    # dx must equal g * mask / (1-p) where mask is the forward's mask.
+    x = torch.ones((1, 32, 8, 8, 8), device=cuda)
+    g = torch.randn((1, 32, 8, 8, 8), device=cuda)
+    xd, gd = ops.ndhwc(x), ops.ndhwc(g)
+    out = ops.norm_act_fwd(xd, None, None, "identity", drop_p=0.3, seed=9, rng_offset=1)
+    dx, _, _ = ops.norm_act_bwd(xd, gd, None, None, "identity", drop_p=0.3, seed=9, rng_offset=1)
+    assert torch.allclose(dx, gd * out, rtol=1e-6, atol=1e-6)
+
+
 def test_dropout_mask_statistics_and_determinism(cuda):
     x = torch.ones((1, 32, 16, 16, 16), device=cuda)
     xd = ops.ndhwc(x)

@@ -1,0 +1,97 @@
+"""Pins the oracle (oracle/torch_ref + oracle/c) against fixtures generated from
+the REAL reference by oracle/make_golden.py. CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cases import UNET_CASES, oracle_cfg
+from oracle import cops
+from oracle.torch_ref.unet import UNetOracle, compound_loss, dice_loss, focal_loss
+from oracle.weights import tensor_for
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+
+
+def oracle_from_golden(g, kw):
+    sd = {}
+    for k in g["param_keys"]:
+        k = str(k)
+        sd[k] = torch.from_numpy(tensor_for(k, g["grad:" + k].shape))
+    return UNetOracle(sd, oracle_cfg(kw))
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_torch_oracle_forward_loss_grads_match_reference(name):
+    g = load(name)
+    net = oracle_from_golden(g, UNET_CASES[name]).requires_grad_(True)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    logits = net.forward(x, return_logits=True)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-5, atol=1e-5)
+    prob = torch.sigmoid(logits)
+    np.testing.assert_allclose(prob.detach().numpy(), g["prob"], rtol=1e-5, atol=1e-6)
+    loss = compound_loss(prob, y)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    loss.backward()
+    for k, p in net.sd.items():
+        ref = g["grad:" + k]
+        tol = 1e-4 * np.abs(ref).max() + 1e-7
+        assert np.abs(p.grad.numpy() - ref).max() <= tol, k
+
+
+@pytest.mark.parametrize("name", ["unet3d_cfg2_small"])
+def test_sgd_nesterov_oracle_matches_reference_step(name):
+    g = load(name)
+    for k in g["param_keys"]:
+        k = str(k)
+        p = tensor_for(k, g["grad:" + k].shape).copy()
+        buf = np.zeros_like(p)
+        cops.sgd_nesterov(p, np.ascontiguousarray(g["grad:" + k]), buf, lr=5e-4, momentum=0.99,
+                          wd=5e-3, nesterov=True, first=True)
+        np.testing.assert_allclose(p, g["step1:" + k], rtol=1e-6, atol=1e-7)
+
+
+def test_c_oracle_adn_and_losses_match_reference():
+    g = load("blocks")
+    x = g["res_x"]
+    for act in ["swish", "relu", "gelu", "sigmoid", "tanh", "elu", "leaky_relu"]:
+        p = 1.0 if act == "elu" else (0.01 if act == "leaky_relu" else 0.0)
+        got = cops.norm_act(x, True, 1e-5, act, p)
+        np.testing.assert_allclose(got, g["adn_" + act], rtol=1e-5, atol=1e-5)
+    d, f = cops.dice_focal(g["loss_p"], g["loss_t"], 1e-5, 1e-6, 1.0, 1e-6)
+    np.testing.assert_allclose(d, g["loss_dice"], rtol=1e-5)
+    np.testing.assert_allclose(f, g["loss_focal"].reshape(-1), rtol=1e-5)
+    _, f2 = cops.dice_focal(g["loss_p"], g["loss_t"], 1e-5, 1e-6, 2.0, 1e-6)
+    np.testing.assert_allclose(f2, g["loss_focal_g2"].reshape(-1), rtol=1e-5)
+    p, t = torch.from_numpy(g["loss_p"]), torch.from_numpy(g["loss_t"])
+    np.testing.assert_allclose(dice_loss(p, t).numpy(), g["loss_dice"], rtol=1e-5)
+    np.testing.assert_allclose(focal_loss(p, t).numpy(), g["loss_focal"], rtol=1e-5)
+
+
+def test_c_oracle_dice_focal_gradient_matches_autograd():
+    g = load("blocks")
+    p = torch.from_numpy(g["loss_p"]).clone().requires_grad_(True)
+    t = torch.from_numpy(g["loss_t"])
+    loss = compound_loss(p, t)
+    loss.backward()
+    B = p.shape[0]
+    _, _, dp = cops.dice_focal(g["loss_p"], g["loss_t"], grad=True, gscale_dice=0.5 / B,
+                               gscale_focal=0.5 / B)
+    np.testing.assert_allclose(dp, p.grad.numpy(), rtol=2e-4, atol=1e-9)
+
+
+def test_c_oracle_residual_block_matches_reference():
+    """ResidualBlock3d (res_blocks.py:150-200) composed from the C ops."""
+    g = load("blocks")
+    x = g["res_x"]
+    w = lambda k, s: tensor_for(k, s)  # noqa: E731
+    h = cops.conv3d(x, w("op.0.weight", (8, 8, 3, 3, 3)), w("op.0.bias", (8,)), 1, 1)
+    h = cops.norm_act(h, True, 1e-5, "swish")
+    h = cops.conv3d(h, w("op.2.weight", (8, 8, 3, 3, 3)), w("op.2.bias", (8,)), 1, 1)
+    out = cops.norm_act(h + x, True, 1e-5, "swish")
+    np.testing.assert_allclose(out, g["res_y"], rtol=1e-4, atol=1e-5)

@@ -1,0 +1,67 @@
+"""CPU-side conformance of the module mirror: constructor surface, module tree and
+state_dict keys equal the reference's (keys recorded in the golden fixtures)."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from adell_mri_amd._lib import AdellHipError
+from adell_mri_amd.modules.activations import activation_factory
+from adell_mri_amd.modules.segmentation.unet import UNet
+from cases import UNET_CASES
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build(kw):
+    kw = dict(kw)
+    kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+    return UNet(**kw)
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_state_dict_keys_and_shapes_equal_reference(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(UNET_CASES[name])
+    sd = net.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["param_keys"]]
+    for k, v in sd.items():
+        assert tuple(v.shape) == g["grad:" + k].shape, k
+
+
+def test_constructor_signature_is_the_reference_one():
+    # adell_mri/modules/segmentation/unet.py:43-68
+    expected = ["self", "spatial_dimensions", "encoding_operations", "conv_type", "link_type",
+                "upscale_type", "interpolation", "norm_type", "dropout_type", "padding",
+                "dropout_param", "activation_fn", "in_channels", "n_classes", "depth",
+                "kernel_sizes", "strides", "bottleneck_classification", "skip_conditioning",
+                "feature_conditioning", "feature_conditioning_params", "deep_supervision",
+                "parent_class", "encoder_only"]
+    sig = inspect.signature(UNet.__init__)
+    assert list(sig.parameters) == expected
+    assert sig.parameters["norm_type"].default == "batch"
+    assert sig.parameters["activation_fn"].default is torch.nn.PReLU
+    assert sig.parameters["depth"].default == [16, 32, 64]
+
+
+def test_config2_parameter_count():
+    # 8 264 303 parameters, 80 state_dict entries
+    net = UNet(spatial_dimensions=3, conv_type="regular", link_type="residual",
+               upscale_type="transpose", norm_type="instance", padding=1, dropout_param=0.15,
+               activation_fn=torch.nn.SiLU, in_channels=2, n_classes=2,
+               depth=[32, 32, 64, 128, 256], kernel_sizes=[3] * 5, strides=[2] * 5)
+    assert sum(p.numel() for p in net.parameters()) == 8264303
+    assert len(net.state_dict()) == 80
+
+
+def test_no_cpu_fallback():
+    net = build(UNET_CASES["unet3d_cfg2_small"])
+    with pytest.raises(AdellHipError):
+        net(torch.zeros(1, 2, 16, 16, 16))
+
+
+def test_parent_class_builds_nothing():
+    net = UNet(parent_class=True)
+    assert len(list(net.parameters())) == 0

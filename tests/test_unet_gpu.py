@@ -1,0 +1,74 @@
+"""Model-level parity of the HIP U-Net with the reference (golden fixtures made
+by oracle/make_golden.py from the real adell_mri code). north_star tolerance:
+logits within 1e-4 relative of the reference PyTorch-CPU forward."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from adell_mri_amd.modules.activations import activation_factory
+from adell_mri_amd.modules.segmentation.unet import UNet
+from cases import UNET_CASES
+from oracle.torch_ref.unet import compound_loss
+from oracle.weights import tensor_for
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def build(kw, device):
+    kw = dict(kw)
+    kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+    net = UNet(**kw)
+    sd = {k: torch.from_numpy(tensor_for(k, v.shape)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    return net.to(device)
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_logits_within_1e4_of_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(UNET_CASES[name], cuda).eval()
+    x = torch.from_numpy(g["x"]).to(cuda)
+    with torch.no_grad():
+        logits, bn = net(x, return_logits=True)
+        prob, _ = net(x)
+    assert bn is None
+    ref = g["logits"]
+    got = logits.cpu().numpy()
+    assert got.shape == ref.shape
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    assert rel < 1e-4, rel
+    np.testing.assert_allclose(prob.cpu().numpy(), g["prob"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(UNET_CASES))
+def test_parameter_gradients_match_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(UNET_CASES[name], cuda).eval()  # eval: dropout off, as in the fixture
+    x = torch.from_numpy(g["x"]).to(cuda)
+    y = torch.from_numpy(g["y"]).to(cuda)
+    prob, _ = net(x)
+    loss = compound_loss(prob, y)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = g["grad:" + k]
+        assert p.grad is not None, k
+        err = np.abs(p.grad.cpu().numpy() - ref).max() / (np.abs(ref).max() + 1e-6)
+        worst = max(worst, err)
+        assert err < 2e-3, (k, err)
+    print("worst relative grad error", worst)
+
+
+def test_train_mode_dropout_runs_and_is_seeded(cuda):
+    net = build(UNET_CASES["unet3d_cfg2_small"], cuda).train()
+    x = torch.rand(2, 2, 16, 16, 16, device=cuda)
+    torch.manual_seed(3)
+    a, _ = net(x, return_logits=True)
+    b, _ = net(x, return_logits=True)
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
+    a.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
