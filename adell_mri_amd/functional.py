@@ -17,33 +17,43 @@ import torch
 
 from . import ops
 
-_PACK_CACHE = {}
 _dropout_counter = itertools.count(1)
 
 
+class _Ref:
+    """Opaque holder so a Parameter object can ride through autograd.Function.apply."""
+
+    __slots__ = ("obj",)
+
+    def __init__(self, obj):
+        self.obj = obj
+
+
 def _packed(w, mode):
-    """Repacked copy of a weight, cached until the parameter is modified in place."""
-    key = (w.data_ptr(), mode)
-    ver = w._version
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver and hit[1].device == w.device and hit[2] == tuple(w.shape):
+    """Repacked copy of a weight. The cache lives ON the tensor object (so it dies
+    with it) and is valid only for the same storage address and version counter."""
+    cache = getattr(w, "_adell_packs", None)
+    if cache is None:
+        cache = {}
+        w._adell_packs = cache
+    hit = cache.get(mode)
+    tag = (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)
+    if hit is not None and hit[0] == tag:
         return hit[1]
     p = ops.pack_weight(w.detach(), mode)
-    if len(_PACK_CACHE) > 4096:
-        _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (ver, p, tuple(w.shape))
+    cache[mode] = (tag, p)
     return p
 
 
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, residual, stride, padding, want_stats):
+    def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
+        stride, padding, want_stats, wref = conf
         k = tuple(weight.shape[2:])
-        wp = _packed(weight, 0)
         y, part = ops.conv3d_fwd(x0, wp, bias, weight.shape[0], k, stride, padding, x1=x1,
                                  residual=residual, want_stats=want_stats)
         ctx.save_for_backward(x0, x1, weight)
-        ctx.conf = (k, stride, padding, bias is not None, residual is not None)
+        ctx.conf = (k, stride, padding, bias is not None, residual is not None, wref)
         if part is None:
             part = y.new_empty(0)
         ctx.mark_non_differentiable(part)
@@ -52,15 +62,15 @@ class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpart):
         x0, x1, weight = ctx.saved_tensors
-        k, stride, padding, has_bias, has_res = ctx.conf
+        k, stride, padding, has_bias, has_res, wref = ctx.conf
         need = ctx.needs_input_grad
         dy = ops.ndhwc(dy)
         dx0 = dx1 = dw = db = dres = None
         C0 = x0.shape[1]
         C1 = 0 if x1 is None else x1.shape[1]
         if need[0] or (x1 is not None and need[1]):
-            dx0, dx1 = ops.conv3d_bwd_data(dy, _packed(weight, 1), tuple(x0.shape[2:]), C0, C1, k,
-                                           stride, padding)
+            dx0, dx1 = ops.conv3d_bwd_data(dy, _packed(wref.obj, 1), tuple(x0.shape[2:]), C0, C1,
+                                           k, stride, padding)
             if not need[0]:
                 dx0 = None
             if x1 is None or not need[1]:
@@ -71,13 +81,14 @@ class _Conv3dFn(torch.autograd.Function):
             db = ops.bias_grad(dy)
         if has_res and need[4]:
             dres = dy
-        return dx0, dx1, dw, db, dres, None, None, None
+        return dx0, dx1, dw, db, dres, None, None
 
 
 def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True):
     """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual)."""
     stride, padding = ops._triple(stride), ops._triple(padding)
-    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual, stride, padding, want_stats)
+    conf = (stride, padding, want_stats, _Ref(weight))
+    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual, _packed(weight, 0), conf)
     if want_stats and part.numel() > 0:
         y._adell_partials = part
     return y
@@ -85,10 +96,11 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
 
 class _ConvT3dK2S2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        y = ops.convtranspose3d_k2s2_fwd(x, _packed(weight, 2), bias, weight.shape[1])
+    def forward(ctx, x, weight, bias, wp, wref):
+        y = ops.convtranspose3d_k2s2_fwd(x, wp, bias, weight.shape[1])
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.wref = wref
         return y
 
     @staticmethod
@@ -98,16 +110,16 @@ class _ConvT3dK2S2Fn(torch.autograd.Function):
         dy = ops.ndhwc(dy)
         dx = dw = db = None
         if need[0]:
-            dx = ops.convtranspose3d_k2s2_bwd_data(dy, _packed(weight, 3), weight.shape[0])
+            dx = ops.convtranspose3d_k2s2_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0])
         if need[1]:
             dw = ops.convtranspose3d_k2s2_bwd_weight(x, dy)
         if ctx.has_bias and need[2]:
             db = ops.bias_grad(dy)
-        return dx, dw, db
+        return dx, dw, db, None, None
 
 
 def conv_transpose3d_k2s2(x, weight, bias=None):
-    return _ConvT3dK2S2Fn.apply(x, weight, bias)
+    return _ConvT3dK2S2Fn.apply(x, weight, bias, _packed(weight, 2), _Ref(weight))
 
 
 class _NormDropActFn(torch.autograd.Function):

@@ -1,0 +1,168 @@
+"""Training-step wrappers (mirror of adell_mri/modules/segmentation/pl.py:197-763).
+
+The reference wraps its networks as ``class UNetPL(UNet, UNetBasePL)`` with
+``UNetBasePL(pl.LightningModule)``. Lightning is optional here: when it is
+importable the base is a LightningModule (so ``Trainer.fit`` works unchanged);
+otherwise the same methods live on a plain ``torch.nn.Module`` and
+``adell_mri_amd.trainer.fit_steps`` drives them. What is kept: method names and
+arithmetic of ``step`` / ``training_step`` / ``calculate_loss`` /
+``configure_optimizers`` (pl.py:218-222, 284-317, 382-421, 529-595) and the
+``UNetPL`` constructor (pl.py:680-700). The optimiser is the fused flat-buffer
+HIP one (``adell_mri_amd.optim``) instead of ``torch.optim``.
+"""
+from typing import Callable
+
+import torch
+import torch.nn.functional as F
+
+from ...optim import FusedAdamW, FusedSGD
+from ..learning_rate import CosineAnnealingWithWarmupLR
+from .unet import UNet
+
+try:  # pragma: no cover - lightning is not installed in the build image
+    import lightning.pytorch as pl
+
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    _Base = torch.nn.Module
+
+
+def get_optimizer(name: str, parameters, **kwargs):
+    """Mirror of adell_mri/utils/optimizer_factory.py:17-30 for the fused optimisers."""
+    name = str(name).lower()
+    if name == "sgd":
+        return FusedSGD(parameters, **kwargs)
+    if name == "adamw":
+        return FusedAdamW(parameters, **kwargs)
+    raise NotImplementedError(f"optimizer {name!r} has no fused HIP implementation yet")
+
+
+class UNetBasePL(_Base):
+    def __init__(self):
+        super().__init__()
+        self.train_batch_size = None
+        self.raise_nan_loss = False
+        self.make_uniform = False
+        self.bottleneck_classification = False
+        self.feature_conditioning_key = None
+        self.skip_conditioning_key = None
+
+    if _Base is torch.nn.Module:
+        current_epoch = 0
+
+        def log(self, *args, **kwargs):  # Lightning's logger hook: nothing to do without it
+            return None
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+    def calculate_loss(self, prediction, y):
+        loss = self.loss_fn(prediction, y)
+        if isinstance(loss, list):
+            loss = torch.stack([loss_value.mean() for loss_value in loss])
+        return loss
+
+    def step(self, x, y, y_class, x_cond, x_fc):
+        y = torch.round(y)
+        output = self.forward(X=x, X_skip_layer=x_cond, X_feature_conditioning=x_fc)
+        if self.deep_supervision is False:
+            prediction, pred_class = output
+            deep_outputs = None
+        else:
+            prediction, pred_class, deep_outputs = output
+        loss = self.calculate_loss(prediction, y)
+        if self.deep_supervision is True:
+            t = len(deep_outputs)
+            interp = {3: "linear", 4: "bilinear", 5: "trilinear"}[len(y.shape)]
+            additional = torch.zeros_like(loss)
+            for i, o in enumerate(deep_outputs):
+                S = o.shape[-self.spatial_dimensions:]
+                y_small = (F.interpolate(y, S, mode=interp, align_corners=True) > 0).float()
+                additional = additional + self.calculate_loss(o, y_small).mean() / (2 ** (t - i)) / (t + 1)
+            loss = loss + additional
+        class_loss = None
+        if self.bottleneck_classification is True:
+            class_loss = self.loss_fn_class(pred_class, y_class.type_as(pred_class)).mean()
+        return prediction, pred_class, loss, class_loss
+
+    def unpack_batch(self, batch):
+        x, y = batch[self.image_key], batch[self.label_key]
+        x_cond = batch[self.skip_conditioning_key] if self.skip_conditioning_key is not None else None
+        y_class = y.flatten(start_dim=1).max(1).values if self.bottleneck_classification else None
+        x_fc = batch[self.feature_conditioning_key] if self.feature_conditioning_key is not None else None
+        return x, x_cond, x_fc, y, y_class
+
+    def log_loss(self, key, loss, **kwargs):
+        for i in range(loss.nelement()):
+            self.log(f"{key}_{i}", loss[i], sync_dist=True, prog_bar=True, **kwargs)
+        self.log(key, loss.mean(), sync_dist=True, prog_bar=True, **kwargs)
+
+    def training_step(self, batch, batch_idx):
+        x, x_cond, x_fc, y, y_class = self.unpack_batch(batch)
+        pred_final, pred_class, loss, class_loss = self.step(x, y, y_class, x_cond, x_fc)
+        if _Base is not torch.nn.Module:
+            self.log_loss("train_loss", loss, batch_size=y.shape[0])
+        self.train_batch_size = x.shape[0]
+        return loss.mean() if class_loss is None else loss.mean() + class_loss
+
+    def configure_optimizers(self) -> dict:
+        encoder_params, rest_of_params = [], []
+        for k, p in self.named_parameters():
+            (encoder_params if ("encoding" in k or "encoder" in k) else rest_of_params).append(p)
+        if self.lr_encoder is None:
+            parameters = encoder_params + rest_of_params
+        else:
+            parameters = [{"params": encoder_params, "lr": self.lr_encoder},
+                          {"params": rest_of_params}]
+        opt_str = getattr(self, "optimizer_str", "sgd")
+        if opt_str == "sgd":
+            optimizer_params = {"momentum": 0.99, "nesterov": True}
+        else:
+            optimizer_params = {"eps": self.optimizer_eps}
+        optimizer = get_optimizer(opt_str, parameters, lr=self.learning_rate,
+                                  weight_decay=self.weight_decay, **optimizer_params)
+        self.cosine_decay = any([
+            isinstance(self.start_decay, float) and (self.start_decay < 1.0),
+            isinstance(self.start_decay, int) and (self.start_decay < self.n_epochs),
+            self.warmup_steps > 0,
+        ])
+        if self.cosine_decay:
+            sched = CosineAnnealingWithWarmupLR(optimizer, T_max=self.n_epochs,
+                                                start_decay=self.start_decay,
+                                                n_warmup_steps=self.warmup_steps)
+            sched.last_epoch = self.current_epoch
+            return {"optimizer": optimizer, "lr_scheduler": sched, "monitor": "val_loss"}
+        return {"optimizer": optimizer, "monitor": "val_loss"}
+
+
+class UNetPL(UNet, UNetBasePL):
+    """Standard U-Net training wrapper (pl.py:673-763)."""
+
+    def __init__(self, image_key: str = "image", label_key: str = "label",
+                 skip_conditioning_key: str = None, feature_conditioning_key: str = None,
+                 optimizer_str: str = "sgd", optimizer_eps: float = 1e-8,
+                 learning_rate: float = 0.001, lr_encoder: float = None,
+                 start_decay: float = 1.0, warmup_steps: int = 0, batch_size: int = 4,
+                 n_epochs: int = 100, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None,
+                 loss_fn: Callable = F.binary_cross_entropy, picai_eval: bool = False,
+                 *args, **kwargs) -> torch.nn.Module:
+        super().__init__(*args, **kwargs)
+        self.image_key = image_key
+        self.label_key = label_key
+        self.skip_conditioning_key = skip_conditioning_key
+        self.feature_conditioning_key = feature_conditioning_key
+        self.optimizer_str = optimizer_str
+        self.optimizer_eps = optimizer_eps
+        self.learning_rate = learning_rate
+        self.lr_encoder = lr_encoder
+        self.start_decay = start_decay
+        self.warmup_steps = warmup_steps
+        self.batch_size = batch_size
+        self.n_epochs = n_epochs
+        self.weight_decay = weight_decay
+        self.training_dataloader_call = training_dataloader_call
+        self.loss_fn = loss_fn
+        self.picai_eval = picai_eval
+        self.loss_fn_class = torch.nn.BCEWithLogitsLoss()

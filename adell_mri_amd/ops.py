@@ -13,6 +13,68 @@ from . import _lib
 from ._lib import ACT_IDS, ConvDesc, NormActDesc, check
 
 
+class KernelTimer:
+    """Per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg).
+
+    Events are recorded on ``torch.cuda.current_stream()``, the stream the kernels
+    are enqueued on; nothing synchronises until ``summary()`` is read.
+    """
+
+    def __init__(self):
+        self.records = []
+        self._agg = None
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, flops, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((name, float(flops), e0, e1))
+
+    def summary(self):
+        if self._agg is None:
+            torch.cuda.synchronize()
+            agg = {}
+            for name, flops, e0, e1 in self.records:
+                a = agg.setdefault(name, [0.0, 0.0, 0])
+                a[0] += flops
+                a[1] += e0.elapsed_time(e1)
+                a[2] += 1
+            self._agg = {k: {"flops": v[0], "ms": v[1], "launches": v[2],
+                             "tflops": v[0] / max(v[1], 1e-9) / 1e9} for k, v in agg.items()}
+        return self._agg
+
+    def dominant(self):
+        s = self.summary()
+        if not s:
+            return None
+        name = max(s, key=lambda k: s[k]["ms"])
+        return name, s[name]["flops"], s[name]["ms"], s[name]["launches"]
+
+    def share(self, name, total_ms):
+        return self.summary()[name]["ms"] / max(total_ms, 1e-9)
+
+
+KERNEL_TIMER = None
+
+
+def _timed(name, flops, fn):
+    t = KERNEL_TIMER
+    if t is None:
+        return fn()
+    e0 = t.start()
+    rc = fn()
+    t.stop(name, flops, e0)
+    return rc
+
+
+def _conv_flops(d):
+    return 2.0 * d.N * d.Do * d.Ho * d.Wo * d.Cout * (d.C0 + d.C1) * d.KD * d.KH * d.KW
+
+
 def _triple(v):
     if isinstance(v, (int,)):
         return (int(v),) * 3
@@ -96,9 +158,9 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
         if nt < 0:
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
-    check(_lib.lib().adell_conv3d_fwd(ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed),
-                                      _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
-                                      _stream()))
+    check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
+        ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y),
+        _ptr(part), _stream())))
     return y, part
 
 
@@ -110,8 +172,8 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding):
     assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
     dx0 = new_act(N, C0, *in_size, dy.device)
     dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
-    check(_lib.lib().adell_conv3d_bwd_data(ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd),
-                                           _ptr(dx0), _ptr(dx1), _stream()))
+    check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_bwd_data(
+        ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd), _ptr(dx0), _ptr(dx1), _stream())))
     return dx0, dx1
 
 
@@ -137,8 +199,9 @@ def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None):
         check(int(nbytes))
     ws = _workspace(nbytes, x0.device)
     dw = torch.empty((Cout, C0 + C1, *k), device=x0.device, dtype=torch.float32)
-    check(_lib.lib().adell_conv3d_bwd_weight(ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy),
-                                             _ptr(dw), _ptr(ws), ws.numel() * 4, _stream()))
+    check(_timed("adell_conv_wgrad_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_bwd_weight(
+        ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
+        _stream())))
     return dw
 
 
@@ -166,8 +229,9 @@ def convtranspose3d_k2s2_bwd_weight(x, dy):
         check(int(nbytes))
     ws = _workspace(nbytes, x.device)
     dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
-    check(_lib.lib().adell_convtranspose3d_k2s2_bwd_weight(
-        N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, _stream()))
+    flops = 2.0 * N * D * H * W * Cin * Cout * 8
+    check(_timed("adell_conv_wgrad_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_k2s2_bwd_weight(
+        N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, _stream())))
     return dw
 
 
@@ -176,9 +240,9 @@ def convtranspose3d_k2s2_fwd(x, w_packed, bias, Cout):
     x = ndhwc(x)
     N, Cin, D, H, W = x.shape
     y = new_act(N, Cout, 2 * D, 2 * H, 2 * W, x.device)
-    check(_lib.lib().adell_convtranspose3d_k2s2_fwd(N, D, H, W, Cin, Cout, _ptr(x),
-                                                    _ptr(w_packed), _ptr(bias), _ptr(y),
-                                                    _stream()))
+    flops = 2.0 * N * D * H * W * Cin * Cout * 8
+    check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_k2s2_fwd(
+        N, D, H, W, Cin, Cout, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), _stream())))
     return y
 
 
@@ -188,9 +252,9 @@ def convtranspose3d_k2s2_bwd_data(dy, w_packed_bwd, Cin):
     N, Cout, D2, H2, W2 = dy.shape
     D, H, W = D2 // 2, H2 // 2, W2 // 2
     dx = new_act(N, Cin, D, H, W, dy.device)
-    check(_lib.lib().adell_convtranspose3d_k2s2_bwd_data(N, D, H, W, Cin, Cout, _ptr(dy),
-                                                         _ptr(w_packed_bwd), _ptr(dx),
-                                                         _stream()))
+    flops = 2.0 * N * D * H * W * Cin * Cout * 8
+    check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_k2s2_bwd_data(
+        N, D, H, W, Cin, Cout, _ptr(dy), _ptr(w_packed_bwd), _ptr(dx), _stream())))
     return dx
 
 
@@ -266,3 +330,64 @@ def norm_act_bwd(x, dout, mean, rstd, act, gamma=None, beta=None, act_w=None, ac
         _ptr(act_w), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
         0 if ws is None else ws.numel() * 4, _stream()))
     return dx, dgamma, dbeta
+
+
+def dice_focal_fwd(prob, target, smooth, dice_eps, gamma, focal_eps):
+    """Per-item (dice[B], focal[B]) and the sums the backward needs. prob/target: [B, ...]."""
+    _require_cuda(prob, target)
+    prob, target = prob.contiguous(), target.contiguous()
+    B = prob.shape[0]
+    S = prob.numel() // B
+    assert target.numel() == prob.numel()
+    ws = _workspace(_lib.lib().adell_dice_focal_workspace(B, S), prob.device)
+    dice = torch.empty((B,), device=prob.device, dtype=torch.float32)
+    focal = torch.empty_like(dice)
+    sums = torch.empty((B, 3), device=prob.device, dtype=torch.float32)
+    check(_lib.lib().adell_dice_focal_fwd(_ptr(prob), _ptr(target), B, S, smooth, dice_eps, gamma,
+                                          focal_eps, _ptr(dice), _ptr(focal), _ptr(sums),
+                                          _ptr(ws), ws.numel() * 4, _stream()))
+    return dice, focal, sums
+
+
+def dice_focal_bwd(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice, gfocal):
+    prob, target = prob.contiguous(), target.contiguous()
+    B = prob.shape[0]
+    S = prob.numel() // B
+    dprob = torch.empty_like(prob)
+    check(_lib.lib().adell_dice_focal_bwd(_ptr(prob), _ptr(target), B, S, smooth, dice_eps, gamma,
+                                          focal_eps, _ptr(sums), float(gdice), float(gfocal),
+                                          _ptr(dprob), _stream()))
+    return dprob
+
+
+# Bumped whenever a HIP kernel rewrites parameters in place (torch's version
+# counters do not see those writes); functional._packed keys its cache on it.
+WEIGHT_EPOCH = 0
+
+
+def _weights_changed():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def sgd_step(param, grad, buf, lr, momentum, weight_decay, nesterov, first, grad_scale=1.0):
+    _require_cuda(param, grad, buf)
+    check(_lib.lib().adell_sgd_step(_ptr(param), _ptr(grad), _ptr(buf), param.numel(), lr,
+                                    momentum, weight_decay, int(nesterov), int(first),
+                                    grad_scale, _stream()))
+    _weights_changed()
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
+               grad_scale=1.0):
+    _require_cuda(param, grad, exp_avg, exp_avg_sq)
+    check(_lib.lib().adell_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                      param.numel(), lr, beta1, beta2, eps, weight_decay,
+                                      int(step), grad_scale, _stream()))
+    _weights_changed()
+
+
+def ema_update(shadow, param, decay):
+    _require_cuda(shadow, param)
+    check(_lib.lib().adell_ema_update(_ptr(shadow), _ptr(param), shadow.numel(), decay, _stream()))
+    _weights_changed()

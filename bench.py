@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Headline benchmark: training volumes/s of the 3-D U-Net of BASELINE config 2
+(sample_configs/u-net-3d-resnet.yaml: regular-conv encoder, residual links,
+instance norm, swish, transposed-conv decoder) on synthetic 2-channel 128^3
+volumes; one step = forward + dice/focal loss + backward + SGD-Nesterov step.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job
+volumes/s, plus `roofline` for the dominant kernel (per-launch HIP-event timing
+inside the timed region) and `cpu_baseline` (the torch-CPU oracle on a bounded
+sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CFG2 = dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+            upscale_type="transpose", norm_type="instance", interpolation="bilinear", padding=1,
+            dropout_param=0.15, in_channels=2, n_classes=2, depth=[32, 32, 64, 128, 256],
+            kernel_sizes=[3] * 5, strides=[2] * 5)
+LOSS = dict(smooth=1e-5, dice_eps=1e-6, gamma=1.0, focal_eps=1e-6)
+LR, WD = 5e-4, 5e-3
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def build_module(device, size):
+    from adell_mri_amd.modules.activations import activation_factory
+    from adell_mri_amd.modules.segmentation.losses import (CompoundLoss, binary_focal_loss,
+                                                           binary_generalized_dice_loss)
+    from adell_mri_amd.modules.segmentation.pl import UNetPL
+
+    loss = CompoundLoss([
+        (binary_generalized_dice_loss, {"smooth": LOSS["smooth"], "eps": LOSS["dice_eps"]}),
+        (binary_focal_loss, {"gamma": LOSS["gamma"], "eps": LOSS["focal_eps"]}),
+    ])
+    torch.manual_seed(0)
+    net = UNetPL(image_key="image", label_key="mask", optimizer_str="sgd", learning_rate=LR,
+                 weight_decay=WD, batch_size=1, n_epochs=100, loss_fn=loss,
+                 activation_fn=activation_factory["swish"], **CFG2)
+    return net.to(device)
+
+
+def synthetic_batch(batch, size, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand((batch, 2, size, size, size), generator=g)
+    y = (torch.rand((batch, 1, size, size, size), generator=g) > 0.9).float()
+    return {"image": x.to(device), "mask": y.to(device)}
+
+
+def cpu_baseline(size, threads):
+    """One training step of the stock-torch CPU oracle (oracle/torch_ref) at size^3."""
+    from oracle.torch_ref.unet import UNetOracle, compound_loss
+    from oracle.weights import tensor_for
+    from adell_mri_amd.modules.segmentation.unet import UNet
+
+    torch.set_num_threads(threads)
+    keys = {k: tuple(v.shape) for k, v in
+            UNet(activation_fn=torch.nn.SiLU, **CFG2).state_dict().items()}
+    sd = {k: torch.from_numpy(tensor_for(k, s)) for k, s in keys.items()}
+    cfg = dict(depth=CFG2["depth"], kernel_sizes=CFG2["kernel_sizes"], strides=CFG2["strides"],
+               padding=1, norm_type="instance", activation="swish", link_type="residual",
+               n_classes=2, dropout_param=CFG2["dropout_param"])
+    net = UNetOracle(sd, cfg).requires_grad_(True)
+    net.training = True
+    opt = torch.optim.SGD(net.parameters(), lr=LR, momentum=0.99, weight_decay=WD, nesterov=True)
+    b = synthetic_batch(1, size, "cpu", 42)
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    prob = net.forward(b["image"], return_logits=False)
+    loss = compound_loss(prob, b["mask"])
+    loss.backward()
+    opt.step()
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=64)
+    args = ap.parse_args()
+
+    from adell_mri_amd import ops
+    from adell_mri_amd.parallel import GradSync, init_distributed, reduce_max
+    from adell_mri_amd.trainer import StepRunner
+
+    rank, world, local_rank = init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    net = build_module(device, args.size)
+    net.train()
+    opt = net.configure_optimizers()["optimizer"]
+    runner = StepRunner(net, opt, GradSync(opt))
+    batch = synthetic_batch(args.batch, args.size, device, 42 + rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.train_step(batch)
+    barrier()
+    ops.KERNEL_TIMER = ops.KernelTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = runner.train_step(batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    dt = reduce_max(dt, device)
+    loss_value = float(loss.detach().cpu())
+
+    if rank != 0:
+        return
+    vols = args.batch * world * args.steps
+    out = {
+        "metric": "volumes/sec 3D U-Net 128^3 2-ch seg (train step: fwd+loss+bwd+SGD)",
+        "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{args.size}^3, "
+                               f"batch {args.batch}/GPU, dice+focal, SGD-Nesterov",
+                   "per_gpu_batch": args.batch, "size": args.size, "parallelism": f"dp{world}"},
+        "final_loss": loss_value,
+    }
+    dom = timer.dominant()
+    if dom is not None:
+        name, flops, ms, launches = dom
+        achieved = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved,
+                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "launches": launches, "avg_launch_ms": ms / launches,
+                           "kernel_time_share": timer.share(name, 1e3 * dt),
+                           "all_kernels": timer.summary()}
+    if world == 1 and not args.no_cpu_baseline:
+        threads = max(1, min(os.cpu_count() or 1, 16))
+        t = cpu_baseline(args.cpu_size, threads)
+        scale = (args.cpu_size / args.size) ** 3
+        out["cpu_baseline"] = {
+            "value": scale / t, "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"1 training step of the stock-torch CPU oracle on one 2x{args.cpu_size}^3 "
+                      f"volume ({t:.2f} s), scaled by voxel count to {args.size}^3"}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,42 @@ int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x, const float
                        float* dbeta, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* ------------------------------------------------------------------------
+ * Segmentation loss: binary generalised dice + binary focal on probabilities
+ * (losses.py:14-54,251-292 with weight=1, scale=1; losses.py:112-164 with
+ * alpha=1, threshold=0.5, scale=1, no label smoothing), the CompoundLoss of
+ * sample_configs/u-net-3d-resnet.yaml evaluated at segmentation/pl.py:218-222.
+ * prob/target are [B][S]; dice/focal are the per-item losses; sums [B][3] is
+ * scratch kept for the backward.
+ * ---------------------------------------------------------------------- */
+long adell_dice_focal_workspace(int B, long S);
+int adell_dice_focal_fwd(const float* prob, const float* target, int B, long S,
+                         float smooth, float dice_eps, float gamma, float focal_eps,
+                         float* dice, float* focal, float* sums, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* dprob = gdice * d(dice_b)/dprob + gfocal * d(focal_b)/dprob */
+int adell_dice_focal_bwd(const float* prob, const float* target, int B, long S,
+                         float smooth, float dice_eps, float gamma, float focal_eps,
+                         const float* sums, float gdice, float gfocal, float* dprob,
+                         void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optimiser / EMA updates over flat fp32 buffers (16-byte aligned).
+ * adell_sgd_step: torch.optim.SGD(momentum, nesterov, weight_decay), the
+ *   default optimiser of UNetBasePL.configure_optimizers (segmentation/pl.py:563-569);
+ * adell_adamw_step: torch.optim.AdamW (self_supervised/pl.py:245-250);
+ * adell_ema_update: ExponentialMovingAverage.update (utils/utils.py:447-493).
+ * grad_scale multiplies the gradient first (1/world_size after a sum
+ * all-reduce, 1/accumulate_grad_batches).
+ * ---------------------------------------------------------------------- */
+int adell_sgd_step(float* param, const float* grad, float* momentum_buf, long n, float lr,
+                   float momentum, float weight_decay, int nesterov, int first_step,
+                   float grad_scale, void* stream);
+int adell_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     long n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, long step, float grad_scale, void* stream);
+int adell_ema_update(float* shadow, const float* param, long n, float decay, void* stream);
+
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
 
