@@ -83,6 +83,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (or `make -C adell_mri_amd/csrc`). adell_mri_amd has no fallback path."
             )
+        # torch ships its own libamdhip64; it must be the HIP runtime already loaded when
+        # libadellhip.so is resolved, or the process ends up with two runtimes (and this
+        # library with one that sees no device and none of torch's allocations).
+        import torch  # noqa: F401
+
         h = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)

@@ -1,4 +1,5 @@
 """Constructor kwargs of the golden U-Net cases (same as oracle/make_golden.py)."""
+import numpy as np
 UNET_CASES = {
     "unet3d_cfg2_tiny": dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
                              upscale_type="transpose", norm_type="instance", padding=1,
@@ -28,3 +29,14 @@ def oracle_cfg(kw):
                 padding=kw["padding"], norm_type=kw["norm_type"], activation=kw["activation_fn"],
                 link_type=kw["link_type"], n_classes=kw["n_classes"],
                 dropout_param=kw["dropout_param"])
+
+
+def grad_rel_err(g, k, got):
+    """Relative error of a parameter gradient. Biases that feed a normalisation have a
+    mathematically zero gradient (the reference's value is rounding noise), so the
+    scale is floored by 1% of the sibling weight's gradient magnitude."""
+    ref = g["grad:" + k]
+    scale = np.abs(ref).max()
+    if k.endswith(".bias") and ("grad:" + k[:-5] + ".weight") in g.files:
+        scale = max(scale, 1e-2 * np.abs(g["grad:" + k[:-5] + ".weight"]).max())
+    return float(np.abs(got - ref).max() / (scale + 1e-12))
