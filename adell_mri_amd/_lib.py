@@ -51,14 +51,15 @@ SIGNATURES = {
     "adell_conv3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "adell_conv3d_bwd_data": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "adell_conv3d_bwd_weight_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv3d_bwd_weight": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_conv3d_bwd_weight": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_bias_grad_workspace": (_l, [_l, _i]),
     "adell_bias_grad": (_i, [_vp, _l, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_k2s2_bwd_weight_workspace": (_l, [_i, _i, _i, _i, _i, _i]),
     "adell_convtranspose3d_k2s2_bwd_weight": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_k2s2_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "adell_convtranspose3d_k2s2_bwd_data": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "adell_stats_finalize": (_i, [_vp, _i, _i, _i, _l, _f, _i, _vp, _vp, _vp]),
+    "adell_stats_finalize_workspace": (_l, [_i, _i, _i]),
+    "adell_stats_finalize": (_i, [_vp, _i, _i, _i, _l, _f, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_channel_partials_ntiles": (_i, [_l]),
     "adell_channel_partials": (_i, [_vp, _i, _l, _i, _vp, _vp]),
     "adell_norm_act_fwd": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -20,6 +20,7 @@ struct WgradArgs {
   const float* x1;
   const float* dy;
   float* ws;          // [R][ntap][Cin][Cout]
+  float* wsdb;        // [R][Cout] column sums of dY (bias gradient) or null
   int N, D, H, W;     // X dims
   int C0, C1, Cin, Cout;
   int KD, KH, KW, SD, SH, SW, PD, PH, PW;
@@ -35,7 +36,7 @@ struct WgradArgs {
 };
 
 template <int MAXJ>
-__global__ __launch_bounds__(256) void adell_conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void adell_conv_wgrad_kernel(WgradArgs a) {
   extern __shared__ float smem[];
   const int TV = 1 << (a.lTX + a.lTY + a.lTZ);
   const int HV = a.HX * a.HY * a.HZ;
@@ -51,21 +52,23 @@ __global__ __launch_bounds__(256) void adell_conv_wgrad_kernel(WgradArgs a) {
   const int tapsg = a.KDg * a.KH * a.KW;
   const int sci = a.TCI >> 5;
   const int nsub = sci * (a.TCO >> 5);
-  const int J = tapsg * nsub;
 
-  // job table of this wave: j = wave + 4q
-  int aoffj[MAXJ], boffj[MAXJ];
+  // A wave owns ONE 32x32 channel sub-tile and every (4/nsub)-th tap of the
+  // group: the dY operand is read once per k-step and shared by all its taps.
+  const int sub = wave % nsub;
+  const int cis = sub % sci, cos = sub / sci;
+  const int tstride = 4 / nsub, tfirst = wave / nsub;
+  int aoffj[MAXJ];
   bool jok[MAXJ];
 #pragma unroll
   for (int q = 0; q < MAXJ; ++q) {
-    const int j = wave + 4 * q;
-    jok[q] = j < J;
-    const int sub = j % nsub, tl = j / nsub;
-    const int cis = sub % sci, cos = sub / sci;
+    int tl = tfirst + tstride * q;
+    jok[q] = tl < tapsg;
+    if (!jok[q]) tl = tfirst;  // duplicate work into a discarded accumulator
     const int kx = tl % a.KW, ky = (tl / a.KW) % a.KH, kz = tl / (a.KW * a.KH);
-    aoffj[q] = ((kz * a.HY + ky) * a.HX + kx) * a.TCI + cis * 32;
-    boffj[q] = cos * 32;
+    aoffj[q] = ((kz * a.HY + ky) * a.HX + kx) * a.TCI + cis * 32 + lh * a.SW * a.TCI + li;
   }
+  const int boff = cos * 32 + lh * a.TCO + li;
 
   f32x16 acc[MAXJ];
 #pragma unroll
@@ -78,6 +81,12 @@ __global__ __launch_bounds__(256) void adell_conv_wgrad_kernel(WgradArgs a) {
   const long ntiles = tiles_per_item * a.N;
   const int HXY = a.HX * a.HY;
   const int c4x = a.TCI >> 2, c4y = a.TCO >> 2;
+  const int ksteps = TV >> 1;
+  const int lhx = a.lTX - 1;  // log2 of k-steps per brick row
+  // bias gradient: thread t always stages channel quad t % c4y, so it can keep a
+  // private running sum of everything it stages (only the ci-tile-0 / group-0 blocks)
+  const bool do_db = a.wsdb != nullptr && cit == 0 && grp == 0;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (long tile = region; tile < ntiles; tile += a.R) {
     long t = tile;
@@ -139,52 +148,88 @@ __global__ __launch_bounds__(256) void adell_conv_wgrad_kernel(WgradArgs a) {
         }
       }
       *reinterpret_cast<float4*>(&sY[v * a.TCO + 4 * c4]) = f;
+      dbacc.x += f.x; dbacc.y += f.y; dbacc.z += f.z; dbacc.w += f.w;
     }
     __syncthreads();
-    // ---- K loop over the brick's voxels, two per MFMA ---------------------
-    const int rows = TV >> a.lTX;
-    for (int r = 0; r < rows; ++r) {
+    // ---- K loop over the brick's voxels, two per MFMA, register double-buffered
+    auto a_row = [&](int ks) {
+      const int xp = (ks & ((1 << lhx) - 1)) << 1;
+      const int r = ks >> lhx;
       const int y = r & (TY - 1), z = r >> a.lTY;
-      const int arow = ((z * a.SD) * a.HY + y * a.SH) * a.HX;
-      for (int xp = 0; xp < TX; xp += 2) {
-        const int abase = (arow + (xp + lh) * a.SW) * a.TCI + li;
-        const int bbase = (r * TX + xp + lh) * a.TCO + li;
+      return (((z * a.SD) * a.HY + y * a.SH) * a.HX + xp * a.SW) * a.TCI;
+    };
+    float av0[MAXJ], av1[MAXJ], bv0, bv1;
+    {
+      const int ab = a_row(0);
 #pragma unroll
-        for (int q = 0; q < MAXJ; ++q) {
-          if (jok[q]) {
-            const float av = sX[abase + aoffj[q]];
-            const float bv = sY[bbase + boffj[q]];
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
-          }
-        }
+      for (int q = 0; q < MAXJ; ++q) av0[q] = sX[ab + aoffj[q]];
+      bv0 = sY[boff];
+    }
+    for (int ks = 0; ks < ksteps; ks += 2) {
+      {
+        const int ab = a_row(ks + 1);
+#pragma unroll
+        for (int q = 0; q < MAXJ; ++q) av1[q] = sX[ab + aoffj[q]];
+        bv1 = sY[(ks + 1) * 2 * a.TCO + boff];
       }
+#pragma unroll
+      for (int q = 0; q < MAXJ; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q], bv0, acc[q], 0, 0, 0);
+      if (ks + 2 < ksteps) {
+        const int ab = a_row(ks + 2);
+#pragma unroll
+        for (int q = 0; q < MAXJ; ++q) av0[q] = sX[ab + aoffj[q]];
+        bv0 = sY[(ks + 2) * 2 * a.TCO + boff];
+      }
+#pragma unroll
+      for (int q = 0; q < MAXJ; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q], bv1, acc[q], 0, 0, 0);
     }
   }
 
+  if (do_db) {
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[tid] = dbacc;
+    __syncthreads();
+    if (tid < c4y) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = tid; k < 256; k += c4y) {
+        const float4 u = red[k];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      const int c = co0 + 4 * tid;
+      float* o = a.wsdb + (size_t)region * a.Cout + c;
+      if (c + 0 < a.Cout) o[0] = t.x;
+      if (c + 1 < a.Cout) o[1] = t.y;
+      if (c + 2 < a.Cout) o[2] = t.z;
+      if (c + 3 < a.Cout) o[3] = t.w;
+    }
+  }
   // ---- write this region's partial slab ------------------------------------
   const int ntap = a.KD * a.KH * a.KW;
+  const int co = co0 + cos * 32 + li;
 #pragma unroll
   for (int q = 0; q < MAXJ; ++q) {
-    if (!jok[q]) continue;
-    const int j = wave + 4 * q;
-    const int sub = j % nsub, tl = j / nsub;
-    const int cis = sub % sci, cos = sub / sci;
+    const int tl = tfirst + tstride * q;
     const int tap = kz0 * a.KH * a.KW + tl;
-    const int co = co0 + cos * 32 + li;
+    const int cib = ci0 + cis * 32 + 4 * lh;
+    float* base = a.ws + (((size_t)region * ntap + tap) * a.Cin + cib) * a.Cout + co;
+    if (jok[q] && co < a.Cout) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int ci = ci0 + cis * 32 + row;
-      if (ci < a.Cin && co < a.Cout)
-        a.ws[(((size_t)region * ntap + tap) * a.Cin + ci) * a.Cout + co] = acc[q][r];
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        if (cib + row < a.Cin) base[(size_t)row * a.Cout] = acc[q][r];
+      }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // out[(co*Cin + ci)*ntap + tap] = sum_r ws[r][tap][ci][co]
 __global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
     const float* __restrict__ ws, float* __restrict__ out, int R, int ntap, int Cin,
-    int Cout) {
+    int Cout, const float* __restrict__ wsdb, float* __restrict__ db) {
   const long total = (long)ntap * Cin * Cout;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
        i += (long)gridDim.x * blockDim.x) {
@@ -195,6 +240,13 @@ __global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
     float s = 0.f;
     for (int r = 0; r < R; ++r) s += ws[(size_t)r * total + i];
     out[((size_t)co * Cin + ci) * ntap + tap] = s;
+  }
+  if (db != nullptr && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) s += wsdb[(size_t)r * Cout + co];
+      db[co] = s;
+    }
   }
 }
 
@@ -220,12 +272,13 @@ static int adell_wgrad_plan(int N, int Cin, int Cout, int KD, int KH, int KW, in
     return ADELL_E_UNSUPPORTED;
   }
   // brick: start from 8x8x2 and shrink until the LDS budget (<= 80 KiB, two
-  // blocks per CU) is met; x extent stays >= 2 (two voxels per MFMA).
+  // blocks per CU) is met; the brick keeps >= 4 voxels (two k-steps per loop trip).
   int l[3] = {3, 3, 1};
   const int cap[3] = {adell_ilog2(Wo) < 1 ? 1 : adell_ilog2(Wo), adell_ilog2(Ho),
                       adell_ilog2(Do)};
   for (int d = 0; d < 3; ++d)
     if (l[d] > cap[d]) l[d] = cap[d];
+  while (l[0] + l[1] + l[2] < 2) ++l[0];
   for (;;) {
     const int TX = 1 << l[0], TY = 1 << l[1], TZ = 1 << l[2];
     p->HX = (TX - 1) * SW + KW;
@@ -238,7 +291,7 @@ static int adell_wgrad_plan(int N, int Cin, int Cout, int KD, int KH, int KW, in
     int d = 2;
     if (l[1] > l[d]) d = 1;
     if (l[0] > l[d] && l[0] > 1) d = 0;
-    if (l[d] == 0 || (d == 0 && l[0] == 1)) {
+    if (l[d] == 0 || (d == 0 && l[0] == 1) || l[0] + l[1] + l[2] <= 2) {
       if (p->lds <= 160 * 1024) break;
       adell_set_error("wgrad: cannot fit LDS");
       return ADELL_E_UNSUPPORTED;
@@ -248,8 +301,13 @@ static int adell_wgrad_plan(int N, int Cin, int Cout, int KD, int KH, int KW, in
   p->lTX = l[0]; p->lTY = l[1]; p->lTZ = l[2];
   p->ntiles = (long)N * adell_cdiv(Wo, 1 << l[0]) * adell_cdiv(Ho, 1 << l[1]) *
               adell_cdiv(Do, 1 << l[2]);
+  // One resident wave of blocks: 2 blocks per CU by registers (<= 256 per lane at
+  // MAXJ <= 9), fewer if LDS does not allow it; R regions fill exactly that.
   const long chan_blocks = (long)p->nci * p->nco * p->ngrp;
-  long R = adell_cdiv(768, (int)chan_blocks);
+  int per_cu = (int)((160 * 1024) / p->lds);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  long R = (256L * per_cu) / chan_blocks;
   if (R > p->ntiles) R = p->ntiles;
   if (R < 1) R = 1;
   p->R = (int)R;
@@ -257,7 +315,7 @@ static int adell_wgrad_plan(int N, int Cin, int Cout, int KD, int KH, int KW, in
 }
 
 static size_t adell_wgrad_ws_bytes(const WgradPlan& p, int ntap, int Cin, int Cout) {
-  return (size_t)p.R * ntap * Cin * Cout * sizeof(float);
+  return ((size_t)p.R * ntap * Cin * Cout + (size_t)p.R * Cout) * sizeof(float);
 }
 
 template <int MAXJ>
@@ -280,7 +338,7 @@ static int adell_launch_wgrad(const WgradArgs& a, dim3 grid, size_t lds, hipStre
 static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const float* x0,
                             const float* x1, int Cout, int Do, int Ho, int Wo,
                             const float* dy, int KD, int KH, int KW, int SD, int SH,
-                            int SW, int PD, int PH, int PW, float* out, void* ws,
+                            int SW, int PD, int PH, int PW, float* out, float* db, void* ws,
                             size_t ws_bytes, hipStream_t st) {
   const int Cin = C0 + C1;
   WgradPlan p;
@@ -292,6 +350,7 @@ static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const fl
                 ws_bytes, need);
   WgradArgs a = {};
   a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = (float*)ws;
+  a.wsdb = db ? (float*)ws + (size_t)p.R * ntap * Cin * Cout : nullptr;
   a.N = N; a.D = D; a.H = H; a.W = W;
   a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout;
   a.KD = KD; a.KH = KH; a.KW = KW; a.SD = SD; a.SH = SH; a.SW = SW;
@@ -321,7 +380,7 @@ static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const fl
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st,
-                     (const float*)ws, out, p.R, ntap, Cin, Cout);
+                     (const float*)ws, out, p.R, ntap, Cin, Cout, (const float*)a.wsdb, db);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
@@ -338,13 +397,13 @@ extern "C" long adell_conv3d_bwd_weight_workspace(const adell_conv3d_desc* d) {
 
 extern "C" int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* x0,
                                        const float* x1, const float* dy, float* dw,
-                                       void* workspace, size_t workspace_bytes,
-                                       void* stream) {
+                                       float* db, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight: C1 > 0 needs x1");
   return adell_wgrad_core(d->N, d->D, d->H, d->W, d->C0, d->C1, x0, x1, d->Cout, d->Do,
                           d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
-                          d->PH, d->PW, dw, workspace, workspace_bytes, (hipStream_t)stream);
+                          d->PH, d->PW, dw, db, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // dW[ci][co][tap] = sum_v x[v][ci] * dy[2v+tap][co]: the same GEMM with the roles
@@ -364,7 +423,7 @@ extern "C" int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W,
                                                      void* stream) {
   ADELL_REQUIRE(x && dy && dw, "convT_bwd_weight: null pointer");
   return adell_wgrad_core(N, 2 * D, 2 * H, 2 * W, Cout, 0, dy, nullptr, Cin, D, H, W, x, 2, 2,
-                          2, 2, 2, 2, 0, 0, 0, dw, workspace, workspace_bytes,
+                          2, 2, 2, 2, 0, 0, 0, dw, nullptr, workspace, workspace_bytes,
                           (hipStream_t)stream);
 }
 

@@ -45,14 +45,67 @@ __global__ __launch_bounds__(256) void adell_stats_finalize_kernel(
   }
 }
 
+// First level of the two-level reduction used when there are many tiles: block
+// (cgroup, n, z) folds tiles [256 z, 256 z + 256) into one row of `out`
+// ([N][Z][C][2] floats, summed in fp64).
+__global__ __launch_bounds__(256) void adell_stats_fold_kernel(const float* __restrict__ part,
+                                                               int ntiles, int C, int Z,
+                                                               float* __restrict__ out) {
+  __shared__ double sh[8][32][2];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y, z = blockIdx.z;
+  const int t0 = z * 256;
+  const int t1 = t0 + 256 < ntiles ? t0 + 256 : ntiles;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C)
+    for (int t = t0 + sl; t < t1; t += 8) {
+      const float2 v =
+          *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
+      s1 += (double)v.x;
+      s2 += (double)v.y;
+    }
+  sh[sl][cl][0] = s1;
+  sh[sl][cl][1] = s2;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a += sh[k][cl][0];
+      b += sh[k][cl][1];
+    }
+    float* o = out + (((size_t)n * Z + z) * C + c) * 2;
+    o[0] = (float)a;
+    o[1] = (float)b;
+  }
+}
+
+extern "C" long adell_stats_finalize_workspace(int N, int ntiles, int C) {
+  if (ntiles <= 512) return 0;
+  const long Z = (ntiles + 255) / 256;
+  return (long)sizeof(float) * N * Z * C * 2;
+}
+
 extern "C" int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
                                     long count, float eps, int per_item, float* mean,
-                                    float* rstd, void* stream) {
+                                    float* rstd, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
   ADELL_REQUIRE(partials && mean && rstd, "stats_finalize: null pointer");
   ADELL_REQUIRE(N > 0 && ntiles > 0 && C > 0 && count > 0, "stats_finalize: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const long need = adell_stats_finalize_workspace(N, ntiles, C);
+  if (need > 0) {
+    ADELL_REQUIRE(workspace && (long)workspace_bytes >= need,
+                  "stats_finalize: workspace too small");
+    const int Z = (ntiles + 255) / 256;
+    hipLaunchKernelGGL(adell_stats_fold_kernel, dim3(adell_cdiv(C, 32), N, Z), dim3(256), 0, st,
+                       partials, ntiles, C, Z, (float*)workspace);
+    partials = (const float*)workspace;
+    ntiles = Z;
+  }
   hipLaunchKernelGGL(adell_stats_finalize_kernel, dim3(adell_cdiv(C, 32), per_item ? N : 1),
-                     dim3(256), 0, (hipStream_t)stream, partials, N, ntiles, C, (double)count,
-                     eps, per_item, mean, rstd);
+                     dim3(256), 0, st, partials, N, ntiles, C, (double)count, eps, per_item, mean,
+                     rstd);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

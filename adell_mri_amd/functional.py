@@ -75,9 +75,12 @@ class _Conv3dFn(torch.autograd.Function):
                 dx0 = None
             if x1 is None or not need[1]:
                 dx1 = None
+        want_db = has_bias and need[3]
         if need[2]:
-            dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1)
-        if has_bias and need[3]:
+            dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db)
+            if want_db:
+                dw, db = dw
+        elif want_db:
             db = ops.bias_grad(dy)
         if has_res and need[4]:
             dres = dy

@@ -19,6 +19,7 @@ from typing import Dict, List
 import numpy as np
 import torch
 
+from ... import functional as HF
 from ..._lib import AdellHipError
 from ..layers.adn_fn import ActDropNorm, norm_fn_dict
 from ..layers.conv import Conv2d, Conv3d, ConvTranspose3d
@@ -290,7 +291,9 @@ class UNet(torch.nn.Module):
             X = mod(X)
         if return_logits is True:
             return X
-        # Sigmoid / Softmax over one small [B, n_classes, ...] tensor
+        if isinstance(mods[-1], torch.nn.Sigmoid):
+            return HF.norm_drop_act(X, act="sigmoid")
+        # Softmax over the class axis of one small [B, n_classes, ...] tensor
         return mods[-1](X)
 
     def forward(self, X: torch.Tensor, X_skip_layer: torch.Tensor = None,

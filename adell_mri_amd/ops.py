@@ -181,8 +181,8 @@ def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 4) + 3) // 4, device=device, dtype=torch.float32)
 
 
-def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None):
-    """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout."""
+def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False):
+    """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout (and db when want_db)."""
     _require_cuda(x0, x1, dy)
     x0, dy = ndhwc(x0), ndhwc(dy)
     N, C0, D, H, W = x0.shape
@@ -199,10 +199,11 @@ def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None):
         check(int(nbytes))
     ws = _workspace(nbytes, x0.device)
     dw = torch.empty((Cout, C0 + C1, *k), device=x0.device, dtype=torch.float32)
+    db = torch.empty((Cout,), device=x0.device, dtype=torch.float32) if want_db else None
     check(_timed("adell_conv_wgrad_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_bwd_weight(
-        ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
-        _stream())))
-    return dw
+        ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+        ws.numel() * 4, _stream())))
+    return (dw, db) if want_db else dw
 
 
 def bias_grad(dy):
@@ -263,9 +264,11 @@ def stats_finalize(partials, count, eps, per_item=True):
     N, nt, C, _ = partials.shape
     mean = torch.empty((N, C) if per_item else (C,), device=partials.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
+    nbytes = _lib.lib().adell_stats_finalize_workspace(N, nt, C)
+    ws = _workspace(nbytes, partials.device) if nbytes > 0 else None
     check(_lib.lib().adell_stats_finalize(_ptr(partials), N, nt, C, int(count), float(eps),
-                                          1 if per_item else 0, _ptr(mean), _ptr(rstd),
-                                          _stream()))
+                                          1 if per_item else 0, _ptr(mean), _ptr(rstd), _ptr(ws),
+                                          0 if ws is None else ws.numel() * 4, _stream()))
     return mean, rstd
 
 

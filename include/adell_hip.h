@@ -96,11 +96,12 @@ int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
                           void* stream);
 
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
- * bricks, fixed-order reduction: deterministic). workspace: device scratch of
- * at least adell_conv3d_bwd_weight_workspace(d) bytes. */
+ * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias
+ * gradient db[Cout] = sum over voxels of dy from the same pass. workspace:
+ * device scratch of at least adell_conv3d_bwd_weight_workspace(d) bytes. */
 long adell_conv3d_bwd_weight_workspace(const adell_conv3d_desc* d);
 int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* x0,
-                            const float* x1, const float* dy, float* dw,
+                            const float* x1, const float* dy, float* dw, float* db,
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* db[c] = sum over rows of dy[rows][C] (torch's bias gradient of Conv3d /
@@ -136,9 +137,11 @@ int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W, int Cin,
 /* mean / rstd from partials [N][ntiles][C][2]; count = voxels per item; biased
  * variance, rstd = 1/sqrt(var+eps). per_item=1: [N][C] (torch.nn.InstanceNorm3d);
  * per_item=0: [C] over the whole batch (torch.nn.BatchNorm3d in training). */
+long adell_stats_finalize_workspace(int N, int ntiles, int C); /* bytes, may be 0 */
 int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
                          long count, float eps, int per_item, float* mean,
-                         float* rstd, void* stream);
+                         float* rstd, void* workspace, size_t workspace_bytes,
+                         void* stream);
 /* Partials of an arbitrary tensor x [N][V][C] (same buffer format). */
 int adell_channel_partials_ntiles(long V);
 int adell_channel_partials(const float* x, int N, long V, int C, float* partials,

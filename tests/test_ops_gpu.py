@@ -151,8 +151,9 @@ def test_conv3d_bwd_weight_and_bias_match_oracle(cuda, N, C0, C1, size, Cout, k,
     x0 = _cl(x[:, :C0], cuda)
     x1 = _cl(x[:, C0:], cuda) if C1 else None
     dyd = _cl(dy, cuda)
-    dw = ops.conv3d_bwd_weight(x0, dyd, k, s, p, x1=x1)
+    dw, db_fused = ops.conv3d_bwd_weight(x0, dyd, k, s, p, x1=x1, want_db=True)
     assert _relerr(_np(dw), dw_ref) < 2e-5
+    assert _relerr(_np(db_fused), db_ref) < 2e-5
     db = ops.bias_grad(dyd)
     assert _relerr(_np(db), db_ref) < 2e-5
 
