@@ -71,6 +71,13 @@ SIGNATURES = {
     "adell_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _i, _f, _vp]),
     "adell_adamw_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),
     "adell_ema_update": (_i, [_vp, _vp, _l, _f, _vp]),
+    "adell_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
+    "adell_layernorm_bwd_workspace": (_l, [_l, _i]),
+    "adell_layernorm_bwd": (_i, [_vp] * 8 + [_l, _i, _vp, ctypes.c_size_t, _vp]),
+    "adell_add_bcast": (_i, [_vp, _vp, _vp, _l, _l, _vp]),
+    "adell_sum_bcast": (_i, [_vp, _vp, _l, _l, _vp]),
+    "adell_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "adell_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),
 }
 

@@ -226,20 +226,39 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// out[(co*Cin + ci)*ntap + tap] = sum_r ws[r][tap][ci][co]
+// out[(co*Cin + ci)*ntap + tap] = sum_r ws[r][tap][ci][co]   (fixed order).
+// 256 threads = 64 consecutive elements x 4 interleaved slab quarters; the four
+// partial sums are combined in a fixed order through LDS.
 __global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
     const float* __restrict__ ws, float* __restrict__ out, int R, int ntap, int Cin,
     int Cout, const float* __restrict__ wsdb, float* __restrict__ db) {
+  __shared__ float sh[4][64];
   const long total = (long)ntap * Cin * Cout;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Cout);
-    const long rest = i / Cout;
-    const int ci = (int)(rest % Cin);
-    const int tap = (int)(rest / Cin);
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += ws[(size_t)r * total + i];
-    out[((size_t)co * Cin + ci) * ntap + tap] = s;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
+    const long i = base + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+      int r = q;
+      for (; r + 12 < R; r += 16) {
+        s0 += ws[(size_t)r * total + i];
+        s1 += ws[(size_t)(r + 4) * total + i];
+        s2 += ws[(size_t)(r + 8) * total + i];
+        s3 += ws[(size_t)(r + 12) * total + i];
+      }
+      for (; r < R; r += 4) s0 += ws[(size_t)r * total + i];
+    }
+    sh[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < total) {
+      const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+      const int co = (int)(i % Cout);
+      const long rest = i / Cout;
+      const int ci = (int)(rest % Cin);
+      const int tap = (int)(rest / Cin);
+      out[((size_t)co * Cin + ci) * ntap + tap] = s;
+    }
+    __syncthreads();
   }
   if (db != nullptr && blockIdx.x == 0) {
     for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
@@ -377,8 +396,8 @@ static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const fl
     rc = adell_launch_wgrad<9>(a, grid, p.lds, st);
   if (rc != ADELL_OK) return rc;
   const long total = (long)ntap * Cin * Cout;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st,
                      (const float*)ws, out, p.R, ntap, Cin, Cout, (const float*)a.wsdb, db);
   ADELL_CHECK_HIP(hipGetLastError());

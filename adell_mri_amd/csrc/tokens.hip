@@ -1,0 +1,559 @@
+// Token-sequence kernels of the ViT encoder in UNETR (reference:
+// adell_mri/modules/layers/vit.py:844-1002, linear_blocks.py:358-417):
+//   * LayerNorm over the last dimension (torch.nn.LayerNorm) forward/backward,
+//   * broadcast add (X + positional_embedding) and its reduction backward,
+//   * scaled-dot-product attention forward/backward with an optional additive
+//     bias (F.scaled_dot_product_attention as called at linear_blocks.py:407-414).
+// The Linear layers run on the conv kernel (a Linear is a 1x1x1 convolution over
+// the token axis). Sequences are short (216 tokens at config 3): these kernels
+// are latency/HBM-bound fp32 VALU code, one wave per row, wavefront-shuffle
+// reductions, fixed summation order.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// LayerNorm: y = (x - mean) * rstd * gamma + beta over rows of length C.
+// One wave per row. mean/rstd are saved for the backward.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_layernorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float m = adell_wave_sum(s) / (float)C;
+  float v = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = xr[c] - m;
+    v += d * d;
+  }
+  const float r = rsqrtf(adell_wave_sum(v) / (float)C + eps);
+  float* yr = y + row * C;
+  for (int c = lane; c < C; c += 64) {
+    float t = (xr[c] - m) * r;
+    if (gamma) t *= gamma[c];
+    if (beta) t += beta[c];
+    yr[c] = t;
+  }
+  if (lane == 0) {
+    mean[row] = m;
+    rstd[row] = r;
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.
+// Also per-block partial dgamma/dbeta: part[block][2][C].
+__global__ __launch_bounds__(256) void adell_layernorm_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part,
+    long rows, int C, int rows_per_block) {
+  extern __shared__ float sh[];  // [4][2][C] per-wave dgamma/dbeta partials
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* wg = sh + (size_t)wave * 2 * C;
+  for (int c = lane; c < C; c += 64) {
+    wg[c] = 0.f;
+    wg[C + c] = 0.f;
+  }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long row = r0 + wave; row < r1; row += 4) {
+    const float* xr = x + row * C;
+    const float* gr = dy + row * C;
+    const float m = mean[row], r = rstd[row];
+    float a = 0.f, b = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] - m) * r;
+      const float g = gr[c] * (gamma ? gamma[c] : 1.f);
+      a += g;
+      b += g * xh;
+      wg[c] += gr[c] * xh;   // dgamma
+      wg[C + c] += gr[c];    // dbeta
+    }
+    a = adell_wave_sum(a) / (float)C;
+    b = adell_wave_sum(b) / (float)C;
+    float* dr = dx + row * C;
+    for (int c = lane; c < C; c += 64) {
+      const float xh = (xr[c] - m) * r;
+      const float g = gr[c] * (gamma ? gamma[c] : 1.f);
+      dr[c] = r * (g - a - xh * b);
+    }
+  }
+  __syncthreads();
+  if (part) {
+    for (int c = threadIdx.x; c < 2 * C; c += 256)
+      part[(size_t)blockIdx.x * 2 * C + c] =
+          (sh[c] + sh[2 * C + c]) + (sh[4 * C + c] + sh[6 * C + c]);
+  }
+}
+
+__global__ void adell_rowsum_final_kernel(const float* __restrict__ part, int nb, int n,
+                                          float* __restrict__ out0, float* __restrict__ out1,
+                                          int half) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += (double)part[(size_t)b * n + c];
+  if (c < half) {
+    if (out0) out0[c] = (float)s;
+  } else if (out1) {
+    out1[c - half] = (float)s;
+  }
+}
+
+extern "C" int adell_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                                   float* y, float* mean, float* rstd, long rows, int C,
+                                   float eps, void* stream) {
+  ADELL_REQUIRE(x && y && mean && rstd, "layernorm_fwd: null pointer");
+  ADELL_REQUIRE(rows > 0 && C > 0, "layernorm_fwd: bad dims");
+  hipLaunchKernelGGL(adell_layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, C, eps);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+#define ADELL_LN_ROWS_PER_BLOCK 64
+extern "C" long adell_layernorm_bwd_workspace(long rows, int C) {
+  const long nb = (rows + ADELL_LN_ROWS_PER_BLOCK - 1) / ADELL_LN_ROWS_PER_BLOCK;
+  return nb * 2 * C * (long)sizeof(float);
+}
+
+extern "C" int adell_layernorm_bwd(const float* x, const float* dy, const float* gamma,
+                                   const float* mean, const float* rstd, float* dx,
+                                   float* dgamma, float* dbeta, long rows, int C,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(x && dy && mean && rstd && dx, "layernorm_bwd: null pointer");
+  ADELL_REQUIRE(rows > 0 && C > 0, "layernorm_bwd: bad dims");
+  ADELL_REQUIRE((size_t)8 * C * sizeof(float) <= 160 * 1024, "layernorm_bwd: C too large");
+  const bool want = dgamma || dbeta;
+  if (want)
+    ADELL_REQUIRE(workspace && (long)workspace_bytes >= adell_layernorm_bwd_workspace(rows, C),
+                  "layernorm_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((rows + ADELL_LN_ROWS_PER_BLOCK - 1) / ADELL_LN_ROWS_PER_BLOCK);
+  const size_t lds = (size_t)8 * C * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_layernorm_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(adell_layernorm_bwd_kernel, dim3(nb), dim3(256), lds, st, x, dy, gamma, mean,
+                     rstd, dx, want ? (float*)workspace : nullptr, rows, C,
+                     ADELL_LN_ROWS_PER_BLOCK);
+  if (want)
+    hipLaunchKernelGGL(adell_rowsum_final_kernel, dim3(adell_cdiv(2 * C, 64)), dim3(64), 0, st,
+                       (const float*)workspace, nb, 2 * C, dgamma, dbeta, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// out[i] = a[i] + b[i % period]  and its backward db[j] = sum_k dout[k*period + j]
+// ---------------------------------------------------------------------------
+__global__ void adell_add_bcast_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                       float* __restrict__ out, long n, long period) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i % period];
+}
+__global__ void adell_sum_bcast_kernel(const float* __restrict__ g, float* __restrict__ db,
+                                       long n, long period) {
+  for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < period;
+       j += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (long i = j; i < n; i += period) s += g[i];
+    db[j] = s;
+  }
+}
+extern "C" int adell_add_bcast(const float* a, const float* b, float* out, long n, long period,
+                               void* stream) {
+  ADELL_REQUIRE(a && b && out && n > 0 && period > 0 && n % period == 0, "add_bcast: bad arguments");
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adell_add_bcast_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a, b, out, n, period);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+extern "C" int adell_sum_bcast(const float* g, float* db, long n, long period, void* stream) {
+  ADELL_REQUIRE(g && db && n > 0 && period > 0 && n % period == 0, "sum_bcast: bad arguments");
+  long blocks = (period + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adell_sum_bcast_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, g, db, n, period);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Attention. Q,K: [BH][T][A]; V,O: [BH][T][Dv]; bias: [nbias][T][T] or null
+// (bias row for sequence bh is bh % nbias). scale = 1/sqrt(A) unless given.
+// One wave per query row; keys streamed through LDS in tiles of 64 with an
+// online softmax; lane j owns key j of the tile for the scores, lane d owns
+// output column d (and d+64, ...) for the PV product.
+// ---------------------------------------------------------------------------
+#define ATT_TK 64
+#define ATT_ROWS 16  // query rows per block (4 waves x 4 rows)
+
+struct AttArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  const float* bias;
+  const float* o;    // bwd
+  const float* dout; // bwd
+  const float* lse;  // bwd: [BH][T] log-sum-exp of the scaled scores
+  float* out;        // fwd: O ; bwd: unused
+  float* lse_out;    // fwd
+  float* dq;
+  float* dk;
+  float* dv;
+  int T, A, Dv, nbias;
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void adell_attention_fwd_kernel(AttArgs a) {
+  extern __shared__ float sh[];
+  const int AP = a.A + 1, DP = a.Dv;  // K rows padded against bank conflicts
+  float* sK = sh;                       // [ATT_TK][AP]
+  float* sV = sK + ATT_TK * AP;         // [ATT_TK][DP]
+  float* sQ = sV + ATT_TK * DP;         // [ATT_ROWS][A]
+  float* sP = sQ + ATT_ROWS * a.A;      // [4 waves][ATT_TK]
+  const int bh = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * ATT_ROWS;
+  const float* qb = a.q + (size_t)bh * a.T * a.A;
+  const float* kb = a.k + (size_t)bh * a.T * a.A;
+  const float* vb = a.v + (size_t)bh * a.T * a.Dv;
+  for (int i = threadIdx.x; i < ATT_ROWS * a.A; i += 256) {
+    const int r = i / a.A, c = i - r * a.A;
+    sQ[i] = (row0 + r < a.T) ? qb[(size_t)(row0 + r) * a.A + c] : 0.f;
+  }
+  constexpr int RPW = ATT_ROWS / 4;
+  constexpr int MAXD = 4;  // output columns per lane: Dv <= 256
+  float m[RPW], l[RPW], acc[RPW][MAXD];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) acc[r][d] = 0.f;
+  }
+  const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  for (int k0 = 0; k0 < a.T; k0 += ATT_TK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ATT_TK * a.A; i += 256) {
+      const int r = i / a.A, c = i - r * a.A;
+      sK[r * AP + c] = (k0 + r < a.T) ? kb[(size_t)(k0 + r) * a.A + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < ATT_TK * a.Dv; i += 256) {
+      const int r = i / a.Dv, c = i - r * a.Dv;
+      sV[r * DP + c] = (k0 + r < a.T) ? vb[(size_t)(k0 + r) * a.Dv + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int qrow = row0 + wave * RPW + r;
+      const float* qr = sQ + (wave * RPW + r) * a.A;
+      float s = -INFINITY;
+      if (k0 + lane < a.T && qrow < a.T) {
+        float t = 0.f;
+        for (int c = 0; c < a.A; ++c) t += qr[c] * sK[lane * AP + c];
+        s = t * a.scale;
+        if (biasb) s += biasb[(size_t)qrow * a.T + k0 + lane];
+      }
+      float mx = s;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mnew = fmaxf(m[r], mx);
+      const float p = (s == -INFINITY) ? 0.f : expf(s - mnew);
+      const float corr = (m[r] == -INFINITY) ? 0.f : expf(m[r] - mnew);
+      const float psum = adell_wave_sum(p);
+      l[r] = l[r] * corr + psum;
+      m[r] = mnew;
+      sP[wave * ATT_TK + lane] = p;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int d = 0; d < MAXD; ++d) {
+        const int col = lane + 64 * d;
+        if (col < a.Dv) {
+          float t = 0.f;
+          for (int j = 0; j < ATT_TK; ++j) t += sP[wave * ATT_TK + j] * sV[j * DP + col];
+          acc[r][d] = acc[r][d] * corr + t;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int qrow = row0 + wave * RPW + r;
+    if (qrow >= a.T) continue;
+    const float inv = 1.0f / l[r];
+#pragma unroll
+    for (int d = 0; d < MAXD; ++d) {
+      const int col = lane + 64 * d;
+      if (col < a.Dv) a.out[((size_t)bh * a.T + qrow) * a.Dv + col] = acc[r][d] * inv;
+    }
+    if (lane == 0) a.lse_out[(size_t)bh * a.T + qrow] = m[r] + logf(l[r]);
+  }
+}
+
+// dQ: one wave per query row (same structure as forward).
+__global__ __launch_bounds__(256) void adell_attention_bwd_q_kernel(AttArgs a) {
+  extern __shared__ float sh[];
+  const int AP = a.A + 1, DP = a.Dv + 1;
+  float* sK = sh;                        // [ATT_TK][AP]
+  float* sV = sK + ATT_TK * AP;          // [ATT_TK][DP]
+  float* sQ = sV + ATT_TK * DP;          // [ATT_ROWS][A]
+  float* sdO = sQ + ATT_ROWS * a.A;      // [ATT_ROWS][Dv]
+  float* sP = sdO + ATT_ROWS * a.Dv;     // [4][ATT_TK]  (holds dS)
+  const int bh = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * ATT_ROWS;
+  const float* qb = a.q + (size_t)bh * a.T * a.A;
+  const float* kb = a.k + (size_t)bh * a.T * a.A;
+  const float* vb = a.v + (size_t)bh * a.T * a.Dv;
+  const float* ob = a.o + (size_t)bh * a.T * a.Dv;
+  const float* gb = a.dout + (size_t)bh * a.T * a.Dv;
+  for (int i = threadIdx.x; i < ATT_ROWS * a.A; i += 256) {
+    const int r = i / a.A, c = i - r * a.A;
+    sQ[i] = (row0 + r < a.T) ? qb[(size_t)(row0 + r) * a.A + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < ATT_ROWS * a.Dv; i += 256) {
+    const int r = i / a.Dv, c = i - r * a.Dv;
+    sdO[i] = (row0 + r < a.T) ? gb[(size_t)(row0 + r) * a.Dv + c] : 0.f;
+  }
+  __syncthreads();
+  constexpr int RPW = ATT_ROWS / 4;
+  constexpr int MAXA = 4;  // A <= 256
+  float Dr[RPW], lse[RPW], acc[RPW][MAXA];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int qrow = row0 + wave * RPW + r;
+    float t = 0.f;
+    if (qrow < a.T)
+      for (int c = lane; c < a.Dv; c += 64)
+        t += sdO[(wave * RPW + r) * a.Dv + c] * ob[(size_t)qrow * a.Dv + c];
+    Dr[r] = adell_wave_sum(t);
+    lse[r] = qrow < a.T ? a.lse[(size_t)bh * a.T + qrow] : 0.f;
+#pragma unroll
+    for (int d = 0; d < MAXA; ++d) acc[r][d] = 0.f;
+  }
+  const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  for (int k0 = 0; k0 < a.T; k0 += ATT_TK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ATT_TK * a.A; i += 256) {
+      const int r = i / a.A, c = i - r * a.A;
+      sK[r * AP + c] = (k0 + r < a.T) ? kb[(size_t)(k0 + r) * a.A + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < ATT_TK * a.Dv; i += 256) {
+      const int r = i / a.Dv, c = i - r * a.Dv;
+      sV[r * DP + c] = (k0 + r < a.T) ? vb[(size_t)(k0 + r) * a.Dv + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int qrow = row0 + wave * RPW + r;
+      const float* qr = sQ + (wave * RPW + r) * a.A;
+      const float* gr = sdO + (wave * RPW + r) * a.Dv;
+      float ds = 0.f;
+      if (k0 + lane < a.T && qrow < a.T) {
+        float t = 0.f;
+        for (int c = 0; c < a.A; ++c) t += qr[c] * sK[lane * AP + c];
+        float s = t * a.scale;
+        if (biasb) s += biasb[(size_t)qrow * a.T + k0 + lane];
+        const float p = expf(s - lse[r]);
+        float dp = 0.f;
+        for (int c = 0; c < a.Dv; ++c) dp += gr[c] * sV[lane * DP + c];
+        ds = p * (dp - Dr[r]);
+      }
+      sP[wave * ATT_TK + lane] = ds;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int d = 0; d < MAXA; ++d) {
+        const int col = lane + 64 * d;
+        if (col < a.A) {
+          float t = 0.f;
+          for (int j = 0; j < ATT_TK; ++j) t += sP[wave * ATT_TK + j] * sK[j * AP + col];
+          acc[r][d] += t;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int qrow = row0 + wave * RPW + r;
+    if (qrow >= a.T) continue;
+#pragma unroll
+    for (int d = 0; d < MAXA; ++d) {
+      const int col = lane + 64 * d;
+      if (col < a.A) a.dq[((size_t)bh * a.T + qrow) * a.A + col] = acc[r][d] * a.scale;
+    }
+  }
+}
+
+// dK, dV: one wave per key row; queries streamed through LDS in tiles of 64.
+__global__ __launch_bounds__(256) void adell_attention_bwd_kv_kernel(AttArgs a) {
+  extern __shared__ float sh[];
+  const int AP = a.A + 1, DP = a.Dv + 1;
+  float* sQ = sh;                        // [ATT_TK][AP]   query tile
+  float* sdO = sQ + ATT_TK * AP;         // [ATT_TK][DP]
+  float* sK = sdO + ATT_TK * DP;         // [ATT_ROWS][A]  this block's keys
+  float* sV = sK + ATT_ROWS * a.A;       // [ATT_ROWS][Dv]
+  float* sP = sV + ATT_ROWS * a.Dv;      // [4][2][ATT_TK] (p, dS)
+  float* sL = sP + 4 * 2 * ATT_TK;       // [ATT_TK][2] lse, D of the query tile
+  const int bh = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * ATT_ROWS;
+  const float* qb = a.q + (size_t)bh * a.T * a.A;
+  const float* kb = a.k + (size_t)bh * a.T * a.A;
+  const float* vb = a.v + (size_t)bh * a.T * a.Dv;
+  const float* ob = a.o + (size_t)bh * a.T * a.Dv;
+  const float* gb = a.dout + (size_t)bh * a.T * a.Dv;
+  for (int i = threadIdx.x; i < ATT_ROWS * a.A; i += 256) {
+    const int r = i / a.A, c = i - r * a.A;
+    sK[i] = (row0 + r < a.T) ? kb[(size_t)(row0 + r) * a.A + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < ATT_ROWS * a.Dv; i += 256) {
+    const int r = i / a.Dv, c = i - r * a.Dv;
+    sV[i] = (row0 + r < a.T) ? vb[(size_t)(row0 + r) * a.Dv + c] : 0.f;
+  }
+  constexpr int RPW = ATT_ROWS / 4;
+  constexpr int MAXC = 4;
+  float dk[RPW][MAXC], dv[RPW][MAXC];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int d = 0; d < MAXC; ++d) dk[r][d] = dv[r][d] = 0.f;
+  const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  for (int q0 = 0; q0 < a.T; q0 += ATT_TK) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < ATT_TK * a.A; i += 256) {
+      const int r = i / a.A, c = i - r * a.A;
+      sQ[r * AP + c] = (q0 + r < a.T) ? qb[(size_t)(q0 + r) * a.A + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < ATT_TK * a.Dv; i += 256) {
+      const int r = i / a.Dv, c = i - r * a.Dv;
+      sdO[r * DP + c] = (q0 + r < a.T) ? gb[(size_t)(q0 + r) * a.Dv + c] : 0.f;
+    }
+    __syncthreads();
+    // D_i = dO_i . O_i for the query tile: wave w handles rows w, w+4, ...
+    for (int r = wave; r < ATT_TK; r += 4) {
+      float t = 0.f;
+      if (q0 + r < a.T)
+        for (int c = lane; c < a.Dv; c += 64) t += sdO[r * DP + c] * ob[(size_t)(q0 + r) * a.Dv + c];
+      t = adell_wave_sum(t);
+      if (lane == 0) {
+        sL[r * 2 + 0] = (q0 + r < a.T) ? a.lse[(size_t)bh * a.T + q0 + r] : 0.f;
+        sL[r * 2 + 1] = t;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int krow = row0 + wave * RPW + r;
+      const float* kr = sK + (wave * RPW + r) * a.A;
+      const float* vr = sV + (wave * RPW + r) * a.Dv;
+      float p = 0.f, ds = 0.f;
+      if (q0 + lane < a.T && krow < a.T) {
+        float t = 0.f;
+        for (int c = 0; c < a.A; ++c) t += kr[c] * sQ[lane * AP + c];
+        float s = t * a.scale;
+        if (biasb) s += biasb[(size_t)(q0 + lane) * a.T + krow];
+        p = expf(s - sL[lane * 2 + 0]);
+        float dp = 0.f;
+        for (int c = 0; c < a.Dv; ++c) dp += vr[c] * sdO[lane * DP + c];
+        ds = p * (dp - sL[lane * 2 + 1]);
+      }
+      sP[(wave * 2 + 0) * ATT_TK + lane] = p;
+      sP[(wave * 2 + 1) * ATT_TK + lane] = ds;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int d = 0; d < MAXC; ++d) {
+        const int col = lane + 64 * d;
+        if (col < a.Dv) {
+          float t = 0.f;
+          for (int j = 0; j < ATT_TK; ++j) t += sP[(wave * 2 + 0) * ATT_TK + j] * sdO[j * DP + col];
+          dv[r][d] += t;
+        }
+        if (col < a.A) {
+          float t = 0.f;
+          for (int j = 0; j < ATT_TK; ++j) t += sP[(wave * 2 + 1) * ATT_TK + j] * sQ[j * AP + col];
+          dk[r][d] += t;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int krow = row0 + wave * RPW + r;
+    if (krow >= a.T) continue;
+#pragma unroll
+    for (int d = 0; d < MAXC; ++d) {
+      const int col = lane + 64 * d;
+      if (col < a.Dv) a.dv[((size_t)bh * a.T + krow) * a.Dv + col] = dv[r][d];
+      if (col < a.A) a.dk[((size_t)bh * a.T + krow) * a.A + col] = dk[r][d] * a.scale;
+    }
+  }
+}
+
+static int adell_att_check(int BH, int T, int A, int Dv, int nbias, const float* bias) {
+  ADELL_REQUIRE(BH > 0 && T > 0 && A > 0 && Dv > 0, "attention: bad dims");
+  ADELL_REQUIRE(A <= 256 && Dv <= 256, "attention: head dims up to 256 supported");
+  ADELL_REQUIRE(bias == nullptr || nbias > 0, "attention: bias needs nbias > 0");
+  return ADELL_OK;
+}
+
+template <typename K>
+static int adell_att_launch(K kern, const AttArgs& a, int BH, size_t lds, hipStream_t st) {
+  ADELL_REQUIRE(lds <= 160 * 1024, "attention: head dims need %zu B of LDS (> 160 KiB)", lds);
+  ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(kern, dim3(adell_cdiv(a.T, ATT_ROWS), BH), dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_attention_fwd(const float* q, const float* k, const float* v,
+                                   const float* bias, int nbias, int BH, int T, int A, int Dv,
+                                   float scale, float* out, float* lse, void* stream) {
+  int rc = adell_att_check(BH, T, A, Dv, nbias, bias);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(q && k && v && out && lse, "attention_fwd: null pointer");
+  AttArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.bias = bias; a.out = out; a.lse_out = lse;
+  a.T = T; a.A = A; a.Dv = Dv; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale;
+  const size_t lds = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * Dv +
+                                      (size_t)ATT_ROWS * A + 4 * ATT_TK);
+  return adell_att_launch(adell_attention_fwd_kernel, a, BH, lds, (hipStream_t)stream);
+}
+
+extern "C" int adell_attention_bwd(const float* q, const float* k, const float* v,
+                                   const float* bias, int nbias, const float* out,
+                                   const float* dout, const float* lse, int BH, int T, int A,
+                                   int Dv, float scale, float* dq, float* dk, float* dv,
+                                   void* stream) {
+  int rc = adell_att_check(BH, T, A, Dv, nbias, bias);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(q && k && v && out && dout && lse && dq && dk && dv, "attention_bwd: null pointer");
+  AttArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = out; a.dout = dout; a.lse = lse;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.T = T; a.A = A; a.Dv = Dv; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale;
+  const size_t lds_q = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * (Dv + 1) +
+                                        (size_t)ATT_ROWS * A + (size_t)ATT_ROWS * Dv + 4 * ATT_TK);
+  rc = adell_att_launch(adell_attention_bwd_q_kernel, a, BH, lds_q, (hipStream_t)stream);
+  if (rc != ADELL_OK) return rc;
+  const size_t lds_kv = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * (Dv + 1) +
+                                         (size_t)ATT_ROWS * A + (size_t)ATT_ROWS * Dv +
+                                         8 * ATT_TK + 2 * ATT_TK);
+  return adell_att_launch(adell_attention_bwd_kv_kernel, a, BH, lds_kv, (hipStream_t)stream);
+}

@@ -40,7 +40,10 @@ def _packed(w, mode):
     tag = (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    p = ops.pack_weight(w.detach(), mode)
+    wd = w.detach()
+    if wd.dim() == 2:  # torch.nn.Linear weight == 1x1x1 convolution weight
+        wd = wd.view(wd.shape[0], wd.shape[1], 1, 1, 1)
+    p = ops.pack_weight(wd, mode)
     cache[mode] = (tag, p)
     return p
 
@@ -49,7 +52,7 @@ class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         stride, padding, want_stats, wref = conf
-        k = tuple(weight.shape[2:])
+        k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
         y, part = ops.conv3d_fwd(x0, wp, bias, weight.shape[0], k, stride, padding, x1=x1,
                                  residual=residual, want_stats=want_stats)
         ctx.save_for_backward(x0, x1, weight)
@@ -80,6 +83,7 @@ class _Conv3dFn(torch.autograd.Function):
             dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db)
             if want_db:
                 dw, db = dw
+            dw = dw.view(weight.shape)
         elif want_db:
             db = ops.bias_grad(dy)
         if has_res and need[4]:
@@ -196,3 +200,95 @@ def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=No
         offset = next(_dropout_counter)
     conf = (act, float(act_p), per_item, p, seed, offset)
     return _NormDropActFn.apply(x, mean, rstd, gamma, beta, act_w, conf)
+
+
+# ---- token-sequence functions (ViT encoder of UNETR) -------------------------------------
+def _rows_as_volume(x):
+    """[..., C] contiguous -> logical [1, C, 1, 1, rows] tensor with NDHWC memory (a view)."""
+    x = x.contiguous()
+    C = x.shape[-1]
+    return x.view(1, 1, 1, -1, C).permute(0, 4, 1, 2, 3)
+
+
+def _volume_as_rows(y, lead_shape):
+    """inverse of _rows_as_volume: [1, C, 1, 1, rows] (NDHWC memory) -> [*lead, C]."""
+    C = y.shape[1]
+    return y.permute(0, 2, 3, 4, 1).reshape(*lead_shape, C)
+
+
+def linear(x, weight, bias=None, residual=None):
+    """torch.nn.functional.linear on the MFMA conv kernel (+ fused residual add)."""
+    lead = x.shape[:-1]
+    res = None if residual is None else _rows_as_volume(residual)
+    y = conv3d(_rows_as_volume(x), weight, bias, 1, 0, residual=res, want_stats=False)
+    return _volume_as_rows(y, lead)
+
+
+def elementwise(x, act="identity", act_p=0.0, drop_p=0.0, training=False):
+    """Dropout -> activation on a tensor of any shape (channel axis irrelevant)."""
+    shp = x.shape
+    y = norm_drop_act(_rows_as_volume(x.reshape(-1, shp[-1])), act=act, act_p=act_p,
+                      drop_p=drop_p, training=training)
+    return _volume_as_rows(y, shp[:-1])
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        want = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dg, db = ops.layernorm_bwd(x, dy, gamma, mean, rstd, want)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma=None, beta=None, eps=1e-5):
+    """torch.nn.LayerNorm over the last dimension."""
+    return _LayerNormFn.apply(x.contiguous(), gamma, beta, float(eps))
+
+
+class _AddBcastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.bshape = b.shape
+        return ops.add_bcast(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        db = ops.sum_bcast(g, ctx.bshape) if ctx.needs_input_grad[1] else None
+        return g, db
+
+
+def add_bcast(a, b):
+    """a + b with b broadcast over a's leading dimensions (positional embedding)."""
+    return _AddBcastFn.apply(a, b)
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, bias, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, lse = ops.attention_fwd(q, k, v, bias, scale)
+        ctx.save_for_backward(q, k, v, bias, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, bias, out, lse = ctx.saved_tensors
+        if bias is not None and ctx.needs_input_grad[3]:
+            raise NotImplementedError("attention bias gradient (SWIN relative positions): next row")
+        dq, dk, dv = ops.attention_bwd(q, k, v, bias, out, dout, lse, ctx.scale)
+        return dq, dk, dv, None, None
+
+
+def attention(q, k, v, bias=None, scale=None):
+    """softmax(q k^T * scale + bias) v for q,k [BH,T,A], v [BH,T,Dv]."""
+    if scale is None:
+        scale = 1.0 / (q.shape[-1] ** 0.5)
+    return _AttentionFn.apply(q, k, v, bias, float(scale))

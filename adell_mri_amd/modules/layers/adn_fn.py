@@ -114,6 +114,10 @@ class ActDropNorm(torch.nn.Module):
         if "A" in stage:
             name, p, w = act_spec(self.op_list[stage["A"]])
             kw.update(act=name, act_p=p, act_w=w)
+        if X.dim() != 5 and kw.get("norm", "none") == "none" and kw.get("act_w") is None:
+            # purely elementwise on a token / feature tensor: no channel semantics
+            return HF.elementwise(X, act=kw.get("act", "identity"), act_p=kw.get("act_p", 0.0),
+                                  drop_p=kw.get("drop_p", 0.0), training=self.training)
         X5, back = _as5d(X)
         if hasattr(X, "_adell_partials") and X5 is not X:
             X5._adell_partials = X._adell_partials

@@ -1,0 +1,122 @@
+"""MLP and multi-head self-attention on the HIP kernels (mirror of
+adell_mri/modules/layers/linear_blocks.py:54-115, 248-417).
+
+Module trees / state_dict keys are the reference's (``op.N`` Linear / ADN members,
+``qkv``, ``q_norm``, ``k_norm``, ``output_layer``). The Linear layers run as
+1x1x1 convolutions on the MFMA conv kernel; QK-LayerNorm and the attention core
+are the token kernels of ``csrc/tokens.hip``.
+"""
+from typing import List
+
+import torch
+
+from ... import functional as HF
+
+
+class Linear(torch.nn.Linear):
+    """torch.nn.Linear whose forward is the MFMA conv kernel (optionally adding a
+    residual inside the epilogue)."""
+
+    def forward(self, X, residual=None):
+        return HF.linear(X, self.weight, self.bias, residual=residual)
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    def forward(self, X):
+        if len(self.normalized_shape) != 1:
+            raise NotImplementedError("HIP LayerNorm normalises the last dimension only")
+        return HF.layer_norm(X, self.weight, self.bias, self.eps)
+
+
+class MLP(torch.nn.Module):
+    def __init__(self, input_dim: int, output_dim: int, structure: List[int] = [],
+                 adn_fn: torch.nn.Module = torch.nn.Identity):
+        super().__init__()
+        self.input_dim = input_dim
+        self.output_dim = output_dim
+        self.structure = structure
+        self.adn_fn = adn_fn
+        self.init_layers()
+
+    def init_layers(self):
+        curr_in = self.input_dim
+        ops = torch.nn.ModuleList([])
+        if len(self.structure) > 0:
+            curr_out = self.structure[0]
+            for i in range(1, len(self.structure)):
+                ops.append(Linear(curr_in, curr_out))
+                ops.append(self.adn_fn(curr_out))
+                curr_in = curr_out
+                curr_out = self.structure[i]
+            ops.append(Linear(curr_in, curr_out))
+        else:
+            curr_out = curr_in
+        ops.append(self.adn_fn(curr_out))
+        ops.append(Linear(curr_out, self.output_dim))
+        self.op = torch.nn.Sequential(*ops)
+
+    def forward(self, X: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
+        mods = list(self.op)
+        for mod in mods[:-1]:
+            X = mod(X)
+        return mods[-1](X, residual=residual) if residual is not None else mods[-1](X)
+
+
+class MultiHeadSelfAttention(torch.nn.Module):
+    def __init__(self, input_dim: int, attention_dim: int, hidden_dim: int, output_dim: int,
+                 n_heads: int = 4, dropout_rate: float = 0.0, window_size: bool = False):
+        super().__init__()
+        self.input_dim = input_dim
+        self.attention_dim = attention_dim
+        self.hidden_dim = hidden_dim
+        self.output_dim = output_dim
+        self.n_heads = n_heads
+        self.dropout_rate = dropout_rate
+        self.window_size = window_size
+        assert (attention_dim % n_heads) == 0, "attention_dim must be divisible by n_heads"
+        assert (hidden_dim % n_heads) == 0, "hidden_dim must be divisible by n_heads"
+        if self.window_size:
+            raise NotImplementedError("windowed attention (SWIN) is a later row")
+        self.init_layers()
+        self.init_output_layer()
+        self.init_weights()
+
+    def init_layers(self):
+        self.real_attention_dim = self.attention_dim // self.n_heads
+        self.real_hidden_dim = self.hidden_dim // self.n_heads
+        self.qkv_dim = self.attention_dim * 2 + self.hidden_dim
+        self.qkv = Linear(self.input_dim, self.qkv_dim, bias=False)
+        self.drop_op = torch.nn.Dropout(self.dropout_rate)
+        self.q_norm = LayerNorm(self.real_attention_dim)
+        self.k_norm = LayerNorm(self.real_attention_dim)
+
+    def init_output_layer(self):
+        self.output_layer = Linear(self.hidden_dim, self.output_dim)
+
+    def init_weights(self):
+        torch.nn.init.xavier_uniform_(self.qkv.weight)
+        torch.nn.init.xavier_uniform_(self.output_layer.weight)
+
+    def forward(self, X: torch.Tensor, mask=None, residual: torch.Tensor = None) -> torch.Tensor:
+        if self.training and self.dropout_rate > 0:
+            raise NotImplementedError("attention-probability dropout has no HIP kernel yet")
+        sh = X.shape
+        b, t = sh[:-2], sh[-2]
+        nb = 1
+        for i in b:
+            nb *= i
+        a, h = self.real_attention_dim, self.real_hidden_dim
+        QKV = self.qkv(X).reshape(nb, t, self.n_heads, 2 * a + h).permute(0, 2, 1, 3)
+        Q = self.q_norm(QKV[..., :a].contiguous())      # per-head interleaved q | k | v
+        K = self.k_norm(QKV[..., a:2 * a].contiguous())
+        V = QKV[..., 2 * a:].contiguous()
+        bias = None
+        if mask is not None:
+            m = mask.to(Q)
+            if m.ndim == 3:
+                m = m.unsqueeze(1)
+            bias = m.expand(nb, self.n_heads, t, t).reshape(nb * self.n_heads, t, t)
+        O = HF.attention(Q.reshape(nb * self.n_heads, t, a), K.reshape(nb * self.n_heads, t, a),
+                         V.reshape(nb * self.n_heads, t, h), bias)
+        O = O.reshape(nb, self.n_heads, t, h).transpose(1, 2).reshape(*b, t, self.hidden_dim)
+        return self.output_layer(O, residual=residual)

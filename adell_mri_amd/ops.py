@@ -394,3 +394,79 @@ def ema_update(shadow, param, decay):
     _require_cuda(shadow, param)
     check(_lib.lib().adell_ema_update(_ptr(shadow), _ptr(param), shadow.numel(), decay, _stream()))
     _weights_changed()
+
+
+# ---- token-sequence ops (ViT encoder of UNETR) ------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps):
+    """LayerNorm over the last dim of a contiguous tensor; returns (y, mean, rstd)."""
+    _require_cuda(x, gamma, beta)
+    x = x.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(_lib.lib().adell_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
+                                         _ptr(rstd), rows, C, float(eps), _stream()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(x, dy, gamma, mean, rstd, want_affine):
+    x, dy = x.contiguous(), dy.contiguous()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    dg = db = ws = None
+    if want_affine:
+        dg = torch.empty((C,), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        ws = _workspace(_lib.lib().adell_layernorm_bwd_workspace(rows, C), x.device)
+    check(_lib.lib().adell_layernorm_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(mean), _ptr(rstd),
+                                         _ptr(dx), _ptr(dg), _ptr(db), rows, C, _ptr(ws),
+                                         0 if ws is None else ws.numel() * 4, _stream()))
+    return dx, dg, db
+
+
+def add_bcast(a, b):
+    """a + b where b is broadcast over a's leading dims (b.numel() divides a.numel())."""
+    _require_cuda(a, b)
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    check(_lib.lib().adell_add_bcast(_ptr(a), _ptr(b), _ptr(out), a.numel(), b.numel(), _stream()))
+    return out
+
+
+def sum_bcast(g, period_shape):
+    g = g.contiguous()
+    db = torch.empty(period_shape, device=g.device, dtype=torch.float32)
+    check(_lib.lib().adell_sum_bcast(_ptr(g), _ptr(db), g.numel(), db.numel(), _stream()))
+    return db
+
+
+def attention_fwd(q, k, v, bias, scale):
+    """q,k: [BH,T,A]; v: [BH,T,Dv]; bias: [nbias,T,T] or None. Returns (out, lse)."""
+    _require_cuda(q, k, v, bias)
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    BH, T, A = q.shape
+    Dv = v.shape[-1]
+    out = torch.empty((BH, T, Dv), device=q.device, dtype=torch.float32)
+    lse = torch.empty((BH, T), device=q.device, dtype=torch.float32)
+    nb = 0
+    if bias is not None:
+        bias = bias.contiguous()
+        nb = bias.numel() // (T * T)
+    check(_lib.lib().adell_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, BH, T, A, Dv,
+                                         float(scale), _ptr(out), _ptr(lse), _stream()))
+    return out, lse
+
+
+def attention_bwd(q, k, v, bias, out, dout, lse, scale):
+    BH, T, A = q.shape
+    Dv = v.shape[-1]
+    dout = dout.contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    nb = 0 if bias is None else bias.numel() // (T * T)
+    check(_lib.lib().adell_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, _ptr(out),
+                                         _ptr(dout), _ptr(lse), BH, T, A, Dv, float(scale),
+                                         _ptr(dq), _ptr(dk), _ptr(dv), _stream()))
+    return dq, dk, dv

@@ -213,6 +213,36 @@ int adell_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      float weight_decay, long step, float grad_scale, void* stream);
 int adell_ema_update(float* shadow, const float* param, long n, float decay, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Token-sequence kernels of the ViT encoder (UNETR): vit.py:844-1002,
+ * linear_blocks.py:358-417. (torch.nn.Linear runs on adell_conv3d_* as a
+ * 1x1x1 convolution over the token axis.)
+ * ---------------------------------------------------------------------- */
+/* torch.nn.LayerNorm over the last dim of x [rows][C]; gamma/beta may be NULL;
+ * mean/rstd [rows] are kept for the backward. */
+int adell_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, long rows, int C, float eps, void* stream);
+long adell_layernorm_bwd_workspace(long rows, int C);
+int adell_layernorm_bwd(const float* x, const float* dy, const float* gamma,
+                        const float* mean, const float* rstd, float* dx, float* dgamma,
+                        float* dbeta, long rows, int C, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* out[i] = a[i] + b[i % period] (X + positional_embedding, vit.py:866-867) and the
+ * gradient of b: db[j] = sum_k g[k*period + j]. */
+int adell_add_bcast(const float* a, const float* b, float* out, long n, long period,
+                    void* stream);
+int adell_sum_bcast(const float* g, float* db, long n, long period, void* stream);
+/* softmax(q k^T * scale + bias) v per sequence: q,k [BH][T][A]; v,out [BH][T][Dv];
+ * bias [nbias][T][T] or NULL (sequence bh uses bias[bh % nbias]); lse [BH][T].
+ * F.scaled_dot_product_attention as called at linear_blocks.py:407-414. */
+int adell_attention_fwd(const float* q, const float* k, const float* v, const float* bias,
+                        int nbias, int BH, int T, int A, int Dv, float scale, float* out,
+                        float* lse, void* stream);
+int adell_attention_bwd(const float* q, const float* k, const float* v, const float* bias,
+                        int nbias, const float* out, const float* dout, const float* lse,
+                        int BH, int T, int A, int Dv, float scale, float* dq, float* dk,
+                        float* dv, void* stream);
+
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
 

@@ -36,6 +36,9 @@ from adell_mri.modules.layers.res_blocks import ResidualBlock3d  # noqa: E402
 from adell_mri.modules.segmentation.losses import (  # noqa: E402
     binary_focal_loss, binary_generalized_dice_loss)
 from adell_mri.modules.segmentation.unet import UNet  # noqa: E402
+from adell_mri.modules.segmentation.unetr import UNETR  # noqa: E402
+from adell_mri.modules.layers.linear_blocks import MultiHeadSelfAttention  # noqa: E402
+from adell_mri.modules.layers.vit import TransformerBlock  # noqa: E402
 
 from oracle.weights import fill_state_dict  # noqa: E402
 
@@ -68,10 +71,21 @@ UNET_CASES = {
 }
 
 
+UNETR_CASES = {
+    "unetr3d_small": (dict(image_size=[32, 32, 32], patch_size=[8, 8, 8], number_of_blocks=4,
+                           return_at=[1, 2], embedding_size=64, attention_dim=64, hidden_dim=64,
+                           n_heads=4, mlp_structure=[128], spatial_dimensions=3,
+                           link_type="identity", upscale_type="transpose", norm_type="instance",
+                           padding=1, dropout_param=0.0, activation_fn="swish", in_channels=1,
+                           n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3]),
+                      (2, 1, 32, 32, 32), "uniform"),
+}
+
+
 def make_unet(kw):
     kw = dict(kw)
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
-    net = UNet(**kw)
+    net = (UNETR if "patch_size" in kw else UNet)(**kw)
     net.load_state_dict(fill_state_dict(net.state_dict()))
     return net
 
@@ -99,13 +113,16 @@ def gen_unet(name, kw, shape, dist):
     loss.backward()
     sd_keys = [k for k, _ in net.named_parameters()]
     for k, p in net.named_parameters():
-        out["grad:" + k] = p.grad.numpy().copy()
+        if p.grad is not None:  # parameters the forward never touches have no gradient
+            out["grad:" + k] = p.grad.numpy().copy()
+    out["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in net.named_parameters()])
     # one and two SGD-Nesterov steps as configured at segmentation/pl.py:563-569
     opt = torch.optim.SGD(net.parameters(), lr=5e-4, momentum=0.99, weight_decay=5e-3,
                           nesterov=True)
     opt.step()
-    for k, p in net.named_parameters():
-        out["step1:" + k] = p.detach().numpy().copy()
+    if "patch_size" not in kw:
+        for k, p in net.named_parameters():
+            out["step1:" + k] = p.detach().numpy().copy()
     out["param_keys"] = np.array(sd_keys)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "params", sum(p.numel() for p in net.parameters()), "loss", float(loss))
@@ -132,11 +149,20 @@ def gen_blocks():
     out["loss_dice"] = binary_generalized_dice_loss(p, t, smooth=1e-5, eps=1e-6).numpy()
     out["loss_focal"] = binary_focal_loss(p, t, gamma=1.0, eps=1e-6).numpy()
     out["loss_focal_g2"] = binary_focal_loss(p, t, gamma=2.0, eps=1e-6).numpy()
+    # token blocks (linear_blocks.py:248-417, vit.py:884-1002)
+    xt = torch.randn((2, 24, 32), generator=g)
+    mha = MultiHeadSelfAttention(32, 32, 48, 32, n_heads=4).eval()
+    mha.load_state_dict(fill_state_dict(mha.state_dict()))
+    out["tok_x"] = xt.numpy()
+    out["mha_y"] = mha(xt).detach().numpy()
+    tb = TransformerBlock(32, 32, 32, n_heads=4, mlp_structure=[64]).eval()
+    tb.load_state_dict(fill_state_dict(tb.state_dict()))
+    out["tb_y"] = tb(xt).detach().numpy()
     np.savez_compressed(os.path.join(OUT, "blocks.npz"), **out)
     print("blocks ok")
 
 
 if __name__ == "__main__":
-    for name, (kw, shape, dist) in UNET_CASES.items():
+    for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES}.items():
         gen_unet(name, kw, shape, dist)
     gen_blocks()

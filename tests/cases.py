@@ -23,6 +23,15 @@ UNET_CASES = {
                                    strides=[2] * 3),
 }
 
+UNETR_CASES = {
+    "unetr3d_small": dict(image_size=[32, 32, 32], patch_size=[8, 8, 8], number_of_blocks=4,
+                          return_at=[1, 2], embedding_size=64, attention_dim=64, hidden_dim=64,
+                          n_heads=4, mlp_structure=[128], spatial_dimensions=3,
+                          link_type="identity", upscale_type="transpose", norm_type="instance",
+                          padding=1, dropout_param=0.0, activation_fn="swish", in_channels=1,
+                          n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3]),
+}
+
 
 def oracle_cfg(kw):
     return dict(depth=kw["depth"], kernel_sizes=kw["kernel_sizes"], strides=kw["strides"],
