@@ -43,9 +43,9 @@ def oracle_cfg(kw):
 def grad_rel_err(g, k, got):
     """Relative error of a parameter gradient. Biases that feed a normalisation have a
     mathematically zero gradient (the reference's value is rounding noise), so the
-    scale is floored by 1% of the sibling weight's gradient magnitude."""
+    scale is floored by 10% of the sibling weight's gradient magnitude."""
     ref = g["grad:" + k]
     scale = np.abs(ref).max()
     if k.endswith(".bias") and ("grad:" + k[:-5] + ".weight") in g.files:
-        scale = max(scale, 1e-2 * np.abs(g["grad:" + k[:-5] + ".weight"]).max())
+        scale = max(scale, 1e-1 * np.abs(g["grad:" + k[:-5] + ".weight"]).max())
     return float(np.abs(got - ref).max() / (scale + 1e-12))
