@@ -78,6 +78,11 @@ SIGNATURES = {
     "adell_sum_bcast": (_i, [_vp, _vp, _l, _l, _vp]),
     "adell_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "adell_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "adell_copy_channels": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "adell_interp_nearest_fwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
+    "adell_interp_nearest_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
+    "adell_maxpool3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "adell_maxpool3d_bwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),
 }
 

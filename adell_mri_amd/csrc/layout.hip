@@ -1,0 +1,277 @@
+// Data-movement kernels (HBM-bound, no arithmetic besides index math and, in the
+// backward of the resampler, a fixed-order sum):
+//   * channel concat / split of NDHWC tensors -- the N-way torch.cat of DenseBlock
+//     (adell_mri/modules/layers/standard_blocks.py:365-371); the 2-way decoder
+//     concat never comes here (the conv kernel reads two sources directly);
+//   * nearest-neighbour resampling, F.interpolate(x, size) with its default mode
+//     (standard_blocks.py:368, unet.py:796-799), forward and backward.
+#include "common.h"
+
+// dst[v][coff + c] = src[v][c]   (dir 0)   |   src[v][c] = dst[v][coff + c]  (dir 1)
+__global__ __launch_bounds__(256) void adell_copy_channels_kernel(float* __restrict__ dst,
+                                                                  float* __restrict__ src,
+                                                                  long V, int Cdst, int Csrc,
+                                                                  int coff, int dir, int vec) {
+  if (vec) {
+    const int c4 = Csrc >> 2;
+    const long n = V * c4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+      const long v = i / c4;
+      const int c = (int)(i - v * c4) << 2;
+      float4* d = reinterpret_cast<float4*>(dst + v * Cdst + coff + c);
+      float4* s = reinterpret_cast<float4*>(src + v * Csrc + c);
+      if (dir == 0) *d = *s; else *s = *d;
+    }
+  } else {
+    const long n = V * Csrc;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+      const long v = i / Csrc;
+      const int c = (int)(i - v * Csrc);
+      if (dir == 0) dst[v * Cdst + coff + c] = src[v * Csrc + c];
+      else src[v * Csrc + c] = dst[v * Cdst + coff + c];
+    }
+  }
+}
+
+// direction 0: write `part` [V][Cpart] into channels [coff, coff+Cpart) of `full` [V][Cfull];
+// direction 1: read them back out of `full` into `part`.
+extern "C" int adell_copy_channels(float* full, float* part, long V, int Cfull, int Cpart,
+                                   int coff, int direction, void* stream) {
+  ADELL_REQUIRE(full && part, "copy_channels: null pointer");
+  ADELL_REQUIRE(V > 0 && Cpart > 0 && coff >= 0 && coff + Cpart <= Cfull,
+                "copy_channels: bad channel range");
+  ADELL_REQUIRE(direction == 0 || direction == 1, "copy_channels: direction must be 0/1");
+  const int vec = (Cfull % 4 == 0) && (Cpart % 4 == 0) && (coff % 4 == 0) &&
+                  (((uintptr_t)full | (uintptr_t)part) & 15) == 0;
+  long n = vec ? V * (Cpart / 4) : V * (long)Cpart;
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adell_copy_channels_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, full, part, V, Cfull, Cpart, coff, direction, vec);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+struct ResampleArgs {
+  const float* in;
+  float* out;
+  int N, C, Di, Hi, Wi, Do, Ho, Wo;
+};
+
+// torch's nearest: src = min(floor(dst * in / out), in - 1) (scale computed in float)
+__device__ __forceinline__ int adell_nn_src(int o, int in, int out) {
+  const float scale = (float)in / (float)out;
+  int s = (int)floorf((float)o * scale);
+  return s < in - 1 ? s : in - 1;
+}
+
+__global__ __launch_bounds__(256) void adell_nearest_fwd_kernel(ResampleArgs a) {
+  const long nvox = (long)a.N * a.Do * a.Ho * a.Wo;
+  const long n = nvox * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % a.C);
+    long v = i / a.C;
+    const int x = (int)(v % a.Wo); v /= a.Wo;
+    const int y = (int)(v % a.Ho); v /= a.Ho;
+    const int z = (int)(v % a.Do);
+    const int nb = (int)(v / a.Do);
+    const int sx = adell_nn_src(x, a.Wi, a.Wo), sy = adell_nn_src(y, a.Hi, a.Ho),
+              sz = adell_nn_src(z, a.Di, a.Do);
+    a.out[i] = a.in[((((size_t)nb * a.Di + sz) * a.Hi + sy) * a.Wi + sx) * a.C + c];
+  }
+}
+
+// backward: din[i] = sum of dout over the output voxels whose source is i. The set
+// is an axis-aligned box found by scanning a small candidate range per axis.
+__device__ __forceinline__ void adell_nn_range(int s, int in, int out, int* lo, int* hi) {
+  // candidates around s*out/in; widen by one on both sides and test exactly
+  int a = (int)floorf((float)s * (float)out / (float)in) - 1;
+  int b = (int)ceilf((float)(s + 1) * (float)out / (float)in) + 1;
+  if (a < 0) a = 0;
+  if (b > out) b = out;
+  while (a < b && adell_nn_src(a, in, out) != s) ++a;
+  while (b > a && adell_nn_src(b - 1, in, out) != s) --b;
+  *lo = a;
+  *hi = b;
+}
+
+__global__ __launch_bounds__(256) void adell_nearest_bwd_kernel(ResampleArgs a) {
+  // here a.in = dout [N,Do,Ho,Wo,C], a.out = din [N,Di,Hi,Wi,C]
+  const long n = (long)a.N * a.Di * a.Hi * a.Wi * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % a.C);
+    long v = i / a.C;
+    const int x = (int)(v % a.Wi); v /= a.Wi;
+    const int y = (int)(v % a.Hi); v /= a.Hi;
+    const int z = (int)(v % a.Di);
+    const int nb = (int)(v / a.Di);
+    int x0, x1, y0, y1, z0, z1;
+    adell_nn_range(x, a.Wi, a.Wo, &x0, &x1);
+    adell_nn_range(y, a.Hi, a.Ho, &y0, &y1);
+    adell_nn_range(z, a.Di, a.Do, &z0, &z1);
+    float s = 0.f;
+    for (int oz = z0; oz < z1; ++oz)
+      for (int oy = y0; oy < y1; ++oy)
+        for (int ox = x0; ox < x1; ++ox)
+          s += a.in[((((size_t)nb * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.C + c];
+    a.out[i] = s;
+  }
+}
+
+static int adell_resample(const float* in, float* out, int N, int C, int Di, int Hi, int Wi,
+                          int Do, int Ho, int Wo, int bwd, hipStream_t st) {
+  ADELL_REQUIRE(in && out, "resample: null pointer");
+  ADELL_REQUIRE(N > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0,
+                "resample: bad dims");
+  ResampleArgs a = {in, out, N, C, Di, Hi, Wi, Do, Ho, Wo};
+  const long n = (long)N * C * (bwd ? (long)Di * Hi * Wi : (long)Do * Ho * Wo);
+  long blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (bwd)
+    hipLaunchKernelGGL(adell_nearest_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(adell_nearest_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_interp_nearest_fwd(const float* x, float* y, int N, int C, int Di, int Hi,
+                                        int Wi, int Do, int Ho, int Wo, void* stream) {
+  return adell_resample(x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, 0, (hipStream_t)stream);
+}
+extern "C" int adell_interp_nearest_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi,
+                                        int Wi, int Do, int Ho, int Wo, void* stream) {
+  return adell_resample(dy, dx, N, C, Di, Hi, Wi, Do, Ho, Wo, 1, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// MaxPool3d (torch.nn.MaxPool3d, ceil_mode=False, dilation 1; padding with -inf):
+// unet.py:335,368,595-603 (backbone / "resnet" encoders and, through
+// init_encoder_backbone, the U-Net++ encoder), res_net.py:180,209.
+// idx keeps the argmax as the flat (z*H + y)*W + x position inside the item.
+// ---------------------------------------------------------------------------
+struct PoolArgs {
+  const float* x;
+  float* y;
+  int* idx;
+  const float* dy;
+  float* dx;
+  int N, C, D, H, W, Do, Ho, Wo, KD, KH, KW, SD, SH, SW, PD, PH, PW;
+};
+
+__global__ __launch_bounds__(256) void adell_maxpool3d_fwd_kernel(PoolArgs a) {
+  const long n = (long)a.N * a.Do * a.Ho * a.Wo * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % a.C);
+    long v = i / a.C;
+    const int ox = (int)(v % a.Wo); v /= a.Wo;
+    const int oy = (int)(v % a.Ho); v /= a.Ho;
+    const int oz = (int)(v % a.Do);
+    const int nb = (int)(v / a.Do);
+    float best = -INFINITY;
+    int bi = -1;
+    for (int kz = 0; kz < a.KD; ++kz) {
+      const int z = oz * a.SD - a.PD + kz;
+      if (z < 0 || z >= a.D) continue;
+      for (int ky = 0; ky < a.KH; ++ky) {
+        const int y = oy * a.SH - a.PH + ky;
+        if (y < 0 || y >= a.H) continue;
+        for (int kx = 0; kx < a.KW; ++kx) {
+          const int x = ox * a.SW - a.PW + kx;
+          if (x < 0 || x >= a.W) continue;
+          const int flat = (z * a.H + y) * a.W + x;
+          const float t = a.x[((size_t)nb * a.D * a.H * a.W + flat) * a.C + c];
+          if (t > best || bi < 0) {
+            best = t;
+            bi = flat;
+          }
+        }
+      }
+    }
+    a.y[i] = best;
+    a.idx[i] = bi;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_maxpool3d_bwd_kernel(PoolArgs a) {
+  const long n = (long)a.N * a.D * a.H * a.W * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % a.C);
+    long v = i / a.C;
+    const int x = (int)(v % a.W); v /= a.W;
+    const int y = (int)(v % a.H); v /= a.H;
+    const int z = (int)(v % a.D);
+    const int nb = (int)(v / a.D);
+    const int flat = (z * a.H + y) * a.W + x;
+    // windows o with o*S - P <= pos <= o*S - P + K - 1
+    int z0 = (z + a.PD - a.KD + a.SD) / a.SD, z1 = (z + a.PD) / a.SD;
+    int y0 = (y + a.PH - a.KH + a.SH) / a.SH, y1 = (y + a.PH) / a.SH;
+    int x0 = (x + a.PW - a.KW + a.SW) / a.SW, x1 = (x + a.PW) / a.SW;
+    if (z + a.PD - a.KD + 1 < 0) z0 = 0;
+    if (y + a.PH - a.KH + 1 < 0) y0 = 0;
+    if (x + a.PW - a.KW + 1 < 0) x0 = 0;
+    if (z0 < 0) z0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x0 < 0) x0 = 0;
+    if (z1 >= a.Do) z1 = a.Do - 1;
+    if (y1 >= a.Ho) y1 = a.Ho - 1;
+    if (x1 >= a.Wo) x1 = a.Wo - 1;
+    float s = 0.f;
+    for (int oz = z0; oz <= z1; ++oz)
+      for (int oy = y0; oy <= y1; ++oy)
+        for (int ox = x0; ox <= x1; ++ox) {
+          const size_t o = ((((size_t)nb * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.C + c;
+          if (a.idx[o] == flat) s += a.dy[o];
+        }
+    a.dx[i] = s;
+  }
+}
+
+static int adell_pool_fill(PoolArgs* a, const adell_conv3d_desc* d) {
+  ADELL_REQUIRE(d != nullptr, "maxpool: null descriptor");
+  ADELL_REQUIRE(d->N > 0 && d->C0 > 0 && d->D > 0 && d->H > 0 && d->W > 0, "maxpool: bad dims");
+  ADELL_REQUIRE(d->KD >= 1 && d->KH >= 1 && d->KW >= 1 && d->SD >= 1 && d->SH >= 1 && d->SW >= 1,
+                "maxpool: bad kernel/stride");
+  ADELL_REQUIRE(2 * d->PD <= d->KD && 2 * d->PH <= d->KH && 2 * d->PW <= d->KW,
+                "maxpool: padding must be at most half the kernel");
+  ADELL_REQUIRE(d->Do == (d->D + 2 * d->PD - d->KD) / d->SD + 1 &&
+                    d->Ho == (d->H + 2 * d->PH - d->KH) / d->SH + 1 &&
+                    d->Wo == (d->W + 2 * d->PW - d->KW) / d->SW + 1,
+                "maxpool: output dims do not match");
+  a->N = d->N; a->C = d->C0; a->D = d->D; a->H = d->H; a->W = d->W;
+  a->Do = d->Do; a->Ho = d->Ho; a->Wo = d->Wo;
+  a->KD = d->KD; a->KH = d->KH; a->KW = d->KW; a->SD = d->SD; a->SH = d->SH; a->SW = d->SW;
+  a->PD = d->PD; a->PH = d->PH; a->PW = d->PW;
+  return ADELL_OK;
+}
+
+// The pooling geometry reuses adell_conv3d_desc (C0 = channels; C1, Cout ignored).
+extern "C" int adell_maxpool3d_fwd(const adell_conv3d_desc* d, const float* x, float* y,
+                                   int32_t* argmax, void* stream) {
+  PoolArgs a = {};
+  int rc = adell_pool_fill(&a, d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(x && y && argmax, "maxpool_fwd: null pointer");
+  a.x = x; a.y = y; a.idx = argmax;
+  long blocks = ((long)a.N * a.Do * a.Ho * a.Wo * a.C + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adell_maxpool3d_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_maxpool3d_bwd(const adell_conv3d_desc* d, const float* dy,
+                                   const int32_t* argmax, float* dx, void* stream) {
+  PoolArgs a = {};
+  int rc = adell_pool_fill(&a, d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(dy && argmax && dx, "maxpool_bwd: null pointer");
+  a.dy = dy; a.idx = const_cast<int32_t*>(argmax); a.dx = dx;
+  long blocks = ((long)a.N * a.D * a.H * a.W * a.C + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adell_maxpool3d_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

@@ -292,3 +292,62 @@ def attention(q, k, v, bias=None, scale=None):
     if scale is None:
         scale = 1.0 / (q.shape[-1] ** 0.5)
     return _AttentionFn.apply(q, k, v, bias, float(scale))
+
+
+# ---- data movement with autograd (U-Net++ dense links) ---------------------------------------
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.sizes = [t.shape[1] for t in tensors]
+        return ops.cat_channels(list(tensors))
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(ops.split_channels(g, ctx.sizes))
+
+
+def cat_channels(tensors):
+    """torch.cat(tensors, 1) for [N,C,D,H,W] activations, staying NDHWC."""
+    tensors = list(tensors)
+    return tensors[0] if len(tensors) == 1 else _CatFn.apply(*tensors)
+
+
+class _NearestFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, size):
+        ctx.in_size = tuple(x.shape[2:])
+        return ops.interp_nearest(x, size)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.interp_nearest(g, None, backward_from=ctx.in_size), None
+
+
+def interpolate_nearest(x, size):
+    """F.interpolate(x, size) (default mode='nearest') for 5-D activations."""
+    size = tuple(int(s) for s in size)
+    if tuple(x.shape[2:]) == size:
+        return x
+    return _NearestFn.apply(x, size)
+
+
+class _MaxPool3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, padding):
+        y, idx = ops.maxpool3d_fwd(x, kernel, stride, padding)
+        ctx.save_for_backward(idx)
+        ctx.conf = (tuple(x.shape), kernel, stride, padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        shape, kernel, stride, padding = ctx.conf
+        return ops.maxpool3d_bwd(dy, idx, shape, kernel, stride, padding), None, None, None
+
+
+def max_pool3d(x, kernel, stride=None, padding=0):
+    """torch.nn.functional.max_pool3d (ceil_mode=False, dilation=1)."""
+    kernel = ops._triple(kernel)
+    stride = kernel if stride is None else ops._triple(stride)
+    return _MaxPool3dFn.apply(x, kernel, stride, ops._triple(padding))

@@ -61,3 +61,14 @@ class ConvTranspose3d(torch.nn.ConvTranspose3d):
                 "HIP ConvTranspose3d implements kernel=stride=2, padding=0 (the U-Net decoder "
                 f"upscaling); got k={self.kernel_size} s={self.stride} p={self.padding}")
         return HF.conv_transpose3d_k2s2(X, self.weight, self.bias)
+
+
+class MaxPool3d(torch.nn.MaxPool3d):
+    def forward(self, X):
+        if self.ceil_mode or self.return_indices or ops_triple(self.dilation) != (1, 1, 1):
+            raise AdellHipError("HIP MaxPool3d supports ceil_mode=False, dilation=1 only")
+        return HF.max_pool3d(X, self.kernel_size, self.stride, self.padding)
+
+
+def ops_triple(v):
+    return (v,) * 3 if isinstance(v, int) else tuple(v)

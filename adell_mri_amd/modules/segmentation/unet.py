@@ -22,7 +22,7 @@ import torch
 from ... import functional as HF
 from ..._lib import AdellHipError
 from ..layers.adn_fn import ActDropNorm, norm_fn_dict
-from ..layers.conv import Conv2d, Conv3d, ConvTranspose3d
+from ..layers.conv import Conv2d, Conv3d, ConvTranspose3d, MaxPool3d
 from ..layers.regularization import UOut
 from ..layers.res_blocks import ResidualBlock3d
 from ..layers.utils import crop_to_size
@@ -182,10 +182,12 @@ class UNet(torch.nn.Module):
         """ResidualBlock3d (+ MaxPool3d when strided): unet.py:344-379."""
         inter_d = int(in_d) if in_d > 32 else None
         stride = _per_dim(1 if stride is None else stride, 3)
+        block = ResidualBlock3d(in_d, kernel_size, inter_d, out_d, adn_fn=self.adn_fn)
         if any(s > 1 for s in stride):
-            raise NotImplementedError("conv_type='resnet' with stride > 1 needs the MaxPool3d "
-                                      "kernel (next row)")
-        return ResidualBlock3d(in_d, kernel_size, inter_d, out_d, adn_fn=self.adn_fn)
+            padding = _per_dim(0 if padding is None else padding, 3)
+            new_padding = [p // 2 if p > s // 2 else p for p, s in zip(padding, stride)]
+            return torch.nn.Sequential(block, MaxPool3d(stride, stride, padding=new_padding))
+        return block
 
     def adn_fn(self, s: int) -> torch.nn.Module:
         return ActDropNorm(in_channels=s, ordering="NDA", norm_fn=self.norm_op,
@@ -249,7 +251,16 @@ class UNet(torch.nn.Module):
         self.encoding_operations.append(torch.nn.ModuleList([op, torch.nn.Identity()]))
 
     def init_encoder_backbone(self):
-        raise NotImplementedError("backbone encoders need the MaxPool3d kernel (next row)")
+        """Every downsampling op becomes MaxPool(kernel=s, stride=s, padding=s//2)
+        (unet.py:588-603); the last level keeps Identity."""
+        if self.spatial_dimensions != 3:
+            raise NotImplementedError("2-D max pooling has no HIP kernel yet")
+        for i in range(len(self.encoding_operations)):
+            s = np.array(_per_dim(self.strides[i], self.spatial_dimensions))
+            self.encoding_operations[i][1] = MaxPool3d(kernel_size=tuple(int(j) for j in s),
+                                                       stride=tuple(int(j) for j in s),
+                                                       padding=tuple(int(j) for j in s // 2))
+        self.encoding_operations[-1][1] = torch.nn.Identity()
 
     def init_decoder(self):
         self.decoding_operations = torch.nn.ModuleList([])

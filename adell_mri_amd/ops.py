@@ -470,3 +470,74 @@ def attention_bwd(q, k, v, bias, out, dout, lse, scale):
                                          _ptr(dout), _ptr(lse), BH, T, A, Dv, float(scale),
                                          _ptr(dq), _ptr(dk), _ptr(dv), _stream()))
     return dq, dk, dv
+
+
+# ---- data movement (U-Net++ dense links) ----------------------------------------------------
+def cat_channels(tensors):
+    """Channel concat of NDHWC tensors [N,Ci,D,H,W] -> [N,sum Ci,D,H,W]."""
+    _require_cuda(*tensors)
+    tensors = [ndhwc(t) for t in tensors]
+    N, _, D, H, W = tensors[0].shape
+    Ct = sum(t.shape[1] for t in tensors)
+    out = new_act(N, Ct, D, H, W, tensors[0].device)
+    off = 0
+    for t in tensors:
+        assert tuple(t.shape[2:]) == (D, H, W) and t.shape[0] == N
+        check(_lib.lib().adell_copy_channels(_ptr(out), _ptr(t), N * D * H * W, Ct, t.shape[1], off,
+                                             0, _stream()))
+        off += t.shape[1]
+    return out
+
+
+def split_channels(full, sizes):
+    full = ndhwc(full)
+    N, Ct, D, H, W = full.shape
+    outs, off = [], 0
+    for c in sizes:
+        t = new_act(N, c, D, H, W, full.device)
+        check(_lib.lib().adell_copy_channels(_ptr(full), _ptr(t), N * D * H * W, Ct, c, off, 1,
+                                             _stream()))
+        outs.append(t)
+        off += c
+    return outs
+
+
+def interp_nearest(x, size, backward_from=None):
+    """Forward: x [N,C,Di,Hi,Wi] -> [N,C,*size]. With backward_from=(Di,Hi,Wi): x is the
+    output gradient and the result the input gradient."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    if backward_from is None:
+        Di, Hi, Wi = x.shape[2:]
+        Do, Ho, Wo = size
+        y = new_act(N, C, Do, Ho, Wo, x.device)
+        check(_lib.lib().adell_interp_nearest_fwd(_ptr(x), _ptr(y), N, C, Di, Hi, Wi, Do, Ho, Wo,
+                                                  _stream()))
+        return y
+    Di, Hi, Wi = backward_from
+    Do, Ho, Wo = x.shape[2:]
+    dx = new_act(N, C, Di, Hi, Wi, x.device)
+    check(_lib.lib().adell_interp_nearest_bwd(_ptr(x), _ptr(dx), N, C, Di, Hi, Wi, Do, Ho, Wo,
+                                              _stream()))
+    return dx
+
+
+def maxpool3d_fwd(x, kernel, stride, padding):
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    d = make_conv_desc(N, (D, H, W), C, 0, C, kernel, stride, padding)
+    y = new_act(N, C, d.Do, d.Ho, d.Wo, x.device)
+    idx = torch.empty((N, d.Do, d.Ho, d.Wo, C), device=x.device, dtype=torch.int32)
+    check(_lib.lib().adell_maxpool3d_fwd(ctypes.byref(d), _ptr(x), _ptr(y), _ptr(idx), _stream()))
+    return y, idx
+
+
+def maxpool3d_bwd(dy, idx, in_shape, kernel, stride, padding):
+    dy = ndhwc(dy)
+    N, C, D, H, W = in_shape
+    d = make_conv_desc(N, (D, H, W), C, 0, C, kernel, stride, padding)
+    dx = new_act(N, C, D, H, W, dy.device)
+    check(_lib.lib().adell_maxpool3d_bwd(ctypes.byref(d), _ptr(dy), _ptr(idx), _ptr(dx), _stream()))
+    return dx

@@ -243,6 +243,27 @@ int adell_attention_bwd(const float* q, const float* k, const float* v, const fl
                         int BH, int T, int A, int Dv, float scale, float* dq, float* dk,
                         float* dv, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Data movement for the U-Net++ dense links (standard_blocks.py:365-371):
+ * N-way channel concat / split of NDHWC tensors, and nearest-neighbour
+ * resampling (F.interpolate's default mode) with its backward.
+ * ---------------------------------------------------------------------- */
+/* direction 0: full[v][coff + c] = part[v][c]; direction 1: the reverse copy. */
+int adell_copy_channels(float* full, float* part, long V, int Cfull, int Cpart, int coff,
+                        int direction, void* stream);
+int adell_interp_nearest_fwd(const float* x, float* y, int N, int C, int Di, int Hi, int Wi,
+                             int Do, int Ho, int Wo, void* stream);
+int adell_interp_nearest_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi, int Wi,
+                             int Do, int Ho, int Wo, void* stream);
+
+/* torch.nn.MaxPool3d (ceil_mode False, dilation 1, -inf padding): unet.py:335,368,
+ * 595-603, res_net.py:180,209. Geometry in an adell_conv3d_desc (C0 = channels, C1 and
+ * Cout ignored); argmax [N][Do][Ho][Wo][C] holds the winner's (z*H+y)*W+x. */
+int adell_maxpool3d_fwd(const adell_conv3d_desc* d, const float* x, float* y,
+                        int32_t* argmax, void* stream);
+int adell_maxpool3d_bwd(const adell_conv3d_desc* d, const float* dy, const int32_t* argmax,
+                        float* dx, void* stream);
+
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
 

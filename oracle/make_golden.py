@@ -37,6 +37,7 @@ from adell_mri.modules.segmentation.losses import (  # noqa: E402
     binary_focal_loss, binary_generalized_dice_loss)
 from adell_mri.modules.segmentation.unet import UNet  # noqa: E402
 from adell_mri.modules.segmentation.unetr import UNETR  # noqa: E402
+from adell_mri.modules.segmentation.unetpp import UNetPlusPlus  # noqa: E402
 from adell_mri.modules.layers.linear_blocks import MultiHeadSelfAttention  # noqa: E402
 from adell_mri.modules.layers.vit import TransformerBlock  # noqa: E402
 
@@ -82,10 +83,20 @@ UNETR_CASES = {
 }
 
 
+UNETPP_CASES = {
+    "unetpp3d_small": (dict(spatial_dimensions=3, conv_type="regular", upscale_type="transpose",
+                            norm_type="instance", padding=1, dropout_param=0.0,
+                            activation_fn="swish", in_channels=2, n_classes=2,
+                            depth=[8, 8, 16, 32], kernel_sizes=[3] * 4, strides=[2] * 4,
+                            _cls="unetpp"), (1, 2, 16, 16, 16), "uniform"),
+}
+
+
 def make_unet(kw):
     kw = dict(kw)
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
-    net = (UNETR if "patch_size" in kw else UNet)(**kw)
+    cls = {"unetpp": UNetPlusPlus}.get(kw.pop("_cls", None), UNETR if "patch_size" in kw else UNet)
+    net = cls(**kw)
     net.load_state_dict(fill_state_dict(net.state_dict()))
     return net
 
@@ -98,9 +109,13 @@ def gen_unet(name, kw, shape, dist):
     net = make_unet(kw).eval()  # eval(): dropout off, instance norm unaffected
     out = {"x": x.numpy(), "y": y.numpy()}
     # forward parity target: logits (north_star: within 1e-4 rel)
-    logits, _ = net(x, return_logits=True)
+    logits = net(x, return_logits=True)[0]
     out["logits"] = logits.detach().numpy()
-    prob, _ = net(x)
+    res = net(x)
+    prob = res[0]
+    if len(res) == 3 and isinstance(res[2], list):  # U-Net++ auxiliary heads
+        for i, a in enumerate(res[2]):
+            out[f"aux{i}"] = a.detach().numpy()
     out["prob"] = prob.detach().numpy()
     # training-step arithmetic (segmentation/pl.py:218-222,284-317): dice + focal
     d = binary_generalized_dice_loss(prob, y, smooth=1e-5, eps=1e-6)
@@ -120,7 +135,7 @@ def gen_unet(name, kw, shape, dist):
     opt = torch.optim.SGD(net.parameters(), lr=5e-4, momentum=0.99, weight_decay=5e-3,
                           nesterov=True)
     opt.step()
-    if "patch_size" not in kw:
+    if "patch_size" not in kw and "_cls" not in kw:
         for k, p in net.named_parameters():
             out["step1:" + k] = p.detach().numpy().copy()
     out["param_keys"] = np.array(sd_keys)
@@ -163,6 +178,6 @@ def gen_blocks():
 
 
 if __name__ == "__main__":
-    for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES}.items():
+    for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES, **UNETPP_CASES}.items():
         gen_unet(name, kw, shape, dist)
     gen_blocks()

@@ -32,6 +32,13 @@ UNETR_CASES = {
                           n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3]),
 }
 
+UNETPP_CASES = {
+    "unetpp3d_small": dict(spatial_dimensions=3, conv_type="regular", upscale_type="transpose",
+                           norm_type="instance", padding=1, dropout_param=0.0,
+                           activation_fn="swish", in_channels=2, n_classes=2,
+                           depth=[8, 8, 16, 32], kernel_sizes=[3] * 4, strides=[2] * 4),
+}
+
 
 def oracle_cfg(kw):
     return dict(depth=kw["depth"], kernel_sizes=kw["kernel_sizes"], strides=kw["strides"],
