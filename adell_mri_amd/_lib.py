@@ -50,6 +50,11 @@ SIGNATURES = {
     "adell_conv3d_fwd_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "adell_conv3d_bwd_data": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
+    "adell_pack_weight_f16x3_bytes": (_l, [_i, _i, _i, _i]),
+    "adell_pack_weight_f16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "adell_conv3d_fwd_ntiles_f16x3": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 9),
+    "adell_conv3d_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
     "adell_conv3d_bwd_weight_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_bwd_weight": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_bias_grad_workspace": (_l, [_l, _i]),

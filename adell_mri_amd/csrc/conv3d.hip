@@ -1,6 +1,7 @@
 // Host launchers + C-ABI for the 3D convolution family (see conv_igemm.h for
 // the kernel). Everything here is NDHWC fp32 on raw device pointers.
 #include "conv_igemm.h"
+#include "conv_igemm_f16.h"
 
 // ---------------------------------------------------------------------------
 // Tile selection. BM voxels are laid out as a TX x TY x TZ brick (powers of 2).
@@ -147,16 +148,15 @@ extern "C" int adell_conv3d_fwd_ntiles(const adell_conv3d_desc* d) {
          adell_cdiv(d->Do, 1 << t.lTZ);
 }
 
-extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
-                                const float* x1, const float* w_packed,
-                                const float* bias, const float* residual,
-                                float* y, float* stat_partials, void* stream) {
+static int adell_fill_fwd(ConvArgs& a, const adell_conv3d_desc* d, const float* x0,
+                          const float* x1, const float* bias, const float* residual, float* y,
+                          float* stat_partials) {
   int rc = adell_check_desc(d);
   if (rc != ADELL_OK) return rc;
-  ADELL_REQUIRE(x0 && w_packed && y, "conv_fwd: null pointer");
+  ADELL_REQUIRE(x0 && y, "conv_fwd: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_fwd: C1 > 0 needs x1");
-  ConvArgs a = {};
-  a.x0 = x0; a.x1 = x1; a.w = w_packed; a.bias = bias; a.res = residual;
+  a = ConvArgs{};
+  a.x0 = x0; a.x1 = x1; a.w = nullptr; a.bias = bias; a.res = residual;
   a.y0 = y; a.y1 = nullptr; a.part = stat_partials;
   a.D = d->D; a.H = d->H; a.W = d->W;
   a.C0 = d->C0; a.C1 = d->C1; a.Cin = d->C0 + d->C1; a.Cout = d->Cout;
@@ -166,6 +166,18 @@ extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
   a.UPS = 1;
   a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo;
   a.ysplit = d->Cout; a.shuffle = 0; a.Cs = d->Cout;
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
+                                const float* x1, const float* w_packed,
+                                const float* bias, const float* residual,
+                                float* y, float* stat_partials, void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_packed, "conv_fwd: null weights");
+  a.w = w_packed;
   return adell_conv_dispatch(a, d->N, (hipStream_t)stream);
 }
 
@@ -173,12 +185,11 @@ extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
 // two sources of the forward's virtual concat. Needs equal strides in all dims
 // when any stride is 2 (UPS is one factor); w_packed_bwd is
 // [flipped tap][Cout][Cin] (adell_pack_weight mode 1).
-extern "C" int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
-                                     const float* w_packed_bwd, float* dx0,
-                                     float* dx1, void* stream) {
+static int adell_fill_bwd_data(ConvArgs& a, const adell_conv3d_desc* d, const float* dy,
+                               float* dx0, float* dx1) {
   int rc = adell_check_desc(d);
   if (rc != ADELL_OK) return rc;
-  ADELL_REQUIRE(dy && w_packed_bwd && dx0, "conv_bwd_data: null pointer");
+  ADELL_REQUIRE(dy && dx0, "conv_bwd_data: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || dx1, "conv_bwd_data: C1 > 0 needs dx1");
   if (!(d->SD == d->SH && d->SH == d->SW)) {
     adell_set_error("conv_bwd_data: anisotropic strides unsupported");
@@ -188,8 +199,8 @@ extern "C" int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy
     adell_set_error("conv_bwd_data: pad > k-1 unsupported");
     return ADELL_E_UNSUPPORTED;
   }
-  ConvArgs a = {};
-  a.x0 = dy; a.x1 = nullptr; a.w = w_packed_bwd; a.bias = nullptr; a.res = nullptr;
+  a = ConvArgs{};
+  a.x0 = dy; a.x1 = nullptr; a.w = nullptr; a.bias = nullptr; a.res = nullptr;
   a.y0 = dx0; a.y1 = dx1; a.part = nullptr;
   a.D = d->Do; a.H = d->Ho; a.W = d->Wo;
   a.C0 = d->Cout; a.C1 = 0; a.Cin = d->Cout; a.Cout = d->C0 + d->C1;
@@ -199,6 +210,17 @@ extern "C" int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy
   a.UPS = d->SD;
   a.Do = d->D; a.Ho = d->H; a.Wo = d->W;
   a.ysplit = d->C0; a.shuffle = 0; a.Cs = a.Cout;
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
+                                     const float* w_packed_bwd, float* dx0,
+                                     float* dx1, void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_packed_bwd, "conv_bwd_data: null weights");
+  a.w = w_packed_bwd;
   return adell_conv_dispatch(a, d->N, (hipStream_t)stream);
 }
 
@@ -300,4 +322,143 @@ extern "C" int adell_pack_weight(const float* w, float* out, int mode, int dim0,
                      (hipStream_t)stream, w, out, mode, dim0, dim1, KD, KH, KW);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// f16x3 path (conv_igemm_f16.h): fp32 tensors in and out, 3 f16 MFMAs per K-block.
+// ---------------------------------------------------------------------------
+template <int MT, int NT, int WM, int WN>
+static int adell_launch_conv_f16(const ConvArgs& a, const ConvF16Extra& e, dim3 grid, size_t lds,
+                                 hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN>;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, e);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// Tile plan of the f16x3 kernel: the heuristic brick, or (when its halo does not fit
+// LDS, i.e. stride 2) the small-brick configuration of the same channel width.
+static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
+  ConvTile t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, g_conv_force_cfg);
+  size_t lds = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    a.lTX = t.lTX; a.lTY = t.lTY; a.lTZ = t.lTZ;
+    const int TX = 1 << t.lTX, TY = 1 << t.lTY, TZ = 1 << t.lTZ;
+    a.ntx = adell_cdiv(a.Wo, TX);
+    a.nty = adell_cdiv(a.Ho, TY);
+    a.ntz = adell_cdiv(a.Do, TZ);
+    a.HX = (TX - 1) * a.SW + a.KW;
+    a.HY = (TY - 1) * a.SH + a.KH;
+    a.HZ = (TZ - 1) * a.SD + a.KD;
+    a.VP = a.HX * a.HY * a.HZ;
+    lds = (size_t)a.VP * 64 + (size_t)a.KH * a.KW * t.BN * 64 + 64;
+    const size_t red = (size_t)4 * t.BN * 2 * sizeof(float);
+    if (lds < red) lds = red;
+    if (lds <= 160 * 1024) break;
+    const int next = t.BN == 64 ? 2 : 3;
+    if (t.cfg == next || g_conv_force_cfg >= 0) break;
+    t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, next);
+  }
+  if (lds > 160 * 1024) {
+    adell_set_error("conv f16x3: LDS need %zu B exceeds 160 KiB", lds);
+    return ADELL_E_UNSUPPORTED;
+  }
+  *tile = t;
+  *lds_out = lds;
+  return ADELL_OK;
+}
+
+static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_t st) {
+  ConvTile t;
+  size_t lds;
+  int rc = adell_plan_f16(a, N, &t, &lds);
+  if (rc != ADELL_OK) return rc;
+  a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
+           (((uintptr_t)a.x1 & 15) == 0);
+  a.vecw = 1;
+  const long nsp = (long)a.ntx * a.nty * a.ntz;
+  if (nsp > 0x7fffffffL || N > 65535) {
+    adell_set_error("conv: grid too large");
+    return ADELL_E_UNSUPPORTED;
+  }
+  dim3 grid((unsigned)nsp, (unsigned)adell_cdiv(a.Cout, t.BN), (unsigned)N);
+  switch (t.cfg) {
+    case 0: return adell_launch_conv_f16<2, 2, 4, 1>(a, e, grid, lds, st);
+    case 1: return adell_launch_conv_f16<2, 1, 4, 1>(a, e, grid, lds, st);
+    case 2: return adell_launch_conv_f16<1, 1, 2, 2>(a, e, grid, lds, st);
+    default: return adell_launch_conv_f16<1, 1, 4, 1>(a, e, grid, lds, st);
+  }
+}
+
+extern "C" int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d) {
+  ConvArgs a;
+  float dummy;
+  if (adell_fill_fwd(a, d, &dummy, &dummy, nullptr, nullptr, &dummy, nullptr) != ADELL_OK)
+    return ADELL_E_BADARG;
+  ConvTile t;
+  size_t lds;
+  if (adell_plan_f16(a, d->N, &t, &lds) != ADELL_OK) return ADELL_E_UNSUPPORTED;
+  return a.ntx * a.nty * a.ntz;
+}
+
+extern "C" long adell_pack_weight_f16x3_bytes(int mode, int dim0, int dim1, int taps) {
+  if (mode < 0 || mode > 1 || dim0 <= 0 || dim1 <= 0 || taps <= 0) return ADELL_E_BADARG;
+  const long N = mode == 0 ? dim0 : dim1, K = mode == 0 ? dim1 : dim0;
+  return (long)taps * N * ((K + 15) / 16) * 64;
+}
+
+// w: canonical conv weight [Cout=dim0][Cin=dim1][taps]. out: split fp16 tiles
+// (adell_pack_weight_f16x3_bytes). wscale: 2 floats of device scratch; wscale[0]
+// receives the factor that undoes the per-layer power-of-two scale.
+extern "C" int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode,
+                                       int dim0, int dim1, int KD, int KH, int KW,
+                                       void* stream) {
+  ADELL_REQUIRE(w && out && wscale, "pack_weight_f16x3: null pointer");
+  ADELL_REQUIRE(mode == 0 || mode == 1, "pack_weight_f16x3: mode must be 0 (fwd) or 1 (bwd-data)");
+  ADELL_REQUIRE(dim0 > 0 && dim1 > 0 && KD > 0 && KH > 0 && KW > 0, "pack_weight_f16x3: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int taps = KD * KH * KW;
+  const long n = (long)dim0 * dim1 * taps;
+  unsigned* amax = reinterpret_cast<unsigned*>(wscale + 1);
+  ADELL_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adell_absmax_kernel, dim3(blocks), dim3(256), 0, st, w, n, amax);
+  const long total = adell_pack_weight_f16x3_bytes(mode, dim0, dim1, taps) / 4;
+  int pb = (int)((total + 255) / 256);
+  if (pb > 4096) pb = 4096;
+  hipLaunchKernelGGL(adell_pack_weight_f16_kernel, dim3(pb), dim3(256), 0, st, w, (_Float16*)out,
+                     (const unsigned*)amax, wscale, mode, dim0, dim1, taps);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x0,
+                                      const float* x1, const void* w_split,
+                                      const float* wscale, const float* bias,
+                                      const float* residual, float* y, float* stat_partials,
+                                      void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
+  ConvF16Extra e = {(const _Float16*)w_split, wscale};
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
+}
+
+extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
+                                           const void* w_split_bwd, const float* wscale,
+                                           float* dx0, float* dx1, void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale};
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }

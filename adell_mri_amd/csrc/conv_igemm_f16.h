@@ -1,0 +1,387 @@
+// Implicit-GEMM 3D convolution with fp32 operands computed on the f16 MFMA by
+// error-compensated splitting ("f16x3"):
+//
+//     a = a_hi + a_lo,  b = b_hi + b_lo     (a_hi = fp16(a), a_lo = fp16(a - a_hi))
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (drops a_lo*b_lo ~ 2^-22 |ab|)
+//
+// Every product of two fp16 values is exact in the MFMA's fp32 accumulator, so the
+// result carries ~22 bits per product -- fp32-class accuracy at 3 f16 MFMAs per
+// K-block, i.e. 16/3 = 5.3x the rate of v_mfma_f32_32x32x2_f32.
+//
+// Range: fp16 has a 5-bit exponent, so each staged 16-channel chunk of the input
+// brick is scaled by a power of two chosen from the block-wide absmax of that
+// chunk (max lands in [2^13, 2^14)); when the scale changes between chunks the
+// fp32 accumulators are rescaled by the exact power-of-two ratio. Weights carry
+// one power-of-two scale per layer (computed by the pack kernel). Both scales
+// are undone in the epilogue. No tensor-wide statistics are needed, so the
+// kernel serves activations (forward) and gradients (backward-data) alike.
+//
+// Tiling is the fp32 kernel's (conv_igemm.h): M = TX x TY x TZ voxel brick, N = 32
+// or 64 channels, 4 waves. LDS (all fp16, 64-byte rows, 16-byte slots XOR-swizzled
+// by (row >> 2) & 3 so that ds_read_b128 fragments are conflict-free):
+//   sA[halo voxel][hi c0..7 | hi c8..15 | lo c0..7 | lo c8..15]
+//   sB[tap of one kz plane][n][same four slots]
+#pragma once
+#include "conv_igemm.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct ConvF16Extra {
+  const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
+  const float* wscale;   // device scalar: 2^-kw (undoes the per-layer weight scale)
+};
+
+__device__ __forceinline__ void adell_split8(const float* v, float scale, half8* hi, half8* lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float t = v[j] * scale;
+    const _Float16 h = (_Float16)t;
+    (*hi)[j] = h;
+    (*lo)[j] = (_Float16)(t - (float)h);
+  }
+}
+
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
+  constexpr int BN = WN * NT * 32, CC = 16;
+  extern __shared__ float smem[];
+  char* sA = reinterpret_cast<char*>(smem);
+  const int HV = a.HX * a.HY * a.HZ;
+  char* sB = sA + (size_t)HV * 64;
+  float* sMax = reinterpret_cast<float*>(sB + (size_t)a.KH * a.KW * BN * 64);  // [4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int t = blockIdx.x;
+  const int tx = t % a.ntx;
+  t /= a.ntx;
+  const int ty = t % a.nty;
+  const int tz = t / a.nty;
+  const int n0 = blockIdx.y * BN;
+  const int nb = blockIdx.z;
+  const int ox0 = tx << a.lTX, oy0 = ty << a.lTY, oz0 = tz << a.lTZ;
+  const int HXY = a.HX * a.HY;
+  const int lx0 = ox0 * a.SW - a.PW, ly0 = oy0 * a.SH - a.PH, lz0 = oz0 * a.SD - a.PD;
+  const int tpg = a.KH * a.KW;  // taps per group (one kz plane)
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int arow[MT];  // halo voxel index of this lane's A row at tap (0,0,0)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = (wm * MT + mt) * 32 + li;
+    const int x = m & ((1 << a.lTX) - 1);
+    const int y = (m >> a.lTX) & ((1 << a.lTY) - 1);
+    const int z = m >> (a.lTX + a.lTY);
+    arow[mt] = ((z * a.SD) * a.HY + y * a.SH) * a.HX + x * a.SW;
+  }
+  int boffh[NT], boffl[NT];  // byte offsets of this lane's B fragments inside one tap
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = (wn * NT + nt) * 32 + li;
+    const int sw = (n >> 2) & 3;
+    boffh[nt] = n * 64 + ((lh ^ sw) << 4);
+    boffl[nt] = n * 64 + (((2 + lh) ^ sw) << 4);
+  }
+
+  // loads the 16 channels [c0, c0+16) of halo voxel hv (zeros outside the tensor)
+  auto load16 = [&](int hv, int c0, float* v) {
+    const int hz = hv / HXY;
+    const int rem = hv - hz * HXY;
+    const int hy = rem / a.HX;
+    const int hx = rem - hy * a.HX;
+    int rx = lx0 + hx, ry = ly0 + hy, rz = lz0 + hz;
+    bool ok = (rx >= 0) & (ry >= 0) & (rz >= 0);
+    if (a.UPS > 1) {
+      ok = ok & (rx % a.UPS == 0) & (ry % a.UPS == 0) & (rz % a.UPS == 0);
+      rx /= a.UPS;
+      ry /= a.UPS;
+      rz /= a.UPS;
+    }
+    ok = ok & (rx < a.W) & (ry < a.H) & (rz < a.D);
+#pragma unroll
+    for (int j = 0; j < CC; ++j) v[j] = 0.f;
+    if (!ok) return;
+    const size_t gv = ((size_t)(nb * a.D + rz) * a.H + ry) * a.W + rx;
+    if (a.vecx) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = c0 + 4 * q;
+        const float* p = nullptr;
+        if (c < a.C0)
+          p = a.x0 + gv * a.C0 + c;
+        else if (c < a.Cin)
+          p = a.x1 + gv * a.C1 + (c - a.C0);
+        if (p) {
+          const float4 f = *reinterpret_cast<const float4*>(p);
+          v[4 * q + 0] = f.x;
+          v[4 * q + 1] = f.y;
+          v[4 * q + 2] = f.z;
+          v[4 * q + 3] = f.w;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CC; ++j) {
+        const int c = c0 + j;
+        if (c < a.C0)
+          v[j] = a.x0[gv * a.C0 + c];
+        else if (c < a.Cin)
+          v[j] = a.x1[gv * a.C1 + (c - a.C0)];
+      }
+    }
+  };
+
+  const int nchunk = (a.Cin + CC - 1) / CC;
+  int kA_prev = 0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * CC;
+    // ---- pass 1: block-wide absmax of this chunk of the halo brick ---------
+    float mx = 0.f;
+    for (int hv = tid; hv < HV; hv += 256) {
+      float v[CC];
+      load16(hv, c0, v);
+#pragma unroll
+      for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(v[j]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __syncthreads();  // previous chunk's MFMAs are done: LDS may be overwritten
+    if (lane == 0) sMax[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+    int kA = 0;
+    {
+      const int ebits = (__float_as_int(mx) >> 23) & 0xff;
+      if (ebits > 0 && ebits < 255) kA = 13 - (ebits - 127);
+      if (kA > 100) kA = 100;
+      if (kA < -100) kA = -100;
+    }
+    const float scaleA = __int_as_float((kA + 127) << 23);
+    if (ch > 0 && kA != kA_prev) {
+      const float f = __int_as_float((kA - kA_prev + 127) << 23);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+    }
+    kA_prev = kA;
+    // ---- pass 2: split into fp16 hi/lo and write the swizzled LDS brick -----
+    for (int hv = tid; hv < HV; hv += 256) {
+      float v[CC];
+      load16(hv, c0, v);
+      half8 h0, l0, h1, l1;
+      adell_split8(v, scaleA, &h0, &l0);
+      adell_split8(v + 8, scaleA, &h1, &l1);
+      const int sw = (hv >> 2) & 3;
+      char* row = sA + (size_t)hv * 64;
+      *reinterpret_cast<half8*>(row + ((0 ^ sw) << 4)) = h0;
+      *reinterpret_cast<half8*>(row + ((1 ^ sw) << 4)) = h1;
+      *reinterpret_cast<half8*>(row + ((2 ^ sw) << 4)) = l0;
+      *reinterpret_cast<half8*>(row + ((3 ^ sw) << 4)) = l1;
+    }
+    for (int kz = 0; kz < a.KD; ++kz) {
+      if (kz > 0) __syncthreads();  // previous tap group consumed
+      // ---- stage the weight slice of this kz plane: [tpg][BN][4 slots] -----
+      for (int it = tid; it < tpg * BN * 4; it += 256) {
+        const int slot = it & 3;
+        const int n = (it >> 2) % BN;
+        const int tl = (it >> 2) / BN;
+        const int tap = kz * tpg + tl;
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + n < a.Cout)
+          f = *reinterpret_cast<const float4*>(
+              reinterpret_cast<const char*>(e.wh) +
+              (((size_t)tap * a.Cout + n0 + n) * nchunk + ch) * 64 + slot * 16);
+        *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) = f;
+      }
+      __syncthreads();
+      // ---- 3 f16 MFMAs per (tap, 32x32 tile) -------------------------------
+      int kx = 0, ky = 0;
+      for (int tl = 0; tl < tpg; ++tl) {
+        const int aoff = (kz * a.HY + ky) * a.HX + kx;
+        half8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int hv = arow[mt] + aoff;
+          const int sw = (hv >> 2) & 3;
+          const char* row = sA + (size_t)hv * 64;
+          ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
+          al[mt] = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
+        }
+        const char* bt = sB + (size_t)tl * BN * 64;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bh[nt] = *reinterpret_cast<const half8*>(bt + boffh[nt]);
+          bl[nt] = *reinterpret_cast<const half8*>(bt + boffl[nt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+        if (++kx == a.KW) {
+          kx = 0;
+          ++ky;
+        }
+      }
+    }
+  }
+
+  // ---- epilogue (same contract as the fp32 kernel) ---------------------------
+  const float outscale = __int_as_float((127 - kA_prev) << 23) * e.wscale[0];
+  float s1[NT], s2[NT], bcol[NT];
+  float* colptr[NT];
+  int rowmul[NT];
+  bool nok[NT];
+  int ncol[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    s1[nt] = s2[nt] = 0.f;
+    const int n = n0 + (wn * NT + nt) * 32 + li;
+    ncol[nt] = n;
+    nok[nt] = n < a.Cout;
+    bcol[nt] = 0.f;
+    colptr[nt] = a.y0;
+    rowmul[nt] = 0;
+    if (nok[nt]) {
+      if (a.shuffle) {
+        const int sub = n / a.Cs, co = n - sub * a.Cs;
+        const int sx = sub & 1, sy = (sub >> 1) & 1, sz = sub >> 2;
+        colptr[nt] = a.y0 + ((size_t)(sz * 2 * a.Ho + sy) * (2 * a.Wo) + sx) * a.Cs + co;
+        rowmul[nt] = a.Cs;
+        if (a.bias) bcol[nt] = a.bias[co];
+      } else {
+        if (n < a.ysplit) {
+          colptr[nt] = a.y0 + n;
+          rowmul[nt] = a.ysplit;
+        } else {
+          colptr[nt] = a.y1 + (n - a.ysplit);
+          rowmul[nt] = a.Cout - a.ysplit;
+        }
+        if (a.bias) bcol[nt] = a.bias[n];
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = (wm * MT + mt) * 32 + row;
+      const int x = ox0 + (m & ((1 << a.lTX) - 1));
+      const int y = oy0 + ((m >> a.lTX) & ((1 << a.lTY) - 1));
+      const int z = oz0 + (m >> (a.lTX + a.lTY));
+      const bool rok = (x < a.Wo) & (y < a.Ho) & (z < a.Do);
+      const int ov = ((nb * a.Do + z) * a.Ho + y) * a.Wo + x;
+      const int ovs = ((nb * 2 * a.Do + 2 * z) * (2 * a.Ho) + 2 * y) * (2 * a.Wo) + 2 * x;
+      const int rowoff = a.shuffle ? ovs : ov;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (rok && nok[nt]) {
+          float v = acc[mt][nt][r] * outscale + bcol[nt];
+          if (a.res) v += a.res[(size_t)ov * a.Cout + ncol[nt]];
+          colptr[nt][(size_t)rowoff * rowmul[nt]] = v;
+          s1[nt] += v;
+          s2[nt] += v * v;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (a.part) {
+    __syncthreads();
+    float* red = smem;  // [WM][BN][2]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float t1 = s1[nt] + __shfl_xor(s1[nt], 32, 64);
+      const float t2 = s2[nt] + __shfl_xor(s2[nt], 32, 64);
+      if (lh == 0) {
+        const int col = (wn * NT + nt) * 32 + li;
+        red[(wm * BN + col) * 2 + 0] = t1;
+        red[(wm * BN + col) * 2 + 1] = t2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < a.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          t1 += red[(w * BN + tid) * 2 + 0];
+          t2 += red[(w * BN + tid) * 2 + 1];
+        }
+        const size_t ntiles = (size_t)a.ntx * a.nty * a.ntz;
+        float* p = a.part + ((nb * ntiles + blockIdx.x) * a.Cout + n) * 2;
+        p[0] = t1;
+        p[1] = t2;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Weight packing for the f16x3 kernel: absmax -> power-of-two scale -> split.
+// ---------------------------------------------------------------------------
+__global__ void adell_absmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
+  float mx = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    mx = fmaxf(mx, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order as uints
+}
+
+// mode 0: conv [Cout=A][Cin=B][taps] -> rows n = cout, k = cin, tap order kept
+// mode 1: same source -> rows n = cin, k = cout, taps flipped (backward-data)
+__global__ void adell_pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
+                                             const unsigned* __restrict__ absmax,
+                                             float* __restrict__ wscale, int mode, int A, int B,
+                                             int taps) {
+  const int N = mode == 0 ? A : B;   // GEMM columns
+  const int K = mode == 0 ? B : A;   // GEMM depth
+  const int nchunk = (K + 15) / 16;
+  const float mx = __uint_as_float(absmax[0]);
+  int kw = 0;
+  const int ebits = (__float_as_int(mx) >> 23) & 0xff;
+  if (ebits > 0 && ebits < 255) kw = 13 - (ebits - 127);
+  if (kw > 100) kw = 100;
+  if (kw < -100) kw = -100;
+  const float scale = __int_as_float((kw + 127) << 23);
+  if (blockIdx.x == 0 && threadIdx.x == 0) wscale[0] = __int_as_float((127 - kw) << 23);
+  const long total = (long)taps * N * nchunk * 16;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 15);
+    long r = i >> 4;
+    const int ch = (int)(r % nchunk); r /= nchunk;
+    const int n = (int)(r % N);
+    const int tap = (int)(r / N);
+    const int k = ch * 16 + j;
+    float v = 0.f;
+    if (k < K) {
+      if (mode == 0)
+        v = w[((long)n * B + k) * taps + tap];
+      else
+        v = w[((long)k * B + n) * taps + (taps - 1 - tap)];
+    }
+    const float tsc = v * scale;
+    const _Float16 h = (_Float16)tsc;
+    _Float16* o = out + (((long)tap * N + n) * nchunk + ch) * 32;
+    o[j] = h;
+    o[16 + j] = (_Float16)(tsc - (float)h);
+  }
+}

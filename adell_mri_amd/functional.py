@@ -12,12 +12,26 @@ Statistics produced by the conv epilogue ride on the output tensor as
 ``y``; they are dropped by any other consumer.
 """
 import itertools
+import os
 
 import torch
 
 from . import ops
 
 _dropout_counter = itertools.count(1)
+
+# How the MFMA convolutions multiply fp32 operands:
+#   "f16x3": three f16 MFMAs on error-compensated hi/lo splits (fp32-class accuracy,
+#            ~2^-22 per product; 5.3x the fp32 MFMA rate)            [default]
+#   "fp32":  v_mfma_f32_32x32x2_f32, bit-exact k-ordered fp32 FMA chain
+CONV_PRECISION = os.environ.get("ADELL_CONV_PRECISION", "f16x3")
+
+
+def set_conv_precision(mode):
+    global CONV_PRECISION
+    if mode not in ("f16x3", "fp32"):
+        raise ValueError("conv precision must be 'f16x3' or 'fp32'")
+    CONV_PRECISION = mode
 
 
 class _Ref:
@@ -36,15 +50,17 @@ def _packed(w, mode):
     if cache is None:
         cache = {}
         w._adell_packs = cache
-    hit = cache.get(mode)
+    split = CONV_PRECISION == "f16x3" and mode in (0, 1)
+    key = (mode, split)
+    hit = cache.get(key)
     tag = (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)
     if hit is not None and hit[0] == tag:
         return hit[1]
     wd = w.detach()
     if wd.dim() == 2:  # torch.nn.Linear weight == 1x1x1 convolution weight
         wd = wd.view(wd.shape[0], wd.shape[1], 1, 1, 1)
-    p = ops.pack_weight(wd, mode)
-    cache[mode] = (tag, p)
+    p = ops.pack_weight_f16x3(wd, mode) if split else ops.pack_weight(wd, mode)
+    cache[key] = (tag, p)
     return p
 
 

@@ -136,10 +136,39 @@ def pack_weight(w, mode):
     return out
 
 
+class SplitWeight:
+    """Weights packed for the f16x3 kernel: fp16 hi/lo tiles + the scale-undo scalar."""
+
+    __slots__ = ("halfs", "scale")
+
+    def __init__(self, halfs, scale):
+        self.halfs, self.scale = halfs, scale
+
+
+def pack_weight_f16x3(w, mode):
+    """mode 0: forward operand, mode 1: backward-data operand, of a conv weight
+    [Cout, Cin, kD, kH, kW]."""
+    _require_cuda(w)
+    w = w.contiguous()
+    d0, d1, kd, kh, kw = w.shape
+    nbytes = _lib.lib().adell_pack_weight_f16x3_bytes(mode, d0, d1, kd * kh * kw)
+    if nbytes < 0:
+        check(int(nbytes))
+    halfs = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
+    scale = torch.empty(2, device=w.device, dtype=torch.float32)
+    check(_lib.lib().adell_pack_weight_f16x3(_ptr(w), _ptr(halfs), _ptr(scale), mode, d0, d1, kd,
+                                             kh, kw, _stream()))
+    return SplitWeight(halfs, scale)
+
+
 def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, residual=None,
                want_stats=False):
-    """y = conv(cat(x0, x1)) + bias + residual ; optional (sum, sumsq) partials."""
-    _require_cuda(x0, x1, w_packed, bias, residual)
+    """y = conv(cat(x0, x1)) + bias + residual ; optional (sum, sumsq) partials.
+    ``w_packed``: fp32 GEMM-B tensor (exact fp32 MFMA) or a SplitWeight (f16x3 MFMA)."""
+    split = isinstance(w_packed, SplitWeight)
+    if not split:
+        _require_cuda(w_packed)
+    _require_cuda(x0, x1, bias, residual)
     x0 = ndhwc(x0)
     N, C0, D, H, W = x0.shape
     C1 = 0
@@ -154,26 +183,43 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
         assert tuple(residual.shape) == tuple(y.shape)
     part = None
     if want_stats:
-        nt = _lib.lib().adell_conv3d_fwd_ntiles(ctypes.byref(d))
+        fn = _lib.lib().adell_conv3d_fwd_ntiles_f16x3 if split else _lib.lib().adell_conv3d_fwd_ntiles
+        nt = fn(ctypes.byref(d))
         if nt < 0:
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
-    check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
-        ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual), _ptr(y),
-        _ptr(part), _stream())))
+    if split:
+        check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
+                     lambda: _lib.lib().adell_conv3d_fwd_f16x3(
+                         ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed.halfs),
+                         _ptr(w_packed.scale), _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
+                         _stream())))
+    else:
+        check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
+            ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual),
+            _ptr(y), _ptr(part), _stream())))
     return y, part
 
 
 def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding):
-    _require_cuda(dy, w_packed_bwd)
+    split = isinstance(w_packed_bwd, SplitWeight)
+    _require_cuda(dy)
     dy = ndhwc(dy)
     N, Cout = dy.shape[:2]
     d = make_conv_desc(N, tuple(in_size), C0, C1, Cout, kernel, stride, padding)
     assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
     dx0 = new_act(N, C0, *in_size, dy.device)
     dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
-    check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_bwd_data(
-        ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd), _ptr(dx0), _ptr(dx1), _stream())))
+    if split:
+        check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
+                     lambda: _lib.lib().adell_conv3d_bwd_data_f16x3(
+                         ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs),
+                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _stream())))
+    else:
+        check(_timed("adell_conv_igemm_kernel", _conv_flops(d),
+                     lambda: _lib.lib().adell_conv3d_bwd_data(
+                         ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd), _ptr(dx0), _ptr(dx1),
+                         _stream())))
     return dx0, dx1
 
 

@@ -95,6 +95,24 @@ int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
                           const float* w_packed_bwd, float* dx0, float* dx1,
                           void* stream);
 
+/* The same two operations on the f16 MFMA with error-compensated operand splitting
+ * ("f16x3": a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, fp32 accumulate, ~2^-22 relative
+ * per product; per-chunk / per-layer power-of-two scaling inside the kernel). Tensors
+ * stay fp32; only the packed weights differ: adell_pack_weight_f16x3 (mode 0 forward,
+ * mode 1 backward-data) writes adell_pack_weight_f16x3_bytes(...) bytes of split fp16
+ * tiles plus wscale (2 floats of device scratch, wscale[0] = the undo factor). */
+long adell_pack_weight_f16x3_bytes(int mode, int dim0, int dim1, int taps);
+int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode, int dim0,
+                            int dim1, int KD, int KH, int KW, void* stream);
+int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d);
+int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                           const void* w_split, const float* wscale, const float* bias,
+                           const float* residual, float* y, float* stat_partials,
+                           void* stream);
+int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
+                                const void* w_split_bwd, const float* wscale, float* dx0,
+                                float* dx1, void* stream);
+
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
  * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias
  * gradient db[Cout] = sum over voxels of dy from the same pass. workspace:

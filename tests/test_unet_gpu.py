@@ -26,8 +26,19 @@ def build(kw, device):
     return net.to(device)
 
 
+@pytest.fixture(params=["f16x3", "fp32"])
+def precision(request):
+    """Both MFMA modes of the convolutions must meet the parity bar."""
+    from adell_mri_amd import functional as HF
+
+    old = HF.CONV_PRECISION
+    HF.set_conv_precision(request.param)
+    yield request.param
+    HF.set_conv_precision(old)
+
+
 @pytest.mark.parametrize("name", list(UNET_CASES))
-def test_logits_within_1e4_of_reference(cuda, name):
+def test_logits_within_1e4_of_reference(cuda, name, precision):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     net = build(UNET_CASES[name], cuda).eval()
     x = torch.from_numpy(g["x"]).to(cuda)
@@ -39,12 +50,13 @@ def test_logits_within_1e4_of_reference(cuda, name):
     got = logits.cpu().numpy()
     assert got.shape == ref.shape
     rel = np.abs(got - ref).max() / np.abs(ref).max()
+    print(f"{name} [{precision}] logits rel err {rel:.2e}")
     assert rel < 1e-4, rel
     np.testing.assert_allclose(prob.cpu().numpy(), g["prob"], rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", list(UNET_CASES))
-def test_parameter_gradients_match_reference(cuda, name):
+def test_parameter_gradients_match_reference(cuda, name, precision):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     net = build(UNET_CASES[name], cuda).eval()  # eval: dropout off, as in the fixture
     x = torch.from_numpy(g["x"]).to(cuda)

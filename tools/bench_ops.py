@@ -33,7 +33,10 @@ for (c0, c1), sz, cout, k, s, p in SHAPES:
     x1 = ops.ndhwc(torch.randn(1, c1, sz, sz, sz, device=dev)) if c1 else None
     w = torch.randn(cout, cin, k, k, k, device=dev) * 0.05
     b = torch.randn(cout, device=dev)
-    wp, wpb = ops.pack_weight(w, 0), ops.pack_weight(w, 1)
+    if "f16" in which:
+        wp, wpb = ops.pack_weight_f16x3(w, 0), ops.pack_weight_f16x3(w, 1)
+    else:
+        wp, wpb = ops.pack_weight(w, 0), ops.pack_weight(w, 1)
     y, _ = ops.conv3d_fwd(x0, wp, b, cout, k, s, p, x1=x1, want_stats=True)
     osz = y.shape[2]
     flops = 2.0 * osz ** 3 * cout * cin * k ** 3
