@@ -414,27 +414,17 @@ extern "C" long adell_pack_weight_f16x3_bytes(int mode, int dim0, int dim1, int 
 }
 
 // w: canonical conv weight [Cout=dim0][Cin=dim1][taps]. out: split fp16 tiles
-// (adell_pack_weight_f16x3_bytes). wscale: 2 floats of device scratch; wscale[0]
-// receives the factor that undoes the per-layer power-of-two scale.
+// (adell_pack_weight_f16x3_bytes). wscale: one float per GEMM column (mode 0: Cout,
+// mode 1: Cin): the factor that undoes that column's power-of-two scale.
 extern "C" int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode,
                                        int dim0, int dim1, int KD, int KH, int KW,
                                        void* stream) {
   ADELL_REQUIRE(w && out && wscale, "pack_weight_f16x3: null pointer");
   ADELL_REQUIRE(mode == 0 || mode == 1, "pack_weight_f16x3: mode must be 0 (fwd) or 1 (bwd-data)");
   ADELL_REQUIRE(dim0 > 0 && dim1 > 0 && KD > 0 && KH > 0 && KW > 0, "pack_weight_f16x3: bad dims");
-  hipStream_t st = (hipStream_t)stream;
-  const int taps = KD * KH * KW;
-  const long n = (long)dim0 * dim1 * taps;
-  unsigned* amax = reinterpret_cast<unsigned*>(wscale + 1);
-  ADELL_CHECK_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), st));
-  int blocks = (int)((n + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adell_absmax_kernel, dim3(blocks), dim3(256), 0, st, w, n, amax);
-  const long total = adell_pack_weight_f16x3_bytes(mode, dim0, dim1, taps) / 4;
-  int pb = (int)((total + 255) / 256);
-  if (pb > 4096) pb = 4096;
-  hipLaunchKernelGGL(adell_pack_weight_f16_kernel, dim3(pb), dim3(256), 0, st, w, (_Float16*)out,
-                     (const unsigned*)amax, wscale, mode, dim0, dim1, taps);
+  const int N = mode == 0 ? dim0 : dim1;
+  hipLaunchKernelGGL(adell_pack_weight_f16_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, w,
+                     (_Float16*)out, wscale, mode, dim0, dim1, KD * KH * KW);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

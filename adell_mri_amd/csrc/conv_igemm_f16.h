@@ -28,7 +28,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 struct ConvF16Extra {
   const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
-  const float* wscale;   // device scalar: 2^-kw (undoes the per-layer weight scale)
+  const float* wscale;   // [Cout] 2^-kw[n]: undoes the per-output-channel weight scale
 };
 
 __device__ __forceinline__ void adell_split8(const float* v, float scale, half8* hi, half8* lo) {
@@ -160,9 +160,10 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     int kA = 0;
     {
       const int ebits = (__float_as_int(mx) >> 23) & 0xff;
-      if (ebits > 0 && ebits < 255) kA = 13 - (ebits - 127);
-      if (kA > 100) kA = 100;
-      if (kA < -100) kA = -100;
+      // max lands in [2^6, 2^14): multiples of 8 so the scale rarely changes per chunk
+      if (ebits > 0 && ebits < 255) kA = 8 * ((13 - (ebits - 127)) >> 3);
+      if (kA > 96) kA = 96;
+      if (kA < -96) kA = -96;
     }
     const float scaleA = __int_as_float((kA + 127) << 23);
     if (ch > 0 && kA != kA_prev) {
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
   }
 
   // ---- epilogue (same contract as the fp32 kernel) ---------------------------
-  const float outscale = __int_as_float((127 - kA_prev) << 23) * e.wscale[0];
-  float s1[NT], s2[NT], bcol[NT];
+  const float ascale = __int_as_float((127 - kA_prev) << 23);
+  float s1[NT], s2[NT], bcol[NT], oscale[NT];
   float* colptr[NT];
   int rowmul[NT];
   bool nok[NT];
@@ -254,9 +255,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     ncol[nt] = n;
     nok[nt] = n < a.Cout;
     bcol[nt] = 0.f;
+    oscale[nt] = 0.f;
     colptr[nt] = a.y0;
     rowmul[nt] = 0;
     if (nok[nt]) {
+      oscale[nt] = ascale * e.wscale[n];
       if (a.shuffle) {
         const int sub = n / a.Cs, co = n - sub * a.Cs;
         const int sx = sub & 1, sy = (sub >> 1) & 1, sz = sub >> 2;
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if (rok && nok[nt]) {
-          float v = acc[mt][nt][r] * outscale + bcol[nt];
+          float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];
           if (a.res) v += a.res[(size_t)ov * a.Cout + ncol[nt]];
           colptr[nt][(size_t)rowoff * rowmul[nt]] = v;
           s1[nt] += v;
@@ -334,51 +337,44 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
 }
 
 // ---------------------------------------------------------------------------
-// Weight packing for the f16x3 kernel: absmax -> power-of-two scale -> split.
+// Weight packing for the f16x3 kernel. One block per GEMM column n (an output
+// channel): absmax over that column's taps x K -> power-of-two scale -> hi/lo split.
+// mode 0: conv [Cout=A][Cin=B][taps] -> column n = cout, k = cin, tap order kept
+// mode 1: same source -> column n = cin, k = cout, taps flipped (backward-data)
 // ---------------------------------------------------------------------------
-__global__ void adell_absmax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ out) {
-  float mx = 0.f;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    mx = fmaxf(mx, fabsf(w[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));  // non-negative floats order as uints
-}
-
-// mode 0: conv [Cout=A][Cin=B][taps] -> rows n = cout, k = cin, tap order kept
-// mode 1: same source -> rows n = cin, k = cout, taps flipped (backward-data)
-__global__ void adell_pack_weight_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ out,
-                                             const unsigned* __restrict__ absmax,
-                                             float* __restrict__ wscale, int mode, int A, int B,
-                                             int taps) {
+__global__ __launch_bounds__(256) void adell_pack_weight_f16_kernel(
+    const float* __restrict__ w, _Float16* __restrict__ out, float* __restrict__ wscale,
+    int mode, int A, int B, int taps) {
+  __shared__ float smx[4];
   const int N = mode == 0 ? A : B;   // GEMM columns
   const int K = mode == 0 ? B : A;   // GEMM depth
   const int nchunk = (K + 15) / 16;
-  const float mx = __uint_as_float(absmax[0]);
+  const int n = blockIdx.x;
+  auto src = [&](int tap, int k) -> long {
+    return mode == 0 ? ((long)n * B + k) * taps + tap
+                     : ((long)k * B + n) * taps + (taps - 1 - tap);
+  };
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < taps * K; i += 256) mx = fmaxf(mx, fabsf(w[src(i / K, i % K)]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
   int kw = 0;
   const int ebits = (__float_as_int(mx) >> 23) & 0xff;
   if (ebits > 0 && ebits < 255) kw = 13 - (ebits - 127);
   if (kw > 100) kw = 100;
   if (kw < -100) kw = -100;
   const float scale = __int_as_float((kw + 127) << 23);
-  if (blockIdx.x == 0 && threadIdx.x == 0) wscale[0] = __int_as_float((127 - kw) << 23);
-  const long total = (long)taps * N * nchunk * 16;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
-       i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 15);
-    long r = i >> 4;
-    const int ch = (int)(r % nchunk); r /= nchunk;
-    const int n = (int)(r % N);
-    const int tap = (int)(r / N);
+  if (threadIdx.x == 0) wscale[n] = __int_as_float((127 - kw) << 23);
+  const int total = taps * nchunk * 16;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int j = i & 15;
+    const int ch = (i >> 4) % nchunk;
+    const int tap = (i >> 4) / nchunk;
     const int k = ch * 16 + j;
-    float v = 0.f;
-    if (k < K) {
-      if (mode == 0)
-        v = w[((long)n * B + k) * taps + tap];
-      else
-        v = w[((long)k * B + n) * taps + (taps - 1 - tap)];
-    }
-    const float tsc = v * scale;
+    const float tsc = (k < K ? w[src(tap, k)] : 0.f) * scale;
     const _Float16 h = (_Float16)tsc;
     _Float16* o = out + (((long)tap * N + n) * nchunk + ch) * 32;
     o[j] = h;

@@ -269,6 +269,18 @@ __global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
   }
 }
 
+// shared with conv_wgrad_f16.hip
+extern "C" int adell_wgrad_reduce_launch(const float* ws, float* out, int R, int ntap, int Cin,
+                                         int Cout, const float* wsdb, float* db, void* stream) {
+  const long total = (long)ntap * Cin * Cout;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     ws, out, R, ntap, Cin, Cout, wsdb, db);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
 struct WgradPlan {
   int lTX, lTY, lTZ, HX, HY, HZ, TCI, TCO, nci, nco, KDg, ngrp, R, maxj;
   size_t lds;

@@ -96,7 +96,8 @@ class _Conv3dFn(torch.autograd.Function):
                 dx1 = None
         want_db = has_bias and need[3]
         if need[2]:
-            dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db)
+            dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db,
+                                       f16x3=(CONV_PRECISION == "f16x3"))
             if want_db:
                 dw, db = dw
             dw = dw.view(weight.shape)

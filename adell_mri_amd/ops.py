@@ -155,7 +155,7 @@ def pack_weight_f16x3(w, mode):
     if nbytes < 0:
         check(int(nbytes))
     halfs = torch.empty(nbytes // 2, device=w.device, dtype=torch.float16)
-    scale = torch.empty(2, device=w.device, dtype=torch.float32)
+    scale = torch.empty(d0 if mode == 0 else d1, device=w.device, dtype=torch.float32)
     check(_lib.lib().adell_pack_weight_f16x3(_ptr(w), _ptr(halfs), _ptr(scale), mode, d0, d1, kd,
                                              kh, kw, _stream()))
     return SplitWeight(halfs, scale)
@@ -227,8 +227,9 @@ def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 4) + 3) // 4, device=device, dtype=torch.float32)
 
 
-def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False):
-    """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout (and db when want_db)."""
+def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f16x3=False):
+    """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout (and db when want_db).
+    f16x3: error-compensated f16 MFMA instead of the fp32 MFMA."""
     _require_cuda(x0, x1, dy)
     x0, dy = ndhwc(x0), ndhwc(dy)
     N, C0, D, H, W = x0.shape
@@ -240,13 +241,18 @@ def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False):
     k = _triple(kernel)
     d = make_conv_desc(N, (D, H, W), C0, C1, Cout, kernel, stride, padding)
     assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
-    nbytes = _lib.lib().adell_conv3d_bwd_weight_workspace(ctypes.byref(d))
+    L = _lib.lib()
+    wsfn, fn, name = ((L.adell_conv3d_bwd_weight_f16x3_workspace, L.adell_conv3d_bwd_weight_f16x3,
+                       "adell_conv_wgrad_f16_kernel") if f16x3 else
+                      (L.adell_conv3d_bwd_weight_workspace, L.adell_conv3d_bwd_weight,
+                       "adell_conv_wgrad_kernel"))
+    nbytes = wsfn(ctypes.byref(d))
     if nbytes < 0:
         check(int(nbytes))
     ws = _workspace(nbytes, x0.device)
     dw = torch.empty((Cout, C0 + C1, *k), device=x0.device, dtype=torch.float32)
     db = torch.empty((Cout,), device=x0.device, dtype=torch.float32) if want_db else None
-    check(_timed("adell_conv_wgrad_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_bwd_weight(
+    check(_timed(name, _conv_flops(d), lambda: fn(
         ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
         ws.numel() * 4, _stream())))
     return (dw, db) if want_db else dw

@@ -100,7 +100,7 @@ int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
  * per product; per-chunk / per-layer power-of-two scaling inside the kernel). Tensors
  * stay fp32; only the packed weights differ: adell_pack_weight_f16x3 (mode 0 forward,
  * mode 1 backward-data) writes adell_pack_weight_f16x3_bytes(...) bytes of split fp16
- * tiles plus wscale (2 floats of device scratch, wscale[0] = the undo factor). */
+ * tiles plus wscale: one undo factor per GEMM column (mode 0: Cout floats, mode 1: Cin). */
 long adell_pack_weight_f16x3_bytes(int mode, int dim0, int dim1, int taps);
 int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode, int dim0,
                             int dim1, int KD, int KH, int KW, void* stream);
@@ -121,6 +121,13 @@ long adell_conv3d_bwd_weight_workspace(const adell_conv3d_desc* d);
 int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* x0,
                             const float* x1, const float* dy, float* dw, float* db,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* The same on the f16 MFMA with error-compensated splitting (f16x3); X and dY get one
+ * power-of-two scale per tensor inside the call. */
+long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc* d);
+int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const float* x0,
+                                  const float* x1, const float* dy, float* dw, float* db,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* db[c] = sum over rows of dy[rows][C] (torch's bias gradient of Conv3d /
  * ConvTranspose3d). workspace >= adell_bias_grad_workspace(rows, C) bytes. */

@@ -95,3 +95,36 @@ def test_concat_residual_f16x3(cuda):
     y, _ = ops.conv3d_fwd(_cl(xa, cuda), wp, _dev(b, cuda), 64, 3, 1, 1, x1=_cl(xb, cuda),
                           residual=_cl(res, cuda))
     assert _relerr(_np(y), ref) < 5e-6
+
+
+WGRAD_CASES = [
+    # N, C0, C1, size, Cout, k, s, p, gscale
+    (1, 32, 0, (8, 8, 8), 32, 3, 1, 1, 1.0),
+    (2, 64, 0, (8, 8, 8), 64, 3, 1, 1, 1e-7),
+    (1, 32, 32, (8, 8, 8), 32, 3, 1, 1, 1.0),
+    (1, 64, 0, (8, 8, 8), 32, 3, 1, 1, 1.0),
+    (1, 32, 0, (16, 16, 16), 32, 3, 2, 1, 1.0),
+    (1, 64, 0, (9, 9, 9), 64, 3, 2, 1, 1e-6),
+    (2, 2, 0, (10, 9, 7), 32, 3, 1, 1, 1.0),
+    (1, 2, 0, (8, 8, 8), 2, 3, 1, 1, 1.0),
+    (1, 32, 0, (8, 8, 8), 1, 1, 1, 0, 1.0),
+    (1, 128, 0, (4, 4, 4), 72, 3, 1, 1, 1.0),
+    (1, 40, 0, (6, 6, 6), 24, 3, 1, 1, 1.0),
+    (1, 16, 0, (5, 1, 9), 16, 3, 1, 1, 1.0),
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,size,Cout,k,s,p,gs", WGRAD_CASES)
+def test_conv3d_bwd_weight_f16x3(cuda, N, C0, C1, size, Cout, k, s, p, gs):
+    rng = np.random.default_rng(21)
+    Cin = C0 + C1
+    x = (rng.standard_normal((N, Cin, *size)) * 3).astype(np.float32)
+    w = np.zeros((Cout, Cin, k, k, k), np.float32)
+    osz = ops.conv_out_size(size, (k,) * 3, (s,) * 3, (p,) * 3)
+    dy = (rng.standard_normal((N, Cout, *osz)) * gs).astype(np.float32)
+    _, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, s, p)
+    x0 = _cl(x[:, :C0], cuda)
+    x1 = _cl(x[:, C0:], cuda) if C1 else None
+    dw, db = ops.conv3d_bwd_weight(x0, _cl(dy, cuda), k, s, p, x1=x1, want_db=True, f16x3=True)
+    assert _relerr(_np(dw), dw_ref) < 5e-6
+    assert _relerr(_np(db), db_ref) < 2e-5

@@ -49,6 +49,6 @@ for (c0, c1), sz, cout, k, s, p in SHAPES:
         t = timeit(lambda: ops.conv3d_bwd_data(dy, wpb, (sz,) * 3, c0, c1, k, s, p))
         line += f" | dX {t:7.3f} ms {flops/t/1e9:6.1f} TF"
     if "bwd_weight" in which:
-        t = timeit(lambda: ops.conv3d_bwd_weight(x0, dy, k, s, p, x1=x1))
+        t = timeit(lambda: ops.conv3d_bwd_weight(x0, dy, k, s, p, x1=x1, f16x3=("f16" in which)))
         line += f" | dW {t:7.3f} ms {flops/t/1e9:6.1f} TF"
     print(line, flush=True)
