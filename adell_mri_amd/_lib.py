@@ -53,12 +53,12 @@ SIGNATURES = {
     "adell_pack_weight_f16x3_bytes": (_l, [_i, _i, _i, _i]),
     "adell_pack_weight_f16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "adell_conv3d_fwd_ntiles_f16x3": (_i, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv3d_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 9),
-    "adell_conv3d_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
+    "adell_conv3d_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10),
+    "adell_conv3d_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
     "adell_conv3d_bwd_weight_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_bwd_weight": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_weight_f16x3_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv3d_bwd_weight_f16x3": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_conv3d_bwd_weight_f16x3": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_bias_grad_workspace": (_l, [_l, _i]),
     "adell_bias_grad": (_i, [_vp, _l, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_k2s2_bwd_weight_workspace": (_l, [_i, _i, _i, _i, _i, _i]),

@@ -433,22 +433,23 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
                                       const float* x1, const void* w_split,
                                       const float* wscale, const float* bias,
                                       const float* residual, float* y, float* stat_partials,
-                                      void* stream) {
+                                      uint32_t* in_absmax, void* stream) {
   ConvArgs a;
   int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
 extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                            const void* w_split_bwd, const float* wscale,
-                                           float* dx0, float* dx1, void* stream) {
+                                           float* dx0, float* dx1, uint32_t* dy_absmax,
+                                           void* stream) {
   ConvArgs a;
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }

@@ -29,6 +29,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 struct ConvF16Extra {
   const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
   const float* wscale;   // [Cout] 2^-kw[n]: undoes the per-output-channel weight scale
+  unsigned* amax_out;    // optional: receives the absmax (float bits) of the input tensor(s)
 };
 
 __device__ __forceinline__ void adell_split8(const float* v, float scale, half8* hi, half8* lo) {
@@ -157,6 +158,9 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     if (lane == 0) sMax[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+    // by-product for the backward-weight kernel: tensor-wide absmax of the input
+    if (e.amax_out != nullptr && tid == 0 && blockIdx.y == 0)
+      atomicMax(e.amax_out, __float_as_uint(mx));
     int kA = 0;
     {
       const int ebits = (__float_as_int(mx) >> 23) & 0xff;

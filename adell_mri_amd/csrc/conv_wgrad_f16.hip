@@ -332,7 +332,8 @@ static int adell_launch_wgrad_f16(const WgradF16Args& a, dim3 grid, size_t lds, 
 static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, const float* x0,
                                 const float* x1, int Cout, int Do, int Ho, int Wo,
                                 const float* dy, int KD, int KH, int KW, int SD, int SH, int SW,
-                                int PD, int PH, int PW, float* out, float* db, void* ws,
+                                int PD, int PH, int PW, float* out, float* db,
+                                const uint32_t* xmax_in, const uint32_t* ymax_in, void* ws,
                                 size_t ws_bytes, hipStream_t st) {
   const int Cin = C0 + C1;
   WgradF16Plan p;
@@ -345,17 +346,23 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   float* slabs = (float*)ws;
   float* wsdb = slabs + (size_t)p.R * ntap * Cin * Cout;
   unsigned* amax = reinterpret_cast<unsigned*>(wsdb + (size_t)p.R * Cout);
-  ADELL_CHECK_HIP(hipMemsetAsync(amax, 0, 4 * sizeof(unsigned), st));
+  // operand scales: taken from the caller when the forward / backward-data kernels
+  // already produced them as a by-product, otherwise one reduction pass each
   const long nx0 = (long)N * D * H * W * C0, nx1 = (long)N * D * H * W * C1;
   const long ny = (long)N * Do * Ho * Wo * Cout;
   auto blocks_for = [](long n) { long b = (n / 4 + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); };
-  hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx0)), dim3(256), 0, st, x0, nx0, amax);
-  if (C1 > 0)
-    hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx1)), dim3(256), 0, st, x1, nx1, amax);
-  hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(ny)), dim3(256), 0, st, dy, ny, amax + 1);
+  if (!xmax_in || !ymax_in) ADELL_CHECK_HIP(hipMemsetAsync(amax, 0, 4 * sizeof(unsigned), st));
+  if (!xmax_in) {
+    hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx0)), dim3(256), 0, st, x0, nx0, amax);
+    if (C1 > 0)
+      hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx1)), dim3(256), 0, st, x1, nx1, amax);
+  }
+  if (!ymax_in)
+    hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(ny)), dim3(256), 0, st, dy, ny, amax + 1);
   WgradF16Args a = {};
   a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = slabs; a.wsdb = db ? wsdb : nullptr;
-  a.xmax = amax; a.ymax = amax + 1;
+  a.xmax = xmax_in ? xmax_in : amax;
+  a.ymax = ymax_in ? ymax_in : amax + 1;
   a.N = N; a.D = D; a.H = H; a.W = W;
   a.C0 = C0; a.C1 = C1; a.Cin = Cin; a.Cout = Cout;
   a.KD = KD; a.KH = KH; a.KW = KW; a.SD = SD; a.SH = SH; a.SW = SW;
@@ -391,13 +398,14 @@ extern "C" long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc*
 
 extern "C" int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const float* x0,
                                              const float* x1, const float* dy, float* dw,
-                                             float* db, void* workspace,
+                                             float* db, const uint32_t* x_absmax,
+                                             const uint32_t* dy_absmax, void* workspace,
                                              size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight_f16x3: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight_f16x3: C1 > 0 needs x1");
   ADELL_REQUIRE(d->KH <= 3 && d->KW <= 3, "conv_bwd_weight_f16x3: kernel up to 3");
   return adell_wgrad_f16_core(d->N, d->D, d->H, d->W, d->C0, d->C1, x0, x1, d->Cout, d->Do,
                               d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
-                              d->PH, d->PW, dw, db, workspace, workspace_bytes,
+                              d->PH, d->PW, dw, db, x_absmax, dy_absmax, workspace, workspace_bytes,
                               (hipStream_t)stream);
 }

@@ -69,8 +69,15 @@ class _Conv3dFn(torch.autograd.Function):
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         stride, padding, want_stats, wref = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
+        # [0]: absmax bits of the input(s), [1]: of dy -- by-products of the f16x3 forward /
+        # backward-data kernels that the backward-weight kernel uses as operand scales
+        amax = None
+        if isinstance(wp, ops.SplitWeight) and ctx.needs_input_grad[2]:
+            amax = torch.zeros(2, device=x0.device, dtype=torch.int32)
         y, part = ops.conv3d_fwd(x0, wp, bias, weight.shape[0], k, stride, padding, x1=x1,
-                                 residual=residual, want_stats=want_stats)
+                                 residual=residual, want_stats=want_stats,
+                                 amax=None if amax is None else amax[0:1])
+        ctx.amax = amax
         ctx.save_for_backward(x0, x1, weight)
         ctx.conf = (k, stride, padding, bias is not None, residual is not None, wref)
         if part is None:
@@ -87,9 +94,14 @@ class _Conv3dFn(torch.autograd.Function):
         dx0 = dx1 = dw = db = dres = None
         C0 = x0.shape[1]
         C1 = 0 if x1 is None else x1.shape[1]
+        amax = ctx.amax
+        dy_amax = None
         if need[0] or (x1 is not None and need[1]):
-            dx0, dx1 = ops.conv3d_bwd_data(dy, _packed(wref.obj, 1), tuple(x0.shape[2:]), C0, C1,
-                                           k, stride, padding)
+            wpb = _packed(wref.obj, 1)
+            if amax is not None and isinstance(wpb, ops.SplitWeight):
+                dy_amax = amax[1:2]
+            dx0, dx1 = ops.conv3d_bwd_data(dy, wpb, tuple(x0.shape[2:]), C0, C1, k, stride,
+                                           padding, amax=dy_amax)
             if not need[0]:
                 dx0 = None
             if x1 is None or not need[1]:
@@ -97,7 +109,9 @@ class _Conv3dFn(torch.autograd.Function):
         want_db = has_bias and need[3]
         if need[2]:
             dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db,
-                                       f16x3=(CONV_PRECISION == "f16x3"))
+                                       f16x3=(CONV_PRECISION == "f16x3"),
+                                       x_amax=None if amax is None else amax[0:1],
+                                       dy_amax=dy_amax)
             if want_db:
                 dw, db = dw
             dw = dw.view(weight.shape)

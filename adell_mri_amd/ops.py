@@ -162,7 +162,7 @@ def pack_weight_f16x3(w, mode):
 
 
 def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, residual=None,
-               want_stats=False):
+               want_stats=False, amax=None):
     """y = conv(cat(x0, x1)) + bias + residual ; optional (sum, sumsq) partials.
     ``w_packed``: fp32 GEMM-B tensor (exact fp32 MFMA) or a SplitWeight (f16x3 MFMA)."""
     split = isinstance(w_packed, SplitWeight)
@@ -193,7 +193,7 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
                      lambda: _lib.lib().adell_conv3d_fwd_f16x3(
                          ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed.halfs),
                          _ptr(w_packed.scale), _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
-                         _stream())))
+                         _ptr(amax), _stream())))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual),
@@ -201,7 +201,7 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
     return y, part
 
 
-def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding):
+def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, amax=None):
     split = isinstance(w_packed_bwd, SplitWeight)
     _require_cuda(dy)
     dy = ndhwc(dy)
@@ -214,7 +214,7 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding):
         check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_bwd_data_f16x3(
                          ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs),
-                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _stream())))
+                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _ptr(amax), _stream())))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_bwd_data(
@@ -227,7 +227,8 @@ def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 4) + 3) // 4, device=device, dtype=torch.float32)
 
 
-def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f16x3=False):
+def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f16x3=False,
+                      x_amax=None, dy_amax=None):
     """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout (and db when want_db).
     f16x3: error-compensated f16 MFMA instead of the fp32 MFMA."""
     _require_cuda(x0, x1, dy)
@@ -252,9 +253,14 @@ def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f
     ws = _workspace(nbytes, x0.device)
     dw = torch.empty((Cout, C0 + C1, *k), device=x0.device, dtype=torch.float32)
     db = torch.empty((Cout,), device=x0.device, dtype=torch.float32) if want_db else None
-    check(_timed(name, _conv_flops(d), lambda: fn(
-        ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
-        ws.numel() * 4, _stream())))
+    if f16x3:
+        check(_timed(name, _conv_flops(d), lambda: fn(
+            ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(x_amax),
+            _ptr(dy_amax), _ptr(ws), ws.numel() * 4, _stream())))
+    else:
+        check(_timed(name, _conv_flops(d), lambda: fn(
+            ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+            ws.numel() * 4, _stream())))
     return (dw, db) if want_db else dw
 
 

@@ -105,13 +105,16 @@ long adell_pack_weight_f16x3_bytes(int mode, int dim0, int dim1, int taps);
 int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode, int dim0,
                             int dim1, int KD, int KH, int KW, void* stream);
 int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d);
+/* in_absmax / dy_absmax (optional, one zero-initialised uint32 on the device): receive
+ * the bit pattern of the absmax of the kernel's input tensor(s) as a by-product;
+ * adell_conv3d_bwd_weight_f16x3 takes them as its operand scales. */
 int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x0, const float* x1,
                            const void* w_split, const float* wscale, const float* bias,
                            const float* residual, float* y, float* stat_partials,
-                           void* stream);
+                           uint32_t* in_absmax, void* stream);
 int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                 const void* w_split_bwd, const float* wscale, float* dx0,
-                                float* dx1, void* stream);
+                                float* dx1, uint32_t* dy_absmax, void* stream);
 
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
  * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias
@@ -123,10 +126,12 @@ int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* x0,
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same on the f16 MFMA with error-compensated splitting (f16x3); X and dY get one
- * power-of-two scale per tensor inside the call. */
+ * power-of-two scale per tensor (x_absmax / dy_absmax from the forward and backward-data
+ * kernels, or NULL to have them reduced inside the call). */
 long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc* d);
 int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const float* x0,
                                   const float* x1, const float* dy, float* dw, float* db,
+                                  const uint32_t* x_absmax, const uint32_t* dy_absmax,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* db[c] = sum over rows of dy[rows][C] (torch's bias gradient of Conv3d /
