@@ -144,13 +144,29 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
   int kA_prev = 0;
   for (int ch = 0; ch < nchunk; ++ch) {
     const int c0 = ch * CC;
-    // ---- pass 1: block-wide absmax of this chunk of the halo brick ---------
+    // ---- load this chunk of the halo brick once (register-resident when the brick
+    // has at most 3 voxels per thread), block-wide absmax, then split to fp16 hi/lo ---
+    constexpr int KEEP = 3;
+    const bool resident = HV <= KEEP * 256;
+    float keep[KEEP][CC];
     float mx = 0.f;
-    for (int hv = tid; hv < HV; hv += 256) {
-      float v[CC];
-      load16(hv, c0, v);
+    if (resident) {
 #pragma unroll
-      for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(v[j]));
+      for (int u = 0; u < KEEP; ++u) {
+        const int hv = tid + 256 * u;
+        if (hv < HV) {
+          load16(hv, c0, keep[u]);
+#pragma unroll
+          for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(keep[u][j]));
+        }
+      }
+    } else {
+      for (int hv = tid; hv < HV; hv += 256) {
+        float v[CC];
+        load16(hv, c0, v);
+#pragma unroll
+        for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(v[j]));
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -180,10 +196,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
           for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
     }
     kA_prev = kA;
-    // ---- pass 2: split into fp16 hi/lo and write the swizzled LDS brick -----
-    for (int hv = tid; hv < HV; hv += 256) {
-      float v[CC];
-      load16(hv, c0, v);
+    auto store_split = [&](int hv, const float* v) {
       half8 h0, l0, h1, l1;
       adell_split8(v, scaleA, &h0, &l0);
       adell_split8(v + 8, scaleA, &h1, &l1);
@@ -193,6 +206,19 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
       *reinterpret_cast<half8*>(row + ((1 ^ sw) << 4)) = h1;
       *reinterpret_cast<half8*>(row + ((2 ^ sw) << 4)) = l0;
       *reinterpret_cast<half8*>(row + ((3 ^ sw) << 4)) = l1;
+    };
+    if (resident) {
+#pragma unroll
+      for (int u = 0; u < KEEP; ++u) {
+        const int hv = tid + 256 * u;
+        if (hv < HV) store_split(hv, keep[u]);
+      }
+    } else {
+      for (int hv = tid; hv < HV; hv += 256) {
+        float v[CC];
+        load16(hv, c0, v);
+        store_split(hv, v);
+      }
     }
     for (int kz = 0; kz < a.KD; ++kz) {
       if (kz > 0) __syncthreads();  // previous tap group consumed
@@ -210,11 +236,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
         *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) = f;
       }
       __syncthreads();
-      // ---- 3 f16 MFMAs per (tap, 32x32 tile) -------------------------------
-      int kx = 0, ky = 0;
-      for (int tl = 0; tl < tpg; ++tl) {
+      // ---- 3 f16 MFMAs per (tap, 32x32 tile); the fragments of tap t+1 are read
+      // while the MFMAs of tap t run (two register sets, statically indexed) -------
+      auto load_frags = [&](int tl, half8* ah, half8* al, half8* bh, half8* bl) {
+        const int ky = tl / a.KW, kx = tl - ky * a.KW;
         const int aoff = (kz * a.HY + ky) * a.HX + kx;
-        half8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int hv = arow[mt] + aoff;
@@ -229,6 +255,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
           bh[nt] = *reinterpret_cast<const half8*>(bt + boffh[nt]);
           bl[nt] = *reinterpret_cast<const half8*>(bt + boffl[nt]);
         }
+      };
+      auto do_mfma = [&](const half8* ah, const half8* al, const half8* bh, const half8* bl) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -237,9 +265,15 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           }
-        if (++kx == a.KW) {
-          kx = 0;
-          ++ky;
+      };
+      half8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+      load_frags(0, ah0, al0, bh0, bl0);
+      for (int tl = 0; tl < tpg; tl += 2) {
+        if (tl + 1 < tpg) load_frags(tl + 1, ah1, al1, bh1, bl1);
+        do_mfma(ah0, al0, bh0, bl0);
+        if (tl + 1 < tpg) {
+          if (tl + 2 < tpg) load_frags(tl + 2, ah0, al0, bh0, bl0);
+          do_mfma(ah1, al1, bh1, bl1);
         }
       }
     }

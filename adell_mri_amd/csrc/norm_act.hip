@@ -295,6 +295,9 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
   }
 }
 
+#define ADELL_EW_UNROLL 4
+__global__ void adell_norm_act_fwd_fast_kernel(NormActArgs a);
+
 static int adell_na_fill(NormActArgs* a, const adell_norm_act_desc* d) {
   ADELL_REQUIRE(d != nullptr, "norm_act: null descriptor");
   ADELL_REQUIRE(d->N > 0 && d->V > 0 && d->C > 0, "norm_act: bad dims");
@@ -337,6 +340,15 @@ extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
   a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
   a.act_w = act_w; a.out = out;
   a.vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0);
+  if (a.vec && adell_is_pow2(d->C) && d->C <= 1024 && (a.VC >> 2) < (1L << 40)) {
+    long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(adell_norm_act_fwd_fast_kernel, dim3((unsigned)bx, (unsigned)d->N),
+                       dim3(256), 0, (hipStream_t)stream, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   hipLaunchKernelGGL(adell_norm_act_fwd_kernel,
                      dim3(adell_ew_blocks(a.vec ? (a.total >> 2) : a.total)), dim3(256), 0,
                      (hipStream_t)stream, a);
@@ -561,6 +573,10 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs 
   }
 }
 
+__global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
+__global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
+#define ADELL_PART_SLAB 2048
+
 static int adell_nab_fill(NormActBwdArgs* a, const adell_norm_act_desc* d) {
   ADELL_REQUIRE(d != nullptr, "norm_act_bwd: null descriptor");
   ADELL_REQUIRE(d->N > 0 && d->V > 0 && d->C > 0, "norm_act_bwd: bad dims");
@@ -604,6 +620,7 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
   a.act_w = act_w; a.dx = dx;
   const bool vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
                    (((uintptr_t)dout & 15) == 0) && (((uintptr_t)dx & 15) == 0);
+  const bool fast = vec && adell_is_pow2(d->C) && d->C <= 1024;
   if (mean || dgamma || dbeta) {
     ADELL_REQUIRE(workspace && (long)workspace_bytes >= adell_norm_act_bwd_workspace(d),
                   "norm_act_bwd: workspace too small");
@@ -612,7 +629,11 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
     float* c2 = c1 + (size_t)d->N * d->C;
     a.part = part; a.c1 = c1; a.c2 = c2;
     dim3 grid(a.ntiles, (unsigned)d->N);
-    if (vec)
+    if (fast) {
+      a.ntiles = (int)((d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB);
+      hipLaunchKernelGGL(adell_na_bwd_partials_fast_kernel, dim3(a.ntiles, (unsigned)d->N),
+                         dim3(256), 0, st, a);
+    } else if (vec)
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<true>, grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<false>, grid, dim3(256), 0, st, a);
@@ -621,7 +642,13 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
                        d->stats_per_item, gamma, c1, c2, dgamma, dbeta);
   }
   const long nw = vec ? a.total / 4 : a.total;
-  if (vec)
+  if (fast) {
+    long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
+    if (bx > 2048) bx = 2048;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(adell_na_bwd_apply_fast_kernel, dim3((unsigned)bx, (unsigned)d->N),
+                       dim3(256), 0, st, a);
+  } else if (vec)
     hipLaunchKernelGGL(adell_na_bwd_apply_kernel<true>, dim3(adell_ew_blocks(nw)), dim3(256), 0,
                        st, a);
   else
@@ -629,4 +656,192 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
                        0, st, a);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Bandwidth-tuned variants used when C is a power of two <= 1024 (every U-Net
+// layer): the grid stride is a multiple of 1024 elements, so a thread keeps ONE
+// channel quad for its whole life and hoists mean / rstd / gamma / beta / c1 / c2
+// into registers; no 64-bit div/mod per element; 4 independent 16-byte loads are
+// in flight per thread before any arithmetic. One grid row per batch item.
+// ---------------------------------------------------------------------------
+struct NaConst {
+  float m[4], r[4], g[4], b[4], p[4], c1[4], c2[4];
+};
+
+__device__ __forceinline__ void adell_na_consts(NaConst& k, const float* mean, const float* rstd,
+                                                const float* gamma, const float* beta,
+                                                const float* act_w, int act_w_n, float act_p,
+                                                const float* c1, const float* c2, long sbase,
+                                                int c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    k.m[j] = mean ? mean[sbase + c + j] : 0.f;
+    k.r[j] = rstd ? rstd[sbase + c + j] : 1.f;
+    k.g[j] = gamma ? gamma[c + j] : 1.f;
+    k.b[j] = beta ? beta[c + j] : 0.f;
+    k.p[j] = act_w ? act_w[act_w_n > 1 ? c + j : 0] : act_p;
+    k.c1[j] = c1 ? c1[sbase + c + j] : 0.f;
+    k.c2[j] = c2 ? c2[sbase + c + j] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArgs a) {
+  const int n = blockIdx.y;
+  const long n4 = a.VC >> 2;  // float4 per item
+  const long j0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  const int c = (int)((j0 << 2) & (a.C - 1));
+  NaConst k;
+  adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
+                  nullptr, (long)n * a.stat_stride_n, c);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
+  float4* yout = reinterpret_cast<float4*>(a.out) + (long)n * n4;
+  for (long j = j0; j < n4; j += stride * ADELL_EW_UNROLL) {
+    float4 v[ADELL_EW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u)
+      if (j + u * stride < n4) v[u] = xin[j + u * stride];
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
+      const long jj = j + u * stride;
+      if (jj >= n4) break;
+      float h[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      uint32_t rr[4] = {0, 0, 0, 0};
+      if (a.drop_p > 0.f) {
+        const long gi = (long)n * n4 + jj;  // same counter as the generic kernel
+        const uint4 r = adell_philox4((uint32_t)gi, (uint32_t)(gi >> 32), a.rng_offset, 0u,
+                                      a.seed_lo, a.seed_hi);
+        rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float t = ((h[q] - k.m[q]) * k.r[q]) * k.g[q] + k.b[q];
+        if (a.drop_p > 0.f) {
+          const float uu = (float)(rr[q] >> 8) * (1.0f / 16777216.0f);
+          t = (uu >= a.drop_p) ? t * keep_scale : 0.f;
+        }
+        h[q] = adell_act_fwd(a.act, t, k.p[q]);
+      }
+      yout[jj] = make_float4(h[0], h[1], h[2], h[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a) {
+  const int n = blockIdx.y;
+  const long n4 = a.VC >> 2;
+  const long j0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  const int c = (int)((j0 << 2) & (a.C - 1));
+  NaConst k;
+  adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, a.c1, a.c2,
+                  (long)n * a.stat_stride_n, c);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
+  const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
+  float4* dxo = reinterpret_cast<float4*>(a.dx) + (long)n * n4;
+  const bool norm = a.mean != nullptr;
+  for (long j = j0; j < n4; j += stride * ADELL_EW_UNROLL) {
+    float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u)
+      if (j + u * stride < n4) {
+        xv[u] = xin[j + u * stride];
+        gv[u] = gin[j + u * stride];
+      }
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
+      const long jj = j + u * stride;
+      if (jj >= n4) break;
+      const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+      const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      bool keep[4];
+      adell_na_keep4(a, (long)n * n4 + jj, keep);
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float hn = (xs[q] - k.m[q]) * k.r[q];
+        const float t = hn * k.g[q] + k.b[q];
+        const float uu = keep[q] ? t * keep_scale : 0.f;
+        const float du = gs[q] * adell_act_grad(a.act, uu, k.p[q]);
+        const float dt = keep[q] ? du * keep_scale : 0.f;
+        float r = dt * k.g[q];
+        if (norm) r = k.r[q] * (r - k.c1[q] - hn * k.c2[q]);
+        o[q] = r;
+      }
+      dxo[jj] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// grid (slabs, N): block = 256 threads = CG channel quads x VL voxel lanes; each thread
+// keeps one channel quad and walks its slab 4 voxels at a time.
+__global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a) {
+  __shared__ float sh[256][8];
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const long v0 = (long)tile * ADELL_PART_SLAB;
+  long v1 = v0 + ADELL_PART_SLAB;
+  if (v1 > a.V) v1 = a.V;
+  const int CG = a.C >> 2;  // <= 256 quads
+  const int VL = 256 / CG;
+  const int cl = threadIdx.x % CG, vl = threadIdx.x / CG;
+  const int c = cl << 2;
+  NaConst k;
+  adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
+                  nullptr, (long)n * a.stat_stride_n, c);
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* xb = a.x + ((long)n * a.V) * a.C + c;
+  const float* gb = a.dout + ((long)n * a.V) * a.C + c;
+  for (long v = v0 + vl; v < v1; v += (long)VL * ADELL_EW_UNROLL) {
+    float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
+      const long vv = v + (long)u * VL;
+      if (vv < v1) {
+        xv[u] = *reinterpret_cast<const float4*>(xb + vv * a.C);
+        gv[u] = *reinterpret_cast<const float4*>(gb + vv * a.C);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
+      const long vv = v + (long)u * VL;
+      if (vv >= v1) break;
+      const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+      const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      bool keep[4];
+      adell_na_keep4(a, (((long)n * a.V + vv) * a.C + c) >> 2, keep);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float hn = (xs[q] - k.m[q]) * k.r[q];
+        const float t = hn * k.g[q] + k.b[q];
+        const float uu = keep[q] ? t * keep_scale : 0.f;
+        const float du = gs[q] * adell_act_grad(a.act, uu, k.p[q]);
+        const float dt = keep[q] ? du * keep_scale : 0.f;
+        A[q] += dt;
+        B[q] += dt * hn;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sh[threadIdx.x][q] = A[q];
+    sh[threadIdx.x][4 + q] = B[q];
+  }
+  __syncthreads();
+  if (vl == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int kk = 0; kk < VL; ++kk) {
+        s1 += sh[kk * CG + cl][q];
+        s2 += sh[kk * CG + cl][4 + q];
+      }
+      float* o = a.part + (((size_t)n * a.ntiles + tile) * a.C + c + q) * 2;
+      o[0] = s1;
+      o[1] = s2;
+    }
+  }
 }
