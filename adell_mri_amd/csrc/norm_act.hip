@@ -575,7 +575,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs 
 
 __global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
 __global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
-#define ADELL_PART_SLAB 2048
+#define ADELL_PART_SLAB 512
 
 static int adell_nab_fill(NormActBwdArgs* a, const adell_norm_act_desc* d) {
   ADELL_REQUIRE(d != nullptr, "norm_act_bwd: null descriptor");
@@ -601,7 +601,9 @@ static int adell_nab_fill(NormActBwdArgs* a, const adell_norm_act_desc* d) {
 // workspace floats: partials [N][ntiles][C][2] + c1 [N][C] + c2 [N][C]
 extern "C" long adell_norm_act_bwd_workspace(const adell_norm_act_desc* d) {
   if (!d || d->N <= 0 || d->V <= 0 || d->C <= 0) return ADELL_E_BADARG;
-  const long nt = adell_channel_partials_ntiles(d->V);
+  long nt = adell_channel_partials_ntiles(d->V);
+  const long ntf = (d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB;
+  if (ntf > nt) nt = ntf;
   return (long)sizeof(float) * (d->N * nt * d->C * 2 + 2 * d->N * d->C);
 }
 
@@ -625,7 +627,10 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
     ADELL_REQUIRE(workspace && (long)workspace_bytes >= adell_norm_act_bwd_workspace(d),
                   "norm_act_bwd: workspace too small");
     float* part = (float*)workspace;
-    float* c1 = part + (size_t)d->N * a.ntiles * d->C * 2;
+    long ntmax = a.ntiles;
+    if ((d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB > ntmax)
+      ntmax = (d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB;
+    float* c1 = part + (size_t)d->N * ntmax * d->C * 2;
     float* c2 = c1 + (size_t)d->N * d->C;
     a.part = part; a.c1 = c1; a.c2 = c2;
     dim3 grid(a.ntiles, (unsigned)d->N);

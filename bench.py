@@ -29,7 +29,12 @@ CFG2 = dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
             kernel_sizes=[3] * 5, strides=[2] * 5)
 LOSS = dict(smooth=1e-5, dice_eps=1e-6, gamma=1.0, focal_eps=1e-6)
 LR, WD = 5e-4, 5e-3
-FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" and "Peak BF16/FP16 MFMA ~2.5 PF dense".
+# The f16x3 kernels execute 3 f16 MFMA FLOPs per algorithmic (fp32-equivalent) FLOP, so the
+# algorithmic ceiling of that path is 2500 / 3.
+FP32_MFMA_PEAK_TFLOPS = 157.3
+F16_MFMA_PEAK_TFLOPS = 2500.0
+F16X3_ALGORITHMIC_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
 
 
 def build_module(device, size):
@@ -93,6 +98,7 @@ def main():
     ap.add_argument("--cpu-size", type=int, default=64)
     args = ap.parse_args()
 
+    from adell_mri_amd import functional as HF
     from adell_mri_amd import ops
     from adell_mri_amd.parallel import GradSync, init_distributed, reduce_max
     from adell_mri_amd.trainer import StepRunner
@@ -134,7 +140,9 @@ def main():
         "metric": "volumes/sec 3D U-Net 128^3 2-ch seg (train step: fwd+loss+bwd+SGD)",
         "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if HF.CONV_PRECISION == "fp32" else "f32 (f16x3 split MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{args.size}^3, "
                                f"batch {args.batch}/GPU, dice+focal, SGD-Nesterov",
                    "per_gpu_batch": args.batch, "size": args.size, "parallelism": f"dp{world}"},
@@ -144,9 +152,15 @@ def main():
     if dom is not None:
         name, flops, ms, launches = dom
         achieved = flops / (ms * 1e-3) / 1e12
+        f16 = "f16" in name
+        peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved,
-                           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "peak": peak, "unit": "TFLOP/s",
+                           "frac": achieved / peak, "traffic": None,
+                           "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product"
+                                          if f16 else "fp32 matrix peak"),
+                           "executed_mfma_tflops": achieved * (3.0 if f16 else 1.0),
+                           "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                            "launches": launches, "avg_launch_ms": ms / launches,
                            "kernel_time_share": timer.share(name, 1e3 * dt),
                            "all_kernels": timer.summary()}
