@@ -63,6 +63,10 @@ SIGNATURES = {
     "adell_bias_grad": (_i, [_vp, _l, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_k2s2_bwd_weight_workspace": (_l, [_i, _i, _i, _i, _i, _i]),
     "adell_convtranspose3d_k2s2_bwd_weight": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_convtranspose3d_fwd": (_i, [_i] * 9 + [_vp] * 5),
+    "adell_convtranspose3d_bwd_data": (_i, [_i] * 9 + [_vp] * 4),
+    "adell_convtranspose3d_bwd_weight_workspace": (_l, [_i] * 9),
+    "adell_convtranspose3d_bwd_weight": (_i, [_i] * 9 + [_vp] * 4 + [ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_k2s2_fwd": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "adell_convtranspose3d_k2s2_bwd_data": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "adell_stats_finalize_workspace": (_l, [_i, _i, _i]),

@@ -126,12 +126,12 @@ static int adell_check_desc(const adell_conv3d_desc* d) {
   ADELL_REQUIRE(d != nullptr, "conv: null descriptor");
   ADELL_REQUIRE(d->N > 0 && d->D > 0 && d->H > 0 && d->W > 0, "conv: bad input dims");
   ADELL_REQUIRE(d->C0 > 0 && d->C1 >= 0 && d->Cout > 0, "conv: bad channel counts");
-  ADELL_REQUIRE(d->KD >= 1 && d->KD <= 3 && d->KH >= 1 && d->KH <= 3 && d->KW >= 1 &&
-                    d->KW <= 3,
-                "conv: kernel size must be 1..3 per dim");
-  ADELL_REQUIRE(d->SD >= 1 && d->SD <= 2 && d->SH >= 1 && d->SH <= 2 && d->SW >= 1 &&
-                    d->SW <= 2,
-                "conv: stride must be 1..2 per dim");
+  ADELL_REQUIRE(d->KD >= 1 && d->KD <= 7 && d->KH >= 1 && d->KH <= 7 && d->KW >= 1 &&
+                    d->KW <= 7,
+                "conv: kernel size must be 1..7 per dim");
+  ADELL_REQUIRE(d->SD >= 1 && d->SD <= 4 && d->SH >= 1 && d->SH <= 4 && d->SW >= 1 &&
+                    d->SW <= 4,
+                "conv: stride must be 1..4 per dim");
   ADELL_REQUIRE(d->PD >= 0 && d->PH >= 0 && d->PW >= 0, "conv: negative padding");
   ADELL_REQUIRE(d->Do == (d->D + 2 * d->PD - d->KD) / d->SD + 1 &&
                     d->Ho == (d->H + 2 * d->PH - d->KH) / d->SH + 1 &&
@@ -224,53 +224,72 @@ extern "C" int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy
   return adell_conv_dispatch(a, d->N, (hipStream_t)stream);
 }
 
-// ConvTranspose3d with kernel = stride = 2, padding 0: a per-voxel GEMM
-// [Cin] -> [8*Cout] whose columns scatter to the 2x2x2 children of the voxel.
-// w_packed is [Cin][8][Cout] (adell_pack_weight mode 2).
-extern "C" int adell_convtranspose3d_k2s2_fwd(int N, int D, int H, int W, int Cin,
-                                              int Cout, const float* x,
-                                              const float* w_packed,
-                                              const float* bias, float* y,
-                                              void* stream) {
-  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0,
-                "convT_fwd: bad dims");
+// ConvTranspose3d with kernel = stride = (FD,FH,FW), each 1 or 2, padding 0: a
+// per-voxel GEMM [Cin] -> [F*Cout] whose columns scatter to the FD x FH x FW children
+// of the voxel. w_packed is [Cin][F][Cout] (adell_pack_weight mode 2).
+static int adell_convt_factors_ok(int FD, int FH, int FW) {
+  return (FD == 1 || FD == 2) && (FH == 1 || FH == 2) && (FW == 1 || FW == 2);
+}
+
+extern "C" int adell_convtranspose3d_fwd(int N, int D, int H, int W, int Cin, int Cout, int FD,
+                                         int FH, int FW, const float* x, const float* w_packed,
+                                         const float* bias, float* y, void* stream) {
+  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "convT_fwd: bad dims");
+  ADELL_REQUIRE(adell_convt_factors_ok(FD, FH, FW), "convT_fwd: kernel=stride must be 1 or 2 per dim");
   ADELL_REQUIRE(x && w_packed && y, "convT_fwd: null pointer");
   ConvArgs a = {};
   a.x0 = x; a.x1 = nullptr; a.w = w_packed; a.bias = bias; a.res = nullptr;
   a.y0 = y; a.y1 = nullptr; a.part = nullptr;
   a.D = D; a.H = H; a.W = W;
-  a.C0 = Cin; a.C1 = 0; a.Cin = Cin; a.Cout = 8 * Cout;
+  a.C0 = Cin; a.C1 = 0; a.Cin = Cin; a.Cout = FD * FH * FW * Cout;
   a.KD = a.KH = a.KW = 1;
   a.SD = a.SH = a.SW = 1;
   a.PD = a.PH = a.PW = 0;
   a.UPS = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
-  a.ysplit = a.Cout; a.shuffle = 1; a.Cs = Cout;
+  a.ysplit = a.Cout; a.Cs = Cout;
+  a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);  // bit 3 marks "scatter store"
   return adell_conv_dispatch(a, N, (hipStream_t)stream);
 }
 
-// dX of the k=s=2 transposed conv = a k=2, s=2, p=0 convolution of dY
-// ([N,2D,2H,2W,Cout]) with w_packed_bwd [8 taps][Cout][Cin] (pack mode 3).
-extern "C" int adell_convtranspose3d_k2s2_bwd_data(int N, int D, int H, int W,
-                                                   int Cin, int Cout,
-                                                   const float* dy,
-                                                   const float* w_packed_bwd,
-                                                   float* dx, void* stream) {
+extern "C" int adell_convtranspose3d_k2s2_fwd(int N, int D, int H, int W, int Cin,
+                                              int Cout, const float* x,
+                                              const float* w_packed,
+                                              const float* bias, float* y,
+                                              void* stream) {
+  return adell_convtranspose3d_fwd(N, D, H, W, Cin, Cout, 2, 2, 2, x, w_packed, bias, y, stream);
+}
+
+// dX of the transposed conv = a kernel = stride = (FD,FH,FW), padding 0 convolution of dY
+// ([N,FD*D,FH*H,FW*W,Cout]) with w_packed_bwd [taps][Cout][Cin] (pack mode 3).
+extern "C" int adell_convtranspose3d_bwd_data(int N, int D, int H, int W, int Cin, int Cout,
+                                              int FD, int FH, int FW, const float* dy,
+                                              const float* w_packed_bwd, float* dx,
+                                              void* stream) {
   ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0,
                 "convT_bwd_data: bad dims");
+  ADELL_REQUIRE(adell_convt_factors_ok(FD, FH, FW), "convT_bwd_data: bad factors");
   ADELL_REQUIRE(dy && w_packed_bwd && dx, "convT_bwd_data: null pointer");
   ConvArgs a = {};
   a.x0 = dy; a.x1 = nullptr; a.w = w_packed_bwd; a.bias = nullptr; a.res = nullptr;
   a.y0 = dx; a.y1 = nullptr; a.part = nullptr;
-  a.D = 2 * D; a.H = 2 * H; a.W = 2 * W;
+  a.D = FD * D; a.H = FH * H; a.W = FW * W;
   a.C0 = Cout; a.C1 = 0; a.Cin = Cout; a.Cout = Cin;
-  a.KD = a.KH = a.KW = 2;
-  a.SD = a.SH = a.SW = 2;
+  a.KD = a.SD = FD; a.KH = a.SH = FH; a.KW = a.SW = FW;
   a.PD = a.PH = a.PW = 0;
   a.UPS = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
   return adell_conv_dispatch(a, N, (hipStream_t)stream);
+}
+
+extern "C" int adell_convtranspose3d_k2s2_bwd_data(int N, int D, int H, int W,
+                                                   int Cin, int Cout,
+                                                   const float* dy,
+                                                   const float* w_packed_bwd,
+                                                   float* dx, void* stream) {
+  return adell_convtranspose3d_bwd_data(N, D, H, W, Cin, Cout, 2, 2, 2, dy, w_packed_bwd, dx,
+                                        stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -357,7 +376,9 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     a.HY = (TY - 1) * a.SH + a.KH;
     a.HZ = (TZ - 1) * a.SD + a.KD;
     a.VP = a.HX * a.HY * a.HZ;
-    lds = (size_t)a.VP * 64 + (size_t)a.KH * a.KW * t.BN * 64 + 64;
+    // weights are staged one kz plane at a time, or row by row when a plane is too big
+    a.GKH = ((size_t)a.KH * a.KW * t.BN * 64 <= 40 * 1024) ? a.KH : 1;
+    lds = (size_t)a.VP * 64 + (size_t)a.GKH * a.KW * t.BN * 64 + 64;
     const size_t red = (size_t)4 * t.BN * 2 * sizeof(float);
     if (lds < red) lds = red;
     if (lds <= 160 * 1024) break;
@@ -366,7 +387,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, next);
   }
   if (lds > 160 * 1024) {
-    adell_set_error("conv f16x3: LDS need %zu B exceeds 160 KiB", lds);
+    adell_set_error("conv f16x3: LDS need %zu B exceeds 160 KiB (k=%d stride=%d)", lds, a.KW, a.SW);
     return ADELL_E_UNSUPPORTED;
   }
   *tile = t;

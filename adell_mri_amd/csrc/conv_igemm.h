@@ -36,7 +36,8 @@ struct ConvArgs {
   int ntx, nty, ntz;
   int HX, HY, HZ, VP; // halo brick dims and LDS channel pitch (floats)
   int ysplit;         // columns [0,ysplit) -> y0, [ysplit,Cout) -> y1
-  int shuffle;        // 1: k=s=2 transposed-conv scatter store
+  int shuffle;        // != 0: transposed-conv scatter store; bits 0/1/2 = factor 2 along x/y/z
+  int GKH;            // f16 kernel: ky rows per staged weight group (KH, or fewer for big kernels)
   int Cs;             // channels of the shuffled destination
   int vecx, vecw;     // 16-byte global loads legal for input / weights
 };
@@ -216,9 +217,10 @@ __global__ __launch_bounds__(256) void adell_conv_igemm_kernel(ConvArgs a) {
     rowmul[nt] = 0;
     if (nok[nt]) {
       if (a.shuffle) {
+        const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1;
         const int sub = n / a.Cs, co = n - sub * a.Cs;
-        const int sx = sub & 1, sy = (sub >> 1) & 1, sz = sub >> 2;
-        colptr[nt] = a.y0 + ((size_t)(sz * 2 * a.Ho + sy) * (2 * a.Wo) + sx) * a.Cs + co;
+        const int sx = sub % fx, sy = (sub / fx) % fy, sz = sub / (fx * fy);
+        colptr[nt] = a.y0 + ((size_t)(sz * fy * a.Ho + sy) * (fx * a.Wo) + sx) * a.Cs + co;
         rowmul[nt] = a.Cs;
         if (a.bias) bcol[nt] = a.bias[co];
       } else {
@@ -244,7 +246,9 @@ __global__ __launch_bounds__(256) void adell_conv_igemm_kernel(ConvArgs a) {
       const int z = oz0 + (m >> (a.lTX + a.lTY));
       const bool rok = (x < a.Wo) & (y < a.Ho) & (z < a.Do);
       const int ov = ((nb * a.Do + z) * a.Ho + y) * a.Wo + x;
-      const int ovs = ((nb * 2 * a.Do + 2 * z) * (2 * a.Ho) + 2 * y) * (2 * a.Wo) + 2 * x;
+      const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1,
+                fz = ((a.shuffle >> 2) & 1) + 1;
+      const int ovs = ((nb * fz * a.Do + fz * z) * (fy * a.Ho) + fy * y) * (fx * a.Wo) + fx * x;
       const int rowoff = a.shuffle ? ovs : ov;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
   char* sA = reinterpret_cast<char*>(smem);
   const int HV = a.HX * a.HY * a.HZ;
   char* sB = sA + (size_t)HV * 64;
-  float* sMax = reinterpret_cast<float*>(sB + (size_t)a.KH * a.KW * BN * 64);  // [4]
+  float* sMax = reinterpret_cast<float*>(sB + (size_t)a.GKH * a.KW * BN * 64);  // [4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
   const int ox0 = tx << a.lTX, oy0 = ty << a.lTY, oz0 = tz << a.lTZ;
   const int HXY = a.HX * a.HY;
   const int lx0 = ox0 * a.SW - a.PW, ly0 = oy0 * a.SH - a.PH, lz0 = oz0 * a.SD - a.PD;
-  const int tpg = a.KH * a.KW;  // taps per group (one kz plane)
+  const int ngy = (a.KH + a.GKH - 1) / a.GKH;  // weight groups per kz plane
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -220,14 +220,18 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
         store_split(hv, v);
       }
     }
-    for (int kz = 0; kz < a.KD; ++kz) {
-      if (kz > 0) __syncthreads();  // previous tap group consumed
+    for (int grp = 0; grp < a.KD * ngy; ++grp) {
+      const int kz = grp / ngy, ky0 = (grp - kz * ngy) * a.GKH;
+      const int gkh = (a.KH - ky0) < a.GKH ? (a.KH - ky0) : a.GKH;
+      const int tpg = gkh * a.KW;              // taps of this group
+      const int tap0 = (kz * a.KH + ky0) * a.KW;
+      if (grp > 0) __syncthreads();  // previous tap group consumed
       // ---- stage the weight slice of this kz plane: [tpg][BN][4 slots] -----
       for (int it = tid; it < tpg * BN * 4; it += 256) {
         const int slot = it & 3;
         const int n = (it >> 2) % BN;
         const int tl = (it >> 2) / BN;
-        const int tap = kz * tpg + tl;
+        const int tap = tap0 + tl;
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n0 + n < a.Cout)
           f = *reinterpret_cast<const float4*>(
@@ -239,8 +243,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
       // ---- 3 f16 MFMAs per (tap, 32x32 tile); the fragments of tap t+1 are read
       // while the MFMAs of tap t run (two register sets, statically indexed) -------
       auto load_frags = [&](int tl, half8* ah, half8* al, half8* bh, half8* bl) {
-        const int ky = tl / a.KW, kx = tl - ky * a.KW;
-        const int aoff = (kz * a.HY + ky) * a.HX + kx;
+        const int kyl = tl / a.KW, kx = tl - kyl * a.KW;
+        const int aoff = (kz * a.HY + ky0 + kyl) * a.HX + kx;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int hv = arow[mt] + aoff;
@@ -299,9 +303,10 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     if (nok[nt]) {
       oscale[nt] = ascale * e.wscale[n];
       if (a.shuffle) {
+        const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1;
         const int sub = n / a.Cs, co = n - sub * a.Cs;
-        const int sx = sub & 1, sy = (sub >> 1) & 1, sz = sub >> 2;
-        colptr[nt] = a.y0 + ((size_t)(sz * 2 * a.Ho + sy) * (2 * a.Wo) + sx) * a.Cs + co;
+        const int sx = sub % fx, sy = (sub / fx) % fy, sz = sub / (fx * fy);
+        colptr[nt] = a.y0 + ((size_t)(sz * fy * a.Ho + sy) * (fx * a.Wo) + sx) * a.Cs + co;
         rowmul[nt] = a.Cs;
         if (a.bias) bcol[nt] = a.bias[co];
       } else {
@@ -327,7 +332,9 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
       const int z = oz0 + (m >> (a.lTX + a.lTY));
       const bool rok = (x < a.Wo) & (y < a.Ho) & (z < a.Do);
       const int ov = ((nb * a.Do + z) * a.Ho + y) * a.Wo + x;
-      const int ovs = ((nb * 2 * a.Do + 2 * z) * (2 * a.Ho) + 2 * y) * (2 * a.Wo) + 2 * x;
+      const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1,
+                fz = ((a.shuffle >> 2) & 1) + 1;
+      const int ovs = ((nb * fz * a.Do + fz * z) * (fy * a.Ho) + fy * y) * (fx * a.Wo) + fx * x;
       const int rowoff = a.shuffle ? ovs : ov;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {

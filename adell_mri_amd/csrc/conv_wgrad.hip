@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_kernel(WgradArgs a) {
   for (int q = 0; q < MAXJ; ++q) {
     int tl = tfirst + tstride * q;
     jok[q] = tl < tapsg;
-    if (!jok[q]) tl = tfirst;  // duplicate work into a discarded accumulator
+    if (!jok[q]) tl = 0;  // duplicate work into a discarded accumulator
     const int kx = tl % a.KW, ky = (tl / a.KW) % a.KH, kz = tl / (a.KW * a.KH);
     aoffj[q] = ((kz * a.HY + ky) * a.HX + kx) * a.TCI + cis * 32 + lh * a.SW * a.TCI + li;
   }
@@ -439,12 +439,29 @@ extern "C" int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* 
 
 // dW[ci][co][tap] = sum_v x[v][ci] * dy[2v+tap][co]: the same GEMM with the roles
 // swapped (dy is the strided operand, x the dense one).
+extern "C" long adell_convtranspose3d_bwd_weight_workspace(int N, int D, int H, int W, int Cin,
+                                                           int Cout, int FD, int FH, int FW) {
+  WgradPlan p;
+  if (adell_wgrad_plan(N, Cout, Cin, FD, FH, FW, FD, FH, FW, D, H, W, &p) != ADELL_OK)
+    return ADELL_E_UNSUPPORTED;
+  return (long)adell_wgrad_ws_bytes(p, FD * FH * FW, Cout, Cin);
+}
+
 extern "C" long adell_convtranspose3d_k2s2_bwd_weight_workspace(int N, int D, int H, int W,
                                                                 int Cin, int Cout) {
-  WgradPlan p;
-  if (adell_wgrad_plan(N, Cout, Cin, 2, 2, 2, 2, 2, 2, D, H, W, &p) != ADELL_OK)
-    return ADELL_E_UNSUPPORTED;
-  return (long)adell_wgrad_ws_bytes(p, 8, Cout, Cin);
+  return adell_convtranspose3d_bwd_weight_workspace(N, D, H, W, Cin, Cout, 2, 2, 2);
+}
+
+extern "C" int adell_convtranspose3d_bwd_weight(int N, int D, int H, int W, int Cin, int Cout,
+                                                int FD, int FH, int FW, const float* x,
+                                                const float* dy, float* dw, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(x && dy && dw, "convT_bwd_weight: null pointer");
+  ADELL_REQUIRE((FD == 1 || FD == 2) && (FH == 1 || FH == 2) && (FW == 1 || FW == 2),
+                "convT_bwd_weight: kernel=stride must be 1 or 2 per dim");
+  return adell_wgrad_core(N, FD * D, FH * H, FW * W, Cout, 0, dy, nullptr, Cin, D, H, W, x, FD,
+                          FH, FW, FD, FH, FW, 0, 0, 0, dw, nullptr, workspace, workspace_bytes,
+                          (hipStream_t)stream);
 }
 
 extern "C" int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W, int Cin,
@@ -452,10 +469,8 @@ extern "C" int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W,
                                                      const float* dy, float* dw,
                                                      void* workspace, size_t workspace_bytes,
                                                      void* stream) {
-  ADELL_REQUIRE(x && dy && dw, "convT_bwd_weight: null pointer");
-  return adell_wgrad_core(N, 2 * D, 2 * H, 2 * W, Cout, 0, dy, nullptr, Cin, D, H, W, x, 2, 2,
-                          2, 2, 2, 2, 0, 0, 0, dw, nullptr, workspace, workspace_bytes,
-                          (hipStream_t)stream);
+  return adell_convtranspose3d_bwd_weight(N, D, H, W, Cin, Cout, 2, 2, 2, x, dy, dw, workspace,
+                                          workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------

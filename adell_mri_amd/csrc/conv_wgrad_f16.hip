@@ -46,7 +46,8 @@ struct WgradF16Args {
   int Do, Ho, Wo;
   int lTY;            // log2 of brick rows (TX = 8, TZ = 1)
   int ntx, nty;       // bricks per row / column (per z slice)
-  int HX, HY;         // halo brick of X: (8-1)*SW + KW by (TY-1)*SH + KH
+  int HX, HY;         // halo brick of X: (8-1)*SW + KW by (TY-1)*SH + GKH
+  int GKH, NGY;       // ky rows per tap group, groups per kz plane
   int TCI, TCO, nci, nco;
   int R;
   int vecx, vecy;
@@ -93,8 +94,9 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
   const int region = blockIdx.x;
   const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
   const int ci0 = cit * a.TCI, co0 = cot * a.TCO;
-  const int kz = blockIdx.z;
-  const int tapsg = a.KH * a.KW;
+  const int kz = blockIdx.z / a.NGY;
+  const int ky0 = (blockIdx.z % a.NGY) * a.GKH;
+  const int tapsg = ((a.KH - ky0) < a.GKH ? (a.KH - ky0) : a.GKH) * a.KW;
   const int nsub = sci * sco;
   const int sub = wave % nsub;
   const int cis = sub % sci, cos = sub / sci;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
   for (int q = 0; q < MAXJ; ++q) {
     int tl = tfirst + tstride * q;
     jok[q] = tl < tapsg;
-    if (!jok[q]) tl = tfirst;
+    if (!jok[q]) tl = 0;
     const int kx = tl % a.KW, ky = tl / a.KW;
     aoffj[q] = abase + (ky * a.HX + kx) * 64;
   }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
   const long bricks_per_item = (long)a.ntx * a.nty * a.Do;
   const long nbricks = bricks_per_item * a.N;
   const int c4x = a.TCI >> 2, c4y = a.TCO >> 2;
-  const bool do_db = a.wsdb != nullptr && cit == 0 && kz == 0;
+  const bool do_db = a.wsdb != nullptr && cit == 0 && blockIdx.z == 0;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (long brick = region; brick < nbricks; brick += a.R) {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
     const int ox0 = tx * 8, oy0 = ty << a.lTY;
     const int iz = oz * a.SD - a.PD + kz;
     const bool zok = iz >= 0 && iz < a.D;
-    const int ix0 = ox0 * a.SW - a.PW, iy0 = oy0 * a.SH - a.PH;
+    const int ix0 = ox0 * a.SW - a.PW, iy0 = oy0 * a.SH - a.PH + ky0;
     __syncthreads();
     // ---- stage the X halo brick: [32-channel group][halo voxel][32 halfs] ------
     for (int it = tid; it < HV * c4x; it += 256) {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
 #pragma unroll
   for (int q = 0; q < MAXJ; ++q) {
     const int tl = tfirst + tstride * q;
-    const int tap = kz * tapsg + tl;
+    const int tap = (kz * a.KH + ky0) * a.KW + tl;
     const int cib = ci0 + cis * 32 + 4 * lh;
     float* base = a.ws + (((size_t)region * ntap + tap) * a.Cin + cib) * a.Cout + co;
     if (jok[q] && co < a.Cout) {
@@ -266,7 +268,7 @@ extern "C" int adell_wgrad_reduce_launch(const float* ws, float* out, int R, int
                                          int Cout, const float* wsdb, float* db, void* stream);
 
 struct WgradF16Plan {
-  int lTY, HX, HY, TCI, TCO, nci, nco, maxj, R, ntx, nty;
+  int lTY, HX, HY, TCI, TCO, nci, nco, maxj, R, ntx, nty, GKH, NGY;
   size_t lds;
 };
 
@@ -277,7 +279,11 @@ static int adell_wgrad_f16_plan(int N, int Cin, int Cout, int KD, int KH, int KW
   p->nci = adell_cdiv(Cin, p->TCI);
   p->nco = adell_cdiv(Cout, p->TCO);
   const int nsub = (p->TCI / 32) * (p->TCO / 32);
-  p->maxj = adell_cdiv(KH * KW * nsub, 4);
+  // a block owns the taps of GKH consecutive ky rows of one kz plane (<= 9 per wave)
+  p->GKH = KH;
+  while (p->GKH > 1 && adell_cdiv(p->GKH * KW * nsub, 4) > 9) --p->GKH;
+  p->NGY = adell_cdiv(KH, p->GKH);
+  p->maxj = adell_cdiv(p->GKH * KW * nsub, 4);
   if (p->maxj > 9) {
     adell_set_error("wgrad f16x3: %d jobs per wave unsupported", p->maxj);
     return ADELL_E_UNSUPPORTED;
@@ -286,7 +292,7 @@ static int adell_wgrad_f16_plan(int N, int Cin, int Cout, int KD, int KH, int KW
   p->lTY = Ho > 4 ? 3 : (Ho > 2 ? 2 : 1);  // TY = 8, 4 or 2
   for (;;) {
     const int TY = 1 << p->lTY;
-    p->HY = (TY - 1) * SH + KH;
+    p->HY = (TY - 1) * SH + p->GKH;
     p->lds = 2 * ((size_t)(p->TCI / 32) * p->HX * p->HY * 64 + (size_t)(p->TCO / 32) * 8 * TY * 64);
     if (p->lds < 4096) p->lds = 4096;
     if (p->lds <= 80 * 1024 || p->lTY == 1) break;
@@ -299,7 +305,7 @@ static int adell_wgrad_f16_plan(int N, int Cin, int Cout, int KD, int KH, int KW
   p->ntx = adell_cdiv(Wo, 8);
   p->nty = adell_cdiv(Ho, 1 << p->lTY);
   const long nbricks = (long)N * p->ntx * p->nty * Do;
-  const long chan_blocks = (long)p->nci * p->nco * KD;
+  const long chan_blocks = (long)p->nci * p->nco * KD * p->NGY;
   int per_cu = (int)((160 * 1024) / p->lds);
   if (per_cu > 2) per_cu = 2;
   if (per_cu < 1) per_cu = 1;
@@ -369,17 +375,20 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   a.PD = PD; a.PH = PH; a.PW = PW;
   a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.lTY = p.lTY; a.ntx = p.ntx; a.nty = p.nty; a.HX = p.HX; a.HY = p.HY;
+  a.GKH = p.GKH; a.NGY = p.NGY;
   a.TCI = p.TCI; a.TCO = p.TCO; a.nci = p.nci; a.nco = p.nco; a.R = p.R;
   a.vecx = (C0 % 4 == 0) && (C1 % 4 == 0) && (((uintptr_t)x0 & 15) == 0) &&
            (((uintptr_t)x1 & 15) == 0);
   a.vecy = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
-  dim3 grid((unsigned)p.R, (unsigned)(p.nci * p.nco), (unsigned)KD);
+  dim3 grid((unsigned)p.R, (unsigned)(p.nci * p.nco), (unsigned)(KD * p.NGY));
   if (p.maxj <= 2)
     rc = adell_launch_wgrad_f16<2>(a, grid, p.lds, st);
   else if (p.maxj <= 3)
     rc = adell_launch_wgrad_f16<3>(a, grid, p.lds, st);
   else if (p.maxj <= 5)
     rc = adell_launch_wgrad_f16<5>(a, grid, p.lds, st);
+  else if (p.maxj <= 7)
+    rc = adell_launch_wgrad_f16<7>(a, grid, p.lds, st);
   else
     rc = adell_launch_wgrad_f16<9>(a, grid, p.lds, st);
   if (rc != ADELL_OK) return rc;
@@ -403,7 +412,6 @@ extern "C" int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const f
                                              size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight_f16x3: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight_f16x3: C1 > 0 needs x1");
-  ADELL_REQUIRE(d->KH <= 3 && d->KW <= 3, "conv_bwd_weight_f16x3: kernel up to 3");
   return adell_wgrad_f16_core(d->N, d->D, d->H, d->W, d->C0, d->C1, x0, x1, d->Cout, d->Do,
                               d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
                               d->PH, d->PW, dw, db, x_absmax, dy_absmax, workspace, workspace_bytes,

@@ -132,13 +132,15 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     return y
 
 
-class _ConvT3dK2S2Fn(torch.autograd.Function):
+class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, wp, wref):
-        y = ops.convtranspose3d_k2s2_fwd(x, wp, bias, weight.shape[1])
+        factors = tuple(weight.shape[2:])
+        y = ops.convtranspose3d_fwd(x, wp, bias, weight.shape[1], factors)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.wref = wref
+        ctx.factors = factors
         return y
 
     @staticmethod
@@ -148,16 +150,21 @@ class _ConvT3dK2S2Fn(torch.autograd.Function):
         dy = ops.ndhwc(dy)
         dx = dw = db = None
         if need[0]:
-            dx = ops.convtranspose3d_k2s2_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0])
+            dx = ops.convtranspose3d_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0],
+                                              ctx.factors)
         if need[1]:
-            dw = ops.convtranspose3d_k2s2_bwd_weight(x, dy)
+            dw = ops.convtranspose3d_bwd_weight(x, dy, ctx.factors)
         if ctx.has_bias and need[2]:
             db = ops.bias_grad(dy)
         return dx, dw, db, None, None
 
 
-def conv_transpose3d_k2s2(x, weight, bias=None):
-    return _ConvT3dK2S2Fn.apply(x, weight, bias, _packed(weight, 2), _Ref(weight))
+def conv_transpose3d(x, weight, bias=None):
+    """ConvTranspose3d whose kernel equals its stride (each 1 or 2 per dim), padding 0."""
+    return _ConvT3dFn.apply(x, weight, bias, _packed(weight, 2), _Ref(weight))
+
+
+conv_transpose3d_k2s2 = conv_transpose3d
 
 
 class _NormDropActFn(torch.autograd.Function):

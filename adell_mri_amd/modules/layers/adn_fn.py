@@ -42,6 +42,8 @@ def _as5d(X):
         return X.unsqueeze(2), lambda t: t.squeeze(2)
     if n == 3:
         return X.unsqueeze(2).unsqueeze(2), lambda t: t.squeeze(2).squeeze(2)
+    if n == 2:
+        return X[:, :, None, None, None], lambda t: t[:, :, 0, 0, 0]
     raise ValueError(f"ActDropNorm expects [N, C, ...] with 1-3 spatial dims, got {tuple(X.shape)}")
 
 

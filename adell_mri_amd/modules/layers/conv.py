@@ -31,7 +31,22 @@ class Conv3d(torch.nn.Conv3d):
         added to the output inside the kernel epilogue."""
         self._check()
         pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
+        k, st = tuple(self.kernel_size), tuple(self.stride)
+        if k == st and max(k) > 2 and tuple(pad) == (0, 0, 0) and X_cat is None:
+            return self._patchify(X, residual)
         return HF.conv3d(X, self.weight, self.bias, self.stride, pad, x1=X_cat, residual=residual)
+
+    def _patchify(self, X, residual):
+        """kernel == stride, no padding (ViT / ConvNeXt stems): space-to-depth view of the
+        input, then a 1x1x1 convolution over K^3*Cin channels on the MFMA kernel."""
+        N, C, D, H, W = X.shape
+        kd, kh, kw = self.kernel_size
+        Do, Ho, Wo = D // kd, H // kh, W // kw
+        X = X[:, :, :Do * kd, :Ho * kh, :Wo * kw]
+        Xp = (X.reshape(N, C, Do, kd, Ho, kh, Wo, kw).permute(0, 2, 4, 6, 3, 5, 7, 1)
+              .reshape(N, Do, Ho, Wo, kd * kh * kw * C).permute(0, 4, 1, 2, 3))
+        w = self.weight.permute(0, 2, 3, 4, 1).reshape(self.out_channels, -1, 1, 1, 1)
+        return HF.conv3d(Xp, w, self.bias, 1, 0, residual=residual)
 
 
 class Conv2d(torch.nn.Conv2d):
@@ -53,14 +68,16 @@ class Conv2d(torch.nn.Conv2d):
 
 class ConvTranspose3d(torch.nn.ConvTranspose3d):
     def forward(self, X, output_size=None):
-        ok = (tuple(self.kernel_size) == (2, 2, 2) and tuple(self.stride) == (2, 2, 2)
-              and tuple(self.padding) == (0, 0, 0) and tuple(self.output_padding) == (0, 0, 0)
-              and self.groups == 1 and tuple(self.dilation) == (1, 1, 1) and output_size is None)
+        k, s = tuple(self.kernel_size), tuple(self.stride)
+        ok = (k == s and all(f in (1, 2) for f in k) and tuple(self.padding) == (0, 0, 0)
+              and tuple(self.output_padding) == (0, 0, 0) and self.groups == 1
+              and tuple(self.dilation) == (1, 1, 1) and output_size is None)
         if not ok:
             raise AdellHipError(
-                "HIP ConvTranspose3d implements kernel=stride=2, padding=0 (the U-Net decoder "
-                f"upscaling); got k={self.kernel_size} s={self.stride} p={self.padding}")
-        return HF.conv_transpose3d_k2s2(X, self.weight, self.bias)
+                "HIP ConvTranspose3d implements kernel == stride in {1,2} per dim, padding 0 (the "
+                f"U-Net decoder upscaling); got k={self.kernel_size} s={self.stride} "
+                f"p={self.padding}")
+        return HF.conv_transpose3d(X, self.weight, self.bias)
 
 
 class MaxPool3d(torch.nn.MaxPool3d):

@@ -277,44 +277,62 @@ def bias_grad(dy):
     return db
 
 
-def convtranspose3d_k2s2_bwd_weight(x, dy):
-    """dW in torch's canonical [Cin, Cout, 2, 2, 2] layout."""
+def convtranspose3d_bwd_weight(x, dy, factors=(2, 2, 2)):
+    """dW in torch's canonical [Cin, Cout, FD, FH, FW] layout (kernel = stride = factors)."""
     _require_cuda(x, dy)
     x, dy = ndhwc(x), ndhwc(dy)
     N, Cin, D, H, W = x.shape
     Cout = dy.shape[1]
-    nbytes = _lib.lib().adell_convtranspose3d_k2s2_bwd_weight_workspace(N, D, H, W, Cin, Cout)
+    fd, fh, fw = factors
+    nbytes = _lib.lib().adell_convtranspose3d_bwd_weight_workspace(N, D, H, W, Cin, Cout, fd, fh, fw)
     if nbytes < 0:
         check(int(nbytes))
     ws = _workspace(nbytes, x.device)
-    dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
-    flops = 2.0 * N * D * H * W * Cin * Cout * 8
-    check(_timed("adell_conv_wgrad_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_k2s2_bwd_weight(
-        N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4, _stream())))
+    dw = torch.empty((Cin, Cout, fd, fh, fw), device=x.device, dtype=torch.float32)
+    flops = 2.0 * N * D * H * W * Cin * Cout * fd * fh * fw
+    check(_timed("adell_conv_wgrad_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_bwd_weight(
+        N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
+        _stream())))
     return dw
 
 
-def convtranspose3d_k2s2_fwd(x, w_packed, bias, Cout):
+def convtranspose3d_k2s2_bwd_weight(x, dy):
+    return convtranspose3d_bwd_weight(x, dy, (2, 2, 2))
+
+
+def convtranspose3d_fwd(x, w_packed, bias, Cout, factors=(2, 2, 2)):
+    """ConvTranspose3d with kernel = stride = factors (each 1 or 2), padding 0."""
     _require_cuda(x, w_packed, bias)
     x = ndhwc(x)
     N, Cin, D, H, W = x.shape
-    y = new_act(N, Cout, 2 * D, 2 * H, 2 * W, x.device)
-    flops = 2.0 * N * D * H * W * Cin * Cout * 8
-    check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_k2s2_fwd(
-        N, D, H, W, Cin, Cout, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y), _stream())))
+    fd, fh, fw = factors
+    y = new_act(N, Cout, fd * D, fh * H, fw * W, x.device)
+    flops = 2.0 * N * D * H * W * Cin * Cout * fd * fh * fw
+    check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_fwd(
+        N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y),
+        _stream())))
     return y
 
 
-def convtranspose3d_k2s2_bwd_data(dy, w_packed_bwd, Cin):
+def convtranspose3d_bwd_data(dy, w_packed_bwd, Cin, factors=(2, 2, 2)):
     _require_cuda(dy, w_packed_bwd)
     dy = ndhwc(dy)
     N, Cout, D2, H2, W2 = dy.shape
-    D, H, W = D2 // 2, H2 // 2, W2 // 2
+    fd, fh, fw = factors
+    D, H, W = D2 // fd, H2 // fh, W2 // fw
     dx = new_act(N, Cin, D, H, W, dy.device)
-    flops = 2.0 * N * D * H * W * Cin * Cout * 8
-    check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_k2s2_bwd_data(
-        N, D, H, W, Cin, Cout, _ptr(dy), _ptr(w_packed_bwd), _ptr(dx), _stream())))
+    flops = 2.0 * N * D * H * W * Cin * Cout * fd * fh * fw
+    check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_bwd_data(
+        N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(dy), _ptr(w_packed_bwd), _ptr(dx), _stream())))
     return dx
+
+
+def convtranspose3d_k2s2_fwd(x, w_packed, bias, Cout):
+    return convtranspose3d_fwd(x, w_packed, bias, Cout, (2, 2, 2))
+
+
+def convtranspose3d_k2s2_bwd_data(dy, w_packed_bwd, Cin):
+    return convtranspose3d_bwd_data(dy, w_packed_bwd, Cin, (2, 2, 2))
 
 
 def stats_finalize(partials, count, eps, per_item=True):

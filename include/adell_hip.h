@@ -145,6 +145,19 @@ int adell_bias_grad(const float* dy, long rows, int C, float* db, void* workspac
  * (init_upscale_ops, upscale_type="transpose"), unetr.py:286-308.
  * x [N,D,H,W,Cin] -> y [N,2D,2H,2W,Cout].
  * ---------------------------------------------------------------------- */
+/* General form: kernel = stride = (FD,FH,FW), each 1 or 2 (anisotropic upscaling of
+ * backbone encoders, e.g. strides [2,2,1]); weights [Cin][Cout][FD][FH][FW]. */
+int adell_convtranspose3d_fwd(int N, int D, int H, int W, int Cin, int Cout, int FD, int FH,
+                              int FW, const float* x, const float* w_packed, const float* bias,
+                              float* y, void* stream);
+int adell_convtranspose3d_bwd_data(int N, int D, int H, int W, int Cin, int Cout, int FD,
+                                   int FH, int FW, const float* dy, const float* w_packed_bwd,
+                                   float* dx, void* stream);
+long adell_convtranspose3d_bwd_weight_workspace(int N, int D, int H, int W, int Cin, int Cout,
+                                                int FD, int FH, int FW);
+int adell_convtranspose3d_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, int FD,
+                                     int FH, int FW, const float* x, const float* dy, float* dw,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 int adell_convtranspose3d_k2s2_fwd(int N, int D, int H, int W, int Cin, int Cout,
                                    const float* x, const float* w_packed,
                                    const float* bias, float* y, void* stream);

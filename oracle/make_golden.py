@@ -40,6 +40,7 @@ from adell_mri.modules.segmentation.unetr import UNETR  # noqa: E402
 from adell_mri.modules.segmentation.unetpp import UNetPlusPlus  # noqa: E402
 from adell_mri.modules.layers.linear_blocks import MultiHeadSelfAttention  # noqa: E402
 from adell_mri.modules.layers.vit import TransformerBlock  # noqa: E402
+from adell_mri.modules.layers.res_net import ResNet  # noqa: E402
 
 from oracle.weights import fill_state_dict  # noqa: E402
 
@@ -92,7 +93,43 @@ UNETPP_CASES = {
 }
 
 
+BACKBONE_CASES = {
+    # BASELINE config 2b in miniature: ResNet backbone (7^3 stem, k=5 / k=3 residual stages,
+    # batch norm) repackaged as U-Net encoder, anisotropic pooling [2,2,1]
+    "unet3d_resnet_backbone": (dict(spatial_dimensions=3, upscale_type="transpose",
+                                    link_type="identity", norm_type="instance", padding=1,
+                                    dropout_param=0.0, activation_fn="swish", in_channels=2,
+                                    n_classes=2, _cls="backbone",
+                                    _structure=[[8, 8, 5, 2], [16, 16, 3, 2]],
+                                    _maxpool=[[2, 2, 1], [2, 2, 2]]),
+                               (2, 2, 16, 16, 8), "uniform"),
+}
+
+
+def make_backbone_unet(kw):
+    """entrypoints/segmentation/train.py:672-765 in miniature."""
+    kw = dict(kw)
+    kw.pop("_cls")
+    structure, mpl = kw.pop("_structure"), kw.pop("_maxpool")
+    kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+    res = ResNet(dict(spatial_dim=3, in_channels=kw["in_channels"], structure=structure,
+                      maxpool_structure=mpl, res_type="resnet",
+                      adn_fn=get_adn_fn(3, "batch", "swish", 0.0)))
+    bb = res.backbone
+    res_ops = [bb.input_layer, *bb.operations]
+    pool_ops = [bb.first_pooling, *bb.pooling_operations]
+    enc = torch.nn.ModuleList([torch.nn.ModuleList([a, b]) for a, b in zip(res_ops, pool_ops)])
+    kw["depth"] = [structure[0][0], *[x[0] for x in structure]]
+    kw["kernel_sizes"] = [3 for _ in kw["depth"]]
+    kw["strides"] = [2, *mpl]
+    net = UNet(encoding_operations=enc, **kw)
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    return net
+
+
 def make_unet(kw):
+    if kw.get("_cls") == "backbone":
+        return make_backbone_unet(kw)
     kw = dict(kw)
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
     cls = {"unetpp": UNetPlusPlus}.get(kw.pop("_cls", None), UNETR if "patch_size" in kw else UNet)
@@ -106,7 +143,10 @@ def gen_unet(name, kw, shape, dist):
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(shape, generator=g) if dist == "uniform" else torch.randn(shape, generator=g)
     y = (torch.rand((shape[0], 1, *shape[2:]), generator=g) > 0.9).float()
-    net = make_unet(kw).eval()  # eval(): dropout off, instance norm unaffected
+    net = make_unet(kw)
+    # eval(): dropout off, instance norm unaffected; the backbone case runs in train() so that
+    # its BatchNorm layers use batch statistics (dropout_param is 0 there)
+    net = net.train() if kw.get("_cls") == "backbone" else net.eval()
     out = {"x": x.numpy(), "y": y.numpy()}
     # forward parity target: logits (north_star: within 1e-4 rel)
     logits = net(x, return_logits=True)[0]
@@ -178,6 +218,7 @@ def gen_blocks():
 
 
 if __name__ == "__main__":
-    for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES, **UNETPP_CASES}.items():
+    for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES, **UNETPP_CASES,
+                                    **BACKBONE_CASES}.items():
         gen_unet(name, kw, shape, dist)
     gen_blocks()
