@@ -189,6 +189,8 @@ class _NormDropActFn(torch.autograd.Function):
             x, dout, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w, act_p=act_p,
             stats_per_item=per_item, drop_p=drop_p, seed=seed, rng_offset=offset,
             want_affine_grads=want_affine)
+        if beta is None:
+            dbeta = None
         return dx, None, None, dgamma, dbeta, None, None
 
 
@@ -389,3 +391,56 @@ def max_pool3d(x, kernel, stride=None, padding=0):
     kernel = ops._triple(kernel)
     stride = kernel if stride is None else ops._triple(stride)
     return _MaxPool3dFn.apply(x, kernel, stride, ops._triple(padding))
+
+
+# ---- ConvNeXt / VICReg ---------------------------------------------------------------------------
+class _DwConv3dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = ops.dwconv3d_fwd(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dx = dw = db = None
+        if need[0]:
+            dx = ops.dwconv3d_bwd_data(dy, weight)
+        if need[1] or (ctx.has_bias and need[2]):
+            dw, db = ops.dwconv3d_bwd_weight(x, dy, tuple(weight.shape[2:]), ctx.has_bias)
+        return dx, dw, db
+
+
+def dwconv3d(x, weight, bias=None):
+    """Depthwise Conv3d (groups = channels, stride 1, 'same' padding)."""
+    return _DwConv3dFn.apply(x, weight, bias)
+
+
+def channel_scale(x, gamma):
+    """gamma[c] * x for a 5-D activation (layer scale of the ConvNeXt block)."""
+    return norm_drop_act(x, norm="none", gamma=gamma)
+
+
+class _VICRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, min_var, eps):
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        out, scratch = ops.vicreg_fwd(x1, x2, min_var, eps)
+        ctx.save_for_backward(x1, x2, scratch)
+        ctx.conf = (min_var, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, scratch = ctx.saved_tensors
+        dx1, dx2 = ops.vicreg_bwd(x1, x2, scratch, *ctx.conf, g,
+                                  ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx1, dx2, None, None
+
+
+def vicreg_terms(x1, x2, min_var=1.0, eps=1e-4):
+    """(invariance, variance, covariance) terms of VICReg, unweighted, as a 3-vector."""
+    return _VICRegFn.apply(x1, x2, float(min_var), float(eps))

@@ -100,6 +100,12 @@ class ActDropNorm(torch.nn.Module):
                 kw.update(norm="batch", eps=m.eps, gamma=m.weight, beta=m.bias,
                           momentum=m.momentum,
                           running=(m.running_mean, m.running_var, m.num_batches_tracked))
+            elif isinstance(m, torch.nn.LayerNorm):
+                # feature vectors / tokens ([..., C]): row LayerNorm kernel, then the rest of
+                # the stage elementwise
+                if X.dim() == 5 or tuple(m.normalized_shape) != (X.shape[-1],):
+                    raise NotImplementedError("torch.nn.LayerNorm in an ADN: [..., C] inputs only")
+                X = HF.layer_norm(X, m.weight, m.bias, m.eps)
             elif not isinstance(m, torch.nn.Identity):
                 raise NotImplementedError(
                     f"normalisation {type(m).__name__} has no HIP kernel on the adell_mri_amd path")

@@ -29,3 +29,32 @@ class UOut(torch.nn.Module):
         if self.training and self.beta != 0.0:
             raise NotImplementedError("UOut: HIP kernel not implemented yet")
         return X
+
+
+class LayerNorm(torch.nn.Module):
+    """LayerNorm over the channel axis for channels_last ([..., C]) or channels_first
+    ([N, C, ...]) tensors (adell_mri/modules/layers/regularization.py:60-92; weight and
+    bias are [1, C] as in the reference). On the HIP path a channels_first activation is
+    NDHWC in memory, so both formats are the same row LayerNorm kernel."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last"):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones([1, normalized_shape]))
+        self.bias = torch.nn.Parameter(torch.zeros([1, normalized_shape]))
+        self.eps = eps
+        self.data_format = data_format
+        if self.data_format not in ["channels_last", "channels_first"]:
+            raise NotImplementedError
+        self.normalized_shape = (normalized_shape,)
+
+    def forward(self, x):
+        from ... import functional as HF
+        from ... import ops
+
+        w, b = self.weight.reshape(-1), self.bias.reshape(-1)
+        if self.data_format == "channels_last":
+            return HF.layer_norm(x, w, b, self.eps)
+        if x.dim() != 5:
+            raise NotImplementedError("channels_first LayerNorm: 5-D activations only")
+        xr = ops.ndhwc(x).permute(0, 2, 3, 4, 1)            # [N, D, H, W, C] contiguous view
+        return HF.layer_norm(xr, w, b, self.eps).permute(0, 4, 1, 2, 3)

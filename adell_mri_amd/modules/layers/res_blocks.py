@@ -7,7 +7,11 @@ operand of the last convolution's epilogue, which also reduces the statistics
 """
 import torch
 
+from ... import functional as HF
+from ... import ops
 from .conv import Conv3d
+from .linear_blocks import LayerNorm as RowLayerNorm
+from .linear_blocks import Linear
 
 
 class ResidualBlock3d(torch.nn.Module):
@@ -47,4 +51,67 @@ class ResidualBlock3d(torch.nn.Module):
         skip = skip_activation if skip_activation is not None else self.skip_activation
         if skip is not True:
             out = self.adn_op(out)
+        return out
+
+
+class DepthwiseConv3d(torch.nn.Conv3d):
+    """torch.nn.Conv3d(groups=in_channels, padding="same") on the HIP stencil kernel."""
+
+    def forward(self, X):
+        if (self.groups != self.in_channels or self.in_channels != self.out_channels
+                or tuple(self.stride) != (1, 1, 1) or tuple(self.dilation) != (1, 1, 1)
+                or self.padding != "same"):
+            raise NotImplementedError("HIP DepthwiseConv3d: groups == channels, stride 1, "
+                                      "padding='same'")
+        return HF.dwconv3d(X, self.weight, self.bias)
+
+
+class ConvNeXtBlock3d(torch.nn.Module):
+    """ConvNeXt block (adell_mri/modules/layers/res_blocks.py:516-604): depthwise conv ->
+    LayerNorm over channels -> Linear -> GELU -> Linear -> layer scale -> + input
+    (-> 1x1x1 conv + GELU when the channel count changes). Activations are NDHWC, so the
+    reference's two permutes are no-ops here and every stage is a HIP kernel."""
+
+    def __init__(self, in_channels: int, kernel_size: int, inter_channels: int,
+                 out_channels: int, adn_fn: torch.nn.Module = torch.nn.Identity,
+                 layer_scale_init_value: float = 1e-6, skip_activation: bool = None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.kernel_size = kernel_size
+        self.inter_channels = inter_channels
+        self.out_channels = out_channels
+        self.adn_fn = adn_fn
+        self.layer_scale_init_value = layer_scale_init_value
+        self.skip_activation = skip_activation
+        self.dwconv = DepthwiseConv3d(in_channels, in_channels, kernel_size=kernel_size,
+                                      padding="same", groups=in_channels)
+        self.norm = RowLayerNorm(in_channels, eps=1e-6)
+        self.pwconv1 = Linear(in_channels, inter_channels)
+        self.act = torch.nn.GELU()
+        self.pwconv2 = Linear(inter_channels, in_channels)
+        self.gamma = (torch.nn.Parameter(layer_scale_init_value * torch.ones((in_channels)),
+                                         requires_grad=True)
+                      if layer_scale_init_value > 0 else None)
+        if out_channels != in_channels:
+            self.out_layer = torch.nn.Sequential(
+                Conv3d(in_channels, out_channels, kernel_size=1, padding="same"),
+                torch.nn.GELU())
+        else:
+            self.out_layer = None
+
+    def forward(self, x):
+        inp = ops.ndhwc(x)
+        h = self.dwconv(inp)
+        rows = ops.ndhwc(h).permute(0, 2, 3, 4, 1)          # [N, D, H, W, C], contiguous
+        rows = self.norm(rows)
+        rows = HF.elementwise(self.pwconv1(rows), act="gelu")
+        if self.gamma is None:
+            rows = self.pwconv2(rows, residual=inp.permute(0, 2, 3, 4, 1))
+            out = rows.permute(0, 4, 1, 2, 3)
+        else:
+            rows = self.pwconv2(rows)
+            scaled = HF.channel_scale(rows.permute(0, 4, 1, 2, 3), self.gamma)
+            out = HF.add_bcast(inp, scaled)
+        if self.out_layer is not None:
+            out = HF.norm_drop_act(self.out_layer[0](out), act="gelu")
         return out

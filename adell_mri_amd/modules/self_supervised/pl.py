@@ -1,0 +1,181 @@
+"""Self-supervised training-step wrappers (mirror of
+adell_mri/modules/self_supervised/pl.py:170-267 ``SelfSLBasePL`` and :759-985
+``SelfSLConvNeXtPL``), VICReg / SimSiam / BYOL on the ConvNeXt backbone.
+
+Kept: constructor arguments, ``step`` arithmetic (which head feeds which loss argument,
+stop-gradient, EMA forward and update, loss symmetrisation), ``configure_optimizers``
+(AdamW over decay + no-decay parameters in one group, cosine schedule with warm-up).
+Lightning is optional as in ``segmentation/pl.py``. SimCLR (NT-Xent) and VICRegL have no
+HIP loss kernel yet and raise at construction.
+"""
+import warnings
+from typing import Callable
+
+import torch
+
+from ...optim import FusedAdamW
+from ..layers.conv_next import ConvNeXt
+from ..learning_rate import CosineAnnealingWithWarmupLR
+from .losses import VICRegLoss
+
+try:  # pragma: no cover - lightning is not installed in the build image
+    import lightning.pytorch as pl
+
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    _Base = torch.nn.Module
+
+OPTIMIZER_EPS_DEFAULT = 1e-8
+
+
+class SelfSLBasePL(_Base):
+    def __init__(self):
+        super().__init__()
+        self.optimizer_eps = OPTIMIZER_EPS_DEFAULT
+
+    if _Base is torch.nn.Module:
+        def log(self, *args, **kwargs):
+            return None
+
+        def save_hyperparameters(self, *args, **kwargs):
+            return None
+
+    def update_metrics(self, y1, y2, metrics, log=True):
+        for k in metrics:
+            metrics[k].update(y1.flatten(), y2.flatten())
+
+    def init_loss(self):
+        if self.ssl_method == "vicreg":
+            self.loss = VICRegLoss(**self.vic_reg_loss_params)
+        elif self.ssl_method in ("vicregl", "simclr"):
+            raise NotImplementedError(f"ssl_method={self.ssl_method!r} has no HIP loss kernel yet")
+        else:
+            raise NotImplementedError("SimSiam/BYOL cosine losses have no HIP kernel yet; "
+                                      "use ssl_method='vicreg'")
+
+    def calculate_loss(self, y1, y2, *args):
+        if self.stop_gradient is False:
+            return self.loss(y1, y2, *args)
+        return self.loss(y1, y2.detach(), *args)
+
+    def safe_sum(self, X):
+        if isinstance(X, torch.Tensor):
+            return X.sum()
+        return sum(X)
+
+    def configure_optimizers(self) -> dict:
+        if self.n_steps is not None:
+            interval, n = "step", self.n_steps
+        else:
+            interval, n = "epoch", self.n_epochs
+        params_no_decay, params_decay = [], []
+        for k, p in self.named_parameters():
+            (params_no_decay if "normalization" in k else params_decay).append(p)
+        optimizer = FusedAdamW(params_decay + params_no_decay, lr=self.learning_rate,
+                               weight_decay=self.weight_decay, eps=self.optimizer_eps)
+        sched = CosineAnnealingWithWarmupLR(optimizer, T_max=n, start_decay=self.start_decay,
+                                            n_warmup_steps=self.warmup_steps, eta_min=0.0)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": sched, "interval": interval, "frequency": 1},
+                "monitor": "val_loss"}
+
+    def setup_metrics(self):
+        self.train_metrics = torch.nn.ModuleDict({})
+        self.val_metrics = torch.nn.ModuleDict({})
+        self.test_metrics = torch.nn.ModuleDict({})
+
+
+class SelfSLConvNeXtPL(ConvNeXt, SelfSLBasePL):
+    def __init__(self, aug_image_key_1: str = "aug_image_1", aug_image_key_2: str = "aug_image_2",
+                 box_key_1: str = "box_1", box_key_2: str = "box_2", learning_rate: float = 0.001,
+                 batch_size: int = 4, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None, n_epochs: int = 1000,
+                 n_steps: int = None, warmup_steps: int = 0, start_decay: int = None,
+                 ema: torch.nn.Module = None, ssl_method: str = "simclr",
+                 temperature: float = 1.0, vic_reg_loss_params: dict = {},
+                 stop_gradient: bool = True, channels_to_batch: bool = False,
+                 optimizer_eps: float = OPTIMIZER_EPS_DEFAULT, *args, **kwargs):
+        self.aug_image_key_1 = aug_image_key_1
+        self.aug_image_key_2 = aug_image_key_2
+        self.box_key_1 = box_key_1
+        self.box_key_2 = box_key_2
+        self.learning_rate = learning_rate
+        self.batch_size = batch_size
+        self.weight_decay = weight_decay
+        self.training_dataloader_call = training_dataloader_call
+        self.n_epochs = n_epochs
+        self.n_steps = n_steps
+        self.warmup_steps = warmup_steps
+        self.start_decay = start_decay
+        self.ssl_method = ssl_method
+        self.temperature = temperature
+        self.vic_reg_loss_params = vic_reg_loss_params
+        self.stop_gradient = stop_gradient
+        self.channels_to_batch = channels_to_batch
+        if channels_to_batch is True:
+            kwargs["backbone_args"]["in_channels"] = 1
+        super().__init__(*args, **kwargs)
+        self.optimizer_eps = optimizer_eps
+        self.ema = ema
+        if self.ssl_method not in ["vicreg", "vicregl", "simclr"] and self.stop_gradient is False:
+            warnings.warn("stop_gradient=False should not (in theory) be used with "
+                          "vic_reg=False, vic_reg_local=False or simclr=False")
+        self.init_loss()
+        if self.ema is not None:
+            self.ema.update(self)
+        else:
+            self.ema = None
+        self.loss_str_dict = {"standard": [None], "vicreg": ["inv", "var", "cov"],
+                              "vicregl": ["inv", "var", "cov", "local"]}
+        self.save_hyperparameters()
+        self.setup_metrics()
+
+    def forward_ema_stop_grad(self, x, ret):
+        op = self.ema.shadow.forward if self.ema is not None else self.forward
+        if self.stop_gradient is True:
+            with torch.no_grad():
+                return op(x, ret)
+        return op(x, ret)
+
+    def step(self, batch, loss_str: str, metrics: dict, train=False):
+        if self.ssl_method == "simclr":
+            ret_string_1, ret_string_2, other_args = "projection", "projection", []
+        elif self.ssl_method != "vicregl":
+            ret_string_1, ret_string_2, other_args = "prediction", "projection", []
+        else:
+            ret_string_1, ret_string_2 = "representation", "representation"
+            other_args = [batch[self.box_key_1], batch[self.box_key_2]]
+        x1, x2 = batch[self.aug_image_key_1], batch[self.aug_image_key_2]
+        if self.channels_to_batch is True:
+            x1 = x1.reshape(-1, 1, *x1.shape[2:])
+            x2 = x2.reshape(-1, 1, *x2.shape[2:])
+        y1 = self.forward(x1, ret=ret_string_1)
+        y2 = self.forward_ema_stop_grad(x2, ret=ret_string_2)
+        losses = self.calculate_loss(y1, y2, *other_args)
+        self.update_metrics(y1, y2, metrics)
+        # loss is already symmetrised for VICReg, VICRegL and SimCLR
+        if self.ssl_method not in ["vicreg", "vicregl", "simclr"]:
+            y1_ = self.forward_ema_stop_grad(x1, ret=ret_string_1)
+            y2_ = self.forward(x2, ret=ret_string_2)
+            losses = losses + self.calculate_loss(y2_, y1_, *other_args)
+            self.update_metrics(y2_, y1_, metrics)
+        if self.ema is not None and train is True:
+            self.ema.update(self)
+        loss = self.safe_sum(losses)
+        self.log(loss_str, loss, batch_size=x1.shape[0], on_epoch=True, on_step=False,
+                 prog_bar=True, sync_dist=True)
+        if self.ssl_method in ("vicregl", "vicreg"):
+            for s, loss_value in zip(self.loss_str_dict[self.ssl_method], losses):
+                self.log("{}:{}".format(loss_str, s), loss_value, batch_size=x1.shape[0],
+                         on_epoch=True, on_step=False, prog_bar=True, sync_dist=True)
+        self.last_losses = losses
+        return loss
+
+    def training_step(self, batch, batch_idx):
+        return self.step(batch, "loss", self.train_metrics, train=True)
+
+    def validation_step(self, batch, batch_idx):
+        return self.step(batch, "val_loss", self.val_metrics)
+
+    def test_step(self, batch, batch_idx):
+        return self.step(batch, "test_loss", self.test_metrics)

@@ -617,3 +617,60 @@ def maxpool3d_bwd(dy, idx, in_shape, kernel, stride, padding):
     dx = new_act(N, C, D, H, W, dy.device)
     check(_lib.lib().adell_maxpool3d_bwd(ctypes.byref(d), _ptr(dy), _ptr(idx), _ptr(dx), _stream()))
     return dx
+
+
+# ---- ConvNeXt / VICReg -------------------------------------------------------------------------
+def dwconv3d_fwd(x, w, bias):
+    _require_cuda(x, w, bias)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    kd, kh, kw = w.shape[2:]
+    y = new_act(N, C, D, H, W, x.device)
+    check(_lib.lib().adell_dwconv3d_fwd(N, C, D, H, W, kd, kh, kw, _ptr(x), _ptr(w.contiguous()),
+                                        _ptr(bias), _ptr(y), _stream()))
+    return y
+
+
+def dwconv3d_bwd_data(dy, w):
+    dy = ndhwc(dy)
+    N, C, D, H, W = dy.shape
+    kd, kh, kw = w.shape[2:]
+    dx = new_act(N, C, D, H, W, dy.device)
+    check(_lib.lib().adell_dwconv3d_bwd_data(N, C, D, H, W, kd, kh, kw, _ptr(dy),
+                                             _ptr(w.contiguous()), _ptr(dx), _stream()))
+    return dx
+
+
+def dwconv3d_bwd_weight(x, dy, kshape, want_db):
+    x, dy = ndhwc(x), ndhwc(dy)
+    N, C, D, H, W = x.shape
+    kd, kh, kw = kshape
+    dw = torch.empty((C, 1, kd, kh, kw), device=x.device, dtype=torch.float32)
+    db = torch.empty((C,), device=x.device, dtype=torch.float32) if want_db else None
+    check(_lib.lib().adell_dwconv3d_bwd_weight(N, C, D, H, W, kd, kh, kw, _ptr(x), _ptr(dy),
+                                               _ptr(dw), _ptr(db), _stream()))
+    return dw, db
+
+
+def vicreg_fwd(x1, x2, min_var, eps):
+    _require_cuda(x1, x2)
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    B, D = x1.shape
+    scratch = torch.empty(_lib.lib().adell_vicreg_scratch_floats(B, D), device=x1.device,
+                          dtype=torch.float32)
+    out = torch.empty(3, device=x1.device, dtype=torch.float32)
+    check(_lib.lib().adell_vicreg_fwd(_ptr(x1), _ptr(x2), B, D, float(min_var), float(eps),
+                                      _ptr(scratch), _ptr(out), _stream()))
+    return out, scratch
+
+
+def vicreg_bwd(x1, x2, scratch, min_var, eps, g, need1, need2):
+    B, D = x1.shape
+    if not (need1 or need2):
+        return None, None
+    g = g.contiguous().float()
+    dx1 = torch.empty_like(x1) if need1 else None
+    dx2 = torch.empty_like(x2) if need2 else None
+    check(_lib.lib().adell_vicreg_bwd(_ptr(x1), _ptr(x2), B, D, float(min_var), float(eps),
+                                      _ptr(scratch), _ptr(g), _ptr(dx1), _ptr(dx2), _stream()))
+    return dx1, dx2

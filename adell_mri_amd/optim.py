@@ -49,7 +49,9 @@ class _FusedBase(torch.optim.Optimizer):
     def _flat(self, group):
         flat = group.get("_flat")
         if flat is None:
-            flat = FlatParameters(group["params"])
+            # frozen parameters (e.g. an EMA shadow) never receive gradients: torch.optim skips
+            # them, so they stay out of the flat buffer
+            flat = FlatParameters([p for p in group["params"] if p.requires_grad])
             group["_flat"] = flat
         return flat
 

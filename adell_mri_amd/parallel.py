@@ -70,11 +70,19 @@ class GradSync:
         for g in optimizer.param_groups:
             g["grad_scale"] = 1.0 / self.world
 
-    def broadcast_parameters(self, src=0):
+    def broadcast_parameters(self, src=0, module=None):
+        """Rank ``src``'s parameters everywhere; with ``module`` also the tensors that are
+        not in the optimiser's flat buffers (frozen parameters, buffers), as DDP does at
+        construction."""
         if self.world == 1:
             return
         for flat in self.optimizer.flat_groups:
             dist.broadcast(flat.data, src=src)
+        if module is not None:
+            flat_ids = {id(p) for f in self.optimizer.flat_groups for p in f.params}
+            for t in list(module.parameters()) + list(module.buffers()):
+                if id(t) not in flat_ids:
+                    dist.broadcast(t.data, src=src)
         from . import ops
 
         ops._weights_changed()

@@ -12,7 +12,7 @@ class StepRunner:
             optimizer = module.configure_optimizers()["optimizer"]
         self.optimizer = optimizer
         self.sync = sync if sync is not None else GradSync(optimizer)
-        self.sync.broadcast_parameters()
+        self.sync.broadcast_parameters(module=module)
         self.step_idx = 0
 
     def train_step(self, batch):

@@ -307,6 +307,30 @@ int adell_maxpool3d_fwd(const adell_conv3d_desc* d, const float* x, float* y,
 int adell_maxpool3d_bwd(const adell_conv3d_desc* d, const float* dy, const int32_t* argmax,
                         float* dx, void* stream);
 
+/* ------------------------------------------------------------------------
+ * ConvNeXt / VICReg self-supervised path (BASELINE config 4).
+ * Depthwise Conv3d(groups=C, stride 1, "same" padding, odd kernels):
+ * res_blocks.py:552-558. w / dw in torch's [C][1][KD][KH][KW] layout.
+ * ---------------------------------------------------------------------- */
+int adell_dwconv3d_fwd(int N, int C, int D, int H, int W, int KD, int KH, int KW,
+                       const float* x, const float* w, const float* bias, float* y,
+                       void* stream);
+int adell_dwconv3d_bwd_data(int N, int C, int D, int H, int W, int KD, int KH, int KW,
+                            const float* dy, const float* w, float* dx, void* stream);
+int adell_dwconv3d_bwd_weight(int N, int C, int D, int H, int W, int KD, int KH, int KW,
+                              const float* x, const float* dy, float* dw, float* db,
+                              void* stream);
+/* VICReg terms of two [B][D] embeddings (self_supervised/losses/vicreg.py:60-140):
+ * out3 = (invariance, variance, covariance), unweighted; scratch of
+ * adell_vicreg_scratch_floats(B, D) floats is kept for the backward, which returns
+ * g3[0]*d(inv) + g3[1]*d(var) + g3[2]*d(cov) (g3: 3 floats on the device) w.r.t. x1 (dx1) and x2 (dx2, may be NULL). */
+long adell_vicreg_scratch_floats(int B, int D);
+int adell_vicreg_fwd(const float* x1, const float* x2, int B, int D, float min_var, float eps,
+                     float* scratch, float* out3, void* stream);
+int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, float min_var, float eps,
+                     const float* scratch, const float* g3, float* dx1, float* dx2,
+                     void* stream);
+
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
 

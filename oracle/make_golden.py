@@ -23,6 +23,8 @@ for name, path in [
     ("adell_mri.modules.layers", "adell_mri/modules/layers"),
     ("adell_mri.modules.segmentation", "adell_mri/modules/segmentation"),
     ("adell_mri.utils", "adell_mri/utils"),
+    ("adell_mri.modules.self_supervised", "adell_mri/modules/self_supervised"),
+    ("adell_mri.modules.self_supervised.losses", "adell_mri/modules/self_supervised/losses"),
 ]:
     m = types.ModuleType(name)
     m.__path__ = [os.path.join(REF, path)]
@@ -41,6 +43,10 @@ from adell_mri.modules.segmentation.unetpp import UNetPlusPlus  # noqa: E402
 from adell_mri.modules.layers.linear_blocks import MultiHeadSelfAttention  # noqa: E402
 from adell_mri.modules.layers.vit import TransformerBlock  # noqa: E402
 from adell_mri.modules.layers.res_net import ResNet  # noqa: E402
+
+from adell_mri.modules.layers.conv_next import ConvNeXt  # noqa: E402
+from adell_mri.modules.layers.res_blocks import ConvNeXtBlock3d  # noqa: E402
+from adell_mri.modules.self_supervised.losses.vicreg import VICRegLoss  # noqa: E402
 
 from oracle.weights import fill_state_dict  # noqa: E402
 
@@ -217,8 +223,94 @@ def gen_blocks():
     print("blocks ok")
 
 
+SSL_CASE = dict(
+    backbone_args=dict(spatial_dim=3, in_channels=1, structure=[[8, 16, 3, 2], [16, 32, 7, 2]],
+                       maxpool_structure=[2, 2]),
+    projection_head_args=dict(in_channels=16, structure=[32, 24]),
+    prediction_head_args=dict(in_channels=24, structure=[32, 24]))
+SSL_GAIN = 3.0
+SSL_OPT = dict(lr=1e-3, weight_decay=5e-3, eps=1e-8)
+
+
+def gen_ssl():
+    """ConvNeXt blocks, VICReg loss and one VICReg training step of a small 3-D ConvNeXt
+    (BASELINE config 4 in miniature; self_supervised/pl.py:904-972 with
+    ssl_method='vicreg', stop_gradient=False), AdamW step and EMA update."""
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    x = torch.randn((2, 8, 6, 6, 6), generator=g)
+    out["blk_x"] = x.numpy()
+    for tag, (k, oc) in {"k3": (3, 8), "k7": (7, 12)}.items():
+        blk = ConvNeXtBlock3d(8, k, 16, oc)
+        blk.load_state_dict(fill_state_dict(blk.state_dict()))
+        xin = x.clone().requires_grad_(True)
+        y = blk(xin)
+        r = torch.randn(y.shape, generator=g)
+        (y * r).sum().backward()
+        out[f"blk_{tag}_y"], out[f"blk_{tag}_r"] = y.detach().numpy(), r.numpy()
+        out[f"blk_{tag}_dx"] = xin.grad.numpy()
+        for n, p in blk.named_parameters():
+            out[f"blk_{tag}_grad:{n}"] = p.grad.numpy().copy()
+    # VICReg loss on its own (losses/vicreg.py:30-165)
+    e1 = torch.randn((6, 40), generator=g).requires_grad_(True)
+    e2 = (0.5 * e1.detach() + 0.7 * torch.randn((6, 40), generator=g)).requires_grad_(True)
+    crit = VICRegLoss()
+    terms = crit(e1, e2)
+    sum(terms).backward()
+    out["vic_x1"], out["vic_x2"] = e1.detach().numpy(), e2.detach().numpy()
+    out["vic_terms"] = torch.stack(terms).detach().numpy()
+    out["vic_dx1"], out["vic_dx2"] = e1.grad.numpy(), e2.grad.numpy()
+    # one training step
+    adn1 = get_adn_fn(1, "layer", "gelu", 0.0)
+    kw = {k: dict(v) for k, v in SSL_CASE.items()}
+    kw["projection_head_args"]["adn_fn"] = adn1
+    kw["prediction_head_args"]["adn_fn"] = adn1
+    net = ConvNeXt(**kw)
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    net.train()
+    # adell_mri/utils/utils.py imports monai (absent here), so the EMA arithmetic of
+    # utils.py:484-487 is restated: shadow.sub_((1 - decay) * (shadow - param))
+    shadow = {k: p.detach().clone() for k, p in net.named_parameters()}
+    # structured volumes (a different spatial pattern per sample) so that the embeddings
+    # differ across the batch; pure noise is averaged away by the 4^3 stem
+    zz, yy, xx = torch.meshgrid(*[torch.arange(32.0)] * 3, indexing="ij")
+    x1 = torch.stack([torch.sin((b + 1) * 0.35 * zz) * torch.cos((b + 2) * 0.23 * yy)
+                      + 0.03 * (b - 1.5) * xx for b in range(4)])[:, None]
+    x1 = x1 + 0.2 * torch.rand(x1.shape, generator=g)
+    x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g)).flip(2)
+    out["x1"], out["x2"] = x1.numpy(), x2.numpy()
+    out["representation"] = net(x1, ret="representation").detach().numpy()
+    y1 = net(x1, ret="prediction")
+    y2 = net(x2, ret="projection")
+    out["y1"], out["y2"] = y1.detach().numpy(), y2.detach().numpy()
+    losses = crit(y1, y2)
+    loss = sum(losses)
+    out["losses"] = torch.stack(losses).detach().numpy()
+    out["loss"] = loss.detach().numpy()
+    loss.backward()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy().copy()
+    decay, no_decay = [], []
+    for k, p in net.named_parameters():
+        (no_decay if "normalization" in k else decay).append(p)
+    opt = torch.optim.AdamW(decay + no_decay, **SSL_OPT)
+    opt.step()
+    for k, p in net.named_parameters():
+        out["step1:" + k] = p.detach().numpy().copy()
+        shadow[k].sub_((1 - 0.99) * (shadow[k] - p.detach()))
+        out["ema1:" + k] = shadow[k].numpy().copy()
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "ssl_convnext_small.npz"), **out)
+    print("ssl ok: loss", float(loss.detach()), "terms", [float(t.detach()) for t in losses],
+          "y1 std over batch", float(y1.detach().std(0).mean()))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ssl":
+        gen_ssl()
+        sys.exit(0)
     for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES, **UNETPP_CASES,
                                     **BACKBONE_CASES}.items():
         gen_unet(name, kw, shape, dist)
     gen_blocks()
+    gen_ssl()

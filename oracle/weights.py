@@ -19,14 +19,17 @@ def tensor_for(name, shape, scale=None):
     return rng.uniform(-scale, scale, size=shape).astype(np.float32)
 
 
-def fill_state_dict(sd):
-    """In-place: every floating-point entry of a torch state_dict gets tensor_for(key)."""
+def fill_state_dict(sd, gain=1.0):
+    """Every floating-point entry of a torch state_dict gets tensor_for(key); matrices and
+    kernels (dim > 1) are multiplied by ``gain`` (deep stacks of Linear layers need > 1 to
+    keep the signal above the biases)."""
     import torch
 
     out = {}
     for k, v in sd.items():
         if v.is_floating_point() and v.numel() > 0 and "running_" not in k:
-            out[k] = torch.from_numpy(tensor_for(k, v.shape)).to(v.dtype)
+            t = torch.from_numpy(tensor_for(k, v.shape)).to(v.dtype)
+            out[k] = t * gain if (v.dim() > 1 and v.shape[0] > 1) else t
         else:
             out[k] = v.clone()
     return out

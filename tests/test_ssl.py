@@ -1,0 +1,250 @@
+"""ConvNeXt backbone + VICReg self-supervised step (SURVEY.md 8 rows a13 / a15;
+BASELINE config 4 in miniature) against fixtures generated from the real reference
+(oracle/make_golden.py gen_ssl)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from cases import grad_rel_err
+from oracle.torch_ref.convnext import ConvNeXtOracle, vicreg_loss
+from oracle.weights import fill_state_dict, tensor_for
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SSL_CASE = dict(
+    backbone_args=dict(spatial_dim=3, in_channels=1, structure=[[8, 16, 3, 2], [16, 32, 7, 2]],
+                       maxpool_structure=[2, 2]),
+    projection_head_args=dict(in_channels=16, structure=[32, 24]),
+    prediction_head_args=dict(in_channels=24, structure=[32, 24]))
+SSL_GAIN = 3.0
+SSL_OPT = dict(learning_rate=1e-3, weight_decay=5e-3, optimizer_eps=1e-8)
+ORACLE_CFG = dict(structure=SSL_CASE["backbone_args"]["structure"], maxpool_structure=[2, 2],
+                  projection_structure=[32, 24], prediction_structure=[32, 24])
+
+
+def gold():
+    return np.load(os.path.join(GOLD, "ssl_convnext_small.npz"), allow_pickle=False)
+
+
+def rel(a, r):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return float(np.abs(a - r).max() / (np.abs(r).max() + 1e-30))
+
+
+def build_pl(ema=None):
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
+
+    adn1 = get_adn_fn(1, "layer", "gelu", 0.0)
+    kw = {k: dict(v) for k, v in SSL_CASE.items()}
+    kw["projection_head_args"]["adn_fn"] = adn1
+    kw["prediction_head_args"]["adn_fn"] = adn1
+    net = SelfSLConvNeXtPL(aug_image_key_1="a", aug_image_key_2="b", ssl_method="vicreg",
+                           stop_gradient=False, n_epochs=10, batch_size=4, ema=None,
+                           **SSL_OPT, **kw)
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    if ema is not None:  # as the constructor does (pl.py:887-889), after the weights are set
+        net.ema = ema
+        ema.update(net)
+    return net
+
+
+# ---- CPU: the oracle is pinned to the reference; the product mirrors its interface -------
+def test_convnext_oracle_matches_reference():
+    g = gold()
+    sd = {str(k): torch.from_numpy(tensor_for(str(k), g["grad:" + str(k)].shape))
+          for k in g["param_keys"]}
+    sd = {k: (v * SSL_GAIN if (v.dim() > 1 and v.shape[0] > 1) else v) for k, v in sd.items()}
+    net = ConvNeXtOracle(sd, ORACLE_CFG).requires_grad_(True)
+    x1, x2 = torch.from_numpy(g["x1"]), torch.from_numpy(g["x2"])
+    assert rel(net.forward(x1, "representation"), g["representation"]) < 1e-5
+    y1, y2 = net.forward(x1, "prediction"), net.forward(x2, "projection")
+    assert rel(y1, g["y1"]) < 1e-5 and rel(y2, g["y2"]) < 1e-5
+    losses = vicreg_loss(y1, y2)
+    np.testing.assert_allclose(torch.stack(losses).detach().numpy(), g["losses"], rtol=2e-4,
+                               atol=1e-9)
+    sum(losses).backward()
+    for k, p in net.sd.items():
+        assert grad_rel_err(g, k, p.grad.numpy()) < 2e-3, k
+
+
+def test_vicreg_oracle_matches_reference():
+    g = gold()
+    x1 = torch.from_numpy(g["vic_x1"]).requires_grad_(True)
+    x2 = torch.from_numpy(g["vic_x2"]).requires_grad_(True)
+    terms = vicreg_loss(x1, x2)
+    np.testing.assert_allclose(torch.stack(terms).detach().numpy(), g["vic_terms"], rtol=1e-5)
+    sum(terms).backward()
+    assert rel(x1.grad, g["vic_dx1"]) < 1e-5 and rel(x2.grad, g["vic_dx2"]) < 1e-5
+
+
+def test_ssl_module_state_dict_keys_equal_reference():
+    g = gold()
+    net = build_pl()
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    for k, p in net.named_parameters():
+        assert tuple(p.shape) == g["grad:" + k].shape, k
+
+
+def test_ssl_module_fails_loudly_without_gpu():
+    net = build_pl()
+    with pytest.raises(Exception):
+        net(torch.zeros((2, 1, 32, 32, 32)), ret="projection")
+
+
+def test_unsupported_ssl_methods_raise():
+    from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
+
+    with pytest.raises(NotImplementedError):
+        SelfSLConvNeXtPL(ssl_method="simclr", **SSL_CASE)
+
+
+# ---- GPU: HIP kernels against stock torch / the reference fixtures ---------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,size,k", [(2, 8, (6, 6, 6), 3), (1, 96, (16, 16, 16), 7),
+                                        (2, 24, (4, 5, 3), 7), (1, 130, (2, 2, 2), 3),
+                                        (1, 8, (7, 6, 9), (3, 1, 5))])
+def test_depthwise_conv3d_fwd_bwd(cuda, N, C, size, k):
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+
+    ks = (k, k, k) if isinstance(k, int) else k
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, C, *size), generator=g, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn((C, 1, *ks), generator=g, dtype=torch.float64) / np.sqrt(np.prod(ks))
+         ).requires_grad_(True)
+    b = torch.randn((C,), generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.conv3d(x, w, b, padding=[q // 2 for q in ks], groups=C)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xd = ops.ndhwc(x.detach().float().to(cuda)).requires_grad_(True)
+    wd = w.detach().float().to(cuda).requires_grad_(True)
+    bd = b.detach().float().to(cuda).requires_grad_(True)
+    yd = HF.dwconv3d(xd, wd, bd)
+    yd.backward(ops.ndhwc(dy.float().to(cuda)))
+    assert rel(yd, y.detach().numpy()) < 2e-6
+    assert rel(xd.grad, x.grad.numpy()) < 2e-6
+    assert rel(wd.grad, w.grad.numpy()) < 5e-6
+    assert rel(bd.grad, b.grad.numpy()) < 5e-6
+
+
+@pytest.mark.gpu
+def test_vicreg_loss_terms_and_grads_match_reference(cuda):
+    from adell_mri_amd.modules.self_supervised.losses import VICRegLoss
+
+    g = gold()
+    x1 = torch.from_numpy(g["vic_x1"]).to(cuda).requires_grad_(True)
+    x2 = torch.from_numpy(g["vic_x2"]).to(cuda).requires_grad_(True)
+    terms = VICRegLoss()(x1, x2)
+    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(), g["vic_terms"],
+                               rtol=2e-5)
+    sum(terms).backward()
+    assert rel(x1.grad, g["vic_dx1"]) < 2e-5 and rel(x2.grad, g["vic_dx2"]) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D", [(2, 7), (16, 1024), (5, 300)])
+def test_vicreg_loss_matches_oracle_at_other_sizes(cuda, B, D):
+    from adell_mri_amd.modules.self_supervised.losses import VICRegLoss
+
+    gen = torch.Generator().manual_seed(B * D)
+    a = torch.randn((B, D), generator=gen, dtype=torch.float64).requires_grad_(True)
+    b = (0.3 * a.detach() + torch.randn((B, D), generator=gen, dtype=torch.float64)
+         ).requires_grad_(True)
+    ref = vicreg_loss(a, b)
+    sum(ref).backward()
+    x1 = a.detach().float().to(cuda).requires_grad_(True)
+    x2 = b.detach().float().to(cuda).requires_grad_(True)
+    terms = VICRegLoss()(x1, x2)
+    np.testing.assert_allclose(torch.stack(terms).detach().cpu().numpy(),
+                               torch.stack(ref).detach().numpy(), rtol=5e-5)
+    sum(terms).backward()
+    assert rel(x1.grad, a.grad.numpy()) < 5e-5 and rel(x2.grad, b.grad.numpy()) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,k,oc", [("k3", 3, 8), ("k7", 7, 12)])
+def test_convnext_block_matches_reference(cuda, tag, k, oc):
+    from adell_mri_amd.modules.layers.res_blocks import ConvNeXtBlock3d
+
+    g = gold()
+    blk = ConvNeXtBlock3d(8, k, 16, oc)
+    blk.load_state_dict(fill_state_dict(blk.state_dict()))
+    blk = blk.to(cuda)
+    x = torch.from_numpy(g["blk_x"]).to(cuda).requires_grad_(True)
+    y = blk(x)
+    assert rel(y, g[f"blk_{tag}_y"]) < 1e-5
+    (y * torch.from_numpy(g[f"blk_{tag}_r"]).to(cuda)).sum().backward()
+    assert rel(x.grad, g[f"blk_{tag}_dx"]) < 1e-4
+    for n, p in blk.named_parameters():
+        ref = g[f"blk_{tag}_grad:{n}"]
+        assert rel(p.grad, ref) < 1e-4, n
+
+
+@pytest.mark.gpu
+def test_vicreg_training_step_matches_reference(cuda):
+    """forward of both views, VICReg terms, every parameter gradient, one AdamW step and the
+    EMA shadow update (self_supervised/pl.py:904-972, :231-267; utils/utils.py:447-493)."""
+    from adell_mri_amd.trainer import StepRunner
+    from adell_mri_amd.utils import ExponentialMovingAverage
+
+    g = gold()
+    net = build_pl().to(cuda).train()
+    net.ema = ExponentialMovingAverage(0.99)
+    net.ema.update(net)
+    x1, x2 = torch.from_numpy(g["x1"]).to(cuda), torch.from_numpy(g["x2"]).to(cuda)
+    assert rel(net(x1, ret="representation"), g["representation"]) < 1e-4
+    assert rel(net(x1, ret="prediction"), g["y1"]) < 1e-4
+    assert rel(net(x2, ret="projection"), g["y2"]) < 1e-4
+
+    # the fixture's second view goes through the online network (no EMA forward): keep the
+    # shadow for the update only
+    ema, net.ema = net.ema, None
+    runner = StepRunner(net)
+    net.ema = None
+    runner.optimizer.zero_grad()
+    loss = net.training_step({"a": x1, "b": x2}, 0)
+    np.testing.assert_allclose(torch.stack(list(net.last_losses)).detach().cpu().numpy(),
+                               g["losses"], rtol=5e-4, atol=1e-8)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert grad_rel_err(g, k, p.grad.cpu().numpy()) < 5e-3, k
+    runner.optimizer.step()
+    ema.update(net)
+    for k, p in net.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g["step1:" + k], rtol=2e-4,
+                                   atol=2e-6, err_msg=k)
+    assert ema._plan is not None, "EMA should take the single-launch flat path"
+    for k, p in ema.shadow.named_parameters():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g["ema1:" + k], rtol=1e-5,
+                                   atol=1e-7, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_ema_forward_and_stop_gradient_step_runs(cuda):
+    """BYOL-style wiring: second view through the EMA shadow under no_grad; the loss
+    decreases over a few steps and the shadow trails the online weights."""
+    from adell_mri_amd.trainer import StepRunner
+    from adell_mri_amd.utils import ExponentialMovingAverage
+
+    g = gold()
+    net = build_pl().to(cuda).train()
+    net.stop_gradient = True
+    net.ema = ExponentialMovingAverage(0.9)
+    net.ema.update(net)
+    runner = StepRunner(net)
+    batch = {"a": torch.from_numpy(g["x1"]).to(cuda), "b": torch.from_numpy(g["x2"]).to(cuda)}
+    w0 = net.backbone.input_layer[0].weight.detach().clone()
+    losses = [runner.train_step(batch).item() for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    w1 = net.backbone.input_layer[0].weight.detach()
+    ws = net.ema.shadow.backbone.input_layer[0].weight.detach()
+    assert not torch.equal(w0, w1)
+    # shadow lies strictly between the initial and the current weights
+    d_total = (w1 - w0).abs().max().item()
+    assert 0 < (ws - w0).abs().max().item() < d_total
+    for _, p in net.ema.shadow.named_parameters():
+        assert p.grad is None and not p.requires_grad
