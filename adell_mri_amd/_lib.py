@@ -96,7 +96,8 @@ SIGNATURES = {
     "adell_maxpool3d_bwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "adell_dwconv3d_fwd": (_i, [_i] * 8 + [_vp] * 5),
     "adell_dwconv3d_bwd_data": (_i, [_i] * 8 + [_vp] * 4),
-    "adell_dwconv3d_bwd_weight": (_i, [_i] * 8 + [_vp] * 5),
+    "adell_dwconv3d_bwd_weight_workspace_floats": (_l, [_i] * 8),
+    "adell_dwconv3d_bwd_weight": (_i, [_i] * 8 + [_vp] * 6),
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),

@@ -68,6 +68,237 @@ __global__ __launch_bounds__(256) void adell_dwconv3d_kernel(DwArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-tiled depthwise kernels for cubic K in {3, 5, 7} (the ConvNeXt shapes).
+//
+// A block owns 16 channels x a 4 x 4 (z, y) tile of output rows x one x-segment of WT
+// voxels. The input halo tile ((4+K-1)^2 rows x WT voxels x 16 channels) is staged in LDS
+// as [row][channel][x] with x contiguous; a thread = (channel, output row) keeps its WT
+// outputs in registers and, per (kz, ky), reads one input row (WT/4 ds_read_b128) and K
+// weights and issues the fully unrolled K x WT FMA stencil along x. Row and channel
+// strides are odd multiples of 4 words so that the 16 channel-lanes of a b128 phase hit
+// 64 distinct banks. VALU-bound: 2*K^3 flops per output at the fp32 vector rate.
+// When W > WT the x axis is cut into segments of WT - 2P outputs (the row carries its own
+// halo); rows, columns and channels beyond the volume are zero in LDS and never stored.
+// ---------------------------------------------------------------------------
+template <int K, int WT>
+struct DwCfg {
+  static constexpr int P = K / 2;
+  static constexpr int TD = 4, TH = 4;
+  static constexpr int HZ = TD + K - 1, HY = TH + K - 1;
+  static constexpr int WS = (WT == 4) ? 4 : WT + 4;
+  static constexpr int KP = (K + 3) & ~3;
+  static constexpr int CS0 = K * K * KP;
+  static constexpr int CS = ((CS0 / 4) & 1) ? CS0 : CS0 + 4;
+  static constexpr int K3 = K * K * K;
+  static constexpr int XT_FLOATS = HZ * HY * 16 * WS;
+  static constexpr int WT_FLOATS = 16 * CS;
+  static constexpr int DY_FLOATS = TD * TH * 16 * WS;
+  static constexpr int WG_THREADS = ((16 * K * K + 63) / 64) * 64;
+};
+
+struct DwTile {
+  int N, C, D, H, W;
+  int tilesX, tilesY, tilesZ, chanBlocks;
+  int seg;      // outputs per x segment (W when one segment covers the row)
+  int single;   // 1: one segment, LDS row starts at x = 0
+};
+
+__device__ __forceinline__ void adell_dw_decode(const DwTile& t, long item, int& n, int& z0,
+                                                int& y0, int& tx) {
+  tx = (int)(item % t.tilesX); item /= t.tilesX;
+  const int ty = (int)(item % t.tilesY); item /= t.tilesY;
+  const int tz = (int)(item % t.tilesZ);
+  n = (int)(item / t.tilesZ);
+  z0 = tz * 4;
+  y0 = ty * 4;
+}
+
+// stage the halo tile of `src` (NDHWC) for channels [c0, c0+16) into LDS
+template <int K, int WT>
+__device__ __forceinline__ void adell_dw_load_halo(const float* __restrict__ src, const DwTile& t,
+                                                   int n, int z0, int y0, int xin0, int c0,
+                                                   float* xt, int tid, int nthreads) {
+  using Cf = DwCfg<K, WT>;
+  constexpr int TOTAL = Cf::HZ * Cf::HY * WT * 16;
+  for (int i = tid; i < TOTAL; i += nthreads) {
+    const int c = i & 15;
+    const int j = (i >> 4) % WT;
+    const int r = (i >> 4) / WT;
+    const int z = z0 - Cf::P + r / Cf::HY, y = y0 - Cf::P + r % Cf::HY, x = xin0 + j;
+    float v = 0.f;
+    if (z >= 0 && z < t.D && y >= 0 && y < t.H && x >= 0 && x < t.W && c0 + c < t.C)
+      v = src[((((size_t)n * t.D + z) * t.H + y) * t.W + x) * t.C + c0 + c];
+    xt[(r * 16 + c) * Cf::WS + j] = v;
+  }
+}
+
+template <int WT>
+__device__ __forceinline__ void adell_dw_read_row(const float* p, float (&v)[WT]) {
+#pragma unroll
+  for (int q = 0; q < WT / 4; ++q) {
+    const float4 f = *reinterpret_cast<const float4*>(p + 4 * q);
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+}
+
+struct DwTileArgs {
+  const float* x;
+  const float* w;
+  const float* b;
+  float* y;
+  DwTile t;
+  int flip;
+};
+
+template <int K, int WT>
+__global__ __launch_bounds__(256) void adell_dw_tile_kernel(DwTileArgs a) {
+  using Cf = DwCfg<K, WT>;
+  extern __shared__ float smem[];
+  float* xt = smem;
+  float* wt = smem + Cf::XT_FLOATS;
+  const int tid = threadIdx.x;
+  const DwTile& t = a.t;
+  const int cb = blockIdx.x % t.chanBlocks;   // channel blocks of one tile run together:
+  const long item = blockIdx.x / t.chanBlocks;  // they share the tile's cache lines
+  int n, z0, y0, tx;
+  adell_dw_decode(t, item, n, z0, y0, tx);
+  const int c0 = cb * 16;
+  const int xin0 = t.single ? 0 : tx * t.seg - Cf::P;
+  for (int i = tid; i < 16 * Cf::K3; i += 256) {
+    const int c = i / Cf::K3, tap = i % Cf::K3;
+    const int src = a.flip ? Cf::K3 - 1 - tap : tap;
+    wt[c * Cf::CS + (tap / K) * Cf::KP + tap % K] =
+        (c0 + c < t.C) ? a.w[(size_t)(c0 + c) * Cf::K3 + src] : 0.f;
+  }
+  adell_dw_load_halo<K, WT>(a.x, t, n, z0, y0, xin0, c0, xt, tid, 256);
+  __syncthreads();
+  const int c = tid & 15, row = tid >> 4, rz = row >> 2, ry = row & 3;
+  float acc[WT];
+  const float bias = (a.b && c0 + c < t.C) ? a.b[c0 + c] : 0.f;
+#pragma unroll
+  for (int j = 0; j < WT; ++j) acc[j] = bias;
+  const float* wc = wt + c * Cf::CS;
+#pragma unroll 1
+  for (int kz = 0; kz < K; ++kz) {
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      float in[WT], wk[Cf::KP];
+      adell_dw_read_row<WT>(xt + (((rz + kz) * Cf::HY + ry + ky) * 16 + c) * Cf::WS, in);
+      adell_dw_read_row<Cf::KP>(wc + (kz * K + ky) * Cf::KP, wk);
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          const int jj = j + kx - Cf::P;
+          if (jj >= 0 && jj < WT) acc[j] = fmaf(wk[kx], in[jj], acc[j]);
+        }
+    }
+  }
+  const int z = z0 + rz, y = y0 + ry;
+  if (z < t.D && y < t.H && c0 + c < t.C) {
+    const int jlo = t.single ? 0 : Cf::P;
+    float* out = a.y + ((((size_t)n * t.D + z) * t.H + y) * t.W) * t.C + c0 + c;
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int x = xin0 + j;
+      if (j >= jlo && j < jlo + t.seg && x < t.W) out[(size_t)x * t.C] = acc[j];
+    }
+  }
+}
+
+struct DwWgradArgs {
+  const float* x;
+  const float* dy;
+  float* part;   // [splits][chanBlocks*16][K3 + 1]
+  DwTile t;
+  long items;
+  int itemsPerSplit;
+};
+
+// thread = (channel, (kz, ky)): K accumulators (kx) in registers over every tile the block
+// visits; per output row it reads the dy row and the matching shifted input row from LDS.
+template <int K, int WT>
+__global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_dw_wgrad_tile_kernel(
+    DwWgradArgs a) {
+  using Cf = DwCfg<K, WT>;
+  constexpr int NT = Cf::WG_THREADS;
+  extern __shared__ float smem[];
+  float* xt = smem;
+  float* dyt = smem + Cf::XT_FLOATS;
+  const int tid = threadIdx.x;
+  const DwTile& t = a.t;
+  const int cb = blockIdx.x % t.chanBlocks, split = blockIdx.x / t.chanBlocks;
+  const int c0 = cb * 16;
+  const int c = tid & 15, kk = tid >> 4;
+  const bool active = kk < K * K;
+  const int kz = kk / K, ky = kk % K;
+  float acc[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) acc[q] = 0.f;
+  float sb = 0.f;
+  const long first = (long)split * a.itemsPerSplit;
+  long last = first + a.itemsPerSplit;
+  if (last > a.items) last = a.items;
+  for (long item = first; item < last; ++item) {
+    int n, z0, y0, tx;
+    adell_dw_decode(t, item, n, z0, y0, tx);
+    const int xin0 = t.single ? 0 : tx * t.seg - Cf::P;
+    const int jlo = t.single ? 0 : Cf::P;
+    __syncthreads();
+    adell_dw_load_halo<K, WT>(a.x, t, n, z0, y0, xin0, c0, xt, tid, NT);
+    for (int i = tid; i < 16 * WT * 16; i += NT) {
+      const int cc = i & 15, j = (i >> 4) % WT, r = (i >> 4) / WT;
+      const int z = z0 + (r >> 2), y = y0 + (r & 3), x = xin0 + j;
+      float v = 0.f;
+      if (z < t.D && y < t.H && j >= jlo && j < jlo + t.seg && x < t.W && c0 + cc < t.C)
+        v = a.dy[((((size_t)n * t.D + z) * t.H + y) * t.W + x) * t.C + c0 + cc];
+      dyt[(r * 16 + cc) * Cf::WS + j] = v;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int row = 0; row < 16; ++row) {
+        const int rz = row >> 2, ry = row & 3;
+        float g[WT], in[WT];
+        adell_dw_read_row<WT>(dyt + (row * 16 + c) * Cf::WS, g);
+        adell_dw_read_row<WT>(xt + (((rz + kz) * Cf::HY + ry + ky) * 16 + c) * Cf::WS, in);
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+          for (int j = 0; j < WT; ++j) {
+            const int jj = j + kx - Cf::P;
+            if (jj >= 0 && jj < WT) acc[kx] = fmaf(g[j], in[jj], acc[kx]);
+          }
+        if (kk == 0) {
+#pragma unroll
+          for (int j = 0; j < WT; ++j) sb += g[j];
+        }
+      }
+    }
+  }
+  if (active) {
+    float* dst = a.part + ((size_t)split * t.chanBlocks * 16 + c0 + c) * (Cf::K3 + 1);
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) dst[(kz * K + ky) * K + kx] = acc[kx];
+    if (kk == 0) dst[Cf::K3] = sb;
+  }
+}
+
+// dw[c][tap] = sum over splits (fixed order); column K3 of the partials is db
+__global__ __launch_bounds__(256) void adell_dw_wgrad_reduce_kernel(
+    const float* __restrict__ part, int splits, int cpad, int C, int K3, float* __restrict__ dw,
+    float* __restrict__ db) {
+  const long total = (long)C * (K3 + 1);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i / (K3 + 1)), tap = (int)(i % (K3 + 1));
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[((size_t)sp * cpad + c) * (K3 + 1) + tap];
+    if (tap < K3) dw[(size_t)c * K3 + tap] = s;
+    else if (db) db[c] = s;
+  }
+}
+
 static int adell_dw_check(int N, int C, int D, int H, int W, int KD, int KH, int KW) {
   ADELL_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0, "dwconv: bad dims");
   ADELL_REQUIRE(KD >= 1 && KH >= 1 && KW >= 1 && (KD & 1) && (KH & 1) && (KW & 1),
@@ -75,7 +306,66 @@ static int adell_dw_check(int N, int C, int D, int H, int W, int KD, int KH, int
   return ADELL_OK;
 }
 
+// tiled path: cubic K in {3,5,7}. Returns the x-row width WT (4 / 8 / 16) or 0.
+static int adell_dw_plan(int N, int C, int D, int H, int W, int KD, int KH, int KW, DwTile* t) {
+  if (KD != KH || KH != KW || (KD != 3 && KD != 5 && KD != 7)) return 0;
+  const int K = KD, P = K / 2;
+  int WT = W <= 4 ? 4 : (W <= 8 ? 8 : 16);
+  t->N = N; t->C = C; t->D = D; t->H = H; t->W = W;
+  t->single = W <= WT;
+  if (!t->single && WT - 2 * P < 4) return 0;
+  t->seg = t->single ? W : WT - 2 * P;
+  t->tilesX = t->single ? 1 : adell_cdiv(W, t->seg);
+  t->tilesY = adell_cdiv(H, 4);
+  t->tilesZ = adell_cdiv(D, 4);
+  t->chanBlocks = adell_cdiv(C, 16);
+  const long blocks = (long)N * t->tilesZ * t->tilesY * t->tilesX * t->chanBlocks;
+  if (blocks > 0x7fffffffL) return 0;
+  return WT;
+}
+
+template <int K, int WT>
+static int adell_dw_tile_launch(const DwTileArgs& a, hipStream_t st) {
+  using Cf = DwCfg<K, WT>;
+  static bool attr_done = false;
+  auto kern = adell_dw_tile_kernel<K, WT>;
+  const size_t lds = (size_t)(Cf::XT_FLOATS + Cf::WT_FLOATS) * sizeof(float);
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const DwTile& t = a.t;
+  const long blocks = (long)t.N * t.tilesZ * t.tilesY * t.tilesX * t.chanBlocks;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+#define ADELL_DW_DISPATCH(FN, K, WT, ...)                                  \
+  do {                                                                     \
+    if (K == 3) {                                                          \
+      if (WT == 4) return FN<3, 4>(__VA_ARGS__);                           \
+      if (WT == 8) return FN<3, 8>(__VA_ARGS__);                           \
+      return FN<3, 16>(__VA_ARGS__);                                       \
+    }                                                                      \
+    if (K == 5) {                                                          \
+      if (WT == 4) return FN<5, 4>(__VA_ARGS__);                           \
+      if (WT == 8) return FN<5, 8>(__VA_ARGS__);                           \
+      return FN<5, 16>(__VA_ARGS__);                                       \
+    }                                                                      \
+    if (WT == 4) return FN<7, 4>(__VA_ARGS__);                             \
+    if (WT == 8) return FN<7, 8>(__VA_ARGS__);                             \
+    return FN<7, 16>(__VA_ARGS__);                                         \
+  } while (0)
+
 static int adell_dw_launch(DwArgs a, hipStream_t st) {
+  DwTileArgs ta;
+  const int WT = adell_dw_plan(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, &ta.t);
+  if (WT) {
+    ta.x = a.x; ta.w = a.w; ta.b = a.b; ta.y = a.y; ta.flip = a.flip;
+    ADELL_DW_DISPATCH(adell_dw_tile_launch, a.KD, WT, ta, st);
+  }
   const long total = (long)a.N * a.D * a.H * a.W * (((a.C & 3) == 0) ? a.C / 4 : a.C);
   long blocks = (total + 255) / 256;
   if (blocks > 16384) blocks = 16384;
@@ -107,6 +397,7 @@ extern "C" int adell_dwconv3d_bwd_data(int N, int C, int D, int H, int W, int KD
 
 // dw[c][tap] = sum_v x[v + tap - p][c] * dy[v][c];  db[c] = sum_v dy[v][c] (tap == centre
 // block also reduces db). grid (taps, channel groups of 64); block = 64 channels x 4 lanes.
+// Generic fallback (non-cubic kernels).
 __global__ __launch_bounds__(256) void adell_dwconv3d_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw,
     float* __restrict__ db, int N, int C, int D, int H, int W, int KD, int KH, int KW) {
@@ -142,14 +433,78 @@ __global__ __launch_bounds__(256) void adell_dwconv3d_wgrad_kernel(
   }
 }
 
+static int adell_dw_wgrad_splits(const DwTile& t, long* items_out, int* ips_out) {
+  const long items = (long)t.N * t.tilesZ * t.tilesY * t.tilesX;
+  long splits = adell_cdiv(512, t.chanBlocks);
+  if (splits > items) splits = items;
+  if (splits < 1) splits = 1;
+  const int ips = (int)((items + splits - 1) / splits);
+  splits = (items + ips - 1) / ips;
+  *items_out = items;
+  *ips_out = ips;
+  return (int)splits;
+}
+
+template <int K, int WT>
+static int adell_dw_wgrad_tile_launch(DwWgradArgs a, int splits, hipStream_t st) {
+  using Cf = DwCfg<K, WT>;
+  static bool attr_done = false;
+  auto kern = adell_dw_wgrad_tile_kernel<K, WT>;
+  const size_t lds = (size_t)(Cf::XT_FLOATS + Cf::DY_FLOATS) * sizeof(float);
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(splits * a.t.chanBlocks)), dim3(Cf::WG_THREADS), lds, st,
+                     a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+static int adell_dw_wgrad_dispatch(int K, int WT, const DwWgradArgs& a, int splits,
+                                   hipStream_t st) {
+  ADELL_DW_DISPATCH(adell_dw_wgrad_tile_launch, K, WT, a, splits, st);
+}
+
+// floats of workspace adell_dwconv3d_bwd_weight needs (0: none)
+extern "C" long adell_dwconv3d_bwd_weight_workspace_floats(int N, int C, int D, int H, int W,
+                                                           int KD, int KH, int KW) {
+  DwTile t;
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+  if (!adell_dw_plan(N, C, D, H, W, KD, KH, KW, &t)) return 0;
+  long items;
+  int ips;
+  const int splits = adell_dw_wgrad_splits(t, &items, &ips);
+  return (long)splits * t.chanBlocks * 16 * ((long)KD * KH * KW + 1);
+}
+
 extern "C" int adell_dwconv3d_bwd_weight(int N, int C, int D, int H, int W, int KD, int KH,
                                          int KW, const float* x, const float* dy, float* dw,
-                                         float* db, void* stream) {
+                                         float* db, float* workspace, void* stream) {
   int rc = adell_dw_check(N, C, D, H, W, KD, KH, KW);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(x && dy && dw, "dwconv_bwd_weight: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  DwWgradArgs a;
+  const int WT = adell_dw_plan(N, C, D, H, W, KD, KH, KW, &a.t);
+  if (WT) {
+    ADELL_REQUIRE(workspace, "dwconv_bwd_weight: workspace of "
+                             "adell_dwconv3d_bwd_weight_workspace_floats() floats required");
+    a.x = x; a.dy = dy; a.part = workspace;
+    const int splits = adell_dw_wgrad_splits(a.t, &a.items, &a.itemsPerSplit);
+    rc = adell_dw_wgrad_dispatch(KD, WT, a, splits, st);
+    if (rc != ADELL_OK) return rc;
+    const int K3 = KD * KH * KW;
+    long blocks = ((long)C * (K3 + 1) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adell_dw_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       workspace, splits, a.t.chanBlocks * 16, C, K3, dw, db);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   hipLaunchKernelGGL(adell_dwconv3d_wgrad_kernel, dim3(KD * KH * KW, adell_cdiv(C, 64)), dim3(256),
-                     0, (hipStream_t)stream, x, dy, dw, db, N, C, D, H, W, KD, KH, KW);
+                     0, st, x, dy, dw, db, N, C, D, H, W, KD, KH, KW);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

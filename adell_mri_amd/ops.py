@@ -647,8 +647,10 @@ def dwconv3d_bwd_weight(x, dy, kshape, want_db):
     kd, kh, kw = kshape
     dw = torch.empty((C, 1, kd, kh, kw), device=x.device, dtype=torch.float32)
     db = torch.empty((C,), device=x.device, dtype=torch.float32) if want_db else None
+    nws = _lib.lib().adell_dwconv3d_bwd_weight_workspace_floats(N, C, D, H, W, kd, kh, kw)
+    ws = torch.empty((nws,), device=x.device, dtype=torch.float32) if nws else None
     check(_lib.lib().adell_dwconv3d_bwd_weight(N, C, D, H, W, kd, kh, kw, _ptr(x), _ptr(dy),
-                                               _ptr(dw), _ptr(db), _stream()))
+                                               _ptr(dw), _ptr(db), _ptr(ws), _stream()))
     return dw, db
 
 

@@ -317,9 +317,13 @@ int adell_dwconv3d_fwd(int N, int C, int D, int H, int W, int KD, int KH, int KW
                        void* stream);
 int adell_dwconv3d_bwd_data(int N, int C, int D, int H, int W, int KD, int KH, int KW,
                             const float* dy, const float* w, float* dx, void* stream);
+/* workspace: adell_dwconv3d_bwd_weight_workspace_floats(...) floats (split partial sums of
+ * the tiled kernel; may be NULL when that returns 0) */
+long adell_dwconv3d_bwd_weight_workspace_floats(int N, int C, int D, int H, int W, int KD, int KH,
+                                                int KW);
 int adell_dwconv3d_bwd_weight(int N, int C, int D, int H, int W, int KD, int KH, int KW,
                               const float* x, const float* dy, float* dw, float* db,
-                              void* stream);
+                              float* workspace, void* stream);
 /* VICReg terms of two [B][D] embeddings (self_supervised/losses/vicreg.py:60-140):
  * out3 = (invariance, variance, covariance), unweighted; scratch of
  * adell_vicreg_scratch_floats(B, D) floats is kept for the backward, which returns

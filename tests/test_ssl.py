@@ -105,7 +105,9 @@ def test_unsupported_ssl_methods_raise():
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,size,k", [(2, 8, (6, 6, 6), 3), (1, 96, (16, 16, 16), 7),
                                         (2, 24, (4, 5, 3), 7), (1, 130, (2, 2, 2), 3),
-                                        (1, 8, (7, 6, 9), (3, 1, 5))])
+                                        (1, 8, (7, 6, 9), (3, 1, 5)),
+                                        (1, 20, (5, 9, 21), 7), (1, 16, (6, 6, 37), 3),
+                                        (2, 8, (9, 10, 11), 5), (1, 33, (3, 17, 16), 5)])
 def test_depthwise_conv3d_fwd_bwd(cuda, N, C, size, k):
     from adell_mri_amd import functional as HF
     from adell_mri_amd import ops
