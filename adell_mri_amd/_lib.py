@@ -101,6 +101,8 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_gemm_f32_workspace_floats": (_l, [_i, _i, _i]),
+    "adell_gemm_f32": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),
 }
 

@@ -476,30 +476,28 @@ extern "C" int adell_convtranspose3d_k2s2_bwd_weight(int N, int D, int H, int W,
 // ---------------------------------------------------------------------------
 // Bias gradient: column sums of dy [rows][C], two deterministic phases.
 // ---------------------------------------------------------------------------
-#define ADELL_BG_ROWS 2048
+// grid (row chunks, groups of 64 columns); block = 64 columns x 4 row lanes.
 __global__ __launch_bounds__(256) void adell_colsum_partial_kernel(
-    const float* __restrict__ dy, long rows, int C, float* __restrict__ part) {
-  __shared__ float sh[256];
-  const long r0 = (long)blockIdx.x * ADELL_BG_ROWS;
-  long r1 = r0 + ADELL_BG_ROWS;
+    const float* __restrict__ dy, long rows, int C, int chunk, float* __restrict__ part) {
+  __shared__ float sh[4][64];
+  const long r0 = (long)blockIdx.x * chunk;
+  long r1 = r0 + chunk;
   if (r1 > rows) r1 = rows;
-  const int CG = C < 256 ? C : 256;
-  const int VL = 256 / CG;
-  const int cl = threadIdx.x % CG, vl = threadIdx.x / CG;
-  for (int cb = 0; cb < C; cb += CG) {
-    const int c = cb + cl;
-    float s = 0.f;
-    if (vl < VL && c < C)
-      for (long r = r0 + vl; r < r1; r += VL) s += dy[r * C + c];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (vl == 0 && c < C) {
-      float t = 0.f;
-      for (int k = 0; k < VL; ++k) t += sh[k * CG + cl];
-      part[(size_t)blockIdx.x * C + c] = t;
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    long r = r0 + vl;
+    for (; r + 4 < r1; r += 8) {
+      s0 += dy[r * C + c];
+      s1 += dy[(r + 4) * C + c];
     }
-    __syncthreads();
+    if (r < r1) s0 += dy[r * C + c];
   }
+  sh[vl][cl] = s0 + s1;
+  __syncthreads();
+  if (vl == 0 && c < C)
+    part[(size_t)blockIdx.x * C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
 __global__ void adell_colsum_final_kernel(const float* __restrict__ part, int nb, int C,
                                           float* __restrict__ out) {
@@ -510,8 +508,22 @@ __global__ void adell_colsum_final_kernel(const float* __restrict__ part, int nb
   out[c] = (float)s;
 }
 
+// rows per block: about 2048 blocks in total, at least 16 rows each
+static int adell_bias_grad_chunk(long rows, int C) {
+  const long colgroups = adell_cdiv(C, 64);
+  long nchunks = 2048 / colgroups;
+  if (nchunks < 1) nchunks = 1;
+  long chunk = (rows + nchunks - 1) / nchunks;
+  if (chunk < 16) chunk = 16;
+  chunk = (chunk + 3) / 4 * 4;
+  if (chunk > 65536) chunk = 65536;
+  return (int)chunk;
+}
+
 extern "C" long adell_bias_grad_workspace(long rows, int C) {
-  return (long)((rows + ADELL_BG_ROWS - 1) / ADELL_BG_ROWS) * C * (long)sizeof(float);
+  if (rows <= 0 || C <= 0) return 0;
+  const int chunk = adell_bias_grad_chunk(rows, C);
+  return (long)((rows + chunk - 1) / chunk) * C * (long)sizeof(float);
 }
 
 extern "C" int adell_bias_grad(const float* dy, long rows, int C, float* db, void* workspace,
@@ -520,9 +532,10 @@ extern "C" int adell_bias_grad(const float* dy, long rows, int C, float* db, voi
   ADELL_REQUIRE(rows > 0 && C > 0, "bias_grad: bad dims");
   ADELL_REQUIRE((long)workspace_bytes >= adell_bias_grad_workspace(rows, C),
                 "bias_grad: workspace too small");
-  const int nb = (int)((rows + ADELL_BG_ROWS - 1) / ADELL_BG_ROWS);
-  hipLaunchKernelGGL(adell_colsum_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream,
-                     dy, rows, C, (float*)workspace);
+  const int chunk = adell_bias_grad_chunk(rows, C);
+  const int nb = (int)((rows + chunk - 1) / chunk);
+  hipLaunchKernelGGL(adell_colsum_partial_kernel, dim3(nb, adell_cdiv(C, 64)), dim3(256), 0,
+                     (hipStream_t)stream, dy, rows, C, chunk, (float*)workspace);
   hipLaunchKernelGGL(adell_colsum_final_kernel, dim3(adell_cdiv(C, 64)), dim3(64), 0,
                      (hipStream_t)stream, (const float*)workspace, nb, C, db);
   ADELL_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,278 @@
+// Row-major fp32 GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32) for the Linear layers of the
+// token / feature paths (ViT encoder of UNETR, ConvNeXt point-wise layers, projection
+// heads; torch.nn.Linear in adell_mri/modules/layers/linear_blocks.py, res_blocks.py:559-566,
+// res_net.py:278-324):
+//
+//     C[M][N] = sum_k A(m, k) * B(k, n)  (+ bias[n]) (+ residual[m][n])
+//
+// Each operand is either "k-contiguous" (KC: A[m*lda + k], B[n*ldb + k]) or "outer-
+// contiguous" (MC: A[k*lda + m], B[k*ldb + n]); that covers forward (X W^T: KC, KC),
+// backward-data (dY W: KC, MC) and backward-weight (dY^T X: MC, MC) without materialising
+// a transpose. A block of 4 waves owns a BM x BN tile; per step of 16 k values the two
+// operand tiles go global -> registers -> LDS (double-buffered, one barrier per step,
+// the next step's global loads in flight during the MFMAs). Within a group of 8 k values
+// lane half h = lane >> 5 takes k = 4h + s for MFMA s = 0..3 (the same permutation for
+// both operands), so a KC operand is one ds_read_b128 per 4 MFMAs. LDS strides are chosen
+// so that every read and write is bank-conflict-free.
+// Skinny problems are split along k (deterministic: each split writes its own slab, a
+// second kernel sums the slabs in fixed order and applies bias / residual).
+#include "common.h"
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* residual;
+  float* slab;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int splits, ksteps_per_split;
+  int a_vec, b_vec;  // operand may be read with 16-byte loads
+};
+
+constexpr int GEMM_BK = 16;
+constexpr int GEMM_KC_STRIDE = GEMM_BK + 4;  // [row][k] layout: 20 words
+
+template <int BR>
+struct GemmOpTile {
+  static constexpr int MC_STRIDE = BR + 8;  // [k][row] layout: 4*stride = 32 (mod 64)
+  static constexpr int FLOATS_KC = BR * GEMM_KC_STRIDE;
+  static constexpr int FLOATS_MC = GEMM_BK * MC_STRIDE;
+  static constexpr int FLOATS = FLOATS_KC > FLOATS_MC ? FLOATS_KC : FLOATS_MC;
+  static constexpr int F4_PER_THREAD = (BR * 4 + 255) / 256;  // float4 loads per thread per step
+};
+
+__device__ __forceinline__ f32x4 adell_gemm_load4(const float* __restrict__ p, long off, int valid,
+                                                  int vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid >= 4 && vec) {
+    v = *reinterpret_cast<const f32x4*>(p + off);
+  } else {
+    if (valid > 0) v.x = p[off];
+    if (valid > 1) v.y = p[off + 1];
+    if (valid > 2) v.z = p[off + 2];
+    if (valid > 3) v.w = p[off + 3];
+  }
+  return v;
+}
+
+// fetch this thread's share of a BR x 16 operand tile (rows r0.., k from k0, k < kend)
+template <int BR, bool KC>
+__device__ __forceinline__ void adell_gemm_fetch(const float* __restrict__ P, long ld, int rows,
+                                                 int r0, int k0, int kend, int vec, int tid,
+                                                 f32x4 (&reg)[GemmOpTile<BR>::F4_PER_THREAD]) {
+#pragma unroll
+  for (int i = 0; i < GemmOpTile<BR>::F4_PER_THREAD; ++i) {
+    const int idx = tid + i * 256;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (idx < BR * 4) {
+      if (KC) {
+        const int row = r0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+        if (row < rows) v = adell_gemm_load4(P, (long)row * ld + k, kend - k, vec);
+      } else {
+        const int k = k0 + idx / (BR / 4), row = r0 + (idx % (BR / 4)) * 4;
+        if (k < kend) v = adell_gemm_load4(P, (long)k * ld + row, rows - row, vec);
+      }
+    }
+    reg[i] = v;
+  }
+}
+
+template <int BR, bool KC>
+__device__ __forceinline__ void adell_gemm_stash(float* lds, int tid,
+                                                 const f32x4 (&reg)[GemmOpTile<BR>::F4_PER_THREAD]) {
+#pragma unroll
+  for (int i = 0; i < GemmOpTile<BR>::F4_PER_THREAD; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < BR * 4) {
+      float* dst = KC ? lds + (idx >> 2) * GEMM_KC_STRIDE + (idx & 3) * 4
+                      : lds + (idx / (BR / 4)) * GemmOpTile<BR>::MC_STRIDE + (idx % (BR / 4)) * 4;
+      *reinterpret_cast<f32x4*>(dst) = reg[i];
+    }
+  }
+}
+
+// the 4 k values (4h + s, s = 0..3) of k-group g for tile row `r`
+template <int BR, bool KC>
+__device__ __forceinline__ f32x4 adell_gemm_frag(const float* lds, int r, int g, int h) {
+  if (KC) return *reinterpret_cast<const f32x4*>(lds + r * GEMM_KC_STRIDE + g * 8 + 4 * h);
+  const float* p = lds + (g * 8 + 4 * h) * GemmOpTile<BR>::MC_STRIDE + r;
+  f32x4 v;
+  v.x = p[0];
+  v.y = p[GemmOpTile<BR>::MC_STRIDE];
+  v.z = p[2 * GemmOpTile<BR>::MC_STRIDE];
+  v.w = p[3 * GemmOpTile<BR>::MC_STRIDE];
+  return v;
+}
+
+template <int WM, int WN, int TM, int TN, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void adell_gemm_f32_kernel(GemmArgs a) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  using TA = GemmOpTile<BM>;
+  using TB = GemmOpTile<BN>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (TA::FLOATS + TB::FLOATS)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int split = blockIdx.z;
+  const int k_begin = split * a.ksteps_per_split * GEMM_BK;
+  int k_end = k_begin + a.ksteps_per_split * GEMM_BK;
+  if (k_end > a.K) k_end = a.K;
+  const int nsteps = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[TA::F4_PER_THREAD], rb[TB::F4_PER_THREAD];
+  adell_gemm_fetch<BM, AKC>(a.A, a.lda, a.M, m0, k_begin, k_end, a.a_vec, tid, ra);
+  adell_gemm_fetch<BN, BKC>(a.B, a.ldb, a.N, n0, k_begin, k_end, a.b_vec, tid, rb);
+  for (int step = 0; step < nsteps; ++step) {
+    float* la = lds + (step & 1) * (TA::FLOATS + TB::FLOATS);
+    float* lb = la + TA::FLOATS;
+    adell_gemm_stash<BM, AKC>(la, tid, ra);
+    adell_gemm_stash<BN, BKC>(lb, tid, rb);
+    __syncthreads();
+    if (step + 1 < nsteps) {
+      const int k0 = k_begin + (step + 1) * GEMM_BK;
+      adell_gemm_fetch<BM, AKC>(a.A, a.lda, a.M, m0, k0, k_end, a.a_vec, tid, ra);
+      adell_gemm_fetch<BN, BKC>(a.B, a.ldb, a.N, n0, k0, k_end, a.b_vec, tid, rb);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = adell_gemm_frag<BM, AKC>(la, (wm * TM + i) * 32 + l31, g, h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = adell_gemm_frag<BN, BKC>(lb, (wn * TN + j) * 32 + l31, g, h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * h
+  const bool direct = a.splits == 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      if (col >= a.N) continue;
+      const float bv = (direct && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= a.M) continue;
+        float v = acc[i][j][r];
+        if (direct) {
+          v += bv;
+          if (a.residual) v += a.residual[(long)row * a.ldr + col];
+          a.C[(long)row * a.ldc + col] = v;
+        } else {
+          a.slab[((long)split * a.M + row) * a.N + col] = v;
+        }
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void adell_gemm_reduce_kernel(GemmArgs a) {
+  const long total = (long)a.M * a.N;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+    float s = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) s += a.slab[(long)sp * total + i];
+    if (a.bias) s += a.bias[col];
+    if (a.residual) s += a.residual[(long)row * a.ldr + col];
+    a.C[(long)row * a.ldc + col] = s;
+  }
+}
+
+struct GemmPlan {
+  int skinny;  // 32 x 128 tile instead of 128 x 128
+  int BM, BN, splits, ksteps_per_split;
+};
+
+static GemmPlan adell_gemm_plan(int M, int N, int K) {
+  GemmPlan p;
+  p.skinny = M <= 32;
+  p.BM = p.skinny ? 32 : 128;
+  p.BN = 128;
+  const long tiles = (long)adell_cdiv(M, p.BM) * adell_cdiv(N, p.BN);
+  const int ksteps = adell_cdiv(K, GEMM_BK);
+  long s = adell_cdiv(512, tiles);
+  if (s > ksteps / 4) s = ksteps / 4;
+  if (s > 128) s = 128;
+  if (s < 1) s = 1;
+  p.ksteps_per_split = adell_cdiv(ksteps, (int)s);
+  p.splits = adell_cdiv(ksteps, p.ksteps_per_split);
+  return p;
+}
+
+extern "C" long adell_gemm_f32_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const GemmPlan p = adell_gemm_plan(M, N, K);
+  return p.splits > 1 ? (long)p.splits * M * N : 0;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int adell_gemm_launch(const GemmArgs& a, int a_kc, int b_kc, dim3 grid, hipStream_t st) {
+  if (a_kc && b_kc)
+    hipLaunchKernelGGL((adell_gemm_f32_kernel<WM, WN, TM, TN, true, true>), grid, dim3(256), 0, st, a);
+  else if (a_kc && !b_kc)
+    hipLaunchKernelGGL((adell_gemm_f32_kernel<WM, WN, TM, TN, true, false>), grid, dim3(256), 0, st, a);
+  else if (!a_kc && !b_kc)
+    hipLaunchKernelGGL((adell_gemm_f32_kernel<WM, WN, TM, TN, false, false>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((adell_gemm_f32_kernel<WM, WN, TM, TN, false, true>), grid, dim3(256), 0, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// C[M][N] (row stride ldc) = A x B (+ bias[N]) (+ residual, row stride ldr).
+// a_kc != 0: A element (m, k) at A[m*lda + k], else at A[k*lda + m];
+// b_kc != 0: B element (k, n) at B[n*ldb + k], else at B[k*ldb + n].
+// workspace: adell_gemm_f32_workspace_floats(M, N, K) floats (NULL when that is 0).
+extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int a_kc,
+                              const float* B, long ldb, int b_kc, float* C, long ldc,
+                              const float* bias, const float* residual, long ldr,
+                              float* workspace, void* stream) {
+  ADELL_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad dims");
+  ADELL_REQUIRE(A && B && C, "gemm: null pointer");
+  ADELL_REQUIRE(lda >= (a_kc ? K : M) && ldb >= (b_kc ? K : N) && ldc >= N, "gemm: bad strides");
+  ADELL_REQUIRE(!residual || ldr >= N, "gemm: bad residual stride");
+  const GemmPlan p = adell_gemm_plan(M, N, K);
+  ADELL_REQUIRE(p.splits == 1 || workspace, "gemm: workspace required for this shape");
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.slab = workspace;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
+  a.splits = p.splits;
+  a.ksteps_per_split = p.ksteps_per_split;
+  a.a_vec = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
+  a.b_vec = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(adell_cdiv(M, p.BM), adell_cdiv(N, p.BN), p.splits);
+  ADELL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
+  int rc = p.skinny ? adell_gemm_launch<1, 4, 1, 1>(a, a_kc, b_kc, grid, st)
+                    : adell_gemm_launch<2, 2, 2, 2>(a, a_kc, b_kc, grid, st);
+  if (rc != ADELL_OK) return rc;
+  if (p.splits > 1) {
+    long blocks = ((long)M * N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+  }
+  return ADELL_OK;
+}

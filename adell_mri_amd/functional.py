@@ -256,12 +256,42 @@ def _volume_as_rows(y, lead_shape):
     return y.permute(0, 2, 3, 4, 1).reshape(*lead_shape, C)
 
 
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        N, K = weight.shape
+        x2 = x.reshape(-1, K).contiguous()
+        rows = x2.shape[0]
+        w = weight.contiguous()
+        res2 = None if residual is None else residual.reshape(rows, N).contiguous()
+        y = ops.gemm(rows, N, K, x2, K, True, w, K, True, bias=bias, residual=res2)
+        ctx.save_for_backward(x2, w)
+        ctx.meta = (x.shape, bias is not None, residual is not None and residual.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        xshape, has_bias, res_shape = ctx.meta
+        N, K = w.shape
+        rows = x2.shape[0]
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(rows, N).contiguous()
+        dx = dw = db = dres = None
+        if need[0]:
+            dx = ops.gemm(rows, K, N, dy2, N, True, w, K, False).view(xshape)
+        if need[1]:
+            dw = ops.gemm(N, K, rows, dy2, N, False, x2, K, False)
+        if has_bias and need[2]:
+            db = ops.bias_grad(_rows_as_volume(dy2))
+        if res_shape and need[3]:
+            dres = dy2.view(res_shape)
+        return dx, dw, db, dres
+
+
 def linear(x, weight, bias=None, residual=None):
-    """torch.nn.functional.linear on the MFMA conv kernel (+ fused residual add)."""
-    lead = x.shape[:-1]
-    res = None if residual is None else _rows_as_volume(residual)
-    y = conv3d(_rows_as_volume(x), weight, bias, 1, 0, residual=res, want_stats=False)
-    return _volume_as_rows(y, lead)
+    """torch.nn.functional.linear on the fp32-MFMA GEMM (+ fused bias / residual add)."""
+    return _LinearFn.apply(x, weight, bias, residual)
 
 
 def elementwise(x, act="identity", act_p=0.0, drop_p=0.0, training=False):

@@ -654,6 +654,24 @@ def dwconv3d_bwd_weight(x, dy, kshape, want_db):
     return dw, db
 
 
+def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, out=None, bias=None, residual=None):
+    """out[M, N] = A x B (+ bias) (+ residual) on the fp32 MFMA GEMM (csrc/gemm.hip).
+    a_kc: A(m,k) = A[m*lda + k] else A[k*lda + m]; b_kc: B(k,n) = B[n*ldb + k] else B[k*ldb + n]."""
+    _require_cuda(A, B, bias, residual)
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    nws = _lib.lib().adell_gemm_f32_workspace_floats(M, N, K)
+    ws = _workspace(nws * 4, A.device) if nws else None
+    ldr = 0 if residual is None else N
+
+    def run():
+        check(_lib.lib().adell_gemm_f32(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb, int(b_kc),
+                                        _ptr(out), N, _ptr(bias), _ptr(residual), ldr, _ptr(ws),
+                                        _stream()))
+    _timed("adell_gemm_f32_kernel", 2.0 * M * N * K, run)
+    return out
+
+
 def vicreg_fwd(x1, x2, min_var, eps):
     _require_cuda(x1, x2)
     x1, x2 = x1.contiguous(), x2.contiguous()

@@ -335,6 +335,16 @@ int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, float min_v
                      const float* scratch, const float* g3, float* dx1, float* dx2,
                      void* stream);
 
+/* Row-major fp32 GEMM (fp32 MFMA) behind torch.nn.Linear (layers/linear_blocks.py,
+ * res_blocks.py:559-566, res_net.py:278-324): C[M][N] = A x B (+ bias[N]) (+ residual).
+ * a_kc != 0: A(m,k) = A[m*lda + k], else A[k*lda + m]; b_kc != 0: B(k,n) = B[n*ldb + k], else
+ * B[k*ldb + n]. Forward X W^T: (1,1); backward-data dY W: (1,0); backward-weight dY^T X: (0,0).
+ * workspace: adell_gemm_f32_workspace_floats(M, N, K) floats of split-k slabs (NULL if 0). */
+long adell_gemm_f32_workspace_floats(int M, int N, int K);
+int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int a_kc, const float* B,
+                   long ldb, int b_kc, float* C, long ldc, const float* bias,
+                   const float* residual, long ldr, float* workspace, void* stream);
+
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
 
