@@ -73,11 +73,12 @@ __global__ __launch_bounds__(256) void adell_dwconv3d_kernel(DwArgs a) {
 //
 // A block owns 16 channels x a 4 x 4 (z, y) tile of output rows x one x-segment of WT
 // voxels. The input halo tile ((4+K-1)^2 rows x WT voxels x 16 channels) is staged in LDS
-// as [row][channel][x] with x contiguous; a thread = (channel, output row) keeps its WT
-// outputs in registers and, per (kz, ky), reads one input row (WT/4 ds_read_b128) and K
-// weights and issues the fully unrolled K x WT FMA stencil along x. Row and channel
-// strides are odd multiples of 4 words so that the 16 channel-lanes of a b128 phase hit
-// 64 distinct banks. VALU-bound: 2*K^3 flops per output at the fp32 vector rate.
+// in the memory order of the activation ([row][x][channel], 64-byte channel segments
+// copied with 16-byte loads, all of a thread's loads in flight together); a thread =
+// (channel, output row) keeps its WT outputs in registers and, per (kz, ky), reads one
+// input row and K weights from LDS and issues the fully unrolled K x WT FMA stencil along
+// x. The row stride is 16 words past a multiple of 64, so the 4 rows x 16 channels of a
+// wave hit 64 distinct banks. VALU-bound: 2*K^3 flops per output at the fp32 vector rate.
 // When W > WT the x axis is cut into segments of WT - 2P outputs (the row carries its own
 // halo); rows, columns and channels beyond the volume are zero in LDS and never stored.
 // ---------------------------------------------------------------------------
@@ -86,14 +87,11 @@ struct DwCfg {
   static constexpr int P = K / 2;
   static constexpr int TD = 4, TH = 4;
   static constexpr int HZ = TD + K - 1, HY = TH + K - 1;
-  static constexpr int WS = (WT == 4) ? 4 : WT + 4;
-  static constexpr int KP = (K + 3) & ~3;
-  static constexpr int CS0 = K * K * KP;
-  static constexpr int CS = ((CS0 / 4) & 1) ? CS0 : CS0 + 4;
+  static constexpr int RS = WT * 16 + 16;   // row stride (words)
   static constexpr int K3 = K * K * K;
-  static constexpr int XT_FLOATS = HZ * HY * 16 * WS;
-  static constexpr int WT_FLOATS = 16 * CS;
-  static constexpr int DY_FLOATS = TD * TH * 16 * WS;
+  static constexpr int XT_FLOATS = HZ * HY * RS;
+  static constexpr int WT_FLOATS = 16 * K3;
+  static constexpr int DY_FLOATS = TD * TH * RS;
   static constexpr int WG_THREADS = ((16 * K * K + 63) / 64) * 64;
 };
 
@@ -102,6 +100,7 @@ struct DwTile {
   int tilesX, tilesY, tilesZ, chanBlocks;
   int seg;      // outputs per x segment (W when one segment covers the row)
   int single;   // 1: one segment, LDS row starts at x = 0
+  int vec;      // 16-byte channel loads are legal (C % 4 == 0, aligned base)
 };
 
 __device__ __forceinline__ void adell_dw_decode(const DwTile& t, long item, int& n, int& z0,
@@ -114,31 +113,54 @@ __device__ __forceinline__ void adell_dw_decode(const DwTile& t, long item, int&
   y0 = ty * 4;
 }
 
-// stage the halo tile of `src` (NDHWC) for channels [c0, c0+16) into LDS
-template <int K, int WT>
-__device__ __forceinline__ void adell_dw_load_halo(const float* __restrict__ src, const DwTile& t,
-                                                   int n, int z0, int y0, int xin0, int c0,
-                                                   float* xt, int tid, int nthreads) {
-  using Cf = DwCfg<K, WT>;
-  constexpr int TOTAL = Cf::HZ * Cf::HY * WT * 16;
-  for (int i = tid; i < TOTAL; i += nthreads) {
-    const int c = i & 15;
-    const int j = (i >> 4) % WT;
-    const int r = (i >> 4) / WT;
-    const int z = z0 - Cf::P + r / Cf::HY, y = y0 - Cf::P + r % Cf::HY, x = xin0 + j;
-    float v = 0.f;
-    if (z >= 0 && z < t.D && y >= 0 && y < t.H && x >= 0 && x < t.W && c0 + c < t.C)
-      v = src[((((size_t)n * t.D + z) * t.H + y) * t.W + x) * t.C + c0 + c];
-    xt[(r * 16 + c) * Cf::WS + j] = v;
+__device__ __forceinline__ f32x4 adell_dw_load_quad(const float* __restrict__ p, int nvalid,
+                                                    int vec) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (nvalid >= 4 && vec) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+    if (nvalid > 0) v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
   }
+  return v;
 }
 
-template <int WT>
-__device__ __forceinline__ void adell_dw_read_row(const float* p, float (&v)[WT]) {
+// Stage ROWS_Z x ROWS_Y rows (from (zs, ys)) x WT voxels x 16 channels of `src` into LDS.
+// jlo/jhi: only x slots in [jlo, jhi) are taken from memory (the rest are zero).
+template <int ROWS_Z, int ROWS_Y, int WT, int NT, int MAXB>
+__device__ __forceinline__ void adell_dw_stage(const float* __restrict__ src, const DwTile& t,
+                                               int n, int zs, int ys, int xin0, int jlo, int jhi,
+                                               int c0, float* lds, int tid) {
+  constexpr int RS = WT * 16 + 16;
+  constexpr int TOTAL = ROWS_Z * ROWS_Y * WT * 4;
+  constexpr int PER = (TOTAL + NT - 1) / NT;
+  constexpr int BATCH = PER < MAXB ? PER : MAXB;
+  for (int base = 0; base < PER; base += BATCH) {
+    f32x4 v[BATCH];
 #pragma unroll
-  for (int q = 0; q < WT / 4; ++q) {
-    const float4 f = *reinterpret_cast<const float4*>(p + 4 * q);
-    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = tid + (base + u) * NT;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (base + u < PER && idx < TOTAL) {
+        const int q = idx & 3, j = (idx >> 2) % WT, r = (idx >> 2) / WT;
+        const int z = zs + r / ROWS_Y, y = ys + r % ROWS_Y, x = xin0 + j;
+        const int c = c0 + q * 4;
+        if (z >= 0 && z < t.D && y >= 0 && y < t.H && x >= 0 && x < t.W && j >= jlo && j < jhi &&
+            c < t.C)
+          v[u] = adell_dw_load_quad(
+              src + ((((size_t)n * t.D + z) * t.H + y) * t.W + x) * t.C + c, t.C - c, t.vec);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = tid + (base + u) * NT;
+      if (base + u < PER && idx < TOTAL) {
+        const int q = idx & 3, j = (idx >> 2) % WT, r = (idx >> 2) / WT;
+        *reinterpret_cast<f32x4*>(lds + r * RS + j * 16 + q * 4) = v[u];
+      }
+    }
   }
 }
 
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(256) void adell_dw_tile_kernel(DwTileArgs a) {
   float* wt = smem + Cf::XT_FLOATS;
   const int tid = threadIdx.x;
   const DwTile& t = a.t;
-  const int cb = blockIdx.x % t.chanBlocks;   // channel blocks of one tile run together:
+  const int cb = blockIdx.x % t.chanBlocks;     // channel blocks of one tile run together:
   const long item = blockIdx.x / t.chanBlocks;  // they share the tile's cache lines
   int n, z0, y0, tx;
   adell_dw_decode(t, item, n, z0, y0, tx);
@@ -168,24 +190,27 @@ __global__ __launch_bounds__(256) void adell_dw_tile_kernel(DwTileArgs a) {
   for (int i = tid; i < 16 * Cf::K3; i += 256) {
     const int c = i / Cf::K3, tap = i % Cf::K3;
     const int src = a.flip ? Cf::K3 - 1 - tap : tap;
-    wt[c * Cf::CS + (tap / K) * Cf::KP + tap % K] =
-        (c0 + c < t.C) ? a.w[(size_t)(c0 + c) * Cf::K3 + src] : 0.f;
+    wt[tap * 16 + c] = (c0 + c < t.C) ? a.w[(size_t)(c0 + c) * Cf::K3 + src] : 0.f;
   }
-  adell_dw_load_halo<K, WT>(a.x, t, n, z0, y0, xin0, c0, xt, tid, 256);
+  adell_dw_stage<Cf::HZ, Cf::HY, WT, 256, 16>(a.x, t, n, z0 - Cf::P, y0 - Cf::P, xin0, 0, WT, c0, xt,
+                                          tid);
   __syncthreads();
   const int c = tid & 15, row = tid >> 4, rz = row >> 2, ry = row & 3;
   float acc[WT];
   const float bias = (a.b && c0 + c < t.C) ? a.b[c0 + c] : 0.f;
 #pragma unroll
   for (int j = 0; j < WT; ++j) acc[j] = bias;
-  const float* wc = wt + c * Cf::CS;
 #pragma unroll 1
   for (int kz = 0; kz < K; ++kz) {
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
-      float in[WT], wk[Cf::KP];
-      adell_dw_read_row<WT>(xt + (((rz + kz) * Cf::HY + ry + ky) * 16 + c) * Cf::WS, in);
-      adell_dw_read_row<Cf::KP>(wc + (kz * K + ky) * Cf::KP, wk);
+      float in[WT], wk[K];
+      const float* xr = xt + ((rz + kz) * Cf::HY + ry + ky) * Cf::RS + c;
+      const float* wr = wt + (kz * K + ky) * K * 16 + c;
+#pragma unroll
+      for (int j = 0; j < WT; ++j) in[j] = xr[j * 16];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) wk[kx] = wr[kx * 16];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx)
 #pragma unroll
@@ -246,23 +271,23 @@ __global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_dw_wgrad_
     const int xin0 = t.single ? 0 : tx * t.seg - Cf::P;
     const int jlo = t.single ? 0 : Cf::P;
     __syncthreads();
-    adell_dw_load_halo<K, WT>(a.x, t, n, z0, y0, xin0, c0, xt, tid, NT);
-    for (int i = tid; i < 16 * WT * 16; i += NT) {
-      const int cc = i & 15, j = (i >> 4) % WT, r = (i >> 4) / WT;
-      const int z = z0 + (r >> 2), y = y0 + (r & 3), x = xin0 + j;
-      float v = 0.f;
-      if (z < t.D && y < t.H && j >= jlo && j < jlo + t.seg && x < t.W && c0 + cc < t.C)
-        v = a.dy[((((size_t)n * t.D + z) * t.H + y) * t.W + x) * t.C + c0 + cc];
-      dyt[(r * 16 + cc) * Cf::WS + j] = v;
-    }
+    adell_dw_stage<Cf::HZ, Cf::HY, WT, NT, 4>(a.x, t, n, z0 - Cf::P, y0 - Cf::P, xin0, 0, WT, c0, xt,
+                                           tid);
+    adell_dw_stage<Cf::TD, Cf::TH, WT, NT, 4>(a.dy, t, n, z0, y0, xin0, jlo, jlo + t.seg, c0, dyt,
+                                           tid);
     __syncthreads();
     if (active) {
 #pragma unroll 1
       for (int row = 0; row < 16; ++row) {
         const int rz = row >> 2, ry = row & 3;
         float g[WT], in[WT];
-        adell_dw_read_row<WT>(dyt + (row * 16 + c) * Cf::WS, g);
-        adell_dw_read_row<WT>(xt + (((rz + kz) * Cf::HY + ry + ky) * 16 + c) * Cf::WS, in);
+        const float* gr = dyt + row * Cf::RS + c;
+        const float* xr = xt + ((rz + kz) * Cf::HY + ry + ky) * Cf::RS + c;
+#pragma unroll
+        for (int j = 0; j < WT; ++j) {
+          g[j] = gr[j * 16];
+          in[j] = xr[j * 16];
+        }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx)
 #pragma unroll
@@ -312,6 +337,7 @@ static int adell_dw_plan(int N, int C, int D, int H, int W, int KD, int KH, int 
   const int K = KD, P = K / 2;
   int WT = W <= 4 ? 4 : (W <= 8 ? 8 : 16);
   t->N = N; t->C = C; t->D = D; t->H = H; t->W = W;
+  t->vec = (C % 4) == 0;
   t->single = W <= WT;
   if (!t->single && WT - 2 * P < 4) return 0;
   t->seg = t->single ? W : WT - 2 * P;
@@ -364,6 +390,7 @@ static int adell_dw_launch(DwArgs a, hipStream_t st) {
   const int WT = adell_dw_plan(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, &ta.t);
   if (WT) {
     ta.x = a.x; ta.w = a.w; ta.b = a.b; ta.y = a.y; ta.flip = a.flip;
+    ta.t.vec = ta.t.vec && ((uintptr_t)a.x % 16 == 0);
     ADELL_DW_DISPATCH(adell_dw_tile_launch, a.KD, WT, ta, st);
   }
   const long total = (long)a.N * a.D * a.H * a.W * (((a.C & 3) == 0) ? a.C / 4 : a.C);
@@ -492,6 +519,7 @@ extern "C" int adell_dwconv3d_bwd_weight(int N, int C, int D, int H, int W, int 
     ADELL_REQUIRE(workspace, "dwconv_bwd_weight: workspace of "
                              "adell_dwconv3d_bwd_weight_workspace_floats() floats required");
     a.x = x; a.dy = dy; a.part = workspace;
+    a.t.vec = a.t.vec && (((uintptr_t)x | (uintptr_t)dy) % 16 == 0);
     const int splits = adell_dw_wgrad_splits(a.t, &a.items, &a.itemsPerSplit);
     rc = adell_dw_wgrad_dispatch(KD, WT, a, splits, st);
     if (rc != ADELL_OK) return rc;

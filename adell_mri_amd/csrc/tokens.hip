@@ -91,13 +91,19 @@ __global__ __launch_bounds__(256) void adell_layernorm_bwd_kernel(
   }
 }
 
-__global__ void adell_rowsum_final_kernel(const float* __restrict__ part, int nb, int n,
-                                          float* __restrict__ out0, float* __restrict__ out1,
-                                          int half) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+__global__ __launch_bounds__(256) void adell_rowsum_final_kernel(
+    const float* __restrict__ part, int nb, int n, float* __restrict__ out0,
+    float* __restrict__ out1, int half) {
+  __shared__ double sh[4][64];
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += (double)part[(size_t)b * n + c];
+  if (c < n)
+    for (int b = vl; b < nb; b += 4) s += (double)part[(size_t)b * n + c];
+  sh[vl][cl] = s;
+  __syncthreads();
+  if (vl != 0 || c >= n) return;
+  s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
   if (c < half) {
     if (out0) out0[c] = (float)s;
   } else if (out1) {
@@ -146,7 +152,7 @@ extern "C" int adell_layernorm_bwd(const float* x, const float* dy, const float*
                      rstd, dx, want ? (float*)workspace : nullptr, rows, C,
                      ADELL_LN_ROWS_PER_BLOCK);
   if (want)
-    hipLaunchKernelGGL(adell_rowsum_final_kernel, dim3(adell_cdiv(2 * C, 64)), dim3(64), 0, st,
+    hipLaunchKernelGGL(adell_rowsum_final_kernel, dim3(adell_cdiv(2 * C, 64)), dim3(256), 0, st,
                        (const float*)workspace, nb, 2 * C, dgamma, dbeta, C);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
