@@ -101,6 +101,15 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "adell_layernorm_rows_fwd": (_i, [_vp, _l, _i, _i, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "adell_layernorm_rows_bwd_workspace": (_l, [_l, _i]),
+    "adell_layernorm_rows_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _l, _l, _vp, _l, _l,
+                                      _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_winattn_fwd": (_i, [_vp, _vp, _vp, _l, _l, _vp, _vp, _i, _l, _i, _i, _i, _i, _f, _f,
+                               ctypes.c_ulong, ctypes.c_uint, _vp, _vp, _vp]),
+    "adell_winattn_bwd": (_i, [_vp, _vp, _vp, _l, _l, _vp, _vp, _i, _vp, _vp, _vp, _l, _i, _i, _i,
+                               _i, _f, _f, ctypes.c_ulong, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp]),
     "adell_gemm_f32_workspace_floats": (_l, [_i, _i, _i]),
     "adell_gemm_f32": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),

@@ -317,9 +317,184 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _LayerNormRowsFn(torch.autograd.Function):
+    """rows of C <= 512 values: several rows per wave (csrc/window.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        rows = x.numel() // C
+        y, mean, rstd = ops.layernorm_rows_fwd(x, rows, C, 1, C, 0, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        want = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx = torch.empty_like(x)
+        dg, db = ops.layernorm_rows_bwd(x, dy.contiguous(), gamma, mean, rstd, rows, C, 1, C, 0,
+                                        dx, C, 0, want)
+        return dx, dg, db, None
+
+
 def layer_norm(x, gamma=None, beta=None, eps=1e-5):
     """torch.nn.LayerNorm over the last dimension."""
+    if x.shape[-1] <= 512:
+        return _LayerNormRowsFn.apply(x.contiguous(), gamma, beta, float(eps))
     return _LayerNormFn.apply(x.contiguous(), gamma, beta, float(eps))
+
+
+# ---- gather-based rearranges (SWIN: window partition / merge, cyclic shift, rescale) -----
+def _inverse_gather(dims, axes):
+    """Spec of the inverse of a bijective gather whose input is dense over ``axes`` (listed
+    outermost first): (inverse dims, inverse axes, roll spec or None)."""
+    nd = len(dims)
+    out_strides = [1] * nd
+    for d in range(nd - 2, -1, -1):
+        out_strides[d] = out_strides[d + 1] * dims[d + 1][0]
+    inv_dims = []
+    for a, (extent, _, _) in enumerate(axes):
+        feed = sorted([d for d in range(nd) if dims[d][1] == a], key=lambda d: -dims[d][2])
+        run = 1
+        for d in reversed(feed):
+            if dims[d][2] != run:
+                raise ValueError("gather is not a mixed-radix bijection")
+            run *= dims[d][0]
+        if run != extent:
+            raise ValueError("gather does not cover its input axis")
+        inv_dims += [(dims[d][0], d, 1) for d in feed]
+    inv_axes = [(dims[d][0], out_strides[d], 0) for d in range(nd)]
+    roll = None
+    if any(a[2] != 0 for a in axes):
+        roll = ([(a[0], i, 1) for i, a in enumerate(axes)],
+                [(a[0], a[1], -a[2]) for a in axes])
+    return inv_dims, inv_axes, roll
+
+
+class _GatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dims, axes, out_shape):
+        ctx.spec = (dims, axes, x.shape)
+        return ops.gather_nd(x, dims, axes).view(out_shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        dims, axes, in_shape = ctx.spec
+        inv_dims, inv_axes, roll = _inverse_gather(dims, axes)
+        gi = ops.gather_nd(g.contiguous(), inv_dims, inv_axes)
+        if roll is not None:
+            gi = ops.gather_nd(gi, *roll)
+        return gi.view(in_shape), None, None, None
+
+
+def _window_spec(shape, nwin, ppw, patch, shift):
+    b, X, Y, Z, c = shape
+    (w1, w2, w3), (h, w, d), (px, py, pz) = nwin, ppw, patch
+    assert (w1 * h * px, w2 * w * py, w3 * d * pz) == (X, Y, Z), "window grid does not tile the image"
+    # the innermost image axis and the channel axis are one dense axis of Z*c elements
+    axes = [(b, X * Y * Z * c, 0), (X, Y * Z * c, shift[0]), (Y, Z * c, shift[1]),
+            (Z * c, 1, shift[2] * c)]
+    dims = [(b, 0, 1), (w1, 1, h * px), (w2, 2, w * py), (w3, 3, d * pz * c), (h, 1, px),
+            (w, 2, py), (d, 3, pz * c), (px, 1, 1), (py, 2, 1), (pz * c, 3, 1)]
+    return dims, axes
+
+
+def window_partition(x, nwin, ppw, patch, shift=(0, 0, 0)):
+    """einops 'b (w1 h x) (w2 w y) (w3 d z) c -> b (w1 w2 w3) (h w d) (x y z c)' of
+    torch.roll(x, [-s for s in shift], dims=(1, 2, 3)) -- one gather (vit.py:650-676,1197-1203)."""
+    x = x.contiguous()
+    dims, axes = _window_spec(x.shape, nwin, ppw, patch, shift)
+    b, c = x.shape[0], x.shape[-1]
+    out_shape = (b, nwin[0] * nwin[1] * nwin[2], ppw[0] * ppw[1] * ppw[2],
+                 patch[0] * patch[1] * patch[2] * c)
+    return _GatherFn.apply(x, dims, axes, out_shape)
+
+
+def window_merge(tokens, image_shape, nwin, ppw, patch):
+    """inverse of window_partition without a shift: [b, nW, T, (x y z c)] -> [b, X, Y, Z, c]."""
+    tokens = tokens.contiguous()
+    dims, axes = _window_spec(image_shape, nwin, ppw, patch, (0, 0, 0))
+    inv_dims, inv_axes, _ = _inverse_gather(dims, axes)
+    return _GatherFn.apply(tokens, inv_dims, inv_axes, tuple(image_shape))
+
+
+def space_to_depth(x, scale):
+    """einops_rescale (vit.py:33-45): 'b c (h p1) (w p2) (d p3) -> b (c p1 p2 p3) h w d' for an
+    NDHWC activation; returns the logical [b, c*p1*p2*p3, h, w, d] tensor (NDHWC memory)."""
+    x = ops.ndhwc(x)
+    b, c, H, W, D = x.shape
+    p1, p2, p3 = scale
+    h, w, d = H // p1, W // p2, D // p3
+    axes = [(b, H * W * D * c, 0), (H, W * D * c, 0), (W, D * c, 0), (D, c, 0), (c, 1, 0)]
+    dims = [(b, 0, 1), (h, 1, p1), (w, 2, p2), (d, 3, p3), (c, 4, 1), (p1, 1, 1), (p2, 2, 1),
+            (p3, 3, 1)]
+    xr = x.permute(0, 2, 3, 4, 1)  # [b, H, W, D, c], contiguous
+    out = _GatherFn.apply(xr, dims, axes, (b, h, w, d, c * p1 * p2 * p3))
+    return out.permute(0, 4, 1, 2, 3)
+
+
+class _WindowAttnFn(torch.autograd.Function):
+    """q-norm, k-norm and windowed attention on a QKV buffer [tokens, H*(2a+hd)] whose heads
+    are laid out q | k | v (linear_blocks.py:369-417). Nothing is sliced or permuted: the
+    LayerNorm kernel reads the q / k slices in place, the attention kernel reads v in place,
+    and the backward writes the three gradients straight into dQKV."""
+
+    @staticmethod
+    def forward(ctx, qkv, qg, qb, kg, kb, rel, mask, conf):
+        W, H, T, a, hd, scale, drop_p, seed, offset, eps = conf
+        per = 2 * a + hd
+        ts = H * per
+        flat = qkv.view(-1)
+        rows = W * T * H
+        qn, qm, qr = ops.layernorm_rows_fwd(flat, rows, a, H, ts, per, qg, qb, eps)
+        kn, km, kr = ops.layernorm_rows_fwd(flat[a:], rows, a, H, ts, per, kg, kb, eps)
+        o, lse = ops.winattn_fwd(qn, kn, flat[2 * a:], ts, per, rel, mask, W, H, T, a, hd, scale,
+                                 drop_p, seed, offset)
+        ctx.save_for_backward(qkv, qg, kg, qn, kn, qm, qr, km, kr, o, lse, rel, mask)
+        ctx.conf = conf
+        return o.view(W * T, H * hd)
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qg, kg, qn, kn, qm, qr, km, kr, o, lse, rel, mask = ctx.saved_tensors
+        W, H, T, a, hd, scale, drop_p, seed, offset, eps = ctx.conf
+        per = 2 * a + hd
+        ts = H * per
+        rows = W * T * H
+        need = ctx.needs_input_grad
+        flat = qkv.view(-1)
+        dqkv = torch.empty_like(qkv)
+        dflat = dqkv.view(-1)
+        dqn, dkn = torch.empty_like(qn), torch.empty_like(kn)
+        ds = ops.winattn_bwd(qn, kn, flat[2 * a:], ts, per, rel, mask, o, do.contiguous(), lse, W,
+                             H, T, a, hd, scale, drop_p, seed, offset, dqn, dkn, dflat[2 * a:],
+                             rel is not None and need[5])
+        dqg, dqb = ops.layernorm_rows_bwd(flat, dqn, qg, qm, qr, rows, a, H, ts, per, dflat, ts,
+                                          per, need[1] or need[2])
+        dkg, dkb = ops.layernorm_rows_bwd(flat[a:], dkn, kg, km, kr, rows, a, H, ts, per,
+                                          dflat[a:], ts, per, need[3] or need[4])
+        drel = None
+        if ds is not None:
+            drel = ops.bias_grad(_rows_as_volume(ds)).view(rel.shape)
+        return dqkv, dqg, dqb, dkg, dkb, drel, None, None
+
+
+def window_attention(qkv, q_gamma, q_beta, k_gamma, k_beta, n_windows, n_heads, tokens, a, hd,
+                     rel=None, mask=None, drop_p=0.0, training=False, eps=1e-5):
+    """qkv: [n_windows * tokens, n_heads * (2a + hd)] -> [n_windows * tokens, n_heads * hd]."""
+    p = float(drop_p) if training else 0.0
+    seed, offset = 0, 0
+    if p > 0.0:
+        seed = torch.initial_seed()
+        offset = next(_dropout_counter)
+    conf = (int(n_windows), int(n_heads), int(tokens), int(a), int(hd), 1.0 / (a ** 0.5), p, seed,
+            offset, float(eps))
+    rel = None if rel is None else rel.contiguous()
+    mask = None if mask is None else mask.contiguous()
+    return _WindowAttnFn.apply(qkv.contiguous(), q_gamma, q_beta, k_gamma, k_beta, rel, mask, conf)
 
 
 class _AddBcastFn(torch.autograd.Function):

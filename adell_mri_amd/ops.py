@@ -654,6 +654,81 @@ def dwconv3d_bwd_weight(x, dy, kshape, want_db):
     return dw, db
 
 
+# ---- shifted-window (SWIN) token path -----------------------------------------------------
+def gather_nd(x, dims, axes):
+    """Flat contiguous gather of ``x`` (csrc/window.hip). ``dims``: [(size, axis, mult)] of the
+    output, outermost first; ``axes``: [(extent, stride, shift)] of the input, in elements."""
+    import ctypes
+
+    _require_cuda(x)
+    nd, na = len(dims), len(axes)
+    total = 1
+    for d in dims:
+        total *= int(d[0])
+    out = torch.empty((total,), device=x.device, dtype=torch.float32)
+    IntA, LongD, LongA = ctypes.c_int * nd, ctypes.c_long * nd, ctypes.c_long * na
+    check(_lib.lib().adell_gather_nd(
+        _ptr(x), _ptr(out), nd, IntA(*[int(d[0]) for d in dims]), IntA(*[int(d[1]) for d in dims]),
+        LongD(*[int(d[2]) for d in dims]), na, LongA(*[int(a[0]) for a in axes]),
+        LongA(*[int(a[1]) for a in axes]), LongA(*[int(a[2]) for a in axes]), _stream()))
+    return out
+
+
+def layernorm_rows_fwd(x, rows, C, inner, so, si, gamma, beta, eps):
+    """LayerNorm of ``rows`` rows of C <= 512 values read at (r//inner)*so + (r%inner)*si."""
+    _require_cuda(x, gamma, beta)
+    y = torch.empty((rows, C), device=x.device, dtype=torch.float32)
+    mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(_lib.lib().adell_layernorm_rows_fwd(_ptr(x), rows, C, inner, so, si, _ptr(gamma),
+                                              _ptr(beta), float(eps), _ptr(y), _ptr(mean),
+                                              _ptr(rstd), _stream()))
+    return y, mean, rstd
+
+
+def layernorm_rows_bwd(x, dy, gamma, mean, rstd, rows, C, inner, so, si, dx, dso, dsi,
+                       want_affine):
+    """dx is written INTO ``dx`` at the strided row positions (dso, dsi)."""
+    _require_cuda(x, dy, dx)
+    dg = db = ws = None
+    nbytes = 0
+    if want_affine:
+        dg = torch.empty((C,), device=x.device, dtype=torch.float32)
+        db = torch.empty_like(dg)
+        nbytes = _lib.lib().adell_layernorm_rows_bwd_workspace(rows, C)
+        ws = _workspace(nbytes, x.device)
+    check(_lib.lib().adell_layernorm_rows_bwd(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(mean),
+                                              _ptr(rstd), rows, C, inner, so, si, _ptr(dx), dso,
+                                              dsi, _ptr(dg), _ptr(db), _ptr(ws),
+                                              0 if ws is None else ws.numel() * 4, _stream()))
+    return dg, db
+
+
+def winattn_fwd(q, k, v, v_ts, v_hs, rel, mask, W, H, T, A, Dv, scale, drop_p, seed, offset):
+    _require_cuda(q, k, v, rel, mask)
+    out = torch.empty((W * T, H, Dv), device=q.device, dtype=torch.float32)
+    lse = torch.empty((W * H * T,), device=q.device, dtype=torch.float32)
+    n_mask = 0 if mask is None else mask.shape[0]
+    check(_lib.lib().adell_winattn_fwd(_ptr(q), _ptr(k), _ptr(v), v_ts, v_hs, _ptr(rel),
+                                       _ptr(mask), n_mask, W, H, T, A, Dv, float(scale),
+                                       float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                       int(offset) & 0xFFFFFFFF, _ptr(out), _ptr(lse), _stream()))
+    return out, lse
+
+
+def winattn_bwd(q, k, v, v_ts, v_hs, rel, mask, o, dout, lse, W, H, T, A, Dv, scale, drop_p,
+                seed, offset, dq, dk, dv, want_ds):
+    _require_cuda(q, k, v, o, dout, lse, dq, dk, dv)
+    n_mask = 0 if mask is None else mask.shape[0]
+    ds = torch.empty((W, H * T * T), device=q.device, dtype=torch.float32) if want_ds else None
+    check(_lib.lib().adell_winattn_bwd(_ptr(q), _ptr(k), _ptr(v), v_ts, v_hs, _ptr(rel),
+                                       _ptr(mask), n_mask, _ptr(o), _ptr(dout), _ptr(lse), W, H, T,
+                                       A, Dv, float(scale), float(drop_p),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF,
+                                       _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ds), _stream()))
+    return ds
+
+
 def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, out=None, bias=None, residual=None):
     """out[M, N] = A x B (+ bias) (+ residual) on the fp32 MFMA GEMM (csrc/gemm.hip).
     a_kc: A(m,k) = A[m*lda + k] else A[k*lda + m]; b_kc: B(k,n) = B[n*ldb + k] else B[k*ldb + n]."""

@@ -335,6 +335,40 @@ int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, float min_v
                      const float* scratch, const float* g3, float* dx1, float* dx2,
                      void* stream);
 
+/* ---- shifted-window (SWIN) token path: vit.py:33-45,95-129,1005-1256; linear_blocks.py:358-417 */
+/* out (contiguous over sizes[0..nd)) = gather of `in`: out dim d adds coord*mult[d] to input
+ * axis axis[d]; input axis a has extent / stride (elements) / cyclic shift:
+ * in_coord[a] = (sum + shift[a]) mod extent[a]. One kernel for every einops rearrange and
+ * torch.roll of the path (window partition + cyclic shift, its inverse, einops_rescale). */
+int adell_gather_nd(const float* in, float* out, int nd, const int* sizes, const int* axis,
+                    const long* mult, int na, const long* extent, const long* stride,
+                    const long* shift, void* stream);
+/* LayerNorm over rows of C <= 512 values; input row r starts at (r/inner)*so + (r%inner)*si
+ * (contiguous rows: inner = 1, so = C); y, dy, mean, rstd are contiguous; dx is strided by
+ * (dso, dsi) the same way, so q / k slices of a QKV buffer are normalised in place. */
+int adell_layernorm_rows_fwd(const float* x, long rows, int C, int inner, long so, long si,
+                             const float* gamma, const float* beta, float eps, float* y,
+                             float* mean, float* rstd, void* stream);
+long adell_layernorm_rows_bwd_workspace(long rows, int C);
+int adell_layernorm_rows_bwd(const float* x, const float* dy, const float* gamma,
+                             const float* mean, const float* rstd, long rows, int C, int inner,
+                             long so, long si, float* dx, long dso, long dsi, float* dgamma,
+                             float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* Attention inside windows of T <= 64 tokens (token row = w*T + i). q, k, out: [tokens][H][A|Dv]
+ * contiguous; v (and dv) element (t,h,d) at v[t*v_ts + h*v_hs + d] (inside a QKV buffer).
+ * S = scale*q k^T + rel[H][T][T] + mask[w % n_mask][T][T]; O = dropout(softmax(S)) v (Philox
+ * mask from (seed, rng_offset), regenerated in the backward); lse [W][H][T] is kept for the
+ * backward; ds (optional [W][H][T][T]) receives dS, the gradient of the additive bias. */
+int adell_winattn_fwd(const float* q, const float* k, const float* v, long v_ts, long v_hs,
+                      const float* rel, const float* mask, int n_mask, long W, int H, int T, int A,
+                      int Dv, float scale, float drop_p, unsigned long seed, unsigned rng_offset,
+                      float* out, float* lse, void* stream);
+int adell_winattn_bwd(const float* q, const float* k, const float* v, long v_ts, long v_hs,
+                      const float* rel, const float* mask, int n_mask, const float* o,
+                      const float* dout, const float* lse, long W, int H, int T, int A, int Dv,
+                      float scale, float drop_p, unsigned long seed, unsigned rng_offset,
+                      float* dq, float* dk, float* dv, float* ds, void* stream);
+
 /* Row-major fp32 GEMM (fp32 MFMA) behind torch.nn.Linear (layers/linear_blocks.py,
  * res_blocks.py:559-566, res_net.py:278-324): C[M][N] = A x B (+ bias[N]) (+ residual).
  * a_kc != 0: A(m,k) = A[m*lda + k], else A[k*lda + m]; b_kc != 0: B(k,n) = B[n*ldb + k], else

@@ -1,0 +1,169 @@
+"""Kernels of the shifted-window (SWIN) token path (csrc/window.hip) against stock torch on
+the CPU: gather-based rearranges (+ cyclic shift), short-row LayerNorm, window attention
+with relative-position bias, shift mask and attention dropout."""
+import einops
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adell_mri_amd import functional as HF
+
+
+def rel(a, r):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    r = r.detach().cpu().numpy() if isinstance(r, torch.Tensor) else r
+    return float(np.abs(a - r).max() / (np.abs(r).max() + 1e-30))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,nwin,ppw,patch,c,shift", [
+    (2, (2, 3, 2), (2, 2, 2), (2, 2, 2), 2, (0, 0, 0)),
+    (1, (2, 2, 1), (2, 1, 2), (4, 4, 4), 2, (1, 1, 1)),
+    (2, (1, 2, 2), (2, 2, 2), (1, 2, 1), 3, (2, 0, 1)),
+    (1, (4, 4, 2), (2, 2, 2), (4, 4, 4), 8, (1, 1, 1))])
+def test_window_partition_merge_match_einops(cuda, b, nwin, ppw, patch, c, shift):
+    X, Y, Z = [n * p * q for n, p, q in zip(nwin, ppw, patch)]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((b, X, Y, Z, c), generator=g, requires_grad=True)
+    kw = dict(w1=nwin[0], w2=nwin[1], w3=nwin[2], h=ppw[0], w=ppw[1], d=ppw[2],
+              x=patch[0], y=patch[1], z=patch[2])
+    pat = "b (w1 h x) (w2 w y) (w3 d z) c -> b (w1 w2 w3) (h w d) (x y z c)"
+    ref = einops.rearrange(torch.roll(x, [-s for s in shift], dims=(1, 2, 3)), pat, **kw)
+    r = torch.randn(ref.shape, generator=g)
+    (ref * r).sum().backward()
+    xd = x.detach().to(cuda).requires_grad_(True)
+    out = HF.window_partition(xd, nwin, ppw, patch, shift)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref.detach())
+    (out * r.to(cuda)).sum().backward()
+    assert torch.equal(xd.grad.cpu(), x.grad)
+    # merge = inverse rearrange (no shift)
+    t = torch.randn(ref.shape, generator=g, requires_grad=True)
+    inv = "b (w1 w2 w3) (h w d) (x y z c) -> b (w1 h x) (w2 w y) (w3 d z) c"
+    ref2 = einops.rearrange(t, inv, c=c, **kw)
+    r2 = torch.randn(ref2.shape, generator=g)
+    (ref2 * r2).sum().backward()
+    td = t.detach().to(cuda).requires_grad_(True)
+    out2 = HF.window_merge(td, (b, X, Y, Z, c), nwin, ppw, patch)
+    assert torch.equal(out2.cpu(), ref2.detach())
+    (out2 * r2.to(cuda)).sum().backward()
+    assert torch.equal(td.grad.cpu(), t.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,scale", [((2, 2, 8, 8, 4), (2, 2, 1)), ((1, 8, 4, 6, 8), (2, 2, 2)),
+                                         ((1, 3, 4, 4, 4), (1, 1, 1))])
+def test_space_to_depth_matches_einops_rescale(cuda, shape, scale):
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(shape, generator=g, requires_grad=True)
+    ref = einops.rearrange(x, "b c (h p1) (w p2) (d p3) -> b (c p1 p2 p3) h w d",
+                           p1=scale[0], p2=scale[1], p3=scale[2])
+    r = torch.randn(ref.shape, generator=g)
+    (ref * r).sum().backward()
+    xd = ops.ndhwc(x.detach().to(cuda)).requires_grad_(True)
+    out = HF.space_to_depth(xd, scale)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref.detach())
+    (out * r.to(cuda)).sum().backward()
+    assert torch.equal(xd.grad.cpu(), x.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,C", [(1000, 2), (37, 4), (4096, 8), (513, 32), (300, 33), (700, 96),
+                                    (64, 128), (50, 512), (3, 5), (20, 768)])
+def test_layer_norm_rows_fwd_bwd(cuda, rows, C):
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn((rows, C), generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn((C,), generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn((C,), generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.layer_norm(x, (C,), w, b, 1e-5)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xd, wd, bd = [t.detach().float().to(cuda).requires_grad_(True) for t in (x, w, b)]
+    yd = HF.layer_norm(xd, wd, bd, 1e-5)
+    yd.backward(dy.float().to(cuda))
+    assert rel(yd, y) < 5e-6
+    assert rel(xd.grad, x.grad) < 2e-5
+    assert rel(wd.grad, w.grad) < 1e-5
+    assert rel(bd.grad, b.grad) < 1e-5
+
+
+def _ref_window_mha(qkv, qg, qb, kg, kb, rel_b, mask, W, H, T, a, hd):
+    q3 = qkv.reshape(W, T, H, 2 * a + hd).permute(0, 2, 1, 3)
+    Q = F.layer_norm(q3[..., :a], (a,), qg, qb)
+    K = F.layer_norm(q3[..., a:2 * a], (a,), kg, kb)
+    V = q3[..., 2 * a:]
+    am = None
+    if rel_b is not None:
+        am = rel_b.unsqueeze(0)
+    if mask is not None:
+        m = mask.repeat(W // mask.shape[0], 1, 1).unsqueeze(1)
+        am = m if am is None else am + m
+    O = F.scaled_dot_product_attention(Q, K, V, attn_mask=am)
+    return O.transpose(1, 2).reshape(W * T, H * hd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,T,a,hd,use_rel,n_mask", [
+    (6, 8, 8, 4, 4, True, 3), (4, 2, 8, 8, 8, False, 0), (5, 4, 27, 16, 16, True, 0),
+    (2, 3, 64, 32, 32, True, 2), (7, 8, 8, 4, 4, False, 7), (3, 2, 5, 3, 6, True, 3)])
+def test_window_attention_matches_sdpa(cuda, W, H, T, a, hd, use_rel, n_mask):
+    g = torch.Generator().manual_seed(W * 100 + T)
+    dd = torch.float64
+    qkv = torch.randn((W * T, H * (2 * a + hd)), generator=g, dtype=dd).requires_grad_(True)
+    ps = [(1 + 0.3 * torch.randn((a,), generator=g, dtype=dd)).requires_grad_(True) for _ in range(4)]
+    rel_b = (torch.randn((H, T, T), generator=g, dtype=dd)).requires_grad_(True) if use_rel else None
+    mask = None
+    if n_mask:
+        mask = torch.where(torch.rand((n_mask, T, T), generator=g) > 0.7, -100.0, 0.0).to(dd)
+    ref = _ref_window_mha(qkv, *ps, rel_b, mask, W, H, T, a, hd)
+    r = torch.randn(ref.shape, generator=g, dtype=dd)
+    (ref * r).sum().backward()
+    dev = [t.detach().float().to(cuda).requires_grad_(True) for t in (qkv, *ps)]
+    rel_d = rel_b.detach().float().to(cuda).requires_grad_(True) if use_rel else None
+    mask_d = mask.float().to(cuda) if mask is not None else None
+    out = HF.window_attention(dev[0], *dev[1:], W, H, T, a, hd, rel=rel_d, mask=mask_d)
+    assert rel(out, ref) < 2e-5
+    (out * r.float().to(cuda)).sum().backward()
+    assert rel(dev[0].grad, qkv.grad) < 5e-5
+    floor = float(qkv.grad.abs().max())   # k-beta shifts every score of a row: zero gradient
+    for d, p in zip(dev[1:], ps):
+        err = float((d.grad.cpu().double() - p.grad).abs().max())
+        assert err < 5e-5 * max(float(p.grad.abs().max()), floor)
+    if use_rel:
+        assert rel(rel_d.grad, rel_b.grad) < 5e-5
+
+
+@pytest.mark.gpu
+def test_window_attention_dropout_mask_is_consistent(cuda):
+    """V = identity exposes the dropped probabilities: kept entries are p / (1 - drop_p), the
+    kept fraction is ~ (1 - drop_p), and the backward regenerates the same mask."""
+    W, H, T, a = 512, 2, 8, 4
+    hd = T
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn((W, T, H, 2 * a + hd), generator=g)
+    qkv[..., 2 * a:] = torch.eye(T).view(1, T, 1, T)
+    qkv = qkv.reshape(W * T, -1).to(cuda).requires_grad_(True)
+    ones, zeros = torch.ones(a, device=cuda), torch.zeros(a, device=cuda)
+    torch.manual_seed(11)
+    p_drop = 0.25
+    out = HF.window_attention(qkv, ones, zeros, ones, zeros, W, H, T, a, hd, drop_p=p_drop,
+                              training=True)
+    ref = HF.window_attention(qkv.detach(), ones, zeros, ones, zeros, W, H, T, a, hd)
+    pt = out.detach().view(W, T, H, T)      # [w, i, h, j] = dropped probability
+    p = ref.view(W, T, H, T)
+    kept = pt != 0
+    frac = kept.float().mean().item()
+    assert abs(frac - (1 - p_drop)) < 0.01, frac
+    assert torch.allclose(pt[kept], p[kept] / (1 - p_drop), rtol=1e-5, atol=1e-7)
+    dO = torch.randn(out.shape, generator=g).to(cuda)
+    out.backward(dO)
+    # dV_j[d] = sum_i pt_ij dO_i[d]
+    dv = qkv.grad.view(W, T, H, 2 * a + hd)[..., 2 * a:]          # [w, j, h, d]
+    want = torch.einsum("wihj,wihd->wjhd", pt, dO.view(W, T, H, hd))
+    assert rel(dv, want) < 1e-5
+    # eval mode: no dropout
+    out_eval = HF.window_attention(qkv.detach(), ones, zeros, ones, zeros, W, H, T, a, hd,
+                                   drop_p=p_drop, training=False)
+    assert torch.equal(out_eval, ref)
