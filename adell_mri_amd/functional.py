@@ -14,6 +14,7 @@ Statistics produced by the conv epilogue ride on the output tensor as
 import itertools
 import os
 
+import numpy as np
 import torch
 
 from . import ops
@@ -317,6 +318,13 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+def add(a, b):
+    """a + b for same-shape tensors (HIP elementwise kernel)."""
+    if a.shape != b.shape:
+        raise ValueError("HF.add: shapes differ")
+    return _AddBcastFn.apply(a.contiguous(), b.contiguous())
+
+
 class _LayerNormRowsFn(torch.autograd.Function):
     """rows of C <= 512 values: several rows per wave (csrc/window.hip)."""
 
@@ -391,21 +399,29 @@ class _GatherFn(torch.autograd.Function):
 
 
 def _window_spec(shape, nwin, ppw, patch, shift):
+    """shift: cyclic shift of the (X, Y, Z, c) axes of the [b, X, Y, Z, c] input."""
     b, X, Y, Z, c = shape
     (w1, w2, w3), (h, w, d), (px, py, pz) = nwin, ppw, patch
     assert (w1 * h * px, w2 * w * py, w3 * d * pz) == (X, Y, Z), "window grid does not tile the image"
-    # the innermost image axis and the channel axis are one dense axis of Z*c elements
-    axes = [(b, X * Y * Z * c, 0), (X, Y * Z * c, shift[0]), (Y, Z * c, shift[1]),
-            (Z * c, 1, shift[2] * c)]
-    dims = [(b, 0, 1), (w1, 1, h * px), (w2, 2, w * py), (w3, 3, d * pz * c), (h, 1, px),
-            (w, 2, py), (d, 3, pz * c), (px, 1, 1), (py, 2, 1), (pz * c, 3, 1)]
+    sx, sy, sz, sc = shift
+    if sc % c == 0:
+        # the innermost image axis and the channel axis are one dense axis of Z*c elements
+        axes = [(b, X * Y * Z * c, 0), (X, Y * Z * c, sx), (Y, Z * c, sy), (Z * c, 1, sz * c)]
+        dims = [(b, 0, 1), (w1, 1, h * px), (w2, 2, w * py), (w3, 3, d * pz * c), (h, 1, px),
+                (w, 2, py), (d, 3, pz * c), (px, 1, 1), (py, 2, 1), (pz * c, 3, 1)]
+    else:
+        axes = [(b, X * Y * Z * c, 0), (X, Y * Z * c, sx), (Y, Z * c, sy), (Z, c, sz), (c, 1, sc)]
+        dims = [(b, 0, 1), (w1, 1, h * px), (w2, 2, w * py), (w3, 3, d * pz), (h, 1, px),
+                (w, 2, py), (d, 3, pz), (px, 1, 1), (py, 2, 1), (pz, 3, 1), (c, 4, 1)]
     return dims, axes
 
 
-def window_partition(x, nwin, ppw, patch, shift=(0, 0, 0)):
+def window_partition(x, nwin, ppw, patch, shift=(0, 0, 0, 0)):
     """einops 'b (w1 h x) (w2 w y) (w3 d z) c -> b (w1 w2 w3) (h w d) (x y z c)' of
-    torch.roll(x, [-s for s in shift], dims=(1, 2, 3)) -- one gather (vit.py:650-676,1197-1203)."""
+    torch.roll(x, [-s for s in shift], dims=(1, 2, 3, 4)) -- one gather (vit.py:650-676,
+    1197-1203). ``shift`` covers the three image axes and the channel axis."""
     x = x.contiguous()
+    shift = tuple(shift) + (0,) * (4 - len(shift))
     dims, axes = _window_spec(x.shape, nwin, ppw, patch, shift)
     b, c = x.shape[0], x.shape[-1]
     out_shape = (b, nwin[0] * nwin[1] * nwin[2], ppw[0] * ppw[1] * ppw[2],
@@ -416,7 +432,7 @@ def window_partition(x, nwin, ppw, patch, shift=(0, 0, 0)):
 def window_merge(tokens, image_shape, nwin, ppw, patch):
     """inverse of window_partition without a shift: [b, nW, T, (x y z c)] -> [b, X, Y, Z, c]."""
     tokens = tokens.contiguous()
-    dims, axes = _window_spec(image_shape, nwin, ppw, patch, (0, 0, 0))
+    dims, axes = _window_spec(image_shape, nwin, ppw, patch, (0, 0, 0, 0))
     inv_dims, inv_axes, _ = _inverse_gather(dims, axes)
     return _GatherFn.apply(tokens, inv_dims, inv_axes, tuple(image_shape))
 
@@ -505,7 +521,10 @@ class _AddBcastFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        db = ops.sum_bcast(g, ctx.bshape) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.needs_input_grad[1]:
+            same = int(np.prod(ctx.bshape)) == g.numel()
+            db = g.reshape(ctx.bshape) if same else ops.sum_bcast(g, ctx.bshape)
         return g, db
 
 

@@ -100,6 +100,8 @@ class ActDropNorm(torch.nn.Module):
                 kw.update(norm="batch", eps=m.eps, gamma=m.weight, beta=m.bias,
                           momentum=m.momentum,
                           running=(m.running_mean, m.running_var, m.num_batches_tracked))
+            elif isinstance(m, LayerNormChannelsFirst):
+                X = m(X)
             elif isinstance(m, torch.nn.LayerNorm):
                 # feature vectors / tokens ([..., C]): row LayerNorm kernel, then the rest of
                 # the stage elementwise
@@ -122,6 +124,9 @@ class ActDropNorm(torch.nn.Module):
         if "A" in stage:
             name, p, w = act_spec(self.op_list[stage["A"]])
             kw.update(act=name, act_p=p, act_w=w)
+        if (kw.get("norm", "none") == "none" and kw.get("act", "identity") == "identity"
+                and not (self.training and kw.get("drop_p", 0.0) > 0.0)):
+            return X  # nothing left to apply (e.g. a LayerNorm-only ADN)
         if X.dim() != 5 and kw.get("norm", "none") == "none" and kw.get("act_w") is None:
             # purely elementwise on a token / feature tensor: no channel semantics
             return HF.elementwise(X, act=kw.get("act", "identity"), act_p=kw.get("act_p", 0.0),

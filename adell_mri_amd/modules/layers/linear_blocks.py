@@ -8,6 +8,7 @@ are the token kernels of ``csrc/tokens.hip``.
 """
 from typing import List
 
+import numpy as np
 import torch
 
 from ... import functional as HF
@@ -26,6 +27,20 @@ class LayerNorm(torch.nn.LayerNorm):
         if len(self.normalized_shape) != 1:
             raise NotImplementedError("HIP LayerNorm normalises the last dimension only")
         return HF.layer_norm(X, self.weight, self.bias, self.eps)
+
+
+def get_relative_position_indices(window_size) -> torch.Tensor:
+    """Index into the relative-position bias table for every ordered pair of positions of a
+    window (linear_blocks.py:17-51; row-major positions, offsets shifted to start at 0 and
+    combined in mixed radix (2*ws-1))."""
+    ws = [int(w) for w in window_size]
+    coords = np.stack(np.meshgrid(*[np.arange(w) for w in ws], indexing="ij")).reshape(len(ws), -1)
+    rel = coords[:, :, None] - coords[:, None, :]          # n, P, P
+    index = np.zeros(rel.shape[1:], dtype=np.int64)
+    for i, w in enumerate(ws):
+        radix = int(np.prod([2 * v - 1 for v in ws[i + 1:]])) if i + 1 < len(ws) else 1
+        index += (rel[i] + w - 1) * radix
+    return torch.from_numpy(index)
 
 
 class MLP(torch.nn.Module):
@@ -75,8 +90,6 @@ class MultiHeadSelfAttention(torch.nn.Module):
         self.window_size = window_size
         assert (attention_dim % n_heads) == 0, "attention_dim must be divisible by n_heads"
         assert (hidden_dim % n_heads) == 0, "hidden_dim must be divisible by n_heads"
-        if self.window_size:
-            raise NotImplementedError("windowed attention (SWIN) is a later row")
         self.init_layers()
         self.init_output_layer()
         self.init_weights()
@@ -89,6 +102,12 @@ class MultiHeadSelfAttention(torch.nn.Module):
         self.drop_op = torch.nn.Dropout(self.dropout_rate)
         self.q_norm = LayerNorm(self.real_attention_dim)
         self.k_norm = LayerNorm(self.real_attention_dim)
+        if self.window_size:
+            # linear_blocks.py:331-343: bias table over the (2*ws-1)^n relative offsets
+            self.relative_position_bias_table = torch.nn.Parameter(torch.zeros(
+                int(np.prod([2 * ws - 1 for ws in self.window_size])), self.n_heads))
+            torch.nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+            self.relative_position_index = get_relative_position_indices(self.window_size)
 
     def init_output_layer(self):
         self.output_layer = Linear(self.hidden_dim, self.output_dim)
@@ -97,15 +116,38 @@ class MultiHeadSelfAttention(torch.nn.Module):
         torch.nn.init.xavier_uniform_(self.qkv.weight)
         torch.nn.init.xavier_uniform_(self.output_layer.weight)
 
+    def relative_position_bias(self, t):
+        """[n_heads, t, t] additive bias. As in the reference (linear_blocks.py:389-393) the
+        gathered [t*t, n_heads] rows are RESHAPED (not permuted) to [n_heads, t, t]."""
+        idx = self.relative_position_index[:t, :t].reshape(-1).to(
+            self.relative_position_bias_table.device)
+        return self.relative_position_bias_table[idx].reshape(self.n_heads, t, t)
+
     def forward(self, X: torch.Tensor, mask=None, residual: torch.Tensor = None) -> torch.Tensor:
-        if self.training and self.dropout_rate > 0:
-            raise NotImplementedError("attention-probability dropout has no HIP kernel yet")
         sh = X.shape
         b, t = sh[:-2], sh[-2]
         nb = 1
         for i in b:
             nb *= i
         a, h = self.real_attention_dim, self.real_hidden_dim
+        if t <= 64 and a <= 32 and h <= 32 and (mask is None or mask.ndim == 3):
+            # short sequences / windows: q-norm, k-norm, bias, mask, dropout and attention on
+            # the QKV buffer in place (csrc/window.hip)
+            rel = self.relative_position_bias(t) if self.window_size else None
+            m = None
+            if mask is not None:
+                m = mask.to(device=X.device, dtype=torch.float32)
+            O = HF.window_attention(self.qkv(X).reshape(nb * t, self.qkv_dim), self.q_norm.weight,
+                                    self.q_norm.bias, self.k_norm.weight, self.k_norm.bias, nb,
+                                    self.n_heads, t, a, h, rel=rel, mask=m,
+                                    drop_p=self.dropout_rate, training=self.training,
+                                    eps=self.q_norm.eps)
+            return self.output_layer(O.view(*b, t, self.hidden_dim), residual=residual)
+        if self.training and self.dropout_rate > 0:
+            raise NotImplementedError("attention-probability dropout beyond 64 tokens has no "
+                                      "HIP kernel yet")
+        if self.window_size:
+            raise NotImplementedError("windowed attention beyond 64 tokens per window")
         QKV = self.qkv(X).reshape(nb, t, self.n_heads, 2 * a + h).permute(0, 2, 1, 3)
         Q = self.q_norm(QKV[..., :a].contiguous())      # per-head interleaved q | k | v
         K = self.k_norm(QKV[..., a:2 * a].contiguous())

@@ -15,7 +15,14 @@ class LayerNormChannelsFirst(torch.nn.Module):
         self.normalized_shape = (normalized_shape,)
 
     def forward(self, x):
-        raise NotImplementedError("LayerNormChannelsFirst: HIP kernel lands with the UNETR/ConvNeXt rows")
+        """NDHWC memory makes the channel axis the row: one short-row LayerNorm kernel."""
+        from ... import functional as HF
+        from ... import ops
+
+        if x.dim() != 5:
+            raise NotImplementedError("HIP LayerNormChannelsFirst: 5-D activations only")
+        rows = ops.ndhwc(x).permute(0, 2, 3, 4, 1)            # [N, D, H, W, C], contiguous
+        return HF.layer_norm(rows, self.weight, self.bias, self.eps).permute(0, 4, 1, 2, 3)
 
 
 class UOut(torch.nn.Module):

@@ -40,21 +40,35 @@ class LinearEmbedding(torch.nn.Module):
         self.channels_last = channels_last
         assert self.embed_method in ["linear", "convolutional"], "embed_method must be linear or convolutional"
         assert len(self.image_size) == len(self.patch_size), "image_size and patch_size must have the same length"
-        unsupported = (embed_method != "linear" or window_size is not None or use_class_token
-                       or n_registers > 0 or channel_to_token or channels_last
-                       or not learnable_embedding)
-        if unsupported:
-            raise NotImplementedError("HIP LinearEmbedding covers the UNETR configuration only "
-                                      "(linear embedding, no windows / class token / registers)")
         self.n_dims = len(self.image_size)
-        self.n_patches_split = [x // y for x, y in zip(self.image_size, self.patch_size)]
+        self.windowed = window_size is not None
+        if use_class_token or n_registers > 0 or channel_to_token or not learnable_embedding:
+            raise NotImplementedError("HIP LinearEmbedding: no class token / registers / "
+                                      "channel tokens / sinusoidal embedding")
+        if self.windowed:
+            # SWIN configuration (vit.py:553-571): tokens are the patches of one window
+            if not channels_last or self.n_dims != 3:
+                raise NotImplementedError("HIP windowed LinearEmbedding: 3-D, channels_last=True")
+            self.n_windows = [x // y for x, y in zip(self.image_size, self.window_size)]
+            self.n_patches_split = [x // z // y for x, y, z in
+                                    zip(self.image_size, self.patch_size, self.n_windows)]
+        else:
+            if embed_method != "linear" or channels_last:
+                raise NotImplementedError("HIP LinearEmbedding without windows covers the UNETR "
+                                          "configuration only (linear embedding, channels first)")
+            self.n_patches_split = [x // y for x, y in zip(self.image_size, self.patch_size)]
         self.n_patches = int(np.prod(self.n_patches_split))
         self.n_features = int(np.prod(self.patch_size) * self.in_channels)
+        if self.embed_method == "convolutional":
+            # parameter container only: the patch convolution runs as gather + GEMM
+            self.conv = torch.nn.Conv3d(self.in_channels, self.true_n_features, self.patch_size,
+                                        stride=self.patch_size)
         self.map_to_out = torch.nn.Identity()
         self.map_to_in = torch.nn.Identity()
         if self.out_dim is not None and self.out_dim != self.n_features:
-            self.map_to_out = torch.nn.Sequential(LayerNorm(self.n_features),
-                                                  Linear(self.n_features, self.out_dim))
+            if self.embed_method == "linear":
+                self.map_to_out = torch.nn.Sequential(LayerNorm(self.n_features),
+                                                      Linear(self.n_features, self.out_dim))
             self.map_to_in = Linear(self.out_dim, self.n_features)
         self.drop_op = torch.nn.Dropout(self.dropout_rate)
         if self.use_pos_embed:
@@ -84,6 +98,32 @@ class LinearEmbedding(torch.nn.Module):
     def rearrange(self, X):
         X = self._to_tokens(X)
         return self.map_to_out(X)
+
+    # ---- windowed (SWIN) path: channels-last images <-> [b, windows, tokens, features] ----
+    def window_tokens(self, X, shift=(0, 0, 0, 0)):
+        """Embedding of torch.roll(X, -shift) for X [b, *image_size, c]: window partition
+        (one gather), then LayerNorm + Linear ("linear") or the patch convolution as a GEMM
+        over (x y z c) features ("convolutional"), + positional embedding, dropout."""
+        tokens = HF.window_partition(X, self.n_windows, self.n_patches_split, self.patch_size,
+                                     shift)
+        if self.embed_method == "convolutional":
+            w = self.conv.weight.permute(0, 2, 3, 4, 1).reshape(self.true_n_features, -1)
+            tokens = HF.linear(tokens, w, self.conv.bias)
+        else:
+            tokens = self.map_to_out(tokens)
+        if self.use_pos_embed is True:
+            tokens = HF.add_bcast(tokens, self.positional_embedding)
+        if self.dropout_rate > 0 and self.training:
+            tokens = HF.elementwise(tokens, drop_p=self.dropout_rate, training=True)
+        return tokens
+
+    def window_image(self, tokens):
+        """rearrange_inverse / rearrange_inverse_basic of the windowed embedding
+        (vit.py:777-811): map_to_in, then tokens back to [b, *image_size, c]."""
+        tokens = self.map_to_in(tokens)
+        shape = (tokens.shape[0], *self.image_size, self.in_channels)
+        return HF.window_merge(tokens, shape, self.n_windows, self.n_patches_split,
+                               self.patch_size)
 
     def _from_tokens(self, X, scale):
         """inverse rearrangement with the per-axis factor ``scale`` moved from the patch
@@ -118,6 +158,8 @@ class LinearEmbedding(torch.nn.Module):
         return self._from_tokens(X, list(scale))
 
     def forward(self, X, no_pos_embed: bool = False):
+        if self.windowed:
+            return self.window_tokens(X)
         X = self.rearrange(X)
         if (no_pos_embed is False) and (self.use_pos_embed is True):
             X = HF.add_bcast(X, self.positional_embedding)
@@ -279,3 +321,227 @@ class ViT(torch.nn.Module):
             if i in return_at:
                 outputs.append(embeded_X)
         return embeded_X, outputs
+
+
+def move_axis(X: torch.Tensor, axis1: int, axis2: int) -> torch.Tensor:
+    axes = list(range(len(X.shape)))
+    if axis1 < 0:
+        axis1 = axes[axis1]
+    if axis2 < 0:
+        axis2 = axes[axis2]
+    axes.insert(axis2, axes.pop(axis1))
+    return X.permute(tuple(axes))
+
+
+def einops_rescale(X: torch.Tensor, scale) -> torch.Tensor:
+    """'b c (h p1) (w p2) (d p3) -> b (c p1 p2 p3) h w d' (vit.py:33-45) as one gather."""
+    if isinstance(scale, int):
+        scale = [scale] * (X.dim() - 2)
+    if all(int(s) == 1 for s in scale):
+        return X
+    return HF.space_to_depth(X, [int(s) for s in scale])
+
+
+def generate_mask(image_size, window_size, shift_size):
+    """Additive attention mask of shifted windows (vit.py:132-207), in patch units:
+    [n_windows, tokens, tokens] with -100 between tokens of different shift regions. Host
+    logic, evaluated once per block. Like the reference, region labels are read with the
+    window index as the FAST factor of each axis ("(w1 h)": position = w1 * n_windows + h)."""
+    nd = len(image_size)
+    if not isinstance(window_size, list):
+        window_size = [window_size for _ in image_size]
+    if not isinstance(shift_size, list):
+        shift_size = [shift_size for _ in image_size]
+    if not any(x > 0 for x in shift_size):
+        return None
+    label = np.zeros(tuple(image_size), dtype=np.float32)
+    regions = [(slice(0, -w), slice(-w, -s), slice(-s, None))
+               for w, s in zip(window_size, shift_size)]
+    cnt = 0
+    for combo in np.ndindex(*[3] * nd):
+        label[tuple(regions[i][c] for i, c in enumerate(combo))] = cnt
+        cnt += 1
+    n_win = [s // w for s, w in zip(image_size, window_size)]
+    shape = []
+    for w, h in zip(window_size, n_win):
+        shape += [w, h]
+    lab = label.reshape(shape)                                   # (w1 h w2 w w3 d)
+    perm = [2 * i + 1 for i in range(nd)] + [2 * i for i in range(nd)]
+    lab = lab.transpose(perm).reshape(int(np.prod(n_win)), int(np.prod(window_size)))
+    diff = lab[:, None, :] - lab[:, :, None]
+    return torch.from_numpy(np.where(diff != 0, -100.0, 0.0).astype(np.float32))
+
+
+class SWINTransformerBlock(torch.nn.Module):
+    """Shifted-window transformer block (vit.py:1005-1198 ``forward``). Image in, image out:
+    [b, c, *image_size] -> cyclic shift + window partition + embedding (one gather + one
+    GEMM) -> LayerNorm -> windowed attention -> Linear -> window merge -> + input ->
+    per-voxel LayerNorm / MLP over the c channels -> (space-to-depth by ``scale``).
+
+    Reference behaviour kept on purpose (vit.py:1130-1145, 1190-1212): the cyclic shift is by
+    ``shift_size`` elements (not patches; the mask is built for ``shift_size`` patches) along
+    dims 2, 3, 4 of the channels-last [b, X, Y, Z, c] tensor -- i.e. Y, Z and the CHANNEL
+    axis, X stays put -- and the attention output is added to the shortcut in that shifted
+    frame (the roll back at vit.py:1207-1210 is overwritten before use)."""
+
+    def __init__(self, image_size, patch_size, window_size, in_channels: int,
+                 attention_dim: int = None, hidden_dim: int = None, embedding_size: int = None,
+                 shift_size: int = 0, n_heads: int = 4, dropout_rate: float = 0.0,
+                 dropout_rate_embedding: float = 0.0, embed_method: str = "linear",
+                 mlp_structure: Union[List[int], float] = [32, 32], use_pos_embed: bool = False,
+                 adn_fn=get_adn_fn(1, "identity", "gelu")):
+        super().__init__()
+        self.image_size = image_size
+        self.patch_size = patch_size
+        self.window_size = window_size
+        self.in_channels = in_channels
+        self.attention_dim = attention_dim
+        self.hidden_dim = hidden_dim
+        self.embedding_size = embedding_size
+        self.shift_size = shift_size
+        self.n_heads = n_heads
+        self.dropout_rate = dropout_rate
+        self.dropout_rate_embedding = dropout_rate_embedding
+        self.embed_method = embed_method
+        self.mlp_structure = mlp_structure
+        self.use_pos_embed = use_pos_embed
+        self.adn_fn = adn_fn
+        self.init_embedding()
+        self.init_drop_ops()
+        self.init_layers()
+        self.init_mask_if_necessary()
+
+    def init_embedding(self):
+        self.embedding = LinearEmbedding(
+            image_size=self.image_size, patch_size=self.patch_size, in_channels=self.in_channels,
+            window_size=self.window_size, dropout_rate=self.dropout_rate_embedding,
+            embed_method=self.embed_method, out_dim=self.embedding_size,
+            use_pos_embed=self.use_pos_embed, channels_last=True)
+        self.input_dim_primary = self.embedding.true_n_features
+
+    def init_mask_if_necessary(self):
+        self.attention_mask = generate_mask(
+            image_size=[x // y for x, y in zip(self.image_size, self.patch_size)],
+            window_size=[x // y for x, y in zip(self.window_size, self.patch_size)],
+            shift_size=self.shift_size)
+        self._mask_dev = None
+
+    def init_layers(self):
+        if isinstance(self.mlp_structure, float):
+            self.mlp_structure = [int(self.in_channels * self.mlp_structure)]
+        d = self.input_dim_primary
+        hidden_dim = d if self.hidden_dim is None else self.hidden_dim
+        attention_dim = d if self.attention_dim is None else self.attention_dim
+        self.mha = MultiHeadSelfAttention(d, attention_dim, hidden_dim, d,
+                                          window_size=self.window_size,
+                                          dropout_rate=self.dropout_rate, n_heads=self.n_heads)
+        self.norm_op_1 = LayerNorm(d)
+        self.norm_op_2 = LayerNorm(self.in_channels)
+        self.mlp = MLP(self.in_channels, self.in_channels, self.mlp_structure, self.adn_fn)
+
+    def init_drop_ops(self):
+        self.drop_op_1 = torch.nn.Dropout(self.dropout_rate)
+        self.drop_op_2 = torch.nn.Dropout(self.dropout_rate)
+
+    def _mask(self, device):
+        if self.attention_mask is None:
+            return None
+        if self._mask_dev is None or self._mask_dev.device != device:
+            self._mask_dev = self.attention_mask.to(device)
+        return self._mask_dev
+
+    def _drop(self, X):
+        if self.training and self.dropout_rate > 0:
+            return HF.elementwise(X, drop_p=self.dropout_rate, training=True)
+        return X
+
+    def forward(self, X: torch.Tensor, scale=None) -> torch.Tensor:
+        from ... import ops
+
+        X = ops.ndhwc(X).permute(0, 2, 3, 4, 1)        # move_axis(X, 1, -1): a view of NDHWC
+        shortcut = X
+        if scale is not None and isinstance(scale, int):
+            scale = [scale for _ in self.patch_size]
+        ss = self.shift_size
+        if isinstance(ss, int):
+            ss = [ss] * len(self.patch_size)
+        # torch.roll(X, [-s...], dims=[2, 3, 4]) on [b, X, Y, Z, c]
+        embedded = self.embedding.window_tokens(X, (0, ss[0], ss[1], ss[2]))
+        attention = self.mha(self.norm_op_1(embedded), mask=self._mask(X.device))
+        shifted = self.embedding.window_image(attention)
+        drop = self.training and self.dropout_rate > 0
+        X = HF.add(shortcut, self._drop(shifted))
+        if drop:
+            X = HF.add(X, self._drop(self.mlp(self.norm_op_2(X))))
+        else:
+            X = self.mlp(self.norm_op_2(X), residual=X)
+        X = X.permute(0, 4, 1, 2, 3)                      # move_axis(X, -1, 1)
+        if scale is not None:
+            X = einops_rescale(X, scale)
+        return X
+
+
+class SWINTransformerBlockStack(torch.nn.Module):
+    """vit.py:1438-1616: one SWINTransformerBlock per entry of ``shift_sizes``; only the
+    first may use the convolutional embedding / positional embedding."""
+
+    def __init__(self, image_size, patch_size, window_size, shift_sizes: List[int],
+                 in_channels: int, attention_dim: int = None, hidden_dim: int = None,
+                 embedding_size: int = None, n_heads: int = 4, dropout_rate: float = 0.0,
+                 dropout_rate_embedding: float = 0.0, embed_method: str = "linear",
+                 mlp_structure: Union[List[int], float] = [128], use_pos_embed: bool = False,
+                 adn_fn=get_adn_fn(1, "identity", "gelu")):
+        super().__init__()
+        self.image_size = image_size
+        self.patch_size = patch_size
+        self.window_size = window_size
+        self.shift_sizes = shift_sizes
+        self.in_channels = in_channels
+        self.attention_dim = attention_dim
+        self.hidden_dim = hidden_dim
+        self.embedding_size = embedding_size
+        self.n_heads = n_heads
+        self.dropout_rate = dropout_rate
+        self.dropout_rate_embedding = dropout_rate_embedding
+        self.embed_method = embed_method
+        self.mlp_structure = mlp_structure
+        self.use_pos_embed = use_pos_embed
+        self.adn_fn = adn_fn
+        self.init_swin_transformers()
+
+    def convert_mlp_structure(self, x):
+        if isinstance(x, float) is True:
+            return [x for _ in self.shift_sizes]
+        if isinstance(x[0], list) is False:
+            return [x for _ in self.shift_sizes]
+        return x
+
+    def convert_to_list_if_necessary(self, x):
+        if isinstance(x, list) is False:
+            return [x for _ in self.shift_sizes]
+        assert len(x) == len(self.shift_sizes)
+        return x
+
+    def init_swin_transformers(self):
+        attention_dim = self.convert_to_list_if_necessary(self.attention_dim)
+        hidden_dim = self.convert_to_list_if_necessary(self.hidden_dim)
+        n_heads = self.convert_to_list_if_necessary(self.n_heads)
+        dropout_rate = self.convert_to_list_if_necessary(self.dropout_rate)
+        mlp_structure = self.convert_mlp_structure(self.mlp_structure)
+        self.stbs = torch.nn.ModuleList([])
+        first = True
+        for ss, ad, hd, nh, dr, mlp_s in zip(self.shift_sizes, attention_dim, hidden_dim, n_heads,
+                                             dropout_rate, mlp_structure):
+            self.stbs.append(SWINTransformerBlock(
+                image_size=self.image_size, patch_size=self.patch_size,
+                window_size=self.window_size, in_channels=self.in_channels, attention_dim=ad,
+                hidden_dim=hd, embedding_size=self.embedding_size, shift_size=ss, n_heads=nh,
+                dropout_rate_embedding=self.dropout_rate_embedding, dropout_rate=dr,
+                embed_method=self.embed_method if first else "linear", mlp_structure=mlp_s,
+                adn_fn=self.adn_fn, use_pos_embed=first and self.use_pos_embed))
+            first = False
+
+    def forward(self, X: torch.Tensor, scale=1) -> torch.Tensor:
+        for block in self.stbs[:-1]:
+            X = block(X, scale=1)
+        return self.stbs[-1](X, scale=scale)

@@ -18,7 +18,8 @@ import torch
 from ..._lib import AdellHipError
 from ..layers.adn_fn import get_adn_fn
 from ..layers.conv import ConvTranspose3d
-from ..layers.vit import LinearEmbedding, ViT
+from ... import functional as HF
+from ..layers.vit import LinearEmbedding, SWINTransformerBlockStack, ViT
 from .unet import UNet
 
 
@@ -215,6 +216,231 @@ class UNETR(UNet, torch.nn.Module):
 
         final_features = curr
         curr = self._final(self.final_layer, curr, return_logits)
+        if return_features is True:
+            return curr, final_features, bottleneck
+        if self.bottleneck_classification is True:
+            pooled = bottleneck.flatten(start_dim=2).max(-1).values
+            bn_out = self.bottleneck_classifier(pooled)
+        else:
+            bn_out = None
+        if self.deep_supervision is True:
+            for i in range(len(deep_outputs)):
+                deep_outputs[i] = self._final(self.deep_supervision_ops[i], deep_outputs[i], False)
+            return curr, bn_out, deep_outputs
+        return curr, bn_out
+
+
+class SWINUNet(UNet, torch.nn.Module):
+    """SWIN-UNet: drop-in mirror of ``adell_mri.modules.segmentation.unetr.SWINUNet``
+    (unetr.py:635-1033). Same constructor, module tree / ``state_dict`` keys
+    (``first_encoder``, ``first_swin_block``, ``swin_blocks``, ``first_rec_op``,
+    ``reconstruction_ops``, ``upscale_ops``, ``link_ops``, ``decoding_operations``,
+    ``final_layer``) and ``forward`` returns. Encoder: stacks of shifted-window transformer
+    blocks at image resolution, each closed by a space-to-depth rescale; channels-first
+    LayerNorm + conv reconstruction; standard U-Net decoder; the head reads the virtual
+    concatenation [first_encoder(X), decoder output]."""
+
+    def __init__(
+        self,
+        image_size,
+        patch_size,
+        window_size,
+        shift_sizes,
+        embedding_size: int = None,
+        n_heads: int = 4,
+        dropout_rate: float = 0.0,
+        embed_method: str = "linear",
+        mlp_structure: List[int] = [256, 256],
+        adn_fn_mlp: Callable = get_adn_fn(1, "identity", "gelu"),
+        spatial_dimensions: int = 2,
+        conv_type: str = "regular",
+        link_type: str = "identity",
+        upscale_type: str = "upsample",
+        interpolation: str = "bilinear",
+        norm_type: str = "batch",
+        dropout_type: str = "dropout",
+        padding: int = 0,
+        dropout_param: float = 0.0,
+        activation_fn: torch.nn.Module = torch.nn.PReLU,
+        in_channels: int = 1,
+        n_classes: int = 2,
+        depth: list = [16, 32, 64],
+        kernel_sizes: list = [3, 3, 3],
+        strides: list = None,
+        bottleneck_classification: bool = False,
+        skip_conditioning: int = None,
+        feature_conditioning: int = None,
+        feature_conditioning_params: Dict[str, torch.Tensor] = None,
+        deep_supervision: bool = False,
+    ):
+        super().__init__(parent_class=True)
+        self.image_size = image_size
+        self.patch_size = patch_size
+        self.window_size = window_size
+        self.shift_sizes = shift_sizes
+        self.embedding_size = embedding_size
+        self.n_heads = n_heads
+        self.dropout_rate = dropout_rate
+        self.embed_method = embed_method
+        self.mlp_structure = mlp_structure
+        self.adn_fn_mlp = adn_fn_mlp
+        self.spatial_dimensions = spatial_dimensions
+        self.conv_type = conv_type
+        self.link_type = link_type
+        self.upscale_type = upscale_type
+        self.interpolation = interpolation
+        self.norm_type = norm_type
+        self.dropout_type = dropout_type
+        self.padding = padding
+        self.dropout_param = dropout_param
+        self.activation_fn = activation_fn
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.depth = depth
+        self.kernel_sizes = kernel_sizes
+        self.strides = strides
+        self.bottleneck_classification = bottleneck_classification
+        self.skip_conditioning = skip_conditioning
+        self.feature_conditioning = feature_conditioning
+        self.feature_conditioning_params = feature_conditioning_params
+        self.deep_supervision = deep_supervision
+        self.encoder_only = False
+        self.number_of_blocks = len(self.depth)
+        if self.spatial_dimensions != 3:
+            raise NotImplementedError("HIP SWINUNet is 3-D (the BASELINE configuration)")
+        if self.feature_conditioning is not None:
+            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
+        self.arg_compliance()
+        self.get_norm_op()
+        self.get_drop_op()
+        self.get_conv_op()
+        self.init_first_encoder()
+        self.init_swin_blocks()
+        self.init_reconstruction_ops()
+        self.init_upscale_ops()
+        self.init_link_ops()
+        self.init_decoder()
+        self.init_final_layer()
+        if self.bottleneck_classification is True:
+            self.init_bottleneck_classifier()
+
+    def arg_compliance(self):
+        msg = "shift_sizes must be list of ints or list of list of ints"
+        assert len(self.depth) == self.number_of_blocks
+        assert isinstance(self.shift_sizes, list), msg
+        if isinstance(self.shift_sizes[0], int):
+            self.shift_sizes = [self.shift_sizes for _ in self.depth]
+        if isinstance(self.n_heads, int):
+            self.n_heads = [self.n_heads for _ in self.depth]
+        if isinstance(self.embedding_size, int) or self.embedding_size is None:
+            self.embedding_size = [self.embedding_size for _ in self.depth]
+        elif isinstance(self.shift_sizes[0], list):
+            assert isinstance(self.shift_sizes[0][0], int), msg
+        else:
+            raise AssertionError(msg)
+        if self.strides is None:
+            self.strides = [2 for _ in range(len(self.depth))]
+        self.strides = list(self.strides)
+        for i in range(len(self.strides)):
+            if isinstance(self.strides[i], int):
+                self.strides[i] = [self.strides[i] for _ in range(self.spatial_dimensions)]
+
+    def init_first_encoder(self):
+        self.first_encoder = torch.nn.Sequential(
+            self.adn_fn(self.in_channels),
+            self.conv_op_enc(self.in_channels, self.depth[0], 3, padding="same"),
+            self.adn_fn(self.depth[0]))
+
+    def init_final_layer(self):
+        self.final_layer = self.get_final_layer(self.depth[0] * 2)
+
+    def init_swin_blocks(self):
+        self.in_channels_rec = []
+        common = dict(patch_size=self.patch_size, window_size=self.window_size,
+                      dropout_rate=self.dropout_rate, mlp_structure=self.mlp_structure,
+                      adn_fn=self.adn_fn_mlp)
+        self.first_swin_block = SWINTransformerBlockStack(
+            image_size=self.image_size, in_channels=self.in_channels,
+            shift_sizes=self.shift_sizes[0], attention_dim=self.embedding_size[0],
+            hidden_dim=self.embedding_size[0], embedding_size=self.embedding_size[0],
+            n_heads=self.n_heads[0], dropout_rate_embedding=self.dropout_rate,
+            embed_method=self.embed_method, use_pos_embed=True, **common)
+        self.swin_blocks = torch.nn.ModuleList([])
+        image_size = self.image_size
+        for i in range(self.number_of_blocks - 1):
+            in_channels = self.in_channels
+            if i > 0:
+                in_channels *= int(np.prod([np.prod(s) for s in self.strides[:i]]))
+                self.in_channels_rec.append(in_channels)
+            self.swin_blocks.append(SWINTransformerBlockStack(
+                image_size=image_size, in_channels=in_channels,
+                shift_sizes=self.shift_sizes[i + 1], attention_dim=self.embedding_size[i + 1],
+                hidden_dim=self.embedding_size[i + 1], embedding_size=self.embedding_size[i + 1],
+                n_heads=self.n_heads[i + 1], dropout_rate_embedding=0.0, embed_method="linear",
+                use_pos_embed=False, **common))
+            image_size = [x // s for x, s in zip(image_size, self.strides[i])]
+        self.in_channels_rec.append(
+            self.in_channels * int(np.prod([np.prod(s) for s in self.strides[:-1]])))
+
+    def init_reconstruction_ops(self):
+        layer_norm = get_adn_fn(self.spatial_dimensions, "layer", None, 0.0)
+        self.first_rec_op = torch.nn.Sequential(
+            layer_norm(self.in_channels),
+            self.conv_op_enc(self.in_channels, self.depth[0], 3, padding="same"),
+            self.adn_fn(self.depth[0]))
+        self.reconstruction_ops = torch.nn.ModuleList([])
+        for i, d in enumerate(self.depth[1:]):
+            self.reconstruction_ops.append(torch.nn.Sequential(
+                layer_norm(self.in_channels_rec[i]),
+                self.conv_op_enc(self.in_channels_rec[i], d, 1, padding="same"),
+                self.conv_op_enc(d, d, 3, padding="same"),
+                self.adn_fn(d)))
+
+    def forward(self, X: torch.Tensor, X_skip_layer: torch.Tensor = None,
+                X_feature_conditioning: torch.Tensor = None, return_features=False,
+                return_bottleneck=False, return_logits=False):
+        if not X.is_cuda:
+            raise AdellHipError("adell_mri_amd.SWINUNet runs on MI355X only (no CPU fallback)")
+        if X_feature_conditioning is not None:
+            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
+        if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
+            X_skip_layer = X_skip_layer.unsqueeze(1)
+
+        X_encoded_first = self.first_encoder(X)
+        curr = self.first_swin_block(X)
+        encoding_out = [self.first_rec_op(curr)]
+        for i in range(len(self.swin_blocks)):
+            curr = self.swin_blocks[i](curr, scale=self.strides[i])
+            encoding_out.append(self.reconstruction_ops[i](curr))
+        curr = encoding_out[-1]
+        bottleneck = curr
+        if return_bottleneck is True:
+            return None, None, bottleneck
+        elif self.encoder_only is True:
+            return bottleneck
+
+        deep_outputs = []
+        for i in range(len(self.decoding_operations)):
+            op = self.decoding_operations[i]
+            link_in = encoding_out[-i - 2]
+            if X_skip_layer is not None:
+                xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
+                link_in = HF.cat_channels([link_in, xfl])
+            encoded = self.link_ops[i](link_in)
+            curr = self.upscale_ops[i](curr)
+            curr = op(curr, X_cat=encoded)
+            deep_outputs.append(curr)
+
+        final_features = curr
+        # final_layer(cat[X_encoded_first, curr]) without materialising the concat
+        mods = list(self.final_layer)
+        out = mods[0](X_encoded_first, X_cat=curr)
+        for mod in mods[1:-1]:
+            out = mod(out)
+        if return_logits is not True:
+            out = (HF.norm_drop_act(out, act="sigmoid") if isinstance(mods[-1], torch.nn.Sigmoid)
+                   else mods[-1](out))
+        curr = out
         if return_features is True:
             return curr, final_features, bottleneck
         if self.bottleneck_classification is True:

@@ -38,7 +38,7 @@ from adell_mri.modules.layers.res_blocks import ResidualBlock3d  # noqa: E402
 from adell_mri.modules.segmentation.losses import (  # noqa: E402
     binary_focal_loss, binary_generalized_dice_loss)
 from adell_mri.modules.segmentation.unet import UNet  # noqa: E402
-from adell_mri.modules.segmentation.unetr import UNETR  # noqa: E402
+from adell_mri.modules.segmentation.unetr import SWINUNet, UNETR  # noqa: E402
 from adell_mri.modules.segmentation.unetpp import UNetPlusPlus  # noqa: E402
 from adell_mri.modules.layers.linear_blocks import MultiHeadSelfAttention  # noqa: E402
 from adell_mri.modules.layers.vit import TransformerBlock  # noqa: E402
@@ -99,6 +99,22 @@ UNETPP_CASES = {
 }
 
 
+SWIN_CASES = {
+    # BASELINE config 5 (unet-swin.yaml) in miniature: convolutional embedding, 8^3 windows of
+    # 4^3 patches (8 tokens), shifts [0, 1], anisotropic first stride, conv links
+    "swinunet3d_small": (dict(image_size=[32, 32, 16], patch_size=[4, 4, 4],
+                              window_size=[8, 8, 8], shift_sizes=[[0, 1], [0, 1], [0, 1]],
+                              embedding_size=[16, 32, 64], n_heads=4, dropout_rate=0.0,
+                              embed_method="convolutional", mlp_structure=4.0,
+                              spatial_dimensions=3, conv_type="regular", link_type="conv",
+                              upscale_type="transpose", norm_type="instance", padding="same",
+                              dropout_param=0.0, activation_fn="leaky_relu", in_channels=2,
+                              n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3],
+                              strides=[[2, 2, 1], 2, 2], _cls="swin"),
+                         (2, 2, 32, 32, 16), "uniform"),
+}
+
+
 BACKBONE_CASES = {
     # BASELINE config 2b in miniature: ResNet backbone (7^3 stem, k=5 / k=3 residual stages,
     # batch norm) repackaged as U-Net encoder, anisotropic pooling [2,2,1]
@@ -138,7 +154,8 @@ def make_unet(kw):
         return make_backbone_unet(kw)
     kw = dict(kw)
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
-    cls = {"unetpp": UNetPlusPlus}.get(kw.pop("_cls", None), UNETR if "patch_size" in kw else UNet)
+    cls = {"unetpp": UNetPlusPlus, "swin": SWINUNet}.get(
+        kw.pop("_cls", None), UNETR if "patch_size" in kw else UNet)
     net = cls(**kw)
     net.load_state_dict(fill_state_dict(net.state_dict()))
     return net
@@ -176,6 +193,22 @@ def gen_unet(name, kw, shape, dist):
     for k, p in net.named_parameters():
         if p.grad is not None:  # parameters the forward never touches have no gradient
             out["grad:" + k] = p.grad.numpy().copy()
+    if kw.get("_cls") == "swin":
+        # the per-voxel LayerNorm over 2 channels is ill-conditioned: fp32 gradients of the
+        # reference itself carry up to ~1e-2 relative noise, so the fp64 gradients of the same
+        # network are stored as the parity target (the test scales its tolerance by the
+        # reference's own fp32-vs-fp64 difference)
+        net64 = make_unet(kw).eval().double()
+        for m in net64.modules():
+            if getattr(m, "attention_mask", None) is not None:
+                m.attention_mask = m.attention_mask.double()
+        prob64 = net64(x.double())[0]
+        d64 = binary_generalized_dice_loss(prob64, y.double(), smooth=1e-5, eps=1e-6)
+        f64 = binary_focal_loss(prob64, y.double(), gamma=1.0, eps=1e-6)
+        torch.stack([d64.mean(), f64.mean()]).mean().backward()
+        for k, p in net64.named_parameters():
+            if p.grad is not None:
+                out["grad64:" + k] = p.grad.numpy().copy()
     out["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in net.named_parameters()])
     # one and two SGD-Nesterov steps as configured at segmentation/pl.py:563-569
     opt = torch.optim.SGD(net.parameters(), lr=5e-4, momentum=0.99, weight_decay=5e-3,
@@ -309,8 +342,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ssl":
         gen_ssl()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "swin":
+        for name, (kw, shape, dist) in SWIN_CASES.items():
+            gen_unet(name, kw, shape, dist)
+        sys.exit(0)
     for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES, **UNETPP_CASES,
-                                    **BACKBONE_CASES}.items():
+                                    **BACKBONE_CASES, **SWIN_CASES}.items():
         gen_unet(name, kw, shape, dist)
     gen_blocks()
     gen_ssl()

@@ -40,6 +40,18 @@ UNETPP_CASES = {
 }
 
 
+SWIN_CASES = {
+    "swinunet3d_small": dict(image_size=[32, 32, 16], patch_size=[4, 4, 4], window_size=[8, 8, 8],
+                             shift_sizes=[[0, 1], [0, 1], [0, 1]], embedding_size=[16, 32, 64],
+                             n_heads=4, dropout_rate=0.0, embed_method="convolutional",
+                             mlp_structure=4.0, spatial_dimensions=3, conv_type="regular",
+                             link_type="conv", upscale_type="transpose", norm_type="instance",
+                             padding="same", dropout_param=0.0, activation_fn="leaky_relu",
+                             in_channels=2, n_classes=2, depth=[8, 16, 32],
+                             kernel_sizes=[3, 3, 3], strides=[[2, 2, 1], 2, 2]),
+}
+
+
 def oracle_cfg(kw):
     return dict(depth=kw["depth"], kernel_sizes=kw["kernel_sizes"], strides=kw["strides"],
                 padding=kw["padding"], norm_type=kw["norm_type"], activation=kw["activation_fn"],

@@ -21,7 +21,9 @@ def rel(a, r):
     (2, (2, 3, 2), (2, 2, 2), (2, 2, 2), 2, (0, 0, 0)),
     (1, (2, 2, 1), (2, 1, 2), (4, 4, 4), 2, (1, 1, 1)),
     (2, (1, 2, 2), (2, 2, 2), (1, 2, 1), 3, (2, 0, 1)),
-    (1, (4, 4, 2), (2, 2, 2), (4, 4, 4), 8, (1, 1, 1))])
+    (1, (4, 4, 2), (2, 2, 2), (4, 4, 4), 8, (1, 1, 1)),
+    (2, (2, 2, 2), (2, 2, 2), (2, 2, 2), 2, (0, 1, 1, 1)),
+    (1, (2, 1, 2), (1, 2, 2), (4, 4, 4), 8, (0, 1, 1, 1))])
 def test_window_partition_merge_match_einops(cuda, b, nwin, ppw, patch, c, shift):
     X, Y, Z = [n * p * q for n, p, q in zip(nwin, ppw, patch)]
     g = torch.Generator().manual_seed(1)
@@ -29,7 +31,8 @@ def test_window_partition_merge_match_einops(cuda, b, nwin, ppw, patch, c, shift
     kw = dict(w1=nwin[0], w2=nwin[1], w3=nwin[2], h=ppw[0], w=ppw[1], d=ppw[2],
               x=patch[0], y=patch[1], z=patch[2])
     pat = "b (w1 h x) (w2 w y) (w3 d z) c -> b (w1 w2 w3) (h w d) (x y z c)"
-    ref = einops.rearrange(torch.roll(x, [-s for s in shift], dims=(1, 2, 3)), pat, **kw)
+    ref = einops.rearrange(torch.roll(x, [-s for s in shift], dims=tuple(range(1, 1 + len(shift)))),
+                           pat, **kw)
     r = torch.randn(ref.shape, generator=g)
     (ref * r).sum().backward()
     xd = x.detach().to(cuda).requires_grad_(True)
