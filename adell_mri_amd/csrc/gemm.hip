@@ -187,16 +187,25 @@ __global__ __launch_bounds__(256) void adell_gemm_f32_kernel(GemmArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void adell_gemm_reduce_kernel(GemmArgs a) {
+// 64 outputs x 16 lanes per block; lane l sums splits l, l+16, ... then a fixed-order fold
+__global__ __launch_bounds__(1024) void adell_gemm_reduce_kernel(GemmArgs a) {
+  __shared__ float sh[16][64];
   const long total = (long)a.M * a.N;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
-    float s = 0.f;
-    for (int sp = 0; sp < a.splits; ++sp) s += a.slab[(long)sp * total + i];
-    if (a.bias) s += a.bias[col];
-    if (a.residual) s += a.residual[(long)row * a.ldr + col];
-    a.C[(long)row * a.ldc + col] = s;
-  }
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + cl;
+  float s = 0.f;
+  if (i < total)
+    for (int sp = vl; sp < a.splits; sp += 16) s += a.slab[(long)sp * total + i];
+  sh[vl][cl] = s;
+  __syncthreads();
+  if (vl != 0 || i >= total) return;
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += sh[k][cl];
+  const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+  if (a.bias) s += a.bias[col];
+  if (a.residual) s += a.residual[(long)row * a.ldr + col];
+  a.C[(long)row * a.ldc + col] = s;
 }
 
 struct GemmPlan {
@@ -212,8 +221,14 @@ static GemmPlan adell_gemm_plan(int M, int N, int K) {
   const long tiles = (long)adell_cdiv(M, p.BM) * adell_cdiv(N, p.BN);
   const int ksteps = adell_cdiv(K, GEMM_BK);
   long s = adell_cdiv(512, tiles);
+  // very long reductions over a small output (per-voxel weight gradients: k = voxels): more,
+  // shorter splits -- at most 256 k-steps each, slabs capped at 64 MB
+  const long by_len = adell_cdiv(ksteps, 256);
+  if (s < by_len) s = by_len;
   if (s > ksteps / 4) s = ksteps / 4;
-  if (s > 128) s = 128;
+  const long slab_cap = (16L << 20) / ((long)M * N);
+  if (s > slab_cap) s = slab_cap;
+  if (s > 65535) s = 65535;
   if (s < 1) s = 1;
   p.ksteps_per_split = adell_cdiv(ksteps, (int)s);
   p.splits = adell_cdiv(ksteps, p.ksteps_per_split);
@@ -269,9 +284,8 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
                     : adell_gemm_launch<2, 2, 2, 2>(a, a_kc, b_kc, grid, st);
   if (rc != ADELL_OK) return rc;
   if (p.splits > 1) {
-    long blocks = ((long)M * N + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    const long blocks = ((long)M * N + 63) / 64;
+    hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, a);
     ADELL_CHECK_HIP(hipGetLastError());
   }
   return ADELL_OK;

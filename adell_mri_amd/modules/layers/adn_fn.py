@@ -127,7 +127,8 @@ class ActDropNorm(torch.nn.Module):
         if (kw.get("norm", "none") == "none" and kw.get("act", "identity") == "identity"
                 and not (self.training and kw.get("drop_p", 0.0) > 0.0)):
             return X  # nothing left to apply (e.g. a LayerNorm-only ADN)
-        if X.dim() != 5 and kw.get("norm", "none") == "none" and kw.get("act_w") is None:
+        if ((X.dim() != 5 or X.is_contiguous()) and kw.get("norm", "none") == "none"
+                and kw.get("act_w") is None):
             # purely elementwise on a token / feature tensor: no channel semantics
             return HF.elementwise(X, act=kw.get("act", "identity"), act_p=kw.get("act_p", 0.0),
                                   drop_p=kw.get("drop_p", 0.0), training=self.training)
