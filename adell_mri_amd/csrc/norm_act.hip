@@ -575,7 +575,13 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs 
 
 __global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
 __global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
-#define ADELL_PART_SLAB 512
+// blocks per item of the grid-strided partials kernel (each covers >= 1024 float4)
+static long adell_na_fast_blocks(long V, int C) {
+  long bx = ((V * C >> 2) + 256 * 4 - 1) / (256 * 4);
+  if (bx > 1024) bx = 1024;
+  if (bx < 1) bx = 1;
+  return bx;
+}
 
 static int adell_nab_fill(NormActBwdArgs* a, const adell_norm_act_desc* d) {
   ADELL_REQUIRE(d != nullptr, "norm_act_bwd: null descriptor");
@@ -602,7 +608,7 @@ static int adell_nab_fill(NormActBwdArgs* a, const adell_norm_act_desc* d) {
 extern "C" long adell_norm_act_bwd_workspace(const adell_norm_act_desc* d) {
   if (!d || d->N <= 0 || d->V <= 0 || d->C <= 0) return ADELL_E_BADARG;
   long nt = adell_channel_partials_ntiles(d->V);
-  const long ntf = (d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB;
+  const long ntf = adell_na_fast_blocks(d->V, d->C);
   if (ntf > nt) nt = ntf;
   return (long)sizeof(float) * (d->N * nt * d->C * 2 + 2 * d->N * d->C);
 }
@@ -628,14 +634,13 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
                   "norm_act_bwd: workspace too small");
     float* part = (float*)workspace;
     long ntmax = a.ntiles;
-    if ((d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB > ntmax)
-      ntmax = (d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB;
+    if (adell_na_fast_blocks(d->V, d->C) > ntmax) ntmax = adell_na_fast_blocks(d->V, d->C);
     float* c1 = part + (size_t)d->N * ntmax * d->C * 2;
     float* c2 = c1 + (size_t)d->N * d->C;
     a.part = part; a.c1 = c1; a.c2 = c2;
     dim3 grid(a.ntiles, (unsigned)d->N);
     if (fast) {
-      a.ntiles = (int)((d->V + ADELL_PART_SLAB - 1) / ADELL_PART_SLAB);
+      a.ntiles = (int)adell_na_fast_blocks(d->V, d->C);
       hipLaunchKernelGGL(adell_na_bwd_partials_fast_kernel, dim3(a.ntiles, (unsigned)d->N),
                          dim3(256), 0, st, a);
     } else if (vec)
@@ -781,43 +786,39 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
   }
 }
 
-// grid (slabs, N): block = 256 threads = CG channel quads x VL voxel lanes; each thread
-// keeps one channel quad and walks its slab 4 voxels at a time.
+// grid (blocks per item, N), grid-strided like the apply kernel: a thread keeps one channel
+// quad, accumulates (sum dt, sum dt*xhat) over its whole share in registers, and the block
+// folds its 256 / (C/4) threads per quad once at the end (fixed order).
 __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a) {
-  __shared__ float sh[256][8];
-  const int n = blockIdx.y, tile = blockIdx.x;
-  const long v0 = (long)tile * ADELL_PART_SLAB;
-  long v1 = v0 + ADELL_PART_SLAB;
-  if (v1 > a.V) v1 = a.V;
-  const int CG = a.C >> 2;  // <= 256 quads
-  const int VL = 256 / CG;
-  const int cl = threadIdx.x % CG, vl = threadIdx.x / CG;
-  const int c = cl << 2;
+  __shared__ float sh[8][256];
+  const int n = blockIdx.y;
+  const long n4 = a.VC >> 2;
+  const long j0 = (long)blockIdx.x * 256 + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
                   nullptr, (long)n * a.stat_stride_n, c);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
+  const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
   float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* xb = a.x + ((long)n * a.V) * a.C + c;
-  const float* gb = a.dout + ((long)n * a.V) * a.C + c;
-  for (long v = v0 + vl; v < v1; v += (long)VL * ADELL_EW_UNROLL) {
+  for (long j = j0; j < n4; j += stride * ADELL_EW_UNROLL) {
     float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
 #pragma unroll
-    for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
-      const long vv = v + (long)u * VL;
-      if (vv < v1) {
-        xv[u] = *reinterpret_cast<const float4*>(xb + vv * a.C);
-        gv[u] = *reinterpret_cast<const float4*>(gb + vv * a.C);
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u)
+      if (j + u * stride < n4) {
+        xv[u] = xin[j + u * stride];
+        gv[u] = gin[j + u * stride];
       }
-    }
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
-      const long vv = v + (long)u * VL;
-      if (vv >= v1) break;
+      const long jj = j + u * stride;
+      if (jj >= n4) break;
       const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
       const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
       bool keep[4];
-      adell_na_keep4(a, (((long)n * a.V + vv) * a.C + c) >> 2, keep);
+      adell_na_keep4(a, (long)n * n4 + jj, keep);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float hn = (xs[q] - k.m[q]) * k.r[q];
@@ -832,21 +833,21 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    sh[threadIdx.x][q] = A[q];
-    sh[threadIdx.x][4 + q] = B[q];
+    sh[q][threadIdx.x] = A[q];
+    sh[4 + q][threadIdx.x] = B[q];
   }
   __syncthreads();
-  if (vl == 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int kk = 0; kk < VL; ++kk) {
-        s1 += sh[kk * CG + cl][q];
-        s2 += sh[kk * CG + cl][4 + q];
-      }
-      float* o = a.part + (((size_t)n * a.ntiles + tile) * a.C + c + q) * 2;
-      o[0] = s1;
-      o[1] = s2;
-    }
+  // threads of one block that share a channel quad are CG = C/4 apart
+  const int CG = a.C >> 2;
+  const int VL = CG >= 256 ? 1 : 256 / CG;
+  const int nout = (CG < 256 ? CG : 256) * 8;
+  for (int o = threadIdx.x; o < nout; o += 256) {
+    const int cl = o % (nout / 8), q8 = o / (nout / 8);
+    float s1 = 0.f;
+    for (int kk = 0; kk < VL; ++kk) s1 += sh[q8][kk * CG + cl];
+    // channel of this quad slot: the block's first thread has quad (blockIdx.x*256) % CG
+    const int quad = (int)((((long)blockIdx.x * 256 + cl) << 2) & (a.C - 1));
+    const int ch = quad + (q8 & 3);
+    a.part[(((size_t)n * a.ntiles + blockIdx.x) * a.C + ch) * 2 + (q8 >> 2)] = s1;
   }
 }
