@@ -29,22 +29,36 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, name, flops, e0):
+    def stop(self, name, flops, e0, tag=None, nbytes=0.0):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((name, float(flops), e0, e1))
+        self.records.append((name, float(flops), e0, e1, tag, float(nbytes)))
+
+    def by_tag(self):
+        """{(kernel, tag): {flops, ms, launches, tflops}} -- per-layer view (tools/)."""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1, tag, _nb in self.records:
+            a = agg.setdefault((name, tag), [0.0, 0.0, 0])
+            a[0] += flops
+            a[1] += e0.elapsed_time(e1)
+            a[2] += 1
+        return {k: {"flops": v[0], "ms": v[1], "launches": v[2],
+                    "tflops": v[0] / max(v[1], 1e-9) / 1e9} for k, v in agg.items()}
 
     def summary(self):
         if self._agg is None:
             torch.cuda.synchronize()
             agg = {}
-            for name, flops, e0, e1 in self.records:
-                a = agg.setdefault(name, [0.0, 0.0, 0])
+            for name, flops, e0, e1, _tag, nb in self.records:
+                a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
                 a[0] += flops
                 a[1] += e0.elapsed_time(e1)
                 a[2] += 1
+                a[3] += nb
             self._agg = {k: {"flops": v[0], "ms": v[1], "launches": v[2],
-                             "tflops": v[0] / max(v[1], 1e-9) / 1e9} for k, v in agg.items()}
+                             "tflops": v[0] / max(v[1], 1e-9) / 1e9,
+                             "algorithmic_bytes": v[3]} for k, v in agg.items()}
         return self._agg
 
     def dominant(self):
@@ -61,14 +75,28 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
-def _timed(name, flops, fn):
+def _timed(name, flops, fn, tag=None, nbytes=0.0):
     t = KERNEL_TIMER
     if t is None:
         return fn()
     e0 = t.start()
     rc = fn()
-    t.stop(name, flops, e0)
+    t.stop(name, flops, e0, tag() if callable(tag) else tag, nbytes)
     return rc
+
+
+def _conv_bytes(d, residual=False):
+    """Algorithmic HBM bytes of one conv launch (any direction): the input volume(s), the
+    output volume (+ residual) and the weights, each touched once, fp32."""
+    vin = d.N * d.D * d.H * d.W * (d.C0 + d.C1)
+    vout = d.N * d.Do * d.Ho * d.Wo * d.Cout
+    w = d.Cout * (d.C0 + d.C1) * d.KD * d.KH * d.KW
+    return 4.0 * (vin + vout * (2 if residual else 1) + w)
+
+
+def _conv_tag(d, kind):
+    return lambda: (f"{kind} {d.C0 + d.C1}->{d.Cout} in {d.D}x{d.H}x{d.W} k{d.KD}{d.KH}{d.KW} "
+                    f"s{d.SD}{d.SH}{d.SW}")
 
 
 def _conv_flops(d):
@@ -193,11 +221,12 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
                      lambda: _lib.lib().adell_conv3d_fwd_f16x3(
                          ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed.halfs),
                          _ptr(w_packed.scale), _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
-                         _ptr(amax), _stream())))
+                         _ptr(amax), _stream()), _conv_tag(d, "fwd"),
+                     _conv_bytes(d, residual is not None)))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual),
-            _ptr(y), _ptr(part), _stream())))
+            _ptr(y), _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d, residual is not None)))
     return y, part
 
 
@@ -214,12 +243,13 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, 
         check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_bwd_data_f16x3(
                          ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs),
-                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _ptr(amax), _stream())))
+                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _ptr(amax), _stream()),
+                     _conv_tag(d, "dgrad"), _conv_bytes(d)))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_bwd_data(
                          ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd), _ptr(dx0), _ptr(dx1),
-                         _stream())))
+                         _stream()), _conv_tag(d, "dgrad"), _conv_bytes(d)))
     return dx0, dx1
 
 
@@ -256,11 +286,12 @@ def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f
     if f16x3:
         check(_timed(name, _conv_flops(d), lambda: fn(
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(x_amax),
-            _ptr(dy_amax), _ptr(ws), ws.numel() * 4, _stream())))
+            _ptr(dy_amax), _ptr(ws), ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"),
+                     _conv_bytes(d)))
     else:
         check(_timed(name, _conv_flops(d), lambda: fn(
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
-            ws.numel() * 4, _stream())))
+            ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"), _conv_bytes(d)))
     return (dw, db) if want_db else dw
 
 

@@ -54,11 +54,29 @@ def build_module(device, size):
     return net.to(device)
 
 
+def _shape(size):
+    return (size, size, size) if isinstance(size, int) else tuple(size)
+
+
 def synthetic_batch(batch, size, device, seed):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    x = torch.rand((batch, 2, size, size, size), generator=g)
-    y = (torch.rand((batch, 1, size, size, size), generator=g) > 0.9).float()
+    x = torch.rand((batch, 2, *_shape(size)), generator=g)
+    y = (torch.rand((batch, 1, *_shape(size)), generator=g) > 0.9).float()
     return {"image": x.to(device), "mask": y.to(device)}
+
+
+def pmc_traffic(kernel):
+    """Mean HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py from separate
+    ``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` runs of this script; gfx950 correction
+    2*FETCH + WRITE as MI355X_MICROARCH.md prescribes). None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"].get(kernel)
+        return None if k is None else float(k["traffic_bytes_mean"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(size, threads):
@@ -93,6 +111,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--shape", type=str, default=None,
+                    help="D,H,W of the synthetic volumes (e.g. 256,256,128); overrides --size")
     ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
@@ -109,11 +129,13 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    net = build_module(device, args.size)
+    shape = _shape(args.size) if args.shape is None else tuple(int(v) for v in args.shape.split(","))
+    shape_str = "x".join(str(v) for v in shape) if len(set(shape)) > 1 else f"{shape[0]}^3"
+    net = build_module(device, shape)
     net.train()
     opt = net.configure_optimizers()["optimizer"]
     runner = StepRunner(net, opt, GradSync(opt))
-    batch = synthetic_batch(args.batch, args.size, device, 42 + rank)
+    batch = synthetic_batch(args.batch, shape, device, 42 + rank)
 
     def barrier():
         if world > 1:
@@ -137,15 +159,15 @@ def main():
         return
     vols = args.batch * world * args.steps
     out = {
-        "metric": "volumes/sec 3D U-Net 128^3 2-ch seg (train step: fwd+loss+bwd+SGD)",
+        "metric": f"volumes/sec 3D U-Net {shape_str} 2-ch seg (train step: fwd+loss+bwd+SGD)",
         "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if HF.CONV_PRECISION == "fp32" else "f32 (f16x3 split MFMA, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{args.size}^3, "
+        "config": {"workload": f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{shape_str}, "
                                f"batch {args.batch}/GPU, dice+focal, SGD-Nesterov",
-                   "per_gpu_batch": args.batch, "size": args.size, "parallelism": f"dp{world}"},
+                   "per_gpu_batch": args.batch, "size": list(shape), "parallelism": f"dp{world}"},
         "final_loss": loss_value,
     }
     dom = timer.dominant()
@@ -156,7 +178,11 @@ def main():
         peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
         out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved,
                            "peak": peak, "unit": "TFLOP/s",
-                           "frac": achieved / peak, "traffic": None,
+                           "frac": achieved / peak, "traffic": pmc_traffic(name),
+                           "traffic_unit": "bytes per launch (mean; rocprofv3 PMC 2*FETCH_SIZE + "
+                                           "WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                           "algorithmic_bytes_per_launch":
+                               timer.summary()[name]["algorithmic_bytes"] / launches,
                            "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product"
                                           if f16 else "fp32 matrix peak"),
                            "executed_mfma_tflops": achieved * (3.0 if f16 else 1.0),
@@ -167,11 +193,11 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         threads = max(1, min(os.cpu_count() or 1, 16))
         t = cpu_baseline(args.cpu_size, threads)
-        scale = (args.cpu_size / args.size) ** 3
+        scale = args.cpu_size ** 3 / float(shape[0] * shape[1] * shape[2])
         out["cpu_baseline"] = {
             "value": scale / t, "unit": "volumes/s", "cores": threads, "kind": "port",
             "sample": f"1 training step of the stock-torch CPU oracle on one 2x{args.cpu_size}^3 "
-                      f"volume ({t:.2f} s), scaled by voxel count to {args.size}^3"}
+                      f"volume ({t:.2f} s), scaled by voxel count to {shape_str}"}
     print(json.dumps(out))
 
 
