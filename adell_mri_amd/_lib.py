@@ -101,6 +101,12 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_conv1_small_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv1_small_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
+    "adell_conv1_small_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5),
+    "adell_conv1_small_wgrad_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv1_small_bwd_weight": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6 + [ctypes.c_size_t, _vp]),
+    "adell_multi_copy": (_i, [_vp, _i, _vp, _vp]),
     "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_fwd": (_i, [_vp, _l, _i, _i, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_bwd_workspace": (_l, [_l, _i]),

@@ -1,0 +1,444 @@
+// Convolutions whose channel counts are too small for an MFMA tile (the 2-channel input
+// layers and the 1-channel logits head of the U-Nets: unet.py:245-273, 712-731):
+//
+//  * adell_wgrad_small: dW / db of a k in {1, 3} stride-1 conv with Cin <= 4 (any Cout). An
+//    MFMA tile would pad Cin to 16 per tap; here the 27*Cin products per (voxel, co) run on
+//    the vector ALU out of an LDS tile -- thread = (co, kz, ky) with Cin x K accumulators
+//    over every tile its block visits, deterministic split partials + fixed-order fold.
+//  * adell_conv1_small_fwd / _bwd_data / _bwd_weight: 1x1x1 conv with Cout <= 4 (the logits
+//    head): one pass over the activation, HBM-bound.
+//
+// Called from the conv entry points of conv3d.hip / conv_wgrad*.hip when the shapes qualify.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// small-Cin weight gradient
+// ---------------------------------------------------------------------------
+struct WgSmallArgs {
+  const float* x0;
+  const float* x1;
+  const float* dy;
+  float* part;   // [splits][coPad][4*K3 + 1]
+  int N, D, H, W, C0, C1, Cout, Do, Ho, Wo, P;
+  int tilesX, tilesY, tilesZ, coBlocks;
+  long items;
+  int itemsPerSplit;
+};
+
+template <int K>
+struct WgSmallCfg {
+  static constexpr int WT = 16;                 // outputs per x segment
+  static constexpr int HX = WT + K - 1;         // input voxels per row
+  static constexpr int HZ = 4 + K - 1, HY = 4 + K - 1;
+  static constexpr int K3 = K * K * K;
+  static constexpr int XT_FLOATS = HZ * HY * HX * 4;      // [row][x][4 ci]
+  static constexpr int DY_FLOATS = 16 * WT * 16;          // [row][x][16 co]
+  static constexpr int THREADS = ((16 * K * K + 63) / 64) * 64;
+};
+
+template <int K, int CIN>   // CIN: channel slots that carry data (2 or 4)
+__global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_wgrad_small_kernel(
+    WgSmallArgs a) {
+  using Cf = WgSmallCfg<K>;
+  constexpr int NT = Cf::THREADS;
+  __shared__ __attribute__((aligned(16))) float xt[Cf::XT_FLOATS];
+  __shared__ __attribute__((aligned(16))) float dyt[Cf::DY_FLOATS];
+  const int tid = threadIdx.x;
+  const int cb = blockIdx.x % a.coBlocks, split = blockIdx.x / a.coBlocks;
+  const int co0 = cb * 16;
+  const int co = tid & 15, kk = tid >> 4;
+  const bool active = kk < K * K;
+  const int kz = kk / K, ky = kk % K;
+  const int Cin = a.C0 + a.C1;
+  float acc[CIN][K];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc[c][q] = 0.f;
+  float sb = 0.f;
+  const long first = (long)split * a.itemsPerSplit;
+  long last = first + a.itemsPerSplit;
+  if (last > a.items) last = a.items;
+  for (long item = first; item < last; ++item) {
+    long t = item;
+    const int tx = (int)(t % a.tilesX); t /= a.tilesX;
+    const int ty = (int)(t % a.tilesY); t /= a.tilesY;
+    const int tz = (int)(t % a.tilesZ);
+    const int n = (int)(t / a.tilesZ);
+    const int z0 = tz * 4, y0 = ty * 4, x0o = tx * Cf::WT;
+    __syncthreads();
+    // input halo tile, 4 channel slots per voxel (zero beyond Cin and beyond the volume)
+    for (int i = tid; i < Cf::HZ * Cf::HY * Cf::HX; i += NT) {
+      const int j = i % Cf::HX, r = i / Cf::HX;
+      const int z = z0 - a.P + r / Cf::HY, y = y0 - a.P + r % Cf::HY, x = x0o - a.P + j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (z >= 0 && z < a.D && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+        const size_t vox = (((size_t)n * a.D + z) * a.H + y) * a.W + x;
+        float c4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < Cin; ++c)
+          c4[c] = c < a.C0 ? a.x0[vox * a.C0 + c] : a.x1[vox * a.C1 + (c - a.C0)];
+        v = f32x4{c4[0], c4[1], c4[2], c4[3]};
+      }
+      *reinterpret_cast<f32x4*>(xt + (size_t)i * 4) = v;
+    }
+    // dy tile: 16 output rows x WT voxels x 16 output channels
+    for (int i = tid; i < 16 * Cf::WT * 4; i += NT) {
+      const int q = i & 3, j = (i >> 2) % Cf::WT, r = (i >> 2) / Cf::WT;
+      const int z = z0 + (r >> 2), y = y0 + (r & 3), x = x0o + j;
+      const int c = co0 + q * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (z < a.Do && y < a.Ho && x < a.Wo && c < a.Cout) {
+        const float* p = a.dy + ((((size_t)n * a.Do + z) * a.Ho + y) * a.Wo + x) * a.Cout + c;
+        const int nv = a.Cout - c;
+        if (nv >= 4 && (a.Cout & 3) == 0) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+          if (nv > 0) v.x = p[0];
+          if (nv > 1) v.y = p[1];
+          if (nv > 2) v.z = p[2];
+          if (nv > 3) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(dyt + (r * Cf::WT + j) * 16 + q * 4) = v;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll 1
+      for (int row = 0; row < 16; ++row) {
+        const int rz = row >> 2, ry = row & 3;
+        float g[Cf::WT];
+        const float* gr = dyt + row * Cf::WT * 16 + co;
+#pragma unroll
+        for (int j = 0; j < Cf::WT; ++j) g[j] = gr[j * 16];
+        const f32x4* xr =
+            reinterpret_cast<const f32x4*>(xt) + ((rz + kz) * Cf::HY + ry + ky) * Cf::HX;
+#pragma unroll
+        for (int jj = 0; jj < Cf::HX; ++jj) {
+          const f32x4 xv = xr[jj];
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const int j = jj - kx;
+            if (j >= 0 && j < Cf::WT) {
+              acc[0][kx] = fmaf(g[j], xv.x, acc[0][kx]);
+              acc[1][kx] = fmaf(g[j], xv.y, acc[1][kx]);
+              if (CIN > 2) {
+                acc[2][kx] = fmaf(g[j], xv.z, acc[2][kx]);
+                acc[3][kx] = fmaf(g[j], xv.w, acc[3][kx]);
+              }
+            }
+          }
+        }
+        if (kk == 0) {
+#pragma unroll
+          for (int j = 0; j < Cf::WT; ++j) sb += g[j];
+        }
+      }
+    }
+  }
+  if (active) {
+    float* dst = a.part + ((size_t)split * a.coBlocks * 16 + co0 + co) * (4 * Cf::K3 + 1);
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) dst[c * Cf::K3 + (kz * K + ky) * K + kx] = acc[c][kx];
+    if (kk == 0) dst[4 * Cf::K3] = sb;
+  }
+}
+
+// dw[co][ci][tap] = sum over splits (fixed order); the last column of a partial row is db
+__global__ __launch_bounds__(256) void adell_wgrad_small_reduce_kernel(
+    const float* __restrict__ part, int splits, int coPad, int Cout, int Cin, int K3,
+    float* __restrict__ dw, float* __restrict__ db) {
+  const int rowlen = 4 * K3 + 1;
+  const long total = (long)Cout * (Cin * K3 + 1);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int co = (int)(i / (Cin * K3 + 1)), e = (int)(i % (Cin * K3 + 1));
+    const int col = e < Cin * K3 ? e : 4 * K3;   // (ci, tap) slots are laid out ci-major
+    double s = 0.0;
+    for (int sp = 0; sp < splits; ++sp) s += (double)part[((size_t)sp * coPad + co) * rowlen + col];
+    if (e < Cin * K3) dw[(size_t)co * Cin * K3 + e] = (float)s;
+    else if (db) db[co] = (float)s;
+  }
+}
+
+static bool adell_wgrad_small_ok(const adell_conv3d_desc* d) {
+  const int Cin = d->C0 + d->C1;
+  return Cin <= 4 && d->KD == d->KH && d->KH == d->KW && (d->KD == 1 || d->KD == 3) &&
+         d->SD == 1 && d->SH == 1 && d->SW == 1 && d->PD == d->PH && d->PH == d->PW;
+}
+
+static void adell_wgrad_small_plan(const adell_conv3d_desc* d, WgSmallArgs* a, int* splits) {
+  a->N = d->N; a->D = d->D; a->H = d->H; a->W = d->W; a->C0 = d->C0; a->C1 = d->C1;
+  a->Cout = d->Cout; a->Do = d->Do; a->Ho = d->Ho; a->Wo = d->Wo; a->P = d->PD;
+  a->tilesX = adell_cdiv(d->Wo, 16);
+  a->tilesY = adell_cdiv(d->Ho, 4);
+  a->tilesZ = adell_cdiv(d->Do, 4);
+  a->coBlocks = adell_cdiv(d->Cout, 16);
+  a->items = (long)d->N * a->tilesZ * a->tilesY * a->tilesX;
+  long s = adell_cdiv(1536, a->coBlocks);
+  if (s > a->items) s = a->items;
+  if (s < 1) s = 1;
+  a->itemsPerSplit = (int)((a->items + s - 1) / s);
+  *splits = (int)((a->items + a->itemsPerSplit - 1) / a->itemsPerSplit);
+}
+
+// bytes of workspace, or 0 when the shape does not take this path
+extern "C" long adell_wgrad_small_workspace(const adell_conv3d_desc* d) {
+  if (!d || !adell_wgrad_small_ok(d)) return 0;
+  WgSmallArgs a;
+  int splits;
+  adell_wgrad_small_plan(d, &a, &splits);
+  const int K3 = d->KD * d->KH * d->KW;
+  return (long)sizeof(float) * splits * a.coBlocks * 16 * (4 * K3 + 1);
+}
+
+extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                                 const float* dy, float* dw, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(d && x0 && dy && dw && workspace, "wgrad_small: null pointer");
+  ADELL_REQUIRE(adell_wgrad_small_ok(d), "wgrad_small: shape not supported");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_wgrad_small_workspace(d),
+                "wgrad_small: workspace too small");
+  WgSmallArgs a;
+  int splits;
+  adell_wgrad_small_plan(d, &a, &splits);
+  a.x0 = x0; a.x1 = x1; a.dy = dy; a.part = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)(splits * a.coBlocks);
+  const bool two = d->C0 + d->C1 <= 2;
+  if (d->KD == 3 && two)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<3, 2>), dim3(grid), dim3(WgSmallCfg<3>::THREADS),
+                       0, st, a);
+  else if (d->KD == 3)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<3, 4>), dim3(grid), dim3(WgSmallCfg<3>::THREADS),
+                       0, st, a);
+  else if (two)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<1, 2>), dim3(grid), dim3(WgSmallCfg<1>::THREADS),
+                       0, st, a);
+  else
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<1, 4>), dim3(grid), dim3(WgSmallCfg<1>::THREADS),
+                       0, st, a);
+  const int K3 = d->KD * d->KH * d->KW, Cin = d->C0 + d->C1;
+  long blocks = ((long)d->Cout * (Cin * K3 + 1) + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(adell_wgrad_small_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                     (const float*)workspace, splits, a.coBlocks * 16, d->Cout, Cin, K3, dw, db);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// 1x1x1 convolution with Cout <= 4 (logits head): y[v][o] = sum_c x[v][c] w[o][c] + b[o]
+// ---------------------------------------------------------------------------
+#define ADELL_C1_MAXO 4
+struct Conv1Args {
+  const float* x0;
+  const float* x1;
+  const float* w;     // [Cout][Cin]
+  const float* bias;
+  const float* dy;
+  float* y;
+  float* dx0;
+  float* dx1;
+  float* part;        // bwd_weight partials [blocks][Cout][Cin + 1]
+  long V;
+  int C0, C1, Cout;
+};
+
+// LPR lanes per voxel, each holding CE = ceil(Cin / LPR) <= 8 channels (like layernorm_rows)
+__global__ __launch_bounds__(256) void adell_conv1_small_fwd_kernel(Conv1Args a, int lpr) {
+  const int Cin = a.C0 + a.C1;
+  const int gl = threadIdx.x % lpr, grp = threadIdx.x / lpr, ngrp = 256 / lpr;
+  float wr[ADELL_C1_MAXO][8];
+#pragma unroll
+  for (int o = 0; o < ADELL_C1_MAXO; ++o)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = gl * 8 + e;   // a lane owns 8 consecutive channels
+      wr[o][e] = (o < a.Cout && c < Cin) ? a.w[o * Cin + c] : 0.f;
+    }
+  for (long vb = (long)blockIdx.x * ngrp; vb < a.V; vb += (long)gridDim.x * ngrp) {
+    const long v = vb + grp;
+    const bool live = v < a.V;
+    float s[ADELL_C1_MAXO] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = gl * 8 + e;
+      float xv = 0.f;
+      if (live && c < Cin) xv = c < a.C0 ? a.x0[v * a.C0 + c] : a.x1[v * a.C1 + (c - a.C0)];
+#pragma unroll
+      for (int o = 0; o < ADELL_C1_MAXO; ++o) s[o] = fmaf(xv, wr[o][e], s[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < ADELL_C1_MAXO; ++o)
+      for (int m = lpr >> 1; m > 0; m >>= 1) s[o] += __shfl_xor(s[o], m, 64);
+    if (live && gl == 0)
+      for (int o = 0; o < a.Cout; ++o) a.y[v * a.Cout + o] = s[o] + (a.bias ? a.bias[o] : 0.f);
+  }
+}
+
+// dx[v][c] = sum_o dy[v][o] w[o][c]
+__global__ __launch_bounds__(256) void adell_conv1_small_bwd_data_kernel(Conv1Args a) {
+  const int Cin = a.C0 + a.C1;
+  const long total = a.V * Cin;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const long v = i / Cin;
+    const int c = (int)(i - v * Cin);
+    float s = 0.f;
+    for (int o = 0; o < a.Cout; ++o) s = fmaf(a.dy[v * a.Cout + o], a.w[o * Cin + c], s);
+    if (c < a.C0) a.dx0[v * a.C0 + c] = s;
+    else a.dx1[v * a.C1 + (c - a.C0)] = s;
+  }
+}
+
+// partial dW[o][c] = sum_v dy[v][o] x[v][c], db[o] = sum_v dy[v][o] over the block's voxels.
+// block = CL channel lanes (power of two >= min(Cin + 1, 64)) x 256 / CL voxel lanes, the
+// voxel loop unrolled by 4 with independent loads (channel groups of CL loop).
+__global__ __launch_bounds__(256) void adell_conv1_small_wgrad_kernel(Conv1Args a, int chunk,
+                                                                      int CL) {
+  __shared__ float sh[256];
+  const int Cin = a.C0 + a.C1;
+  const int VL = 256 / CL;
+  const int cl = threadIdx.x % CL, vl = threadIdx.x / CL;
+  const long v0 = (long)blockIdx.x * chunk;
+  long v1 = v0 + chunk;
+  if (v1 > a.V) v1 = a.V;
+  float* prow = a.part + (size_t)blockIdx.x * a.Cout * (Cin + 1);
+  for (int cb = 0; cb < Cin + 1; cb += CL) {
+    const int c = cb + cl;   // c == Cin: the bias column (x := 1)
+    float s[ADELL_C1_MAXO] = {0.f, 0.f, 0.f, 0.f};
+    if (c <= Cin) {
+      long v = v0 + vl;
+      for (; v + 3L * VL < v1; v += 4L * VL) {
+        float xv[4], g[4][ADELL_C1_MAXO];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long vv = v + (long)u * VL;
+          xv[u] = 1.f;
+          if (c < Cin) xv[u] = c < a.C0 ? a.x0[vv * a.C0 + c] : a.x1[vv * a.C1 + (c - a.C0)];
+#pragma unroll
+          for (int o = 0; o < ADELL_C1_MAXO; ++o) g[u][o] = o < a.Cout ? a.dy[vv * a.Cout + o] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int o = 0; o < ADELL_C1_MAXO; ++o) s[o] = fmaf(g[u][o], xv[u], s[o]);
+      }
+      for (; v < v1; v += VL) {
+        float xv = 1.f;
+        if (c < Cin) xv = c < a.C0 ? a.x0[v * a.C0 + c] : a.x1[v * a.C1 + (c - a.C0)];
+#pragma unroll
+        for (int o = 0; o < ADELL_C1_MAXO; ++o)
+          if (o < a.Cout) s[o] = fmaf(a.dy[v * a.Cout + o], xv, s[o]);
+      }
+    }
+    for (int o = 0; o < a.Cout; ++o) {
+      sh[threadIdx.x] = s[o];
+      __syncthreads();
+      if (vl == 0 && c <= Cin) {
+        float t = 0.f;
+        for (int k = 0; k < VL; ++k) t += sh[k * CL + cl];
+        prow[o * (Cin + 1) + c] = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_conv1_small_wgrad_fold_kernel(
+    const float* __restrict__ part, int nb, int Cout, int Cin, float* __restrict__ dw,
+    float* __restrict__ db) {
+  __shared__ double sh[4][64];
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const int n = Cout * (Cin + 1);
+  const int e = blockIdx.x * 64 + cl;
+  double s = 0.0;
+  if (e < n)
+    for (int b = vl; b < nb; b += 4) s += (double)part[(size_t)b * n + e];
+  sh[vl][cl] = s;
+  __syncthreads();
+  if (vl != 0 || e >= n) return;
+  s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  const int o = e / (Cin + 1), c = e % (Cin + 1);
+  if (c < Cin) dw[o * Cin + c] = (float)s;
+  else if (db) db[o] = (float)s;
+}
+
+static bool adell_conv1_small_ok(const adell_conv3d_desc* d) {
+  return d->KD == 1 && d->KH == 1 && d->KW == 1 && d->SD == 1 && d->SH == 1 && d->SW == 1 &&
+         d->PD == 0 && d->PH == 0 && d->PW == 0 && d->Cout <= ADELL_C1_MAXO &&
+         d->C0 + d->C1 <= 512;
+}
+
+static int adell_conv1_chunk(long V) {
+  long nb = 2048;
+  long chunk = (V + nb - 1) / nb;
+  if (chunk < 64) chunk = 64;
+  return (int)((chunk + 3) / 4 * 4);
+}
+
+extern "C" int adell_conv1_small_applicable(const adell_conv3d_desc* d) {
+  return d && adell_conv1_small_ok(d) ? 1 : 0;
+}
+
+extern "C" long adell_conv1_small_wgrad_workspace(const adell_conv3d_desc* d) {
+  if (!d || !adell_conv1_small_ok(d)) return 0;
+  const long V = (long)d->N * d->D * d->H * d->W;
+  const int chunk = adell_conv1_chunk(V);
+  return (long)sizeof(float) * ((V + chunk - 1) / chunk) * d->Cout * (d->C0 + d->C1 + 1);
+}
+
+extern "C" int adell_conv1_small_fwd(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                                     const float* w, const float* bias, float* y, void* stream) {
+  ADELL_REQUIRE(d && x0 && w && y && adell_conv1_small_ok(d), "conv1_small_fwd: bad arguments");
+  Conv1Args a = {};
+  a.x0 = x0; a.x1 = x1; a.w = w; a.bias = bias; a.y = y;
+  a.V = (long)d->N * d->D * d->H * d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout;
+  const int Cin = d->C0 + d->C1;
+  int lpr = 1;
+  while (lpr < 64 && (Cin + lpr - 1) / lpr > 8) lpr <<= 1;
+  const int ngrp = 256 / lpr;
+  long blocks = (a.V + ngrp - 1) / ngrp;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adell_conv1_small_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a, lpr);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv1_small_bwd_data(const adell_conv3d_desc* d, const float* dy,
+                                          const float* w, float* dx0, float* dx1, void* stream) {
+  ADELL_REQUIRE(d && dy && w && dx0 && adell_conv1_small_ok(d), "conv1_small_bwd_data: bad arguments");
+  Conv1Args a = {};
+  a.dy = dy; a.w = w; a.dx0 = dx0; a.dx1 = dx1;
+  a.V = (long)d->N * d->D * d->H * d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout;
+  long blocks = (a.V * (d->C0 + d->C1) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(adell_conv1_small_bwd_data_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const float* x0,
+                                            const float* x1, const float* dy, float* dw, float* db,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(d && x0 && dy && dw && workspace && adell_conv1_small_ok(d),
+                "conv1_small_bwd_weight: bad arguments");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_conv1_small_wgrad_workspace(d),
+                "conv1_small_bwd_weight: workspace too small");
+  Conv1Args a = {};
+  a.x0 = x0; a.x1 = x1; a.dy = dy; a.part = (float*)workspace;
+  a.V = (long)d->N * d->D * d->H * d->W; a.C0 = d->C0; a.C1 = d->C1; a.Cout = d->Cout;
+  const int chunk = adell_conv1_chunk(a.V);
+  const int nb = (int)((a.V + chunk - 1) / chunk);
+  hipStream_t st = (hipStream_t)stream;
+  int CL = 4;
+  while (CL < 64 && CL < d->C0 + d->C1 + 1) CL <<= 1;
+  hipLaunchKernelGGL(adell_conv1_small_wgrad_kernel, dim3(nb), dim3(256), 0, st, a, chunk, CL);
+  const int n = d->Cout * (d->C0 + d->C1 + 1);
+  hipLaunchKernelGGL(adell_conv1_small_wgrad_fold_kernel, dim3(adell_cdiv(n, 64)), dim3(256), 0, st,
+                     (const float*)workspace, nb, d->Cout, d->C0 + d->C1, dw, db);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

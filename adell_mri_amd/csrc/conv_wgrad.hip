@@ -416,8 +416,15 @@ static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const fl
   return ADELL_OK;
 }
 
+// small-channel paths (conv_small.hip)
+extern "C" long adell_wgrad_small_workspace(const adell_conv3d_desc* d);
+extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                                 const float* dy, float* dw, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 extern "C" long adell_conv3d_bwd_weight_workspace(const adell_conv3d_desc* d) {
   if (!d) return ADELL_E_BADARG;
+  if (adell_wgrad_small_workspace(d) > 0) return adell_wgrad_small_workspace(d);
   WgradPlan p;
   const int Cin = d->C0 + d->C1;
   if (adell_wgrad_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->Do,
@@ -432,6 +439,8 @@ extern "C" int adell_conv3d_bwd_weight(const adell_conv3d_desc* d, const float* 
                                        size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight: C1 > 0 needs x1");
+  if (adell_wgrad_small_workspace(d) > 0)
+    return adell_wgrad_small(d, x0, x1, dy, dw, db, workspace, workspace_bytes, stream);
   return adell_wgrad_core(d->N, d->D, d->H, d->W, d->C0, d->C1, x0, x1, d->Cout, d->Do,
                           d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
                           d->PH, d->PW, dw, db, workspace, workspace_bytes, (hipStream_t)stream);

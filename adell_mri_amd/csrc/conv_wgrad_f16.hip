@@ -395,8 +395,15 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   return adell_wgrad_reduce_launch(slabs, out, p.R, ntap, Cin, Cout, a.wsdb, db, st);
 }
 
+// small-channel paths (conv_small.hip)
+extern "C" long adell_wgrad_small_workspace(const adell_conv3d_desc* d);
+extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                                 const float* dy, float* dw, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 extern "C" long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc* d) {
   if (!d) return ADELL_E_BADARG;
+  if (adell_wgrad_small_workspace(d) > 0) return adell_wgrad_small_workspace(d);
   WgradF16Plan p;
   const int Cin = d->C0 + d->C1;
   if (adell_wgrad_f16_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SH, d->SW, d->Do, d->Ho,
@@ -412,6 +419,8 @@ extern "C" int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const f
                                              size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight_f16x3: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight_f16x3: C1 > 0 needs x1");
+  if (adell_wgrad_small_workspace(d) > 0)  // Cin <= 4: vector-ALU kernel, exact fp32
+    return adell_wgrad_small(d, x0, x1, dy, dw, db, workspace, workspace_bytes, stream);
   return adell_wgrad_f16_core(d->N, d->D, d->H, d->W, d->C0, d->C1, x0, x1, d->Cout, d->Do,
                               d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
                               d->PH, d->PW, dw, db, x_absmax, dy_absmax, workspace, workspace_bytes,

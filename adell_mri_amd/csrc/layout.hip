@@ -52,6 +52,34 @@ extern "C" int adell_copy_channels(float* full, float* part, long V, int Cfull, 
   return ADELL_OK;
 }
 
+// dst[off_r + i] = src_r[i] for every row r of a device-resident table of (source pointer,
+// destination offset, element count) triples; one block per row (rows are <= 16384 elements).
+// Gathers the per-parameter gradient tensors autograd produced into the flat gradient buffer
+// the fused optimiser and the gradient all-reduce work on.
+__global__ __launch_bounds__(256) void adell_multi_copy_kernel(const long* __restrict__ table,
+                                                               float* __restrict__ dst) {
+  const long* row = table + (size_t)blockIdx.x * 3;
+  const float* src = reinterpret_cast<const float*>(row[0]);
+  float* d = dst + row[1];
+  const long n = row[2];
+  if (((((uintptr_t)src) | ((uintptr_t)d)) & 15) == 0) {
+    const long n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256)
+      reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) d[i] = src[i];
+  } else {
+    for (long i = threadIdx.x; i < n; i += 256) d[i] = src[i];
+  }
+}
+
+extern "C" int adell_multi_copy(const long* table, int rows, float* dst, void* stream) {
+  ADELL_REQUIRE(table && dst && rows > 0, "multi_copy: bad arguments");
+  hipLaunchKernelGGL(adell_multi_copy_kernel, dim3((unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, table, dst);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
 struct ResampleArgs {
   const float* in;
   float* out;

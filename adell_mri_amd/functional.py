@@ -70,6 +70,14 @@ class _Conv3dFn(torch.autograd.Function):
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         stride, padding, want_stats, wref = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
+        ctx.small1 = wp is None
+        if ctx.small1:  # logits head: 1x1x1, Cout <= 4 -- one HBM-bound pass on canonical weights
+            y = ops.conv1_small_fwd(x0, x1, weight, bias)
+            ctx.save_for_backward(x0, x1, weight)
+            ctx.conf = (k, stride, padding, bias is not None, False, wref)
+            part = y.new_empty(0)
+            ctx.mark_non_differentiable(part)
+            return y, part
         # [0]: absmax bits of the input(s), [1]: of dy -- by-products of the f16x3 forward /
         # backward-data kernels that the backward-weight kernel uses as operand scales
         amax = None
@@ -95,6 +103,15 @@ class _Conv3dFn(torch.autograd.Function):
         dx0 = dx1 = dw = db = dres = None
         C0 = x0.shape[1]
         C1 = 0 if x1 is None else x1.shape[1]
+        if ctx.small1:
+            if need[0] or (x1 is not None and need[1]):
+                dx0, dx1 = ops.conv1_small_bwd_data(dy, weight, tuple(x0.shape[2:]), C0, C1)
+                dx0 = dx0 if need[0] else None
+                dx1 = dx1 if (x1 is not None and need[1]) else None
+            if need[2] or (has_bias and need[3]):
+                dw, db = ops.conv1_small_bwd_weight(x0, x1, dy, has_bias and need[3])
+                dw = dw.view(weight.shape) if need[2] else None
+            return dx0, dx1, dw, db, None, None, None
         amax = ctx.amax
         dy_amax = None
         if need[0] or (x1 is not None and need[1]):
@@ -127,7 +144,10 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual)."""
     stride, padding = ops._triple(stride), ops._triple(padding)
     conf = (stride, padding, want_stats, _Ref(weight))
-    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual, _packed(weight, 0), conf)
+    Cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
+    small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
+    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual,
+                              None if small1 else _packed(weight, 0), conf)
     if want_stats and part.numel() > 0:
         y._adell_partials = part
     return y

@@ -20,9 +20,10 @@ class KernelTimer:
     are enqueued on; nothing synchronises until ``summary()`` is read.
     """
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []
         self._agg = None
+        self.only = None if only is None else set(only)  # kernel families to time (None: all)
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -77,7 +78,7 @@ KERNEL_TIMER = None
 
 def _timed(name, flops, fn, tag=None, nbytes=0.0):
     t = KERNEL_TIMER
-    if t is None:
+    if t is None or (t.only is not None and name not in t.only):
         return fn()
     e0 = t.start()
     rc = fn()
@@ -228,6 +229,69 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual),
             _ptr(y), _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d, residual is not None)))
     return y, part
+
+
+# ---- 1x1x1 convolution with Cout <= 4 (logits head): canonical weights, one pass each way ----
+def conv1_small_ok(weight, Cin, stride, padding, residual):
+    return (residual is None and weight.dim() == 5 and tuple(weight.shape[2:]) == (1, 1, 1)
+            and weight.shape[0] <= 4 and Cin <= 512 and tuple(stride) == (1, 1, 1)
+            and tuple(padding) == (0, 0, 0))
+
+
+def _conv1_desc(N, size, C0, C1, Cout):
+    return make_conv_desc(N, tuple(size), C0, C1, Cout, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+
+
+def conv1_small_fwd(x0, x1, weight, bias):
+    _require_cuda(x0, x1, weight, bias)
+    x0 = ndhwc(x0)
+    N, C0, D, H, W = x0.shape
+    C1 = 0
+    if x1 is not None:
+        x1 = ndhwc(x1)
+        C1 = x1.shape[1]
+    Cout = weight.shape[0]
+    d = _conv1_desc(N, (D, H, W), C0, C1, Cout)
+    y = new_act(N, Cout, D, H, W, x0.device)
+    check(_timed("adell_conv1_small_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv1_small_fwd(ctypes.byref(d), _ptr(x0), _ptr(x1),
+                                                          _ptr(weight.contiguous()), _ptr(bias),
+                                                          _ptr(y), _stream()),
+                 _conv_tag(d, "fwd"), _conv_bytes(d)))
+    return y
+
+
+def conv1_small_bwd_data(dy, weight, in_size, C0, C1):
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    d = _conv1_desc(N, in_size, C0, C1, Cout)
+    dx0 = new_act(N, C0, *in_size, dy.device)
+    dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
+    check(_timed("adell_conv1_small_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv1_small_bwd_data(ctypes.byref(d), _ptr(dy),
+                                                               _ptr(weight.contiguous()),
+                                                               _ptr(dx0), _ptr(dx1), _stream()),
+                 _conv_tag(d, "dgrad"), _conv_bytes(d)))
+    return dx0, dx1
+
+
+def conv1_small_bwd_weight(x0, x1, dy, want_db):
+    x0, dy = ndhwc(x0), ndhwc(dy)
+    N, C0, D, H, W = x0.shape
+    C1 = 0
+    if x1 is not None:
+        x1 = ndhwc(x1)
+        C1 = x1.shape[1]
+    Cout = dy.shape[1]
+    d = _conv1_desc(N, (D, H, W), C0, C1, Cout)
+    ws = _workspace(_lib.lib().adell_conv1_small_wgrad_workspace(ctypes.byref(d)), x0.device)
+    dw = torch.empty((Cout, C0 + C1, 1, 1, 1), device=x0.device, dtype=torch.float32)
+    db = torch.empty((Cout,), device=x0.device, dtype=torch.float32) if want_db else None
+    check(_timed("adell_conv1_small_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv1_small_bwd_weight(
+                     ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+                     ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"), _conv_bytes(d)))
+    return dw, db
 
 
 def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, amax=None):
@@ -683,6 +747,14 @@ def dwconv3d_bwd_weight(x, dy, kshape, want_db):
     check(_lib.lib().adell_dwconv3d_bwd_weight(N, C, D, H, W, kd, kh, kw, _ptr(x), _ptr(dy),
                                                _ptr(dw), _ptr(db), _ptr(ws), _stream()))
     return dw, db
+
+
+def multi_copy(table, rows, dst):
+    """table: int64 device tensor [rows, 3] of (src pointer, dst offset, numel <= 16384)."""
+    _require_cuda(dst)
+    if not table.is_cuda or table.dtype != torch.int64:
+        raise _lib.AdellHipError("multi_copy: the table must be an int64 CUDA tensor")
+    check(_lib.lib().adell_multi_copy(_ptr(table), int(rows), _ptr(dst), _stream()))
 
 
 # ---- shifted-window (SWIN) token path -----------------------------------------------------

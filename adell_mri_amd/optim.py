@@ -38,10 +38,57 @@ class FlatParameters:
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
-    def zero_grad(self):
+    CHUNK = 16384
+
+    def zero_grad(self, set_to_none=True):
+        """Zero the flat gradient. ``set_to_none`` (torch's default) also detaches the
+        parameters from it: autograd then hands each parameter its freshly computed gradient
+        tensor (no per-parameter accumulate kernels) and ``collect()`` gathers them into the
+        flat buffer with one launch. Otherwise ``p.grad`` stays a view of the flat buffer."""
         self.grad.zero_()
-        for p, o in zip(self.params, self.offsets):  # re-attach if a caller set them to None
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+        for p, o in zip(self.params, self.offsets):
+            p.grad = None if set_to_none else self.grad[o:o + p.numel()].view(p.shape)
+
+    def _upload_and_copy(self, rows):
+        """Stage the (pointer, offset, count) table through a small ring of pinned host buffers
+        (asynchronous upload, no host synchronisation unless the ring wraps onto a copy that is
+        still in flight) and launch the multi-copy."""
+        n = len(rows)
+        ring = getattr(self, "_ring", None)
+        if ring is None or ring[0][0].shape[0] < n:
+            cap = max(2 * n, 1024)
+            ring = [(torch.empty((cap, 3), dtype=torch.int64).pin_memory(),
+                     torch.empty((cap, 3), dtype=torch.int64, device=self.grad.device),
+                     torch.cuda.Event()) for _ in range(4)]
+            self._ring, self._ring_pos = ring, 0
+        host, dev, ev = ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(ring)
+        ev.synchronize()
+        host[:n] = torch.tensor(rows, dtype=torch.int64)
+        dev[:n].copy_(host[:n], non_blocking=True)
+        ev.record()
+        ops.multi_copy(dev, n, self.grad)
+
+    def collect(self):
+        """Copy every parameter gradient that is not already a view of the flat buffer into its
+        slot (one multi-copy launch), then point ``p.grad`` at the slots."""
+        base = self.grad.data_ptr()
+        rows, keep = [], []
+        for p, o in zip(self.params, self.offsets):
+            g = p.grad
+            if g is None or g.data_ptr() == base + 4 * o:
+                continue
+            if g.dtype != torch.float32 or g.device != self.grad.device:
+                raise ValueError("FlatParameters.collect: gradients must be fp32 on the GPU")
+            g = g.contiguous()
+            keep.append(g)
+            ptr, n = g.data_ptr(), g.numel()
+            for s in range(0, n, self.CHUNK):
+                rows.append((ptr + 4 * s, o + s, min(self.CHUNK, n - s)))
+        if rows:
+            self._upload_and_copy(rows)
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is not None:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
 
 
@@ -59,9 +106,14 @@ class _FusedBase(torch.optim.Optimizer):
     def flat_groups(self):
         return [self._flat(g) for g in self.param_groups]
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = True):
         for g in self.param_groups:
-            self._flat(g).zero_grad()
+            self._flat(g).zero_grad(set_to_none)
+
+    def collect_grads(self):
+        """Gather the parameters' gradients into the flat buffers (idempotent)."""
+        for g in self.param_groups:
+            self._flat(g).collect()
 
 
 class FusedSGD(_FusedBase):
@@ -77,6 +129,7 @@ class FusedSGD(_FusedBase):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        self.collect_grads()
         for gi, g in enumerate(self.param_groups):
             flat = self._flat(g)
             st = self.state.setdefault(f"flat{gi}", {})
@@ -98,6 +151,7 @@ class FusedAdamW(_FusedBase):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        self.collect_grads()
         for gi, g in enumerate(self.param_groups):
             flat = self._flat(g)
             st = self.state.setdefault(f"flat{gi}", {})

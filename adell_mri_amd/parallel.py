@@ -88,6 +88,9 @@ class GradSync:
         ops._weights_changed()
 
     def all_reduce(self):
+        collect = getattr(self.optimizer, "collect_grads", None)
+        if collect is not None:
+            collect()
         all_reduce_flat([f.grad for f in self.optimizer.flat_groups], self.chunk, self.async_op)
 
 

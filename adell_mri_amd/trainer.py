@@ -2,7 +2,12 @@
 the part of ``lightning.Trainer.fit`` the reference's training step relies on
 (adell_mri/entrypoints/segmentation/train.py:799-819): zero_grad ->
 training_step -> backward -> gradient exchange -> optimizer.step."""
+import os
+
 from .parallel import GradSync
+
+# ADELL_GRAD_COLLECT=0: keep p.grad as views of the flat buffer (autograd accumulates into them)
+_SET_TO_NONE = os.environ.get("ADELL_GRAD_COLLECT", "1") != "0"
 
 
 class StepRunner:
@@ -16,7 +21,7 @@ class StepRunner:
         self.step_idx = 0
 
     def train_step(self, batch):
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=_SET_TO_NONE)
         loss = self.module.training_step(batch, self.step_idx)
         loss.backward()
         self.sync.all_reduce()

@@ -142,10 +142,16 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # warm-up (untimed): every MFMA kernel family is event-timed to find the dominant one; the
+    # timed region then carries events for that family only (fewer markers in the stream)
+    ops.KERNEL_TIMER = ops.KernelTimer()
     for _ in range(args.warmup):
         runner.train_step(batch)
     barrier()
-    ops.KERNEL_TIMER = ops.KernelTimer()
+    warm, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    dom_warm = warm.dominant() if args.warmup > 0 else None
+    warm_summary = warm.summary() if args.warmup > 0 else {}
+    ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = runner.train_step(batch)
@@ -189,7 +195,7 @@ def main():
                            "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                            "launches": launches, "avg_launch_ms": ms / launches,
                            "kernel_time_share": timer.share(name, 1e3 * dt),
-                           "all_kernels": timer.summary()}
+                           "all_kernels_warmup": warm_summary}
     if world == 1 and not args.no_cpu_baseline:
         threads = max(1, min(os.cpu_count() or 1, 16))
         t = cpu_baseline(args.cpu_size, threads)

@@ -335,6 +335,24 @@ int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, float min_v
                      const float* scratch, const float* g3, float* dx1, float* dx2,
                      void* stream);
 
+/* 1x1x1 convolution with Cout <= 4 (the logits head, unet.py:712-731) on canonical weights
+ * w [Cout][C0+C1]: one HBM-bound pass each way. `applicable` tells whether a descriptor takes
+ * this path (k = 1, stride 1, no padding, Cout <= 4, Cin <= 512). */
+int adell_conv1_small_applicable(const adell_conv3d_desc* d);
+int adell_conv1_small_fwd(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                          const float* w, const float* bias, float* y, void* stream);
+int adell_conv1_small_bwd_data(const adell_conv3d_desc* d, const float* dy, const float* w,
+                               float* dx0, float* dx1, void* stream);
+long adell_conv1_small_wgrad_workspace(const adell_conv3d_desc* d);
+int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                                 const float* dy, float* dw, float* db, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
+/* dst[off_r + i] = src_r[i] for rows r of a DEVICE table of `rows` triples (source pointer,
+ * destination offset in elements, element count <= 16384 per row): gathers the parameter
+ * gradients autograd produced into the flat gradient buffer of the fused optimisers. */
+int adell_multi_copy(const long* table, int rows, float* dst, void* stream);
+
 /* ---- shifted-window (SWIN) token path: vit.py:33-45,95-129,1005-1256; linear_blocks.py:358-417 */
 /* out (contiguous over sizes[0..nd)) = gather of `in`: out dim d adds coord*mult[d] to input
  * axis axis[d]; input axis a has extent / stride (elements) / cyclic shift:

@@ -240,3 +240,59 @@ def test_dropout_mask_statistics_and_determinism(cuda):
 def test_cpu_tensor_is_refused():
     with pytest.raises(_lib.AdellHipError):
         ops.norm_act_fwd(torch.zeros(1, 4, 2, 2, 2), None, None, "relu")
+
+
+# ---- small-channel paths (csrc/conv_small.hip) ---------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C0,C1,size,Cout,k,p", [
+    (1, 2, 0, (20, 18, 33), 32, 3, 1), (2, 2, 0, (9, 7, 5), 2, 3, 1), (1, 1, 2, (8, 8, 17), 5, 3, 1),
+    (1, 4, 0, (6, 6, 6), 19, 3, 1), (1, 3, 0, (7, 5, 9), 8, 1, 0), (1, 2, 0, (8, 8, 8), 16, 3, 0)])
+@pytest.mark.parametrize("prec", ["f16x3", "fp32"])
+def test_small_cin_weight_gradient(cuda, prec, N, C0, C1, size, Cout, k, p):
+    """Cin <= 4: the vector-ALU weight-gradient kernel behind both conv_bwd_weight entries."""
+    rng = np.random.default_rng(C0 * 7 + Cout)
+    Cin = C0 + C1
+    x = rng.standard_normal((N, Cin, *size)).astype(np.float32)
+    w = rng.standard_normal((Cout, Cin, k, k, k)).astype(np.float32)
+    osz = [s + 2 * p - k + 1 for s in size]
+    dy = rng.standard_normal((N, Cout, *osz)).astype(np.float32)
+    _, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, 1, p)
+    xd = torch.from_numpy(x).to(cuda)
+    x0 = ops.ndhwc(xd[:, :C0].contiguous())
+    x1 = ops.ndhwc(xd[:, C0:].contiguous()) if C1 else None
+    dw, db = ops.conv3d_bwd_weight(x0, ops.ndhwc(torch.from_numpy(dy).to(cuda)), k, 1, p, x1=x1,
+                                   want_db=True, f16x3=(prec == "f16x3"))
+    assert np.abs(dw.cpu().numpy().reshape(dw_ref.shape) - dw_ref).max() < 2e-5 * np.abs(dw_ref).max()
+    assert np.abs(db.cpu().numpy() - db_ref).max() < 2e-5 * np.abs(db_ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C0,C1,size,Cout", [(1, 32, 0, (16, 16, 16), 1), (2, 8, 8, (5, 6, 7), 3),
+                                               (1, 70, 0, (4, 4, 9), 4), (1, 3, 0, (8, 8, 8), 2)])
+def test_conv1_small_head_fwd_bwd(cuda, N, C0, C1, size, Cout):
+    """1x1x1 conv with Cout <= 4 (logits head) through HF.conv3d: forward, dX, dW, db."""
+    from adell_mri_amd import functional as HF
+
+    rng = np.random.default_rng(C0 + Cout)
+    Cin = C0 + C1
+    x = rng.standard_normal((N, Cin, *size)).astype(np.float32)
+    w = rng.standard_normal((Cout, Cin, 1, 1, 1)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = cops.conv3d(x, w, b, 1, 0)
+    dy = rng.standard_normal(ref.shape).astype(np.float32)
+    dx_ref, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, 1, 0)
+    xd = torch.from_numpy(x).to(cuda)
+    x0 = ops.ndhwc(xd[:, :C0].contiguous()).requires_grad_(True)
+    x1 = ops.ndhwc(xd[:, C0:].contiguous()).requires_grad_(True) if C1 else None
+    wd = torch.from_numpy(w).to(cuda).requires_grad_(True)
+    bd = torch.from_numpy(b).to(cuda).requires_grad_(True)
+    y = HF.conv3d(x0, wd, bd, 1, 0, x1=x1)
+    assert not hasattr(y, "_adell_partials")
+    y.backward(ops.ndhwc(torch.from_numpy(dy).to(cuda)))
+    rel = lambda a, r: float(np.abs(a - r).max() / (np.abs(r).max() + 1e-30))  # noqa: E731
+    assert rel(y.detach().cpu().numpy(), ref) < 1e-5
+    dx = x0.grad.cpu().numpy() if x1 is None else np.concatenate(
+        [x0.grad.cpu().numpy(), x1.grad.cpu().numpy()], 1)
+    assert rel(dx, dx_ref) < 1e-5
+    assert rel(wd.grad.cpu().numpy(), dw_ref) < 2e-5
+    assert rel(bd.grad.cpu().numpy(), db_ref) < 2e-5

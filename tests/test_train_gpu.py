@@ -67,10 +67,13 @@ def test_fused_sgd_matches_oracle_and_torch(cuda):
     ref_b = [np.zeros_like(r) for r in ref_p]
     opt = FusedSGD(ps, lr=5e-4, momentum=0.99, weight_decay=5e-3, nesterov=True)
     for step in range(3):
-        opt.zero_grad()
+        opt.zero_grad(set_to_none=(step % 2 == 0))   # both conventions
         grads = [rng.standard_normal(s).astype(np.float32) for s in shapes]
         for p, g in zip(ps, grads):
-            p.grad.copy_(torch.from_numpy(g))
+            if p.grad is None:
+                p.grad = torch.from_numpy(g).to(cuda)
+            else:
+                p.grad.copy_(torch.from_numpy(g))
         opt.step()
         for r, g, b in zip(ref_p, grads, ref_b):
             cops.sgd_nesterov(r, g, b, 5e-4, 0.99, 5e-3, True, first=(step == 0))
@@ -88,7 +91,7 @@ def test_fused_adamw_matches_torch(cuda):
     for _ in range(4):
         g = rng.standard_normal(w0.shape).astype(np.float32)
         oa.zero_grad()
-        a.grad.copy_(torch.from_numpy(g))
+        a.grad = torch.from_numpy(g).to(cuda)
         b.grad = torch.from_numpy(g.copy())
         oa.step()
         ob.step()
