@@ -51,6 +51,7 @@ struct WgradF16Args {
   int TCI, TCO, nci, nco;
   int R;
   int vecx, vecy;
+  int ksplit;         // 1: a wave owns every tap of its sub-tile and a share of the k-steps
 };
 
 __device__ __forceinline__ int adell_scale_exp(unsigned maxbits) {
@@ -76,7 +77,8 @@ __device__ __forceinline__ void adell_split4_store(char* hi_plane, char* lo_plan
   *reinterpret_cast<half4*>(lo_plane + off) = l;
 }
 
-template <int MAXJ>
+// PFX / PFY: 16-byte loads per thread of the register-prefetch pipeline (0: stage in place)
+template <int MAXJ, int PFX, int PFY>
 __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Args a) {
   extern __shared__ float smem[];
   const int TY = 1 << a.lTY;
@@ -100,7 +102,17 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
   const int nsub = sci * sco;
   const int sub = wave % nsub;
   const int cis = sub % sci, cos = sub / sci;
-  const int tstride = 4 / nsub, tfirst = wave / nsub;
+  // Work split inside a block. Default: the 4 / nsub waves of a sub-tile share the taps. With
+  // ksplit (fewer than 4 sub-tiles, e.g. 32 x 32 channels) they share the k-steps instead:
+  // every wave then amortises its dY fragment over all taps of the group and no wave idles on
+  // a ragged tap count; the waves' accumulators are folded through LDS after the region loop.
+  // (a.ksplit = number of k-groups: 1, 2 or 4; the remaining factor of the 4 / nsub waves of a
+  // sub-tile splits the taps.)
+  const int kgroups = (PFX > 0 && a.ksplit > 1) ? a.ksplit : 1;   // only the pipelined variant
+  const int wi = wave / nsub;                  // wave index inside its sub-tile
+  const int tgroups = (4 / nsub) / kgroups;
+  const int kw = wi % kgroups;
+  const int tstride = tgroups, tfirst = wi / kgroups;
 
   const int kX = adell_scale_exp(a.xmax[0]), kY = adell_scale_exp(a.ymax[0]);
   const float sX = __int_as_float((kX + 127) << 23), sY = __int_as_float((kY + 127) << 23);
@@ -137,6 +149,124 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
   const bool do_db = a.wsdb != nullptr && cit == 0 && blockIdx.z == 0;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  if constexpr (PFX > 0) {
+  // Software pipeline over this region's bricks: the global loads of brick i+1 are issued
+  // into registers right after brick i has been written to LDS, so they are in flight while
+  // the MFMAs of brick i run (PFX + PFY 16-byte loads per thread; the plan guarantees the fit).
+  float4 xr[PFX > 0 ? PFX : 1], yr[PFY > 0 ? PFY : 1];
+  auto fetch = [&](long brick) {
+    long t = brick;
+    const int tx = (int)(t % a.ntx); t /= a.ntx;
+    const int ty = (int)(t % a.nty); t /= a.nty;
+    const int oz = (int)(t % a.Do);
+    const int nb = (int)(t / a.Do);
+    const int ox0 = tx * 8, oy0 = ty << a.lTY;
+    const int iz = oz * a.SD - a.PD + kz;
+    const bool zok = iz >= 0 && iz < a.D;
+    const int ix0 = ox0 * a.SW - a.PW, iy0 = oy0 * a.SH - a.PH + ky0;
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) {
+      int it = tid + u * 256;
+      if (PFX >= 7) asm volatile("" : "+v"(it));  // opaque: keeps the index math out of the
+                                                    // loop-invariant set (register pressure)
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < HV * c4x) {
+        const int c4 = it % c4x, hv = it / c4x;
+        const int hy = hv / a.HX, hx = hv - hy * a.HX;
+        const int ix = ix0 + hx, iy = iy0 + hy;
+        const int c = ci0 + 4 * c4;
+        if (zok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+          const size_t gv = ((size_t)(nb * a.D + iz) * a.H + iy) * a.W + ix;
+          if (a.vecx) {
+            if (c < a.C0)
+              f = *reinterpret_cast<const float4*>(a.x0 + gv * a.C0 + c);
+            else if (c < a.Cin)
+              f = *reinterpret_cast<const float4*>(a.x1 + gv * a.C1 + (c - a.C0));
+          } else {
+            float uu[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int cc = c + j;
+              uu[j] = cc < a.C0 ? a.x0[gv * a.C0 + cc]
+                                : (cc < a.Cin ? a.x1[gv * a.C1 + (cc - a.C0)] : 0.f);
+            }
+            f = make_float4(uu[0], uu[1], uu[2], uu[3]);
+          }
+        }
+      }
+      xr[u] = f;
+    }
+#pragma unroll
+    for (int u = 0; u < PFY; ++u) {
+      int it = tid + u * 256;
+      if (PFX >= 7) asm volatile("" : "+v"(it));  // opaque: keeps the index math out of the
+                                                    // loop-invariant set (register pressure)
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < TV * c4y) {
+        const int c4 = it % c4y, v = it / c4y;
+        const int ox = ox0 + (v & 7), oy = oy0 + (v >> 3);
+        const int c = co0 + 4 * c4;
+        if (oy < a.Ho && ox < a.Wo) {
+          const size_t gv = ((size_t)(nb * a.Do + oz) * a.Ho + oy) * a.Wo + ox;
+          const float* ptr = a.dy + gv * a.Cout + c;
+          if (a.vecy) {
+            if (c < a.Cout) f = *reinterpret_cast<const float4*>(ptr);
+          } else {
+            if (c + 0 < a.Cout) f.x = ptr[0];
+            if (c + 1 < a.Cout) f.y = ptr[1];
+            if (c + 2 < a.Cout) f.z = ptr[2];
+            if (c + 3 < a.Cout) f.w = ptr[3];
+          }
+        }
+      }
+      yr[u] = f;
+    }
+  };
+  if (region < nbricks) fetch(region);
+  for (long brick = region; brick < nbricks; brick += a.R) {
+    __syncthreads();
+    // ---- registers -> LDS: [32-channel group][voxel][32 halfs], hi and lo planes ----
+#pragma unroll
+    for (int u = 0; u < PFX; ++u) {
+      int it = tid + u * 256;
+      if (PFX >= 7) asm volatile("" : "+v"(it));  // opaque: keeps the index math out of the
+                                                    // loop-invariant set (register pressure)
+      if (it < HV * c4x) {
+        const int c4 = it % c4x, hv = it / c4x;
+        const size_t off = ((size_t)((4 * c4) >> 5) * HV + hv) * 64 + ((4 * c4) & 31) * 2;
+        adell_split4_store(sXh, sXl, off, xr[u].x, xr[u].y, xr[u].z, xr[u].w, sX);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PFY; ++u) {
+      int it = tid + u * 256;
+      if (PFX >= 7) asm volatile("" : "+v"(it));  // opaque: keeps the index math out of the
+                                                    // loop-invariant set (register pressure)
+      if (it < TV * c4y) {
+        const int c4 = it % c4y, v = it / c4y;
+        dbacc.x += yr[u].x; dbacc.y += yr[u].y; dbacc.z += yr[u].z; dbacc.w += yr[u].w;
+        const size_t off = ((size_t)((4 * c4) >> 5) * TV + v) * 64 + ((4 * c4) & 31) * 2;
+        adell_split4_store(sYh, sYl, off, yr[u].x, yr[u].y, yr[u].z, yr[u].w, sY);
+      }
+    }
+    __syncthreads();
+    if (brick + a.R < nbricks) fetch(brick + a.R);
+    // ---- k-steps of 16 voxels (two brick rows), fragments by transposed reads ----
+    for (int s = kw; s < (TY >> 1); s += kgroups) {
+      const half8 bh = adell_tr_frag(sYh, bbase + s * 16 * 64, 4 * 64);
+      const half8 bl = adell_tr_frag(sYl, bbase + s * 16 * 64, 4 * 64);
+#pragma unroll
+      for (int q = 0; q < MAXJ; ++q) {
+        const half8 ah = adell_tr_frag(sXh, aoffj[q] + s * akstep, astep);
+        const half8 al = adell_tr_frag(sXl, aoffj[q] + s * akstep, astep);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[q], 0, 0, 0);
+      }
+    }
+  }
+
+  } else {
   for (long brick = region; brick < nbricks; brick += a.R) {
     long t = brick;
     const int tx = (int)(t % a.ntx); t /= a.ntx;
@@ -200,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
     }
     __syncthreads();
     // ---- k-steps of 16 voxels (two brick rows), fragments by transposed reads ----
-    for (int s = 0; s < (TY >> 1); ++s) {
+    for (int s = kw; s < (TY >> 1); s += kgroups) {
       const half8 bh = adell_tr_frag(sYh, bbase + s * 16 * 64, 4 * 64);
       const half8 bl = adell_tr_frag(sYl, bbase + s * 16 * 64, 4 * 64);
 #pragma unroll
@@ -212,6 +342,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[q], 0, 0, 0);
       }
     }
+  }
+
   }
 
   if (do_db) {
@@ -231,6 +363,30 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_f16_kernel(WgradF16Ar
       if (c + 1 < a.Cout) o[1] = tsum.y;
       if (c + 2 < a.Cout) o[2] = tsum.z;
       if (c + 3 < a.Cout) o[3] = tsum.w;
+    }
+  }
+  if (PFX > 0 && a.ksplit > 1) {
+    // fold the k-groups of each (sub-tile, tap group) in fixed order: red[group][job][r][lane]
+    __syncthreads();
+    float* red = smem;
+    for (int g = 0; g < kgroups; ++g) {
+      if (kw == g) {
+#pragma unroll
+        for (int q = 0; q < MAXJ; ++q)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* slot = red + ((size_t)((sub * tgroups + tfirst) * MAXJ + q) * 16 + r) * 64 + lane;
+            *slot = (g == 0 ? 0.f : *slot) + acc[q][r];
+          }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < MAXJ; ++q) {
+      if (kw != 0) jok[q] = false;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[q][r] = red[((size_t)((sub * tgroups + tfirst) * MAXJ + q) * 16 + r) * 64 + lane];
     }
   }
   // ---- partial slab (undo the operand scales) --------------------------------
@@ -268,7 +424,7 @@ extern "C" int adell_wgrad_reduce_launch(const float* ws, float* out, int R, int
                                          int Cout, const float* wsdb, float* db, void* stream);
 
 struct WgradF16Plan {
-  int lTY, HX, HY, TCI, TCO, nci, nco, maxj, R, ntx, nty, GKH, NGY;
+  int lTY, HX, HY, TCI, TCO, nci, nco, maxj, R, ntx, nty, GKH, NGY, ksplit;
   size_t lds;
 };
 
@@ -280,10 +436,13 @@ static int adell_wgrad_f16_plan(int N, int Cin, int Cout, int KD, int KH, int KW
   p->nco = adell_cdiv(Cout, p->TCO);
   const int nsub = (p->TCI / 32) * (p->TCO / 32);
   // a block owns the taps of GKH consecutive ky rows of one kz plane (<= 9 per wave)
+  // one 32 x 32 channel tile: two k-groups x two tap groups (TY = 8 gives four k-steps)
+  p->ksplit = (nsub == 1 && Ho > 4 && KW <= 3 && KH <= 3 && SH == 1 && SW == 1) ? 2 : 1;
+  const int tgroups = (4 / nsub) / p->ksplit;
   p->GKH = KH;
-  while (p->GKH > 1 && adell_cdiv(p->GKH * KW * nsub, 4) > 9) --p->GKH;
+  while (p->GKH > 1 && adell_cdiv(p->GKH * KW, tgroups) > 9) --p->GKH;
+  p->maxj = adell_cdiv(p->GKH * KW, tgroups);
   p->NGY = adell_cdiv(KH, p->GKH);
-  p->maxj = adell_cdiv(p->GKH * KW * nsub, 4);
   if (p->maxj > 9) {
     adell_set_error("wgrad f16x3: %d jobs per wave unsupported", p->maxj);
     return ADELL_E_UNSUPPORTED;
@@ -295,6 +454,11 @@ static int adell_wgrad_f16_plan(int N, int Cin, int Cout, int KD, int KH, int KW
     p->HY = (TY - 1) * SH + p->GKH;
     p->lds = 2 * ((size_t)(p->TCI / 32) * p->HX * p->HY * 64 + (size_t)(p->TCO / 32) * 8 * TY * 64);
     if (p->lds < 4096) p->lds = 4096;
+    if (p->ksplit > 1) {  // room for the accumulator fold (MAXJ template sizes: 2, 3, 5, 7, 9)
+      const int mj = p->maxj <= 2 ? 2 : (p->maxj <= 3 ? 3 : (p->maxj <= 5 ? 5 : (p->maxj <= 7 ? 7 : 9)));
+      const size_t red = (size_t)nsub * tgroups * mj * 16 * 64 * sizeof(float);
+      if (p->lds < red) p->lds = red;
+    }
     if (p->lds <= 80 * 1024 || p->lTY == 1) break;
     --p->lTY;
   }
@@ -321,10 +485,10 @@ static size_t adell_wgrad_f16_ws(const WgradF16Plan& p, int ntap, int Cin, int C
   return ((size_t)p.R * ntap * Cin * Cout + (size_t)p.R * Cout + 4) * sizeof(float);
 }
 
-template <int MAXJ>
+template <int MAXJ, int PFX = 0, int PFY = 0>
 static int adell_launch_wgrad_f16(const WgradF16Args& a, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr_done = false;
-  auto kern = adell_conv_wgrad_f16_kernel<MAXJ>;
+  auto kern = adell_conv_wgrad_f16_kernel<MAXJ, PFX, PFY>;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -377,6 +541,7 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   a.lTY = p.lTY; a.ntx = p.ntx; a.nty = p.nty; a.HX = p.HX; a.HY = p.HY;
   a.GKH = p.GKH; a.NGY = p.NGY;
   a.TCI = p.TCI; a.TCO = p.TCO; a.nci = p.nci; a.nco = p.nco; a.R = p.R;
+  a.ksplit = p.ksplit;
   a.vecx = (C0 % 4 == 0) && (C1 % 4 == 0) && (((uintptr_t)x0 & 15) == 0) &&
            (((uintptr_t)x1 & 15) == 0);
   a.vecy = (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0);
@@ -385,6 +550,15 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
     rc = adell_launch_wgrad_f16<2>(a, grid, p.lds, st);
   else if (p.maxj <= 3)
     rc = adell_launch_wgrad_f16<3>(a, grid, p.lds, st);
+  else if (p.maxj <= 5 && p.ksplit > 1 && (long)p.HX * p.HY * (p.TCI / 4) <= 4 * 256 &&
+           8L * (1 << p.lTY) * (p.TCO / 4) <= 2 * 256)
+    rc = adell_launch_wgrad_f16<5, 4, 2>(a, grid, p.lds, st);  // 32 x 32 channels: pipelined
+  else if (p.maxj <= 5 && (long)p.HX * p.HY * (p.TCI / 4) <= 7 * 256 &&
+           8L * (1 << p.lTY) * (p.TCO / 4) <= 2 * 256)
+    rc = adell_launch_wgrad_f16<5, 7, 2>(a, grid, p.lds, st);  // 64 x 32 channels: pipelined
+  else if (p.maxj <= 5 && (long)p.HX * p.HY * (p.TCI / 4) <= 4 * 256 &&
+           8L * (1 << p.lTY) * (p.TCO / 4) <= 4 * 256)
+    rc = adell_launch_wgrad_f16<5, 4, 4>(a, grid, p.lds, st);  // 32 x 64 channels: pipelined
   else if (p.maxj <= 5)
     rc = adell_launch_wgrad_f16<5>(a, grid, p.lds, st);
   else if (p.maxj <= 7)
