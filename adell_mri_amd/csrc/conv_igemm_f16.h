@@ -42,6 +42,13 @@ __device__ __forceinline__ void adell_split8(const float* v, float scale, half8*
   }
 }
 
+#ifndef ADELL_IGEMM_PIPE
+#define ADELL_IGEMM_PIPE 0
+#endif
+#ifndef ADELL_IGEMM_ONESET
+#define ADELL_IGEMM_ONESET 0
+#endif
+
 template <int MT, int NT, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
@@ -142,20 +149,34 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
 
   const int nchunk = (a.Cin + CC - 1) / CC;
   int kA_prev = 0;
+  // The halo brick of a chunk is loaded once into registers when it has at most KEEP voxels per
+  // thread ("resident"). ADELL_IGEMM_PIPE: the loads of chunk ch+1 are issued right after chunk
+  // ch has been written to LDS, so they are in flight during the MFMAs of chunk ch (the
+  // registers are free by then); the absmax over them is taken at the top of the next turn.
+  constexpr int KEEP = 3;
+  const bool resident = HV <= KEEP * 256;
+  float keep[KEEP][CC];
+  auto load_keep = [&](int c0) {
+#pragma unroll
+    for (int u = 0; u < KEEP; ++u) {
+      const int hv = tid + 256 * u;
+      if (hv < HV) load16(hv, c0, keep[u]);
+    }
+  };
+#if ADELL_IGEMM_PIPE
+  if (resident) load_keep(0);
+#endif
   for (int ch = 0; ch < nchunk; ++ch) {
     const int c0 = ch * CC;
-    // ---- load this chunk of the halo brick once (register-resident when the brick
-    // has at most 3 voxels per thread), block-wide absmax, then split to fp16 hi/lo ---
-    constexpr int KEEP = 3;
-    const bool resident = HV <= KEEP * 256;
-    float keep[KEEP][CC];
     float mx = 0.f;
     if (resident) {
+#if !ADELL_IGEMM_PIPE
+      load_keep(c0);
+#endif
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
         const int hv = tid + 256 * u;
         if (hv < HV) {
-          load16(hv, c0, keep[u]);
 #pragma unroll
           for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(keep[u][j]));
         }
@@ -213,6 +234,9 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
         const int hv = tid + 256 * u;
         if (hv < HV) store_split(hv, keep[u]);
       }
+#if ADELL_IGEMM_PIPE
+      if (ch + 1 < nchunk) load_keep(c0 + CC);
+#endif
     } else {
       for (int hv = tid; hv < HV; hv += 256) {
         float v[CC];
@@ -270,6 +294,14 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           }
       };
+#if ADELL_IGEMM_ONESET
+      // one fragment set: the MFMAs are asynchronous, the next tap's LDS reads follow their issue
+      half8 ah0[MT], al0[MT], bh0[NT], bl0[NT];
+      for (int tl = 0; tl < tpg; ++tl) {
+        load_frags(tl, ah0, al0, bh0, bl0);
+        do_mfma(ah0, al0, bh0, bl0);
+      }
+#else
       half8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
       load_frags(0, ah0, al0, bh0, bl0);
       for (int tl = 0; tl < tpg; tl += 2) {
@@ -280,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
           do_mfma(ah1, al1, bh1, bl1);
         }
       }
+#endif
     }
   }
 
