@@ -166,6 +166,37 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
 #if ADELL_IGEMM_PIPE
   if (resident) load_keep(0);
 #endif
+  // Weight slices of the 32-channel tile go through a register prefetch: the slice of the next
+  // tap group is fetched while the MFMAs of the current one run (<= 10 16-byte loads per
+  // thread; the 64-channel tile has no registers to spare and stages in place).
+  // (a kz plane of a 3^3 kernel: 9 taps x 32 ch x 4 slots = 4.5 x 256 slots. Row-wise groups
+  // with a 3-slot prefetch were tried for the 64-channel tile: 266 -> 258 TF, spills + barriers.)
+  constexpr int WPF = (BN == 32) ? 5 : 0;
+  const bool wpipe = WPF > 0 && a.GKH * a.KW * BN * 4 <= WPF * 256;
+  float4 wreg[WPF > 0 ? WPF : 1];
+  const int ngroups = a.KD * ngy;
+  auto wfetch = [&](int ch_, int grp_) {
+    const int kz = grp_ / ngy, ky0 = (grp_ - kz * ngy) * a.GKH;
+    const int gkh = (a.KH - ky0) < a.GKH ? (a.KH - ky0) : a.GKH;
+    const int tpg = gkh * a.KW;
+    const int tap0 = (kz * a.KH + ky0) * a.KW;
+#pragma unroll
+    for (int u = 0; u < WPF; ++u) {
+      const int it = tid + u * 256;
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (it < tpg * BN * 4) {
+        const int slot = it & 3;
+        const int n = (it >> 2) % BN;
+        const int tap = tap0 + (it >> 2) / BN;
+        if (n0 + n < a.Cout)
+          f = *reinterpret_cast<const float4*>(
+              reinterpret_cast<const char*>(e.wh) +
+              (((size_t)tap * a.Cout + n0 + n) * nchunk + ch_) * 64 + slot * 16);
+      }
+      wreg[u] = f;
+    }
+  };
+  if (wpipe) wfetch(0, 0);
   for (int ch = 0; ch < nchunk; ++ch) {
     const int c0 = ch * CC;
     float mx = 0.f;
@@ -251,6 +282,19 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
       const int tap0 = (kz * a.KH + ky0) * a.KW;
       if (grp > 0) __syncthreads();  // previous tap group consumed
       // ---- stage the weight slice of this kz plane: [tpg][BN][4 slots] -----
+      if (wpipe) {
+#pragma unroll
+        for (int u = 0; u < WPF; ++u) {
+          const int it = tid + u * 256;
+          if (it < tpg * BN * 4) {
+            const int slot = it & 3;
+            const int n = (it >> 2) % BN;
+            const int tl = (it >> 2) / BN;
+            *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) =
+                wreg[u];
+          }
+        }
+      } else
       for (int it = tid; it < tpg * BN * 4; it += 256) {
         const int slot = it & 3;
         const int n = (it >> 2) % BN;
@@ -264,6 +308,10 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
         *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) = f;
       }
       __syncthreads();
+      if (wpipe) {
+        if (grp + 1 < ngroups) wfetch(ch, grp + 1);
+        else if (ch + 1 < nchunk) wfetch(ch + 1, 0);
+      }
       // ---- 3 f16 MFMAs per (tap, 32x32 tile); the fragments of tap t+1 are read
       // while the MFMAs of tap t run (two register sets, statically indexed) -------
       auto load_frags = [&](int tl, half8* ah, half8* al, half8* bh, half8* bl) {
