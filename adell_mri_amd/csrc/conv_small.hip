@@ -145,20 +145,32 @@ __global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_wgrad_sma
   }
 }
 
-// dw[co][ci][tap] = sum over splits (fixed order); the last column of a partial row is db
-__global__ __launch_bounds__(256) void adell_wgrad_small_reduce_kernel(
+// dw[co][ci][tap] = sum over splits (fixed order); the last column of a partial row is db.
+// block = 64 outputs x 16 split lanes.
+__global__ __launch_bounds__(1024) void adell_wgrad_small_reduce_kernel(
     const float* __restrict__ part, int splits, int coPad, int Cout, int Cin, int K3,
     float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ double sh[16][64];
   const int rowlen = 4 * K3 + 1;
   const long total = (long)Cout * (Cin * K3 + 1);
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int co = (int)(i / (Cin * K3 + 1)), e = (int)(i % (Cin * K3 + 1));
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const long i = blockIdx.x * 64L + cl;
+  int co = 0, e = 0;
+  double s = 0.0;
+  if (i < total) {
+    co = (int)(i / (Cin * K3 + 1));
+    e = (int)(i % (Cin * K3 + 1));
     const int col = e < Cin * K3 ? e : 4 * K3;   // (ci, tap) slots are laid out ci-major
-    double s = 0.0;
-    for (int sp = 0; sp < splits; ++sp) s += (double)part[((size_t)sp * coPad + co) * rowlen + col];
-    if (e < Cin * K3) dw[(size_t)co * Cin * K3 + e] = (float)s;
-    else if (db) db[co] = (float)s;
+    for (int sp = vl; sp < splits; sp += 16) s += (double)part[((size_t)sp * coPad + co) * rowlen + col];
   }
+  sh[vl][cl] = s;
+  __syncthreads();
+  if (vl != 0 || i >= total) return;
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += sh[k][cl];
+  if (e < Cin * K3) dw[(size_t)co * Cin * K3 + e] = (float)s;
+  else if (db) db[co] = (float)s;
 }
 
 static bool adell_wgrad_small_ok(const adell_conv3d_desc* d) {
@@ -219,9 +231,8 @@ extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, co
     hipLaunchKernelGGL((adell_wgrad_small_kernel<1, 4>), dim3(grid), dim3(WgSmallCfg<1>::THREADS),
                        0, st, a);
   const int K3 = d->KD * d->KH * d->KW, Cin = d->C0 + d->C1;
-  long blocks = ((long)d->Cout * (Cin * K3 + 1) + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(adell_wgrad_small_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+  const long blocks = ((long)d->Cout * (Cin * K3 + 1) + 63) / 64;
+  hipLaunchKernelGGL(adell_wgrad_small_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st,
                      (const float*)workspace, splits, a.coBlocks * 16, d->Cout, Cin, K3, dw, db);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
@@ -345,20 +356,22 @@ __global__ __launch_bounds__(256) void adell_conv1_small_wgrad_kernel(Conv1Args 
   }
 }
 
-__global__ __launch_bounds__(256) void adell_conv1_small_wgrad_fold_kernel(
+__global__ __launch_bounds__(1024) void adell_conv1_small_wgrad_fold_kernel(
     const float* __restrict__ part, int nb, int Cout, int Cin, float* __restrict__ dw,
     float* __restrict__ db) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[16][64];
   const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
   const int n = Cout * (Cin + 1);
   const int e = blockIdx.x * 64 + cl;
   double s = 0.0;
   if (e < n)
-    for (int b = vl; b < nb; b += 4) s += (double)part[(size_t)b * n + e];
+    for (int b = vl; b < nb; b += 16) s += (double)part[(size_t)b * n + e];
   sh[vl][cl] = s;
   __syncthreads();
   if (vl != 0 || e >= n) return;
-  s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += sh[k][cl];
   const int o = e / (Cin + 1), c = e % (Cin + 1);
   if (c < Cin) dw[o * Cin + c] = (float)s;
   else if (db) db[o] = (float)s;
@@ -437,7 +450,7 @@ extern "C" int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const fl
   while (CL < 64 && CL < d->C0 + d->C1 + 1) CL <<= 1;
   hipLaunchKernelGGL(adell_conv1_small_wgrad_kernel, dim3(nb), dim3(256), 0, st, a, chunk, CL);
   const int n = d->Cout * (d->C0 + d->C1 + 1);
-  hipLaunchKernelGGL(adell_conv1_small_wgrad_fold_kernel, dim3(adell_cdiv(n, 64)), dim3(256), 0, st,
+  hipLaunchKernelGGL(adell_conv1_small_wgrad_fold_kernel, dim3(adell_cdiv(n, 64)), dim3(1024), 0, st,
                      (const float*)workspace, nb, d->Cout, d->C0 + d->C1, dw, db);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;

@@ -508,18 +508,22 @@ __global__ __launch_bounds__(256) void adell_colsum_partial_kernel(
   if (vl == 0 && c < C)
     part[(size_t)blockIdx.x * C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
 }
-// block = 64 columns x 4 lanes, each lane a fixed quarter of the partials (fp64, fixed order)
-__global__ __launch_bounds__(256) void adell_colsum_final_kernel(
+// block = 64 columns x 16 lanes, each lane a fixed share of the partials (fp64, fixed order)
+__global__ __launch_bounds__(1024) void adell_colsum_final_kernel(
     const float* __restrict__ part, int nb, int C, float* __restrict__ out) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[16][64];
   const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s = 0.0;
   if (c < C)
-    for (int b = vl; b < nb; b += 4) s += (double)part[(size_t)b * C + c];
+    for (int b = vl; b < nb; b += 16) s += (double)part[(size_t)b * C + c];
   sh[vl][cl] = s;
   __syncthreads();
-  if (vl == 0 && c < C) out[c] = (float)((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]));
+  if (vl != 0 || c >= C) return;
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += sh[k][cl];
+  out[c] = (float)s;
 }
 
 // rows per block: about 2048 blocks in total, at least 16 rows each
@@ -550,7 +554,7 @@ extern "C" int adell_bias_grad(const float* dy, long rows, int C, float* db, voi
   const int nb = (int)((rows + chunk - 1) / chunk);
   hipLaunchKernelGGL(adell_colsum_partial_kernel, dim3(nb, adell_cdiv(C, 64)), dim3(256), 0,
                      (hipStream_t)stream, dy, rows, C, chunk, (float*)workspace);
-  hipLaunchKernelGGL(adell_colsum_final_kernel, dim3(adell_cdiv(C, 64)), dim3(256), 0,
+  hipLaunchKernelGGL(adell_colsum_final_kernel, dim3(adell_cdiv(C, 64)), dim3(1024), 0,
                      (hipStream_t)stream, (const float*)workspace, nb, C, db);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;

@@ -482,18 +482,18 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_kernel(NormActBwdAr
 }
 
 // c1/c2 [N][C] (per_item) or [C]; dgamma/dbeta [C] (optional).
-__global__ __launch_bounds__(256) void adell_na_bwd_finalize_kernel(
+__global__ __launch_bounds__(1024) void adell_na_bwd_finalize_kernel(
     const float* __restrict__ part, int N, int ntiles, int C, double count, int per_item,
     const float* __restrict__ gamma, float* __restrict__ c1, float* __restrict__ c2,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double sh[8][32][2];
+  __shared__ double sh[32][32][2];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   double accA = 0.0, accB = 0.0;  // over all items (batch statistics / dgamma)
   for (int n = 0; n < N; ++n) {
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-      for (int t = sl; t < ntiles; t += 8) {
+      for (int t = sl; t < ntiles; t += 32) {
         const float2 v =
             *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
         s1 += (double)v.x;
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_finalize_kernel(
     if (sl == 0 && c < C) {
       double A = 0.0, B = 0.0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 32; ++k) {
         A += sh[k][cl][0];
         B += sh[k][cl][1];
       }
@@ -647,7 +647,7 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<true>, grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<false>, grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(adell_na_bwd_finalize_kernel, dim3(adell_cdiv(d->C, 32)), dim3(256), 0,
+    hipLaunchKernelGGL(adell_na_bwd_finalize_kernel, dim3(adell_cdiv(d->C, 32)), dim3(1024), 0,
                        st, (const float*)part, (int)d->N, a.ntiles, d->C, (double)d->V,
                        d->stats_per_item, gamma, c1, c2, dgamma, dbeta);
   }
