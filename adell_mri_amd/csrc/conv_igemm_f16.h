@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
   // thread; the 64-channel tile has no registers to spare and stages in place).
   // (a kz plane of a 3^3 kernel: 9 taps x 32 ch x 4 slots = 4.5 x 256 slots. Row-wise groups
   // with a 3-slot prefetch were tried for the 64-channel tile: 266 -> 258 TF, spills + barriers.)
-  constexpr int WPF = (BN == 32) ? 5 : 0;
+  constexpr int WPF = (BN == 32) ? 5 : 9;   // 64-channel tiles: a kz plane = 9 x 256 slots
   const bool wpipe = WPF > 0 && a.GKH * a.KW * BN * 4 <= WPF * 256;
   float4 wreg[WPF > 0 ? WPF : 1];
   const int ngroups = a.KD * ngy;
@@ -342,14 +342,14 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           }
       };
-#if ADELL_IGEMM_ONESET
+      if constexpr (ADELL_IGEMM_ONESET || MT * NT == 4) {
       // one fragment set: the MFMAs are asynchronous, the next tap's LDS reads follow their issue
       half8 ah0[MT], al0[MT], bh0[NT], bl0[NT];
       for (int tl = 0; tl < tpg; ++tl) {
         load_frags(tl, ah0, al0, bh0, bl0);
         do_mfma(ah0, al0, bh0, bl0);
       }
-#else
+      } else {
       half8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
       load_frags(0, ah0, al0, bh0, bl0);
       for (int tl = 0; tl < tpg; tl += 2) {
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
           do_mfma(ah1, al1, bh1, bl1);
         }
       }
-#endif
+      }
     }
   }
 
