@@ -101,6 +101,8 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_convtranspose3d_fwd_f16x3": (_i, [_i] * 9 + [_vp] * 7),
+    "adell_convtranspose3d_bwd_data_f16x3": (_i, [_i] * 9 + [_vp] * 6),
     "adell_conv1_small_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv1_small_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
     "adell_conv1_small_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5),

@@ -463,6 +463,52 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
+// ConvTranspose3d (kernel = stride = factors) on the f16x3 kernel. Forward: w_split = the
+// VIRTUAL 1x1x1 conv weight V[(f, co)][ci] = w[ci][co][f] packed with mode 0 (wscale has
+// F*Cout entries); backward-data: the torch weight [Cin][Cout][taps] read as a conv weight with
+// Cin outputs and Cout inputs, packed with mode 0 as well.
+extern "C" int adell_convtranspose3d_fwd_f16x3(int N, int D, int H, int W, int Cin, int Cout,
+                                               int FD, int FH, int FW, const float* x,
+                                               const void* w_split, const float* wscale,
+                                               const float* bias, float* y, uint32_t* in_absmax,
+                                               void* stream) {
+  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "convT_fwd: bad dims");
+  ADELL_REQUIRE(adell_convt_factors_ok(FD, FH, FW), "convT_fwd: kernel=stride must be 1 or 2 per dim");
+  ADELL_REQUIRE(x && w_split && wscale && y, "convT_fwd_f16x3: null pointer");
+  ConvArgs a = {};
+  a.x0 = x; a.bias = bias; a.y0 = y;
+  a.D = D; a.H = H; a.W = W;
+  a.C0 = Cin; a.C1 = 0; a.Cin = Cin; a.Cout = FD * FH * FW * Cout;
+  a.KD = a.KH = a.KW = 1;
+  a.SD = a.SH = a.SW = 1;
+  a.UPS = 1;
+  a.Do = D; a.Ho = H; a.Wo = W;
+  a.ysplit = a.Cout; a.Cs = Cout;
+  a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax};
+  return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
+}
+
+extern "C" int adell_convtranspose3d_bwd_data_f16x3(int N, int D, int H, int W, int Cin, int Cout,
+                                                    int FD, int FH, int FW, const float* dy,
+                                                    const void* w_split_bwd, const float* wscale,
+                                                    float* dx, uint32_t* dy_absmax, void* stream) {
+  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0,
+                "convT_bwd_data: bad dims");
+  ADELL_REQUIRE(adell_convt_factors_ok(FD, FH, FW), "convT_bwd_data: bad factors");
+  ADELL_REQUIRE(dy && w_split_bwd && wscale && dx, "convT_bwd_data_f16x3: null pointer");
+  ConvArgs a = {};
+  a.x0 = dy; a.y0 = dx;
+  a.D = FD * D; a.H = FH * H; a.W = FW * W;
+  a.C0 = Cout; a.C1 = 0; a.Cin = Cout; a.Cout = Cin;
+  a.KD = a.SD = FD; a.KH = a.SH = FH; a.KW = a.SW = FW;
+  a.UPS = 1;
+  a.Do = D; a.Ho = H; a.Wo = W;
+  a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax};
+  return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
+}
+
 extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                            const void* w_split_bwd, const float* wscale,
                                            float* dx0, float* dx1, uint32_t* dy_absmax,

@@ -51,7 +51,7 @@ def _packed(w, mode):
     if cache is None:
         cache = {}
         w._adell_packs = cache
-    split = CONV_PRECISION == "f16x3" and mode in (0, 1)
+    split = CONV_PRECISION == "f16x3" and mode in (0, 1, 2, 3)
     key = (mode, split)
     hit = cache.get(key)
     tag = (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)
@@ -60,7 +60,15 @@ def _packed(w, mode):
     wd = w.detach()
     if wd.dim() == 2:  # torch.nn.Linear weight == 1x1x1 convolution weight
         wd = wd.view(wd.shape[0], wd.shape[1], 1, 1, 1)
-    p = ops.pack_weight_f16x3(wd, mode) if split else ops.pack_weight(wd, mode)
+    if split and mode == 2:
+        # transposed conv forward = 1x1x1 conv with F*Cout outputs: V[(f, co)][ci] = w[ci][co][f]
+        v = wd.permute(2, 3, 4, 1, 0).reshape(-1, wd.shape[0], 1, 1, 1)
+        p = ops.pack_weight_f16x3(v, 0)
+    elif split and mode == 3:
+        # its backward-data = kernel == stride conv with Cin outputs / Cout inputs: w as is
+        p = ops.pack_weight_f16x3(wd, 0)
+    else:
+        p = ops.pack_weight_f16x3(wd, mode) if split else ops.pack_weight(wd, mode)
     cache[key] = (tag, p)
     return p
 

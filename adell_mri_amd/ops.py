@@ -396,13 +396,23 @@ def convtranspose3d_k2s2_bwd_weight(x, dy):
 
 
 def convtranspose3d_fwd(x, w_packed, bias, Cout, factors=(2, 2, 2)):
-    """ConvTranspose3d with kernel = stride = factors (each 1 or 2), padding 0."""
-    _require_cuda(x, w_packed, bias)
+    """ConvTranspose3d with kernel = stride = factors (each 1 or 2), padding 0. ``w_packed``:
+    fp32 pack (mode 2) or the SplitWeight of the virtual 1x1x1 weight (f16x3)."""
+    _require_cuda(x, bias)
     x = ndhwc(x)
     N, Cin, D, H, W = x.shape
     fd, fh, fw = factors
     y = new_act(N, Cout, fd * D, fh * H, fw * W, x.device)
     flops = 2.0 * N * D * H * W * Cin * Cout * fd * fh * fw
+    if isinstance(w_packed, SplitWeight):
+        check(_timed("adell_conv_igemm_f16_kernel", flops,
+                     lambda: _lib.lib().adell_convtranspose3d_fwd_f16x3(
+                         N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(x), _ptr(w_packed.halfs),
+                         _ptr(w_packed.scale), _ptr(bias), _ptr(y), None, _stream()),
+                     f"convT fwd {Cin}->{Cout} in {D}x{H}x{W} f{fd}{fh}{fw}",
+                     4.0 * (x.numel() + y.numel())))
+        return y
+    _require_cuda(w_packed)
     check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_fwd(
         N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(x), _ptr(w_packed), _ptr(bias), _ptr(y),
         _stream())))
@@ -410,13 +420,22 @@ def convtranspose3d_fwd(x, w_packed, bias, Cout, factors=(2, 2, 2)):
 
 
 def convtranspose3d_bwd_data(dy, w_packed_bwd, Cin, factors=(2, 2, 2)):
-    _require_cuda(dy, w_packed_bwd)
+    _require_cuda(dy)
     dy = ndhwc(dy)
     N, Cout, D2, H2, W2 = dy.shape
     fd, fh, fw = factors
     D, H, W = D2 // fd, H2 // fh, W2 // fw
     dx = new_act(N, Cin, D, H, W, dy.device)
     flops = 2.0 * N * D * H * W * Cin * Cout * fd * fh * fw
+    if isinstance(w_packed_bwd, SplitWeight):
+        check(_timed("adell_conv_igemm_f16_kernel", flops,
+                     lambda: _lib.lib().adell_convtranspose3d_bwd_data_f16x3(
+                         N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(dy), _ptr(w_packed_bwd.halfs),
+                         _ptr(w_packed_bwd.scale), _ptr(dx), None, _stream()),
+                     f"convT dgrad {Cin}->{Cout} in {D}x{H}x{W} f{fd}{fh}{fw}",
+                     4.0 * (dy.numel() + dx.numel())))
+        return dx
+    _require_cuda(w_packed_bwd)
     check(_timed("adell_conv_igemm_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_bwd_data(
         N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(dy), _ptr(w_packed_bwd), _ptr(dx), _stream())))
     return dx

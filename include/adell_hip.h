@@ -153,6 +153,17 @@ int adell_convtranspose3d_fwd(int N, int D, int H, int W, int Cin, int Cout, int
 int adell_convtranspose3d_bwd_data(int N, int D, int H, int W, int Cin, int Cout, int FD,
                                    int FH, int FW, const float* dy, const float* w_packed_bwd,
                                    float* dx, void* stream);
+/* The same two on the f16x3 kernels. Forward: w_split / wscale = adell_pack_weight_f16x3(mode 0)
+ * of the virtual 1x1x1 conv weight V[(f, co)][ci] = w[ci][co][f] (F*Cout columns);
+ * backward-data: mode 0 of the torch weight read as [Cin outputs][Cout inputs][taps]. */
+int adell_convtranspose3d_fwd_f16x3(int N, int D, int H, int W, int Cin, int Cout, int FD, int FH,
+                                    int FW, const float* x, const void* w_split,
+                                    const float* wscale, const float* bias, float* y,
+                                    uint32_t* in_absmax, void* stream);
+int adell_convtranspose3d_bwd_data_f16x3(int N, int D, int H, int W, int Cin, int Cout, int FD,
+                                         int FH, int FW, const float* dy, const void* w_split_bwd,
+                                         const float* wscale, float* dx, uint32_t* dy_absmax,
+                                         void* stream);
 long adell_convtranspose3d_bwd_weight_workspace(int N, int D, int H, int W, int Cin, int Cout,
                                                 int FD, int FH, int FW);
 int adell_convtranspose3d_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, int FD,
