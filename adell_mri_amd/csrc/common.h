@@ -51,8 +51,11 @@ __device__ __forceinline__ double adell_wave_sum_d(double v) {
 }
 
 // Activation ids shared with the host side (adell_hip.h: ADELL_ACT_*).
+// v_exp_f32 + v_rcp_f32: ~1 ulp each (2^-23-level relative error, far inside the 1e-4 parity
+// bar) instead of the ~35-instruction IEEE expf + division, which made the elementwise
+// kernels VALU-bound at ~2.5 TB/s.
 __device__ __forceinline__ float adell_sigmoidf(float x) {
-  return 1.0f / (1.0f + expf(-x));
+  return __frcp_rn(1.0f + __expf(-x));
 }
 
 // Philox-4x32-10 counter RNG: one call -> 4 uniform 32-bit words. The dropout

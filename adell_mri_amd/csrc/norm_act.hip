@@ -296,7 +296,44 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
 }
 
 #define ADELL_EW_UNROLL 4
-__global__ void adell_norm_act_fwd_fast_kernel(NormActArgs a);
+// the bandwidth-tuned kernels are compiled once per activation (the runtime switch inside
+// the element loop made one 40 KB kernel out of nine small ones)
+#define ADELL_ACT_DISPATCH(KERN, act, grid, st, args)                                         \
+  switch (act) {                                                                              \
+    case 0: hipLaunchKernelGGL(KERN<0>, grid, dim3(256), 0, st, args); break;                 \
+    case 1: hipLaunchKernelGGL(KERN<1>, grid, dim3(256), 0, st, args); break;                 \
+    case 2: hipLaunchKernelGGL(KERN<2>, grid, dim3(256), 0, st, args); break;                 \
+    case 3: hipLaunchKernelGGL(KERN<3>, grid, dim3(256), 0, st, args); break;                 \
+    case 4: hipLaunchKernelGGL(KERN<4>, grid, dim3(256), 0, st, args); break;                 \
+    case 5: hipLaunchKernelGGL(KERN<5>, grid, dim3(256), 0, st, args); break;                 \
+    case 6: hipLaunchKernelGGL(KERN<6>, grid, dim3(256), 0, st, args); break;                 \
+    case 7: hipLaunchKernelGGL(KERN<7>, grid, dim3(256), 0, st, args); break;                 \
+    default: hipLaunchKernelGGL(KERN<8>, grid, dim3(256), 0, st, args); break;                \
+  }
+#ifndef ADELL_EW_MAXBLOCKS
+#define ADELL_EW_MAXBLOCKS 65535
+#endif
+// Element range of a block of the bandwidth-tuned kernels. ADELL_EW_CONTIG: each block walks
+// ONE contiguous chunk (a multiple of 1024 float4, so a thread keeps its channel quad) instead
+// of grid-striding over the whole tensor.
+#ifndef ADELL_EW_CONTIG
+#define ADELL_EW_CONTIG 1
+#endif
+#if ADELL_EW_CONTIG
+#define ADELL_EW_RANGE(n4)                                                                   \
+  const long chunk_ = (((n4) + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;            \
+  const long jbeg = (long)blockIdx.x * chunk_;                                               \
+  const long jend = jbeg + chunk_ < (n4) ? jbeg + chunk_ : (n4);                             \
+  const long j0 = jbeg + threadIdx.x;                                                        \
+  const long stride = 256
+#else
+#define ADELL_EW_RANGE(n4)                                                                   \
+  const long jbeg = (long)blockIdx.x * 256;                                                  \
+  const long jend = (n4);                                                                    \
+  const long j0 = jbeg + threadIdx.x;                                                        \
+  const long stride = (long)gridDim.x * 256
+#endif
+template <int ACT> __global__ void adell_norm_act_fwd_fast_kernel(NormActArgs a);
 
 static int adell_na_fill(NormActArgs* a, const adell_norm_act_desc* d) {
   ADELL_REQUIRE(d != nullptr, "norm_act: null descriptor");
@@ -342,10 +379,10 @@ extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
   a.vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0);
   if (a.vec && adell_is_pow2(d->C) && d->C <= 1024 && (a.VC >> 2) < (1L << 40)) {
     long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
-    if (bx > 2048) bx = 2048;
+    if (bx > ADELL_EW_MAXBLOCKS) bx = ADELL_EW_MAXBLOCKS;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(adell_norm_act_fwd_fast_kernel, dim3((unsigned)bx, (unsigned)d->N),
-                       dim3(256), 0, (hipStream_t)stream, a);
+    ADELL_ACT_DISPATCH(adell_norm_act_fwd_fast_kernel, d->act, dim3((unsigned)bx, (unsigned)d->N),
+                       (hipStream_t)stream, a);
     ADELL_CHECK_HIP(hipGetLastError());
     return ADELL_OK;
   }
@@ -573,8 +610,8 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs 
   }
 }
 
-__global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
-__global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
+template <int ACT> __global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
+template <int ACT> __global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
 // blocks per item of the grid-strided partials kernel (each covers >= 1024 float4)
 static long adell_na_fast_blocks(long V, int C) {
   long bx = ((V * C >> 2) + 256 * 4 - 1) / (256 * 4);
@@ -641,8 +678,8 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
     dim3 grid(a.ntiles, (unsigned)d->N);
     if (fast) {
       a.ntiles = (int)adell_na_fast_blocks(d->V, d->C);
-      hipLaunchKernelGGL(adell_na_bwd_partials_fast_kernel, dim3(a.ntiles, (unsigned)d->N),
-                         dim3(256), 0, st, a);
+      ADELL_ACT_DISPATCH(adell_na_bwd_partials_fast_kernel, d->act,
+                         dim3(a.ntiles, (unsigned)d->N), st, a);
     } else if (vec)
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<true>, grid, dim3(256), 0, st, a);
     else
@@ -654,10 +691,10 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
   const long nw = vec ? a.total / 4 : a.total;
   if (fast) {
     long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
-    if (bx > 2048) bx = 2048;
+    if (bx > ADELL_EW_MAXBLOCKS) bx = ADELL_EW_MAXBLOCKS;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(adell_na_bwd_apply_fast_kernel, dim3((unsigned)bx, (unsigned)d->N),
-                       dim3(256), 0, st, a);
+    ADELL_ACT_DISPATCH(adell_na_bwd_apply_fast_kernel, d->act, dim3((unsigned)bx, (unsigned)d->N),
+                       st, a);
   } else if (vec)
     hipLaunchKernelGGL(adell_na_bwd_apply_kernel<true>, dim3(adell_ew_blocks(nw)), dim3(256), 0,
                        st, a);
@@ -696,11 +733,11 @@ __device__ __forceinline__ void adell_na_consts(NaConst& k, const float* mean, c
   }
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArgs a) {
   const int n = blockIdx.y;
   const long n4 = a.VC >> 2;  // float4 per item
-  const long j0 = (long)blockIdx.x * 256 + threadIdx.x;
-  const long stride = (long)gridDim.x * 256;
+  ADELL_EW_RANGE(n4);
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
@@ -708,15 +745,15 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   float4* yout = reinterpret_cast<float4*>(a.out) + (long)n * n4;
-  for (long j = j0; j < n4; j += stride * ADELL_EW_UNROLL) {
+  for (long j = j0; j < jend; j += stride * ADELL_EW_UNROLL) {
     float4 v[ADELL_EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u)
-      if (j + u * stride < n4) v[u] = xin[j + u * stride];
+      if (j + u * stride < jend) v[u] = xin[j + u * stride];
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
       const long jj = j + u * stride;
-      if (jj >= n4) break;
+      if (jj >= jend) break;
       float h[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
       uint32_t rr[4] = {0, 0, 0, 0};
       if (a.drop_p > 0.f) {
@@ -732,18 +769,18 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
           const float uu = (float)(rr[q] >> 8) * (1.0f / 16777216.0f);
           t = (uu >= a.drop_p) ? t * keep_scale : 0.f;
         }
-        h[q] = adell_act_fwd(a.act, t, k.p[q]);
+        h[q] = adell_act_fwd(ACT, t, k.p[q]);
       }
       yout[jj] = make_float4(h[0], h[1], h[2], h[3]);
     }
   }
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a) {
   const int n = blockIdx.y;
   const long n4 = a.VC >> 2;
-  const long j0 = (long)blockIdx.x * 256 + threadIdx.x;
-  const long stride = (long)gridDim.x * 256;
+  ADELL_EW_RANGE(n4);
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, a.c1, a.c2,
@@ -753,18 +790,18 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
   float4* dxo = reinterpret_cast<float4*>(a.dx) + (long)n * n4;
   const bool norm = a.mean != nullptr;
-  for (long j = j0; j < n4; j += stride * ADELL_EW_UNROLL) {
+  for (long j = j0; j < jend; j += stride * ADELL_EW_UNROLL) {
     float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u)
-      if (j + u * stride < n4) {
+      if (j + u * stride < jend) {
         xv[u] = xin[j + u * stride];
         gv[u] = gin[j + u * stride];
       }
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
       const long jj = j + u * stride;
-      if (jj >= n4) break;
+      if (jj >= jend) break;
       const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
       const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
       bool keep[4];
@@ -775,7 +812,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
         const float hn = (xs[q] - k.m[q]) * k.r[q];
         const float t = hn * k.g[q] + k.b[q];
         const float uu = keep[q] ? t * keep_scale : 0.f;
-        const float du = gs[q] * adell_act_grad(a.act, uu, k.p[q]);
+        const float du = gs[q] * adell_act_grad(ACT, uu, k.p[q]);
         const float dt = keep[q] ? du * keep_scale : 0.f;
         float r = dt * k.g[q];
         if (norm) r = k.r[q] * (r - k.c1[q] - hn * k.c2[q]);
@@ -789,12 +826,12 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
 // grid (blocks per item, N), grid-strided like the apply kernel: a thread keeps one channel
 // quad, accumulates (sum dt, sum dt*xhat) over its whole share in registers, and the block
 // folds its 256 / (C/4) threads per quad once at the end (fixed order).
+template <int ACT>
 __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a) {
   __shared__ float sh[8][256];
   const int n = blockIdx.y;
   const long n4 = a.VC >> 2;
-  const long j0 = (long)blockIdx.x * 256 + threadIdx.x;
-  const long stride = (long)gridDim.x * 256;
+  ADELL_EW_RANGE(n4);
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
@@ -803,18 +840,18 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
   float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};
-  for (long j = j0; j < n4; j += stride * ADELL_EW_UNROLL) {
+  for (long j = j0; j < jend; j += stride * ADELL_EW_UNROLL) {
     float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u)
-      if (j + u * stride < n4) {
+      if (j + u * stride < jend) {
         xv[u] = xin[j + u * stride];
         gv[u] = gin[j + u * stride];
       }
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
       const long jj = j + u * stride;
-      if (jj >= n4) break;
+      if (jj >= jend) break;
       const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
       const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
       bool keep[4];
@@ -824,7 +861,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
         const float hn = (xs[q] - k.m[q]) * k.r[q];
         const float t = hn * k.g[q] + k.b[q];
         const float uu = keep[q] ? t * keep_scale : 0.f;
-        const float du = gs[q] * adell_act_grad(a.act, uu, k.p[q]);
+        const float du = gs[q] * adell_act_grad(ACT, uu, k.p[q]);
         const float dt = keep[q] ? du * keep_scale : 0.f;
         A[q] += dt;
         B[q] += dt * hn;
@@ -846,7 +883,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
     float s1 = 0.f;
     for (int kk = 0; kk < VL; ++kk) s1 += sh[q8][kk * CG + cl];
     // channel of this quad slot: the block's first thread has quad (blockIdx.x*256) % CG
-    const int quad = (int)((((long)blockIdx.x * 256 + cl) << 2) & (a.C - 1));
+    const int quad = (int)(((jbeg + cl) << 2) & (a.C - 1));
     const int ch = quad + (q8 & 3);
     a.part[(((size_t)n * a.ntiles + blockIdx.x) * a.C + ch) * 2 + (q8 >> 2)] = s1;
   }

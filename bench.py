@@ -25,7 +25,8 @@ import torch  # noqa: E402
 
 CFG2 = dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
             upscale_type="transpose", norm_type="instance", interpolation="bilinear", padding=1,
-            dropout_param=0.15, in_channels=2, n_classes=2, depth=[32, 32, 64, 128, 256],
+            dropout_param=float(os.environ.get("ADELL_BENCH_DROPOUT", "0.15")),  # config value 0.15
+            in_channels=2, n_classes=2, depth=[32, 32, 64, 128, 256],
             kernel_sizes=[3] * 5, strides=[2] * 5)
 LOSS = dict(smooth=1e-5, dice_eps=1e-6, gamma=1.0, focal_eps=1e-6)
 LR, WD = 5e-4, 5e-3
