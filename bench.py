@@ -114,7 +114,9 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--shape", type=str, default=None,
                     help="D,H,W of the synthetic volumes (e.g. 256,256,128); overrides --size")
-    ap.add_argument("--batch", type=int, default=1, help="volumes per GPU per step")
+    ap.add_argument("--batch", type=int, default=2,
+                    help="volumes per GPU per step (u-net-3d-resnet.yaml:16 ships batch_size: 2; "
+                         "SURVEY.md 8(d): B per GPU in {1, 2})")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=64)
     args = ap.parse_args()
