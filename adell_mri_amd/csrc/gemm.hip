@@ -208,6 +208,19 @@ __global__ __launch_bounds__(1024) void adell_gemm_reduce_kernel(GemmArgs a) {
   a.C[(long)row * a.ldc + col] = s;
 }
 
+// few splits: one thread per output (float4 when the row length allows), fixed order
+__global__ __launch_bounds__(256) void adell_gemm_reduce_flat_kernel(GemmArgs a) {
+  const long total = (long)a.M * a.N;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    float s = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) s += a.slab[(long)sp * total + i];
+    const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+    if (a.bias) s += a.bias[col];
+    if (a.residual) s += a.residual[(long)row * a.ldr + col];
+    a.C[(long)row * a.ldc + col] = s;
+  }
+}
+
 struct GemmPlan {
   int skinny;  // 32 x 128 tile instead of 128 x 128
   int BM, BN, splits, ksteps_per_split;
@@ -284,8 +297,14 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
                     : adell_gemm_launch<2, 2, 2, 2>(a, a_kc, b_kc, grid, st);
   if (rc != ADELL_OK) return rc;
   if (p.splits > 1) {
-    const long blocks = ((long)M * N + 63) / 64;
-    hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, a);
+    if (p.splits <= 8) {
+      long blocks = ((long)M * N + 255) / 256;
+      if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(adell_gemm_reduce_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    } else {
+      const long blocks = ((long)M * N + 63) / 64;
+      hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, a);
+    }
     ADELL_CHECK_HIP(hipGetLastError());
   }
   return ADELL_OK;

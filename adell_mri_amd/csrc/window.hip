@@ -280,20 +280,22 @@ extern "C" int adell_layernorm_rows_fwd(const float* x, long rows, int C, int in
   return ADELL_OK;
 }
 
-__global__ __launch_bounds__(256) void adell_lnr_final_kernel(const float* __restrict__ part,
-                                                              int nb, int C,
-                                                              float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
-  __shared__ double sh[4][64];
+__global__ __launch_bounds__(1024) void adell_lnr_final_kernel(const float* __restrict__ part,
+                                                               int nb, int C,
+                                                               float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  __shared__ double sh[16][64];
   const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s = 0.0;
   if (c < 2 * C)
-    for (int b = vl; b < nb; b += 4) s += (double)part[(size_t)b * 2 * C + c];
+    for (int b = vl; b < nb; b += 16) s += (double)part[(size_t)b * 2 * C + c];
   sh[vl][cl] = s;
   __syncthreads();
   if (vl != 0 || c >= 2 * C) return;
-  s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += sh[k][cl];
   if (c < C) {
     if (dgamma) dgamma[c] = (float)s;
   } else if (dbeta) {
@@ -324,7 +326,7 @@ extern "C" int adell_layernorm_rows_bwd(const float* x, const float* dy, const f
   const size_t lds = want ? (size_t)(256 / a.lpr) * 2 * C * sizeof(float) : 0;
   hipLaunchKernelGGL(adell_layernorm_rows_bwd_kernel, dim3(blocks), dim3(256), lds, st, a);
   if (want)
-    hipLaunchKernelGGL(adell_lnr_final_kernel, dim3(adell_cdiv(2 * C, 64)), dim3(256), 0, st,
+    hipLaunchKernelGGL(adell_lnr_final_kernel, dim3(adell_cdiv(2 * C, 64)), dim3(1024), 0, st,
                        (const float*)workspace, blocks, C, dgamma, dbeta);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
