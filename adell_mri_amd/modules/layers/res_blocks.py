@@ -105,13 +105,17 @@ class ConvNeXtBlock3d(torch.nn.Module):
         rows = ops.ndhwc(h).permute(0, 2, 3, 4, 1)          # [N, D, H, W, C], contiguous
         rows = self.norm(rows)
         rows = HF.elementwise(self.pwconv1(rows), act="gelu")
+        # pwconv2 -> layer scale -> + input as ONE GEMM: gamma * (h W^T + b) = h (gamma W)^T +
+        # gamma b, so the scale is folded into the [C, 4C] weight (parameter algebra on a tiny
+        # tensor; autograd carries dgamma / dW back through it) and the residual add rides the
+        # GEMM epilogue. No full-size scale / add passes.
         if self.gamma is None:
-            rows = self.pwconv2(rows, residual=inp.permute(0, 2, 3, 4, 1))
-            out = rows.permute(0, 4, 1, 2, 3)
+            w2, b2 = self.pwconv2.weight, self.pwconv2.bias
         else:
-            rows = self.pwconv2(rows)
-            scaled = HF.channel_scale(rows.permute(0, 4, 1, 2, 3), self.gamma)
-            out = HF.add_bcast(inp, scaled)
+            w2 = self.gamma.unsqueeze(1) * self.pwconv2.weight
+            b2 = self.gamma * self.pwconv2.bias
+        rows = HF.linear(rows, w2, b2, residual=inp.permute(0, 2, 3, 4, 1))
+        out = rows.permute(0, 4, 1, 2, 3)
         if self.out_layer is not None:
             out = HF.norm_drop_act(self.out_layer[0](out), act="gelu")
         return out
