@@ -79,6 +79,7 @@ SIGNATURES = {
     "adell_dice_focal_workspace": (_l, [_i, _l]),
     "adell_dice_focal_fwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_dice_focal_bwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _f, _f, _vp, _vp]),
+    "adell_dice_focal_bwd_dev": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "adell_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _i, _f, _vp]),
     "adell_adamw_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),
     "adell_ema_update": (_i, [_vp, _vp, _l, _f, _vp]),
@@ -101,6 +102,8 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_prelu_wgrad_workspace": (_l, [ctypes.POINTER(NormActDesc)]),
+    "adell_prelu_wgrad": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 8 + [ctypes.c_size_t, _vp]),
     "adell_convtranspose3d_fwd_f16x3": (_i, [_i] * 9 + [_vp] * 7),
     "adell_convtranspose3d_bwd_data_f16x3": (_i, [_i] * 9 + [_vp] * 6),
     "adell_conv1_small_applicable": (_i, [ctypes.POINTER(ConvDesc)]),

@@ -163,7 +163,7 @@ static int adell_fill_fwd(ConvArgs& a, const adell_conv3d_desc* d, const float* 
   a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
   a.SD = d->SD; a.SH = d->SH; a.SW = d->SW;
   a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
-  a.UPS = 1;
+  a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo;
   a.ysplit = d->Cout; a.shuffle = 0; a.Cs = d->Cout;
   return ADELL_OK;
@@ -182,8 +182,8 @@ extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
 }
 
 // dX = conv_stride1(zero_insert(dY, S), flip(W)^T, pad = K-1-P), written to the
-// two sources of the forward's virtual concat. Needs equal strides in all dims
-// when any stride is 2 (UPS is one factor); w_packed_bwd is
+// two sources of the forward's virtual concat (per-axis insertion factors, so anisotropic
+// strides such as the (1,2,2) of a 2-D network work); w_packed_bwd is
 // [flipped tap][Cout][Cin] (adell_pack_weight mode 1).
 static int adell_fill_bwd_data(ConvArgs& a, const adell_conv3d_desc* d, const float* dy,
                                float* dx0, float* dx1) {
@@ -191,10 +191,6 @@ static int adell_fill_bwd_data(ConvArgs& a, const adell_conv3d_desc* d, const fl
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(dy && dx0, "conv_bwd_data: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || dx1, "conv_bwd_data: C1 > 0 needs dx1");
-  if (!(d->SD == d->SH && d->SH == d->SW)) {
-    adell_set_error("conv_bwd_data: anisotropic strides unsupported");
-    return ADELL_E_UNSUPPORTED;
-  }
   if (d->PD > d->KD - 1 || d->PH > d->KH - 1 || d->PW > d->KW - 1) {
     adell_set_error("conv_bwd_data: pad > k-1 unsupported");
     return ADELL_E_UNSUPPORTED;
@@ -207,7 +203,7 @@ static int adell_fill_bwd_data(ConvArgs& a, const adell_conv3d_desc* d, const fl
   a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
   a.SD = a.SH = a.SW = 1;
   a.PD = d->KD - 1 - d->PD; a.PH = d->KH - 1 - d->PH; a.PW = d->KW - 1 - d->PW;
-  a.UPS = d->SD;
+  a.UPS = d->SW; a.UPSY = d->SH; a.UPSZ = d->SD;   // per-axis zero insertion
   a.Do = d->D; a.Ho = d->H; a.Wo = d->W;
   a.ysplit = d->C0; a.shuffle = 0; a.Cs = a.Cout;
   return ADELL_OK;
@@ -245,7 +241,7 @@ extern "C" int adell_convtranspose3d_fwd(int N, int D, int H, int W, int Cin, in
   a.KD = a.KH = a.KW = 1;
   a.SD = a.SH = a.SW = 1;
   a.PD = a.PH = a.PW = 0;
-  a.UPS = 1;
+  a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.Cs = Cout;
   a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);  // bit 3 marks "scatter store"
@@ -277,7 +273,7 @@ extern "C" int adell_convtranspose3d_bwd_data(int N, int D, int H, int W, int Ci
   a.C0 = Cout; a.C1 = 0; a.Cin = Cout; a.Cout = Cin;
   a.KD = a.SD = FD; a.KH = a.SH = FH; a.KW = a.SW = FW;
   a.PD = a.PH = a.PW = 0;
-  a.UPS = 1;
+  a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
   return adell_conv_dispatch(a, N, (hipStream_t)stream);
@@ -481,7 +477,7 @@ extern "C" int adell_convtranspose3d_fwd_f16x3(int N, int D, int H, int W, int C
   a.C0 = Cin; a.C1 = 0; a.Cin = Cin; a.Cout = FD * FH * FW * Cout;
   a.KD = a.KH = a.KW = 1;
   a.SD = a.SH = a.SW = 1;
-  a.UPS = 1;
+  a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.Cs = Cout;
   a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);
@@ -502,7 +498,7 @@ extern "C" int adell_convtranspose3d_bwd_data_f16x3(int N, int D, int H, int W, 
   a.D = FD * D; a.H = FH * H; a.W = FW * W;
   a.C0 = Cout; a.C1 = 0; a.Cin = Cout; a.Cout = Cin;
   a.KD = a.SD = FD; a.KH = a.SH = FH; a.KW = a.SW = FW;
-  a.UPS = 1;
+  a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
   ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax};

@@ -30,7 +30,8 @@ struct ConvArgs {
   int D, H, W;        // real input dims
   int C0, C1, Cin, Cout;
   int KD, KH, KW, SD, SH, SW, PD, PH, PW;
-  int UPS;            // zero-insertion factor applied to the input (1 = none)
+  int UPS;            // zero-insertion factor applied to the input along x (1 = none)
+  int UPSY, UPSZ;     // ... along y and z
   int Do, Ho, Wo;     // GEMM-M spatial dims
   int lTX, lTY, lTZ;  // log2 of the output brick dims
   int ntx, nty, ntz;
@@ -99,11 +100,11 @@ __global__ __launch_bounds__(256) void adell_conv_igemm_kernel(ConvArgs a) {
       const int hx = rem - hy * a.HX;
       int rx = lx0 + hx, ry = ly0 + hy, rz = lz0 + hz;
       bool ok = (rx >= 0) & (ry >= 0) & (rz >= 0);
-      if (a.UPS > 1) {
-        ok = ok & (rx % a.UPS == 0) & (ry % a.UPS == 0) & (rz % a.UPS == 0);
+      if ((a.UPS | a.UPSY | a.UPSZ) > 1) {
+        ok = ok & (rx % a.UPS == 0) & (ry % a.UPSY == 0) & (rz % a.UPSZ == 0);
         rx /= a.UPS;
-        ry /= a.UPS;
-        rz /= a.UPS;
+        ry /= a.UPSY;
+        rz /= a.UPSZ;
       }
       ok = ok & (rx < a.W) & (ry < a.H) & (rz < a.D);
       const size_t gv = ((size_t)(nb * a.D + rz) * a.H + ry) * a.W + rx;

@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     const int hx = rem - hy * a.HX;
     int rx = lx0 + hx, ry = ly0 + hy, rz = lz0 + hz;
     bool ok = (rx >= 0) & (ry >= 0) & (rz >= 0);
-    if (a.UPS > 1) {
-      ok = ok & (rx % a.UPS == 0) & (ry % a.UPS == 0) & (rz % a.UPS == 0);
+    if ((a.UPS | a.UPSY | a.UPSZ) > 1) {
+      ok = ok & (rx % a.UPS == 0) & (ry % a.UPSY == 0) & (rz % a.UPSZ == 0);
       rx /= a.UPS;
-      ry /= a.UPS;
-      rz /= a.UPS;
+      ry /= a.UPSY;
+      rz /= a.UPSZ;
     }
     ok = ok & (rx < a.W) & (ry < a.H) & (rz < a.D);
 #pragma unroll

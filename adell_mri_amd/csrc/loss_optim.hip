@@ -18,6 +18,8 @@ struct LossArgs {
   int nblk;
   float smooth, dice_eps, gamma, focal_eps;
   float gdice, gfocal;  // d(total)/d(dice_b), d(total)/d(focal_b)
+  const float* gdice_dev;   // optional per-item device arrays [B] (override the scalars)
+  const float* gfocal_dev;
 };
 
 __device__ __forceinline__ float adell_powg(float x, float g) {
@@ -91,6 +93,8 @@ __global__ __launch_bounds__(256) void adell_dice_focal_bwd_kernel(LossArgs a) {
   const float num = a.sums[b * 3 + 0], den = a.sums[b * 3 + 1];
   const float inv_den2 = 1.0f / (den * den);
   const float invS = 1.0f / (float)a.S;
+  const float wd = a.gdice_dev ? a.gdice_dev[b] : a.gdice;
+  const float wf = a.gfocal_dev ? a.gfocal_dev[b] : a.gfocal;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < a.S; i += (long)gridDim.x * 256L) {
     const float pi = p[i], ti = t[i];
     const float dnum = (ti * pi > 0.f) ? ti : 0.f;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void adell_dice_focal_bwd_kernel(LossArgs a) {
         gf -= (1.f - tb) * (a.gamma * qg * logf(q) + qg);
       }
     }
-    dp[i] = a.gdice * gd + a.gfocal * (-gf * invS);
+    dp[i] = wd * gd + wf * (-gf * invS);
   }
 }
 
@@ -150,6 +154,26 @@ extern "C" int adell_dice_focal_bwd(const float* prob, const float* target, int 
   a.p = prob; a.t = target; a.sums = sums; a.dp = dprob; a.S = S;
   a.smooth = smooth; a.dice_eps = dice_eps; a.gamma = gamma; a.focal_eps = focal_eps;
   a.gdice = gdice; a.gfocal = gfocal;
+  long blocks = (S + 1023) / 1024;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adell_dice_focal_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// Same with the upstream gradients of every item on the device (gdice[B], gfocal[B]; either
+// may be NULL = 0): no host read-back of the autograd inputs.
+extern "C" int adell_dice_focal_bwd_dev(const float* prob, const float* target, int B, long S,
+                                        float smooth, float dice_eps, float gamma,
+                                        float focal_eps, const float* sums, const float* gdice,
+                                        const float* gfocal, float* dprob, void* stream) {
+  ADELL_REQUIRE(prob && target && sums && dprob, "dice_focal_bwd: null pointer");
+  ADELL_REQUIRE(B > 0 && S > 0, "dice_focal_bwd: bad dims");
+  LossArgs a = {};
+  a.p = prob; a.t = target; a.sums = sums; a.dp = dprob; a.S = S;
+  a.smooth = smooth; a.dice_eps = dice_eps; a.gamma = gamma; a.focal_eps = focal_eps;
+  a.gdice = 0.f; a.gfocal = 0.f; a.gdice_dev = gdice; a.gfocal_dev = gfocal;
   long blocks = (S + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adell_dice_focal_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0,

@@ -888,3 +888,114 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
     a.part[(((size_t)n * a.ntiles + blockIdx.x) * a.C + ch) * 2 + (q8 >> 2)] = s1;
   }
 }
+
+
+// ---------------------------------------------------------------------------
+// PReLU weight gradient (torch.nn.PReLU, the reference's default activation_fn:
+// unet.py:56, adn_fn.py:56-152): with u = dropout(norm(x)), y = u > 0 ? u : a*u, so
+// dL/da[c] = sum over the elements of channel c with u < 0 of dout * u. Column-sum layout:
+// grid (row chunks, groups of 64 channels), block = 64 channels x 4 row lanes, fixed order.
+// part: [chunks][C]; the caller folds it (adell_bias_grad-style) to [C] (and to one value
+// for a single-parameter PReLU).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_prelu_wgrad_partial_kernel(NormActBwdArgs a, int chunk) {
+  __shared__ float sh[4][64];
+  const long rows = a.total / a.C;
+  const long r0 = (long)blockIdx.x * chunk;
+  long r1 = r0 + chunk;
+  if (r1 > rows) r1 = rows;
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const int c = blockIdx.y * 64 + cl;
+  const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+  float s = 0.f;
+  if (c < a.C) {
+    for (long r = r0 + vl; r < r1; r += 4) {
+      const long n = r / a.V;
+      const long e = r * a.C + c;
+      float h = a.x[e];
+      if (a.mean) {
+        const long si = n * a.stat_stride_n + c;
+        h = (h - a.mean[si]) * a.rstd[si];
+      }
+      float t = h;
+      if (a.gamma) t *= a.gamma[c];
+      if (a.beta) t += a.beta[c];
+      bool keep[4];
+      adell_na_keep4(a, e >> 2, keep);
+      const float u = keep[e & 3] ? t * keep_scale : 0.f;
+      if (u < 0.f) s += a.dout[e] * u;
+    }
+  }
+  sh[vl][cl] = s;
+  __syncthreads();
+  if (vl == 0 && c < a.C)
+    a.part[(size_t)blockIdx.x * a.C + c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+
+__global__ __launch_bounds__(1024) void adell_prelu_wgrad_final_kernel(
+    const float* __restrict__ part, int nb, int C, int single, float* __restrict__ out) {
+  __shared__ double sh[16][64];
+  __shared__ double tot[64];
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  double grand = 0.0;
+  for (int cb = 0; cb < C; cb += 64) {   // one block walks every channel group (C <= ~1k)
+    const int c = cb + cl;
+    double s = 0.0;
+    if (c < C)
+      for (int b = vl; b < nb; b += 16) s += (double)part[(size_t)b * C + c];
+    sh[vl][cl] = s;
+    __syncthreads();
+    if (vl == 0) {
+      s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += sh[k][cl];
+      if (c < C && !single) out[c] = (float)s;
+      tot[cl] = c < C ? s : 0.0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 0; k < 64; ++k) grand += tot[k];
+    __syncthreads();
+  }
+  if (single && threadIdx.x == 0) out[0] = (float)grand;
+}
+
+static int adell_prelu_chunk(long rows) {
+  long chunk = (rows + 1023) / 1024;
+  if (chunk < 16) chunk = 16;
+  return (int)((chunk + 3) / 4 * 4);
+}
+
+extern "C" long adell_prelu_wgrad_workspace(const adell_norm_act_desc* d) {
+  if (!d || d->N <= 0 || d->V <= 0 || d->C <= 0) return ADELL_E_BADARG;
+  const long rows = d->N * d->V;
+  const int chunk = adell_prelu_chunk(rows);
+  return (long)sizeof(float) * ((rows + chunk - 1) / chunk) * d->C;
+}
+
+// dact_w: [act_w_n] (1 or C). Same descriptor / operands as adell_norm_act_bwd.
+extern "C" int adell_prelu_wgrad(const adell_norm_act_desc* d, const float* x, const float* dout,
+                                 const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, float* dact_w, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  NormActBwdArgs a = {};
+  int rc = adell_nab_fill(&a, d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(x && dout && dact_w && workspace, "prelu_wgrad: null pointer");
+  ADELL_REQUIRE(d->act == ADELL_ACT_PRELU && (d->act_w_n == 1 || d->act_w_n == d->C),
+                "prelu_wgrad: needs a PReLU with 1 or C parameters");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_prelu_wgrad_workspace(d),
+                "prelu_wgrad: workspace too small");
+  a.x = x; a.dout = dout; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
+  a.part = (float*)workspace;
+  const long rows = d->N * d->V;
+  const int chunk = adell_prelu_chunk(rows);
+  const int nb = (int)((rows + chunk - 1) / chunk);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_prelu_wgrad_partial_kernel, dim3(nb, adell_cdiv(d->C, 64)), dim3(256), 0,
+                     st, a, chunk);
+  hipLaunchKernelGGL(adell_prelu_wgrad_final_kernel, dim3(1), dim3(1024), 0, st,
+                     (const float*)workspace, nb, d->C, d->act_w_n == 1 ? 1 : 0, dact_w);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

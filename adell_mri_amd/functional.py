@@ -211,8 +211,11 @@ class _NormDropActFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, mean, rstd, gamma, beta, act_w = ctx.saved_tensors
         act, act_p, per_item, drop_p, seed, offset = ctx.conf
+        dact_w = None
         if act_w is not None and ctx.needs_input_grad[5]:
-            raise NotImplementedError("PReLU weight gradient is not implemented yet")
+            dact_w = ops.prelu_wgrad(x, dout, mean, rstd, act_w, gamma=gamma, beta=beta,
+                                     stats_per_item=per_item, drop_p=drop_p, seed=seed,
+                                     rng_offset=offset)
         want_affine = gamma is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
         dx, dgamma, dbeta = ops.norm_act_bwd(
             x, dout, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w, act_p=act_p,
@@ -220,7 +223,7 @@ class _NormDropActFn(torch.autograd.Function):
             want_affine_grads=want_affine)
         if beta is None:
             dbeta = None
-        return dx, None, None, dgamma, dbeta, None, None
+        return dx, None, None, dgamma, dbeta, dact_w, None
 
 
 def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=None,

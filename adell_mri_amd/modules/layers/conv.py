@@ -80,6 +80,20 @@ class ConvTranspose3d(torch.nn.ConvTranspose3d):
         return HF.conv_transpose3d(X, self.weight, self.bias)
 
 
+class ConvTranspose2d(torch.nn.ConvTranspose2d):
+    """2-D transposed convolution (kernel == stride) run as a depth-1 3-D one."""
+
+    def forward(self, X, output_size=None):
+        k, s = tuple(self.kernel_size), tuple(self.stride)
+        ok = (k == s and all(f in (1, 2) for f in k) and tuple(self.padding) == (0, 0)
+              and tuple(self.output_padding) == (0, 0) and self.groups == 1
+              and tuple(self.dilation) == (1, 1) and output_size is None)
+        if not ok:
+            raise AdellHipError("HIP ConvTranspose2d implements kernel == stride in {1,2}, padding 0; "
+                                f"got k={self.kernel_size} s={self.stride} p={self.padding}")
+        return HF.conv_transpose3d(X.unsqueeze(2), self.weight.unsqueeze(2), self.bias).squeeze(2)
+
+
 class MaxPool3d(torch.nn.MaxPool3d):
     def forward(self, X):
         if self.ceil_mode or self.return_indices or ops_triple(self.dilation) != (1, 1, 1):

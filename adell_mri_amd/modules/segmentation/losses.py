@@ -29,19 +29,9 @@ class DiceFocalFn(torch.autograd.Function):
     def backward(ctx, gdice, gfocal):
         pred, target, sums = ctx.saved_tensors
         smooth, dice_eps, gamma, focal_eps = ctx.conf
-        # mean()-style reductions hand every item the same upstream gradient,
-        # which is what the kernel takes (one scalar per loss).
-        gd_l = [0.0] * pred.shape[0] if gdice is None else gdice.tolist()
-        gf_l = [0.0] * pred.shape[0] if gfocal is None else gfocal.tolist()
-        if len(set(gd_l)) == 1 and len(set(gf_l)) == 1:
-            dp = ops.dice_focal_bwd(pred, target, sums, smooth, dice_eps, gamma, focal_eps,
-                                    gd_l[0], gf_l[0])
-        else:
-            dp = torch.empty_like(pred)
-            for b in range(pred.shape[0]):
-                dp[b:b + 1] = ops.dice_focal_bwd(pred[b:b + 1], target[b:b + 1], sums[b:b + 1],
-                                                 smooth, dice_eps, gamma, focal_eps, gd_l[b],
-                                                 gf_l[b])
+        # per-item upstream gradients stay on the device (no host read-back / sync)
+        dp = ops.dice_focal_bwd_dev(pred, target, sums, smooth, dice_eps, gamma, focal_eps,
+                                    gdice, gfocal)
         return dp, None, None, None, None, None
 
 

@@ -22,7 +22,7 @@ import torch
 from ... import functional as HF
 from ..._lib import AdellHipError
 from ..layers.adn_fn import ActDropNorm, norm_fn_dict
-from ..layers.conv import Conv2d, Conv3d, ConvTranspose3d, MaxPool3d
+from ..layers.conv import Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool3d
 from ..layers.regularization import UOut
 from ..layers.res_blocks import ResidualBlock3d
 from ..layers.utils import crop_to_size
@@ -202,12 +202,11 @@ class UNet(torch.nn.Module):
         if self.upscale_type != "transpose":
             raise NotImplementedError("upscale_type='upsample' is outside the HIP path built so "
                                       "far (all BASELINE configs use 'transpose')")
-        if self.spatial_dimensions != 3:
-            raise NotImplementedError("2-D transposed convolution has no HIP kernel yet")
+        convt = ConvTranspose3d if self.spatial_dimensions == 3 else ConvTranspose2d
         for d1, d2, s in zip(depths_a, depths_b, self.strides[::-1][1:]):
             s = _per_dim(s, self.spatial_dimensions)
             p = [int(np.maximum(i - 2, 0)) for i in s]
-            ops_.append(ConvTranspose3d(d1, d2, s, stride=s, padding=p))
+            ops_.append(convt(d1, d2, s, stride=s, padding=p))
         self.upscale_ops = torch.nn.ModuleList(ops_)
 
     def init_link_ops(self):
@@ -303,6 +302,8 @@ class UNet(torch.nn.Module):
         if return_logits is True:
             return X
         if isinstance(mods[-1], torch.nn.Sigmoid):
+            if X.dim() == 4:  # 2-D network: depth-1 volume
+                return HF.norm_drop_act(X.unsqueeze(2), act="sigmoid").squeeze(2)
             return HF.norm_drop_act(X, act="sigmoid")
         # Softmax over the class axis of one small [B, n_classes, ...] tensor
         return mods[-1](X)

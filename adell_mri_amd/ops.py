@@ -503,6 +503,21 @@ def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.
     return out
 
 
+def prelu_wgrad(x, dout, mean, rstd, act_w, gamma=None, beta=None, stats_per_item=1, drop_p=0.0,
+                seed=0, rng_offset=0):
+    """Gradient of the PReLU weight(s) of norm -> dropout -> PReLU (same operands as
+    norm_act_bwd)."""
+    _require_cuda(x, dout, mean, rstd, gamma, beta, act_w)
+    x, dout = ndhwc(x), ndhwc(dout)
+    d = make_na_desc(x, "prelu", stats_per_item, 0.0, act_w.numel(), drop_p, seed, rng_offset)
+    ws = _workspace(_lib.lib().adell_prelu_wgrad_workspace(ctypes.byref(d)), x.device)
+    dw = torch.empty_like(act_w)
+    check(_lib.lib().adell_prelu_wgrad(ctypes.byref(d), _ptr(x), _ptr(dout), _ptr(mean), _ptr(rstd),
+                                       _ptr(gamma), _ptr(beta), _ptr(dw), _ptr(ws),
+                                       ws.numel() * 4, _stream()))
+    return dw
+
+
 def norm_act_bwd(x, dout, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.0,
                  stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0, want_affine_grads=False):
     """dx (and dgamma, dbeta when want_affine_grads) of norm_act_fwd."""
@@ -550,6 +565,20 @@ def dice_focal_bwd(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice
     check(_lib.lib().adell_dice_focal_bwd(_ptr(prob), _ptr(target), B, S, smooth, dice_eps, gamma,
                                           focal_eps, _ptr(sums), float(gdice), float(gfocal),
                                           _ptr(dprob), _stream()))
+    return dprob
+
+
+def dice_focal_bwd_dev(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice, gfocal):
+    """gdice / gfocal: per-item upstream gradients as CUDA tensors [B] (or None)."""
+    prob, target = prob.contiguous(), target.contiguous()
+    B = prob.shape[0]
+    S = prob.numel() // B
+    dprob = torch.empty_like(prob)
+    gd = None if gdice is None else gdice.contiguous().float()
+    gf = None if gfocal is None else gfocal.contiguous().float()
+    check(_lib.lib().adell_dice_focal_bwd_dev(_ptr(prob), _ptr(target), B, S, smooth, dice_eps,
+                                              gamma, focal_eps, _ptr(sums), _ptr(gd), _ptr(gf),
+                                              _ptr(dprob), _stream()))
     return dprob
 
 

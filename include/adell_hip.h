@@ -230,6 +230,12 @@ int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x, const float
                        const float* beta, const float* act_w, float* dx, float* dgamma,
                        float* dbeta, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* Gradient of the PReLU weight(s) of the same fused op (torch.nn.PReLU is the reference's
+ * default activation_fn): dact_w[act_w_n] with act_w_n = 1 or C; operands as above. */
+long adell_prelu_wgrad_workspace(const adell_norm_act_desc* d);
+int adell_prelu_wgrad(const adell_norm_act_desc* d, const float* x, const float* dout,
+                      const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      float* dact_w, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Segmentation loss: binary generalised dice + binary focal on probabilities
@@ -249,6 +255,11 @@ int adell_dice_focal_bwd(const float* prob, const float* target, int B, long S,
                          float smooth, float dice_eps, float gamma, float focal_eps,
                          const float* sums, float gdice, float gfocal, float* dprob,
                          void* stream);
+/* the same with per-item upstream gradients on the device (gdice[B], gfocal[B], NULL = 0) */
+int adell_dice_focal_bwd_dev(const float* prob, const float* target, int B, long S, float smooth,
+                             float dice_eps, float gamma, float focal_eps, const float* sums,
+                             const float* gdice, const float* gfocal, float* dprob,
+                             void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimiser / EMA updates over flat fp32 buffers (16-byte aligned).

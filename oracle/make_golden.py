@@ -79,6 +79,18 @@ UNET_CASES = {
 }
 
 
+UNET2D_CASES = {
+    # BASELINE configs[0]: the 2-D U-Net of the reference's own testing/test_unet.py:63-72 with
+    # the constructor defaults (BatchNorm2d, PReLU), 140 748 parameters. train() for batch
+    # statistics; dropout_param (default 0.1) is 0 because torch's dropout stream cannot be
+    # reproduced
+    "unet2d_cfg1": (dict(spatial_dimensions=2, depth=[16, 32, 64], upscale_type="transpose",
+                         padding="same", strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
+                         conv_type="regular", link_type="identity", activation_fn="prelu",
+                         dropout_param=0.0, _train=True), (2, 1, 64, 64), "uniform"),
+}
+
+
 UNETR_CASES = {
     "unetr3d_small": (dict(image_size=[32, 32, 32], patch_size=[8, 8, 8], number_of_blocks=4,
                            return_at=[1, 2], embedding_size=64, attention_dim=64, hidden_dim=64,
@@ -153,6 +165,7 @@ def make_unet(kw):
     if kw.get("_cls") == "backbone":
         return make_backbone_unet(kw)
     kw = dict(kw)
+    kw.pop("_train", None)
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
     cls = {"unetpp": UNetPlusPlus, "swin": SWINUNet}.get(
         kw.pop("_cls", None), UNETR if "patch_size" in kw else UNet)
@@ -169,7 +182,7 @@ def gen_unet(name, kw, shape, dist):
     net = make_unet(kw)
     # eval(): dropout off, instance norm unaffected; the backbone case runs in train() so that
     # its BatchNorm layers use batch statistics (dropout_param is 0 there)
-    net = net.train() if kw.get("_cls") == "backbone" else net.eval()
+    net = net.train() if (kw.get("_cls") == "backbone" or kw.get("_train")) else net.eval()
     out = {"x": x.numpy(), "y": y.numpy()}
     # forward parity target: logits (north_star: within 1e-4 rel)
     logits = net(x, return_logits=True)[0]
@@ -342,11 +355,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ssl":
         gen_ssl()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "unet2d":
+        for name, (kw, shape, dist) in UNET2D_CASES.items():
+            gen_unet(name, kw, shape, dist)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         for name, (kw, shape, dist) in SWIN_CASES.items():
             gen_unet(name, kw, shape, dist)
         sys.exit(0)
-    for name, (kw, shape, dist) in {**UNET_CASES, **UNETR_CASES, **UNETPP_CASES,
+    for name, (kw, shape, dist) in {**UNET_CASES, **UNET2D_CASES, **UNETR_CASES, **UNETPP_CASES,
                                     **BACKBONE_CASES, **SWIN_CASES}.items():
         gen_unet(name, kw, shape, dist)
     gen_blocks()
