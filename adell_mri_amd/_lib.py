@@ -88,8 +88,10 @@ SIGNATURES = {
     "adell_layernorm_bwd": (_i, [_vp] * 8 + [_l, _i, _vp, ctypes.c_size_t, _vp]),
     "adell_add_bcast": (_i, [_vp, _vp, _vp, _l, _l, _vp]),
     "adell_sum_bcast": (_i, [_vp, _vp, _l, _l, _vp]),
-    "adell_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
-    "adell_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "adell_attention_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, ctypes.c_ulonglong,
+                                 ctypes.c_uint, _vp, _vp, _vp]),
+    "adell_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f,
+                                 ctypes.c_ulonglong, ctypes.c_uint, _vp, _vp, _vp, _vp]),
     "adell_copy_channels": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "adell_interp_nearest_fwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
     "adell_interp_nearest_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),

@@ -221,7 +221,20 @@ struct AttArgs {
   float* dv;
   int T, A, Dv, nbias;
   float scale;
+  float drop_p;      // attention-probability dropout (0 = off)
+  uint32_t seed_lo, seed_hi, rng_offset;
 };
+
+// Keep decision of probability (bh, qrow, kcol): a pure function of the seed, so the two
+// backward kernels regenerate the mask the forward applied.
+__device__ __forceinline__ bool adell_att_keep(const AttArgs& a, int bh, int qrow, int kcol) {
+  if (a.drop_p <= 0.f) return true;
+  const uint64_t e = ((uint64_t)bh * a.T + qrow) * a.T + kcol;
+  const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34), a.rng_offset, 2u,
+                                a.seed_lo, a.seed_hi);
+  const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+  return (float)(rr[e & 3] >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
+}
 
 __global__ __launch_bounds__(256) void adell_attention_fwd_kernel(AttArgs a) {
   extern __shared__ float sh[];
@@ -251,6 +264,7 @@ __global__ __launch_bounds__(256) void adell_attention_fwd_kernel(AttArgs a) {
     for (int d = 0; d < MAXD; ++d) acc[r][d] = 0.f;
   }
   const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   for (int k0 = 0; k0 < a.T; k0 += ATT_TK) {
     __syncthreads();
     for (int i = threadIdx.x; i < ATT_TK * a.A; i += 256) {
@@ -282,7 +296,10 @@ __global__ __launch_bounds__(256) void adell_attention_fwd_kernel(AttArgs a) {
       const float psum = adell_wave_sum(p);
       l[r] = l[r] * corr + psum;
       m[r] = mnew;
-      sP[wave * ATT_TK + lane] = p;
+      // dropout acts on the normalised probabilities: l keeps the full sum, the PV product
+      // sees the kept entries scaled by 1/(1-p)
+      sP[wave * ATT_TK + lane] =
+          (p != 0.f && adell_att_keep(a, bh, qrow, k0 + lane)) ? p * keep_scale : 0.f;
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int d = 0; d < MAXD; ++d) {
@@ -352,6 +369,7 @@ __global__ __launch_bounds__(256) void adell_attention_bwd_q_kernel(AttArgs a) {
     for (int d = 0; d < MAXA; ++d) acc[r][d] = 0.f;
   }
   const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   for (int k0 = 0; k0 < a.T; k0 += ATT_TK) {
     __syncthreads();
     for (int i = threadIdx.x; i < ATT_TK * a.A; i += 256) {
@@ -377,6 +395,7 @@ __global__ __launch_bounds__(256) void adell_attention_bwd_q_kernel(AttArgs a) {
         const float p = expf(s - lse[r]);
         float dp = 0.f;
         for (int c = 0; c < a.Dv; ++c) dp += gr[c] * sV[lane * DP + c];
+        dp = adell_att_keep(a, bh, qrow, k0 + lane) ? dp * keep_scale : 0.f;
         ds = p * (dp - Dr[r]);
       }
       sP[wave * ATT_TK + lane] = ds;
@@ -439,6 +458,7 @@ __global__ __launch_bounds__(256) void adell_attention_bwd_kv_kernel(AttArgs a) 
 #pragma unroll
     for (int d = 0; d < MAXC; ++d) dk[r][d] = dv[r][d] = 0.f;
   const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   for (int q0 = 0; q0 < a.T; q0 += ATT_TK) {
     __syncthreads();
     for (int i = threadIdx.x; i < ATT_TK * a.A; i += 256) {
@@ -476,7 +496,9 @@ __global__ __launch_bounds__(256) void adell_attention_bwd_kv_kernel(AttArgs a) 
         p = expf(s - sL[lane * 2 + 0]);
         float dp = 0.f;
         for (int c = 0; c < a.Dv; ++c) dp += vr[c] * sdO[lane * DP + c];
-        ds = p * (dp - sL[lane * 2 + 1]);
+        const float km = adell_att_keep(a, bh, q0 + lane, krow) ? keep_scale : 0.f;
+        ds = p * (dp * km - sL[lane * 2 + 1]);
+        p *= km;  // dV sees the dropped probabilities
       }
       sP[(wave * 2 + 0) * ATT_TK + lane] = p;
       sP[(wave * 2 + 1) * ATT_TK + lane] = ds;
@@ -530,13 +552,18 @@ static int adell_att_launch(K kern, const AttArgs& a, int BH, size_t lds, hipStr
 
 extern "C" int adell_attention_fwd(const float* q, const float* k, const float* v,
                                    const float* bias, int nbias, int BH, int T, int A, int Dv,
-                                   float scale, float* out, float* lse, void* stream) {
+                                   float scale, float drop_p, unsigned long long seed,
+                                   unsigned int rng_offset, float* out, float* lse,
+                                   void* stream) {
   int rc = adell_att_check(BH, T, A, Dv, nbias, bias);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(q && k && v && out && lse, "attention_fwd: null pointer");
   AttArgs a = {};
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.out = out; a.lse_out = lse;
   a.T = T; a.A = A; a.Dv = Dv; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale;
+  ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
+  a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  a.rng_offset = rng_offset;
   const size_t lds = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * Dv +
                                       (size_t)ATT_ROWS * A + 4 * ATT_TK);
   return adell_att_launch(adell_attention_fwd_kernel, a, BH, lds, (hipStream_t)stream);
@@ -545,7 +572,8 @@ extern "C" int adell_attention_fwd(const float* q, const float* k, const float* 
 extern "C" int adell_attention_bwd(const float* q, const float* k, const float* v,
                                    const float* bias, int nbias, const float* out,
                                    const float* dout, const float* lse, int BH, int T, int A,
-                                   int Dv, float scale, float* dq, float* dk, float* dv,
+                                   int Dv, float scale, float drop_p, unsigned long long seed,
+                                   unsigned int rng_offset, float* dq, float* dk, float* dv,
                                    void* stream) {
   int rc = adell_att_check(BH, T, A, Dv, nbias, bias);
   if (rc != ADELL_OK) return rc;
@@ -554,6 +582,9 @@ extern "C" int adell_attention_bwd(const float* q, const float* k, const float* 
   a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = out; a.dout = dout; a.lse = lse;
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.T = T; a.A = A; a.Dv = Dv; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale;
+  ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
+  a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  a.rng_offset = rng_offset;
   const size_t lds_q = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * (Dv + 1) +
                                         (size_t)ATT_ROWS * A + (size_t)ATT_ROWS * Dv + 4 * ATT_TK);
   rc = adell_att_launch(adell_attention_bwd_q_kernel, a, BH, lds_q, (hipStream_t)stream);

@@ -566,11 +566,11 @@ def add_bcast(a, b):
 
 class _AttentionFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, bias, scale):
+    def forward(ctx, q, k, v, bias, scale, drop):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out, lse = ops.attention_fwd(q, k, v, bias, scale)
+        out, lse = ops.attention_fwd(q, k, v, bias, scale, *drop)
         ctx.save_for_backward(q, k, v, bias, out, lse)
-        ctx.scale = scale
+        ctx.scale, ctx.drop = scale, drop
         return out
 
     @staticmethod
@@ -578,15 +578,18 @@ class _AttentionFn(torch.autograd.Function):
         q, k, v, bias, out, lse = ctx.saved_tensors
         if bias is not None and ctx.needs_input_grad[3]:
             raise NotImplementedError("attention bias gradient (SWIN relative positions): next row")
-        dq, dk, dv = ops.attention_bwd(q, k, v, bias, out, dout, lse, ctx.scale)
-        return dq, dk, dv, None, None
+        dq, dk, dv = ops.attention_bwd(q, k, v, bias, out, dout, lse, ctx.scale, *ctx.drop)
+        return dq, dk, dv, None, None, None
 
 
-def attention(q, k, v, bias=None, scale=None):
-    """softmax(q k^T * scale + bias) v for q,k [BH,T,A], v [BH,T,Dv]."""
+def attention(q, k, v, bias=None, scale=None, drop_p=0.0, training=False):
+    """dropout(softmax(q k^T * scale + bias)) v for q,k [BH,T,A], v [BH,T,Dv]."""
     if scale is None:
         scale = 1.0 / (q.shape[-1] ** 0.5)
-    return _AttentionFn.apply(q, k, v, bias, float(scale))
+    drop = (0.0, 0, 0)
+    if training and drop_p > 0:
+        drop = (float(drop_p), torch.initial_seed(), next(_dropout_counter))
+    return _AttentionFn.apply(q, k, v, bias, float(scale), drop)
 
 
 # ---- data movement with autograd (U-Net++ dense links) ---------------------------------------

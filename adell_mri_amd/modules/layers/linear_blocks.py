@@ -143,9 +143,6 @@ class MultiHeadSelfAttention(torch.nn.Module):
                                     drop_p=self.dropout_rate, training=self.training,
                                     eps=self.q_norm.eps)
             return self.output_layer(O.view(*b, t, self.hidden_dim), residual=residual)
-        if self.training and self.dropout_rate > 0:
-            raise NotImplementedError("attention-probability dropout beyond 64 tokens has no "
-                                      "HIP kernel yet")
         if self.window_size:
             raise NotImplementedError("windowed attention beyond 64 tokens per window")
         QKV = self.qkv(X).reshape(nb, t, self.n_heads, 2 * a + h).permute(0, 2, 1, 3)
@@ -159,6 +156,7 @@ class MultiHeadSelfAttention(torch.nn.Module):
                 m = m.unsqueeze(1)
             bias = m.expand(nb, self.n_heads, t, t).reshape(nb * self.n_heads, t, t)
         O = HF.attention(Q.reshape(nb * self.n_heads, t, a), K.reshape(nb * self.n_heads, t, a),
-                         V.reshape(nb * self.n_heads, t, h), bias)
+                         V.reshape(nb * self.n_heads, t, h), bias, drop_p=self.dropout_rate,
+                         training=self.training)
         O = O.reshape(nb, self.n_heads, t, h).transpose(1, 2).reshape(*b, t, self.hidden_dim)
         return self.output_layer(O, residual=residual)

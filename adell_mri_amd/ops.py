@@ -662,7 +662,7 @@ def sum_bcast(g, period_shape):
     return db
 
 
-def attention_fwd(q, k, v, bias, scale):
+def attention_fwd(q, k, v, bias, scale, drop_p=0.0, seed=0, offset=0):
     """q,k: [BH,T,A]; v: [BH,T,Dv]; bias: [nbias,T,T] or None. Returns (out, lse)."""
     _require_cuda(q, k, v, bias)
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
@@ -675,11 +675,13 @@ def attention_fwd(q, k, v, bias, scale):
         bias = bias.contiguous()
         nb = bias.numel() // (T * T)
     check(_lib.lib().adell_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, BH, T, A, Dv,
-                                         float(scale), _ptr(out), _ptr(lse), _stream()))
+                                         float(scale), float(drop_p),
+                                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF,
+                                         _ptr(out), _ptr(lse), _stream()))
     return out, lse
 
 
-def attention_bwd(q, k, v, bias, out, dout, lse, scale):
+def attention_bwd(q, k, v, bias, out, dout, lse, scale, drop_p=0.0, seed=0, offset=0):
     BH, T, A = q.shape
     Dv = v.shape[-1]
     dout = dout.contiguous()
@@ -687,6 +689,8 @@ def attention_bwd(q, k, v, bias, out, dout, lse, scale):
     nb = 0 if bias is None else bias.numel() // (T * T)
     check(_lib.lib().adell_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, _ptr(out),
                                          _ptr(dout), _ptr(lse), BH, T, A, Dv, float(scale),
+                                         float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                         int(offset) & 0xFFFFFFFF,
                                          _ptr(dq), _ptr(dk), _ptr(dv), _stream()))
     return dq, dk, dv
 

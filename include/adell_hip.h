@@ -299,13 +299,17 @@ int adell_add_bcast(const float* a, const float* b, float* out, long n, long per
 int adell_sum_bcast(const float* g, float* db, long n, long period, void* stream);
 /* softmax(q k^T * scale + bias) v per sequence: q,k [BH][T][A]; v,out [BH][T][Dv];
  * bias [nbias][T][T] or NULL (sequence bh uses bias[bh % nbias]); lse [BH][T].
+ * drop_p > 0 drops attention probabilities (dropout_p of the same call): the mask of entry
+ * (bh, query, key) is a Philox function of (seed, rng_offset), regenerated by the backward.
  * F.scaled_dot_product_attention as called at linear_blocks.py:407-414. */
 int adell_attention_fwd(const float* q, const float* k, const float* v, const float* bias,
-                        int nbias, int BH, int T, int A, int Dv, float scale, float* out,
+                        int nbias, int BH, int T, int A, int Dv, float scale, float drop_p,
+                        unsigned long long seed, unsigned int rng_offset, float* out,
                         float* lse, void* stream);
 int adell_attention_bwd(const float* q, const float* k, const float* v, const float* bias,
                         int nbias, const float* out, const float* dout, const float* lse,
-                        int BH, int T, int A, int Dv, float scale, float* dq, float* dk,
+                        int BH, int T, int A, int Dv, float scale, float drop_p,
+                        unsigned long long seed, unsigned int rng_offset, float* dq, float* dk,
                         float* dv, void* stream);
 
 /* ------------------------------------------------------------------------

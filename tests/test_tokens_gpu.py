@@ -87,6 +87,64 @@ def test_attention_fwd_bwd_matches_manual_softmax(cuda, BH, T, A, Dv, use_bias):
     assert _rel(vd.grad.cpu(), v.grad) < 5e-5
 
 
+@pytest.mark.parametrize("BH,T,A,Dv,use_bias", [(8, 216, 64, 64, False), (3, 70, 16, 24, True)])
+def test_attention_dropout_fwd_bwd_matches_masked_softmax(cuda, BH, T, A, Dv, use_bias):
+    """dropout_p of the scaled_dot_product_attention call (linear_blocks.py:407-414): V = identity
+    exposes the dropped probabilities, i.e. the mask the kernel drew for (seed, offset); the
+    forward and the three gradients with random V then have to match torch CPU autograd on
+    (softmax(S) * mask / (1 - p)) V with that same mask."""
+    from adell_mri_amd import ops
+    g = torch.Generator().manual_seed(3)
+    p_drop, seed, offset = 0.1, 1234567891011, 7
+    q = torch.randn(BH, T, A, generator=g).requires_grad_(True)
+    k = torch.randn(BH, T, A, generator=g).requires_grad_(True)
+    v = torch.randn(BH, T, Dv, generator=g).requires_grad_(True)
+    bias = torch.randn(BH, T, T, generator=g) if use_bias else None
+    do = torch.randn(BH, T, Dv, generator=g)
+    scale = 1.0 / A ** 0.5
+    bd = None if bias is None else bias.to(cuda)
+    qd, kd, vd = (t.detach().to(cuda) for t in (q, k, v))
+    eye = torch.eye(T, device=cuda).expand(BH, T, T).contiguous()
+    pt, _ = ops.attention_fwd(qd, kd, eye, bd, scale, p_drop, seed, offset)
+    p0, _ = ops.attention_fwd(qd, kd, eye, bd, scale)
+    kept = pt != 0
+    frac = kept.float().mean().item()
+    assert abs(frac - (1 - p_drop)) < 0.01, frac
+    assert torch.allclose(pt[kept], p0[kept] / (1 - p_drop), rtol=1e-5, atol=1e-8)
+    # a different offset draws a different mask
+    pt2, _ = ops.attention_fwd(qd, kd, eye, bd, scale, p_drop, seed, offset + 1)
+    assert ((pt2 != 0) != kept).float().mean().item() > 0.05
+    mask = kept.cpu().float() / (1 - p_drop)
+    s = q @ k.transpose(-1, -2) * scale
+    if bias is not None:
+        s = s + bias
+    ref = (torch.softmax(s, -1) * mask) @ v
+    ref.backward(do)
+    out, lse = ops.attention_fwd(qd, kd, vd, bd, scale, p_drop, seed, offset)
+    dq, dk, dv = ops.attention_bwd(qd, kd, vd, bd, out, do.to(cuda), lse, scale, p_drop, seed,
+                                   offset)
+    assert _rel(out.cpu(), ref.detach()) < 1e-5
+    assert _rel(dq.cpu(), q.grad) < 5e-5
+    assert _rel(dk.cpu(), k.grad) < 5e-5
+    assert _rel(dv.cpu(), v.grad) < 5e-5
+
+
+def test_mhsa_attention_dropout_trains_beyond_window_size(cuda):
+    """unetr.yaml ships dropout_rate 0.1 with 216 tokens: training mode runs, is seeded, and
+    eval mode is dropout-free."""
+    mha = _load(MultiHeadSelfAttention(32, 32, 48, 32, n_heads=4, dropout_rate=0.25)).to(cuda)
+    x = torch.randn(2, 100, 32, generator=torch.Generator().manual_seed(0)).to(cuda)
+    mha.train()
+    y1 = mha(x)
+    y2 = mha(x)
+    assert not torch.equal(y1, y2)
+    y1.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in mha.parameters() if p.grad is not None)
+    mha.eval()
+    with torch.no_grad():
+        assert torch.equal(mha(x), mha(x))
+
+
 def _load(mod):
     mod.load_state_dict({k: torch.from_numpy(tensor_for(k, v.shape))
                          for k, v in mod.state_dict().items()})
