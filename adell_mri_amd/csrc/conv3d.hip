@@ -342,17 +342,17 @@ extern "C" int adell_pack_weight(const float* w, float* out, int mode, int dim0,
 // ---------------------------------------------------------------------------
 // f16x3 path (conv_igemm_f16.h): fp32 tensors in and out, 3 f16 MFMAs per K-block.
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN>
+template <int MT, int NT, int WM, int WN, int SPEC>
 static int adell_launch_conv_f16(const ConvArgs& a, const ConvF16Extra& e, dim3 grid, size_t lds,
                                  hipStream_t st) {
   static bool attr_done = false;
-  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN>;
+  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN, SPEC>;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, e);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, a, e);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
@@ -375,7 +375,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     // weights are staged one kz plane at a time, or row by row when a plane is too big
     a.GKH = ((size_t)a.KH * a.KW * t.BN * 64 <= 40 * 1024) ? a.KH : 1;
     lds = (size_t)a.VP * 64 + (size_t)a.GKH * a.KW * t.BN * 64 + 64;
-    const size_t red = (size_t)4 * t.BN * 2 * sizeof(float);
+    const size_t red = (size_t)8 * t.BN * 2 * sizeof(float);
     if (lds < red) lds = red;
     if (lds <= 160 * 1024) break;
     const int next = t.BN == 64 ? 2 : 3;
@@ -399,17 +399,44 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
            (((uintptr_t)a.x1 & 15) == 0);
   a.vecw = 1;
+  e.dbg = getenv("ADELL_IGEMM_DBG") ? atoi(getenv("ADELL_IGEMM_DBG")) : 0;
   const long nsp = (long)a.ntx * a.nty * a.ntz;
-  if (nsp > 0x7fffffffL || N > 65535) {
+  if (nsp > 0x0fffffffL || N > 65535) {
     adell_set_error("conv: grid too large");
     return ADELL_E_UNSUPPORTED;
   }
-  dim3 grid((unsigned)nsp, (unsigned)adell_cdiv(a.Cout, t.BN), (unsigned)N);
+  {
+    // the epilogue addresses rows inside a brick with 32-bit element offsets
+    const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1,
+              fz = ((a.shuffle >> 2) & 1) + 1;
+    const size_t span = ((size_t)fz << a.lTZ) * ((size_t)fy * a.Ho) * ((size_t)fx * a.Wo) *
+                        (size_t)(a.shuffle ? a.Cs : a.Cout);
+    if (span >= ((size_t)1 << 32)) {
+      adell_set_error("conv f16x3: a brick of %d output planes spans %zu elements (>= 2^32)",
+                      1 << a.lTZ, span);
+      return ADELL_E_UNSUPPORTED;
+    }
+  }
+  // blocks are dealt to the 8 XCDs in contiguous ranges (see the kernel): pad the grid
+  dim3 grid((unsigned)(8 * ((nsp + 7) / 8)), (unsigned)adell_cdiv(a.Cout, t.BN), (unsigned)N);
+  const bool spec = a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 &&
+                    a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.lTX == 3 && a.lTY == 3 &&
+                    a.lTZ == 2 && a.shuffle == 0 && a.vecx && a.GKH == 3 && t.cfg <= 1 &&
+                    a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
+                    (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
+                    getenv("ADELL_IGEMM_NOSPEC") == nullptr;
+  const bool w8 = getenv("ADELL_IGEMM_W8") != nullptr;   // experiment: 8-wave blocks (measured slower)
   switch (t.cfg) {
-    case 0: return adell_launch_conv_f16<2, 2, 4, 1>(a, e, grid, lds, st);
-    case 1: return adell_launch_conv_f16<2, 1, 4, 1>(a, e, grid, lds, st);
-    case 2: return adell_launch_conv_f16<1, 1, 2, 2>(a, e, grid, lds, st);
-    default: return adell_launch_conv_f16<1, 1, 4, 1>(a, e, grid, lds, st);
+    case 0:
+      if (spec && w8) return adell_launch_conv_f16<1, 2, 8, 1, 1>(a, e, grid, lds, st);
+      return spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
+                  : adell_launch_conv_f16<2, 2, 4, 1, 0>(a, e, grid, lds, st);
+    case 1:
+      if (spec && w8) return adell_launch_conv_f16<1, 1, 8, 1, 1>(a, e, grid, lds, st);
+      return spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)
+                  : adell_launch_conv_f16<2, 1, 4, 1, 0>(a, e, grid, lds, st);
+    case 2: return adell_launch_conv_f16<1, 1, 2, 2, 0>(a, e, grid, lds, st);
+    default: return adell_launch_conv_f16<1, 1, 4, 1, 0>(a, e, grid, lds, st);
   }
 }
 
@@ -455,7 +482,7 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
   int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
@@ -481,7 +508,7 @@ extern "C" int adell_convtranspose3d_fwd_f16x3(int N, int D, int H, int W, int C
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.Cs = Cout;
   a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
   return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
 }
 
@@ -501,7 +528,7 @@ extern "C" int adell_convtranspose3d_bwd_data_f16x3(int N, int D, int H, int W, 
   a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
   return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
 }
 
@@ -513,6 +540,6 @@ extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const flo
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }

@@ -22,14 +22,28 @@
 //   sA[halo voxel][hi c0..7 | hi c8..15 | lo c0..7 | lo c8..15]
 //   sB[tap of one kz plane][n][same four slots]
 #pragma once
+#include <type_traits>
 #include "conv_igemm.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// A pointer the caller knows to be wave-uniform, pinned into SGPRs so that `p + (unsigned)offset`
+// becomes one scalar-base + 32-bit-VGPR-offset access instead of a 64-bit per-lane pointer (which
+// the compiler would hoist out of the loops, one register pair per access, and spill).
+__device__ __forceinline__ const char* adell_uniform_ptr(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 
 struct ConvF16Extra {
   const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
   const float* wscale;   // [Cout] 2^-kw[n]: undoes the per-output-channel weight scale
   unsigned* amax_out;    // optional: receives the absmax (float bits) of the input tensor(s)
+  int dbg;               // timing experiments (ADELL_IGEMM_DBG, tools/igemm_dbg.py): results are
+                         // wrong when nonzero. 1: halo staged for chunk 0 only; 2: weights staged
+                         // for the first tap group only; 8: no MFMAs; 16: no output stores
 };
 
 __device__ __forceinline__ void adell_split8(const float* v, float scale, half8* hi, half8* lo) {
@@ -42,36 +56,49 @@ __device__ __forceinline__ void adell_split8(const float* v, float scale, half8*
   }
 }
 
-#ifndef ADELL_IGEMM_PIPE
-#define ADELL_IGEMM_PIPE 0
-#endif
-#ifndef ADELL_IGEMM_ONESET
-#define ADELL_IGEMM_ONESET 0
-#endif
-
-template <int MT, int NT, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
+// SPEC = 1 is the instance for the configuration that carries the FLOPs of a U-Net: 3x3x3 taps,
+// stride 1, no zero insertion, 8x8x4 output brick (10x10x6 halo), 16-byte-aligned channel
+// counts, plain store. Every index of the halo, tap and epilogue arithmetic is then a
+// compile-time constant (no integer divisions in the loops, tap loop fully unrolled).
+// SPEC = 0 takes all of them from ConvArgs.
+template <int MT, int NT, int WM, int WN, int SPEC>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2)
+void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
+  constexpr int NW = WM * WN, NTHR = NW * 64;  // 4 waves (2 blocks per CU) or 8 (4 waves per SIMD)
+  const int lTX = SPEC ? 3 : a.lTX, lTY = SPEC ? 3 : a.lTY, lTZ = SPEC ? 2 : a.lTZ;
+  const int HX = SPEC ? 10 : a.HX, HY = SPEC ? 10 : a.HY, HZ = SPEC ? 6 : a.HZ;
+  const int KD = SPEC ? 3 : a.KD, KH = SPEC ? 3 : a.KH, KW = SPEC ? 3 : a.KW;
+  const int SD = SPEC ? 1 : a.SD, SH = SPEC ? 1 : a.SH, SW = SPEC ? 1 : a.SW;
+  const int GKH = SPEC ? 3 : a.GKH;
+  const int shuffle = SPEC ? 0 : a.shuffle;
   extern __shared__ float smem[];
   char* sA = reinterpret_cast<char*>(smem);
-  const int HV = a.HX * a.HY * a.HZ;
+  const int HV = HX * HY * HZ;
   char* sB = sA + (size_t)HV * 64;
-  float* sMax = reinterpret_cast<float*>(sB + (size_t)a.GKH * a.KW * BN * 64);  // [4]
+  float* sMax = reinterpret_cast<float*>(sB + (size_t)GKH * KW * BN * 64);  // [NW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
-  int t = blockIdx.x;
+  // consecutive blocks go round-robin to the 8 XCDs (one L2 each): give every XCD one
+  // contiguous range of bricks so that neighbouring halos meet in the same L2
+  const int nsp = a.ntx * a.nty * a.ntz;
+  int t = (blockIdx.x & 7) * ((nsp + 7) >> 3) + (blockIdx.x >> 3);
+  if (t >= nsp) return;
+  const int tile_id = t;
   const int tx = t % a.ntx;
   t /= a.ntx;
   const int ty = t % a.nty;
   const int tz = t / a.nty;
   const int n0 = blockIdx.y * BN;
   const int nb = blockIdx.z;
-  const int ox0 = tx << a.lTX, oy0 = ty << a.lTY, oz0 = tz << a.lTZ;
-  const int HXY = a.HX * a.HY;
-  const int lx0 = ox0 * a.SW - a.PW, ly0 = oy0 * a.SH - a.PH, lz0 = oz0 * a.SD - a.PD;
-  const int ngy = (a.KH + a.GKH - 1) / a.GKH;  // weight groups per kz plane
+  const int ox0 = tx << lTX, oy0 = ty << lTY, oz0 = tz << lTZ;
+  const int HXY = HX * HY;
+  const int lx0 = ox0 * SW - a.PW, ly0 = oy0 * SH - a.PH, lz0 = oz0 * SD - a.PD;
+  const int ngy = (KH + GKH - 1) / GKH;  // weight groups per kz plane
+
+  const int nchunk = (a.Cin + CC - 1) / CC;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -85,10 +112,10 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = (wm * MT + mt) * 32 + li;
-    const int x = m & ((1 << a.lTX) - 1);
-    const int y = (m >> a.lTX) & ((1 << a.lTY) - 1);
-    const int z = m >> (a.lTX + a.lTY);
-    arow[mt] = ((z * a.SD) * a.HY + y * a.SH) * a.HX + x * a.SW;
+    const int x = m & ((1 << lTX) - 1);
+    const int y = (m >> lTX) & ((1 << lTY) - 1);
+    const int z = m >> (lTX + lTY);
+    arow[mt] = ((z * SD) * HY + y * SH) * HX + x * SW;
   }
   int boffh[NT], boffl[NT];  // byte offsets of this lane's B fragments inside one tap
 #pragma unroll
@@ -99,34 +126,59 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     boffl[nt] = n * 64 + (((2 + lh) ^ sw) << 4);
   }
 
-  // loads the 16 channels [c0, c0+16) of halo voxel hv (zeros outside the tensor)
-  auto load16 = [&](int hv, int c0, float* v) {
+  // input voxel behind halo voxel hv: its DHW index inside batch item nb, or -1 outside the
+  // tensor / on an inserted zero. Independent of the channel chunk.
+  auto halo_voxel = [&](int hv) -> int {
     const int hz = hv / HXY;
     const int rem = hv - hz * HXY;
-    const int hy = rem / a.HX;
-    const int hx = rem - hy * a.HX;
+    const int hy = rem / HX;
+    const int hx = rem - hy * HX;
     int rx = lx0 + hx, ry = ly0 + hy, rz = lz0 + hz;
     bool ok = (rx >= 0) & (ry >= 0) & (rz >= 0);
-    if ((a.UPS | a.UPSY | a.UPSZ) > 1) {
+    if (!SPEC && (a.UPS | a.UPSY | a.UPSZ) > 1) {
       ok = ok & (rx % a.UPS == 0) & (ry % a.UPSY == 0) & (rz % a.UPSZ == 0);
       rx /= a.UPS;
       ry /= a.UPSY;
       rz /= a.UPSZ;
     }
     ok = ok & (rx < a.W) & (ry < a.H) & (rz < a.D);
+    return ok ? (rz * a.H + ry) * a.W + rx : -1;
+  };
+  const size_t vox0 = (size_t)nb * a.D * a.H * a.W;
+  const float* x0n = a.x0 + vox0 * a.C0;                           // this batch item
+  const float* x1n = a.x1 ? a.x1 + vox0 * a.C1 : nullptr;
+  // the 16 channels [c0, c0+16) of input voxel gv (zeros for gv < 0)
+  auto load16 = [&](int gvi, int c0, float* v) {
 #pragma unroll
     for (int j = 0; j < CC; ++j) v[j] = 0.f;
-    if (!ok) return;
-    const size_t gv = ((size_t)(nb * a.D + rz) * a.H + ry) * a.W + rx;
+    if (gvi < 0) return;
+    if constexpr (SPEC) {
+      // both sources hold whole chunks (C0, C1 multiples of 16): one uniform base per chunk
+      const bool first = c0 < a.C0;
+      const char* src = adell_uniform_ptr(first ? x0n + c0 : x1n + (c0 - a.C0));
+      const unsigned cs = first ? a.C0 : a.C1;
+      // byte offset inside the batch item: < 2^32 (checked on the host)
+      const float4* p = reinterpret_cast<const float4*>(src + (unsigned)gvi * cs * 4u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 f = p[q];
+        v[4 * q + 0] = f.x;
+        v[4 * q + 1] = f.y;
+        v[4 * q + 2] = f.z;
+        v[4 * q + 3] = f.w;
+      }
+      return;
+    }
+    const size_t gv = (size_t)gvi;
     if (a.vecx) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = c0 + 4 * q;
         const float* p = nullptr;
         if (c < a.C0)
-          p = a.x0 + gv * a.C0 + c;
+          p = x0n + gv * a.C0 + c;
         else if (c < a.Cin)
-          p = a.x1 + gv * a.C1 + (c - a.C0);
+          p = x1n + gv * a.C1 + (c - a.C0);
         if (p) {
           const float4 f = *reinterpret_cast<const float4*>(p);
           v[4 * q + 0] = f.x;
@@ -140,49 +192,60 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
       for (int j = 0; j < CC; ++j) {
         const int c = c0 + j;
         if (c < a.C0)
-          v[j] = a.x0[gv * a.C0 + c];
+          v[j] = x0n[gv * a.C0 + c];
         else if (c < a.Cin)
-          v[j] = a.x1[gv * a.C1 + (c - a.C0)];
+          v[j] = x1n[gv * a.C1 + (c - a.C0)];
       }
     }
   };
 
-  const int nchunk = (a.Cin + CC - 1) / CC;
   int kA_prev = 0;
-  // The halo brick of a chunk is loaded once into registers when it has at most KEEP voxels per
-  // thread ("resident"). ADELL_IGEMM_PIPE: the loads of chunk ch+1 are issued right after chunk
-  // ch has been written to LDS, so they are in flight during the MFMAs of chunk ch (the
-  // registers are free by then); the absmax over them is taken at the top of the next turn.
-  constexpr int KEEP = 3;
-  const bool resident = HV <= KEEP * 256;
+  // The halo brick of a chunk goes through registers in one piece when it has at most KEEP
+  // voxels per thread ("resident"): one load, absmax, split, store.
+  constexpr int KEEP = SPEC ? (600 + NTHR - 1) / NTHR : 3;
+  const bool resident = SPEC || HV <= KEEP * NTHR;
   float keep[KEEP][CC];
-  auto load_keep = [&](int c0) {
+  int gvk[KEEP];
 #pragma unroll
-    for (int u = 0; u < KEEP; ++u) {
-      const int hv = tid + 256 * u;
-      if (hv < HV) load16(hv, c0, keep[u]);
-    }
-  };
-#if ADELL_IGEMM_PIPE
-  if (resident) load_keep(0);
-#endif
-  // Weight slices of the 32-channel tile go through a register prefetch: the slice of the next
-  // tap group is fetched while the MFMAs of the current one run (<= 10 16-byte loads per
-  // thread; the 64-channel tile has no registers to spare and stages in place).
-  // (a kz plane of a 3^3 kernel: 9 taps x 32 ch x 4 slots = 4.5 x 256 slots. Row-wise groups
-  // with a 3-slot prefetch were tried for the 64-channel tile: 266 -> 258 TF, spills + barriers.)
-  constexpr int WPF = (BN == 32) ? 5 : 9;   // 64-channel tiles: a kz plane = 9 x 256 slots
-  const bool wpipe = WPF > 0 && a.GKH * a.KW * BN * 4 <= WPF * 256;
-  float4 wreg[WPF > 0 ? WPF : 1];
-  const int ngroups = a.KD * ngy;
+  for (int u = 0; u < KEEP; ++u) {
+    const int hv = tid + NTHR * u;
+    gvk[u] = (resident && hv < HV) ? halo_voxel(hv) : -1;
+  }
+  // Weight slices go through a register prefetch: the slice of the next tap group is fetched
+  // while the MFMAs of the current one run (a kz plane of a 3^3 kernel: 9 taps x BN ch x 4
+  // slots = 4.5 (BN 32) / 9 (BN 64) x 256 slots of 16 bytes).
+  constexpr int WPF = (9 * BN * 4 + NTHR - 1) / NTHR;  // a kz plane of a 3^3 kernel
+  const bool wpipe = SPEC || GKH * KW * BN * 4 <= WPF * NTHR;
+  float4 wreg[WPF];
+  const int ngroups = KD * ngy;
+  // SPEC: slot index it = tid + u * NTHR means column (tid >> 2) % BN, tap u * TPU + (tid >> 2) / BN
+  // of the plane: a per-thread 32-bit offset plus a uniform stride per u, on both sides
+  constexpr int TPU = NTHR / 4 / BN;
+  const int wcol = (tid >> 2) % BN, wtap = (tid >> 2) / BN;
+  const unsigned wgoff = ((unsigned)(wtap * a.Cout + n0 + wcol) * nchunk) * 64 + (tid & 3) * 16;
+  const unsigned wloff = ((wtap * BN + wcol) * 4 + ((tid & 3) ^ ((wcol >> 2) & 3))) * 16;
+  const bool wcolok = n0 + wcol < a.Cout;
   auto wfetch = [&](int ch_, int grp_) {
-    const int kz = grp_ / ngy, ky0 = (grp_ - kz * ngy) * a.GKH;
-    const int gkh = (a.KH - ky0) < a.GKH ? (a.KH - ky0) : a.GKH;
-    const int tpg = gkh * a.KW;
-    const int tap0 = (kz * a.KH + ky0) * a.KW;
+    if constexpr (SPEC) {
+      const char* base = reinterpret_cast<const char*>(e.wh) +
+                         ((size_t)(grp_ * 9) * a.Cout * nchunk + ch_) * 64;
+      const size_t ustride = (size_t)TPU * a.Cout * nchunk * 64;
+#pragma unroll
+      for (int u = 0; u < WPF; ++u) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wcolok && u * TPU + wtap < 9)
+          f = *reinterpret_cast<const float4*>(adell_uniform_ptr(base + u * ustride) + wgoff);
+        wreg[u] = f;
+      }
+      return;
+    }
+    const int kz = grp_ / ngy, ky0 = (grp_ - kz * ngy) * GKH;
+    const int gkh = (KH - ky0) < GKH ? (KH - ky0) : GKH;
+    const int tpg = gkh * KW;
+    const int tap0 = (kz * KH + ky0) * KW;
 #pragma unroll
     for (int u = 0; u < WPF; ++u) {
-      const int it = tid + u * 256;
+      const int it = tid + u * NTHR;
       float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it < tpg * BN * 4) {
         const int slot = it & 3;
@@ -200,22 +263,21 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
   for (int ch = 0; ch < nchunk; ++ch) {
     const int c0 = ch * CC;
     float mx = 0.f;
-    if (resident) {
-#if !ADELL_IGEMM_PIPE
-      load_keep(c0);
-#endif
+    const bool skipA = (e.dbg & 1) && ch > 0;
+    if (skipA) {
+    } else if (resident) {
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
-        const int hv = tid + 256 * u;
-        if (hv < HV) {
+        if (tid + NTHR * u < HV) {
+          load16(gvk[u], c0, keep[u]);
 #pragma unroll
           for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(keep[u][j]));
         }
       }
     } else {
-      for (int hv = tid; hv < HV; hv += 256) {
+      for (int hv = tid; hv < HV; hv += NTHR) {
         float v[CC];
-        load16(hv, c0, v);
+        load16(halo_voxel(hv), c0, v);
 #pragma unroll
         for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(v[j]));
       }
@@ -225,7 +287,9 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
     __syncthreads();  // previous chunk's MFMAs are done: LDS may be overwritten
     if (lane == 0) sMax[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+    mx = sMax[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, sMax[w]);
     // by-product for the backward-weight kernel: tensor-wide absmax of the input
     if (e.amax_out != nullptr && tid == 0 && blockIdx.y == 0)
       atomicMax(e.amax_out, __float_as_uint(mx));
@@ -252,40 +316,49 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
       half8 h0, l0, h1, l1;
       adell_split8(v, scaleA, &h0, &l0);
       adell_split8(v + 8, scaleA, &h1, &l1);
-      const int sw = (hv >> 2) & 3;
+      // SPEC: slot permutation by the halo row's y. The 16-lane groups of a ds_read_b128 hold
+      // 4 x-neighbours in each of 4 consecutive y (8x8 brick faces), so rows of one y differ in
+      // the bank quarter and the 4 y's in the slot: conflict-free fragment reads (the generic
+      // permutation costs 3x the LDS cycles on this brick).
+      const int sw = SPEC ? ((hv / 10) % 10) & 3 : (hv >> 2) & 3;
       char* row = sA + (size_t)hv * 64;
       *reinterpret_cast<half8*>(row + ((0 ^ sw) << 4)) = h0;
       *reinterpret_cast<half8*>(row + ((1 ^ sw) << 4)) = h1;
       *reinterpret_cast<half8*>(row + ((2 ^ sw) << 4)) = l0;
       *reinterpret_cast<half8*>(row + ((3 ^ sw) << 4)) = l1;
     };
-    if (resident) {
+    if (skipA) {
+    } else if (resident) {
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
-        const int hv = tid + 256 * u;
+        const int hv = tid + NTHR * u;
         if (hv < HV) store_split(hv, keep[u]);
       }
-#if ADELL_IGEMM_PIPE
-      if (ch + 1 < nchunk) load_keep(c0 + CC);
-#endif
     } else {
-      for (int hv = tid; hv < HV; hv += 256) {
+      for (int hv = tid; hv < HV; hv += NTHR) {
         float v[CC];
-        load16(hv, c0, v);
+        load16(halo_voxel(hv), c0, v);
         store_split(hv, v);
       }
     }
-    for (int grp = 0; grp < a.KD * ngy; ++grp) {
-      const int kz = grp / ngy, ky0 = (grp - kz * ngy) * a.GKH;
-      const int gkh = (a.KH - ky0) < a.GKH ? (a.KH - ky0) : a.GKH;
-      const int tpg = gkh * a.KW;              // taps of this group
-      const int tap0 = (kz * a.KH + ky0) * a.KW;
+    for (int grp = 0; grp < ngroups; ++grp) {
+      const int kz = grp / ngy, ky0 = (grp - kz * ngy) * GKH;
+      const int gkh = (KH - ky0) < GKH ? (KH - ky0) : GKH;
+      const int tpg = gkh * KW;              // taps of this group
+      const int tap0 = (kz * KH + ky0) * KW;
       if (grp > 0) __syncthreads();  // previous tap group consumed
-      // ---- stage the weight slice of this kz plane: [tpg][BN][4 slots] -----
-      if (wpipe) {
+      // ---- stage the weight slice of this tap group: [tpg][BN][4 slots] -----
+      const bool skipB = (e.dbg & 2) && (ch > 0 || grp > 0);
+      if (skipB) {
+      } else if (SPEC) {
+#pragma unroll
+        for (int u = 0; u < WPF; ++u)
+          if (u * TPU + wtap < 9)
+            *reinterpret_cast<float4*>(sB + wloff + u * (TPU * BN * 64)) = wreg[u];
+      } else if (wpipe) {
 #pragma unroll
         for (int u = 0; u < WPF; ++u) {
-          const int it = tid + u * 256;
+          const int it = tid + u * NTHR;
           if (it < tpg * BN * 4) {
             const int slot = it & 3;
             const int n = (it >> 2) % BN;
@@ -294,34 +367,36 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
                 wreg[u];
           }
         }
-      } else
-      for (int it = tid; it < tpg * BN * 4; it += 256) {
-        const int slot = it & 3;
-        const int n = (it >> 2) % BN;
-        const int tl = (it >> 2) / BN;
-        const int tap = tap0 + tl;
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n0 + n < a.Cout)
-          f = *reinterpret_cast<const float4*>(
-              reinterpret_cast<const char*>(e.wh) +
-              (((size_t)tap * a.Cout + n0 + n) * nchunk + ch) * 64 + slot * 16);
-        *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) = f;
+      } else {
+        for (int it = tid; it < tpg * BN * 4; it += NTHR) {
+          const int slot = it & 3;
+          const int n = (it >> 2) % BN;
+          const int tl = (it >> 2) / BN;
+          const int tap = tap0 + tl;
+          float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (n0 + n < a.Cout)
+            f = *reinterpret_cast<const float4*>(
+                reinterpret_cast<const char*>(e.wh) +
+                (((size_t)tap * a.Cout + n0 + n) * nchunk + ch) * 64 + slot * 16);
+          *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) = f;
+        }
       }
       __syncthreads();
-      if (wpipe) {
+      if (wpipe && !skipB) {
         if (grp + 1 < ngroups) wfetch(ch, grp + 1);
         else if (ch + 1 < nchunk) wfetch(ch + 1, 0);
       }
-      // ---- 3 f16 MFMAs per (tap, 32x32 tile); the fragments of tap t+1 are read
-      // while the MFMAs of tap t run (two register sets, statically indexed) -------
+      // ---- 3 f16 MFMAs per (tap, 32x32 tile) ---------------------------------------------
+      const char* sAg = sA + (size_t)((kz * HY + ky0) * HX) * 64;
       auto load_frags = [&](int tl, half8* ah, half8* al, half8* bh, half8* bl) {
-        const int kyl = tl / a.KW, kx = tl - kyl * a.KW;
-        const int aoff = (kz * a.HY + ky0 + kyl) * a.HX + kx;
+        const int kyl = tl / KW, kx = tl - kyl * KW;
+        const int aoff = kyl * HX + kx;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int hv = arow[mt] + aoff;
-          const int sw = (hv >> 2) & 3;
-          const char* row = sA + (size_t)hv * 64;
+          // SPEC: y of the halo row = (li >> 3) + 4 * (m-tile & 1) + ky  (no carries: x + kx < 10)
+          const int sw = SPEC ? ((li >> 3) + kyl) & 3 : ((hv + (kz * HY + ky0) * HX) >> 2) & 3;
+          const char* row = sAg + (size_t)hv * 64;
           ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
           al[mt] = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
         }
@@ -342,49 +417,80 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           }
       };
-      if constexpr (ADELL_IGEMM_ONESET || MT * NT == 4) {
-      // one fragment set: the MFMAs are asynchronous, the next tap's LDS reads follow their issue
-      half8 ah0[MT], al0[MT], bh0[NT], bl0[NT];
-      for (int tl = 0; tl < tpg; ++tl) {
-        load_frags(tl, ah0, al0, bh0, bl0);
-        do_mfma(ah0, al0, bh0, bl0);
-      }
-      } else {
-      half8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
-      load_frags(0, ah0, al0, bh0, bl0);
-      for (int tl = 0; tl < tpg; tl += 2) {
-        if (tl + 1 < tpg) load_frags(tl + 1, ah1, al1, bh1, bl1);
-        do_mfma(ah0, al0, bh0, bl0);
-        if (tl + 1 < tpg) {
-          if (tl + 2 < tpg) load_frags(tl + 2, ah0, al0, bh0, bl0);
-          do_mfma(ah1, al1, bh1, bl1);
+      if (e.dbg & 8) continue;
+      if constexpr (SPEC) {
+        // 9 taps, statically indexed, two fragment sets: the LDS reads of tap t+1 are issued
+        // before the MFMAs of tap t
+        half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+        load_frags(0, ah[0], al[0], bh[0], bl[0]);
+#pragma unroll
+        for (int tl = 0; tl < 9; ++tl) {
+          if (tl + 1 < 9) load_frags(tl + 1, ah[(tl + 1) & 1], al[(tl + 1) & 1], bh[(tl + 1) & 1], bl[(tl + 1) & 1]);
+          do_mfma(ah[tl & 1], al[tl & 1], bh[tl & 1], bl[tl & 1]);
+          // pin the interleave: one LDS read of the next tap behind each of the first MFMAs
+          // (the 2x2 tile has no registers for the second fragment set: it spills when pinned)
+          if (MT * NT == 2 && tl + 1 < 9) {
+#pragma unroll
+            for (int i = 0; i < 2 * MT + 2 * NT; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            if constexpr (3 * MT * NT > 2 * MT + 2 * NT)
+              __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT - (2 * MT + 2 * NT), 0);
+          }
         }
-      }
+      } else if constexpr (MT * NT == 4) {
+        // one fragment set: the MFMAs are asynchronous, the next tap's LDS reads follow them
+        half8 ah0[MT], al0[MT], bh0[NT], bl0[NT];
+        for (int tl = 0; tl < tpg; ++tl) {
+          load_frags(tl, ah0, al0, bh0, bl0);
+          do_mfma(ah0, al0, bh0, bl0);
+        }
+      } else {
+        // the fragments of tap t+1 are read while the MFMAs of tap t run (two register sets)
+        half8 ah0[MT], al0[MT], bh0[NT], bl0[NT], ah1[MT], al1[MT], bh1[NT], bl1[NT];
+        load_frags(0, ah0, al0, bh0, bl0);
+        for (int tl = 0; tl < tpg; tl += 2) {
+          if (tl + 1 < tpg) load_frags(tl + 1, ah1, al1, bh1, bl1);
+          do_mfma(ah0, al0, bh0, bl0);
+          if (tl + 1 < tpg) {
+            if (tl + 2 < tpg) load_frags(tl + 2, ah0, al0, bh0, bl0);
+            do_mfma(ah1, al1, bh1, bl1);
+          }
+        }
       }
     }
   }
 
   // ---- epilogue (same contract as the fp32 kernel) ---------------------------
+  // A row of the output is addressed as (64-bit block base, per lane and column tile) +
+  // (32-bit offset of the row inside the brick); the brick spans < 2^31 elements (checked on
+  // the host), so the per-row arithmetic is three 24-bit multiply-adds.
   const float ascale = __int_as_float((127 - kA_prev) << 23);
+  const int fx = (shuffle & 1) + 1, fy = ((shuffle >> 1) & 1) + 1, fz = ((shuffle >> 2) & 1) + 1;
+  // steps (in output rows) of one brick-local x / y / z step; destination grid when shuffling
+  const int sX = fx, sY = fy * fx * a.Wo, sZ = fz * fy * a.Ho * fx * a.Wo;
+  const size_t row0 =   // destination row of the brick origin
+      ((size_t)((nb * fz * a.Do + fz * oz0) * (fy * a.Ho) + fy * oy0)) * (fx * a.Wo) + fx * ox0;
+  const size_t rrow0 = ((size_t)((nb * a.Do + oz0) * a.Ho + oy0)) * a.Wo + ox0;  // residual row
   float s1[NT], s2[NT], bcol[NT], oscale[NT];
   float* colptr[NT];
+  const float* resptr[NT];
   int rowmul[NT];
   bool nok[NT];
-  int ncol[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     s1[nt] = s2[nt] = 0.f;
     const int n = n0 + (wn * NT + nt) * 32 + li;
-    ncol[nt] = n;
     nok[nt] = n < a.Cout;
     bcol[nt] = 0.f;
     oscale[nt] = 0.f;
     colptr[nt] = a.y0;
+    resptr[nt] = a.res;
     rowmul[nt] = 0;
     if (nok[nt]) {
       oscale[nt] = ascale * e.wscale[n];
-      if (a.shuffle) {
-        const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1;
+      if (shuffle) {
         const int sub = n / a.Cs, co = n - sub * a.Cs;
         const int sx = sub % fx, sy = (sub / fx) % fy, sz = sub / (fx * fy);
         colptr[nt] = a.y0 + ((size_t)(sz * fy * a.Ho + sy) * (fx * a.Wo) + sx) * a.Cs + co;
@@ -400,35 +506,83 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
         }
         if (a.bias) bcol[nt] = a.bias[n];
       }
+      colptr[nt] += row0 * rowmul[nt];
+      if (a.res) resptr[nt] = a.res + rrow0 * a.Cout + n;
     }
   }
+  bool stored = false;
+  if constexpr (SPEC) {
+    // interior brick, all columns valid: rows of an m-tile are 4 x-neighbours (r & 3) in 4
+    // y-rows (r >> 2), so a row is the m-tile's base pointer + a compile-time multiple of two
+    // per-lane strides; no bounds checks, the residual values of an m-tile are fetched at once
+    const bool full = (ox0 + 8 <= a.Wo) & (oy0 + 8 <= a.Ho) & (oz0 + 4 <= a.Do) &
+                      (n0 + BN <= a.Cout);
+    if (full) {
+      stored = true;
+      auto fast = [&](auto has_res) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int tile = wm * MT + mt;
+          const unsigned rbase =
+              (unsigned)(tile >> 1) * (unsigned)(a.Ho * a.Wo) + (unsigned)((tile & 1) * 4 * a.Wo) +
+              4 * lh;
+          float resv[NT][16];
+          if constexpr (has_res.value) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const float* rp = resptr[nt] + (size_t)rbase * a.Cout;
+              const unsigned dY = a.Wo * a.Cout, dX = a.Cout;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) resv[nt][r] = rp[(r >> 2) * dY + (r & 3) * dX];
+            }
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float* p = colptr[nt] + (size_t)rbase * rowmul[nt];
+            const unsigned dY = a.Wo * rowmul[nt], dX = rowmul[nt];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];
+              if constexpr (has_res.value) v += resv[nt][r];
+              if (!(e.dbg & 16)) p[(r >> 2) * dY + (r & 3) * dX] = v;
+              s1[nt] += v;
+              s2[nt] += v * v;
+            }
+          }
+        }
+      };
+      if (a.res)
+        fast(std::true_type{});
+      else
+        fast(std::false_type{});
+    }
+  }
+  if (!stored) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int m = (wm * MT + mt) * 32 + row;
-      const int x = ox0 + (m & ((1 << a.lTX) - 1));
-      const int y = oy0 + ((m >> a.lTX) & ((1 << a.lTY) - 1));
-      const int z = oz0 + (m >> (a.lTX + a.lTY));
-      const bool rok = (x < a.Wo) & (y < a.Ho) & (z < a.Do);
-      const int ov = ((nb * a.Do + z) * a.Ho + y) * a.Wo + x;
-      const int fx = (a.shuffle & 1) + 1, fy = ((a.shuffle >> 1) & 1) + 1,
-                fz = ((a.shuffle >> 2) & 1) + 1;
-      const int ovs = ((nb * fz * a.Do + fz * z) * (fy * a.Ho) + fy * y) * (fx * a.Wo) + fx * x;
-      const int rowoff = a.shuffle ? ovs : ov;
+      const int xl = m & ((1 << lTX) - 1);
+      const int yl = (m >> lTX) & ((1 << lTY) - 1);
+      const int zl = m >> (lTX + lTY);
+      const bool rok = (ox0 + xl < a.Wo) & (oy0 + yl < a.Ho) & (oz0 + zl < a.Do);
+      const unsigned loc = (unsigned)zl * (unsigned)sZ + __umul24(yl, sY) + __umul24(xl, sX);
+      const unsigned rloc = (unsigned)zl * (unsigned)(a.Ho * a.Wo) + __umul24(yl, a.Wo) + xl;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         if (rok && nok[nt]) {
           float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];
-          if (a.res) v += a.res[(size_t)ov * a.Cout + ncol[nt]];
-          colptr[nt][(size_t)rowoff * rowmul[nt]] = v;
+          if (a.res) v += resptr[nt][rloc * (unsigned)a.Cout];
+          colptr[nt][loc * (unsigned)rowmul[nt]] = v;
           s1[nt] += v;
           s2[nt] += v * v;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+  }
   }
   if (a.part) {
     __syncthreads();
@@ -453,8 +607,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_igemm_f16_kernel(ConvArgs a
           t1 += red[(w * BN + tid) * 2 + 0];
           t2 += red[(w * BN + tid) * 2 + 1];
         }
-        const size_t ntiles = (size_t)a.ntx * a.nty * a.ntz;
-        float* p = a.part + ((nb * ntiles + blockIdx.x) * a.Cout + n) * 2;
+        float* p = a.part + (((size_t)nb * nsp + tile_id) * a.Cout + n) * 2;
         p[0] = t1;
         p[1] = t2;
       }
