@@ -227,12 +227,45 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_kernel(WgradArgs a) {
 }
 
 // out[(co*Cin + ci)*ntap + tap] = sum_r ws[r][tap][ci][co]   (fixed order).
-// 256 threads = 64 consecutive elements x 4 interleaved slab quarters; the four
-// partial sums are combined in a fixed order through LDS.
-__global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
+// db[co] = sum_r wsdb[r][co] by one 1024-thread block: 64 channels x 16 slab lanes with 4
+// independent partial sums each (a serial chain over R = 512 slabs costs > 100 us), combined in
+// fixed order through LDS.
+__device__ __forceinline__ void adell_db_fold(const float* __restrict__ wsdb,
+                                              float* __restrict__ db, int R, int Cout) {
+  __shared__ float shdb[16][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < Cout; c0 += 64) {
+    const int co = c0 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (co < Cout) {
+      int r = q;
+      for (; r + 48 < R; r += 64) {
+        s0 += wsdb[(size_t)r * Cout + co];
+        s1 += wsdb[(size_t)(r + 16) * Cout + co];
+        s2 += wsdb[(size_t)(r + 32) * Cout + co];
+        s3 += wsdb[(size_t)(r + 48) * Cout + co];
+      }
+      for (; r < R; r += 16) s0 += wsdb[(size_t)r * Cout + co];
+    }
+    __syncthreads();
+    shdb[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && co < Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += shdb[k][e];
+      db[co] = s;
+    }
+  }
+}
+
+// 1024 threads = 64 consecutive elements x 16 interleaved slab lanes (4 independent partial
+// sums each, so 64 slab rows are in flight per element); the partial sums are combined in a
+// fixed order through LDS.
+__global__ __launch_bounds__(1024) void adell_wgrad_reduce_kernel(
     const float* __restrict__ ws, float* __restrict__ out, int R, int ntap, int Cin,
     int Cout, const float* __restrict__ wsdb, float* __restrict__ db) {
-  __shared__ float sh[4][64];
+  __shared__ float sh[16][64];
   const long total = (long)ntap * Cin * Cout;
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
   for (long base = (long)blockIdx.x * 64; base < total; base += (long)gridDim.x * 64) {
@@ -240,18 +273,20 @@ __global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < total) {
       int r = q;
-      for (; r + 12 < R; r += 16) {
+      for (; r + 48 < R; r += 64) {
         s0 += ws[(size_t)r * total + i];
-        s1 += ws[(size_t)(r + 4) * total + i];
-        s2 += ws[(size_t)(r + 8) * total + i];
-        s3 += ws[(size_t)(r + 12) * total + i];
+        s1 += ws[(size_t)(r + 16) * total + i];
+        s2 += ws[(size_t)(r + 32) * total + i];
+        s3 += ws[(size_t)(r + 48) * total + i];
       }
-      for (; r < R; r += 4) s0 += ws[(size_t)r * total + i];
+      for (; r < R; r += 16) s0 += ws[(size_t)r * total + i];
     }
     sh[q][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (q == 0 && i < total) {
-      const float s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += sh[k][e];
       const int co = (int)(i % Cout);
       const long rest = i / Cout;
       const int ci = (int)(rest % Cin);
@@ -260,22 +295,75 @@ __global__ __launch_bounds__(256) void adell_wgrad_reduce_kernel(
     }
     __syncthreads();
   }
-  if (db != nullptr && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
-      float s = 0.f;
-      for (int r = 0; r < R; ++r) s += wsdb[(size_t)r * Cout + co];
-      db[co] = s;
+  if (db != nullptr && blockIdx.x == 0) adell_db_fold(wsdb, db, R, Cout);
+}
+
+// The same fold for Cout % 4 == 0 (every f16x3 / MFMA tile): 1024 threads = 64 float4 lanes
+// (256 consecutive elements, 1 KiB of every slab) x 16 slab lanes, 8 independent 16-byte loads
+// in flight per thread -- a streaming read of the slabs instead of 4-byte strided gathers
+// (R = 512 slabs of 27 x 32 x 32: 124 us -> the HBM time of 56 MB).
+__global__ __launch_bounds__(1024) void adell_wgrad_reduce4_kernel(
+    const float* __restrict__ ws, float* __restrict__ out, int R, int ntap, int Cin,
+    int Cout, const float* __restrict__ wsdb, float* __restrict__ db) {
+  __shared__ float4 sh[16][64];
+  const long total = (long)ntap * Cin * Cout;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + e) * 4;
+  float4 acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total) {
+    int r = q;
+    for (; r + 7 * 16 < R; r += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)(r + 16 * u) * total + i);
+        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+      }
+    }
+    for (; r < R; r += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)r * total + i);
+      acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
     }
   }
+  float4 t;
+  t.x = ((acc[0].x + acc[1].x) + (acc[2].x + acc[3].x)) + ((acc[4].x + acc[5].x) + (acc[6].x + acc[7].x));
+  t.y = ((acc[0].y + acc[1].y) + (acc[2].y + acc[3].y)) + ((acc[4].y + acc[5].y) + (acc[6].y + acc[7].y));
+  t.z = ((acc[0].z + acc[1].z) + (acc[2].z + acc[3].z)) + ((acc[4].z + acc[5].z) + (acc[6].z + acc[7].z));
+  t.w = ((acc[0].w + acc[1].w) + (acc[2].w + acc[3].w)) + ((acc[4].w + acc[5].w) + (acc[6].w + acc[7].w));
+  sh[q][e] = t;
+  __syncthreads();
+  if (q == 0 && i < total) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 v = sh[k][e];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int co = (int)(i % Cout);
+    const long rest = i / Cout;
+    const int ci = (int)(rest % Cin);
+    const int tap = (int)(rest / Cin);
+    float* o = out + ((size_t)co * Cin + ci) * ntap + tap;
+    const size_t cs = (size_t)Cin * ntap;
+    o[0] = s.x; o[cs] = s.y; o[2 * cs] = s.z; o[3 * cs] = s.w;
+  }
+  if (db != nullptr && blockIdx.x == 0) adell_db_fold(wsdb, db, R, Cout);
 }
 
 // shared with conv_wgrad_f16.hip
 extern "C" int adell_wgrad_reduce_launch(const float* ws, float* out, int R, int ntap, int Cin,
                                          int Cout, const float* wsdb, float* db, void* stream) {
   const long total = (long)ntap * Cin * Cout;
+  if (Cout % 4 == 0 && (((uintptr_t)ws) & 15) == 0) {
+    hipLaunchKernelGGL(adell_wgrad_reduce4_kernel, dim3((unsigned)((total / 4 + 63) / 64)),
+                       dim3(1024), 0, (hipStream_t)stream, ws, out, R, ntap, Cin, Cout, wsdb, db);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   int blocks = (int)((total + 63) / 64);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream,
                      ws, out, R, ntap, Cin, Cout, wsdb, db);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
@@ -407,13 +495,8 @@ static int adell_wgrad_core(int N, int D, int H, int W, int C0, int C1, const fl
   else
     rc = adell_launch_wgrad<9>(a, grid, p.lds, st);
   if (rc != ADELL_OK) return rc;
-  const long total = (long)ntap * Cin * Cout;
-  int blocks = (int)((total + 63) / 64);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adell_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st,
-                     (const float*)ws, out, p.R, ntap, Cin, Cout, (const float*)a.wsdb, db);
-  ADELL_CHECK_HIP(hipGetLastError());
-  return ADELL_OK;
+  return adell_wgrad_reduce_launch((const float*)ws, out, p.R, ntap, Cin, Cout,
+                                   (const float*)a.wsdb, db, st);
 }
 
 // small-channel paths (conv_small.hip)

@@ -423,6 +423,20 @@ __global__ void adell_absmax2_kernel(const float* __restrict__ x, long n, unsign
 extern "C" int adell_wgrad_reduce_launch(const float* ws, float* out, int R, int ntap, int Cin,
                                          int Cout, const float* wsdb, float* db, void* stream);
 
+// z-ring kernel for 3^3 stride-1 convolutions (conv_wgrad_zring.hip)
+struct WgradZrPlan {
+  int ntx, nty, nseg, seglen, nci, nco, R;
+};
+extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
+                                      int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,
+                                      WgradZrPlan* p);
+extern "C" size_t adell_wgrad_zring_ws_floats(const WgradZrPlan* p, int Cin, int Cout);
+extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int H, int W, int C0,
+                                        int C1, const float* x0, const float* x1, int Cout, int Do,
+                                        int Ho, int Wo, const float* dy, int PD, int PH, int PW,
+                                        float* slabs, float* wsdb, const unsigned* xmax,
+                                        const unsigned* ymax, hipStream_t st);
+
 struct WgradF16Plan {
   int lTY, HX, HY, TCI, TCO, nci, nco, maxj, R, ntx, nty, GKH, NGY, ksplit;
   size_t lds;
@@ -506,8 +520,15 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
                                 const uint32_t* xmax_in, const uint32_t* ymax_in, void* ws,
                                 size_t ws_bytes, hipStream_t st) {
   const int Cin = C0 + C1;
-  WgradF16Plan p;
-  int rc = adell_wgrad_f16_plan(N, Cin, Cout, KD, KH, KW, SH, SW, Do, Ho, Wo, &p);
+  WgradF16Plan p = {};
+  WgradZrPlan zp;
+  const bool zring = adell_wgrad_zring_plan(N, D, H, W, C0, C1, Cout, KD, KH, KW, SD, SH, SW, Do, Ho,
+                                            Wo, &zp) != 0;
+  int rc = ADELL_OK;
+  if (zring)
+    p.R = zp.R;
+  else
+    rc = adell_wgrad_f16_plan(N, Cin, Cout, KD, KH, KW, SH, SW, Do, Ho, Wo, &p);
   if (rc != ADELL_OK) return rc;
   const int ntap = KD * KH * KW;
   const size_t need = adell_wgrad_f16_ws(p, ntap, Cin, Cout);
@@ -529,6 +550,13 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   }
   if (!ymax_in)
     hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(ny)), dim3(256), 0, st, dy, ny, amax + 1);
+  if (zring) {
+    rc = adell_wgrad_zring_launch(&zp, N, D, H, W, C0, C1, x0, x1, Cout, Do, Ho, Wo, dy, PD, PH, PW,
+                                  slabs, db ? wsdb : nullptr, xmax_in ? xmax_in : amax,
+                                  ymax_in ? ymax_in : amax + 1, st);
+    if (rc != ADELL_OK) return rc;
+    return adell_wgrad_reduce_launch(slabs, out, zp.R, ntap, Cin, Cout, db ? wsdb : nullptr, db, st);
+  }
   WgradF16Args a = {};
   a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = slabs; a.wsdb = db ? wsdb : nullptr;
   a.xmax = xmax_in ? xmax_in : amax;
@@ -579,10 +607,19 @@ extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, co
 extern "C" long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc* d) {
   if (!d) return ADELL_E_BADARG;
   if (adell_wgrad_small_workspace(d) > 0) return adell_wgrad_small_workspace(d);
-  WgradF16Plan p;
+  WgradF16Plan p = {};
+  WgradZrPlan zp;
   const int Cin = d->C0 + d->C1;
-  if (adell_wgrad_f16_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SH, d->SW, d->Do, d->Ho,
-                           d->Wo, &p) != ADELL_OK)
+  if (adell_wgrad_zring_plan(d->N, d->D, d->H, d->W, d->C0, d->C1, d->Cout, d->KD, d->KH, d->KW,
+                             d->SD, d->SH, d->SW, d->Do, d->Ho, d->Wo, &zp)) {
+    // the larger of the two plans, so that a later call may take either kernel
+    WgradF16Plan q = {};
+    if (adell_wgrad_f16_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SH, d->SW, d->Do, d->Ho,
+                             d->Wo, &q) != ADELL_OK)
+      q.R = 0;
+    p.R = zp.R > q.R ? zp.R : q.R;
+  } else if (adell_wgrad_f16_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SH, d->SW, d->Do,
+                                  d->Ho, d->Wo, &p) != ADELL_OK)
     return ADELL_E_UNSUPPORTED;
   return (long)adell_wgrad_f16_ws(p, d->KD * d->KH * d->KW, Cin, d->Cout);
 }

@@ -1,0 +1,370 @@
+// Backward-weight of 3x3x3 stride-1 convolutions on the f16 MFMA (f16x3 operand split, see
+// conv_igemm_f16.h / conv_wgrad_f16.hip), marching along z with a ring of input planes.
+//
+//   dW[kz][ky][kx][ci][co] = sum_{n,z,y,x} X[n, z-PD+kz, y-PH+ky, x-PW+kx][ci] * dY[n, z, y, x][co]
+//
+// GEMM view as in conv_wgrad_f16.hip (M = ci, N = co, K = voxels, transposing LDS reads over the
+// natural [voxel][32 channels] fp16 hi / lo planes). What is different is the work decomposition:
+// a block owns ONE 32 x 32 channel tile and ALL 27 taps, and walks a column of 8 x 8 x 1 output
+// bricks along z. LDS keeps a ring of three 10 x 10 input planes, so each step converts and
+// stores ONE new input plane (100 rows) and ONE dY plane (64 rows) and then runs 27 taps x 4
+// k-steps x 3 MFMAs on them -- three times the MFMA work per staged byte of the per-kz-plane
+// kernel, whose staging (fp32 -> fp16 hi/lo conversion on the vector ALU) bounds it.
+// Wave w owns taps w, w+4, w+8, ... (7 accumulators of 16 registers), every k-step.
+// Work units are (column, z segment) pairs dealt round-robin to the blocks; every block writes
+// one partial slab, folded in fixed order by adell_wgrad_reduce_kernel (deterministic).
+#include "common.h"
+
+typedef _Float16 zr_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 zr_half4 __attribute__((ext_vector_type(4)));
+typedef __fp16 zr_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ zr_half8 adell_zr_frag(const char* p) {
+  typedef __attribute__((address_space(3))) zr_fp16x4* lds_p;
+  const zr_fp16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_p)(p));
+  const zr_fp16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_p)(p + 4 * 64));
+  zr_half8 r;
+  r[0] = (_Float16)lo4[0]; r[1] = (_Float16)lo4[1]; r[2] = (_Float16)lo4[2]; r[3] = (_Float16)lo4[3];
+  r[4] = (_Float16)hi4[0]; r[5] = (_Float16)hi4[1]; r[6] = (_Float16)hi4[2]; r[7] = (_Float16)hi4[3];
+  return r;
+}
+
+struct WgradZrArgs {
+  const float* x0;
+  const float* x1;
+  const float* dy;
+  float* ws;             // [R][27][Cin][Cout]
+  float* wsdb;           // [R][Cout] or null
+  const unsigned* xmax;  // device absmax (float bits) of X and dY
+  const unsigned* ymax;
+  int N, D, H, W;
+  int C0, C1, Cin, Cout;
+  int PD, PH, PW;
+  int Do, Ho, Wo;
+  int ntx, nty;          // 8 x 8 bricks per output plane
+  int nseg, seglen;      // z segments per column and their length
+  int nci, nco;          // 32-channel tiles
+  int R;                 // blocks per channel tile (= slabs)
+  int dbg;               // timing experiments (ADELL_ZR_DBG): 1 no global loads after priming,
+                         // 2 no conversion / LDS stores after priming, 4 no MFMAs
+};
+
+__device__ __forceinline__ int adell_zr_scale_exp(unsigned maxbits) {
+  const int ebits = (int)((maxbits >> 23) & 0xff);
+  int k = 0;
+  if (ebits > 0 && ebits < 255) k = 8 * ((13 - (ebits - 127)) >> 3);
+  if (k > 96) k = 96;
+  if (k < -96) k = -96;
+  return k;
+}
+
+// 4 floats -> 4 fp16 hi + 4 fp16 lo, 8 bytes each, at byte offset `off` of the two planes
+__device__ __forceinline__ void adell_zr_split_store(char* hi_plane, char* lo_plane, unsigned off,
+                                                     float4 f, float scale) {
+  zr_half4 h, l;
+  const float t[4] = {f.x * scale, f.y * scale, f.z * scale, f.w * scale};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = (_Float16)t[j];
+    l[j] = (_Float16)(t[j] - (float)h[j]);
+  }
+  *reinterpret_cast<zr_half4*>(hi_plane + off) = h;
+  *reinterpret_cast<zr_half4*>(lo_plane + off) = l;
+}
+
+__device__ __forceinline__ const char* adell_zr_uniform(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+constexpr int ZR_HX = 10, ZR_HV = 100;      // halo plane of an 8 x 8 brick
+constexpr int ZR_PLANE = ZR_HV * 64;        // bytes of one fp16 plane of 32 channels
+constexpr int ZR_NX = 4, ZR_NY = 2;         // 16-byte loads per thread: 100 x 8 and 64 x 8 slots
+constexpr int ZR_MAXJ = 7;                  // taps per wave
+
+__global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrArgs a) {
+  extern __shared__ float smem[];
+  char* sXh = reinterpret_cast<char*>(smem);          // [3 ring slots][100][32 halfs]
+  char* sXl = sXh + 3 * ZR_PLANE;
+  char* sYh = sXl + 3 * ZR_PLANE;                     // [64][32 halfs]
+  char* sYl = sYh + 64 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int region = blockIdx.x;
+  const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
+  const int ci0 = cit * 32, co0 = cot * 32;
+
+  const int kX = adell_zr_scale_exp(a.xmax[0]), kY = adell_zr_scale_exp(a.ymax[0]);
+  const float sX = __int_as_float((kX + 127) << 23), sY = __int_as_float((kY + 127) << 23);
+
+  // the 32 input channels of this tile live in one source (C0 is a multiple of 32)
+  const bool first = ci0 < a.C0;
+  const float* xsrc = first ? a.x0 + ci0 : a.x1 + (ci0 - a.C0);
+  const unsigned xcs = first ? a.C0 : a.C1;
+
+  // transposed-read lane roles (conv_wgrad_f16.hip): lane 4q+p of a 16-lane group addresses
+  // voxel row q, channels 4p..4p+3 of channel half cg; the two lane halves take two brick rows
+  const int cg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int colb = (16 * cg + 4 * tp) * 2;
+  const int abase = (lh * ZR_HX + tq) * 64 + colb;   // + tap offset + k-step * 2 rows
+  const int bbase = (lh * 8 + tq) * 64 + colb;       // + k-step * 16 rows
+  int tapoff[ZR_MAXJ], tapkz[ZR_MAXJ];
+  bool jok[ZR_MAXJ];
+#pragma unroll
+  for (int q = 0; q < ZR_MAXJ; ++q) {
+    int t = wave + 4 * q;
+    jok[q] = t < 27;
+    if (!jok[q]) t = 0;
+    const int kz = t / 9, ky = (t - 9 * kz) / 3, kx = t - 9 * kz - 3 * ky;
+    tapkz[q] = kz;
+    tapoff[q] = abase + (ky * ZR_HX + kx) * 64;
+  }
+  f32x16 acc[ZR_MAXJ];
+#pragma unroll
+  for (int q = 0; q < ZR_MAXJ; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  // staging slots of this thread: 16-byte piece c4 = tid & 7 of rows tid / 8 + 32 u
+  const int c4 = tid & 7, row0 = tid >> 3;
+  const bool do_db = a.wsdb != nullptr && cit == 0;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int ncols = a.N * a.ntx * a.nty;
+  const long nunits = (long)ncols * a.nseg;
+  for (long unit = region; unit < nunits; unit += a.R) {
+    const int col = (int)(unit / a.nseg), seg = (int)(unit - (long)col * a.nseg);
+    const int tx = col % a.ntx, ty = (col / a.ntx) % a.nty, nb = col / (a.ntx * a.nty);
+    const int ox0 = tx * 8, oy0 = ty * 8;
+    const int z0 = seg * a.seglen;
+    const int z1 = (z0 + a.seglen < a.Do) ? z0 + a.seglen : a.Do;
+    if (z0 >= z1) continue;
+    // per-column geometry of this thread's slots: offsets inside an input / output plane
+    unsigned xoff[ZR_NX], yoff[ZR_NY];
+    bool xok[ZR_NX], yok[ZR_NY];
+#pragma unroll
+    for (int u = 0; u < ZR_NX; ++u) {
+      const int hv = row0 + 32 * u;
+      const int hy = hv / ZR_HX, hx = hv - hy * ZR_HX;
+      const int ix = ox0 - a.PW + hx, iy = oy0 - a.PH + hy;
+      xok[u] = (hv < ZR_HV) & (ix >= 0) & (ix < a.W) & (iy >= 0) & (iy < a.H);
+      xoff[u] = xok[u] ? ((unsigned)(iy * a.W + ix) * xcs + 4 * c4) * 4u : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < ZR_NY; ++u) {
+      const int v = row0 + 32 * u;
+      const int ox = ox0 + (v & 7), oy = oy0 + (v >> 3);
+      yok[u] = (ox < a.Wo) & (oy < a.Ho);
+      yoff[u] = yok[u] ? ((unsigned)(oy * a.Wo + ox) * (unsigned)a.Cout + co0 + 4 * c4) * 4u : 0u;
+    }
+    float4 xr[ZR_NX], yr[ZR_NY];
+    auto fetch_x = [&](int p) {   // input plane p of item nb (zeros outside the tensor)
+      const bool pok = p >= 0 && p < a.D;
+      const char* base =
+          adell_zr_uniform(xsrc + ((size_t)(nb * a.D + (pok ? p : 0)) * a.H * a.W) * xcs);
+#pragma unroll
+      for (int u = 0; u < ZR_NX; ++u) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pok && xok[u]) f = *reinterpret_cast<const float4*>(base + xoff[u]);
+        xr[u] = f;
+      }
+    };
+    auto fetch_y = [&](int z) {
+      const char* base =
+          adell_zr_uniform(a.dy + ((size_t)(nb * a.Do + z) * a.Ho * a.Wo) * a.Cout);
+#pragma unroll
+      for (int u = 0; u < ZR_NY; ++u) {
+        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (yok[u]) f = *reinterpret_cast<const float4*>(base + yoff[u]);
+        yr[u] = f;
+      }
+    };
+    auto store_x = [&](int slot) {
+#pragma unroll
+      for (int u = 0; u < ZR_NX; ++u) {
+        const int hv = row0 + 32 * u;
+        if (hv < ZR_HV)
+          adell_zr_split_store(sXh, sXl, (unsigned)(slot * ZR_PLANE + hv * 64 + c4 * 8), xr[u], sX);
+      }
+    };
+    auto store_y = [&]() {
+#pragma unroll
+      for (int u = 0; u < ZR_NY; ++u) {
+        const int v = row0 + 32 * u;
+        dbacc.x += yr[u].x; dbacc.y += yr[u].y; dbacc.z += yr[u].z; dbacc.w += yr[u].w;
+        adell_zr_split_store(sYh, sYl, (unsigned)(v * 64 + c4 * 8), yr[u], sY);
+      }
+    };
+    // prime the ring: planes of taps kz = 0, 1 of the first step. Plane p = z - PD + kz sits in
+    // slot (z + kz) % 3.
+    __syncthreads();   // the previous unit's MFMAs are done with LDS
+    fetch_x(z0 - a.PD);
+    store_x(z0 % 3);
+    fetch_x(z0 - a.PD + 1);
+    store_x((z0 + 1) % 3);
+    fetch_x(z0 - a.PD + 2);
+    fetch_y(z0);
+    for (int z = z0; z < z1; ++z) {
+      // registers -> LDS: the new input plane (tap kz = 2 of this step) and this step's dY
+      if (!(a.dbg & 2) || z == z0) {
+        store_x((z + 2) % 3);
+        store_y();
+      }
+      __syncthreads();
+      if (z + 1 < z1 && !(a.dbg & 1)) {  // next step's loads fly during this step's MFMAs
+        fetch_x(z + 1 - a.PD + 2);
+        fetch_y(z + 1);
+      }
+      const int zm = z % 3;
+      int slotoff[3];   // byte offset of the ring slot holding tap plane kz
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        int s = zm + kz;
+        s = s >= 3 ? s - 3 : s;
+        slotoff[kz] = s * ZR_PLANE;
+      }
+      // 4 k-steps of 16 voxels (two brick rows) x 7 taps, flattened and software-pipelined: the
+      // fragments of job i+1 are read while the 3 MFMAs of job i run (two register sets)
+      int tslot[ZR_MAXJ];
+#pragma unroll
+      for (int q = 0; q < ZR_MAXJ; ++q)
+        tslot[q] = tapoff[q] + (tapkz[q] == 0 ? slotoff[0] : (tapkz[q] == 1 ? slotoff[1] : slotoff[2]));
+      zr_half8 ah[2], al[2], bh[2], bl[2];
+      if (a.dbg & 4) { __syncthreads(); continue; }
+      bh[0] = adell_zr_frag(sYh + bbase);
+      bl[0] = adell_zr_frag(sYl + bbase);
+      ah[0] = adell_zr_frag(sXh + tslot[0]);
+      al[0] = adell_zr_frag(sXl + tslot[0]);
+#pragma unroll
+      for (int i = 0; i < 4 * ZR_MAXJ; ++i) {
+        const int s = i / ZR_MAXJ, q = i - s * ZR_MAXJ;
+        const int cur = i & 1, nxt = cur ^ 1;
+        const bool more = i + 1 < 4 * ZR_MAXJ;
+        const bool newb = more && q + 1 == ZR_MAXJ;
+        if (more) {
+          const int s2 = (i + 1) / ZR_MAXJ, q2 = (i + 1) - s2 * ZR_MAXJ;
+          if (newb) {
+            bh[s2 & 1] = adell_zr_frag(sYh + bbase + s2 * 16 * 64);
+            bl[s2 & 1] = adell_zr_frag(sYl + bbase + s2 * 16 * 64);
+          }
+          ah[nxt] = adell_zr_frag(sXh + tslot[q2] + s2 * 2 * ZR_HX * 64);
+          al[nxt] = adell_zr_frag(sXl + tslot[q2] + s2 * 2 * ZR_HX * 64);
+        }
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[s & 1], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[s & 1], acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[s & 1], acc[q], 0, 0, 0);
+        if (more) {  // pin: the next job's LDS reads go between this job's MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (newb) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (newb) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+      __syncthreads();   // ring slot (z + 3) % 3 = z % 3 and sY are free again
+    }
+  }
+
+  if (do_db) {
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(smem);
+    red[tid] = dbacc;
+    __syncthreads();
+    if (tid < 8) {
+      float4 tsum = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = tid; k < 256; k += 8) {
+        const float4 u = red[k];
+        tsum.x += u.x; tsum.y += u.y; tsum.z += u.z; tsum.w += u.w;
+      }
+      float* o = a.wsdb + (size_t)region * a.Cout + co0 + 4 * tid;
+      o[0] = tsum.x; o[1] = tsum.y; o[2] = tsum.z; o[3] = tsum.w;
+    }
+  }
+  // ---- partial slab (undo the operand scales) --------------------------------
+  const float unscale = __int_as_float((127 - kX - kY) << 23);
+  const int co = co0 + li;
+#pragma unroll
+  for (int q = 0; q < ZR_MAXJ; ++q) {
+    const int tap = wave + 4 * q;
+    const int cib = ci0 + 4 * lh;
+    float* base = a.ws + (((size_t)region * 27 + tap) * a.Cin + cib) * a.Cout + co;
+    if (jok[q]) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2);
+        base[(size_t)row * a.Cout] = acc[q][r] * unscale;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+struct WgradZrPlan {
+  int ntx, nty, nseg, seglen, nci, nco, R;
+};
+
+// 1 when the z-ring kernel serves this problem (3^3 taps, stride 1, whole 32-channel tiles)
+extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
+                                      int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,
+                                      WgradZrPlan* p) {
+  const int Cin = C0 + C1;
+  if (KD != 3 || KH != 3 || KW != 3 || SD != 1 || SH != 1 || SW != 1) return 0;
+  if (Cin % 32 || Cout % 32 || C0 % 32) return 0;
+  if (Wo < 8 || Ho < 8 || Do < 4) return 0;   // small planes: the per-plane kernel wastes less
+  const size_t cmax = (size_t)(C0 > C1 ? C0 : C1);
+  if ((size_t)H * W * cmax >= ((size_t)1 << 30) || (size_t)Ho * Wo * Cout >= ((size_t)1 << 30))
+    return 0;                                  // 32-bit byte offsets inside a plane
+  if (getenv("ADELL_WGRAD_NOZRING")) return 0;
+  p->ntx = adell_cdiv(Wo, 8);
+  p->nty = adell_cdiv(Ho, 8);
+  p->nci = Cin / 32;
+  p->nco = Cout / 32;
+  const long ncols = (long)N * p->ntx * p->nty;
+  const long chan_blocks = (long)p->nci * p->nco;
+  long target = 512 / chan_blocks;             // two blocks per CU over all channel tiles
+  if (target < 8) target = 8;
+  // z segments: enough units to fill the target, at least 8 steps each (2 priming planes)
+  long nseg = (target + ncols - 1) / ncols;
+  const int minseg = getenv("ADELL_ZR_MINSEG") ? atoi(getenv("ADELL_ZR_MINSEG")) : 16;
+  const long maxseg = Do / minseg > 0 ? Do / minseg : 1;
+  if (nseg > maxseg) nseg = maxseg;
+  if (nseg < 1) nseg = 1;
+  p->seglen = (int)adell_cdiv(Do, (int)nseg);
+  p->nseg = adell_cdiv(Do, p->seglen);
+  const long nunits = ncols * p->nseg;
+  p->R = (int)(nunits < target ? nunits : target);
+  return 1;
+}
+
+extern "C" size_t adell_wgrad_zring_ws_floats(const WgradZrPlan* p, int Cin, int Cout) {
+  return (size_t)p->R * 27 * Cin * Cout + (size_t)p->R * Cout + 4;
+}
+
+extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int H, int W, int C0,
+                                        int C1, const float* x0, const float* x1, int Cout, int Do,
+                                        int Ho, int Wo, const float* dy, int PD, int PH, int PW,
+                                        float* slabs, float* wsdb, const unsigned* xmax,
+                                        const unsigned* ymax, hipStream_t st) {
+  WgradZrArgs a = {};
+  a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = slabs; a.wsdb = wsdb; a.xmax = xmax; a.ymax = ymax;
+  a.N = N; a.D = D; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.Cout = Cout;
+  a.PD = PD; a.PH = PH; a.PW = PW; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+  a.ntx = p->ntx; a.nty = p->nty; a.nseg = p->nseg; a.seglen = p->seglen;
+  a.nci = p->nci; a.nco = p->nco; a.R = p->R;
+  a.dbg = getenv("ADELL_ZR_DBG") ? atoi(getenv("ADELL_ZR_DBG")) : 0;
+  const size_t lds = 2 * (3 * (size_t)ZR_PLANE + 64 * 64);
+  static bool attr_done = false;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_conv_wgrad_zring_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(adell_conv_wgrad_zring_kernel, dim3((unsigned)p->R, (unsigned)(p->nci * p->nco)),
+                     dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
