@@ -113,6 +113,10 @@ SIGNATURES = {
     "adell_conv1_small_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5),
     "adell_conv1_small_wgrad_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv1_small_bwd_weight": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6 + [ctypes.c_size_t, _vp]),
+    "adell_conv_cin_small_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv_cin_small_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv_cin_small_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
+    "adell_conv_cin_small_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),
     "adell_multi_copy": (_i, [_vp, _i, _vp, _vp]),
     "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_fwd": (_i, [_vp, _l, _i, _i, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp]),

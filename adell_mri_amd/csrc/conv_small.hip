@@ -455,3 +455,258 @@ extern "C" int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const fl
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------
+// small-Cin forward and backward-data (the 2-channel input block of the U-Nets,
+// unet.py:260-273: Conv3d(2 -> 2), Conv3d(2 -> 32)): exact fp32 on the vector ALU.
+// An MFMA tile would pad Cin to a 16-channel chunk and Cout to 32 columns (2 -> 2 ran at 1.3
+// TFLOP/s, i.e. 0.34 ms for a 34 MB pass).
+//   forward      : thread = one output voxel, its KD*9*Cin inputs in registers, all output
+//                  channels of a 32-wide tile accumulated from LDS-broadcast weights; bias and
+//                  the per-channel (sum, sum of squares) partials in the epilogue.
+//   backward-data: thread = one input voxel, dX[ci] += dY[v + P - tap][co] * w[co][ci][tap],
+//                  rows of dY by 16-byte loads, weights [tap][co][ci] broadcast from LDS.
+// k = 3 in H and W, 1 or 3 in D (the 2-D U-Net is the D = 1 case), stride 1, one source.
+// ---------------------------------------------------------------------------
+struct CinSmallArgs {
+  const float* x;      // fwd: input [N][D][H][W][Cin];  dgrad: dY [N][Do][Ho][Wo][Cout]
+  const float* w;      // canonical [Cout][Cin][KD][3][3]
+  const float* bias;
+  float* y;            // fwd: [N][Do][Ho][Wo][Cout];     dgrad: dX [N][D][H][W][Cin]
+  float* part;         // fwd: [N][tiles][Cout][2] or null
+  int N, D, H, W, Cout, Do, Ho, Wo, PD, PH, PW;
+  int tiles;           // blocks per batch item
+};
+
+// Work mapping of both kernels: a lane is (voxel, quad of 4 output channels); the LPV = 2^k
+// lanes of a voxel sit next to each other, so a wave touches 64 / LPV consecutive voxels and
+// every global access is a run of whole NDHWC rows (thread-per-voxel mappings measured 2-3x
+// slower than the MFMA path they replace: 64 partial lines per access).
+template <int CIN, int KD>
+__global__ __launch_bounds__(256) void adell_cin_small_fwd_kernel(CinSmallArgs a, int lpv) {
+  constexpr int NTAP = KD * 9, COT = 64;
+  __shared__ __attribute__((aligned(16))) float sw[NTAP * CIN * COT];   // [tap][ci][co]
+  __shared__ float sred[4][COT][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.z, co0 = blockIdx.y * COT;
+  const int nco = (a.Cout - co0) < COT ? (a.Cout - co0) : COT;
+  for (int i = tid; i < NTAP * CIN * COT; i += 256) {
+    const int co = i % COT, ci = (i / COT) % CIN, tap = i / (COT * CIN);
+    sw[i] = co < nco ? a.w[((size_t)(co0 + co) * CIN + ci) * NTAP + tap] : 0.f;
+  }
+  const int vpb = 256 / lpv;                       // voxels per block
+  const int quad = tid & (lpv - 1);
+  const long vox = (long)a.Do * a.Ho * a.Wo;
+  const long v = (long)blockIdx.x * vpb + tid / lpv;
+  const bool vok = v < vox;
+  const int ox = (int)(v % a.Wo), oy = (int)((v / a.Wo) % a.Ho), oz = (int)(v / ((long)a.Wo * a.Ho));
+  float in[NTAP][CIN];
+  const float* xb = a.x + (size_t)nb * a.D * a.H * a.W * CIN;
+#pragma unroll
+  for (int kz = 0; kz < KD; ++kz)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t = (kz * 3 + ky) * 3 + kx;
+        const int iz = oz - a.PD + kz, iy = oy - a.PH + ky, ix = ox - a.PW + kx;
+        const bool ok = vok & (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+        const float* p = xb + ((size_t)(iz * a.H + iy) * a.W + ix) * CIN;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) in[t][c] = ok ? p[c] : 0.f;
+      }
+  __syncthreads();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      const float4 wv = *reinterpret_cast<const float4*>(sw + (t * CIN + c) * COT + 4 * quad);
+      acc.x += in[t][c] * wv.x;
+      acc.y += in[t][c] * wv.y;
+      acc.z += in[t][c] * wv.z;
+      acc.w += in[t][c] * wv.w;
+    }
+  const int c = 4 * quad;                              // first channel of this lane inside the tile
+  float val[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bool ok = vok && c + j < nco;
+    val[j] = ok ? val[j] + (a.bias ? a.bias[co0 + c + j] : 0.f) : 0.f;
+  }
+  if (vok && c < nco) {
+    float* yp = a.y + ((size_t)nb * vox + v) * a.Cout + co0 + c;
+    if (c + 3 < nco && (a.Cout & 3) == 0) {
+      *reinterpret_cast<float4*>(yp) = make_float4(val[0], val[1], val[2], val[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < nco) yp[j] = val[j];
+    }
+  }
+  if (a.part) {
+    float s1[4], s2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1[j] = val[j];
+      s2[j] = val[j] * val[j];
+      for (int o = 32; o >= lpv; o >>= 1) {   // over the voxels of the wave (same quad)
+        s1[j] += __shfl_xor(s1[j], o, 64);
+        s2[j] += __shfl_xor(s2[j], o, 64);
+      }
+    }
+    if (lane < lpv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sred[wave][c + j][0] = s1[j];
+        sred[wave][c + j][1] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < nco) {
+      float* p = a.part + (((size_t)nb * a.tiles + blockIdx.x) * a.Cout + co0 + tid) * 2;
+      p[0] = (sred[0][tid][0] + sred[1][tid][0]) + (sred[2][tid][0] + sred[3][tid][0]);
+      p[1] = (sred[0][tid][1] + sred[1][tid][1]) + (sred[2][tid][1] + sred[3][tid][1]);
+    }
+  }
+}
+
+template <int CIN, int KD>
+__global__ __launch_bounds__(256) void adell_cin_small_bwd_data_kernel(CinSmallArgs a, int lpv) {
+  constexpr int NTAP = KD * 9;
+  extern __shared__ float swd[];   // [tap][co][CIN]
+  const int tid = threadIdx.x;
+  const int nb = blockIdx.z;
+  for (int i = tid; i < NTAP * a.Cout * CIN; i += 256) {
+    const int ci = i % CIN, co = (i / CIN) % a.Cout, tap = i / (CIN * a.Cout);
+    swd[i] = a.w[((size_t)co * CIN + ci) * NTAP + tap];
+  }
+  __syncthreads();
+  const int vpb = 256 / lpv;
+  const int quad = tid & (lpv - 1);
+  const long vox = (long)a.D * a.H * a.W;
+  const long v = (long)blockIdx.x * vpb + tid / lpv;
+  const bool vok = v < vox;
+  const int ix = (int)(v % a.W), iy = (int)((v / a.W) % a.H), iz = (int)(v / ((long)a.W * a.H));
+  const float* yb = a.x + (size_t)nb * a.Do * a.Ho * a.Wo * a.Cout;
+  const int nq = a.Cout >> 2;      // quads of the dY row; lane `quad` takes quad, quad + lpv, ...
+  float acc[CIN];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int kz = 0; kz < KD; ++kz)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int t = (kz * 3 + ky) * 3 + kx;
+        const int oz = iz + a.PD - kz, oy = iy + a.PH - ky, ox = ix + a.PW - kx;
+        if (vok & (oz >= 0) & (oz < a.Do) & (oy >= 0) & (oy < a.Ho) & (ox >= 0) & (ox < a.Wo)) {
+          const float4* dyr = reinterpret_cast<const float4*>(
+              yb + ((size_t)(oz * a.Ho + oy) * a.Wo + ox) * a.Cout);
+          const float* wt = swd + t * a.Cout * CIN;
+          for (int q = quad; q < nq; q += lpv) {
+            const float4 g = dyr[q];
+            const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < CIN; ++c) acc[c] += gv[j] * wt[(4 * q + j) * CIN + c];
+          }
+        }
+      }
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+    for (int o = 1; o < lpv; o <<= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+  if (vok && quad == 0) {
+    float* o = a.y + ((size_t)nb * vox + v) * CIN;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) o[c] = acc[c];
+  }
+}
+
+static bool adell_cin_small_ok(const adell_conv3d_desc* d) {
+  const int Cin = d->C0 + d->C1;
+  return d->C1 == 0 && Cin >= 1 && Cin <= 4 && (d->KD == 1 || d->KD == 3) && d->KH == 3 &&
+         d->KW == 3 && d->SD == 1 && d->SH == 1 && d->SW == 1;
+}
+
+extern "C" int adell_conv_cin_small_applicable(const adell_conv3d_desc* d) {
+  return d && adell_cin_small_ok(d) ? 1 : 0;
+}
+
+/* rows per batch item of the statistics-partials buffer the forward writes */
+// lanes per voxel: one per quad of output channels of a 64-channel tile, a power of two
+static int adell_cin_small_lpv(int Cout) {
+  const int q = ((Cout < 64 ? Cout : 64) + 3) / 4;
+  int l = 1;
+  while (l < q) l <<= 1;
+  return l;
+}
+
+extern "C" int adell_conv_cin_small_ntiles(const adell_conv3d_desc* d) {
+  if (!d || !adell_cin_small_ok(d)) return ADELL_E_BADARG;
+  const int vpb = 256 / adell_cin_small_lpv(d->Cout);
+  return (int)(((long)d->Do * d->Ho * d->Wo + vpb - 1) / vpb);
+}
+
+template <int KD>
+static int adell_cin_small_fwd_launch(const CinSmallArgs& a, int Cin, dim3 grid, int lpv,
+                                      hipStream_t st) {
+  switch (Cin) {
+    case 1: hipLaunchKernelGGL((adell_cin_small_fwd_kernel<1, KD>), grid, dim3(256), 0, st, a, lpv); break;
+    case 2: hipLaunchKernelGGL((adell_cin_small_fwd_kernel<2, KD>), grid, dim3(256), 0, st, a, lpv); break;
+    case 3: hipLaunchKernelGGL((adell_cin_small_fwd_kernel<3, KD>), grid, dim3(256), 0, st, a, lpv); break;
+    default: hipLaunchKernelGGL((adell_cin_small_fwd_kernel<4, KD>), grid, dim3(256), 0, st, a, lpv); break;
+  }
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv_cin_small_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
+                                        const float* bias, float* y, float* stat_partials,
+                                        void* stream) {
+  ADELL_REQUIRE(d && x && w && y && adell_cin_small_ok(d), "conv_cin_small_fwd: bad arguments");
+  ADELL_REQUIRE(d->N <= 65535, "conv_cin_small_fwd: batch too large");
+  CinSmallArgs a = {};
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.part = stat_partials;
+  a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo; a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
+  a.tiles = adell_conv_cin_small_ntiles(d);
+  const int lpv = adell_cin_small_lpv(d->Cout);
+  dim3 grid((unsigned)a.tiles, (unsigned)adell_cdiv(d->Cout, 64), (unsigned)d->N);
+  return d->KD == 1 ? adell_cin_small_fwd_launch<1>(a, d->C0, grid, lpv, (hipStream_t)stream)
+                    : adell_cin_small_fwd_launch<3>(a, d->C0, grid, lpv, (hipStream_t)stream);
+}
+
+template <int KD>
+static int adell_cin_small_bwd_launch(const CinSmallArgs& a, int Cin, dim3 grid, size_t lds,
+                                      int lpv, hipStream_t st) {
+  switch (Cin) {
+    case 1: hipLaunchKernelGGL((adell_cin_small_bwd_data_kernel<1, KD>), grid, dim3(256), lds, st, a, lpv); break;
+    case 2: hipLaunchKernelGGL((adell_cin_small_bwd_data_kernel<2, KD>), grid, dim3(256), lds, st, a, lpv); break;
+    case 3: hipLaunchKernelGGL((adell_cin_small_bwd_data_kernel<3, KD>), grid, dim3(256), lds, st, a, lpv); break;
+    default: hipLaunchKernelGGL((adell_cin_small_bwd_data_kernel<4, KD>), grid, dim3(256), lds, st, a, lpv); break;
+  }
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv_cin_small_bwd_data(const adell_conv3d_desc* d, const float* dy,
+                                             const float* w, float* dx, void* stream) {
+  ADELL_REQUIRE(d && dy && w && dx && adell_cin_small_ok(d), "conv_cin_small_bwd_data: bad arguments");
+  ADELL_REQUIRE(d->Cout % 4 == 0 && (((uintptr_t)dy) & 15) == 0,
+                "conv_cin_small_bwd_data: Cout must be a multiple of 4");
+  const size_t lds = (size_t)d->KD * 9 * d->Cout * d->C0 * sizeof(float);
+  ADELL_REQUIRE(lds <= 64 * 1024 && d->N <= 65535, "conv_cin_small_bwd_data: Cout too large");
+  CinSmallArgs a = {};
+  a.x = dy; a.w = w; a.y = dx;
+  a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
+  a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo; a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
+  int lpv = 1;                       // lanes per voxel: one per quad of dY, at most 16
+  while (lpv < d->Cout / 4 && lpv < 16) lpv <<= 1;
+  const int vpb = 256 / lpv;
+  dim3 grid((unsigned)(((long)d->D * d->H * d->W + vpb - 1) / vpb), 1, (unsigned)d->N);
+  return d->KD == 1 ? adell_cin_small_bwd_launch<1>(a, d->C0, grid, lds, lpv, (hipStream_t)stream)
+                    : adell_cin_small_bwd_launch<3>(a, d->C0, grid, lds, lpv, (hipStream_t)stream);
+}

@@ -78,6 +78,17 @@ class _Conv3dFn(torch.autograd.Function):
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         stride, padding, want_stats, wref = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
+        ctx.cin_small = wp == "cin_small"
+        if ctx.cin_small:  # 2-channel input block: exact fp32 on the vector ALU, canonical weights
+            y, part = ops.conv_cin_small_fwd(x0, weight, bias, padding, want_stats)
+            ctx.small1 = False
+            ctx.amax = None
+            ctx.save_for_backward(x0, x1, weight)
+            ctx.conf = (k, stride, padding, bias is not None, False, wref)
+            if part is None:
+                part = y.new_empty(0)
+            ctx.mark_non_differentiable(part)
+            return y, part
         ctx.small1 = wp is None
         if ctx.small1:  # logits head: 1x1x1, Cout <= 4 -- one HBM-bound pass on canonical weights
             y = ops.conv1_small_fwd(x0, x1, weight, bias)
@@ -122,7 +133,9 @@ class _Conv3dFn(torch.autograd.Function):
             return dx0, dx1, dw, db, None, None, None
         amax = ctx.amax
         dy_amax = None
-        if need[0] or (x1 is not None and need[1]):
+        if ctx.cin_small and need[0] and dy.shape[1] % 4 == 0:
+            dx0 = ops.conv_cin_small_bwd_data(dy, weight, tuple(x0.shape[2:]), padding)
+        elif need[0] or (x1 is not None and need[1]):
             wpb = _packed(wref.obj, 1)
             if amax is not None and isinstance(wpb, ops.SplitWeight):
                 dy_amax = amax[1:2]
@@ -154,8 +167,13 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     conf = (stride, padding, want_stats, _Ref(weight))
     Cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
     small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
-    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual,
-                              None if small1 else _packed(weight, 0), conf)
+    if small1:
+        wp = None
+    elif ops.conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
+        wp = "cin_small"
+    else:
+        wp = _packed(weight, 0)
+    y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual, wp, conf)
     if want_stats and part.numel() > 0:
         y._adell_partials = part
     return y

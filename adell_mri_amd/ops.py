@@ -6,6 +6,7 @@ are the only places that care about strides. Everything is enqueued on
 ``torch.cuda.current_stream()``; PyTorch only provides memory and streams.
 """
 import ctypes
+import os
 
 import torch
 
@@ -229,6 +230,54 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual),
             _ptr(y), _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d, residual is not None)))
     return y, part
+
+
+# ---- convolutions with Cin <= 4 (the 2-channel input block): canonical weights, vector ALU ----
+def conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
+    if residual is not None or x1 is not None or weight.dim() != 5 or x0.shape[1] > 4:
+        return False
+    if os.environ.get("ADELL_NO_CIN_SMALL"):
+        return False
+    k = tuple(weight.shape[2:])
+    # measured at 128^3 (tools/bench_layers.py): 2 -> 2 0.21 ms here vs 0.34 ms on the MFMA path,
+    # but 2 -> 32 is slower here (the vector ALU does 1728 FMAs per voxel): narrow outputs only
+    if weight.shape[0] > 4 and not os.environ.get("ADELL_CIN_SMALL_ALL"):
+        return False
+    return k[0] in (1, 3) and k[1:] == (3, 3) and tuple(stride) == (1, 1, 1)
+
+
+def conv_cin_small_fwd(x, weight, bias, padding, want_stats):
+    _require_cuda(x, weight, bias)
+    x = ndhwc(x)
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[0]
+    d = make_conv_desc(N, (D, H, W), Cin, 0, Cout, tuple(weight.shape[2:]), 1, padding)
+    y = new_act(N, Cout, d.Do, d.Ho, d.Wo, x.device)
+    part = None
+    if want_stats:
+        nt = _lib.lib().adell_conv_cin_small_ntiles(ctypes.byref(d))
+        if nt < 0:
+            check(nt)
+        part = torch.empty((N, nt, Cout, 2), device=x.device, dtype=torch.float32)
+    check(_timed("adell_cin_small_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv_cin_small_fwd(
+                     ctypes.byref(d), _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(y),
+                     _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
+    return y, part
+
+
+def conv_cin_small_bwd_data(dy, weight, in_size, padding):
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    Cin = weight.shape[1]
+    d = make_conv_desc(N, tuple(in_size), Cin, 0, Cout, tuple(weight.shape[2:]), 1, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    dx = new_act(N, Cin, *in_size, dy.device)
+    check(_timed("adell_cin_small_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv_cin_small_bwd_data(
+                     ctypes.byref(d), _ptr(dy), _ptr(weight.contiguous()), _ptr(dx), _stream()),
+                 _conv_tag(d, "dgrad"), _conv_bytes(d)))
+    return dx
 
 
 # ---- 1x1x1 convolution with Cout <= 4 (logits head): canonical weights, one pass each way ----

@@ -374,6 +374,18 @@ int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const float* x0, co
                                  const float* dy, float* dw, float* db, void* workspace,
                                  size_t workspace_bytes, void* stream);
 
+/* Convolutions with Cin <= 4 (the 2-channel input block, unet.py:260-273), k = 3 in H and W,
+ * 1 or 3 in D, stride 1, one source, canonical weights w [Cout][Cin][KD][3][3]: exact fp32 on
+ * the vector ALU instead of an MFMA tile padded to 16 input channels. The forward writes the
+ * same (sum, sum of squares) partials as adell_conv3d_fwd, [N][ntiles][Cout][2]. The
+ * backward-data produces dX [N][D][H][W][Cin] from dY (Cout a multiple of 4). */
+int adell_conv_cin_small_applicable(const adell_conv3d_desc* d);
+int adell_conv_cin_small_ntiles(const adell_conv3d_desc* d);
+int adell_conv_cin_small_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
+                             const float* bias, float* y, float* stat_partials, void* stream);
+int adell_conv_cin_small_bwd_data(const adell_conv3d_desc* d, const float* dy, const float* w,
+                                  float* dx, void* stream);
+
 /* dst[off_r + i] = src_r[i] for rows r of a DEVICE table of `rows` triples (source pointer,
  * destination offset in elements, element count <= 16384 per row): gathers the parameter
  * gradients autograd produced into the flat gradient buffer of the fused optimisers. */

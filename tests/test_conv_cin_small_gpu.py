@@ -1,0 +1,46 @@
+"""Small-Cin (<= 4) convolution kernels (csrc/conv_small.hip) against torch CPU fp64."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adell_mri_amd import functional as HF
+from adell_mri_amd import ops
+
+pytestmark = pytest.mark.gpu
+os.environ["ADELL_CIN_SMALL_ALL"] = "1"   # exercise the kernels at every width, not only Cout <= 4
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("n,cin,cout,size,kd,pad,bias", [(1, 2, 2, (9, 17, 21), 3, 1, True),
+                                                         (2, 2, 32, (8, 12, 19), 3, 1, True),
+                                                         (1, 1, 16, (1, 33, 30), 1, (0, 1, 1), True),
+                                                         (1, 3, 40, (7, 9, 11), 3, 0, False),
+                                                         (1, 4, 8, (6, 10, 34), 3, 1, True)])
+def test_cin_small_fwd_stats_and_grads_match_torch(cuda, n, cin, cout, size, kd, pad, bias):
+    g = torch.Generator().manual_seed(cin * 10 + cout)
+    x = torch.randn(n, cin, *size, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn(cout, cin, kd, 3, 3, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
+    b = torch.randn(cout, generator=g, dtype=torch.float64).requires_grad_(True) if bias else None
+    y = F.conv3d(x, w, b, padding=pad)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xd = ops.ndhwc(x.detach().float().to(cuda)).requires_grad_(True)
+    wd = w.detach().float().to(cuda).requires_grad_(True)
+    bd = b.detach().float().to(cuda).requires_grad_(True) if bias else None
+    assert ops.conv_cin_small_ok(wd, xd, None, (1, 1, 1), ops._triple(pad), None)
+    yd = HF.conv3d(xd, wd, bd, stride=1, padding=pad, want_stats=True)
+    assert _rel(yd.detach().cpu().double(), y.detach()) < 1e-5
+    part = yd._adell_partials.double().sum(1).cpu()     # [N, Cout, 2]
+    want = torch.stack([y.detach().sum((2, 3, 4)), (y.detach() ** 2).sum((2, 3, 4))], -1)
+    assert _rel(part, want) < 1e-5
+    yd.backward(ops.ndhwc(dy.float().to(cuda)))
+    assert _rel(wd.grad.cpu().double(), w.grad) < 2e-5
+    if bias:
+        assert _rel(bd.grad.cpu().double(), b.grad) < 2e-5
+    if cout % 4 == 0:
+        assert _rel(xd.grad.cpu().double(), x.grad) < 1e-5
