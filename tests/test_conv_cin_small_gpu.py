@@ -1,6 +1,4 @@
 """Small-Cin (<= 4) convolution kernels (csrc/conv_small.hip) against torch CPU fp64."""
-import os
-
 import pytest
 import torch
 import torch.nn.functional as F
@@ -9,7 +7,6 @@ from adell_mri_amd import functional as HF
 from adell_mri_amd import ops
 
 pytestmark = pytest.mark.gpu
-os.environ["ADELL_CIN_SMALL_ALL"] = "1"   # exercise the kernels at every width, not only Cout <= 4
 
 
 def _rel(a, b):
@@ -21,7 +18,9 @@ def _rel(a, b):
                                                          (1, 1, 16, (1, 33, 30), 1, (0, 1, 1), True),
                                                          (1, 3, 40, (7, 9, 11), 3, 0, False),
                                                          (1, 4, 8, (6, 10, 34), 3, 1, True)])
-def test_cin_small_fwd_stats_and_grads_match_torch(cuda, n, cin, cout, size, kd, pad, bias):
+def test_cin_small_fwd_stats_and_grads_match_torch(cuda, monkeypatch, n, cin, cout, size, kd, pad,
+                                                   bias):
+    monkeypatch.setenv("ADELL_CIN_SMALL_ALL", "1")   # every width, not only Cout <= 4
     g = torch.Generator().manual_seed(cin * 10 + cout)
     x = torch.randn(n, cin, *size, generator=g, dtype=torch.float64).requires_grad_(True)
     w = (torch.randn(cout, cin, kd, 3, 3, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
