@@ -391,7 +391,89 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   return ADELL_OK;
 }
 
-static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_t st) {
+// ---- split-K for the low-resolution layers --------------------------------------------------
+// 8^3 - 16^3 levels have 8 - 64 bricks: a block that walks all 8 - 16 channel chunks of its brick
+// takes ~80 us while most of the chip idles. The chunks are shared out over `ksplit` blocks per
+// brick instead (blockIdx.z); each writes raw partial outputs to its slab, and this kernel folds
+// the slabs in fixed order, adds bias and residual, stores y (or the two halves of a split
+// store) and emits the per-tile (sum, sum of squares) partials of the normal epilogue.
+struct ConvFoldArgs {
+  const float* slabs;
+  const float* bias;
+  const float* res;
+  float* y0;
+  float* y1;
+  float* part;
+  long vox;           // output voxels per batch item
+  long slab;          // floats per slab
+  int ksplit, Cout, ysplit, ntiles;
+};
+
+__global__ __launch_bounds__(256) void adell_conv_splitk_fold_kernel(ConvFoldArgs a) {
+  __shared__ float4 sred[256][2];
+  const int tid = threadIdx.x;
+  const int cq = a.Cout >> 2;              // quads per row; 256 % cq == 0 (checked on the host)
+  const int q = tid % cq, r0 = tid / cq, rstep = 256 / cq;
+  const int nb = blockIdx.y, tile = blockIdx.x;
+  const long vpt = (a.vox + a.ntiles - 1) / a.ntiles;
+  const long v0 = (long)tile * vpt;
+  const long v1 = (v0 + vpt) < a.vox ? (v0 + vpt) : a.vox;
+  const int c = 4 * q;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + c);
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (long v = v0 + r0; v < v1; v += rstep) {
+    const size_t row = (size_t)nb * a.vox + v;
+    float4 t = bv;
+    for (int k = 0; k < a.ksplit; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(a.slabs + (size_t)k * a.slab + row * a.Cout + c);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    if (a.res) {
+      const float4 u = *reinterpret_cast<const float4*>(a.res + row * a.Cout + c);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    float* o = c < a.ysplit ? a.y0 + row * a.ysplit + c
+                            : a.y1 + row * (a.Cout - a.ysplit) + (c - a.ysplit);
+    *reinterpret_cast<float4*>(o) = t;
+    s1.x += t.x; s1.y += t.y; s1.z += t.z; s1.w += t.w;
+    s2.x += t.x * t.x; s2.y += t.y * t.y; s2.z += t.z * t.z; s2.w += t.w * t.w;
+  }
+  if (a.part) {
+    sred[tid][0] = s1;
+    sred[tid][1] = s2;
+    __syncthreads();
+    if (tid < cq) {
+      float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+      for (int r = 0; r < rstep; ++r) {
+        const float4 u = sred[r * cq + tid][0], w = sred[r * cq + tid][1];
+        t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
+        t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
+      }
+      float* p = a.part + (((size_t)nb * a.ntiles + tile) * a.Cout + 4 * tid) * 2;
+      p[0] = t1.x; p[1] = t2.x; p[2] = t1.y; p[3] = t2.y;
+      p[4] = t1.z; p[5] = t2.z; p[6] = t1.w; p[7] = t2.w;
+    }
+  }
+}
+
+// number of K shares for this problem (1 = no split) given the planned tile
+static int adell_splitk_shares(const ConvArgs& a, const ConvTile& t, int N) {
+  if (getenv("ADELL_NO_SPLITK")) return 1;
+  const int nchunk = adell_cdiv(a.Cin, 16);
+  const long blocks = (long)a.ntx * a.nty * a.ntz * adell_cdiv(a.Cout, t.BN) * N;
+  const int cq = a.Cout / 4;
+  if (a.shuffle || a.Cout % 4 || cq > 256 || 256 % cq || a.ysplit % 4 || nchunk < 4 || blocks > 256)
+    return 1;
+  int ks = (int)(512 / blocks);   // measured: a target of 1024 blocks costs more slab traffic than it hides
+  if (ks > nchunk) ks = nchunk;
+  if (ks < 2) return 1;
+  const int cpk = adell_cdiv(nchunk, ks);
+  return adell_cdiv(nchunk, cpk);
+}
+
+static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_t st,
+                                   void* ws = nullptr, size_t ws_bytes = 0) {
   ConvTile t;
   size_t lds;
   int rc = adell_plan_f16(a, N, &t, &lds);
@@ -417,8 +499,17 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
       return ADELL_E_UNSUPPORTED;
     }
   }
+  // split-K when the caller supplied a workspace and the problem is small (see the fold kernel)
+  ConvArgs full = a;
+  int shares = ws ? adell_splitk_shares(a, t, N) : 1;
+  const long slab = (long)N * a.Do * a.Ho * a.Wo * a.Cout;
+  if (shares > 1 && (size_t)shares * slab * sizeof(float) > ws_bytes) shares = 1;
+  a.ksplit = shares;
+  a.slab = slab;
+  if (shares > 1) a.y0 = (float*)ws;
   // blocks are dealt to the 8 XCDs in contiguous ranges (see the kernel): pad the grid
-  dim3 grid((unsigned)(8 * ((nsp + 7) / 8)), (unsigned)adell_cdiv(a.Cout, t.BN), (unsigned)N);
+  dim3 grid((unsigned)(8 * ((nsp + 7) / 8)), (unsigned)adell_cdiv(a.Cout, t.BN),
+            (unsigned)(N * shares));
   const bool spec = a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 &&
                     a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.lTX == 3 && a.lTY == 3 &&
                     a.lTZ == 2 && a.shuffle == 0 && a.vecx && a.GKH == 3 && t.cfg <= 1 &&
@@ -426,18 +517,30 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
                     getenv("ADELL_IGEMM_NOSPEC") == nullptr;
   const bool w8 = getenv("ADELL_IGEMM_W8") != nullptr;   // experiment: 8-wave blocks (measured slower)
+  int rc2 = ADELL_OK;
   switch (t.cfg) {
     case 0:
-      if (spec && w8) return adell_launch_conv_f16<1, 2, 8, 1, 1>(a, e, grid, lds, st);
-      return spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
+      if (spec && w8) { rc2 = adell_launch_conv_f16<1, 2, 8, 1, 1>(a, e, grid, lds, st); break; }
+      rc2 = spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 2, 4, 1, 0>(a, e, grid, lds, st);
+      break;
     case 1:
-      if (spec && w8) return adell_launch_conv_f16<1, 1, 8, 1, 1>(a, e, grid, lds, st);
-      return spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)
+      if (spec && w8) { rc2 = adell_launch_conv_f16<1, 1, 8, 1, 1>(a, e, grid, lds, st); break; }
+      rc2 = spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 1, 4, 1, 0>(a, e, grid, lds, st);
-    case 2: return adell_launch_conv_f16<1, 1, 2, 2, 0>(a, e, grid, lds, st);
-    default: return adell_launch_conv_f16<1, 1, 4, 1, 0>(a, e, grid, lds, st);
+      break;
+    case 2: rc2 = adell_launch_conv_f16<1, 1, 2, 2, 0>(a, e, grid, lds, st); break;
+    default: rc2 = adell_launch_conv_f16<1, 1, 4, 1, 0>(a, e, grid, lds, st); break;
   }
+  if (rc2 != ADELL_OK || shares == 1) return rc2;
+  ConvFoldArgs f = {};
+  f.slabs = (const float*)ws; f.bias = full.bias; f.res = full.res; f.y0 = full.y0; f.y1 = full.y1;
+  f.part = full.part; f.vox = (long)a.Do * a.Ho * a.Wo; f.slab = slab; f.ksplit = shares;
+  f.Cout = a.Cout; f.ysplit = full.ysplit; f.ntiles = (int)nsp;
+  hipLaunchKernelGGL(adell_conv_splitk_fold_kernel, dim3((unsigned)nsp, (unsigned)N), dim3(256), 0,
+                     st, f);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
 }
 
 extern "C" int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d) {
@@ -484,6 +587,51 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
   ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
+}
+
+// Workspace that lets the forward / backward-data calls below split K on small problems
+// (0: this problem never splits).
+extern "C" long adell_conv3d_splitk_workspace(const adell_conv3d_desc* d, int backward_data) {
+  if (!d) return ADELL_E_BADARG;
+  ConvArgs a;
+  float dummy;
+  int rc = backward_data ? adell_fill_bwd_data(a, d, &dummy, &dummy, d->C1 > 0 ? &dummy : nullptr)
+                         : adell_fill_fwd(a, d, &dummy, d->C1 > 0 ? &dummy : nullptr, nullptr,
+                                          nullptr, &dummy, nullptr);
+  if (rc != ADELL_OK) return 0;
+  ConvTile t;
+  size_t lds;
+  if (adell_plan_f16(a, d->N, &t, &lds) != ADELL_OK) return 0;
+  const int shares = adell_splitk_shares(a, t, d->N);
+  if (shares <= 1) return 0;
+  return (long)sizeof(float) * shares * d->N * a.Do * a.Ho * a.Wo * a.Cout;
+}
+
+extern "C" int adell_conv3d_fwd_f16x3_ws(const adell_conv3d_desc* d, const float* x0,
+                                         const float* x1, const void* w_split,
+                                         const float* wscale, const float* bias,
+                                         const float* residual, float* y, float* stat_partials,
+                                         uint32_t* in_absmax, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+extern "C" int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const float* dy,
+                                              const void* w_split_bwd, const float* wscale,
+                                              float* dx0, float* dx1, uint32_t* dy_absmax,
+                                              void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 // ConvTranspose3d (kernel = stride = factors) on the f16x3 kernel. Forward: w_split = the

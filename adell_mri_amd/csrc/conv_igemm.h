@@ -41,6 +41,8 @@ struct ConvArgs {
   int GKH;            // f16 kernel: ky rows per staged weight group (KH, or fewer for big kernels)
   int Cs;             // channels of the shuffled destination
   int vecx, vecw;     // 16-byte global loads legal for input / weights
+  int ksplit;         // f16 kernel: > 1 = blockIdx.z also indexes a share of the channel chunks
+  long slab;          // ... whose partial outputs go to y0 + share * slab (plain [N][vox][Cout])
 };
 
 template <int MT, int NT, int WM, int WN>

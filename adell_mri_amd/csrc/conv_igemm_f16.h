@@ -92,7 +92,10 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   const int ty = t % a.nty;
   const int tz = t / a.nty;
   const int n0 = blockIdx.y * BN;
-  const int nb = blockIdx.z;
+  // split-K (low-resolution layers: too few bricks to fill the chip): blockIdx.z = item * ksplit
+  // + share; a share accumulates its channel chunks and stores raw partial outputs to its slab
+  const int ksplit = a.ksplit > 1 ? a.ksplit : 1;
+  const int nb = blockIdx.z / ksplit, kshare = blockIdx.z - nb * ksplit;
   const int ox0 = tx << lTX, oy0 = ty << lTY, oz0 = tz << lTZ;
   const int HXY = HX * HY;
   const int lx0 = ox0 * SW - a.PW, ly0 = oy0 * SH - a.PH, lz0 = oz0 * SD - a.PD;
@@ -259,8 +262,17 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       wreg[u] = f;
     }
   };
-  if (wpipe) wfetch(0, 0);
-  for (int ch = 0; ch < nchunk; ++ch) {
+  const int cpk = (nchunk + ksplit - 1) / ksplit;
+  const int c_beg = kshare * cpk, c_end = (c_beg + cpk) < nchunk ? (c_beg + cpk) : nchunk;
+  if (ksplit > 1) {
+    a.y0 += (size_t)kshare * a.slab;
+    a.ysplit = a.Cout;
+    a.bias = nullptr;
+    a.res = nullptr;
+    a.part = nullptr;
+  }
+  if (wpipe && c_beg < c_end) wfetch(c_beg, 0);
+  for (int ch = c_beg; ch < c_end; ++ch) {
     const int c0 = ch * CC;
     float mx = 0.f;
     const bool skipA = (e.dbg & 1) && ch > 0;
@@ -302,7 +314,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       if (kA < -96) kA = -96;
     }
     const float scaleA = __int_as_float((kA + 127) << 23);
-    if (ch > 0 && kA != kA_prev) {
+    if (ch > c_beg && kA != kA_prev) {
       const float f = __int_as_float((kA - kA_prev + 127) << 23);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -384,7 +396,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       __syncthreads();
       if (wpipe && !skipB) {
         if (grp + 1 < ngroups) wfetch(ch, grp + 1);
-        else if (ch + 1 < nchunk) wfetch(ch + 1, 0);
+        else if (ch + 1 < c_end) wfetch(ch + 1, 0);
       }
       // ---- 3 f16 MFMAs per (tap, 32x32 tile) ---------------------------------------------
       const char* sAg = sA + (size_t)((kz * HY + ky0) * HX) * 64;

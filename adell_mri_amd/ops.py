@@ -191,6 +191,14 @@ def pack_weight_f16x3(w, mode):
     return SplitWeight(halfs, scale)
 
 
+def _splitk_workspace(d, backward, device):
+    """(workspace tensor or None, bytes) for the split-K path of the small (8^3 - 16^3) layers."""
+    nbytes = _lib.lib().adell_conv3d_splitk_workspace(ctypes.byref(d), backward)
+    if nbytes <= 0:
+        return None, 0
+    return _workspace(nbytes, device), nbytes
+
+
 def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, residual=None,
                want_stats=False, amax=None):
     """y = conv(cat(x0, x1)) + bias + residual ; optional (sum, sumsq) partials.
@@ -219,11 +227,12 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
     if split:
+        ws, wsb = _splitk_workspace(d, 0, x0.device)
         check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
-                     lambda: _lib.lib().adell_conv3d_fwd_f16x3(
+                     lambda: _lib.lib().adell_conv3d_fwd_f16x3_ws(
                          ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed.halfs),
                          _ptr(w_packed.scale), _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
-                         _ptr(amax), _stream()), _conv_tag(d, "fwd"),
+                         _ptr(amax), _ptr(ws), wsb, _stream()), _conv_tag(d, "fwd"),
                      _conv_bytes(d, residual is not None)))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
@@ -353,11 +362,12 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, 
     dx0 = new_act(N, C0, *in_size, dy.device)
     dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
     if split:
+        ws, wsb = _splitk_workspace(d, 1, dy.device)
         check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
-                     lambda: _lib.lib().adell_conv3d_bwd_data_f16x3(
+                     lambda: _lib.lib().adell_conv3d_bwd_data_f16x3_ws(
                          ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs),
-                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _ptr(amax), _stream()),
-                     _conv_tag(d, "dgrad"), _conv_bytes(d)))
+                         _ptr(w_packed_bwd.scale), _ptr(dx0), _ptr(dx1), _ptr(amax), _ptr(ws), wsb,
+                         _stream()), _conv_tag(d, "dgrad"), _conv_bytes(d)))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_bwd_data(

@@ -116,6 +116,22 @@ int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                 const void* w_split_bwd, const float* wscale, float* dx0,
                                 float* dx1, uint32_t* dy_absmax, void* stream);
 
+/* The same two calls with a caller-provided workspace (adell_conv3d_splitk_workspace bytes; 0 =
+ * never needed): layers with too few output bricks to fill the chip (the 8^3 - 16^3 levels)
+ * share the channel chunks of a brick out over several blocks (split-K) and fold the partial
+ * outputs in fixed order -- bit-reproducible, bias / residual / statistics as in the plain call.
+ * Without a workspace (or with one that is too small) they behave like the plain calls. */
+long adell_conv3d_splitk_workspace(const adell_conv3d_desc* d, int backward_data);
+int adell_conv3d_fwd_f16x3_ws(const adell_conv3d_desc* d, const float* x0, const float* x1,
+                              const void* w_split, const float* wscale, const float* bias,
+                              const float* residual, float* y, float* stat_partials,
+                              uint32_t* in_absmax, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const float* dy,
+                                   const void* w_split_bwd, const float* wscale, float* dx0,
+                                   float* dx1, uint32_t* dy_absmax, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
  * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias
  * gradient db[Cout] = sum over voxels of dy from the same pass. workspace:

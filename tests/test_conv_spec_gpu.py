@@ -77,3 +77,42 @@ def test_spec_backward_data_matches_generic(cuda, cin, cout, size, split):
     for u, v in zip(a, b):
         if u is not None:
             assert _rel(u, v) < 2e-6
+
+
+@pytest.mark.parametrize("n,c0,c1,cout,size,res", [(1, 128, 0, 128, (8, 8, 8), True),
+                                                   (2, 64, 64, 64, (16, 16, 16), False),
+                                                   (1, 256, 0, 128, (16, 16, 16), False),
+                                                   (1, 128, 0, 256, (6, 10, 12), True)])
+def test_split_k_matches_single_pass(cuda, monkeypatch, n, c0, c1, cout, size, res):
+    """Low-resolution layers share the channel chunks of a brick out over several blocks and fold
+    the slabs (csrc/conv3d.hip): same y, same statistics partials, same split dX as one pass."""
+    g = torch.Generator().manual_seed(c0 + cout)
+    D, H, W = size
+    x0 = ops.ndhwc(torch.randn(n, c0, D, H, W, generator=g).to(cuda))
+    x1 = ops.ndhwc(torch.randn(n, c1, D, H, W, generator=g).to(cuda)) if c1 else None
+    w = (torch.randn(cout, c0 + c1, 3, 3, 3, generator=g) * 0.05).to(cuda)
+    b = torch.randn(cout, generator=g).to(cuda)
+    r = ops.ndhwc(torch.randn(n, cout, D, H, W, generator=g).to(cuda)) if res else None
+    dy = ops.ndhwc((torch.randn(n, cout, D, H, W, generator=g) * 1e-3).to(cuda))
+    wp, wpb = ops.pack_weight_f16x3(w, 0), ops.pack_weight_f16x3(w, 1)
+    d = ops.make_conv_desc(n, size, c0, c1, cout, 3, 1, 1)
+    import ctypes
+    from adell_mri_amd import _lib
+    assert _lib.lib().adell_conv3d_splitk_workspace(ctypes.byref(d), 0) > 0   # the case does split
+
+    def run():
+        y, st = ops.conv3d_fwd(x0, wp, b, cout, 3, 1, 1, x1=x1, residual=r, want_stats=True)
+        dx = ops.conv3d_bwd_data(dy, wpb, size, c0, c1, 3, 1, 1)
+        return y, st, dx
+
+    y_s, st_s, dx_s = run()
+    monkeypatch.setenv("ADELL_NO_SPLITK", "1")
+    y_1, st_1, dx_1 = run()
+    assert _rel(y_s, y_1) < 2e-6
+    assert _rel(st_s.double().sum(1), st_1.double().sum(1)) < 1e-5
+    for u, v in zip(dx_s, dx_1):
+        if u is not None:
+            assert _rel(u, v) < 2e-6
+    monkeypatch.delenv("ADELL_NO_SPLITK")
+    y_s2, _, _ = run()
+    assert torch.equal(y_s, y_s2)   # fixed fold order
