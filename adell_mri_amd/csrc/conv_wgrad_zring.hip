@@ -327,9 +327,10 @@ extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1
   const long chan_blocks = (long)p->nci * p->nco;
   long target = 512 / chan_blocks;             // two blocks per CU over all channel tiles
   if (target < 8) target = 8;
-  // z segments: enough units to fill the target, at least 8 steps each (2 priming planes)
+  // z segments: enough units to fill the target, at least 4 steps each (2 priming planes;
+  // measured best from 8^3 to 128^3 once the slab fold stopped scaling with the slab count)
   long nseg = (target + ncols - 1) / ncols;
-  const int minseg = getenv("ADELL_ZR_MINSEG") ? atoi(getenv("ADELL_ZR_MINSEG")) : 16;
+  const int minseg = getenv("ADELL_ZR_MINSEG") ? atoi(getenv("ADELL_ZR_MINSEG")) : 4;
   const long maxseg = Do / minseg > 0 ? Do / minseg : 1;
   if (nseg > maxseg) nseg = maxseg;
   if (nseg < 1) nseg = 1;

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from adell_mri_amd import ops
 dev = torch.device("cuda:0")
-for cin, cout, sz in [(32, 32, 128), (64, 64, 128), (64, 32, 128), (32, 32, 64), (128, 128, 32)]:
+for cin, cout, sz in [(32, 32, 128), (64, 64, 128), (32, 32, 64), (64, 64, 64), (128, 128, 32), (64, 64, 32),
+                      (64, 64, 16), (128, 128, 16), (256, 256, 16), (128, 128, 8)]:
     x = ops.ndhwc(torch.randn(1, cin, sz, sz, sz, device=dev))
     dy = ops.ndhwc(torch.randn(1, cout, sz, sz, sz, device=dev) * 1e-3)
     xa = x.abs().max().view(1).view(torch.int32)
