@@ -386,6 +386,23 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     adell_set_error("conv f16x3: LDS need %zu B exceeds 160 KiB (k=%d stride=%d)", lds, a.KW, a.SW);
     return ADELL_E_UNSUPPORTED;
   }
+  // 32-channel tiles of 3x3x3 stride-1 layers: 8x8x8 bricks (cfg 4, SPEC = 3 instance of the
+  // kernel): a third less halo per output and half the weight staging of the 8x8x4 brick
+  if (t.cfg == 1 && a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 &&
+      a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.shuffle == 0 && a.lTX == 3 && a.lTY == 3 &&
+      a.lTZ == 2 && a.Do >= 8 && a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
+      (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
+      g_conv_force_cfg < 0 && getenv("ADELL_IGEMM_NOSPEC") == nullptr &&
+      getenv("ADELL_IGEMM_NO8") == nullptr) {
+    t.cfg = 4;
+    t.BM = 512;
+    t.lTZ = 3;
+    a.lTZ = 3;
+    a.ntz = adell_cdiv(a.Do, 8);
+    a.HZ = 10;
+    a.VP = a.HX * a.HY * a.HZ;
+    lds = (size_t)1000 * 64 + (size_t)7 * 32 * 64 + 64;
+  }
   *tile = t;
   *lds_out = lds;
   return ADELL_OK;
@@ -524,7 +541,18 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
       rc2 = spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 2, 4, 1, 0>(a, e, grid, lds, st);
       break;
+    case 4:   // 8x8x8 bricks, four m-tiles per wave (adell_plan_f16)
+      if (!a.vecx) {
+        adell_set_error("conv f16x3: input pointers must be 16-byte aligned");
+        return ADELL_E_BADARG;
+      }
+      rc2 = adell_launch_conv_f16<4, 1, 4, 1, 3>(a, e, grid, lds, st);
+      break;
     case 1:
+      if (spec && getenv("ADELL_IGEMM_B3")) {   // three blocks per CU: 7 taps of weights in LDS
+        rc2 = adell_launch_conv_f16<2, 1, 4, 1, 2>(a, e, grid, (size_t)600 * 64 + 7 * 32 * 64 + 64, st);
+        break;
+      }
       if (spec && w8) { rc2 = adell_launch_conv_f16<1, 1, 8, 1, 1>(a, e, grid, lds, st); break; }
       rc2 = spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 1, 4, 1, 0>(a, e, grid, lds, st);

@@ -62,12 +62,18 @@ __device__ __forceinline__ void adell_split8(const float* v, float scale, half8*
 // compile-time constant (no integer divisions in the loops, tap loop fully unrolled).
 // SPEC = 0 takes all of them from ConvArgs.
 template <int MT, int NT, int WM, int WN, int SPEC>
-__global__ __launch_bounds__(WM * WN * 64, WM * WN / 2)
+__global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : WM * WN / 2)
 void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
+  // SPEC = 2: the same with the 27 taps staged in 4 linear groups of <= 7 (not per kz plane):
+  // 52.8 KB of LDS and <= 168 registers, i.e. three blocks per CU for the 32-channel tile.
+  constexpr int GT = SPEC >= 2 ? 7 : 9;               // taps per weight group (SPEC)
+  constexpr int NGRP = (27 + GT - 1) / GT;
   constexpr int NW = WM * WN, NTHR = NW * 64;  // 4 waves (2 blocks per CU) or 8 (4 waves per SIMD)
-  const int lTX = SPEC ? 3 : a.lTX, lTY = SPEC ? 3 : a.lTY, lTZ = SPEC ? 2 : a.lTZ;
-  const int HX = SPEC ? 10 : a.HX, HY = SPEC ? 10 : a.HY, HZ = SPEC ? 6 : a.HZ;
+  // SPEC = 3: 8x8x8 brick (10x10x10 halo), 4 m-tiles per wave, 7-tap weight groups: 78 KB of
+  // LDS, two blocks per CU -- less halo per output, fewer LDS reads and barriers per MFMA.
+  const int lTX = SPEC ? 3 : a.lTX, lTY = SPEC ? 3 : a.lTY, lTZ = SPEC == 3 ? 3 : (SPEC ? 2 : a.lTZ);
+  const int HX = SPEC ? 10 : a.HX, HY = SPEC ? 10 : a.HY, HZ = SPEC == 3 ? 10 : (SPEC ? 6 : a.HZ);
   const int KD = SPEC ? 3 : a.KD, KH = SPEC ? 3 : a.KH, KW = SPEC ? 3 : a.KW;
   const int SD = SPEC ? 1 : a.SD, SH = SPEC ? 1 : a.SH, SW = SPEC ? 1 : a.SW;
   const int GKH = SPEC ? 3 : a.GKH;
@@ -76,7 +82,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   char* sA = reinterpret_cast<char*>(smem);
   const int HV = HX * HY * HZ;
   char* sB = sA + (size_t)HV * 64;
-  float* sMax = reinterpret_cast<float*>(sB + (size_t)GKH * KW * BN * 64);  // [NW]
+  float* sMax = reinterpret_cast<float*>(sB + (size_t)(SPEC ? GT : GKH * KW) * BN * 64);  // [NW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
@@ -205,7 +211,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   int kA_prev = 0;
   // The halo brick of a chunk goes through registers in one piece when it has at most KEEP
   // voxels per thread ("resident"): one load, absmax, split, store.
-  constexpr int KEEP = SPEC ? (600 + NTHR - 1) / NTHR : 3;
+  constexpr int KEEP = SPEC ? ((SPEC == 3 ? 1000 : 600) + NTHR - 1) / NTHR : 3;
   const bool resident = SPEC || HV <= KEEP * NTHR;
   float keep[KEEP][CC];
   int gvk[KEEP];
@@ -217,10 +223,10 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   // Weight slices go through a register prefetch: the slice of the next tap group is fetched
   // while the MFMAs of the current one run (a kz plane of a 3^3 kernel: 9 taps x BN ch x 4
   // slots = 4.5 (BN 32) / 9 (BN 64) x 256 slots of 16 bytes).
-  constexpr int WPF = (9 * BN * 4 + NTHR - 1) / NTHR;  // a kz plane of a 3^3 kernel
+  constexpr int WPF = (GT * BN * 4 + NTHR - 1) / NTHR;  // a kz plane of a 3^3 kernel
   const bool wpipe = SPEC || GKH * KW * BN * 4 <= WPF * NTHR;
   float4 wreg[WPF];
-  const int ngroups = KD * ngy;
+  const int ngroups = SPEC ? NGRP : KD * ngy;
   // SPEC: slot index it = tid + u * NTHR means column (tid >> 2) % BN, tap u * TPU + (tid >> 2) / BN
   // of the plane: a per-thread 32-bit offset plus a uniform stride per u, on both sides
   constexpr int TPU = NTHR / 4 / BN;
@@ -231,12 +237,13 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   auto wfetch = [&](int ch_, int grp_) {
     if constexpr (SPEC) {
       const char* base = reinterpret_cast<const char*>(e.wh) +
-                         ((size_t)(grp_ * 9) * a.Cout * nchunk + ch_) * 64;
+                         ((size_t)(grp_ * GT) * a.Cout * nchunk + ch_) * 64;
       const size_t ustride = (size_t)TPU * a.Cout * nchunk * 64;
+      const int tpg_ = (27 - grp_ * GT) < GT ? (27 - grp_ * GT) : GT;
 #pragma unroll
       for (int u = 0; u < WPF; ++u) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (wcolok && u * TPU + wtap < 9)
+        if (wcolok && u * TPU + wtap < tpg_)
           f = *reinterpret_cast<const float4*>(adell_uniform_ptr(base + u * ustride) + wgoff);
         wreg[u] = f;
       }
@@ -353,11 +360,14 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
         store_split(hv, v);
       }
     }
+#pragma unroll SPEC >= 2 ? NGRP : 1
     for (int grp = 0; grp < ngroups; ++grp) {
-      const int kz = grp / ngy, ky0 = (grp - kz * ngy) * GKH;
+      // SPEC 1: group = kz plane; SPEC 2: group = taps [GT * grp, GT * grp + tpg) in (kz, ky, kx)
+      // order (the loop is unrolled, so the tap coordinates are still compile-time)
+      const int kz = SPEC >= 2 ? 0 : grp / ngy, ky0 = SPEC >= 2 ? 0 : (grp - kz * ngy) * GKH;
       const int gkh = (KH - ky0) < GKH ? (KH - ky0) : GKH;
-      const int tpg = gkh * KW;              // taps of this group
-      const int tap0 = (kz * KH + ky0) * KW;
+      const int tpg = SPEC >= 2 ? ((27 - grp * GT) < GT ? (27 - grp * GT) : GT) : gkh * KW;
+      const int tap0 = SPEC >= 2 ? grp * GT : (kz * KH + ky0) * KW;
       if (grp > 0) __syncthreads();  // previous tap group consumed
       // ---- stage the weight slice of this tap group: [tpg][BN][4 slots] -----
       const bool skipB = (e.dbg & 2) && (ch > 0 || grp > 0);
@@ -365,7 +375,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       } else if (SPEC) {
 #pragma unroll
         for (int u = 0; u < WPF; ++u)
-          if (u * TPU + wtap < 9)
+          if (u * TPU + wtap < tpg)
             *reinterpret_cast<float4*>(sB + wloff + u * (TPU * BN * 64)) = wreg[u];
       } else if (wpipe) {
 #pragma unroll
@@ -401,8 +411,12 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       // ---- 3 f16 MFMAs per (tap, 32x32 tile) ---------------------------------------------
       const char* sAg = sA + (size_t)((kz * HY + ky0) * HX) * 64;
       auto load_frags = [&](int tl, half8* ah, half8* al, half8* bh, half8* bl) {
-        const int kyl = tl / KW, kx = tl - kyl * KW;
-        const int aoff = kyl * HX + kx;
+        // SPEC 2: absolute tap -> (kz, ky, kx); sAg is then the brick origin
+        const int tabs = tap0 + tl;
+        const int kzl = SPEC >= 2 ? tabs / 9 : 0;
+        const int kyl = SPEC >= 2 ? (tabs - 9 * kzl) / 3 : tl / KW;
+        const int kx = SPEC >= 2 ? tabs - 9 * kzl - 3 * kyl : tl - kyl * KW;
+        const int aoff = (kzl * HY + kyl) * HX + kx;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int hv = arow[mt] + aoff;
@@ -436,19 +450,22 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
         half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
         load_frags(0, ah[0], al[0], bh[0], bl[0]);
 #pragma unroll
-        for (int tl = 0; tl < 9; ++tl) {
-          if (tl + 1 < 9) load_frags(tl + 1, ah[(tl + 1) & 1], al[(tl + 1) & 1], bh[(tl + 1) & 1], bl[(tl + 1) & 1]);
-          do_mfma(ah[tl & 1], al[tl & 1], bh[tl & 1], bl[tl & 1]);
-          // pin the interleave: one LDS read of the next tap behind each of the first MFMAs
-          // (the 2x2 tile has no registers for the second fragment set: it spills when pinned)
-          if (MT * NT == 2 && tl + 1 < 9) {
+        for (int tl = 0; tl < GT; ++tl) {
+          if (tl < tpg) {
+            if (tl + 1 < tpg)
+              load_frags(tl + 1, ah[(tl + 1) & 1], al[(tl + 1) & 1], bh[(tl + 1) & 1], bl[(tl + 1) & 1]);
+            do_mfma(ah[tl & 1], al[tl & 1], bh[tl & 1], bl[tl & 1]);
+            // pin the interleave: one LDS read of the next tap behind each of the first MFMAs
+            // (the 2x2 tile has no registers for the second fragment set: it spills when pinned)
+            if (SPEC == 1 && MT * NT == 2 && tl + 1 < tpg) {
 #pragma unroll
-            for (int i = 0; i < 2 * MT + 2 * NT; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              for (int i = 0; i < 2 * MT + 2 * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              if constexpr (3 * MT * NT > 2 * MT + 2 * NT)
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT - (2 * MT + 2 * NT), 0);
             }
-            if constexpr (3 * MT * NT > 2 * MT + 2 * NT)
-              __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT * NT - (2 * MT + 2 * NT), 0);
           }
         }
       } else if constexpr (MT * NT == 4) {
@@ -527,7 +544,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     // interior brick, all columns valid: rows of an m-tile are 4 x-neighbours (r & 3) in 4
     // y-rows (r >> 2), so a row is the m-tile's base pointer + a compile-time multiple of two
     // per-lane strides; no bounds checks, the residual values of an m-tile are fetched at once
-    const bool full = (ox0 + 8 <= a.Wo) & (oy0 + 8 <= a.Ho) & (oz0 + 4 <= a.Do) &
+    const bool full = (ox0 + 8 <= a.Wo) & (oy0 + 8 <= a.Ho) & (oz0 + (SPEC == 3 ? 8 : 4) <= a.Do) &
                       (n0 + BN <= a.Cout);
     if (full) {
       stored = true;
