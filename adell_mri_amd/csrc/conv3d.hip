@@ -533,11 +533,9 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
                     getenv("ADELL_IGEMM_NOSPEC") == nullptr;
-  const bool w8 = getenv("ADELL_IGEMM_W8") != nullptr;   // experiment: 8-wave blocks (measured slower)
   int rc2 = ADELL_OK;
   switch (t.cfg) {
     case 0:
-      if (spec && w8) { rc2 = adell_launch_conv_f16<1, 2, 8, 1, 1>(a, e, grid, lds, st); break; }
       rc2 = spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 2, 4, 1, 0>(a, e, grid, lds, st);
       break;
@@ -549,11 +547,6 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
       rc2 = adell_launch_conv_f16<4, 1, 4, 1, 3>(a, e, grid, lds, st);
       break;
     case 1:
-      if (spec && getenv("ADELL_IGEMM_B3")) {   // three blocks per CU: 7 taps of weights in LDS
-        rc2 = adell_launch_conv_f16<2, 1, 4, 1, 2>(a, e, grid, (size_t)600 * 64 + 7 * 32 * 64 + 64, st);
-        break;
-      }
-      if (spec && w8) { rc2 = adell_launch_conv_f16<1, 1, 8, 1, 1>(a, e, grid, lds, st); break; }
       rc2 = spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 1, 4, 1, 0>(a, e, grid, lds, st);
       break;

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : WM * WN / 2)
 void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
   // SPEC = 2: the same with the 27 taps staged in 4 linear groups of <= 7 (not per kz plane):
-  // 52.8 KB of LDS and <= 168 registers, i.e. three blocks per CU for the 32-channel tile.
+  // 52.8 KB of LDS and <= 168 registers, i.e. three blocks per CU for the 32-channel tile
+  // (measured +5 % over SPEC 1; superseded by SPEC 3 and not instantiated).
   constexpr int GT = SPEC >= 2 ? 7 : 9;               // taps per weight group (SPEC)
   constexpr int NGRP = (27 + GT - 1) / GT;
   constexpr int NW = WM * WN, NTHR = NW * 64;  // 4 waves (2 blocks per CU) or 8 (4 waves per SIMD)

@@ -6,7 +6,7 @@
 // GEMM view as in conv_wgrad_f16.hip (M = ci, N = co, K = voxels, transposing LDS reads over the
 // natural [voxel][32 channels] fp16 hi / lo planes). What is different is the work decomposition:
 // a block owns ONE 32 x 32 channel tile and ALL 27 taps, and walks a column of 8 x 8 x 1 output
-// bricks along z. LDS keeps a ring of three 10 x 10 input planes, so each step converts and
+// bricks along z. LDS keeps a ring of 10 x 10 input planes (three live, a fourth being written), so each step converts and
 // stores ONE new input plane (100 rows) and ONE dY plane (64 rows) and then runs 27 taps x 4
 // k-steps x 3 MFMAs on them -- three times the MFMA work per staged byte of the per-kz-plane
 // kernel, whose staging (fp32 -> fp16 hi/lo conversion on the vector ALU) bounds it.
@@ -83,13 +83,17 @@ constexpr int ZR_HX = 10, ZR_HV = 100;      // halo plane of an 8 x 8 brick
 constexpr int ZR_PLANE = ZR_HV * 64;        // bytes of one fp16 plane of 32 channels
 constexpr int ZR_NX = 4, ZR_NY = 2;         // 16-byte loads per thread: 100 x 8 and 64 x 8 slots
 constexpr int ZR_MAXJ = 7;                  // taps per wave
+// Ring of FOUR plane slots and two dY buffers: step z reads slots z..z+2 (mod 4) and dY buffer
+// z & 1 while step z+1 is already being written into slot z+3 and buffer (z+1) & 1 -- one barrier
+// per step (stores done -> reads), none after the reads.
+constexpr int ZR_SLOTS = 4;
 
 __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrArgs a) {
   extern __shared__ float smem[];
-  char* sXh = reinterpret_cast<char*>(smem);          // [3 ring slots][100][32 halfs]
-  char* sXl = sXh + 3 * ZR_PLANE;
-  char* sYh = sXl + 3 * ZR_PLANE;                     // [64][32 halfs]
-  char* sYl = sYh + 64 * 64;
+  char* sXh = reinterpret_cast<char*>(smem);          // [4 ring slots][100][32 halfs]
+  char* sXl = sXh + ZR_SLOTS * ZR_PLANE;
+  char* sYh = sXl + ZR_SLOTS * ZR_PLANE;              // [2 steps][64][32 halfs]
+  char* sYl = sYh + 2 * 64 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int region = blockIdx.x;
@@ -189,42 +193,38 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
           adell_zr_split_store(sXh, sXl, (unsigned)(slot * ZR_PLANE + hv * 64 + c4 * 8), xr[u], sX);
       }
     };
-    auto store_y = [&]() {
+    auto store_y = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < ZR_NY; ++u) {
         const int v = row0 + 32 * u;
         dbacc.x += yr[u].x; dbacc.y += yr[u].y; dbacc.z += yr[u].z; dbacc.w += yr[u].w;
-        adell_zr_split_store(sYh, sYl, (unsigned)(v * 64 + c4 * 8), yr[u], sY);
+        adell_zr_split_store(sYh, sYl, (unsigned)(buf * 64 * 64 + v * 64 + c4 * 8), yr[u], sY);
       }
     };
     // prime the ring: planes of taps kz = 0, 1 of the first step. Plane p = z - PD + kz sits in
-    // slot (z + kz) % 3.
+    // slot (z + kz) & 3.
     __syncthreads();   // the previous unit's MFMAs are done with LDS
     fetch_x(z0 - a.PD);
-    store_x(z0 % 3);
+    store_x(z0 & 3);
     fetch_x(z0 - a.PD + 1);
-    store_x((z0 + 1) % 3);
+    store_x((z0 + 1) & 3);
     fetch_x(z0 - a.PD + 2);
     fetch_y(z0);
     for (int z = z0; z < z1; ++z) {
       // registers -> LDS: the new input plane (tap kz = 2 of this step) and this step's dY
       if (!(a.dbg & 2) || z == z0) {
-        store_x((z + 2) % 3);
-        store_y();
+        store_x((z + 2) & 3);
+        store_y(z & 1);
       }
-      __syncthreads();
       if (z + 1 < z1 && !(a.dbg & 1)) {  // next step's loads fly during this step's MFMAs
         fetch_x(z + 1 - a.PD + 2);
         fetch_y(z + 1);
       }
-      const int zm = z % 3;
+      __syncthreads();
       int slotoff[3];   // byte offset of the ring slot holding tap plane kz
 #pragma unroll
-      for (int kz = 0; kz < 3; ++kz) {
-        int s = zm + kz;
-        s = s >= 3 ? s - 3 : s;
-        slotoff[kz] = s * ZR_PLANE;
-      }
+      for (int kz = 0; kz < 3; ++kz) slotoff[kz] = ((z + kz) & 3) * ZR_PLANE;
+      const int ybuf = (z & 1) * 64 * 64;
       // 4 k-steps of 16 voxels (two brick rows) x 7 taps, flattened and software-pipelined: the
       // fragments of job i+1 are read while the 3 MFMAs of job i run (two register sets)
       int tslot[ZR_MAXJ];
@@ -232,9 +232,9 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
       for (int q = 0; q < ZR_MAXJ; ++q)
         tslot[q] = tapoff[q] + (tapkz[q] == 0 ? slotoff[0] : (tapkz[q] == 1 ? slotoff[1] : slotoff[2]));
       zr_half8 ah[2], al[2], bh[2], bl[2];
-      if (a.dbg & 4) { __syncthreads(); continue; }
-      bh[0] = adell_zr_frag(sYh + bbase);
-      bl[0] = adell_zr_frag(sYl + bbase);
+      if (a.dbg & 4) continue;
+      bh[0] = adell_zr_frag(sYh + ybuf + bbase);
+      bl[0] = adell_zr_frag(sYl + ybuf + bbase);
       ah[0] = adell_zr_frag(sXh + tslot[0]);
       al[0] = adell_zr_frag(sXl + tslot[0]);
 #pragma unroll
@@ -246,8 +246,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
         if (more) {
           const int s2 = (i + 1) / ZR_MAXJ, q2 = (i + 1) - s2 * ZR_MAXJ;
           if (newb) {
-            bh[s2 & 1] = adell_zr_frag(sYh + bbase + s2 * 16 * 64);
-            bl[s2 & 1] = adell_zr_frag(sYl + bbase + s2 * 16 * 64);
+            bh[s2 & 1] = adell_zr_frag(sYh + ybuf + bbase + s2 * 16 * 64);
+            bl[s2 & 1] = adell_zr_frag(sYl + ybuf + bbase + s2 * 16 * 64);
           }
           ah[nxt] = adell_zr_frag(sXh + tslot[q2] + s2 * 2 * ZR_HX * 64);
           al[nxt] = adell_zr_frag(sXl + tslot[q2] + s2 * 2 * ZR_HX * 64);
@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
       }
-      __syncthreads();   // ring slot (z + 3) % 3 = z % 3 and sY are free again
     }
   }
 
@@ -357,7 +356,7 @@ extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int 
   a.ntx = p->ntx; a.nty = p->nty; a.nseg = p->nseg; a.seglen = p->seglen;
   a.nci = p->nci; a.nco = p->nco; a.R = p->R;
   a.dbg = getenv("ADELL_ZR_DBG") ? atoi(getenv("ADELL_ZR_DBG")) : 0;
-  const size_t lds = 2 * (3 * (size_t)ZR_PLANE + 64 * 64);
+  const size_t lds = 2 * (ZR_SLOTS * (size_t)ZR_PLANE + 2 * 64 * 64);
   static bool attr_done = false;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_conv_wgrad_zring_kernel),
