@@ -1,0 +1,139 @@
+"""Whole-volume inference operators: the reference's own tests
+(testing/test_segmentation_inference_pl.py:21-52: identity round trip, shapes, value range) on
+the mirror, and the mirror against the plain restatement in oracle/inference_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+from adell_mri_amd.utils.inference import (FlippedInference, SegmentationInference,
+                                           SlidingWindowSegmentation, TensorListReduction,
+                                           window_plan)
+from oracle import inference_ref
+
+h, w, d, c = 32, 32, 32, 1
+
+
+def test_sliding_window_inference_identity():
+    net = torch.nn.Identity()
+    x = torch.rand([1, c, h, w, d], generator=torch.Generator().manual_seed(0))
+    sli = SlidingWindowSegmentation([8, 8, 8], lambda t: net.forward(t), n_classes=1)
+    out = sli(x)
+    assert list(out.shape) == [1, 1, h, w, d]
+    assert out.max() <= 1 and out.min() >= 0
+    assert torch.all(torch.isclose(out, x))
+
+
+def test_segmentation_inference_identity_with_flip():
+    net = torch.nn.Identity()
+    x = torch.rand([1, c, h, w, d], generator=torch.Generator().manual_seed(1))
+    keep = x.clone()
+    sli = SegmentationInference(base_inference_function=lambda t: net.forward(t),
+                                sliding_window_size=[8, 8, 8], n_classes=1, flip=True)
+    out = sli(x)
+    assert list(out.shape) == [1, 1, h, w, d]
+    assert torch.all(torch.isclose(out, x))
+    assert torch.equal(x, keep)   # the input is not modified
+
+
+@pytest.mark.parametrize("shape,window,stride", [((20, 17, 13), (8, 8, 8), (5, 5, 5)),
+                                                 ((16, 16, 16), (8, 8, 8), (8, 8, 8)),
+                                                 ((9, 30, 11), (8, 16, 8), (3, 7, 8))])
+def test_window_plan_matches_restatement(shape, window, stride):
+    assert window_plan(shape, window, stride) == inference_ref.windows_3d(shape, window, stride)
+
+
+@pytest.mark.parametrize("batch", [1, 3, 4])
+def test_overlapping_windows_match_restatement(batch):
+    """A position-dependent 'network' (2 output channels) over ragged overlapping windows, window
+    batches of several sizes, dict input."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn([2, 3, 20, 17, 13], generator=g)
+    wgt = torch.randn([2, 3], generator=g)
+
+    def net(t):   # 1x1x1 conv + a nonlinearity: not translation-trivial once windows overlap
+        t = t["image"] if isinstance(t, dict) else t
+        return torch.tanh(torch.einsum("oc,bcxyz->boxyz", wgt, t)) * t.sum(1, keepdim=True)
+
+    sli = SlidingWindowSegmentation([8, 8, 8], net, n_classes=2, stride=[5, 6, 7],
+                                    inference_batch_size=batch)
+    out = sli({"image": x})
+    ref = inference_ref.sliding_window_3d(
+        x.numpy().astype(np.float64), lambda a: net(torch.from_numpy(a).float()).numpy(),
+        (8, 8, 8), (5, 6, 7), 2)
+    np.testing.assert_allclose(out.numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_flipped_inference_matches_restatement():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([1, 2, 6, 7, 8], generator=g)
+    ramp = torch.arange(8.0).view(1, 1, 1, 1, 8)
+
+    def net(t):
+        return t * ramp   # not flip-equivariant along the last axis
+
+    out = FlippedInference(net, flips=[(2,), (4,)])(x)
+    ref = inference_ref.flipped(x.numpy().astype(np.float64),
+                                lambda a: net(torch.from_numpy(np.ascontiguousarray(a)).float()).numpy(),
+                                [(2,), (4,)])
+    np.testing.assert_allclose(out.numpy(), ref, rtol=1e-6, atol=1e-6)
+
+
+def test_mc_dropout_and_reduction_shapes():
+    drop = torch.nn.Dropout(0.5).train()
+    x = torch.ones([1, c, 16, 16, 16])
+    sli = SegmentationInference(base_inference_function=lambda t: torch.sigmoid(drop(t)),
+                                sliding_window_size=[8, 8, 8], n_classes=1, flip=True,
+                                mc_iterations=3)
+    out = sli(x)
+    assert list(out.shape) == [1, 2, 16, 16, 16]        # mean and standard deviation
+    assert out.max() <= 1 and out.min() >= 0
+    red = TensorListReduction(postproc_fn=lambda t: t * 2)
+    two = SegmentationInference(base_inference_function=[lambda t: t, lambda t: 3 * t],
+                                sliding_window_size=[8, 8, 8], n_classes=1, reduction=red)
+    assert torch.allclose(two(x), 4 * x)
+
+
+def test_unbatched_input_and_stride_fraction():
+    x = torch.rand([c, 16, 16, 16], generator=torch.Generator().manual_seed(4))
+    sli = SegmentationInference(base_inference_function=lambda t: t, sliding_window_size=[8, 8, 8],
+                                stride=0.5, n_classes=1)
+    assert sli.stride == [4, 4, 4]
+    out = sli(x)
+    assert list(out.shape) == [1, 16, 16, 16] and torch.allclose(out, x)
+
+
+@pytest.mark.gpu
+def test_sliding_window_unet_matches_oracle_composition(cuda):
+    """The HIP U-Net over overlapping windows of a ragged volume == the torch-CPU oracle U-Net
+    composed by the plain restatement."""
+    from adell_mri_amd.modules.activations import activation_factory
+    from adell_mri_amd.modules.segmentation.unet import UNet
+    from oracle.torch_ref.unet import UNetOracle
+    from oracle.weights import tensor_for
+    kw = dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+              upscale_type="transpose", norm_type="instance", padding=1, dropout_param=0.0,
+              in_channels=2, n_classes=2, depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3)
+    net = UNet(activation_fn=activation_factory["swish"], **kw)
+    sd = {k: torch.from_numpy(tensor_for(k, v.shape)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to(cuda).eval()
+    ref = UNetOracle(sd, dict(depth=kw["depth"], kernel_sizes=kw["kernel_sizes"],
+                              strides=kw["strides"], padding=1, norm_type="instance",
+                              activation="swish", link_type="residual", n_classes=2,
+                              dropout_param=0.0))
+    x = torch.rand([1, 2, 40, 24, 36], generator=torch.Generator().manual_seed(5))
+    sli = SegmentationInference(base_inference_function=lambda t: net(t)[0],
+                                sliding_window_size=[16, 16, 16], stride=[12, 8, 10], n_classes=2,
+                                flip=True, inference_batch_size=4)
+    out = sli(x.to(cuda)).cpu().numpy()
+
+    def ref_fn(a):
+        with torch.no_grad():
+            return ref.forward(torch.from_numpy(np.ascontiguousarray(a)).float(),
+                               return_logits=False).numpy()
+
+    want = inference_ref.flipped(
+        x.numpy(), lambda a: inference_ref.sliding_window_3d(a, ref_fn, (16,) * 3, (12, 8, 10), 1),
+        [(2,)])
+    assert out.shape == want.shape
+    np.testing.assert_allclose(out, want, rtol=1e-4, atol=1e-5)
