@@ -98,6 +98,8 @@ SIGNATURES = {
     "adell_copy_channels": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "adell_interp_nearest_fwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
     "adell_interp_nearest_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
+    "adell_interp_linear_fwd": (_i, [_vp, _vp] + [_i] * 8 + [_f] * 3 + [_vp]),
+    "adell_interp_linear_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_f] * 3 + [_vp]),
     "adell_maxpool3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "adell_maxpool3d_bwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "adell_dwconv3d_fwd": (_i, [_i] * 8 + [_vp] * 5),

@@ -303,3 +303,127 @@ extern "C" int adell_maxpool3d_bwd(const adell_conv3d_desc* d, const float* dy,
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Linear upsampling (torch.nn.Upsample(scale_factor=s, mode="bilinear" | "trilinear"),
+// align_corners=False) of the "upsample" upscaling path, unet.py:419-443, on NDHWC tensors.
+// Source coordinate of output index o along an axis: max(0, (o + 0.5) / scale - 0.5); the two
+// taps are floor(src) and min(floor(src) + 1, size - 1) with weights (1 - t, t). A 2-D tensor is
+// the D = 1, scale_z = 1 case (t = 0 along z). Backward is a gather over the output positions
+// that can touch an input voxel (deterministic, no atomics).
+// ---------------------------------------------------------------------------
+struct LinArgs {
+  const float* x;   // fwd: input;  bwd: dY
+  float* y;         // fwd: output; bwd: dX
+  int N, C, Di, Hi, Wi, Do, Ho, Wo;
+  float rz, ry, rx; // 1 / scale_factor per axis
+};
+
+__device__ __forceinline__ void adell_lin_taps(int o, float r, int size, int* i0, int* i1, float* t) {
+  float src = ((float)o + 0.5f) * r - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  const int f = (int)src;
+  *i0 = f < size - 1 ? f : size - 1;
+  *i1 = f + 1 < size ? f + 1 : size - 1;
+  *t = src - (float)f;
+}
+
+__global__ __launch_bounds__(256) void adell_interp_linear_fwd_kernel(LinArgs a) {
+  const long n = (long)a.N * a.Do * a.Ho * a.Wo * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % a.C);
+    long v = i / a.C;
+    const int ox = (int)(v % a.Wo); v /= a.Wo;
+    const int oy = (int)(v % a.Ho); v /= a.Ho;
+    const int oz = (int)(v % a.Do);
+    const int nb = (int)(v / a.Do);
+    int z0, z1, y0, y1, x0, x1;
+    float tz, ty, tx;
+    adell_lin_taps(oz, a.rz, a.Di, &z0, &z1, &tz);
+    adell_lin_taps(oy, a.ry, a.Hi, &y0, &y1, &ty);
+    adell_lin_taps(ox, a.rx, a.Wi, &x0, &x1, &tx);
+    const float* xb = a.x + (size_t)nb * a.Di * a.Hi * a.Wi * a.C + c;
+    auto at = [&](int z, int y, int x) { return xb[((size_t)(z * a.Hi + y) * a.Wi + x) * a.C]; };
+    const float c00 = at(z0, y0, x0) * (1.f - tx) + at(z0, y0, x1) * tx;
+    const float c01 = at(z0, y1, x0) * (1.f - tx) + at(z0, y1, x1) * tx;
+    const float c10 = at(z1, y0, x0) * (1.f - tx) + at(z1, y0, x1) * tx;
+    const float c11 = at(z1, y1, x0) * (1.f - tx) + at(z1, y1, x1) * tx;
+    const float c0 = c00 * (1.f - ty) + c01 * ty, c1 = c10 * (1.f - ty) + c11 * ty;
+    a.y[i] = c0 * (1.f - tz) + c1 * tz;
+  }
+}
+
+// weight with which input index `in` enters output index o along one axis
+__device__ __forceinline__ float adell_lin_weight(int o, float r, int size, int in) {
+  int i0, i1;
+  float t;
+  adell_lin_taps(o, r, size, &i0, &i1, &t);
+  return (i0 == in ? 1.f - t : 0.f) + (i1 == in ? t : 0.f);
+}
+
+__global__ __launch_bounds__(256) void adell_interp_linear_bwd_kernel(LinArgs a) {
+  const long n = (long)a.N * a.Di * a.Hi * a.Wi * a.C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % a.C);
+    long v = i / a.C;
+    const int ix = (int)(v % a.Wi); v /= a.Wi;
+    const int iy = (int)(v % a.Hi); v /= a.Hi;
+    const int iz = (int)(v % a.Di);
+    const int nb = (int)(v / a.Di);
+    // output indices whose taps can reach this input index: src in (in - 1, in + 1)
+    auto lo = [](int in, float r) { int o = (int)floorf(((float)in - 0.5f) / r - 0.5f); return o < 0 ? 0 : o; };
+    auto hi = [](int in, float r, int osz) { int o = (int)ceilf(((float)in + 1.5f) / r - 0.5f); return o > osz - 1 ? osz - 1 : o; };
+    const int zl = lo(iz, a.rz), zh = hi(iz, a.rz, a.Do);
+    const int yl = lo(iy, a.ry), yh = hi(iy, a.ry, a.Ho);
+    const int xl = lo(ix, a.rx), xh = hi(ix, a.rx, a.Wo);
+    const float* gb = a.x + (size_t)nb * a.Do * a.Ho * a.Wo * a.C + c;
+    float acc = 0.f;
+    for (int oz = zl; oz <= zh; ++oz) {
+      const float wz = adell_lin_weight(oz, a.rz, a.Di, iz);
+      if (wz == 0.f) continue;
+      for (int oy = yl; oy <= yh; ++oy) {
+        const float wy = adell_lin_weight(oy, a.ry, a.Hi, iy);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = xl; ox <= xh; ++ox) {
+          const float wx = adell_lin_weight(ox, a.rx, a.Wi, ix);
+          if (wx != 0.f) row += wx * gb[((size_t)(oz * a.Ho + oy) * a.Wo + ox) * a.C];
+        }
+        acc += wz * wy * row;
+      }
+    }
+    a.y[i] = acc;
+  }
+}
+
+static int adell_interp_linear(const float* x, float* y, int N, int C, int Di, int Hi, int Wi,
+                               int Do, int Ho, int Wo, float sz, float sy, float sx, int bwd,
+                               hipStream_t st) {
+  ADELL_REQUIRE(x && y, "interp_linear: null pointer");
+  ADELL_REQUIRE(N > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0,
+                "interp_linear: bad dims");
+  ADELL_REQUIRE(sz > 0.f && sy > 0.f && sx > 0.f, "interp_linear: bad scale factors");
+  LinArgs a = {x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, 1.f / sz, 1.f / sy, 1.f / sx};
+  const long n = (long)N * C * (bwd ? (long)Di * Hi * Wi : (long)Do * Ho * Wo);
+  long blocks = (n + 255) / 256;
+  if (blocks > 65535 * 4) blocks = 65535 * 4;
+  if (bwd)
+    hipLaunchKernelGGL(adell_interp_linear_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(adell_interp_linear_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_interp_linear_fwd(const float* x, float* y, int N, int C, int Di, int Hi,
+                                       int Wi, int Do, int Ho, int Wo, float scale_d,
+                                       float scale_h, float scale_w, void* stream) {
+  return adell_interp_linear(x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, 0,
+                             (hipStream_t)stream);
+}
+extern "C" int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi,
+                                       int Wi, int Do, int Ho, int Wo, float scale_d,
+                                       float scale_h, float scale_w, void* stream) {
+  return adell_interp_linear(dy, dx, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, 1,
+                             (hipStream_t)stream);
+}

@@ -647,6 +647,28 @@ def interpolate_nearest(x, size):
     return _NearestFn.apply(x, size)
 
 
+class _LinearUpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scales):
+        ctx.in_size, ctx.scales = tuple(x.shape[2:]), scales
+        return ops.interp_linear(x, scales)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.interp_linear(g, ctx.scales, backward_from=ctx.in_size), None
+
+
+def upsample_linear(x, scale_factor):
+    """torch.nn.Upsample(scale_factor, mode="bilinear" (4-D) / "trilinear" (5-D),
+    align_corners=False) as used by the "upsample" upscaling path (unet.py:419-443)."""
+    nd = x.dim() - 2
+    sc = (float(scale_factor),) * nd if not isinstance(scale_factor, (tuple, list)) else \
+        tuple(float(s) for s in scale_factor)
+    if nd == 2:
+        return _LinearUpFn.apply(x.unsqueeze(2), (1.0,) + sc).squeeze(2)
+    return _LinearUpFn.apply(x, sc)
+
+
 class _MaxPool3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, padding):

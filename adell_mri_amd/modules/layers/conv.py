@@ -94,6 +94,27 @@ class ConvTranspose2d(torch.nn.ConvTranspose2d):
         return HF.conv_transpose3d(X.unsqueeze(2), self.weight.unsqueeze(2), self.bias).squeeze(2)
 
 
+class Upsample(torch.nn.Upsample):
+    """torch.nn.Upsample for the "upsample" upscaling path (unet.py:419-443): linear modes
+    ("bilinear" on 4-D, "trilinear" on 5-D input, align_corners False) and "nearest"."""
+
+    def forward(self, X):
+        if self.size is not None or self.align_corners or self.recompute_scale_factor:
+            raise AdellHipError("HIP Upsample implements scale_factor with align_corners=False")
+        if self.mode == "nearest":
+            sf = self.scale_factor
+            sf = (sf,) * (X.dim() - 2) if not isinstance(sf, (tuple, list)) else tuple(sf)
+            size = [int(n * f) for n, f in zip(X.shape[2:], sf)]
+            if X.dim() == 4:
+                return HF.interpolate_nearest(X.unsqueeze(2), [1] + size).squeeze(2)
+            return HF.interpolate_nearest(X, size)
+        want = "bilinear" if X.dim() == 4 else "trilinear"
+        if self.mode != want:   # torch raises for a mode / rank mismatch as well
+            raise NotImplementedError(f"Got {X.dim()}D input, but {self.mode} mode needs "
+                                      f"{'4' if self.mode == 'bilinear' else '5'}D input")
+        return HF.upsample_linear(X, self.scale_factor)
+
+
 class MaxPool3d(torch.nn.MaxPool3d):
     def forward(self, X):
         if self.ceil_mode or self.return_indices or ops_triple(self.dilation) != (1, 1, 1):

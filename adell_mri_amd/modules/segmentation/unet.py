@@ -22,7 +22,8 @@ import torch
 from ... import functional as HF
 from ..._lib import AdellHipError
 from ..layers.adn_fn import ActDropNorm, norm_fn_dict
-from ..layers.conv import Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool3d
+from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool3d,
+                           Upsample)
 from ..layers.regularization import UOut
 from ..layers.res_blocks import ResidualBlock3d
 from ..layers.utils import crop_to_size
@@ -199,14 +200,17 @@ class UNet(torch.nn.Module):
         depths_a = self.depth[:0:-1]
         depths_b = self.depth[-2::-1]
         ops_ = []
-        if self.upscale_type != "transpose":
-            raise NotImplementedError("upscale_type='upsample' is outside the HIP path built so "
-                                      "far (all BASELINE configs use 'transpose')")
-        convt = ConvTranspose3d if self.spatial_dimensions == 3 else ConvTranspose2d
-        for d1, d2, s in zip(depths_a, depths_b, self.strides[::-1][1:]):
-            s = _per_dim(s, self.spatial_dimensions)
-            p = [int(np.maximum(i - 2, 0)) for i in s]
-            ops_.append(convt(d1, d2, s, stride=s, padding=p))
+        if self.upscale_type == "upsample":   # unet.py:419-443: 1x1 conv, then interpolation
+            conv = Conv3d if self.spatial_dimensions == 3 else Conv2d
+            for d1, d2, s in zip(depths_a, depths_b, self.strides[::-1][1:]):
+                ops_.append(torch.nn.Sequential(conv(d1, d2, 1),
+                                                Upsample(scale_factor=s, mode=self.interpolation)))
+        elif self.upscale_type == "transpose":
+            convt = ConvTranspose3d if self.spatial_dimensions == 3 else ConvTranspose2d
+            for d1, d2, s in zip(depths_a, depths_b, self.strides[::-1][1:]):
+                s = _per_dim(s, self.spatial_dimensions)
+                p = [int(np.maximum(i - 2, 0)) for i in s]
+                ops_.append(convt(d1, d2, s, stride=s, padding=p))
         self.upscale_ops = torch.nn.ModuleList(ops_)
 
     def init_link_ops(self):

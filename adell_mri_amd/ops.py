@@ -6,6 +6,7 @@ are the only places that care about strides. Everything is enqueued on
 ``torch.cuda.current_stream()``; PyTorch only provides memory and streams.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -802,6 +803,28 @@ def interp_nearest(x, size, backward_from=None):
     dx = new_act(N, C, Di, Hi, Wi, x.device)
     check(_lib.lib().adell_interp_nearest_bwd(_ptr(x), _ptr(dx), N, C, Di, Hi, Wi, Do, Ho, Wo,
                                               _stream()))
+    return dx
+
+
+def interp_linear(x, scales, backward_from=None):
+    """torch.nn.Upsample(scale_factor=scales, mode="trilinear", align_corners=False) on
+    [N,C,Di,Hi,Wi]; with backward_from=(Di,Hi,Wi): x is the output gradient, result = dX."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    sd, sh, sw = (float(s) for s in scales)
+    if backward_from is None:
+        Di, Hi, Wi = x.shape[2:]
+        Do, Ho, Wo = (int(math.floor(n * s)) for n, s in zip((Di, Hi, Wi), (sd, sh, sw)))
+        y = new_act(N, C, Do, Ho, Wo, x.device)
+        check(_lib.lib().adell_interp_linear_fwd(_ptr(x), _ptr(y), N, C, Di, Hi, Wi, Do, Ho, Wo,
+                                                 sd, sh, sw, _stream()))
+        return y
+    Di, Hi, Wi = backward_from
+    Do, Ho, Wo = x.shape[2:]
+    dx = new_act(N, C, Di, Hi, Wi, x.device)
+    check(_lib.lib().adell_interp_linear_bwd(_ptr(x), _ptr(dx), N, C, Di, Hi, Wi, Do, Ho, Wo,
+                                             sd, sh, sw, _stream()))
     return dx
 
 

@@ -340,6 +340,16 @@ int adell_interp_nearest_fwd(const float* x, float* y, int N, int C, int Di, int
                              int Do, int Ho, int Wo, void* stream);
 int adell_interp_nearest_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi, int Wi,
                              int Do, int Ho, int Wo, void* stream);
+/* torch.nn.Upsample(scale_factor, mode="bilinear" | "trilinear", align_corners=False) of the
+ * "upsample" upscaling path (unet.py:419-443): x [N][Di][Hi][Wi][C] -> y [N][Do][Ho][Wo][C] with
+ * Do = floor(Di * scale_d) etc.; a 2-D tensor is Di = Do = 1, scale_d = 1. The backward gathers
+ * (deterministic). */
+int adell_interp_linear_fwd(const float* x, float* y, int N, int C, int Di, int Hi, int Wi,
+                            int Do, int Ho, int Wo, float scale_d, float scale_h, float scale_w,
+                            void* stream);
+int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi, int Wi,
+                            int Do, int Ho, int Wo, float scale_d, float scale_h, float scale_w,
+                            void* stream);
 
 /* torch.nn.MaxPool3d (ceil_mode False, dilation 1, -inf padding): unet.py:335,368,
  * 595-603, res_net.py:180,209. Geometry in an adell_conv3d_desc (C0 = channels, C1 and

@@ -88,6 +88,17 @@ UNET2D_CASES = {
                          padding="same", strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
                          conv_type="regular", link_type="identity", activation_fn="prelu",
                          dropout_param=0.0, _train=True), (2, 1, 64, 64), "uniform"),
+    # the constructor defaults of the reference (unet.py:43-68): upscale_type="upsample" with
+    # bilinear interpolation, identity links, BatchNorm2d, PReLU
+    "unet2d_upsample": (dict(spatial_dimensions=2, depth=[8, 16, 32], padding="same",
+                             strides=[2, 2, 2], kernel_sizes=[3, 3, 3], activation_fn="prelu",
+                             dropout_param=0.0, _train=True), (2, 1, 40, 48), "uniform"),
+    # 3-D: 1x1x1 conv + trilinear Upsample, anisotropic stride at the deepest level
+    "unet3d_upsample": (dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1,
+                             strides=[2, 2, [2, 2, 1]], kernel_sizes=[3, 3, 3],
+                             upscale_type="upsample", interpolation="trilinear",
+                             norm_type="instance", activation_fn="swish", dropout_param=0.0,
+                             link_type="identity", in_channels=2), (1, 2, 16, 24, 12), "uniform"),
 }
 
 
