@@ -427,3 +427,86 @@ extern "C" int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C,
   return adell_interp_linear(dy, dx, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, 1,
                              (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------
+// Per-(item, channel) scaling of an NDHWC activation: y[n][v][c] = x[n][v][c] * s[n][c].
+// Two call sites of the reference: the tabular feature gates of the U-Net decoder
+// (torch.multiply(encoded, transformed_features), unet.py:803-810) and U-out
+// (X + X * r, r ~ U(-beta, beta) per item and channel, regularization.py:48-55).
+// Backward: dx = dy * s (this kernel again), ds[n][c] = sum_v dy * x (partials + fixed-order fold).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_scale_bc_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ s,
+                                                             float* __restrict__ y, long VC, int C) {
+  const int nb = blockIdx.y;
+  const float* xb = x + (size_t)nb * VC;
+  float* yb = y + (size_t)nb * VC;
+  const float* sb = s + (size_t)nb * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < VC; i += (long)gridDim.x * 256L)
+    yb[i] = xb[i] * sb[i % C];
+}
+
+// partial[n][tile][c] = sum over the tile's voxels of dy * x
+__global__ __launch_bounds__(256) void adell_scale_bc_dscale_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, long V,
+    int C, int vpt) {
+  const int nb = blockIdx.y, tile = blockIdx.x;
+  const long v0 = (long)tile * vpt;
+  const long v1 = (v0 + vpt) < V ? (v0 + vpt) : V;
+  const size_t base = (size_t)nb * V * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    for (long v = v0; v < v1; ++v) acc += dy[base + v * C + c] * x[base + v * C + c];
+    part[((size_t)nb * gridDim.x + tile) * C + c] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_scale_bc_fold_kernel(const float* __restrict__ part,
+                                                                  float* __restrict__ ds, int tiles,
+                                                                  int C) {
+  const int nb = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double acc = 0.0;
+  for (int t = 0; t < tiles; ++t) acc += (double)part[((size_t)nb * tiles + t) * C + c];
+  ds[(size_t)nb * C + c] = (float)acc;
+}
+
+extern "C" int adell_scale_bc(const float* x, const float* s, float* y, int N, long V, int C,
+                              void* stream) {
+  ADELL_REQUIRE(x && s && y && N > 0 && V > 0 && C > 0 && N <= 65535, "scale_bc: bad arguments");
+  long blocks = (V * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(adell_scale_bc_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0,
+                     (hipStream_t)stream, x, s, y, V * C, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+static int adell_scale_bc_tiles(long V, int C) {
+  long t = V / 64;           // >= 64 voxels per tile
+  if (t > 1024) t = 1024;
+  if (t < 1) t = 1;
+  (void)C;
+  return (int)t;
+}
+
+extern "C" long adell_scale_bc_dscale_workspace_floats(int N, long V, int C) {
+  if (N <= 0 || V <= 0 || C <= 0) return ADELL_E_BADARG;
+  return (long)N * adell_scale_bc_tiles(V, C) * C;
+}
+
+extern "C" int adell_scale_bc_dscale(const float* x, const float* dy, float* ds, int N, long V,
+                                     int C, float* workspace, void* stream) {
+  ADELL_REQUIRE(x && dy && ds && workspace && N > 0 && V > 0 && C > 0 && N <= 65535,
+                "scale_bc_dscale: bad arguments");
+  const int tiles = adell_scale_bc_tiles(V, C);
+  const int vpt = (int)((V + tiles - 1) / tiles);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_scale_bc_dscale_kernel, dim3((unsigned)tiles, (unsigned)N), dim3(256), 0,
+                     st, x, dy, workspace, V, C, vpt);
+  hipLaunchKernelGGL(adell_scale_bc_fold_kernel, dim3((unsigned)adell_cdiv(C, 256), (unsigned)N),
+                     dim3(256), 0, st, (const float*)workspace, ds, tiles, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

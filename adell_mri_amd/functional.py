@@ -669,6 +669,35 @@ def upsample_linear(x, scale_factor):
     return _LinearUpFn.apply(x, sc)
 
 
+class _ScaleBcFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.save_for_backward(x, s)
+        return ops.scale_bc(x, s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        dx = ops.scale_bc(dy, s) if ctx.needs_input_grad[0] else None
+        ds = ops.scale_bc_dscale(x, dy) if ctx.needs_input_grad[1] else None
+        return dx, ds
+
+
+def scale_per_item_channel(x, s):
+    """x [N, C, *spatial] times s [N, C] broadcast over the spatial axes (feature gates of the
+    decoder, unet.py:803-810; U-out, regularization.py:48-55)."""
+    nd = x.dim()
+    if nd == 5:
+        return _ScaleBcFn.apply(x, s)
+    if nd == 4:
+        return _ScaleBcFn.apply(x.unsqueeze(2), s).squeeze(2)
+    if nd == 3:
+        return _ScaleBcFn.apply(x.unsqueeze(2).unsqueeze(2), s).squeeze(2).squeeze(2)
+    if nd == 2:
+        return _ScaleBcFn.apply(x[:, :, None, None, None], s)[:, :, 0, 0, 0]
+    raise ValueError(f"scale_per_item_channel: [N, C, ...] with <= 3 spatial dims, got {tuple(x.shape)}")
+
+
 class _MaxPool3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, padding):

@@ -117,7 +117,15 @@ class ActDropNorm(torch.nn.Module):
                 kw["drop_p"] = m.p
             elif isinstance(m, UOut):
                 if self.training and m.beta != 0.0:
-                    raise NotImplementedError("UOut has no HIP kernel yet")
+                    # not a per-element mask: apply what precedes it (the norm), U-out itself
+                    # (one broadcast-scale kernel), then the rest of the stage
+                    if kw.get("norm", "none") != "none":
+                        X5, back = _as5d(X)
+                        if hasattr(X, "_adell_partials") and X5 is not X:
+                            X5._adell_partials = X._adell_partials
+                        X = back(HF.norm_drop_act(X5, **kw))
+                        kw = {"training": self.training}
+                    X = m(X)
             elif not isinstance(m, torch.nn.Identity):
                 raise NotImplementedError(
                     f"dropout {type(m).__name__} has no HIP kernel on the adell_mri_amd path")

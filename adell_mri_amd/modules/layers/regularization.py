@@ -33,9 +33,13 @@ class UOut(torch.nn.Module):
         self.beta = beta
 
     def forward(self, X):
-        if self.training and self.beta != 0.0:
-            raise NotImplementedError("UOut: HIP kernel not implemented yet")
-        return X
+        if not (self.training and self.beta != 0.0):
+            return X
+        from ... import functional as HF
+
+        # X + X * r, r ~ U(-beta, beta) drawn per (item, channel): one broadcast-scale kernel
+        r = torch.rand(X.shape[:2], device=X.device) * (2.0 * self.beta) - self.beta
+        return HF.scale_per_item_channel(X, 1.0 + r)
 
 
 class LayerNorm(torch.nn.Module):

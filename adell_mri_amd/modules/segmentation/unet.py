@@ -21,9 +21,10 @@ import torch
 
 from ... import functional as HF
 from ..._lib import AdellHipError
-from ..layers.adn_fn import ActDropNorm, norm_fn_dict
+from ..layers.adn_fn import ActDropNorm, get_adn_fn, norm_fn_dict
 from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool3d,
                            Upsample)
+from ..layers.linear_blocks import Linear
 from ..layers.regularization import UOut
 from ..layers.res_blocks import ResidualBlock3d
 from ..layers.utils import crop_to_size
@@ -129,8 +130,7 @@ class UNet(torch.nn.Module):
             if self.feature_conditioning == 0:
                 self.feature_conditioning = None
             if self.feature_conditioning is not None:
-                raise NotImplementedError(
-                    "feature_conditioning is outside the HIP path built so far")
+                self.init_feature_conditioning_operations()
 
     # ---- operator selection ------------------------------------------------
     def get_norm_op(self):
@@ -294,6 +294,27 @@ class UNet(torch.nn.Module):
     def init_final_layer(self):
         self.final_layer = self.get_final_layer(self.depth[0])
 
+    def init_feature_conditioning_operations(self):
+        """Tabular features -> per-level channel gates (unet.py:716-740)."""
+        depths = self.depth[-2::-1]
+        self.feature_conditioning_ops = torch.nn.ModuleList([])
+        if self.feature_conditioning_params is not None:
+            self.f_mean = torch.nn.parameter.Parameter(
+                self.feature_conditioning_params["mean"], requires_grad=False)
+            self.f_std = torch.nn.parameter.Parameter(
+                self.feature_conditioning_params["std"], requires_grad=False)
+        else:
+            self.f_mean = torch.nn.parameter.Parameter(
+                torch.zeros([self.feature_conditioning]), requires_grad=False)
+            self.f_std = torch.nn.parameter.Parameter(
+                torch.ones([self.feature_conditioning]), requires_grad=False)
+        for d in depths:
+            self.feature_conditioning_ops.append(torch.nn.Sequential(
+                Linear(self.feature_conditioning, d),
+                get_adn_fn(1, "batch", "swish", self.dropout_param)(d),
+                Linear(d, d),
+                get_adn_fn(1, "batch", "sigmoid", self.dropout_param)(d)))
+
     def init_bottleneck_classifier(self):
         nc = self.n_classes if self.n_classes > 2 else 1
         self.bottleneck_classifier = torch.nn.Linear(self.depth[-1], nc)
@@ -317,10 +338,10 @@ class UNet(torch.nn.Module):
                 return_bottleneck=False, return_logits=False):
         if not X.is_cuda:
             raise AdellHipError("adell_mri_amd.UNet runs on MI355X only (no CPU fallback)")
-        if X_feature_conditioning is not None:
-            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
         if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
             X_skip_layer = X_skip_layer.unsqueeze(1)
+        if X_feature_conditioning is not None:   # tiny [B, F] tensor: normalise the features
+            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
 
         encoding_out = []
         curr = X
@@ -345,6 +366,9 @@ class UNet(torch.nn.Module):
                 xfl = torch.nn.functional.interpolate(X_skip_layer, S, mode="nearest")
                 link_in = torch.cat([link_in, xfl], axis=1)
             encoded = link_op(link_in)
+            if X_feature_conditioning is not None:   # channel gates, unet.py:803-810
+                gates = self.feature_conditioning_ops[i](X_feature_conditioning)
+                encoded = HF.scale_per_item_channel(encoded, gates)
             curr = up(curr)
             sh, sh2 = list(curr.shape)[2:], list(encoded.shape)[2:]
             if np.prod(sh) < np.prod(sh2):

@@ -828,6 +828,29 @@ def interp_linear(x, scales, backward_from=None):
     return dx
 
 
+def scale_bc(x, s):
+    """x [N,C,D,H,W] (NDHWC memory) times s [N,C]."""
+    _require_cuda(x, s)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    V = x.numel() // (N * C)
+    y = new_act(N, C, *x.shape[2:], x.device)
+    check(_lib.lib().adell_scale_bc(_ptr(x), _ptr(s.contiguous()), _ptr(y), N, V, C, _stream()))
+    return y
+
+
+def scale_bc_dscale(x, dy):
+    """ds[n,c] = sum over voxels of dy * x."""
+    x, dy = ndhwc(x), ndhwc(dy)
+    N, C = x.shape[:2]
+    V = x.numel() // (N * C)
+    ws = _workspace(4 * _lib.lib().adell_scale_bc_dscale_workspace_floats(N, V, C), x.device)
+    ds = torch.empty((N, C), device=x.device, dtype=torch.float32)
+    check(_lib.lib().adell_scale_bc_dscale(_ptr(x), _ptr(dy), _ptr(ds), N, V, C, _ptr(ws),
+                                           _stream()))
+    return ds
+
+
 def maxpool3d_fwd(x, kernel, stride, padding):
     _require_cuda(x)
     x = ndhwc(x)

@@ -351,6 +351,15 @@ int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C, int Di, in
                             int Do, int Ho, int Wo, float scale_d, float scale_h, float scale_w,
                             void* stream);
 
+/* y[n][v][c] = x[n][v][c] * s[n][c] on NDHWC activations (x, y: [N][V][C]; s: [N][C]): the tabular
+ * feature gates of the decoder (unet.py:803-810) and U-out (regularization.py:48-55). The
+ * backward is the same call on dy (dx = dy * s) plus ds[n][c] = sum_v dy * x
+ * (adell_scale_bc_dscale; workspace of adell_scale_bc_dscale_workspace_floats floats). */
+int adell_scale_bc(const float* x, const float* s, float* y, int N, long V, int C, void* stream);
+long adell_scale_bc_dscale_workspace_floats(int N, long V, int C);
+int adell_scale_bc_dscale(const float* x, const float* dy, float* ds, int N, long V, int C,
+                          float* workspace, void* stream);
+
 /* torch.nn.MaxPool3d (ceil_mode False, dilation 1, -inf padding): unet.py:335,368,
  * 595-603, res_net.py:180,209. Geometry in an adell_conv3d_desc (C0 = channels, C1 and
  * Cout ignored); argmax [N][Do][Ho][Wo][C] holds the winner's (z*H+y)*W+x. */

@@ -93,6 +93,15 @@ UNET2D_CASES = {
     "unet2d_upsample": (dict(spatial_dimensions=2, depth=[8, 16, 32], padding="same",
                              strides=[2, 2, 2], kernel_sizes=[3, 3, 3], activation_fn="prelu",
                              dropout_param=0.0, _train=True), (2, 1, 40, 48), "uniform"),
+    # tabular feature conditioning (unet.py:716-740, 803-810): Linear -> BatchNorm1d -> swish ->
+    # Linear -> BatchNorm1d -> sigmoid gates on every skip connection; train() for the batch
+    # statistics of the BatchNorm1d layers over 4 items
+    "unet3d_feature_cond": (dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1,
+                                 strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
+                                 upscale_type="transpose", norm_type="instance",
+                                 activation_fn="swish", dropout_param=0.0, link_type="identity",
+                                 in_channels=1, feature_conditioning=5, _train=True),
+                            (4, 1, 16, 16, 16), "uniform"),
     # 3-D: 1x1x1 conv + trilinear Upsample, anisotropic stride at the deepest level
     "unet3d_upsample": (dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1,
                              strides=[2, 2, [2, 2, 1]], kernel_sizes=[3, 3, 3],
@@ -196,9 +205,14 @@ def gen_unet(name, kw, shape, dist):
     net = net.train() if (kw.get("_cls") == "backbone" or kw.get("_train")) else net.eval()
     out = {"x": x.numpy(), "y": y.numpy()}
     # forward parity target: logits (north_star: within 1e-4 rel)
-    logits = net(x, return_logits=True)[0]
+    extra = {}
+    if kw.get("feature_conditioning"):   # tabular features gating the skip connections
+        fc = torch.randn((shape[0], kw["feature_conditioning"]), generator=g)
+        out["x_fc"] = fc.numpy()
+        extra["X_feature_conditioning"] = fc
+    logits = net(x, return_logits=True, **extra)[0]
     out["logits"] = logits.detach().numpy()
-    res = net(x)
+    res = net(x, **extra)
     prob = res[0]
     if len(res) == 3 and isinstance(res[2], list):  # U-Net++ auxiliary heads
         for i, a in enumerate(res[2]):
