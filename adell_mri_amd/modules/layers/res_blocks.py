@@ -9,12 +9,14 @@ import torch
 
 from ... import functional as HF
 from ... import ops
-from .conv import Conv3d
+from .conv import Conv2d, Conv3d
 from .linear_blocks import LayerNorm as RowLayerNorm
 from .linear_blocks import Linear
 
 
 class ResidualBlock3d(torch.nn.Module):
+    _conv = Conv3d   # ResidualBlock2d swaps in the 2-D convolution
+
     def __init__(self, in_channels: int, kernel_size: int, inter_channels: int = None,
                  out_channels: int = None, adn_fn: torch.nn.Module = torch.nn.Identity,
                  skip_activation: bool = None):
@@ -29,15 +31,16 @@ class ResidualBlock3d(torch.nn.Module):
 
     def init_layers(self):
         c, k, m = self.in_channels, self.kernel_size, self.inter_channels
+        conv = self._conv
         if m is not None:
             self.op = torch.nn.Sequential(
-                Conv3d(c, m, 1), self.adn_fn(m), Conv3d(m, m, k, padding="same"),
-                self.adn_fn(m), Conv3d(m, c, 1))
+                conv(c, m, 1), self.adn_fn(m), conv(m, m, k, padding="same"),
+                self.adn_fn(m), conv(m, c, 1))
         else:
             self.op = torch.nn.Sequential(
-                Conv3d(c, c, k, padding="same"), self.adn_fn(c), Conv3d(c, c, k, padding="same"))
+                conv(c, c, k, padding="same"), self.adn_fn(c), conv(c, c, k, padding="same"))
         if self.in_channels != self.out_channels:
-            self.final_op = Conv3d(self.in_channels, self.out_channels, 1)
+            self.final_op = conv(self.in_channels, self.out_channels, 1)
         else:
             self.final_op = torch.nn.Identity()
         self.adn_op = self.adn_fn(self.out_channels)
@@ -52,6 +55,12 @@ class ResidualBlock3d(torch.nn.Module):
         if skip is not True:
             out = self.adn_op(out)
         return out
+
+
+class ResidualBlock2d(ResidualBlock3d):
+    """2-D residual block (res_blocks.py:13-105): the same tree on 2-D convolutions."""
+
+    _conv = Conv2d
 
 
 class DepthwiseConv3d(torch.nn.Conv3d):

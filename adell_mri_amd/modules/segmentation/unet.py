@@ -26,7 +26,7 @@ from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, Max
                            Upsample)
 from ..layers.linear_blocks import Linear
 from ..layers.regularization import UOut
-from ..layers.res_blocks import ResidualBlock3d
+from ..layers.res_blocks import ResidualBlock2d, ResidualBlock3d
 from ..layers.utils import crop_to_size
 
 
@@ -223,10 +223,9 @@ class UNet(torch.nn.Module):
                 torch.nn.Sequential(self._conv(d + ex, d, 3, padding=self.padding), self.adn_fn(d))
                 for d in rev_depth])
         elif self.link_type == "residual":
-            if self.spatial_dimensions != 3:
-                raise NotImplementedError("2-D residual links are outside the HIP path so far")
+            block = ResidualBlock3d if self.spatial_dimensions == 3 else ResidualBlock2d
             self.link_ops = torch.nn.ModuleList([
-                ResidualBlock3d(d + ex, 3, out_channels=d, adn_fn=self.adn_fn) for d in rev_depth])
+                block(d + ex, 3, out_channels=d, adn_fn=self.adn_fn) for d in rev_depth])
         else:
             raise NotImplementedError(f"link_type={self.link_type!r} is outside the HIP path")
 

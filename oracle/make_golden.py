@@ -93,6 +93,12 @@ UNET2D_CASES = {
     "unet2d_upsample": (dict(spatial_dimensions=2, depth=[8, 16, 32], padding="same",
                              strides=[2, 2, 2], kernel_sizes=[3, 3, 3], activation_fn="prelu",
                              dropout_param=0.0, _train=True), (2, 1, 40, 48), "uniform"),
+    # 2-D residual skip links (ResidualBlock2d, res_blocks.py:13-105) + skip conditioning input
+    "unet2d_residual_links": (dict(spatial_dimensions=2, depth=[8, 16, 32], padding=1,
+                                   strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
+                                   upscale_type="transpose", norm_type="instance",
+                                   activation_fn="swish", dropout_param=0.0,
+                                   link_type="residual", in_channels=2), (2, 2, 32, 40), "uniform"),
     # tabular feature conditioning (unet.py:716-740, 803-810): Linear -> BatchNorm1d -> swish ->
     # Linear -> BatchNorm1d -> sigmoid gates on every skip connection; train() for the batch
     # statistics of the BatchNorm1d layers over 4 items

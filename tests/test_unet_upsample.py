@@ -1,4 +1,5 @@
-"""upscale_type="upsample" (the reference's constructor default: 1x1 conv + torch.nn.Upsample,
+"""Constructor corners of the U-Net: 2-D residual skip links (ResidualBlock2d,
+res_blocks.py:13-105) and upscale_type="upsample" (the reference's constructor default: 1x1 conv + torch.nn.Upsample,
 unet.py:419-443) against fixtures generated from the real reference (oracle/make_golden.py cases
 unet2d_upsample: all-default 2-D U-Net; unet3d_upsample: trilinear, anisotropic last stride), and
 the interpolation kernels against torch."""
@@ -20,6 +21,11 @@ CASES = {
     "unet2d_upsample": dict(spatial_dimensions=2, depth=[8, 16, 32], padding="same",
                             strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
                             activation_fn=torch.nn.PReLU, dropout_param=0.0),
+    "unet2d_residual_links": dict(spatial_dimensions=2, depth=[8, 16, 32], padding=1,
+                                  strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
+                                  upscale_type="transpose", norm_type="instance",
+                                  activation_fn=activation_factory["swish"], dropout_param=0.0,
+                                  link_type="residual", in_channels=2),
     "unet3d_upsample": dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1,
                             strides=[2, 2, [2, 2, 1]], kernel_sizes=[3, 3, 3],
                             upscale_type="upsample", interpolation="trilinear",
