@@ -85,6 +85,7 @@ SIGNATURES = {
     "adell_dice_focal_bwd_dev": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "adell_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _i, _f, _vp]),
     "adell_adamw_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),
+    "adell_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),
     "adell_ema_update": (_i, [_vp, _vp, _l, _f, _vp]),
     "adell_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _vp]),
     "adell_layernorm_bwd_workspace": (_l, [_l, _i]),

@@ -244,6 +244,8 @@ extern "C" int adell_sgd_step(float* param, const float* grad, float* momentum_b
   return ADELL_OK;
 }
 
+// DECOUPLED: AdamW (p *= 1 - lr * wd); otherwise Adam (the decay enters the gradient: g += wd * p)
+template <bool DECOUPLED>
 __global__ __launch_bounds__(256) void adell_adamw_kernel(float* __restrict__ p,
                                                           const float* __restrict__ g,
                                                           float* __restrict__ m,
@@ -252,8 +254,12 @@ __global__ __launch_bounds__(256) void adell_adamw_kernel(float* __restrict__ p,
                                                           float bc1, float bc2_sqrt,
                                                           float grad_scale) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
-    const float gi = g[i] * grad_scale;
-    float pi = p[i] * (1.0f - lr * wd);
+    float gi = g[i] * grad_scale;
+    float pi = p[i];
+    if (DECOUPLED)
+      pi *= 1.0f - lr * wd;
+    else
+      gi += wd * pi;
     const float mi = b1 * m[i] + (1.0f - b1) * gi;
     const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
     m[i] = mi;
@@ -264,22 +270,44 @@ __global__ __launch_bounds__(256) void adell_adamw_kernel(float* __restrict__ p,
   }
 }
 
+static int adell_adam_launch(bool decoupled, float* param, const float* grad, float* exp_avg,
+                             float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, long step, float grad_scale,
+                             void* stream) {
+  ADELL_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adam(w)_step: null pointer");
+  ADELL_REQUIRE(n > 0 && step >= 1, "adam(w)_step: bad n / step");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (decoupled)
+    hipLaunchKernelGGL(adell_adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2s, grad_scale);
+  else
+    hipLaunchKernelGGL(adell_adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2s, grad_scale);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
 // torch.optim.AdamW (amsgrad off), step = 1-based step count.
 extern "C" int adell_adamw_step(float* param, const float* grad, float* exp_avg,
                                 float* exp_avg_sq, long n, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, long step, float grad_scale,
                                 void* stream) {
-  ADELL_REQUIRE(param && grad && exp_avg && exp_avg_sq, "adamw_step: null pointer");
-  ADELL_REQUIRE(n > 0 && step >= 1, "adamw_step: bad n / step");
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
-  long blocks = (n + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adell_adamw_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2,
-                     eps, weight_decay, bc1, bc2s, grad_scale);
-  ADELL_CHECK_HIP(hipGetLastError());
-  return ADELL_OK;
+  return adell_adam_launch(true, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                           weight_decay, step, grad_scale, stream);
+}
+
+// torch.optim.Adam (amsgrad off): L2 weight decay added to the gradient.
+extern "C" int adell_adam_step(float* param, const float* grad, float* exp_avg,
+                               float* exp_avg_sq, long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, long step, float grad_scale,
+                               void* stream) {
+  return adell_adam_launch(false, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                           weight_decay, step, grad_scale, stream);
 }
 
 __global__ __launch_bounds__(256) void adell_ema_kernel(float* __restrict__ shadow,

@@ -15,7 +15,7 @@ from typing import Callable
 import torch
 import torch.nn.functional as F
 
-from ...optim import FusedAdamW, FusedSGD
+from ...optim import FusedAdam, FusedAdamW, FusedSGD
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .unet import UNet
 
@@ -34,6 +34,8 @@ def get_optimizer(name: str, parameters, **kwargs):
         return FusedSGD(parameters, **kwargs)
     if name == "adamw":
         return FusedAdamW(parameters, **kwargs)
+    if name == "adam":
+        return FusedAdam(parameters, **kwargs)
     raise NotImplementedError(f"optimizer {name!r} has no fused HIP implementation yet")
 
 

@@ -661,11 +661,12 @@ def sgd_step(param, grad, buf, lr, momentum, weight_decay, nesterov, first, grad
 
 
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
-               grad_scale=1.0):
+               grad_scale=1.0, decoupled=True):
+    """torch.optim.AdamW (decoupled decay) or torch.optim.Adam (decay added to the gradient)."""
     _require_cuda(param, grad, exp_avg, exp_avg_sq)
-    check(_lib.lib().adell_adamw_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
-                                      param.numel(), lr, beta1, beta2, eps, weight_decay,
-                                      int(step), grad_scale, _stream()))
+    fn = _lib.lib().adell_adamw_step if decoupled else _lib.lib().adell_adam_step
+    check(fn(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), param.numel(), lr, beta1,
+             beta2, eps, weight_decay, int(step), grad_scale, _stream()))
     _weights_changed()
 
 

@@ -142,6 +142,8 @@ class FusedSGD(_FusedBase):
 
 
 class FusedAdamW(_FusedBase):
+    decoupled = True
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       grad_scale=1.0))
@@ -162,5 +164,14 @@ class FusedAdamW(_FusedBase):
             st["step"] += 1
             ops.adamw_step(flat.data, flat.grad, st["exp_avg"], st["exp_avg_sq"], g["lr"],
                            g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], st["step"],
-                           g.get("grad_scale", 1.0))
+                           g.get("grad_scale", 1.0), decoupled=self.decoupled)
         return loss
+
+
+class FusedAdam(FusedAdamW):
+    """torch.optim.Adam: same kernel, weight decay added to the gradient (default 0)."""
+
+    decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)

@@ -292,6 +292,11 @@ int adell_sgd_step(float* param, const float* grad, float* momentum_buf, long n,
 int adell_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      long n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, long step, float grad_scale, void* stream);
+/* torch.optim.Adam ("adam" of optimizer_factory.py:5-14): as above with the weight decay added
+ * to the gradient instead of decoupled. */
+int adell_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, long step,
+                    float grad_scale, void* stream);
 int adell_ema_update(float* shadow, const float* param, long n, float decay, void* stream);
 
 /* ------------------------------------------------------------------------
