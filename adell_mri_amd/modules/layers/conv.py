@@ -122,5 +122,16 @@ class MaxPool3d(torch.nn.MaxPool3d):
         return HF.max_pool3d(X, self.kernel_size, self.stride, self.padding)
 
 
+class MaxPool2d(torch.nn.MaxPool2d):
+    """2-D max pooling run as a depth-1 3-D one."""
+
+    def forward(self, X):
+        pair = lambda v: (v, v) if isinstance(v, int) else tuple(v)  # noqa: E731
+        if self.ceil_mode or self.return_indices or pair(self.dilation) != (1, 1):
+            raise AdellHipError("HIP MaxPool2d supports ceil_mode=False, dilation=1 only")
+        k, st, p = pair(self.kernel_size), pair(self.stride), pair(self.padding)
+        return HF.max_pool3d(X.unsqueeze(2), (1, *k), (1, *st), (0, *p)).squeeze(2)
+
+
 def ops_triple(v):
     return (v,) * 3 if isinstance(v, int) else tuple(v)

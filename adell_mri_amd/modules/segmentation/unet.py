@@ -22,8 +22,8 @@ import torch
 from ... import functional as HF
 from ..._lib import AdellHipError
 from ..layers.adn_fn import ActDropNorm, get_adn_fn, norm_fn_dict
-from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool3d,
-                           Upsample)
+from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool2d,
+                           MaxPool3d, Upsample)
 from ..layers.linear_blocks import Linear
 from ..layers.regularization import UOut
 from ..layers.res_blocks import ResidualBlock2d, ResidualBlock3d
@@ -153,7 +153,7 @@ class UNet(torch.nn.Module):
         if self.conv_type == "regular":
             self.conv_op_enc = self.conv_block
             self.conv_op_dec = self.conv_block
-        elif self.conv_type == "resnet" and self.spatial_dimensions == 3:
+        elif self.conv_type == "resnet":
             self.conv_op_enc = self.res_block_conv_3d
             self.conv_op_dec = self.conv_block
         else:
@@ -180,14 +180,16 @@ class UNet(torch.nn.Module):
     conv_block_3d = conv_block
 
     def res_block_conv_3d(self, in_d, out_d, kernel_size, stride=None, padding=None):
-        """ResidualBlock3d (+ MaxPool3d when strided): unet.py:344-379."""
+        """ResidualBlock3d / 2d (+ max pooling when strided): unet.py:309-379."""
+        nd = self.spatial_dimensions
+        res, pool = (ResidualBlock3d, MaxPool3d) if nd == 3 else (ResidualBlock2d, MaxPool2d)
         inter_d = int(in_d) if in_d > 32 else None
-        stride = _per_dim(1 if stride is None else stride, 3)
-        block = ResidualBlock3d(in_d, kernel_size, inter_d, out_d, adn_fn=self.adn_fn)
+        stride = _per_dim(1 if stride is None else stride, nd)
+        block = res(in_d, kernel_size, inter_d, out_d, adn_fn=self.adn_fn)
         if any(s > 1 for s in stride):
-            padding = _per_dim(0 if padding is None else padding, 3)
+            padding = _per_dim(0 if padding is None else padding, nd)
             new_padding = [p // 2 if p > s // 2 else p for p, s in zip(padding, stride)]
-            return torch.nn.Sequential(block, MaxPool3d(stride, stride, padding=new_padding))
+            return torch.nn.Sequential(block, pool(stride, stride, padding=new_padding))
         return block
 
     def adn_fn(self, s: int) -> torch.nn.Module:
@@ -255,13 +257,12 @@ class UNet(torch.nn.Module):
     def init_encoder_backbone(self):
         """Every downsampling op becomes MaxPool(kernel=s, stride=s, padding=s//2)
         (unet.py:588-603); the last level keeps Identity."""
-        if self.spatial_dimensions != 3:
-            raise NotImplementedError("2-D max pooling has no HIP kernel yet")
+        pool = MaxPool3d if self.spatial_dimensions == 3 else MaxPool2d
         for i in range(len(self.encoding_operations)):
             s = np.array(_per_dim(self.strides[i], self.spatial_dimensions))
-            self.encoding_operations[i][1] = MaxPool3d(kernel_size=tuple(int(j) for j in s),
-                                                       stride=tuple(int(j) for j in s),
-                                                       padding=tuple(int(j) for j in s // 2))
+            self.encoding_operations[i][1] = pool(kernel_size=tuple(int(j) for j in s),
+                                                  stride=tuple(int(j) for j in s),
+                                                  padding=tuple(int(j) for j in s // 2))
         self.encoding_operations[-1][1] = torch.nn.Identity()
 
     def init_decoder(self):

@@ -99,6 +99,13 @@ UNET2D_CASES = {
                                    upscale_type="transpose", norm_type="instance",
                                    activation_fn="swish", dropout_param=0.0,
                                    link_type="residual", in_channels=2), (2, 2, 32, 40), "uniform"),
+    # conv_type="resnet" in 2-D: ResidualBlock2d encoder blocks followed by MaxPool2d
+    # (res_block_conv_2d, unet.py:309-342)
+    "unet2d_resnet_blocks": (dict(spatial_dimensions=2, depth=[8, 16, 32], padding=1,
+                                  strides=[2, 2, 2], kernel_sizes=[3, 3, 3], conv_type="resnet",
+                                  upscale_type="transpose", norm_type="instance",
+                                  activation_fn="swish", dropout_param=0.0,
+                                  link_type="identity", in_channels=1), (2, 1, 32, 48), "uniform"),
     # tabular feature conditioning (unet.py:716-740, 803-810): Linear -> BatchNorm1d -> swish ->
     # Linear -> BatchNorm1d -> sigmoid gates on every skip connection; train() for the batch
     # statistics of the BatchNorm1d layers over 4 items

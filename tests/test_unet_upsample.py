@@ -26,6 +26,11 @@ CASES = {
                                   upscale_type="transpose", norm_type="instance",
                                   activation_fn=activation_factory["swish"], dropout_param=0.0,
                                   link_type="residual", in_channels=2),
+    "unet2d_resnet_blocks": dict(spatial_dimensions=2, depth=[8, 16, 32], padding=1,
+                                 strides=[2, 2, 2], kernel_sizes=[3, 3, 3], conv_type="resnet",
+                                 upscale_type="transpose", norm_type="instance",
+                                 activation_fn=activation_factory["swish"], dropout_param=0.0,
+                                 link_type="identity", in_channels=1),
     "unet3d_upsample": dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1,
                             strides=[2, 2, [2, 2, 1]], kernel_sizes=[3, 3, 3],
                             upscale_type="upsample", interpolation="trilinear",
