@@ -316,11 +316,13 @@ struct LinArgs {
   const float* x;   // fwd: input;  bwd: dY
   float* y;         // fwd: output; bwd: dX
   int N, C, Di, Hi, Wi, Do, Ho, Wo;
-  float rz, ry, rx; // 1 / scale_factor per axis
+  float rz, ry, rx; // 1 / scale_factor per axis (align_corners: (in - 1) / (out - 1))
+  int align;        // align_corners=True: src = o * r
 };
 
-__device__ __forceinline__ void adell_lin_taps(int o, float r, int size, int* i0, int* i1, float* t) {
-  float src = ((float)o + 0.5f) * r - 0.5f;
+__device__ __forceinline__ void adell_lin_taps(int o, float r, int size, int* i0, int* i1, float* t,
+                                               int align = 0) {
+  float src = align ? (float)o * r : ((float)o + 0.5f) * r - 0.5f;
   src = src < 0.f ? 0.f : src;
   const int f = (int)src;
   *i0 = f < size - 1 ? f : size - 1;
@@ -339,9 +341,9 @@ __global__ __launch_bounds__(256) void adell_interp_linear_fwd_kernel(LinArgs a)
     const int nb = (int)(v / a.Do);
     int z0, z1, y0, y1, x0, x1;
     float tz, ty, tx;
-    adell_lin_taps(oz, a.rz, a.Di, &z0, &z1, &tz);
-    adell_lin_taps(oy, a.ry, a.Hi, &y0, &y1, &ty);
-    adell_lin_taps(ox, a.rx, a.Wi, &x0, &x1, &tx);
+    adell_lin_taps(oz, a.rz, a.Di, &z0, &z1, &tz, a.align);
+    adell_lin_taps(oy, a.ry, a.Hi, &y0, &y1, &ty, a.align);
+    adell_lin_taps(ox, a.rx, a.Wi, &x0, &x1, &tx, a.align);
     const float* xb = a.x + (size_t)nb * a.Di * a.Hi * a.Wi * a.C + c;
     auto at = [&](int z, int y, int x) { return xb[((size_t)(z * a.Hi + y) * a.Wi + x) * a.C]; };
     const float c00 = at(z0, y0, x0) * (1.f - tx) + at(z0, y0, x1) * tx;
@@ -354,10 +356,10 @@ __global__ __launch_bounds__(256) void adell_interp_linear_fwd_kernel(LinArgs a)
 }
 
 // weight with which input index `in` enters output index o along one axis
-__device__ __forceinline__ float adell_lin_weight(int o, float r, int size, int in) {
+__device__ __forceinline__ float adell_lin_weight(int o, float r, int size, int in, int align) {
   int i0, i1;
   float t;
-  adell_lin_taps(o, r, size, &i0, &i1, &t);
+  adell_lin_taps(o, r, size, &i0, &i1, &t, align);
   return (i0 == in ? 1.f - t : 0.f) + (i1 == in ? t : 0.f);
 }
 
@@ -371,22 +373,31 @@ __global__ __launch_bounds__(256) void adell_interp_linear_bwd_kernel(LinArgs a)
     const int iz = (int)(v % a.Di);
     const int nb = (int)(v / a.Di);
     // output indices whose taps can reach this input index: src in (in - 1, in + 1)
-    auto lo = [](int in, float r) { int o = (int)floorf(((float)in - 0.5f) / r - 0.5f); return o < 0 ? 0 : o; };
-    auto hi = [](int in, float r, int osz) { int o = (int)ceilf(((float)in + 1.5f) / r - 0.5f); return o > osz - 1 ? osz - 1 : o; };
+    // (a conservative range: every candidate's weight is recomputed, most are zero)
+    auto lo = [&](int in, float r) {
+      if (r <= 0.f) return 0;
+      int o = (int)floorf(((float)in - 1.0f) / r - 1.0f);
+      return o < 0 ? 0 : o;
+    };
+    auto hi = [&](int in, float r, int osz) {
+      if (r <= 0.f) return osz - 1;
+      int o = (int)ceilf(((float)in + 1.5f) / r + 1.0f);
+      return o > osz - 1 ? osz - 1 : o;
+    };
     const int zl = lo(iz, a.rz), zh = hi(iz, a.rz, a.Do);
     const int yl = lo(iy, a.ry), yh = hi(iy, a.ry, a.Ho);
     const int xl = lo(ix, a.rx), xh = hi(ix, a.rx, a.Wo);
     const float* gb = a.x + (size_t)nb * a.Do * a.Ho * a.Wo * a.C + c;
     float acc = 0.f;
     for (int oz = zl; oz <= zh; ++oz) {
-      const float wz = adell_lin_weight(oz, a.rz, a.Di, iz);
+      const float wz = adell_lin_weight(oz, a.rz, a.Di, iz, a.align);
       if (wz == 0.f) continue;
       for (int oy = yl; oy <= yh; ++oy) {
-        const float wy = adell_lin_weight(oy, a.ry, a.Hi, iy);
+        const float wy = adell_lin_weight(oy, a.ry, a.Hi, iy, a.align);
         if (wy == 0.f) continue;
         float row = 0.f;
         for (int ox = xl; ox <= xh; ++ox) {
-          const float wx = adell_lin_weight(ox, a.rx, a.Wi, ix);
+          const float wx = adell_lin_weight(ox, a.rx, a.Wi, ix, a.align);
           if (wx != 0.f) row += wx * gb[((size_t)(oz * a.Ho + oy) * a.Wo + ox) * a.C];
         }
         acc += wz * wy * row;
@@ -397,13 +408,18 @@ __global__ __launch_bounds__(256) void adell_interp_linear_bwd_kernel(LinArgs a)
 }
 
 static int adell_interp_linear(const float* x, float* y, int N, int C, int Di, int Hi, int Wi,
-                               int Do, int Ho, int Wo, float sz, float sy, float sx, int bwd,
-                               hipStream_t st) {
+                               int Do, int Ho, int Wo, float sz, float sy, float sx, int align,
+                               int bwd, hipStream_t st) {
   ADELL_REQUIRE(x && y, "interp_linear: null pointer");
   ADELL_REQUIRE(N > 0 && C > 0 && Di > 0 && Hi > 0 && Wi > 0 && Do > 0 && Ho > 0 && Wo > 0,
                 "interp_linear: bad dims");
   ADELL_REQUIRE(sz > 0.f && sy > 0.f && sx > 0.f, "interp_linear: bad scale factors");
-  LinArgs a = {x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, 1.f / sz, 1.f / sy, 1.f / sx};
+  LinArgs a = {x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, 1.f / sz, 1.f / sy, 1.f / sx, align};
+  if (align) {   // align_corners=True: the corner voxels map onto each other
+    a.rz = Do > 1 ? (float)(Di - 1) / (float)(Do - 1) : 0.f;
+    a.ry = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+    a.rx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  }
   const long n = (long)N * C * (bwd ? (long)Di * Hi * Wi : (long)Do * Ho * Wo);
   long blocks = (n + 255) / 256;
   if (blocks > 65535 * 4) blocks = 65535 * 4;
@@ -417,15 +433,17 @@ static int adell_interp_linear(const float* x, float* y, int N, int C, int Di, i
 
 extern "C" int adell_interp_linear_fwd(const float* x, float* y, int N, int C, int Di, int Hi,
                                        int Wi, int Do, int Ho, int Wo, float scale_d,
-                                       float scale_h, float scale_w, void* stream) {
-  return adell_interp_linear(x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, 0,
-                             (hipStream_t)stream);
+                                       float scale_h, float scale_w, int align_corners,
+                                       void* stream) {
+  return adell_interp_linear(x, y, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w,
+                             align_corners, 0, (hipStream_t)stream);
 }
 extern "C" int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi,
                                        int Wi, int Do, int Ho, int Wo, float scale_d,
-                                       float scale_h, float scale_w, void* stream) {
-  return adell_interp_linear(dy, dx, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w, 1,
-                             (hipStream_t)stream);
+                                       float scale_h, float scale_w, int align_corners,
+                                       void* stream) {
+  return adell_interp_linear(dy, dx, N, C, Di, Hi, Wi, Do, Ho, Wo, scale_d, scale_h, scale_w,
+                             align_corners, 1, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -669,6 +669,19 @@ def upsample_linear(x, scale_factor):
     return _LinearUpFn.apply(x, sc)
 
 
+def resize_linear_aligned(x, size):
+    """F.interpolate(x, size, mode="linear"-family, align_corners=True) for [N, C, *spatial]
+    tensors that need no gradient (the deep-supervision targets, pl.py:305-309)."""
+    size = [int(v) for v in size]
+    x = x.detach()
+    nd = x.dim() - 2
+    if nd == 3:
+        return ops.interp_linear(x, None, size=tuple(size))
+    if nd == 2:
+        return ops.interp_linear(x.unsqueeze(2), None, size=(1, *size)).squeeze(2)
+    return ops.interp_linear(x[:, :, None, None], None, size=(1, 1, *size))[:, :, 0, 0]
+
+
 class _ScaleBcFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, s):

@@ -15,6 +15,7 @@ from typing import Callable
 import torch
 import torch.nn.functional as F
 
+from ... import functional as HF
 from ...optim import FusedAdam, FusedAdamW, FusedSGD
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .unet import UNet
@@ -76,11 +77,11 @@ class UNetBasePL(_Base):
         loss = self.calculate_loss(prediction, y)
         if self.deep_supervision is True:
             t = len(deep_outputs)
-            interp = {3: "linear", 4: "bilinear", 5: "trilinear"}[len(y.shape)]
             additional = torch.zeros_like(loss)
             for i, o in enumerate(deep_outputs):
                 S = o.shape[-self.spatial_dimensions:]
-                y_small = (F.interpolate(y, S, mode=interp, align_corners=True) > 0).float()
+                # F.interpolate(y, S, mode=linear family, align_corners=True) > 0 (pl.py:305-309)
+                y_small = (HF.resize_linear_aligned(y, S) > 0).float()
                 additional = additional + self.calculate_loss(o, y_small).mean() / (2 ** (t - i)) / (t + 1)
             loss = loss + additional
         class_loss = None

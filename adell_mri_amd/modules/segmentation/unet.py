@@ -47,6 +47,20 @@ class ConcatConvBlock(torch.nn.Sequential):
         return h
 
 
+def _cat_channels(a, b):
+    """torch.cat((a, b), 1) for 4-D / 5-D activations on the channel-copy kernel."""
+    if a.dim() == 4:
+        return HF.cat_channels([a.unsqueeze(2), b.unsqueeze(2)]).squeeze(2)
+    return HF.cat_channels([a, b])
+
+
+def _nearest(x, size):
+    """F.interpolate(x, size, mode="nearest") for 4-D / 5-D tensors on the resampling kernel."""
+    if x.dim() == 4:
+        return HF.interpolate_nearest(x.unsqueeze(2), (1, *size)).squeeze(2)
+    return HF.interpolate_nearest(x, size)
+
+
 class _DecoderOp(torch.nn.Sequential):
     """``Sequential(conv_block, adn)`` forwarding the concat operand."""
 
@@ -55,7 +69,7 @@ class _DecoderOp(torch.nn.Sequential):
         if X_cat is not None and isinstance(mods[0], ConcatConvBlock):
             h = mods[0](X, X_cat=X_cat)
         else:
-            h = mods[0](X if X_cat is None else torch.cat((X, X_cat), 1))
+            h = mods[0](X if X_cat is None else _cat_channels(X, X_cat))
         for mod in mods[1:]:
             h = mod(h)
         return h
@@ -363,8 +377,7 @@ class UNet(torch.nn.Module):
             link_in = encoding_out[-i - 2]
             if X_skip_layer is not None:
                 S = link_in.shape[2:]
-                xfl = torch.nn.functional.interpolate(X_skip_layer, S, mode="nearest")
-                link_in = torch.cat([link_in, xfl], axis=1)
+                link_in = _cat_channels(link_in, _nearest(X_skip_layer, S))
             encoded = link_op(link_in)
             if X_feature_conditioning is not None:   # channel gates, unet.py:803-810
                 gates = self.feature_conditioning_ops[i](X_feature_conditioning)

@@ -206,9 +206,8 @@ class UNETR(UNet, torch.nn.Module):
             op = self.decoding_operations[i]
             link_in = encoding_out[-i - 2]
             if X_skip_layer is not None:
-                xfl = torch.nn.functional.interpolate(X_skip_layer, link_in.shape[2:],
-                                                      mode="nearest")
-                link_in = torch.cat([link_in, xfl], axis=1)
+                xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
+                link_in = HF.cat_channels([link_in, xfl])
             encoded = self.link_ops[i](link_in)
             curr = self.upscale_ops[i](curr)
             curr = op(curr, X_cat=encoded)

@@ -807,25 +807,28 @@ def interp_nearest(x, size, backward_from=None):
     return dx
 
 
-def interp_linear(x, scales, backward_from=None):
+def interp_linear(x, scales, backward_from=None, size=None):
     """torch.nn.Upsample(scale_factor=scales, mode="trilinear", align_corners=False) on
-    [N,C,Di,Hi,Wi]; with backward_from=(Di,Hi,Wi): x is the output gradient, result = dX."""
+    [N,C,Di,Hi,Wi]; with size=(Do,Ho,Wo): F.interpolate(size=..., align_corners=True) instead;
+    with backward_from=(Di,Hi,Wi): x is the output gradient, result = dX."""
     _require_cuda(x)
     x = ndhwc(x)
     N, C = x.shape[:2]
-    sd, sh, sw = (float(s) for s in scales)
+    align = int(size is not None)
+    sd, sh, sw = (1.0, 1.0, 1.0) if align else (float(s) for s in scales)
     if backward_from is None:
         Di, Hi, Wi = x.shape[2:]
-        Do, Ho, Wo = (int(math.floor(n * s)) for n, s in zip((Di, Hi, Wi), (sd, sh, sw)))
+        Do, Ho, Wo = size if align else (int(math.floor(n * s))
+                                         for n, s in zip((Di, Hi, Wi), (sd, sh, sw)))
         y = new_act(N, C, Do, Ho, Wo, x.device)
         check(_lib.lib().adell_interp_linear_fwd(_ptr(x), _ptr(y), N, C, Di, Hi, Wi, Do, Ho, Wo,
-                                                 sd, sh, sw, _stream()))
+                                                 sd, sh, sw, align, _stream()))
         return y
     Di, Hi, Wi = backward_from
     Do, Ho, Wo = x.shape[2:]
     dx = new_act(N, C, Di, Hi, Wi, x.device)
     check(_lib.lib().adell_interp_linear_bwd(_ptr(x), _ptr(dx), N, C, Di, Hi, Wi, Do, Ho, Wo,
-                                             sd, sh, sw, _stream()))
+                                             sd, sh, sw, align, _stream()))
     return dx
 
 

@@ -347,14 +347,15 @@ int adell_interp_nearest_bwd(const float* dy, float* dx, int N, int C, int Di, i
                              int Do, int Ho, int Wo, void* stream);
 /* torch.nn.Upsample(scale_factor, mode="bilinear" | "trilinear", align_corners=False) of the
  * "upsample" upscaling path (unet.py:419-443): x [N][Di][Hi][Wi][C] -> y [N][Do][Ho][Wo][C] with
- * Do = floor(Di * scale_d) etc.; a 2-D tensor is Di = Do = 1, scale_d = 1. The backward gathers
- * (deterministic). */
+ * Do = floor(Di * scale_d) etc.; a 2-D tensor is Di = Do = 1, scale_d = 1. align_corners != 0:
+ * F.interpolate(size=(Do,Ho,Wo), align_corners=True) (the deep-supervision targets of
+ * pl.py:305-309; the scale arguments are then ignored). The backward gathers (deterministic). */
 int adell_interp_linear_fwd(const float* x, float* y, int N, int C, int Di, int Hi, int Wi,
                             int Do, int Ho, int Wo, float scale_d, float scale_h, float scale_w,
-                            void* stream);
+                            int align_corners, void* stream);
 int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C, int Di, int Hi, int Wi,
                             int Do, int Ho, int Wo, float scale_d, float scale_h, float scale_w,
-                            void* stream);
+                            int align_corners, void* stream);
 
 /* y[n][v][c] = x[n][v][c] * s[n][c] on NDHWC activations (x, y: [N][V][C]; s: [N][C]): the tabular
  * feature gates of the decoder (unet.py:803-810) and U-out (regularization.py:48-55). The

@@ -106,6 +106,14 @@ UNET2D_CASES = {
                                   upscale_type="transpose", norm_type="instance",
                                   activation_fn="swish", dropout_param=0.0,
                                   link_type="identity", in_channels=1), (2, 1, 32, 48), "uniform"),
+    # skip conditioning (X_skip_layer resized to every skip resolution and concatenated,
+    # unet.py:796-801) + deep supervision heads (unet.py:657-683, 836-841)
+    "unet3d_skipcond_deepsup": (dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1,
+                                     strides=[2, 2, 2], kernel_sizes=[3, 3, 3],
+                                     upscale_type="transpose", norm_type="instance",
+                                     activation_fn="swish", dropout_param=0.0,
+                                     link_type="conv", in_channels=1, skip_conditioning=1,
+                                     deep_supervision=True), (1, 1, 24, 24, 24), "uniform"),
     # tabular feature conditioning (unet.py:716-740, 803-810): Linear -> BatchNorm1d -> swish ->
     # Linear -> BatchNorm1d -> sigmoid gates on every skip connection; train() for the batch
     # statistics of the BatchNorm1d layers over 4 items
@@ -223,6 +231,10 @@ def gen_unet(name, kw, shape, dist):
         fc = torch.randn((shape[0], kw["feature_conditioning"]), generator=g)
         out["x_fc"] = fc.numpy()
         extra["X_feature_conditioning"] = fc
+    if kw.get("skip_conditioning"):      # extra image channels concatenated to every skip tensor
+        sk = torch.rand((shape[0], kw["skip_conditioning"], *shape[2:]), generator=g)
+        out["x_skip"] = sk.numpy()
+        extra["X_skip_layer"] = sk
     logits = net(x, return_logits=True, **extra)[0]
     out["logits"] = logits.detach().numpy()
     res = net(x, **extra)

@@ -90,3 +90,51 @@ def test_uout_scales_every_item_and_channel_uniformly(cuda):
     out, _ = net(torch.rand((2, 1, 8, 8, 8), device=cuda))
     out.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+KW_SKIP = dict(spatial_dimensions=3, depth=[8, 16, 32], padding=1, strides=[2, 2, 2],
+               kernel_sizes=[3, 3, 3], upscale_type="transpose", norm_type="instance",
+               activation_fn=activation_factory["swish"], dropout_param=0.0, link_type="conv",
+               in_channels=1, skip_conditioning=1, deep_supervision=True)
+
+
+@pytest.mark.gpu
+def test_skip_conditioning_and_deep_supervision_match_reference(cuda):
+    """X_skip_layer resized (nearest) to every skip resolution and concatenated (unet.py:796-801),
+    deep-supervision heads (unet.py:657-683, 836-841): logits, every auxiliary output and every
+    gradient of the main loss against the reference fixture."""
+    g = np.load(os.path.join(GOLD, "unet3d_skipcond_deepsup.npz"))
+    net = UNet(**KW_SKIP)
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    net = net.to(cuda).eval()
+    x, y = torch.from_numpy(g["x"]).to(cuda), torch.from_numpy(g["y"]).to(cuda)
+    sk = torch.from_numpy(g["x_skip"]).to(cuda)
+    logits = net(x, X_skip_layer=sk, return_logits=True)[0]
+    ref = g["logits"]
+    assert np.abs(logits.detach().cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    prob, _, deep = net(x, X_skip_layer=sk)
+    for i, o in enumerate(deep):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), g[f"aux{i}"], rtol=1e-4, atol=1e-5)
+    loss = compound_loss(prob, y)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    for k, p in net.named_parameters():
+        if ("grad:" + k) in g.files:   # the auxiliary heads do not enter the main loss
+            assert grad_rel_err(g, k, p.grad.cpu().numpy()) < 3e-3, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", [((2, 1, 12, 10, 8), (5, 7, 3)), ((1, 3, 9, 11), (4, 6)),
+                                        ((2, 2, 6, 6, 6), (1, 13, 6))])
+def test_aligned_linear_resize_matches_torch(cuda, shape, size):
+    """F.interpolate(size=..., align_corners=True) of the deep-supervision targets (pl.py:305-309)."""
+    import torch.nn.functional as F
+
+    from adell_mri_amd import functional as HF
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(7))
+    mode = "bilinear" if len(shape) == 4 else "trilinear"
+    want = F.interpolate(x, size, mode=mode, align_corners=True)
+    got = HF.resize_linear_aligned(x.to(cuda), size).cpu()
+    assert tuple(got.shape) == tuple(want.shape)
+    assert float((got - want).abs().max()) < 1e-5
