@@ -597,6 +597,18 @@ extern "C" int adell_pack_weight_f16x3(const float* w, void* out, float* wscale,
   return ADELL_OK;
 }
 
+// table: DEVICE array of `entries` rows of 8 int64 {w, out, wscale, mode, dim0, dim1, taps,
+// first block}; total_blocks = sum of the GEMM-column counts.
+extern "C" int adell_pack_weight_f16x3_multi(const long* table, int entries, long total_blocks,
+                                             void* stream) {
+  ADELL_REQUIRE(table && entries > 0 && total_blocks > 0 && total_blocks < 0x7fffffffL,
+                "pack_weight_f16x3_multi: bad arguments");
+  hipLaunchKernelGGL(adell_pack_weight_f16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     (hipStream_t)stream, table, entries);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
 extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x0,
                                       const float* x1, const void* w_split,
                                       const float* wscale, const float* bias,

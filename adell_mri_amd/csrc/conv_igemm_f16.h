@@ -651,14 +651,12 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
 // mode 0: conv [Cout=A][Cin=B][taps] -> column n = cout, k = cin, tap order kept
 // mode 1: same source -> column n = cin, k = cout, taps flipped (backward-data)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adell_pack_weight_f16_kernel(
+__device__ __forceinline__ void adell_pack_weight_f16_column(
     const float* __restrict__ w, _Float16* __restrict__ out, float* __restrict__ wscale,
-    int mode, int A, int B, int taps) {
-  __shared__ float smx[4];
+    int mode, int A, int B, int taps, int n, float* smx) {
   const int N = mode == 0 ? A : B;   // GEMM columns
   const int K = mode == 0 ? B : A;   // GEMM depth
   const int nchunk = (K + 15) / 16;
-  const int n = blockIdx.x;
   auto src = [&](int tap, int k) -> long {
     return mode == 0 ? ((long)n * B + k) * taps + tap
                      : ((long)k * B + n) * taps + (taps - 1 - tap);
@@ -689,4 +687,32 @@ __global__ __launch_bounds__(256) void adell_pack_weight_f16_kernel(
     o[j] = h;
     o[16 + j] = (_Float16)(tsc - (float)h);
   }
+}
+
+__global__ __launch_bounds__(256) void adell_pack_weight_f16_kernel(
+    const float* __restrict__ w, _Float16* __restrict__ out, float* __restrict__ wscale,
+    int mode, int A, int B, int taps) {
+  __shared__ float smx[4];
+  adell_pack_weight_f16_column(w, out, wscale, mode, A, B, taps, blockIdx.x, smx);
+}
+
+// Every weight of a network in ONE launch (the per-weight launches are ~6 us each, 76 per
+// training step). table[e] = {w, out, wscale (pointers), mode, A, B, taps, first block}: block b
+// packs column b - first_block(e) of the entry e it falls into (binary search).
+__global__ __launch_bounds__(256) void adell_pack_weight_f16_multi_kernel(
+    const long* __restrict__ table, int entries) {
+  __shared__ float smx[4];
+  int lo = 0, hi = entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(size_t)mid * 8 + 7] <= (long)blockIdx.x)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const long* t = table + (size_t)lo * 8;
+  adell_pack_weight_f16_column(reinterpret_cast<const float*>(t[0]),
+                               reinterpret_cast<_Float16*>(t[1]), reinterpret_cast<float*>(t[2]),
+                               (int)t[3], (int)t[4], (int)t[5], (int)t[6],
+                               (int)((long)blockIdx.x - t[7]), smx);
 }

@@ -44,14 +44,71 @@ class _Ref:
         self.obj = obj
 
 
+# Conv weights packed for the f16x3 kernels (modes 0 / 1) are registered here so that, after an
+# optimiser step has rewritten the parameters, ALL of them are repacked by one launch
+# (adell_pack_weight_f16x3_multi) instead of one ~6 us launch per weight and mode.
+_PACK_REG = {}      # (id(weight), mode) -> [weakref(weight), mode, SplitWeight, tag]
+_PACK_BATCH = {"epoch": -1, "sig": None, "table": None, "blocks": 0}
+
+
+def _pack_tag(w):
+    return (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)
+
+
+def _repack_registered():
+    """Repack every live registered weight in one launch; returns False when nothing is
+    registered."""
+    live = []
+    for key, ent in list(_PACK_REG.items()):
+        w = ent[0]()
+        if w is None or not w.is_contiguous() or not w.is_cuda:
+            del _PACK_REG[key]
+            continue
+        live.append((w, ent))
+    if not live:
+        return False
+    rows, first = [], 0
+    for w, ent in live:
+        d0, d1 = w.shape[0], w.shape[1]
+        taps = w.shape[2] * w.shape[3] * w.shape[4]
+        rows.append((w.data_ptr(), ent[2].halfs.data_ptr(), ent[2].scale.data_ptr(), ent[1], d0,
+                     d1, taps, first))
+        first += d0 if ent[1] == 0 else d1
+    sig = tuple(rows)
+    if _PACK_BATCH["sig"] != sig:
+        _PACK_BATCH["table"] = torch.tensor(rows, dtype=torch.int64, device=live[0][0].device)
+        _PACK_BATCH["sig"] = sig
+        _PACK_BATCH["blocks"] = first
+    ops.pack_weight_f16x3_multi(_PACK_BATCH["table"], len(rows), _PACK_BATCH["blocks"])
+    for w, ent in live:
+        ent[3] = _pack_tag(w)
+    _PACK_BATCH["epoch"] = ops.WEIGHT_EPOCH
+    return True
+
+
 def _packed(w, mode):
     """Repacked copy of a weight. The cache lives ON the tensor object (so it dies
     with it) and is valid only for the same storage address and version counter."""
+    split = CONV_PRECISION == "f16x3" and mode in (0, 1, 2, 3)
+    if split and mode in (0, 1) and w.dim() == 5 and w.is_contiguous():
+        import weakref
+        key = (id(w), mode)
+        ent = _PACK_REG.get(key)
+        if ent is not None and ent[0]() is not w:
+            ent = None
+        if ent is not None:
+            if ent[3] == _pack_tag(w):
+                return ent[2]
+            if _PACK_BATCH["epoch"] != ops.WEIGHT_EPOCH and _repack_registered() \
+                    and ent[3] == _pack_tag(w):
+                return ent[2]
+        p = ops.pack_weight_f16x3(w.detach(), mode)
+        _PACK_REG[key] = [weakref.ref(w), mode, p, _pack_tag(w)]
+        return p
     cache = getattr(w, "_adell_packs", None)
     if cache is None:
         cache = {}
         w._adell_packs = cache
-    split = CONV_PRECISION == "f16x3" and mode in (0, 1, 2, 3)
     key = (mode, split)
     hit = cache.get(key)
     tag = (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)

@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_IDS, ConvDesc, NormActDesc, check
+from ._lib import ACT_IDS, AdellHipError, ConvDesc, NormActDesc, check
 
 
 class KernelTimer:
@@ -190,6 +190,14 @@ def pack_weight_f16x3(w, mode):
     check(_lib.lib().adell_pack_weight_f16x3(_ptr(w), _ptr(halfs), _ptr(scale), mode, d0, d1, kd,
                                              kh, kw, _stream()))
     return SplitWeight(halfs, scale)
+
+
+def pack_weight_f16x3_multi(table, entries, total_blocks):
+    """table: int64 [entries, 8] device tensor (see adell_pack_weight_f16x3_multi)."""
+    if not (table.is_cuda and table.dtype == torch.int64 and table.is_contiguous()):
+        raise AdellHipError("pack_weight_f16x3_multi: table must be a contiguous int64 CUDA tensor")
+    check(_lib.lib().adell_pack_weight_f16x3_multi(_ptr(table), int(entries), int(total_blocks),
+                                                   _stream()))
 
 
 def _splitk_workspace(d, backward, device):

@@ -104,6 +104,11 @@ int adell_conv3d_bwd_data(const adell_conv3d_desc* d, const float* dy,
 long adell_pack_weight_f16x3_bytes(int mode, int dim0, int dim1, int taps);
 int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode, int dim0,
                             int dim1, int KD, int KH, int KW, void* stream);
+/* The same for many weights in one launch: `table` is a DEVICE array of `entries` rows of 8
+ * int64 {w pointer, out pointer, wscale pointer, mode, dim0, dim1, taps, first block}, rows
+ * ordered by first block (= running sum of the GEMM-column counts: dim0 for mode 0, dim1 for
+ * mode 1); total_blocks = that sum over all rows. */
+int adell_pack_weight_f16x3_multi(const long* table, int entries, long total_blocks, void* stream);
 int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d);
 /* in_absmax / dy_absmax (optional, one zero-initialised uint32 on the device): receive
  * the bit pattern of the absmax of the kernel's input tensor(s) as a by-product;
