@@ -567,6 +567,46 @@ __global__ __launch_bounds__(1024) void adell_na_bwd_finalize_kernel(
   }
 }
 
+// The per-item case without affine-parameter gradients (every InstanceNorm of the U-Nets): one
+// block per (8 channels, item) instead of one block walking all items (15 us -> a few us, 35 times
+// per training step). Same fixed-order fp64 fold: tile lanes, then a tree over the 32 lanes.
+__global__ __launch_bounds__(256) void adell_na_bwd_finalize_item_kernel(
+    const float* __restrict__ part, int ntiles, int C, double count,
+    const float* __restrict__ gamma, float* __restrict__ c1, float* __restrict__ c2) {
+  __shared__ double sh[32][8][2];
+  const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl, n = blockIdx.y;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  if (c < C) {
+    int t = sl;
+    for (; t + 32 < ntiles; t += 64) {
+      const float2 u = *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
+      const float2 v =
+          *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t + 32) * C + c) * 2);
+      a0 += (double)u.x; b0 += (double)u.y;
+      a1 += (double)v.x; b1 += (double)v.y;
+    }
+    for (; t < ntiles; t += 32) {
+      const float2 u = *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
+      a0 += (double)u.x; b0 += (double)u.y;
+    }
+  }
+  sh[sl][cl][0] = a0 + a1;
+  sh[sl][cl][1] = b0 + b1;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double A = 0.0, B = 0.0;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      A += sh[k][cl][0];
+      B += sh[k][cl][1];
+    }
+    const double g = gamma ? (double)gamma[c] : 1.0;
+    c1[(size_t)n * C + c] = (float)(g * A / count);
+    c2[(size_t)n * C + c] = (float)(g * B / count);
+  }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs a) {
   constexpr int W = VEC ? 4 : 1;
@@ -684,9 +724,14 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<true>, grid, dim3(256), 0, st, a);
     else
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<false>, grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(adell_na_bwd_finalize_kernel, dim3(adell_cdiv(d->C, 32)), dim3(1024), 0,
-                       st, (const float*)part, (int)d->N, a.ntiles, d->C, (double)d->V,
-                       d->stats_per_item, gamma, c1, c2, dgamma, dbeta);
+    if (d->stats_per_item && !dgamma && !dbeta && d->N <= 65535)
+      hipLaunchKernelGGL(adell_na_bwd_finalize_item_kernel,
+                         dim3(adell_cdiv(d->C, 8), (unsigned)d->N), dim3(256), 0, st,
+                         (const float*)part, a.ntiles, d->C, (double)d->V, gamma, c1, c2);
+    else
+      hipLaunchKernelGGL(adell_na_bwd_finalize_kernel, dim3(adell_cdiv(d->C, 32)), dim3(1024), 0,
+                         st, (const float*)part, (int)d->N, a.ntiles, d->C, (double)d->V,
+                         d->stats_per_item, gamma, c1, c2, dgamma, dbeta);
   }
   const long nw = vec ? a.total / 4 : a.total;
   if (fast) {
