@@ -260,6 +260,7 @@ struct Conv1Args {
 __global__ __launch_bounds__(256) void adell_conv1_small_fwd_kernel(Conv1Args a, int lpr) {
   const int Cin = a.C0 + a.C1;
   const int gl = threadIdx.x % lpr, grp = threadIdx.x / lpr, ngrp = 256 / lpr;
+  const bool vec8 = a.C1 == 0 && (a.C0 & 7) == 0 && ((reinterpret_cast<uintptr_t>(a.x0) & 15) == 0);
   float wr[ADELL_C1_MAXO][8];
 #pragma unroll
   for (int o = 0; o < ADELL_C1_MAXO; ++o)
@@ -272,14 +273,28 @@ __global__ __launch_bounds__(256) void adell_conv1_small_fwd_kernel(Conv1Args a,
     const long v = vb + grp;
     const bool live = v < a.V;
     float s[ADELL_C1_MAXO] = {0.f, 0.f, 0.f, 0.f};
+    float xv[8];
+    if (vec8) {   // one source, whole 8-channel groups: two 16-byte loads per lane
+      float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0;
+      if (live && gl * 8 < Cin) {
+        const float4* p = reinterpret_cast<const float4*>(a.x0 + v * a.C0 + gl * 8);
+        f0 = p[0];
+        f1 = p[1];
+      }
+      xv[0] = f0.x; xv[1] = f0.y; xv[2] = f0.z; xv[3] = f0.w;
+      xv[4] = f1.x; xv[5] = f1.y; xv[6] = f1.z; xv[7] = f1.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = gl * 8 + e;
-      float xv = 0.f;
-      if (live && c < Cin) xv = c < a.C0 ? a.x0[v * a.C0 + c] : a.x1[v * a.C1 + (c - a.C0)];
-#pragma unroll
-      for (int o = 0; o < ADELL_C1_MAXO; ++o) s[o] = fmaf(xv, wr[o][e], s[o]);
+      for (int e = 0; e < 8; ++e) {
+        const int c = gl * 8 + e;
+        xv[e] = 0.f;
+        if (live && c < Cin) xv[e] = c < a.C0 ? a.x0[v * a.C0 + c] : a.x1[v * a.C1 + (c - a.C0)];
+      }
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int o = 0; o < ADELL_C1_MAXO; ++o) s[o] = fmaf(xv[e], wr[o][e], s[o]);
 #pragma unroll
     for (int o = 0; o < ADELL_C1_MAXO; ++o)
       for (int m = lpr >> 1; m > 0; m >>= 1) s[o] += __shfl_xor(s[o], m, 64);
@@ -291,6 +306,24 @@ __global__ __launch_bounds__(256) void adell_conv1_small_fwd_kernel(Conv1Args a,
 // dx[v][c] = sum_o dy[v][o] w[o][c]
 __global__ __launch_bounds__(256) void adell_conv1_small_bwd_data_kernel(Conv1Args a) {
   const int Cin = a.C0 + a.C1;
+  if (a.C1 == 0 && (a.C0 & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.dx0) & 15) == 0)) {
+    // one destination, whole channel quads: 16-byte stores
+    const int cq = Cin >> 2;
+    const long quads = a.V * cq;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < quads; i += (long)gridDim.x * 256L) {
+      const long v = i / cq;
+      const int c = (int)(i - v * cq) * 4;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int o = 0; o < a.Cout; ++o) {
+        const float g = a.dy[v * a.Cout + o];
+        const float4 wv = *reinterpret_cast<const float4*>(a.w + o * Cin + c);
+        s.x = fmaf(g, wv.x, s.x); s.y = fmaf(g, wv.y, s.y);
+        s.z = fmaf(g, wv.z, s.z); s.w = fmaf(g, wv.w, s.w);
+      }
+      *reinterpret_cast<float4*>(a.dx0 + v * a.C0 + c) = s;
+    }
+    return;
+  }
   const long total = a.V * Cin;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
     const long v = i / Cin;
@@ -353,6 +386,75 @@ __global__ __launch_bounds__(256) void adell_conv1_small_wgrad_kernel(Conv1Args 
       }
       __syncthreads();
     }
+  }
+}
+
+// The same partials for one source with whole channel quads: thread = (channel quad, voxel lane),
+// 16-byte loads of x, the quad after the last one carries the bias column (x := 1).
+__global__ __launch_bounds__(256) void adell_conv1_small_wgrad4_kernel(Conv1Args a, int chunk,
+                                                                       int QL) {
+  __shared__ float4 sh[256];
+  const int Cin = a.C0, cq = Cin >> 2;
+  const int VL = 256 / QL;
+  const int ql = threadIdx.x % QL, vl = threadIdx.x / QL;
+  const long v0 = (long)blockIdx.x * chunk;
+  long v1 = v0 + chunk;
+  if (v1 > a.V) v1 = a.V;
+  float* prow = a.part + (size_t)blockIdx.x * a.Cout * (Cin + 1);
+  float4 s[ADELL_C1_MAXO];
+#pragma unroll
+  for (int o = 0; o < ADELL_C1_MAXO; ++o) s[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ql <= cq) {
+    long v = v0 + vl;
+    for (; v + 3L * VL < v1; v += 4L * VL) {
+      float4 xv[4];
+      float g[4][ADELL_C1_MAXO];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long vv = v + (long)u * VL;
+        xv[u] = ql < cq ? *reinterpret_cast<const float4*>(a.x0 + vv * Cin + 4 * ql)
+                        : make_float4(1.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 0; o < ADELL_C1_MAXO; ++o) g[u][o] = o < a.Cout ? a.dy[vv * a.Cout + o] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int o = 0; o < ADELL_C1_MAXO; ++o) {
+          s[o].x = fmaf(g[u][o], xv[u].x, s[o].x);
+          s[o].y = fmaf(g[u][o], xv[u].y, s[o].y);
+          s[o].z = fmaf(g[u][o], xv[u].z, s[o].z);
+          s[o].w = fmaf(g[u][o], xv[u].w, s[o].w);
+        }
+    }
+    for (; v < v1; v += VL) {
+      const float4 xv = ql < cq ? *reinterpret_cast<const float4*>(a.x0 + v * Cin + 4 * ql)
+                                : make_float4(1.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int o = 0; o < ADELL_C1_MAXO; ++o)
+        if (o < a.Cout) {
+          const float g = a.dy[v * a.Cout + o];
+          s[o].x = fmaf(g, xv.x, s[o].x);
+          s[o].y = fmaf(g, xv.y, s[o].y);
+          s[o].z = fmaf(g, xv.z, s[o].z);
+          s[o].w = fmaf(g, xv.w, s[o].w);
+        }
+    }
+  }
+  for (int o = 0; o < a.Cout; ++o) {
+    sh[threadIdx.x] = s[o];
+    __syncthreads();
+    if (vl == 0 && ql <= cq) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < VL; ++k) {
+        const float4 u = sh[k * QL + ql];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      float* o4 = prow + o * (Cin + 1) + 4 * ql;
+      o4[0] = t.x;                       // ql == cq: the bias column (only x is meaningful)
+      if (ql < cq) { o4[1] = t.y; o4[2] = t.z; o4[3] = t.w; }
+    }
+    __syncthreads();
   }
 }
 
@@ -446,9 +548,15 @@ extern "C" int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const fl
   const int chunk = adell_conv1_chunk(a.V);
   const int nb = (int)((a.V + chunk - 1) / chunk);
   hipStream_t st = (hipStream_t)stream;
-  int CL = 4;
-  while (CL < 64 && CL < d->C0 + d->C1 + 1) CL <<= 1;
-  hipLaunchKernelGGL(adell_conv1_small_wgrad_kernel, dim3(nb), dim3(256), 0, st, a, chunk, CL);
+  if (d->C1 == 0 && d->C0 % 4 == 0 && d->C0 / 4 + 1 <= 64 && (((uintptr_t)x0) & 15) == 0) {
+    int QL = 2;
+    while (QL < d->C0 / 4 + 1) QL <<= 1;
+    hipLaunchKernelGGL(adell_conv1_small_wgrad4_kernel, dim3(nb), dim3(256), 0, st, a, chunk, QL);
+  } else {
+    int CL = 4;
+    while (CL < 64 && CL < d->C0 + d->C1 + 1) CL <<= 1;
+    hipLaunchKernelGGL(adell_conv1_small_wgrad_kernel, dim3(nb), dim3(256), 0, st, a, chunk, CL);
+  }
   const int n = d->Cout * (d->C0 + d->C1 + 1);
   hipLaunchKernelGGL(adell_conv1_small_wgrad_fold_kernel, dim3(adell_cdiv(n, 64)), dim3(1024), 0, st,
                      (const float*)workspace, nb, d->Cout, d->C0 + d->C1, dw, db);
