@@ -403,6 +403,25 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     a.VP = a.HX * a.HY * a.HZ;
     lds = (size_t)1000 * 64 + (size_t)7 * 32 * 64 + 64;
   }
+  // transposed-conv forward (1 tap, F * Cs columns with a pixel-shuffle store): one block takes a
+  // 64-voxel brick and up to 256 columns (cfg 5), so the input brick is staged once instead of
+  // once per 32 / 64-column tile
+  if (a.shuffle != 0 && a.KD == 1 && a.KH == 1 && a.KW == 1 && a.Cout >= 128 &&
+      g_conv_force_cfg < 0 && getenv("ADELL_IGEMM_NOSPEC") == nullptr) {
+    t.cfg = 5;
+    t.BM = 64;
+    t.BN = 256;
+    adell_shape_brick(64, a.Wo, a.Ho, a.Do, &t.lTX, &t.lTY, &t.lTZ);
+    a.lTX = t.lTX; a.lTY = t.lTY; a.lTZ = t.lTZ;
+    a.ntx = adell_cdiv(a.Wo, 1 << t.lTX);
+    a.nty = adell_cdiv(a.Ho, 1 << t.lTY);
+    a.ntz = adell_cdiv(a.Do, 1 << t.lTZ);
+    a.HX = 1 << t.lTX; a.HY = 1 << t.lTY; a.HZ = 1 << t.lTZ;
+    a.VP = a.HX * a.HY * a.HZ;
+    a.GKH = 1;
+    lds = (size_t)a.VP * 64 + (size_t)256 * 64 + 64;
+    if (lds < (size_t)1 * 256 * 2 * sizeof(float)) lds = (size_t)256 * 2 * sizeof(float);
+  }
   *tile = t;
   *lds_out = lds;
   return ADELL_OK;
@@ -538,6 +557,9 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
     case 0:
       rc2 = spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
                   : adell_launch_conv_f16<2, 2, 4, 1, 0>(a, e, grid, lds, st);
+      break;
+    case 5:   // transposed-conv forward: 64 voxels x 256 columns per block
+      rc2 = adell_launch_conv_f16<2, 2, 1, 4, 0>(a, e, grid, lds, st);
       break;
     case 4:   // 8x8x8 bricks, four m-tiles per wave (adell_plan_f16)
       if (!a.vecx) {

@@ -224,7 +224,8 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   // Weight slices go through a register prefetch: the slice of the next tap group is fetched
   // while the MFMAs of the current one run (a kz plane of a 3^3 kernel: 9 taps x BN ch x 4
   // slots = 4.5 (BN 32) / 9 (BN 64) x 256 slots of 16 bytes).
-  constexpr int WPF = (GT * BN * 4 + NTHR - 1) / NTHR;  // a kz plane of a 3^3 kernel
+  // (the 256-column transposed-conv instance, WN = 4, has one tap per group)
+  constexpr int WPF = ((WN == 4 ? 1 : GT) * BN * 4 + NTHR - 1) / NTHR;  // a kz plane of a 3^3 kernel
   const bool wpipe = SPEC || GKH * KW * BN * 4 <= WPF * NTHR;
   float4 wreg[WPF];
   const int ngroups = SPEC ? NGRP : KD * ngy;
