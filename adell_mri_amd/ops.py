@@ -927,9 +927,10 @@ def multi_copy(table, rows, dst):
 
 
 # ---- shifted-window (SWIN) token path -----------------------------------------------------
-def gather_nd(x, dims, axes):
+def gather_nd(x, dims, axes, out=None):
     """Flat contiguous gather of ``x`` (csrc/window.hip). ``dims``: [(size, axis, mult)] of the
-    output, outermost first; ``axes``: [(extent, stride, shift)] of the input, in elements."""
+    output, outermost first; ``axes``: [(extent, stride, shift)] of the input, in elements.
+    ``out``: optional contiguous destination of exactly prod(sizes) elements."""
     import ctypes
 
     _require_cuda(x)
@@ -937,7 +938,12 @@ def gather_nd(x, dims, axes):
     total = 1
     for d in dims:
         total *= int(d[0])
-    out = torch.empty((total,), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((total,), device=x.device, dtype=torch.float32)
+    else:
+        _require_cuda(out)
+        if out.numel() != total or not out.is_contiguous():
+            raise AdellHipError("gather_nd: out must be contiguous with prod(sizes) elements")
     IntA, LongD, LongA = ctypes.c_int * nd, ctypes.c_long * nd, ctypes.c_long * na
     check(_lib.lib().adell_gather_nd(
         _ptr(x), _ptr(out), nd, IntA(*[int(d[0]) for d in dims]), IntA(*[int(d[1]) for d in dims]),
