@@ -175,7 +175,8 @@ __global__ __launch_bounds__(1024) void adell_wgrad_small_reduce_kernel(
 
 static bool adell_wgrad_small_ok(const adell_conv3d_desc* d) {
   const int Cin = d->C0 + d->C1;
-  return Cin <= 4 && d->KD == d->KH && d->KH == d->KW && (d->KD == 1 || d->KD == 3) &&
+  return Cin <= 4 && d->KD == d->KH && d->KH == d->KW &&
+         (d->KD == 1 || d->KD == 3 || d->KD == 5 || d->KD == 7) &&
          d->SD == 1 && d->SH == 1 && d->SW == 1 && d->PD == d->PH && d->PH == d->PW;
 }
 
@@ -218,7 +219,20 @@ extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, co
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)(splits * a.coBlocks);
   const bool two = d->C0 + d->C1 <= 2;
-  if (d->KD == 3 && two)
+  // k = 5 / 7: the stems of the ResNet backbones (res_net.py:60-130; 7^3 x 2 channels at 128^3)
+  if (d->KD == 7 && two)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<7, 2>), dim3(grid), dim3(WgSmallCfg<7>::THREADS),
+                       0, st, a);
+  else if (d->KD == 7)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<7, 4>), dim3(grid), dim3(WgSmallCfg<7>::THREADS),
+                       0, st, a);
+  else if (d->KD == 5 && two)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<5, 2>), dim3(grid), dim3(WgSmallCfg<5>::THREADS),
+                       0, st, a);
+  else if (d->KD == 5)
+    hipLaunchKernelGGL((adell_wgrad_small_kernel<5, 4>), dim3(grid), dim3(WgSmallCfg<5>::THREADS),
+                       0, st, a);
+  else if (d->KD == 3 && two)
     hipLaunchKernelGGL((adell_wgrad_small_kernel<3, 2>), dim3(grid), dim3(WgSmallCfg<3>::THREADS),
                        0, st, a);
   else if (d->KD == 3)

@@ -68,6 +68,12 @@ def main():
     dt = time.perf_counter() - t0
     timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     ks = timer.summary()
+    if os.environ.get("ADELL_BENCH_LAYERS"):
+        tags = timer.by_tag()
+        tot = sum(v["ms"] for v in tags.values())
+        for (name, tag), v in sorted(tags.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            print(f"{v['ms'] / args.steps:7.3f} ms {100 * v['ms'] / tot:5.1f}% {v['tflops']:7.1f} TF "
+                  f"x{v['launches'] // args.steps:2d}  {name.replace('adell_', '')}  {tag}")
     print(json.dumps({"workload": f"U-Net + ResNet backbone (config 2b) 128^3 batch {args.batch}",
                       "params": sum(p.numel() for p in net.parameters()),
                       "depth": cfg["depth"], "strides": cfg["strides"],
