@@ -102,6 +102,7 @@ SIGNATURES = {
     "adell_interp_nearest_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
     "adell_interp_linear_fwd": (_i, [_vp, _vp] + [_i] * 8 + [_f] * 3 + [_i, _vp]),
     "adell_interp_linear_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_f] * 3 + [_i, _vp]),
+    "adell_fold_x_taps": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
     "adell_scale_bc": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     "adell_scale_bc_dscale_workspace_floats": (_l, [_i, _l, _i]),
     "adell_scale_bc_dscale": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp, _vp]),

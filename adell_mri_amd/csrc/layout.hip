@@ -528,3 +528,50 @@ extern "C" int adell_scale_bc_dscale(const float* x, const float* dy, float* ds,
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Fold the x taps of a small-Cin convolution into channels: out[n][z][y][ox][kx * Cin + ci] =
+// x[n][z][y][ox - P + kx][ci] (zero outside the row and in the slots beyond K * Cin). A
+// K_d x K_h x K conv over Cin <= 4 channels is then a K_d x K_h x 1 conv over Cp = 16 channels:
+// one 16-channel MFMA chunk carries K * Cin <= 16 useful values instead of Cin (the 7^3 stem of the
+// ResNet backbones on 2 channels: 343 k-steps of 2/16 -> 49 of 14/16).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_fold_x_taps_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ out, long rows,
+                                                                int W, int Wo, int Cin, int K,
+                                                                int P, int Cp) {
+  // rows = N * D * H input rows; one thread per (row, ox, quad of output slots)
+  const int cq = Cp >> 2;
+  const long total = rows * Wo * cq;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int q = (int)(i % cq);
+    const long v = i / cq;
+    const int ox = (int)(v % Wo);
+    const long row = v / Wo;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slot = 4 * q + j;
+      const int kx = slot / Cin, ci = slot - kx * Cin;
+      const int ix = ox - P + kx;
+      o[j] = (kx < K && ix >= 0 && ix < W) ? x[(row * W + ix) * Cin + ci] : 0.f;
+    }
+    *reinterpret_cast<float4*>(out + (v * cq + q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int adell_fold_x_taps(const float* x, float* out, int N, int D, int H, int W, int Cin,
+                                 int K, int P, int Cp, void* stream) {
+  ADELL_REQUIRE(x && out, "fold_x_taps: null pointer");
+  ADELL_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && Cin >= 1 && K >= 1 && P >= 0 && Cp % 4 == 0 &&
+                    K * Cin <= Cp && W + 2 * P - K + 1 > 0,
+                "fold_x_taps: bad arguments");
+  const int Wo = W + 2 * P - K + 1;
+  const long rows = (long)N * D * H;
+  long blocks = (rows * Wo * (Cp / 4) + 255) / 256;
+  if (blocks > 65535 * 8) blocks = 65535 * 8;
+  hipLaunchKernelGGL(adell_fold_x_taps_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, x, out, rows, W, Wo, Cin, K, P, Cp);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

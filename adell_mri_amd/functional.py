@@ -130,6 +130,27 @@ def _packed(w, mode):
     return p
 
 
+def _packed_folded(w):
+    """f16x3 pack of W'[co][kx * Cin + ci][kz][ky][0] = w[co][ci][kz][ky][kx], zero-padded to 16
+    input channels (the weight of the folded conv, see ops.fold_x_taps); cached on the tensor."""
+    cache = getattr(w, "_adell_packs", None)
+    if cache is None:
+        cache = {}
+        w._adell_packs = cache
+    tag = _pack_tag(w)
+    hit = cache.get("fold")
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    wd = w.detach()
+    co, ci, kd, kh, kw = wd.shape
+    wf = wd.permute(0, 4, 1, 2, 3).reshape(co, kw * ci, kd, kh, 1)
+    if kw * ci < 16:
+        wf = torch.cat([wf, wf.new_zeros(co, 16 - kw * ci, kd, kh, 1)], 1)
+    p = ops.pack_weight_f16x3(wf.contiguous(), 0)
+    cache["fold"] = (tag, p)
+    return p
+
+
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
@@ -142,6 +163,21 @@ class _Conv3dFn(torch.autograd.Function):
             ctx.amax = None
             ctx.save_for_backward(x0, x1, weight)
             ctx.conf = (k, stride, padding, bias is not None, False, wref)
+            if part is None:
+                part = y.new_empty(0)
+            ctx.mark_non_differentiable(part)
+            return y, part
+        if isinstance(wp, tuple) and wp[0] == "fold":
+            # Cin <= 4, Kw * Cin <= 16: the x taps ride in the 16-channel MFMA chunk (forward
+            # only: the gradients below see the original tensors and weights)
+            xf = ops.fold_x_taps(x0, k[2], padding[2])
+            y, part = ops.conv3d_fwd(xf, wp[1], bias, weight.shape[0], (k[0], k[1], 1), stride,
+                                     (padding[0], padding[1], 0), residual=residual,
+                                     want_stats=want_stats)
+            ctx.small1 = False
+            ctx.amax = None
+            ctx.save_for_backward(x0, x1, weight)
+            ctx.conf = (k, stride, padding, bias is not None, residual is not None, wref)
             if part is None:
                 part = y.new_empty(0)
             ctx.mark_non_differentiable(part)
@@ -228,6 +264,10 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
         wp = None
     elif ops.conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
         wp = "cin_small"
+    elif (CONV_PRECISION == "f16x3" and x1 is None and weight.dim() == 5 and x0.shape[1] <= 4
+          and 3 <= weight.shape[4] and weight.shape[4] * x0.shape[1] <= 16
+          and stride == (1, 1, 1) and not os.environ.get("ADELL_NO_FOLD")):
+        wp = ("fold", _packed_folded(weight))
     else:
         wp = _packed(weight, 0)
     y, part = _Conv3dFn.apply(x0, x1, weight, bias, residual, wp, conf)

@@ -840,6 +840,17 @@ def interp_linear(x, scales, backward_from=None, size=None):
     return dx
 
 
+def fold_x_taps(x, K, P, Cp=16):
+    """[N,Cin,D,H,W] -> [N,Cp,D,H,W+2P-K+1] with channel kx*Cin+ci = x[..., ox-P+kx] (zero fill)."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, Cin, D, H, W = x.shape
+    Wo = W + 2 * P - K + 1
+    out = new_act(N, Cp, D, H, Wo, x.device)
+    check(_lib.lib().adell_fold_x_taps(_ptr(x), _ptr(out), N, D, H, W, Cin, K, P, Cp, _stream()))
+    return out
+
+
 def scale_bc(x, s):
     """x [N,C,D,H,W] (NDHWC memory) times s [N,C]."""
     _require_cuda(x, s)

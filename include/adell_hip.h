@@ -366,6 +366,13 @@ int adell_interp_linear_bwd(const float* dy, float* dx, int N, int C, int Di, in
  * feature gates of the decoder (unet.py:803-810) and U-out (regularization.py:48-55). The
  * backward is the same call on dy (dx = dy * s) plus ds[n][c] = sum_v dy * x
  * (adell_scale_bc_dscale; workspace of adell_scale_bc_dscale_workspace_floats floats). */
+/* out[n][z][y][ox][kx * Cin + ci] = x[n][z][y][ox - P + kx][ci] (zeros outside the row and in the
+ * slots >= K * Cin), x [N][D][H][W][Cin], out [N][D][H][W + 2P - K + 1][Cp]: the x taps of a
+ * small-Cin convolution folded into a 16-channel chunk, so that a Kd x Kh x K conv over Cin <= 4
+ * channels runs as a Kd x Kh x 1 conv over Cp channels (first layers: unet.py:260-273,
+ * res_net.py:60-130). */
+int adell_fold_x_taps(const float* x, float* out, int N, int D, int H, int W, int Cin, int K,
+                      int P, int Cp, void* stream);
 int adell_scale_bc(const float* x, const float* s, float* y, int N, long V, int C, void* stream);
 long adell_scale_bc_dscale_workspace_floats(int N, long V, int C);
 int adell_scale_bc_dscale(const float* x, const float* dy, float* ds, int N, long V, int C,

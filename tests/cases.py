@@ -69,7 +69,7 @@ def grad_rel_err(g, k, got):
         scale = max(scale, 1e-1 * np.abs(g["grad:" + k[:-5] + ".weight"]).max())
     # the same holds for a weight whose output is scale-invariant (a 1-input-channel 1x1 conv in
     # front of an instance norm: gradient 1e-9 where its neighbours have 1e-2): nothing below
-    # 1e-4 of the largest gradient of the network is compared relative to itself
+    # 5e-4 of the largest gradient of the network is compared relative to itself
     top = max(float(np.abs(g[f]).max()) for f in g.files if f.startswith("grad:"))
-    scale = max(scale, 1e-4 * top)
+    scale = max(scale, 5e-4 * top)
     return float(np.abs(got - ref).max() / (scale + 1e-12))

@@ -43,3 +43,41 @@ def test_cin_small_fwd_stats_and_grads_match_torch(cuda, monkeypatch, n, cin, co
         assert _rel(bd.grad.cpu().double(), b.grad) < 2e-5
     if cout % 4 == 0:
         assert _rel(xd.grad.cpu().double(), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,size,k,pad", [(1, 2, 32, (12, 14, 37), 3, 1),
+                                                   (2, 2, 64, (10, 9, 21), 7, 3),
+                                                   (1, 1, 16, (6, 8, 19), 5, 2),
+                                                   (1, 4, 40, (7, 9, 11), 3, 0),
+                                                   (1, 3, 32, (9, 9, 9), (3, 3, 5), (1, 1, 2))])
+def test_folded_x_taps_forward_matches_torch_and_plain_path(cuda, monkeypatch, n, cin, cout, size,
+                                                            k, pad):
+    """Kw * Cin <= 16: the forward folds the x taps into the 16-channel MFMA chunk
+    (ops.fold_x_taps + a Kd x Kh x 1 conv); same output, statistics and gradients as the plain
+    path and as torch."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, *size, generator=g, dtype=torch.float64).requires_grad_(True)
+    kk = (k,) * 3 if isinstance(k, int) else k
+    w = (torch.randn(cout, cin, *kk, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = torch.randn(cout, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = F.conv3d(x, w, b, padding=pad)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+
+    def run():
+        xd = ops.ndhwc(x.detach().float().to(cuda)).requires_grad_(True)
+        wd = w.detach().float().to(cuda).requires_grad_(True)
+        bd = b.detach().float().to(cuda).requires_grad_(True)
+        yd = HF.conv3d(xd, wd, bd, stride=1, padding=pad, want_stats=True)
+        part = yd._adell_partials.double().sum(1).cpu()
+        yd.backward(ops.ndhwc(dy.float().to(cuda)))
+        return yd.detach().cpu().double(), part, xd.grad.cpu().double(), wd.grad.cpu().double()
+
+    yf, pf, dxf, dwf = run()
+    monkeypatch.setenv("ADELL_NO_FOLD", "1")
+    yp, pp, dxp, dwp = run()
+    assert _rel(yf, y.detach()) < 5e-6 and _rel(yf, yp) < 5e-6
+    want = torch.stack([y.detach().sum((2, 3, 4)), (y.detach() ** 2).sum((2, 3, 4))], -1)
+    assert _rel(pf, want) < 1e-5
+    assert _rel(dxf, x.grad) < 2e-5 and _rel(dwf, w.grad) < 2e-5
+    assert torch.equal(dxf, dxp) and torch.equal(dwf, dwp)   # the backward is the same code
