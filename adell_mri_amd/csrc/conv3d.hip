@@ -689,6 +689,55 @@ extern "C" int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const 
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+// Backward-data of a stride-2 conv by parity classes. dX[2i + p] (p in {0,1}^3) only receives the
+// taps t with t = p + P (mod 2) per axis, so each of the 8 classes is a stride-1 conv of dY with a
+// (1..2)^3 sub-kernel whose outputs land on a stride-2 lattice of dX (the pixel-shuffle store of
+// the transposed conv with one sub-position): exactly the useful MFMA work, where the
+// zero-insertion formulation multiplies 7 zeros out of 8. w_split[c] / wscale[c]: the class's
+// sub-kernel w[:, :, t0z::2, t0y::2, t0x::2] packed with mode 1; c = 4 pz + 2 py + px.
+// Needs even input dims, one destination (C1 = 0), k = 3.
+extern "C" int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const float* dy,
+                                              const void* const* w_split,
+                                              const float* const* wscale, float* dx,
+                                              uint32_t* dy_absmax, void* stream) {
+  int rc = adell_check_desc(d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(dy && w_split && wscale && dx, "conv_bwd_data_s2: null pointer");
+  ADELL_REQUIRE(d->C1 == 0 && d->SD == 2 && d->SH == 2 && d->SW == 2 && d->KD == 3 && d->KH == 3 &&
+                    d->KW == 3 && d->D % 2 == 0 && d->H % 2 == 0 && d->W % 2 == 0 &&
+                    d->PD <= 2 && d->PH <= 2 && d->PW <= 2,
+                "conv_bwd_data_s2: stride 2, k = 3, even input dims, one destination only");
+  for (int c = 0; c < 8; ++c) {
+    const int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+    const int p3[3] = {pz, py, px}, P3[3] = {d->PD, d->PH, d->PW};
+    int n3[3], pad3[3];
+    for (int ax = 0; ax < 3; ++ax) {
+      const int t0 = (p3[ax] + P3[ax]) & 1;
+      n3[ax] = (3 - t0 + 1) / 2;                 // taps t0, t0 + 2, ... below 3
+      const int cc = (p3[ax] + P3[ax]) / 2;      // dX[2i + p] = sum_s dY[i + cc - s] Wsub[s]
+      pad3[ax] = n3[ax] - 1 - cc;
+      ADELL_REQUIRE(pad3[ax] >= 0, "conv_bwd_data_s2: padding > 1 not supported for this class");
+    }
+    ADELL_REQUIRE(w_split[c] && wscale[c], "conv_bwd_data_s2: null class weights");
+    ConvArgs a = {};
+    a.x0 = dy;
+    a.y0 = dx + ((size_t)(pz * d->H + py) * d->W + px) * d->C0;
+    a.D = d->Do; a.H = d->Ho; a.W = d->Wo;
+    a.C0 = d->Cout; a.C1 = 0; a.Cin = d->Cout; a.Cout = d->C0;
+    a.KD = n3[0]; a.KH = n3[1]; a.KW = n3[2];
+    a.SD = a.SH = a.SW = 1;
+    a.PD = pad3[0]; a.PH = pad3[1]; a.PW = pad3[2];
+    a.UPS = a.UPSY = a.UPSZ = 1;
+    a.Do = d->D / 2; a.Ho = d->H / 2; a.Wo = d->W / 2;
+    a.ysplit = a.Cout; a.Cs = a.Cout;
+    a.shuffle = 8 | 7;                           // rows on the stride-2 lattice, sub-position 0
+    ConvF16Extra e = {(const _Float16*)w_split[c], wscale[c], c == 0 ? dy_absmax : nullptr, 0};
+    rc = adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
+    if (rc != ADELL_OK) return rc;
+  }
+  return ADELL_OK;
+}
+
 // ConvTranspose3d (kernel = stride = factors) on the f16x3 kernel. Forward: w_split = the
 // VIRTUAL 1x1x1 conv weight V[(f, co)][ci] = w[ci][co][f] packed with mode 0 (wscale has
 // F*Cout entries); backward-data: the torch weight [Cin][Cout][taps] read as a conv weight with

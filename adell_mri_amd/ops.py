@@ -385,6 +385,25 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, 
     return dx0, dx1
 
 
+def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None):
+    """Backward-data of a stride-2 k = 3 conv by parity classes; ``class_weights``: 8 SplitWeights
+    (c = 4 pz + 2 py + px) of the sub-kernels packed with mode 1."""
+    _require_cuda(dy)
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    d = make_conv_desc(N, tuple(in_size), C0, 0, Cout, 3, 2, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    dx = new_act(N, C0, *in_size, dy.device)
+    PA = ctypes.c_void_p * 8
+    wh = PA(*[_ptr(w.halfs) for w in class_weights])
+    ws = PA(*[_ptr(w.scale) for w in class_weights])
+    check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv3d_bwd_data_s2_f16x3(
+                     ctypes.byref(d), _ptr(dy), wh, ws, _ptr(dx), _ptr(amax), _stream()),
+                 _conv_tag(d, "dgrad"), _conv_bytes(d)))
+    return dx
+
+
 def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 4) + 3) // 4, device=device, dtype=torch.float32)
 

@@ -121,6 +121,14 @@ int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                 const void* w_split_bwd, const float* wscale, float* dx0,
                                 float* dx1, uint32_t* dy_absmax, void* stream);
 
+/* Backward-data of a stride-2, k = 3 convolution by parity classes: dX[2i + p], p in {0,1}^3, is a
+ * stride-1 convolution of dY with the sub-kernel w[:, :, t0z::2, t0y::2, t0x::2] (t0 = (p + P) mod 2
+ * per axis), written onto the stride-2 lattice of dX. w_split[c] / wscale[c] (c = 4 pz + 2 py + px):
+ * that sub-kernel packed with adell_pack_weight_f16x3 mode 1. Even input dims, C1 = 0. */
+int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const float* dy,
+                                   const void* const* w_split, const float* const* wscale,
+                                   float* dx, uint32_t* dy_absmax, void* stream);
+
 /* The same two calls with a caller-provided workspace (adell_conv3d_splitk_workspace bytes; 0 =
  * never needed): layers with too few output bricks to fill the chip (the 8^3 - 16^3 levels)
  * share the channel chunks of a brick out over several blocks (split-K) and fold the partial

@@ -116,3 +116,33 @@ def test_split_k_matches_single_pass(cuda, monkeypatch, n, c0, c1, cout, size, r
     monkeypatch.delenv("ADELL_NO_SPLITK")
     y_s2, _, _ = run()
     assert torch.equal(y_s, y_s2)   # fixed fold order
+
+
+@pytest.mark.parametrize("n,cin,cout,size,pad", [(1, 32, 32, (16, 24, 32), 1), (2, 16, 48, (12, 8, 20), 1),
+                                                 (1, 64, 64, (8, 8, 8), 0), (1, 32, 32, (64, 64, 64), 1)])
+def test_stride2_backward_data_by_parity_classes(cuda, monkeypatch, n, cin, cout, size, pad):
+    """dX of a stride-2 k = 3 conv computed as 8 stride-1 sub-kernel convs on the stride-2 lattice
+    (adell_conv3d_bwd_data_s2_f16x3) == the zero-insertion formulation == torch."""
+    from adell_mri_amd import functional as HF
+    monkeypatch.setenv("ADELL_S2CLASS_ALWAYS", "1")   # also below the size where it pays
+    g = torch.Generator().manual_seed(cin + size[0])
+    x = torch.randn(n, cin, *size, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05
+
+    def run():
+        xd = ops.ndhwc(x.to(cuda)).requires_grad_(True)
+        wd = w.to(cuda).requires_grad_(True)
+        y = HF.conv3d(xd, wd, None, stride=2, padding=pad)
+        gy = torch.Generator().manual_seed(1)
+        dy = torch.randn(y.shape, generator=gy).to(cuda)
+        y.backward(ops.ndhwc(dy))
+        return y.detach(), dy, xd.grad.detach()
+
+    y, dy, dx_c = run()
+    monkeypatch.setenv("ADELL_NO_S2CLASS", "1")
+    _, _, dx_z = run()
+    xr = x.double().requires_grad_(True)
+    yr = torch.nn.functional.conv3d(xr, w.double(), None, stride=2, padding=pad)
+    yr.backward(dy.cpu().double())
+    assert _rel(dx_c.cpu().double(), xr.grad) < 5e-6
+    assert _rel(dx_c, dx_z) < 5e-6
