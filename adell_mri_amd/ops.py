@@ -32,16 +32,18 @@ class KernelTimer:
         e.record()
         return e
 
-    def stop(self, name, flops, e0, tag=None, nbytes=0.0):
+    def stop(self, name, flops, e0, tag=None, nbytes=0.0, kernels=1):
+        """``kernels``: device launches of the named kernel behind this call (8 for the
+        parity-class backward-data), so that ms / launches is a per-kernel average."""
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((name, float(flops), e0, e1, tag, float(nbytes)))
+        self.records.append((name, float(flops), e0, e1, tag, float(nbytes), int(kernels)))
 
     def by_tag(self):
         """{(kernel, tag): {flops, ms, launches, tflops}} -- per-layer view (tools/)."""
         torch.cuda.synchronize()
         agg = {}
-        for name, flops, e0, e1, tag, _nb in self.records:
+        for name, flops, e0, e1, tag, _nb, _k in self.records:
             a = agg.setdefault((name, tag), [0.0, 0.0, 0])
             a[0] += flops
             a[1] += e0.elapsed_time(e1)
@@ -53,11 +55,11 @@ class KernelTimer:
         if self._agg is None:
             torch.cuda.synchronize()
             agg = {}
-            for name, flops, e0, e1, _tag, nb in self.records:
+            for name, flops, e0, e1, _tag, nb, k in self.records:
                 a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
                 a[0] += flops
                 a[1] += e0.elapsed_time(e1)
-                a[2] += 1
+                a[2] += k
                 a[3] += nb
             self._agg = {k: {"flops": v[0], "ms": v[1], "launches": v[2],
                              "tflops": v[0] / max(v[1], 1e-9) / 1e9,
@@ -78,13 +80,13 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
-def _timed(name, flops, fn, tag=None, nbytes=0.0):
+def _timed(name, flops, fn, tag=None, nbytes=0.0, kernels=1):
     t = KERNEL_TIMER
     if t is None or (t.only is not None and name not in t.only):
         return fn()
     e0 = t.start()
     rc = fn()
-    t.stop(name, flops, e0, tag() if callable(tag) else tag, nbytes)
+    t.stop(name, flops, e0, tag() if callable(tag) else tag, nbytes, kernels)
     return rc
 
 
@@ -400,7 +402,7 @@ def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None):
     check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
                  lambda: _lib.lib().adell_conv3d_bwd_data_s2_f16x3(
                      ctypes.byref(d), _ptr(dy), wh, ws, _ptr(dx), _ptr(amax), _stream()),
-                 _conv_tag(d, "dgrad"), _conv_bytes(d)))
+                 _conv_tag(d, "dgrad"), _conv_bytes(d), kernels=8))
     return dx
 
 
