@@ -746,9 +746,19 @@ def add_bcast(a, b):
 
 
 def sum_bcast(g, period_shape):
+    _require_cuda(g)
     g = g.contiguous()
     db = torch.empty(period_shape, device=g.device, dtype=torch.float32)
-    check(_lib.lib().adell_sum_bcast(_ptr(g), _ptr(db), g.numel(), db.numel(), _stream()))
+    period = db.numel()
+    rows = g.numel() // period
+    if rows >= 64 and period < 2 ** 31:
+        # column sums of the [rows][period] view: chunked partials + fixed-order fold
+        nbytes = _lib.lib().adell_bias_grad_workspace(rows, period)
+        ws = _workspace(nbytes, g.device)
+        check(_lib.lib().adell_bias_grad(_ptr(g), rows, period, _ptr(db), _ptr(ws),
+                                         ws.numel() * 4, _stream()))
+        return db
+    check(_lib.lib().adell_sum_bcast(_ptr(g), _ptr(db), g.numel(), period, _stream()))
     return db
 
 

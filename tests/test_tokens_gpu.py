@@ -41,6 +41,24 @@ def test_layernorm_fwd_bwd_matches_torch_cpu(cuda, rows, C):
     assert _rel(bd.grad.cpu(), b.grad) < 5e-5
 
 
+@pytest.mark.parametrize("lead,bshape", [((2,), (216, 48)), ((1500,), (27, 36)), ((3, 70), (5,)),
+                                         ((1,), (64, 8))])
+def test_add_bcast_fwd_bwd_matches_torch_cpu(cuda, lead, bshape):
+    """Positional-embedding add: few rows (one thread per output) and many rows (chunked
+    column sums) take different kernels for the embedding gradient."""
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(*lead, *bshape, generator=g).requires_grad_(True)
+    b = torch.randn(*bshape, generator=g).requires_grad_(True)
+    dy = torch.randn(*lead, *bshape, generator=g)
+    (a + b).backward(dy)
+    ad, bd = (t.detach().to(cuda).requires_grad_(True) for t in (a, b))
+    out = HF.add_bcast(ad, bd)
+    out.backward(dy.to(cuda))
+    assert torch.equal(out.detach().cpu(), (a + b).detach())
+    assert _rel(ad.grad.cpu(), a.grad) == 0.0
+    assert _rel(bd.grad.cpu(), b.grad) < 1e-5
+
+
 @pytest.mark.parametrize("rows,cin,cout", [(216, 512, 1536), (64, 64, 512), (10, 30, 7)])
 def test_linear_as_conv_fwd_bwd(cuda, rows, cin, cout):
     g = torch.Generator().manual_seed(1)
