@@ -361,6 +361,13 @@ static int adell_launch_conv_f16(const ConvArgs& a, const ConvF16Extra& e, dim3 
 // LDS, i.e. stride 2) the small-brick configuration of the same channel width.
 static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   ConvTile t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, g_conv_force_cfg);
+  // kernel == stride > 1 (transposed-conv backward-data): every staged voxel feeds one tap, so
+  // the launch is bound by staging, not MFMA. 64-voxel bricks (32 KB of LDS, 4 blocks per CU)
+  // overlap the staging of one block with the MFMAs of another (measured, 2 x 64^3 x 32 ->
+  // 32: 0.47 -> 0.31 ms against the 256-voxel brick at one block per CU)
+  if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.KD == a.SD && a.KH == a.SH && a.KW == a.SW &&
+      a.KD * a.KH * a.KW > 1 && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1)
+    t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 2);
   size_t lds = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     a.lTX = t.lTX; a.lTY = t.lTY; a.lTZ = t.lTZ;

@@ -173,6 +173,103 @@ __global__ __launch_bounds__(1024) void adell_wgrad_small_reduce_kernel(
   else if (db) db[co] = (float)s;
 }
 
+// Cin <= 2 and Cout <= 2, k = 3 (Conv3d(2 -> 2) of the input block): the tile kernel above keeps
+// 2 of its 16 output-channel lanes busy. Here a thread owns whole voxels and all 27 * CIN * COUT
+// products in registers; one shuffle + LDS fold per block at the end. Partial rows have the
+// layout the reduce kernel above reads (one split per block, 16 channel rows per split).
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void adell_wgrad_tiny_kernel(WgSmallArgs a, long vox_per_block) {
+  __shared__ float sred[4][27 * CIN * COUT + COUT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[27][CIN][COUT];
+  float sb[COUT];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) acc[t][c][o] = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) sb[o] = 0.f;
+  const long total = (long)a.N * a.Do * a.Ho * a.Wo;
+  const long v0 = (long)blockIdx.x * vox_per_block;
+  long v1 = v0 + vox_per_block;
+  if (v1 > total) v1 = total;
+  for (long v = v0 + tid; v < v1; v += 256) {
+    long t = v;
+    const int x = (int)(t % a.Wo); t /= a.Wo;
+    const int y = (int)(t % a.Ho); t /= a.Ho;
+    const int z = (int)(t % a.Do);
+    const int n = (int)(t / a.Do);
+    float g[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) g[o] = a.dy[v * COUT + o];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) sb[o] += g[o];
+    const float* xb = a.x0 + (size_t)n * a.D * a.H * a.W * CIN;
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iz = z - a.P + kz, iy = y - a.P + ky, ix = x - a.P + kx;
+          const bool ok = (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+          const float* p = xb + ((size_t)(iz * a.H + iy) * a.W + ix) * CIN;
+#pragma unroll
+          for (int c = 0; c < CIN; ++c) {
+            const float xv = ok ? p[c] : 0.f;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o)
+              acc[(kz * 3 + ky) * 3 + kx][c][o] = fmaf(xv, g[o], acc[(kz * 3 + ky) * 3 + kx][c][o]);
+          }
+        }
+  }
+  // wave fold (fixed butterfly order), then the four waves through LDS
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int c = 0; c < CIN; ++c)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        float s = acc[t][c][o];
+        for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
+        if (lane == 0) sred[wave][(t * CIN + c) * COUT + o] = s;
+      }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    float s = sb[o];
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh, 64);
+    if (lane == 0) sred[wave][27 * CIN * COUT + o] = s;
+  }
+  __syncthreads();
+  constexpr int NV = 27 * CIN * COUT + COUT;
+  if (tid < NV) {
+    const float s = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+    int co, col;
+    if (tid < 27 * CIN * COUT) {
+      const int o = tid % COUT, c = (tid / COUT) % CIN, t = tid / (COUT * CIN);
+      co = o;
+      col = c * 27 + t;
+    } else {
+      co = tid - 27 * CIN * COUT;
+      col = 4 * 27;
+    }
+    a.part[((size_t)blockIdx.x * 16 + co) * (4 * 27 + 1) + col] = s;
+  }
+}
+
+template <int CIN, int COUT>
+static void adell_wgrad_tiny_launch(const WgSmallArgs& a, int blocks, long vpb, hipStream_t st) {
+  hipLaunchKernelGGL((adell_wgrad_tiny_kernel<CIN, COUT>), dim3((unsigned)blocks), dim3(256), 0, st,
+                     a, vpb);
+}
+
+static bool adell_wgrad_tiny_ok(const adell_conv3d_desc* d) {
+  return d->C1 == 0 && d->C0 <= 2 && d->Cout <= 2 && d->KD == 3 && d->KH == 3 && d->KW == 3 &&
+         getenv("ADELL_NO_WGRAD_TINY") == nullptr;
+}
+
 static bool adell_wgrad_small_ok(const adell_conv3d_desc* d) {
   const int Cin = d->C0 + d->C1;
   return Cin <= 4 && d->KD == d->KH && d->KH == d->KW &&
@@ -217,6 +314,22 @@ extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, co
   adell_wgrad_small_plan(d, &a, &splits);
   a.x0 = x0; a.x1 = x1; a.dy = dy; a.part = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
+  if (adell_wgrad_tiny_ok(d)) {
+    const long total = (long)d->N * d->Do * d->Ho * d->Wo;
+    int nb = splits < 1024 ? splits : 1024;          // the workspace holds `splits` partial rows
+    long vpb = ((total + nb - 1) / nb + 255) / 256 * 256;
+    nb = (int)((total + vpb - 1) / vpb);
+    if (d->C0 == 2 && d->Cout == 2) adell_wgrad_tiny_launch<2, 2>(a, nb, vpb, st);
+    else if (d->C0 == 2) adell_wgrad_tiny_launch<2, 1>(a, nb, vpb, st);
+    else if (d->Cout == 2) adell_wgrad_tiny_launch<1, 2>(a, nb, vpb, st);
+    else adell_wgrad_tiny_launch<1, 1>(a, nb, vpb, st);
+    const int Cin = d->C0;
+    const long blocks = ((long)d->Cout * (Cin * 27 + 1) + 63) / 64;
+    hipLaunchKernelGGL(adell_wgrad_small_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st,
+                       (const float*)workspace, nb, 16, d->Cout, Cin, 27, dw, db);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   const unsigned grid = (unsigned)(splits * a.coBlocks);
   const bool two = d->C0 + d->C1 <= 2;
   // k = 5 / 7: the stems of the ResNet backbones (res_net.py:60-130; 7^3 x 2 channels at 128^3)
@@ -612,9 +725,12 @@ __global__ __launch_bounds__(256) void adell_cin_small_fwd_kernel(CinSmallArgs a
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nb = blockIdx.z, co0 = blockIdx.y * COT;
   const int nco = (a.Cout - co0) < COT ? (a.Cout - co0) : COT;
-  for (int i = tid; i < NTAP * CIN * COT; i += 256) {
-    const int co = i % COT, ci = (i / COT) % CIN, tap = i / (COT * CIN);
-    sw[i] = co < nco ? a.w[((size_t)(co0 + co) * CIN + ci) * NTAP + tap] : 0.f;
+  // only the 4 * lpv columns the lanes read are staged (Cout = 2: 216 values, not 3456)
+  const int cw = 4 * lpv, lcw = __ffs(cw) - 1;
+  for (int i = tid; i < NTAP * CIN * cw; i += 256) {
+    const int co = i & (cw - 1), r = i >> lcw;           // r = tap * CIN + ci
+    const int ci = r % CIN, tap = r / CIN;
+    sw[r * COT + co] = co < nco ? a.w[((size_t)(co0 + co) * CIN + ci) * NTAP + tap] : 0.f;
   }
   const int vpb = 256 / lpv;                       // voxels per block
   const int quad = tid & (lpv - 1);

@@ -17,7 +17,12 @@ def _rel(a, b):
                                                          (2, 2, 32, (8, 12, 19), 3, 1, True),
                                                          (1, 1, 16, (1, 33, 30), 1, (0, 1, 1), True),
                                                          (1, 3, 40, (7, 9, 11), 3, 0, False),
-                                                         (1, 4, 8, (6, 10, 34), 3, 1, True)])
+                                                         (1, 4, 8, (6, 10, 34), 3, 1, True),
+                                                         # Cin, Cout <= 2: voxel-per-thread dW kernel
+                                                         (2, 1, 2, (5, 9, 70), 3, 1, True),
+                                                         (1, 2, 1, (6, 7, 9), 3, 0, True),
+                                                         (3, 1, 1, (4, 5, 6), 3, 1, False),
+                                                         (2, 2, 2, (16, 24, 40), 3, 1, True)])
 def test_cin_small_fwd_stats_and_grads_match_torch(cuda, monkeypatch, n, cin, cout, size, kd, pad,
                                                    bias):
     monkeypatch.setenv("ADELL_CIN_SMALL_ALL", "1")   # every width, not only Cout <= 4

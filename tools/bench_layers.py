@@ -18,7 +18,8 @@ net = bench.build_module(dev, size)
 net.train()
 opt = net.configure_optimizers()["optimizer"]
 runner = StepRunner(net, opt, GradSync(opt))
-batch = bench.synthetic_batch(1, size, dev, 42)
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+batch = bench.synthetic_batch(nb, size, dev, 42)
 for _ in range(2):
     runner.train_step(batch)
 torch.cuda.synchronize()
