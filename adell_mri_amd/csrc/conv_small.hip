@@ -14,6 +14,8 @@
 // ---------------------------------------------------------------------------
 // small-Cin weight gradient
 // ---------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct WgSmallArgs {
   const float* x0;
   const float* x1;
@@ -50,11 +52,11 @@ __global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_wgrad_sma
   const bool active = kk < K * K;
   const int kz = kk / K, ky = kk % K;
   const int Cin = a.C0 + a.C1;
-  float acc[CIN][K];
+  f32x2 acc2[CIN / 2][K];                       // (ci, ci + 1) pairs
 #pragma unroll
-  for (int c = 0; c < CIN; ++c)
+  for (int c = 0; c < CIN / 2; ++c)
 #pragma unroll
-    for (int q = 0; q < K; ++q) acc[c][q] = 0.f;
+    for (int q = 0; q < K; ++q) acc2[c][q] = f32x2{0.f, 0.f};
   float sb = 0.f;
   const long first = (long)split * a.itemsPerSplit;
   long last = first + a.itemsPerSplit;
@@ -119,12 +121,11 @@ __global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_wgrad_sma
           for (int kx = 0; kx < K; ++kx) {
             const int j = jj - kx;
             if (j >= 0 && j < Cf::WT) {
-              acc[0][kx] = fmaf(g[j], xv.x, acc[0][kx]);
-              acc[1][kx] = fmaf(g[j], xv.y, acc[1][kx]);
-              if (CIN > 2) {
-                acc[2][kx] = fmaf(g[j], xv.z, acc[2][kx]);
-                acc[3][kx] = fmaf(g[j], xv.w, acc[3][kx]);
-              }
+              // channel pairs as packed fp32 FMAs (v_pk_fma_f32: two lanes' worth per issue;
+              // the kernel is bound by vector-ALU issue)
+              const f32x2 gg = {g[j], g[j]};
+              acc2[0][kx] = __builtin_elementwise_fma(gg, f32x2{xv.x, xv.y}, acc2[0][kx]);
+              if (CIN > 2) acc2[1][kx] = __builtin_elementwise_fma(gg, f32x2{xv.z, xv.w}, acc2[1][kx]);
             }
           }
         }
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(((16 * K * K + 63) / 64) * 64) void adell_wgrad_sma
 #pragma unroll
     for (int c = 0; c < CIN; ++c)
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) dst[c * Cf::K3 + (kz * K + ky) * K + kx] = acc[c][kx];
+      for (int kx = 0; kx < K; ++kx)
+        dst[c * Cf::K3 + (kz * K + ky) * K + kx] = (c & 1) ? acc2[c / 2][kx].y : acc2[c / 2][kx].x;
     if (kk == 0) dst[4 * Cf::K3] = sb;
   }
 }
@@ -754,19 +756,29 @@ __global__ __launch_bounds__(256) void adell_cin_small_fwd_kernel(CinSmallArgs a
         for (int c = 0; c < CIN; ++c) in[t][c] = ok ? p[c] : 0.f;
       }
   __syncthreads();
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // output channel pairs as packed fp32 FMAs; a layer of <= 2 channels skips the second pair
+  f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+  if (nco > 2) {
 #pragma unroll
-  for (int t = 0; t < NTAP; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      const float4 wv = *reinterpret_cast<const float4*>(sw + (t * CIN + c) * COT + 4 * quad);
-      acc.x += in[t][c] * wv.x;
-      acc.y += in[t][c] * wv.y;
-      acc.z += in[t][c] * wv.z;
-      acc.w += in[t][c] * wv.w;
-    }
+      for (int c = 0; c < CIN; ++c) {
+        const float4 wv = *reinterpret_cast<const float4*>(sw + (t * CIN + c) * COT + 4 * quad);
+        const f32x2 iv = {in[t][c], in[t][c]};
+        acc01 = __builtin_elementwise_fma(iv, f32x2{wv.x, wv.y}, acc01);
+        acc23 = __builtin_elementwise_fma(iv, f32x2{wv.z, wv.w}, acc23);
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+      for (int c = 0; c < CIN; ++c) {
+        const f32x2 wv = *reinterpret_cast<const f32x2*>(sw + (t * CIN + c) * COT + 4 * quad);
+        acc01 = __builtin_elementwise_fma(f32x2{in[t][c], in[t][c]}, wv, acc01);
+      }
+  }
   const int c = 4 * quad;                              // first channel of this lane inside the tile
-  float val[4] = {acc.x, acc.y, acc.z, acc.w};
+  float val[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const bool ok = vok && c + j < nco;

@@ -118,7 +118,9 @@ def main():
                     help="volumes per GPU per step (u-net-3d-resnet.yaml:16 ships batch_size: 2; "
                          "SURVEY.md 8(d): B per GPU in {1, 2})")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--cpu-size", type=int, default=128,
+                    help="edge of the one volume the CPU oracle is timed on (128: the workload's own "
+                         "volume size, ~10-15 s on 16 threads)")
     args = ap.parse_args()
 
     from adell_mri_amd import functional as HF
@@ -205,8 +207,9 @@ def main():
         scale = args.cpu_size ** 3 / float(shape[0] * shape[1] * shape[2])
         out["cpu_baseline"] = {
             "value": scale / t, "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"1 training step of the stock-torch CPU oracle on one 2x{args.cpu_size}^3 "
-                      f"volume ({t:.2f} s), scaled by voxel count to {shape_str}"}
+            "sample": f"1 training step (fwd + loss + bwd + SGD) of the stock-torch CPU oracle on one "
+                      f"2-channel {args.cpu_size}^3 volume ({t:.2f} s)"
+                      + ("" if scale == 1.0 else f", scaled by voxel count to {shape_str}")}
     print(json.dumps(out))
 
 
