@@ -107,6 +107,10 @@ SIGNATURES = {
     "adell_scale_bc": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     "adell_scale_bc_dscale_workspace_floats": (_l, [_i, _l, _i]),
     "adell_scale_bc_dscale": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp, _vp]),
+    "adell_cse_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp]),
+    "adell_cse_apply_bwd_workspace_floats": (_l, [_i, _l, _i]),
+    "adell_cse_apply_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _l, _i, _vp, _vp]),
+    "adell_bcast_nc": (_i, [_vp, _vp, _i, _l, _i, _f, _vp]),
     "adell_maxpool3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "adell_maxpool3d_bwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "adell_dwconv3d_fwd": (_i, [_i] * 8 + [_vp] * 5),

@@ -530,6 +530,145 @@ extern "C" int adell_scale_bc_dscale(const float* x, const float* dy, float* ds,
 }
 
 // ---------------------------------------------------------------------------
+// Concurrent squeeze-and-excite gate of the multi-branch U-Net (self_attention.py:21-150,
+// unet.py:1186-1207): y = acc + x * (s[n][v] + c[n][ch]) * inv[n] on NDHWC tensors. s is the
+// spatial gate (sigmoid of a C -> 1 pointwise conv), c the channel gate (sigmoid of the MLP of the
+// per-channel means), inv[n] = 1 / (sum of the branch weights of item n), acc the running sum over
+// the branches merged so far (or null). One pass instead of two scales, an add and a division.
+// Backward: dx = dy * (s + c) * inv, ds[n][v] = inv * sum_ch dy * x, dc[n][ch] = inv * sum_v dy * x
+// (per-tile partials + the fixed-order fold of adell_scale_bc); d acc = dy.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_cse_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ c,
+    const float* __restrict__ inv, const float* __restrict__ acc, float* __restrict__ y, long V,
+    int C) {
+  const int nb = blockIdx.y;
+  const size_t base = (size_t)nb * V * C;
+  const float* sb = s + (size_t)nb * V;
+  const float* cb = c + (size_t)nb * C;
+  const float iv = inv ? inv[nb] : 1.f;
+  const long VC = V * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < VC; i += (long)gridDim.x * 256L) {
+    const long v = i / C;
+    const int ch = (int)(i - v * C);
+    const float g = (sb[v] + cb[ch]) * iv;
+    y[base + i] = (acc ? acc[base + i] : 0.f) + x[base + i] * g;
+  }
+}
+
+// block = 4 waves; a wave walks voxels of the tile, LPV lanes per voxel (64 / LPV voxels at a
+// time), lane l of a voxel owns channels l, l + LPV, ... (C <= 8 * LPV)
+__global__ __launch_bounds__(256) void adell_cse_apply_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ s,
+    const float* __restrict__ c, const float* __restrict__ inv, float* __restrict__ dx,
+    float* __restrict__ ds, float* __restrict__ part, long V, int C, int vpt, int lpv) {
+  __shared__ float sred[256][8];
+  const int nb = blockIdx.y, tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cl = lane & (lpv - 1), sub = lane / lpv, vpw = 64 / lpv;
+  const long v0 = (long)tile * vpt;
+  const long v1 = (v0 + vpt) < V ? (v0 + vpt) : V;
+  const size_t base = (size_t)nb * V * C;
+  const float iv = inv ? inv[nb] : 1.f;
+  float cg[8], col[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ch = cl + lpv * k;
+    cg[k] = ch < C ? c[(size_t)nb * C + ch] : 0.f;
+    col[k] = 0.f;
+  }
+  for (long vb = v0 + (long)wave * vpw; vb < v1; vb += 4L * vpw) {
+    const long v = vb + sub;
+    const bool live = v < v1;
+    const float sv = live ? s[(size_t)nb * V + v] : 0.f;
+    float row = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ch = cl + lpv * k;
+      if (live && ch < C) {
+        const size_t i = base + (size_t)v * C + ch;
+        const float g = dy[i], xv = x[i];
+        dx[i] = g * (sv + cg[k]) * iv;
+        const float p = g * xv;
+        col[k] += p;
+        row += p;
+      }
+    }
+    for (int o = lpv >> 1; o > 0; o >>= 1) row += __shfl_xor(row, o, 64);
+    if (live && cl == 0) ds[(size_t)nb * V + v] = row * iv;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sred[tid][k] = col[k];
+  __syncthreads();
+  // column sums over the 4 waves x (64 / lpv) voxel slots that share a channel (fixed order)
+  for (int ch = tid; ch < C; ch += 256) {
+    const int l = ch & (lpv - 1), k = ch / lpv;
+    float acc = 0.f;
+    for (int w = 0; w < 4; ++w)
+      for (int sb = 0; sb < vpw; ++sb) acc += sred[w * 64 + sb * lpv + l][k];
+    part[((size_t)nb * gridDim.x + tile) * C + ch] = acc * iv;
+  }
+}
+
+extern "C" int adell_cse_apply(const float* x, const float* s, const float* c, const float* inv,
+                               const float* acc, float* y, int N, long V, int C, void* stream) {
+  ADELL_REQUIRE(x && s && c && y && N > 0 && V > 0 && C > 0 && N <= 65535,
+                "cse_apply: bad arguments");
+  long blocks = (V * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(adell_cse_apply_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0,
+                     (hipStream_t)stream, x, s, c, inv, acc, y, V, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" long adell_cse_apply_bwd_workspace_floats(int N, long V, int C) {
+  return adell_scale_bc_dscale_workspace_floats(N, V, C);
+}
+
+extern "C" int adell_cse_apply_bwd(const float* x, const float* dy, const float* s, const float* c,
+                                   const float* inv, float* dx, float* ds, float* dc, int N, long V,
+                                   int C, float* workspace, void* stream) {
+  ADELL_REQUIRE(x && dy && s && c && dx && ds && dc && workspace && N > 0 && V > 0 && C > 0 &&
+                    N <= 65535,
+                "cse_apply_bwd: bad arguments");
+  ADELL_REQUIRE(C <= 512, "cse_apply_bwd: at most 512 channels");
+  int lpv = 16;
+  while (lpv < 64 && lpv < C) lpv <<= 1;
+  const int tiles = adell_scale_bc_tiles(V, C);
+  const int vpt = (int)((V + tiles - 1) / tiles);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_cse_apply_bwd_kernel, dim3((unsigned)tiles, (unsigned)N), dim3(256), 0,
+                     st, x, dy, s, c, inv, dx, ds, workspace, V, C, vpt, lpv);
+  hipLaunchKernelGGL(adell_scale_bc_fold_kernel, dim3((unsigned)adell_cdiv(C, 256), (unsigned)N),
+                     dim3(256), 0, st, (const float*)workspace, dc, tiles, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// out[n][v][ch] = g[n][ch] * scale (the gradient of a per-channel spatial mean, scale = 1 / V)
+__global__ __launch_bounds__(256) void adell_bcast_nc_kernel(const float* __restrict__ g,
+                                                             float* __restrict__ out, long VC,
+                                                             int C, float scale) {
+  const int nb = blockIdx.y;
+  const float* gb = g + (size_t)nb * C;
+  float* ob = out + (size_t)nb * VC;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < VC; i += (long)gridDim.x * 256L)
+    ob[i] = gb[i % C] * scale;
+}
+
+extern "C" int adell_bcast_nc(const float* g, float* out, int N, long V, int C, float scale,
+                              void* stream) {
+  ADELL_REQUIRE(g && out && N > 0 && V > 0 && C > 0 && N <= 65535, "bcast_nc: bad arguments");
+  long blocks = (V * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(adell_bcast_nc_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256), 0,
+                     (hipStream_t)stream, g, out, V * C, C, scale);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
 // Fold the x taps of a small-Cin convolution into channels: out[n][z][y][ox][kx * Cin + ci] =
 // x[n][z][y][ox - P + kx][ci] (zero outside the row and in the slots beyond K * Cin). A
 // K_d x K_h x K conv over Cin <= 4 channels is then a K_d x K_h x 1 conv over Cp = 16 channels:

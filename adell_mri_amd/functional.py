@@ -842,6 +842,48 @@ def scale_per_item_channel(x, s):
     raise ValueError(f"scale_per_item_channel: [N, C, ...] with <= 3 spatial dims, got {tuple(x.shape)}")
 
 
+class _ChannelMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        mean, _ = ops.instance_stats(x)
+        return mean
+
+    @staticmethod
+    def backward(ctx, g):
+        V = int(np.prod(ctx.shape[2:]))
+        return ops.bcast_nc(g, ctx.shape, 1.0 / V)
+
+
+def channel_mean(x):
+    """[N, C, D, H, W] -> [N, C]: mean over the voxels (torch.flatten(X, 2).mean(-1))."""
+    return _ChannelMeanFn.apply(x)
+
+
+class _CseApplyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, c, inv, acc):
+        ctx.save_for_backward(x, s, c, inv)
+        return ops.cse_apply(x, s, c, inv, acc)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s, c, inv = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dx = ds = dc = None
+        if need[0] or need[1] or need[2]:
+            dx, ds, dc = ops.cse_apply_bwd(x, dy, s, c, inv)
+        return (dx if need[0] else None, ds if need[1] else None, dc if need[2] else None, None,
+                dy if need[4] else None)
+
+
+def cse_apply(x, s, c, inv=None, acc=None):
+    """acc + x * (s + c) * inv: the concurrent squeeze-and-excite gate (spatial gate s [N,1,D,H,W],
+    channel gate c [N,C]) with the branch sum and the division by the summed branch weights of
+    BrUNet.forward (unet.py:1186-1207) folded in. inv [N] carries no gradient."""
+    return _CseApplyFn.apply(x, s, c, inv, acc)
+
+
 class _MaxPool3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, padding):

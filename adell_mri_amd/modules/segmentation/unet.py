@@ -246,7 +246,11 @@ class UNet(torch.nn.Module):
             raise NotImplementedError(f"link_type={self.link_type!r} is outside the HIP path")
 
     def init_encoder(self):
-        self.encoding_operations = torch.nn.ModuleList([])
+        self.encoding_operations = self._build_encoder()
+
+    def _build_encoder(self):
+        """One encoder tree (unet.py:531-586; BrUNet builds one per input branch, :999-1041)."""
+        encoding_operations = torch.nn.ModuleList([])
         previous_d = self.in_channels
         nd = self.spatial_dimensions
         k = None
@@ -260,13 +264,14 @@ class UNet(torch.nn.Module):
                 self.adn_fn(d))
             op_downsample = torch.nn.Sequential(
                 self.conv_op_enc(d, d, kernel_size=k, stride=s, padding=p), self.adn_fn(d))
-            self.encoding_operations.append(torch.nn.ModuleList([op, op_downsample]))
+            encoding_operations.append(torch.nn.ModuleList([op, op_downsample]))
             previous_d = d
         op = torch.nn.Sequential(
             self.conv_op_enc(self.depth[-2], self.depth[-1], kernel_size=k, stride=1,
                              padding=self.padding),
             self.adn_fn(self.depth[-1]))
-        self.encoding_operations.append(torch.nn.ModuleList([op, torch.nn.Identity()]))
+        encoding_operations.append(torch.nn.ModuleList([op, torch.nn.Identity()]))
+        return encoding_operations
 
     def init_encoder_backbone(self):
         """Every downsampling op becomes MaxPool(kernel=s, stride=s, padding=s//2)
@@ -368,7 +373,14 @@ class UNet(torch.nn.Module):
             return None, None, bottleneck
         elif self.encoder_only is True:
             return bottleneck
+        return self._decode(encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
+                            return_features, return_logits)
 
+    def _decode(self, encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
+                return_features, return_logits):
+        """Decoder, head, bottleneck classifier and deep supervision (unet.py:790-843; the same
+        code closes BrUNet.forward, :1209-1253)."""
+        curr = bottleneck
         deep_outputs = []
         for i in range(len(self.decoding_operations)):
             op = self.decoding_operations[i]
@@ -407,3 +419,169 @@ class UNet(torch.nn.Module):
                 deep_outputs[i] = self._final(self.deep_supervision_ops[i], deep_outputs[i], False)
             return curr, bn_out, deep_outputs
         return curr, bn_out
+
+
+class BrUNet(UNet):
+    """Multi-branch U-Net (mirror of adell_mri/modules/segmentation/unet.py:846-1253): one encoder
+    per input, the branches merged at every skip level and at the bottleneck by concurrent
+    squeeze-and-excite gates, summed and divided by the summed branch weights; decoder, head,
+    conditioning and deep supervision as in ``UNet``. Same constructor arguments, attribute names
+    and ``state_dict`` keys (``encoders.B.L.{0,1}...``, ``merge_ops.L.B.{spatial,channel}...``).
+
+    On the HIP path the merge of one level is ``n_input_branches`` passes of one kernel
+    (``acc + x * (s + c) / w_sum``, functional.cse_apply) instead of, per branch, two gated copies,
+    an add, a division and the running sum."""
+
+    def __init__(self, spatial_dimensions: int = 2, n_input_branches: int = 1,
+                 encoders: List[torch.nn.ModuleList] = None, conv_type: str = "regular",
+                 link_type: str = "identity", upscale_type: str = "upsample",
+                 interpolation: str = "bilinear", norm_type: str = "batch",
+                 dropout_type: str = "dropout", padding: str = "same", dropout_param: float = 0.1,
+                 activation_fn: torch.nn.Module = torch.nn.PReLU, in_channels: int = 1,
+                 n_classes: int = 2, depth: list = [16, 32, 64], kernel_sizes: list = [3, 3, 3],
+                 strides: list = [2, 2, 2], bottleneck_classification: bool = False,
+                 skip_conditioning: int = None, feature_conditioning: int = None,
+                 feature_conditioning_params: Dict[str, torch.Tensor] = None,
+                 deep_supervision: bool = False, encoder_only: bool = False):
+        super().__init__(parent_class=True)
+        self.spatial_dimensions = spatial_dimensions
+        self.n_input_branches = n_input_branches
+        self.encoders = encoders
+        self.conv_type = conv_type
+        self.link_type = link_type
+        self.upscale_type = upscale_type
+        self.interpolation = interpolation
+        self.norm_type = norm_type
+        self.dropout_type = dropout_type
+        self.padding = padding
+        self.dropout_param = dropout_param
+        self.activation_fn = activation_fn
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self.depth = depth
+        self.kernel_sizes = kernel_sizes
+        self.strides = strides
+        self.bottleneck_classification = bottleneck_classification
+        self.skip_conditioning = skip_conditioning
+        self.feature_conditioning = feature_conditioning
+        self.feature_conditioning_params = feature_conditioning_params
+        self.deep_supervision = deep_supervision
+        self.encoder_only = encoder_only
+
+        self.get_norm_op()
+        self.get_drop_op()
+        self.get_conv_op()
+        if self.encoders is None:
+            self.init_encoders()
+        else:
+            self.init_backbone_encoders()
+        self.init_merge_ops()
+
+        if self.encoder_only is not True:
+            self.init_upscale_ops()
+            self.init_link_ops()
+            self.init_decoder()
+            self.init_final_layer()
+            if self.bottleneck_classification is True:
+                self.init_bottleneck_classifier()
+            if self.feature_conditioning is not None:
+                self.init_feature_conditioning_operations()
+
+    def init_encoders(self):
+        self.encoders = torch.nn.ModuleList(
+            [self._build_encoder() for _ in range(self.n_input_branches)])
+
+    def init_backbone_encoders(self):
+        """Backbone encoders: max pooling (kernel k, stride 2, padding k // 2) between levels
+        (unet.py:1043-1062)."""
+        assert len(self.encoders) == self.n_input_branches, \
+            "n_input_branches and len(self.encoders) must be the same"
+        pool = MaxPool3d if self.spatial_dimensions == 3 else MaxPool2d
+        for i in range(self.n_input_branches):
+            for j in range(len(self.encoders[i])):
+                self.encoders[i][j][1] = pool(self.kernel_sizes[j], 2, self.kernel_sizes[j] // 2)
+            self.encoders[i][-1][1] = torch.nn.Identity()
+
+    def init_merge_ops(self):
+        from ..layers.self_attention import (ConcurrentSqueezeAndExcite2d,
+                                             ConcurrentSqueezeAndExcite3d)
+        cse = (ConcurrentSqueezeAndExcite3d if self.spatial_dimensions == 3
+               else ConcurrentSqueezeAndExcite2d)
+        D = [self.depth[-1]] if self.encoder_only is True else self.depth
+        self.merge_ops = torch.nn.ModuleList([
+            torch.nn.ModuleList([cse(d) for _ in range(self.n_input_branches)]) for d in D])
+
+    @staticmethod
+    def fix_input(X: List[List[torch.Tensor]]):
+        """Lists of per-item tensors with ``None`` for a missing input -> stacked batches (zeros
+        where missing) and the 0 / 1 branch weights (unet.py:1094-1111)."""
+        shapes = []
+        for items in X:
+            found = {tuple(x.shape) for x in items if x is not None}
+            assert len(found) == 1, "all tensors must have the same shape"
+            shapes.append(found.pop())
+        weights = [torch.ones(len(X[0])) for _ in X]
+        batches = []
+        for i, items in enumerate(X):
+            like = next(x for x in items if x is not None)
+            row = []
+            for j, x in enumerate(items):
+                if x is None:
+                    x = torch.zeros(shapes[i], dtype=like.dtype, device=like.device)
+                    weights[i][j] = 0.0
+                row.append(x)
+            batches.append(torch.stack(row, 0))
+        return batches, weights
+
+    @staticmethod
+    def _weighted(t, w):
+        """t * w[n] (per batch item) on the per-(item, channel) scale kernel."""
+        if w is None:
+            return t
+        return HF.scale_per_item_channel(t, w[:, None].expand(t.shape[0], t.shape[1]).contiguous())
+
+    def forward(self, X: List[torch.Tensor], X_weights: List[torch.Tensor] = None,
+                X_skip_layer: torch.Tensor = None, X_feature_conditioning: torch.Tensor = None,
+                return_features=False, return_bottleneck=False, return_logits=False):
+        if not all(x.is_cuda for x in X):
+            raise AdellHipError("adell_mri_amd.BrUNet runs on MI355X only (no CPU fallback)")
+        dev, B = X[0].device, X[0].shape[0]
+        if X_weights is not None:
+            assert len(X) == len(X_weights), "X and X_weights should have identical length"
+            assert all(x.shape[0] == xw.shape[0] for x, xw in zip(X, X_weights)), \
+                "The elements of X and X_weights should have identical batch sizes"
+            X_weights = [xw.to(dev, torch.float32) for xw in X_weights]
+            inv = 1.0 / sum(X_weights)                      # [B]: tiny host-launched divide
+        else:   # the reference multiplies by ones and divides by the branch count
+            inv = torch.full((B,), 1.0 / len(X), device=dev)
+        if X_skip_layer is not None and len(X_skip_layer.shape) < len(X[0].shape):
+            X_skip_layer = X_skip_layer.unsqueeze(1)
+        if X_feature_conditioning is not None:
+            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
+
+        pre_merge = [[] for _ in self.encoders]
+        bottleneck_pre = []
+        for i in range(self.n_input_branches):
+            curr = X[i]
+            w = None if X_weights is None else X_weights[i]
+            for op, op_ds in self.encoders[i]:
+                curr = op(curr)
+                pre_merge[i].append(self._weighted(curr, w))
+                curr = op_ds(curr)
+            bottleneck_pre.append(self._weighted(curr, w))
+
+        def merge(ops_, tensors):
+            acc = None
+            for j in range(self.n_input_branches):
+                acc = ops_[j](tensors[j], inv, acc)
+            return acc
+
+        bottleneck = merge(self.merge_ops[-1], bottleneck_pre)
+        if self.encoder_only is True:
+            return bottleneck
+        if return_bottleneck is True:
+            return None, None, bottleneck
+        encoding_out = [merge(self.merge_ops[i], tensors)
+                        for i, tensors in enumerate(zip(*pre_merge))]
+        return self._decode(encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
+                            return_features, return_logits)

@@ -905,6 +905,52 @@ def scale_bc_dscale(x, dy):
     return ds
 
 
+def cse_apply(x, s, c, inv=None, acc=None):
+    """y = acc + x * (s[n, v] + c[n, ch]) * inv[n]; x/acc [N,C,D,H,W] (NDHWC memory), s [N,1,D,H,W],
+    c [N,C], inv [N] or None, acc or None."""
+    _require_cuda(x, s, c, inv, acc)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    V = x.numel() // (N * C)
+    s, c = s.contiguous(), c.contiguous()
+    if s.numel() != N * V or c.numel() != N * C:
+        raise AdellHipError(f"cse_apply: gates {tuple(s.shape)}, {tuple(c.shape)} do not fit "
+                            f"x {tuple(x.shape)}")
+    acc = None if acc is None else ndhwc(acc)
+    inv = None if inv is None else inv.contiguous()
+    y = new_act(N, C, *x.shape[2:], x.device)
+    check(_lib.lib().adell_cse_apply(_ptr(x), _ptr(s), _ptr(c), _ptr(inv), _ptr(acc), _ptr(y), N, V,
+                                     C, _stream()))
+    return y
+
+
+def cse_apply_bwd(x, dy, s, c, inv=None):
+    """(dx, ds [N,1,D,H,W], dc [N,C]) of cse_apply."""
+    _require_cuda(x, dy, s, c, inv)
+    x, dy = ndhwc(x), ndhwc(dy)
+    N, C = x.shape[:2]
+    V = x.numel() // (N * C)
+    s, c = s.contiguous(), c.contiguous()
+    inv = None if inv is None else inv.contiguous()
+    ws = _workspace(4 * _lib.lib().adell_cse_apply_bwd_workspace_floats(N, V, C), x.device)
+    dx = new_act(N, C, *x.shape[2:], x.device)
+    ds = torch.empty((N, 1, *x.shape[2:]), device=x.device, dtype=torch.float32)
+    dc = torch.empty((N, C), device=x.device, dtype=torch.float32)
+    check(_lib.lib().adell_cse_apply_bwd(_ptr(x), _ptr(dy), _ptr(s), _ptr(c), _ptr(inv), _ptr(dx),
+                                         _ptr(ds), _ptr(dc), N, V, C, _ptr(ws), _stream()))
+    return dx, ds, dc
+
+
+def bcast_nc(g, shape, scale=1.0):
+    """out[n, c, ...] = g[n, c] * scale, out of logical shape [N, C, D, H, W] (NDHWC memory)."""
+    _require_cuda(g)
+    N, C = shape[:2]
+    V = int(math.prod(shape[2:]))
+    out = new_act(N, C, *shape[2:], g.device)
+    check(_lib.lib().adell_bcast_nc(_ptr(g.contiguous()), _ptr(out), N, V, C, float(scale), _stream()))
+    return out
+
+
 def maxpool3d_fwd(x, kernel, stride, padding):
     _require_cuda(x)
     x = ndhwc(x)

@@ -386,6 +386,22 @@ long adell_scale_bc_dscale_workspace_floats(int N, long V, int C);
 int adell_scale_bc_dscale(const float* x, const float* dy, float* ds, int N, long V, int C,
                           float* workspace, void* stream);
 
+/* Concurrent squeeze-and-excite gate used where the multi-branch U-Net merges its encoders
+ * (reference adell_mri/modules/layers/self_attention.py:21-150 ConcurrentSqueezeAndExcite{2,3}d,
+ * called at adell_mri/modules/segmentation/unet.py:1186-1207): y = acc + x * (s[n][v] + c[n][ch]) *
+ * inv[n]. x, acc, y: [N][V][C] (NDHWC); s: [N][V] spatial gate; c: [N][C] channel gate; inv: [N] or
+ * null (1); acc null = 0. Backward: dx, ds [N][V], dc [N][C] (C <= 512; workspace of
+ * adell_cse_apply_bwd_workspace_floats floats). */
+int adell_cse_apply(const float* x, const float* s, const float* c, const float* inv,
+                    const float* acc, float* y, int N, long V, int C, void* stream);
+long adell_cse_apply_bwd_workspace_floats(int N, long V, int C);
+int adell_cse_apply_bwd(const float* x, const float* dy, const float* s, const float* c,
+                        const float* inv, float* dx, float* ds, float* dc, int N, long V, int C,
+                        float* workspace, void* stream);
+/* out[n][v][ch] = g[n][ch] * scale: gradient of the per-channel spatial mean the channel gate is
+ * computed from (self_attention.py:95-96, torch.flatten(X, 2).mean(-1)). */
+int adell_bcast_nc(const float* g, float* out, int N, long V, int C, float scale, void* stream);
+
 /* torch.nn.MaxPool3d (ceil_mode False, dilation 1, -inf padding): unet.py:335,368,
  * 595-603, res_net.py:180,209. Geometry in an adell_conv3d_desc (C0 = channels, C1 and
  * Cout ignored); argmax [N][Do][Ho][Wo][C] holds the winner's (z*H+y)*W+x. */

@@ -37,7 +37,7 @@ from adell_mri.modules.layers.adn_fn import get_adn_fn  # noqa: E402
 from adell_mri.modules.layers.res_blocks import ResidualBlock3d  # noqa: E402
 from adell_mri.modules.segmentation.losses import (  # noqa: E402
     binary_focal_loss, binary_generalized_dice_loss)
-from adell_mri.modules.segmentation.unet import UNet  # noqa: E402
+from adell_mri.modules.segmentation.unet import BrUNet, UNet  # noqa: E402
 from adell_mri.modules.segmentation.unetr import SWINUNet, UNETR  # noqa: E402
 from adell_mri.modules.segmentation.unetpp import UNetPlusPlus  # noqa: E402
 from adell_mri.modules.layers.linear_blocks import MultiHeadSelfAttention  # noqa: E402
@@ -285,6 +285,67 @@ def gen_unet(name, kw, shape, dist):
     print(name, "params", sum(p.numel() for p in net.parameters()), "loss", float(loss))
 
 
+BRUNET_CASES = {
+    # multi-branch U-Net (unet.py:846-1253): two encoders, concurrent squeeze-and-excite merges.
+    # (constructor kwargs, per-branch input shape, missing[(branch, item), ...])
+    "brunet3d_two_branch": (dict(spatial_dimensions=3, n_input_branches=2, depth=[8, 16, 32],
+                                 upscale_type="transpose", padding=1, strides=[2, 2, 2],
+                                 kernel_sizes=[3, 3, 3], conv_type="regular",
+                                 link_type="identity", norm_type="instance",
+                                 activation_fn="swish", dropout_param=0.0, in_channels=1),
+                            (2, 1, 16, 24, 16), []),
+    # 2-D, conv links, inputs missing for some items (fix_input zero-fills them and the branch
+    # weights drop them from the merge, unet.py:1094-1111, 1160-1207)
+    "brunet2d_missing_inputs": (dict(spatial_dimensions=2, n_input_branches=2, depth=[8, 16, 32],
+                                     upscale_type="transpose", padding=1, strides=[2, 2, 2],
+                                     kernel_sizes=[3, 3, 3], conv_type="regular",
+                                     link_type="conv", norm_type="instance",
+                                     activation_fn="swish", dropout_param=0.0, in_channels=2),
+                                (3, 2, 32, 40), [(0, 2), (1, 1)]),
+}
+
+
+def gen_brunet(name, kw, shape, missing):
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(4321)
+    nb = kw["n_input_branches"]
+    items = [[torch.rand(shape[1:], generator=g) for _ in range(shape[0])] for _ in range(nb)]
+    for b, i in missing:
+        items[b][i] = None
+    y = (torch.rand((shape[0], 1, *shape[2:]), generator=g) > 0.9).float()
+    kw = dict(kw)
+    kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+    net = BrUNet(**kw)
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    net = net.eval()
+    if missing:
+        xs, ws = BrUNet.fix_input(items)
+    else:
+        xs, ws = [torch.stack(it, 0) for it in items], None
+    out = {"y": y.numpy()}
+    for b in range(nb):
+        out[f"x{b}"] = xs[b].numpy()
+        if ws is not None:
+            out[f"w{b}"] = ws[b].numpy()
+    out["logits"] = net(xs, ws, return_logits=True)[0].detach().numpy()
+    out["bottleneck"] = net(xs, ws, return_bottleneck=True)[2].detach().numpy()
+    prob = net(xs, ws)[0]
+    out["prob"] = prob.detach().numpy()
+    d = binary_generalized_dice_loss(prob, y, smooth=1e-5, eps=1e-6)
+    f = binary_focal_loss(prob, y, gamma=1.0, eps=1e-6)
+    loss = torch.stack([d.mean(), f.mean()]).mean()
+    out["loss"] = loss.detach().numpy()
+    net.zero_grad()
+    loss.backward()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            out["grad:" + k] = p.grad.numpy().copy()
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    out["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "params", sum(p.numel() for p in net.parameters()), "loss", float(loss))
+
+
 def gen_blocks():
     g = torch.Generator().manual_seed(7)
     out = {}
@@ -409,6 +470,10 @@ if __name__ == "__main__":
         for name, (kw, shape, dist) in UNET2D_CASES.items():
             gen_unet(name, kw, shape, dist)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "brunet":
+        for name, (kw, shape, missing) in BRUNET_CASES.items():
+            gen_brunet(name, kw, shape, missing)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         for name, (kw, shape, dist) in SWIN_CASES.items():
             gen_unet(name, kw, shape, dist)
@@ -416,5 +481,7 @@ if __name__ == "__main__":
     for name, (kw, shape, dist) in {**UNET_CASES, **UNET2D_CASES, **UNETR_CASES, **UNETPP_CASES,
                                     **BACKBONE_CASES, **SWIN_CASES}.items():
         gen_unet(name, kw, shape, dist)
+    for name, (kw, shape, missing) in BRUNET_CASES.items():
+        gen_brunet(name, kw, shape, missing)
     gen_blocks()
     gen_ssl()

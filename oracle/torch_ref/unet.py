@@ -74,6 +74,11 @@ class UNetOracle:
 
     # -- forward -----------------------------------------------------------
     def forward(self, x, return_logits=True):
+        enc, cur = self.encode("encoding_operations", x)
+        return self.decode(enc, cur, return_logits)
+
+    def encode(self, prefix, x):
+        """One encoder tree (unet.py:543-586): the per-level outputs and the bottleneck."""
         c = self.cfg
         depth, strides, ks = c["depth"], c["strides"], c["kernel_sizes"]
         pad = c.get("padding", "same")
@@ -82,13 +87,21 @@ class UNetOracle:
         cur = x
         for i in range(L):
             k = _t(ks[min(i, L - 2)] if i == L - 1 else ks[i])
-            key = f"encoding_operations.{i}"
+            key = f"{prefix}.{i}"
             p_ = [kk // 2 for kk in k] if pad == "same" else pad
             cur = self.adn(self.conv_block(key + ".0.0", cur, 1, p_))
             enc.append(cur)
             if i < L - 1:
                 cur = self.adn(self.conv_block(key + ".1.0", cur, _t(strides[i]),
                                                [kk // 2 for kk in k]))
+        return enc, cur
+
+    def decode(self, enc, cur, return_logits=True):
+        """Links, upscaling, decoder and head (unet.py:790-843)."""
+        c = self.cfg
+        depth, strides, ks = c["depth"], c["strides"], c["kernel_sizes"]
+        pad = c.get("padding", "same")
+        L = len(depth)
         for i in range(L - 1):
             skip = enc[-i - 2]
             lt = c.get("link_type", "identity")

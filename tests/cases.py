@@ -73,3 +73,21 @@ def grad_rel_err(g, k, got):
     top = max(float(np.abs(g[f]).max()) for f in g.files if f.startswith("grad:"))
     scale = max(scale, 5e-4 * top)
     return float(np.abs(got - ref).max() / (scale + 1e-12))
+
+
+# multi-branch U-Net fixtures (oracle/make_golden.py BRUNET_CASES): constructor kwargs with the
+# activation by name, per-branch input shape
+BRUNET_CASES = {
+    "brunet3d_two_branch": (dict(spatial_dimensions=3, n_input_branches=2, depth=[8, 16, 32],
+                                 upscale_type="transpose", padding=1, strides=[2, 2, 2],
+                                 kernel_sizes=[3, 3, 3], conv_type="regular",
+                                 link_type="identity", norm_type="instance",
+                                 activation_fn="swish", dropout_param=0.0, in_channels=1),
+                            (2, 1, 16, 24, 16)),
+    "brunet2d_missing_inputs": (dict(spatial_dimensions=2, n_input_branches=2, depth=[8, 16, 32],
+                                     upscale_type="transpose", padding=1, strides=[2, 2, 2],
+                                     kernel_sizes=[3, 3, 3], conv_type="regular",
+                                     link_type="conv", norm_type="instance",
+                                     activation_fn="swish", dropout_param=0.0, in_channels=2),
+                                (3, 2, 32, 40)),
+}

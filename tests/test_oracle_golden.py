@@ -95,3 +95,26 @@ def test_c_oracle_residual_block_matches_reference():
     h = cops.conv3d(h, w("op.2.weight", (8, 8, 3, 3, 3)), w("op.2.bias", (8,)), 1, 1)
     out = cops.norm_act(h + x, True, 1e-5, "swish")
     np.testing.assert_allclose(out, g["res_y"], rtol=1e-4, atol=1e-5)
+
+
+def test_brunet_oracle_matches_reference():
+    """Multi-branch U-Net restatement (oracle/torch_ref/brunet.py) against the reference's
+    logits, merged bottleneck, loss and every gradient (fixture brunet3d_two_branch)."""
+    from cases import BRUNET_CASES
+    from oracle.torch_ref.brunet import BrUNetOracle
+    g = load("brunet3d_two_branch")
+    kw = dict(BRUNET_CASES["brunet3d_two_branch"][0], n_classes=2)
+    sd = {str(k): torch.from_numpy(tensor_for(str(k), g["grad:" + str(k)].shape))
+          for k in g["param_keys"]}
+    net = BrUNetOracle(sd, oracle_cfg(kw)).requires_grad_(True)
+    xs = [torch.from_numpy(g["x0"]), torch.from_numpy(g["x1"])]
+    _, bottleneck = net.merged(xs)
+    np.testing.assert_allclose(bottleneck.detach().numpy(), g["bottleneck"], rtol=1e-5, atol=1e-5)
+    logits = net.forward(xs, return_logits=True)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-5, atol=1e-5)
+    loss = compound_loss(torch.sigmoid(logits), torch.from_numpy(g["y"]))
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    loss.backward()
+    for k, p in net.sd.items():
+        ref = g["grad:" + k]
+        assert np.abs(p.grad.numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, k
