@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from ... import functional as HF
 from ...optim import FusedAdam, FusedAdamW, FusedSGD
 from ..learning_rate import CosineAnnealingWithWarmupLR
-from .unet import UNet
+from .unet import BrUNet, UNet
 
 try:  # pragma: no cover - lightning is not installed in the build image
     import lightning.pytorch as pl
@@ -169,3 +169,80 @@ class UNetPL(UNet, UNetBasePL):
         self.loss_fn = loss_fn
         self.picai_eval = picai_eval
         self.loss_fn_class = torch.nn.BCEWithLogitsLoss()
+
+
+class BrUNetPL(BrUNet, UNetBasePL):
+    """Multi-branch U-Net training wrapper (pl.py:1324-1560): a batch carries one tensor per
+    ``image_keys`` entry plus ``<key>_weight`` [B] branch weights; deep-supervision targets are
+    resized with nearest-neighbour sampling (pl.py:1437-1445)."""
+
+    def __init__(self, image_keys: str = ["image"], label_key: str = "label",
+                 skip_conditioning_key: str = None, feature_conditioning_key: str = None,
+                 optimizer_str: str = "sgd", optimizer_eps: float = 1e-8,
+                 learning_rate: float = 0.001, lr_encoder: float = None,
+                 start_decay: float = 1.0, warmup_steps: int = 0, batch_size: int = 4,
+                 n_epochs: int = 100, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None,
+                 loss_fn: Callable = F.binary_cross_entropy, picai_eval: bool = False,
+                 *args, **kwargs) -> torch.nn.Module:
+        super().__init__(*args, **kwargs)
+        self.image_keys = image_keys
+        self.label_key = label_key
+        self.skip_conditioning_key = skip_conditioning_key
+        self.feature_conditioning_key = feature_conditioning_key
+        self.optimizer_str = optimizer_str
+        self.optimizer_eps = optimizer_eps
+        self.learning_rate = learning_rate
+        self.lr_encoder = lr_encoder
+        self.start_decay = start_decay
+        self.warmup_steps = warmup_steps
+        self.batch_size = batch_size
+        self.n_epochs = n_epochs
+        self.weight_decay = weight_decay
+        self.training_dataloader_call = training_dataloader_call
+        self.loss_fn = loss_fn
+        self.picai_eval = picai_eval
+        self.loss_fn_class = torch.nn.BCEWithLogitsLoss()
+        self.all_pred = []
+        self.all_true = []
+        self.bn_mult = 0.1
+
+    def step(self, x, x_weights, y, y_class, x_cond, x_fc):
+        y = torch.round(y)
+        output = self.forward(x, x_weights, X_skip_layer=x_cond, X_feature_conditioning=x_fc)
+        if self.deep_supervision is False:
+            prediction, pred_class = output
+            deep_outputs = None
+        else:
+            prediction, pred_class, deep_outputs = output
+        loss = self.calculate_loss(prediction, y)
+        if self.deep_supervision is True:
+            t = len(deep_outputs)
+            additional = torch.zeros_like(loss)
+            y5 = y if y.dim() == 5 else y.unsqueeze(2)
+            for i, o in enumerate(deep_outputs):
+                S = list(o.shape[-self.spatial_dimensions:])
+                y_small = HF.interpolate_nearest(y5, S if y.dim() == 5 else [1] + S)
+                y_small = y_small if y.dim() == 5 else y_small.squeeze(2)
+                additional = additional + self.calculate_loss(o, y_small).mean() / (2 ** (t - i)) / (t + 1)
+            loss = loss + additional
+        class_loss = None
+        if self.bottleneck_classification is True:
+            class_loss = self.loss_fn_class(pred_class, y_class.type_as(pred_class)).mean()
+        return prediction, pred_class, loss, class_loss
+
+    def unpack_batch(self, batch):
+        x, y = [batch[k] for k in self.image_keys], batch[self.label_key]
+        x_weights = [batch[k + "_weight"] for k in self.image_keys]
+        x_cond = batch[self.skip_conditioning_key] if self.skip_conditioning_key is not None else None
+        y_class = y.flatten(start_dim=1).max(1).values if self.bottleneck_classification else None
+        x_fc = batch[self.feature_conditioning_key] if self.feature_conditioning_key is not None else None
+        return x, x_weights, y, x_cond, x_fc, y_class
+
+    def training_step(self, batch, batch_idx):
+        x, x_weights, y, x_cond, x_fc, y_class = self.unpack_batch(batch)
+        pred_final, pred_class, loss, class_loss = self.step(x, x_weights, y, y_class, x_cond, x_fc)
+        if _Base is not torch.nn.Module:
+            self.log_loss("train_loss", loss, batch_size=y.shape[0])
+        self.train_batch_size = y.shape[0]
+        return loss.mean() if class_loss is None else loss.mean() + class_loss

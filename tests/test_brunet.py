@@ -127,3 +127,45 @@ def test_channel_mean_fwd_bwd_matches_torch(cuda):
     assert float((md.detach().cpu().double() - m.detach()).abs().max()) < 1e-6
     md.backward(dm.float().to(cuda))
     assert float((xd.grad.cpu().double() - x.grad).abs().max()) < 1e-7
+
+
+@pytest.mark.gpu
+def test_brunetpl_training_step_matches_oracle_sgd_step(cuda):
+    """One BrUNetPL step (forward with branch weights, dice + focal loss, backward, fused
+    SGD-Nesterov) against the CPU oracle stepped by torch.optim.SGD on the same weights."""
+    from adell_mri_amd.modules.segmentation.losses import (CompoundLoss, binary_focal_loss,
+                                                           binary_generalized_dice_loss)
+    from adell_mri_amd.modules.segmentation.pl import BrUNetPL
+    from adell_mri_amd.trainer import StepRunner
+    from cases import oracle_cfg
+    from oracle.torch_ref.brunet import BrUNetOracle
+    name = "brunet3d_two_branch"
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    kw = dict(BRUNET_CASES[name][0])
+    loss_fn = CompoundLoss([(binary_generalized_dice_loss, {"smooth": 1e-5, "eps": 1e-6}),
+                            (binary_focal_loss, {"gamma": 1.0, "eps": 1e-6})])
+    net = BrUNetPL(image_keys=["t2", "adc"], label_key="mask", loss_fn=loss_fn, learning_rate=5e-4,
+                   weight_decay=5e-3, **dict(kw, activation_fn=activation_factory["swish"]))
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    w = [torch.tensor([1.0, 0.5]), torch.tensor([0.25, 1.0])]
+    batch = {"t2": torch.from_numpy(g["x0"]), "adc": torch.from_numpy(g["x1"]),
+             "t2_weight": w[0], "adc_weight": w[1], "mask": torch.from_numpy(g["y"])}
+    # CPU side: oracle on the same state dict, torch SGD-Nesterov (pl.py:563-569)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype == torch.float32}
+    oracle = BrUNetOracle(sd, oracle_cfg(dict(kw, n_classes=2))).requires_grad_(True)   # own copies
+    params = [oracle.sd[k] for k, _ in net.named_parameters()]
+    opt_ref = torch.optim.SGD(params, lr=5e-4, momentum=0.99, weight_decay=5e-3, nesterov=True)
+    prob = torch.sigmoid(oracle.forward([batch["t2"], batch["adc"]], w))
+    loss_ref = compound_loss(prob, batch["mask"])
+    loss_ref.backward()
+    opt_ref.step()
+    # MI355X side
+    net = net.to(cuda).eval()   # eval(): dropout_param is 0, instance norm has no running stats
+    opt = net.configure_optimizers()["optimizer"]
+    loss = StepRunner(net, opt).train_step({k: v.to(cuda) for k, v in batch.items()})
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4)
+    for (k, p), r in zip(net.named_parameters(), params):
+        step_ref = r.detach() - sd[k]                 # what the reference step changed
+        step = p.detach().cpu() - sd[k]
+        scale = max(step_ref.abs().max().item(), 1e-9)
+        assert (step - step_ref).abs().max().item() <= 5e-3 * scale + 1e-8, k
