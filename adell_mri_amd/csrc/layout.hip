@@ -479,14 +479,23 @@ __global__ __launch_bounds__(256) void adell_scale_bc_dscale_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void adell_scale_bc_fold_kernel(const float* __restrict__ part,
-                                                                  float* __restrict__ ds, int tiles,
-                                                                  int C) {
+// block = 64 channels x 16 lanes, each lane a fixed share of the tiles (fp64, fixed order)
+__global__ __launch_bounds__(1024) void adell_scale_bc_fold_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ ds, int tiles,
+                                                                   int C) {
+  __shared__ double sh[16][64];
   const int nb = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double acc = 0.0;
-  for (int t = 0; t < tiles; ++t) acc += (double)part[((size_t)nb * tiles + t) * C + c];
+  if (c < C)
+    for (int t = vl; t < tiles; t += 16) acc += (double)part[((size_t)nb * tiles + t) * C + c];
+  sh[vl][cl] = acc;
+  __syncthreads();
+  if (vl != 0 || c >= C) return;
+  acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc += sh[k][cl];
   ds[(size_t)nb * C + c] = (float)acc;
 }
 
@@ -523,8 +532,8 @@ extern "C" int adell_scale_bc_dscale(const float* x, const float* dy, float* ds,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adell_scale_bc_dscale_kernel, dim3((unsigned)tiles, (unsigned)N), dim3(256), 0,
                      st, x, dy, workspace, V, C, vpt);
-  hipLaunchKernelGGL(adell_scale_bc_fold_kernel, dim3((unsigned)adell_cdiv(C, 256), (unsigned)N),
-                     dim3(256), 0, st, (const float*)workspace, ds, tiles, C);
+  hipLaunchKernelGGL(adell_scale_bc_fold_kernel, dim3((unsigned)adell_cdiv(C, 64), (unsigned)N),
+                     dim3(1024), 0, st, (const float*)workspace, ds, tiles, C);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
@@ -640,8 +649,8 @@ extern "C" int adell_cse_apply_bwd(const float* x, const float* dy, const float*
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adell_cse_apply_bwd_kernel, dim3((unsigned)tiles, (unsigned)N), dim3(256), 0,
                      st, x, dy, s, c, inv, dx, ds, workspace, V, C, vpt, lpv);
-  hipLaunchKernelGGL(adell_scale_bc_fold_kernel, dim3((unsigned)adell_cdiv(C, 256), (unsigned)N),
-                     dim3(256), 0, st, (const float*)workspace, dc, tiles, C);
+  hipLaunchKernelGGL(adell_scale_bc_fold_kernel, dim3((unsigned)adell_cdiv(C, 64), (unsigned)N),
+                     dim3(1024), 0, st, (const float*)workspace, dc, tiles, C);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
