@@ -118,7 +118,14 @@ def _triple(v):
     return v
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw handle (the private fast path
+    when this torch build has it: ~0.3 us instead of ~10 us per launch)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
