@@ -118,7 +118,8 @@ def _triple(v):
     return v
 
 
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_stream = (None if os.environ.get("ADELL_TORCH_STREAM_API")
+               else getattr(torch._C, "_cuda_getCurrentRawStream", None))
 
 
 def _stream():
