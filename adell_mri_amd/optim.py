@@ -8,6 +8,7 @@ exchange (``parallel.GradSync``) is an all-reduce of that same buffer.
 configured by the reference (adell_mri/modules/segmentation/pl.py:563-569);
 ``FusedAdamW`` follows ``torch.optim.AdamW`` (self_supervised/pl.py:245-250).
 """
+import numpy as np
 import torch
 
 from . import ops
@@ -64,7 +65,7 @@ class FlatParameters:
         host, dev, ev = ring[self._ring_pos]
         self._ring_pos = (self._ring_pos + 1) % len(ring)
         ev.synchronize()
-        host[:n] = torch.tensor(rows, dtype=torch.int64)
+        host[:n] = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64))
         dev[:n].copy_(host[:n], non_blocking=True)
         ev.record()
         ops.multi_copy(dev, n, self.grad)
@@ -73,7 +74,7 @@ class FlatParameters:
         """Copy every parameter gradient that is not already a view of the flat buffer into its
         slot (one multi-copy launch), then point ``p.grad`` at the slots."""
         base = self.grad.data_ptr()
-        rows, keep = [], []
+        todo, keep = [], []
         for p, o in zip(self.params, self.offsets):
             g = p.grad
             if g is None or g.data_ptr() == base + 4 * o:
@@ -82,10 +83,15 @@ class FlatParameters:
                 raise ValueError("FlatParameters.collect: gradients must be fp32 on the GPU")
             g = g.contiguous()
             keep.append(g)
-            ptr, n = g.data_ptr(), g.numel()
-            for s in range(0, n, self.CHUNK):
-                rows.append((ptr + 4 * s, o + s, min(self.CHUNK, n - s)))
-        if rows:
+            todo.append((g.data_ptr(), o, g.numel()))
+        if todo:
+            # one row per CHUNK-element piece of every gradient, built without a Python loop
+            ptr, off, num = np.array(todo, dtype=np.int64).T
+            k = (num + self.CHUNK - 1) // self.CHUNK
+            idx = np.repeat(np.arange(len(k)), k)
+            start = (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k)) * self.CHUNK
+            rows = np.stack([ptr[idx] + 4 * start, off[idx] + start,
+                             np.minimum(self.CHUNK, num[idx] - start)], 1)
             self._upload_and_copy(rows)
         for p, o in zip(self.params, self.offsets):
             if p.grad is not None:
