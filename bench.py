@@ -131,7 +131,9 @@ def main():
     rank, world, local_rank = init_distributed()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local_rank)
+    # ADELL_SINGLE_GPU_REHEARSAL=1 (with ADELL_DIST_BACKEND=gloo): all ranks on device 0, to run the
+    # multi-rank code path on a one-GPU box; never set by the driver
+    device = torch.device("cuda", 0 if os.environ.get("ADELL_SINGLE_GPU_REHEARSAL") else local_rank)
     torch.cuda.set_device(device)
 
     shape = _shape(args.size) if args.shape is None else tuple(int(v) for v in args.shape.split(","))
