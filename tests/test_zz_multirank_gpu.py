@@ -1,0 +1,37 @@
+"""The N > 1 code path of bench.py on the GPU box: two ranks launched exactly as the driver
+launches them (torch.distributed.run, one process per rank), sharing the one card and exchanging
+gradients over gloo (RCCL needs one GPU per rank; `ADELL_DIST_BACKEND` / `ADELL_SINGLE_GPU_REHEARSAL`
+exist for this rehearsal only). Checks the contract fields of the single JSON line rank 0 prints."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_prints_one_contract_line(cuda):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ADELL_DIST_BACKEND="gloo", ADELL_SINGLE_GPU_REHEARSAL="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = ["timeout", "-k", "10", "240", sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "1", "--size", "32"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["per_gpu_batch"] == 1
+    assert "cpu_baseline" not in d                      # rank 0 at N = 1 only
+    # whole-job throughput: both ranks' volumes over the slowest rank's time
+    assert abs(d["value"] - 2 * 1 * 2 / (2 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["frac"] > 0 and d["final_loss"] == d["final_loss"]
