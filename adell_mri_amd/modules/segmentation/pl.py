@@ -19,6 +19,8 @@ from ... import functional as HF
 from ...optim import FusedAdam, FusedAdamW, FusedSGD
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .unet import BrUNet, UNet
+from .unetpp import UNetPlusPlus
+from .unetr import SWINUNet, UNETR
 
 try:  # pragma: no cover - lightning is not installed in the build image
     import lightning.pytorch as pl
@@ -246,3 +248,73 @@ class BrUNetPL(BrUNet, UNetBasePL):
             self.log_loss("train_loss", loss, batch_size=y.shape[0])
         self.train_batch_size = y.shape[0]
         return loss.mean() if class_loss is None else loss.mean() + class_loss
+
+
+def _training_attributes(module, hp: dict):
+    """Store the optimisation hyper-parameters the reference's wrappers keep as attributes
+    (pl.py:829-853 and its copies at :918-944, :1180-1205) on ``module``."""
+    for name in ("image_key", "label_key", "skip_conditioning_key", "feature_conditioning_key",
+                 "optimizer_str", "optimizer_eps", "learning_rate", "lr_encoder", "start_decay",
+                 "warmup_steps", "batch_size", "n_epochs", "weight_decay",
+                 "training_dataloader_call", "loss_fn", "picai_eval"):
+        setattr(module, name, hp[name])
+    module.loss_fn_class = torch.nn.BCEWithLogitsLoss()
+    module.all_pred, module.all_true = [], []   # the reference's AUC / AP accumulators
+    module.bn_mult = 0.1
+
+
+class UNETRPL(UNETR, UNetBasePL):
+    """UNETR training wrapper (pl.py:766-851): ``UNETR`` keyword arguments plus the
+    optimisation hyper-parameters of ``UNetPL``; ``step`` / ``training_step`` /
+    ``configure_optimizers`` come from ``UNetBasePL``."""
+
+    def __init__(self, image_key: str = "image", label_key: str = "label",
+                 skip_conditioning_key: str = None, feature_conditioning_key: str = None,
+                 optimizer_str: str = "sgd", optimizer_eps: float = 1e-8,
+                 learning_rate: float = 0.001, lr_encoder: float = None,
+                 start_decay: float = 1.0, warmup_steps: int = 0, batch_size: int = 4,
+                 n_epochs: int = 100, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None,
+                 loss_fn: Callable = F.binary_cross_entropy, picai_eval: bool = False,
+                 *args, **kwargs) -> torch.nn.Module:
+        hp = {k: v for k, v in locals().items() if k not in ("self", "args", "kwargs", "__class__")}
+        super().__init__(*args, **kwargs)
+        _training_attributes(self, hp)
+
+
+class SWINUNetPL(SWINUNet, UNetBasePL):
+    """SWIN-UNet training wrapper (pl.py:854-941)."""
+
+    def __init__(self, image_key: str = "image", label_key: str = "label",
+                 skip_conditioning_key: str = None, feature_conditioning_key: str = None,
+                 optimizer_str: str = "sgd", optimizer_eps: float = 1e-8,
+                 learning_rate: float = 0.001, lr_encoder: float = None,
+                 start_decay: float = 1.0, warmup_steps: int = 0, batch_size: int = 4,
+                 n_epochs: int = 100, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None,
+                 loss_fn: Callable = F.binary_cross_entropy, picai_eval: bool = False,
+                 *args, **kwargs) -> torch.nn.Module:
+        hp = {k: v for k, v in locals().items() if k not in ("self", "args", "kwargs", "__class__")}
+        super().__init__(*args, **kwargs)
+        _training_attributes(self, hp)
+
+
+class UNetPlusPlusPL(UNetPlusPlus, UNetBasePL):
+    """U-Net++ training wrapper (pl.py:1121-1205). ``deep_supervision`` is forced on after
+    construction: ``UNetPlusPlus.forward`` returns ``(pred, bn_out, aux)`` and
+    ``UNetBasePL.step`` then weights the auxiliary heads as deep-supervision outputs against
+    aligned-corner resized targets (pl.py:1199, 298-316)."""
+
+    def __init__(self, image_key: str = "image", label_key: str = "label",
+                 skip_conditioning_key: str = None, feature_conditioning_key: str = None,
+                 optimizer_str: str = "sgd", optimizer_eps: float = 1e-8,
+                 learning_rate: float = 0.001, lr_encoder: float = None,
+                 start_decay: float = 1.0, warmup_steps: int = 0, batch_size: int = 4,
+                 n_epochs: int = 100, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None,
+                 loss_fn: Callable = F.binary_cross_entropy, picai_eval: bool = False,
+                 *args, **kwargs) -> torch.nn.Module:
+        hp = {k: v for k, v in locals().items() if k not in ("self", "args", "kwargs", "__class__")}
+        super().__init__(*args, **kwargs)
+        _training_attributes(self, hp)
+        self.deep_supervision = True

@@ -102,7 +102,7 @@ class UNETR(UNet, torch.nn.Module):
         self.assertions()
         if self.spatial_dimensions != 3:
             raise NotImplementedError("HIP UNETR is 3-D (the BASELINE configuration)")
-        if self.feature_conditioning is not None:
+        if self.feature_conditioning:
             raise NotImplementedError("feature conditioning is outside the HIP path built so far")
 
         self.get_norm_op()
@@ -119,6 +119,11 @@ class UNETR(UNet, torch.nn.Module):
             self.init_rescalers()
             if self.bottleneck_classification is True:
                 self.init_bottleneck_classifier()
+            if self.feature_conditioning is not None:
+                # get_segmentation_network passes feature_conditioning=len([]) == 0 and the
+                # reference then still builds its (never used) Linear(0, d) gate stacks
+                # (unetr.py:217-218): kept so that state_dict keys interchange
+                self.init_feature_conditioning_operations()
 
     def assertions(self):
         assert (len(self.depth) - 1) == len(self.return_at), \
@@ -307,7 +312,7 @@ class SWINUNet(UNet, torch.nn.Module):
         self.number_of_blocks = len(self.depth)
         if self.spatial_dimensions != 3:
             raise NotImplementedError("HIP SWINUNet is 3-D (the BASELINE configuration)")
-        if self.feature_conditioning is not None:
+        if self.feature_conditioning:
             raise NotImplementedError("feature conditioning is outside the HIP path built so far")
         self.arg_compliance()
         self.get_norm_op()
@@ -322,6 +327,8 @@ class SWINUNet(UNet, torch.nn.Module):
         self.init_final_layer()
         if self.bottleneck_classification is True:
             self.init_bottleneck_classifier()
+        if self.feature_conditioning is not None:   # == 0 from the factory, unetr.py:818-819
+            self.init_feature_conditioning_operations()
 
     def arg_compliance(self):
         msg = "shift_sizes must be list of ints or list of list of ints"

@@ -15,6 +15,7 @@ import torch
 
 from ...optim import FusedAdamW
 from ..layers.conv_next import ConvNeXt
+from ..layers.res_net import ResNet
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .losses import VICRegLoss
 
@@ -85,46 +86,33 @@ class SelfSLBasePL(_Base):
         self.test_metrics = torch.nn.ModuleDict({})
 
 
-class SelfSLConvNeXtPL(ConvNeXt, SelfSLBasePL):
-    def __init__(self, aug_image_key_1: str = "aug_image_1", aug_image_key_2: str = "aug_image_2",
-                 box_key_1: str = "box_1", box_key_2: str = "box_2", learning_rate: float = 0.001,
-                 batch_size: int = 4, weight_decay: float = 0.005,
-                 training_dataloader_call: Callable = None, n_epochs: int = 1000,
-                 n_steps: int = None, warmup_steps: int = 0, start_decay: int = None,
-                 ema: torch.nn.Module = None, ssl_method: str = "simclr",
-                 temperature: float = 1.0, vic_reg_loss_params: dict = {},
-                 stop_gradient: bool = True, channels_to_batch: bool = False,
-                 optimizer_eps: float = OPTIMIZER_EPS_DEFAULT, *args, **kwargs):
-        self.aug_image_key_1 = aug_image_key_1
-        self.aug_image_key_2 = aug_image_key_2
-        self.box_key_1 = box_key_1
-        self.box_key_2 = box_key_2
-        self.learning_rate = learning_rate
-        self.batch_size = batch_size
-        self.weight_decay = weight_decay
-        self.training_dataloader_call = training_dataloader_call
-        self.n_epochs = n_epochs
-        self.n_steps = n_steps
-        self.warmup_steps = warmup_steps
-        self.start_decay = start_decay
-        self.ssl_method = ssl_method
-        self.temperature = temperature
-        self.vic_reg_loss_params = vic_reg_loss_params
-        self.stop_gradient = stop_gradient
-        self.channels_to_batch = channels_to_batch
-        if channels_to_batch is True:
+_SSL_HYPERPARAMETERS = (
+    "aug_image_key_1", "aug_image_key_2", "box_key_1", "box_key_2", "learning_rate", "batch_size",
+    "weight_decay", "training_dataloader_call", "n_epochs", "n_steps", "warmup_steps",
+    "start_decay", "ssl_method", "temperature", "vic_reg_loss_params", "stop_gradient",
+    "channels_to_batch")
+
+
+class _TwoViewSSL:
+    """What ``SelfSLResNetPL`` (pl.py:312-535) and ``SelfSLConvNeXtPL`` (:759-985) share: two
+    augmented views through one network with three heads (``ret`` = representation /
+    projection / prediction), an optional EMA or stop-gradient target branch, and a loss that
+    returns a list of terms. The backbone class comes first in the MRO of the concrete class."""
+
+    def _init_two_view(self, hp, args, kwargs):
+        for k in _SSL_HYPERPARAMETERS:   # plain attributes: set before Module.__init__, as the
+            object.__setattr__(self, k, hp[k])   # reference does
+        if hp["channels_to_batch"] is True:
             kwargs["backbone_args"]["in_channels"] = 1
         super().__init__(*args, **kwargs)
-        self.optimizer_eps = optimizer_eps
-        self.ema = ema
+        self.optimizer_eps = hp["optimizer_eps"]
+        self.ema = hp["ema"]
         if self.ssl_method not in ["vicreg", "vicregl", "simclr"] and self.stop_gradient is False:
             warnings.warn("stop_gradient=False should not (in theory) be used with "
                           "vic_reg=False, vic_reg_local=False or simclr=False")
         self.init_loss()
         if self.ema is not None:
             self.ema.update(self)
-        else:
-            self.ema = None
         self.loss_str_dict = {"standard": [None], "vicreg": ["inv", "var", "cov"],
                               "vicregl": ["inv", "var", "cov", "local"]}
         self.save_hyperparameters()
@@ -137,37 +125,40 @@ class SelfSLConvNeXtPL(ConvNeXt, SelfSLBasePL):
                 return op(x, ret)
         return op(x, ret)
 
-    def step(self, batch, loss_str: str, metrics: dict, train=False):
+    def _heads_for_method(self, batch):
+        """(head of view 1, head of view 2, extra loss arguments), pl.py:457-470."""
         if self.ssl_method == "simclr":
-            ret_string_1, ret_string_2, other_args = "projection", "projection", []
-        elif self.ssl_method != "vicregl":
-            ret_string_1, ret_string_2, other_args = "prediction", "projection", []
-        else:
-            ret_string_1, ret_string_2 = "representation", "representation"
-            other_args = [batch[self.box_key_1], batch[self.box_key_2]]
+            return "projection", "projection", []
+        if self.ssl_method == "vicregl":
+            return "representation", "representation", [batch[self.box_key_1],
+                                                        batch[self.box_key_2]]
+        return "prediction", "projection", []
+
+    def step(self, batch, loss_str: str, metrics: dict, train=False):
+        ret_1, ret_2, other_args = self._heads_for_method(batch)
         x1, x2 = batch[self.aug_image_key_1], batch[self.aug_image_key_2]
         if self.channels_to_batch is True:
             x1 = x1.reshape(-1, 1, *x1.shape[2:])
             x2 = x2.reshape(-1, 1, *x2.shape[2:])
-        y1 = self.forward(x1, ret=ret_string_1)
-        y2 = self.forward_ema_stop_grad(x2, ret=ret_string_2)
+        y1 = self.forward(x1, ret=ret_1)
+        y2 = self.forward_ema_stop_grad(x2, ret=ret_2)
         losses = self.calculate_loss(y1, y2, *other_args)
         self.update_metrics(y1, y2, metrics)
-        # loss is already symmetrised for VICReg, VICRegL and SimCLR
-        if self.ssl_method not in ["vicreg", "vicregl", "simclr"]:
-            y1_ = self.forward_ema_stop_grad(x1, ret=ret_string_1)
-            y2_ = self.forward(x2, ret=ret_string_2)
+        symmetric_already = self.ssl_method in ("vicreg", "vicregl", "simclr")
+        if not symmetric_already:   # SimSiam / BYOL: add the loss with the two views swapped
+            y1_ = self.forward_ema_stop_grad(x1, ret=ret_1)
+            y2_ = self.forward(x2, ret=ret_2)
             losses = losses + self.calculate_loss(y2_, y1_, *other_args)
             self.update_metrics(y2_, y1_, metrics)
         if self.ema is not None and train is True:
             self.ema.update(self)
         loss = self.safe_sum(losses)
-        self.log(loss_str, loss, batch_size=x1.shape[0], on_epoch=True, on_step=False,
-                 prog_bar=True, sync_dist=True)
+        log_kw = dict(batch_size=x1.shape[0], on_epoch=True, on_step=False, prog_bar=True,
+                      sync_dist=True)
+        self.log(loss_str, loss, **log_kw)
         if self.ssl_method in ("vicregl", "vicreg"):
             for s, loss_value in zip(self.loss_str_dict[self.ssl_method], losses):
-                self.log("{}:{}".format(loss_str, s), loss_value, batch_size=x1.shape[0],
-                         on_epoch=True, on_step=False, prog_bar=True, sync_dist=True)
+                self.log("{}:{}".format(loss_str, s), loss_value, **log_kw)
         self.last_losses = losses
         return loss
 
@@ -179,3 +170,36 @@ class SelfSLConvNeXtPL(ConvNeXt, SelfSLBasePL):
 
     def test_step(self, batch, batch_idx):
         return self.step(batch, "test_loss", self.test_metrics)
+
+
+class SelfSLConvNeXtPL(_TwoViewSSL, ConvNeXt, SelfSLBasePL):
+    """ConvNeXt backbone (pl.py:759-985)."""
+
+    def __init__(self, aug_image_key_1: str = "aug_image_1", aug_image_key_2: str = "aug_image_2",
+                 box_key_1: str = "box_1", box_key_2: str = "box_2", learning_rate: float = 0.001,
+                 batch_size: int = 4, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None, n_epochs: int = 1000,
+                 n_steps: int = None, warmup_steps: int = 0, start_decay: int = None,
+                 ema: torch.nn.Module = None, ssl_method: str = "simclr",
+                 temperature: float = 1.0, vic_reg_loss_params: dict = {},
+                 stop_gradient: bool = True, channels_to_batch: bool = False,
+                 optimizer_eps: float = OPTIMIZER_EPS_DEFAULT, *args, **kwargs):
+        hp = {k: v for k, v in locals().items() if k not in ("self", "args", "kwargs", "__class__")}
+        self._init_two_view(hp, args, kwargs)
+
+
+class SelfSLResNetPL(_TwoViewSSL, ResNet, SelfSLBasePL):
+    """ResNet backbone (pl.py:312-535): what ``get_ssl_network`` builds for simclr / byol /
+    vicreg / vicregl, transferable to a U-Net encoder (utils/handoff.py)."""
+
+    def __init__(self, aug_image_key_1: str = "aug_image_1", aug_image_key_2: str = "aug_image_2",
+                 box_key_1: str = "box_1", box_key_2: str = "box_2", learning_rate: float = 0.001,
+                 batch_size: int = 4, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None, n_epochs: int = 1000,
+                 n_steps: int = None, warmup_steps: int = 0, start_decay: int = None,
+                 ema: torch.nn.Module = None, ssl_method: str = "simclr",
+                 temperature: float = 1.0, vic_reg_loss_params: dict = {},
+                 stop_gradient: bool = True, channels_to_batch: bool = False,
+                 optimizer_eps: float = OPTIMIZER_EPS_DEFAULT, *args, **kwargs):
+        hp = {k: v for k, v in locals().items() if k not in ("self", "args", "kwargs", "__class__")}
+        self._init_two_view(hp, args, kwargs)

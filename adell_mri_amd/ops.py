@@ -67,7 +67,9 @@ class KernelTimer:
         return self._agg
 
     def dominant(self):
-        s = self.summary()
+        """The kernel family with the most time among those that carry FLOPs (the HBM-bound
+        families are recorded with flops = 0 and reported through their bytes)."""
+        s = {k: v for k, v in self.summary().items() if v["flops"] > 0}
         if not s:
             return None
         name = max(s, key=lambda k: s[k]["ms"])
@@ -78,6 +80,7 @@ class KernelTimer:
 
 
 KERNEL_TIMER = None
+NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
 
 
 def _timed(name, flops, fn, tag=None, nbytes=0.0, kernels=1):
@@ -282,6 +285,7 @@ def conv_cin_small_fwd(x, weight, bias, padding, want_stats):
     d = make_conv_desc(N, (D, H, W), Cin, 0, Cout, tuple(weight.shape[2:]), 1, padding)
     y = new_act(N, Cout, d.Do, d.Ho, d.Wo, x.device)
     part = None
+    wc = weight.contiguous()   # bound to a local: must outlive the launch
     if want_stats:
         nt = _lib.lib().adell_conv_cin_small_ntiles(ctypes.byref(d))
         if nt < 0:
@@ -289,7 +293,7 @@ def conv_cin_small_fwd(x, weight, bias, padding, want_stats):
         part = torch.empty((N, nt, Cout, 2), device=x.device, dtype=torch.float32)
     check(_timed("adell_cin_small_kernel", _conv_flops(d),
                  lambda: _lib.lib().adell_conv_cin_small_fwd(
-                     ctypes.byref(d), _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(y),
+                     ctypes.byref(d), _ptr(x), _ptr(wc), _ptr(bias), _ptr(y),
                      _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
     return y, part
 
@@ -301,9 +305,10 @@ def conv_cin_small_bwd_data(dy, weight, in_size, padding):
     d = make_conv_desc(N, tuple(in_size), Cin, 0, Cout, tuple(weight.shape[2:]), 1, padding)
     assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
     dx = new_act(N, Cin, *in_size, dy.device)
+    wc = weight.contiguous()
     check(_timed("adell_cin_small_kernel", _conv_flops(d),
                  lambda: _lib.lib().adell_conv_cin_small_bwd_data(
-                     ctypes.byref(d), _ptr(dy), _ptr(weight.contiguous()), _ptr(dx), _stream()),
+                     ctypes.byref(d), _ptr(dy), _ptr(wc), _ptr(dx), _stream()),
                  _conv_tag(d, "dgrad"), _conv_bytes(d)))
     return dx
 
@@ -330,9 +335,10 @@ def conv1_small_fwd(x0, x1, weight, bias):
     Cout = weight.shape[0]
     d = _conv1_desc(N, (D, H, W), C0, C1, Cout)
     y = new_act(N, Cout, D, H, W, x0.device)
+    wc = weight.contiguous()
     check(_timed("adell_conv1_small_kernel", _conv_flops(d),
                  lambda: _lib.lib().adell_conv1_small_fwd(ctypes.byref(d), _ptr(x0), _ptr(x1),
-                                                          _ptr(weight.contiguous()), _ptr(bias),
+                                                          _ptr(wc), _ptr(bias),
                                                           _ptr(y), _stream()),
                  _conv_tag(d, "fwd"), _conv_bytes(d)))
     return y
@@ -344,9 +350,10 @@ def conv1_small_bwd_data(dy, weight, in_size, C0, C1):
     d = _conv1_desc(N, in_size, C0, C1, Cout)
     dx0 = new_act(N, C0, *in_size, dy.device)
     dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
+    wc = weight.contiguous()
     check(_timed("adell_conv1_small_kernel", _conv_flops(d),
                  lambda: _lib.lib().adell_conv1_small_bwd_data(ctypes.byref(d), _ptr(dy),
-                                                               _ptr(weight.contiguous()),
+                                                               _ptr(wc),
                                                                _ptr(dx0), _ptr(dx1), _stream()),
                  _conv_tag(d, "dgrad"), _conv_bytes(d)))
     return dx0, dx1
@@ -594,9 +601,10 @@ def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.
     d = make_na_desc(x, act, stats_per_item, act_p, 0 if act_w is None else act_w.numel(),
                      drop_p, seed, rng_offset)
     out = new_act(*x.shape, x.device)
-    check(_lib.lib().adell_norm_act_fwd(ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd),
-                                        _ptr(gamma), _ptr(beta), _ptr(act_w), _ptr(out),
-                                        _stream()))
+    # HBM-bound family of the roofline report: algorithmic bytes = read x + write out
+    check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_fwd(
+        ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(act_w),
+        _ptr(out), _stream()), "fwd", 8.0 * x.numel()))
     return out
 
 
@@ -630,10 +638,11 @@ def norm_act_bwd(x, dout, mean, rstd, act, gamma=None, beta=None, act_w=None, ac
     ws = None
     if mean is not None or want_affine_grads:
         ws = _workspace(_lib.lib().adell_norm_act_bwd_workspace(ctypes.byref(d)), x.device)
-    check(_lib.lib().adell_norm_act_bwd(
+    # algorithmic bytes: read x and dout once, write dx once
+    check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_bwd(
         ctypes.byref(d), _ptr(x), _ptr(dout), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
         _ptr(act_w), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
-        0 if ws is None else ws.numel() * 4, _stream()))
+        0 if ws is None else ws.numel() * 4, _stream()), "bwd", 12.0 * x.numel()))
     return dx, dgamma, dbeta
 
 
@@ -897,7 +906,8 @@ def scale_bc(x, s):
     N, C = x.shape[:2]
     V = x.numel() // (N * C)
     y = new_act(N, C, *x.shape[2:], x.device)
-    check(_lib.lib().adell_scale_bc(_ptr(x), _ptr(s.contiguous()), _ptr(y), N, V, C, _stream()))
+    sc = s.contiguous()
+    check(_lib.lib().adell_scale_bc(_ptr(x), _ptr(sc), _ptr(y), N, V, C, _stream()))
     return y
 
 
@@ -955,7 +965,8 @@ def bcast_nc(g, shape, scale=1.0):
     N, C = shape[:2]
     V = int(math.prod(shape[2:]))
     out = new_act(N, C, *shape[2:], g.device)
-    check(_lib.lib().adell_bcast_nc(_ptr(g.contiguous()), _ptr(out), N, V, C, float(scale), _stream()))
+    gc = g.contiguous()
+    check(_lib.lib().adell_bcast_nc(_ptr(gc), _ptr(out), N, V, C, float(scale), _stream()))
     return out
 
 
@@ -986,7 +997,8 @@ def dwconv3d_fwd(x, w, bias):
     N, C, D, H, W = x.shape
     kd, kh, kw = w.shape[2:]
     y = new_act(N, C, D, H, W, x.device)
-    check(_lib.lib().adell_dwconv3d_fwd(N, C, D, H, W, kd, kh, kw, _ptr(x), _ptr(w.contiguous()),
+    wc = w.contiguous()
+    check(_lib.lib().adell_dwconv3d_fwd(N, C, D, H, W, kd, kh, kw, _ptr(x), _ptr(wc),
                                         _ptr(bias), _ptr(y), _stream()))
     return y
 
@@ -996,8 +1008,9 @@ def dwconv3d_bwd_data(dy, w):
     N, C, D, H, W = dy.shape
     kd, kh, kw = w.shape[2:]
     dx = new_act(N, C, D, H, W, dy.device)
+    wc = w.contiguous()
     check(_lib.lib().adell_dwconv3d_bwd_data(N, C, D, H, W, kd, kh, kw, _ptr(dy),
-                                             _ptr(w.contiguous()), _ptr(dx), _stream()))
+                                             _ptr(wc), _ptr(dx), _stream()))
     return dx
 
 

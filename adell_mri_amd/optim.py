@@ -3,10 +3,18 @@
 ``FlatParameters`` re-homes every parameter of a group into a single contiguous
 device buffer (and ``.grad`` into a matching flat gradient buffer), so that an
 optimiser step is one HIP launch per group and the data-parallel gradient
-exchange (``parallel.GradSync``) is an all-reduce of that same buffer.
+exchange (``parallel.GradSync``) is an all-reduce of slices of that same buffer.
 ``FusedSGD`` follows ``torch.optim.SGD(momentum, nesterov, weight_decay)`` as
 configured by the reference (adell_mri/modules/segmentation/pl.py:563-569);
 ``FusedAdamW`` follows ``torch.optim.AdamW`` (self_supervised/pl.py:245-250).
+
+Kept from ``torch.optim`` so that the reference's checkpoints interchange:
+
+* ``state_dict()`` / ``load_state_dict()`` use the per-parameter layout of the torch
+  optimisers (``momentum_buffer`` / ``exp_avg`` / ``exp_avg_sq`` / ``step`` keyed by
+  parameter index); loading copies INTO the flat buffers, the parameters keep aliasing them.
+* a parameter whose ``.grad`` is ``None`` is skipped by ``step()`` (no weight decay, no
+  momentum update), and its state starts at the first step it does receive a gradient.
 """
 import numpy as np
 import torch
@@ -30,6 +38,7 @@ class FlatParameters:
             self.offsets.append(n)
             n += (p.numel() + 3) // 4 * 4  # keep every slice 16-byte aligned
         self.numel = n
+        self.ends = self.offsets[1:] + [n]   # padded end of every slice
         self.data = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
         with torch.no_grad():
@@ -41,14 +50,18 @@ class FlatParameters:
 
     CHUNK = 16384
 
+    def slot(self, i):
+        p, o = self.params[i], self.offsets[i]
+        return self.grad[o:o + p.numel()].view(p.shape)
+
     def zero_grad(self, set_to_none=True):
         """Zero the flat gradient. ``set_to_none`` (torch's default) also detaches the
         parameters from it: autograd then hands each parameter its freshly computed gradient
         tensor (no per-parameter accumulate kernels) and ``collect()`` gathers them into the
         flat buffer with one launch. Otherwise ``p.grad`` stays a view of the flat buffer."""
         self.grad.zero_()
-        for p, o in zip(self.params, self.offsets):
-            p.grad = None if set_to_none else self.grad[o:o + p.numel()].view(p.shape)
+        for i, p in enumerate(self.params):
+            p.grad = None if set_to_none else self.slot(i)
 
     def _upload_and_copy(self, rows):
         """Stage the (pointer, offset, count) table through a small ring of pinned host buffers
@@ -60,7 +73,7 @@ class FlatParameters:
             cap = max(2 * n, 1024)
             ring = [(torch.empty((cap, 3), dtype=torch.int64).pin_memory(),
                      torch.empty((cap, 3), dtype=torch.int64, device=self.grad.device),
-                     torch.cuda.Event()) for _ in range(4)]
+                     torch.cuda.Event()) for _ in range(8)]
             self._ring, self._ring_pos = ring, 0
         host, dev, ev = ring[self._ring_pos]
         self._ring_pos = (self._ring_pos + 1) % len(ring)
@@ -70,14 +83,18 @@ class FlatParameters:
         ev.record()
         ops.multi_copy(dev, n, self.grad)
 
-    def collect(self):
-        """Copy every parameter gradient that is not already a view of the flat buffer into its
-        slot (one multi-copy launch), then point ``p.grad`` at the slots."""
+    def collect(self, indices=None):
+        """Copy every parameter gradient (of ``indices``, default all) that is not already a
+        view of the flat buffer into its slot (one multi-copy launch), then point ``p.grad`` at
+        the slots. Returns nothing; parameters without a gradient keep ``grad is None`` and a
+        zero slot."""
         base = self.grad.data_ptr()
         todo, keep = [], []
-        for p, o in zip(self.params, self.offsets):
+        idx = range(len(self.params)) if indices is None else indices
+        for i in idx:
+            p, o = self.params[i], self.offsets[i]
             g = p.grad
-            if g is None or g.data_ptr() == base + 4 * o:
+            if g is None or g.data_ptr() == base + 4 * o or g.numel() == 0:
                 continue
             if g.dtype != torch.float32 or g.device != self.grad.device:
                 raise ValueError("FlatParameters.collect: gradients must be fp32 on the GPU")
@@ -88,89 +105,208 @@ class FlatParameters:
             # one row per CHUNK-element piece of every gradient, built without a Python loop
             ptr, off, num = np.array(todo, dtype=np.int64).T
             k = (num + self.CHUNK - 1) // self.CHUNK
-            idx = np.repeat(np.arange(len(k)), k)
+            ix = np.repeat(np.arange(len(k)), k)
             start = (np.arange(int(k.sum())) - np.repeat(np.cumsum(k) - k, k)) * self.CHUNK
-            rows = np.stack([ptr[idx] + 4 * start, off[idx] + start,
-                             np.minimum(self.CHUNK, num[idx] - start)], 1)
+            rows = np.stack([ptr[ix] + 4 * start, off[ix] + start,
+                             np.minimum(self.CHUNK, num[ix] - start)], 1)
             self._upload_and_copy(rows)
-        for p, o in zip(self.params, self.offsets):
+        for i in idx:
+            p = self.params[i]
             if p.grad is not None:
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p.grad = self.slot(i)
+
+    def has_grad(self):
+        return np.fromiter((p.grad is not None for p in self.params), dtype=bool,
+                           count=len(self.params))
+
+    def runs(self, active, key=None):
+        """Maximal runs of consecutive parameters with ``active[i]`` true and equal ``key[i]``:
+        [(first index, element offset, element end)], ends padded so that a run is one
+        contiguous 16-byte-aligned slice of the flat buffers."""
+        out, i, n = [], 0, len(self.params)
+        while i < n:
+            if not active[i]:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and active[j + 1] and (key is None or key[j + 1] == key[i]):
+                j += 1
+            if self.ends[j] > self.offsets[i]:   # zero-element parameters make empty runs
+                out.append((i, self.offsets[i], self.ends[j]))
+            i = j + 1
+        return out
 
 
 class _FusedBase(torch.optim.Optimizer):
-    def _flat(self, group):
-        flat = group.get("_flat")
+    _state_names = ()
+
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        # flat buffers live beside param_groups (not inside: torch pickles / deep-copies groups)
+        self._flats = {}
+        self._flat_state = {}
+        for gi in range(len(self.param_groups)):
+            self._flat(gi)
+
+    def _flat(self, gi):
+        flat = self._flats.get(gi)
         if flat is None:
             # frozen parameters (e.g. an EMA shadow) never receive gradients: torch.optim skips
             # them, so they stay out of the flat buffer
+            group = self.param_groups[gi]
             flat = FlatParameters([p for p in group["params"] if p.requires_grad])
-            group["_flat"] = flat
+            self._flats[gi] = flat
+            self._flat_state[gi] = {"steps": np.zeros(len(flat.params), dtype=np.int64)}
         return flat
 
     @property
     def flat_groups(self):
-        return [self._flat(g) for g in self.param_groups]
+        return [self._flat(gi) for gi in range(len(self.param_groups))]
 
     def zero_grad(self, set_to_none: bool = True):
-        for g in self.param_groups:
-            self._flat(g).zero_grad(set_to_none)
+        for flat in self.flat_groups:
+            flat.zero_grad(set_to_none)
 
     def collect_grads(self):
         """Gather the parameters' gradients into the flat buffers (idempotent)."""
-        for g in self.param_groups:
-            self._flat(g).collect()
+        for flat in self.flat_groups:
+            flat.collect()
+
+    def _buffer(self, gi, name):
+        st = self._flat_state[gi]
+        if name not in st:
+            st[name] = torch.zeros_like(self._flat(gi).data)
+        return st[name]
+
+    # ---- torch.optim-compatible (de)serialisation ------------------------------------------
+    def _hyper(self, group):
+        return {k: v for k, v in group.items() if k != "params"}
+
+    def state_dict(self):
+        """Same layout as ``torch.optim.Optimizer.state_dict()`` of the optimiser this class
+        replaces: ``state[index]`` holds per-parameter tensors (copies), ``param_groups`` the
+        hyper-parameters and parameter indices. Frozen parameters have no state, as in torch."""
+        state, groups, start = {}, [], 0
+        for gi, group in enumerate(self.param_groups):
+            flat, st = self._flat(gi), self._flat_state[gi]
+            slot = {id(p): i for i, p in enumerate(flat.params)}
+            ids = list(range(start, start + len(group["params"])))
+            for pid, p in zip(ids, group["params"]):
+                i = slot.get(id(p))
+                if i is None or st["steps"][i] == 0:
+                    continue
+                o, n = flat.offsets[i], p.numel()
+                state[pid] = self._param_state(st, i, o, n, p.shape)
+            groups.append({**self._hyper(group), "params": ids})
+            start += len(ids)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        start = 0
+        for gi, (group, saved) in enumerate(zip(self.param_groups, groups)):
+            if len(saved["params"]) != len(group["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't "
+                                 "match the size of optimizer's group")
+            keep_scale = group.get("grad_scale", 1.0)
+            for k, v in saved.items():
+                if k != "params":
+                    group[k] = v
+            group["grad_scale"] = keep_scale   # world-size dependent, not a checkpoint property
+            flat, st = self._flat(gi), self._flat_state[gi]
+            slot = {id(p): i for i, p in enumerate(flat.params)}
+            st["steps"][:] = 0
+            for name in self._state_names:
+                if name in st:
+                    st[name].zero_()
+            for pid, p in zip(saved["params"], group["params"]):
+                ent = state_dict["state"].get(pid, state_dict["state"].get(str(pid)))
+                i = slot.get(id(p))
+                if ent is None or i is None:
+                    continue
+                self._load_param_state(gi, st, i, flat.offsets[i], p.numel(), ent)
+            start += len(group["params"])
+        ops._weights_changed()
 
 
 class FusedSGD(_FusedBase):
+    _state_names = ("momentum_buffer",)
+
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0,
                  nesterov=False):
         if dampening != 0.0:
             raise NotImplementedError("FusedSGD: dampening must be 0")
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay,
-                                      nesterov=nesterov, grad_scale=1.0))
-        for g in self.param_groups:
-            self._flat(g)
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening,
+                                      weight_decay=weight_decay, nesterov=nesterov,
+                                      grad_scale=1.0))
+
+    def _param_state(self, st, i, o, n, shape):
+        if "momentum_buffer" not in st:
+            return {"momentum_buffer": None}
+        return {"momentum_buffer": st["momentum_buffer"][o:o + n].view(shape).clone()}
+
+    def _load_param_state(self, gi, st, i, o, n, ent):
+        buf = ent.get("momentum_buffer")
+        if buf is not None:
+            self._buffer(gi, "momentum_buffer")[o:o + n].copy_(buf.reshape(-1))
+        st["steps"][i] = 1
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self.collect_grads()
         for gi, g in enumerate(self.param_groups):
-            flat = self._flat(g)
-            st = self.state.setdefault(f"flat{gi}", {})
-            first = "momentum_buffer" not in st
-            if first and g["momentum"] != 0.0:
-                st["momentum_buffer"] = torch.zeros_like(flat.data)
-            ops.sgd_step(flat.data, flat.grad, st.get("momentum_buffer"), g["lr"], g["momentum"],
-                         g["weight_decay"], g["nesterov"], first, g.get("grad_scale", 1.0))
+            flat, st = self._flat(gi), self._flat_state[gi]
+            buf = self._buffer(gi, "momentum_buffer") if g["momentum"] != 0.0 else None
+            active = flat.has_grad()
+            first = st["steps"] == 0
+            # one launch per run of parameters that share "has a gradient" and "first step"
+            # (normally ONE run: the whole buffer)
+            for i, lo, hi in flat.runs(active, first):
+                ops.sgd_step(flat.data[lo:hi], flat.grad[lo:hi],
+                             None if buf is None else buf[lo:hi], g["lr"], g["momentum"],
+                             g["weight_decay"], g["nesterov"], bool(first[i]),
+                             g.get("grad_scale", 1.0))
+            st["steps"][active] += 1
         return loss
 
 
 class FusedAdamW(_FusedBase):
     decoupled = True
+    _state_names = ("exp_avg", "exp_avg_sq")
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                       grad_scale=1.0))
-        for g in self.param_groups:
-            self._flat(g)
+
+    def _param_state(self, st, i, o, n, shape):
+        return {"step": torch.tensor(float(st["steps"][i])),
+                "exp_avg": st["exp_avg"][o:o + n].view(shape).clone(),
+                "exp_avg_sq": st["exp_avg_sq"][o:o + n].view(shape).clone()}
+
+    def _load_param_state(self, gi, st, i, o, n, ent):
+        self._buffer(gi, "exp_avg")[o:o + n].copy_(ent["exp_avg"].reshape(-1))
+        self._buffer(gi, "exp_avg_sq")[o:o + n].copy_(ent["exp_avg_sq"].reshape(-1))
+        st["steps"][i] = int(float(ent["step"]))
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         self.collect_grads()
         for gi, g in enumerate(self.param_groups):
-            flat = self._flat(g)
-            st = self.state.setdefault(f"flat{gi}", {})
-            if "step" not in st:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(flat.data)
-                st["exp_avg_sq"] = torch.zeros_like(flat.data)
-            st["step"] += 1
-            ops.adamw_step(flat.data, flat.grad, st["exp_avg"], st["exp_avg_sq"], g["lr"],
-                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], st["step"],
-                           g.get("grad_scale", 1.0), decoupled=self.decoupled)
+            flat, st = self._flat(gi), self._flat_state[gi]
+            m, v = self._buffer(gi, "exp_avg"), self._buffer(gi, "exp_avg_sq")
+            active = flat.has_grad()
+            st["steps"][active] += 1
+            # the bias correction depends on a parameter's own step count (torch keeps one per
+            # parameter): one launch per run of equal counts (normally ONE run)
+            for i, lo, hi in flat.runs(active, st["steps"]):
+                ops.adamw_step(flat.data[lo:hi], flat.grad[lo:hi], m[lo:hi], v[lo:hi], g["lr"],
+                               g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                               int(st["steps"][i]), g.get("grad_scale", 1.0),
+                               decoupled=self.decoupled)
         return loss
 
 

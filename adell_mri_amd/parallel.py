@@ -3,12 +3,20 @@
 
 The reference gets data parallelism from ``lightning.Trainer(strategy="ddp")``
 (adell_mri/entrypoints/segmentation/train.py:799-819, utils/pl_utils.py:424-458):
-bucketed sum-all-reduce of gradients divided by the world size. Here the
-optimiser already owns ONE flat gradient buffer per parameter group
-(``optim.FlatParameters``), so the exchange is an all-reduce of that buffer in a
-few large chunks (xGMI rings are per-link bound: few large messages), and the
-division by the world size is folded into the fused optimiser kernel
-(``grad_scale``), not a separate pass.
+torch DDP's bucketed sum-all-reduce of gradients, launched from backward hooks and divided
+by the world size. Here the optimiser already owns ONE flat gradient buffer per parameter
+group (``optim.FlatParameters``), so a bucket is a contiguous slice of that buffer:
+
+* the flat buffer is cut into a few buckets of consecutive parameters (xGMI rings are
+  per-link bound: few, large messages -- 4 buckets of >= 4 MB by default);
+* a post-accumulate-grad hook on every parameter counts arrivals; when the last parameter
+  of a bucket has its gradient (backward visits the buckets last-to-first), the bucket's
+  gradients are gathered into their slots by one multi-copy launch and an ASYNC all-reduce
+  of the slice is issued on the process group's stream -- it overlaps the rest of backward;
+* ``all_reduce()`` (called before ``optimizer.step``) sends whatever has not gone out yet
+  (parameters without a gradient leave their bucket incomplete) and waits for every handle;
+* the division by the world size is folded into the fused optimiser kernel
+  (``grad_scale``), not a separate pass.
 """
 import os
 
@@ -56,21 +64,90 @@ def all_reduce_flat(buffers, chunk_elems, async_op=False):
         h.wait()
 
 
+def plan_buckets(sizes, n_buckets=4, min_elems=1 << 20):
+    """Cut consecutive parameters (element counts ``sizes``, in flat-buffer order) into at most
+    ``n_buckets`` runs of roughly equal element count, none smaller than ``min_elems`` unless
+    it is the only one. Returns [(first index, last index + 1)], in buffer order."""
+    total = int(sum(sizes))
+    n = max(1, min(int(n_buckets), total // max(int(min_elems), 1) or 1, len(sizes)))
+    out, start, acc, left, remaining = [], 0, 0, n, total
+    for i, s in enumerate(sizes):
+        acc += int(s)
+        # cut when this bucket has its share of what is left, keeping >= 1 parameter for each
+        # of the buckets still to come
+        if left > 1 and acc >= remaining / left and len(sizes) - (i + 1) >= left - 1:
+            out.append((start, i + 1))
+            start, remaining, left, acc = i + 1, remaining - acc, left - 1, 0
+    out.append((start, len(sizes)))
+    return out
+
+
+class _Bucket:
+    __slots__ = ("flat", "lo", "hi", "e0", "e1", "pending", "sent")
+
+    def __init__(self, flat, lo, hi):
+        self.flat, self.lo, self.hi = flat, lo, hi
+        self.e0, self.e1 = flat.offsets[lo], flat.ends[hi - 1]
+        self.pending = hi - lo
+        self.sent = False
+
+
 class GradSync:
     """Sum-all-reduce the flat gradient buffers of a fused optimiser.
 
-    ``chunk_mb`` bounds one collective's payload; config 2's whole gradient
-    (33 MB) goes out as a single message.
+    ``overlap`` (default: on when the world size is > 1, ``ADELL_DDP_OVERLAP=0`` turns it off)
+    issues the collectives bucket by bucket from backward hooks; otherwise the whole buffer
+    goes out in ``chunk_mb`` messages when ``all_reduce()`` is called.
     """
 
-    def __init__(self, optimizer, chunk_mb=64, async_op=False):
+    def __init__(self, optimizer, chunk_mb=64, async_op=False, overlap=None, n_buckets=None,
+                 min_bucket_elems=None):
         self.optimizer = optimizer
         self.chunk = int(chunk_mb * 1024 * 1024 // 4)
         self.async_op = async_op
         self.world = world_size()
         for g in optimizer.param_groups:
             g["grad_scale"] = 1.0 / self.world
+        if overlap is None:
+            overlap = self.world > 1 and os.environ.get("ADELL_DDP_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and self.world > 1
+        self.buckets, self._handles, self._hooks = [], [], []
+        if self.overlap:
+            nb = int(os.environ.get("ADELL_DDP_BUCKETS", "4")) if n_buckets is None else n_buckets
+            me = (1 << 20) if min_bucket_elems is None else min_bucket_elems
+            self._install(nb, me)
 
+    # ---- bucketed, overlapped path --------------------------------------------------------
+    def _install(self, n_buckets, min_elems):
+        for flat in self.optimizer.flat_groups:
+            sizes = [e - o for o, e in zip(flat.offsets, flat.ends)]
+            for lo, hi in plan_buckets(sizes, n_buckets, min_elems):
+                b = _Bucket(flat, lo, hi)
+                self.buckets.append(b)
+                for i in range(lo, hi):
+                    self._hooks.append(
+                        flat.params[i].register_post_accumulate_grad_hook(self._make_hook(b)))
+
+    def _make_hook(self, bucket):
+        def hook(_param):
+            bucket.pending -= 1
+            if bucket.pending == 0 and not bucket.sent:
+                self._send(bucket)
+        return hook
+
+    def _send(self, b):
+        b.flat.collect(range(b.lo, b.hi))
+        b.sent = True
+        if b.e1 > b.e0:
+            self._handles.append(dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
+                                                 async_op=True))
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    # ---- public ---------------------------------------------------------------------------
     def broadcast_parameters(self, src=0, module=None):
         """Rank ``src``'s parameters everywhere; with ``module`` also the tensors that are
         not in the optimiser's flat buffers (frozen parameters, buffers), as DDP does at
@@ -82,13 +159,25 @@ class GradSync:
         if module is not None:
             flat_ids = {id(p) for f in self.optimizer.flat_groups for p in f.params}
             for t in list(module.parameters()) + list(module.buffers()):
-                if id(t) not in flat_ids:
+                if id(t) not in flat_ids and t.numel() > 0:
                     dist.broadcast(t.data, src=src)
         from . import ops
 
         ops._weights_changed()
 
     def all_reduce(self):
+        """Complete the gradient exchange of this step: after it returns (stream-ordered), every
+        flat gradient buffer holds the sum over ranks."""
+        if self.overlap:
+            for b in self.buckets:           # buckets that a gradient-less parameter held back
+                if not b.sent:
+                    self._send(b)
+            for h in self._handles:
+                h.wait()
+            self._handles = []
+            for b in self.buckets:
+                b.pending, b.sent = b.hi - b.lo, False
+            return
         collect = getattr(self.optimizer, "collect_grads", None)
         if collect is not None:
             collect()

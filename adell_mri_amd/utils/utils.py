@@ -1,4 +1,4 @@
-"""``ExponentialMovingAverage`` (mirror of adell_mri/utils/utils.py:396-522).
+"""``loss_factory`` (adell_mri/utils/utils.py:39-59) and ``ExponentialMovingAverage`` (mirror of adell_mri/utils/utils.py:396-522).
 
 Same contract: the first ``update(model)`` deep-copies the model into ``self.shadow``
 (eval mode, requires_grad False), later calls apply
@@ -14,6 +14,40 @@ from copy import deepcopy
 import torch
 
 from .. import ops
+from ..modules.segmentation import losses as _seg_losses
+
+
+def _not_built(name):
+    def raiser(*args, **kwargs):
+        raise NotImplementedError(f"loss {name!r} has no HIP kernel yet (built: binary dice, "
+                                  f"binary focal, categorical cross-entropy / dice / focal)")
+    raiser.__name__ = name
+    return raiser
+
+
+# adell_mri/utils/utils.py:39-59: name -> loss function, per target family. Entries without a
+# HIP implementation raise on call (no eager-torch fallback) but keep the key set, so that
+# configuration files are validated the same way.
+loss_factory = {
+    "binary": {
+        "cross_entropy": _not_built("binary_cross_entropy"),
+        "focal": _seg_losses.binary_focal_loss,
+        "dice": _seg_losses.binary_generalized_dice_loss,
+        "tversky_focal": _not_built("binary_focal_tversky_loss"),
+        "combo": _not_built("combo_loss"),
+        "hybrid_focal": _not_built("hybrid_focal_loss"),
+        "unified_focal": _not_built("unified_focal_loss"),
+    },
+    "categorical": {
+        "cross_entropy": _not_built("cat_cross_entropy"),
+        "focal": _not_built("mc_focal_loss"),
+        "dice": _not_built("mc_generalized_dice_loss"),
+        "tversky_focal": _not_built("mc_focal_tversky_loss"),
+        "combo": _not_built("mc_combo_loss"),
+        "hybrid_focal": _not_built("mc_hybrid_focal_loss"),
+        "unified_focal": _not_built("mc_unified_focal_loss"),
+    },
+}
 
 
 class ExponentialMovingAverage(torch.nn.Module):

@@ -1,127 +1,241 @@
 #!/usr/bin/env python
 """Headline benchmark: training volumes/s of the 3-D U-Net of BASELINE config 2
-(sample_configs/u-net-3d-resnet.yaml: regular-conv encoder, residual links,
-instance norm, swish, transposed-conv decoder) on synthetic 2-channel 128^3
-volumes; one step = forward + dice/focal loss + backward + SGD-Nesterov step.
+(configs/u-net-3d-resnet.yaml = the reference's sample_configs/u-net-3d-resnet.yaml: regular-conv
+encoder, residual links, instance norm, swish, transposed-conv decoder) on synthetic 2-channel
+128^3 volumes; one step = forward + dice/focal loss + backward + SGD-Nesterov step. The module
+is built the way the reference's entrypoint builds it: YAML -> ``parse_config_unet`` ->
+``get_segmentation_network("unet", ...)``.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job
-volumes/s, plus `roofline` for the dominant kernel (per-launch HIP-event timing
-inside the timed region) and `cpu_baseline` (the torch-CPU oracle on a bounded
-sample, rank 0, N=1 only).
+Started without torchrun and with --gpus N > 1, it launches the N ranks itself (child
+``torch.distributed.run`` process, before anything touches the GPU) and relays rank 0's line.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job volumes/s over the
+timed K steps, plus
+
+* ``roofline``: the dominant MFMA kernel family (per-launch HIP-event timing inside the timed
+  region), with ``hbm`` = the dominant HBM-bound family (the fused norm/dropout/activation
+  kernels) against 8 TB/s and ``step_frac`` = whole-step algorithmic FLOPs / step time / ceiling;
+* ``cpu_baseline``: the stock-torch CPU oracle (rank 0, N = 1 only), 1 warm-up + 3 timed
+  training steps on the host's physical cores, and a one-thread figure on a 64^3 volume;
+* ``fp32_mfma``: the same step on the bit-exact fp32-MFMA kernels (secondary figure);
+* ``median_ms_per_step``: median of per-step HIP-event times; ``value`` keeps
+  the contract's definition (all K steps between two barriers).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-CFG2 = dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
-            upscale_type="transpose", norm_type="instance", interpolation="bilinear", padding=1,
-            dropout_param=float(os.environ.get("ADELL_BENCH_DROPOUT", "0.15")),  # config value 0.15
-            in_channels=2, n_classes=2, depth=[32, 32, 64, 128, 256],
-            kernel_sizes=[3] * 5, strides=[2] * 5)
-LOSS = dict(smooth=1e-5, dice_eps=1e-6, gamma=1.0, focal_eps=1e-6)
-LR, WD = 5e-4, 5e-3
+CONFIG = os.path.join(ROOT, "configs", "u-net-3d-resnet.yaml")
+KEYS = ["image", "image_1"]          # two image keys x in_channels 1 = the 2-channel input
 # /opt/skills/guides/MI355X_MICROARCH.md: "Peak FP32 (matrix)" and "Peak BF16/FP16 MFMA ~2.5 PF dense".
 # The f16x3 kernels execute 3 f16 MFMA FLOPs per algorithmic (fp32-equivalent) FLOP, so the
 # algorithmic ceiling of that path is 2500 / 3.
 FP32_MFMA_PEAK_TFLOPS = 157.3
 F16_MFMA_PEAK_TFLOPS = 2500.0
 F16X3_ALGORITHMIC_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3.0
+HBM_PEAK_TBS = 8.0
 
 
-def build_module(device, size):
-    from adell_mri_amd.modules.activations import activation_factory
-    from adell_mri_amd.modules.segmentation.losses import (CompoundLoss, binary_focal_loss,
-                                                           binary_generalized_dice_loss)
-    from adell_mri_amd.modules.segmentation.pl import UNetPL
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--shape", type=str, default=None,
+                    help="D,H,W of the synthetic volumes (e.g. 256,256,128); overrides --size")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="volumes per GPU per step (default: batch_size of the YAML = 2; "
+                         "SURVEY.md 8(d): B per GPU in {1, 2})")
+    ap.add_argument("--config", type=str, default=CONFIG)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-MFMA secondary figure")
+    ap.add_argument("--cpu-size", type=int, default=128,
+                    help="edge of the volume the CPU oracle is timed on with all cores")
+    return ap.parse_args()
 
-    loss = CompoundLoss([
-        (binary_generalized_dice_loss, {"smooth": LOSS["smooth"], "eps": LOSS["dice_eps"]}),
-        (binary_focal_loss, {"gamma": LOSS["gamma"], "eps": LOSS["focal_eps"]}),
-    ])
-    torch.manual_seed(0)
-    net = UNetPL(image_key="image", label_key="mask", optimizer_str="sgd", learning_rate=LR,
-                 weight_decay=WD, batch_size=1, n_epochs=100, loss_fn=loss,
-                 activation_fn=activation_factory["swish"], **CFG2)
-    return net.to(device)
+
+def launch_ranks(args):
+    """--gpus N > 1 without torchrun: start the ranks as a child process (never re-exec this
+    one) and pass rank 0's JSON line through."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+           str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def _shape(size):
     return (size, size, size) if isinstance(size, int) else tuple(size)
 
 
+def build_module(device, config=CONFIG):
+    """YAML -> parse_config_unet -> get_segmentation_network, as entrypoints/segmentation/
+    train.py:736 does (no SSL backbone: encoding_operations = [None])."""
+    import torch
+
+    from adell_mri_amd.modules.config_parsing import parse_config_unet
+    from adell_mri_amd.utils.network_factories import get_segmentation_network
+
+    cfg, loss_keys = parse_config_unet(config, len(KEYS), 2)
+    if "ADELL_BENCH_DROPOUT" in os.environ:     # profiling aid; the YAML ships 0.15
+        cfg["dropout_param"] = float(os.environ["ADELL_BENCH_DROPOUT"])
+    torch.manual_seed(0)
+    net = get_segmentation_network(
+        net_type="unet", network_config=cfg, bottleneck_classification=False,
+        clinical_feature_keys=[], all_aux_keys=[], clinical_feature_params=None,
+        clinical_feature_key_net=None, aux_key_net=None, max_epochs=100,
+        encoding_operations=[None], picai_eval=False, lr_encoder=None, encoder_checkpoint=None,
+        res_config_file=None, deep_supervision=False, n_classes=2, keys=KEYS,
+        optimizer_str="sgd")
+    return net.to(device), loss_keys
+
+
 def synthetic_batch(batch, size, device, seed):
+    import torch
+
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.rand((batch, 2, *_shape(size)), generator=g)
     y = (torch.rand((batch, 1, *_shape(size)), generator=g) > 0.9).float()
     return {"image": x.to(device), "mask": y.to(device)}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, workload):
     """Mean HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_traffic.json, made by tools/pmc_traffic.py from separate
-    ``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` runs of this script; gfx950 correction
-    2*FETCH + WRITE as MI355X_MICROARCH.md prescribes). None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    (tools/pmc_traffic.py: separate ``--pmc FETCH_SIZE`` / ``--pmc WRITE_SIZE`` runs of this
+    script; gfx950 correction 2*FETCH + WRITE as MI355X_MICROARCH.md prescribes). Offline
+    figure: returned only when the profile was taken on the same workload, else None."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if not (name.startswith("r") and name.endswith("_pmc_traffic.json")):
+            continue
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                d = json.load(fh)
+            if d.get("workload") != workload:
+                continue
+            k = d["kernels"].get(kernel)
+            return None if k is None else (float(k["traffic_bytes_mean"]), name)
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def host_cpu():
+    """(model name, logical CPUs visible, physical cores usable by this process)."""
+    model, cores = "unknown", set()
     try:
-        with open(path) as fh:
-            k = json.load(fh)["kernels"].get(kernel)
-        return None if k is None else float(k["traffic_bytes_mean"])
-    except (OSError, ValueError, KeyError):
-        return None
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    physical = min(len(cores) or usable, usable)
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs quota) bounds what the process can
+    # really run in parallel: more threads than that only oversubscribe
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, \
+                    open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = float(fq.read()), float(fp.read())
+                quota = None if q <= 0 else q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        physical = min(physical, max(1, int(quota)))
+    return model, os.cpu_count() or 1, max(1, physical)
 
 
-def cpu_baseline(size, threads):
-    """One training step of the stock-torch CPU oracle (oracle/torch_ref) at size^3."""
+def cpu_training_steps(cfg_kwargs, size, threads, warmup, steps):
+    """Median time of one training step (fwd + dice/focal + bwd + SGD-Nesterov) of the
+    stock-torch CPU oracle (oracle/torch_ref) on one 2-channel size^3 volume."""
+    import torch
+
+    from adell_mri_amd.modules.segmentation.unet import UNet
     from oracle.torch_ref.unet import UNetOracle, compound_loss
     from oracle.weights import tensor_for
-    from adell_mri_amd.modules.segmentation.unet import UNet
 
     torch.set_num_threads(threads)
-    keys = {k: tuple(v.shape) for k, v in
-            UNet(activation_fn=torch.nn.SiLU, **CFG2).state_dict().items()}
+    keys = {k: tuple(v.shape) for k, v in UNet(**cfg_kwargs).state_dict().items()}
     sd = {k: torch.from_numpy(tensor_for(k, s)) for k, s in keys.items()}
-    cfg = dict(depth=CFG2["depth"], kernel_sizes=CFG2["kernel_sizes"], strides=CFG2["strides"],
-               padding=1, norm_type="instance", activation="swish", link_type="residual",
-               n_classes=2, dropout_param=CFG2["dropout_param"])
+    cfg = dict(depth=cfg_kwargs["depth"], kernel_sizes=cfg_kwargs["kernel_sizes"],
+               strides=cfg_kwargs["strides"], padding=cfg_kwargs["padding"],
+               norm_type=cfg_kwargs["norm_type"], activation="swish",
+               link_type=cfg_kwargs["link_type"], n_classes=2,
+               dropout_param=cfg_kwargs["dropout_param"])
     net = UNetOracle(sd, cfg).requires_grad_(True)
     net.training = True
-    opt = torch.optim.SGD(net.parameters(), lr=LR, momentum=0.99, weight_decay=WD, nesterov=True)
+    opt = torch.optim.SGD(net.parameters(), lr=5e-4, momentum=0.99, weight_decay=5e-3,
+                          nesterov=True)
     b = synthetic_batch(1, size, "cpu", 42)
+    times = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        prob = net.forward(b["image"], return_logits=False)
+        loss = compound_loss(prob, b["mask"])
+        loss.backward()
+        opt.step()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    return statistics.median(times), torch.get_num_threads()
+
+
+def timed_steps(runner, batch, steps, barrier, per_step_events=True):
+    import torch
+
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step_events else None
     t0 = time.perf_counter()
-    opt.zero_grad()
-    prob = net.forward(b["image"], return_logits=False)
-    loss = compound_loss(prob, b["mask"])
-    loss.backward()
-    opt.step()
-    return time.perf_counter() - t0
+    loss = None
+    for i in range(steps):
+        if evs:
+            evs[i].record()
+        loss = runner.train_step(batch)
+    if evs:
+        evs[steps].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)] if evs else []
+    return dt, loss, per
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--shape", type=str, default=None,
-                    help="D,H,W of the synthetic volumes (e.g. 256,256,128); overrides --size")
-    ap.add_argument("--batch", type=int, default=2,
-                    help="volumes per GPU per step (u-net-3d-resnet.yaml:16 ships batch_size: 2; "
-                         "SURVEY.md 8(d): B per GPU in {1, 2})")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-size", type=int, default=128,
-                    help="edge of the one volume the CPU oracle is timed on (128: the workload's own "
-                         "volume size, ~10-15 s on 16 threads)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
+    import torch
 
     from adell_mri_amd import functional as HF
     from adell_mri_amd import ops
@@ -129,7 +243,7 @@ def main():
     from adell_mri_amd.trainer import StepRunner
 
     rank, world, local_rank = init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # ADELL_SINGLE_GPU_REHEARSAL=1 (with ADELL_DIST_BACKEND=gloo): all ranks on device 0, to run the
     # multi-rank code path on a one-GPU box; never set by the driver
@@ -138,19 +252,22 @@ def main():
 
     shape = _shape(args.size) if args.shape is None else tuple(int(v) for v in args.shape.split(","))
     shape_str = "x".join(str(v) for v in shape) if len(set(shape)) > 1 else f"{shape[0]}^3"
-    net = build_module(device, shape)
+    net, loss_keys = build_module(device, args.config)
     net.train()
+    per_gpu_batch = args.batch if args.batch is not None else int(net.batch_size)
     opt = net.configure_optimizers()["optimizer"]
-    runner = StepRunner(net, opt, GradSync(opt))
-    batch = synthetic_batch(args.batch, shape, device, 42 + rank)
+    sync = GradSync(opt)
+    runner = StepRunner(net, opt, sync)
+    batch = synthetic_batch(per_gpu_batch, shape, device, 42 + rank)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (untimed): every MFMA kernel family is event-timed to find the dominant one; the
-    # timed region then carries events for that family only (fewer markers in the stream)
+    # warm-up (untimed): every instrumented kernel family is event-timed to find the dominant
+    # MFMA one; the timed region then carries events for that family and the HBM-bound
+    # norm/activation family only (fewer markers in the stream)
     ops.KERNEL_TIMER = ops.KernelTimer()
     for _ in range(args.warmup):
         runner.train_step(batch)
@@ -158,60 +275,120 @@ def main():
     warm, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     dom_warm = warm.dominant() if args.warmup > 0 else None
     warm_summary = warm.summary() if args.warmup > 0 else {}
-    ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = runner.train_step(batch)
+    ops.KERNEL_TIMER = ops.KernelTimer(
+        only=None if dom_warm is None else {dom_warm[0], ops.NORM_ACT_FAMILY})
     barrier()
-    dt = time.perf_counter() - t0
+    dt, loss, per_step = timed_steps(runner, batch, args.steps, barrier)
     timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     dt = reduce_max(dt, device)
     loss_value = float(loss.detach().cpu())
 
+    f16 = HF.CONV_PRECISION != "fp32"
+    fp32_line = None
+    if not args.no_fp32 and f16:
+        # secondary figure: the same step on the bit-exact fp32-MFMA conv kernels
+        HF.set_conv_precision("fp32")
+        for _ in range(2):
+            runner.train_step(batch)
+        barrier()
+        n32 = max(3, min(args.steps, 5))
+        dt32, _, _ = timed_steps(runner, batch, n32, barrier, per_step_events=False)
+        dt32 = reduce_max(dt32, device)
+        HF.set_conv_precision("f16x3")
+        fp32_line = {"value": per_gpu_batch * world * n32 / dt32, "unit": "volumes/s",
+                     "ms_per_step": 1e3 * dt32 / n32, "steps": n32,
+                     "dtype": "f32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains)"}
+
     if rank != 0:
         return
-    vols = args.batch * world * args.steps
+    vols = per_gpu_batch * world * args.steps
+    workload = (f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{shape_str}, "
+                f"batch {per_gpu_batch}/GPU, {'+'.join(loss_keys)}, SGD-Nesterov")
     out = {
         "metric": f"volumes/sec 3D U-Net {shape_str} 2-ch seg (train step: fwd+loss+bwd+SGD)",
         "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if HF.CONV_PRECISION == "fp32" else "f32 (f16x3 split MFMA, fp32 accumulate)",
+        "dtype": "f32 (f16x3 split MFMA, fp32 accumulate)" if f16 else "f32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{shape_str}, "
-                               f"batch {args.batch}/GPU, dice+focal, SGD-Nesterov",
-                   "per_gpu_batch": args.batch, "size": list(shape), "parallelism": f"dp{world}"},
+        "config": {"workload": workload, "per_gpu_batch": per_gpu_batch, "size": list(shape),
+                   "parallelism": f"dp{world}", "yaml": os.path.relpath(args.config, ROOT),
+                   "built_by": "parse_config_unet -> get_segmentation_network('unet')",
+                   "gradient_exchange": ("none (1 rank)" if world == 1 else
+                                         f"{len(sync.buckets)} bucket all-reduces issued from "
+                                         f"backward hooks" if sync.overlap else
+                                         "one all-reduce after backward")},
         "final_loss": loss_value,
     }
+    if per_step:
+        med = statistics.median(per_step)
+        out["median_ms_per_step"] = med
+        out["value_median"] = per_gpu_batch * world / (med * 1e-3)
+    if fp32_line is not None:
+        out["fp32_mfma"] = fp32_line
     dom = timer.dominant()
     if dom is not None:
         name, flops, ms, launches = dom
         achieved = flops / (ms * 1e-3) / 1e12
-        f16 = "f16" in name
-        peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
-        out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved,
-                           "peak": peak, "unit": "TFLOP/s",
-                           "frac": achieved / peak, "traffic": pmc_traffic(name),
-                           "traffic_unit": "bytes per launch (mean; rocprofv3 PMC 2*FETCH_SIZE + "
-                                           "WRITE_SIZE, profiles/r01_pmc_traffic.json)",
-                           "algorithmic_bytes_per_launch":
-                               timer.summary()[name]["algorithmic_bytes"] / launches,
-                           "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product"
-                                          if f16 else "fp32 matrix peak"),
-                           "executed_mfma_tflops": achieved * (3.0 if f16 else 1.0),
-                           "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
-                           "launches": launches, "avg_launch_ms": ms / launches,
-                           "kernel_time_share": timer.share(name, 1e3 * dt),
-                           "all_kernels_warmup": warm_summary}
+        kf16 = "f16" in name
+        peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if kf16 else FP32_MFMA_PEAK_TFLOPS
+        traffic = pmc_traffic(name, workload)
+        roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak,
+                "traffic": None if traffic is None else traffic[0],
+                "traffic_source": None if traffic is None else
+                f"offline rocprofv3 PMC passes of this workload (profiles/{traffic[1]}): mean bytes "
+                f"per launch, 2*FETCH_SIZE + WRITE_SIZE",
+                "algorithmic_bytes_per_launch":
+                    timer.summary()[name]["algorithmic_bytes"] / launches,
+                "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product"
+                               if kf16 else "fp32 matrix peak"),
+                "executed_mfma_tflops": achieved * (3.0 if kf16 else 1.0),
+                "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
+                "launches": launches, "avg_launch_ms": ms / launches,
+                "kernel_time_share": timer.share(name, 1e3 * dt)}
+        # whole step: algorithmic FLOPs of every instrumented MFMA / conv family (from the
+        # warm-up census, per step) over the measured step time, against the same ceiling
+        if args.warmup > 0:
+            step_flops = sum(v["flops"] for v in warm_summary.values()) / args.warmup
+            roof["step_frac"] = step_flops / (dt / args.steps) / 1e12 / peak
+            roof["step_algorithmic_tflop"] = step_flops / 1e12
+        hb = timer.summary().get(ops.NORM_ACT_FAMILY)
+        if hb is not None and hb["ms"] > 0:
+            tbs = hb["algorithmic_bytes"] / (hb["ms"] * 1e-3) / 1e12
+            roof["hbm"] = {"bound": "hbm", "kernel": ops.NORM_ACT_FAMILY + " (fused norm -> dropout "
+                           "-> activation, forward + backward)", "achieved": tbs * 1e3,
+                           "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": tbs / HBM_PEAK_TBS,
+                           "launches": hb["launches"],
+                           "ms_per_step": hb["ms"] / args.steps,
+                           "time_share": timer.share(ops.NORM_ACT_FAMILY, 1e3 * dt),
+                           "algorithmic_bytes_per_step": hb["algorithmic_bytes"] / args.steps}
+        roof["all_kernels_warmup"] = warm_summary
+        out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline:
-        threads = max(1, min(os.cpu_count() or 1, 16))
-        t = cpu_baseline(args.cpu_size, threads)
-        scale = args.cpu_size ** 3 / float(shape[0] * shape[1] * shape[2])
+        from adell_mri_amd.modules.config_parsing import parse_config_unet
+
+        cfg, _ = parse_config_unet(args.config, len(KEYS), 2)
+        kw = {k: cfg[k] for k in ("spatial_dimensions", "conv_type", "link_type", "upscale_type",
+                                  "norm_type", "interpolation", "padding", "dropout_param",
+                                  "activation_fn", "in_channels", "depth", "kernel_sizes",
+                                  "strides")}
+        model, logical, physical = host_cpu()
+        t_all, used = cpu_training_steps(kw, args.cpu_size, physical, 1, 3)
+        small = min(64, args.cpu_size)
+        t_one, _ = cpu_training_steps(kw, small, 1, 0, 1)
+        vox = float(shape[0] * shape[1] * shape[2])
         out["cpu_baseline"] = {
-            "value": scale / t, "unit": "volumes/s", "cores": threads, "kind": "port",
-            "sample": f"1 training step (fwd + loss + bwd + SGD) of the stock-torch CPU oracle on one "
-                      f"2-channel {args.cpu_size}^3 volume ({t:.2f} s)"
-                      + ("" if scale == 1.0 else f", scaled by voxel count to {shape_str}")}
+            "value": (args.cpu_size ** 3 / vox) / t_all, "unit": "volumes/s", "cores": used,
+            "kind": "port", "cpu_model": model, "os_cpu_count": logical,
+            "torch_num_threads": used,
+            "sample": f"stock-torch CPU oracle (oracle/torch_ref), one 2-channel {args.cpu_size}^3 "
+                      f"volume per step: 1 warm-up + 3 timed training steps (fwd + dice/focal + bwd "
+                      f"+ SGD-Nesterov), median {t_all:.2f} s/step on {used} threads"
+                      + ("" if args.cpu_size ** 3 == vox else f", scaled by voxel count to {shape_str}"),
+            "one_thread": {"value": (small ** 3 / vox) / t_one, "unit": "volumes/s", "cores": 1,
+                           "sample": f"1 training step on one {small}^3 volume ({t_one:.2f} s), "
+                                     f"scaled by voxel count to {shape_str}"}}
     print(json.dumps(out))
 
 

@@ -461,8 +461,141 @@ def gen_ssl():
     print("ssl ok: loss", float(loss.detach()), "terms", [float(t.detach()) for t in losses],
           "y1 std over batch", float(y1.detach().std(0).mean()))
 
+FULL_CFG2 = dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                 upscale_type="transpose", norm_type="instance", padding=1, dropout_param=0.15,
+                 activation_fn="swish", in_channels=2, n_classes=2, depth=[32, 32, 64, 128, 256],
+                 kernel_sizes=[3] * 5, strides=[2] * 5)
+FULL_CASES = {
+    # BASELINE config 2 at the size bench.py runs ("Full-size configs: only
+    # statistics + 64 sampled voxels"). name: (kwargs, input shape, with gradients?)
+    "unet3d_cfg2_full": (FULL_CFG2, (1, 2, 128, 128, 128), True),
+    # north_star's 256x256x128 variant: forward only (the eager reference's backward at this
+    # size did not finish in 15 minutes / 2 CPU-hours in the build container and was stopped)
+    "unet3d_cfg2_full_256x256x128": (FULL_CFG2, (1, 2, 256, 256, 128), False),
+}
+from oracle.fullsize import FULL_SEED, full_inputs, sample_positions, zlib_crc  # noqa: E402
+
+
+def gen_full(name, kw, shape, with_grads):
+    """Reference UNet.forward (unet.py:751-843) + dice/focal + backward at the benchmark's size,
+    eval() (dropout off; instance norm is mode-independent). Stores statistics and sampled values
+    only: logits mean/std/min/max + 64 sampled voxels + a 128-entry line, loss terms, and for
+    every parameter the gradient's L2 norm, absolute maximum and 16 sampled entries."""
+    import time
+    torch.manual_seed(0)
+    x, y = full_inputs(shape)
+    net = make_unet(kw).eval()
+    out = {"seed": np.array(FULL_SEED), "shape": np.array(shape),
+           "x_checksum": np.array([float(x.double().sum()), float(y.double().sum())])}
+    t0 = time.time()
+    if with_grads:
+        logits = net(x, return_logits=True)[0]
+    else:
+        with torch.no_grad():
+            logits = net(x, return_logits=True)[0]
+    print(name, "forward", round(time.time() - t0, 1), "s")
+    lg = logits.detach()
+    flat = lg.reshape(-1)
+    pos = sample_positions(flat.numel(), 64, 1)
+    out["logit_stats"] = np.array([float(lg.double().mean()), float(lg.double().std()),
+                                   float(lg.min()), float(lg.max()),
+                                   float(lg.double().abs().mean())])
+    out["logit_pos"], out["logit_val"] = pos, flat[pos].numpy().copy()
+    # one full line through the middle of the volume and the eight corners (edge handling)
+    mid = [s // 2 for s in shape[2:]]
+    out["logit_line"] = lg[0, 0, mid[0], mid[1], :].numpy().copy()
+    out["logit_corners"] = lg[0, 0][::shape[2] - 1, ::shape[3] - 1, ::shape[4] - 1].numpy().copy()
+    prob = torch.sigmoid(logits)
+    d = binary_generalized_dice_loss(prob, y, smooth=1e-5, eps=1e-6)
+    f = binary_focal_loss(prob, y, gamma=1.0, eps=1e-6)
+    loss = torch.stack([d.mean(), f.mean()]).mean()
+    out["dice"], out["focal"] = d.detach().numpy(), f.detach().numpy()
+    out["loss"] = loss.detach().numpy()
+    if with_grads:
+        # the reference's own probability output (final_layer's Sigmoid, unet.py:641-655) equals
+        # sigmoid(logits); the loss is taken on it as pl.py:284-317 does
+        t0 = time.time()
+        net.zero_grad()
+        loss.backward()
+        print(name, "backward", round(time.time() - t0, 1), "s")
+        keys = []
+        for k, p in net.named_parameters():
+            if p.grad is None:
+                continue
+            gflat = p.grad.reshape(-1)
+            gp = sample_positions(gflat.numel(), 16, zlib_crc(k))
+            out["gnorm:" + k] = np.array([float(gflat.double().norm()), float(gflat.abs().max())])
+            out["gpos:" + k], out["gval:" + k] = gp, gflat[gp].numpy().copy()
+            keys.append(k)
+        out["grad_keys"] = np.array(keys)
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "params", sum(p.numel() for p in net.parameters()), "loss", float(loss),
+          "logit stats", out["logit_stats"])
+
+
+SURFACE_CASES = {
+    # name: (net_type, sample YAML, image size the entrypoint would pass, number of image keys)
+    "unet": ("unet", "u-net-3d-resnet.yaml", None, 2),
+    "unetpp": ("unetpp", "u-net-3d-resnet.yaml", None, 2),
+    "unetr": ("unetr", "unetr.yaml", [96, 96, 96], 1),
+    "swin": ("swin", "unet-swin.yaml", [256, 256, 128], 2),
+}
+
+
+def gen_surface():
+    """What ``get_segmentation_network`` (network_factories.py:493-701) makes of every sample
+    YAML: the factory itself imports Lightning (absent), so the reference's *network classes*
+    are built with the keyword arguments the factory would splat -- the YAML through
+    ``parse_config_unet``'s documented steps (config_parsing.py:30-58; ``n_channels`` read as
+    ``in_channels``) plus the factory's model-side boilerplate (:587-604) -- and the
+    state_dict key / shape lists are stored. tests/test_config_surface.py compares the HIP
+    package's factory output with them."""
+    import json
+    import yaml
+    classes = {"unet": UNet, "unetpp": UNetPlusPlus, "unetr": UNETR, "swin": SWINUNet}
+    out = {}
+    for name, (net_type, fname, size, n_keys) in SURFACE_CASES.items():
+        with open(os.path.join(REF, "sample_configs", fname)) as fh:
+            cfg = yaml.safe_load(fh)
+        cfg["in_channels"] = n_keys * cfg.pop("n_channels")
+        cfg["activation_fn"] = activation_factory[cfg["activation_fn"]]
+        cfg.setdefault("spatial_dimensions", 3)
+        train_only = {k: cfg.pop(k) for k in ("learning_rate", "batch_size", "weight_decay",
+                                              "loss_fn")}
+        model_kw = dict(n_classes=2, bottleneck_classification=False, skip_conditioning=0,
+                        feature_conditioning=0, feature_conditioning_params=None)
+        if net_type != "unetpp":
+            model_kw["deep_supervision"] = False
+        if net_type in ("unet", "unetpp"):
+            model_kw["encoding_operations"] = None
+        if net_type in ("unetr", "swin"):
+            cfg["image_size"] = size[:cfg["spatial_dimensions"]]
+        if net_type == "unetr":
+            cfg["patch_size"] = cfg["patch_size"][:cfg["spatial_dimensions"]]
+        torch.manual_seed(0)
+        net = classes[net_type](**model_kw, **cfg)
+        sd = net.state_dict()
+        out[name] = {"yaml": fname, "n_keys": n_keys, "size": size,
+                     "train_only": {k: v for k, v in train_only.items() if k != "loss_fn"},
+                     "loss_fn": train_only["loss_fn"],
+                     "n_parameters": sum(p.numel() for p in net.parameters()),
+                     "state_dict": [[k, list(v.shape)] for k, v in sd.items()]}
+        print(name, out[name]["n_parameters"], len(sd))
+    with open(os.path.join(OUT, "factory_surface.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "surface":
+        gen_surface()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        for name, (kw, shape, wg) in FULL_CASES.items():
+            if len(sys.argv) > 2 and sys.argv[2] != name:
+                continue
+            gen_full(name, kw, shape, wg)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ssl":
         gen_ssl()
         sys.exit(0)

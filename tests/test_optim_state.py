@@ -1,0 +1,102 @@
+"""Fused optimisers: torch.optim-compatible state_dict round trip (CPU: no kernel launch is
+needed to load / save), and on the GPU the step after a load and the treatment of parameters
+without a gradient against torch.optim itself (reference: torch.optim.SGD / AdamW as configured
+at adell_mri/modules/segmentation/pl.py:563-569, self_supervised/pl.py:245-250)."""
+import copy
+import io
+
+import pytest
+import torch
+
+from adell_mri_amd.optim import FusedAdamW, FusedSGD
+
+
+def _model():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    m.frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+    m.unused = torch.nn.Parameter(torch.full((7,), 2.0))
+    return m
+
+
+def _torch_steps(m, make, n):
+    opt = make(m.parameters())
+    g = torch.Generator().manual_seed(1)
+    for _ in range(n):
+        opt.zero_grad()
+        m(torch.randn(4, 6, generator=g)).pow(2).mean().backward()
+        opt.step()
+    return opt
+
+
+SGD = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.01)
+ADAMW = dict(lr=0.01, betas=(0.8, 0.9), eps=1e-6, weight_decay=0.1)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+def test_load_torch_state_dict_keeps_parameters_aliased_and_round_trips(kind):
+    m = _model()
+    topt = _torch_steps(m, (lambda p: torch.optim.SGD(p, **SGD)) if kind == "sgd"
+                        else (lambda p: torch.optim.AdamW(p, **ADAMW)), 2)
+    sd = topt.state_dict()
+    m2 = copy.deepcopy(m)
+    fused = FusedSGD(m2.parameters(), lr=1.0, momentum=0.5) if kind == "sgd" \
+        else FusedAdamW(m2.parameters(), lr=1.0)
+    flat = fused.flat_groups[0]
+    assert "_flat" not in fused.param_groups[0]
+    fused.load_state_dict(sd)
+    # parameters still alias the flat buffer after the load
+    for p, o in zip(flat.params, flat.offsets):
+        assert p.data_ptr() == flat.data.data_ptr() + 4 * o
+    assert fused.flat_groups[0] is flat
+    g = fused.param_groups[0]
+    assert g["lr"] == (SGD if kind == "sgd" else ADAMW)["lr"]
+    out = fused.state_dict()
+    assert [pg["params"] for pg in out["param_groups"]] == [pg["params"] for pg in sd["param_groups"]]
+    assert set(out["state"]) == set(sd["state"])        # frozen / unused parameters: no state
+    for pid, ent in sd["state"].items():
+        for k, v in ent.items():
+            got = out["state"][pid][k]
+            if torch.is_tensor(v):
+                assert torch.equal(got.reshape(v.shape).to(v.dtype), v), (pid, k)
+    # and it survives torch.save / torch.load(weights_only=True) like a torch optimiser's
+    buf = io.BytesIO()
+    torch.save(out, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=True)
+    fused.load_state_dict(again)
+    assert set(fused.state_dict()["state"]) == set(sd["state"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+def test_step_after_load_and_gradientless_parameters_match_torch(cuda, kind):
+    make = (lambda p: torch.optim.SGD(p, **SGD)) if kind == "sgd" else \
+        (lambda p: torch.optim.AdamW(p, **ADAMW))
+    m = _model()
+    topt = _torch_steps(m, make, 2)
+    m2 = copy.deepcopy(m).to(cuda)
+    fused = (FusedSGD if kind == "sgd" else FusedAdamW)(m2.parameters())
+    fused.load_state_dict(topt.state_dict())
+    g = torch.Generator().manual_seed(9)
+    for _ in range(2):
+        x = torch.randn(4, 6, generator=g)
+        topt.zero_grad()
+        m(x).pow(2).mean().backward()
+        topt.step()
+        fused.zero_grad()
+        m2(x.to(cuda)).pow(2).mean().backward()
+        fused.step()
+    for (k, a), b in zip(m.named_parameters(), m2.parameters()):
+        assert torch.allclose(a, b.cpu(), rtol=2e-5, atol=1e-6), k
+    # no gradient -> untouched (no weight decay, no momentum), as torch.optim
+    assert torch.equal(m2.unused.detach().cpu(), torch.full((7,), 2.0))
+    # a parameter that starts receiving gradients later begins its own state then
+    for mm, opt in ((m, topt), (m2, fused)):
+        dev = next(mm.parameters()).device
+        opt.zero_grad()
+        (mm(torch.ones(2, 6, device=dev)).sum() + (mm.unused ** 2).sum()).backward()
+        opt.step()
+    assert torch.allclose(m.unused, m2.unused.cpu(), rtol=2e-5, atol=1e-6)
+    for (k, a), b in zip(m.named_parameters(), m2.parameters()):
+        assert torch.allclose(a, b.cpu(), rtol=2e-5, atol=1e-6), k

@@ -35,3 +35,39 @@ def test_two_rank_bench_prints_one_contract_line(cuda):
     # whole-job throughput: both ranks' volumes over the slowest rank's time
     assert abs(d["value"] - 2 * 1 * 2 / (2 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["frac"] > 0 and d["final_loss"] == d["final_loss"]
+
+
+@pytest.mark.gpu
+def test_two_rank_unet_equals_single_process_batch(cuda, tmp_path):
+    """The real small U-Net on two ranks (one fixture item each, bucketed all-reduce issued from
+    backward hooks, 1/world folded into the optimiser) == one process on the batch of two: the
+    averaged first-step gradients and the parameters after two SGD-Nesterov steps. Reference
+    semantics: torch DDP under entrypoints/segmentation/train.py:799-819."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ddp_worker
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ADELL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = ["timeout", "-k", "10", "240", sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "ddp_worker.py"), str(tmp_path)]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = [torch.load(tmp_path / f"rank{r}.pt") for r in range(2)]
+    g = np.load(os.path.join(ROOT, "tests", "golden", "unet3d_cfg2_small.npz"))
+    net = ddp_worker.build(cuda)
+    batch = {"image": torch.from_numpy(g["x"]).to(cuda), "mask": torch.from_numpy(g["y"]).to(cuda)}
+    grads, params, sync = ddp_worker.run(net, batch, 2)
+    assert not sync.overlap                      # world size 1: no hooks, no collectives
+    scale = float(grads.abs().max())
+    for r in range(2):
+        assert float((res[r]["grads"] - grads).abs().max()) < 2e-5 * scale
+        for k, p in params.items():
+            assert torch.allclose(res[r]["params"][k], p, rtol=1e-4, atol=2e-6), k
+    for k in params:
+        assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k

@@ -3,7 +3,11 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d <dirF> -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d <dirW> -- python3 bench.py ...
-    python tools/pmc_traffic.py <dirF> <dirW> profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py <dirF> <dirW> profiles/rNN_pmc_traffic.json <bench_line.json>
+
+The last argument is the JSON line bench.py printed in the profiled run: its
+``config.workload`` (shape, batch, loss, optimiser) and ``dtype`` are stored with the
+figures, and bench.py attaches a traffic figure only to a run of the same workload.
 
 Units / corrections as MI355X_MICROARCH.md "HBM" prescribes: the counters are in KiB; on gfx950
 FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the read side
@@ -35,7 +39,14 @@ def per_kernel(d, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+line = {}
+if len(sys.argv) > 4:
+    with open(sys.argv[4]) as fh:
+        for ln in fh:
+            if ln.startswith("{"):
+                line = json.loads(ln)
 out = {"unit": "bytes per launch (mean)",
+       "workload": line.get("config", {}).get("workload"), "dtype": line.get("dtype"),
        "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950: FETCH_SIZE counts 128-B requests "
                   "as 64 B; separate --pmc passes]", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -fetch[k][0]):
