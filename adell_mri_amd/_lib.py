@@ -145,7 +145,13 @@ SIGNATURES = {
                                _i, _f, _f, ctypes.c_ulong, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp]),
     "adell_gemm_f32_workspace_floats": (_l, [_i, _i, _i]),
     "adell_gemm_f32": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
+    "adell_channel_softmax_fwd": (_i, [_vp, _vp, _l, _i, _vp]),
+    "adell_channel_softmax_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
+    "adell_channel_max_fwd": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
+    "adell_channel_max_bwd": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),
+    "adell_set_tuning": (_i, [ctypes.c_char_p, _i]),
+    "adell_get_tuning": (_i, [ctypes.c_char_p]),
 }
 
 
@@ -179,3 +185,25 @@ def check(rc):
                 E_NOMEM: "out of memory"}.get(rc, f"error {rc}")
         raise AdellHipError(f"libadellhip: {kind}: {msg}")
     return rc
+
+
+class tuning:
+    """``with _lib.tuning(igemm_nospec=1): ...`` -- set launch-plan switches (adell_set_tuning)
+    for the duration of a block; used by the A/B tests of the kernel instances."""
+
+    def __init__(self, **switches):
+        self.switches = switches
+        self.old = {}
+
+    def __enter__(self):
+        h = lib()
+        for k, v in self.switches.items():
+            self.old[k] = h.adell_get_tuning(k.encode())
+            check(h.adell_set_tuning(k.encode(), int(v)))
+        return self
+
+    def __exit__(self, *exc):
+        h = lib()
+        for k, v in self.old.items():
+            h.adell_set_tuning(k.encode(), int(v))
+        return False

@@ -13,3 +13,62 @@ void adell_set_error(const char* fmt, ...) {
 
 extern "C" const char* adell_last_error(void) { return g_err; }
 extern "C" int adell_abi_version(void) { return ADELL_ABI_VERSION; }
+
+// ---- launch-plan switches -------------------------------------------------------------------
+#include <stdlib.h>
+#include <string.h>
+
+static int adell_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+static int adell_env_set(const char* name) { return getenv(name) != nullptr; }
+
+static AdellTuning adell_tuning_from_env() {
+  AdellTuning t;
+  t.igemm_nospec = adell_env_set("ADELL_IGEMM_NOSPEC");
+  t.igemm_no8 = adell_env_set("ADELL_IGEMM_NO8");
+  t.no_splitk = adell_env_set("ADELL_NO_SPLITK");
+  t.no_wgrad_tiny = adell_env_set("ADELL_NO_WGRAD_TINY");
+  t.wgrad_nozring = adell_env_set("ADELL_WGRAD_NOZRING");
+  t.zr_minseg = adell_env_int("ADELL_ZR_MINSEG", 4);
+#ifdef ADELL_DEBUG
+  t.igemm_dbg = adell_env_int("ADELL_IGEMM_DBG", 0);
+  t.zr_dbg = adell_env_int("ADELL_ZR_DBG", 0);
+#else
+  t.igemm_dbg = 0;
+  t.zr_dbg = 0;
+#endif
+  return t;
+}
+AdellTuning g_adell_tune = adell_tuning_from_env();
+
+static int* adell_tuning_slot(const char* name) {
+  if (!name) return nullptr;
+  if (!strcmp(name, "igemm_nospec")) return &g_adell_tune.igemm_nospec;
+  if (!strcmp(name, "igemm_no8")) return &g_adell_tune.igemm_no8;
+  if (!strcmp(name, "no_splitk")) return &g_adell_tune.no_splitk;
+  if (!strcmp(name, "no_wgrad_tiny")) return &g_adell_tune.no_wgrad_tiny;
+  if (!strcmp(name, "wgrad_nozring")) return &g_adell_tune.wgrad_nozring;
+  if (!strcmp(name, "zr_minseg")) return &g_adell_tune.zr_minseg;
+#ifdef ADELL_DEBUG
+  if (!strcmp(name, "igemm_dbg")) return &g_adell_tune.igemm_dbg;
+  if (!strcmp(name, "zr_dbg")) return &g_adell_tune.zr_dbg;
+#endif
+  return nullptr;
+}
+
+extern "C" int adell_set_tuning(const char* name, int value) {
+  int* slot = adell_tuning_slot(name);
+  if (!slot) {
+    adell_set_error("adell_set_tuning: unknown switch '%s'", name ? name : "(null)");
+    return ADELL_E_BADARG;
+  }
+  *slot = value;
+  return ADELL_OK;
+}
+
+extern "C" int adell_get_tuning(const char* name) {
+  int* slot = adell_tuning_slot(name);
+  return slot ? *slot : -1;
+}

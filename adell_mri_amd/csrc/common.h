@@ -12,6 +12,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void adell_set_error(const char* fmt, ...);
 
+// Launch-plan switches (A/B tests of kernel instances). Read from the environment ONCE when the
+// library is loaded (ADELL_IGEMM_NOSPEC, ADELL_IGEMM_NO8, ADELL_NO_SPLITK, ADELL_NO_WGRAD_TINY,
+// ADELL_WGRAD_NOZRING, ADELL_ZR_MINSEG); afterwards only adell_set_tuning() changes them, so
+// the per-launch host path never calls getenv().
+struct AdellTuning {
+  int igemm_nospec, igemm_no8, no_splitk, no_wgrad_tiny, wgrad_nozring, zr_minseg;
+  int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
+};
+extern AdellTuning g_adell_tune;
+// Kernel-side timing experiments make results WRONG; they exist only in -DADELL_DEBUG builds.
+#ifdef ADELL_DEBUG
+#define ADELL_DBG(bits) (bits)
+#else
+#define ADELL_DBG(bits) 0
+#endif
+
 #define ADELL_CHECK_HIP(expr)                                                  \
   do {                                                                         \
     hipError_t _e = (expr);                                                    \

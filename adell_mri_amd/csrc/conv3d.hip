@@ -399,8 +399,8 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
       a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.shuffle == 0 && a.lTX == 3 && a.lTY == 3 &&
       a.lTZ == 2 && a.Do >= 8 && a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
       (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
-      g_conv_force_cfg < 0 && getenv("ADELL_IGEMM_NOSPEC") == nullptr &&
-      getenv("ADELL_IGEMM_NO8") == nullptr) {
+      g_conv_force_cfg < 0 && !g_adell_tune.igemm_nospec &&
+      !g_adell_tune.igemm_no8) {
     t.cfg = 4;
     t.BM = 512;
     t.lTZ = 3;
@@ -414,7 +414,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   // 64-voxel brick and up to 256 columns (cfg 5), so the input brick is staged once instead of
   // once per 32 / 64-column tile
   if (a.shuffle != 0 && a.KD == 1 && a.KH == 1 && a.KW == 1 && a.Cout >= 128 &&
-      g_conv_force_cfg < 0 && getenv("ADELL_IGEMM_NOSPEC") == nullptr) {
+      g_conv_force_cfg < 0 && !g_adell_tune.igemm_nospec) {
     t.cfg = 5;
     t.BM = 64;
     t.BN = 256;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void adell_conv_splitk_fold_kernel(ConvFoldArg
 
 // number of K shares for this problem (1 = no split) given the planned tile
 static int adell_splitk_shares(const ConvArgs& a, const ConvTile& t, int N) {
-  if (getenv("ADELL_NO_SPLITK")) return 1;
+  if (g_adell_tune.no_splitk) return 1;
   const int nchunk = adell_cdiv(a.Cin, 16);
   const long blocks = (long)a.ntx * a.nty * a.ntz * adell_cdiv(a.Cout, t.BN) * N;
   const int cq = a.Cout / 4;
@@ -524,7 +524,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
            (((uintptr_t)a.x1 & 15) == 0);
   a.vecw = 1;
-  e.dbg = getenv("ADELL_IGEMM_DBG") ? atoi(getenv("ADELL_IGEMM_DBG")) : 0;
+  e.dbg = g_adell_tune.igemm_dbg;
   const long nsp = (long)a.ntx * a.nty * a.ntz;
   if (nsp > 0x0fffffffL || N > 65535) {
     adell_set_error("conv: grid too large");
@@ -558,7 +558,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     a.lTZ == 2 && a.shuffle == 0 && a.vecx && a.GKH == 3 && t.cfg <= 1 &&
                     a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
-                    getenv("ADELL_IGEMM_NOSPEC") == nullptr;
+                    !g_adell_tune.igemm_nospec;
   int rc2 = ADELL_OK;
   switch (t.cfg) {
     case 0:

@@ -41,8 +41,8 @@ struct ConvF16Extra {
   const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
   const float* wscale;   // [Cout] 2^-kw[n]: undoes the per-output-channel weight scale
   unsigned* amax_out;    // optional: receives the absmax (float bits) of the input tensor(s)
-  int dbg;               // timing experiments (ADELL_IGEMM_DBG, tools/igemm_dbg.py): results are
-                         // wrong when nonzero. 1: halo staged for chunk 0 only; 2: weights staged
+  int dbg;               // timing experiments (-DADELL_DEBUG builds only: ADELL_IGEMM_DBG,
+                         // tools/igemm_dbg.py): results are wrong when nonzero. 1: halo staged for chunk 0 only; 2: weights staged
                          // for the first tap group only; 8: no MFMAs; 16: no output stores
 };
 
@@ -284,7 +284,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   for (int ch = c_beg; ch < c_end; ++ch) {
     const int c0 = ch * CC;
     float mx = 0.f;
-    const bool skipA = (e.dbg & 1) && ch > 0;
+    const bool skipA = (ADELL_DBG(e.dbg) & 1) && ch > 0;
     if (skipA) {
     } else if (resident) {
 #pragma unroll
@@ -372,7 +372,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       const int tap0 = SPEC >= 2 ? grp * GT : (kz * KH + ky0) * KW;
       if (grp > 0) __syncthreads();  // previous tap group consumed
       // ---- stage the weight slice of this tap group: [tpg][BN][4 slots] -----
-      const bool skipB = (e.dbg & 2) && (ch > 0 || grp > 0);
+      const bool skipB = (ADELL_DBG(e.dbg) & 2) && (ch > 0 || grp > 0);
       if (skipB) {
       } else if (SPEC) {
 #pragma unroll
@@ -445,7 +445,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           }
       };
-      if (e.dbg & 8) continue;
+      if (ADELL_DBG(e.dbg) & 8) continue;
       if constexpr (SPEC) {
         // 9 taps, statically indexed, two fragment sets: the LDS reads of tap t+1 are issued
         // before the MFMAs of tap t
@@ -575,7 +575,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
             for (int r = 0; r < 16; ++r) {
               float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];
               if constexpr (has_res.value) v += resv[nt][r];
-              if (!(e.dbg & 16)) p[(r >> 2) * dY + (r & 3) * dX] = v;
+              if (!(ADELL_DBG(e.dbg) & 16)) p[(r >> 2) * dY + (r & 3) * dX] = v;
               s1[nt] += v;
               s2[nt] += v * v;
             }

@@ -212,11 +212,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
     fetch_y(z0);
     for (int z = z0; z < z1; ++z) {
       // registers -> LDS: the new input plane (tap kz = 2 of this step) and this step's dY
-      if (!(a.dbg & 2) || z == z0) {
+      if (!(ADELL_DBG(a.dbg) & 2) || z == z0) {
         store_x((z + 2) & 3);
         store_y(z & 1);
       }
-      if (z + 1 < z1 && !(a.dbg & 1)) {  // next step's loads fly during this step's MFMAs
+      if (z + 1 < z1 && !(ADELL_DBG(a.dbg) & 1)) {  // next step's loads fly during this step's MFMAs
         fetch_x(z + 1 - a.PD + 2);
         fetch_y(z + 1);
       }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
       for (int q = 0; q < ZR_MAXJ; ++q)
         tslot[q] = tapoff[q] + (tapkz[q] == 0 ? slotoff[0] : (tapkz[q] == 1 ? slotoff[1] : slotoff[2]));
       zr_half8 ah[2], al[2], bh[2], bl[2];
-      if (a.dbg & 4) continue;
+      if (ADELL_DBG(a.dbg) & 4) continue;
       bh[0] = adell_zr_frag(sYh + ybuf + bbase);
       bl[0] = adell_zr_frag(sYl + ybuf + bbase);
       ah[0] = adell_zr_frag(sXh + tslot[0]);
@@ -317,7 +317,7 @@ extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1
   const size_t cmax = (size_t)(C0 > C1 ? C0 : C1);
   if ((size_t)H * W * cmax >= ((size_t)1 << 30) || (size_t)Ho * Wo * Cout >= ((size_t)1 << 30))
     return 0;                                  // 32-bit byte offsets inside a plane
-  if (getenv("ADELL_WGRAD_NOZRING")) return 0;
+  if (g_adell_tune.wgrad_nozring) return 0;
   p->ntx = adell_cdiv(Wo, 8);
   p->nty = adell_cdiv(Ho, 8);
   p->nci = Cin / 32;
@@ -329,7 +329,7 @@ extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1
   // z segments: enough units to fill the target, at least 4 steps each (2 priming planes;
   // measured best from 8^3 to 128^3 once the slab fold stopped scaling with the slab count)
   long nseg = (target + ncols - 1) / ncols;
-  const int minseg = getenv("ADELL_ZR_MINSEG") ? atoi(getenv("ADELL_ZR_MINSEG")) : 4;
+  const int minseg = g_adell_tune.zr_minseg;
   const long maxseg = Do / minseg > 0 ? Do / minseg : 1;
   if (nseg > maxseg) nseg = maxseg;
   if (nseg < 1) nseg = 1;
@@ -355,7 +355,7 @@ extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int 
   a.PD = PD; a.PH = PH; a.PW = PW; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.ntx = p->ntx; a.nty = p->nty; a.nseg = p->nseg; a.seglen = p->seglen;
   a.nci = p->nci; a.nco = p->nco; a.R = p->R;
-  a.dbg = getenv("ADELL_ZR_DBG") ? atoi(getenv("ADELL_ZR_DBG")) : 0;
+  a.dbg = g_adell_tune.zr_dbg;
   const size_t lds = 2 * (ZR_SLOTS * (size_t)ZR_PLANE + 2 * 64 * 64);
   static bool attr_done = false;
   if (!attr_done) {

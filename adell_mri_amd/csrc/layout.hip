@@ -723,3 +723,149 @@ extern "C" int adell_fold_x_taps(const float* x, float* out, int N, int D, int H
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Softmax over the channel axis of an NDHWC tensor: rows = N * voxels, C contiguous values per row
+// (the n_classes > 2 head of the U-Net family, torch.nn.Softmax(dim=1), unet.py:641-655).
+// One thread per row (C <= 32: the class count), row in registers, exp via v_exp_f32.
+// backward: dx = y * (dy - sum_c dy * y).
+// ---------------------------------------------------------------------------------------------
+template <int CMAX>
+__global__ __launch_bounds__(256) void adell_channel_softmax_fwd_kernel(
+    const float* __restrict__ x, float* __restrict__ y, long rows, int C) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256L) {
+    const float* xr = x + r * C;
+    float v[CMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      v[c] = c < C ? xr[c] : -INFINITY;
+      mx = fmaxf(mx, v[c]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      v[c] = c < C ? __expf(v[c] - mx) : 0.f;
+      sum += v[c];
+    }
+    const float inv = 1.0f / sum;
+    float* yr = y + r * C;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) yr[c] = v[c] * inv;
+  }
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(256) void adell_channel_softmax_bwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long rows,
+    int C) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256L) {
+    float p[CMAX], g[CMAX];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      p[c] = c < C ? y[r * C + c] : 0.f;
+      g[c] = c < C ? dy[r * C + c] : 0.f;
+      dot += p[c] * g[c];
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) dx[r * C + c] = p[c] * (g[c] - dot);
+  }
+}
+
+static unsigned adell_rows_grid(long rows) {
+  long b = (rows + 255) / 256;
+  return (unsigned)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
+}
+
+extern "C" int adell_channel_softmax_fwd(const float* x, float* y, long rows, int C, void* stream) {
+  ADELL_REQUIRE(x && y && rows > 0 && C > 0 && C <= 32, "channel_softmax: 1 <= C <= 32 classes");
+  const dim3 g(adell_rows_grid(rows)), b(256);
+  if (C <= 4)
+    hipLaunchKernelGGL(adell_channel_softmax_fwd_kernel<4>, g, b, 0, (hipStream_t)stream, x, y, rows, C);
+  else if (C <= 8)
+    hipLaunchKernelGGL(adell_channel_softmax_fwd_kernel<8>, g, b, 0, (hipStream_t)stream, x, y, rows, C);
+  else
+    hipLaunchKernelGGL(adell_channel_softmax_fwd_kernel<32>, g, b, 0, (hipStream_t)stream, x, y, rows, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_channel_softmax_bwd(const float* y, const float* dy, float* dx, long rows,
+                                         int C, void* stream) {
+  ADELL_REQUIRE(y && dy && dx && rows > 0 && C > 0 && C <= 32,
+                "channel_softmax_bwd: 1 <= C <= 32 classes");
+  const dim3 g(adell_rows_grid(rows)), b(256);
+  if (C <= 4)
+    hipLaunchKernelGGL(adell_channel_softmax_bwd_kernel<4>, g, b, 0, (hipStream_t)stream, y, dy, dx, rows, C);
+  else if (C <= 8)
+    hipLaunchKernelGGL(adell_channel_softmax_bwd_kernel<8>, g, b, 0, (hipStream_t)stream, y, dy, dx, rows, C);
+  else
+    hipLaunchKernelGGL(adell_channel_softmax_bwd_kernel<32>, g, b, 0, (hipStream_t)stream, y, dy, dx, rows, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-(item, channel) maximum over the voxels of an NDHWC tensor with its argmax (first maximum
+// in voxel order, as torch.max): the pooling in front of the bottleneck classifier
+// (X.flatten(2).max(-1).values, unet.py:826-828). One block per item, thread t owns channels
+// t, t + 256, ...; consecutive threads read consecutive channels of one voxel (coalesced).
+// backward: dx = 0 except dx[n, arg[n, c], c] = dout[n, c].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_channel_max_kernel(const float* __restrict__ x,
+                                                                float* __restrict__ out,
+                                                                int* __restrict__ arg, long V, int C) {
+  const float* xb = x + (size_t)blockIdx.x * V * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float best = xb[c];
+    long at = 0;
+    for (long v = 1; v < V; ++v) {
+      const float t = xb[v * C + c];
+      // NaN propagates like torch.max: the first NaN wins
+      if (t > best || (t != t && best == best)) {
+        best = t;
+        at = v;
+      }
+    }
+    out[(size_t)blockIdx.x * C + c] = best;
+    arg[(size_t)blockIdx.x * C + c] = (int)at;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_channel_max_bwd_kernel(const float* __restrict__ dout,
+                                                                    const int* __restrict__ arg,
+                                                                    float* __restrict__ dx, long V,
+                                                                    int C) {
+  const size_t nb = blockIdx.y;
+  float* db = dx + nb * V * C;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < V * C; i += (long)gridDim.x * 256L) {
+    const int c = (int)(i % C);
+    const long v = i / C;
+    db[i] = arg[nb * C + c] == v ? dout[nb * C + c] : 0.f;
+  }
+}
+
+extern "C" int adell_channel_max_fwd(const float* x, float* out, int* arg, int N, long V, int C,
+                                     void* stream) {
+  ADELL_REQUIRE(x && out && arg && N > 0 && V > 0 && V < (1L << 31) && C > 0,
+                "channel_max: bad arguments");
+  hipLaunchKernelGGL(adell_channel_max_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                     x, out, arg, V, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_channel_max_bwd(const float* dout, const int* arg, float* dx, int N, long V,
+                                     int C, void* stream) {
+  ADELL_REQUIRE(dout && arg && dx && N > 0 && N <= 65535 && V > 0 && C > 0,
+                "channel_max_bwd: bad arguments");
+  long blocks = (V * C + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(adell_channel_max_bwd_kernel, dim3((unsigned)blocks, (unsigned)N), dim3(256),
+                     0, (hipStream_t)stream, dout, arg, dx, V, C);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

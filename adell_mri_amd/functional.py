@@ -26,6 +26,12 @@ _dropout_counter = itertools.count(1)
 #            ~2^-22 per product; 5.3x the fp32 MFMA rate)            [default]
 #   "fp32":  v_mfma_f32_32x32x2_f32, bit-exact k-ordered fp32 FMA chain
 CONV_PRECISION = os.environ.get("ADELL_CONV_PRECISION", "f16x3")
+# dispatch switches for A/B tests, read from the environment once at import (tests flip the
+# dictionary entries): parity-class stride-2 backward-data at every size / never; no folding
+# of the x taps of <= 4-channel inputs into the 16-channel MFMA chunk
+FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
+         "no_s2class": bool(os.environ.get("ADELL_NO_S2CLASS")),
+         "no_fold": bool(os.environ.get("ADELL_NO_FOLD"))}
 
 
 def set_conv_precision(mode):
@@ -254,8 +260,8 @@ class _Conv3dFn(torch.autograd.Function):
         elif (need[0] and x1 is None and CONV_PRECISION == "f16x3" and stride == (2, 2, 2)
               and k == (3, 3, 3) and all(p <= 1 for p in padding)
               and all(s % 2 == 0 for s in x0.shape[2:])
-              and (x0.numel() // C0 >= (1 << 20) or os.environ.get("ADELL_S2CLASS_ALWAYS"))
-              and not os.environ.get("ADELL_NO_S2CLASS")):
+              and (x0.numel() // C0 >= (1 << 20) or FLAGS["s2class_always"])
+              and not FLAGS["no_s2class"]):
             # stride-2 backward-data by parity classes (no zero-inserted MFMA work). Eight
             # launches: pays from ~1 M voxels (measured: 128^3 0.52 -> 0.33 ms, 32^3 0.06 -> 0.16)
             if amax is not None:
@@ -300,7 +306,7 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
         wp = "cin_small"
     elif (CONV_PRECISION == "f16x3" and x1 is None and weight.dim() == 5 and x0.shape[1] <= 4
           and 3 <= weight.shape[4] and weight.shape[4] * x0.shape[1] <= 16
-          and stride == (1, 1, 1) and not os.environ.get("ADELL_NO_FOLD")):
+          and stride == (1, 1, 1) and not FLAGS["no_fold"]):
         wp = ("fold", _packed_folded(weight))
     else:
         wp = _packed(weight, 0)
@@ -957,3 +963,46 @@ class _VICRegFn(torch.autograd.Function):
 def vicreg_terms(x1, x2, min_var=1.0, eps=1e-4):
     """(invariance, variance, covariance) terms of VICReg, unweighted, as a 3-vector."""
     return _VICRegFn.apply(x1, x2, float(min_var), float(eps))
+
+
+class _ChannelSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.channel_softmax_fwd(x)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return ops.channel_softmax_bwd(y, dy)
+
+
+def channel_softmax(x):
+    """torch.nn.Softmax(dim=1) on a [N, C, *spatial] activation (the n_classes > 2 head,
+    unet.py:641-655); 4-D inputs are depth-1 volumes."""
+    if x.dim() == 4:
+        return _ChannelSoftmaxFn.apply(x.unsqueeze(2)).squeeze(2)
+    return _ChannelSoftmaxFn.apply(x)
+
+
+class _ChannelMaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        out, arg = ops.channel_max_fwd(x)
+        ctx.save_for_backward(arg)
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        return ops.channel_max_bwd(g, arg, ctx.shape)
+
+
+def channel_max(x):
+    """X.flatten(start_dim=2).max(-1).values for a [N, C, *spatial] activation (the pooling in
+    front of the bottleneck classifier, unet.py:826-828)."""
+    if x.dim() == 4:
+        return _ChannelMaxFn.apply(x.unsqueeze(2))
+    return _ChannelMaxFn.apply(x)

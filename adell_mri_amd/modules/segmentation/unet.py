@@ -336,7 +336,7 @@ class UNet(torch.nn.Module):
 
     def init_bottleneck_classifier(self):
         nc = self.n_classes if self.n_classes > 2 else 1
-        self.bottleneck_classifier = torch.nn.Linear(self.depth[-1], nc)
+        self.bottleneck_classifier = Linear(self.depth[-1], nc)   # fp32-MFMA GEMM
 
     # ---- forward (unet.py:751-843) --------------------------------------------
     def _final(self, layer, X, return_logits):
@@ -349,8 +349,7 @@ class UNet(torch.nn.Module):
             if X.dim() == 4:  # 2-D network: depth-1 volume
                 return HF.norm_drop_act(X.unsqueeze(2), act="sigmoid").squeeze(2)
             return HF.norm_drop_act(X, act="sigmoid")
-        # Softmax over the class axis of one small [B, n_classes, ...] tensor
-        return mods[-1](X)
+        return HF.channel_softmax(X)   # torch.nn.Softmax(dim=1) of the n_classes > 2 head
 
     def forward(self, X: torch.Tensor, X_skip_layer: torch.Tensor = None,
                 X_feature_conditioning: torch.Tensor = None, return_features=False,
@@ -409,7 +408,7 @@ class UNet(torch.nn.Module):
             return curr, final_features, bottleneck
 
         if self.bottleneck_classification is True:
-            pooled = bottleneck.flatten(start_dim=2).max(-1).values
+            pooled = HF.channel_max(bottleneck)
             bn_out = self.bottleneck_classifier(pooled)
         else:
             bn_out = None

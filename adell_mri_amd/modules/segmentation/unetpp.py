@@ -92,7 +92,7 @@ class UNetPlusPlus(UNet):
     def _act(self, X):
         if isinstance(self.final_act, torch.nn.Sigmoid):
             return HF.norm_drop_act(X, act="sigmoid")
-        return self.final_act(X)
+        return HF.channel_softmax(X)   # torch.nn.Softmax(dim=1)
 
     def forward(self, X: torch.Tensor, return_aux=True, X_skip_layer: torch.Tensor = None,
                 X_feature_conditioning: torch.Tensor = None, return_features=False,
@@ -146,7 +146,7 @@ class UNetPlusPlus(UNet):
         else:
             curr_aux = None
         if self.bottleneck_classification is True:
-            pooled = bottleneck.flatten(start_dim=2).max(-1).values
+            pooled = HF.channel_max(bottleneck)
             bn_out = self.bottleneck_classifier(pooled)
         else:
             bn_out = None

@@ -223,7 +223,7 @@ class UNETR(UNet, torch.nn.Module):
         if return_features is True:
             return curr, final_features, bottleneck
         if self.bottleneck_classification is True:
-            pooled = bottleneck.flatten(start_dim=2).max(-1).values
+            pooled = HF.channel_max(bottleneck)
             bn_out = self.bottleneck_classifier(pooled)
         else:
             bn_out = None
@@ -450,7 +450,7 @@ class SWINUNet(UNet, torch.nn.Module):
         if return_features is True:
             return curr, final_features, bottleneck
         if self.bottleneck_classification is True:
-            pooled = bottleneck.flatten(start_dim=2).max(-1).values
+            pooled = HF.channel_max(bottleneck)
             bn_out = self.bottleneck_classifier(pooled)
         else:
             bn_out = None

@@ -80,6 +80,9 @@ class KernelTimer:
 
 
 KERNEL_TIMER = None
+# dispatch switches for A/B tests (read from the environment once at import)
+FLAGS = {"no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
+         "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
 
 
@@ -267,12 +270,12 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
 def conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
     if residual is not None or x1 is not None or weight.dim() != 5 or x0.shape[1] > 4:
         return False
-    if os.environ.get("ADELL_NO_CIN_SMALL"):
+    if FLAGS["no_cin_small"]:
         return False
     k = tuple(weight.shape[2:])
     # measured at 128^3 (tools/bench_layers.py): 2 -> 2 0.21 ms here vs 0.34 ms on the MFMA path,
     # but 2 -> 32 is slower here (the vector ALU does 1728 FMAs per voxel): narrow outputs only
-    if weight.shape[0] > 4 and not os.environ.get("ADELL_CIN_SMALL_ALL"):
+    if weight.shape[0] > 4 and not FLAGS["cin_small_all"]:
         return False
     return k[0] in (1, 3) and k[1:] == (3, 3) and tuple(stride) == (1, 1, 1)
 
@@ -1156,3 +1159,46 @@ def vicreg_bwd(x1, x2, scratch, min_var, eps, g, need1, need2):
     check(_lib.lib().adell_vicreg_bwd(_ptr(x1), _ptr(x2), B, D, float(min_var), float(eps),
                                       _ptr(scratch), _ptr(g), _ptr(dx1), _ptr(dx2), _stream()))
     return dx1, dx2
+
+
+# ---- class-axis softmax head, channel max pooling -------------------------------------------------
+def channel_softmax_fwd(x):
+    """softmax over dim 1 of a logical [N, C, *spatial] tensor (NDHWC memory), C <= 32."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    C = x.shape[1]
+    y = new_act(*x.shape, x.device)
+    check(_lib.lib().adell_channel_softmax_fwd(_ptr(x), _ptr(y), x.numel() // C, C, _stream()))
+    return y
+
+
+def channel_softmax_bwd(y, dy):
+    _require_cuda(y, dy)
+    y, dy = ndhwc(y), ndhwc(dy)
+    C = y.shape[1]
+    dx = new_act(*y.shape, y.device)
+    check(_lib.lib().adell_channel_softmax_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel() // C, C,
+                                               _stream()))
+    return dx
+
+
+def channel_max_fwd(x):
+    """[N, C, D, H, W] -> ([N, C] maxima over the voxels, [N, C] int32 voxel indices)."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    V = x.numel() // (N * C)
+    out = torch.empty((N, C), device=x.device, dtype=torch.float32)
+    arg = torch.empty((N, C), device=x.device, dtype=torch.int32)
+    check(_lib.lib().adell_channel_max_fwd(_ptr(x), _ptr(out), _ptr(arg), N, V, C, _stream()))
+    return out, arg
+
+
+def channel_max_bwd(dout, arg, shape):
+    _require_cuda(dout, arg)
+    N, C = shape[:2]
+    V = int(math.prod(shape[2:]))
+    dx = new_act(N, C, *shape[2:], dout.device)
+    dc = dout.contiguous()
+    check(_lib.lib().adell_channel_max_bwd(_ptr(dc), _ptr(arg), _ptr(dx), N, V, C, _stream()))
+    return dx

@@ -512,8 +512,32 @@ int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int a_kc, cons
                    long ldb, int b_kc, float* C, long ldc, const float* bias,
                    const float* residual, long ldr, float* workspace, void* stream);
 
+/* Softmax over the channel axis of an NDHWC tensor (rows = N * voxels, C <= 32 contiguous
+ * class values per row): the n_classes > 2 head, torch.nn.Softmax(dim=1) at unet.py:641-655.
+ * backward: dx = y * (dy - sum_c dy * y). */
+int adell_channel_softmax_fwd(const float* x, float* y, long rows, int C, void* stream);
+int adell_channel_softmax_bwd(const float* y, const float* dy, float* dx, long rows, int C,
+                              void* stream);
+
+/* out[n][c] = max over the V voxels of NDHWC x[n][v][c], arg = the first voxel attaining it
+ * (torch.max semantics): X.flatten(2).max(-1).values in front of the bottleneck classifier
+ * (unet.py:826-828). backward: dx = 0 except dx[n][arg[n][c]][c] = dout[n][c]. */
+int adell_channel_max_fwd(const float* x, float* out, int* arg, int N, long V, int C,
+                          void* stream);
+int adell_channel_max_bwd(const float* dout, const int* arg, float* dx, int N, long V, int C,
+                          void* stream);
+
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
+
+/* Launch-plan switches for A/B tests of kernel instances: "igemm_nospec", "igemm_no8",
+ * "no_splitk", "no_wgrad_tiny", "wgrad_nozring" (0 / 1) and "zr_minseg" (planes). Initialised
+ * once at load from the environment variables of the same names (ADELL_ prefix, upper case);
+ * the launch path itself never reads the environment. The kernel timing experiments
+ * ("igemm_dbg", "zr_dbg": results become WRONG) exist only in -DADELL_DEBUG builds of the
+ * library. adell_set_tuning returns ADELL_E_BADARG for an unknown name; adell_get_tuning -1. */
+int adell_set_tuning(const char* name, int value);
+int adell_get_tuning(const char* name);
 
 #ifdef __cplusplus
 }

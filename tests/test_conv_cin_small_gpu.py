@@ -25,7 +25,7 @@ def _rel(a, b):
                                                          (2, 2, 2, (16, 24, 40), 3, 1, True)])
 def test_cin_small_fwd_stats_and_grads_match_torch(cuda, monkeypatch, n, cin, cout, size, kd, pad,
                                                    bias):
-    monkeypatch.setenv("ADELL_CIN_SMALL_ALL", "1")   # every width, not only Cout <= 4
+    monkeypatch.setitem(ops.FLAGS, "cin_small_all", True)   # every width, not only Cout <= 4
     g = torch.Generator().manual_seed(cin * 10 + cout)
     x = torch.randn(n, cin, *size, generator=g, dtype=torch.float64).requires_grad_(True)
     w = (torch.randn(cout, cin, kd, 3, 3, generator=g, dtype=torch.float64) * 0.2).requires_grad_(True)
@@ -79,7 +79,7 @@ def test_folded_x_taps_forward_matches_torch_and_plain_path(cuda, monkeypatch, n
         return yd.detach().cpu().double(), part, xd.grad.cpu().double(), wd.grad.cpu().double()
 
     yf, pf, dxf, dwf = run()
-    monkeypatch.setenv("ADELL_NO_FOLD", "1")
+    monkeypatch.setitem(HF.FLAGS, "no_fold", True)
     yp, pp, dxp, dwp = run()
     assert _rel(yf, y.detach()) < 5e-6 and _rel(yf, yp) < 5e-6
     want = torch.stack([y.detach().sum((2, 3, 4)), (y.detach() ** 2).sum((2, 3, 4))], -1)

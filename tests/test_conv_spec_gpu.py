@@ -5,7 +5,7 @@ import os
 import pytest
 import torch
 
-from adell_mri_amd import ops
+from adell_mri_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 
@@ -34,11 +34,8 @@ def test_spec_instance_matches_generic_and_fp32(cuda, cin, c1, cout, size, res):
         return ops.conv3d_fwd(x0, wp, b, cout, 3, 1, 1, x1=x1, residual=r, want_stats=True)
 
     y_spec, st_spec = run()
-    os.environ["ADELL_IGEMM_NOSPEC"] = "1"
-    try:
+    with _lib.tuning(igemm_nospec=1):
         y_gen, st_gen = run()
-    finally:
-        del os.environ["ADELL_IGEMM_NOSPEC"]
     y32, _ = ops.conv3d_fwd(x0, ops.pack_weight(w, 0), b, cout, 3, 1, 1, x1=x1, residual=r,
                             want_stats=True)
     assert _rel(y_spec, y_gen) < 2e-6
@@ -67,11 +64,8 @@ def test_spec_backward_data_matches_generic(cuda, cin, cout, size, split):
         return ops.conv3d_bwd_data(dy, wpb, (D, H, W), cin - split, split, 3, 1, 1)
 
     a = run()
-    os.environ["ADELL_IGEMM_NOSPEC"] = "1"
-    try:
+    with _lib.tuning(igemm_nospec=1):
         b = run()
-    finally:
-        del os.environ["ADELL_IGEMM_NOSPEC"]
     a = a if isinstance(a, (tuple, list)) else (a,)
     b = b if isinstance(b, (tuple, list)) else (b,)
     for u, v in zip(a, b):
@@ -97,7 +91,6 @@ def test_split_k_matches_single_pass(cuda, monkeypatch, n, c0, c1, cout, size, r
     wp, wpb = ops.pack_weight_f16x3(w, 0), ops.pack_weight_f16x3(w, 1)
     d = ops.make_conv_desc(n, size, c0, c1, cout, 3, 1, 1)
     import ctypes
-    from adell_mri_amd import _lib
     assert _lib.lib().adell_conv3d_splitk_workspace(ctypes.byref(d), 0) > 0   # the case does split
 
     def run():
@@ -106,14 +99,13 @@ def test_split_k_matches_single_pass(cuda, monkeypatch, n, c0, c1, cout, size, r
         return y, st, dx
 
     y_s, st_s, dx_s = run()
-    monkeypatch.setenv("ADELL_NO_SPLITK", "1")
-    y_1, st_1, dx_1 = run()
+    with _lib.tuning(no_splitk=1):
+        y_1, st_1, dx_1 = run()
     assert _rel(y_s, y_1) < 2e-6
     assert _rel(st_s.double().sum(1), st_1.double().sum(1)) < 1e-5
     for u, v in zip(dx_s, dx_1):
         if u is not None:
             assert _rel(u, v) < 2e-6
-    monkeypatch.delenv("ADELL_NO_SPLITK")
     y_s2, _, _ = run()
     assert torch.equal(y_s, y_s2)   # fixed fold order
 
@@ -124,7 +116,7 @@ def test_stride2_backward_data_by_parity_classes(cuda, monkeypatch, n, cin, cout
     """dX of a stride-2 k = 3 conv computed as 8 stride-1 sub-kernel convs on the stride-2 lattice
     (adell_conv3d_bwd_data_s2_f16x3) == the zero-insertion formulation == torch."""
     from adell_mri_amd import functional as HF
-    monkeypatch.setenv("ADELL_S2CLASS_ALWAYS", "1")   # also below the size where it pays
+    monkeypatch.setitem(HF.FLAGS, "s2class_always", True)   # also below the size where it pays
     g = torch.Generator().manual_seed(cin + size[0])
     x = torch.randn(n, cin, *size, generator=g)
     w = torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05
@@ -139,7 +131,7 @@ def test_stride2_backward_data_by_parity_classes(cuda, monkeypatch, n, cin, cout
         return y.detach(), dy, xd.grad.detach()
 
     y, dy, dx_c = run()
-    monkeypatch.setenv("ADELL_NO_S2CLASS", "1")
+    monkeypatch.setitem(HF.FLAGS, "no_s2class", True)
     _, _, dx_z = run()
     xr = x.double().requires_grad_(True)
     yr = torch.nn.functional.conv3d(xr, w.double(), None, stride=2, padding=pad)

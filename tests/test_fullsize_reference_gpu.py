@@ -20,7 +20,7 @@ import pytest
 import torch
 
 from adell_mri_amd import functional as HF
-from adell_mri_amd import ops
+from adell_mri_amd import _lib, ops
 from adell_mri_amd.modules.activations import activation_factory
 from adell_mri_amd.modules.segmentation.unet import UNet
 from oracle import cops
@@ -198,14 +198,10 @@ def test_spec_instances_and_zring_against_c_oracle(cuda, cin, cout):
     dx_ref, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, 1, 1)
     xt, wt = ops.ndhwc(torch.from_numpy(x).to(cuda)), torch.from_numpy(w).to(cuda)
     dyt, bt = ops.ndhwc(torch.from_numpy(dy).to(cuda)), torch.from_numpy(b).to(cuda)
-    for nospec in (False, True):
-        if nospec:
-            os.environ["ADELL_IGEMM_NOSPEC"] = "1"
-        try:
+    for nospec in (0, 1):
+        with _lib.tuning(igemm_nospec=nospec):
             y, _ = ops.conv3d_fwd(xt, ops.pack_weight_f16x3(wt, 0), bt, cout, 3, 1, 1)
             dx, _ = ops.conv3d_bwd_data(dyt, ops.pack_weight_f16x3(wt, 1), SHAPE, cin, 0, 3, 1, 1)
-        finally:
-            os.environ.pop("ADELL_IGEMM_NOSPEC", None)
         e_y = np.abs(y.cpu().numpy() - y_ref).max() / np.abs(y_ref).max()
         e_dx = np.abs(dx.cpu().numpy() - dx_ref).max() / np.abs(dx_ref).max()
         assert e_y < 2e-6 and e_dx < 2e-6, (nospec, e_y, e_dx)

@@ -5,7 +5,7 @@ import os
 import pytest
 import torch
 
-from adell_mri_amd import ops
+from adell_mri_amd import _lib, ops
 
 pytestmark = pytest.mark.gpu
 
@@ -32,11 +32,8 @@ def test_zring_matches_plane_kernel_and_fp32(cuda, n, c0, c1, cout, size, pad):
         return ops.conv3d_bwd_weight(x0, dy, 3, 1, pad, x1=x1, want_db=True, f16x3=f16)
 
     dw_z, db_z = run(True)
-    os.environ["ADELL_WGRAD_NOZRING"] = "1"
-    try:
+    with _lib.tuning(wgrad_nozring=1):
         dw_p, db_p = run(True)
-    finally:
-        del os.environ["ADELL_WGRAD_NOZRING"]
     dw_32, db_32 = run(False)
     assert _rel(dw_z, dw_32) < 2e-5
     assert _rel(dw_z, dw_p) < 2e-5
