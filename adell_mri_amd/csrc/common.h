@@ -14,10 +14,11 @@ void adell_set_error(const char* fmt, ...);
 
 // Launch-plan switches (A/B tests of kernel instances). Read from the environment ONCE when the
 // library is loaded (ADELL_IGEMM_NOSPEC, ADELL_IGEMM_NO8, ADELL_NO_SPLITK, ADELL_NO_WGRAD_TINY,
-// ADELL_WGRAD_NOZRING, ADELL_ZR_MINSEG); afterwards only adell_set_tuning() changes them, so
+// ADELL_WGRAD_NOZRING, ADELL_ZR_MINSEG, ADELL_IGEMM_WS, ADELL_WS_MIN_ITEMS); afterwards only adell_set_tuning() changes them, so
 // the per-launch host path never calls getenv().
 struct AdellTuning {
   int igemm_nospec, igemm_no8, no_splitk, no_wgrad_tiny, wgrad_nozring, zr_minseg;
+  int igemm_ws, ws_min_items;   // persistent wave-specialised conv instance: opt-in / size gate
   int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;

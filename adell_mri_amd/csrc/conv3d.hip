@@ -2,6 +2,7 @@
 // the kernel). Everything here is NDHWC fp32 on raw device pointers.
 #include "conv_igemm.h"
 #include "conv_igemm_f16.h"
+#include "conv_igemm_ws.h"
 
 // ---------------------------------------------------------------------------
 // Tile selection. BM voxels are laid out as a TX x TY x TZ brick (powers of 2).
@@ -357,6 +358,37 @@ static int adell_launch_conv_f16(const ConvArgs& a, const ConvF16Extra& e, dim3 
   return ADELL_OK;
 }
 
+static int adell_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <int MT, int NT, int BZ>
+static int adell_launch_conv_ws(const ConvArgs& a, const ConvF16Extra& e, int items, int nct,
+                                hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = adell_conv_igemm_ws_kernel<MT, NT, BZ>;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  constexpr int BN = NT * 32, HV = 100 * (BZ + 2), GT = BZ == 8 ? 7 : 9;
+  const size_t lds = (size_t)2 * HV * 64 + (size_t)2 * GT * BN * 64 + 16 + 8 + (size_t)4 * BN * 2 * 4;
+  int blocks = adell_cu_count() & ~7;   // one block per CU, dealt to the 8 XCDs in equal shares
+  if (blocks < 8) blocks = 8;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, e, items, nct);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
 // Tile plan of the f16x3 kernel: the heuristic brick, or (when its halo does not fit
 // LDS, i.e. stride 2) the small-brick configuration of the same channel width.
 static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
@@ -560,6 +592,19 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
                     !g_adell_tune.igemm_nospec;
   int rc2 = ADELL_OK;
+  // large 3x3x3 stride-1 layers, opt-in ("igemm_ws"): the persistent wave-specialised instance
+  // (conv_igemm_ws.h), one block per CU walking >= ws_min_items / CUs bricks. Measured on MI355X
+  // (round 2): +5-9 % over the one-brick-per-block instances when a layer is timed alone
+  // (64->64 @ 2 x 128^3: 2.62 vs 2.87 ms), -3 % inside the training step (41.0 vs 39.9 ms), where
+  // the chip holds a lower clock under the denser MFMA issue; not the default.
+  if (shares == 1 && g_adell_tune.igemm_ws && a.Cin % 16 == 0 &&
+      ((t.cfg == 0 && spec) || t.cfg == 4)) {
+    const int nct = adell_cdiv(a.Cout, t.BN);
+    const long items = (long)N * nsp * nct;
+    if (items >= g_adell_tune.ws_min_items && items < 0x7fffffffL)
+      return t.cfg == 0 ? adell_launch_conv_ws<2, 2, 4>(a, e, (int)items, nct, st)
+                        : adell_launch_conv_ws<4, 1, 8>(a, e, (int)items, nct, st);
+  }
   switch (t.cfg) {
     case 0:
       rc2 = spec ? adell_launch_conv_f16<2, 2, 4, 1, 1>(a, e, grid, lds, st)
@@ -802,3 +847,14 @@ extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const flo
   ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
+
+#ifdef ADELL_WS_CENSUS
+// census builds only: read and clear the role cycle census of the wave-specialised conv kernel
+extern "C" int adell_debug_ws_prof(unsigned long long* out) {
+  ADELL_CHECK_HIP(hipDeviceSynchronize());
+  ADELL_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_prof), 16 * sizeof(unsigned long long)));
+  unsigned long long z[16] = {0};
+  ADELL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_prof), z, sizeof(z)));
+  return ADELL_OK;
+}
+#endif

@@ -44,51 +44,57 @@ __global__ __launch_bounds__(256) void adell_layernorm_fwd_kernel(
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.
-// Also per-block partial dgamma/dbeta: part[block][2][C].
-__global__ __launch_bounds__(256) void adell_layernorm_bwd_kernel(
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma. One wave per row, four rows
+// per block: rows are independent, so the grid is rows / 4 blocks whatever C is (the first
+// version walked 64 rows per block and accumulated dgamma / dbeta by LDS read-modify-write:
+// 14 blocks and 4.9 ms for the [864, 4096] rescaler tensors of UNETR).
+__global__ __launch_bounds__(256) void adell_layernorm_bwd_dx_kernel(
     const float* __restrict__ x, const float* __restrict__ dy,
     const float* __restrict__ gamma, const float* __restrict__ mean,
-    const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ part,
-    long rows, int C, int rows_per_block) {
-  extern __shared__ float sh[];  // [4][2][C] per-wave dgamma/dbeta partials
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* wg = sh + (size_t)wave * 2 * C;
+    const float* __restrict__ rstd, float* __restrict__ dx, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * C;
+  const float* gr = dy + row * C;
+  const float m = mean[row], r = rstd[row];
+  float a = 0.f, b = 0.f;
   for (int c = lane; c < C; c += 64) {
-    wg[c] = 0.f;
-    wg[C + c] = 0.f;
+    const float xh = (xr[c] - m) * r;
+    const float g = gr[c] * (gamma ? gamma[c] : 1.f);
+    a += g;
+    b += g * xh;
   }
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  long r1 = r0 + rows_per_block;
+  a = adell_wave_sum(a) / (float)C;
+  b = adell_wave_sum(b) / (float)C;
+  float* dr = dx + row * C;
+  for (int c = lane; c < C; c += 64) {   // second read of the row comes from L1 / L2
+    const float xh = (xr[c] - m) * r;
+    const float g = gr[c] * (gamma ? gamma[c] : 1.f);
+    dr[c] = r * (g - a - xh * b);
+  }
+}
+
+// dgamma / dbeta partials: grid (column tiles of 256, row chunks); thread = one column, walks the
+// rows of its chunk (consecutive threads read consecutive columns: coalesced), fixed order.
+// part[chunk][2][C] = (sum dy * xhat, sum dy) over the chunk's rows.
+__global__ __launch_bounds__(256) void adell_layernorm_bwd_affine_kernel(
+    const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ part, long rows, int C,
+    int rows_per_chunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
   if (r1 > rows) r1 = rows;
-  for (long row = r0 + wave; row < r1; row += 4) {
-    const float* xr = x + row * C;
-    const float* gr = dy + row * C;
-    const float m = mean[row], r = rstd[row];
-    float a = 0.f, b = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float xh = (xr[c] - m) * r;
-      const float g = gr[c] * (gamma ? gamma[c] : 1.f);
-      a += g;
-      b += g * xh;
-      wg[c] += gr[c] * xh;   // dgamma
-      wg[C + c] += gr[c];    // dbeta
-    }
-    a = adell_wave_sum(a) / (float)C;
-    b = adell_wave_sum(b) / (float)C;
-    float* dr = dx + row * C;
-    for (int c = lane; c < C; c += 64) {
-      const float xh = (xr[c] - m) * r;
-      const float g = gr[c] * (gamma ? gamma[c] : 1.f);
-      dr[c] = r * (g - a - xh * b);
-    }
+  if (c >= C) return;
+  float sg = 0.f, sb = 0.f;
+  for (long row = r0; row < r1; ++row) {
+    const float d = dy[row * C + c];
+    sg += d * (x[row * C + c] - mean[row]) * rstd[row];
+    sb += d;
   }
-  __syncthreads();
-  if (part) {
-    for (int c = threadIdx.x; c < 2 * C; c += 256)
-      part[(size_t)blockIdx.x * 2 * C + c] =
-          (sh[c] + sh[2 * C + c]) + (sh[4 * C + c] + sh[6 * C + c]);
-  }
+  part[((size_t)blockIdx.y * 2 + 0) * C + c] = sg;
+  part[((size_t)blockIdx.y * 2 + 1) * C + c] = sb;
 }
 
 __global__ __launch_bounds__(256) void adell_rowsum_final_kernel(
@@ -122,9 +128,18 @@ extern "C" int adell_layernorm_fwd(const float* x, const float* gamma, const flo
   return ADELL_OK;
 }
 
-#define ADELL_LN_ROWS_PER_BLOCK 64
+// rows per chunk of the affine-gradient partials: enough chunks for ~512 blocks, >= 8 rows each
+static int adell_ln_rows_per_chunk(long rows, int C) {
+  const long tiles = (C + 255) / 256;
+  long chunks = 512 / tiles;
+  if (chunks < 1) chunks = 1;
+  long rpc = (rows + chunks - 1) / chunks;
+  if (rpc < 8) rpc = 8;
+  return (int)rpc;
+}
 extern "C" long adell_layernorm_bwd_workspace(long rows, int C) {
-  const long nb = (rows + ADELL_LN_ROWS_PER_BLOCK - 1) / ADELL_LN_ROWS_PER_BLOCK;
+  const int rpc = adell_ln_rows_per_chunk(rows, C);
+  const long nb = (rows + rpc - 1) / rpc;
   return nb * 2 * C * (long)sizeof(float);
 }
 
@@ -134,26 +149,21 @@ extern "C" int adell_layernorm_bwd(const float* x, const float* dy, const float*
                                    void* workspace, size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(x && dy && mean && rstd && dx, "layernorm_bwd: null pointer");
   ADELL_REQUIRE(rows > 0 && C > 0, "layernorm_bwd: bad dims");
-  ADELL_REQUIRE((size_t)8 * C * sizeof(float) <= 160 * 1024, "layernorm_bwd: C too large");
   const bool want = dgamma || dbeta;
   if (want)
     ADELL_REQUIRE(workspace && (long)workspace_bytes >= adell_layernorm_bwd_workspace(rows, C),
                   "layernorm_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int nb = (int)((rows + ADELL_LN_ROWS_PER_BLOCK - 1) / ADELL_LN_ROWS_PER_BLOCK);
-  const size_t lds = (size_t)8 * C * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_layernorm_bwd_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(adell_layernorm_bwd_kernel, dim3(nb), dim3(256), lds, st, x, dy, gamma, mean,
-                     rstd, dx, want ? (float*)workspace : nullptr, rows, C,
-                     ADELL_LN_ROWS_PER_BLOCK);
-  if (want)
+  hipLaunchKernelGGL(adell_layernorm_bwd_dx_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     st, x, dy, gamma, mean, rstd, dx, rows, C);
+  if (want) {
+    const int rpc = adell_ln_rows_per_chunk(rows, C);
+    const int nb = (int)((rows + rpc - 1) / rpc);
+    hipLaunchKernelGGL(adell_layernorm_bwd_affine_kernel, dim3(adell_cdiv(C, 256), nb), dim3(256),
+                       0, st, x, dy, mean, rstd, (float*)workspace, rows, C, rpc);
     hipLaunchKernelGGL(adell_rowsum_final_kernel, dim3(adell_cdiv(2 * C, 64)), dim3(256), 0, st,
                        (const float*)workspace, nb, 2 * C, dgamma, dbeta, C);
+  }
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

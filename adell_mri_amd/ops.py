@@ -1195,7 +1195,9 @@ def channel_max_fwd(x):
 
 
 def channel_max_bwd(dout, arg, shape):
-    _require_cuda(dout, arg)
+    _require_cuda(dout)
+    if not arg.is_cuda or arg.dtype != torch.int32:
+        raise _lib.AdellHipError("channel_max_bwd: arg must be the int32 CUDA tensor of the forward")
     N, C = shape[:2]
     V = int(math.prod(shape[2:]))
     dx = new_act(N, C, *shape[2:], dout.device)

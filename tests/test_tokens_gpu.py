@@ -23,7 +23,8 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
 
-@pytest.mark.parametrize("rows,C", [(37, 64), (216, 512), (5, 4096), (1000, 7)])
+@pytest.mark.parametrize("rows,C", [(37, 64), (216, 512), (5, 4096), (1000, 7), (864, 4096),
+                                    (300, 1024)])
 def test_layernorm_fwd_bwd_matches_torch_cpu(cuda, rows, C):
     g = torch.Generator().manual_seed(0)
     x = (torch.randn(rows, C, generator=g) * 2 + 1).requires_grad_(True)

@@ -14,7 +14,7 @@ from adell_mri_amd.trainer import StepRunner  # noqa: E402
 
 dev = torch.device("cuda", 0)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-net = bench.build_module(dev, size)
+net, _ = bench.build_module(dev)
 net.train()
 opt = net.configure_optimizers()["optimizer"]
 runner = StepRunner(net, opt, GradSync(opt))
