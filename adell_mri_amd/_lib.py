@@ -145,6 +145,13 @@ SIGNATURES = {
                                _i, _f, _f, ctypes.c_ulong, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp]),
     "adell_gemm_f32_workspace_floats": (_l, [_i, _i, _i]),
     "adell_gemm_f32": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _l, _vp, _vp]),
+    "adell_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _l, _f, _f, _f, ctypes.POINTER(ctypes.c_float),
+                              _vp]),
+    "adell_seg_loss_workspace": (_l, [_i, _l, _i]),
+    "adell_seg_loss_fwd": (_i, [_i, _vp, _vp, _vp, _i, _l, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp,
+                                ctypes.c_size_t, _vp]),
+    "adell_seg_loss_bwd": (_i, [_i, _vp, _vp, _vp, _i, _l, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp,
+                                _vp]),
     "adell_channel_softmax_fwd": (_i, [_vp, _vp, _l, _i, _vp]),
     "adell_channel_softmax_bwd": (_i, [_vp, _vp, _vp, _l, _i, _vp]),
     "adell_channel_max_fwd": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),

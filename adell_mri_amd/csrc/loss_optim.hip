@@ -328,3 +328,333 @@ extern "C" int adell_ema_update(float* shadow, const float* param, long n, float
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Element-wise segmentation losses on probabilities p[B][V][C] (NDHWC memory; C = 1 for the
+// binary family) against targets of the same layout -- the members of the reference's
+// loss_factory (adell_mri/utils/utils.py:39-59) beyond the fused binary dice + focal pair:
+//   kind 0  binary_cross_entropy   (losses.py:79-109)
+//   kind 1  cat_cross_entropy      (losses.py:528-562)   target' = t (1 - ls) + 1 / C   [sic]
+//   kind 2  mc_focal_loss          (losses.py:565-607)
+//   kind 3  mc_generalized_dice_loss (losses.py:610-653, generalised_dice_score :14-54)
+// Forward: per-(item, block, class) partial sums (S0, S1) -> fixed-order fp64 fold -> loss[B] and
+// sums[B][C][2] (kept for the backward). cw[C] = class weights / alpha (1-vectors are broadcast
+// by the caller). HBM-bound: one read of (p, t); the backward reads (p, t) and writes dp.
+// ---------------------------------------------------------------------------------------------
+struct SegLossArgs {
+  const float* p;
+  const float* t;
+  const float* cw;     // [C]
+  float* part;         // [B][nblk][C][2]
+  const float* sums;   // [B][C][2]
+  const float* gout;   // [B] upstream gradient (backward)
+  float* dp;
+  long V;
+  int C, nblk, kind;
+  float eps, scale, ls, gamma, smooth, w_pos;
+};
+
+#define ADELL_SEGLOSS_ROWS 2048   // voxels per block
+
+__device__ __forceinline__ void adell_segloss_terms(const SegLossArgs& a, float p, float t, int c,
+                                                    float* s0, float* s1) {
+  switch (a.kind) {
+    case 0: {
+      const float tt = t * (1.f - a.ls) + 0.5f * a.ls;
+      *s0 = (a.w_pos * tt * logf(p + a.eps) + (1.f - tt) * logf(1.f - p + a.eps)) * a.scale;
+      *s1 = 0.f;
+      break;
+    }
+    case 1: {
+      const float tt = t * (1.f - a.ls) + 1.f / (float)a.C;
+      *s0 = -tt * logf(p + a.eps) * a.cw[c] * a.scale;
+      *s1 = 0.f;
+      break;
+    }
+    case 2: {
+      const float pt = t > 0.5f ? p : 1.f - p;
+      const float tt = t * (1.f - a.ls) + 1.f / (float)a.C;
+      const float ce = -tt * logf(p + a.eps);
+      *s0 = a.cw[c] * powf(1.f - pt + a.eps, a.gamma) * ce * a.scale;
+      *s1 = 0.f;
+      break;
+    }
+    default: {
+      *s0 = fmaxf(t * p * a.scale, 0.f);
+      *s1 = fmaxf((t + p + a.smooth) * a.scale, a.eps);
+      break;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_segloss_partials_kernel(SegLossArgs a) {
+  extern __shared__ float sh[];   // [256][2] staging for the per-class fold
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const long v0 = (long)blk * ADELL_SEGLOSS_ROWS;
+  long v1 = v0 + ADELL_SEGLOSS_ROWS;
+  if (v1 > a.V) v1 = a.V;
+  const float* p = a.p + (size_t)b * a.V * a.C;
+  const float* t = a.t + (size_t)b * a.V * a.C;
+  const long e0 = v0 * a.C, e1 = v1 * a.C;
+  // thread tid visits elements tid, tid + 256, ...: its class is constant iff 256 % C == 0;
+  // otherwise accumulate per class in a short loop
+  for (int c = 0; c < a.C; ++c) {
+    float s0 = 0.f, s1 = 0.f;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+      if ((int)(e % a.C) != c) continue;
+      float u0, u1;
+      adell_segloss_terms(a, p[e], t[e], c, &u0, &u1);
+      s0 += u0;
+      s1 += u1;
+    }
+    s0 = adell_wave_sum(s0);
+    s1 = adell_wave_sum(s1);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      sh[(threadIdx.x >> 6) * 2 + 0] = s0;
+      sh[(threadIdx.x >> 6) * 2 + 1] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+      a.part[(((size_t)b * a.nblk + blk) * a.C + c) * 2 + threadIdx.x] =
+          (sh[threadIdx.x] + sh[2 + threadIdx.x]) + (sh[4 + threadIdx.x] + sh[6 + threadIdx.x]);
+  }
+}
+
+__global__ void adell_segloss_finalize_kernel(SegLossArgs a, float* __restrict__ sums,
+                                              float* __restrict__ loss) {
+  const int b = blockIdx.x;
+  __shared__ double acc[32][2];
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < a.nblk; ++k) {
+      s0 += (double)a.part[(((size_t)b * a.nblk + k) * a.C + c) * 2 + 0];
+      s1 += (double)a.part[(((size_t)b * a.nblk + k) * a.C + c) * 2 + 1];
+    }
+    sums[((size_t)b * a.C + c) * 2 + 0] = (float)s0;
+    sums[((size_t)b * a.C + c) * 2 + 1] = (float)s1;
+    acc[c][0] = s0;
+    acc[c][1] = s1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double n = (double)a.V * a.C;
+    double out;
+    if (a.kind == 3) {
+      double num = 0.0, den = 0.0;
+      for (int c = 0; c < a.C; ++c) {
+        num += (double)a.cw[c] * acc[c][0];
+        den += (double)a.cw[c] * acc[c][1];
+      }
+      out = 1.0 - 2.0 * num / den;
+    } else {
+      double s = 0.0;
+      for (int c = 0; c < a.C; ++c) s += acc[c][0];
+      out = (a.kind == 0 ? -s : s) / n;
+    }
+    loss[b] = (float)out;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_segloss_bwd_kernel(SegLossArgs a) {
+  const int b = blockIdx.y;
+  const float* p = a.p + (size_t)b * a.V * a.C;
+  const float* t = a.t + (size_t)b * a.V * a.C;
+  float* dp = a.dp + (size_t)b * a.V * a.C;
+  const long n = a.V * a.C;
+  const float g = a.gout[b];
+  float num = 0.f, den = 1.f;
+  if (a.kind == 3) {
+    num = den = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+      num += a.cw[c] * a.sums[((size_t)b * a.C + c) * 2 + 0];
+      den += a.cw[c] * a.sums[((size_t)b * a.C + c) * 2 + 1];
+    }
+  }
+  const float inv_n = 1.0f / (float)n, inv_den2 = 1.0f / (den * den);
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % a.C);
+    const float pe = p[e], te = t[e];
+    float d;
+    switch (a.kind) {
+      case 0: {
+        const float tt = te * (1.f - a.ls) + 0.5f * a.ls;
+        d = -(a.w_pos * tt / (pe + a.eps) - (1.f - tt) / (1.f - pe + a.eps)) * a.scale * inv_n;
+        break;
+      }
+      case 1: {
+        const float tt = te * (1.f - a.ls) + 1.f / (float)a.C;
+        d = -tt / (pe + a.eps) * a.cw[c] * a.scale * inv_n;
+        break;
+      }
+      case 2: {
+        const bool pos = te > 0.5f;
+        const float q = 1.f - (pos ? pe : 1.f - pe) + a.eps;      // 1 - pt + eps
+        const float dq = pos ? -1.f : 1.f;
+        const float tt = te * (1.f - a.ls) + 1.f / (float)a.C;
+        const float lg = logf(pe + a.eps);
+        const float qg1 = powf(q, a.gamma - 1.f);
+        // d/dp [ q^g * (-tt log(p + eps)) ]
+        d = a.cw[c] * (-tt) * (a.gamma * qg1 * dq * lg + qg1 * q / (pe + a.eps)) * a.scale * inv_n;
+        break;
+      }
+      default: {
+        const float dnum = (te * pe * a.scale > 0.f) ? a.cw[c] * te * a.scale : 0.f;
+        const float dden = ((te + pe + a.smooth) * a.scale > a.eps) ? a.cw[c] * a.scale : 0.f;
+        d = -2.0f * (dnum * den - num * dden) * inv_den2;
+        break;
+      }
+    }
+    dp[e] = g * d;
+  }
+}
+
+static int adell_segloss_fill(SegLossArgs* a, int kind, const float* p, const float* t,
+                              const float* cw, int B, long V, int C, float eps, float scale,
+                              float ls, float gamma, float smooth, float w_pos) {
+  ADELL_REQUIRE(kind >= 0 && kind <= 3, "seg_loss: kind must be 0..3");
+  ADELL_REQUIRE(p && t && B > 0 && B <= 65535 && V > 0 && C > 0 && C <= 32, "seg_loss: bad arguments");
+  ADELL_REQUIRE(kind == 0 || cw, "seg_loss: class weights missing");
+  *a = SegLossArgs{};
+  a->p = p; a->t = t; a->cw = cw; a->V = V; a->C = C; a->kind = kind;
+  a->nblk = (int)((V + ADELL_SEGLOSS_ROWS - 1) / ADELL_SEGLOSS_ROWS);
+  a->eps = eps; a->scale = scale; a->ls = ls; a->gamma = gamma; a->smooth = smooth; a->w_pos = w_pos;
+  return ADELL_OK;
+}
+
+extern "C" long adell_seg_loss_workspace(int B, long V, int C) {
+  if (B <= 0 || V <= 0 || C <= 0) return ADELL_E_BADARG;
+  return (long)sizeof(float) * B * ((V + ADELL_SEGLOSS_ROWS - 1) / ADELL_SEGLOSS_ROWS) * C * 2;
+}
+
+extern "C" int adell_seg_loss_fwd(int kind, const float* p, const float* t, const float* cw, int B,
+                                  long V, int C, float eps, float scale, float label_smoothing,
+                                  float gamma, float smooth, float w_pos, float* loss,
+                                  float* sums, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  SegLossArgs a;
+  int rc = adell_segloss_fill(&a, kind, p, t, cw, B, V, C, eps, scale, label_smoothing, gamma,
+                              smooth, w_pos);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(loss && sums && workspace &&
+                    (long)workspace_bytes >= adell_seg_loss_workspace(B, V, C),
+                "seg_loss_fwd: null output or workspace too small");
+  a.part = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_segloss_partials_kernel, dim3(a.nblk, B), dim3(256), 8 * sizeof(float),
+                     st, a);
+  hipLaunchKernelGGL(adell_segloss_finalize_kernel, dim3(B), dim3(32), 0, st, a, sums, loss);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_seg_loss_bwd(int kind, const float* p, const float* t, const float* cw, int B,
+                                  long V, int C, float eps, float scale, float label_smoothing,
+                                  float gamma, float smooth, float w_pos, const float* sums,
+                                  const float* gout, float* dp, void* stream) {
+  SegLossArgs a;
+  int rc = adell_segloss_fill(&a, kind, p, t, cw, B, V, C, eps, scale, label_smoothing, gamma,
+                              smooth, w_pos);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(sums && gout && dp, "seg_loss_bwd: null pointer");
+  a.sums = sums; a.gout = gout; a.dp = dp;
+  long blocks = (V * C + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adell_segloss_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The other members of the reference's optimizer factory (adell_mri/utils/optimizer_factory.py:
+// 5-14) over flat fp32 buffers, torch.optim single-tensor semantics with L2 weight decay added to
+// the gradient; the per-step scalars (bias corrections, NAdam's mu products, RAdam's rectifier)
+// are computed on the host and passed in c[]:
+//   kind 0 Adamax   s1 = exp_avg, s2 = exp_inf;   c = {beta1, beta2, lr / (1 - beta1^t)}
+//   kind 1 Adagrad  s1 = sum;                     c = {lr / (1 + (t - 1) lr_decay)}
+//   kind 2 NAdam    s1 = exp_avg, s2 = exp_avg_sq; c = {beta1, beta2, 1 - beta2^t,
+//                                                      lr (1 - mu) / (1 - mu_prod),
+//                                                      lr mu_next / (1 - mu_prod mu_next)}
+//   kind 3 RAdam    s1 = exp_avg, s2 = exp_avg_sq; c = {beta1, beta2, lr / (1 - beta1^t),
+//                                                      rect sqrt(1 - beta2^t) or < 0: not rectified}
+//   kind 4 RMSprop  s1 = square_avg;              c = {alpha, lr}      (momentum 0, not centered)
+// ---------------------------------------------------------------------------------------------
+struct OptimArgs {
+  float* p;
+  const float* g;
+  float* s1;
+  float* s2;
+  long n;
+  int kind;
+  float wd, eps, grad_scale;
+  float c[5];
+};
+
+__global__ __launch_bounds__(256) void adell_optim_kernel(OptimArgs a) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < a.n; i += (long)gridDim.x * 256L) {
+    float pi = a.p[i];
+    const float gi = a.g[i] * a.grad_scale + a.wd * pi;
+    switch (a.kind) {
+      case 0: {
+        const float m = a.c[0] * a.s1[i] + (1.f - a.c[0]) * gi;
+        const float u = fmaxf(a.c[1] * a.s2[i], fabsf(gi) + a.eps);
+        a.s1[i] = m;
+        a.s2[i] = u;
+        pi -= a.c[2] * m / u;
+        break;
+      }
+      case 1: {
+        const float s = a.s1[i] + gi * gi;
+        a.s1[i] = s;
+        pi -= a.c[0] * gi / (sqrtf(s) + a.eps);
+        break;
+      }
+      case 2: {
+        const float m = a.c[0] * a.s1[i] + (1.f - a.c[0]) * gi;
+        const float v = a.c[1] * a.s2[i] + (1.f - a.c[1]) * gi * gi;
+        a.s1[i] = m;
+        a.s2[i] = v;
+        const float denom = sqrtf(v / a.c[2]) + a.eps;
+        pi -= a.c[3] * gi / denom;
+        pi -= a.c[4] * m / denom;
+        break;
+      }
+      case 3: {
+        const float m = a.c[0] * a.s1[i] + (1.f - a.c[0]) * gi;
+        const float v = a.c[1] * a.s2[i] + (1.f - a.c[1]) * gi * gi;
+        a.s1[i] = m;
+        a.s2[i] = v;
+        if (a.c[3] >= 0.f)
+          pi -= a.c[2] * m * a.c[3] / (sqrtf(v) + a.eps);
+        else
+          pi -= a.c[2] * m;
+        break;
+      }
+      default: {
+        const float s = a.c[0] * a.s1[i] + (1.f - a.c[0]) * gi * gi;
+        a.s1[i] = s;
+        pi -= a.c[1] * gi / (sqrtf(s) + a.eps);
+        break;
+      }
+    }
+    a.p[i] = pi;
+  }
+}
+
+extern "C" int adell_optim_step(int kind, float* param, const float* grad, float* state1,
+                                float* state2, long n, float weight_decay, float eps,
+                                float grad_scale, const float* c5, void* stream) {
+  ADELL_REQUIRE(kind >= 0 && kind <= 4, "optim_step: kind must be 0..4");
+  ADELL_REQUIRE(param && grad && state1 && c5 && n > 0, "optim_step: bad arguments");
+  ADELL_REQUIRE(state2 || kind == 1 || kind == 4, "optim_step: this optimiser needs two state buffers");
+  OptimArgs a;
+  a.p = param; a.g = grad; a.s1 = state1; a.s2 = state2; a.n = n; a.kind = kind;
+  a.wd = weight_decay; a.eps = eps; a.grad_scale = grad_scale;
+  for (int i = 0; i < 5; ++i) a.c[i] = c5[i];   // host array
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adell_optim_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

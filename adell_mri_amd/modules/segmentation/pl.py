@@ -16,7 +16,8 @@ import torch
 import torch.nn.functional as F
 
 from ... import functional as HF
-from ...optim import FusedAdam, FusedAdamW, FusedSGD
+from ...optim import (FusedAdagrad, FusedAdam, FusedAdamax, FusedAdamW, FusedNAdam, FusedRAdam,
+                      FusedRMSprop, FusedSGD)
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .unet import BrUNet, UNet
 from .unetpp import UNetPlusPlus
@@ -30,16 +31,16 @@ except Exception:  # noqa: BLE001
     _Base = torch.nn.Module
 
 
-def get_optimizer(name: str, parameters, **kwargs):
-    """Mirror of adell_mri/utils/optimizer_factory.py:17-30 for the fused optimisers."""
-    name = str(name).lower()
-    if name == "sgd":
-        return FusedSGD(parameters, **kwargs)
-    if name == "adamw":
-        return FusedAdamW(parameters, **kwargs)
-    if name == "adam":
-        return FusedAdam(parameters, **kwargs)
-    raise NotImplementedError(f"optimizer {name!r} has no fused HIP implementation yet")
+OPTIMIZER_MATCH = {"adam": FusedAdam, "adamw": FusedAdamW, "adamax": FusedAdamax, "sgd": FusedSGD,
+                   "adagrad": FusedAdagrad, "nadam": FusedNAdam, "radam": FusedRAdam,
+                   "rmsprop": FusedRMSprop}
+
+
+def get_optimizer(optimizer_str: str, *args, **kwargs):
+    """adell_mri/utils/optimizer_factory.py:17-30 on the fused flat-buffer optimisers: the same
+    eight names; as there, an unknown name returns None."""
+    if optimizer_str in OPTIMIZER_MATCH:
+        return OPTIMIZER_MATCH[optimizer_str](*args, **kwargs)
 
 
 class UNetBasePL(_Base):

@@ -1204,3 +1204,44 @@ def channel_max_bwd(dout, arg, shape):
     dc = dout.contiguous()
     check(_lib.lib().adell_channel_max_bwd(_ptr(dc), _ptr(arg), _ptr(dx), N, V, C, _stream()))
     return dx
+
+
+# ---- element-wise segmentation losses (loss_factory members beyond dice + focal) ---------------
+SEG_LOSS_KINDS = {"binary_cross_entropy": 0, "cat_cross_entropy": 1, "mc_focal": 2, "mc_dice": 3}
+
+
+def seg_loss_fwd(kind, p, t, cw, eps, scale, ls, gamma, smooth, w_pos):
+    """p, t: [B, V, C] contiguous (NDHWC order). Returns (loss [B], sums [B, C, 2])."""
+    _require_cuda(p, t, cw)
+    B, V, C = p.shape
+    ws = _workspace(_lib.lib().adell_seg_loss_workspace(B, V, C), p.device)
+    loss = torch.empty((B,), device=p.device, dtype=torch.float32)
+    sums = torch.empty((B, C, 2), device=p.device, dtype=torch.float32)
+    check(_lib.lib().adell_seg_loss_fwd(kind, _ptr(p), _ptr(t), _ptr(cw), B, V, C, eps, scale, ls,
+                                        gamma, smooth, w_pos, _ptr(loss), _ptr(sums), _ptr(ws),
+                                        ws.numel() * 4, _stream()))
+    return loss, sums
+
+
+def seg_loss_bwd(kind, p, t, cw, eps, scale, ls, gamma, smooth, w_pos, sums, gout):
+    _require_cuda(p, t, cw, sums, gout)
+    B, V, C = p.shape
+    dp = torch.empty_like(p)
+    gc = gout.contiguous()
+    check(_lib.lib().adell_seg_loss_bwd(kind, _ptr(p), _ptr(t), _ptr(cw), B, V, C, eps, scale, ls,
+                                        gamma, smooth, w_pos, _ptr(sums), _ptr(gc), _ptr(dp),
+                                        _stream()))
+    return dp
+
+
+OPTIM_KINDS = {"adamax": 0, "adagrad": 1, "nadam": 2, "radam": 3, "rmsprop": 4}
+
+
+def optim_step(kind, param, grad, s1, s2, weight_decay, eps, grad_scale, c5):
+    """One fused step of adamax / adagrad / nadam / radam / rmsprop on flat fp32 buffers."""
+    _require_cuda(param, grad, s1, s2)
+    arr = (ctypes.c_float * 5)(*[float(v) for v in (list(c5) + [0.0] * 5)[:5]])
+    check(_lib.lib().adell_optim_step(OPTIM_KINDS[kind], _ptr(param), _ptr(grad), _ptr(s1),
+                                      _ptr(s2), param.numel(), weight_decay, eps, grad_scale, arr,
+                                      _stream()))
+    _weights_changed()

@@ -317,3 +317,142 @@ class FusedAdam(FusedAdamW):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+
+class _FusedScalarPlan(_FusedBase):
+    """Shared driver of the optimisers whose step is ``ops.optim_step`` with host-computed
+    per-step scalars: ``_kind``, ``_buffers`` (flat state names: torch state_dict keys) and
+    ``_scalars(group, t, extra)`` -> the five floats of the kernel."""
+
+    _kind = None
+    _buffers = ()
+    _extra_state = ()        # per-parameter host scalars kept beside ``steps`` (NAdam: mu_product)
+
+    @property
+    def _state_names(self):
+        return self._buffers
+
+    def _param_state(self, st, i, o, n, shape):
+        out = {"step": torch.tensor(float(st["steps"][i]))}
+        for name in self._extra_state:
+            out[name] = torch.tensor(float(st[name][i]))
+        for name in self._buffers:
+            out[name] = st[name][o:o + n].view(shape).clone()
+        return out
+
+    def _load_param_state(self, gi, st, i, o, n, ent):
+        for name in self._buffers:
+            self._buffer(gi, name)[o:o + n].copy_(ent[name].reshape(-1))
+        for name in self._extra_state:
+            self._extras(gi, name)[i] = float(ent[name])
+        st["steps"][i] = int(float(ent["step"]))
+
+    def _extras(self, gi, name):
+        st = self._flat_state[gi]
+        if name not in st or torch.is_tensor(st[name]):
+            st[name] = np.ones(len(self._flat(gi).params), dtype=np.float64)
+        return st[name]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.collect_grads()
+        for gi, g in enumerate(self.param_groups):
+            flat, st = self._flat(gi), self._flat_state[gi]
+            bufs = [self._buffer(gi, name) for name in self._buffers]
+            extras = {name: self._extras(gi, name) for name in self._extra_state}
+            active = flat.has_grad()
+            st["steps"][active] += 1
+            key = st["steps"] if not extras else np.stack(
+                [st["steps"].astype(np.float64)] + [extras[n] for n in self._extra_state], 1)
+            # one launch per run of parameters with equal step counts (normally ONE run)
+            for i, lo, hi in flat.runs(active, [tuple(np.atleast_1d(k)) for k in key]):
+                c5 = self._scalars(g, int(st["steps"][i]), {n: extras[n] for n in extras}, i, lo, hi,
+                                   flat, active)
+                ops.optim_step(self._kind, flat.data[lo:hi], flat.grad[lo:hi], bufs[0][lo:hi],
+                               bufs[1][lo:hi] if len(bufs) > 1 else None, g["weight_decay"],
+                               g["eps"], g.get("grad_scale", 1.0), c5)
+        return loss
+
+
+class FusedAdamax(_FusedScalarPlan):
+    _kind, _buffers = "adamax", ("exp_avg", "exp_inf")
+
+    def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      grad_scale=1.0))
+
+    def _scalars(self, g, t, extras, i, lo, hi, flat, active):
+        b1, b2 = g["betas"]
+        return [b1, b2, g["lr"] / (1.0 - b1 ** t)]
+
+
+class FusedAdagrad(_FusedScalarPlan):
+    _kind, _buffers = "adagrad", ("sum",)
+
+    def __init__(self, params, lr=1e-2, lr_decay=0.0, weight_decay=0.0,
+                 initial_accumulator_value=0.0, eps=1e-10):
+        if initial_accumulator_value != 0.0:
+            raise NotImplementedError("FusedAdagrad: initial_accumulator_value must be 0")
+        super().__init__(params, dict(lr=lr, lr_decay=lr_decay, eps=eps, weight_decay=weight_decay,
+                                      initial_accumulator_value=0.0, grad_scale=1.0))
+
+    def _scalars(self, g, t, extras, i, lo, hi, flat, active):
+        return [g["lr"] / (1.0 + (t - 1) * g["lr_decay"])]
+
+
+class FusedNAdam(_FusedScalarPlan):
+    _kind, _buffers, _extra_state = "nadam", ("exp_avg", "exp_avg_sq"), ("mu_product",)
+
+    def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 momentum_decay=4e-3):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      momentum_decay=momentum_decay, grad_scale=1.0))
+
+    def _scalars(self, g, t, extras, i, lo, hi, flat, active):
+        b1, b2 = g["betas"]
+        md = g["momentum_decay"]
+        mu = b1 * (1.0 - 0.5 * 0.96 ** (t * md))
+        mu_next = b1 * (1.0 - 0.5 * 0.96 ** ((t + 1) * md))
+        # every parameter of the run shares the step count and the product so far
+        j = i
+        while j < len(flat.params) and flat.offsets[j] < hi:
+            if active[j]:
+                extras["mu_product"][j] *= mu
+            j += 1
+        prod = extras["mu_product"][i]
+        return [b1, b2, 1.0 - b2 ** t, g["lr"] * (1.0 - mu) / (1.0 - prod),
+                g["lr"] * mu_next / (1.0 - prod * mu_next)]
+
+
+class FusedRAdam(_FusedScalarPlan):
+    _kind, _buffers = "radam", ("exp_avg", "exp_avg_sq")
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                      grad_scale=1.0))
+
+    def _scalars(self, g, t, extras, i, lo, hi, flat, active):
+        b1, b2 = g["betas"]
+        bc2 = 1.0 - b2 ** t
+        rho_inf = 2.0 / (1.0 - b2) - 1.0
+        rho_t = rho_inf - 2.0 * t * (b2 ** t) / bc2
+        rect = -1.0
+        if rho_t > 5.0:
+            rect = (((rho_t - 4) * (rho_t - 2) * rho_inf)
+                    / ((rho_inf - 4) * (rho_inf - 2) * rho_t)) ** 0.5 * bc2 ** 0.5
+        return [b1, b2, g["lr"] / (1.0 - b1 ** t), rect]
+
+
+class FusedRMSprop(_FusedScalarPlan):
+    _kind, _buffers = "rmsprop", ("square_avg",)
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0,
+                 centered=False):
+        if momentum != 0.0 or centered:
+            raise NotImplementedError("FusedRMSprop: momentum 0 and centered=False only")
+        super().__init__(params, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay,
+                                      momentum=0.0, centered=False, grad_scale=1.0))
+
+    def _scalars(self, g, t, extras, i, lo, hi, flat, active):
+        return [g["alpha"], g["lr"]]

@@ -19,8 +19,8 @@ from ..modules.segmentation import losses as _seg_losses
 
 def _not_built(name):
     def raiser(*args, **kwargs):
-        raise NotImplementedError(f"loss {name!r} has no HIP kernel yet (built: binary dice, "
-                                  f"binary focal, categorical cross-entropy / dice / focal)")
+        raise NotImplementedError(f"loss {name!r} has no HIP kernel yet (built: binary cross-entropy / dice "
+                                  f"/ focal, categorical cross-entropy / dice / focal)")
     raiser.__name__ = name
     return raiser
 
@@ -30,7 +30,7 @@ def _not_built(name):
 # configuration files are validated the same way.
 loss_factory = {
     "binary": {
-        "cross_entropy": _not_built("binary_cross_entropy"),
+        "cross_entropy": _seg_losses.binary_cross_entropy,
         "focal": _seg_losses.binary_focal_loss,
         "dice": _seg_losses.binary_generalized_dice_loss,
         "tversky_focal": _not_built("binary_focal_tversky_loss"),
@@ -39,9 +39,9 @@ loss_factory = {
         "unified_focal": _not_built("unified_focal_loss"),
     },
     "categorical": {
-        "cross_entropy": _not_built("cat_cross_entropy"),
-        "focal": _not_built("mc_focal_loss"),
-        "dice": _not_built("mc_generalized_dice_loss"),
+        "cross_entropy": _seg_losses.cat_cross_entropy,
+        "focal": _seg_losses.mc_focal_loss,
+        "dice": _seg_losses.mc_generalized_dice_loss,
         "tversky_focal": _not_built("mc_focal_tversky_loss"),
         "combo": _not_built("mc_combo_loss"),
         "hybrid_focal": _not_built("mc_hybrid_focal_loss"),

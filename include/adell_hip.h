@@ -310,6 +310,15 @@ int adell_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
 int adell_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n,
                     float lr, float beta1, float beta2, float eps, float weight_decay, long step,
                     float grad_scale, void* stream);
+
+/* The other optimisers of the reference's factory (utils/optimizer_factory.py:5-14), torch.optim
+ * single-tensor semantics, L2 weight decay added to the gradient: kind 0 Adamax (state1 exp_avg,
+ * state2 exp_inf), 1 Adagrad (sum), 2 NAdam (exp_avg, exp_avg_sq), 3 RAdam (exp_avg, exp_avg_sq),
+ * 4 RMSprop (square_avg; momentum 0, not centered). c5: HOST array of the five per-step scalars
+ * documented at adell_optim_kernel (csrc/loss_optim.hip). */
+int adell_optim_step(int kind, float* param, const float* grad, float* state1, float* state2,
+                     long n, float weight_decay, float eps, float grad_scale, const float* c5,
+                     void* stream);
 int adell_ema_update(float* shadow, const float* param, long n, float decay, void* stream);
 
 /* ------------------------------------------------------------------------
@@ -511,6 +520,22 @@ long adell_gemm_f32_workspace_floats(int M, int N, int K);
 int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int a_kc, const float* B,
                    long ldb, int b_kc, float* C, long ldc, const float* bias,
                    const float* residual, long ldr, float* workspace, void* stream);
+
+/* Element-wise segmentation losses beyond the fused binary dice + focal pair, on probabilities
+ * p[B][V][C] (NDHWC; C = 1 for the binary family) against targets of the same layout:
+ * kind 0 binary_cross_entropy (losses.py:79-109), 1 cat_cross_entropy (:528-562), 2 mc_focal_loss
+ * (:565-607), 3 mc_generalized_dice_loss (:610-653). cw[C] = class weights / alpha (not used by
+ * kind 0, which takes w_pos). loss[B]; sums[B][C][2] is kept for the backward, which writes
+ * dp = gout[b] * d loss[b] / d p. workspace: adell_seg_loss_workspace(B, V, C) bytes. */
+long adell_seg_loss_workspace(int B, long V, int C);
+int adell_seg_loss_fwd(int kind, const float* p, const float* t, const float* cw, int B, long V,
+                       int C, float eps, float scale, float label_smoothing, float gamma,
+                       float smooth, float w_pos, float* loss, float* sums, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int adell_seg_loss_bwd(int kind, const float* p, const float* t, const float* cw, int B, long V,
+                       int C, float eps, float scale, float label_smoothing, float gamma,
+                       float smooth, float w_pos, const float* sums, const float* gout, float* dp,
+                       void* stream);
 
 /* Softmax over the channel axis of an NDHWC tensor (rows = N * voxels, C <= 32 contiguous
  * class values per row): the n_classes > 2 head, torch.nn.Softmax(dim=1) at unet.py:641-655.

@@ -585,8 +585,39 @@ def gen_surface():
     with open(os.path.join(OUT, "factory_surface.json"), "w") as fh:
         json.dump(out, fh, indent=0)
 
+from oracle.make_golden_cases import LOSS_CASES  # noqa: E402
+
+
+def gen_losses():
+    """The loss_factory members beyond binary dice / focal (utils/utils.py:39-59), values and
+    gradients with respect to the probabilities, from the reference's own functions."""
+    from adell_mri.modules.segmentation import losses as L
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    logits = torch.randn((2, 3, 6, 7, 5), generator=g) * 2
+    cls = torch.randint(0, 3, (2, 6, 7, 5), generator=g)
+    onehot = torch.nn.functional.one_hot(cls, 3).permute(0, 4, 1, 2, 3).float()
+    pb = torch.sigmoid(torch.randn((2, 1, 6, 7, 5), generator=g) * 2)
+    tb = (torch.rand((2, 1, 6, 7, 5), generator=g) > 0.7).float()
+    r = torch.rand((2,), generator=g) + 0.5
+    out.update(logits=logits.numpy(), cls=cls.numpy(), pb=pb.numpy(), tb=tb.numpy(), r=r.numpy())
+    for name, (fn, kw, kind) in LOSS_CASES.items():
+        if kind == "binary":
+            p, t = pb.clone().requires_grad_(True), tb
+        else:
+            p = torch.softmax(logits, 1).detach().requires_grad_(True)
+            t = onehot if kind == "onehot" else cls
+        val = getattr(L, fn)(p, t, **kw)
+        (val * r).sum().backward()
+        out[name + ":value"], out[name + ":grad"] = val.detach().numpy(), p.grad.numpy().copy()
+        print(name, val.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "losses_mc.npz"), **out)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":
+        gen_losses()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         gen_surface()
         sys.exit(0)

@@ -1,0 +1,82 @@
+"""HIP element-wise segmentation losses (csrc/loss_optim.hip, adell_seg_loss_*) against the
+reference fixture tests/golden/losses_mc.npz (values + gradients from the reference's own
+functions) and, on larger ragged shapes, against the CPU restatement oracle/torch_ref/losses.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from adell_mri_amd.modules.segmentation import losses as HL
+from adell_mri_amd.modules.segmentation.losses import CompoundLoss
+from adell_mri_amd.utils.utils import loss_factory
+from oracle.make_golden_cases import LOSS_CASES
+from oracle.torch_ref import losses as RL
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HIP = {"binary_cross_entropy": HL.binary_cross_entropy, "cat_cross_entropy": HL.cat_cross_entropy,
+       "mc_focal_loss": HL.mc_focal_loss, "mc_generalized_dice_loss": HL.mc_generalized_dice_loss}
+REF = {"binary_cross_entropy": RL.binary_cross_entropy, "cat_cross_entropy": RL.cat_cross_entropy,
+       "mc_focal_loss": RL.mc_focal_loss, "mc_generalized_dice_loss": RL.mc_generalized_dice_loss}
+
+
+@pytest.mark.parametrize("name", list(LOSS_CASES))
+def test_loss_matches_reference_fixture(cuda, name):
+    g = np.load(os.path.join(GOLD, "losses_mc.npz"))
+    fn, kw, kind = LOSS_CASES[name]
+    cls = torch.from_numpy(g["cls"])
+    if kind == "binary":
+        p, t = torch.from_numpy(g["pb"]), torch.from_numpy(g["tb"])
+    else:
+        p = torch.softmax(torch.from_numpy(g["logits"]), 1)
+        t = torch.nn.functional.one_hot(cls, 3).permute(0, 4, 1, 2, 3).float() if kind == "onehot" else cls
+    pd = p.to(cuda).requires_grad_(True)
+    val = HIP[fn](pd, t.to(cuda), **kw)
+    (val * torch.from_numpy(g["r"]).to(cuda)).sum().backward()
+    np.testing.assert_allclose(val.detach().cpu().numpy(), g[name + ":value"], rtol=2e-5, atol=1e-7)
+    ref = g[name + ":grad"]
+    assert np.abs(pd.grad.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max() + 1e-9
+
+
+@pytest.mark.parametrize("fn,kw,C,shape", [
+    ("cat_cross_entropy", dict(weight=[1.0, 0.5, 2.0, 1.5, 1.0], label_smoothing=0.2), 5, (3, 17, 9, 11)),
+    ("mc_focal_loss", dict(alpha=[0.3, 1.0, 2.0, 1.0], gamma=3.0), 4, (2, 33, 29)),
+    ("mc_generalized_dice_loss", dict(weight=[1.0, 3.0, 0.2, 1.0, 1.0, 2.0, 1.0], smooth=0.1, scale=2.0), 7,
+     (2, 20, 24, 28)),
+    ("binary_cross_entropy", dict(weight=0.7, scale=2.0), 1, (4, 50, 60, 10)),
+])
+def test_loss_matches_cpu_restatement_on_ragged_shapes(cuda, fn, kw, C, shape):
+    g = torch.Generator().manual_seed(C)
+    B = shape[0]
+    if C == 1:
+        p = torch.sigmoid(torch.randn((B, 1, *shape[1:]), generator=g) * 2)
+        t = (torch.rand(p.shape, generator=g) > 0.6).float()
+    else:
+        p = torch.softmax(torch.randn((B, C, *shape[1:]), generator=g) * 2, 1)
+        cls = torch.randint(0, C, (B, *shape[1:]), generator=g)
+        t = torch.nn.functional.one_hot(cls, C).permute(0, len(shape), *range(1, len(shape))).float()
+    r = torch.rand((B,), generator=g) + 0.5
+    pr = p.clone().requires_grad_(True)
+    vr = REF[fn](pr, t, **kw)
+    (vr * r).sum().backward()
+    pd = p.to(cuda).requires_grad_(True)
+    vd = HIP[fn](pd, t.to(cuda), **kw)
+    (vd * r.to(cuda)).sum().backward()
+    assert torch.allclose(vd.detach().cpu(), vr.detach(), rtol=2e-5, atol=1e-7)
+    assert float((pd.grad.cpu() - pr.grad).abs().max()) < 3e-5 * float(pr.grad.abs().max()) + 1e-10
+
+
+def test_categorical_compound_loss_from_the_factory(cuda):
+    """parse_config_unet(n_classes = 3) -> CompoundLoss over loss_factory["categorical"]: the
+    list-of-[B] contract of calculate_loss (pl.py:218-222) on a softmax head."""
+    loss = CompoundLoss([(loss_factory["categorical"]["dice"], {"smooth": 1e-5}),
+                         (loss_factory["categorical"]["focal"], {"alpha": 1.0, "gamma": 2.0}),
+                         (loss_factory["categorical"]["cross_entropy"], None)])
+    g = torch.Generator().manual_seed(0)
+    p = torch.softmax(torch.randn((2, 3, 8, 8, 8), generator=g), 1).to(cuda).requires_grad_(True)
+    cls = torch.randint(0, 3, (2, 8, 8, 8), generator=g).to(cuda)
+    out = loss(p, cls)
+    assert len(out) == 3 and all(o.shape == (2,) for o in out)
+    torch.stack([o.mean() for o in out]).mean().backward()
+    assert torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0

@@ -8,7 +8,8 @@ import io
 import pytest
 import torch
 
-from adell_mri_amd.optim import FusedAdamW, FusedSGD
+from adell_mri_amd.optim import (FusedAdagrad, FusedAdamax, FusedAdamW, FusedNAdam, FusedRAdam,
+                                 FusedRMSprop, FusedSGD)
 
 
 def _model():
@@ -31,17 +32,27 @@ def _torch_steps(m, make, n):
 
 SGD = dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=0.01)
 ADAMW = dict(lr=0.01, betas=(0.8, 0.9), eps=1e-6, weight_decay=0.1)
+# name -> (torch.optim class, fused class, keyword arguments): the eight names of the
+# reference's optimizer factory (utils/optimizer_factory.py:5-14)
+KINDS = {
+    "sgd": (torch.optim.SGD, FusedSGD, SGD),
+    "adamw": (torch.optim.AdamW, FusedAdamW, ADAMW),
+    "adamax": (torch.optim.Adamax, FusedAdamax, dict(lr=0.01, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.05)),
+    "adagrad": (torch.optim.Adagrad, FusedAdagrad, dict(lr=0.05, lr_decay=0.01, eps=1e-8, weight_decay=0.05)),
+    "nadam": (torch.optim.NAdam, FusedNAdam, dict(lr=0.01, betas=(0.8, 0.95), eps=1e-6, weight_decay=0.05)),
+    "radam": (torch.optim.RAdam, FusedRAdam, dict(lr=0.01, betas=(0.8, 0.9), eps=1e-6, weight_decay=0.05)),
+    "rmsprop": (torch.optim.RMSprop, FusedRMSprop, dict(lr=0.01, alpha=0.9, eps=1e-6, weight_decay=0.05)),
+}
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+@pytest.mark.parametrize("kind", list(KINDS))
 def test_load_torch_state_dict_keeps_parameters_aliased_and_round_trips(kind):
+    tcls, fcls, kw = KINDS[kind]
     m = _model()
-    topt = _torch_steps(m, (lambda p: torch.optim.SGD(p, **SGD)) if kind == "sgd"
-                        else (lambda p: torch.optim.AdamW(p, **ADAMW)), 2)
+    topt = _torch_steps(m, lambda p: tcls(p, **kw), 2)
     sd = topt.state_dict()
     m2 = copy.deepcopy(m)
-    fused = FusedSGD(m2.parameters(), lr=1.0, momentum=0.5) if kind == "sgd" \
-        else FusedAdamW(m2.parameters(), lr=1.0)
+    fused = fcls(m2.parameters(), lr=1.0)
     flat = fused.flat_groups[0]
     assert "_flat" not in fused.param_groups[0]
     fused.load_state_dict(sd)
@@ -50,11 +61,16 @@ def test_load_torch_state_dict_keeps_parameters_aliased_and_round_trips(kind):
         assert p.data_ptr() == flat.data.data_ptr() + 4 * o
     assert fused.flat_groups[0] is flat
     g = fused.param_groups[0]
-    assert g["lr"] == (SGD if kind == "sgd" else ADAMW)["lr"]
+    assert g["lr"] == kw["lr"]
     out = fused.state_dict()
     assert [pg["params"] for pg in out["param_groups"]] == [pg["params"] for pg in sd["param_groups"]]
-    assert set(out["state"]) == set(sd["state"])        # frozen / unused parameters: no state
+    # frozen / unused parameters: no state (torch's Adagrad creates zero-step entries for every
+    # parameter at construction: those carry no information)
+    stepped = {k for k, v in sd["state"].items() if float(v.get("step", 1)) > 0}
+    assert set(out["state"]) == stepped
     for pid, ent in sd["state"].items():
+        if pid not in stepped:
+            continue
         for k, v in ent.items():
             got = out["state"][pid][k]
             if torch.is_tensor(v):
@@ -65,21 +81,20 @@ def test_load_torch_state_dict_keeps_parameters_aliased_and_round_trips(kind):
     buf.seek(0)
     again = torch.load(buf, weights_only=True)
     fused.load_state_dict(again)
-    assert set(fused.state_dict()["state"]) == set(sd["state"])
+    assert set(fused.state_dict()["state"]) == stepped
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+@pytest.mark.parametrize("kind", list(KINDS))
 def test_step_after_load_and_gradientless_parameters_match_torch(cuda, kind):
-    make = (lambda p: torch.optim.SGD(p, **SGD)) if kind == "sgd" else \
-        (lambda p: torch.optim.AdamW(p, **ADAMW))
+    tcls, fcls, kw = KINDS[kind]
     m = _model()
-    topt = _torch_steps(m, make, 2)
+    topt = _torch_steps(m, lambda p: tcls(p, **kw), 2)
     m2 = copy.deepcopy(m).to(cuda)
-    fused = (FusedSGD if kind == "sgd" else FusedAdamW)(m2.parameters())
+    fused = fcls(m2.parameters())
     fused.load_state_dict(topt.state_dict())
     g = torch.Generator().manual_seed(9)
-    for _ in range(2):
+    for _ in range(6 if kind == "radam" else 2):   # RAdam: past the rectification threshold
         x = torch.randn(4, 6, generator=g)
         topt.zero_grad()
         m(x).pow(2).mean().backward()
@@ -100,3 +115,11 @@ def test_step_after_load_and_gradientless_parameters_match_torch(cuda, kind):
     assert torch.allclose(m.unused, m2.unused.cpu(), rtol=2e-5, atol=1e-6)
     for (k, a), b in zip(m.named_parameters(), m2.parameters()):
         assert torch.allclose(a, b.cpu(), rtol=2e-5, atol=1e-6), k
+
+
+def test_get_optimizer_covers_the_reference_factory_names():
+    from adell_mri_amd.modules.segmentation.pl import OPTIMIZER_MATCH, get_optimizer
+
+    assert sorted(OPTIMIZER_MATCH) == sorted(["adam", "adamw", "adamax", "sgd", "adagrad", "nadam",
+                                              "radam", "rmsprop"])
+    assert get_optimizer("str", []) is None       # unknown name -> None, as the reference

@@ -118,3 +118,29 @@ def test_brunet_oracle_matches_reference():
     for k, p in net.sd.items():
         ref = g["grad:" + k]
         assert np.abs(p.grad.numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-7, k
+
+
+def test_loss_restatements_match_reference_fixture():
+    """oracle/torch_ref/losses.py against tests/golden/losses_mc.npz (values and gradients from the
+    reference's own functions, oracle/make_golden.py gen_losses)."""
+    import torch
+
+    from oracle.make_golden_cases import LOSS_CASES
+    from oracle.torch_ref import losses as L
+
+    g = np.load(os.path.join(GOLD, "losses_mc.npz"))
+    logits, cls = torch.from_numpy(g["logits"]), torch.from_numpy(g["cls"])
+    onehot = torch.nn.functional.one_hot(cls, 3).permute(0, 4, 1, 2, 3).float()
+    r = torch.from_numpy(g["r"])
+    fns = {"binary_cross_entropy": L.binary_cross_entropy, "cat_cross_entropy": L.cat_cross_entropy,
+           "mc_focal_loss": L.mc_focal_loss, "mc_generalized_dice_loss": L.mc_generalized_dice_loss}
+    for name, (fn, kw, kind) in LOSS_CASES.items():
+        if kind == "binary":
+            p, t = torch.from_numpy(g["pb"]).requires_grad_(True), torch.from_numpy(g["tb"])
+        else:
+            p = torch.softmax(logits, 1).detach().requires_grad_(True)
+            t = onehot if kind == "onehot" else cls
+        val = fns[fn](p, t, **kw)
+        (val * r).sum().backward()
+        np.testing.assert_allclose(val.detach().numpy(), g[name + ":value"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(p.grad.numpy(), g[name + ":grad"], rtol=1e-4, atol=1e-8)
