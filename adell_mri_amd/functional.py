@@ -760,9 +760,14 @@ class _CatFn(torch.autograd.Function):
 
 
 def cat_channels(tensors):
-    """torch.cat(tensors, 1) for [N,C,D,H,W] activations, staying NDHWC."""
+    """torch.cat(tensors, 1) for [N,C,D,H,W] activations, staying NDHWC ([N,C,H,W]: depth-1
+    volumes)."""
     tensors = list(tensors)
-    return tensors[0] if len(tensors) == 1 else _CatFn.apply(*tensors)
+    if len(tensors) == 1:
+        return tensors[0]
+    if tensors[0].dim() == 4:
+        return _CatFn.apply(*[t.unsqueeze(2) for t in tensors]).squeeze(2)
+    return _CatFn.apply(*tensors)
 
 
 class _NearestFn(torch.autograd.Function):
@@ -781,6 +786,8 @@ def interpolate_nearest(x, size):
     size = tuple(int(s) for s in size)
     if tuple(x.shape[2:]) == size:
         return x
+    if x.dim() == 4:
+        return _NearestFn.apply(x.unsqueeze(2), (1, *size)).squeeze(2)
     return _NearestFn.apply(x, size)
 
 

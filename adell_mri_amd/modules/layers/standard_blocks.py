@@ -43,8 +43,6 @@ class DenseBlock(torch.nn.Module):
                                                 self.adn_fn(d)))
 
     def forward(self, X: torch.Tensor, X_skip=None):
-        if X.dim() != 5:
-            raise NotImplementedError("HIP DenseBlock is 3-D")
         outputs = [X]
         out = X
         for i in range(len(self.ops)):

@@ -91,6 +91,8 @@ class UNetPlusPlus(UNet):
 
     def _act(self, X):
         if isinstance(self.final_act, torch.nn.Sigmoid):
+            if X.dim() == 4:   # 2-D network: depth-1 volume
+                return HF.norm_drop_act(X.unsqueeze(2), act="sigmoid").squeeze(2)
             return HF.norm_drop_act(X, act="sigmoid")
         return HF.channel_softmax(X)   # torch.nn.Softmax(dim=1)
 

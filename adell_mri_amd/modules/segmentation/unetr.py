@@ -17,7 +17,7 @@ import torch
 
 from ..._lib import AdellHipError
 from ..layers.adn_fn import get_adn_fn
-from ..layers.conv import ConvTranspose3d
+from ..layers.conv import ConvTranspose2d, ConvTranspose3d
 from ... import functional as HF
 from ..layers.vit import LinearEmbedding, SWINTransformerBlockStack, ViT
 from .unet import UNet
@@ -100,8 +100,6 @@ class UNETR(UNet, torch.nn.Module):
         self.in_channels_rec = int(np.prod([self.scale ** self.spatial_dimensions,
                                             self.in_channels]))
         self.assertions()
-        if self.spatial_dimensions != 3:
-            raise NotImplementedError("HIP UNETR is 3-D (the BASELINE configuration)")
         if self.feature_conditioning:
             raise NotImplementedError("feature conditioning is outside the HIP path built so far")
 
@@ -157,8 +155,9 @@ class UNETR(UNet, torch.nn.Module):
             self.adn_fn(self.depth[0]))
 
     def unetr_transp_op(self, in_d: int, out_d: int, kernel_size: int = 3) -> torch.nn.Module:
+        transp_conv = ConvTranspose2d if self.spatial_dimensions == 2 else ConvTranspose3d
         return torch.nn.Sequential(
-            ConvTranspose3d(in_d, out_d, 2, 2), self.adn_fn(out_d),
+            transp_conv(in_d, out_d, 2, 2), self.adn_fn(out_d),
             self.conv_op_enc(out_d, out_d, kernel_size, padding="same"), self.adn_fn(out_d))
 
     def unetr_transp_block(self, in_d: int, out_d: int, n_ops: int,

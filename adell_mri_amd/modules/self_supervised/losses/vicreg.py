@@ -23,8 +23,14 @@ class VICRegLoss(torch.nn.Module):
         self.nu = nu
 
     def flatten_if_necessary(self, x):
+        """[B, C, *spatial] feature maps -> [B, C] spatial means (vicreg.py:138-141), on the
+        channel-statistics kernel."""
         if len(x.shape) > 2:
-            return x.flatten(start_dim=2).mean(-1)
+            if x.dim() == 5:
+                return HF.channel_mean(x)
+            if x.dim() == 4:
+                return HF.channel_mean(x.unsqueeze(2))
+            return HF.channel_mean(x.unsqueeze(2).unsqueeze(2))
         return x
 
     def vicreg_loss(self, X1: torch.Tensor, X2: torch.Tensor, adj: float = 1.0):
@@ -34,7 +40,6 @@ class VICRegLoss(torch.nn.Module):
 
     def forward(self, X1: torch.Tensor, X2: torch.Tensor
                 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        if len(X1.shape) > 2 or len(X2.shape) > 2:
-            raise NotImplementedError("HIP VICRegLoss takes [B, D] embeddings")
-        var_loss, cov_loss, inv_loss = self.vicreg_loss(X1, X2)
+        var_loss, cov_loss, inv_loss = self.vicreg_loss(self.flatten_if_necessary(X1),
+                                                        self.flatten_if_necessary(X2))
         return self.lam * inv_loss, self.mu * var_loss, self.nu * cov_loss

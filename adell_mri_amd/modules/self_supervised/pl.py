@@ -16,6 +16,7 @@ import torch
 from ...optim import FusedAdamW
 from ..layers.conv_next import ConvNeXt
 from ..layers.res_net import ResNet
+from ..segmentation.unet import UNet
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .losses import VICRegLoss
 
@@ -103,7 +104,12 @@ class _TwoViewSSL:
         for k in _SSL_HYPERPARAMETERS:   # plain attributes: set before Module.__init__, as the
             object.__setattr__(self, k, hp[k])   # reference does
         if hp["channels_to_batch"] is True:
-            kwargs["backbone_args"]["in_channels"] = 1
+            if self._has_heads:
+                kwargs["backbone_args"]["in_channels"] = 1
+            else:
+                kwargs["in_channels"] = 1
+        if not self._has_heads:
+            kwargs["encoder_only"] = True     # the U-Net encoder alone: forward(x) -> bottleneck
         super().__init__(*args, **kwargs)
         self.optimizer_eps = hp["optimizer_eps"]
         self.ema = hp["ema"]
@@ -118,12 +124,18 @@ class _TwoViewSSL:
         self.save_hyperparameters()
         self.setup_metrics()
 
-    def forward_ema_stop_grad(self, x, ret):
+    _has_heads = True   # forward(x, ret=...) selects representation / projection / prediction
+
+    def _view(self, x, ret):
+        return self.forward(x, ret=ret) if self._has_heads else self.forward(x)
+
+    def forward_ema_stop_grad(self, x, ret=None):
         op = self.ema.shadow.forward if self.ema is not None else self.forward
+        args = (x, ret) if self._has_heads else (x,)
         if self.stop_gradient is True:
             with torch.no_grad():
-                return op(x, ret)
-        return op(x, ret)
+                return op(*args)
+        return op(*args)
 
     def _heads_for_method(self, batch):
         """(head of view 1, head of view 2, extra loss arguments), pl.py:457-470."""
@@ -140,14 +152,14 @@ class _TwoViewSSL:
         if self.channels_to_batch is True:
             x1 = x1.reshape(-1, 1, *x1.shape[2:])
             x2 = x2.reshape(-1, 1, *x2.shape[2:])
-        y1 = self.forward(x1, ret=ret_1)
+        y1 = self._view(x1, ret_1)
         y2 = self.forward_ema_stop_grad(x2, ret=ret_2)
         losses = self.calculate_loss(y1, y2, *other_args)
         self.update_metrics(y1, y2, metrics)
         symmetric_already = self.ssl_method in ("vicreg", "vicregl", "simclr")
         if not symmetric_already:   # SimSiam / BYOL: add the loss with the two views swapped
             y1_ = self.forward_ema_stop_grad(x1, ret=ret_1)
-            y2_ = self.forward(x2, ret=ret_2)
+            y2_ = self._view(x2, ret_2)
             losses = losses + self.calculate_loss(y2_, y1_, *other_args)
             self.update_metrics(y2_, y1_, metrics)
         if self.ema is not None and train is True:
@@ -191,6 +203,27 @@ class SelfSLConvNeXtPL(_TwoViewSSL, ConvNeXt, SelfSLBasePL):
 class SelfSLResNetPL(_TwoViewSSL, ResNet, SelfSLBasePL):
     """ResNet backbone (pl.py:312-535): what ``get_ssl_network`` builds for simclr / byol /
     vicreg / vicregl, transferable to a U-Net encoder (utils/handoff.py)."""
+
+    def __init__(self, aug_image_key_1: str = "aug_image_1", aug_image_key_2: str = "aug_image_2",
+                 box_key_1: str = "box_1", box_key_2: str = "box_2", learning_rate: float = 0.001,
+                 batch_size: int = 4, weight_decay: float = 0.005,
+                 training_dataloader_call: Callable = None, n_epochs: int = 1000,
+                 n_steps: int = None, warmup_steps: int = 0, start_decay: int = None,
+                 ema: torch.nn.Module = None, ssl_method: str = "simclr",
+                 temperature: float = 1.0, vic_reg_loss_params: dict = {},
+                 stop_gradient: bool = True, channels_to_batch: bool = False,
+                 optimizer_eps: float = OPTIMIZER_EPS_DEFAULT, *args, **kwargs):
+        hp = {k: v for k, v in locals().items() if k not in ("self", "args", "kwargs", "__class__")}
+        self._init_two_view(hp, args, kwargs)
+
+
+class SelfSLUNetPL(_TwoViewSSL, UNet, SelfSLBasePL):
+    """U-Net encoder as the self-supervised backbone (pl.py:538-756): ``UNet(encoder_only=True)``
+    returns the bottleneck feature map, the VICReg loss takes its spatial means
+    (``VICRegLoss.flatten_if_necessary``); the trained encoder transfers to a segmentation U-Net
+    by ``state_dict`` (same ``encoding_operations.*`` keys)."""
+
+    _has_heads = False
 
     def __init__(self, aug_image_key_1: str = "aug_image_1", aug_image_key_2: str = "aug_image_2",
                  box_key_1: str = "box_1", box_key_2: str = "box_2", learning_rate: float = 0.001,

@@ -11,7 +11,7 @@ import torch
 
 from ..modules.segmentation.pl import (BrUNetPL, SWINUNetPL, UNETRPL, UNetPL,
                                        UNetPlusPlusPL)
-from ..modules.self_supervised.pl import SelfSLConvNeXtPL, SelfSLResNetPL
+from ..modules.self_supervised.pl import SelfSLConvNeXtPL, SelfSLResNetPL, SelfSLUNetPL
 
 OPTIMIZER_EPS_DEFAULT = 1e-8
 ALLOWED_NET_TYPES = {
@@ -132,8 +132,7 @@ def get_ssl_network(train_loader_call: Callable, max_epochs: int, max_steps_opti
                    "stop_gradient": stop_gradient, "temperature": 0.1,
                    "optimizer_eps": optimizer_eps}
     if net_type == "unet_encoder":
-        raise NotImplementedError("SelfSLUNetPL (self_supervised/pl.py:538-756) is not part of "
-                                  "the HIP path yet")
+        return SelfSLUNetPL(**boilerplate, **network_config)
     if net_type == "convnext":
         network_config["backbone_args"] = {k: v for k, v in network_config["backbone_args"].items()
                                            if k != "res_type"}

@@ -143,12 +143,27 @@ UNETR_CASES = {
 }
 
 
+UNETR_CASES["unetr2d_small"] = (
+    # 2-D UNETR (unetr.py:104 of the HIP mirror raised for this before round 2)
+    dict(image_size=[32, 48], patch_size=[8, 8], number_of_blocks=4, return_at=[1, 2],
+         embedding_size=64, attention_dim=64, hidden_dim=64, n_heads=4, mlp_structure=[128],
+         spatial_dimensions=2, link_type="identity", upscale_type="transpose",
+         norm_type="instance", padding=1, dropout_param=0.0, activation_fn="swish", in_channels=2,
+         n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3]), (2, 2, 32, 48), "uniform")
+
+
 UNETPP_CASES = {
     "unetpp3d_small": (dict(spatial_dimensions=3, conv_type="regular", upscale_type="transpose",
                             norm_type="instance", padding=1, dropout_param=0.0,
                             activation_fn="swish", in_channels=2, n_classes=2,
                             depth=[8, 8, 16, 32], kernel_sizes=[3] * 4, strides=[2] * 4,
                             _cls="unetpp"), (1, 2, 16, 16, 16), "uniform"),
+    # 2-D U-Net++ (DenseBlock 2-D, standard_blocks.py:284-376)
+    "unetpp2d_small": (dict(spatial_dimensions=2, conv_type="regular", upscale_type="transpose",
+                            norm_type="instance", padding=1, dropout_param=0.0,
+                            activation_fn="swish", in_channels=1, n_classes=2,
+                            depth=[8, 8, 16], kernel_sizes=[3] * 3, strides=[2] * 3,
+                            _cls="unetpp"), (2, 1, 24, 40), "uniform"),
 }
 
 
@@ -617,6 +632,10 @@ def gen_losses():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         gen_losses()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "twod":
+        gen_unet("unetr2d_small", *UNETR_CASES["unetr2d_small"])
+        gen_unet("unetpp2d_small", *UNETPP_CASES["unetpp2d_small"])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         gen_surface()

@@ -32,11 +32,22 @@ UNETR_CASES = {
                           n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3]),
 }
 
+UNETR_CASES["unetr2d_small"] = dict(
+    image_size=[32, 48], patch_size=[8, 8], number_of_blocks=4, return_at=[1, 2],
+    embedding_size=64, attention_dim=64, hidden_dim=64, n_heads=4, mlp_structure=[128],
+    spatial_dimensions=2, link_type="identity", upscale_type="transpose", norm_type="instance",
+    padding=1, dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+    depth=[8, 16, 32], kernel_sizes=[3, 3, 3])
+
 UNETPP_CASES = {
     "unetpp3d_small": dict(spatial_dimensions=3, conv_type="regular", upscale_type="transpose",
                            norm_type="instance", padding=1, dropout_param=0.0,
                            activation_fn="swish", in_channels=2, n_classes=2,
                            depth=[8, 8, 16, 32], kernel_sizes=[3] * 4, strides=[2] * 4),
+    "unetpp2d_small": dict(spatial_dimensions=2, conv_type="regular", upscale_type="transpose",
+                           norm_type="instance", padding=1, dropout_param=0.0,
+                           activation_fn="swish", in_channels=1, n_classes=2, depth=[8, 8, 16],
+                           kernel_sizes=[3] * 3, strides=[2] * 3),
 }
 
 

@@ -183,15 +183,19 @@ def test_mhsa_and_transformer_block_match_reference(cuda):
     np.testing.assert_allclose(y.cpu().numpy(), g["tb_y"], rtol=1e-4, atol=1e-5)
 
 
-def _build_unetr(device):
-    kw = dict(UNETR_CASES["unetr3d_small"])
+UNETR_NAMES = ["unetr3d_small", "unetr2d_small"]
+
+
+def _build_unetr(device, name="unetr3d_small"):
+    kw = dict(UNETR_CASES[name])
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
     return _load(UNETR(**kw)).to(device)
 
 
-def test_unetr_logits_within_1e4_of_reference(cuda):
-    g = np.load(os.path.join(GOLD, "unetr3d_small.npz"))
-    net = _build_unetr(cuda).eval()
+@pytest.mark.parametrize("name", UNETR_NAMES)
+def test_unetr_logits_within_1e4_of_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = _build_unetr(cuda, name).eval()
     with torch.no_grad():
         logits, _ = net(torch.from_numpy(g["x"]).to(cuda), return_logits=True)
     ref = g["logits"]
@@ -199,9 +203,10 @@ def test_unetr_logits_within_1e4_of_reference(cuda):
     assert rel < 1e-4, rel
 
 
-def test_unetr_parameter_gradients_match_reference(cuda):
-    g = np.load(os.path.join(GOLD, "unetr3d_small.npz"))
-    net = _build_unetr(cuda).eval()
+@pytest.mark.parametrize("name", UNETR_NAMES)
+def test_unetr_parameter_gradients_match_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = _build_unetr(cuda, name).eval()
     prob, _ = net(torch.from_numpy(g["x"]).to(cuda))
     loss = compound_loss(prob, torch.from_numpy(g["y"]).to(cuda))
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)

@@ -15,8 +15,11 @@ from oracle.weights import tensor_for
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def build():
-    kw = dict(UNETPP_CASES["unetpp3d_small"])
+NAMES = ["unetpp3d_small", "unetpp2d_small"]
+
+
+def build(name="unetpp3d_small"):
+    kw = dict(UNETPP_CASES[name])
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
     net = UNetPlusPlus(**kw)
     net.load_state_dict({k: torch.from_numpy(tensor_for(k, v.shape))
@@ -24,9 +27,10 @@ def build():
     return net
 
 
-def test_unetpp_state_dict_keys_and_shapes_equal_reference():
-    g = np.load(os.path.join(GOLD, "unetpp3d_small.npz"))
-    sd = build().state_dict()
+@pytest.mark.parametrize("name", NAMES)
+def test_unetpp_state_dict_keys_and_shapes_equal_reference(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = build(name).state_dict()
     assert list(sd.keys()) == [str(k) for k in g["param_keys"]]
     shapes = {str(k): tuple(int(i) for i in str(s).split(",")) for k, s in
               zip(g["param_keys"], g["param_shapes"])}
@@ -35,16 +39,17 @@ def test_unetpp_state_dict_keys_and_shapes_equal_reference():
 
 
 @pytest.mark.gpu
-def test_unetpp_logits_aux_and_grads_match_reference(cuda):
-    g = np.load(os.path.join(GOLD, "unetpp3d_small.npz"))
-    net = build().to(cuda).eval()
+@pytest.mark.parametrize("name", NAMES)
+def test_unetpp_logits_aux_and_grads_match_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(name).to(cuda).eval()
     x = torch.from_numpy(g["x"]).to(cuda)
     with torch.no_grad():
         logits = net(x, return_logits=True)[0]
     ref = g["logits"]
     assert np.abs(logits.cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
     prob, bn, aux = net(x)
-    assert bn is None and len(aux) == 2
+    assert bn is None and len(aux) == len(UNETPP_CASES[name]["depth"]) - 2
     for i, a in enumerate(aux):
         np.testing.assert_allclose(a.detach().cpu().numpy(), g[f"aux{i}"], rtol=1e-4, atol=1e-5)
     loss = compound_loss(prob, torch.from_numpy(g["y"]).to(cuda))

@@ -18,9 +18,13 @@ def build(kw):
     return UNETR(**kw)
 
 
-def test_unetr_state_dict_keys_and_shapes_equal_reference():
-    g = np.load(os.path.join(GOLD, "unetr3d_small.npz"))
-    net = build(UNETR_CASES["unetr3d_small"])
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["unetr3d_small", "unetr2d_small"])
+def test_unetr_state_dict_keys_and_shapes_equal_reference(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(UNETR_CASES[name])
     sd = net.state_dict()
     assert list(sd.keys()) == [str(k) for k in g["param_keys"]]
     shapes = {str(k): tuple(int(i) for i in str(s).split(",")) for k, s in
