@@ -416,8 +416,13 @@ def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=No
                     rm.mul_(1 - mom).add_(mean, alpha=mom)
                     rv.mul_(1 - mom).add_(var, alpha=mom)
         else:
-            mean = running[0]
-            rstd = torch.rsqrt(running[1] + eps)
+            # running statistics are constants, not functions of x: fold them into the affine
+            # pair (y = x * (rstd gamma) + (beta - mean rstd gamma)) so that the backward is the
+            # plain elementwise one; [C]-sized parameter algebra, autograd carries dgamma / dbeta
+            rstd_c = torch.rsqrt(running[1] + eps)
+            gamma = rstd_c if gamma is None else rstd_c * gamma
+            shift = -running[0] * gamma
+            beta = shift if beta is None else beta + shift
     elif norm != "none":
         raise NotImplementedError(f"norm {norm!r} has no HIP kernel yet")
     p = float(drop_p) if training else 0.0

@@ -100,9 +100,6 @@ class UNETR(UNet, torch.nn.Module):
         self.in_channels_rec = int(np.prod([self.scale ** self.spatial_dimensions,
                                             self.in_channels]))
         self.assertions()
-        if self.feature_conditioning:
-            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
-
         self.get_norm_op()
         self.get_drop_op()
         self.get_conv_op()
@@ -185,8 +182,8 @@ class UNETR(UNet, torch.nn.Module):
                 return_bottleneck=False, return_logits=False):
         if not X.is_cuda:
             raise AdellHipError("adell_mri_amd.UNETR runs on MI355X only (no CPU fallback)")
-        if X_feature_conditioning is not None:
-            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
+        if X_feature_conditioning is not None:   # tiny [B, F] tensor: normalise the features
+            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
         if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
             X_skip_layer = X_skip_layer.unsqueeze(1)
 
@@ -213,6 +210,9 @@ class UNETR(UNet, torch.nn.Module):
                 xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
                 link_in = HF.cat_channels([link_in, xfl])
             encoded = self.link_ops[i](link_in)
+            if X_feature_conditioning is not None:   # channel gates on the skip tensor
+                gates = self.feature_conditioning_ops[i](X_feature_conditioning)
+                encoded = HF.scale_per_item_channel(encoded, gates)
             curr = self.upscale_ops[i](curr)
             curr = op(curr, X_cat=encoded)
             deep_outputs.append(curr)
@@ -311,8 +311,6 @@ class SWINUNet(UNet, torch.nn.Module):
         self.number_of_blocks = len(self.depth)
         if self.spatial_dimensions != 3:
             raise NotImplementedError("HIP SWINUNet is 3-D (the BASELINE configuration)")
-        if self.feature_conditioning:
-            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
         self.arg_compliance()
         self.get_norm_op()
         self.get_drop_op()
@@ -407,7 +405,7 @@ class SWINUNet(UNet, torch.nn.Module):
         if not X.is_cuda:
             raise AdellHipError("adell_mri_amd.SWINUNet runs on MI355X only (no CPU fallback)")
         if X_feature_conditioning is not None:
-            raise NotImplementedError("feature conditioning is outside the HIP path built so far")
+            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
         if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
             X_skip_layer = X_skip_layer.unsqueeze(1)
 
@@ -432,6 +430,9 @@ class SWINUNet(UNet, torch.nn.Module):
                 xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
                 link_in = HF.cat_channels([link_in, xfl])
             encoded = self.link_ops[i](link_in)
+            if X_feature_conditioning is not None:   # channel gates on the skip tensor
+                gates = self.feature_conditioning_ops[i](X_feature_conditioning)
+                encoded = HF.scale_per_item_channel(encoded, gates)
             curr = self.upscale_ops[i](curr)
             curr = op(curr, X_cat=encoded)
             deep_outputs.append(curr)

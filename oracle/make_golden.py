@@ -143,6 +143,16 @@ UNETR_CASES = {
 }
 
 
+UNETR_CASES["unetr3d_feature_cond"] = (
+    # tabular feature gates on the UNETR skip tensors (unetr.py:217-218, 356-358, 399-405);
+    # eval(): the MLP blocks of the ViT carry the default dropout of get_adn_fn (0.1), whose
+    # random stream cannot be reproduced, so the BatchNorm1d gates use their running statistics
+    dict(image_size=[16, 16, 16], patch_size=[4, 4, 4], number_of_blocks=2, return_at=[1],
+         embedding_size=32, attention_dim=32, hidden_dim=32, n_heads=2, mlp_structure=[64],
+         spatial_dimensions=3, link_type="identity", upscale_type="transpose",
+         norm_type="instance", padding=1, dropout_param=0.0, activation_fn="swish", in_channels=1,
+         n_classes=2, depth=[8, 16], kernel_sizes=[3, 3], feature_conditioning=5),
+    (4, 1, 16, 16, 16), "uniform")
 UNETR_CASES["unetr2d_small"] = (
     # 2-D UNETR (unetr.py:104 of the HIP mirror raised for this before round 2)
     dict(image_size=[32, 48], patch_size=[8, 8], number_of_blocks=4, return_at=[1, 2],
@@ -632,6 +642,9 @@ def gen_losses():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         gen_losses()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "unetr_fc":
+        gen_unet("unetr3d_feature_cond", *UNETR_CASES["unetr3d_feature_cond"])
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "twod":
         gen_unet("unetr2d_small", *UNETR_CASES["unetr2d_small"])

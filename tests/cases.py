@@ -32,6 +32,12 @@ UNETR_CASES = {
                           n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3]),
 }
 
+UNETR_CASES["unetr3d_feature_cond"] = dict(
+    image_size=[16, 16, 16], patch_size=[4, 4, 4], number_of_blocks=2, return_at=[1],
+    embedding_size=32, attention_dim=32, hidden_dim=32, n_heads=2, mlp_structure=[64],
+    spatial_dimensions=3, link_type="identity", upscale_type="transpose", norm_type="instance",
+    padding=1, dropout_param=0.0, activation_fn="swish", in_channels=1, n_classes=2,
+    depth=[8, 16], kernel_sizes=[3, 3], feature_conditioning=5)
 UNETR_CASES["unetr2d_small"] = dict(
     image_size=[32, 48], patch_size=[8, 8], number_of_blocks=4, return_at=[1, 2],
     embedding_size=64, attention_dim=64, hidden_dim=64, n_heads=4, mlp_structure=[128],

@@ -138,3 +138,33 @@ def test_aligned_linear_resize_matches_torch(cuda, shape, size):
     got = HF.resize_linear_aligned(x.to(cuda), size).cpu()
     assert tuple(got.shape) == tuple(want.shape)
     assert float((got - want).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_feature_conditioned_unetr_matches_reference(cuda):
+    """Tabular feature gates on the UNETR skip tensors (unetr.py:217-218, 356-358, 399-405)
+    against the fixture unetr3d_feature_cond made from the real reference."""
+    from adell_mri_amd.modules.segmentation.unetr import UNETR
+    from cases import UNETR_CASES
+
+    g = np.load(os.path.join(GOLD, "unetr3d_feature_cond.npz"))
+    kw = dict(UNETR_CASES["unetr3d_feature_cond"])
+    kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+    net = UNETR(**kw)
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    net = net.to(cuda).eval()       # the gates' BatchNorm1d layers on their running statistics
+    x, y = torch.from_numpy(g["x"]).to(cuda), torch.from_numpy(g["y"]).to(cuda)
+    fc = torch.from_numpy(g["x_fc"]).to(cuda)
+    logits, _ = net(x, X_feature_conditioning=fc, return_logits=True)
+    ref = g["logits"]
+    assert np.abs(logits.detach().cpu().numpy() - ref).max() / np.abs(ref).max() < 1e-4
+    prob, _ = net(x, X_feature_conditioning=fc)
+    loss = compound_loss(prob, y)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    for k, p in net.named_parameters():
+        if not p.requires_grad or ("grad:" + k) not in g.files:
+            continue
+        assert p.grad is not None, k
+        assert grad_rel_err(g, k, p.grad.cpu().numpy()) < 3e-3, k
