@@ -246,6 +246,28 @@ __device__ __forceinline__ bool adell_att_keep(const AttArgs& a, int bh, int qro
   return (float)(rr[e & 3] >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
 }
 
+// The same decisions for the four consecutive keys kcol0 .. kcol0 + 3 of one query: element
+// indices e0 .. e0 + 3 fall into at most two Philox blocks (one when e0 is a multiple of 4).
+__device__ __forceinline__ void adell_att_keep4(const AttArgs& a, int bh, int qrow, int kcol0,
+                                                bool keep[4]) {
+  keep[0] = keep[1] = keep[2] = keep[3] = true;
+  if (a.drop_p <= 0.f) return;
+  const uint64_t e0 = ((uint64_t)bh * a.T + qrow) * a.T + kcol0;
+  const uint64_t b0 = e0 >> 2, b1 = (e0 + 3) >> 2;
+  const uint4 r0 = adell_philox4((uint32_t)b0, (uint32_t)(b0 >> 32), a.rng_offset, 2u, a.seed_lo,
+                                 a.seed_hi);
+  uint4 r1 = r0;
+  if (b1 != b0)
+    r1 = adell_philox4((uint32_t)b1, (uint32_t)(b1 >> 32), a.rng_offset, 2u, a.seed_lo, a.seed_hi);
+  const uint32_t w0[4] = {r0.x, r0.y, r0.z, r0.w}, w1[4] = {r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t e = e0 + j;
+    const uint32_t w = (e >> 2) == b0 ? w0[e & 3] : w1[e & 3];
+    keep[j] = (float)(w >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
+  }
+}
+
 __global__ __launch_bounds__(256) void adell_attention_fwd_kernel(AttArgs a) {
   extern __shared__ float sh[];
   const int AP = a.A + 1, DP = a.Dv;  // K rows padded against bank conflicts
@@ -543,6 +565,463 @@ __global__ __launch_bounds__(256) void adell_attention_bwd_kv_kernel(AttArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA attention (head dims that are multiples of 32, up to 128): QK^T and PV -- and in the
+// backward dO V^T, dS K, dS^T Q, P^T dO -- on v_mfma_f32_32x32x2_f32, i.e. exact fp32 FMA chains
+// (the reference op is F.scaled_dot_product_attention on fp32 tensors, linear_blocks.py:358-417).
+// One wave per 32-row tile, one tile per block: 7 x BH blocks at the 216 tokens of config 3.
+//
+// The score tile is always computed with the SUMMATION index of the product that follows in its
+// accumulator ROWS (registers): a 32x32 accumulator holds column (lane & 31) and rows
+// am_row(r, lane >> 5) in its 16 registers, and the A operand of the 32x32x2 MFMA wants
+// A[i = lane & 31][k = lane >> 5] -- so register r of the tile IS the A operand of k-step r of the
+// next product (k = rows am_row(r, 0), am_row(r, 1)), with no lane movement and no LDS trip:
+//   forward / dQ kernel:  S^T = K Q^T (rows = keys, column = query)  ->  O = P V,  dQ = dS K
+//   dK/dV kernel:         S   = Q K^T (rows = queries, column = key) ->  dV = P^T dO, dK = dS^T Q
+// Softmax statistics are per column (= per lane) in the first form: a max / sum over the 16
+// registers plus one exchange between the two lane halves; the forward makes two passes over the
+// keys (statistics, then normalised probabilities), so the output tile is never rescaled.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int am_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// rows [r0, r0 + NR) x C columns of a [T][C] matrix -> LDS rows of C + 1 floats, rows >= T zero,
+// by the 256 threads of the block. All 16-byte loads are issued before the first LDS store, from
+// clamped row indices (a select on the loaded value, not a branch around the load: hipcc would
+// otherwise wait for every load in turn -- dependent L2 round trips).
+template <int C>
+__device__ __forceinline__ void am_stage32(float* dst, const float* src, int r0, int T, int tid) {
+  constexpr int N4 = 32 * C / 4 / 256;   // float4 per thread for a 32-row tile
+  float4 v[N4];
+#pragma unroll
+  for (int u = 0; u < N4; ++u) {
+    const int i = tid + 256 * u, r = i / (C / 4), c4 = i - r * (C / 4);
+    const int row = r0 + r < T ? r0 + r : T - 1;
+    v[u] = *reinterpret_cast<const float4*>(src + (size_t)row * C + 4 * c4);
+  }
+#pragma unroll
+  for (int u = 0; u < N4; ++u) {
+    const int i = tid + 256 * u, r = i / (C / 4), c4 = i - r * (C / 4);
+    const bool ok = r0 + r < T;
+    float* d = dst + r * (C + 1) + 4 * c4;
+    d[0] = ok ? v[u].x : 0.f;
+    d[1] = ok ? v[u].y : 0.f;
+    d[2] = ok ? v[u].z : 0.f;
+    d[3] = ok ? v[u].w : 0.f;
+  }
+}
+// the whole [T][C] matrix, padded to a multiple of 32 rows (resident variants): the loads of
+// four tiles are in flight together
+template <int C>
+__device__ __forceinline__ void am_stage_all(float* dst, const float* src, int T, int tid) {
+  constexpr int N4 = 32 * C / 4 / 256, G = 4;
+  const int tiles = (T + 31) / 32;
+  for (int t0 = 0; t0 < tiles; t0 += G) {
+    float4 v[G][N4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int u = 0; u < N4; ++u) {
+        const int i = tid + 256 * u, r = i / (C / 4), c4 = i - r * (C / 4);
+        int row = (t0 + g) * 32 + r;
+        row = row < T ? row : T - 1;
+        v[g][u] = *reinterpret_cast<const float4*>(src + (size_t)row * C + 4 * c4);
+      }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      if (t0 + g < tiles) {
+#pragma unroll
+        for (int u = 0; u < N4; ++u) {
+          const int i = tid + 256 * u, r = i / (C / 4), c4 = i - r * (C / 4);
+          const bool ok = (t0 + g) * 32 + r < T;
+          float* d = dst + (size_t)((t0 + g) * 32 + r) * (C + 1) + 4 * c4;
+          d[0] = ok ? v[g][u].x : 0.f;
+          d[1] = ok ? v[g][u].y : 0.f;
+          d[2] = ok ? v[g][u].z : 0.f;
+          d[3] = ok ? v[g][u].w : 0.f;
+        }
+      }
+  }
+}
+
+// S^T tile: rows = keys k0 + am_row(r, h), column = this lane's query; -inf outside the sequence
+template <int A>
+__device__ __forceinline__ void am_scores_t(const AttArgs& a, const float* sK, const float* qreg,
+                                            const float* biasb, int qrow, bool qok, int k0, int li,
+                                            int h, float* val) {
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+  for (int ss = 0; ss < A / 2; ++ss)
+    s = __builtin_amdgcn_mfma_f32_32x32x2f32(sK[li * (A + 1) + 2 * ss + h], qreg[ss], s, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = k0 + am_row(r, h);
+    float v = -INFINITY;
+    if (qok && key < a.T) {
+      v = s[r] * a.scale;
+      if (biasb) v += biasb[(size_t)qrow * a.T + key];
+    }
+    val[r] = v;
+  }
+}
+
+// Block = 4 waves = 4 query tiles of 32 rows sharing the staged K / V. RES: every K / V row of the
+// sequence is staged ONCE and stays in LDS (config 3: 216 tokens x (64 + 64) floats = 110 KB), no
+// further global loads or barriers in the key loops; otherwise 32-key tiles are streamed.
+template <int AT, int DT, bool RES>
+__global__ __launch_bounds__(256) void adell_attn_mfma_fwd_kernel(AttArgs a) {
+  constexpr int A = AT * 32, Dv = DT * 32;
+  extern __shared__ float sh[];
+  const int Tpad = (a.T + 31) & ~31;
+  float* sK = sh;
+  float* sV = sK + (size_t)(RES ? Tpad : 32) * (A + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + li;
+  const bool qok = qrow < a.T, active = q0 < a.T;   // `active` is wave-uniform
+  const float* qb = a.q + (size_t)bh * a.T * A;
+  const float* kb = a.k + (size_t)bh * a.T * A;
+  const float* vb = a.v + (size_t)bh * a.T * Dv;
+  const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  float qreg[A / 2];
+#pragma unroll
+  for (int ss = 0; ss < A / 2; ++ss) qreg[ss] = qok ? qb[(size_t)qrow * A + 2 * ss + h] : 0.f;
+  if (RES) {
+    am_stage_all<A>(sK, kb, a.T, tid);
+    am_stage_all<Dv>(sV, vb, a.T, tid);
+    __syncthreads();
+  }
+  // pass 1: log-sum-exp of this lane's query
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < a.T; k0 += 32) {
+    if (!RES) {
+      __syncthreads();
+      am_stage32<A>(sK, kb, k0, a.T, tid);
+      __syncthreads();
+    }
+    if (!active) continue;
+    float val[16];
+    am_scores_t<A>(a, sK + (size_t)(RES ? k0 : 0) * (A + 1), qreg, biasb, qrow, qok, k0, li, h, val);
+    float mt = val[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, val[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mnew = fmaxf(m, mt);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ps += (val[r] == -INFINITY) ? 0.f : expf(val[r] - mnew);
+    ps += __shfl_xor(ps, 32, 64);
+    l = l * ((m == -INFINITY) ? 0.f : expf(m - mnew)) + ps;
+    m = mnew;
+  }
+  const float lse = m + logf(l);
+  // pass 2: O = dropout(softmax) V with the normalised probabilities as the MFMA A operand
+  const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  for (int k0 = 0; k0 < a.T; k0 += 32) {
+    if (!RES) {
+      __syncthreads();
+      am_stage32<A>(sK, kb, k0, a.T, tid);
+      am_stage32<Dv>(sV, vb, k0, a.T, tid);
+      __syncthreads();
+    }
+    if (!active) continue;
+    const float* sVt = sV + (size_t)(RES ? k0 : 0) * (Dv + 1);
+    float val[16];
+    am_scores_t<A>(a, sK + (size_t)(RES ? k0 : 0) * (A + 1), qreg, biasb, qrow, qok, k0, li, h, val);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      bool keep[4];   // registers 4 r4 .. 4 r4 + 3 are four consecutive keys
+      adell_att_keep4(a, bh, qrow, k0 + am_row(4 * r4, h), keep);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * r4 + j;
+        const float p = (val[r] == -INFINITY) ? 0.f : expf(val[r] - lse);
+        val[r] = keep[j] ? p * keep_scale : 0.f;
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+            val[r], sVt[am_row(r, h) * (Dv + 1) + dt * 32 + li], o[dt], 0, 0, 0);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = q0 + am_row(r, h);
+      if (row < a.T) a.out[((size_t)bh * a.T + row) * Dv + dt * 32 + li] = o[dt][r];
+    }
+  if (h == 0 && qok) a.lse_out[(size_t)bh * a.T + qrow] = lse;
+}
+
+// dQ = scale * dS K with dS^T tiles (rows = keys, column = this lane's query)
+template <int AT, int DT, bool RES>
+__global__ __launch_bounds__(256) void adell_attn_mfma_bwd_q_kernel(AttArgs a) {
+  constexpr int A = AT * 32, Dv = DT * 32;
+  extern __shared__ float sh[];
+  const int Tpad = (a.T + 31) & ~31;
+  float* sK = sh;
+  float* sV = sK + (size_t)(RES ? Tpad : 32) * (A + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + li;
+  const bool qok = qrow < a.T, active = q0 < a.T;
+  const float* qb = a.q + (size_t)bh * a.T * A;
+  const float* kb = a.k + (size_t)bh * a.T * A;
+  const float* vb = a.v + (size_t)bh * a.T * Dv;
+  const float* ob = a.o + (size_t)bh * a.T * Dv;
+  const float* gb = a.dout + (size_t)bh * a.T * Dv;
+  const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  float qreg[A / 2], doreg[Dv / 2];
+  float D = 0.f;
+#pragma unroll
+  for (int ss = 0; ss < A / 2; ++ss) qreg[ss] = qok ? qb[(size_t)qrow * A + 2 * ss + h] : 0.f;
+#pragma unroll
+  for (int ss = 0; ss < Dv / 2; ++ss) {
+    doreg[ss] = qok ? gb[(size_t)qrow * Dv + 2 * ss + h] : 0.f;
+    D += qok ? doreg[ss] * ob[(size_t)qrow * Dv + 2 * ss + h] : 0.f;
+  }
+  D += __shfl_xor(D, 32, 64);
+  const float lse = qok ? a.lse[(size_t)bh * a.T + qrow] : 0.f;
+  const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  f32x16 dq[AT];
+#pragma unroll
+  for (int at = 0; at < AT; ++at)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[at][r] = 0.f;
+  if (RES) {
+    am_stage_all<A>(sK, kb, a.T, tid);
+    am_stage_all<Dv>(sV, vb, a.T, tid);
+    __syncthreads();
+  }
+  for (int k0 = 0; k0 < a.T; k0 += 32) {
+    if (!RES) {
+      __syncthreads();
+      am_stage32<A>(sK, kb, k0, a.T, tid);
+      am_stage32<Dv>(sV, vb, k0, a.T, tid);
+      __syncthreads();
+    }
+    if (!active) continue;
+    const float* sKt = sK + (size_t)(RES ? k0 : 0) * (A + 1);
+    const float* sVt = sV + (size_t)(RES ? k0 : 0) * (Dv + 1);
+    float val[16];
+    am_scores_t<A>(a, sKt, qreg, biasb, qrow, qok, k0, li, h, val);
+    f32x16 dp;   // dP^T = V dO^T: rows = keys, column = query
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+#pragma unroll
+    for (int ss = 0; ss < Dv / 2; ++ss)
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sVt[li * (Dv + 1) + 2 * ss + h], doreg[ss], dp, 0, 0, 0);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      bool keep[4];
+      adell_att_keep4(a, bh, qrow, k0 + am_row(4 * r4, h), keep);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * r4 + j;
+        const float p = (val[r] == -INFINITY) ? 0.f : expf(val[r] - lse);
+        const float g = keep[j] ? dp[r] * keep_scale : 0.f;
+        val[r] = p * (g - D);   // dS
+      }
+    }
+#pragma unroll
+    for (int at = 0; at < AT; ++at)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dq[at] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+            val[r], sKt[am_row(r, h) * (A + 1) + at * 32 + li], dq[at], 0, 0, 0);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int at = 0; at < AT; ++at)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = q0 + am_row(r, h);
+      if (row < a.T) a.dq[((size_t)bh * a.T + row) * A + at * 32 + li] = dq[at][r] * a.scale;
+    }
+}
+
+// dV = P_drop^T dO, dK = scale * dS^T Q with S tiles (rows = queries, column = this lane's key);
+// block = 4 key tiles sharing the staged Q / dO (+ D = rowsum(dO * O) and lse per query)
+template <int AT, int DT, bool RES>
+__global__ __launch_bounds__(256) void adell_attn_mfma_bwd_kv_kernel(AttArgs a) {
+  constexpr int A = AT * 32, Dv = DT * 32;
+  extern __shared__ float sh[];
+  const int Tpad = (a.T + 31) & ~31;
+  const int rows = RES ? Tpad : 32;
+  float* sQ = sh;
+  float* sG = sQ + (size_t)rows * (A + 1);     // dO
+  float* sD = sG + (size_t)rows * (Dv + 1);
+  float* sL = sD + rows;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.y, k0 = (blockIdx.x * 4 + wave) * 32, krow = k0 + li;
+  const bool kok = krow < a.T, active = k0 < a.T;
+  const float* qb = a.q + (size_t)bh * a.T * A;
+  const float* kb = a.k + (size_t)bh * a.T * A;
+  const float* vb = a.v + (size_t)bh * a.T * Dv;
+  const float* ob = a.o + (size_t)bh * a.T * Dv;
+  const float* gb = a.dout + (size_t)bh * a.T * Dv;
+  const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
+  float kreg[A / 2], vreg[Dv / 2];
+#pragma unroll
+  for (int ss = 0; ss < A / 2; ++ss) kreg[ss] = kok ? kb[(size_t)krow * A + 2 * ss + h] : 0.f;
+#pragma unroll
+  for (int ss = 0; ss < Dv / 2; ++ss) vreg[ss] = kok ? vb[(size_t)krow * Dv + 2 * ss + h] : 0.f;
+  const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
+  f32x16 dv[DT], dk[AT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dv[t][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < AT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[t][r] = 0.f;
+  // D[q] = sum_dv dO[q][dv] O[q][dv] and lse[q] of queries [r0, r0 + n): 8 threads per query
+  auto stage_stats = [&](int r0, int n, float* dD, float* dL) {
+    for (int qi = tid >> 3; qi < n; qi += 32) {
+      const int qr = r0 + qi;
+      float d = 0.f;
+      if (qr < a.T)
+        for (int c = (tid & 7) * 4; c < Dv; c += 32) {
+          const float4 g4 = *reinterpret_cast<const float4*>(gb + (size_t)qr * Dv + c);
+          const float4 o4 = *reinterpret_cast<const float4*>(ob + (size_t)qr * Dv + c);
+          d += g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
+        }
+      d += __shfl_xor(d, 1, 64);
+      d += __shfl_xor(d, 2, 64);
+      d += __shfl_xor(d, 4, 64);
+      if ((tid & 7) == 0) {
+        dD[qi] = d;
+        dL[qi] = qr < a.T ? a.lse[(size_t)bh * a.T + qr] : 0.f;
+      }
+    }
+  };
+  if (RES) {
+    am_stage_all<A>(sQ, qb, a.T, tid);
+    am_stage_all<Dv>(sG, gb, a.T, tid);
+    stage_stats(0, Tpad, sD, sL);
+    __syncthreads();
+  }
+  for (int q0 = 0; q0 < a.T; q0 += 32) {
+    if (!RES) {
+      __syncthreads();
+      am_stage32<A>(sQ, qb, q0, a.T, tid);
+      am_stage32<Dv>(sG, gb, q0, a.T, tid);
+      stage_stats(q0, 32, sD, sL);
+      __syncthreads();
+    }
+    if (!active) continue;
+    const int base = RES ? q0 : 0;
+    const float* sQt = sQ + (size_t)base * (A + 1);
+    const float* sGt = sG + (size_t)base * (Dv + 1);
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int ss = 0; ss < A / 2; ++ss)
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(sQt[li * (A + 1) + 2 * ss + h], kreg[ss], s, 0, 0, 0);
+#pragma unroll
+    for (int ss = 0; ss < Dv / 2; ++ss)
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(sGt[li * (Dv + 1) + 2 * ss + h], vreg[ss], dp, 0, 0, 0);
+    float pd[16], ds[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = am_row(r, h), qr = q0 + row;
+      float p = 0.f;
+      if (kok && qr < a.T) {
+        float v = s[r] * a.scale;
+        if (biasb) v += biasb[(size_t)qr * a.T + krow];
+        p = expf(v - sL[base + row]);
+      }
+      const bool keep = adell_att_keep(a, bh, qr, krow);
+      pd[r] = keep ? p * keep_scale : 0.f;
+      ds[r] = p * ((keep ? dp[r] * keep_scale : 0.f) - sD[base + row]);
+    }
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dv[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+            pd[r], sGt[am_row(r, h) * (Dv + 1) + t * 32 + li], dv[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < AT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dk[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+            ds[r], sQt[am_row(r, h) * (A + 1) + t * 32 + li], dk[t], 0, 0, 0);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = k0 + am_row(r, h);
+      if (row < a.T) a.dv[((size_t)bh * a.T + row) * Dv + t * 32 + li] = dv[t][r];
+    }
+#pragma unroll
+  for (int t = 0; t < AT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = k0 + am_row(r, h);
+      if (row < a.T) a.dk[((size_t)bh * a.T + row) * A + t * 32 + li] = dk[t][r] * a.scale;
+    }
+}
+
+static bool adell_att_mfma_ok(int T, int A, int Dv) {
+  return T >= 16 && (A == 32 || A == 64 || A == 128) && (Dv == 32 || Dv == 64 || Dv == 128);
+}
+
+// which: 0 forward, 1 backward dQ, 2 backward dK/dV
+template <int AT, int DT, bool RES>
+static int adell_att_mfma_launch3(int which, const AttArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+  const void* fn = which == 0 ? reinterpret_cast<const void*>(adell_attn_mfma_fwd_kernel<AT, DT, RES>)
+                   : which == 1 ? reinterpret_cast<const void*>(adell_attn_mfma_bwd_q_kernel<AT, DT, RES>)
+                                : reinterpret_cast<const void*>(adell_attn_mfma_bwd_kv_kernel<AT, DT, RES>);
+  if (lds > 48 * 1024)
+    ADELL_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (which == 0)
+    hipLaunchKernelGGL((adell_attn_mfma_fwd_kernel<AT, DT, RES>), grid, dim3(256), lds, st, a);
+  else if (which == 1)
+    hipLaunchKernelGGL((adell_attn_mfma_bwd_q_kernel<AT, DT, RES>), grid, dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((adell_attn_mfma_bwd_kv_kernel<AT, DT, RES>), grid, dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+template <int AT, int DT>
+static int adell_att_mfma_launch2(int which, const AttArgs& a, int BH, hipStream_t st) {
+  const dim3 grid((unsigned)adell_cdiv(a.T, 128), (unsigned)BH);
+  const size_t tpad = (size_t)((a.T + 31) & ~31);
+  const size_t per_row = (size_t)(AT * 32 + 1) + (size_t)(DT * 32 + 1) + (which == 2 ? 2 : 0);
+  const size_t res = sizeof(float) * tpad * per_row;
+  if (res <= 150 * 1024)   // the whole sequence stays in LDS
+    return adell_att_mfma_launch3<AT, DT, true>(which, a, grid, res, st);
+  return adell_att_mfma_launch3<AT, DT, false>(which, a, grid, sizeof(float) * 32 * per_row, st);
+}
+template <int AT>
+static int adell_att_mfma_launch1(int which, const AttArgs& a, int BH, hipStream_t st) {
+  switch (a.Dv) {
+    case 32: return adell_att_mfma_launch2<AT, 1>(which, a, BH, st);
+    case 64: return adell_att_mfma_launch2<AT, 2>(which, a, BH, st);
+    default: return adell_att_mfma_launch2<AT, 4>(which, a, BH, st);
+  }
+}
+static int adell_att_mfma_launch(int which, const AttArgs& a, int BH, hipStream_t st) {
+  switch (a.A) {
+    case 32: return adell_att_mfma_launch1<1>(which, a, BH, st);
+    case 64: return adell_att_mfma_launch1<2>(which, a, BH, st);
+    default: return adell_att_mfma_launch1<4>(which, a, BH, st);
+  }
+}
+
 static int adell_att_check(int BH, int T, int A, int Dv, int nbias, const float* bias) {
   ADELL_REQUIRE(BH > 0 && T > 0 && A > 0 && Dv > 0, "attention: bad dims");
   ADELL_REQUIRE(A <= 256 && Dv <= 256, "attention: head dims up to 256 supported");
@@ -574,6 +1053,8 @@ extern "C" int adell_attention_fwd(const float* q, const float* k, const float* 
   ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
   a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   a.rng_offset = rng_offset;
+  if (adell_att_mfma_ok(T, A, Dv) && !g_adell_tune.attn_nomfma)
+    return adell_att_mfma_launch(0, a, BH, (hipStream_t)stream);
   const size_t lds = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * Dv +
                                       (size_t)ATT_ROWS * A + 4 * ATT_TK);
   return adell_att_launch(adell_attention_fwd_kernel, a, BH, lds, (hipStream_t)stream);
@@ -595,6 +1076,11 @@ extern "C" int adell_attention_bwd(const float* q, const float* k, const float* 
   ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
   a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   a.rng_offset = rng_offset;
+  if (adell_att_mfma_ok(T, A, Dv) && !g_adell_tune.attn_nomfma) {
+    rc = adell_att_mfma_launch(1, a, BH, (hipStream_t)stream);
+    if (rc != ADELL_OK) return rc;
+    return adell_att_mfma_launch(2, a, BH, (hipStream_t)stream);
+  }
   const size_t lds_q = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * (Dv + 1) +
                                         (size_t)ATT_ROWS * A + (size_t)ATT_ROWS * Dv + 4 * ATT_TK);
   rc = adell_att_launch(adell_attention_bwd_q_kernel, a, BH, lds_q, (hipStream_t)stream);

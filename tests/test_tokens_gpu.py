@@ -82,7 +82,11 @@ def test_linear_as_conv_fwd_bwd(cuda, rows, cin, cout):
 
 
 @pytest.mark.parametrize("BH,T,A,Dv,use_bias", [(8, 216, 64, 64, False), (6, 24, 8, 12, True),
-                                                 (3, 70, 32, 16, True), (4, 8, 4, 4, False)])
+                                                 (3, 70, 32, 16, True), (4, 8, 4, 4, False),
+                                                 # MFMA path (head dims 32 / 64 / 128), ragged T
+                                                 (3, 70, 32, 32, True), (2, 33, 32, 64, False),
+                                                 (2, 300, 128, 64, True), (1, 96, 64, 128, False),
+                                                 (5, 17, 64, 32, True)])
 def test_attention_fwd_bwd_matches_manual_softmax(cuda, BH, T, A, Dv, use_bias):
     """softmax(QK^T/sqrt(d) + bias)V, the identity the reference's own value test checks
     (testing/test_self_attention.py:121-197), here against torch CPU autograd."""
@@ -106,7 +110,8 @@ def test_attention_fwd_bwd_matches_manual_softmax(cuda, BH, T, A, Dv, use_bias):
     assert _rel(vd.grad.cpu(), v.grad) < 5e-5
 
 
-@pytest.mark.parametrize("BH,T,A,Dv,use_bias", [(8, 216, 64, 64, False), (3, 70, 16, 24, True)])
+@pytest.mark.parametrize("BH,T,A,Dv,use_bias", [(8, 216, 64, 64, False), (3, 70, 16, 24, True),
+                                                 (2, 100, 32, 32, True)])
 def test_attention_dropout_fwd_bwd_matches_masked_softmax(cuda, BH, T, A, Dv, use_bias):
     """dropout_p of the scaled_dot_product_attention call (linear_blocks.py:407-414): V = identity
     exposes the dropped probabilities, i.e. the mask the kernel drew for (seed, offset); the
@@ -217,3 +222,22 @@ def test_unetr_parameter_gradients_match_reference(cuda, name):
             continue
         err = grad_rel_err(g, k, p.grad.cpu().numpy())
         assert err < 2e-3, (k, err)
+
+
+@pytest.mark.parametrize("BH,T,A,Dv", [(4, 216, 64, 64), (2, 77, 32, 128)])
+def test_mfma_attention_equals_vector_alu_attention(cuda, BH, T, A, Dv):
+    """The fp32-MFMA kernels (csrc/tokens.hip, adell_attn_mfma_*) against the vector-ALU kernels
+    they replace for head dims 32 / 64 / 128: same outputs, log-sum-exp and gradients, with
+    attention dropout drawing the same mask."""
+    from adell_mri_amd import _lib, ops
+    g = torch.Generator().manual_seed(BH + T)
+    q, k = (torch.randn(BH, T, A, generator=g).to(cuda) for _ in range(2))
+    v, do = (torch.randn(BH, T, Dv, generator=g).to(cuda) for _ in range(2))
+    scale = 1.0 / A ** 0.5
+    res = {}
+    for name, sw in (("mfma", 0), ("valu", 1)):
+        with _lib.tuning(attn_nomfma=sw):
+            out, lse = ops.attention_fwd(q, k, v, None, scale, 0.1, 99, 3)
+            res[name] = (out, lse, *ops.attention_bwd(q, k, v, None, out, do, lse, scale, 0.1, 99, 3))
+    for a, b in zip(res["mfma"], res["valu"]):
+        assert _rel(a, b) < 2e-5
