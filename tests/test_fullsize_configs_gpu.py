@@ -1,0 +1,126 @@
+"""BASELINE configs 3, 4 and 5 at their FULL sizes (-m gpu): built from the YAMLs in configs/
+through the same factories the entrypoints use, one training step each, with the
+size-independent properties the domain offers -- probabilities in (0, 1), finite loss and
+gradients, every gradient-carrying parameter moved by the optimiser step, eval-mode determinism,
+batch items independent of one another (instance / layer norms only), the parameter counts the
+reference reports for these configurations."""
+import os
+
+import pytest
+import torch
+
+from adell_mri_amd.modules.config_parsing import parse_config_ssl, parse_config_unet
+from adell_mri_amd.trainer import StepRunner
+from adell_mri_amd.utils.network_factories import get_segmentation_network, get_ssl_network
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = os.path.join(ROOT, "configs")
+
+
+def _seg(net_type, yaml_name, keys, size, patch=None):
+    cfg, _ = parse_config_unet(os.path.join(CONFIGS, yaml_name), len(keys), 2)
+    if patch is not None:
+        cfg["patch_size"] = patch
+    torch.manual_seed(0)
+    return get_segmentation_network(
+        net_type, cfg, False, [], [], None, None, None, 100, [None], False, None, None, None,
+        False, 2, keys, random_crop_size=size)
+
+
+def _batch(n, c, size, cuda, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((n, c, *size), generator=g).to(cuda)
+    y = (torch.rand((n, 1, *size), generator=g) > 0.9).float().to(cuda)
+    return {"image": x, "mask": y}
+
+
+def _step_properties(net, batch, expect_params):
+    n_params = sum(p.numel() for p in net.parameters())
+    assert n_params == expect_params, n_params
+    net.eval()
+    with torch.no_grad():
+        p1 = net(batch["image"])[0]
+        p2 = net(batch["image"])[0]
+        one = net(batch["image"][:1])[0]
+    assert torch.equal(p1, p2)                                   # fixed-order reductions
+    assert float(p1.min()) > 0.0 and float(p1.max()) < 1.0       # sigmoid head
+    scale = float(p1.max() - p1.min())
+    assert float((one - p1[:1]).abs().max()) < 1e-5 * max(scale, 1e-3)   # items independent
+    net.train()
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    loss = StepRunner(net).train_step(batch)
+    assert torch.isfinite(loss)
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            assert torch.equal(p.detach(), before[k]), k
+            continue
+        assert torch.isfinite(p.grad).all(), k
+        if float(p.grad.abs().max()) > 0:
+            assert not torch.equal(p.detach(), before[k]), k
+    return float(loss.detach())
+
+
+def test_config3_unetr_full_size(cuda):
+    """unetr.yaml at image 96^3 / patch 16^3 (SURVEY.md 8(d) cfg 3), batch 2. Through the factory
+    the model also carries the never-used feature_conditioning = 0 gate stacks."""
+    net = _seg("unetr", "unetr.yaml", ["image"], [96, 96, 96], patch=[16, 16, 16]).to(cuda)
+    gates = sum(p.numel() for k, p in net.named_parameters() if k.startswith("feature_conditioning_ops"))
+    assert sum(p.numel() for p in net.parameters()) - gates == 36068253
+    loss = _step_properties(net, _batch(2, 1, (96, 96, 96), cuda), 36068253 + gates)
+    assert 0.0 < loss < 5.0
+
+
+def test_config5_swin_unet_full_size(cuda):
+    """unet-swin.yaml at 256 x 256 x 128, 2 channels, batch 1 (cfg 5)."""
+    net = _seg("swin", "unet-swin.yaml", ["image", "image_1"], [256, 256, 128]).to(cuda)
+    gates = sum(p.numel() for k, p in net.named_parameters() if k.startswith("feature_conditioning_ops"))
+    assert sum(p.numel() for p in net.parameters()) - gates == 12626945
+    net.train()
+    batch = _batch(1, 2, (256, 256, 128), cuda)
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    loss = StepRunner(net).train_step(batch)
+    assert torch.isfinite(loss) and 0.0 < float(loss) < 5.0
+    moved = sum(not torch.equal(before[k], p.detach()) for k, p in net.named_parameters()
+                if p.grad is not None)
+    assert moved > 200
+    net.eval()
+    with torch.no_grad():
+        p1 = net(batch["image"])[0]
+    assert p1.shape == (1, 1, 256, 256, 128) and float(p1.min()) > 0.0 and float(p1.max()) < 1.0
+
+
+def test_config4_vicreg_convnext_full_size(cuda):
+    """ssl-3d-convnext.yaml (cfg 4): two views of 16 crops of 64^3, VICReg, AdamW."""
+    _, cfg = parse_config_ssl(os.path.join(CONFIGS, "ssl-3d-convnext.yaml"), 0.0, 1)
+    cfg.pop("batch_size", None)
+    cfg["vic_reg_loss_params"] = {}
+    torch.manual_seed(0)
+    from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
+    cfg["backbone_args"] = {k: v for k, v in cfg["backbone_args"].items() if k != "res_type"}
+    net = SelfSLConvNeXtPL(aug_image_key_1="augmented_image_1", aug_image_key_2="augmented_image_2",
+                           ssl_method="vicreg", stop_gradient=False, n_epochs=100, **cfg).to(cuda)
+    assert sum(p.numel() for p in net.parameters()) == 33862368
+    assert (net.learning_rate, net.weight_decay) == (0.005, 0.001)
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.randn((16, 1, 64, 64, 64), generator=g).to(cuda)
+    x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g).to(cuda)).flip(2)
+    batch = {"augmented_image_1": x1, "augmented_image_2": x2}
+    net.train()
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    loss = StepRunner(net).train_step(batch)
+    assert torch.isfinite(loss)
+    assert len(net.last_losses) == 3 and all(torch.isfinite(t) for t in net.last_losses)
+    moved = sum(not torch.equal(before[k], p.detach()) for k, p in net.named_parameters()
+                if p.grad is not None)
+    assert moved > 0.9 * len(before)
+    # get_ssl_network routes "vicreg" to the ResNet wrapper (network_factories.py:749-796)
+    small = {"backbone_args": dict(spatial_dim=3, in_channels=1, structure=[[8, 8, 3, 1]],
+                                   maxpool_structure=[[2, 2, 2]], res_type="resnet",
+                                   adn_fn=torch.nn.Identity),
+             "projection_head_args": dict(in_channels=8, structure=[16, 8], adn_fn=torch.nn.Identity),
+             "prediction_head_args": dict(in_channels=8, structure=[16, 8], adn_fn=torch.nn.Identity)}
+    r = get_ssl_network(None, 10, 100, 0, "vicreg", None, "resnet", small, False).to(cuda).train()
+    xb = {"aug_image_1": torch.randn(6, 1, 16, 16, 16, device=cuda),
+          "aug_image_2": torch.randn(6, 1, 16, 16, 16, device=cuda)}
+    assert torch.isfinite(StepRunner(r).train_step(xb))
