@@ -103,8 +103,12 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
   const int kX = adell_zr_scale_exp(a.xmax[0]), kY = adell_zr_scale_exp(a.ymax[0]);
   const float sX = __int_as_float((kX + 127) << 23), sY = __int_as_float((kY + 127) << 23);
 
-  // the 32 input channels of this tile live in one source (C0 is a multiple of 32)
+  // Whole tile inside one source (every 32-channel-aligned layer): one wave-uniform base per
+  // plane. Otherwise (channel counts that are multiples of 16 only: a tile that straddles the two
+  // sources of a virtual concat, or the ragged last tile) every thread addresses its own 4-channel
+  // piece -- pieces never straddle a source (C0 % 16 == 0) -- and pieces past Cin are zero.
   const bool first = ci0 < a.C0;
+  const bool uni = first ? (ci0 + 32 <= a.C0) : (ci0 + 32 <= a.Cin);
   const float* xsrc = first ? a.x0 + ci0 : a.x1 + (ci0 - a.C0);
   const unsigned xcs = first ? a.C0 : a.C1;
 
@@ -133,6 +137,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
 
   // staging slots of this thread: 16-byte piece c4 = tid & 7 of rows tid / 8 + 32 u
   const int c4 = tid & 7, row0 = tid >> 3;
+  const int cpiece = ci0 + 4 * c4;                     // first input channel of this piece
+  const bool pvalid = cpiece < a.Cin, pfirst = cpiece < a.C0;
+  const float* xsrc_t = pfirst ? a.x0 + cpiece : a.x1 + (pvalid ? cpiece - a.C0 : 0);
+  const unsigned xcs_t = pfirst ? a.C0 : a.C1;
+  const bool yvalid = co0 + 4 * c4 < a.Cout;
   const bool do_db = a.wsdb != nullptr && cit == 0;
   float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -153,26 +162,38 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
       const int hv = row0 + 32 * u;
       const int hy = hv / ZR_HX, hx = hv - hy * ZR_HX;
       const int ix = ox0 - a.PW + hx, iy = oy0 - a.PH + hy;
-      xok[u] = (hv < ZR_HV) & (ix >= 0) & (ix < a.W) & (iy >= 0) & (iy < a.H);
-      xoff[u] = xok[u] ? ((unsigned)(iy * a.W + ix) * xcs + 4 * c4) * 4u : 0u;
+      xok[u] = (hv < ZR_HV) & (ix >= 0) & (ix < a.W) & (iy >= 0) & (iy < a.H) & (uni | pvalid);
+      xoff[u] = !xok[u] ? 0u
+                : uni   ? ((unsigned)(iy * a.W + ix) * xcs + 4 * c4) * 4u
+                        : ((unsigned)(iy * a.W + ix) * xcs_t) * 4u;
     }
 #pragma unroll
     for (int u = 0; u < ZR_NY; ++u) {
       const int v = row0 + 32 * u;
       const int ox = ox0 + (v & 7), oy = oy0 + (v >> 3);
-      yok[u] = (ox < a.Wo) & (oy < a.Ho);
+      yok[u] = (ox < a.Wo) & (oy < a.Ho) & yvalid;
       yoff[u] = yok[u] ? ((unsigned)(oy * a.Wo + ox) * (unsigned)a.Cout + co0 + 4 * c4) * 4u : 0u;
     }
     float4 xr[ZR_NX], yr[ZR_NY];
     auto fetch_x = [&](int p) {   // input plane p of item nb (zeros outside the tensor)
       const bool pok = p >= 0 && p < a.D;
-      const char* base =
-          adell_zr_uniform(xsrc + ((size_t)(nb * a.D + (pok ? p : 0)) * a.H * a.W) * xcs);
+      const size_t plane = (size_t)(nb * a.D + (pok ? p : 0)) * a.H * a.W;
+      if (uni) {
+        const char* base = adell_zr_uniform(xsrc + plane * xcs);
 #pragma unroll
-      for (int u = 0; u < ZR_NX; ++u) {
-        float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (pok && xok[u]) f = *reinterpret_cast<const float4*>(base + xoff[u]);
-        xr[u] = f;
+        for (int u = 0; u < ZR_NX; ++u) {
+          float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pok && xok[u]) f = *reinterpret_cast<const float4*>(base + xoff[u]);
+          xr[u] = f;
+        }
+      } else {
+        const char* base = reinterpret_cast<const char*>(xsrc_t + plane * xcs_t);
+#pragma unroll
+        for (int u = 0; u < ZR_NX; ++u) {
+          float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (pok && xok[u]) f = *reinterpret_cast<const float4*>(base + xoff[u]);
+          xr[u] = f;
+        }
       }
     };
     auto fetch_y = [&](int z) {
@@ -279,8 +300,10 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
         const float4 u = red[k];
         tsum.x += u.x; tsum.y += u.y; tsum.z += u.z; tsum.w += u.w;
       }
-      float* o = a.wsdb + (size_t)region * a.Cout + co0 + 4 * tid;
-      o[0] = tsum.x; o[1] = tsum.y; o[2] = tsum.z; o[3] = tsum.w;
+      if (co0 + 4 * tid < a.Cout) {
+        float* o = a.wsdb + (size_t)region * a.Cout + co0 + 4 * tid;
+        o[0] = tsum.x; o[1] = tsum.y; o[2] = tsum.z; o[3] = tsum.w;
+      }
     }
   }
   // ---- partial slab (undo the operand scales) --------------------------------
@@ -291,11 +314,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
     const int tap = wave + 4 * q;
     const int cib = ci0 + 4 * lh;
     float* base = a.ws + (((size_t)region * 27 + tap) * a.Cin + cib) * a.Cout + co;
-    if (jok[q]) {
+    if (jok[q] && co < a.Cout) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2);
-        base[(size_t)row * a.Cout] = acc[q][r] * unscale;
+        if (cib + row < a.Cin) base[(size_t)row * a.Cout] = acc[q][r] * unscale;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -306,13 +329,16 @@ struct WgradZrPlan {
   int ntx, nty, nseg, seglen, nci, nco, R;
 };
 
-// 1 when the z-ring kernel serves this problem (3^3 taps, stride 1, whole 32-channel tiles)
+// 1 when the z-ring kernel serves this problem (3^3 taps, stride 1, channel counts in whole 16s)
 extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
                                       int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,
                                       WgradZrPlan* p) {
   const int Cin = C0 + C1;
   if (KD != 3 || KH != 3 || KW != 3 || SD != 1 || SH != 1 || SW != 1) return 0;
-  if (Cin % 32 || Cout % 32 || C0 % 32) return 0;
+  // whole 16-channel pieces: tiles are 32 x 32 channels, a ragged last tile or one that straddles
+  // the two sources of a virtual concat is masked per 4-channel piece (half the MFMA columns idle,
+  // still far ahead of the generic kernel on the 16-channel decoder levels of UNETR)
+  if (Cin % 16 || Cout % 16 || C0 % 16) return 0;
   if (Wo < 8 || Ho < 8 || Do < 4) return 0;   // small planes: the per-plane kernel wastes less
   const size_t cmax = (size_t)(C0 > C1 ? C0 : C1);
   if ((size_t)H * W * cmax >= ((size_t)1 << 30) || (size_t)Ho * Wo * Cout >= ((size_t)1 << 30))
@@ -320,8 +346,8 @@ extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1
   if (g_adell_tune.wgrad_nozring) return 0;
   p->ntx = adell_cdiv(Wo, 8);
   p->nty = adell_cdiv(Ho, 8);
-  p->nci = Cin / 32;
-  p->nco = Cout / 32;
+  p->nci = adell_cdiv(Cin, 32);
+  p->nco = adell_cdiv(Cout, 32);
   const long ncols = (long)N * p->ntx * p->nty;
   const long chan_blocks = (long)p->nci * p->nco;
   long target = 512 / chan_blocks;             // two blocks per CU over all channel tiles

@@ -1,5 +1,6 @@
 """The z-marching backward-weight kernel (conv_wgrad_zring.hip) against the per-plane f16x3 kernel
 and the fp32-MFMA kernel: ragged planes, batch > 1, virtual concat, padding 0 and 1."""
+import ctypes
 import os
 
 import pytest
@@ -19,7 +20,17 @@ def _rel(a, b):
                                                     (1, 32, 32, 32, (9, 17, 33), 1),
                                                     (1, 64, 0, 64, (24, 16, 16), 1),
                                                     (1, 32, 0, 32, (14, 18, 22), 0),
-                                                    (1, 32, 0, 32, (64, 64, 64), 1)])
+                                                    (1, 32, 0, 32, (64, 64, 64), 1),
+                                                    # channel counts in whole 16s: ragged last
+                                                    # tile, tile straddling the concat boundary
+                                                    (1, 16, 0, 16, (16, 24, 40), 1),
+                                                    (1, 16, 0, 32, (12, 20, 28), 1),
+                                                    (2, 32, 0, 16, (12, 20, 28), 1),
+                                                    (1, 16, 16, 32, (9, 17, 33), 1),
+                                                    (1, 48, 0, 48, (14, 18, 22), 0),
+                                                    (2, 16, 32, 16, (10, 16, 24), 1),
+                                                    (1, 48, 16, 80, (10, 16, 24), 1),
+                                                    (1, 16, 0, 16, (48, 48, 48), 1)])
 def test_zring_matches_plane_kernel_and_fp32(cuda, n, c0, c1, cout, size, pad):
     g = torch.Generator().manual_seed(c0 + cout + size[0])
     D, H, W = size
@@ -27,6 +38,10 @@ def test_zring_matches_plane_kernel_and_fp32(cuda, n, c0, c1, cout, size, pad):
     x1 = ops.ndhwc(torch.randn(n, c1, D, H, W, generator=g).to(cuda)) if c1 else None
     Do, Ho, Wo = (s + 2 * pad - 2 for s in size)
     dy = ops.ndhwc((torch.randn(n, cout, Do, Ho, Wo, generator=g) * 1e-3).to(cuda))
+
+    plan = (ctypes.c_int * 7)()
+    assert _lib.lib().adell_wgrad_zring_plan(n, D, H, W, c0, c1, cout, 3, 3, 3, 1, 1, 1, Do, Ho, Wo,
+                                             plan) == 1
 
     def run(f16):
         return ops.conv3d_bwd_weight(x0, dy, 3, 1, pad, x1=x1, want_db=True, f16x3=f16)
