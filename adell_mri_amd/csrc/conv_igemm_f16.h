@@ -212,7 +212,10 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   int kA_prev = 0;
   // The halo brick of a chunk goes through registers in one piece when it has at most KEEP
   // voxels per thread ("resident"): one load, absmax, split, store.
-  constexpr int KEEP = SPEC ? ((SPEC == 3 ? 1000 : 600) + NTHR - 1) / NTHR : 3;
+  // (generic single-tile instances have registers to spare: 6 voxels per thread keep the
+  // 17 x 9 x 9 halo of a stride-2 3^3 layer out of the two-pass loop below, whose loads are
+  // issued one dependent round at a time -- 2 x 64^3 x 32 -> 32 stride 2: 0.76 ms before)
+  constexpr int KEEP = SPEC ? ((SPEC == 3 ? 1000 : 600) + NTHR - 1) / NTHR : (MT * NT == 1 ? 6 : 3);
   const bool resident = SPEC || HV <= KEEP * NTHR;
   float keep[KEEP][CC];
   int gvk[KEEP];

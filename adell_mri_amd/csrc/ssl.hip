@@ -662,3 +662,289 @@ extern "C" int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, 
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Local contrastive loss of the semi-supervised U-Net (adell_mri/modules/
+// semi_supervised_segmentation/losses.py:480-526, used by UNetContrastiveSemiSL.step_semi_sl_loco,
+// semi_supervised_segmentation/pl.py:244-281): f1, f2 are the decoder features of two views,
+// NDHWC [B][S][C]. Per voxel s the B x B matrix cos(f2[i,s,:], f1[j,s,:]) / T is soft-maxed over
+// j and loss_i = mean_s -log(max(softmax_i[i], eps)). HBM-bound: a group of G = min(64, pow2 <=
+// C/4) lanes owns one voxel, each lane a channel quad (coalesced float4 loads), the B^2 + 2B
+// partial dot products are folded across the group with xor shuffles, every lane then holds the
+// full matrix. The backward recomputes the matrix and writes its own quads of df1 (and df2).
+// torch's cosine_similarity clamps each norm at 1e-8 separately (checked against torch 2.10).
+// ---------------------------------------------------------------------------
+#define ADELL_LOCO_MAXB 8
+#define ADELL_LOCO_COS_EPS 1e-8f
+
+template <int B>
+struct LocoMat {
+  float dot[B][B];  // dot[i][j] = f2[i] . f1[j]
+  float n1[B], n2[B];
+};
+
+template <int B>
+__device__ __forceinline__ void adell_loco_dots(LocoMat<B>& m, const float4* __restrict__ f1,
+                                                const float4* __restrict__ f2, long S, long s,
+                                                int C4, int G, int gl, bool ok) {
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    m.n1[i] = 0.f;
+    m.n2[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < B; ++j) m.dot[i][j] = 0.f;
+  }
+  if (ok) {
+    for (int q = gl; q < C4; q += G) {
+      float4 a[B], b[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        a[i] = f2[((size_t)i * S + s) * C4 + q];
+        b[i] = f1[((size_t)i * S + s) * C4 + q];
+      }
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        m.n2[i] += a[i].x * a[i].x + a[i].y * a[i].y + a[i].z * a[i].z + a[i].w * a[i].w;
+        m.n1[i] += b[i].x * b[i].x + b[i].y * b[i].y + b[i].z * b[i].z + b[i].w * b[i].w;
+#pragma unroll
+        for (int j = 0; j < B; ++j)
+          m.dot[i][j] += a[i].x * b[j].x + a[i].y * b[j].y + a[i].z * b[j].z + a[i].w * b[j].w;
+      }
+    }
+  }
+  for (int o = G >> 1; o > 0; o >>= 1) {
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      m.n1[i] += __shfl_xor(m.n1[i], o, 64);
+      m.n2[i] += __shfl_xor(m.n2[i], o, 64);
+#pragma unroll
+      for (int j = 0; j < B; ++j) m.dot[i][j] += __shfl_xor(m.dot[i][j], o, 64);
+    }
+  }
+}
+
+// grid-strided over voxels; part: [gridDim.x][B] block sums of the per-voxel losses
+template <int B>
+__global__ __launch_bounds__(256) void adell_loco_fwd_kernel(const float* __restrict__ f1,
+                                                             const float* __restrict__ f2, long S,
+                                                             int C, int G, float invT, float eps,
+                                                             float* __restrict__ part) {
+  __shared__ float sh[256];
+  const int C4 = C >> 2, gl = threadIdx.x & (G - 1), vpb = 256 / G;
+  const long stride = (long)gridDim.x * vpb;
+  const long rounds = (S + stride - 1) / stride;  // every thread runs every round (shuffles)
+  float lsum[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) lsum[i] = 0.f;
+  for (long r = 0; r < rounds; ++r) {
+    const long s = r * stride + (long)blockIdx.x * vpb + threadIdx.x / G;
+    const bool ok = s < S;
+    LocoMat<B> m;
+    adell_loco_dots<B>(m, reinterpret_cast<const float4*>(f1), reinterpret_cast<const float4*>(f2),
+                       S, s, C4, G, gl, ok);
+    if (!ok || gl != 0) continue;
+    float r1[B], r2[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      r1[i] = 1.f / fmaxf(sqrtf(m.n1[i]), ADELL_LOCO_COS_EPS);
+      r2[i] = 1.f / fmaxf(sqrtf(m.n2[i]), ADELL_LOCO_COS_EPS);
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      float z[B], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        z[j] = m.dot[i][j] * r2[i] * r1[j] * invT;
+        mx = fmaxf(mx, z[j]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j < B; ++j) den += expf(z[j] - mx);
+      const float p = expf(z[i] - mx) / den;
+      lsum[i] += -logf(fmaxf(p, eps));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B; ++i) {
+    const float t = adell_block_sum(lsum[i], sh);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * B + i] = t;
+  }
+}
+
+// loss[i] = (sum over blocks, fixed order) / S
+__global__ void adell_loco_finalize_kernel(const float* __restrict__ part, int nblocks, int B,
+                                           double invS, float* __restrict__ loss) {
+  const int i = threadIdx.x;
+  if (i >= B) return;
+  double t = 0.0;
+  for (int b = 0; b < nblocks; ++b) t += (double)part[(size_t)b * B + i];
+  loss[i] = (float)(t * invS);
+}
+
+// df1[j] = sum_i c_ij d cos_ij / d f1[j], df2[i] = sum_j c_ij d cos_ij / d f2[i] with
+// c_ij = gloss[i] / S * (softmax_ij - delta_ij) / T where softmax_ii > eps (else the max() of
+// the reference passes no gradient), d cos / d b = ra rb (a - [|b| > 1e-8] (a.b) rb^2 b).
+template <int B>
+__global__ __launch_bounds__(256) void adell_loco_bwd_kernel(const float* __restrict__ f1,
+                                                             const float* __restrict__ f2,
+                                                             const float* __restrict__ gloss,
+                                                             long S, int C, int G, float invT,
+                                                             float eps, float invS,
+                                                             float* __restrict__ df1,
+                                                             float* __restrict__ df2) {
+  const int C4 = C >> 2, gl = threadIdx.x & (G - 1), vpb = 256 / G;
+  const long stride = (long)gridDim.x * vpb;
+  const long rounds = (S + stride - 1) / stride;
+  float g[B];
+#pragma unroll
+  for (int i = 0; i < B; ++i) g[i] = gloss[i] * invS * invT;
+  const float4* F1 = reinterpret_cast<const float4*>(f1);
+  const float4* F2 = reinterpret_cast<const float4*>(f2);
+  for (long r = 0; r < rounds; ++r) {
+    const long s = r * stride + (long)blockIdx.x * vpb + threadIdx.x / G;
+    const bool ok = s < S;
+    LocoMat<B> m;
+    adell_loco_dots<B>(m, F1, F2, S, s, C4, G, gl, ok);
+    if (!ok) continue;
+    float r1[B], r2[B], k1[B], k2[B];  // k: 1/|.|^2 when the norm is above the clamp, else 0
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const float a1 = sqrtf(m.n1[i]), a2 = sqrtf(m.n2[i]);
+      r1[i] = 1.f / fmaxf(a1, ADELL_LOCO_COS_EPS);
+      r2[i] = 1.f / fmaxf(a2, ADELL_LOCO_COS_EPS);
+      k1[i] = a1 > ADELL_LOCO_COS_EPS ? r1[i] * r1[i] : 0.f;
+      k2[i] = a2 > ADELL_LOCO_COS_EPS ? r2[i] * r2[i] : 0.f;
+    }
+    float c[B][B];  // c_ij * ra_i * rb_j
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      float z[B], mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        z[j] = m.dot[i][j] * r2[i] * r1[j] * invT;
+        mx = fmaxf(mx, z[j]);
+      }
+      float den = 0.f;
+#pragma unroll
+      for (int j = 0; j < B; ++j) {
+        z[j] = expf(z[j] - mx);
+        den += z[j];
+      }
+      const float live = (z[i] / den > eps) ? g[i] : 0.f;
+#pragma unroll
+      for (int j = 0; j < B; ++j)
+        c[i][j] = live * (z[j] / den - (i == j ? 1.f : 0.f)) * r2[i] * r1[j];
+    }
+    for (int q = gl; q < C4; q += G) {
+      float4 a[B], b[B];
+#pragma unroll
+      for (int i = 0; i < B; ++i) {
+        a[i] = F2[((size_t)i * S + s) * C4 + q];
+        b[i] = F1[((size_t)i * S + s) * C4 + q];
+      }
+      if (df1) {
+#pragma unroll
+        for (int j = 0; j < B; ++j) {
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          float self = 0.f;
+#pragma unroll
+          for (int i = 0; i < B; ++i) {
+            o.x += c[i][j] * a[i].x; o.y += c[i][j] * a[i].y;
+            o.z += c[i][j] * a[i].z; o.w += c[i][j] * a[i].w;
+            self += c[i][j] * m.dot[i][j];
+          }
+          self *= k1[j];
+          o.x -= self * b[j].x; o.y -= self * b[j].y; o.z -= self * b[j].z; o.w -= self * b[j].w;
+          reinterpret_cast<float4*>(df1)[((size_t)j * S + s) * C4 + q] = o;
+        }
+      }
+      if (df2) {
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          float self = 0.f;
+#pragma unroll
+          for (int j = 0; j < B; ++j) {
+            o.x += c[i][j] * b[j].x; o.y += c[i][j] * b[j].y;
+            o.z += c[i][j] * b[j].z; o.w += c[i][j] * b[j].w;
+            self += c[i][j] * m.dot[i][j];
+          }
+          self *= k2[i];
+          o.x -= self * a[i].x; o.y -= self * a[i].y; o.z -= self * a[i].z; o.w -= self * a[i].w;
+          reinterpret_cast<float4*>(df2)[((size_t)i * S + s) * C4 + q] = o;
+        }
+      }
+    }
+  }
+}
+
+static int adell_loco_group(int C) {
+  int G = 1;
+  while (2 * G <= C / 4 && 2 * G <= 64) G *= 2;
+  return G;
+}
+static int adell_loco_blocks(long S, int G) {
+  const long vpb = 256 / G;
+  long b = (S + vpb - 1) / vpb;
+  if (b > 4096) b = 4096;
+  return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" long adell_loco_loss_workspace(int B, long S, int C) {
+  ADELL_REQUIRE(B >= 1 && B <= ADELL_LOCO_MAXB, "loco_loss: batch must be 1..%d (got %d)",
+                ADELL_LOCO_MAXB, B);
+  ADELL_REQUIRE(S > 0 && C >= 4 && (C & 3) == 0, "loco_loss: need S > 0 and C %% 4 == 0 (C = %d)", C);
+  return (long)sizeof(float) * adell_loco_blocks(S, adell_loco_group(C)) * B;
+}
+
+#define ADELL_LOCO_DISPATCH(KERN, B, ...)                                                      \
+  switch (B) {                                                                                 \
+    case 1: hipLaunchKernelGGL(KERN<1>, __VA_ARGS__); break;                                   \
+    case 2: hipLaunchKernelGGL(KERN<2>, __VA_ARGS__); break;                                   \
+    case 3: hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); break;                                   \
+    case 4: hipLaunchKernelGGL(KERN<4>, __VA_ARGS__); break;                                   \
+    case 5: hipLaunchKernelGGL(KERN<5>, __VA_ARGS__); break;                                   \
+    case 6: hipLaunchKernelGGL(KERN<6>, __VA_ARGS__); break;                                   \
+    case 7: hipLaunchKernelGGL(KERN<7>, __VA_ARGS__); break;                                   \
+    default: hipLaunchKernelGGL(KERN<8>, __VA_ARGS__); break;                                  \
+  }
+
+extern "C" int adell_loco_loss_fwd(const float* f1, const float* f2, int B, long S, int C,
+                                   float temperature, float eps, float* loss, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(f1 && f2 && loss && workspace, "loco_loss_fwd: null pointer");
+  ADELL_REQUIRE(B >= 1 && B <= ADELL_LOCO_MAXB, "loco_loss_fwd: batch must be 1..%d (got %d)",
+                ADELL_LOCO_MAXB, B);
+  ADELL_REQUIRE(S > 0 && C >= 4 && (C & 3) == 0, "loco_loss_fwd: need S > 0 and C %% 4 == 0");
+  ADELL_REQUIRE(temperature > 0.f, "loco_loss_fwd: temperature must be positive");
+  ADELL_REQUIRE((((uintptr_t)f1 | (uintptr_t)f2) & 15) == 0, "loco_loss_fwd: unaligned features");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_loco_loss_workspace(B, S, C),
+                "loco_loss_fwd: workspace too small");
+  const int G = adell_loco_group(C), blocks = adell_loco_blocks(S, G);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  ADELL_LOCO_DISPATCH(adell_loco_fwd_kernel, B, dim3(blocks), dim3(256), 0, st, f1, f2, S, C, G,
+                      1.f / temperature, eps, part);
+  hipLaunchKernelGGL(adell_loco_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)part,
+                     blocks, B, 1.0 / (double)S, loss);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_loco_loss_bwd(const float* f1, const float* f2, const float* gloss, int B,
+                                   long S, int C, float temperature, float eps, float* df1,
+                                   float* df2, void* stream) {
+  ADELL_REQUIRE(f1 && f2 && gloss && (df1 || df2), "loco_loss_bwd: null pointer");
+  ADELL_REQUIRE(B >= 1 && B <= ADELL_LOCO_MAXB, "loco_loss_bwd: batch must be 1..%d (got %d)",
+                ADELL_LOCO_MAXB, B);
+  ADELL_REQUIRE(S > 0 && C >= 4 && (C & 3) == 0, "loco_loss_bwd: need S > 0 and C %% 4 == 0");
+  ADELL_REQUIRE(temperature > 0.f, "loco_loss_bwd: temperature must be positive");
+  ADELL_REQUIRE((((uintptr_t)f1 | (uintptr_t)f2 | (uintptr_t)df1 | (uintptr_t)df2) & 15) == 0,
+                "loco_loss_bwd: unaligned pointer");
+  const int G = adell_loco_group(C), blocks = adell_loco_blocks(S, G);
+  ADELL_LOCO_DISPATCH(adell_loco_bwd_kernel, B, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                      f1, f2, gloss, S, C, G, 1.f / temperature, eps, (float)(1.0 / (double)S),
+                      df1, df2);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

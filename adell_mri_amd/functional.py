@@ -977,6 +977,29 @@ def vicreg_terms(x1, x2, min_var=1.0, eps=1e-4):
     return _VICRegFn.apply(x1, x2, float(min_var), float(eps))
 
 
+class _LocoLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f1, f2, temperature, eps):
+        f1, f2 = ops.ndhwc(f1), ops.ndhwc(f2)
+        loss = ops.loco_loss_fwd(f1, f2, temperature, eps)
+        ctx.save_for_backward(f1, f2)
+        ctx.conf = (temperature, eps)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        f1, f2 = ctx.saved_tensors
+        df1, df2 = ops.loco_loss_bwd(f1, f2, g, *ctx.conf, ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[1])
+        return df1, df2, None, None
+
+
+def loco_loss(f1, f2, temperature=0.1, eps=1e-8):
+    """Per-item local contrastive loss [B] between the features of two views [B, C, *spatial]
+    (LocalContrastiveLoss.forward, semi_supervised_segmentation/losses.py:498-526)."""
+    return _LocoLossFn.apply(f1, f2, float(temperature), float(eps))
+
+
 class _ChannelSoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

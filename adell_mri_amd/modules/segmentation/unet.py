@@ -375,10 +375,9 @@ class UNet(torch.nn.Module):
         return self._decode(encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
                             return_features, return_logits)
 
-    def _decode(self, encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
-                return_features, return_logits):
-        """Decoder, head, bottleneck classifier and deep supervision (unet.py:790-843; the same
-        code closes BrUNet.forward, :1209-1253)."""
+    def _run_decoder(self, encoding_out, bottleneck, X_skip_layer, X_feature_conditioning):
+        """Decoder levels only (unet.py:790-822): the last feature map and the per-level outputs
+        (also semi_supervised_segmentation/unet.py:84-131)."""
         curr = bottleneck
         deep_outputs = []
         for i in range(len(self.decoding_operations)):
@@ -401,7 +400,14 @@ class UNet(torch.nn.Module):
                 curr = crop_to_size(curr, sh2)
             curr = op(curr, X_cat=encoded)  # virtual concat (curr, encoded)
             deep_outputs.append(curr)
+        return curr, deep_outputs
 
+    def _decode(self, encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
+                return_features, return_logits):
+        """Decoder, head, bottleneck classifier and deep supervision (unet.py:790-843; the same
+        code closes BrUNet.forward, :1209-1253)."""
+        curr, deep_outputs = self._run_decoder(encoding_out, bottleneck, X_skip_layer,
+                                               X_feature_conditioning)
         final_features = curr
         curr = self._final(self.final_layer, curr, return_logits)
         if return_features is True:

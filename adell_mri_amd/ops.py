@@ -26,6 +26,9 @@ class KernelTimer:
         self.records = []
         self._agg = None
         self.only = None if only is None else set(only)  # kernel families to time (None: all)
+        # an event pair costs ~6 us of stream idle time per launch (measured: rocprofv3 timeline,
+        # DESIGN.md 8); bench.py switches the timer off for the steps it does not sample
+        self.active = True
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -88,7 +91,7 @@ NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, fo
 
 def _timed(name, flops, fn, tag=None, nbytes=0.0, kernels=1):
     t = KERNEL_TIMER
-    if t is None or (t.only is not None and name not in t.only):
+    if t is None or not t.active or (t.only is not None and name not in t.only):
         return fn()
     e0 = t.start()
     rc = fn()
@@ -1159,6 +1162,41 @@ def vicreg_bwd(x1, x2, scratch, min_var, eps, g, need1, need2):
     check(_lib.lib().adell_vicreg_bwd(_ptr(x1), _ptr(x2), B, D, float(min_var), float(eps),
                                       _ptr(scratch), _ptr(g), _ptr(dx1), _ptr(dx2), _stream()))
     return dx1, dx2
+
+
+def loco_loss_fwd(f1, f2, temperature, eps):
+    """Per-item local contrastive loss [B] of two NDHWC feature maps [B, C, *spatial]
+    (semi_supervised_segmentation/losses.py:498-526)."""
+    _require_cuda(f1, f2)
+    f1, f2 = ndhwc(f1), ndhwc(f2)
+    if f1.shape != f2.shape:
+        raise AdellHipError(f"loco_loss: feature shapes differ ({tuple(f1.shape)} vs "
+                            f"{tuple(f2.shape)})")
+    B, C = f1.shape[0], f1.shape[1]
+    S = f1.numel() // (B * C)
+    nbytes = _lib.lib().adell_loco_loss_workspace(B, S, C)
+    check(min(nbytes, 0))
+    ws = _workspace(nbytes, f1.device)
+    loss = torch.empty(B, device=f1.device, dtype=torch.float32)
+    check(_lib.lib().adell_loco_loss_fwd(_ptr(f1), _ptr(f2), B, S, C, float(temperature),
+                                         float(eps), _ptr(loss), _ptr(ws), ws.numel() * 4,
+                                         _stream()))
+    return loss
+
+
+def loco_loss_bwd(f1, f2, gloss, temperature, eps, need1, need2):
+    if not (need1 or need2):
+        return None, None
+    f1, f2 = ndhwc(f1), ndhwc(f2)
+    B, C = f1.shape[0], f1.shape[1]
+    S = f1.numel() // (B * C)
+    gloss = gloss.contiguous().float()
+    df1 = new_act(*f1.shape, f1.device) if need1 else None
+    df2 = new_act(*f2.shape, f2.device) if need2 else None
+    check(_lib.lib().adell_loco_loss_bwd(_ptr(f1), _ptr(f2), _ptr(gloss), B, S, C,
+                                         float(temperature), float(eps), _ptr(df1), _ptr(df2),
+                                         _stream()))
+    return df1, df2
 
 
 # ---- class-axis softmax head, channel max pooling -------------------------------------------------

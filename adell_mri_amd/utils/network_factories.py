@@ -55,9 +55,17 @@ def get_segmentation_network(
         picai_eval=picai_eval, lr_encoder=lr_encoder, start_decay=start_decay,
         warmup_steps=warmup_steps, optimizer_str=optimizer_str, optimizer_eps=optimizer_eps)
 
-    if net_type == "unet" and semi_supervised is True:
-        raise NotImplementedError("UNetContrastiveSemiSL (network_factories.py:602-620) is not "
-                                  "part of the HIP path yet")
+    if net_type == "unet" and semi_supervised is True:   # network_factories.py:602-620
+        from ..modules.semi_supervised_segmentation import (LocalContrastiveLoss,
+                                                            UNetContrastiveSemiSL)
+        from .utils import ExponentialMovingAverage
+
+        ema = ExponentialMovingAverage(decay=0.99, final_decay=1.0, n_steps=max_steps_optim)
+        return UNetContrastiveSemiSL(
+            encoding_operations=encoding_operations[0], image_key="image",
+            semi_sl_image_key_1="semi_sl_image_1", semi_sl_image_key_2="semi_sl_image_2",
+            deep_supervision=deep_supervision, ema=ema,
+            loss_fn_semi_sl=LocalContrastiveLoss(seed=seed), **common, **network_config)
     if net_type in ("monai_unetr", "monai_swin"):
         raise NotImplementedError(f"{net_type}: the MONAI wrappers are outside the HIP path "
                                   "(SURVEY.md section 2: out of scope)")

@@ -16,8 +16,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement): whole-job volum
 timed K steps, plus
 
 * ``roofline``: the dominant MFMA kernel family (per-launch HIP-event timing inside the timed
-  region), with ``hbm`` = the dominant HBM-bound family (the fused norm/dropout/activation
-  kernels) against 8 TB/s and ``step_frac`` = whole-step algorithmic FLOPs / step time / ceiling;
+  region, on every ``--event-every``-th step: an event pair idles the stream ~6 us, so timing
+  all ~85 launches of every step would cost the step it measures ~1 ms), with ``hbm`` = the
+  dominant HBM-bound family (the fused norm/dropout/activation kernels; event-timed on 2 steps
+  directly after the timed region) against 8 TB/s and ``step_frac`` = whole-step algorithmic
+  FLOPs / step time / ceiling;
 * ``cpu_baseline``: the stock-torch CPU oracle (rank 0, N = 1 only), 1 warm-up + 3 timed
   training steps on the host's physical cores, and a one-thread figure on a 64^3 volume;
 * ``fp32_mfma``: the same step on the bit-exact fp32-MFMA kernels (secondary figure);
@@ -58,6 +61,9 @@ def parse_args():
                     help="volumes per GPU per step (default: batch_size of the YAML = 2; "
                          "SURVEY.md 8(d): B per GPU in {1, 2})")
     ap.add_argument("--config", type=str, default=CONFIG)
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="event-time the dominant kernel family on every M-th timed step "
+                         "(1: every step; each event pair idles the stream ~6 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-MFMA secondary figure")
     ap.add_argument("--cpu-size", type=int, default=128,
@@ -212,7 +218,10 @@ def cpu_training_steps(cfg_kwargs, size, threads, warmup, steps):
     return statistics.median(times), torch.get_num_threads()
 
 
-def timed_steps(runner, batch, steps, barrier, per_step_events=True):
+def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None, event_every=1):
+    """K training steps between two barriers. ``timer``: the per-launch event timer of the
+    dominant kernel family, switched on for every ``event_every``-th step only (each event pair
+    idles the stream ~6 us; sampling keeps the instrument from slowing what it measures)."""
     import torch
 
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step_events else None
@@ -221,7 +230,11 @@ def timed_steps(runner, batch, steps, barrier, per_step_events=True):
     for i in range(steps):
         if evs:
             evs[i].record()
+        if timer is not None:
+            timer.active = event_every > 0 and i % event_every == 0
         loss = runner.train_step(batch)
+    if timer is not None:
+        timer.active = True
     if evs:
         evs[steps].record()
     barrier()
@@ -275,11 +288,22 @@ def main():
     warm, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     dom_warm = warm.dominant() if args.warmup > 0 else None
     warm_summary = warm.summary() if args.warmup > 0 else {}
-    ops.KERNEL_TIMER = ops.KernelTimer(
-        only=None if dom_warm is None else {dom_warm[0], ops.NORM_ACT_FAMILY})
+    ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
+    every = max(1, args.event_every)
+    sampled = len(range(0, args.steps, every))
     barrier()
-    dt, loss, per_step = timed_steps(runner, batch, args.steps, barrier)
+    dt, loss, per_step = timed_steps(runner, batch, args.steps, barrier, timer=ops.KERNEL_TIMER,
+                                     event_every=every)
     timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    # the HBM-bound norm / dropout / activation family: its own instrumented steps right after the
+    # timed region (clocks still in their loaded state), so that its ~140 event pairs per step do
+    # not sit inside the region `value` is measured over
+    hbm_steps = 2 if args.warmup > 0 else 0
+    ops.KERNEL_TIMER = ops.KernelTimer(only={ops.NORM_ACT_FAMILY})
+    for _ in range(hbm_steps):
+        runner.train_step(batch)
+    barrier()
+    hbm_timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     dt = reduce_max(dt, device)
     loss_value = float(loss.detach().cpu())
 
@@ -346,23 +370,27 @@ def main():
                 "executed_mfma_tflops": achieved * (3.0 if kf16 else 1.0),
                 "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
                 "launches": launches, "avg_launch_ms": ms / launches,
-                "kernel_time_share": timer.share(name, 1e3 * dt)}
+                "event_timed_steps": f"{sampled} of the {args.steps} timed steps (every "
+                                     f"{every}{'st' if every == 1 else 'th'})",
+                "kernel_time_share": timer.share(name, 1e3 * dt * sampled / args.steps)}
         # whole step: algorithmic FLOPs of every instrumented MFMA / conv family (from the
         # warm-up census, per step) over the measured step time, against the same ceiling
         if args.warmup > 0:
             step_flops = sum(v["flops"] for v in warm_summary.values()) / args.warmup
             roof["step_frac"] = step_flops / (dt / args.steps) / 1e12 / peak
             roof["step_algorithmic_tflop"] = step_flops / 1e12
-        hb = timer.summary().get(ops.NORM_ACT_FAMILY)
+        hb = hbm_timer.summary().get(ops.NORM_ACT_FAMILY) if hbm_steps else None
         if hb is not None and hb["ms"] > 0:
             tbs = hb["algorithmic_bytes"] / (hb["ms"] * 1e-3) / 1e12
             roof["hbm"] = {"bound": "hbm", "kernel": ops.NORM_ACT_FAMILY + " (fused norm -> dropout "
                            "-> activation, forward + backward)", "achieved": tbs * 1e3,
                            "peak": HBM_PEAK_TBS * 1e3, "unit": "GB/s", "frac": tbs / HBM_PEAK_TBS,
                            "launches": hb["launches"],
-                           "ms_per_step": hb["ms"] / args.steps,
-                           "time_share": timer.share(ops.NORM_ACT_FAMILY, 1e3 * dt),
-                           "algorithmic_bytes_per_step": hb["algorithmic_bytes"] / args.steps}
+                           "ms_per_step": hb["ms"] / hbm_steps,
+                           "time_share": hb["ms"] / hbm_steps / (1e3 * dt / args.steps),
+                           "algorithmic_bytes_per_step": hb["algorithmic_bytes"] / hbm_steps,
+                           "measured": f"{hbm_steps} instrumented steps directly after the timed "
+                                       f"region"}
         roof["all_kernels_warmup"] = warm_summary
         out["roofline"] = roof
     if world == 1 and not args.no_cpu_baseline:

@@ -447,6 +447,20 @@ int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, float min_v
                      const float* scratch, const float* g3, float* dx1, float* dx2,
                      void* stream);
 
+/* Local contrastive loss of the semi-supervised U-Net (LocalContrastiveLoss.forward,
+ * semi_supervised_segmentation/losses.py:498-526; called by UNetContrastiveSemiSL.step_semi_sl_loco,
+ * semi_supervised_segmentation/pl.py:244-281): f1 / f2 = decoder features of the two views, NDHWC
+ * [B][S][C] (B <= 8, C % 4 == 0). loss[i] = mean_s -log(max(softmax_j(cos(f2[i,s], f1[j,s]) / T)[i],
+ * eps)). Backward: gloss[B] (device) = dL/dloss; df1 / df2 [B][S][C], either may be NULL.
+ * Workspace of the forward: adell_loco_loss_workspace(B, S, C) bytes (per-block partial sums,
+ * folded in fixed order). */
+long adell_loco_loss_workspace(int B, long S, int C);
+int adell_loco_loss_fwd(const float* f1, const float* f2, int B, long S, int C, float temperature,
+                        float eps, float* loss, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int adell_loco_loss_bwd(const float* f1, const float* f2, const float* gloss, int B, long S, int C,
+                        float temperature, float eps, float* df1, float* df2, void* stream);
+
 /* 1x1x1 convolution with Cout <= 4 (the logits head, unet.py:712-731) on canonical weights
  * w [Cout][C0+C1]: one HBM-bound pass each way. `applicable` tells whether a descriptor takes
  * this path (k = 1, stride 1, no padding, Cout <= 4, Cin <= 512). */

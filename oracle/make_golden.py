@@ -25,6 +25,8 @@ for name, path in [
     ("adell_mri.utils", "adell_mri/utils"),
     ("adell_mri.modules.self_supervised", "adell_mri/modules/self_supervised"),
     ("adell_mri.modules.self_supervised.losses", "adell_mri/modules/self_supervised/losses"),
+    ("adell_mri.modules.semi_supervised_segmentation",
+     "adell_mri/modules/semi_supervised_segmentation"),
 ]:
     m = types.ModuleType(name)
     m.__path__ = [os.path.join(REF, path)]
@@ -639,7 +641,88 @@ def gen_losses():
     np.savez_compressed(os.path.join(OUT, "losses_mc.npz"), **out)
 
 
+SEMISL_CASES = {
+    # UNetSemiSL (semi_supervised_segmentation/unet.py) in the shape of BASELINE config 2
+    "unet3d_semisl": (dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                           upscale_type="transpose", norm_type="instance", padding=1,
+                           dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                           depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                      (2, 2, 16, 16, 16)),
+    "unet2d_semisl": (dict(spatial_dimensions=2, conv_type="regular", link_type="identity",
+                           upscale_type="transpose", norm_type="instance", padding=1,
+                           dropout_param=0.0, activation_fn="swish", in_channels=1, n_classes=2,
+                           depth=[8, 16], kernel_sizes=[3] * 2, strides=[2] * 2),
+                      (3, 1, 24, 32)),
+}
+
+
+def gen_semisl():
+    """UNetContrastiveSemiSL.training_step arithmetic (semi_supervised_segmentation/pl.py:371-450)
+    from the reference's own UNetSemiSL and LocalContrastiveLoss: supervised dice + focal on the
+    annotated batch plus 0.01 * mean(LoCo(features(x_1), linear_transformation(features(x_2))))
+    with the stop-gradient teacher (ema=None, stop_gradient=True); and the loss alone on random
+    features, with the gradient for both arguments."""
+    from adell_mri.modules.semi_supervised_segmentation.losses import LocalContrastiveLoss
+    from adell_mri.modules.semi_supervised_segmentation.unet import UNetSemiSL
+
+    for name, (kw, shape) in SEMISL_CASES.items():
+        torch.manual_seed(0)
+        g = torch.Generator().manual_seed(4321)
+        kw = dict(kw)
+        kw["activation_fn"] = activation_factory[kw["activation_fn"]]
+        net = UNetSemiSL(**kw)
+        net.load_state_dict(fill_state_dict(net.state_dict()))
+        net.eval()
+        x, x1, x2 = (torch.rand(shape, generator=g) for _ in range(3))
+        y = (torch.rand((shape[0], 1, *shape[2:]), generator=g) > 0.9).float()
+        out = {"x": x.numpy(), "x1": x1.numpy(), "x2": x2.numpy(), "y": y.numpy()}
+        prob = net(x)[0]
+        d = binary_generalized_dice_loss(prob, y, smooth=1e-5, eps=1e-6)
+        f = binary_focal_loss(prob, y, gamma=1.0, eps=1e-6)
+        sup = torch.stack([d.mean(), f.mean()]).mean()
+        f1 = net.forward_features(X=x1)
+        with torch.no_grad():
+            f2 = net.forward_features(X=x2, apply_linear_transformation=True)
+        loco = LocalContrastiveLoss(seed=42)(f1, f2)
+        ssl = loco.mean() * 0.01
+        total = sup + ssl
+        net.zero_grad()
+        total.backward()
+        out.update(prob=prob.detach().numpy(), features_1=f1.detach().numpy(),
+                   features_2=f2.numpy(), loco=loco.detach().numpy(),
+                   sup=sup.detach().numpy(), ssl=ssl.detach().numpy(),
+                   total=total.detach().numpy())
+        for k, p in net.named_parameters():
+            if p.grad is not None:
+                out["grad:" + k] = p.grad.numpy().copy()
+        out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "sup", float(sup), "ssl", float(ssl), "loco", loco.detach().numpy())
+    # the loss on its own
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for tag, shape, temp in (("a", (3, 8, 4, 5, 6), 0.1), ("b", (2, 32, 6, 6, 6), 0.1),
+                             ("c", (4, 12, 7, 9), 0.5), ("d", (1, 4, 3, 3, 3), 0.1)):
+        a = (torch.randn(shape, generator=g) * 2).requires_grad_(True)
+        b = (torch.randn(shape, generator=g) + 0.3 * a.detach()).requires_grad_(True)
+        if tag == "a":   # a voxel whose features are all zero: the clamp of cosine_similarity
+            with torch.no_grad():
+                a[0, :, 0, 0, 0] = 0.0
+        r = torch.rand((shape[0],), generator=g) + 0.5
+        val = LocalContrastiveLoss(temperature=temp)(a, b)
+        (val * r).sum().backward()
+        out.update({f"{tag}:x1": a.detach().numpy(), f"{tag}:x2": b.detach().numpy(),
+                    f"{tag}:r": r.numpy(), f"{tag}:temperature": np.float32(temp),
+                    f"{tag}:value": val.detach().numpy(), f"{tag}:grad1": a.grad.numpy().copy(),
+                    f"{tag}:grad2": b.grad.numpy().copy()})
+        print("loco", tag, val.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "loco_loss.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "semisl":
+        gen_semisl()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "losses":
         gen_losses()
         sys.exit(0)

@@ -108,3 +108,14 @@ BRUNET_CASES = {
                                      activation_fn="swish", dropout_param=0.0, in_channels=2),
                                 (3, 2, 32, 40)),
 }
+
+SEMISL_CASES = {
+    "unet3d_semisl": dict(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                          upscale_type="transpose", norm_type="instance", padding=1,
+                          dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                          depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+    "unet2d_semisl": dict(spatial_dimensions=2, conv_type="regular", link_type="identity",
+                          upscale_type="transpose", norm_type="instance", padding=1,
+                          dropout_param=0.0, activation_fn="swish", in_channels=1, n_classes=2,
+                          depth=[8, 16], kernel_sizes=[3] * 2, strides=[2] * 2),
+}

@@ -144,3 +144,22 @@ def test_loss_restatements_match_reference_fixture():
         (val * r).sum().backward()
         np.testing.assert_allclose(val.detach().numpy(), g[name + ":value"], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(p.grad.numpy(), g[name + ":grad"], rtol=1e-4, atol=1e-8)
+
+
+def test_local_contrastive_loss_restatement_matches_reference_fixture():
+    """oracle/torch_ref/semi_sl.py against tests/golden/loco_loss.npz (values and both gradients
+    from the reference's LocalContrastiveLoss, oracle/make_golden.py gen_semisl)."""
+    import torch
+
+    from oracle.torch_ref.semi_sl import local_contrastive_loss
+
+    g = np.load(os.path.join(GOLD, "loco_loss.npz"))
+    for tag in "abcd":
+        x1 = torch.from_numpy(g[f"{tag}:x1"]).requires_grad_(True)
+        x2 = torch.from_numpy(g[f"{tag}:x2"]).requires_grad_(True)
+        val = local_contrastive_loss(x1, x2, float(g[f"{tag}:temperature"]))
+        (val * torch.from_numpy(g[f"{tag}:r"])).sum().backward()
+        np.testing.assert_allclose(val.detach().numpy(), g[f"{tag}:value"], rtol=2e-5, atol=1e-6)
+        for grad, key in ((x1.grad, "grad1"), (x2.grad, "grad2")):
+            ref = g[f"{tag}:{key}"]
+            assert np.abs(grad.numpy() - ref).max() <= 1e-4 * np.abs(ref).max() + 1e-9, (tag, key)
