@@ -16,20 +16,22 @@ from .res_blocks import ResidualBlock3d
 
 
 def resnet_to_encoding_ops(res_net: List[torch.nn.Module]) -> torch.nn.ModuleList:
-    """U-Net ``encoding_operations`` ([[op, pool], ...] per backbone) from ResNet objects
-    (res_net.py:27-48; the same repackaging is inlined at
-    entrypoints/segmentation/train.py:711-733)."""
-    backbone = [x.backbone for x in res_net]
-    res_ops = [[x.input_layer, *x.operations] for x in backbone]
-    res_pool_ops = [[x.first_pooling, *x.pooling_operations] for x in backbone]
-    encoding_operations = [torch.nn.ModuleList([]) for _ in res_ops]
-    for i in range(len(res_ops)):
-        for a, b in zip(res_ops[i], res_pool_ops[i]):
-            encoding_operations[i].append(torch.nn.ModuleList([a, b]))
-    return torch.nn.ModuleList(encoding_operations)
+    """U-Net ``encoding_operations`` from ResNet objects (res_net.py:27-48; inlined again at
+    entrypoints/segmentation/train.py:711-733): per network, the list of [level, pooling] pairs
+    -- the stem with its pooling first, then every residual stage with its own."""
+    per_network = []
+    for backbone in (net.backbone for net in res_net):
+        levels = [backbone.input_layer, *backbone.operations]
+        pools = [backbone.first_pooling, *backbone.pooling_operations]
+        per_network.append(torch.nn.ModuleList(
+            [torch.nn.ModuleList([level, pool]) for level, pool in zip(levels, pools)]))
+    return torch.nn.ModuleList(per_network)
 
 
 class ResNetBackbone(torch.nn.Module):
+    """Stem (7^3 conv + ADN + 3^3 conv + ADN, max-pool 2) and residual stages of bottleneck
+    blocks, each followed by a max-pool (res_net.py:51-275). 3-D, ``res_type="resnet"``."""
+
     def __init__(self, spatial_dim: int, in_channels: int,
                  structure: List[Tuple[int, int, int, int]],
                  maxpool_structure: List[Union[Tuple[int, int], Tuple[int, int, int]]] = None,
@@ -37,76 +39,56 @@ class ResNetBackbone(torch.nn.Module):
                  res_type: str = "resnet", batch_ensemble: int = 0,
                  skip_last_activation: bool = False):
         super().__init__()
-        self.spatial_dim = spatial_dim
-        self.in_channels = in_channels
-        self.structure = structure
-        self.maxpool_structure = maxpool_structure
-        if self.maxpool_structure is None:
-            self.maxpool_structure = [2 for _ in self.structure]
-        self.adn_fn = adn_fn
-        self.res_type = res_type
-        self.batch_ensemble = batch_ensemble
-        self.skip_last_activation = skip_last_activation
         if spatial_dim != 3 or res_type != "resnet" or batch_ensemble > 0:
             raise NotImplementedError("HIP ResNetBackbone covers spatial_dim=3, res_type='resnet', "
                                       "batch_ensemble=0")
-        self.get_ops()
-        self.init_layers()
-        self.output_features = self.structure[-1][0]
-
-    def get_ops(self):
-        self.res_op = ResidualBlock3d
-        self.conv_op = Conv3d
-        self.max_pool_op = MaxPool3d
-
-    def init_layers(self):
-        f = self.structure[0][0]
+        if maxpool_structure is None:
+            maxpool_structure = [2] * len(structure)
+        self.spatial_dim, self.in_channels, self.structure = spatial_dim, in_channels, structure
+        self.maxpool_structure, self.adn_fn, self.res_type = maxpool_structure, adn_fn, res_type
+        self.batch_ensemble, self.skip_last_activation = batch_ensemble, skip_last_activation
+        self.res_op, self.conv_op, self.max_pool_op = ResidualBlock3d, Conv3d, MaxPool3d
+        stem = structure[0][0]
         self.input_layer = torch.nn.Sequential(
-            self.conv_op(self.in_channels, f, 7, padding="same"), self.adn_fn(f),
-            self.conv_op(f, f, 3, padding="same"), self.adn_fn(f))
-        self.first_pooling = self.max_pool_op(2, 2)
-        self.operations = torch.nn.ModuleList([])
-        self.be_operations = torch.nn.ModuleList([])
-        self.pooling_operations = torch.nn.ModuleList([])
-        prev_inp = f
-        for s, mp in zip(self.structure, self.maxpool_structure):
-            inp, inter, k, N = s
-            op = [self.res_op(prev_inp, k, inter, inp, self.adn_fn)]
-            for _ in range(1, N - 1):
-                op.append(self.res_op(inp, k, inter, inp, self.adn_fn))
-            op.append(self.res_op(inp, k, inter, inp, self.adn_fn))
-            prev_inp = inp
-            self.operations.append(torch.nn.Sequential(*op))
-            self.be_operations.append(None)
-            self.pooling_operations.append(self.max_pool_op(mp, mp))
+            Conv3d(in_channels, stem, 7, padding="same"), adn_fn(stem),
+            Conv3d(stem, stem, 3, padding="same"), adn_fn(stem))
+        self.first_pooling = MaxPool3d(2, 2)
+        stages, pools, width_in = [], [], stem
+        for (width, inner, kernel, n_blocks), pool in zip(structure, maxpool_structure):
+            # at least two blocks per stage, the first one changes the width
+            widths = [width_in] + [width] * max(n_blocks - 1, 1)
+            stages.append(torch.nn.Sequential(
+                *[ResidualBlock3d(w, kernel, inner, width, adn_fn) for w in widths]))
+            pools.append(MaxPool3d(pool, pool))
+            width_in = width
+        self.operations = torch.nn.ModuleList(stages)
+        self.be_operations = torch.nn.ModuleList([None] * len(stages))  # batch-ensemble slots: unused
+        self.pooling_operations = torch.nn.ModuleList(pools)
+        self.output_features = structure[-1][0]
 
-    def forward_with_intermediate(self, X, after_pool: bool = False, batch_idx: int = None):
-        X = self.first_pooling(self.input_layer(X))
-        output_list = []
-        for op, pool_op in zip(self.operations, self.pooling_operations):
-            X = op(X)
-            pooled_X = pool_op(X)
-            output_list.append(pooled_X if after_pool is True else X)
-            X = pooled_X
-        return X, output_list
+    def _walk(self, X):
+        """Yields (level output, pooled level output): the stem first, then the stages."""
+        X = self.input_layer(X)
+        pooled = self.first_pooling(X)
+        yield X, pooled
+        for stage, pool in zip(self.operations, self.pooling_operations):
+            X = stage(pooled)
+            pooled = pool(X)
+            yield X, pooled
 
     def forward_intermediate(self, X, after_pool: bool = False, batch_idx: int = None):
-        output_list = []
-        X = self.input_layer(X)
-        if after_pool is False:
-            output_list.append(X)
-        X = self.first_pooling(X)
-        if after_pool is True:
-            output_list.append(X)
-        for op, pooling_op in zip(self.operations, self.pooling_operations):
-            X = op(X)
-            pooled_X = pooling_op(X)
-            output_list.append(pooled_X if after_pool is True else X)
-            X = pooled_X
-        return output_list
+        """Every level including the stem."""
+        return [pooled if after_pool else features for features, pooled in self._walk(X)]
+
+    def forward_with_intermediate(self, X, after_pool: bool = False, batch_idx: int = None):
+        """(output, the residual stages' tensors) -- the stem is not listed."""
+        levels = list(self._walk(X))
+        return levels[-1][1], [pooled if after_pool else features
+                               for features, pooled in levels[1:]]
 
     def forward_regular(self, X, batch_idx: int = None):
-        X, _ = self.forward_with_intermediate(X, after_pool=False, batch_idx=batch_idx)
+        for _, X in self._walk(X):
+            pass
         return X
 
     def forward(self, X, return_intermediate: bool = False, after_pool: bool = False,
@@ -117,60 +99,51 @@ class ResNetBackbone(torch.nn.Module):
 
 
 class ProjectionHead(torch.nn.Module):
-    """Global max over the volume, then Linear (+ADN) layers (res_net.py:278-324)."""
+    """Global max over the volume, then ``linear_i`` = Linear + ADN for every width but the last,
+    which is a bare Linear (res_net.py:278-324)."""
 
     def __init__(self, in_channels: int, structure: List[int],
                  adn_fn: torch.nn.Module = torch.nn.Identity):
         super().__init__()
-        self.in_channels = in_channels
-        self.structure = structure
-        self.adn_fn = adn_fn
-        self.init_head()
-
-    def init_head(self):
-        prev_d = self.in_channels
-        ops = OrderedDict()
-        i = -1
-        for i, fd in enumerate(self.structure[:-1]):
-            ops["linear_{}".format(i)] = torch.nn.Sequential(Linear(prev_d, fd), self.adn_fn(fd))
-            prev_d = fd
-        ops["linear_{}".format(i + 1)] = Linear(prev_d, self.structure[-1])
-        self.op = torch.nn.Sequential(ops)
+        self.in_channels, self.structure, self.adn_fn = in_channels, structure, adn_fn
+        layers, width_in = OrderedDict(), in_channels
+        for i, width in enumerate(structure):
+            fc = Linear(width_in, width)
+            last = i == len(structure) - 1
+            layers[f"linear_{i}"] = fc if last else torch.nn.Sequential(fc, adn_fn(width))
+            width_in = width
+        self.op = torch.nn.Sequential(layers)
 
     def forward(self, X):
-        if len(X.shape) == 5:
+        if X.dim() == 5:
             X = HF.max_pool3d(X, tuple(X.shape[2:]), tuple(X.shape[2:]), 0).flatten(1)
-        elif len(X.shape) > 2:
+        elif X.dim() > 2:
             raise NotImplementedError("HIP ProjectionHead pools 5-D volumes only")
         return self.op(X)
 
 
 class ResNet(torch.nn.Module):
+    """Backbone + optional projection head (closed by a normalisation) + optional prediction
+    head (res_net.py:327-396)."""
+
     def __init__(self, backbone_args: dict, projection_head_args: dict = None,
                  prediction_head_args: dict = None):
         super().__init__()
         self.backbone_args = backbone_args
         self.projection_head_args = projection_head_args
         self.prediction_head_args = prediction_head_args
-        self.backbone = ResNetBackbone(**self.backbone_args)
-        self.init_projection_head()
-        self.init_prediction_head()
-
-    def init_projection_head(self):
-        if self.projection_head_args is not None:
-            args = dict(self.projection_head_args)
-            d = args["structure"][-1]
-            if "last_layer_norm" in args:
-                norm_fn = args.pop("last_layer_norm")
-            elif hasattr(args["adn_fn"](d), "norm_fn"):
-                norm_fn = args["adn_fn"](d).norm_fn
-            else:
-                norm_fn = LayerNorm
-            self.projection_head = torch.nn.Sequential(ProjectionHead(**args), _NormLeaf(norm_fn, d))
-
-    def init_prediction_head(self):
-        if self.prediction_head_args is not None:
-            self.prediction_head = ProjectionHead(**self.prediction_head_args)
+        self.backbone = ResNetBackbone(**backbone_args)
+        if projection_head_args is not None:
+            head_args = dict(projection_head_args)
+            width = head_args["structure"][-1]
+            # closing normalisation: explicit, else the one of the head's ADN, else LayerNorm
+            norm_fn = head_args.pop("last_layer_norm", None)
+            if norm_fn is None:
+                norm_fn = getattr(head_args["adn_fn"](width), "norm_fn", LayerNorm)
+            self.projection_head = torch.nn.Sequential(ProjectionHead(**head_args),
+                                                       _NormLeaf(norm_fn, width))
+        if prediction_head_args is not None:
+            self.prediction_head = ProjectionHead(**prediction_head_args)
 
     def forward_representation(self, X, *args, **kwargs):
         return self.backbone(X, *args, **kwargs)
@@ -182,15 +155,15 @@ class ResNet(torch.nn.Module):
         return self.backbone.forward_intermediate(X)
 
     def forward(self, X, ret="projection"):
-        X = self.backbone(X)
-        if ret == "representation":
-            return X
-        X = self.projection_head(X)
-        if ret == "projection":
-            return X
-        X = self.prediction_head(X)
-        if ret == "prediction":
-            return X
+        """``ret``: "representation" (backbone output), "projection" or "prediction"."""
+        out = self.backbone(X)
+        if ret != "representation":
+            out = self.projection_head(out)
+            if ret == "prediction":
+                out = self.prediction_head(out)
+            elif ret != "projection":
+                return None
+        return out
 
 
 def _NormLeaf(norm_fn, d):

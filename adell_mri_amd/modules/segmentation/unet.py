@@ -75,56 +75,32 @@ class _DecoderOp(torch.nn.Sequential):
         return h
 
 
+def _keep_arguments(module, arguments: dict, skip=("self", "parent_class")):
+    """Store constructor arguments under their own names (the attribute set the reference's
+    classes expose and its wrappers / entry points read)."""
+    for name, value in arguments.items():
+        if name not in skip and not name.startswith("__"):
+            setattr(module, name, value)
+
+
 class UNet(torch.nn.Module):
-    def __init__(
-        self,
-        spatial_dimensions: int = 2,
-        encoding_operations: List[torch.nn.ModuleList] = None,
-        conv_type: str = "regular",
-        link_type: str = "identity",
-        upscale_type: str = "upsample",
-        interpolation: str = "bilinear",
-        norm_type: str = "batch",
-        dropout_type: str = "dropout",
-        padding: str = "same",
-        dropout_param: float = 0.1,
-        activation_fn: torch.nn.Module = torch.nn.PReLU,
-        in_channels: int = 1,
-        n_classes: int = 2,
-        depth: list = [16, 32, 64],
-        kernel_sizes: list = [3, 3, 3],
-        strides: list = [2, 2, 2],
-        bottleneck_classification: bool = False,
-        skip_conditioning: int = None,
-        feature_conditioning: int = None,
-        feature_conditioning_params: Dict[str, torch.Tensor] = None,
-        deep_supervision: bool = False,
-        parent_class: bool = False,
-        encoder_only: bool = False,
-    ):
+    # signature: adell_mri/modules/segmentation/unet.py:43-68
+    def __init__(self, spatial_dimensions: int = 2,
+                 encoding_operations: List[torch.nn.ModuleList] = None,
+                 conv_type: str = "regular", link_type: str = "identity",
+                 upscale_type: str = "upsample", interpolation: str = "bilinear",
+                 norm_type: str = "batch", dropout_type: str = "dropout", padding: str = "same",
+                 dropout_param: float = 0.1, activation_fn: torch.nn.Module = torch.nn.PReLU,
+                 in_channels: int = 1, n_classes: int = 2, depth: list = [16, 32, 64],
+                 kernel_sizes: list = [3, 3, 3], strides: list = [2, 2, 2],
+                 bottleneck_classification: bool = False, skip_conditioning: int = None,
+                 feature_conditioning: int = None,
+                 feature_conditioning_params: Dict[str, torch.Tensor] = None,
+                 deep_supervision: bool = False, parent_class: bool = False,
+                 encoder_only: bool = False):
+        arguments = dict(locals())
         super().__init__()
-        self.spatial_dimensions = spatial_dimensions
-        self.encoding_operations = encoding_operations
-        self.conv_type = conv_type
-        self.link_type = link_type
-        self.upscale_type = upscale_type
-        self.interpolation = interpolation
-        self.norm_type = norm_type
-        self.dropout_type = dropout_type
-        self.padding = padding
-        self.dropout_param = dropout_param
-        self.activation_fn = activation_fn
-        self.in_channels = in_channels
-        self.n_classes = n_classes
-        self.depth = depth
-        self.kernel_sizes = kernel_sizes
-        self.strides = strides
-        self.bottleneck_classification = bottleneck_classification
-        self.skip_conditioning = skip_conditioning
-        self.feature_conditioning = feature_conditioning
-        self.feature_conditioning_params = feature_conditioning_params
-        self.deep_supervision = deep_supervision
-        self.encoder_only = encoder_only
+        _keep_arguments(self, arguments)
 
         if self.encoder_only is True or parent_class is False:
             self.get_norm_op()
@@ -356,24 +332,28 @@ class UNet(torch.nn.Module):
                 return_bottleneck=False, return_logits=False):
         if not X.is_cuda:
             raise AdellHipError("adell_mri_amd.UNet runs on MI355X only (no CPU fallback)")
-        if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
-            X_skip_layer = X_skip_layer.unsqueeze(1)
-        if X_feature_conditioning is not None:   # tiny [B, F] tensor: normalise the features
-            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
-
-        encoding_out = []
-        curr = X
-        for op, op_ds in self.encoding_operations:
-            curr = op(curr)
-            encoding_out.append(curr)
-            curr = op_ds(curr)
-        bottleneck = curr
+        encoding_out, bottleneck, X_skip_layer, X_feature_conditioning = self._encode(
+            X, X_skip_layer, X_feature_conditioning)
         if return_bottleneck is True:
             return None, None, bottleneck
         elif self.encoder_only is True:
             return bottleneck
         return self._decode(encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
                             return_features, return_logits)
+
+    def _encode(self, X, X_skip_layer, X_feature_conditioning):
+        """Encoder levels (unet.py:768-788): the per-level outputs, the bottleneck and the two
+        conditioning inputs made ready for the decoder (channel axis added / standardised)."""
+        if X_skip_layer is not None and X_skip_layer.dim() < X.dim():
+            X_skip_layer = X_skip_layer.unsqueeze(1)
+        if X_feature_conditioning is not None:   # tiny [B, F] tensor
+            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
+        encoding_out, curr = [], X
+        for level, downsample in self.encoding_operations:
+            curr = level(curr)
+            encoding_out.append(curr)
+            curr = downsample(curr)
+        return encoding_out, curr, X_skip_layer, X_feature_conditioning
 
     def _run_decoder(self, encoding_out, bottleneck, X_skip_layer, X_feature_conditioning):
         """Decoder levels only (unet.py:790-822): the last feature map and the per-level outputs
@@ -408,22 +388,21 @@ class UNet(torch.nn.Module):
         code closes BrUNet.forward, :1209-1253)."""
         curr, deep_outputs = self._run_decoder(encoding_out, bottleneck, X_skip_layer,
                                                X_feature_conditioning)
-        final_features = curr
-        curr = self._final(self.final_layer, curr, return_logits)
+        head = self._final(self.final_layer, curr, return_logits)
+        return self._outputs(head, curr, bottleneck, deep_outputs, return_features)
+
+    def _outputs(self, head, final_features, bottleneck, deep_outputs, return_features):
+        """What ``forward`` returns once the head has run (unet.py:824-843): (head, features,
+        bottleneck) on request, else (head, bottleneck class logits or None[, auxiliary heads])."""
         if return_features is True:
-            return curr, final_features, bottleneck
-
-        if self.bottleneck_classification is True:
-            pooled = HF.channel_max(bottleneck)
-            bn_out = self.bottleneck_classifier(pooled)
-        else:
-            bn_out = None
-
+            return head, final_features, bottleneck
+        bn_out = None
+        if self.bottleneck_classification is True:   # global max over space, then the GEMM
+            bn_out = self.bottleneck_classifier(HF.channel_max(bottleneck))
         if self.deep_supervision is True:
-            for i in range(len(deep_outputs)):
-                deep_outputs[i] = self._final(self.deep_supervision_ops[i], deep_outputs[i], False)
-            return curr, bn_out, deep_outputs
-        return curr, bn_out
+            aux = [self._final(op, o, False) for op, o in zip(self.deep_supervision_ops, deep_outputs)]
+            return head, bn_out, aux
+        return head, bn_out
 
 
 class BrUNet(UNet):

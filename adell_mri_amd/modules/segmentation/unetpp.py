@@ -13,42 +13,26 @@ from ... import functional as HF
 from ..._lib import AdellHipError
 from ..layers.standard_blocks import DenseBlock
 from ..layers.utils import crop_to_size
-from .unet import UNet
+from .unet import UNet, _cat_channels, _nearest
 
 
 class UNetPlusPlus(UNet):
-    def __init__(
-        self,
-        spatial_dimensions: int = 2,
-        encoding_operations: List[torch.nn.ModuleList] = None,
-        conv_type: str = "regular",
-        link_type: str = "identity",
-        upscale_type: str = "upsample",
-        interpolation: str = "bilinear",
-        norm_type: str = "batch",
-        dropout_type: str = "dropout",
-        padding: int = 0,
-        dropout_param: float = 0.1,
-        activation_fn: torch.nn.Module = torch.nn.PReLU,
-        in_channels: int = 1,
-        n_classes: int = 2,
-        depth: list = [16, 32, 64],
-        kernel_sizes: list = [3, 3, 3],
-        strides: list = [2, 2, 2],
-        bottleneck_classification: bool = False,
-        skip_conditioning: int = None,
-        feature_conditioning: int = None,
-        feature_conditioning_params: Dict[str, torch.Tensor] = None,
-    ) -> torch.nn.Module:
-        super().__init__(
-            spatial_dimensions=spatial_dimensions, encoding_operations=encoding_operations,
-            conv_type=conv_type, upscale_type=upscale_type, interpolation=interpolation,
-            norm_type=norm_type, dropout_type=dropout_type, padding=padding,
-            dropout_param=dropout_param, activation_fn=activation_fn, in_channels=in_channels,
-            n_classes=n_classes, depth=depth, kernel_sizes=kernel_sizes, strides=strides,
-            bottleneck_classification=bottleneck_classification,
-            skip_conditioning=skip_conditioning, feature_conditioning=feature_conditioning,
-            feature_conditioning_params=feature_conditioning_params)
+    # signature: adell_mri/modules/segmentation/unetpp.py:26-48 (the U-Net's, without deep
+    # supervision / encoder_only; ``link_type`` is accepted and ignored: the links are dense)
+    def __init__(self, spatial_dimensions: int = 2,
+                 encoding_operations: List[torch.nn.ModuleList] = None,
+                 conv_type: str = "regular", link_type: str = "identity",
+                 upscale_type: str = "upsample", interpolation: str = "bilinear",
+                 norm_type: str = "batch", dropout_type: str = "dropout", padding: int = 0,
+                 dropout_param: float = 0.1, activation_fn: torch.nn.Module = torch.nn.PReLU,
+                 in_channels: int = 1, n_classes: int = 2, depth: list = [16, 32, 64],
+                 kernel_sizes: list = [3, 3, 3], strides: list = [2, 2, 2],
+                 bottleneck_classification: bool = False, skip_conditioning: int = None,
+                 feature_conditioning: int = None,
+                 feature_conditioning_params: Dict[str, torch.Tensor] = None) -> torch.nn.Module:
+        passed = {k: v for k, v in locals().items()
+                  if k not in ("self", "link_type") and not k.startswith("__")}
+        super().__init__(**passed)
         # The reference builds every layer a second time here (unetpp.py:128-145). Because
         # ``encoding_operations`` is no longer None on that second pass it takes the
         # backbone branch, which swaps every strided downsampling conv block for
@@ -106,27 +90,24 @@ class UNetPlusPlus(UNet):
         if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
             X_skip_layer = X_skip_layer.unsqueeze(1)
 
-        encoding_out = []
-        curr = X
-        for op, op_ds in self.encoding_operations:
-            curr = op(curr)
+        encoding_out, curr = [], X
+        for level, downsample in self.encoding_operations:
+            curr = level(curr)
             encoding_out.append(curr)
-            curr = op_ds(curr)
+            curr = downsample(curr)
         bottleneck = curr
-        link_outputs = []
-        for i in range(len(self.decoding_operations)):
-            op = self.decoding_operations[i]
-            lo = link_outputs[-1][:-1] if len(link_outputs) > 0 else None
+        # dense links: level i's DenseBlock takes the skip tensor and all but the last output
+        # of the previous (coarser) level's block, upsampled inside the block
+        dense = None
+        for i, op in enumerate(self.decoding_operations):
             link_in = encoding_out[-i - 2]
             if X_skip_layer is not None:
-                xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
-                link_in = HF.cat_channels([link_in, xfl])
-            encoded = self.link_ops[i](link_in, lo)
-            link_outputs.append(encoded)
-            encoded = encoded[-1]
+                link_in = _cat_channels(link_in, _nearest(X_skip_layer, link_in.shape[2:]))
+            dense = self.link_ops[i](link_in, None if dense is None else dense[:-1])
+            encoded = dense[-1]
             curr = self.upscale_ops[i](curr)
             sh, sh2 = list(curr.shape)[2:], list(encoded.shape)[2:]
-            if np.prod(sh) < np.prod(sh2):
+            if np.prod(sh) < np.prod(sh2):      # the pooling encoder leaves odd sizes behind
                 encoded = crop_to_size(encoded, sh)
             if np.prod(sh) > np.prod(sh2):
                 curr = crop_to_size(curr, sh2)
@@ -138,18 +119,14 @@ class UNetPlusPlus(UNet):
             curr = self._act(curr)
         if return_features is True:
             return curr, final_features, bottleneck
-
-        if return_aux is True:
+        curr_aux = None
+        if return_aux is True:   # one auxiliary head per intermediate output of the last block
             curr_aux = []
-            for op, x in zip(self.final_layer_aux, link_outputs[-1][1:-1]):
+            for head, x in zip(self.final_layer_aux, dense[1:-1]):
                 if X_skip_layer is not None:
-                    x = HF.cat_channels([x, X_skip_layer])
-                curr_aux.append(self._act(op(x)))
-        else:
-            curr_aux = None
+                    x = _cat_channels(x, X_skip_layer)
+                curr_aux.append(self._act(head(x)))
+        bn_out = None
         if self.bottleneck_classification is True:
-            pooled = HF.channel_max(bottleneck)
-            bn_out = self.bottleneck_classifier(pooled)
-        else:
-            bn_out = None
+            bn_out = self.bottleneck_classifier(HF.channel_max(bottleneck))
         return curr, bn_out, curr_aux

@@ -20,80 +20,29 @@ from ..layers.adn_fn import get_adn_fn
 from ..layers.conv import ConvTranspose2d, ConvTranspose3d
 from ... import functional as HF
 from ..layers.vit import LinearEmbedding, SWINTransformerBlockStack, ViT
-from .unet import UNet
+from .unet import UNet, _keep_arguments
 
 
 class UNETR(UNet, torch.nn.Module):
-    def __init__(
-        self,
-        # linear embedding and transformer
-        image_size,
-        patch_size,
-        number_of_blocks: int,
-        return_at: List[int],
-        attention_dim: int = None,
-        hidden_dim: int = None,
-        embedding_size: int = None,
-        n_heads: int = 4,
-        dropout_rate: float = 0.0,
-        embed_method: str = "linear",
-        mlp_structure: List[int] = [256, 256],
-        adn_fn_mlp: Callable = get_adn_fn(1, "identity", "gelu"),
-        # regular u-net parametrization
-        spatial_dimensions: int = 2,
-        conv_type: str = "regular",
-        link_type: str = "identity",
-        upscale_type: str = "upsample",
-        interpolation: str = "bilinear",
-        norm_type: str = "batch",
-        dropout_type: str = "dropout",
-        padding: int = 0,
-        dropout_param: float = 0.0,
-        activation_fn: torch.nn.Module = torch.nn.PReLU,
-        in_channels: int = 1,
-        n_classes: int = 2,
-        depth: list = [16, 32, 64],
-        kernel_sizes: list = [3, 3, 3],
-        bottleneck_classification: bool = False,
-        skip_conditioning: int = None,
-        feature_conditioning: int = None,
-        feature_conditioning_params: Dict[str, torch.Tensor] = None,
-        deep_supervision: bool = False,
-        encoder_only: bool = False,
-    ):
+    # signature: adell_mri/modules/segmentation/unetr.py:30-66 (ViT arguments, then the U-Net's)
+    def __init__(self, image_size, patch_size, number_of_blocks: int, return_at: List[int],
+                 attention_dim: int = None, hidden_dim: int = None, embedding_size: int = None,
+                 n_heads: int = 4, dropout_rate: float = 0.0, embed_method: str = "linear",
+                 mlp_structure: List[int] = [256, 256],
+                 adn_fn_mlp: Callable = get_adn_fn(1, "identity", "gelu"),
+                 spatial_dimensions: int = 2, conv_type: str = "regular",
+                 link_type: str = "identity", upscale_type: str = "upsample",
+                 interpolation: str = "bilinear", norm_type: str = "batch",
+                 dropout_type: str = "dropout", padding: int = 0, dropout_param: float = 0.0,
+                 activation_fn: torch.nn.Module = torch.nn.PReLU, in_channels: int = 1,
+                 n_classes: int = 2, depth: list = [16, 32, 64], kernel_sizes: list = [3, 3, 3],
+                 bottleneck_classification: bool = False, skip_conditioning: int = None,
+                 feature_conditioning: int = None,
+                 feature_conditioning_params: Dict[str, torch.Tensor] = None,
+                 deep_supervision: bool = False, encoder_only: bool = False):
+        arguments = dict(locals())
         super().__init__(parent_class=True)
-        self.image_size = image_size
-        self.patch_size = patch_size
-        self.number_of_blocks = number_of_blocks
-        self.attention_dim = attention_dim
-        self.hidden_dim = hidden_dim
-        self.embedding_size = embedding_size
-        self.return_at = return_at
-        self.n_heads = n_heads
-        self.dropout_rate = dropout_rate
-        self.embed_method = embed_method
-        self.mlp_structure = mlp_structure
-        self.adn_fn_mlp = adn_fn_mlp
-        self.spatial_dimensions = spatial_dimensions
-        self.conv_type = conv_type
-        self.link_type = link_type
-        self.upscale_type = upscale_type
-        self.interpolation = interpolation
-        self.norm_type = norm_type
-        self.dropout_type = dropout_type
-        self.padding = padding
-        self.dropout_param = dropout_param
-        self.activation_fn = activation_fn
-        self.in_channels = in_channels
-        self.n_classes = n_classes
-        self.depth = depth
-        self.kernel_sizes = kernel_sizes
-        self.bottleneck_classification = bottleneck_classification
-        self.skip_conditioning = skip_conditioning
-        self.feature_conditioning = feature_conditioning
-        self.feature_conditioning_params = feature_conditioning_params
-        self.deep_supervision = deep_supervision
-        self.encoder_only = encoder_only
+        _keep_arguments(self, arguments)
 
         self.strides = [2 for _ in self.depth]
         self.scale = int(2 ** len(self.return_at))
@@ -202,35 +151,8 @@ class UNETR(UNet, torch.nn.Module):
         elif self.encoder_only is True:
             return bottleneck
 
-        deep_outputs = []
-        for i in range(len(self.decoding_operations)):
-            op = self.decoding_operations[i]
-            link_in = encoding_out[-i - 2]
-            if X_skip_layer is not None:
-                xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
-                link_in = HF.cat_channels([link_in, xfl])
-            encoded = self.link_ops[i](link_in)
-            if X_feature_conditioning is not None:   # channel gates on the skip tensor
-                gates = self.feature_conditioning_ops[i](X_feature_conditioning)
-                encoded = HF.scale_per_item_channel(encoded, gates)
-            curr = self.upscale_ops[i](curr)
-            curr = op(curr, X_cat=encoded)
-            deep_outputs.append(curr)
-
-        final_features = curr
-        curr = self._final(self.final_layer, curr, return_logits)
-        if return_features is True:
-            return curr, final_features, bottleneck
-        if self.bottleneck_classification is True:
-            pooled = HF.channel_max(bottleneck)
-            bn_out = self.bottleneck_classifier(pooled)
-        else:
-            bn_out = None
-        if self.deep_supervision is True:
-            for i in range(len(deep_outputs)):
-                deep_outputs[i] = self._final(self.deep_supervision_ops[i], deep_outputs[i], False)
-            return curr, bn_out, deep_outputs
-        return curr, bn_out
+        return self._decode(encoding_out, bottleneck, X_skip_layer, X_feature_conditioning,
+                            return_features, return_logits)   # the U-Net's decoder and head
 
 
 class SWINUNet(UNet, torch.nn.Module):
@@ -243,70 +165,24 @@ class SWINUNet(UNet, torch.nn.Module):
     LayerNorm + conv reconstruction; standard U-Net decoder; the head reads the virtual
     concatenation [first_encoder(X), decoder output]."""
 
-    def __init__(
-        self,
-        image_size,
-        patch_size,
-        window_size,
-        shift_sizes,
-        embedding_size: int = None,
-        n_heads: int = 4,
-        dropout_rate: float = 0.0,
-        embed_method: str = "linear",
-        mlp_structure: List[int] = [256, 256],
-        adn_fn_mlp: Callable = get_adn_fn(1, "identity", "gelu"),
-        spatial_dimensions: int = 2,
-        conv_type: str = "regular",
-        link_type: str = "identity",
-        upscale_type: str = "upsample",
-        interpolation: str = "bilinear",
-        norm_type: str = "batch",
-        dropout_type: str = "dropout",
-        padding: int = 0,
-        dropout_param: float = 0.0,
-        activation_fn: torch.nn.Module = torch.nn.PReLU,
-        in_channels: int = 1,
-        n_classes: int = 2,
-        depth: list = [16, 32, 64],
-        kernel_sizes: list = [3, 3, 3],
-        strides: list = None,
-        bottleneck_classification: bool = False,
-        skip_conditioning: int = None,
-        feature_conditioning: int = None,
-        feature_conditioning_params: Dict[str, torch.Tensor] = None,
-        deep_supervision: bool = False,
-    ):
+    # signature: adell_mri/modules/segmentation/unetr.py:644-678
+    def __init__(self, image_size, patch_size, window_size, shift_sizes,
+                 embedding_size: int = None, n_heads: int = 4, dropout_rate: float = 0.0,
+                 embed_method: str = "linear", mlp_structure: List[int] = [256, 256],
+                 adn_fn_mlp: Callable = get_adn_fn(1, "identity", "gelu"),
+                 spatial_dimensions: int = 2, conv_type: str = "regular",
+                 link_type: str = "identity", upscale_type: str = "upsample",
+                 interpolation: str = "bilinear", norm_type: str = "batch",
+                 dropout_type: str = "dropout", padding: int = 0, dropout_param: float = 0.0,
+                 activation_fn: torch.nn.Module = torch.nn.PReLU, in_channels: int = 1,
+                 n_classes: int = 2, depth: list = [16, 32, 64], kernel_sizes: list = [3, 3, 3],
+                 strides: list = None, bottleneck_classification: bool = False,
+                 skip_conditioning: int = None, feature_conditioning: int = None,
+                 feature_conditioning_params: Dict[str, torch.Tensor] = None,
+                 deep_supervision: bool = False):
+        arguments = dict(locals())
         super().__init__(parent_class=True)
-        self.image_size = image_size
-        self.patch_size = patch_size
-        self.window_size = window_size
-        self.shift_sizes = shift_sizes
-        self.embedding_size = embedding_size
-        self.n_heads = n_heads
-        self.dropout_rate = dropout_rate
-        self.embed_method = embed_method
-        self.mlp_structure = mlp_structure
-        self.adn_fn_mlp = adn_fn_mlp
-        self.spatial_dimensions = spatial_dimensions
-        self.conv_type = conv_type
-        self.link_type = link_type
-        self.upscale_type = upscale_type
-        self.interpolation = interpolation
-        self.norm_type = norm_type
-        self.dropout_type = dropout_type
-        self.padding = padding
-        self.dropout_param = dropout_param
-        self.activation_fn = activation_fn
-        self.in_channels = in_channels
-        self.n_classes = n_classes
-        self.depth = depth
-        self.kernel_sizes = kernel_sizes
-        self.strides = strides
-        self.bottleneck_classification = bottleneck_classification
-        self.skip_conditioning = skip_conditioning
-        self.feature_conditioning = feature_conditioning
-        self.feature_conditioning_params = feature_conditioning_params
-        self.deep_supervision = deep_supervision
+        _keep_arguments(self, arguments)
         self.encoder_only = False
         self.number_of_blocks = len(self.depth)
         if self.spatial_dimensions != 3:
@@ -422,40 +298,14 @@ class SWINUNet(UNet, torch.nn.Module):
         elif self.encoder_only is True:
             return bottleneck
 
-        deep_outputs = []
-        for i in range(len(self.decoding_operations)):
-            op = self.decoding_operations[i]
-            link_in = encoding_out[-i - 2]
-            if X_skip_layer is not None:
-                xfl = HF.interpolate_nearest(X_skip_layer, link_in.shape[2:])
-                link_in = HF.cat_channels([link_in, xfl])
-            encoded = self.link_ops[i](link_in)
-            if X_feature_conditioning is not None:   # channel gates on the skip tensor
-                gates = self.feature_conditioning_ops[i](X_feature_conditioning)
-                encoded = HF.scale_per_item_channel(encoded, gates)
-            curr = self.upscale_ops[i](curr)
-            curr = op(curr, X_cat=encoded)
-            deep_outputs.append(curr)
-
-        final_features = curr
+        curr, deep_outputs = self._run_decoder(encoding_out, curr, X_skip_layer,
+                                               X_feature_conditioning)
         # final_layer(cat[X_encoded_first, curr]) without materialising the concat
         mods = list(self.final_layer)
-        out = mods[0](X_encoded_first, X_cat=curr)
+        head = mods[0](X_encoded_first, X_cat=curr)
         for mod in mods[1:-1]:
-            out = mod(out)
+            head = mod(head)
         if return_logits is not True:
-            out = (HF.norm_drop_act(out, act="sigmoid") if isinstance(mods[-1], torch.nn.Sigmoid)
-                   else mods[-1](out))
-        curr = out
-        if return_features is True:
-            return curr, final_features, bottleneck
-        if self.bottleneck_classification is True:
-            pooled = HF.channel_max(bottleneck)
-            bn_out = self.bottleneck_classifier(pooled)
-        else:
-            bn_out = None
-        if self.deep_supervision is True:
-            for i in range(len(deep_outputs)):
-                deep_outputs[i] = self._final(self.deep_supervision_ops[i], deep_outputs[i], False)
-            return curr, bn_out, deep_outputs
-        return curr, bn_out
+            head = (HF.norm_drop_act(head, act="sigmoid")
+                    if isinstance(mods[-1], torch.nn.Sigmoid) else mods[-1](head))
+        return self._outputs(head, curr, bottleneck, deep_outputs, return_features)

@@ -26,17 +26,10 @@ class UNetSemiSL(UNet):
                          apply_linear_transformation: bool = False) -> torch.Tensor:
         """Last decoder feature map [B, depth[0], *spatial], optionally through
         ``linear_transformation`` (semi_supervised_segmentation/unet.py:193-223)."""
-        if X_skip_layer is not None and len(X_skip_layer.shape) < len(X.shape):
-            X_skip_layer = X_skip_layer.unsqueeze(1)
-        if X_feature_conditioning is not None:
-            X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
-        encoding_out = []
-        curr = X
-        for op, op_ds in self.encoding_operations:
-            curr = op(curr)
-            encoding_out.append(curr)
-            curr = op_ds(curr)
-        curr, _ = self._run_decoder(encoding_out, curr, X_skip_layer, X_feature_conditioning)
+        encoding_out, bottleneck, X_skip_layer, X_feature_conditioning = self._encode(
+            X, X_skip_layer, X_feature_conditioning)
+        features, _ = self._run_decoder(encoding_out, bottleneck, X_skip_layer,
+                                        X_feature_conditioning)
         if apply_linear_transformation is True:
-            curr = self.linear_transformation(curr)
-        return curr
+            features = self.linear_transformation(features)
+        return features

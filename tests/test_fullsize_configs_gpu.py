@@ -80,7 +80,7 @@ def test_config5_swin_unet_full_size(cuda):
     batch = _batch(1, 2, (256, 256, 128), cuda)
     before = {k: p.detach().clone() for k, p in net.named_parameters()}
     loss = StepRunner(net).train_step(batch)
-    assert torch.isfinite(loss) and 0.0 < float(loss) < 5.0
+    assert torch.isfinite(loss) and 0.0 < float(loss.detach()) < 5.0
     moved = sum(not torch.equal(before[k], p.detach()) for k, p in net.named_parameters()
                 if p.grad is not None)
     assert moved > 200
