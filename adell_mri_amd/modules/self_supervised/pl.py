@@ -137,6 +137,26 @@ class _TwoViewSSL:
                 return op(*args)
         return op(*args)
 
+    def _views_share_a_pass(self, ret_1, ret_2):
+        """Both views can go through the network as ONE batch of 2B items: same network for both
+        (no EMA target, no stop-gradient), heads that nest (projection inside prediction), and no
+        layer that couples the items of a batch in training (batch norm). Per item the arithmetic
+        is the one of two separate passes; the launches -- this step is bound by the host -- and
+        the gradient accumulations of the second pass are halved."""
+        if self.ema is not None or self.stop_gradient is True or not self._has_heads:
+            return False
+        if (ret_1, ret_2) not in (("prediction", "projection"), ("projection", "projection")):
+            return False
+        if getattr(self, "_batch_coupled", None) is None:
+            self._batch_coupled = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+                                      for m in self.modules())
+        return not self._batch_coupled
+
+    def _both_views(self, x1, x2, ret_1):
+        z = self.forward(torch.cat([x1, x2], 0), ret="projection")
+        z1, z2 = z[:x1.shape[0]], z[x1.shape[0]:]
+        return (self.prediction_head(z1) if ret_1 == "prediction" else z1), z2
+
     def _heads_for_method(self, batch):
         """(head of view 1, head of view 2, extra loss arguments), pl.py:457-470."""
         if self.ssl_method == "simclr":
@@ -152,8 +172,11 @@ class _TwoViewSSL:
         if self.channels_to_batch is True:
             x1 = x1.reshape(-1, 1, *x1.shape[2:])
             x2 = x2.reshape(-1, 1, *x2.shape[2:])
-        y1 = self._view(x1, ret_1)
-        y2 = self.forward_ema_stop_grad(x2, ret=ret_2)
+        if x1.shape == x2.shape and self._views_share_a_pass(ret_1, ret_2):
+            y1, y2 = self._both_views(x1, x2, ret_1)
+        else:
+            y1 = self._view(x1, ret_1)
+            y2 = self.forward_ema_stop_grad(x2, ret=ret_2)
         losses = self.calculate_loss(y1, y2, *other_args)
         self.update_metrics(y1, y2, metrics)
         symmetric_already = self.ssl_method in ("vicreg", "vicregl", "simclr")

@@ -226,6 +226,35 @@ def test_vicreg_training_step_matches_reference(cuda):
 
 
 @pytest.mark.gpu
+def test_vicreg_one_pass_over_both_views_equals_two_passes(cuda):
+    """Without batch-coupled layers the two views share one pass of 2B items: the same loss
+    terms and gradients as the two separate passes (which the EMA / stop-gradient / batch-norm
+    configurations keep)."""
+    g = gold()
+    batch = {"a": torch.from_numpy(g["x1"]).to(cuda), "b": torch.from_numpy(g["x2"]).to(cuda)}
+    out = {}
+    for mode in ("one", "two"):
+        net = build_pl().to(cuda).train()
+        assert net._views_share_a_pass("prediction", "projection") is True
+        if mode == "two":
+            net._batch_coupled = True      # what a BatchNorm layer anywhere in the module sets
+            assert net._views_share_a_pass("prediction", "projection") is False
+        loss = net.training_step(batch, 0)
+        loss.backward()
+        out[mode] = (torch.stack(list(net.last_losses)).detach(),
+                     {k: p.grad.detach().clone() for k, p in net.named_parameters()})
+    np.testing.assert_allclose(out["one"][0].cpu().numpy(), out["two"][0].cpu().numpy(), rtol=1e-5)
+    gmax = max(float(v.abs().max()) for v in out["two"][1].values())
+    for k, v in out["two"][1].items():
+        assert float((out["one"][1][k] - v).abs().max()) <= 1e-4 * max(float(v.abs().max()),
+                                                                        1e-3 * gmax), k
+    # a target branch of its own (EMA or stop-gradient) keeps the two passes
+    net = build_pl().to(cuda)
+    net.stop_gradient = True
+    assert net._views_share_a_pass("prediction", "projection") is False
+
+
+@pytest.mark.gpu
 def test_ema_forward_and_stop_gradient_step_runs(cuda):
     """BYOL-style wiring: second view through the EMA shadow under no_grad; the loss
     decreases over a few steps and the shadow trails the online weights."""
