@@ -57,6 +57,7 @@ static ConvTile adell_pick_tile(int N, int Do, int Ho, int Wo, int Cout,
     case 0: t.BM = 256; t.BN = 64; break;
     case 1: t.BM = 256; t.BN = 32; break;
     case 2: t.BM = 64; t.BN = 64; break;
+    case 6: t.BM = 64; t.BN = 32; break;   // two-wave blocks (adell_plan_f16: strided layers)
     default: t.BM = 128; t.BN = 32; break;
   }
   adell_shape_brick(t.BM, Wo, Ho, Do, &t.lTX, &t.lTY, &t.lTZ);
@@ -399,7 +400,16 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   // 32: 0.47 -> 0.31 ms against the 256-voxel brick at one block per CU)
   if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.KD == a.SD && a.KH == a.SH && a.KW == a.SW &&
       a.KD * a.KH * a.KW > 1 && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1)
-    t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 2);
+    t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout,
+                        a.Cout <= 32 && !g_adell_tune.igemm_no2wave ? 6 : 2);
+  // strided k > stride layers with <= 32 output channels (the 3^3 stride-2 downsampling convs):
+  // the halo of a 128-voxel brick is 17 x 9 x 9 voxels = 88 KB, one block per CU, and nothing
+  // overlaps its staging (measured 2 x 128^3 -> 64^3, 32 -> 32: 0.73 ms at 40 TF). 64-voxel bricks
+  // on two-wave blocks (46 KB halo) keep two to three blocks per CU in different phases.
+  else if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.Cout <= 32 &&
+           (a.SD > 1 || a.SH > 1 || a.SW > 1) && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 &&
+           !g_adell_tune.igemm_no2wave)
+    t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 6);
   size_t lds = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     a.lTX = t.lTX; a.lTY = t.lTY; a.lTZ = t.lTZ;
@@ -417,7 +427,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     const size_t red = (size_t)8 * t.BN * 2 * sizeof(float);
     if (lds < red) lds = red;
     if (lds <= 160 * 1024) break;
-    const int next = t.BN == 64 ? 2 : 3;
+    const int next = t.BN == 64 ? 2 : (t.cfg == 3 && !g_adell_tune.igemm_no2wave ? 6 : 3);
     if (t.cfg == next || g_conv_force_cfg >= 0) break;
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, next);
   }
@@ -625,6 +635,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                   : adell_launch_conv_f16<2, 1, 4, 1, 0>(a, e, grid, lds, st);
       break;
     case 2: rc2 = adell_launch_conv_f16<1, 1, 2, 2, 0>(a, e, grid, lds, st); break;
+    case 6: rc2 = adell_launch_conv_f16<1, 1, 2, 1, 0>(a, e, grid, lds, st); break;
     default: rc2 = adell_launch_conv_f16<1, 1, 4, 1, 0>(a, e, grid, lds, st); break;
   }
   if (rc2 != ADELL_OK || shares == 1) return rc2;
@@ -692,7 +703,7 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
   int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
@@ -724,7 +735,7 @@ extern "C" int adell_conv3d_fwd_f16x3_ws(const adell_conv3d_desc* d, const float
   int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -737,7 +748,7 @@ extern "C" int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const 
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -783,7 +794,8 @@ extern "C" int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const 
     a.Do = d->D / 2; a.Ho = d->H / 2; a.Wo = d->W / 2;
     a.ysplit = a.Cout; a.Cs = a.Cout;
     a.shuffle = 8 | 7;                           // rows on the stride-2 lattice, sub-position 0
-    ConvF16Extra e = {(const _Float16*)w_split[c], wscale[c], c == 0 ? dy_absmax : nullptr, 0};
+    ConvF16Extra e = {(const _Float16*)w_split[c], wscale[c], c == 0 ? dy_absmax : nullptr,
+                      nullptr, nullptr, nullptr, 0};
     rc = adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
     if (rc != ADELL_OK) return rc;
   }
@@ -812,7 +824,7 @@ extern "C" int adell_convtranspose3d_fwd_f16x3(int N, int D, int H, int W, int C
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.Cs = Cout;
   a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, 0};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr, 0};
   return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
 }
 
@@ -832,7 +844,7 @@ extern "C" int adell_convtranspose3d_bwd_data_f16x3(int N, int D, int H, int W, 
   a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
   return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
 }
 
@@ -844,7 +856,7 @@ extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const flo
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
@@ -858,3 +870,77 @@ extern "C" int adell_debug_ws_prof(unsigned long long* out) {
   return ADELL_OK;
 }
 #endif
+
+#ifdef ADELL_EXPERIMENTS
+// ---------------------------------------------------------------------------
+// EXPERIMENT (tools/presplit_exp.py): activations stored pre-split.
+// adell_presplit rewrites an NDHWC fp32 tensor as the 64-byte rows the f16x3 kernels stage into
+// LDS (same bytes per element), scaled per (item, 16-channel chunk) by 2^xk; the forward below
+// takes such tensors, so that its halo staging is a copy. Not part of include/adell_hip.h and
+// not in the shipped library: `make -C adell_mri_amd/csrc EXPERIMENTS=1`. Measured (round 2,
+// 2 x 128^3): 32 -> 32 +10 %, 64 -> 64 +3 %, 32+32 -> 32 +11 % -- less than the extra 4 B / element
+// the norm / activation kernels would have to write, so the format change was not made.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_presplit_kernel(const float* __restrict__ x,
+                                                             const int* __restrict__ xk,
+                                                             char* __restrict__ xs, long V, int C,
+                                                             long total) {
+  const int nch = C >> 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int ch = (int)(i % nch);
+    const long v = i / nch;                    // voxel over the whole batch
+    const int n = (int)(v / V);
+    const float scale = __int_as_float((xk[n * nch + ch] + 127) << 23);
+    const float4* p = reinterpret_cast<const float4*>(x + v * C + ch * 16);
+    float f[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t = p[q];
+      f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
+    }
+    half8 h0, l0, h1, l1;
+    adell_split8(f, scale, &h0, &l0);
+    adell_split8(f + 8, scale, &h1, &l1);
+    half8* o = reinterpret_cast<half8*>(xs + i * 64);
+    o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
+  }
+}
+
+extern "C" int adell_presplit(const float* x, int N, long V, int C, const int* xk, void* xs,
+                              void* stream) {
+  ADELL_REQUIRE(x && xk && xs && N > 0 && V > 0 && C >= 16 && C % 16 == 0, "presplit: bad arguments");
+  const long total = (long)N * V * (C >> 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(adell_presplit_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, x, xk, (char*)xs, V, C, total);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_conv3d_fwd_f16x3_presplit(const adell_conv3d_desc* d, const void* xs0,
+                                               const void* xs1, const int* xk,
+                                               const void* w_split, const float* wscale,
+                                               const float* bias, const float* residual, float* y,
+                                               float* stat_partials, void* stream) {
+  ConvArgs a;
+  // the fp32 pointers are never dereferenced on this path; they carry alignment checks only
+  int rc = adell_fill_fwd(a, d, (const float*)xs0, (const float*)xs1, bias, residual, y,
+                          stat_partials);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split && wscale && xs0 && xk, "conv_fwd_f16x3_presplit: null pointer");
+  ADELL_REQUIRE(d->KD == 3 && d->KH == 3 && d->KW == 3 && d->SD == 1 && d->SH == 1 && d->SW == 1 &&
+                    d->C0 % 16 == 0 && d->C1 % 16 == 0,
+                "conv_fwd_f16x3_presplit: 3x3x3 stride-1 layers with 16-channel-aligned sources");
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, nullptr, (const char*)xs0,
+                    (const char*)xs1, xk, 0};
+  ConvTile t;
+  size_t lds;
+  ConvArgs probe = a;
+  rc = adell_plan_f16(probe, d->N, &t, &lds);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(t.cfg == 4 || t.cfg == 0,
+                "conv_fwd_f16x3_presplit: this shape does not take a specialised instance");
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
+}
+#endif  // ADELL_EXPERIMENTS

@@ -41,6 +41,13 @@ struct ConvF16Extra {
   const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
   const float* wscale;   // [Cout] 2^-kw[n]: undoes the per-output-channel weight scale
   unsigned* amax_out;    // optional: receives the absmax (float bits) of the input tensor(s)
+  // pre-split activations (optional): the input tensor(s) already hold, per voxel and 16-channel
+  // chunk, the 64-byte row [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] of the LDS image, scaled by
+  // 2^xk[item * nchunk + chunk] (same bytes per element as fp32). Staging is then a copy: no
+  // block-wide absmax, no conversion VALU work.
+  const char* xs0;
+  const char* xs1;
+  const int* xk;
   int dbg;               // timing experiments (-DADELL_DEBUG builds only: ADELL_IGEMM_DBG,
                          // tools/igemm_dbg.py): results are wrong when nonzero. 1: halo staged for chunk 0 only; 2: weights staged
                          // for the first tap group only; 8: no MFMAs; 16: no output stores
@@ -288,7 +295,39 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     const int c0 = ch * CC;
     float mx = 0.f;
     const bool skipA = (ADELL_DBG(e.dbg) & 1) && ch > 0;
+#ifdef ADELL_EXPERIMENTS
+    const bool presplit = SPEC && e.xs0 != nullptr;
+#else
+    constexpr bool presplit = false;   // tools/presplit_exp.py: `make EXPERIMENTS=1` builds
+#endif
     if (skipA) {
+    } else if (presplit) {
+      if constexpr (SPEC) {
+        const bool first = c0 < a.C0;
+        const unsigned nch = (first ? a.C0 : a.C1) >> 4;       // chunks per voxel of this source
+        const char* src = adell_uniform_ptr(
+            (first ? e.xs0 + ((size_t)vox0 * (a.C0 >> 4) + (c0 >> 4)) * 64
+                   : e.xs1 + ((size_t)vox0 * (a.C1 >> 4) + ((c0 - a.C0) >> 4)) * 64));
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+          if (tid + NTHR * u < HV) {
+            float4 f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gvk[u] >= 0) {
+              const float4* p =
+                  reinterpret_cast<const float4*>(src + (size_t)((unsigned)gvk[u] * nch) * 64u);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) f[q] = p[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              keep[u][4 * q + 0] = f[q].x; keep[u][4 * q + 1] = f[q].y;
+              keep[u][4 * q + 2] = f[q].z; keep[u][4 * q + 3] = f[q].w;
+            }
+          }
+        }
+      }
     } else if (resident) {
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
@@ -306,6 +345,11 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
         for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(v[j]));
       }
     }
+    int kA = 0;
+    if (presplit) {
+      __syncthreads();  // previous chunk's MFMAs are done: LDS may be overwritten
+      kA = e.xk[nb * nchunk + ch];
+    } else {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     __syncthreads();  // previous chunk's MFMAs are done: LDS may be overwritten
@@ -317,13 +361,13 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     // by-product for the backward-weight kernel: tensor-wide absmax of the input
     if (e.amax_out != nullptr && tid == 0 && blockIdx.y == 0)
       atomicMax(e.amax_out, __float_as_uint(mx));
-    int kA = 0;
     {
       const int ebits = (__float_as_int(mx) >> 23) & 0xff;
       // max lands in [2^6, 2^14): multiples of 8 so the scale rarely changes per chunk
       if (ebits > 0 && ebits < 255) kA = 8 * ((13 - (ebits - 127)) >> 3);
       if (kA > 96) kA = 96;
       if (kA < -96) kA = -96;
+    }
     }
     const float scaleA = __int_as_float((kA + 127) << 23);
     if (ch > c_beg && kA != kA_prev) {
@@ -352,6 +396,20 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       *reinterpret_cast<half8*>(row + ((3 ^ sw) << 4)) = l1;
     };
     if (skipA) {
+    } else if (presplit) {
+#pragma unroll
+      for (int u = 0; u < KEEP; ++u) {
+        const int hv = tid + NTHR * u;
+        if (hv < HV) {
+          const int sw = ((hv / 10) % 10) & 3;
+          char* row = sA + (size_t)hv * 64;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(row + ((q ^ sw) << 4)) =
+                make_float4(keep[u][4 * q + 0], keep[u][4 * q + 1], keep[u][4 * q + 2],
+                            keep[u][4 * q + 3]);
+        }
+      }
     } else if (resident) {
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
