@@ -120,6 +120,9 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_pair_loss_scratch_floats": (_l, [_i, _i]),
+    "adell_pair_loss_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "adell_pair_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "adell_loco_loss_workspace": (_l, [_i, _l, _i]),
     "adell_loco_loss_fwd": (_i, [_vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_loco_loss_bwd": (_i, [_vp, _vp, _vp, _i, _l, _i, _f, _f, _vp, _vp, _vp]),

@@ -948,3 +948,176 @@ extern "C" int adell_loco_loss_bwd(const float* f1, const float* f2, const float
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Cosine-similarity losses between two [B][D] embedding batches (the non-VICReg methods of
+// SelfSLBasePL.init_loss, adell_mri/modules/self_supervised/pl.py:202-212):
+//   kind 0  simsiam_loss  = -mean_i cos(x1_i, x2_i)              (losses/functional.py:138-150)
+//   kind 1  byol_loss     = 2 * simsiam_loss + 2                 (losses/functional.py:153-164)
+//   kind 2  NTXentLoss    (SimCLR, losses/ntxent.py:11-46): Z = [relu(x1); relu(x2)] (2B rows),
+//           S = cos(Z_i, Z_j) / T, loss = mean_i ( -S[i][(i + B) % 2B] + logsumexp_{j != i} S[i][j] )
+// cosine = dot / (max(|a|, 1e-8) max(|b|, 1e-8)) as torch.nn.functional.cosine_similarity.
+// scratch (floats): G [R][R] raw dot products (R = 2B), W [R][R] = dL/dC. Small tensors: one block
+// per row for the Gram matrix and for the gradient, one block for the loss itself.
+// ---------------------------------------------------------------------------
+#define ADELL_PAIR_MAXR 256
+#define ADELL_PAIR_EPS 1e-8f
+
+struct PairArgs {
+  const float* x1;
+  const float* x2;
+  float* G;
+  float* W;
+  float* loss;
+  const float* g;
+  float* dx1;
+  float* dx2;
+  int B, D, kind, relu;
+  float invT;
+};
+
+__device__ __forceinline__ float adell_pair_elem(const PairArgs& a, int row, int d) {
+  const float v = row < a.B ? a.x1[(size_t)row * a.D + d] : a.x2[(size_t)(row - a.B) * a.D + d];
+  return a.relu ? fmaxf(v, 0.f) : v;
+}
+
+// grid R, block 256: G[i][j] for the j this kind needs (kinds 0 / 1: itself and its partner)
+__global__ __launch_bounds__(256) void adell_pair_gram_kernel(PairArgs a) {
+  const int R = 2 * a.B, i = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int partner = (i + a.B) % R;
+  for (int j = wave; j < R; j += 4) {
+    if (a.kind != 2 && j != i && j != partner) continue;   // wave-uniform
+    float s = 0.f;
+    for (int d = lane; d < a.D; d += 64) s += adell_pair_elem(a, i, d) * adell_pair_elem(a, j, d);
+    s = adell_wave_sum(s);
+    if (lane == 0) a.G[(size_t)i * R + j] = s;
+  }
+}
+
+// one block: loss and W = dL/dC (C = cosine matrix)
+__global__ __launch_bounds__(256) void adell_pair_loss_kernel(PairArgs a) {
+  __shared__ float sh[4];
+  __shared__ float rn[ADELL_PAIR_MAXR];
+  const int R = 2 * a.B, tid = threadIdx.x;
+  for (int i = tid; i < R; i += 256) rn[i] = 1.f / fmaxf(sqrtf(a.G[(size_t)i * R + i]), ADELL_PAIR_EPS);
+  for (int i = tid; i < R * R; i += 256) a.W[i] = 0.f;
+  __syncthreads();
+  float part = 0.f;
+  if (a.kind != 2) {
+    const float coef = a.kind == 0 ? -1.f / a.B : -2.f / a.B;
+    for (int i = tid; i < a.B; i += 256) {
+      const float c = a.G[(size_t)i * R + i + a.B] * rn[i] * rn[i + a.B];
+      part += coef * c;
+      a.W[(size_t)i * R + i + a.B] = coef;
+    }
+  } else {
+    for (int i = tid; i < R; i += 256) {
+      const int p = (i + a.B) % R;
+      float mx = -INFINITY;
+      for (int j = 0; j < R; ++j)
+        if (j != i) mx = fmaxf(mx, a.G[(size_t)i * R + j] * rn[i] * rn[j] * a.invT);
+      float den = 0.f;
+      for (int j = 0; j < R; ++j)
+        if (j != i) den += expf(a.G[(size_t)i * R + j] * rn[i] * rn[j] * a.invT - mx);
+      const float sp = a.G[(size_t)i * R + p] * rn[i] * rn[p] * a.invT;
+      part += (-sp + mx + logf(den)) / R;
+      for (int j = 0; j < R; ++j)
+        if (j != i) {
+          const float sm = expf(a.G[(size_t)i * R + j] * rn[i] * rn[j] * a.invT - mx) / den;
+          a.W[(size_t)i * R + j] = (sm - (j == p ? 1.f : 0.f)) * a.invT / R;
+        }
+    }
+  }
+  const float total = adell_block_sum(part, sh);
+  if (tid == 0) a.loss[0] = total + (a.kind == 1 ? 2.f : 0.f);
+}
+
+// grid R, block 256: dz_i = g * (v - [|z_i| > eps] (v . zh_i) zh_i) / max(|z_i|, eps) with
+// v = sum_j (W[i][j] + W[j][i]) zh_j, zh = z / max(|z|, eps); ReLU mask on top for kind 2
+__global__ __launch_bounds__(256) void adell_pair_bwd_kernel(PairArgs a) {
+  extern __shared__ float v[];   // [D]
+  __shared__ float sh[4];
+  __shared__ float wt[ADELL_PAIR_MAXR];
+  const int R = 2 * a.B, i = blockIdx.x, tid = threadIdx.x;
+  float* out = i < a.B ? (a.dx1 ? a.dx1 + (size_t)i * a.D : nullptr)
+                       : (a.dx2 ? a.dx2 + (size_t)(i - a.B) * a.D : nullptr);
+  if (!out) return;   // whole block
+  for (int j = tid; j < R; j += 256) {
+    const float w = a.W[(size_t)i * R + j] + a.W[(size_t)j * R + i];
+    wt[j] = w == 0.f ? 0.f : w / fmaxf(sqrtf(a.G[(size_t)j * R + j]), ADELL_PAIR_EPS);
+  }
+  __syncthreads();
+  const float ni = sqrtf(a.G[(size_t)i * R + i]);
+  const float ri = 1.f / fmaxf(ni, ADELL_PAIR_EPS);
+  float s = 0.f;
+  for (int d = tid; d < a.D; d += 256) {
+    float t = 0.f;
+    for (int j = 0; j < R; ++j)
+      if (wt[j] != 0.f) t += wt[j] * adell_pair_elem(a, j, d);
+    v[d] = t;
+    s += t * adell_pair_elem(a, i, d) * ri;
+  }
+  s = adell_block_sum(s, sh);
+  if (!(ni > ADELL_PAIR_EPS)) s = 0.f;
+  const float g = a.g[0];
+  const float* raw = i < a.B ? a.x1 + (size_t)i * a.D : a.x2 + (size_t)(i - a.B) * a.D;
+  for (int d = tid; d < a.D; d += 256) {
+    float r = g * (v[d] - s * adell_pair_elem(a, i, d) * ri) * ri;
+    if (a.relu && !(raw[d] > 0.f)) r = 0.f;
+    out[d] = r;
+  }
+}
+
+static int adell_pair_check(const float* x1, const float* x2, int B, int D, int kind) {
+  ADELL_REQUIRE(x1 && x2, "pair_loss: null pointer");
+  ADELL_REQUIRE(kind >= 0 && kind <= 2, "pair_loss: kind must be 0 (simsiam), 1 (byol), 2 (nt-xent)");
+  ADELL_REQUIRE(B >= 1 && 2 * B <= ADELL_PAIR_MAXR, "pair_loss: batch must be 1..%d (got %d)",
+                ADELL_PAIR_MAXR / 2, B);
+  ADELL_REQUIRE(D >= 1 && D <= 36000, "pair_loss: embedding size must be 1..36000 (got %d)", D);
+  return ADELL_OK;
+}
+
+extern "C" long adell_pair_loss_scratch_floats(int B, int D) { return 8L * B * B; }
+
+extern "C" int adell_pair_loss_fwd(const float* x1, const float* x2, int B, int D, int kind,
+                                   float temperature, int apply_relu, float* scratch,
+                                   float* loss, void* stream) {
+  int rc = adell_pair_check(x1, x2, B, D, kind);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(scratch && loss, "pair_loss_fwd: null pointer");
+  ADELL_REQUIRE(kind != 2 || temperature > 0.f, "pair_loss_fwd: temperature must be positive");
+  PairArgs a = {};
+  const int R = 2 * B;
+  a.x1 = x1; a.x2 = x2; a.G = scratch; a.W = scratch + (size_t)R * R; a.loss = loss;
+  a.B = B; a.D = D; a.kind = kind; a.relu = (kind == 2 && apply_relu) ? 1 : 0;
+  a.invT = kind == 2 ? 1.f / temperature : 1.f;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_pair_gram_kernel, dim3(R), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(adell_pair_loss_kernel, dim3(1), dim3(256), 0, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_pair_loss_bwd(const float* x1, const float* x2, int B, int D, int kind,
+                                   float temperature, int apply_relu, const float* scratch,
+                                   const float* g, float* dx1, float* dx2, void* stream) {
+  int rc = adell_pair_check(x1, x2, B, D, kind);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(scratch && g && (dx1 || dx2), "pair_loss_bwd: null pointer");
+  PairArgs a = {};
+  const int R = 2 * B;
+  a.x1 = x1; a.x2 = x2; a.G = const_cast<float*>(scratch);
+  a.W = const_cast<float*>(scratch) + (size_t)R * R; a.g = g; a.dx1 = dx1; a.dx2 = dx2;
+  a.B = B; a.D = D; a.kind = kind; a.relu = (kind == 2 && apply_relu) ? 1 : 0;
+  a.invT = kind == 2 ? 1.f / temperature : 1.f;
+  static bool attr_done = false;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_pair_bwd_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(adell_pair_bwd_kernel, dim3(R), dim3(256), (size_t)D * sizeof(float),
+                     (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

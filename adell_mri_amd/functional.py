@@ -977,6 +977,29 @@ def vicreg_terms(x1, x2, min_var=1.0, eps=1e-4):
     return _VICRegFn.apply(x1, x2, float(min_var), float(eps))
 
 
+class _PairLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, kind, temperature, apply_relu):
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        loss, scratch = ops.pair_loss_fwd(x1, x2, kind, temperature, apply_relu)
+        ctx.save_for_backward(x1, x2, scratch)
+        ctx.conf = (kind, temperature, apply_relu)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, scratch = ctx.saved_tensors
+        dx1, dx2 = ops.pair_loss_bwd(x1, x2, *ctx.conf, scratch, g, ctx.needs_input_grad[0],
+                                     ctx.needs_input_grad[1])
+        return dx1, dx2, None, None, None
+
+
+def pair_loss(x1, x2, kind, temperature=1.0, apply_relu=False):
+    """Scalar cosine-similarity loss between two [B, D] embedding batches: ``kind`` = "simsiam",
+    "byol" (self_supervised/losses/functional.py:138-164) or "ntxent" (losses/ntxent.py:11-46)."""
+    return _PairLossFn.apply(x1, x2, kind, float(temperature), bool(apply_relu))
+
+
 class _LocoLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f1, f2, temperature, eps):

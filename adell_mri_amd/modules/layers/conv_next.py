@@ -1,5 +1,5 @@
 """ConvNeXt on the HIP kernels: drop-in for ``adell_mri/modules/layers/conv_next.py:86-235``
-(backbone) and ``:388-452`` (backbone + heads), 3-D only. The boundary is the reference's
+(backbone) and ``:388-452`` (backbone + heads), 2-D (depth-1 volumes) and 3-D. The boundary is the reference's
 constructor signatures, attribute names and ``state_dict`` keys (``input_layer.{0,1}``,
 ``operations.<stage>.<block>``, ``projection_head.{0,1}``, ``prediction_head``); everything behind
 it is this package's layers -- depthwise stencil + LDS-tiled pointwise GEMMs inside
@@ -8,17 +8,17 @@ from typing import List, Tuple, Union
 
 import torch
 
-from .conv import Conv3d, MaxPool3d
+from .conv import Conv2d, Conv3d, MaxPool2d, MaxPool3d
 from .regularization import LayerNorm
-from .res_blocks import ConvNeXtBlock3d
+from .res_blocks import ConvNeXtBlock2d, ConvNeXtBlock3d
 from .res_net import ProjectionHead, _NormLeaf
 
 
-def _stage(width_in: int, width: int, inner: int, kernel: int, n_blocks: int):
+def _stage(block, width_in: int, width: int, inner: int, kernel: int, n_blocks: int):
     """One resolution level: ``n_blocks`` ConvNeXt blocks (never fewer than two, as the reference
     builds them), the first of which changes the channel count."""
     widths = [width_in] + [width] * max(n_blocks - 1, 1)
-    return torch.nn.Sequential(*[ConvNeXtBlock3d(w, kernel, inner, width) for w in widths])
+    return torch.nn.Sequential(*[block(w, kernel, inner, width) for w in widths])
 
 
 class ConvNeXtBackbone(torch.nn.Module):
@@ -28,31 +28,34 @@ class ConvNeXtBackbone(torch.nn.Module):
                  first_layer_stride=4, padding=None, adn_fn: torch.nn.Module = torch.nn.Identity,
                  batch_ensemble: int = 0):
         super().__init__()
-        if spatial_dim != 3 or batch_ensemble > 0:
-            raise NotImplementedError("HIP ConvNeXtBackbone covers spatial_dim=3, batch_ensemble=0")
+        if spatial_dim not in (2, 3) or batch_ensemble > 0:
+            raise NotImplementedError("HIP ConvNeXtBackbone covers spatial_dim 2 / 3, "
+                                      "batch_ensemble=0")
         if maxpool_structure is None:
             maxpool_structure = [2] * len(structure)
         self.spatial_dim, self.in_channels = spatial_dim, in_channels
         self.structure, self.maxpool_structure = structure, maxpool_structure
         self.first_layer_stride, self.adn_fn, self.batch_ensemble = (first_layer_stride, adn_fn,
                                                                      batch_ensemble)
-        self.res_op, self.conv_op, self.max_pool_op = ConvNeXtBlock3d, Conv3d, MaxPool3d
+        self.res_op, self.conv_op, self.max_pool_op = (
+            (ConvNeXtBlock2d, Conv2d, MaxPool2d) if spatial_dim == 2
+            else (ConvNeXtBlock3d, Conv3d, MaxPool3d))
         stem_width = structure[0][0]
         # patchify stem: k = 4 conv at the stem stride, then LayerNorm over channels per voxel
         self.input_layer = torch.nn.Sequential(
-            Conv3d(in_channels, stem_width, 4, stride=first_layer_stride),
+            self.conv_op(in_channels, stem_width, 4, stride=first_layer_stride),
             LayerNorm(stem_width, data_format="channels_first"))
         stages, pools, width_in = [], [], stem_width
         for (width, inner, kernel, n_blocks), pool in zip(structure, maxpool_structure):
-            stages.append(_stage(width_in, width, inner, kernel, n_blocks))
-            pools.append(MaxPool3d(pool, pool))
+            stages.append(_stage(self.res_op, width_in, width, inner, kernel, n_blocks))
+            pools.append(self.max_pool_op(pool, pool))
             width_in = width
         self.operations = torch.nn.ModuleList(stages)
         self.be_operations = torch.nn.ModuleList([None] * len(stages))  # batch-ensemble slots: unused
         self.pooling_operations = torch.nn.ModuleList(pools)
         self.output_features = structure[-1][0]
         for m in self.modules():   # trunc-normal(0.02) weights, zero biases on convs and linears
-            if isinstance(m, (torch.nn.Conv3d, torch.nn.Linear)):
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Conv3d, torch.nn.Linear)):
                 torch.nn.init.trunc_normal_(m.weight, std=0.02)
                 torch.nn.init.constant_(m.bias, 0)
 

@@ -65,7 +65,9 @@ class LayerNorm(torch.nn.Module):
         w, b = self.weight.reshape(-1), self.bias.reshape(-1)
         if self.data_format == "channels_last":
             return HF.layer_norm(x, w, b, self.eps)
+        if x.dim() == 4:   # 2-D network: depth-1 volume
+            return self.forward(x.unsqueeze(2)).squeeze(2)
         if x.dim() != 5:
-            raise NotImplementedError("channels_first LayerNorm: 5-D activations only")
+            raise NotImplementedError("channels_first LayerNorm: 4-D / 5-D activations only")
         xr = ops.ndhwc(x).permute(0, 2, 3, 4, 1)            # [N, D, H, W, C] contiguous view
         return HF.layer_norm(xr, w, b, self.eps).permute(0, 4, 1, 2, 3)

@@ -75,6 +75,19 @@ class DepthwiseConv3d(torch.nn.Conv3d):
         return HF.dwconv3d(X, self.weight, self.bias)
 
 
+class DepthwiseConv2d(torch.nn.Conv2d):
+    """torch.nn.Conv2d(groups=in_channels, padding="same") as a depth-1 volume on the stencil
+    kernel."""
+
+    def forward(self, X):
+        if (self.groups != self.in_channels or self.in_channels != self.out_channels
+                or tuple(self.stride) != (1, 1) or tuple(self.dilation) != (1, 1)
+                or self.padding != "same"):
+            raise NotImplementedError("HIP DepthwiseConv2d: groups == channels, stride 1, "
+                                      "padding='same'")
+        return HF.dwconv3d(X.unsqueeze(2), self.weight.unsqueeze(2), self.bias).squeeze(2)
+
+
 class ConvNeXtBlock3d(torch.nn.Module):
     """ConvNeXt block (adell_mri/modules/layers/res_blocks.py:516-604): depthwise conv ->
     LayerNorm over channels -> Linear -> GELU -> Linear -> layer scale -> + input
@@ -92,7 +105,7 @@ class ConvNeXtBlock3d(torch.nn.Module):
         self.adn_fn = adn_fn
         self.layer_scale_init_value = layer_scale_init_value
         self.skip_activation = skip_activation
-        self.dwconv = DepthwiseConv3d(in_channels, in_channels, kernel_size=kernel_size,
+        self.dwconv = self._depthwise(in_channels, in_channels, kernel_size=kernel_size,
                                       padding="same", groups=in_channels)
         self.norm = RowLayerNorm(in_channels, eps=1e-6)
         self.pwconv1 = Linear(in_channels, inter_channels)
@@ -103,14 +116,22 @@ class ConvNeXtBlock3d(torch.nn.Module):
                       if layer_scale_init_value > 0 else None)
         if out_channels != in_channels:
             self.out_layer = torch.nn.Sequential(
-                Conv3d(in_channels, out_channels, kernel_size=1, padding="same"),
+                self._pointwise(in_channels, out_channels, kernel_size=1, padding="same"),
                 torch.nn.GELU())
         else:
             self.out_layer = None
 
+    _depthwise, _pointwise = DepthwiseConv3d, Conv3d
+
     def forward(self, x):
+        if x.dim() == 4:   # ConvNeXtBlock2d: the same kernels on a depth-1 volume
+            return self._forward5(x.unsqueeze(2)).squeeze(2)
+        return self._forward5(x)
+
+    def _forward5(self, x):
         inp = ops.ndhwc(x)
-        h = self.dwconv(inp)
+        w = self.dwconv.weight
+        h = HF.dwconv3d(inp, w if w.dim() == 5 else w.unsqueeze(2), self.dwconv.bias)
         rows = ops.ndhwc(h).permute(0, 2, 3, 4, 1)          # [N, D, H, W, C], contiguous
         rows = self.norm(rows)
         rows = HF.elementwise(self.pwconv1(rows), act="gelu")
@@ -126,5 +147,15 @@ class ConvNeXtBlock3d(torch.nn.Module):
         rows = HF.linear(rows, w2, b2, residual=inp.permute(0, 2, 3, 4, 1))
         out = rows.permute(0, 4, 1, 2, 3)
         if self.out_layer is not None:
-            out = HF.norm_drop_act(self.out_layer[0](out), act="gelu")
+            proj = self.out_layer[0]
+            y = proj(out.squeeze(2)).unsqueeze(2) if proj.weight.dim() == 4 else proj(out)
+            out = HF.norm_drop_act(y, act="gelu")
         return out
+
+
+class ConvNeXtBlock2d(ConvNeXtBlock3d):
+    """Two-dimensional ConvNeXt block (res_blocks.py:429-513): same arithmetic and kernels as the
+    3-D block on depth-1 volumes; parameters keep their 2-D shapes (``dwconv.weight`` [C, 1, k, k],
+    ``out_layer.0.weight`` [Co, Ci, 1, 1])."""
+
+    _depthwise, _pointwise = DepthwiseConv2d, Conv2d

@@ -115,6 +115,8 @@ class ProjectionHead(torch.nn.Module):
         self.op = torch.nn.Sequential(layers)
 
     def forward(self, X):
+        if X.dim() == 4:   # 2-D feature map: depth-1 volume
+            X = X.unsqueeze(2)
         if X.dim() == 5:
             X = HF.max_pool3d(X, tuple(X.shape[2:]), tuple(X.shape[2:]), 0).flatten(1)
         elif X.dim() > 2:

@@ -18,7 +18,7 @@ from ..layers.conv_next import ConvNeXt
 from ..layers.res_net import ResNet
 from ..segmentation.unet import UNet
 from ..learning_rate import CosineAnnealingWithWarmupLR
-from .losses import VICRegLoss
+from .losses import NTXentLoss, VICRegLoss, byol_loss, simsiam_loss
 
 try:  # pragma: no cover - lightning is not installed in the build image
     import lightning.pytorch as pl
@@ -47,13 +47,16 @@ class SelfSLBasePL(_Base):
             metrics[k].update(y1.flatten(), y2.flatten())
 
     def init_loss(self):
+        """pl.py:202-212: SimSiam by default, BYOL with an EMA target, else by ``ssl_method``."""
+        self.loss = simsiam_loss
+        if getattr(self, "ema", None) is not None:
+            self.loss = byol_loss
         if self.ssl_method == "vicreg":
             self.loss = VICRegLoss(**self.vic_reg_loss_params)
-        elif self.ssl_method in ("vicregl", "simclr"):
-            raise NotImplementedError(f"ssl_method={self.ssl_method!r} has no HIP loss kernel yet")
-        else:
-            raise NotImplementedError("SimSiam/BYOL cosine losses have no HIP kernel yet; "
-                                      "use ssl_method='vicreg'")
+        if self.ssl_method == "vicregl":
+            raise NotImplementedError("ssl_method='vicregl' (VICRegLocalLoss) has no HIP kernel")
+        if self.ssl_method == "simclr":
+            self.loss = NTXentLoss(temperature=self.temperature)
 
     def calculate_loss(self, y1, y2, *args):
         if self.stop_gradient is False:

@@ -1164,6 +1164,39 @@ def vicreg_bwd(x1, x2, scratch, min_var, eps, g, need1, need2):
     return dx1, dx2
 
 
+PAIR_LOSS_KINDS = {"simsiam": 0, "byol": 1, "ntxent": 2}
+
+
+def pair_loss_fwd(x1, x2, kind, temperature=1.0, apply_relu=False):
+    """(loss [1], scratch) of a cosine-similarity loss between two [B, D] embedding batches."""
+    _require_cuda(x1, x2)
+    x1, x2 = x1.contiguous(), x2.contiguous()
+    if x1.dim() != 2 or x1.shape != x2.shape:
+        raise AdellHipError(f"pair_loss: two [B, D] tensors of one shape expected, got "
+                            f"{tuple(x1.shape)} and {tuple(x2.shape)}")
+    B, D = x1.shape
+    scratch = torch.empty(max(_lib.lib().adell_pair_loss_scratch_floats(B, D), 1),
+                          device=x1.device, dtype=torch.float32)
+    loss = torch.empty(1, device=x1.device, dtype=torch.float32)
+    check(_lib.lib().adell_pair_loss_fwd(_ptr(x1), _ptr(x2), B, D, PAIR_LOSS_KINDS[kind],
+                                         float(temperature), int(bool(apply_relu)),
+                                         _ptr(scratch), _ptr(loss), _stream()))
+    return loss, scratch
+
+
+def pair_loss_bwd(x1, x2, kind, temperature, apply_relu, scratch, g, need1, need2):
+    if not (need1 or need2):
+        return None, None
+    B, D = x1.shape
+    g = g.reshape(1).contiguous().float()
+    dx1 = torch.empty_like(x1) if need1 else None
+    dx2 = torch.empty_like(x2) if need2 else None
+    check(_lib.lib().adell_pair_loss_bwd(_ptr(x1), _ptr(x2), B, D, PAIR_LOSS_KINDS[kind],
+                                         float(temperature), int(bool(apply_relu)),
+                                         _ptr(scratch), _ptr(g), _ptr(dx1), _ptr(dx2), _stream()))
+    return dx1, dx2
+
+
 def loco_loss_fwd(f1, f2, temperature, eps):
     """Per-item local contrastive loss [B] of two NDHWC feature maps [B, C, *spatial]
     (semi_supervised_segmentation/losses.py:498-526)."""

@@ -447,6 +447,20 @@ int adell_vicreg_bwd(const float* x1, const float* x2, int B, int D, float min_v
                      const float* scratch, const float* g3, float* dx1, float* dx2,
                      void* stream);
 
+/* Cosine-similarity losses between two [B][D] embedding batches, the non-VICReg choices of
+ * SelfSLBasePL.init_loss (self_supervised/pl.py:202-212): kind 0 simsiam_loss, kind 1 byol_loss
+ * (self_supervised/losses/functional.py:138-164), kind 2 NTXentLoss (losses/ntxent.py:11-46;
+ * temperature, apply_relu). loss: 1 float on the device. scratch of
+ * adell_pair_loss_scratch_floats(B, D) floats is kept for the backward, which returns
+ * g[0] * dloss/dx1 (dx1) and / or dx2 (either may be NULL). 2 B <= 256. */
+long adell_pair_loss_scratch_floats(int B, int D);
+int adell_pair_loss_fwd(const float* x1, const float* x2, int B, int D, int kind,
+                        float temperature, int apply_relu, float* scratch, float* loss,
+                        void* stream);
+int adell_pair_loss_bwd(const float* x1, const float* x2, int B, int D, int kind,
+                        float temperature, int apply_relu, const float* scratch, const float* g,
+                        float* dx1, float* dx2, void* stream);
+
 /* Local contrastive loss of the semi-supervised U-Net (LocalContrastiveLoss.forward,
  * semi_supervised_segmentation/losses.py:498-526; called by UNetContrastiveSemiSL.step_semi_sl_loco,
  * semi_supervised_segmentation/pl.py:244-281): f1 / f2 = decoder features of the two views, NDHWC

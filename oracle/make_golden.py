@@ -719,7 +719,99 @@ def gen_semisl():
     np.savez_compressed(os.path.join(OUT, "loco_loss.npz"), **out)
 
 
+SSL2D_CASE = dict(
+    # the reference's sample_configs/ssl-2d-convnext.yaml in miniature (spatial_dim 2)
+    backbone_args=dict(spatial_dim=2, in_channels=1, structure=[[8, 16, 7, 2], [16, 32, 3, 2]],
+                       maxpool_structure=[[2, 2], [2, 2]], first_layer_stride=4),
+    projection_head_args=dict(in_channels=16, structure=[32, 24]),
+    prediction_head_args=dict(in_channels=24, structure=[32, 24]))
+
+
+def gen_ssl2d():
+    """2-D ConvNeXt (conv_next.py:86-235 with spatial_dim=2, ConvNeXtBlock2d res_blocks.py:429-513):
+    a block on its own (output, input gradient, parameter gradients) and the network's three heads
+    with the VICReg loss and every parameter gradient."""
+    from adell_mri.modules.layers.res_blocks import ConvNeXtBlock2d
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    x = torch.randn((2, 8, 10, 12), generator=g)
+    out["blk_x"] = x.numpy()
+    for tag, (k, oc) in {"k3": (3, 8), "k7": (7, 12)}.items():
+        blk = ConvNeXtBlock2d(8, k, 16, oc)
+        blk.load_state_dict(fill_state_dict(blk.state_dict()))
+        xin = x.clone().requires_grad_(True)
+        y = blk(xin)
+        r = torch.randn(y.shape, generator=g)
+        (y * r).sum().backward()
+        out[f"blk_{tag}_y"], out[f"blk_{tag}_r"] = y.detach().numpy(), r.numpy()
+        out[f"blk_{tag}_dx"] = xin.grad.numpy()
+        for n, p in blk.named_parameters():
+            out[f"blk_{tag}_grad:{n}"] = p.grad.numpy().copy()
+    adn1 = get_adn_fn(1, "layer", "gelu", 0.0)
+    kw = {k: dict(v) for k, v in SSL2D_CASE.items()}
+    kw["projection_head_args"]["adn_fn"] = adn1
+    kw["prediction_head_args"]["adn_fn"] = adn1
+    net = ConvNeXt(**kw)
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    net.train()
+    yy, xx = torch.meshgrid(torch.arange(64.0), torch.arange(48.0), indexing="ij")
+    x1 = torch.stack([torch.sin((b + 1) * 0.31 * yy) * torch.cos((b + 2) * 0.17 * xx)
+                      + 0.02 * (b - 1.5) * xx for b in range(4)])[:, None]
+    x1 = x1 + 0.2 * torch.rand(x1.shape, generator=g)
+    x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g)).flip(2)
+    out["x1"], out["x2"] = x1.numpy(), x2.numpy()
+    out["representation"] = net(x1, ret="representation").detach().numpy()
+    y1, y2 = net(x1, ret="prediction"), net(x2, ret="projection")
+    out["y1"], out["y2"] = y1.detach().numpy(), y2.detach().numpy()
+    losses = VICRegLoss()(y1, y2)
+    sum(losses).backward()
+    out["losses"] = torch.stack(losses).detach().numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy().copy()
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    out["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "ssl_convnext2d_small.npz"), **out)
+    print("ssl2d ok: terms", [float(t.detach()) for t in losses], "representation",
+          tuple(out["representation"].shape))
+
+
+def gen_pair_losses():
+    """simsiam_loss / byol_loss / NTXentLoss (the non-VICReg choices of SelfSLBasePL.init_loss,
+    self_supervised/pl.py:202-212) from the reference's own code: values and both gradients."""
+    from adell_mri.modules.self_supervised.losses.functional import byol_loss, simsiam_loss
+    from adell_mri.modules.self_supervised.losses.ntxent import NTXentLoss
+    g = torch.Generator().manual_seed(31)
+    out = {}
+    cases = [("simsiam_a", "simsiam", (6, 40), 1.0, False), ("byol_a", "byol", (5, 33), 1.0, False),
+             ("simsiam_zero_row", "simsiam", (4, 16), 1.0, False),
+             ("ntxent_relu", "ntxent", (6, 40), 0.5, True),
+             ("ntxent_norelu", "ntxent", (4, 24), 0.1, False),
+             ("ntxent_t1", "ntxent", (3, 8), 1.0, True), ("byol_b1", "byol", (1, 12), 1.0, False)]
+    for tag, kind, shape, temp, relu in cases:
+        a = torch.randn(shape, generator=g).requires_grad_(True)
+        b = (0.5 * a.detach() + 0.8 * torch.randn(shape, generator=g)).requires_grad_(True)
+        if tag == "simsiam_zero_row":
+            with torch.no_grad():
+                a[1] = 0.0   # the clamp of cosine_similarity
+        fn = {"simsiam": simsiam_loss, "byol": byol_loss,
+              "ntxent": NTXentLoss(temperature=temp, apply_relu=relu)}[kind]
+        val = fn(a, b)
+        val.backward()
+        out.update({f"{tag}:kind": np.array(kind), f"{tag}:temperature": np.float32(temp),
+                    f"{tag}:relu": np.array(relu), f"{tag}:x1": a.detach().numpy(),
+                    f"{tag}:x2": b.detach().numpy(), f"{tag}:value": val.detach().numpy(),
+                    f"{tag}:grad1": a.grad.numpy().copy(), f"{tag}:grad2": b.grad.numpy().copy()})
+        print(tag, float(val))
+    np.savez_compressed(os.path.join(OUT, "ssl_pair_losses.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "pairloss":
+        gen_pair_losses()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ssl2d":
+        gen_ssl2d()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "semisl":
         gen_semisl()
         sys.exit(0)

@@ -8,6 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from adell_mri_amd import functional as HF
 from cases import grad_rel_err
 from oracle.torch_ref.convnext import ConvNeXtOracle, vicreg_loss
 from oracle.weights import fill_state_dict, tensor_for
@@ -98,7 +99,22 @@ def test_unsupported_ssl_methods_raise():
     from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
 
     with pytest.raises(NotImplementedError):
-        SelfSLConvNeXtPL(ssl_method="simclr", **SSL_CASE)
+        SelfSLConvNeXtPL(ssl_method="vicregl", **SSL_CASE)
+
+
+def test_loss_selection_follows_the_reference():
+    """self_supervised/pl.py:202-212."""
+    from adell_mri_amd.modules.self_supervised.losses import (NTXentLoss, VICRegLoss, byol_loss,
+                                                              simsiam_loss)
+    from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
+    from adell_mri_amd.utils import ExponentialMovingAverage
+
+    assert SelfSLConvNeXtPL(ssl_method="simsiam", **SSL_CASE).loss is simsiam_loss
+    assert SelfSLConvNeXtPL(ssl_method="byol", ema=ExponentialMovingAverage(0.99),
+                            **SSL_CASE).loss is byol_loss
+    simclr = SelfSLConvNeXtPL(ssl_method="simclr", temperature=0.5, **SSL_CASE).loss
+    assert isinstance(simclr, NTXentLoss) and simclr.temperature == 0.5 and simclr.apply_relu
+    assert isinstance(SelfSLConvNeXtPL(ssl_method="vicreg", **SSL_CASE).loss, VICRegLoss)
 
 
 # ---- GPU: HIP kernels against stock torch / the reference fixtures ---------------------
@@ -310,10 +326,172 @@ def test_selfsl_unet_vicreg_step(cuda):
     assert y1.shape == (6, 32, 4, 4, 4)
     m1, m2 = y1.flatten(2).mean(-1).detach().cpu(), y2.flatten(2).mean(-1).detach().cpu()
     want = vicreg_loss(m1, m2)       # (inv, var, cov) weighted 25 / 25 / 0.1
-    got = [float(t) for t in net.last_losses]
+    got = [float(t.detach()) for t in net.last_losses]
     np.testing.assert_allclose(got, [float(t) for t in want], rtol=2e-4, atol=1e-6)
-    np.testing.assert_allclose(float(loss), sum(got), rtol=1e-6)
+    np.testing.assert_allclose(float(loss.detach()), sum(got), rtol=1e-6)
     before = {k: p.detach().clone() for k, p in net.named_parameters()}
     StepRunner(net).train_step(batch)
     moved = sum(not torch.equal(before[k], p.detach()) for k, p in net.named_parameters())
     assert moved > 0.8 * len(before)
+
+
+# ---- 2-D ConvNeXt (the reference's sample_configs/ssl-2d-convnext.yaml) --------------------------
+SSL2D_CASE = dict(
+    backbone_args=dict(spatial_dim=2, in_channels=1, structure=[[8, 16, 7, 2], [16, 32, 3, 2]],
+                       maxpool_structure=[[2, 2], [2, 2]], first_layer_stride=4),
+    projection_head_args=dict(in_channels=16, structure=[32, 24]),
+    prediction_head_args=dict(in_channels=24, structure=[32, 24]))
+
+
+def gold2d():
+    return np.load(os.path.join(GOLD, "ssl_convnext2d_small.npz"), allow_pickle=False)
+
+
+def build_pl2d():
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
+
+    adn1 = get_adn_fn(1, "layer", "gelu", 0.0)
+    kw = {k: dict(v) for k, v in SSL2D_CASE.items()}
+    kw["projection_head_args"]["adn_fn"] = adn1
+    kw["prediction_head_args"]["adn_fn"] = adn1
+    net = SelfSLConvNeXtPL(aug_image_key_1="a", aug_image_key_2="b", ssl_method="vicreg",
+                           stop_gradient=False, n_epochs=10, batch_size=4, ema=None,
+                           **SSL_OPT, **kw)
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    return net
+
+
+def test_convnext2d_state_dict_shapes_equal_reference():
+    g = gold2d()
+    net = build_pl2d()
+    mine = {k: ",".join(map(str, p.shape)) for k, p in net.named_parameters()}
+    assert list(mine) == list(g["param_keys"])
+    assert list(mine.values()) == list(g["param_shapes"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,k,oc", [("k3", 3, 8), ("k7", 7, 12)])
+def test_convnext_block2d_matches_reference(cuda, tag, k, oc):
+    from adell_mri_amd.modules.layers.res_blocks import ConvNeXtBlock2d
+
+    g = gold2d()
+    blk = ConvNeXtBlock2d(8, k, 16, oc)
+    blk.load_state_dict(fill_state_dict(blk.state_dict()))
+    blk = blk.to(cuda)
+    x = torch.from_numpy(g["blk_x"]).to(cuda).requires_grad_(True)
+    y = blk(x)
+    assert y.dim() == 4 and rel(y, g[f"blk_{tag}_y"]) < 1e-5
+    (y * torch.from_numpy(g[f"blk_{tag}_r"]).to(cuda)).sum().backward()
+    assert rel(x.grad, g[f"blk_{tag}_dx"]) < 1e-4
+    for n, p in blk.named_parameters():
+        assert rel(p.grad, g[f"blk_{tag}_grad:{n}"]) < 1e-4, n
+
+
+@pytest.mark.gpu
+def test_convnext2d_vicreg_step_matches_reference(cuda):
+    """The three heads, the VICReg terms and every parameter gradient of the 2-D network, then one
+    fused AdamW step through the PL wrapper."""
+    from adell_mri_amd.trainer import StepRunner
+
+    g = gold2d()
+    net = build_pl2d().to(cuda).train()
+    x1, x2 = torch.from_numpy(g["x1"]).to(cuda), torch.from_numpy(g["x2"]).to(cuda)
+    assert rel(net(x1, ret="representation"), g["representation"]) < 1e-4
+    assert rel(net(x1, ret="prediction"), g["y1"]) < 1e-4
+    assert rel(net(x2, ret="projection"), g["y2"]) < 1e-4
+    runner = StepRunner(net)
+    runner.optimizer.zero_grad()
+    loss = net.training_step({"a": x1, "b": x2}, 0)
+    np.testing.assert_allclose(torch.stack(list(net.last_losses)).detach().cpu().numpy(),
+                               g["losses"], rtol=5e-4, atol=1e-6)
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert grad_rel_err(g, k, p.grad.cpu().numpy()) < 5e-3, k
+    before = net.backbone.input_layer[0].weight.detach().clone()
+    runner.optimizer.step()
+    assert not torch.equal(before, net.backbone.input_layer[0].weight.detach())
+
+
+# ---- SimSiam / BYOL / NT-Xent losses ------------------------------------------------------------
+def test_pair_loss_restatement_matches_reference_fixture():
+    from oracle.torch_ref.ssl_losses import pair_loss
+
+    g = np.load(os.path.join(GOLD, "ssl_pair_losses.npz"))
+    for tag in [k[:-6] for k in g.files if k.endswith(":value")]:
+        kind, temp, relu = str(g[f"{tag}:kind"]), float(g[f"{tag}:temperature"]), bool(g[f"{tag}:relu"])
+        x1 = torch.from_numpy(g[f"{tag}:x1"]).requires_grad_(True)
+        x2 = torch.from_numpy(g[f"{tag}:x2"]).requires_grad_(True)
+        val = pair_loss(x1, x2, kind, temp, relu)
+        val.backward()
+        np.testing.assert_allclose(val.item(), g[f"{tag}:value"], rtol=2e-5, atol=1e-6)
+        assert rel(x1.grad, g[f"{tag}:grad1"]) < 1e-4 and rel(x2.grad, g[f"{tag}:grad2"]) < 1e-4, tag
+
+
+@pytest.mark.gpu
+def test_pair_losses_match_reference_fixture(cuda):
+    """simsiam_loss / byol_loss / NTXentLoss against values and gradients from the reference's
+    own functions (oracle/make_golden.py gen_pair_losses)."""
+    from adell_mri_amd.modules.self_supervised.losses import NTXentLoss, byol_loss, simsiam_loss
+
+    g = np.load(os.path.join(GOLD, "ssl_pair_losses.npz"))
+    tags = [k[:-6] for k in g.files if k.endswith(":value")]
+    assert len(tags) >= 6
+    for tag in tags:
+        kind, temp, relu = str(g[f"{tag}:kind"]), float(g[f"{tag}:temperature"]), bool(g[f"{tag}:relu"])
+        x1 = torch.from_numpy(g[f"{tag}:x1"]).to(cuda).requires_grad_(True)
+        x2 = torch.from_numpy(g[f"{tag}:x2"]).to(cuda).requires_grad_(True)
+        fn = {"simsiam": simsiam_loss, "byol": byol_loss,
+              "ntxent": NTXentLoss(temperature=temp, apply_relu=relu)}[kind]
+        val = fn(x1, x2)
+        assert val.dim() == 0
+        np.testing.assert_allclose(val.item(), g[f"{tag}:value"], rtol=3e-5, atol=2e-6)
+        (val * 1.7).backward()
+        assert rel(x1.grad, 1.7 * g[f"{tag}:grad1"]) < 2e-4, tag
+        assert rel(x2.grad, 1.7 * g[f"{tag}:grad2"]) < 2e-4, tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,B,D", [("simsiam", 16, 1024), ("byol", 3, 7), ("ntxent", 32, 2048),
+                                      ("ntxent", 128, 65), ("simsiam", 1, 5000)])
+def test_pair_losses_match_oracle_at_other_sizes(cuda, kind, B, D):
+    from oracle.torch_ref.ssl_losses import pair_loss
+
+    g = torch.Generator().manual_seed(B + D)
+    a = torch.randn(B, D, generator=g)
+    b = 0.6 * a + 0.8 * torch.randn(B, D, generator=g)
+    ac, bc = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = pair_loss(ac, bc, kind, 0.3, True)
+    ref.backward()
+    ah, bh = a.to(cuda).requires_grad_(True), b.to(cuda).requires_grad_(True)
+    val = HF.pair_loss(ah, bh, kind, 0.3, True)
+    val.backward()
+    np.testing.assert_allclose(val.item(), ref.item(), rtol=3e-5, atol=2e-6)
+    assert rel(ah.grad, ac.grad.numpy()) < 2e-4 and rel(bh.grad, bc.grad.numpy()) < 2e-4
+    # stop-gradient: only the first argument gets a gradient, the same one
+    a2 = a.to(cuda).requires_grad_(True)
+    HF.pair_loss(a2, b.to(cuda), kind, 0.3, True).backward()
+    assert torch.equal(a2.grad, ah.grad)
+
+
+@pytest.mark.gpu
+def test_byol_step_with_ema_target_trains(cuda):
+    """ssl_method='byol': prediction of view 1 against the EMA shadow's projection of view 2 and
+    the swapped pair (pl.py:456-500), cosine loss on the fused kernel."""
+    from adell_mri_amd.modules.self_supervised.losses import byol_loss
+    from adell_mri_amd.trainer import StepRunner
+    from adell_mri_amd.utils import ExponentialMovingAverage
+
+    g = gold()
+    net = build_pl().to(cuda).train()
+    net.ssl_method, net.stop_gradient = "byol", True
+    net.ema = ExponentialMovingAverage(0.9)
+    net.ema.update(net)
+    del net.loss          # a VICRegLoss module was registered under this name
+    net.init_loss()
+    assert net.loss is byol_loss
+    runner = StepRunner(net)
+    batch = {"a": torch.from_numpy(g["x1"]).to(cuda), "b": torch.from_numpy(g["x2"]).to(cuda)}
+    losses = [runner.train_step(batch).item() for _ in range(4)]
+    assert all(np.isfinite(losses)) and 0.0 <= min(losses) and max(losses) <= 8.0
+    assert losses[-1] < losses[0]
