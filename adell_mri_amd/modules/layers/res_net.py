@@ -10,9 +10,9 @@ from typing import List, OrderedDict, Tuple, Union
 import torch
 
 from ... import functional as HF
-from .conv import Conv3d, MaxPool3d
+from .conv import Conv2d, Conv3d, MaxPool2d, MaxPool3d
 from .linear_blocks import LayerNorm, Linear
-from .res_blocks import ResidualBlock3d
+from .res_blocks import ResidualBlock2d, ResidualBlock3d
 
 
 def resnet_to_encoding_ops(res_net: List[torch.nn.Module]) -> torch.nn.ModuleList:
@@ -30,7 +30,7 @@ def resnet_to_encoding_ops(res_net: List[torch.nn.Module]) -> torch.nn.ModuleLis
 
 class ResNetBackbone(torch.nn.Module):
     """Stem (7^3 conv + ADN + 3^3 conv + ADN, max-pool 2) and residual stages of bottleneck
-    blocks, each followed by a max-pool (res_net.py:51-275). 3-D, ``res_type="resnet"``."""
+    blocks, each followed by a max-pool (res_net.py:51-275). 2-D or 3-D, ``res_type="resnet"``."""
 
     def __init__(self, spatial_dim: int, in_channels: int,
                  structure: List[Tuple[int, int, int, int]],
@@ -39,27 +39,29 @@ class ResNetBackbone(torch.nn.Module):
                  res_type: str = "resnet", batch_ensemble: int = 0,
                  skip_last_activation: bool = False):
         super().__init__()
-        if spatial_dim != 3 or res_type != "resnet" or batch_ensemble > 0:
-            raise NotImplementedError("HIP ResNetBackbone covers spatial_dim=3, res_type='resnet', "
-                                      "batch_ensemble=0")
+        if spatial_dim not in (2, 3) or res_type != "resnet" or batch_ensemble > 0:
+            raise NotImplementedError("HIP ResNetBackbone covers spatial_dim 2 / 3, "
+                                      "res_type='resnet', batch_ensemble=0")
         if maxpool_structure is None:
             maxpool_structure = [2] * len(structure)
         self.spatial_dim, self.in_channels, self.structure = spatial_dim, in_channels, structure
         self.maxpool_structure, self.adn_fn, self.res_type = maxpool_structure, adn_fn, res_type
         self.batch_ensemble, self.skip_last_activation = batch_ensemble, skip_last_activation
-        self.res_op, self.conv_op, self.max_pool_op = ResidualBlock3d, Conv3d, MaxPool3d
+        block, conv, pool_op = ((ResidualBlock2d, Conv2d, MaxPool2d) if spatial_dim == 2
+                                else (ResidualBlock3d, Conv3d, MaxPool3d))   # 2-D: depth-1 volumes
+        self.res_op, self.conv_op, self.max_pool_op = block, conv, pool_op
         stem = structure[0][0]
         self.input_layer = torch.nn.Sequential(
-            Conv3d(in_channels, stem, 7, padding="same"), adn_fn(stem),
-            Conv3d(stem, stem, 3, padding="same"), adn_fn(stem))
-        self.first_pooling = MaxPool3d(2, 2)
+            conv(in_channels, stem, 7, padding="same"), adn_fn(stem),
+            conv(stem, stem, 3, padding="same"), adn_fn(stem))
+        self.first_pooling = pool_op(2, 2)
         stages, pools, width_in = [], [], stem
         for (width, inner, kernel, n_blocks), pool in zip(structure, maxpool_structure):
             # at least two blocks per stage, the first one changes the width
             widths = [width_in] + [width] * max(n_blocks - 1, 1)
             stages.append(torch.nn.Sequential(
-                *[ResidualBlock3d(w, kernel, inner, width, adn_fn) for w in widths]))
-            pools.append(MaxPool3d(pool, pool))
+                *[block(w, kernel, inner, width, adn_fn) for w in widths]))
+            pools.append(pool_op(pool, pool))
             width_in = width
         self.operations = torch.nn.ModuleList(stages)
         self.be_operations = torch.nn.ModuleList([None] * len(stages))  # batch-ensemble slots: unused

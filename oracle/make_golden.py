@@ -775,6 +775,39 @@ def gen_ssl2d():
           tuple(out["representation"].shape))
 
 
+def gen_resnet2d():
+    """2-D ResNet (res_net.py:51-396 with spatial_dim=2) as the VICReg wrapper builds it from a 2-D
+    backbone configuration: heads, loss terms, every parameter gradient."""
+    g = torch.Generator().manual_seed(41)
+    adn = get_adn_fn(2, "batch", "swish", 0.0)
+    adn1 = get_adn_fn(1, "layer", "gelu", 0.0)
+    net = ResNet(dict(spatial_dim=2, in_channels=1, structure=[[8, 8, 5, 2], [16, 16, 3, 2]],
+                      maxpool_structure=[[2, 2], [2, 2]], res_type="resnet", adn_fn=adn),
+                 dict(in_channels=16, structure=[32, 24], adn_fn=adn1),
+                 dict(in_channels=24, structure=[32, 24], adn_fn=adn1))
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    net.train()
+    yy, xx = torch.meshgrid(torch.arange(40.0), torch.arange(48.0), indexing="ij")
+    x1 = torch.stack([torch.sin((b + 1) * 0.31 * yy) * torch.cos((b + 2) * 0.17 * xx)
+                      + 0.02 * (b - 1.5) * xx for b in range(4)])[:, None]
+    x1 = x1 + 0.2 * torch.rand(x1.shape, generator=g)
+    x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g)).flip(2)
+    out = {"x1": x1.numpy(), "x2": x2.numpy()}
+    out["representation"] = net(x1, ret="representation").detach().numpy()
+    y1, y2 = net(x1, ret="prediction"), net(x2, ret="projection")
+    out["y1"], out["y2"] = y1.detach().numpy(), y2.detach().numpy()
+    losses = VICRegLoss()(y1, y2)
+    sum(losses).backward()
+    out["losses"] = torch.stack(losses).detach().numpy()
+    for k, p in net.named_parameters():
+        out["grad:" + k] = p.grad.numpy().copy()
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    out["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "ssl_resnet2d_small.npz"), **out)
+    print("resnet2d ok: terms", [float(t.detach()) for t in losses], "representation",
+          tuple(out["representation"].shape))
+
+
 def gen_pair_losses():
     """simsiam_loss / byol_loss / NTXentLoss (the non-VICReg choices of SelfSLBasePL.init_loss,
     self_supervised/pl.py:202-212) from the reference's own code: values and both gradients."""
@@ -806,6 +839,9 @@ def gen_pair_losses():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet2d":
+        gen_resnet2d()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pairloss":
         gen_pair_losses()
         sys.exit(0)

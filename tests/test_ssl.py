@@ -495,3 +495,34 @@ def test_byol_step_with_ema_target_trains(cuda):
     losses = [runner.train_step(batch).item() for _ in range(4)]
     assert all(np.isfinite(losses)) and 0.0 <= min(losses) and max(losses) <= 8.0
     assert losses[-1] < losses[0]
+
+
+# ---- 2-D ResNet backbone (what vicreg / simclr / byol build from a 2-D backbone configuration) ---
+@pytest.mark.gpu
+def test_resnet2d_vicreg_step_matches_reference(cuda):
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.self_supervised.pl import SelfSLResNetPL
+
+    g = np.load(os.path.join(GOLD, "ssl_resnet2d_small.npz"), allow_pickle=False)
+    adn, adn1 = get_adn_fn(2, "batch", "swish", 0.0), get_adn_fn(1, "layer", "gelu", 0.0)
+    net = SelfSLResNetPL(
+        aug_image_key_1="a", aug_image_key_2="b", ssl_method="vicreg", stop_gradient=False,
+        n_epochs=10, batch_size=4, ema=None, **SSL_OPT,
+        backbone_args=dict(spatial_dim=2, in_channels=1, structure=[[8, 8, 5, 2], [16, 16, 3, 2]],
+                           maxpool_structure=[[2, 2], [2, 2]], res_type="resnet", adn_fn=adn),
+        projection_head_args=dict(in_channels=16, structure=[32, 24], adn_fn=adn1),
+        prediction_head_args=dict(in_channels=24, structure=[32, 24], adn_fn=adn1))
+    assert [k for k, _ in net.named_parameters()] == list(g["param_keys"])
+    assert [",".join(map(str, p.shape)) for _, p in net.named_parameters()] == list(g["param_shapes"])
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    net = net.to(cuda).train()
+    x1, x2 = torch.from_numpy(g["x1"]).to(cuda), torch.from_numpy(g["x2"]).to(cuda)
+    assert rel(net(x1, ret="representation"), g["representation"]) < 1e-4
+    # batch norm couples the items of a batch: the two views keep their own passes
+    assert net._views_share_a_pass("prediction", "projection") is False
+    loss = net.training_step({"a": x1, "b": x2}, 0)
+    np.testing.assert_allclose(torch.stack(list(net.last_losses)).detach().cpu().numpy(),
+                               g["losses"], rtol=5e-4, atol=1e-6)
+    loss.backward()
+    for k, p in net.named_parameters():
+        assert grad_rel_err(g, k, p.grad.cpu().numpy()) < 5e-3, k
