@@ -99,6 +99,61 @@ class UNetBasePL(_Base):
         x_fc = batch[self.feature_conditioning_key] if self.feature_conditioning_key is not None else None
         return x, x_cond, x_fc, y, y_class
 
+    def calculate_loss_class(self, prediction, y):
+        return self.loss_fn_class(prediction, y.type_as(prediction)).mean()
+
+    def crop_if_necessary(self, y, prediction):
+        """Centre-crop the ground truth to the prediction's spatial size when ``make_uniform`` is
+        set (pl.py:258-282)."""
+        if self.make_uniform is True:
+            extra = [a - b for a, b in zip(y.shape[2:], prediction.shape[2:])]
+            if any(e > 0 for e in extra):
+                window = tuple(slice(e // 2, n - (e - e // 2)) for e, n in zip(extra, y.shape[2:]))
+                y = y[(slice(None), slice(None), *window)]
+        return y, prediction
+
+    def unpack_batch_prediction(self, batch):
+        x_cond = batch[self.skip_conditioning_key] if self.skip_conditioning_key is not None else None
+        x_fc = (batch[self.feature_conditioning_key]
+                if self.feature_conditioning_key is not None else None)
+        return batch[self.image_key], x_cond, x_fc
+
+    def predict_step(self, batch, batch_idx=0, return_only_segmentation=False, *args, **kwargs):
+        """Forward pass on a batch or on a single un-batched volume (pl.py:347-373)."""
+        x, x_cond, x_fc = self.unpack_batch_prediction(batch)
+        single = x.dim() == self.spatial_dimensions + 1
+        if single:
+            x, x_cond, x_fc = (None if t is None else t.unsqueeze(0) for t in (x, x_cond, x_fc))
+        output = self.forward(X=x, X_skip_layer=x_cond, X_feature_conditioning=x_fc, *args,
+                              **kwargs)
+        if return_only_segmentation is True:
+            output = output[0]
+        return output[0] if single else output
+
+    def _evaluation_loss(self, batch):
+        """What validation_step / test_step return (pl.py:423-524): the step loss over micro-batches
+        of the training batch size, averaged. (Metric objects and PI-CAI lists are Lightning /
+        torchmetrics bookkeeping outside the path.)"""
+        x, x_cond, x_fc, y, y_class = self.unpack_batch(batch)
+        total = torch.zeros((), device=x.device, dtype=x.dtype)
+        bs = x.shape[0]
+        mbs = self.batch_size if self.train_batch_size is None else self.train_batch_size
+        for m in range(0, bs, mbs):
+            part = slice(m, m + mbs)
+            _, _, loss, class_loss = self.step(
+                x[part], y[part], None if y_class is None else y_class[part],
+                None if x_cond is None else x_cond[part],
+                x_fc[part] if x_cond is not None else None)   # sic: keyed on x_cond, pl.py:440
+            total = total + (loss.mean() if class_loss is None
+                             else loss.mean() + class_loss) / (bs // mbs)
+        return total
+
+    def validation_step(self, batch, batch_idx):
+        return self._evaluation_loss(batch)
+
+    def test_step(self, batch, batch_idx):
+        return self._evaluation_loss(batch)
+
     def log_loss(self, key, loss, **kwargs):
         for i in range(loss.nelement()):
             self.log(f"{key}_{i}", loss[i], sync_dist=True, prog_bar=True, **kwargs)

@@ -70,7 +70,7 @@ def test_unetpp_pl_step_matches_reference_deep_supervision_arithmetic(cuda):
         want = want + calc(o, y_small).mean() / (2 ** (t - i)) / (t + 1)
     batch = {"image": x.to(cuda), "mask": y.to(cuda)}
     got = net.training_step(batch, 0)
-    assert abs(float(got) - float(want.mean())) < 1e-4 * abs(float(want.mean()))
+    assert abs(float(got.detach()) - float(want.mean())) < 1e-4 * abs(float(want.mean()))
     # and a full optimiser step through the runner moves every parameter that has a gradient
     before = {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
     loss = StepRunner(net).train_step(batch)
@@ -104,3 +104,31 @@ def test_swin_pl_step(cuda):
     loss = StepRunner(net).train_step(batch)
     assert torch.isfinite(loss)
     _check_moved(net, before)
+
+
+def test_validation_test_and_predict_steps(cuda):
+    """validation_step / test_step = mean of the step loss over micro-batches of the training batch
+    size (pl.py:423-524); predict_step takes a batch or one un-batched volume (pl.py:347-373);
+    crop_if_necessary centre-crops the target (pl.py:258-282)."""
+    from cases import UNET_CASES
+
+    g = np.load(os.path.join(GOLD, "unet3d_cfg2_small.npz"))
+    net = _build("unet", UNET_CASES["unet3d_cfg2_small"], 2).to(cuda).eval()
+    x, y = torch.from_numpy(g["x"]).to(cuda), torch.from_numpy(g["y"]).to(cuda)
+    batch = {"image": x, "mask": y}
+    with torch.no_grad():
+        net.batch_size, net.train_batch_size = 2, None
+        whole = net.validation_step(batch, 0)
+        np.testing.assert_allclose(whole.item(), g["loss"], rtol=1e-4)
+        net.train_batch_size = 1      # two micro-batches of one item: the mean of their losses
+        halves = [net.step(x[i:i + 1], y[i:i + 1], None, None, None)[2].mean() for i in range(2)]
+        split = net.test_step(batch, 0)
+        np.testing.assert_allclose(split.item(), (halves[0].item() + halves[1].item()) / 2, rtol=1e-5)
+        pred = net.predict_step({"image": x}, return_only_segmentation=True)
+        np.testing.assert_allclose(pred.cpu().numpy(), g["prob"], rtol=1e-4, atol=1e-6)
+        one = net.predict_step({"image": x[1]}, return_only_segmentation=True)
+        assert one.shape == pred.shape[1:]
+        np.testing.assert_allclose(one.cpu().numpy(), g["prob"][1], rtol=1e-4, atol=1e-6)
+    net.make_uniform = True
+    yy, pp = net.crop_if_necessary(torch.zeros(1, 1, 10, 11, 12), torch.zeros(1, 1, 8, 8, 12))
+    assert tuple(yy.shape) == (1, 1, 8, 8, 12) and pp.shape[2] == 8
