@@ -1,0 +1,401 @@
+// 3x3x3 stride-1 convolutions whose input has 1..4 channels and whose output is wide (the
+// 2 -> 32 conv of the U-Net input block, unet.py:260-273; the 1 -> 16 conv of UNETR's first
+// encoder, unetr.py:225-237), as ONE small GEMM per brick on the fp32 MFMA:
+//
+//   forward          y[v][co]      = sum_k  A[v][k] W[k][co],   k = (tap, ci), K = 27 Cin <= 108
+//   weight gradient  dW[co][k]     = sum_v  dy[v][co] A[v][k]
+//
+// where A is the im2col row of voxel v. An MFMA tile of the general kernels pads Cin to a
+// 16-channel chunk PER TAP (8x the MFMA work and staging for Cin = 2; the x taps folded into one
+// chunk still leave it 2.7x), and the vector-ALU kernels issue 27 Cin Cout FMAs per voxel. Here
+// K = 27 Cin is the whole contraction: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32
+// accumulation) takes two k per step, the A values are gathered from a 10x10x6 input halo in LDS
+// (4.8 KB for Cin = 2) with one ds_read_b32 per MFMA, and the other operand lives in registers
+// (forward: the 27 Cin / 2 weight values of this lane's output channel; weight gradient: dY rows
+// read straight from global memory, 128 contiguous bytes per half-wave). Both directions are then
+// bound by the one pass over the wide tensor (y or dY).
+#include "common.h"
+
+struct CinFoldArgs {
+  const float* x;      // [N][D][H][W][Cin]
+  const float* w;      // canonical [Cout][Cin][27]
+  const float* bias;   // [Cout] or null
+  const float* dy;     // [N][Do][Ho][Wo][Cout] (weight gradient)
+  float* y;            // [N][Do][Ho][Wo][Cout]
+  float* part;         // forward: [N][ntiles][Cout][2] statistics partials or null
+  float* ws;           // weight gradient: [blocks][CoutPad][KP + 1] partial sums
+  int N, D, H, W, Cout, Do, Ho, Wo, PD, PH, PW;
+  int ntx, nty, ntz;
+};
+
+// The input halo of an 8x8x4 output brick, [6][10][10][CIN] floats, goes through registers:
+// `fetch` issues this thread's global loads (clamped addresses, zeros outside the volume), `put`
+// stores them to an LDS image later -- so the loads of the NEXT brick are in flight while the
+// MFMAs of the current one run.
+template <int CIN>
+struct CinFoldHalo {
+  static constexpr int PER = (600 * CIN + 255) / 256;
+  float v[PER];
+  __device__ __forceinline__ void fetch(const CinFoldArgs& a, int nb, int ox0, int oy0, int oz0) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      const int ci = i % CIN, hv = i / CIN;
+      const int hx = hv % 10, hy = (hv / 10) % 10, hz = hv / 100;
+      const int x = ox0 - a.PW + hx, y = oy0 - a.PH + hy, z = oz0 - a.PD + hz;
+      const bool ok = i < 600 * CIN && x >= 0 && x < a.W && y >= 0 && y < a.H && z >= 0 && z < a.D;
+      const size_t off = ok ? ((((size_t)nb * a.D + z) * a.H + y) * a.W + x) * CIN + ci : 0;
+      const float t = a.x[off];
+      v[u] = ok ? t : 0.f;
+    }
+  }
+  __device__ __forceinline__ void put(float* xh) const {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      if (i < 600 * CIN) xh[i] = v[u];
+    }
+  }
+};
+
+// LDS offset (floats) of im2col column k = tap * CIN + ci relative to the voxel's halo origin
+template <int CIN>
+__device__ __forceinline__ int adell_cinfold_koff(int k) {
+  const int tap = k / CIN, ci = k - tap * CIN;
+  const int kz = tap / 9, ky = (tap - 9 * kz) / 3, kx = tap - 9 * kz - 3 * ky;
+  return ((kz * 10 + ky) * 10 + kx) * CIN + ci;
+}
+
+struct CinFoldBrick {
+  int nb, tile, ox0, oy0, oz0;
+};
+__device__ __forceinline__ CinFoldBrick adell_cinfold_brick(const CinFoldArgs& a, int b, int nsp) {
+  CinFoldBrick k;
+  int t = b % nsp;
+  k.nb = b / nsp;
+  k.tile = t;
+  const int tx = t % a.ntx;
+  t /= a.ntx;
+  k.ox0 = tx * 8;
+  k.oy0 = (t % a.nty) * 8;
+  k.oz0 = (t / a.nty) * 4;
+  return k;
+}
+
+// grid (blocks, ceil(Cout / 32)), 256 threads. A block walks `per` consecutive bricks (over all
+// batch items) with its 27 Cin / 2 weight values per lane loaded once; wave w owns the z = w slice
+// of a brick (two 32-voxel M tiles), all waves the same 32 output channels. The halo image is
+// double buffered.
+template <int CIN>
+__global__ __launch_bounds__(256) void adell_cinfold_fwd_kernel(CinFoldArgs a, int total_bricks,
+                                                                int per) {
+  constexpr int KT = 27 * CIN, KS = (KT + 1) / 2;
+  __shared__ float xh[2][600 * CIN];
+  __shared__ float red[2][4][32][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32, col = n0 + li;
+  const bool colok = col < a.Cout;
+  const int nsp = a.ntx * a.nty * a.ntz;
+  const int b0 = blockIdx.x * per;
+  const int b1 = (b0 + per) < total_bricks ? (b0 + per) : total_bricks;
+  if (b0 >= b1) return;
+  float bf[KS];
+  int aoff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + lh;
+    const bool ok = k < KT;
+    aoff[s] = ok ? adell_cinfold_koff<CIN>(k) : 0;
+    const int tap = ok ? k / CIN : 0, ci = ok ? k - tap * CIN : 0;
+    const float t = a.w[((size_t)(colok ? col : 0) * CIN + ci) * 27 + tap];
+    bf[s] = (ok && colok) ? t : 0.f;
+  }
+  int abase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) abase[j] = ((wave * 10 + 4 * j + (li >> 3)) * 10 + (li & 7)) * CIN;
+  const float bcol = (a.bias && colok) ? a.bias[col] : 0.f;
+  CinFoldHalo<CIN> halo;
+  CinFoldBrick cur = adell_cinfold_brick(a, b0, nsp);
+  halo.fetch(a, cur.nb, cur.ox0, cur.oy0, cur.oz0);
+  halo.put(xh[0]);
+  __syncthreads();
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    CinFoldBrick nxt = cur;
+    if (b + 1 < b1) {
+      nxt = adell_cinfold_brick(a, b + 1, nsp);
+      halo.fetch(a, nxt.nb, nxt.ox0, nxt.oy0, nxt.oz0);   // in flight during the MFMAs below
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float* xb = xh[buf];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[abase[j] + aoff[s]], bf[s], acc[j], 0, 0, 0);
+    }
+    float s1 = 0.f, s2 = 0.f;
+    const int oz = cur.oz0 + wave;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // voxel of the M tile
+        const int ox = cur.ox0 + (row & 7), oy = cur.oy0 + 4 * j + (row >> 3);
+        if (colok && ox < a.Wo && oy < a.Ho && oz < a.Do) {
+          const float v = acc[j][r] + bcol;
+          a.y[((((size_t)cur.nb * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    if (a.part) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0) {
+        red[buf][wave][li][0] = s1;
+        red[buf][wave][li][1] = s2;
+      }
+    }
+    if (b + 1 < b1) halo.put(xh[buf ^ 1]);
+    __syncthreads();   // next halo image complete, this brick's statistics visible
+    if (a.part && tid < 32 && n0 + tid < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[buf][w][tid][0];
+        t2 += red[buf][w][tid][1];
+      }
+      float* p = a.part + (((size_t)cur.nb * nsp + cur.tile) * a.Cout + n0 + tid) * 2;
+      p[0] = t1;
+      p[1] = t2;
+    }
+    cur = nxt;
+  }
+}
+
+// Weight gradient. grid (blocks, ceil(Cout / 32)); a block walks bricks b = blockIdx.x,
+// blockIdx.x + gridDim.x, ... over all batch items and keeps dW[32 co][KP] in accumulators;
+// wave w takes the z = w slice of each brick (32 K steps of two voxels). The input halo image is
+// double buffered and the dY values of the next brick are fetched before the MFMAs of the
+// current one. Partial sums (and the bias gradient in column KP) go to ws[block][co][KP + 1];
+// adell_cinfold_wgrad_reduce folds them in block order.
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void adell_cinfold_wgrad_kernel(CinFoldArgs a, int total_bricks) {
+  constexpr int KT = 27 * CIN, NTL = (KT + 31) / 32, KP = NTL * 32;
+  __shared__ float xh[2][600 * CIN];
+  __shared__ float red[32][KP + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32, col = n0 + li;
+  const bool colok = col < a.Cout;
+  const int nsp = a.ntx * a.nty * a.ntz;
+  int boff[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt) {
+    const int k = nt * 32 + li;
+    boff[nt] = k < KT ? adell_cinfold_koff<CIN>(k) : -1;
+  }
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  float sdy = 0.f;
+  // this lane's dY values of a brick: voxel 2 s + lh of the wave's 8x8 slice, output channel col
+  auto fetch_dy = [&](const CinFoldBrick& k, float* av) {
+    const int oz = k.oz0 + wave;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int v = 2 * s + lh, ox = k.ox0 + (v & 7), oy = k.oy0 + (v >> 3);
+      const bool ok = colok && ox < a.Wo && oy < a.Ho && oz < a.Do;
+      const size_t off =
+          ok ? ((((size_t)k.nb * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + col : 0;
+      const float t = a.dy[off];
+      av[s] = ok ? t : 0.f;
+    }
+  };
+  CinFoldHalo<CIN> halo;
+  float av[2][32];
+  if (blockIdx.x < total_bricks) {
+    const CinFoldBrick k0 = adell_cinfold_brick(a, blockIdx.x, nsp);
+    halo.fetch(a, k0.nb, k0.ox0, k0.oy0, k0.oz0);
+    fetch_dy(k0, av[0]);
+    halo.put(xh[0]);
+  }
+  __syncthreads();
+  int it = 0;
+  for (int b = blockIdx.x; b < total_bricks; b += gridDim.x, ++it) {
+    const int buf = it & 1;
+    const bool more = b + (int)gridDim.x < total_bricks;
+    if (more) {
+      const CinFoldBrick kn = adell_cinfold_brick(a, b + gridDim.x, nsp);
+      halo.fetch(a, kn.nb, kn.ox0, kn.oy0, kn.oz0);
+    }
+    // (two static copies of the loop body so that av[buf] stays in registers)
+    auto body = [&](const float* cur, float* nxt) {
+      if (more) fetch_dy(adell_cinfold_brick(a, b + gridDim.x, nsp), nxt);
+      const float* xb = xh[buf];
+#pragma unroll
+      for (int s = 0; s < 32; ++s) {
+        const int v = 2 * s + lh;
+        const int vbase = ((wave * 10 + (v >> 3)) * 10 + (v & 7)) * CIN;
+        sdy += cur[s];
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+          const float bv = boff[nt] >= 0 ? xb[vbase + boff[nt]] : 0.f;
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[s], bv, acc[nt], 0, 0, 0);
+        }
+      }
+    };
+    if (buf == 0)
+      body(av[0], av[1]);
+    else
+      body(av[1], av[0]);
+    if (more) halo.put(xh[buf ^ 1]);
+    __syncthreads();
+  }
+  // fold the four waves in wave order (fixed order), then one partial row set per block
+  sdy += __shfl_xor(sdy, 32, 64);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;      // output channel of the tile
+          float* q = &red[row][nt * 32 + li];
+          *q = w == 0 ? acc[nt][r] : *q + acc[nt][r];
+        }
+      if (lh == 0) red[li][KP] = w == 0 ? sdy : red[li][KP] + sdy;
+    }
+    __syncthreads();
+  }
+  float* out = a.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 32 * (KP + 1);
+  for (int i = tid; i < 32 * (KP + 1); i += 256) out[i] = (&red[0][0])[i];
+}
+
+// dw[co][ci][tap] (and db[co]) = sum over the blocks' partials: one wave per output value, lane l
+// adds blocks l, l + 64, ... and the wave folds its 64 sums with the fixed xor-shuffle tree (a
+// thread per value walking 1024 strided partials in turn took longer than the MFMA kernel).
+__global__ __launch_bounds__(256) void adell_cinfold_wgrad_reduce_kernel(
+    const float* __restrict__ ws, int blocks, int ntile, int KP, int Cin, int Cout,
+    float* __restrict__ dw, float* __restrict__ db) {
+  const int KT = 27 * Cin;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= Cout * (KT + 1)) return;   // whole wave
+  const int co = i / (KT + 1), k = i - co * (KT + 1);
+  const bool is_db = k == KT;
+  if (is_db && !db) return;
+  const int kk = is_db ? KP : k;
+  const float* p = ws + ((size_t)(co >> 5) * 32 + (co & 31)) * (KP + 1) + kk;
+  const size_t stride = (size_t)ntile * 32 * (KP + 1);
+  float s = 0.f;
+  for (int b = lane; b < blocks; b += 64) s += p[(size_t)b * stride];
+  s = adell_wave_sum(s);
+  if (lane == 0) {
+    if (is_db) {
+      db[co] = s;
+    } else {
+      const int tap = k / Cin, ci = k - tap * Cin;
+      dw[((size_t)co * Cin + ci) * 27 + tap] = s;
+    }
+  }
+}
+
+static bool adell_cinfold_ok(const adell_conv3d_desc* d) {
+  return d && d->C1 == 0 && d->C0 >= 1 && d->C0 <= 4 && d->KD == 3 && d->KH == 3 && d->KW == 3 &&
+         d->SD == 1 && d->SH == 1 && d->SW == 1 && d->PD <= 1 && d->PH <= 1 && d->PW <= 1 &&
+         d->PD >= 0 && d->PH >= 0 && d->PW >= 0 && d->Cout >= 1 && d->N >= 1 && d->N <= 65535 &&
+         d->Do == d->D + 2 * d->PD - 2 && d->Ho == d->H + 2 * d->PH - 2 &&
+         d->Wo == d->W + 2 * d->PW - 2 && d->Do > 0 && d->Ho > 0 && d->Wo > 0;
+}
+
+extern "C" int adell_conv_cinfold_applicable(const adell_conv3d_desc* d) {
+  return adell_cinfold_ok(d) ? 1 : 0;
+}
+
+static void adell_cinfold_fill(CinFoldArgs* a, const adell_conv3d_desc* d) {
+  a->N = d->N; a->D = d->D; a->H = d->H; a->W = d->W; a->Cout = d->Cout;
+  a->Do = d->Do; a->Ho = d->Ho; a->Wo = d->Wo; a->PD = d->PD; a->PH = d->PH; a->PW = d->PW;
+  a->ntx = adell_cdiv(d->Wo, 8);
+  a->nty = adell_cdiv(d->Ho, 8);
+  a->ntz = adell_cdiv(d->Do, 4);
+}
+
+extern "C" int adell_conv_cinfold_ntiles(const adell_conv3d_desc* d) {
+  if (!adell_cinfold_ok(d)) return ADELL_E_BADARG;
+  return adell_cdiv(d->Wo, 8) * adell_cdiv(d->Ho, 8) * adell_cdiv(d->Do, 4);
+}
+
+extern "C" int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
+                                      const float* bias, float* y, float* stat_partials,
+                                      void* stream) {
+  ADELL_REQUIRE(x && w && y && adell_cinfold_ok(d),
+                "conv_cinfold_fwd: 3x3x3 stride-1 conv with 1..4 input channels expected");
+  CinFoldArgs a = {};
+  adell_cinfold_fill(&a, d);
+  a.x = x; a.w = w; a.bias = bias; a.y = y; a.part = stat_partials;
+  const long total = (long)d->N * a.ntx * a.nty * a.ntz;
+  ADELL_REQUIRE(total < 0x7fffffffL, "conv_cinfold_fwd: too many bricks");
+  // consecutive bricks per block: enough blocks to fill the chip several times over, few enough
+  // that the per-block weight loads and the first (exposed) halo fetch are amortised
+  int per = (int)(total / 4096);
+  if (per < 1) per = 1;
+  if (per > 16) per = 16;
+  dim3 grid((unsigned)((total + per - 1) / per), (unsigned)adell_cdiv(d->Cout, 32));
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->C0) {
+    case 1: hipLaunchKernelGGL(adell_cinfold_fwd_kernel<1>, grid, dim3(256), 0, st, a, (int)total, per); break;
+    case 2: hipLaunchKernelGGL(adell_cinfold_fwd_kernel<2>, grid, dim3(256), 0, st, a, (int)total, per); break;
+    case 3: hipLaunchKernelGGL(adell_cinfold_fwd_kernel<3>, grid, dim3(256), 0, st, a, (int)total, per); break;
+    default: hipLaunchKernelGGL(adell_cinfold_fwd_kernel<4>, grid, dim3(256), 0, st, a, (int)total, per); break;
+  }
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+static int adell_cinfold_wgrad_blocks(const adell_conv3d_desc* d) {
+  const long total = (long)d->N * adell_cdiv(d->Wo, 8) * adell_cdiv(d->Ho, 8) * adell_cdiv(d->Do, 4);
+  return (int)(total < 512 ? total : 512);   // two resident blocks per CU: one round
+}
+
+extern "C" long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d) {
+  if (!adell_cinfold_ok(d)) return ADELL_E_BADARG;
+  const int KP = adell_cdiv(27 * d->C0, 32) * 32;
+  return (long)sizeof(float) * adell_cinfold_wgrad_blocks(d) * adell_cdiv(d->Cout, 32) * 32 * (KP + 1);
+}
+
+extern "C" int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x,
+                                             const float* dy, float* dw, float* db,
+                                             void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  ADELL_REQUIRE(x && dy && dw && workspace && adell_cinfold_ok(d),
+                "conv_cinfold_bwd_weight: 3x3x3 stride-1 conv with 1..4 input channels expected");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_conv_cinfold_wgrad_workspace(d),
+                "conv_cinfold_bwd_weight: workspace too small");
+  CinFoldArgs a = {};
+  adell_cinfold_fill(&a, d);
+  a.x = x; a.dy = dy; a.ws = (float*)workspace;
+  const long total = (long)d->N * a.ntx * a.nty * a.ntz;
+  ADELL_REQUIRE(total < 0x7fffffffL, "conv_cinfold_bwd_weight: too many bricks");
+  const int blocks = adell_cinfold_wgrad_blocks(d), ntile = adell_cdiv(d->Cout, 32);
+  dim3 grid((unsigned)blocks, (unsigned)ntile);
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->C0) {
+    case 1: hipLaunchKernelGGL(adell_cinfold_wgrad_kernel<1>, grid, dim3(256), 0, st, a, (int)total); break;
+    case 2: hipLaunchKernelGGL(adell_cinfold_wgrad_kernel<2>, grid, dim3(256), 0, st, a, (int)total); break;
+    case 3: hipLaunchKernelGGL(adell_cinfold_wgrad_kernel<3>, grid, dim3(256), 0, st, a, (int)total); break;
+    default: hipLaunchKernelGGL(adell_cinfold_wgrad_kernel<4>, grid, dim3(256), 0, st, a, (int)total); break;
+  }
+  const int KP = adell_cdiv(27 * d->C0, 32) * 32;
+  const int outs = d->Cout * (27 * d->C0 + 1);
+  hipLaunchKernelGGL(adell_cinfold_wgrad_reduce_kernel, dim3(adell_cdiv(outs, 4)), dim3(256), 0, st,
+                     (const float*)workspace, blocks, ntile, KP, d->C0, d->Cout, dw, db);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

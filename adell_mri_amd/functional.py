@@ -186,6 +186,17 @@ class _Conv3dFn(torch.autograd.Function):
         stride, padding, want_stats, wref = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
         ctx.cin_small = wp == "cin_small"
+        ctx.cinfold = wp == "cinfold"
+        if ctx.cinfold:
+            y, part = ops.conv_cinfold_fwd(x0, weight, bias, padding, want_stats)
+            ctx.small1 = False
+            ctx.amax = None
+            ctx.save_for_backward(x0, x1, weight)
+            ctx.conf = (k, stride, padding, bias is not None, False, wref)
+            if part is None:
+                part = y.new_empty(0)
+            ctx.mark_non_differentiable(part)
+            return y, part
         if ctx.cin_small:  # 2-channel input block: exact fp32 on the vector ALU, canonical weights
             y, part = ops.conv_cin_small_fwd(x0, weight, bias, padding, want_stats)
             ctx.small1 = False
@@ -279,7 +290,10 @@ class _Conv3dFn(torch.autograd.Function):
             if x1 is None or not need[1]:
                 dx1 = None
         want_db = has_bias and need[3]
-        if need[2]:
+        if need[2] and getattr(ctx, "cinfold", False):
+            dw, db = ops.conv_cinfold_bwd_weight(x0, dy, padding, want_db)
+            dw = dw.view(weight.shape)
+        elif need[2]:
             dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db,
                                        f16x3=(CONV_PRECISION == "f16x3"),
                                        x_amax=None if amax is None else amax[0:1],
@@ -304,6 +318,8 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
         wp = None
     elif ops.conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
         wp = "cin_small"
+    elif ops.conv_cinfold_ok(weight, x0, x1, stride, padding, residual):
+        wp = "cinfold"   # K = 27 Cin im2col GEMM on the fp32 MFMA (forward, dW); dX: f16x3 igemm
     elif (CONV_PRECISION == "f16x3" and x1 is None and weight.dim() == 5 and x0.shape[1] <= 4
           and 3 <= weight.shape[4] and weight.shape[4] * x0.shape[1] <= 16
           and stride == (1, 1, 1) and not FLAGS["no_fold"]):

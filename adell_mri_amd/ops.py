@@ -84,7 +84,8 @@ class KernelTimer:
 
 KERNEL_TIMER = None
 # dispatch switches for A/B tests (read from the environment once at import)
-FLAGS = {"no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
+FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
+         "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
 
@@ -317,6 +318,59 @@ def conv_cin_small_bwd_data(dy, weight, in_size, padding):
                      ctypes.byref(d), _ptr(dy), _ptr(wc), _ptr(dx), _stream()),
                  _conv_tag(d, "dgrad"), _conv_bytes(d)))
     return dx
+
+
+# ---- 3x3x3 stride-1 conv with 1..4 input channels and a wide output: K = 27 Cin GEMM per brick ---
+def conv_cinfold_ok(weight, x0, x1, stride, padding, residual):
+    """True when the im2col-GEMM kernels (csrc/conv_cinfold.hip) take this conv: they replace the
+    x-tap fold + 16-channel MFMA chunk (forward) and the vector-ALU weight gradient."""
+    if residual is not None or x1 is not None or weight.dim() != 5 or x0.dim() != 5:
+        return False
+    if FLAGS.get("no_cinfold") or x0.shape[1] > 4 or weight.shape[0] <= 4:
+        return False
+    return (tuple(weight.shape[2:]) == (3, 3, 3) and tuple(stride) == (1, 1, 1)
+            and all(0 <= p <= 1 for p in padding))
+
+
+def conv_cinfold_fwd(x, weight, bias, padding, want_stats):
+    _require_cuda(x, weight, bias)
+    x = ndhwc(x)
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[0]
+    d = make_conv_desc(N, (D, H, W), Cin, 0, Cout, 3, 1, padding)
+    y = new_act(N, Cout, d.Do, d.Ho, d.Wo, x.device)
+    part = None
+    wc = weight.contiguous()   # bound to a local: must outlive the launch
+    if want_stats:
+        nt = _lib.lib().adell_conv_cinfold_ntiles(ctypes.byref(d))
+        if nt < 0:
+            check(nt)
+        part = torch.empty((N, nt, Cout, 2), device=x.device, dtype=torch.float32)
+    check(_timed("adell_cinfold_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv_cinfold_fwd(
+                     ctypes.byref(d), _ptr(x), _ptr(wc), _ptr(bias), _ptr(y), _ptr(part),
+                     _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
+    return y, part
+
+
+def conv_cinfold_bwd_weight(x, dy, padding, want_db):
+    """(dw [Cout, Cin, 3, 3, 3], db or None)."""
+    _require_cuda(x, dy)
+    x, dy = ndhwc(x), ndhwc(dy)
+    N, Cin, D, H, W = x.shape
+    Cout = dy.shape[1]
+    d = make_conv_desc(N, (D, H, W), Cin, 0, Cout, 3, 1, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    nbytes = _lib.lib().adell_conv_cinfold_wgrad_workspace(ctypes.byref(d))
+    check(min(nbytes, 0))
+    ws = _workspace(nbytes, x.device)
+    dw = torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_db else None
+    check(_timed("adell_cinfold_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv_cinfold_bwd_weight(
+                     ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+                     ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"), _conv_bytes(d)))
+    return dw, db
 
 
 # ---- 1x1x1 convolution with Cout <= 4 (logits head): canonical weights, one pass each way ----

@@ -475,6 +475,21 @@ int adell_loco_loss_fwd(const float* f1, const float* f2, int B, long S, int C, 
 int adell_loco_loss_bwd(const float* f1, const float* f2, const float* gloss, int B, long S, int C,
                         float temperature, float eps, float* df1, float* df2, void* stream);
 
+/* 3x3x3 stride-1 convolution with 1..4 input channels and a wide output (the 2 -> 32 conv of the
+ * U-Net input block, unet.py:260-273; UNETR's first encoder, unetr.py:225-237) as one small GEMM per
+ * brick over K = 27 Cin on the fp32 MFMA (exact fp32 products): forward (+ bias, + the statistics
+ * partials [N][adell_conv_cinfold_ntiles][Cout][2] of the fused norm) and weight / bias gradient.
+ * x [N][D][H][W][Cin], w / dw canonical [Cout][Cin][3][3][3]. `applicable` tells whether a
+ * descriptor takes this path. */
+int adell_conv_cinfold_applicable(const adell_conv3d_desc* d);
+int adell_conv_cinfold_ntiles(const adell_conv3d_desc* d);
+int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
+                           const float* bias, float* y, float* stat_partials, void* stream);
+long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d);
+int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x, const float* dy,
+                                  float* dw, float* db, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* 1x1x1 convolution with Cout <= 4 (the logits head, unet.py:712-731) on canonical weights
  * w [Cout][C0+C1]: one HBM-bound pass each way. `applicable` tells whether a descriptor takes
  * this path (k = 1, stride 1, no padding, Cout <= 4, Cin <= 512). */
