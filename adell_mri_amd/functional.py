@@ -266,7 +266,11 @@ class _Conv3dFn(torch.autograd.Function):
             return dx0, dx1, dw, db, None, None, None
         amax = ctx.amax
         dy_amax = None
-        if ctx.cin_small and need[0] and dy.shape[1] % 4 == 0:
+        if getattr(ctx, "cinfold", False) and need[0]:
+            dx0 = ops.conv_cinfold_bwd_data(dy, weight, tuple(x0.shape[2:]), padding)
+        if dx0 is not None:
+            pass
+        elif ctx.cin_small and need[0] and dy.shape[1] % 4 == 0:
             dx0 = ops.conv_cin_small_bwd_data(dy, weight, tuple(x0.shape[2:]), padding)
         elif (need[0] and x1 is None and CONV_PRECISION == "f16x3" and stride == (2, 2, 2)
               and k == (3, 3, 3) and all(p <= 1 for p in padding)

@@ -373,6 +373,26 @@ def conv_cinfold_bwd_weight(x, dy, padding, want_db):
     return dw, db
 
 
+def conv_cinfold_bwd_data(dy, weight, in_size, padding):
+    """dx [N, Cin, *in_size] of a narrow-input conv, or None when the kernel does not take the
+    shape (Cout > 64 or not a multiple of 4: the caller falls to the implicit-GEMM kernel)."""
+    _require_cuda(dy, weight)
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    Cin = weight.shape[1]
+    d = make_conv_desc(N, tuple(in_size), Cin, 0, Cout, 3, 1, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    if not _lib.lib().adell_conv_cinfold_dx_applicable(ctypes.byref(d)):
+        return None
+    dx = new_act(N, Cin, *in_size, dy.device)
+    wc = weight.contiguous()
+    check(_timed("adell_cinfold_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv_cinfold_bwd_data(
+                     ctypes.byref(d), _ptr(dy), _ptr(wc), _ptr(dx), _stream()),
+                 _conv_tag(d, "dgrad"), _conv_bytes(d)))
+    return dx
+
+
 # ---- 1x1x1 convolution with Cout <= 4 (logits head): canonical weights, one pass each way ----
 def conv1_small_ok(weight, Cin, stride, padding, residual):
     return (residual is None and weight.dim() == 5 and tuple(weight.shape[2:]) == (1, 1, 1)

@@ -489,6 +489,12 @@ long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d);
 int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x, const float* dy,
                                   float* dw, float* db, void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* backward-data of the same convs (dx has 1..4 channels): one GEMM per dY voxel over K = Cout
+ * (Cout <= 64, multiple of 4) into the 27 Cin (tap, channel) columns, gathered into dx along a
+ * z march. dy 16-byte aligned. */
+int adell_conv_cinfold_dx_applicable(const adell_conv3d_desc* d);
+int adell_conv_cinfold_bwd_data(const adell_conv3d_desc* d, const float* dy, const float* w,
+                                float* dx, void* stream);
 
 /* 1x1x1 convolution with Cout <= 4 (the logits head, unet.py:712-731) on canonical weights
  * w [Cout][C0+C1]: one HBM-bound pass each way. `applicable` tells whether a descriptor takes

@@ -14,7 +14,7 @@ from oracle import cops
 pytestmark = pytest.mark.gpu
 
 CASES = [  # N, Cin, size, Cout, pad
-    (2, 2, (16, 16, 16), 32, 1), (1, 1, (9, 13, 11), 16, 1), (1, 3, (8, 8, 8), 40, 1),
+    (2, 2, (16, 16, 16), 32, 1), (1, 2, (40, 12, 9), 64, 1), (1, 1, (33, 8, 8), 16, 0), (1, 1, (9, 13, 11), 16, 1), (1, 3, (8, 8, 8), 40, 1),
     (1, 4, (12, 10, 9), 72, 1), (2, 2, (10, 11, 12), 32, 0), (1, 2, (5, 6, 7), 8, 1),
     (1, 1, (32, 32, 32), 16, 1), (3, 2, (4, 4, 4), 33, 1)]
 
@@ -31,7 +31,7 @@ def test_cinfold_forward_and_weight_gradient_match_oracle(cuda, N, Cin, size, Co
     b = rng.standard_normal(Cout).astype(np.float32)
     ref = cops.conv3d(x, w, b, 1, pad)
     dy = rng.standard_normal(ref.shape).astype(np.float32)
-    _, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, 1, pad)
+    dx_ref, dw_ref, db_ref = cops.conv3d_bwd(x, w, dy, 1, pad)
     xd = ops.ndhwc(torch.from_numpy(x).to(cuda))
     wd, bd = torch.from_numpy(w).to(cuda), torch.from_numpy(b).to(cuda)
     assert ops.conv_cinfold_ok(wd, xd, None, (1, 1, 1), (pad,) * 3, None) == (Cout > 4)
@@ -47,6 +47,11 @@ def test_cinfold_forward_and_weight_gradient_match_oracle(cuda, N, Cin, size, Co
     dw, db = ops.conv_cinfold_bwd_weight(xd, dyd, (pad,) * 3, True)
     assert _rel(dw.cpu().numpy(), dw_ref) < 5e-6
     assert _rel(db.cpu().numpy(), db_ref) < 5e-6
+    dx = ops.conv_cinfold_bwd_data(dyd, wd, size, (pad,) * 3)
+    if Cout <= 64 and Cout % 4 == 0:
+        assert _rel(dx.cpu().numpy(), dx_ref) < 5e-6
+    else:
+        assert dx is None
     dw2, none = ops.conv_cinfold_bwd_weight(xd, dyd, (pad,) * 3, False)
     assert none is None and torch.equal(dw, dw2)      # deterministic fold order
 

@@ -1,6 +1,7 @@
 """A/B of one launch-plan switch on the bench workload, alternating blocks of steps inside ONE
 process on ONE box (box-to-box and clock-ramp noise is +-0.3 ms of a 40 ms step, more than most
-single changes). usage: ab_step.py switch [value] [rounds] [steps per block]"""
+single changes). usage: ab_step.py switch [value] [rounds] [steps per block]   (switch: a launch-plan switch of
+adell_set_tuning, or py:<name> for a dispatch flag of ops.FLAGS)"""
 import json
 import os
 import statistics
@@ -25,14 +26,30 @@ net.train()
 opt = net.configure_optimizers()["optimizer"]
 runner = StepRunner(net, opt, GradSync(opt))
 batch = bench.synthetic_batch(int(net.batch_size), (128, 128, 128), dev, 42)
-base = _lib.lib().adell_get_tuning(switch.encode())
+PY = switch.startswith("py:")       # "py:no_cinfold": a Python-level dispatch flag (ops.FLAGS)
+if PY:
+    from adell_mri_amd import ops  # noqa: E402
+
+
+def get_switch():
+    return int(bool(ops.FLAGS[switch[3:]])) if PY else _lib.lib().adell_get_tuning(switch.encode())
+
+
+def set_switch(v):
+    if PY:
+        ops.FLAGS[switch[3:]] = bool(v)
+    else:
+        _lib.lib().adell_set_tuning(switch.encode(), v)
+
+
+base = get_switch()
 for _ in range(6):
     runner.train_step(batch)
 torch.cuda.synchronize()
 res = {0: [], 1: []}
 for r in range(rounds):
     for which in (0, 1):
-        _lib.lib().adell_set_tuning(switch.encode(), value if which else base)
+        set_switch(value if which else base)
         runner.train_step(batch)          # settle (weights repacked, allocator)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,7 +59,7 @@ for r in range(rounds):
         e1.record()
         torch.cuda.synchronize()
         res[which].append(e0.elapsed_time(e1) / steps)
-_lib.lib().adell_set_tuning(switch.encode(), base)
+set_switch(base)
 print(json.dumps({"switch": switch, "base_value": base, "test_value": value,
                   "ms_per_step_base": round(statistics.median(res[0]), 3),
                   "ms_per_step_test": round(statistics.median(res[1]), 3),
