@@ -120,6 +120,11 @@ SIGNATURES = {
     "adell_vicreg_scratch_floats": (_l, [_i, _i]),
     "adell_vicreg_fwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp]),
     "adell_vicreg_bwd": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_convt_k2_applicable": (_i, [_i] * 6),
+    "adell_convt_k2_fwd": (_i, [_i] * 6 + [_vp] * 5),
+    "adell_convt_k2_bwd_data": (_i, [_i] * 6 + [_vp] * 4),
+    "adell_convt_k2_wgrad_workspace": (_l, [_i] * 6),
+    "adell_convt_k2_bwd_weight": (_i, [_i] * 6 + [_vp] * 4 + [ctypes.c_size_t, _vp]),
     "adell_conv_cinfold_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),

@@ -1,0 +1,315 @@
+// ConvTranspose3d with kernel = stride = 2 on every axis and 32 / 64 channels on both sides (the
+// decoder upscaling of the high-resolution U-Net levels, unet.py:445-458) as streaming GEMMs on the
+// fp32 MFMA (exact fp32 products). Every input voxel v feeds exactly the 8 output voxels 2 v + f:
+//
+//   forward   y[2v + f][co]  = b[co] + sum_ci x[v][ci] w[ci][co][f]      M = v, K = Cin,   N = (f, co)
+//   dX        dx[v][ci]      = sum_{f, co} dy[2v + f][co] w[ci][co][f]   M = v, K = (f, co), N = ci
+//   dW        dw[ci][co][f]  = sum_v x[v][ci] dy[2v + f][co]             M = ci, K = v,     N = (f, co)
+//
+// The implicit-GEMM kernels treat these as convolutions with a one-voxel halo and a pixel-shuffle
+// store, 4 blocks per CU of staging-bound work (0.28 / 0.39 / 0.34 ms at 2 x 64^3 -> 128^3, 32
+// channels); nothing here needs a halo, so a wave takes 32 consecutive input voxels, the (fz, fy)
+// pair of its wave index (both fx: 2 Cout contiguous floats per voxel on the fine grid) and streams:
+// operands go through a wave-private LDS tile (coalesced float4 loads, conflict-free column reads),
+// weights live in registers, and the only traffic is the one pass over the fine-grid tensor.
+#include "common.h"
+
+struct ConvTK2Args {
+  const float* x;     // [N][D][H][W][Cin]
+  const float* w;     // canonical ConvTranspose weight [Cin][Cout][2][2][2]
+  const float* bias;  // [Cout] or null
+  const float* dy;    // [N][2D][2H][2W][Cout]
+  float* y;           // [N][2D][2H][2W][Cout]
+  float* dx;          // [N][D][H][W][Cin]
+  float* ws;          // dW partials [blocks][pairs][8 f][32 ci][32 co]
+  int N, D, H, W, Cin, Cout;
+  long V;             // N D H W
+  int ntiles;         // ceil(V / 32)
+};
+
+// fine-grid row (in units of voxels) of coarse voxel v at offset (fz, fy, fx = 0); v < 2^31
+// (checked on the host): 32-bit divisions
+__device__ __forceinline__ size_t adell_ctk2_fine(const ConvTK2Args& a, long v64, int fz, int fy) {
+  const unsigned v = (unsigned)v64, W = (unsigned)a.W, H = (unsigned)a.H, D = (unsigned)a.D;
+  const unsigned t1 = v / W, x = v - t1 * W;
+  const unsigned t2 = t1 / H, y = t1 - t2 * H;
+  const unsigned n = t2 / D, z = t2 - n * D;
+  return (((size_t)n * 2 * D + 2 * z + fz) * 2 * H + 2 * y + fy) * 2 * W + 2 * x;
+}
+
+__device__ __forceinline__ size_t adell_ctk2_shfl(size_t v, int src) {
+  const unsigned lo = __shfl((unsigned)v, src, 64), hi = __shfl((unsigned)(v >> 32), src, 64);
+  return ((size_t)hi << 32) | lo;
+}
+
+// wave-private copy of 32 rows x WIDTH floats into an LDS tile with row stride `ld`: lane l holds
+// the element offset of row l & 31 in `myrow` (the address arithmetic of a row is done once, by one
+// lane); rows >= valid are zero-filled. All loads are issued before the first LDS store.
+template <int WIDTH>
+__device__ __forceinline__ void adell_ctk2_stage(float* tile, int ld, int valid, int lane,
+                                                 const float* src, size_t myrow, int col0 = 0) {
+  constexpr int W4 = WIDTH / 4, PER = 32 * W4 / 64;
+  float4 f[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = lane + 64 * u, r = i / W4, c4 = i - r * W4;
+    const size_t off = adell_ctk2_shfl(myrow, r);
+    f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < valid) f[u] = *reinterpret_cast<const float4*>(src + off + col0 + 4 * c4);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int i = lane + 64 * u, r = i / W4, c4 = i - r * W4;
+    float* q = tile + r * ld + 4 * c4;
+    q[0] = f[u].x; q[1] = f[u].y; q[2] = f[u].z; q[3] = f[u].w;
+  }
+}
+
+// ---- forward: grid (blocks, Cout / 32); wave w = (fz, fy), both fx ------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void adell_convt_k2_fwd_kernel(ConvTK2Args a) {
+  constexpr int LD = CIN + 1, KS = CIN / 2;
+  __shared__ float sx[4][32 * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int fz = wave >> 1, fy = wave & 1, n0 = blockIdx.y * 32, col = n0 + li;
+  float bw[2][KS];
+#pragma unroll
+  for (int fx = 0; fx < 2; ++fx)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      bw[fx][s] = a.w[((size_t)(2 * s + lh) * a.Cout + col) * 8 + (fz * 2 + fy) * 2 + fx];
+  const float bcol = a.bias ? a.bias[col] : 0.f;
+  float* tile = sx[wave];
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    adell_ctk2_stage<CIN>(tile, LD, valid, lane, a.x + (size_t)v0 * CIN, (size_t)li * CIN);
+    const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) : 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done
+    f32x16 acc[2];
+#pragma unroll
+    for (int fx = 0; fx < 2; ++fx)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[fx][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float av = tile[li * LD + 2 * s + lh];
+#pragma unroll
+      for (int fx = 0; fx < 2; ++fx)
+        acc[fx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[fx][s], acc[fx], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < valid) {
+        float* o = a.y + adell_ctk2_shfl(yrow, row) * a.Cout + col;
+        o[0] = acc[0][r] + bcol;
+        o[a.Cout] = acc[1][r] + bcol;
+      }
+    }
+  }
+}
+
+// ---- backward-data: grid (blocks, Cin / 32); wave w = (fz, fy) owns a K slice of 2 Cout ---------
+template <int COUT>
+__global__ __launch_bounds__(256) void adell_convt_k2_dx_kernel(ConvTK2Args a) {
+  constexpr int KW = 2 * COUT, LD = KW + 1, KS = KW / 2;
+  extern __shared__ float smem[];
+  float* sred = smem + 4 * 32 * LD;   // [3][32][33] partial tiles of waves 1..3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int fz = wave >> 1, fy = wave & 1, n0 = blockIdx.y * 32, ci = n0 + li;
+  float bw[KS];   // B[k = (fx, co)][j = ci]
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + lh, fx = k / COUT, co = k - fx * COUT;
+    bw[s] = a.w[((size_t)ci * COUT + co) * 8 + (fz * 2 + fy) * 2 + fx];
+  }
+  float* tile = smem + wave * 32 * LD;
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    adell_ctk2_stage<KW>(tile, LD, valid, lane, a.dy,
+                         li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) * COUT : 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[li * LD + 2 * s + lh], bw[s], acc, 0, 0, 0);
+    // fold the four K slices in wave order: waves 1..3 park theirs, wave 0 adds and stores
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        sred[((wave - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < valid)
+          a.dx[(size_t)(v0 + row) * a.Cin + ci] =
+              ((acc[r] + sred[row * 33 + li]) + sred[(32 + row) * 33 + li]) +
+              sred[(64 + row) * 33 + li];
+      }
+    }
+    __syncthreads();   // sred is free again
+  }
+}
+
+// ---- weight gradient: grid (blocks, (Cin / 32) (Cout / 32)); wave w = (fz, fy), both fx --------
+__global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
+  constexpr int LDX = 33, LDY = 65;
+  __shared__ float sx[4][32 * LDX];
+  __shared__ float sy[4][32 * LDY];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int fz = wave >> 1, fy = wave & 1;
+  const int nct = a.Cout / 32, ci0 = (blockIdx.y / nct) * 32, co0 = (blockIdx.y % nct) * 32;
+  f32x16 acc[2];
+#pragma unroll
+  for (int fx = 0; fx < 2; ++fx)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[fx][r] = 0.f;
+  float* tx = sx[wave];
+  float* tyl = sy[wave];
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) * a.Cout : 0;
+    adell_ctk2_stage<32>(tx, LDX, valid, lane, a.x + (size_t)v0 * a.Cin + ci0, (size_t)li * a.Cin);
+    // the two fine-grid voxels (fx = 0, 1) of a coarse voxel are adjacent rows of Cout floats
+    adell_ctk2_stage<32>(tyl, LDY, valid, lane, a.dy, yrow, co0);
+    adell_ctk2_stage<32>(tyl + 32, LDY, valid, lane, a.dy, yrow, a.Cout + co0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int v = 2 * s + lh;
+      const float av = tx[v * LDX + li];                 // A[i = ci][k = v]
+#pragma unroll
+      for (int fx = 0; fx < 2; ++fx)
+        acc[fx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tyl[v * LDY + fx * 32 + li], acc[fx],
+                                                        0, 0, 0);
+    }
+  }
+  // every wave owns its own two f: no fold inside the block
+  float* out = a.ws + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8) * 1024;
+#pragma unroll
+  for (int fx = 0; fx < 2; ++fx)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // ci
+      out[(size_t)((fz * 2 + fy) * 2 + fx) * 1024 + row * 32 + li] = acc[fx][r];
+    }
+}
+
+// dw[ci][co][f] = sum over blocks: one wave per value (lane l adds blocks l, l + 64, ...)
+__global__ __launch_bounds__(256) void adell_convt_k2_dw_reduce_kernel(
+    const float* __restrict__ ws, int blocks, int Cin, int Cout, float* __restrict__ dw) {
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= (long)Cin * Cout * 8) return;   // whole wave
+  const int f = (int)(i & 7);
+  const long cc = i >> 3;
+  const int co = (int)(cc % Cout), ci = (int)(cc / Cout);
+  const int nct = Cout / 32, pairs = (Cin / 32) * nct;
+  const int pair = (ci >> 5) * nct + (co >> 5);
+  const float* p = ws + ((size_t)pair * 8 + f) * 1024 + (ci & 31) * 32 + (co & 31);
+  const size_t stride = (size_t)pairs * 8 * 1024;
+  float s = 0.f;
+  for (int b = lane; b < blocks; b += 64) s += p[(size_t)b * stride];
+  s = adell_wave_sum(s);
+  if (lane == 0) dw[i] = s;
+}
+
+static bool adell_convt_k2_ok(int N, int D, int H, int W, int Cin, int Cout) {
+  return N >= 1 && D >= 1 && H >= 1 && W >= 1 && (Cin == 32 || Cin == 64) &&
+         (Cout == 32 || Cout == 64) && (long)N * D * H * W >= 32768 &&
+         (long)N * D * H * W < 0x7fffffe0L;
+}
+
+// 1 when the streaming kernels take this problem (factors 2x2x2, 32 / 64 channels, >= 32 K voxels)
+extern "C" int adell_convt_k2_applicable(int N, int D, int H, int W, int Cin, int Cout) {
+  return adell_convt_k2_ok(N, D, H, W, Cin, Cout) ? 1 : 0;
+}
+
+static void adell_ctk2_fill(ConvTK2Args* a, int N, int D, int H, int W, int Cin, int Cout) {
+  a->N = N; a->D = D; a->H = H; a->W = W; a->Cin = Cin; a->Cout = Cout;
+  a->V = (long)N * D * H * W;
+  a->ntiles = (int)((a->V + 31) / 32);
+}
+static int adell_ctk2_blocks(const ConvTK2Args& a, int per_cu) {
+  const int want = 256 * per_cu;
+  return a.ntiles < want ? a.ntiles : want;
+}
+
+extern "C" int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                                  const float* w, const float* bias, float* y, void* stream) {
+  ADELL_REQUIRE(x && w && y && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
+                "convt_k2_fwd: factor-2 transposed conv with 32 / 64 channels expected");
+  ADELL_REQUIRE(((uintptr_t)x & 15) == 0, "convt_k2_fwd: x must be 16-byte aligned");
+  ConvTK2Args a = {};
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  a.x = x; a.w = w; a.bias = bias; a.y = y;
+  dim3 grid((unsigned)adell_ctk2_blocks(a, 8), (unsigned)(Cout / 32));
+  if (Cin == 32)
+    hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_convt_k2_bwd_data(int N, int D, int H, int W, int Cin, int Cout,
+                                       const float* dy, const float* w, float* dx, void* stream) {
+  ADELL_REQUIRE(dy && w && dx && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
+                "convt_k2_bwd_data: factor-2 transposed conv with 32 / 64 channels expected");
+  ADELL_REQUIRE(((uintptr_t)dy & 15) == 0, "convt_k2_bwd_data: dy must be 16-byte aligned");
+  ConvTK2Args a = {};
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  a.dy = dy; a.w = w; a.dx = dx;
+  const size_t lds = (size_t)(4 * 32 * (2 * Cout + 1) + 3 * 32 * 33) * sizeof(float);
+  dim3 grid((unsigned)adell_ctk2_blocks(a, 4), (unsigned)(Cin / 32));
+  static bool attr_done = false;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_convt_k2_dx_kernel<64>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  if (Cout == 32)
+    hipLaunchKernelGGL(adell_convt_k2_dx_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(adell_convt_k2_dx_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+  if (!adell_convt_k2_ok(N, D, H, W, Cin, Cout)) return ADELL_E_BADARG;
+  ConvTK2Args a = {};
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  return (long)sizeof(float) * adell_ctk2_blocks(a, 2) * (Cin / 32) * (Cout / 32) * 8 * 1024;
+}
+
+extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout,
+                                         const float* x, const float* dy, float* dw,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(x && dy && dw && workspace && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
+                "convt_k2_bwd_weight: factor-2 transposed conv with 32 / 64 channels expected");
+  ADELL_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
+                "convt_k2_bwd_weight: x and dy must be 16-byte aligned");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_convt_k2_wgrad_workspace(N, D, H, W, Cin, Cout),
+                "convt_k2_bwd_weight: workspace too small");
+  ConvTK2Args a = {};
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  a.x = x; a.dy = dy; a.ws = (float*)workspace;
+  const int blocks = adell_ctk2_blocks(a, 2);
+  dim3 grid((unsigned)blocks, (unsigned)((Cin / 32) * (Cout / 32)));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_convt_k2_dw_kernel, grid, dim3(256), 0, st, a);
+  const long outs = (long)Cin * Cout * 8;
+  hipLaunchKernelGGL(adell_convt_k2_dw_reduce_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0,
+                     st, (const float*)workspace, blocks, Cin, Cout, dw);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

@@ -340,7 +340,11 @@ class _ConvT3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, wp, wref):
         factors = tuple(weight.shape[2:])
-        y = ops.convtranspose3d_fwd(x, wp, bias, weight.shape[1], factors)
+        ctx.k2 = wp is None    # streaming factor-2 kernels on the canonical weight
+        if ctx.k2:
+            y = ops.convt_k2_fwd(x, weight, bias)
+        else:
+            y = ops.convtranspose3d_fwd(x, wp, bias, weight.shape[1], factors)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.wref = wref
@@ -354,10 +358,12 @@ class _ConvT3dFn(torch.autograd.Function):
         dy = ops.ndhwc(dy)
         dx = dw = db = None
         if need[0]:
-            dx = ops.convtranspose3d_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0],
-                                              ctx.factors)
+            dx = (ops.convt_k2_bwd_data(dy, weight) if ctx.k2 else
+                  ops.convtranspose3d_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0],
+                                               ctx.factors))
         if need[1]:
-            dw = ops.convtranspose3d_bwd_weight(x, dy, ctx.factors)
+            dw = (ops.convt_k2_bwd_weight(x, dy) if ctx.k2 else
+                  ops.convtranspose3d_bwd_weight(x, dy, ctx.factors))
         if ctx.has_bias and need[2]:
             db = ops.bias_grad(dy)
         return dx, dw, db, None, None
@@ -365,7 +371,8 @@ class _ConvT3dFn(torch.autograd.Function):
 
 def conv_transpose3d(x, weight, bias=None):
     """ConvTranspose3d whose kernel equals its stride (each 1 or 2 per dim), padding 0."""
-    return _ConvT3dFn.apply(x, weight, bias, _packed(weight, 2), _Ref(weight))
+    wp = None if (x.dim() == 5 and ops.convt_k2_ok(x.shape, weight)) else _packed(weight, 2)
+    return _ConvT3dFn.apply(x, weight, bias, wp, _Ref(weight))
 
 
 conv_transpose3d_k2s2 = conv_transpose3d

@@ -85,6 +85,7 @@ class KernelTimer:
 KERNEL_TIMER = None
 # dispatch switches for A/B tests (read from the environment once at import)
 FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
+         "no_convt_k2": bool(os.environ.get("ADELL_NO_CONVT_K2")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
@@ -572,6 +573,61 @@ def convtranspose3d_bwd_weight(x, dy, factors=(2, 2, 2)):
     check(_timed("adell_conv_wgrad_kernel", flops, lambda: _lib.lib().adell_convtranspose3d_bwd_weight(
         N, D, H, W, Cin, Cout, fd, fh, fw, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), ws.numel() * 4,
         _stream())))
+    return dw
+
+
+# ---- factor-2 transposed conv with 32 / 64 channels: streaming GEMMs, canonical weights ----------
+def convt_k2_ok(x_shape, weight):
+    """True when csrc/convt_k2.hip takes ConvTranspose3d(x) with this weight [Cin, Cout, 2, 2, 2]."""
+    if FLAGS.get("no_convt_k2") or weight.dim() != 5 or tuple(weight.shape[2:]) != (2, 2, 2):
+        return False
+    N, _, D, H, W = x_shape
+    return bool(_lib.lib().adell_convt_k2_applicable(N, D, H, W, weight.shape[0], weight.shape[1]))
+
+
+def convt_k2_fwd(x, weight, bias):
+    _require_cuda(x, weight, bias)
+    x = ndhwc(x)
+    N, Cin, D, H, W = x.shape
+    Cout = weight.shape[1]
+    y = new_act(N, Cout, 2 * D, 2 * H, 2 * W, x.device)
+    wc = weight.contiguous()   # bound to a local: must outlive the launch
+    check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
+                 lambda: _lib.lib().adell_convt_k2_fwd(N, D, H, W, Cin, Cout, _ptr(x), _ptr(wc),
+                                                       _ptr(bias), _ptr(y), _stream()),
+                 f"convT fwd {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (x.numel() + y.numel())))
+    return y
+
+
+def convt_k2_bwd_data(dy, weight):
+    _require_cuda(dy, weight)
+    dy = ndhwc(dy)
+    N, Cout, D2, H2, W2 = dy.shape
+    Cin = weight.shape[0]
+    D, H, W = D2 // 2, H2 // 2, W2 // 2
+    dx = new_act(N, Cin, D, H, W, dy.device)
+    wc = weight.contiguous()
+    check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
+                 lambda: _lib.lib().adell_convt_k2_bwd_data(N, D, H, W, Cin, Cout, _ptr(dy),
+                                                            _ptr(wc), _ptr(dx), _stream()),
+                 f"convT dgrad {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (dy.numel() + dx.numel())))
+    return dx
+
+
+def convt_k2_bwd_weight(x, dy):
+    _require_cuda(x, dy)
+    x, dy = ndhwc(x), ndhwc(dy)
+    N, Cin, D, H, W = x.shape
+    Cout = dy.shape[1]
+    nbytes = _lib.lib().adell_convt_k2_wgrad_workspace(N, D, H, W, Cin, Cout)
+    check(min(nbytes, 0))
+    ws = _workspace(nbytes, x.device)
+    dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
+    check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
+                 lambda: _lib.lib().adell_convt_k2_bwd_weight(
+                     N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
+                     ws.numel() * 4, _stream()),
+                 f"convT wgrad {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (x.numel() + dy.numel())))
     return dw
 
 

@@ -475,6 +475,22 @@ int adell_loco_loss_fwd(const float* f1, const float* f2, int B, long S, int C, 
 int adell_loco_loss_bwd(const float* f1, const float* f2, const float* gloss, int B, long S, int C,
                         float temperature, float eps, float* df1, float* df2, void* stream);
 
+/* ConvTranspose3d with kernel = stride = 2 on all three axes and 32 / 64 channels on both sides
+ * (unet.py:445-458, the upscaling of the high-resolution decoder levels) as streaming GEMMs on the
+ * fp32 MFMA: every input voxel feeds exactly its 8 output voxels, so nothing needs a halo or a
+ * packed weight. w / dw: torch's canonical [Cin][Cout][2][2][2]. `applicable`: factors 2x2x2,
+ * channels in {32, 64}, at least 32 768 input voxels (below that the implicit-GEMM entry points
+ * above stay in use). x / dy 16-byte aligned. */
+int adell_convt_k2_applicable(int N, int D, int H, int W, int Cin, int Cout);
+int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                       const float* w, const float* bias, float* y, void* stream);
+int adell_convt_k2_bwd_data(int N, int D, int H, int W, int Cin, int Cout, const float* dy,
+                            const float* w, float* dx, void* stream);
+long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout);
+int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                              const float* dy, float* dw, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
 /* 3x3x3 stride-1 convolution with 1..4 input channels and a wide output (the 2 -> 32 conv of the
  * U-Net input block, unet.py:260-273; UNETR's first encoder, unetr.py:225-237) as one small GEMM per
  * brick over K = 27 Cin on the fp32 MFMA (exact fp32 products): forward (+ bias, + the statistics
