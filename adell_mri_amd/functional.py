@@ -180,11 +180,30 @@ def _packed_folded(w):
     return p
 
 
+# absmax by-product slots ([0]: input(s) of a conv, [1]: its dy), zeroed in bulk: every slot is
+# handed out once and never reused, so a slot stays valid as long as the graph that holds it --
+# one fill per 256 conv calls instead of one per call
+_AMAX_ARENA = {"buf": None, "next": 0}
+
+
+def _amax_pair(device):
+    a = _AMAX_ARENA
+    if a["buf"] is None or a["buf"].device != device or a["next"] + 2 > a["buf"].numel():
+        a["buf"] = torch.zeros(512, device=device, dtype=torch.int32)
+        a["next"] = 0
+    pair = a["buf"][a["next"]:a["next"] + 2]
+    a["next"] += 2
+    return pair
+
+
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         stride, padding, want_stats, wref = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
+        # the statistics partials are a non-differentiable by-product: without this autograd
+        # materialises a zero gradient for them in every backward (a 2 MB fill per conv site)
+        ctx.set_materialize_grads(False)
         ctx.cin_small = wp == "cin_small"
         ctx.cinfold = wp == "cinfold"
         if ctx.cinfold:
@@ -234,7 +253,7 @@ class _Conv3dFn(torch.autograd.Function):
         # backward-data kernels that the backward-weight kernel uses as operand scales
         amax = None
         if isinstance(wp, ops.SplitWeight) and ctx.needs_input_grad[2]:
-            amax = torch.zeros(2, device=x0.device, dtype=torch.int32)
+            amax = _amax_pair(x0.device)
         y, part = ops.conv3d_fwd(x0, wp, bias, weight.shape[0], k, stride, padding, x1=x1,
                                  residual=residual, want_stats=want_stats,
                                  amax=None if amax is None else amax[0:1])
@@ -251,6 +270,8 @@ class _Conv3dFn(torch.autograd.Function):
         x0, x1, weight = ctx.saved_tensors
         k, stride, padding, has_bias, has_res, wref = ctx.conf
         need = ctx.needs_input_grad
+        if dy is None:   # the output took no part in the loss
+            return None, None, None, None, None, None, None
         dy = ops.ndhwc(dy)
         dx0 = dx1 = dw = db = dres = None
         C0 = x0.shape[1]
