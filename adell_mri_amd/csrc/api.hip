@@ -33,6 +33,7 @@ static AdellTuning adell_tuning_from_env() {
   t.wgrad_nozring = adell_env_set("ADELL_WGRAD_NOZRING");
   t.zr_minseg = adell_env_int("ADELL_ZR_MINSEG", 4);
   t.igemm_no2wave = adell_env_set("ADELL_IGEMM_NO2WAVE");
+  t.igemm_oldtile = adell_env_set("ADELL_IGEMM_OLDTILE");
   t.igemm_ws = adell_env_set("ADELL_IGEMM_WS");
   t.attn_nomfma = adell_env_set("ADELL_ATTN_NOMFMA");
   t.ws_min_items = adell_env_int("ADELL_WS_MIN_ITEMS", 1024);
@@ -56,6 +57,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "wgrad_nozring")) return &g_adell_tune.wgrad_nozring;
   if (!strcmp(name, "zr_minseg")) return &g_adell_tune.zr_minseg;
   if (!strcmp(name, "igemm_no2wave")) return &g_adell_tune.igemm_no2wave;
+  if (!strcmp(name, "igemm_oldtile")) return &g_adell_tune.igemm_oldtile;
   if (!strcmp(name, "igemm_ws")) return &g_adell_tune.igemm_ws;
   if (!strcmp(name, "attn_nomfma")) return &g_adell_tune.attn_nomfma;
   if (!strcmp(name, "ws_min_items")) return &g_adell_tune.ws_min_items;

@@ -18,6 +18,7 @@ void adell_set_error(const char* fmt, ...);
 // the per-launch host path never calls getenv().
 struct AdellTuning {
   int igemm_nospec, igemm_no8, no_splitk, no_wgrad_tiny, wgrad_nozring, zr_minseg;
+  int igemm_oldtile;              // low-resolution wide layers: the round-1 tile rule
   int igemm_no2wave;              // strided / k == stride layers: not the two-wave 64-voxel instance
   int attn_nomfma;                // attention: vector-ALU kernels even for MFMA-eligible head dims
   int igemm_ws, ws_min_items;   // persistent wave-specialised conv instance: opt-in / size gate

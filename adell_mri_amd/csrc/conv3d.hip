@@ -410,6 +410,28 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
            (a.SD > 1 || a.SH > 1 || a.SW > 1) && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 &&
            !g_adell_tune.igemm_no2wave)
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 6);
+  // Low-resolution 3x3x3 stride-1 levels with wide outputs (measured with warm clocks,
+  // tools/cfg_exp.py, batch 2): the 64-voxel x 64-column bricks of the "small problem" rule make
+  // every block stream the whole weight slice of its column tile from L2 (256 -> 256 at 16^3:
+  // 0.9 GB of weight reads, 214 us); 256-voxel x 32-column bricks + split-K read a quarter of
+  // that (139 us). 8^3 levels: 64-voxel x 32-column two-wave bricks (256 -> 256: 89 -> 68 us).
+  bool retiled = false;
+  if (g_conv_force_cfg < 0 && !g_adell_tune.igemm_oldtile && a.shuffle == 0 && a.KD == 3 &&
+      a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 && a.UPS == 1 &&
+      a.UPSY == 1 && a.UPSZ == 1 && a.Cout > 32) {
+    const long vox = (long)N * a.Do * a.Ho * a.Wo;
+    int pick = -1;
+    if (vox < 4096)
+      pick = 6;
+    else if (vox < 32768)
+      pick = a.Cin >= 256 ? 1 : 3;
+    else if (vox < 262144 && a.Cout <= 64)
+      pick = 1;
+    if (pick >= 0) {
+      t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, pick);
+      retiled = true;
+    }
+  }
   size_t lds = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     a.lTX = t.lTX; a.lTY = t.lTY; a.lTZ = t.lTZ;
@@ -437,7 +459,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   }
   // 32-channel tiles of 3x3x3 stride-1 layers: 8x8x8 bricks (cfg 4, SPEC = 3 instance of the
   // kernel): a third less halo per output and half the weight staging of the 8x8x4 brick
-  if (t.cfg == 1 && a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 &&
+  if (t.cfg == 1 && !retiled && a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 &&
       a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.shuffle == 0 && a.lTX == 3 && a.lTY == 3 &&
       a.lTZ == 2 && a.Do >= 8 && a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
       (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&

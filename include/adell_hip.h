@@ -621,7 +621,8 @@ int adell_channel_max_bwd(const float* dout, const int* arg, float* dx, int N, l
 void adell_debug_force_conv_cfg(int cfg);
 
 /* Launch-plan switches for A/B tests of kernel instances: "igemm_nospec", "igemm_no8",
- * "igemm_no2wave" (strided layers back on the four-wave bricks), "no_splitk", "no_wgrad_tiny", "wgrad_nozring", "igemm_ws" (0 / 1; the last one opts INTO the
+ * "igemm_no2wave" (strided layers back on the four-wave bricks), "igemm_oldtile" (low-resolution
+ * wide layers back on 64 x 64 bricks), "no_splitk", "no_wgrad_tiny", "wgrad_nozring", "igemm_ws" (0 / 1; the last one opts INTO the
  * persistent wave-specialised conv instance for layers of >= "ws_min_items" bricks) and
  * "zr_minseg" (planes). Initialised
  * once at load from the environment variables of the same names (ADELL_ prefix, upper case);
