@@ -418,10 +418,14 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   bool retiled = false;
   if (g_conv_force_cfg < 0 && !g_adell_tune.igemm_oldtile && a.shuffle == 0 && a.KD == 3 &&
       a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 && a.UPS == 1 &&
-      a.UPSY == 1 && a.UPSZ == 1 && a.Cout > 32) {
+      a.UPSY == 1 && a.UPSZ == 1) {
     const long vox = (long)N * a.Do * a.Ho * a.Wo;
     int pick = -1;
-    if (vox < 4096)
+    if (a.Cout <= 32) {
+      // 16^3 / 32^3 levels with <= 32 columns: 8x8x4 bricks (the 8x8x8 bricks of the large
+      // layers leave half the chip without a block: 32 -> 32 at 2 x 32^3 30 -> 20 us)
+      if (vox >= 4096 && vox < 262144) pick = 1;
+    } else if (vox < 4096)
       pick = 6;
     else if (vox < 32768)
       pick = a.Cin >= 256 ? 1 : 3;
