@@ -60,6 +60,8 @@ SIGNATURES = {
     "adell_conv3d_splitk_workspace": (_l, [ctypes.POINTER(ConvDesc), _i]),
     "adell_conv3d_fwd_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10 + [ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_data_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7 + [ctypes.c_size_t, _vp]),
+    "adell_conv3d_bwd_data_f16x3_add": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7
+                                        + [ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_weight_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_bwd_weight": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_weight_f16x3_workspace": (_l, [ctypes.POINTER(ConvDesc)]),

@@ -778,6 +778,24 @@ extern "C" int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const 
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+// The same with `add0` ([N][D][H][W][C0], one destination only) added to dx0 in the epilogue: the
+// gradient a residual link sends straight to the block input (`op(X) + X`, res_blocks.py:192),
+// which autograd would otherwise add in a separate full-size pass.
+extern "C" int adell_conv3d_bwd_data_f16x3_add(const adell_conv3d_desc* d, const float* dy,
+                                               const void* w_split_bwd, const float* wscale,
+                                               const float* add0, float* dx0,
+                                               uint32_t* dy_absmax, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_bwd_data(a, d, dy, dx0, nullptr);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split_bwd && wscale && add0, "conv_bwd_data_f16x3_add: null pointer");
+  ADELL_REQUIRE(d->C1 == 0, "conv_bwd_data_f16x3_add: one destination only");
+  a.res = add0;
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
 // Backward-data of a stride-2 conv by parity classes. dX[2i + p] (p in {0,1}^3) only receives the
 // taps t with t = p + P (mod 2) per axis, so each of the 8 classes is a stride-1 conv of dY with a
 // (1..2)^3 sub-kernel whose outputs land on a stride-2 lattice of dX (the pixel-shuffle store of

@@ -199,7 +199,7 @@ def _amax_pair(device):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
-        stride, padding, want_stats, wref = conf
+        stride, padding, want_stats, wref, ctx.carry_in, ctx.carry_out = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
         # the statistics partials are a non-differentiable by-product: without this autograd
         # materialises a zero gradient for them in every backward (a 2 MB fill per conv site)
@@ -274,6 +274,7 @@ class _Conv3dFn(torch.autograd.Function):
             return None, None, None, None, None, None, None
         dy = ops.ndhwc(dy)
         dx0 = dx1 = dw = db = dres = None
+        add0 = ctx.carry_in.take() if ctx.carry_in is not None else None
         C0 = x0.shape[1]
         C1 = 0 if x1 is None else x1.shape[1]
         if ctx.small1:
@@ -308,8 +309,11 @@ class _Conv3dFn(torch.autograd.Function):
             wpb = _packed(wref.obj, 1)
             if amax is not None and isinstance(wpb, ops.SplitWeight):
                 dy_amax = amax[1:2]
+            fused = add0 is not None and C1 == 0 and isinstance(wpb, ops.SplitWeight)
             dx0, dx1 = ops.conv3d_bwd_data(dy, wpb, tuple(x0.shape[2:]), C0, C1, k, stride,
-                                           padding, amax=dy_amax)
+                                           padding, amax=dy_amax, add0=add0 if fused else None)
+            if fused:
+                add0 = None
             if not need[0]:
                 dx0 = None
             if x1 is None or not need[1]:
@@ -328,15 +332,39 @@ class _Conv3dFn(torch.autograd.Function):
             dw = dw.view(weight.shape)
         elif want_db:
             db = ops.bias_grad(dy)
+        if add0 is not None and dx0 is not None:   # a path without the fused add
+            dx0 = dx0 + add0
         if has_res and need[4]:
-            dres = dy
+            if ctx.carry_out is not None:
+                ctx.carry_out.grad = dy      # the head conv of the block adds it to its dX
+            else:
+                dres = dy
         return dx0, dx1, dw, db, dres, None, None
 
 
-def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True):
-    """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual)."""
+class GradCarry:
+    """Hands the gradient of a residual link from the conv that adds the link (it parks its dy
+    here instead of returning it for autograd to accumulate) to the conv at the head of the same
+    block, whose backward-data kernel adds it in its epilogue: one full-size add pass less per
+    residual block (``op(X) + X``, res_blocks.py:192). Both convs read the same X; the tail's
+    backward always runs before the head's."""
+
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+    def take(self):
+        g, self.grad = self.grad, None
+        return g
+
+
+def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True,
+           carry_in=None, carry_out=None):
+    """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual). ``carry_out`` /
+    ``carry_in``: see GradCarry (tail / head conv of a residual block)."""
     stride, padding = ops._triple(stride), ops._triple(padding)
-    conf = (stride, padding, want_stats, _Ref(weight))
+    conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out)
     Cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
     small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
     if small1:

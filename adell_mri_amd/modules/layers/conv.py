@@ -26,15 +26,17 @@ class Conv3d(torch.nn.Conv3d):
         if self.groups != 1 or any(d != 1 for d in self.dilation) or self.padding_mode != "zeros":
             raise AdellHipError("HIP Conv3d supports groups=1, dilation=1, zero padding only")
 
-    def forward(self, X, X_cat=None, residual=None):
+    def forward(self, X, X_cat=None, residual=None, carry_in=None, carry_out=None):
         """``X_cat``: second source of a virtual channel concat; ``residual``: tensor
-        added to the output inside the kernel epilogue."""
+        added to the output inside the kernel epilogue; ``carry_in`` / ``carry_out``:
+        functional.GradCarry of a residual block (head / tail conv)."""
         self._check()
         pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
         k, st = tuple(self.kernel_size), tuple(self.stride)
         if k == st and max(k) > 2 and tuple(pad) == (0, 0, 0) and X_cat is None:
             return self._patchify(X, residual)
-        return HF.conv3d(X, self.weight, self.bias, self.stride, pad, x1=X_cat, residual=residual)
+        return HF.conv3d(X, self.weight, self.bias, self.stride, pad, x1=X_cat, residual=residual,
+                         carry_in=carry_in, carry_out=carry_out)
 
     def _patchify(self, X, residual):
         """kernel == stride, no padding (ViT / ConvNeXt stems): space-to-depth view of the

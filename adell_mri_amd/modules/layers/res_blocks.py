@@ -46,11 +46,16 @@ class ResidualBlock3d(torch.nn.Module):
         self.adn_op = self.adn_fn(self.out_channels)
 
     def forward(self, X: torch.Tensor, skip_activation: bool = None):
-        h = X
         mods = list(self.op)
-        for mod in mods[:-1]:
+        # the link's gradient rides the head conv's backward-data epilogue (functional.GradCarry)
+        carry = (HF.GradCarry() if (self._conv is Conv3d and X.requires_grad
+                                    and torch.is_grad_enabled()
+                                    and not ops.FLAGS["no_grad_carry"]) else None)
+        h = mods[0](X, carry_in=carry) if carry is not None else mods[0](X)
+        for mod in mods[1:-1]:
             h = mod(h)
-        out = self.final_op(mods[-1](h, residual=X))
+        out = self.final_op(mods[-1](h, residual=X, carry_out=carry) if carry is not None
+                            else mods[-1](h, residual=X))
         skip = skip_activation if skip_activation is not None else self.skip_activation
         if skip is not True:
             out = self.adn_op(out)

@@ -86,6 +86,7 @@ KERNEL_TIMER = None
 # dispatch switches for A/B tests (read from the environment once at import)
 FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          "no_convt_k2": bool(os.environ.get("ADELL_NO_CONVT_K2")),
+         "no_grad_carry": bool(os.environ.get("ADELL_NO_GRAD_CARRY")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
@@ -459,8 +460,24 @@ def conv1_small_bwd_weight(x0, x1, dy, want_db):
     return dw, db
 
 
-def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, amax=None):
+def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, amax=None,
+                    add0=None):
+    """``add0``: a tensor of dx0's shape added to it inside the kernel epilogue (f16x3 path, one
+    destination); the caller adds it itself when this returns it unused (third value)."""
     split = isinstance(w_packed_bwd, SplitWeight)
+    if add0 is not None and split and C1 == 0:
+        _require_cuda(dy, add0)
+        dy, add0 = ndhwc(dy), ndhwc(add0)
+        N, Cout = dy.shape[:2]
+        d = make_conv_desc(N, tuple(in_size), C0, 0, Cout, kernel, stride, padding)
+        dx0 = new_act(N, C0, *in_size, dy.device)
+        ws, wsb = _splitk_workspace(d, 1, dy.device)
+        check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
+                     lambda: _lib.lib().adell_conv3d_bwd_data_f16x3_add(
+                         ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs),
+                         _ptr(w_packed_bwd.scale), _ptr(add0), _ptr(dx0), _ptr(amax), _ptr(ws), wsb,
+                         _stream()), _conv_tag(d, "dgrad"), _conv_bytes(d, True)))
+        return dx0, None
     _require_cuda(dy)
     dy = ndhwc(dy)
     N, Cout = dy.shape[:2]

@@ -144,6 +144,12 @@ int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const float* dy,
                                    const void* w_split_bwd, const float* wscale, float* dx0,
                                    float* dx1, uint32_t* dy_absmax, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* the same with add0 ([N][D][H][W][C0]; C1 must be 0) added to dx0 in the epilogue: the gradient a
+ * residual link (res_blocks.py:192, `op(X) + X`) sends straight to the block input */
+int adell_conv3d_bwd_data_f16x3_add(const adell_conv3d_desc* d, const float* dy,
+                                    const void* w_split_bwd, const float* wscale,
+                                    const float* add0, float* dx0, uint32_t* dy_absmax,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
  * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias

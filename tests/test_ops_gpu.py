@@ -296,3 +296,39 @@ def test_conv1_small_head_fwd_bwd(cuda, N, C0, C1, size, Cout):
     assert rel(dx, dx_ref) < 1e-5
     assert rel(wd.grad.cpu().numpy(), dw_ref) < 2e-5
     assert rel(bd.grad.cpu().numpy(), db_ref) < 2e-5
+
+
+@pytest.mark.gpu
+def test_residual_block_link_gradient_rides_the_head_conv(cuda):
+    """functional.GradCarry: the gradient of `op(X) + X` (res_blocks.py:192) is added inside the
+    backward-data epilogue of the block's first conv. Same gradients as the autograd-accumulated
+    form, bit for bit in the weights, to fp32 rounding in dX (one add order differs)."""
+    from adell_mri_amd import ops as _ops
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.layers.res_blocks import ResidualBlock3d
+
+    torch.manual_seed(0)
+    out = {}
+    for inter in (None, 16):
+        blk = ResidualBlock3d(32, 3, inter, 32, get_adn_fn(3, "instance", "swish", 0.0)).to(cuda)
+        x0 = torch.randn(2, 32, 16, 24, 16, device=cuda)
+        r = torch.randn(2, 32, 16, 24, 16, device=cuda)
+        for mode in ("carry", "autograd"):
+            _ops.FLAGS["no_grad_carry"] = mode == "autograd"
+            try:
+                x = x0.clone().requires_grad_(True)
+                blk.zero_grad()
+                y = blk(x)
+                (y * r).sum().backward()
+            finally:
+                _ops.FLAGS["no_grad_carry"] = False
+            out[mode] = (y.detach(), x.grad.clone(),
+                         {k: p.grad.clone() for k, p in blk.named_parameters()})
+        assert torch.equal(out["carry"][0], out["autograd"][0])
+        gx_c, gx_a = out["carry"][1], out["autograd"][1]
+        assert float((gx_c - gx_a).abs().max()) <= 2e-6 * float(gx_a.abs().max())
+        for k, g in out["autograd"][2].items():
+            assert torch.equal(out["carry"][2][k], g), k
+        # no gradient wanted for X: no carry, the block still runs
+        with torch.no_grad():
+            assert torch.equal(blk(x0), out["carry"][0])
