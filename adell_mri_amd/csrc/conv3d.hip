@@ -803,10 +803,10 @@ extern "C" int adell_conv3d_bwd_data_f16x3_add(const adell_conv3d_desc* d, const
 // zero-insertion formulation multiplies 7 zeros out of 8. w_split[c] / wscale[c]: the class's
 // sub-kernel w[:, :, t0z::2, t0y::2, t0x::2] packed with mode 1; c = 4 pz + 2 py + px.
 // Needs even input dims, one destination (C1 = 0), k = 3.
-extern "C" int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const float* dy,
-                                              const void* const* w_split,
-                                              const float* const* wscale, float* dx,
-                                              uint32_t* dy_absmax, void* stream) {
+static int adell_bwd_data_s2_classes(const adell_conv3d_desc* d, const float* dy,
+                                     const void* const* w_split, const float* const* wscale,
+                                     const float* add0, float* dx, uint32_t* dy_absmax,
+                                     void* stream) {
   int rc = adell_check_desc(d);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(dy && w_split && wscale && dx, "conv_bwd_data_s2: null pointer");
@@ -828,7 +828,9 @@ extern "C" int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const 
     ADELL_REQUIRE(w_split[c] && wscale[c], "conv_bwd_data_s2: null class weights");
     ConvArgs a = {};
     a.x0 = dy;
-    a.y0 = dx + ((size_t)(pz * d->H + py) * d->W + px) * d->C0;
+    const size_t class_origin = ((size_t)(pz * d->H + py) * d->W + px) * d->C0;
+    a.y0 = dx + class_origin;
+    a.res = add0 ? add0 + class_origin : nullptr;   // dX-shaped: read where the class stores
     a.D = d->Do; a.H = d->Ho; a.W = d->Wo;
     a.C0 = d->Cout; a.C1 = 0; a.Cin = d->Cout; a.Cout = d->C0;
     a.KD = n3[0]; a.KH = n3[1]; a.KW = n3[2];
@@ -837,13 +839,30 @@ extern "C" int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const 
     a.UPS = a.UPSY = a.UPSZ = 1;
     a.Do = d->D / 2; a.Ho = d->H / 2; a.Wo = d->W / 2;
     a.ysplit = a.Cout; a.Cs = a.Cout;
-    a.shuffle = 8 | 7;                           // rows on the stride-2 lattice, sub-position 0
+    a.shuffle = 8 | 7 | (add0 ? 16 : 0);         // rows on the stride-2 lattice, sub-position 0
     ConvF16Extra e = {(const _Float16*)w_split[c], wscale[c], c == 0 ? dy_absmax : nullptr,
                       nullptr, nullptr, nullptr, 0};
     rc = adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
     if (rc != ADELL_OK) return rc;
   }
   return ADELL_OK;
+}
+
+extern "C" int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const float* dy,
+                                              const void* const* w_split,
+                                              const float* const* wscale, float* dx,
+                                              uint32_t* dy_absmax, void* stream) {
+  return adell_bwd_data_s2_classes(d, dy, w_split, wscale, nullptr, dx, dy_absmax, stream);
+}
+
+// ... + add0 (dX-shaped: the gradient another consumer of the same input parked, see
+// functional.GradCarry) in the epilogue of every class launch.
+extern "C" int adell_conv3d_bwd_data_s2_f16x3_add(const adell_conv3d_desc* d, const float* dy,
+                                                  const void* const* w_split,
+                                                  const float* const* wscale, const float* add0,
+                                                  float* dx, uint32_t* dy_absmax, void* stream) {
+  ADELL_REQUIRE(add0, "conv_bwd_data_s2_add: null add0");
+  return adell_bwd_data_s2_classes(d, dy, w_split, wscale, add0, dx, dy_absmax, stream);
 }
 
 // ConvTranspose3d (kernel = stride = factors) on the f16x3 kernel. Forward: w_split = the

@@ -565,6 +565,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   const size_t row0 =   // destination row of the brick origin
       ((size_t)((nb * fz * a.Do + fz * oz0) * (fy * a.Ho) + fy * oy0)) * (fx * a.Wo) + fx * ox0;
   const size_t rrow0 = ((size_t)((nb * a.Do + oz0) * a.Ho + oy0)) * a.Wo + ox0;  // residual row
+  const bool res_like_y = (a.shuffle & 16) != 0;
   float s1[NT], s2[NT], bcol[NT], oscale[NT];
   float* colptr[NT];
   const float* resptr[NT];
@@ -599,7 +600,9 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
         if (a.bias) bcol[nt] = a.bias[n];
       }
       colptr[nt] += row0 * rowmul[nt];
-      if (a.res) resptr[nt] = a.res + rrow0 * a.Cout + n;
+      // residual: output-shaped rows, or (shuffle bit 4) laid out like the shuffled destination
+      if (a.res)
+        resptr[nt] = res_like_y ? a.res + (colptr[nt] - a.y0) : a.res + rrow0 * a.Cout + n;
     }
   }
   bool stored = false;
@@ -608,7 +611,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     // y-rows (r >> 2), so a row is the m-tile's base pointer + a compile-time multiple of two
     // per-lane strides; no bounds checks, the residual values of an m-tile are fetched at once
     const bool full = (ox0 + 8 <= a.Wo) & (oy0 + 8 <= a.Ho) & (oz0 + (SPEC == 3 ? 8 : 4) <= a.Do) &
-                      (n0 + BN <= a.Cout);
+                      (n0 + BN <= a.Cout) & !res_like_y;
     if (full) {
       stored = true;
       auto fast = [&](auto has_res) {
@@ -650,8 +653,31 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     }
   }
   if (!stored) {
+  // the residual values of an m-tile are fetched together (16 loads in flight per column tile)
+  // before its rows are stored; wide column tiles (NT > 2) read them row by row instead
+  constexpr bool RES_BATCH = NT <= 2;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    float resv[RES_BATCH ? NT : 1][16];
+    if (RES_BATCH && a.res) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = (wm * MT + mt) * 32 + row;
+        const int xl = m & ((1 << lTX) - 1);
+        const int yl = (m >> lTX) & ((1 << lTY) - 1);
+        const int zl = m >> (lTX + lTY);
+        const bool rok = (ox0 + xl < a.Wo) & (oy0 + yl < a.Ho) & (oz0 + zl < a.Do);
+        const unsigned loc = (unsigned)zl * (unsigned)sZ + __umul24(yl, sY) + __umul24(xl, sX);
+        const unsigned rloc = (unsigned)zl * (unsigned)(a.Ho * a.Wo) + __umul24(yl, a.Wo) + xl;
+#pragma unroll
+        for (int nt = 0; nt < (RES_BATCH ? NT : 1); ++nt)
+          resv[nt][r] = (rok && nok[nt])
+                            ? resptr[nt][res_like_y ? loc * (unsigned)rowmul[nt]
+                                                    : rloc * (unsigned)a.Cout]
+                            : 0.f;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -666,7 +692,12 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       for (int nt = 0; nt < NT; ++nt) {
         if (rok && nok[nt]) {
           float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];
-          if (a.res) v += resptr[nt][rloc * (unsigned)a.Cout];
+          if (a.res) {
+            if constexpr (RES_BATCH)
+              v += resv[nt][r];
+            else
+              v += resptr[nt][res_like_y ? loc * (unsigned)rowmul[nt] : rloc * (unsigned)a.Cout];
+          }
           colptr[nt][loc * (unsigned)rowmul[nt]] = v;
           s1[nt] += v;
           s2[nt] += v * v;

@@ -199,7 +199,8 @@ def _amax_pair(device):
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
-        stride, padding, want_stats, wref, ctx.carry_in, ctx.carry_out = conf
+        (stride, padding, want_stats, wref, ctx.carry_in, ctx.carry_out, ctx.carry_x0,
+         ctx.carry_cat) = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
         # the statistics partials are a non-differentiable by-product: without this autograd
         # materialises a zero gradient for them in every backward (a 2 MB fill per conv site)
@@ -285,6 +286,9 @@ class _Conv3dFn(torch.autograd.Function):
             if need[2] or (has_bias and need[3]):
                 dw, db = ops.conv1_small_bwd_weight(x0, x1, dy, has_bias and need[3])
                 dw = dw.view(weight.shape) if need[2] else None
+            if add0 is not None and dx0 is not None:
+                dx0 = dx0 + add0
+            dx0, dx1 = _park_input_grads(ctx, dx0, dx1)
             return dx0, dx1, dw, db, None, None, None
         amax = ctx.amax
         dy_amax = None
@@ -304,7 +308,9 @@ class _Conv3dFn(torch.autograd.Function):
             if amax is not None:
                 dy_amax = amax[1:2]
             dx0 = ops.conv3d_bwd_data_s2(dy, _packed_s2_classes(wref.obj, padding),
-                                         tuple(x0.shape[2:]), C0, padding, amax=dy_amax)
+                                         tuple(x0.shape[2:]), C0, padding, amax=dy_amax,
+                                         add0=add0)
+            add0 = None
         elif need[0] or (x1 is not None and need[1]):
             wpb = _packed(wref.obj, 1)
             if amax is not None and isinstance(wpb, ops.SplitWeight):
@@ -334,6 +340,7 @@ class _Conv3dFn(torch.autograd.Function):
             db = ops.bias_grad(dy)
         if add0 is not None and dx0 is not None:   # a path without the fused add
             dx0 = dx0 + add0
+        dx0, dx1 = _park_input_grads(ctx, dx0, dx1)
         if has_res and need[4]:
             if ctx.carry_out is not None:
                 ctx.carry_out.grad = dy      # the head conv of the block adds it to its dX
@@ -342,12 +349,26 @@ class _Conv3dFn(torch.autograd.Function):
         return dx0, dx1, dw, db, dres, None, None
 
 
+def _park_input_grads(ctx, dx0, dx1):
+    """Skip fork: leave dX of x0 / x1 with the consumer of the same tensor that runs later."""
+    if dx0 is not None and ctx.carry_x0 is not None:
+        ctx.carry_x0.grad, dx0 = dx0, None
+    if dx1 is not None and ctx.carry_cat is not None:
+        ctx.carry_cat.grad, dx1 = dx1, None
+    return dx0, dx1
+
+
 class GradCarry:
-    """Hands the gradient of a residual link from the conv that adds the link (it parks its dy
-    here instead of returning it for autograd to accumulate) to the conv at the head of the same
-    block, whose backward-data kernel adds it in its epilogue: one full-size add pass less per
-    residual block (``op(X) + X``, res_blocks.py:192). Both convs read the same X; the tail's
-    backward always runs before the head's."""
+    """Hands a gradient from one consumer of a tensor to another consumer of the SAME tensor whose
+    backward runs later and whose backward-data kernel adds it in its epilogue -- one full-size
+    add pass (autograd's accumulation) less per fork.
+    * residual link (``op(X) + X``, res_blocks.py:192): the conv that adds the link parks its dy
+      (``carry_out``), the conv at the head of the block takes it (``carry_in``);
+    * U-Net skip fork (unet.py:768-822): the first conv of the link op parks its dX
+      (``carry_x0``; with identity links it is the decoder conv that reads the level output as
+      the second half of its channel concat, ``carry_cat``), the strided conv that downsamples the
+      same level output takes it (``carry_in``). The downsampling conv's backward depends on the
+      decoder's (through the bottleneck), so it always runs later."""
 
     __slots__ = ("grad",)
 
@@ -360,11 +381,11 @@ class GradCarry:
 
 
 def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True,
-           carry_in=None, carry_out=None):
-    """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual). ``carry_out`` /
-    ``carry_in``: see GradCarry (tail / head conv of a residual block)."""
+           carry_in=None, carry_out=None, carry_x0=None, carry_cat=None):
+    """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual). ``carry_in`` /
+    ``carry_out`` / ``carry_x0`` / ``carry_cat``: see GradCarry."""
     stride, padding = ops._triple(stride), ops._triple(padding)
-    conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out)
+    conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out, carry_x0, carry_cat)
     Cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
     small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
     if small1:

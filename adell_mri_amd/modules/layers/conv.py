@@ -26,17 +26,26 @@ class Conv3d(torch.nn.Conv3d):
         if self.groups != 1 or any(d != 1 for d in self.dilation) or self.padding_mode != "zeros":
             raise AdellHipError("HIP Conv3d supports groups=1, dilation=1, zero padding only")
 
-    def forward(self, X, X_cat=None, residual=None, carry_in=None, carry_out=None):
+    def takes_carry(self):
+        """Whether forward() hands GradCarry arguments to the conv kernels (the space-to-depth
+        stem path does not)."""
+        k, st = tuple(self.kernel_size), tuple(self.stride)
+        pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
+        return not (k == st and max(k) > 2 and tuple(pad) == (0, 0, 0))
+
+    def forward(self, X, X_cat=None, residual=None, carry_in=None, carry_out=None,
+                carry_x0=None, carry_cat=None):
         """``X_cat``: second source of a virtual channel concat; ``residual``: tensor
-        added to the output inside the kernel epilogue; ``carry_in`` / ``carry_out``:
-        functional.GradCarry of a residual block (head / tail conv)."""
+        added to the output inside the kernel epilogue; ``carry_in`` / ``carry_out`` /
+        ``carry_x0`` / ``carry_cat``: functional.GradCarry (residual link, skip fork)."""
         self._check()
         pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
         k, st = tuple(self.kernel_size), tuple(self.stride)
         if k == st and max(k) > 2 and tuple(pad) == (0, 0, 0) and X_cat is None:
             return self._patchify(X, residual)
         return HF.conv3d(X, self.weight, self.bias, self.stride, pad, x1=X_cat, residual=residual,
-                         carry_in=carry_in, carry_out=carry_out)
+                         carry_in=carry_in, carry_out=carry_out, carry_x0=carry_x0,
+                         carry_cat=carry_cat)
 
     def _patchify(self, X, residual):
         """kernel == stride, no padding (ViT / ConvNeXt stems): space-to-depth view of the

@@ -45,13 +45,16 @@ class ResidualBlock3d(torch.nn.Module):
             self.final_op = torch.nn.Identity()
         self.adn_op = self.adn_fn(self.out_channels)
 
-    def forward(self, X: torch.Tensor, skip_activation: bool = None):
+    def forward(self, X: torch.Tensor, skip_activation: bool = None, fork=None):
+        """``fork``: functional.GradCarry of a U-Net skip fork -- the block's gradient with respect
+        to X is left there for the other consumer of X (segmentation/unet.py); ignored (autograd adds
+        the two gradients) when the block runs without its own carry."""
         mods = list(self.op)
         # the link's gradient rides the head conv's backward-data epilogue (functional.GradCarry)
         carry = (HF.GradCarry() if (self._conv is Conv3d and X.requires_grad
                                     and torch.is_grad_enabled()
                                     and not ops.FLAGS["no_grad_carry"]) else None)
-        h = mods[0](X, carry_in=carry) if carry is not None else mods[0](X)
+        h = mods[0](X, carry_in=carry, carry_x0=fork) if carry is not None else mods[0](X)
         for mod in mods[1:-1]:
             h = mod(h)
         out = self.final_op(mods[-1](h, residual=X, carry_out=carry) if carry is not None

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from ... import functional as HF
+from ... import ops
 from ..._lib import AdellHipError
 from ..layers.adn_fn import ActDropNorm, get_adn_fn, norm_fn_dict
 from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, MaxPool2d,
@@ -39,12 +40,34 @@ class ConcatConvBlock(torch.nn.Sequential):
     of a channel concat separately (same children / keys as the Sequential built
     by the reference's ``conv_block_3d``, unet.py:260-273)."""
 
-    def forward(self, X, X_cat=None):
+    def forward(self, X, X_cat=None, carry_cat=None):
         mods = list(self)
-        h = mods[0](X, X_cat=X_cat) if X_cat is not None else mods[0](X)
+        if X_cat is not None and carry_cat is not None and _takes_carry(mods[0]):
+            h = mods[0](X, X_cat=X_cat, carry_cat=carry_cat)
+        else:
+            h = mods[0](X, X_cat=X_cat) if X_cat is not None else mods[0](X)
         for mod in mods[1:]:
             h = mod(h)
         return h
+
+
+def _takes_carry(module):
+    return type(module) is Conv3d and module.takes_carry()
+
+
+def _head_with_carry(module, X, **carries):
+    """``module(X)`` with the functional.GradCarry arguments delivered to the Conv3d that reads X
+    (through nested Sequentials); None when X is not read by such a conv first."""
+    if _takes_carry(module):
+        return module(X, **carries)
+    if isinstance(module, torch.nn.Sequential) and len(module) > 0:
+        mods = list(module)
+        h = _head_with_carry(mods[0], X, **carries)
+        if h is not None:
+            for mod in mods[1:]:
+                h = mod(h)
+        return h
+    return None
 
 
 def _cat_channels(a, b):
@@ -64,10 +87,10 @@ def _nearest(x, size):
 class _DecoderOp(torch.nn.Sequential):
     """``Sequential(conv_block, adn)`` forwarding the concat operand."""
 
-    def forward(self, X, X_cat=None):
+    def forward(self, X, X_cat=None, carry_cat=None):
         mods = list(self)
         if X_cat is not None and isinstance(mods[0], ConcatConvBlock):
-            h = mods[0](X, X_cat=X_cat)
+            h = mods[0](X, X_cat=X_cat, carry_cat=carry_cat)
         else:
             h = mods[0](X if X_cat is None else _cat_channels(X, X_cat))
         for mod in mods[1:]:
@@ -349,10 +372,21 @@ class UNet(torch.nn.Module):
         if X_feature_conditioning is not None:   # tiny [B, F] tensor
             X_feature_conditioning = (X_feature_conditioning - self.f_mean) / self.f_std
         encoding_out, curr = [], X
+        # skip forks: a level output feeds the downsampling conv and (later) the link op / the
+        # decoder's concat. The later reader's gradient is left in a functional.GradCarry and
+        # added in the epilogue of the downsampling conv's backward-data kernel.
         for level, downsample in self.encoding_operations:
             curr = level(curr)
             encoding_out.append(curr)
-            curr = downsample(curr)
+            fork, down = None, None
+            if (curr.dim() == 5 and curr.requires_grad and torch.is_grad_enabled()
+                    and not ops.FLAGS["no_grad_carry"] and not ops.FLAGS["no_skip_fork"]):
+                fork = HF.GradCarry()
+                down = _head_with_carry(downsample, curr, carry_in=fork)
+            if down is None:
+                fork, down = None, downsample(curr)
+            curr._adell_fork = fork    # for the first later reader of this tensor (one use)
+            curr = down
         return encoding_out, curr, X_skip_layer, X_feature_conditioning
 
     def _run_decoder(self, encoding_out, bottleneck, X_skip_layer, X_feature_conditioning):
@@ -365,10 +399,19 @@ class UNet(torch.nn.Module):
             link_op = self.link_ops[i]
             up = self.upscale_ops[i]
             link_in = encoding_out[-i - 2]
+            fork = getattr(link_in, "_adell_fork", None)
+            link_in._adell_fork = None
             if X_skip_layer is not None:
                 S = link_in.shape[2:]
                 link_in = _cat_channels(link_in, _nearest(X_skip_layer, S))
-            encoded = link_op(link_in)
+                fork = None
+            encoded = None
+            if fork is not None and isinstance(link_op, ResidualBlock3d):
+                encoded, fork = link_op(link_in, fork=fork), None
+            elif fork is not None and not isinstance(link_op, torch.nn.Identity):
+                encoded, fork = _head_with_carry(link_op, link_in, carry_x0=fork), None
+            if encoded is None:
+                encoded = link_op(link_in)
             if X_feature_conditioning is not None:   # channel gates, unet.py:803-810
                 gates = self.feature_conditioning_ops[i](X_feature_conditioning)
                 encoded = HF.scale_per_item_channel(encoded, gates)
@@ -378,7 +421,12 @@ class UNet(torch.nn.Module):
                 encoded = crop_to_size(encoded, sh)
             if np.prod(sh) > np.prod(sh2):
                 curr = crop_to_size(curr, sh2)
-            curr = op(curr, X_cat=encoded)  # virtual concat (curr, encoded)
+            # virtual concat (curr, encoded); identity link: the fork's gradient is the concat's
+            # second half
+            if fork is not None and encoded is encoding_out[-i - 2] and isinstance(op, _DecoderOp):
+                curr = op(curr, X_cat=encoded, carry_cat=fork)
+            else:
+                curr = op(curr, X_cat=encoded)
             deep_outputs.append(curr)
         return curr, deep_outputs
 

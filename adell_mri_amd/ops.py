@@ -87,6 +87,7 @@ KERNEL_TIMER = None
 FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          "no_convt_k2": bool(os.environ.get("ADELL_NO_CONVT_K2")),
          "no_grad_carry": bool(os.environ.get("ADELL_NO_GRAD_CARRY")),
+         "no_skip_fork": bool(os.environ.get("ADELL_NO_SKIP_FORK")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
@@ -500,10 +501,11 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, 
     return dx0, dx1
 
 
-def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None):
+def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None, add0=None):
     """Backward-data of a stride-2 k = 3 conv by parity classes; ``class_weights``: 8 SplitWeights
-    (c = 4 pz + 2 py + px) of the sub-kernels packed with mode 1."""
-    _require_cuda(dy)
+    (c = 4 pz + 2 py + px) of the sub-kernels packed with mode 1. ``add0`` (dX-shaped) is added in
+    the epilogue of the class launches."""
+    _require_cuda(dy, add0)
     dy = ndhwc(dy)
     N, Cout = dy.shape[:2]
     d = make_conv_desc(N, tuple(in_size), C0, 0, Cout, 3, 2, padding)
@@ -512,9 +514,15 @@ def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None):
     PA = ctypes.c_void_p * 8
     wh = PA(*[_ptr(w.halfs) for w in class_weights])
     ws = PA(*[_ptr(w.scale) for w in class_weights])
-    check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
-                 lambda: _lib.lib().adell_conv3d_bwd_data_s2_f16x3(
-                     ctypes.byref(d), _ptr(dy), wh, ws, _ptr(dx), _ptr(amax), _stream()),
+    if add0 is not None:
+        add0 = ndhwc(add0)
+        assert add0.shape == dx.shape
+        call = lambda: _lib.lib().adell_conv3d_bwd_data_s2_f16x3_add(
+            ctypes.byref(d), _ptr(dy), wh, ws, _ptr(add0), _ptr(dx), _ptr(amax), _stream())
+    else:
+        call = lambda: _lib.lib().adell_conv3d_bwd_data_s2_f16x3(
+            ctypes.byref(d), _ptr(dy), wh, ws, _ptr(dx), _ptr(amax), _stream())
+    check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d), call,
                  _conv_tag(d, "dgrad"), _conv_bytes(d), kernels=8))
     return dx
 

@@ -128,6 +128,13 @@ int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
 int adell_conv3d_bwd_data_s2_f16x3(const adell_conv3d_desc* d, const float* dy,
                                    const void* const* w_split, const float* const* wscale,
                                    float* dx, uint32_t* dy_absmax, void* stream);
+/* ... + add0 ([N, D, H, W, C0] like dx: the gradient another consumer of the same input produced,
+ * e.g. the decoder's half of a U-Net skip fork, unet.py:768-822) added in every class launch's
+ * epilogue instead of by a separate full-size pass. */
+int adell_conv3d_bwd_data_s2_f16x3_add(const adell_conv3d_desc* d, const float* dy,
+                                       const void* const* w_split, const float* const* wscale,
+                                       const float* add0, float* dx, uint32_t* dy_absmax,
+                                       void* stream);
 
 /* The same two calls with a caller-provided workspace (adell_conv3d_splitk_workspace bytes; 0 =
  * never needed): layers with too few output bricks to fill the chip (the 8^3 - 16^3 levels)
