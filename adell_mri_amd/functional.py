@@ -298,6 +298,16 @@ class _Conv3dFn(torch.autograd.Function):
             pass
         elif ctx.cin_small and need[0] and dy.shape[1] % 4 == 0:
             dx0 = ops.conv_cin_small_bwd_data(dy, weight, tuple(x0.shape[2:]), padding)
+        elif (need[0] and x1 is None and CONV_PRECISION == "f16x3"
+              and ops.conv3d_bwd_data_s2_fused_ok(x0.shape[2:], C0, C1, dy.shape[1], k, stride,
+                                                  padding)
+              and isinstance(_packed(wref.obj, 1), ops.SplitWeight)):
+            # the U-Net downsampling layer at 32 channels: one persistent launch
+            if amax is not None:
+                dy_amax = amax[1:2]
+            dx0 = ops.conv3d_bwd_data_s2_fused(dy, _packed(wref.obj, 1), tuple(x0.shape[2:]),
+                                               amax=dy_amax, add0=add0)
+            add0 = None
         elif (need[0] and x1 is None and CONV_PRECISION == "f16x3" and stride == (2, 2, 2)
               and k == (3, 3, 3) and all(p <= 1 for p in padding)
               and all(s % 2 == 0 for s in x0.shape[2:])

@@ -88,6 +88,7 @@ FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          "no_convt_k2": bool(os.environ.get("ADELL_NO_CONVT_K2")),
          "no_grad_carry": bool(os.environ.get("ADELL_NO_GRAD_CARRY")),
          "no_skip_fork": bool(os.environ.get("ADELL_NO_SKIP_FORK")),
+         "no_s2fused": bool(os.environ.get("ADELL_NO_S2FUSED")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
@@ -524,6 +525,33 @@ def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None, add0=
             ctypes.byref(d), _ptr(dy), wh, ws, _ptr(dx), _ptr(amax), _stream())
     check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d), call,
                  _conv_tag(d, "dgrad"), _conv_bytes(d), kernels=8))
+    return dx
+
+
+def conv3d_bwd_data_s2_fused_ok(in_size, C0, C1, Cout, kernel, stride, padding):
+    """The one-launch backward-data of the 32 -> 32 stride-2 k = 3 padding-1 layer applies."""
+    if FLAGS["no_s2fused"] or C1 != 0:
+        return False
+    d = make_conv_desc(1, tuple(in_size), C0, 0, Cout, kernel, stride, padding)
+    return bool(_lib.lib().adell_conv3d_bwd_data_s2_fused_applicable(ctypes.byref(d)))
+
+
+def conv3d_bwd_data_s2_fused(dy, w, in_size, amax=None, add0=None):
+    """dX of that layer (csrc/conv_dgrad_s2.hip); ``w``: SplitWeight of the full weight, mode 1."""
+    _require_cuda(dy, add0)
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    d = make_conv_desc(N, tuple(in_size), 32, 0, Cout, 3, 2, 1)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    dx = new_act(N, 32, *in_size, dy.device)
+    if add0 is not None:
+        add0 = ndhwc(add0)
+        assert add0.shape == dx.shape
+    check(_timed("adell_dgrad_s2_fused_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv3d_bwd_data_s2_fused(
+                     ctypes.byref(d), _ptr(dy), _ptr(w.halfs), _ptr(w.scale), _ptr(add0), _ptr(dx),
+                     _ptr(amax), _stream()),
+                 _conv_tag(d, "dgrad"), _conv_bytes(d)))
     return dx
 
 

@@ -136,6 +136,16 @@ int adell_conv3d_bwd_data_s2_f16x3_add(const adell_conv3d_desc* d, const float* 
                                        const float* add0, float* dx, uint32_t* dy_absmax,
                                        void* stream);
 
+/* The U-Net downsampling layer (32 -> 32 channels, k = 3, stride 2, padding 1, even input dims:
+ * unet.py:571-579) in ONE launch: a persistent block keeps the split weight in LDS, stages the dY
+ * halo of a brick once and produces all eight parity classes of the dX voxels behind it
+ * (csrc/conv_dgrad_s2.hip). w_split_bwd / wscale: adell_pack_weight_f16x3 mode 1 of the full
+ * weight; add0: null or as above. _applicable: 1 when the layer qualifies. */
+int adell_conv3d_bwd_data_s2_fused_applicable(const adell_conv3d_desc* d);
+int adell_conv3d_bwd_data_s2_fused(const adell_conv3d_desc* d, const float* dy,
+                                   const void* w_split_bwd, const float* wscale,
+                                   const float* add0, float* dx, uint32_t* dy_absmax, void* stream);
+
 /* The same two calls with a caller-provided workspace (adell_conv3d_splitk_workspace bytes; 0 =
  * never needed): layers with too few output bricks to fill the chip (the 8^3 - 16^3 levels)
  * share the channel chunks of a brick out over several blocks (split-K) and fold the partial
