@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadellhip.so")
+# ADELL_HIP_LIBRARY: another build of the same library (tools/ab_lib.py compares two builds)
+LIB_PATH = os.environ.get("ADELL_HIP_LIBRARY") or os.path.join(_HERE, "libadellhip.so")
 
 _lib = None
 

@@ -9,6 +9,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define ADELL_WAVE 64
+// Pointer into GLOBAL memory (address space 1). A pointer rebuilt from integers (e.g. after
+// readfirstlane) is a generic pointer: accessed with flat_load / flat_store, which count on lgkmcnt
+// as well as vmcnt, so every LDS wait behind one becomes a wait for the memory operation too.
+#define ADELL_GLOBAL __attribute__((address_space(1)))
 
 void adell_set_error(const char* fmt, ...);
 

@@ -35,10 +35,7 @@ constexpr int kPer = (kItems + 255) / 256;                         // ... per th
 
 // a wave-uniform pointer pinned into SGPRs: `p[(unsigned)lane_offset]` is then one scalar-base +
 // 32-bit-VGPR-offset access
-// (typed as a GLOBAL-address-space pointer: rebuilt from integers as a generic pointer it would be
-// accessed with flat_load / flat_store, which also count on lgkmcnt and turn every LDS wait of the
-// MFMA loop into a wait for the memory operations in flight)
-#define ADELL_GLOBAL __attribute__((address_space(1)))
+// (typed ADELL_GLOBAL, see common.h: no flat_load / flat_store in the MFMA loop)
 template <typename T>
 __device__ __forceinline__ ADELL_GLOBAL T* uniform_ptr(T* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);

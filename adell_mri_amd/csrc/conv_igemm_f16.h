@@ -30,11 +30,19 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 // A pointer the caller knows to be wave-uniform, pinned into SGPRs so that `p + (unsigned)offset`
 // becomes one scalar-base + 32-bit-VGPR-offset access instead of a 64-bit per-lane pointer (which
 // the compiler would hoist out of the loops, one register pair per access, and spill).
-__device__ __forceinline__ const char* adell_uniform_ptr(const void* p) {
+// (ADELL_GLOBAL, common.h: global_load, not flat_load -- round 2 shipped the generic-pointer form,
+// whose flat loads made every LDS fragment wait of the MFMA loop a wait for the weight prefetch)
+__device__ __forceinline__ const ADELL_GLOBAL char* adell_uniform_ptr(const void* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  return reinterpret_cast<const ADELL_GLOBAL char*>(((uint64_t)hi << 32) | lo);
+}
+
+// 16 bytes from global memory
+__device__ __forceinline__ float4 adell_gload4(const ADELL_GLOBAL char* p) {
+  const f32x4 v = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 struct ConvF16Extra {
@@ -172,13 +180,13 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     if constexpr (SPEC) {
       // both sources hold whole chunks (C0, C1 multiples of 16): one uniform base per chunk
       const bool first = c0 < a.C0;
-      const char* src = adell_uniform_ptr(first ? x0n + c0 : x1n + (c0 - a.C0));
+      const ADELL_GLOBAL char* src = adell_uniform_ptr(first ? x0n + c0 : x1n + (c0 - a.C0));
       const unsigned cs = first ? a.C0 : a.C1;
       // byte offset inside the batch item: < 2^32 (checked on the host)
-      const float4* p = reinterpret_cast<const float4*>(src + (unsigned)gvi * cs * 4u);
+      const ADELL_GLOBAL char* p = src + (unsigned)gvi * cs * 4u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 f = p[q];
+        const float4 f = adell_gload4(p + 16 * q);
         v[4 * q + 0] = f.x;
         v[4 * q + 1] = f.y;
         v[4 * q + 2] = f.z;
@@ -256,7 +264,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       for (int u = 0; u < WPF; ++u) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
         if (wcolok && u * TPU + wtap < tpg_)
-          f = *reinterpret_cast<const float4*>(adell_uniform_ptr(base + u * ustride) + wgoff);
+          f = adell_gload4(adell_uniform_ptr(base + u * ustride) + wgoff);
         wreg[u] = f;
       }
       return;
@@ -305,7 +313,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       if constexpr (SPEC) {
         const bool first = c0 < a.C0;
         const unsigned nch = (first ? a.C0 : a.C1) >> 4;       // chunks per voxel of this source
-        const char* src = adell_uniform_ptr(
+        const ADELL_GLOBAL char* src = adell_uniform_ptr(
             (first ? e.xs0 + ((size_t)vox0 * (a.C0 >> 4) + (c0 >> 4)) * 64
                    : e.xs1 + ((size_t)vox0 * (a.C1 >> 4) + ((c0 - a.C0) >> 4)) * 64));
 #pragma unroll
@@ -315,10 +323,9 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) f[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gvk[u] >= 0) {
-              const float4* p =
-                  reinterpret_cast<const float4*>(src + (size_t)((unsigned)gvk[u] * nch) * 64u);
+              const ADELL_GLOBAL char* p = src + (size_t)((unsigned)gvk[u] * nch) * 64u;
 #pragma unroll
-              for (int q = 0; q < 4; ++q) f[q] = p[q];
+              for (int q = 0; q < 4; ++q) f[q] = adell_gload4(p + 16 * q);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {

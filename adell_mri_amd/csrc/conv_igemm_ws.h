@@ -125,7 +125,7 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
       const int c0 = ch * CC;
       const size_t vox0 = (size_t)it.nb * a.D * a.H * a.W;
       const bool firstsrc = c0 < a.C0;
-      const char* src = adell_uniform_ptr(firstsrc ? a.x0 + vox0 * a.C0 + c0
+      const ADELL_GLOBAL char* src = adell_uniform_ptr(firstsrc ? a.x0 + vox0 * a.C0 + c0
                                                    : a.x1 + vox0 * a.C1 + (c0 - a.C0));
       const unsigned cs = firstsrc ? a.C0 : a.C1;
 #pragma unroll
@@ -133,10 +133,10 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
         // exactly 4 loads per voxel whatever the lane's voxel is (the counted vmcnt below relies
         // on it): voxels outside the tensor read voxel 0 and are zeroed
         const bool ok = gvk[u] >= 0;
-        const float4* p = reinterpret_cast<const float4*>(src + (unsigned)(ok ? gvk[u] : 0) * cs * 4u);
+        const ADELL_GLOBAL char* p = src + (unsigned)(ok ? gvk[u] : 0) * cs * 4u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 f = p[q];
+          const float4 f = adell_gload4(p + 16 * q);
           keep[u][4 * q + 0] = ok ? f.x : 0.f;
           keep[u][4 * q + 1] = ok ? f.y : 0.f;
           keep[u][4 * q + 2] = ok ? f.z : 0.f;

@@ -72,11 +72,18 @@ __device__ __forceinline__ void adell_zr_split_store(char* hi_plane, char* lo_pl
   *reinterpret_cast<zr_half4*>(lo_plane + off) = l;
 }
 
-__device__ __forceinline__ const char* adell_zr_uniform(const void* p) {
+// (ADELL_GLOBAL, common.h: the plane prefetches are in flight under the MFMAs of a z step; as flat
+// loads they made every LDS fragment wait of that step a wait for them)
+__device__ __forceinline__ const ADELL_GLOBAL char* adell_zr_uniform(const void* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+  return reinterpret_cast<const ADELL_GLOBAL char*>(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float4 adell_zr_gload4(const ADELL_GLOBAL char* p) {
+  const f32x4 v = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 
 constexpr int ZR_HX = 10, ZR_HV = 100;      // halo plane of an 8 x 8 brick
@@ -179,11 +186,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
       const bool pok = p >= 0 && p < a.D;
       const size_t plane = (size_t)(nb * a.D + (pok ? p : 0)) * a.H * a.W;
       if (uni) {
-        const char* base = adell_zr_uniform(xsrc + plane * xcs);
+        const ADELL_GLOBAL char* base = adell_zr_uniform(xsrc + plane * xcs);
 #pragma unroll
         for (int u = 0; u < ZR_NX; ++u) {
           float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (pok && xok[u]) f = *reinterpret_cast<const float4*>(base + xoff[u]);
+          if (pok && xok[u]) f = adell_zr_gload4(base + xoff[u]);
           xr[u] = f;
         }
       } else {
@@ -197,12 +204,12 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
       }
     };
     auto fetch_y = [&](int z) {
-      const char* base =
+      const ADELL_GLOBAL char* base =
           adell_zr_uniform(a.dy + ((size_t)(nb * a.Do + z) * a.Ho * a.Wo) * a.Cout);
 #pragma unroll
       for (int u = 0; u < ZR_NY; ++u) {
         float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (yok[u]) f = *reinterpret_cast<const float4*>(base + yoff[u]);
+        if (yok[u]) f = adell_zr_gload4(base + yoff[u]);
         yr[u] = f;
       }
     };
