@@ -335,6 +335,35 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
           }
         }
       }
+    } else if (SPEC) {
+      if constexpr (SPEC != 0) {
+        // branch-free: every load of the chunk is in flight before the first value is looked at
+        // (voxels outside the tensor / past the halo read voxel 0 and are zeroed). With the
+        // per-voxel early-out of load16 each voxel's four loads were waited for in turn.
+        const bool first = c0 < a.C0;
+        const ADELL_GLOBAL char* src = adell_uniform_ptr(first ? x0n + c0 : x1n + (c0 - a.C0));
+        const unsigned cs = first ? a.C0 : a.C1;
+        float4 f[KEEP][4];
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+          const ADELL_GLOBAL char* p = src + (unsigned)(gvk[u] >= 0 ? gvk[u] : 0) * cs * 4u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) f[u][q] = adell_gload4(p + 16 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+          const bool ok = gvk[u] >= 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            keep[u][4 * q + 0] = ok ? f[u][q].x : 0.f;
+            keep[u][4 * q + 1] = ok ? f[u][q].y : 0.f;
+            keep[u][4 * q + 2] = ok ? f[u][q].z : 0.f;
+            keep[u][4 * q + 3] = ok ? f[u][q].w : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < CC; ++j) mx = fmaxf(mx, fabsf(keep[u][j]));
+        }
+      }
     } else if (resident) {
 #pragma unroll
       for (int u = 0; u < KEEP; ++u) {
@@ -475,8 +504,12 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       }
       __syncthreads();
       if (wpipe && !skipB) {
-        if (grp + 1 < ngroups) wfetch(ch, grp + 1);
-        else if (ch + 1 < c_end) wfetch(ch + 1, 0);
+        // ONE fetch site: with two (next group / first group of the next chunk) the prefetch
+        // registers meet in a phi, the copies behind it read them, and the wait for those copies
+        // (vmcnt(0) right here) exposed the whole prefetch latency in front of every tap group
+        const bool same_chunk = grp + 1 < ngroups;
+        const int fch = same_chunk ? ch : ch + 1, fgrp = same_chunk ? grp + 1 : 0;
+        if (fch < c_end) wfetch(fch, fgrp);
       }
       // ---- 3 f16 MFMAs per (tap, 32x32 tile) ---------------------------------------------
       const char* sAg = sA + (size_t)((kz * HY + ky0) * HX) * 64;
