@@ -42,26 +42,36 @@ __device__ __forceinline__ size_t adell_ctk2_shfl(size_t v, int src) {
   return ((size_t)hi << 32) | lo;
 }
 
-// wave-private copy of 32 rows x WIDTH floats into an LDS tile with row stride `ld`: lane l holds
-// the element offset of row l & 31 in `myrow` (the address arithmetic of a row is done once, by one
-// lane); rows >= valid are zero-filled. All loads are issued before the first LDS store.
+// wave-private copy of 32 rows x WIDTH floats into an LDS tile with row stride `ld`, in two halves
+// so that the loads of the NEXT tile are in flight while the MFMAs of the current one run: lane l
+// holds the element offset of row l & 31 in `myrow` (the address arithmetic of a row is done once,
+// by one lane); rows >= valid are zero-filled.
 template <int WIDTH>
-__device__ __forceinline__ void adell_ctk2_stage(float* tile, int ld, int valid, int lane,
+struct CtK2Regs {
+  static constexpr int W4 = WIDTH / 4, PER = 32 * W4 / 64;
+  float4 f[PER];
+};
+template <int WIDTH>
+__device__ __forceinline__ void adell_ctk2_fetch(CtK2Regs<WIDTH>& g, int valid, int lane,
                                                  const float* src, size_t myrow, int col0 = 0) {
   constexpr int W4 = WIDTH / 4, PER = 32 * W4 / 64;
-  float4 f[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = lane + 64 * u, r = i / W4, c4 = i - r * W4;
     const size_t off = adell_ctk2_shfl(myrow, r);
-    f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < valid) f[u] = *reinterpret_cast<const float4*>(src + off + col0 + 4 * c4);
+    g.f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < valid) g.f[u] = *reinterpret_cast<const float4*>(src + off + col0 + 4 * c4);
   }
+}
+template <int WIDTH>
+__device__ __forceinline__ void adell_ctk2_put(float* tile, int ld, int lane,
+                                               const CtK2Regs<WIDTH>& g) {
+  constexpr int W4 = WIDTH / 4, PER = 32 * W4 / 64;
 #pragma unroll
   for (int u = 0; u < PER; ++u) {
     const int i = lane + 64 * u, r = i / W4, c4 = i - r * W4;
     float* q = tile + r * ld + 4 * c4;
-    q[0] = f[u].x; q[1] = f[u].y; q[2] = f[u].z; q[3] = f[u].w;
+    q[0] = g.f[u].x; q[1] = g.f[u].y; q[2] = g.f[u].z; q[3] = g.f[u].w;
   }
 }
 
@@ -80,12 +90,20 @@ __global__ __launch_bounds__(256) void adell_convt_k2_fwd_kernel(ConvTK2Args a) 
       bw[fx][s] = a.w[((size_t)(2 * s + lh) * a.Cout + col) * 8 + (fz * 2 + fy) * 2 + fx];
   const float bcol = a.bias ? a.bias[col] : 0.f;
   float* tile = sx[wave];
+  CtK2Regs<CIN> regs;
+  auto fetch = [&](int t) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    adell_ctk2_fetch<CIN>(regs, valid, lane, a.x + (size_t)v0 * CIN, (size_t)li * CIN);
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const long v0 = (long)t * 32;
     const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
-    adell_ctk2_stage<CIN>(tile, LD, valid, lane, a.x + (size_t)v0 * CIN, (size_t)li * CIN);
+    adell_ctk2_put<CIN>(tile, LD, lane, regs);
     const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) : 0;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done
+    if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);   // in flight under the MFMAs / stores
     f32x16 acc[2];
 #pragma unroll
     for (int fx = 0; fx < 2; ++fx)
@@ -125,12 +143,20 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dx_kernel(ConvTK2Args a) {
     bw[s] = a.w[((size_t)ci * COUT + co) * 8 + (fz * 2 + fy) * 2 + fx];
   }
   float* tile = smem + wave * 32 * LD;
+  CtK2Regs<KW> regs;
+  auto fetch = [&](int t) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    adell_ctk2_fetch<KW>(regs, valid, lane, a.dy,
+                         li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) * COUT : 0);
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const long v0 = (long)t * 32;
     const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
-    adell_ctk2_stage<KW>(tile, LD, valid, lane, a.dy,
-                         li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) * COUT : 0);
+    adell_ctk2_put<KW>(tile, LD, lane, regs);
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -173,15 +199,23 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
     for (int r = 0; r < 16; ++r) acc[fx][r] = 0.f;
   float* tx = sx[wave];
   float* tyl = sy[wave];
-  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+  CtK2Regs<32> rx, ry0, ry1;
+  auto fetch = [&](int t) {
     const long v0 = (long)t * 32;
     const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
     const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) * a.Cout : 0;
-    adell_ctk2_stage<32>(tx, LDX, valid, lane, a.x + (size_t)v0 * a.Cin + ci0, (size_t)li * a.Cin);
+    adell_ctk2_fetch<32>(rx, valid, lane, a.x + (size_t)v0 * a.Cin + ci0, (size_t)li * a.Cin);
     // the two fine-grid voxels (fx = 0, 1) of a coarse voxel are adjacent rows of Cout floats
-    adell_ctk2_stage<32>(tyl, LDY, valid, lane, a.dy, yrow, co0);
-    adell_ctk2_stage<32>(tyl + 32, LDY, valid, lane, a.dy, yrow, a.Cout + co0);
+    adell_ctk2_fetch<32>(ry0, valid, lane, a.dy, yrow, co0);
+    adell_ctk2_fetch<32>(ry1, valid, lane, a.dy, yrow, a.Cout + co0);
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    adell_ctk2_put<32>(tx, LDX, lane, rx);
+    adell_ctk2_put<32>(tyl, LDY, lane, ry0);
+    adell_ctk2_put<32>(tyl + 32, LDY, lane, ry1);
     __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int v = 2 * s + lh;
@@ -251,7 +285,7 @@ extern "C" int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout,
   ConvTK2Args a = {};
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
-  dim3 grid((unsigned)adell_ctk2_blocks(a, 8), (unsigned)(Cout / 32));
+  dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cout / 32));
   if (Cin == 32)
     hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else
@@ -269,7 +303,7 @@ extern "C" int adell_convt_k2_bwd_data(int N, int D, int H, int W, int Cin, int 
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
   a.dy = dy; a.w = w; a.dx = dx;
   const size_t lds = (size_t)(4 * 32 * (2 * Cout + 1) + 3 * 32 * 33) * sizeof(float);
-  dim3 grid((unsigned)adell_ctk2_blocks(a, 4), (unsigned)(Cin / 32));
+  dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cin / 32));
   static bool attr_done = false;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_convt_k2_dx_kernel<64>),
