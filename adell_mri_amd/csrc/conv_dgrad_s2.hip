@@ -66,6 +66,9 @@ struct DgradS2Args {
   int nbricks;
 };
 
+}  // namespace
+
+// (at global scope so that profilers print its name)
 // DBG: timing experiments, results are wrong when nonzero (instantiated by -DADELL_DEBUG builds
 // only): 1 no MFMAs, 2 no dX stores, 4 no weight staging, 8 no halo split / LDS stores, 16 no halo
 // loads after the first brick
@@ -330,6 +333,8 @@ __global__ __launch_bounds__(256, 1) void adell_dgrad_s2_fused_kernel(DgradS2Arg
   }
   if (a.amax_out != nullptr && tid == 0) atomicMax(a.amax_out, __float_as_uint(block_max));
 }
+
+namespace {
 
 int cu_count() {
   static int cus = 0;
