@@ -1,0 +1,394 @@
+// Row-major fp32 GEMM on the f16 MFMA by error-compensated splitting ("f16x3", see
+// conv_igemm_f16.h) for the Linear layers of the token / feature paths (ConvNeXt point-wise MLPs
+// res_blocks.py:559-566, ViT / SWIN projections linear_blocks.py, projection heads
+// res_net.py:278-324): same contract as adell_gemm_f32 (csrc/gemm.hip),
+//
+//     C[M][N] = sum_k A(m, k) * B(k, n)  (+ bias[n]) (+ residual[m][n])
+//
+// with each operand k-contiguous (KC: A[m*lda + k], B[n*ldb + k]) or outer-contiguous (A[k*lda + m],
+// B[k*ldb + n]) -- forward X W^T (KC, KC), backward-data dY W (KC, outer), backward-weight dY^T X
+// (outer, outer) -- at 3 f16 MFMAs per product instead of the fp32 MFMA's 5.3x lower rate.
+//
+// Range: one power-of-two scale per operand TENSOR from its absmax (a device word the caller
+// provides: adell_absmax_f32; max lands in [2^13, 2^14)), undone in the epilogue.
+//
+// A block of 4 waves owns a 128 x 128 tile (wave = 64 x 64 = 2 x 2 MFMA tiles); a stage is 64 k
+// values: both operand tiles go global -> registers -> split to (hi, lo) halves -> LDS
+// (one 64 KB image, the next stage's loads in flight in registers under the MFMAs; two resident
+// blocks per CU).
+// LDS image of an operand tile: [16-k chunk][row][64 B = hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15],
+// rows permuted inside blocks of 16 and slots XOR-swizzled so that the ds_read_b128 fragment
+// reads are conflict-free AND the 8-byte writes of a transposed (outer-contiguous) operand spread
+// over the banks. A KC tile is loaded as rows of 256 contiguous bytes (16 lanes per row); an
+// outer-contiguous tile as k-rows of 512 contiguous bytes, each thread holding 4 k x 4 rows and
+// writing the four 4-k half-slots of its rows -- the transpose costs no extra pass.
+// Skinny problems split K (deterministic: slabs + fixed-order fold with bias / residual).
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct GemmHArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* residual;
+  float* slab;
+  const unsigned* amaxA;
+  const unsigned* amaxB;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int splits, stages_per_split;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64, NCH = BK / 16;
+constexpr int kTileBytes = NCH * 128 * 64;   // one operand tile: [4 chunks][128 rows][64 B] = 32 KB
+
+// byte offset of (row, 16-byte slot) inside a chunk image
+__device__ __forceinline__ int lds_off(int r, int slot) {
+  const int r2 = (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3);
+  const int s2 = slot ^ (r & 3) ^ ((r >> 4) & 3);
+  return r2 * 64 + s2 * 16;
+}
+
+__device__ __forceinline__ int scale_exp(unsigned amax_bits) {
+  const int ebits = (amax_bits >> 23) & 0xff;
+  int k = 0;
+  if (ebits > 0 && ebits < 255) k = 13 - (ebits - 127);
+  if (k > 100) k = 100;
+  if (k < -100) k = -100;
+  return k;
+}
+
+__device__ __forceinline__ void split4(const float4& f, float scale, half4* h, half4* l) {
+  const float v[4] = {f.x * scale, f.y * scale, f.z * scale, f.w * scale};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    (*h)[j] = (_Float16)v[j];
+    (*l)[j] = (_Float16)(v[j] - (float)(*h)[j]);
+  }
+}
+
+}  // namespace
+
+// KC operand tile: X[(r0 + row) * ld + k0 + k], 128 rows x 64 k. Thread t: k quad q = t & 15 of
+// rows (t >> 4) + 16 u (a row = 256 contiguous bytes over 16 lanes). Outer operand tile:
+// X[(k0 + k) * ld + r0 + row]. Thread t: rows 4 (t & 31) .. + 3, k = 32 u + 4 (t >> 5) .. + 3 (a k-row
+// = 512 contiguous bytes over 32 lanes).
+template <bool KC>
+__device__ __forceinline__ unsigned gemm_h_fetch(float4 (&f)[8], const float* X, long ld, int rows,
+                                                 int kext, int r0, int k0, int tid) {
+  unsigned okbits = 0;   // bit u: f[u] is inside the matrix (applied by gemm_h_put: a select here
+                         // would wait for the loads right after they are issued)
+  // branch-free: positions past the matrix read element (0, 0) and are zeroed, so that the eight
+  // loads are in flight together (a conditional load per element made them wait for each other)
+  if constexpr (KC) {
+    const int k = k0 + 4 * (tid & 15);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = r0 + (tid >> 4) + 16 * u;
+      const bool ok = (r < rows) & (k < kext);
+      f[u] = *reinterpret_cast<const float4*>(X + (ok ? (long)r * ld + k : 0L));
+      okbits |= ok ? (1u << u) : 0u;
+    }
+  } else {
+    const int r = r0 + 4 * (tid & 31);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 32 * u + 4 * (tid >> 5) + j;
+        const bool ok = (r < rows) & (k < kext);
+        f[4 * u + j] = *reinterpret_cast<const float4*>(X + (ok ? (long)k * ld + r : 0L));
+        okbits |= ok ? (1u << (4 * u + j)) : 0u;
+      }
+  }
+  return okbits;
+}
+
+template <bool KC>
+__device__ __forceinline__ void gemm_h_put(char* tile, const float4 (&fin)[8], unsigned okbits,
+                                           float scale, int tid) {
+  float4 f[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const bool ok = (okbits >> u) & 1u;
+    f[u] = make_float4(ok ? fin[u].x : 0.f, ok ? fin[u].y : 0.f, ok ? fin[u].z : 0.f,
+                       ok ? fin[u].w : 0.f);
+  }
+  if constexpr (KC) {
+    const int q = tid & 15, chunk = q >> 2, slot = (q & 3) >> 1, half = q & 1;
+    char* base = tile + chunk * (128 * 64) + half * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = (tid >> 4) + 16 * u;
+      half4 h, l;
+      split4(f[u], scale, &h, &l);
+      *reinterpret_cast<half4*>(base + lds_off(r, slot)) = h;
+      *reinterpret_cast<half4*>(base + lds_off(r, 2 + slot)) = l;
+    }
+  } else {
+    const int kg = tid >> 5, slot = (kg & 3) >> 1, half = kg & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      char* base = tile + (2 * u + (kg >> 2)) * (128 * 64) + half * 8;
+      const float4* g = f + 4 * u;
+      const float v[4][4] = {{g[0].x, g[0].y, g[0].z, g[0].w}, {g[1].x, g[1].y, g[1].z, g[1].w},
+                             {g[2].x, g[2].y, g[2].z, g[2].w}, {g[3].x, g[3].y, g[3].z, g[3].w}};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // row 4 (t & 31) + c: its k = 32 u + 4 kg .. + 3
+        const float4 col = make_float4(v[0][c], v[1][c], v[2][c], v[3][c]);
+        half4 h, l;
+        split4(col, scale, &h, &l);
+        const int r = 4 * (tid & 31) + c;
+        *reinterpret_cast<half4*>(base + lds_off(r, slot)) = h;
+        *reinterpret_cast<half4*>(base + lds_off(r, 2 + slot)) = l;
+      }
+    }
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * kTileBytes];   // [A | B], 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  const int nstages = (a.K + BK - 1) / BK;
+  const int s_beg = split * a.stages_per_split;
+  const int s_end = (s_beg + a.stages_per_split) < nstages ? (s_beg + a.stages_per_split) : nstages;
+  const int kA = scale_exp(*a.amaxA), kB = scale_exp(*a.amaxB);
+  const float scaleA = __int_as_float((kA + 127) << 23), scaleB = __int_as_float((kB + 127) << 23);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // One LDS image, the next stage in registers: with two resident blocks per CU a stage's loads
+  // are in flight for two MFMA phases (2 x 48 MFMAs per wave), enough to cover the memory latency
+  // that a 32-k double-buffered stage (24 MFMAs) exposed.
+  float4 fa[8], fb[8];
+  unsigned oka = 0, okb = 0;
+  auto fetch = [&](int s) {
+    oka = gemm_h_fetch<AKC>(fa, a.A, a.lda, a.M, a.K, m0, s * BK, tid);
+    okb = gemm_h_fetch<BKC>(fb, a.B, a.ldb, a.N, a.K, n0, s * BK, tid);
+  };
+  const char* tA = smem;
+  const char* tB = smem + kTileBytes;
+  // iteration s: issue the loads of stage s, run the MFMAs of stage s - 1 out of LDS, then move
+  // stage s from registers to LDS. ONE fetch site: with a prologue fetch + a loop fetch the
+  // registers meet in a phi whose copies wait for the loads right after they are issued.
+  for (int s = s_beg; s <= s_end; ++s) {
+    if (s < s_end) fetch(s);
+    if (s > s_beg) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      half8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + li;
+        ah[i] = *reinterpret_cast<const half8*>(tA + ch * (128 * 64) + lds_off(r, lh));
+        al[i] = *reinterpret_cast<const half8*>(tA + ch * (128 * 64) + lds_off(r, 2 + lh));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = wn * 64 + j * 32 + li;
+        bh[j] = *reinterpret_cast<const half8*>(tB + ch * (128 * 64) + lds_off(r, lh));
+        bl[j] = *reinterpret_cast<const half8*>(tB + ch * (128 * 64) + lds_off(r, 2 + lh));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    }
+    if (s < s_end) {
+      __syncthreads();   // the fragments of stage s - 1 are read
+      gemm_h_put<AKC>(smem, fa, oka, scaleA, tid);
+      gemm_h_put<BKC>(smem + kTileBytes, fb, okb, scaleB, tid);
+      __syncthreads();
+    }
+  }
+
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const float oscale = __int_as_float((127 - kA - kB) << 23);
+  const bool direct = a.splits == 1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + li;
+      if (col >= a.N) continue;
+      const float bv = (direct && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= a.M) continue;
+        float v = acc[i][j][r] * oscale;
+        if (direct) {
+          v += bv;
+          if (a.residual) v += a.residual[(long)row * a.ldr + col];
+          a.C[(long)row * a.ldc + col] = v;
+        } else {
+          a.slab[((long)split * a.M + row) * a.N + col] = v;
+        }
+      }
+    }
+}
+
+// fixed-order fold of the split-K slabs (+ bias, residual): one thread per output
+__global__ __launch_bounds__(256) void adell_gemm_f16x3_fold_kernel(GemmHArgs a) {
+  const long total = (long)a.M * a.N;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    float s = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) s += a.slab[(long)sp * total + i];
+    const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+    if (a.bias) s += a.bias[col];
+    if (a.residual) s += a.residual[(long)row * a.ldr + col];
+    a.C[(long)row * a.ldc + col] = s;
+  }
+}
+
+// absmax (float bits, atomicMax into a zero-initialised word) of n floats
+__global__ __launch_bounds__(256) void adell_absmax_f32_kernel(const float* __restrict__ x, long n,
+                                                               unsigned* __restrict__ out) {
+  float mx = 0.f;
+  const long n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+    const float4 f = x4[i];
+    mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f.x)), fmaxf(fabsf(f.y), fabsf(f.z))), fabsf(f.w));
+  }
+  for (long i = (n4 << 2) + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+    mx = fmaxf(mx, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  // one atomic per block, and only when it can raise the word (thousands of waves hitting one
+  // address serialised: 100 us for a 50 MB tensor)
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const unsigned bits = __float_as_uint(mx);
+    if (bits > *reinterpret_cast<volatile unsigned*>(out)) atomicMax(out, bits);
+  }
+}
+
+namespace {
+
+struct GemmHPlan {
+  int splits, stages_per_split;
+};
+
+GemmHPlan gemm_h_plan(int M, int N, int K) {
+  GemmHPlan p;
+  const long tiles = (long)adell_cdiv(M, BM) * adell_cdiv(N, BN);
+  const int stages = adell_cdiv(K, BK);
+  long s = adell_cdiv(512, (int)(tiles < 512 ? tiles : 512));   // two resident blocks per CU
+  if (s > stages / 4) s = stages / 4;                          // at least four stages per split
+  const long slab_cap = (16L << 20) / ((long)M * N);           // slabs capped at 64 MB
+  if (s > slab_cap) s = slab_cap;
+  if (s > 65535) s = 65535;
+  if (s < 1) s = 1;
+  p.stages_per_split = adell_cdiv(stages, (int)s);
+  p.splits = adell_cdiv(stages, p.stages_per_split);
+  return p;
+}
+
+bool gemm_h_ok(int M, int N, int K, const float* A, long lda, int a_kc, const float* B, long ldb,
+               int b_kc) {
+  if (M <= 0 || N <= 0 || K <= 0) return false;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return false;
+  if ((lda | ldb) & 3) return false;
+  // whole 16-byte groups along each operand's contiguous axis
+  if (K & 3) return (false);
+  if (!a_kc && (M & 3)) return false;
+  if (!b_kc && (N & 3)) return false;
+  return true;
+}
+
+}  // namespace
+
+// absmax of n floats as float bits into *out (zero-initialised by the caller): the operand scale
+// words of adell_gemm_f16x3.
+extern "C" int adell_absmax_f32(const float* x, long n, uint32_t* out, void* stream) {
+  ADELL_REQUIRE(x && out && n > 0, "absmax_f32: bad arguments");
+  ADELL_REQUIRE(((uintptr_t)x & 15) == 0, "absmax_f32: x must be 16-byte aligned");
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adell_absmax_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     x, n, out);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// 1 when adell_gemm_f16x3 takes the problem (16-byte aligned operands, leading dimensions and K
+// multiples of 4, outer-contiguous operands with a multiple-of-4 outer extent).
+extern "C" int adell_gemm_f16x3_applicable(int M, int N, int K, const float* A, long lda, int a_kc,
+                                           const float* B, long ldb, int b_kc) {
+  return gemm_h_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc) ? 1 : 0;
+}
+
+extern "C" long adell_gemm_f16x3_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const GemmHPlan p = gemm_h_plan(M, N, K);
+  return p.splits > 1 ? (long)p.splits * M * N : 0;
+}
+
+// Same contract as adell_gemm_f32 + a_absmax / b_absmax: device words holding the float bits of
+// the absmax of the A / B tensors (adell_absmax_f32, or any upper bound within a factor of 2^10).
+extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, int a_kc,
+                                const float* B, long ldb, int b_kc, float* C, long ldc,
+                                const float* bias, const float* residual, long ldr,
+                                const uint32_t* a_absmax, const uint32_t* b_absmax,
+                                float* workspace, void* stream) {
+  ADELL_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f16x3: bad dims");
+  ADELL_REQUIRE(A && B && C && a_absmax && b_absmax, "gemm_f16x3: null pointer");
+  ADELL_REQUIRE(lda >= (a_kc ? K : M) && ldb >= (b_kc ? K : N) && ldc >= N, "gemm_f16x3: bad strides");
+  ADELL_REQUIRE(!residual || ldr >= N, "gemm_f16x3: bad residual stride");
+  if (!gemm_h_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc)) {
+    adell_set_error("gemm_f16x3: operands need 16-byte alignment, leading dimensions / K multiples of 4");
+    return ADELL_E_UNSUPPORTED;
+  }
+  const GemmHPlan p = gemm_h_plan(M, N, K);
+  ADELL_REQUIRE(p.splits == 1 || workspace, "gemm_f16x3: workspace required for this shape");
+  GemmHArgs a;
+  a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.slab = workspace;
+  a.amaxA = a_absmax; a.amaxB = b_absmax;
+  a.M = M; a.N = N; a.K = K;
+  a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
+  a.splits = p.splits;
+  a.stages_per_split = p.stages_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(adell_cdiv(M, BM), adell_cdiv(N, BN), p.splits);
+  ADELL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_f16x3: grid too large");
+  if (a_kc && b_kc)
+    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<true, true>), grid, dim3(256), 0, st, a);
+  else if (a_kc && !b_kc)
+    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<true, false>), grid, dim3(256), 0, st, a);
+  else if (!a_kc && !b_kc)
+    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<false, false>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<false, true>), grid, dim3(256), 0, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  if (p.splits > 1) {
+    long blocks = ((long)M * N + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(adell_gemm_f16x3_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+  }
+  return ADELL_OK;
+}

@@ -556,6 +556,11 @@ def _volume_as_rows(y, lead_shape):
 
 
 class _LinearFn(torch.autograd.Function):
+    """x W^T (+ bias) (+ residual) on the fp32-MFMA GEMM (ops.gemm). Opt-in
+    (``ops.FLAGS["gemm_f16x3"]`` / ADELL_GEMM_F16X3=1, with CONV_PRECISION "f16x3"): the three GEMMs
+    on the f16 MFMA with the error-compensated split (ops.gemm_f16x3) whenever the operands
+    qualify -- faster per launch, slower per step at the measured configurations."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
         N, K = weight.shape
@@ -563,8 +568,16 @@ class _LinearFn(torch.autograd.Function):
         rows = x2.shape[0]
         w = weight.contiguous()
         res2 = None if residual is None else residual.reshape(rows, N).contiguous()
-        y = ops.gemm(rows, N, K, x2, K, True, w, K, True, bias=bias, residual=res2)
+        split = CONV_PRECISION == "f16x3" and ops.gemm_f16x3_ok(rows, N, K, x2, K, True, w, K, True)
+        x_amax = w_amax = None
+        if split:
+            x_amax, w_amax = ops.absmax_word(x2), ops.absmax_word(w)
+            y = ops.gemm_f16x3(rows, N, K, x2, K, True, w, K, True, x_amax, w_amax, bias=bias,
+                               residual=res2)
+        else:
+            y = ops.gemm(rows, N, K, x2, K, True, w, K, True, bias=bias, residual=res2)
         ctx.save_for_backward(x2, w)
+        ctx.amax = (x_amax, w_amax)
         ctx.meta = (x.shape, bias is not None, residual is not None and residual.shape)
         return y.view(*x.shape[:-1], N)
 
@@ -572,15 +585,26 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         xshape, has_bias, res_shape = ctx.meta
+        x_amax, w_amax = ctx.amax
         N, K = w.shape
         rows = x2.shape[0]
         need = ctx.needs_input_grad
         dy2 = dy.reshape(rows, N).contiguous()
         dx = dw = db = dres = None
+        dy_amax = None
+        if x_amax is not None and (need[0] or need[1]):
+            dy_amax = ops.absmax_word(dy2)
         if need[0]:
-            dx = ops.gemm(rows, K, N, dy2, N, True, w, K, False).view(xshape)
+            if dy_amax is not None and ops.gemm_f16x3_ok(rows, K, N, dy2, N, True, w, K, False):
+                dx = ops.gemm_f16x3(rows, K, N, dy2, N, True, w, K, False, dy_amax, w_amax)
+            else:
+                dx = ops.gemm(rows, K, N, dy2, N, True, w, K, False)
+            dx = dx.view(xshape)
         if need[1]:
-            dw = ops.gemm(N, K, rows, dy2, N, False, x2, K, False)
+            if dy_amax is not None and ops.gemm_f16x3_ok(N, K, rows, dy2, N, False, x2, K, False):
+                dw = ops.gemm_f16x3(N, K, rows, dy2, N, False, x2, K, False, dy_amax, x_amax)
+            else:
+                dw = ops.gemm(N, K, rows, dy2, N, False, x2, K, False)
         if has_bias and need[2]:
             db = ops.bias_grad(_rows_as_volume(dy2))
         if res_shape and need[3]:
@@ -589,7 +613,7 @@ class _LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, residual=None):
-    """torch.nn.functional.linear on the fp32-MFMA GEMM (+ fused bias / residual add)."""
+    """torch.nn.functional.linear on the MFMA GEMMs (+ fused bias / residual add)."""
     return _LinearFn.apply(x, weight, bias, residual)
 
 

@@ -89,6 +89,9 @@ FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          "no_grad_carry": bool(os.environ.get("ADELL_NO_GRAD_CARRY")),
          "no_skip_fork": bool(os.environ.get("ADELL_NO_SKIP_FORK")),
          "no_s2fused": bool(os.environ.get("ADELL_NO_S2FUSED")),
+         # opt-in: Linear layers on the f16x3 GEMM (1.3-2x the fp32-MFMA GEMM per launch, but its two
+         # absmax passes per layer make the near-host-bound token / ConvNeXt steps 3-6 % slower)
+         "gemm_f16x3": bool(os.environ.get("ADELL_GEMM_F16X3")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
@@ -1320,6 +1323,44 @@ def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, out=None, bias=None, residual=None
                                         _ptr(out), N, _ptr(bias), _ptr(residual), ldr, _ptr(ws),
                                         _stream()))
     _timed("adell_gemm_f32_kernel", 2.0 * M * N * K, run)
+    return out
+
+
+def absmax_word(x):
+    """Device word (int32 tensor holding float bits) with the absmax of a dense fp32 tensor: the
+    operand scale of ``gemm_f16x3``."""
+    _require_cuda(x)
+    x = x.contiguous()
+    word = torch.zeros(1, device=x.device, dtype=torch.int32)
+    check(_lib.lib().adell_absmax_f32(_ptr(x), x.numel(), _ptr(word), _stream()))
+    return word
+
+
+def gemm_f16x3_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc):
+    if not FLAGS["gemm_f16x3"]:
+        return False
+    return bool(_lib.lib().adell_gemm_f16x3_applicable(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb,
+                                                       int(b_kc)))
+
+
+def gemm_f16x3(M, N, K, A, lda, a_kc, B, ldb, b_kc, a_amax, b_amax, out=None, bias=None,
+               residual=None):
+    """``gemm`` on the f16 MFMA with the error-compensated split (csrc/gemm_f16x3.hip);
+    ``a_amax`` / ``b_amax``: ``absmax_word`` of the two operand tensors."""
+    _require_cuda(A, B, bias, residual)
+    if not (a_amax.is_cuda and b_amax.is_cuda):
+        raise _lib.AdellHipError("gemm_f16x3: the absmax words live on the device")
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    nws = _lib.lib().adell_gemm_f16x3_workspace_floats(M, N, K)
+    ws = _workspace(nws * 4, A.device) if nws else None
+    ldr = 0 if residual is None else N
+
+    def run():
+        check(_lib.lib().adell_gemm_f16x3(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb, int(b_kc),
+                                          _ptr(out), N, _ptr(bias), _ptr(residual), ldr,
+                                          _ptr(a_amax), _ptr(b_amax), _ptr(ws), _stream()))
+    _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run)
     return out
 
 

@@ -609,6 +609,23 @@ int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int a_kc, cons
                    long ldb, int b_kc, float* C, long ldc, const float* bias,
                    const float* residual, long ldr, float* workspace, void* stream);
 
+/* The same GEMM on the f16 MFMA by error-compensated splitting (3 MFMAs per product, fp32-class
+ * accuracy: csrc/gemm_f16x3.hip) -- torch.nn.Linear forward / dX / dW of the ConvNeXt point-wise
+ * MLPs (res_blocks.py:559-566), the ViT / SWIN projections (linear_blocks.py) and the projection
+ * heads (res_net.py:278-324). a_absmax / b_absmax: device words with the float bits of the absmax
+ * of the A / B tensors (adell_absmax_f32 into a zero-initialised word). _applicable: 1 when the
+ * operands qualify (16-byte alignment; leading dimensions, K and the outer extent of an
+ * outer-contiguous operand multiples of 4); otherwise the call returns ADELL_E_UNSUPPORTED and the
+ * caller uses adell_gemm_f32. */
+int adell_absmax_f32(const float* x, long n, uint32_t* out, void* stream);
+int adell_gemm_f16x3_applicable(int M, int N, int K, const float* A, long lda, int a_kc,
+                                const float* B, long ldb, int b_kc);
+long adell_gemm_f16x3_workspace_floats(int M, int N, int K);
+int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, int a_kc, const float* B,
+                     long ldb, int b_kc, float* C, long ldc, const float* bias,
+                     const float* residual, long ldr, const uint32_t* a_absmax,
+                     const uint32_t* b_absmax, float* workspace, void* stream);
+
 /* Element-wise segmentation losses beyond the fused binary dice + focal pair, on probabilities
  * p[B][V][C] (NDHWC; C = 1 for the binary family) against targets of the same layout:
  * kind 0 binary_cross_entropy (losses.py:79-109), 1 cat_cross_entropy (:528-562), 2 mc_focal_loss

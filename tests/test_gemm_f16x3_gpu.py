@@ -1,0 +1,105 @@
+"""f16x3 GEMM (csrc/gemm_f16x3.hip): the three operand layouts of a Linear layer (forward X W^T,
+backward-data dY W, backward-weight dY^T X), ragged tiles, split-K, bias / residual epilogue and
+extreme operand scales, against fp64; HF.linear takes it when ops.FLAGS["gemm_f16x3"] is set (opt-in) and
+falls back to the fp32-MFMA GEMM when the operands do not qualify."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _opt_in(monkeypatch):
+    from adell_mri_amd import ops
+
+    monkeypatch.setitem(ops.FLAGS, "gemm_f16x3", True)
+
+
+def _rel(a, b):
+    return float((a.detach().cpu().double() - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 96), (100, 36, 64), (4, 8, 4),
+                                   (1000, 132, 260), (64, 3072, 768), (4096, 96, 384)])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
+def test_layouts_against_fp64(cuda, M, N, K, a_kc, b_kc):
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    want = A.double() @ B.double() + bias.double() + res.double()
+    Ad = (A if a_kc else A.t()).contiguous().to(cuda)
+    Bd = (B.t() if b_kc else B).contiguous().to(cuda)
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+    if not ops.gemm_f16x3_ok(M, N, K, Ad, lda, a_kc, Bd, ldb, b_kc):
+        assert (not a_kc and M % 4) or (not b_kc and N % 4) or K % 4
+        pytest.skip("operands do not qualify (checked: the reason is an extent that is not a multiple of 4)")
+    got = ops.gemm_f16x3(M, N, K, Ad, lda, a_kc, Bd, ldb, b_kc, ops.absmax_word(Ad),
+                         ops.absmax_word(Bd), bias=bias.to(cuda), residual=res.to(cuda))
+    scale = (A.double().abs() @ B.double().abs()).max()
+    assert float((got.cpu().double() - want).abs().max() / scale) < 2e-6
+
+
+def test_split_k_is_deterministic_and_exact_enough(cuda):
+    from adell_mri_amd import _lib, ops
+
+    M, N, K = 96, 160, 65536       # dW of a point-wise layer: K = rows
+    assert _lib.lib().adell_gemm_f16x3_workspace_floats(M, N, K) > 0
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(K, M, generator=g).to(cuda)     # outer-contiguous operands
+    B = torch.randn(K, N, generator=g).to(cuda)
+    wa, wb = ops.absmax_word(A), ops.absmax_word(B)
+    c1 = ops.gemm_f16x3(M, N, K, A, M, False, B, N, False, wa, wb)
+    c2 = ops.gemm_f16x3(M, N, K, A, M, False, B, N, False, wa, wb)
+    assert torch.equal(c1, c2)
+    want = A.cpu().double().t() @ B.cpu().double()
+    assert _rel(c1, want) < 3e-6
+
+
+@pytest.mark.parametrize("sa,sb", [(1e-7, 1.0), (3e6, 1e-5), (1.0, 1e-12)])
+def test_operand_scales(cuda, sa, sb):
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    A = (torch.randn(200, 128, generator=g) * sa).to(cuda)
+    B = (torch.randn(64, 128, generator=g) * sb).to(cuda)
+    got = ops.gemm_f16x3(200, 64, 128, A, 128, True, B, 128, True, ops.absmax_word(A), ops.absmax_word(B))
+    want = A.cpu().double() @ B.cpu().double().t()
+    assert _rel(got, want) < 3e-6
+
+
+def test_linear_takes_the_f16x3_gemm_and_matches_torch(cuda, monkeypatch):
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+
+    calls = []
+    real = ops.gemm_f16x3
+    monkeypatch.setattr(ops, "gemm_f16x3", lambda *a, **k: calls.append(a[:3]) or real(*a, **k))
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 40, 96, generator=g)
+    w = torch.randn(384, 96, generator=g) / 10
+    b = torch.randn(384, generator=g)
+    r = torch.randn(3, 40, 384, generator=g)
+    dy = torch.randn(3, 40, 384, generator=g)
+    xr, wr, br, rr = (t.double().requires_grad_(True) for t in (x, w, b, r))
+    (torch.nn.functional.linear(xr, wr, br) + rr).backward(dy.double())
+    xd, wd, bd, rd = (t.to(cuda).requires_grad_(True) for t in (x, w, b, r))
+    y = HF.linear(xd, wd, bd, residual=rd)
+    y.backward(dy.to(cuda))
+    assert calls == [(120, 384, 96), (120, 96, 384), (384, 96, 120)]
+    assert _rel(y, (torch.nn.functional.linear(xr, wr, br) + rr).detach()) < 2e-6
+    assert _rel(xd.grad, xr.grad) < 2e-6 and _rel(wd.grad, wr.grad) < 2e-6
+    assert _rel(bd.grad, br.grad) < 2e-6 and torch.equal(rd.grad.cpu(), dy)
+    # 5 input features: no 16-byte rows -> the fp32-MFMA GEMM
+    calls.clear()
+    x5 = torch.randn(7, 5, generator=g).to(cuda).requires_grad_(True)
+    w5 = torch.randn(12, 5, generator=g).to(cuda).requires_grad_(True)
+    HF.linear(x5, w5).sum().backward()
+    assert calls == [] and x5.grad is not None and w5.grad is not None
+    # and not at all without the opt-in
+    monkeypatch.setitem(ops.FLAGS, "gemm_f16x3", False)
+    HF.linear(xd, wd, bd).sum().backward()
+    assert calls == []
