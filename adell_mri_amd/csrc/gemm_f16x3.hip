@@ -9,8 +9,10 @@
 // B[k*ldb + n]) -- forward X W^T (KC, KC), backward-data dY W (KC, outer), backward-weight dY^T X
 // (outer, outer) -- at 3 f16 MFMAs per product instead of the fp32 MFMA's 5.3x lower rate.
 //
-// Range: one power-of-two scale per operand TENSOR from its absmax (a device word the caller
-// provides: adell_absmax_f32; max lands in [2^13, 2^14)), undone in the epilogue.
+// Range: power-of-two operand scales, undone in the epilogue: per block and 64-k stage from the
+// absmax of the staged tiles (default: no extra pass over the operands; the accumulators are
+// rescaled by the exact ratio when the exponents change), or one per operand TENSOR from absmax
+// words the caller provides (adell_absmax_f32).
 //
 // A block of 4 waves owns a 128 x 128 tile (wave = 64 x 64 = 2 x 2 MFMA tiles); a stage is 64 k
 // values: both operand tiles go global -> registers -> split to (hi, lo) halves -> LDS
@@ -109,16 +111,20 @@ __device__ __forceinline__ unsigned gemm_h_fetch(float4 (&f)[8], const float* X,
   return okbits;
 }
 
-template <bool KC>
-__device__ __forceinline__ void gemm_h_put(char* tile, const float4 (&fin)[8], unsigned okbits,
-                                           float scale, int tid) {
-  float4 f[8];
+// zero the positions past the matrix; returns the absmax of what is left
+__device__ __forceinline__ float gemm_h_mask(float4 (&f)[8], unsigned okbits) {
+  float mx = 0.f;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const bool ok = (okbits >> u) & 1u;
-    f[u] = make_float4(ok ? fin[u].x : 0.f, ok ? fin[u].y : 0.f, ok ? fin[u].z : 0.f,
-                       ok ? fin[u].w : 0.f);
+    f[u] = make_float4(ok ? f[u].x : 0.f, ok ? f[u].y : 0.f, ok ? f[u].z : 0.f, ok ? f[u].w : 0.f);
+    mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f[u].x)), fmaxf(fabsf(f[u].y), fabsf(f[u].z))), fabsf(f[u].w));
   }
+  return mx;
+}
+
+template <bool KC>
+__device__ __forceinline__ void gemm_h_put(char* tile, const float4 (&f)[8], float scale, int tid) {
   if constexpr (KC) {
     const int q = tid & 15, chunk = q >> 2, slot = (q & 3) >> 1, half = q & 1;
     char* base = tile + chunk * (128 * 64) + half * 8;
@@ -153,15 +159,20 @@ __device__ __forceinline__ void gemm_h_put(char* tile, const float4 (&fin)[8], u
 
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * kTileBytes];   // [A | B], 64 KB
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [A | B] 64 KB + 8 floats
+  float* sMax = reinterpret_cast<float*>(smem + 2 * kTileBytes);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
   const int nstages = (a.K + BK - 1) / BK;
   const int s_beg = split * a.stages_per_split;
   const int s_end = (s_beg + a.stages_per_split) < nstages ? (s_beg + a.stages_per_split) : nstages;
-  const int kA = scale_exp(*a.amaxA), kB = scale_exp(*a.amaxB);
-  const float scaleA = __int_as_float((kA + 127) << 23), scaleB = __int_as_float((kB + 127) << 23);
+  // operand scales: per tensor from the caller's absmax words, or (no words) per block and stage
+  // from the absmax of the staged tiles, the accumulators rescaled by the exact power of two
+  // whenever the pair of exponents changes (as the conv kernels do per chunk)
+  const bool dyn = a.amaxA == nullptr;
+  int kA = dyn ? 0 : scale_exp(*a.amaxA), kB = dyn ? 0 : scale_exp(*a.amaxB);
+  int kprev = kA + kB;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -214,15 +225,45 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
     }
     }
     if (s < s_end) {
-      __syncthreads();   // the fragments of stage s - 1 are read
-      gemm_h_put<AKC>(smem, fa, oka, scaleA, tid);
-      gemm_h_put<BKC>(smem + kTileBytes, fb, okb, scaleB, tid);
+      float ma = gemm_h_mask(fa, oka), mb = gemm_h_mask(fb, okb);
+      if (dyn) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          ma = fmaxf(ma, __shfl_xor(ma, o, 64));
+          mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+        }
+      }
+      __syncthreads();   // the fragments of stage s - 1 are read (and sMax of the previous stage)
+      if (dyn) {
+        if (lane == 0) {
+          sMax[wave] = ma;
+          sMax[4 + wave] = mb;
+        }
+        __syncthreads();
+        ma = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+        mb = fmaxf(fmaxf(sMax[4], sMax[5]), fmaxf(sMax[6], sMax[7]));
+        // multiples of 8 (max lands in [2^6, 2^14)) so that the pair rarely changes
+        kA = 8 * ((scale_exp(__float_as_uint(ma))) >> 3);
+        kB = 8 * ((scale_exp(__float_as_uint(mb))) >> 3);
+        if (s > s_beg && kA + kB != kprev) {
+          const float fix = __int_as_float((kA + kB - kprev + 127) << 23);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] *= fix;
+        }
+        kprev = kA + kB;
+      }
+      gemm_h_put<AKC>(smem, fa, __int_as_float((kA + 127) << 23), tid);
+      gemm_h_put<BKC>(smem + kTileBytes, fb, __int_as_float((kB + 127) << 23), tid);
       __syncthreads();
     }
   }
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-  const float oscale = __int_as_float((127 - kA - kB) << 23);
+  const float oscale = __int_as_float((127 - kprev) << 23);
   const bool direct = a.splits == 1;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -348,15 +389,18 @@ extern "C" long adell_gemm_f16x3_workspace_floats(int M, int N, int K) {
   return p.splits > 1 ? (long)p.splits * M * N : 0;
 }
 
-// Same contract as adell_gemm_f32 + a_absmax / b_absmax: device words holding the float bits of
-// the absmax of the A / B tensors (adell_absmax_f32, or any upper bound within a factor of 2^10).
+// Same contract as adell_gemm_f32 + a_absmax / b_absmax: both NULL (operand scales chosen per block
+// and 64-k stage inside the kernel), or device words holding the float bits of the absmax of the
+// A / B tensors (adell_absmax_f32, or any upper bound within a factor of 2^10): one scale per tensor.
 extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, int a_kc,
                                 const float* B, long ldb, int b_kc, float* C, long ldc,
                                 const float* bias, const float* residual, long ldr,
                                 const uint32_t* a_absmax, const uint32_t* b_absmax,
                                 float* workspace, void* stream) {
   ADELL_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f16x3: bad dims");
-  ADELL_REQUIRE(A && B && C && a_absmax && b_absmax, "gemm_f16x3: null pointer");
+  ADELL_REQUIRE(A && B && C, "gemm_f16x3: null pointer");
+  ADELL_REQUIRE((a_absmax == nullptr) == (b_absmax == nullptr),
+                "gemm_f16x3: give both absmax words or neither");
   ADELL_REQUIRE(lda >= (a_kc ? K : M) && ldb >= (b_kc ? K : N) && ldc >= N, "gemm_f16x3: bad strides");
   ADELL_REQUIRE(!residual || ldr >= N, "gemm_f16x3: bad residual stride");
   if (!gemm_h_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc)) {
@@ -375,15 +419,24 @@ extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, i
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(adell_cdiv(M, BM), adell_cdiv(N, BN), p.splits);
   ADELL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_f16x3: grid too large");
+  constexpr size_t kLds = 2 * kTileBytes + 8 * sizeof(float);
+  auto launch = [&](auto kern) -> int {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+    hipLaunchKernelGGL(kern, grid, dim3(256), kLds, st, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  };
+  int rc;
   if (a_kc && b_kc)
-    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<true, true>), grid, dim3(256), 0, st, a);
+    rc = launch(adell_gemm_f16x3_kernel<true, true>);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<true, false>), grid, dim3(256), 0, st, a);
+    rc = launch(adell_gemm_f16x3_kernel<true, false>);
   else if (!a_kc && !b_kc)
-    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<false, false>), grid, dim3(256), 0, st, a);
+    rc = launch(adell_gemm_f16x3_kernel<false, false>);
   else
-    hipLaunchKernelGGL((adell_gemm_f16x3_kernel<false, true>), grid, dim3(256), 0, st, a);
-  ADELL_CHECK_HIP(hipGetLastError());
+    rc = launch(adell_gemm_f16x3_kernel<false, true>);
+  if (rc != ADELL_OK) return rc;
   if (p.splits > 1) {
     long blocks = ((long)M * N + 255) / 256;
     if (blocks > 8192) blocks = 8192;

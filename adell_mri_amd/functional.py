@@ -569,15 +569,12 @@ class _LinearFn(torch.autograd.Function):
         w = weight.contiguous()
         res2 = None if residual is None else residual.reshape(rows, N).contiguous()
         split = CONV_PRECISION == "f16x3" and ops.gemm_f16x3_ok(rows, N, K, x2, K, True, w, K, True)
-        x_amax = w_amax = None
         if split:
-            x_amax, w_amax = ops.absmax_word(x2), ops.absmax_word(w)
-            y = ops.gemm_f16x3(rows, N, K, x2, K, True, w, K, True, x_amax, w_amax, bias=bias,
-                               residual=res2)
+            y = ops.gemm_f16x3(rows, N, K, x2, K, True, w, K, True, bias=bias, residual=res2)
         else:
             y = ops.gemm(rows, N, K, x2, K, True, w, K, True, bias=bias, residual=res2)
         ctx.save_for_backward(x2, w)
-        ctx.amax = (x_amax, w_amax)
+        ctx.split = split
         ctx.meta = (x.shape, bias is not None, residual is not None and residual.shape)
         return y.view(*x.shape[:-1], N)
 
@@ -585,24 +582,21 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         xshape, has_bias, res_shape = ctx.meta
-        x_amax, w_amax = ctx.amax
+        split = ctx.split
         N, K = w.shape
         rows = x2.shape[0]
         need = ctx.needs_input_grad
         dy2 = dy.reshape(rows, N).contiguous()
         dx = dw = db = dres = None
-        dy_amax = None
-        if x_amax is not None and (need[0] or need[1]):
-            dy_amax = ops.absmax_word(dy2)
         if need[0]:
-            if dy_amax is not None and ops.gemm_f16x3_ok(rows, K, N, dy2, N, True, w, K, False):
-                dx = ops.gemm_f16x3(rows, K, N, dy2, N, True, w, K, False, dy_amax, w_amax)
+            if split and ops.gemm_f16x3_ok(rows, K, N, dy2, N, True, w, K, False):
+                dx = ops.gemm_f16x3(rows, K, N, dy2, N, True, w, K, False)
             else:
                 dx = ops.gemm(rows, K, N, dy2, N, True, w, K, False)
             dx = dx.view(xshape)
         if need[1]:
-            if dy_amax is not None and ops.gemm_f16x3_ok(N, K, rows, dy2, N, False, x2, K, False):
-                dw = ops.gemm_f16x3(N, K, rows, dy2, N, False, x2, K, False, dy_amax, x_amax)
+            if split and ops.gemm_f16x3_ok(N, K, rows, dy2, N, False, x2, K, False):
+                dw = ops.gemm_f16x3(N, K, rows, dy2, N, False, x2, K, False)
             else:
                 dw = ops.gemm(N, K, rows, dy2, N, False, x2, K, False)
         if has_bias and need[2]:

@@ -89,8 +89,8 @@ FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          "no_grad_carry": bool(os.environ.get("ADELL_NO_GRAD_CARRY")),
          "no_skip_fork": bool(os.environ.get("ADELL_NO_SKIP_FORK")),
          "no_s2fused": bool(os.environ.get("ADELL_NO_S2FUSED")),
-         # opt-in: Linear layers on the f16x3 GEMM (1.3-2x the fp32-MFMA GEMM per launch, but its two
-         # absmax passes per layer make the near-host-bound token / ConvNeXt steps 3-6 % slower)
+         # opt-in: Linear layers on the f16x3 GEMM (1.2-2x the fp32-MFMA GEMM per launch; per step
+         # -5 % VICReg ConvNeXt, -1 % UNETR, +2 % SWIN-UNet: DESIGN.md section 8)
          "gemm_f16x3": bool(os.environ.get("ADELL_GEMM_F16X3")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
@@ -1343,13 +1343,15 @@ def gemm_f16x3_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc):
                                                        int(b_kc)))
 
 
-def gemm_f16x3(M, N, K, A, lda, a_kc, B, ldb, b_kc, a_amax, b_amax, out=None, bias=None,
+def gemm_f16x3(M, N, K, A, lda, a_kc, B, ldb, b_kc, a_amax=None, b_amax=None, out=None, bias=None,
                residual=None):
     """``gemm`` on the f16 MFMA with the error-compensated split (csrc/gemm_f16x3.hip);
-    ``a_amax`` / ``b_amax``: ``absmax_word`` of the two operand tensors."""
+    ``a_amax`` / ``b_amax``: None (scales chosen inside the kernel) or the ``absmax_word`` of the
+    two operand tensors."""
     _require_cuda(A, B, bias, residual)
-    if not (a_amax.is_cuda and b_amax.is_cuda):
-        raise _lib.AdellHipError("gemm_f16x3: the absmax words live on the device")
+    if (a_amax is None) != (b_amax is None) or (a_amax is not None
+                                                and not (a_amax.is_cuda and b_amax.is_cuda)):
+        raise _lib.AdellHipError("gemm_f16x3: both absmax words (device tensors) or neither")
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=torch.float32)
     nws = _lib.lib().adell_gemm_f16x3_workspace_floats(M, N, K)

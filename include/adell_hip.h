@@ -612,8 +612,9 @@ int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int a_kc, cons
 /* The same GEMM on the f16 MFMA by error-compensated splitting (3 MFMAs per product, fp32-class
  * accuracy: csrc/gemm_f16x3.hip) -- torch.nn.Linear forward / dX / dW of the ConvNeXt point-wise
  * MLPs (res_blocks.py:559-566), the ViT / SWIN projections (linear_blocks.py) and the projection
- * heads (res_net.py:278-324). a_absmax / b_absmax: device words with the float bits of the absmax
- * of the A / B tensors (adell_absmax_f32 into a zero-initialised word). _applicable: 1 when the
+ * heads (res_net.py:278-324). a_absmax / b_absmax: both NULL (operand scales chosen inside the
+ * kernel per block and 64-k stage), or device words with the float bits of the absmax of the A / B
+ * tensors (adell_absmax_f32 into a zero-initialised word): one scale per tensor. _applicable: 1 when the
  * operands qualify (16-byte alignment; leading dimensions, K and the outer extent of an
  * outer-contiguous operand multiples of 4); otherwise the call returns ADELL_E_UNSUPPORTED and the
  * caller uses adell_gemm_f32. */

@@ -22,7 +22,8 @@ def _rel(a, b):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 384, 96), (100, 36, 64), (4, 8, 4),
                                    (1000, 132, 260), (64, 3072, 768), (4096, 96, 384)])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False), (False, True)])
-def test_layouts_against_fp64(cuda, M, N, K, a_kc, b_kc):
+@pytest.mark.parametrize("words", [False, True])
+def test_layouts_against_fp64(cuda, M, N, K, a_kc, b_kc, words):
     from adell_mri_amd import ops
 
     g = torch.Generator().manual_seed(M + N + K)
@@ -37,8 +38,10 @@ def test_layouts_against_fp64(cuda, M, N, K, a_kc, b_kc):
     if not ops.gemm_f16x3_ok(M, N, K, Ad, lda, a_kc, Bd, ldb, b_kc):
         assert (not a_kc and M % 4) or (not b_kc and N % 4) or K % 4
         pytest.skip("operands do not qualify (checked: the reason is an extent that is not a multiple of 4)")
-    got = ops.gemm_f16x3(M, N, K, Ad, lda, a_kc, Bd, ldb, b_kc, ops.absmax_word(Ad),
-                         ops.absmax_word(Bd), bias=bias.to(cuda), residual=res.to(cuda))
+    # operand scales: chosen per block and stage inside the kernel, or per tensor from absmax words
+    wa, wb = (ops.absmax_word(Ad), ops.absmax_word(Bd)) if words else (None, None)
+    got = ops.gemm_f16x3(M, N, K, Ad, lda, a_kc, Bd, ldb, b_kc, wa, wb, bias=bias.to(cuda),
+                         residual=res.to(cuda))
     scale = (A.double().abs() @ B.double().abs()).max()
     assert float((got.cpu().double() - want).abs().max() / scale) < 2e-6
 
@@ -51,9 +54,8 @@ def test_split_k_is_deterministic_and_exact_enough(cuda):
     g = torch.Generator().manual_seed(1)
     A = torch.randn(K, M, generator=g).to(cuda)     # outer-contiguous operands
     B = torch.randn(K, N, generator=g).to(cuda)
-    wa, wb = ops.absmax_word(A), ops.absmax_word(B)
-    c1 = ops.gemm_f16x3(M, N, K, A, M, False, B, N, False, wa, wb)
-    c2 = ops.gemm_f16x3(M, N, K, A, M, False, B, N, False, wa, wb)
+    c1 = ops.gemm_f16x3(M, N, K, A, M, False, B, N, False)
+    c2 = ops.gemm_f16x3(M, N, K, A, M, False, B, N, False)
     assert torch.equal(c1, c2)
     want = A.cpu().double().t() @ B.cpu().double()
     assert _rel(c1, want) < 3e-6
@@ -66,9 +68,27 @@ def test_operand_scales(cuda, sa, sb):
     g = torch.Generator().manual_seed(3)
     A = (torch.randn(200, 128, generator=g) * sa).to(cuda)
     B = (torch.randn(64, 128, generator=g) * sb).to(cuda)
-    got = ops.gemm_f16x3(200, 64, 128, A, 128, True, B, 128, True, ops.absmax_word(A), ops.absmax_word(B))
     want = A.cpu().double() @ B.cpu().double().t()
+    got = ops.gemm_f16x3(200, 64, 128, A, 128, True, B, 128, True, ops.absmax_word(A), ops.absmax_word(B))
     assert _rel(got, want) < 3e-6
+    assert _rel(ops.gemm_f16x3(200, 64, 128, A, 128, True, B, 128, True), want) < 3e-6
+
+
+def test_scale_changes_between_stages_rescale_the_accumulators(cuda):
+    """K blocks of very different magnitude: the per-stage exponents change along K and the
+    accumulators follow by exact powers of two."""
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 130, 140, 512
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    mag = torch.tensor([1e-6, 1.0, 3e4, 1e-3, 1.0, 1e5, 1e-8, 1.0]).repeat_interleave(64)
+    A, B = A * mag, B * mag.flip(0)
+    want = A.double() @ B.double().t()
+    got = ops.gemm_f16x3(M, N, K, A.to(cuda), K, True, B.to(cuda), K, True)
+    scale = (A.double().abs() @ B.double().abs().t()).max()
+    assert float((got.cpu().double() - want).abs().max() / scale) < 2e-6
 
 
 def test_linear_takes_the_f16x3_gemm_and_matches_torch(cuda, monkeypatch):

@@ -48,10 +48,11 @@ for rows, cin, cout in SHAPES:
         "gemm_fwd": timed(lambda: ops.gemm(rows, cout, cin, x, cin, True, w, cin, True)),
         "gemm_dx": timed(lambda: ops.gemm(rows, cin, cout, dy, cout, True, w, cin, False)),
         "gemm_dw": timed(lambda: ops.gemm(cout, cin, rows, dy, cout, False, x, cin, False)),
-        "h_fwd": timed(lambda: ops.gemm_f16x3(rows, cout, cin, x, cin, True, w, cin, True, xa, wa)),
-        "h_dx": timed(lambda: ops.gemm_f16x3(rows, cin, cout, dy, cout, True, w, cin, False, ya, wa)),
-        "h_dw": timed(lambda: ops.gemm_f16x3(cout, cin, rows, dy, cout, False, x, cin, False, ya, xa)),
+        "h_fwd": timed(lambda: ops.gemm_f16x3(rows, cout, cin, x, cin, True, w, cin, True)),
+        "h_dx": timed(lambda: ops.gemm_f16x3(rows, cin, cout, dy, cout, True, w, cin, False)),
+        "h_dw": timed(lambda: ops.gemm_f16x3(cout, cin, rows, dy, cout, False, x, cin, False)),
         "amax_x": timed(lambda: ops.absmax_word(x)),
+        "h_fwd_words": timed(lambda: ops.gemm_f16x3(rows, cout, cin, x, cin, True, w, cin, True, xa, wa)),
         "conv_fwd": timed(lambda: ops.conv3d_fwd(vol(x), p0, None, cout, 1, 1, 0, want_stats=False)),
         "conv_dx": timed(lambda: ops.conv3d_bwd_data(vol(dy), p1, size, cin, 0, (1, 1, 1), (1, 1, 1), (0, 0, 0))),
         "conv_dw": timed(lambda: ops.conv3d_bwd_weight(vol(x), vol(dy), 1, 1, 0, f16x3=True, x_amax=xa, dy_amax=ya)),
