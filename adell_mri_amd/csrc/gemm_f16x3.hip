@@ -174,6 +174,20 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
   int kA = dyn ? 0 : scale_exp(*a.amaxA), kB = dyn ? 0 : scale_exp(*a.amaxB);
   int kprev = kA + kB;
 
+#ifdef ADELL_GEMM_MFMA16
+  // experiment: the same wave tile on v_mfma_f32_16x16x32_f16 (K = 32 = two 16-k chunks)
+  f32x4 acc4[2][2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc4[i][j][ih][jh][r] = 0.f;
+#else
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -181,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#endif
 
   // One LDS image, the next stage in registers: with two resident blocks per CU a stage's loads
   // are in flight for two MFMA phases (2 x 48 MFMAs per wave), enough to cover the memory latency
@@ -199,6 +214,44 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
   for (int s = s_beg; s <= s_end; ++s) {
     if (s < s_end) fetch(s);
     if (s > s_beg) {
+#ifdef ADELL_GEMM_MFMA16
+    const int l16 = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int cp = 0; cp < NCH / 2; ++cp) {
+      const int choff = (2 * cp + (kq >> 1)) * (128 * 64);
+      half8 ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+          const int r = wm * 64 + i * 32 + ih * 16 + l16;
+          ah[i][ih] = *reinterpret_cast<const half8*>(tA + choff + lds_off(r, kq & 1));
+          al[i][ih] = *reinterpret_cast<const half8*>(tA + choff + lds_off(r, 2 + (kq & 1)));
+        }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+          const int r = wn * 64 + j * 32 + jh * 16 + l16;
+          bh[j][jh] = *reinterpret_cast<const half8*>(tB + choff + lds_off(r, kq & 1));
+          bl[j][jh] = *reinterpret_cast<const half8*>(tB + choff + lds_off(r, 2 + (kq & 1)));
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+              f32x4& c = acc4[i][j][ih][jh];
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i][ih], bh[j][jh], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][ih], bl[j][jh], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i][ih], bh[j][jh], c, 0, 0, 0);
+            }
+    }
+    }
+#else
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       half8 ah[2], al[2], bh[2], bl[2];
@@ -224,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
         }
     }
     }
+#endif
     if (s < s_end) {
       float ma = gemm_h_mask(fa, oka), mb = gemm_h_mask(fb, okb);
       if (dyn) {
@@ -252,7 +306,13 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[i][j][r] *= fix;
+              for (int r = 0; r < 16; ++r) {
+#ifdef ADELL_GEMM_MFMA16
+                acc4[i][j][r >> 3][(r >> 2) & 1][r & 3] *= fix;
+#else
+                acc[i][j][r] *= fix;
+#endif
+              }
         }
         kprev = kA + kB;
       }
@@ -265,6 +325,34 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
   const float oscale = __int_as_float((127 - kprev) << 23);
   const bool direct = a.splits == 1;
+#ifdef ADELL_GEMM_MFMA16
+  // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih)
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+          const int col = n0 + wn * 64 + j * 32 + jh * 16 + (lane & 15);
+          if (col >= a.N) continue;
+          const float bv = (direct && a.bias) ? a.bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + ih * 16 + 4 * (lane >> 4) + r;
+            if (row >= a.M) continue;
+            float v = acc4[i][j][ih][jh][r] * oscale;
+            if (direct) {
+              v += bv;
+              if (a.residual) v += a.residual[(long)row * a.ldr + col];
+              a.C[(long)row * a.ldc + col] = v;
+            } else {
+              a.slab[((long)split * a.M + row) * a.N + col] = v;
+            }
+          }
+        }
+#else
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -286,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
         }
       }
     }
+#endif
 }
 
 // fixed-order fold of the split-K slabs (+ bias, residual): one thread per output
