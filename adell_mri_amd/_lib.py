@@ -59,6 +59,9 @@ SIGNATURES = {
     "adell_pack_weight_f16x3_multi": (_i, [_vp, _i, _l, _vp]),
     "adell_conv3d_bwd_data_s2_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
     "adell_conv3d_bwd_data_s2_f16x3_add": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
+    "adell_conv3d_fwd_s2_fused_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_fwd_s2_fused_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_fwd_s2_fused": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 8),
     "adell_conv3d_bwd_data_s2_fused_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_bwd_data_s2_fused": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
     "adell_conv3d_splitk_workspace": (_l, [ctypes.POINTER(ConvDesc), _i]),

@@ -1,0 +1,374 @@
+// Forward of the U-Net downsampling convolution (3x3x3, stride 2, padding 1, 32 -> 32 channels:
+// unet.py:571-579 at the two high-resolution levels) in ONE persistent launch, f16x3 arithmetic --
+// the companion of csrc/conv_dgrad_s2.hip.
+//
+//   y[o][co] = b[co] + sum_t x[2 o - 1 + t][.] w[co][.][t]
+//
+// Per axis the input index 2 o - 1 + t has parity 0 for t = 1 (sub-lattice index o) and parity 1
+// for t = 0 (index o - 1) and t = 2 (index o). So the eight parity sub-lattices of x contribute
+// through 1, 2, 4 or 8 taps each (27 in all), and the part of ONE sub-lattice behind an 8 x 8 x 4
+// output brick is a 9 x 9 x 5 halo of 51 KB -- where the halo of the whole brick (17 x 17 x 9
+// voxels, 333 KB) fits no LDS, which is why the implicit-GEMM kernel runs this layer on 64-voxel
+// bricks at one wave per SIMD (0.56 ms at 2 x 128^3 for 0.1 ms of MFMA work and 0.13 ms of HBM).
+// Here a persistent block (one per CU, 4 waves)
+//   * keeps the whole split weight (27 x 32 x 32 x (hi, lo) = 108 KB) in LDS for its lifetime,
+//   * walks the eight sub-lattices of a brick: stage + split one 51 KB halo, run its taps into the
+//     SAME 2 x 16 accumulator registers per wave, while the next sub-lattice's halo is in flight in
+//     registers (a sub-lattice voxel is a full 128-byte line of x),
+//   * takes the operand scale per (brick, sub-lattice) from the block-wide absmax of the staged
+//     halo and rescales the accumulators by the exact power of two when it changes,
+//   * emits bias, the per-channel (sum, sum of squares) partials of the following norm and the
+//     absmax of x (for the weight-gradient kernel) like the implicit-GEMM epilogue.
+// Roofline: HBM (x read once: 537 MB at 2 x 128^3, y 67 MB).
+#include <type_traits>
+#include <utility>
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kHX = 9, kHY = 9, kHZ = 5, kHV = kHX * kHY * kHZ;
+constexpr int kWBytes = 27 * 2 * 32 * 64;
+constexpr int kABytes = kHV * 128;
+constexpr int kRedFloats = 4 * 32 * 2;                       // statistics fold: [wave][channel][2]
+constexpr int kLds = kWBytes + kABytes + 32 + kRedFloats * 4;
+constexpr int kItems = kHV * 8;
+constexpr int kPer = (kItems + 255) / 256;
+
+template <typename T>
+__device__ __forceinline__ ADELL_GLOBAL T* uniform_ptr(T* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<ADELL_GLOBAL T*>(((uint64_t)hi << 32) | lo);
+}
+
+template <int N, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& body, std::integer_sequence<int, I...>) {
+  (body(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& body) {
+  static_for_impl<N>(body, std::make_integer_sequence<int, N>{});
+}
+
+struct FwdS2Args {
+  const float* x;       // [N][D][H][W][32]
+  const char* wpack;    // adell_pack_weight_f16x3 mode 0 of the full weight: [tap][co][chunk][64 B]
+  const float* wscale;  // [32]
+  const float* bias;    // [32] or null
+  float* y;             // [N][D/2][H/2][W/2][32]
+  float* part;          // [N][bricks per item][32][2] or null
+  unsigned* amax_out;   // optional: absmax of x (float bits)
+  int N, D, H, W, Do, Ho, Wo;
+  int ntx, nty, ntz;
+  int nbricks;
+};
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a) {
+  extern __shared__ char smem[];
+  char* sW = smem;
+  char* sA = smem + kWBytes;
+  float* sMax = reinterpret_cast<float*>(sA + kABytes);
+  float* sRed = sMax + 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int q = tid & 7;
+  const int nsp = a.ntx * a.nty * a.ntz;
+
+  auto brick_origin = [&](int t, int& nb, int& tile, int& ox0, int& oy0, int& oz0) {
+    tile = t % nsp;
+    nb = t / nsp;
+    int r = tile;
+    const int tx = r % a.ntx;
+    r /= a.ntx;
+    const int ty = r % a.nty;
+    const int tz = r / a.nty;
+    ox0 = tx * 8;
+    oy0 = ty * 8;
+    oz0 = tz * 4;
+  };
+  // halo of sub-lattice (pz, py, px) behind brick t: halo voxel h <-> x index 2 (o0 - 1 + h) + p per axis
+  float4 f[kPer];
+  unsigned okbits = 0;
+  auto prefetch = [&](int phase) {
+    const int t = blockIdx.x + (phase >> 3) * gridDim.x, cls = phase & 7;
+    int nb, tile, ox0, oy0, oz0;
+    brick_origin(t, nb, tile, ox0, oy0, oz0);
+    const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+    const int bz = 2 * (oz0 - 1) + pz, by = 2 * (oy0 - 1) + py, bx = 2 * (ox0 - 1) + px;
+    const ADELL_GLOBAL float* src = uniform_ptr(a.x + (size_t)nb * a.D * a.H * a.W * 32);
+    int tt = tid;
+    asm volatile("" : "+v"(tt));   // (keeps the per-item arithmetic inside the loop: see conv_dgrad_s2.hip)
+    okbits = 0;
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int it = tt + 256 * u;
+      const int hv = it >> 3;
+      const int hz = hv / (kHX * kHY), rem = hv - hz * (kHX * kHY);
+      const int hy = rem / kHX, hx = rem - hy * kHX;
+      const int iz = bz + 2 * hz, iy = by + 2 * hy, ix = bx + 2 * hx;
+      const bool ok = (it < kItems) & (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) & (ix >= 0) &
+                      (ix < a.W);
+      const unsigned rel = ok ? (unsigned)((iz * a.H + iy) * a.W + ix) * 32u + 4u * q : 0u;
+      const f32x4 v = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(src + rel);
+      f[u] = make_float4(v.x, v.y, v.z, v.w);
+      okbits |= ok ? (1u << u) : 0u;
+    }
+  };
+
+  // ---- the split weight, once: global row (tap * 32 + n) * 2 + chunk -> [tap][chunk][n] ---------
+#pragma unroll 1
+  for (int b = 0; b < 3; ++b) {
+    float4 v[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u)
+      v[u] = *reinterpret_cast<const float4*>(a.wpack + (size_t)(tid + 256 * (9 * b + u)) * 16);
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int it = tid + 256 * (9 * b + u);
+      const int slot = it & 3, row = it >> 2;
+      const int ch = row & 1, n = (row >> 1) & 31, tap = row >> 6;
+      *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v[u];
+    }
+  }
+
+  // A rows of this lane at offset (0, 0, 0): wave w = output plane z = w; m-tile mt: y = 4 mt .. + 3
+  int arow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) arow[mt] = (wave * kHY + (li >> 3) + 4 * mt) * kHX + (li & 7);
+  const int bsw = (li >> 2) & 3;
+  const int boffh = li * 64 + ((lh ^ bsw) << 4), boffl = li * 64 + (((2 + lh) ^ bsw) << 4);
+  const float wsc = a.wscale[li];
+  const float bcol = a.bias ? a.bias[li] : 0.f;
+  float block_max = 0.f;
+
+  const int my_bricks = ((int)blockIdx.x < a.nbricks)
+                            ? (a.nbricks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int nphases = my_bricks * 8;
+  f32x16 acc[2];
+  int kprev = 0;
+  // one phase = one sub-lattice of one brick. Iteration ph: issue the loads of phase ph (one fetch
+  // site), run the MFMAs of phase ph - 1 out of LDS, close a brick after its eighth sub-lattice,
+  // then move phase ph from registers to LDS.
+  for (int ph = 0; ph <= nphases; ++ph) {
+    if (ph < nphases) prefetch(ph);
+    __builtin_amdgcn_sched_barrier(0);
+    if (ph > 0) {
+      const int cls = (ph - 1) & 7;
+      // ---- taps of sub-lattice cls: per axis parity 0 -> tap 1 at offset 1; parity 1 -> tap 0 at
+      // offset 0 and tap 2 at offset 1 (offsets in the halo whose origin is o0 - 1)
+      static_for<8>([&](auto CLS) {
+        constexpr int c = decltype(CLS)::value;
+        if (cls == c) {
+          constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+          static_for<2>([&](auto CH) {
+            constexpr int ch = decltype(CH)::value;
+            const char* sAc = sA + ch * (kHV * 64);
+            static_for<8>([&](auto T) {
+              constexpr int tb = decltype(T)::value;   // bit a: the second tap of axis a (parity 1 only)
+              constexpr int sz = tb >> 2, sy = (tb >> 1) & 1, sx = tb & 1;
+              if constexpr ((sz <= pz) && (sy <= py) && (sx <= px)) {
+                constexpr int tz = pz ? 2 * sz : 1, ty = py ? 2 * sy : 1, tx = px ? 2 * sx : 1;
+                constexpr int dz = pz ? sz : 1, dy = py ? sy : 1, dx = px ? sx : 1;
+                constexpr int tap = (tz * 3 + ty) * 3 + tx;
+                half8 ah[2], al[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                  const int hv = arow[mt] + (dz * kHY + dy) * kHX + dx;
+                  const int sw = (hv >> 2) & 3;
+                  const char* row = sAc + hv * 64;
+                  ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
+                  al[mt] = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
+                }
+                const char* bt = sW + (tap * 2 + ch) * (32 * 64);
+                const half8 bh = *reinterpret_cast<const half8*>(bt + boffh);
+                const half8 bl = *reinterpret_cast<const half8*>(bt + boffl);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                  acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt], 0, 0, 0);
+                  acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt], 0, 0, 0);
+                  acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt], 0, 0, 0);
+                }
+              }
+            });
+          });
+        }
+      });
+      if (cls == 7) {
+        // ---- epilogue of the brick: C row r of m-tile mt = output (x = (r & 3) + 4 lh, y = (r >> 2) + 4 mt)
+        const int t = blockIdx.x + ((ph - 1) >> 3) * gridDim.x;
+        int nb, tile, ox0, oy0, oz0;
+        brick_origin(t, nb, tile, ox0, oy0, oz0);
+        const float oscale = __int_as_float((127 - kprev) << 23) * wsc;
+        const int z = oz0 + wave;
+        float s1 = 0.f, s2 = 0.f;
+        if (z < a.Do) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int x = ox0 + (r & 3) + 4 * lh, yy = oy0 + (r >> 2) + 4 * mt;
+              if (x < a.Wo && yy < a.Ho) {
+                const float v = acc[mt][r] * oscale + bcol;
+                a.y[((((size_t)nb * a.Do + z) * a.Ho + yy) * a.Wo + x) * 32 + li] = v;
+                s1 += v;
+                s2 += v * v;
+              }
+            }
+        }
+        if (a.part) {
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (lh == 0) {
+            sRed[(wave * 32 + li) * 2 + 0] = s1;
+            sRed[(wave * 32 + li) * 2 + 1] = s2;
+          }
+          __syncthreads();
+          if (tid < 32) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              t1 += sRed[(w * 32 + tid) * 2 + 0];
+              t2 += sRed[(w * 32 + tid) * 2 + 1];
+            }
+            float* p = a.part + (((size_t)nb * nsp + tile) * 32 + tid) * 2;
+            p[0] = t1;
+            p[1] = t2;
+          }
+        }
+      }
+    }
+    if (ph < nphases) {
+      // ---- mask, absmax -> power-of-two scale of this sub-lattice halo ----------------------------
+      float mx = 0.f;
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const bool ok = (okbits >> u) & 1u;
+        f[u] = make_float4(ok ? f[u].x : 0.f, ok ? f[u].y : 0.f, ok ? f[u].z : 0.f, ok ? f[u].w : 0.f);
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f[u].x)), fmaxf(fabsf(f[u].y), fabsf(f[u].z))), fabsf(f[u].w));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      __syncthreads();   // the fragments of phase ph - 1 are read (and its sMax / sRed values)
+      if (lane == 0) sMax[wave] = mx;
+      __syncthreads();
+      mx = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+      block_max = fmaxf(block_max, mx);
+      int kA = 0;
+      {
+        const int ebits = (__float_as_int(mx) >> 23) & 0xff;
+        // multiples of 8 (max lands in [2^6, 2^14)): the scale rarely changes inside a brick
+        if (ebits > 0 && ebits < 255) kA = 8 * ((13 - (ebits - 127)) >> 3);
+        if (kA > 96) kA = 96;
+        if (kA < -96) kA = -96;
+      }
+      if ((ph & 7) == 0) {   // first sub-lattice of a brick: fresh accumulators
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      } else if (kA != kprev) {
+        const float fix = __int_as_float((kA - kprev + 127) << 23);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] *= fix;
+      }
+      kprev = kA;
+      const float scaleA = __int_as_float((kA + 127) << 23);
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const int it = tid + 256 * u;
+        if (it < kItems) {
+          const int hv = it >> 3;
+          const float v[4] = {f[u].x * scaleA, f[u].y * scaleA, f[u].z * scaleA, f[u].w * scaleA};
+          half4 h, l;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            h[j] = (_Float16)v[j];
+            l[j] = (_Float16)(v[j] - (float)h[j]);
+          }
+          const int sw = (hv >> 2) & 3, slot = (q & 3) >> 1;
+          char* row = sA + (q >> 2) * (kHV * 64) + hv * 64 + (q & 1) * 8;
+          *reinterpret_cast<half4*>(row + ((slot ^ sw) << 4)) = h;
+          *reinterpret_cast<half4*>(row + (((2 + slot) ^ sw) << 4)) = l;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (a.amax_out != nullptr && tid == 0) atomicMax(a.amax_out, __float_as_uint(block_max));
+}
+
+namespace {
+
+int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+bool fwd_s2_fused_ok(const adell_conv3d_desc* d) {
+  return d && d->C1 == 0 && d->C0 == 32 && d->Cout == 32 && d->KD == 3 && d->KH == 3 && d->KW == 3 &&
+         d->SD == 2 && d->SH == 2 && d->SW == 2 && d->PD == 1 && d->PH == 1 && d->PW == 1 &&
+         d->D % 2 == 0 && d->H % 2 == 0 && d->W % 2 == 0 && d->N > 0 && d->D > 0 && d->H > 0 &&
+         d->W > 0 && d->Do == d->D / 2 && d->Ho == d->H / 2 && d->Wo == d->W / 2 &&
+         (size_t)d->D * d->H * d->W * 32 < ((size_t)1 << 29);   // 32-bit offsets inside an item
+}
+
+}  // namespace
+
+// 1 when adell_conv3d_fwd_s2_fused takes this layer (the conditions of the backward-data twin).
+extern "C" int adell_conv3d_fwd_s2_fused_applicable(const adell_conv3d_desc* d) {
+  return fwd_s2_fused_ok(d) ? 1 : 0;
+}
+
+// statistics partial rows per batch item (stat_partials is [N][this][32][2]), or an error code
+extern "C" int adell_conv3d_fwd_s2_fused_ntiles(const adell_conv3d_desc* d) {
+  if (!fwd_s2_fused_ok(d)) return ADELL_E_UNSUPPORTED;
+  return adell_cdiv(d->Wo, 8) * adell_cdiv(d->Ho, 8) * adell_cdiv(d->Do, 4);
+}
+
+// y (+ bias, + statistics partials, + absmax of x) of such a layer in one launch. w_split / wscale:
+// adell_pack_weight_f16x3 mode 0 of the [32][32][3][3][3] weight (the pack adell_conv3d_fwd_f16x3 takes).
+extern "C" int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float* x,
+                                         const void* w_split, const float* wscale,
+                                         const float* bias, float* y, float* stat_partials,
+                                         uint32_t* in_absmax, void* stream) {
+  ADELL_REQUIRE(fwd_s2_fused_ok(d),
+                "conv_fwd_s2_fused: needs 32 -> 32 channels, k = 3, stride 2, padding 1, even dims");
+  ADELL_REQUIRE(x && w_split && wscale && y, "conv_fwd_s2_fused: null pointer");
+  ADELL_REQUIRE(((uintptr_t)x & 15) == 0, "conv_fwd_s2_fused: x must be 16-byte aligned");
+  FwdS2Args a;
+  a.x = x;
+  a.wpack = reinterpret_cast<const char*>(w_split);
+  a.wscale = wscale;
+  a.bias = bias;
+  a.y = y;
+  a.part = stat_partials;
+  a.amax_out = in_absmax;
+  a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo;
+  a.ntx = adell_cdiv(d->Wo, 8);
+  a.nty = adell_cdiv(d->Ho, 8);
+  a.ntz = adell_cdiv(d->Do, 4);
+  const long nbricks = (long)d->N * a.ntx * a.nty * a.ntz;
+  ADELL_REQUIRE(nbricks < 0x0fffffffL, "conv_fwd_s2_fused: too many bricks");
+  a.nbricks = (int)nbricks;
+  const int grid = (int)(nbricks < cu_count() ? nbricks : cu_count());   // one block per CU
+  ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_fwd_s2_fused_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+  hipLaunchKernelGGL(adell_fwd_s2_fused_kernel, dim3(grid), dim3(256), kLds, (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

@@ -256,13 +256,24 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
         residual = ndhwc(residual)
         assert tuple(residual.shape) == tuple(y.shape)
     part = None
+    # the 32 -> 32 stride-2 downsampling layer: one persistent launch (csrc/conv_fwd_s2.hip)
+    s2fused = (split and x1 is None and residual is None and not FLAGS["no_s2fused"]
+               and bool(_lib.lib().adell_conv3d_fwd_s2_fused_applicable(ctypes.byref(d))))
     if want_stats:
-        fn = _lib.lib().adell_conv3d_fwd_ntiles_f16x3 if split else _lib.lib().adell_conv3d_fwd_ntiles
+        fn = (_lib.lib().adell_conv3d_fwd_s2_fused_ntiles if s2fused
+              else _lib.lib().adell_conv3d_fwd_ntiles_f16x3 if split
+              else _lib.lib().adell_conv3d_fwd_ntiles)
         nt = fn(ctypes.byref(d))
         if nt < 0:
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
-    if split:
+    if s2fused:
+        check(_timed("adell_fwd_s2_fused_kernel", _conv_flops(d),
+                     lambda: _lib.lib().adell_conv3d_fwd_s2_fused(
+                         ctypes.byref(d), _ptr(x0), _ptr(w_packed.halfs), _ptr(w_packed.scale),
+                         _ptr(bias), _ptr(y), _ptr(part), _ptr(amax), _stream()),
+                     _conv_tag(d, "fwd"), _conv_bytes(d)))
+    elif split:
         ws, wsb = _splitk_workspace(d, 0, x0.device)
         check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_fwd_f16x3_ws(

@@ -142,6 +142,15 @@ int adell_conv3d_bwd_data_s2_f16x3_add(const adell_conv3d_desc* d, const float* 
  * (csrc/conv_dgrad_s2.hip). w_split_bwd / wscale: adell_pack_weight_f16x3 mode 1 of the full
  * weight; add0: null or as above. _applicable: 1 when the layer qualifies. */
 int adell_conv3d_bwd_data_s2_fused_applicable(const adell_conv3d_desc* d);
+/* The forward of the same layer in one persistent launch (csrc/conv_fwd_s2.hip): the eight parity
+ * sub-lattices of x behind an output brick are staged one after the other (a 51 KB halo each) and
+ * accumulate into the same registers; bias, statistics partials ([N][_ntiles][32][2]) and the
+ * absmax by-product as adell_conv3d_fwd_f16x3. w_split / wscale: adell_pack_weight_f16x3 mode 0. */
+int adell_conv3d_fwd_s2_fused_applicable(const adell_conv3d_desc* d);
+int adell_conv3d_fwd_s2_fused_ntiles(const adell_conv3d_desc* d);
+int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float* x, const void* w_split,
+                              const float* wscale, const float* bias, float* y,
+                              float* stat_partials, uint32_t* in_absmax, void* stream);
 int adell_conv3d_bwd_data_s2_fused(const adell_conv3d_desc* d, const float* dy,
                                    const void* w_split_bwd, const float* wscale,
                                    const float* add0, float* dx, uint32_t* dy_absmax, void* stream);
