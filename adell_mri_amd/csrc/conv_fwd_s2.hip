@@ -13,8 +13,8 @@
 // Here a persistent block (one per CU, 4 waves)
 //   * keeps the whole split weight (27 x 32 x 32 x (hi, lo) = 108 KB) in LDS for its lifetime,
 //   * walks the eight sub-lattices of a brick: stage + split one 51 KB halo, run its taps into the
-//     SAME 2 x 16 accumulator registers per wave, while the next sub-lattice's halo is in flight in
-//     registers (a sub-lattice voxel is a full 128-byte line of x),
+//     SAME 2 x 16 accumulator registers per wave, while the halos of the next TWO sub-lattices are
+//     in flight in registers (a sub-lattice voxel is a full 128-byte line of x),
 //   * takes the operand scale per (brick, sub-lattice) from the block-wide absmax of the staged
 //     halo and rescales the accumulators by the exact power of two when it changes,
 //   * emits bias, the per-channel (sum, sum of squares) partials of the following norm and the
@@ -69,6 +69,9 @@ struct FwdS2Args {
 
 }  // namespace
 
+// DBG: timing experiments (-DADELL_DEBUG builds only; results are wrong when nonzero): 1 no MFMAs,
+// 2 no y stores / statistics, 8 no halo split / LDS stores, 16 no halo loads after the first phase
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a) {
   extern __shared__ char smem[];
   char* sW = smem;
@@ -93,9 +96,11 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
     oz0 = tz * 4;
   };
   // halo of sub-lattice (pz, py, px) behind brick t: halo voxel h <-> x index 2 (o0 - 1 + h) + p per axis
-  float4 f[kPer];
-  unsigned okbits = 0;
-  auto prefetch = [&](int phase) {
+  // two register images: the loads of a phase are issued two phases ahead of their use (a
+  // one-tap sub-lattice runs 12 MFMAs per wave: far less than a memory round trip)
+  float4 fbuf[2][kPer];
+  unsigned okbuf[2] = {0u, 0u};
+  auto prefetch = [&](int phase, float4 (&f)[kPer], unsigned& okbits) {
     const int t = blockIdx.x + (phase >> 3) * gridDim.x, cls = phase & 7;
     int nb, tile, ox0, oy0, oz0;
     brick_origin(t, nb, tile, ox0, oy0, oz0);
@@ -152,14 +157,16 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
   const int nphases = my_bricks * 8;
   f32x16 acc[2];
   int kprev = 0;
-  // one phase = one sub-lattice of one brick. Iteration ph: issue the loads of phase ph (one fetch
-  // site), run the MFMAs of phase ph - 1 out of LDS, close a brick after its eighth sub-lattice,
-  // then move phase ph from registers to LDS.
-  for (int ph = 0; ph <= nphases; ++ph) {
-    if (ph < nphases) prefetch(ph);
+  // one phase = one sub-lattice of one brick.
+  // iteration ph: issue the loads of phase ph (into register image ph & 1), run the MFMAs of phase
+  // ph - 2 out of LDS (and close its brick after the eighth sub-lattice), move phase ph - 1 from
+  // its register image to LDS. Unrolled by two so that each image has ONE fetch site.
+  auto step = [&](int ph, auto BUF) __attribute__((always_inline)) {
+    constexpr int B = decltype(BUF)::value;
+    if (ph < nphases && !((DBG & 16) && ph > 1)) prefetch(ph, fbuf[B], okbuf[B]);
     __builtin_amdgcn_sched_barrier(0);
-    if (ph > 0) {
-      const int cls = (ph - 1) & 7;
+    if (ph > 1) {
+      const int cls = (ph - 2) & 7;
       // ---- taps of sub-lattice cls: per axis parity 0 -> tap 1 at offset 1; parity 1 -> tap 0 at
       // offset 0 and tap 2 at offset 1 (offsets in the halo whose origin is o0 - 1)
       static_for<8>([&](auto CLS) {
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
             static_for<8>([&](auto T) {
               constexpr int tb = decltype(T)::value;   // bit a: the second tap of axis a (parity 1 only)
               constexpr int sz = tb >> 2, sy = (tb >> 1) & 1, sx = tb & 1;
-              if constexpr ((sz <= pz) && (sy <= py) && (sx <= px)) {
+              if constexpr ((sz <= pz) && (sy <= py) && (sx <= px) && !(DBG & 1)) {
                 constexpr int tz = pz ? 2 * sz : 1, ty = py ? 2 * sy : 1, tx = px ? 2 * sx : 1;
                 constexpr int dz = pz ? sz : 1, dy = py ? sy : 1, dx = px ? sx : 1;
                 constexpr int tap = (tz * 3 + ty) * 3 + tx;
@@ -201,13 +208,13 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
       });
       if (cls == 7) {
         // ---- epilogue of the brick: C row r of m-tile mt = output (x = (r & 3) + 4 lh, y = (r >> 2) + 4 mt)
-        const int t = blockIdx.x + ((ph - 1) >> 3) * gridDim.x;
+        const int t = blockIdx.x + ((ph - 2) >> 3) * gridDim.x;
         int nb, tile, ox0, oy0, oz0;
         brick_origin(t, nb, tile, ox0, oy0, oz0);
         const float oscale = __int_as_float((127 - kprev) << 23) * wsc;
         const int z = oz0 + wave;
         float s1 = 0.f, s2 = 0.f;
-        if (z < a.Do) {
+        if (z < a.Do && !(DBG & 2)) {
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -243,7 +250,9 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
         }
       }
     }
-    if (ph < nphases) {
+    if (ph > 0 && ph - 1 < nphases) {
+      float4 (&f)[kPer] = fbuf[1 - B];
+      const unsigned okbits = okbuf[1 - B];
       // ---- mask, absmax -> power-of-two scale of this sub-lattice halo ----------------------------
       float mx = 0.f;
 #pragma unroll
@@ -254,10 +263,13 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      __syncthreads();   // the fragments of phase ph - 1 are read (and its sMax / sRed values)
-      if (lane == 0) sMax[wave] = mx;
+      // (two sMax rows used in turn: a row is rewritten two phases after it was read, with a
+      // barrier in between, so one barrier serves "fragments of phase ph - 2 are read" and "the
+      // four wave maxima are visible")
+      float* sm = sMax + 4 * (ph & 1);
+      if (lane == 0) sm[wave] = mx;
       __syncthreads();
-      mx = fmaxf(fmaxf(sMax[0], sMax[1]), fmaxf(sMax[2], sMax[3]));
+      mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
       block_max = fmaxf(block_max, mx);
       int kA = 0;
       {
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
         if (kA > 96) kA = 96;
         if (kA < -96) kA = -96;
       }
-      if ((ph & 7) == 0) {   // first sub-lattice of a brick: fresh accumulators
+      if (((ph - 1) & 7) == 0) {   // first sub-lattice of a brick: fresh accumulators
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
         const int it = tid + 256 * u;
-        if (it < kItems) {
+        if (it < kItems && !(DBG & 8)) {
           const int hv = it >> 3;
           const float v[4] = {f[u].x * scaleA, f[u].y * scaleA, f[u].z * scaleA, f[u].w * scaleA};
           half4 h, l;
@@ -301,6 +313,10 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
       }
       __syncthreads();
     }
+  };
+  for (int ph = 0; ph <= nphases + 1; ph += 2) {
+    step(ph, std::integral_constant<int, 0>{});
+    step(ph + 1, std::integral_constant<int, 1>{});
   }
   if (a.amax_out != nullptr && tid == 0) atomicMax(a.amax_out, __float_as_uint(block_max));
 }
@@ -366,9 +382,27 @@ extern "C" int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float
   ADELL_REQUIRE(nbricks < 0x0fffffffL, "conv_fwd_s2_fused: too many bricks");
   a.nbricks = (int)nbricks;
   const int grid = (int)(nbricks < cu_count() ? nbricks : cu_count());   // one block per CU
-  ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_fwd_s2_fused_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-  hipLaunchKernelGGL(adell_fwd_s2_fused_kernel, dim3(grid), dim3(256), kLds, (hipStream_t)stream, a);
+  auto launch = [&](auto kern) -> int {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, (hipStream_t)stream, a);
+    return ADELL_OK;
+  };
+  int rc = ADELL_OK;
+#ifdef ADELL_DEBUG
+  switch (g_adell_tune.igemm_dbg) {
+    case 1: rc = launch(adell_fwd_s2_fused_kernel<1>); break;
+    case 2: rc = launch(adell_fwd_s2_fused_kernel<2>); break;
+    case 3: rc = launch(adell_fwd_s2_fused_kernel<3>); break;
+    case 8: rc = launch(adell_fwd_s2_fused_kernel<8>); break;
+    case 16: rc = launch(adell_fwd_s2_fused_kernel<16>); break;
+    case 27: rc = launch(adell_fwd_s2_fused_kernel<27>); break;
+    default: rc = launch(adell_fwd_s2_fused_kernel<0>); break;
+  }
+#else
+  rc = launch(adell_fwd_s2_fused_kernel<0>);
+#endif
+  if (rc != ADELL_OK) return rc;
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
