@@ -431,6 +431,17 @@ extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1
                                       int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,
                                       WgradZrPlan* p);
 extern "C" size_t adell_wgrad_zring_ws_floats(const WgradZrPlan* p, int Cin, int Cout);
+// the 32 -> 32 stride-2 downsampling layer (conv_wgrad_s2.hip)
+struct WgradS2Plan {
+  int ntx, nty, ntz, nbricks, blocks, R;
+};
+extern "C" int adell_wgrad_s2_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
+                                   int KH, int KW, int SD, int SH, int SW, int PD, int PH, int PW,
+                                   int Do, int Ho, int Wo, WgradS2Plan* p);
+extern "C" int adell_wgrad_s2_launch(const WgradS2Plan* p, int N, int D, int H, int W, const float* x,
+                                     int Do, int Ho, int Wo, const float* dy, float* slabs,
+                                     float* wsdb, const unsigned* xmax, const unsigned* ymax,
+                                     hipStream_t st);
 extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int H, int W, int C0,
                                         int C1, const float* x0, const float* x1, int Cout, int Do,
                                         int Ho, int Wo, const float* dy, int PD, int PH, int PW,
@@ -524,9 +535,14 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   WgradZrPlan zp;
   const bool zring = adell_wgrad_zring_plan(N, D, H, W, C0, C1, Cout, KD, KH, KW, SD, SH, SW, Do, Ho,
                                             Wo, &zp) != 0;
+  WgradS2Plan sp;
+  const bool s2 = !zring && adell_wgrad_s2_plan(N, D, H, W, C0, C1, Cout, KD, KH, KW, SD, SH, SW, PD,
+                                                PH, PW, Do, Ho, Wo, &sp) != 0;
   int rc = ADELL_OK;
   if (zring)
     p.R = zp.R;
+  else if (s2)
+    p.R = sp.R;
   else
     rc = adell_wgrad_f16_plan(N, Cin, Cout, KD, KH, KW, SH, SW, Do, Ho, Wo, &p);
   if (rc != ADELL_OK) return rc;
@@ -556,6 +572,12 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
                                   ymax_in ? ymax_in : amax + 1, st);
     if (rc != ADELL_OK) return rc;
     return adell_wgrad_reduce_launch(slabs, out, zp.R, ntap, Cin, Cout, db ? wsdb : nullptr, db, st);
+  }
+  if (s2) {
+    rc = adell_wgrad_s2_launch(&sp, N, D, H, W, x0, Do, Ho, Wo, dy, slabs, db ? wsdb : nullptr,
+                               xmax_in ? xmax_in : amax, ymax_in ? ymax_in : amax + 1, st);
+    if (rc != ADELL_OK) return rc;
+    return adell_wgrad_reduce_launch(slabs, out, sp.R, ntap, Cin, Cout, db ? wsdb : nullptr, db, st);
   }
   WgradF16Args a = {};
   a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = slabs; a.wsdb = db ? wsdb : nullptr;
@@ -621,6 +643,11 @@ extern "C" long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc*
   } else if (adell_wgrad_f16_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SH, d->SW, d->Do,
                                   d->Ho, d->Wo, &p) != ADELL_OK)
     return ADELL_E_UNSUPPORTED;
+  WgradS2Plan sp;
+  if (adell_wgrad_s2_plan(d->N, d->D, d->H, d->W, d->C0, d->C1, d->Cout, d->KD, d->KH, d->KW, d->SD,
+                          d->SH, d->SW, d->PD, d->PH, d->PW, d->Do, d->Ho, d->Wo, &sp) &&
+      sp.R > p.R)
+    p.R = sp.R;   // the larger plan, so that a later call may take either kernel
   return (long)adell_wgrad_f16_ws(p, d->KD * d->KH * d->KW, Cin, d->Cout);
 }
 
