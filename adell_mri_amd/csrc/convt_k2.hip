@@ -22,6 +22,7 @@ struct ConvTK2Args {
   float* y;           // [N][2D][2H][2W][Cout]
   float* dx;          // [N][D][H][W][Cin]
   float* ws;          // dW partials [blocks][pairs][8 f][32 ci][32 co]
+  float* wsdb;        // db partials [blocks][4 waves][Cout] or null
   int N, D, H, W, Cin, Cout;
   long V;             // N D H W
   int ntiles;         // ceil(V / 32)
@@ -200,6 +201,10 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
   float* tx = sx[wave];
   float* tyl = sy[wave];
   CtK2Regs<32> rx, ry0, ry1;
+  // bias gradient as a by-product (blocks of the first ci tile): this lane's pieces of dY are always
+  // the channels co0 + 4 (lane & 7) .. + 3, rows past the tensor are zero
+  const bool do_db = a.wsdb != nullptr && ci0 == 0;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
   auto fetch = [&](int t) {
     const long v0 = (long)t * 32;
     const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
@@ -214,6 +219,15 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
     adell_ctk2_put<32>(tx, LDX, lane, rx);
     adell_ctk2_put<32>(tyl, LDY, lane, ry0);
     adell_ctk2_put<32>(tyl + 32, LDY, lane, ry1);
+    if (do_db) {
+#pragma unroll
+      for (int u = 0; u < CtK2Regs<32>::PER; ++u) {
+        dbacc.x += ry0.f[u].x + ry1.f[u].x;
+        dbacc.y += ry0.f[u].y + ry1.f[u].y;
+        dbacc.z += ry0.f[u].z + ry1.f[u].z;
+        dbacc.w += ry0.f[u].w + ry1.f[u].w;
+      }
+    }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);
 #pragma unroll
@@ -235,14 +249,38 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // ci
       out[(size_t)((fz * 2 + fy) * 2 + fx) * 1024 + row * 32 + li] = acc[fx][r];
     }
+  if (do_db) {
+    // lanes with the same lane & 7 hold the same four channels: fold over lane bits 3, 4, 5
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      dbacc.x += __shfl_xor(dbacc.x, o, 64);
+      dbacc.y += __shfl_xor(dbacc.y, o, 64);
+      dbacc.z += __shfl_xor(dbacc.z, o, 64);
+      dbacc.w += __shfl_xor(dbacc.w, o, 64);
+    }
+    if (lane < 8) {
+      float* o = a.wsdb + ((size_t)blockIdx.x * 4 + wave) * a.Cout + co0 + 4 * lane;
+      o[0] = dbacc.x; o[1] = dbacc.y; o[2] = dbacc.z; o[3] = dbacc.w;
+    }
+  }
 }
 
 // dw[ci][co][f] = sum over blocks: one wave per value (lane l adds blocks l, l + 64, ...)
 __global__ __launch_bounds__(256) void adell_convt_k2_dw_reduce_kernel(
-    const float* __restrict__ ws, int blocks, int Cin, int Cout, float* __restrict__ dw) {
+    const float* __restrict__ ws, int blocks, int Cin, int Cout, float* __restrict__ dw,
+    const float* __restrict__ wsdb, float* __restrict__ db) {
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (i >= (long)Cin * Cout * 8) return;   // whole wave
+  const long ndw = (long)Cin * Cout * 8;
+  if (i >= ndw) {   // whole wave: the waves past dW fold the bias-gradient rows, one channel each
+    const long co = i - ndw;
+    if (db == nullptr || co >= Cout) return;
+    float s = 0.f;
+    for (int r = lane; r < blocks * 4; r += 64) s += wsdb[(size_t)r * Cout + co];
+    s = adell_wave_sum(s);
+    if (lane == 0) db[co] = s;
+    return;
+  }
   const int f = (int)(i & 7);
   const long cc = i >> 3;
   const int co = (int)(cc % Cout), ci = (int)(cc / Cout);
@@ -322,11 +360,13 @@ extern "C" long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int C
   if (!adell_convt_k2_ok(N, D, H, W, Cin, Cout)) return ADELL_E_BADARG;
   ConvTK2Args a = {};
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
-  return (long)sizeof(float) * adell_ctk2_blocks(a, 2) * (Cin / 32) * (Cout / 32) * 8 * 1024;
+  const long blocks = adell_ctk2_blocks(a, 2);
+  return (long)sizeof(float) * (blocks * (Cin / 32) * (Cout / 32) * 8 * 1024 + blocks * 4 * Cout);
 }
 
+// db (optional): the bias gradient sum_v dy[v][co], a by-product of the same pass over dy.
 extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout,
-                                         const float* x, const float* dy, float* dw,
+                                         const float* x, const float* dy, float* dw, float* db,
                                          void* workspace, size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(x && dy && dw && workspace && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
                 "convt_k2_bwd_weight: factor-2 transposed conv with 32 / 64 channels expected");
@@ -338,12 +378,13 @@ extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, in
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
   a.x = x; a.dy = dy; a.ws = (float*)workspace;
   const int blocks = adell_ctk2_blocks(a, 2);
+  a.wsdb = db ? a.ws + (size_t)blocks * (Cin / 32) * (Cout / 32) * 8 * 1024 : nullptr;
   dim3 grid((unsigned)blocks, (unsigned)((Cin / 32) * (Cout / 32)));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adell_convt_k2_dw_kernel, grid, dim3(256), 0, st, a);
-  const long outs = (long)Cin * Cout * 8;
+  const long outs = (long)Cin * Cout * 8 + (db ? Cout : 0);
   hipLaunchKernelGGL(adell_convt_k2_dw_reduce_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0,
-                     st, (const float*)workspace, blocks, Cin, Cout, dw);
+                     st, (const float*)workspace, blocks, Cin, Cout, dw, (const float*)a.wsdb, db);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

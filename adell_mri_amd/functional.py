@@ -441,10 +441,13 @@ class _ConvT3dFn(torch.autograd.Function):
             dx = (ops.convt_k2_bwd_data(dy, weight) if ctx.k2 else
                   ops.convtranspose3d_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0],
                                                ctx.factors))
-        if need[1]:
+        want_db = ctx.has_bias and need[2]
+        if need[1] and ctx.k2 and want_db:
+            dw, db = ops.convt_k2_bwd_weight(x, dy, want_db=True)   # db from the same pass over dy
+        elif need[1]:
             dw = (ops.convt_k2_bwd_weight(x, dy) if ctx.k2 else
                   ops.convtranspose3d_bwd_weight(x, dy, ctx.factors))
-        if ctx.has_bias and need[2]:
+        if want_db and db is None:
             db = ops.bias_grad(dy)
         return dx, dw, db, None, None
 

@@ -681,7 +681,8 @@ def convt_k2_bwd_data(dy, weight):
     return dx
 
 
-def convt_k2_bwd_weight(x, dy):
+def convt_k2_bwd_weight(x, dy, want_db=False):
+    """dW (and, with want_db, the bias gradient from the same pass over dy: returns (dw, db))."""
     _require_cuda(x, dy)
     x, dy = ndhwc(x), ndhwc(dy)
     N, Cin, D, H, W = x.shape
@@ -690,12 +691,13 @@ def convt_k2_bwd_weight(x, dy):
     check(min(nbytes, 0))
     ws = _workspace(nbytes, x.device)
     dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_db else None
     check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
                  lambda: _lib.lib().adell_convt_k2_bwd_weight(
-                     N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(ws),
+                     N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
                      ws.numel() * 4, _stream()),
                  f"convT wgrad {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (x.numel() + dy.numel())))
-    return dw
+    return (dw, db) if want_db else dw
 
 
 def convtranspose3d_k2s2_bwd_weight(x, dy):

@@ -519,9 +519,10 @@ int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const floa
 int adell_convt_k2_bwd_data(int N, int D, int H, int W, int Cin, int Cout, const float* dy,
                             const float* w, float* dx, void* stream);
 long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout);
+/* db (optional, [Cout]): the bias gradient, a by-product of the same pass over dy */
 int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, const float* x,
-                              const float* dy, float* dw, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              const float* dy, float* dw, float* db, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* 3x3x3 stride-1 convolution with 1..4 input channels and a wide output (the 2 -> 32 conv of the
  * U-Net input block, unet.py:260-273; UNETR's first encoder, unetr.py:225-237) as one small GEMM per

@@ -41,7 +41,7 @@ def test_convt_k2_matches_torch_cpu(cuda, n, cin, cout, size):
     assert _rel(y.detach().cpu(), y_ref.detach()) < 2e-6
     assert _rel(hx.grad.cpu(), x.grad) < 2e-6
     assert _rel(hw.grad.cpu(), w.grad) < 5e-6
-    assert _rel(hb.grad.cpu(), b.grad) < 5e-5     # bias_grad kernel (unchanged path), ~10^5 terms
+    assert _rel(hb.grad.cpu(), b.grad) < 5e-5     # by-product of the dW kernel (fp32 sums of ~10^5 terms)
     # deterministic weight gradient (fixed fold order of the block partials)
     dw2 = ops.convt_k2_bwd_weight(hx.detach(), ops.ndhwc(r.to(cuda)))
     assert torch.equal(dw2, hw.grad)
