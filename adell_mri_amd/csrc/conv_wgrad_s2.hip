@@ -8,13 +8,13 @@
 // transposing LDS read over natural [voxel][32 channels] fp16 hi / lo planes). The decomposition
 // is the forward kernel's: per axis the input index 2 o - 1 + t has parity 0 for t = 1 and parity 1
 // for t in {0, 2}, so the eight parity sub-lattices of x pair with 1, 2, 4 or 8 taps each, and the
-// part of ONE sub-lattice behind an 8 x 8 x 4 brick of dY is a 9 x 9 x 5 halo. A block (8 waves,
-// one per CU) keeps the brick of dY (32 KB) in LDS, stages the eight sub-lattice halos of x in turn
-// (51 KB, the next one in flight in registers) and accumulates all 27 taps in registers for its
-// whole life: wave = (group g, lane-set w); group g takes the z planes 2 g, 2 g + 1 of every brick
-// (half of K), w owns 7 (6) of the 27 taps, dealt so that every sub-lattice keeps the four w of a
-// group as evenly busy as its tap count allows. Every (block, group) writes ONE partial slab at the
-// end, folded in fixed order by the slab fold of conv_wgrad_f16.hip. Operand scales: one power of
+// part of ONE sub-lattice behind an 8 x 8 x 2 brick of dY is a 9 x 9 x 3 halo. A block (4 waves,
+// two per CU so that one stages while the other multiplies) keeps the brick of dY (16 KB) in LDS,
+// stages the eight sub-lattice halos of x in turn (31 KB, the next one in flight in registers) and
+// accumulates all 27 taps in registers for its whole life: wave w owns 7 (6) of the 27 taps, dealt
+// so that every sub-lattice keeps the four waves as evenly busy as its tap count allows. Every
+// block writes ONE partial slab at the end, folded in fixed order by the slab fold of
+// conv_wgrad_f16.hip. Operand scales: one power of
 // two per tensor from the absmax words (by-products of the forward / backward-data kernels).
 // Roofline: HBM (x 537 MB + dY 67 MB read once at 2 x 128^3).
 #include <type_traits>
@@ -27,12 +27,15 @@ typedef __fp16 ws2_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 namespace {
 
-constexpr int kHX = 9, kHY = 9, kHZ = 5, kHV = kHX * kHY * kHZ;   // sub-lattice halo of a brick
+constexpr int kBZ = 2;                                             // brick = 8 x 8 x kBZ voxels of dY
+constexpr int kHX = 9, kHY = 9, kHZ = kBZ + 1, kHV = kHX * kHY * kHZ;   // sub-lattice halo of a brick
 constexpr int kXPlane = kHV * 64;                                  // one fp16 plane of the halo
-constexpr int kYPlane = 256 * 64;                                  // ... of the dY brick
+constexpr int kYRows = 64 * kBZ;
+constexpr int kYPlane = kYRows * 64;                               // ... of the dY brick
 constexpr int kLds = 2 * kXPlane + 2 * kYPlane;
-constexpr int kXItems = kHV * 8, kXPer = (kXItems + 511) / 512;    // float4 pieces per thread (7)
-constexpr int kYPer = 256 * 8 / 512;                               // 4
+constexpr int kThreads = 256;
+constexpr int kXItems = kHV * 8, kXPer = (kXItems + kThreads - 1) / kThreads;   // float4 pieces per thread (8)
+constexpr int kYPer = kYRows * 8 / kThreads;                       // 4
 
 template <typename T>
 __device__ __forceinline__ ADELL_GLOBAL T* uniform_ptr(T* p) {
@@ -138,14 +141,17 @@ struct WgradS2Args {
   int ntx, nty, ntz, nbricks;
 };
 
-__global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args a) {
+// DBG: timing experiments (-DADELL_DEBUG builds only; results are wrong when nonzero): 1 no MFMAs,
+// 8 no split / LDS stores, 16 no loads after the first phase
+template <int DBG>
+__global__ __launch_bounds__(kThreads, 2) void adell_conv_wgrad_s2_kernel(WgradS2Args a) {
   extern __shared__ char smem[];
   char* sXh = smem;
   char* sXl = sXh + kXPlane;
   char* sYh = sXl + kXPlane;
   char* sYl = sYh + kYPlane;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = wave >> 2, w4 = wave & 3, lh = lane >> 5;
+  const int w4 = wave, lh = lane >> 5;
   const int nsp = a.ntx * a.nty * a.ntz;
   const int kX = scale_exp(a.xmax[0]), kY = scale_exp(a.ymax[0]);
   const float sX = __int_as_float((kX + 127) << 23), sY = __int_as_float((kY + 127) << 23);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
     const int tz = r / a.nty;
     ox0 = tx * 8;
     oy0 = ty * 8;
-    oz0 = tz * 4;
+    oz0 = tz * kBZ;
   };
   float4 fx[kXPer], fy[kYPer];
   unsigned okx = 0, oky = 0;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
     okx = 0;
 #pragma unroll
     for (int u = 0; u < kXPer; ++u) {
-      const int it = tt + 512 * u;
+      const int it = tt + kThreads * u;
       const int hv = it >> 3;
       const int hz = hv / (kHX * kHY), rem = hv - hz * (kHX * kHY);
       const int hy = rem / kHX, hx = rem - hy * kHX;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
       oky = 0;
 #pragma unroll
       for (int u = 0; u < kYPer; ++u) {
-        const int it = tt + 512 * u;
+        const int it = tt + kThreads * u;
         const int v = it >> 3;                       // brick voxel: x + 8 (y + 8 z)
         const int oz = oz0 + (v >> 6), oy = oy0 + ((v >> 3) & 7), ox = ox0 + (v & 7);
         const bool ok = (oz < a.Do) & (oy < a.Ho) & (ox < a.Wo);
@@ -227,9 +233,9 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
   // iteration ph: issue the loads of phase ph (one fetch site), run the MFMAs of phase ph - 1 out
   // of LDS, then move phase ph from registers to LDS
   for (int ph = 0; ph <= nphases; ++ph) {
-    if (ph < nphases) prefetch(ph);
+    if (ph < nphases && !((DBG & 16) && ph > 0)) prefetch(ph);
     __builtin_amdgcn_sched_barrier(0);
-    if (ph > 0) {
+    if (ph > 0 && !(DBG & 1)) {
       const int cls = (ph - 1) & 7;
       static_for<8>([&](auto CLS) {
         constexpr int c = decltype(CLS)::value;
@@ -238,10 +244,10 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
             constexpr int j = decltype(J)::value;
             constexpr int slot = tap_slot(c, j), hoff = cls_hoff(c, j);
             if (w4 == tap_owner(c, j)) {
-              // 8 k-steps of 16 voxels: planes 2 g, 2 g + 1, row pairs 0 .. 3
+              // k-steps of 16 voxels: the planes of the brick, row pairs 0 .. 3
 #pragma unroll
-              for (int s = 0; s < 8; ++s) {
-                const int z = 2 * g + (s >> 2), yp = 2 * (s & 3);
+              for (int s = 0; s < 4 * kBZ; ++s) {
+                const int z = s >> 2, yp = 2 * (s & 3);
                 const int xo = abase + ((z * kHY + yp) * kHX + hoff) * 64;
                 const int yo = bbase + ((z * 8 + yp) * 8) * 64;
                 const ws2_half8 ah = tr_frag(sXh + xo), al = tr_frag(sXl + xo);
@@ -259,8 +265,8 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
       __syncthreads();   // the fragments of phase ph - 1 are read
 #pragma unroll
       for (int u = 0; u < kXPer; ++u) {
-        const int it = tid + 512 * u;
-        if (it < kXItems) {
+        const int it = tid + kThreads * u;
+        if (it < kXItems && !(DBG & 8)) {
           const bool ok = (okx >> u) & 1u;
           const float4 f = make_float4(ok ? fx[u].x : 0.f, ok ? fx[u].y : 0.f, ok ? fx[u].z : 0.f,
                                        ok ? fx[u].w : 0.f);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
       if ((ph & 7) == 0) {
 #pragma unroll
         for (int u = 0; u < kYPer; ++u) {
-          const int it = tid + 512 * u;
+          const int it = tid + kThreads * u;
           const bool ok = (oky >> u) & 1u;
           const float4 f = make_float4(ok ? fy[u].x : 0.f, ok ? fy[u].y : 0.f, ok ? fy[u].z : 0.f,
                                        ok ? fy[u].w : 0.f);
@@ -282,24 +288,22 @@ __global__ __launch_bounds__(512, 1) void adell_conv_wgrad_s2_kernel(WgradS2Args
     }
   }
 
-  // ---- bias gradient of this block's bricks -> region 2 b (region 2 b + 1 gets zeros) ---------
-  const int region = blockIdx.x * 2 + g;
+  // ---- bias gradient of this block's bricks ------------------------------------------------
+  const int region = blockIdx.x;
   if (a.wsdb) {
     __syncthreads();
     // threads with the same c4 hold the same four channels: fold the 64 of them in fixed order
-    float4* red = reinterpret_cast<float4*>(smem);   // 512 float4 = 8 KB (the halo image is free)
+    float4* red = reinterpret_cast<float4*>(smem);   // one float4 per thread (the halo image is free)
     red[tid] = dbacc;
     __syncthreads();
     if (tid < 8) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = tid; k < 512; k += 8) {
+      for (int k = tid; k < kThreads; k += 8) {
         const float4 u = red[k];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
-      float* o0 = a.wsdb + (size_t)(blockIdx.x * 2) * 32 + 4 * tid;
-      float* o1 = o0 + 32;
+      float* o0 = a.wsdb + (size_t)region * 32 + 4 * tid;
       o0[0] = t.x; o0[1] = t.y; o0[2] = t.z; o0[3] = t.w;
-      o1[0] = 0.f; o1[1] = 0.f; o1[2] = 0.f; o1[3] = 0.f;
     }
   }
   // ---- partial slab of (block, group): C row = ci, column = co (undo the operand scales) -------
@@ -350,15 +354,16 @@ extern "C" int adell_wgrad_s2_plan(int N, int D, int H, int W, int C0, int C1, i
   if (g_adell_tune.wgrad_nozring) return 0;                     // the A/B switch of the z-ring kernel
   p->ntx = adell_cdiv(Wo, 8);
   p->nty = adell_cdiv(Ho, 8);
-  p->ntz = adell_cdiv(Do, 4);
+  p->ntz = adell_cdiv(Do, kBZ);
   const long nb = (long)N * p->ntx * p->nty * p->ntz;
   if (nb >= 0x0fffffffL) return 0;
   // every (block, group) writes a 108 KB slab: below a few bricks per block the slab fold costs more
   // than the kernel saves (2 x 64^3: 0.087 ms here against 0.077 on the generic kernel)
-  if (nb < 4L * wgrad_s2_cus()) return 0;
+  if (nb < 8L * wgrad_s2_cus()) return 0;
   p->nbricks = (int)nb;
-  p->blocks = (int)(nb < wgrad_s2_cus() ? nb : wgrad_s2_cus());
-  p->R = 2 * p->blocks;
+  const long want = 2L * wgrad_s2_cus();     // two resident blocks per CU
+  p->blocks = (int)(nb < want ? nb : want);
+  p->R = p->blocks;
   return 1;
 }
 
@@ -370,9 +375,25 @@ extern "C" int adell_wgrad_s2_launch(const WgradS2Plan* p, int N, int D, int H, 
   a.x = x; a.dy = dy; a.ws = slabs; a.wsdb = wsdb; a.xmax = xmax; a.ymax = ymax;
   a.N = N; a.D = D; a.H = H; a.W = W; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.ntx = p->ntx; a.nty = p->nty; a.ntz = p->ntz; a.nbricks = p->nbricks;
-  ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_conv_wgrad_s2_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-  hipLaunchKernelGGL(adell_conv_wgrad_s2_kernel, dim3((unsigned)p->blocks), dim3(512), kLds, st, a);
+  auto launch = [&](auto kern) -> int {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)p->blocks), dim3(kThreads), kLds, st, a);
+    return ADELL_OK;
+  };
+  int rc = ADELL_OK;
+#ifdef ADELL_DEBUG
+  switch (g_adell_tune.zr_dbg) {
+    case 1: rc = launch(adell_conv_wgrad_s2_kernel<1>); break;
+    case 8: rc = launch(adell_conv_wgrad_s2_kernel<8>); break;
+    case 16: rc = launch(adell_conv_wgrad_s2_kernel<16>); break;
+    case 25: rc = launch(adell_conv_wgrad_s2_kernel<25>); break;
+    default: rc = launch(adell_conv_wgrad_s2_kernel<0>); break;
+  }
+#else
+  rc = launch(adell_conv_wgrad_s2_kernel<0>);
+#endif
+  if (rc != ADELL_OK) return rc;
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

@@ -16,8 +16,8 @@ def _rel(a, b):
                                     (3, (2, 2, 2)), (1, (64, 64, 64)), (5, (8, 16, 8))])
 @pytest.mark.parametrize("words", [False, True])
 def test_wgrad_matches_fp64_and_the_generic_kernel(cuda, n, size, words):
-    """(the planner takes this kernel from 4 bricks per CU upwards; whichever kernel runs, the
-    result is checked against fp64 -- the 64^3 case below is on this kernel only with >= 1024 bricks,
+    """(the planner takes this kernel from 8 bricks per CU upwards; whichever kernel runs, the
+    result is checked against fp64 -- the kernel itself is exercised by
     see test_large_problem_takes_the_sublattice_kernel)"""
     from adell_mri_amd import _lib, ops
 
@@ -65,8 +65,8 @@ def test_other_shapes_keep_their_kernels(cuda):
 
 
 def test_large_problem_takes_the_sublattice_kernel(cuda):
-    """2 x 128 x 128 x 64 input: 1024 bricks -> csrc/conv_wgrad_s2.hip (checked through the workspace
-    size, which follows the larger of the plans), against fp64 on a slice of taps."""
+    """2 x 64 x 128 x 128 input: 2048 bricks of 8 x 8 x 2 -> csrc/conv_wgrad_s2.hip (checked through the
+    workspace size, which follows the larger of the plans), against fp64."""
     import ctypes
 
     from adell_mri_amd import _lib, ops
@@ -80,7 +80,7 @@ def test_large_problem_takes_the_sublattice_kernel(cuda):
         ws_big_generic = L.adell_conv3d_bwd_weight_f16x3_workspace(ctypes.byref(d_big))
     finally:
         L.adell_set_tuning(b"wgrad_nozring", 0)
-    assert ws_big > ws_big_generic          # 512 slabs of the sub-lattice kernel
+    assert ws_big > ws_big_generic          # one slab per block of the sub-lattice kernel
     assert L.adell_conv3d_bwd_weight_f16x3_workspace(ctypes.byref(d_small)) > 0
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 32, 64, 128, 128, generator=g)
