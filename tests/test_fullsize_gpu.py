@@ -85,3 +85,41 @@ def test_config2_unet_forward_at_full_size_is_deterministic(cuda):
     with torch.no_grad():
         q, _ = net(x[:1].contiguous())
     assert float((q - p1[:1]).abs().max()) < 1e-6
+
+
+def test_stride2_downsampling_layer_full_size_fused_vs_generic_kernels(cuda, monkeypatch):
+    """The three one-launch kernels of the 32 -> 32 stride-2 layer (conv_fwd_s2 / conv_dgrad_s2 /
+    conv_wgrad_s2.hip) at the benchmark's level-0 size (2 x 128^3 in, 2 x 64^3 out) against the
+    implicit-GEMM / parity-class / generic weight-gradient kernels they replace (different
+    decompositions of the same sums: agreement to f16x3 accuracy), plus the statistics partials."""
+    import torch
+
+    from adell_mri_amd import _lib
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    x = ops.ndhwc(torch.randn(2, 32, 128, 128, 128, generator=g).to(cuda))
+    w = (torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05).to(cuda)
+    b = torch.randn(32, generator=g).to(cuda)
+    dy = ops.ndhwc((torch.randn(2, 32, 64, 64, 64, generator=g) * 1e-3).to(cuda))
+
+    def run():
+        xg = x.detach().requires_grad_(True)
+        wg, bg = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
+        y = HF.conv3d(xg, wg, bg, stride=2, padding=1, want_stats=True)
+        part = y._adell_partials.double().sum(1)
+        y.backward(dy)
+        return y.detach(), part, xg.grad, wg.grad, bg.grad
+
+    fused = run()
+    monkeypatch.setitem(ops.FLAGS, "no_s2fused", True)
+    L = _lib.lib()
+    L.adell_set_tuning(b"wgrad_nozring", 1)     # also turns the sub-lattice weight-gradient kernel off
+    try:
+        generic = run()
+    finally:
+        L.adell_set_tuning(b"wgrad_nozring", 0)
+    for name, a_, b_ in zip(("y", "partials", "dx", "dw", "db"), fused, generic):
+        rel = float((a_ - b_).abs().max()) / float(b_.abs().max())
+        assert rel < 5e-6, (name, rel)
