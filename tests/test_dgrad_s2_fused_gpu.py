@@ -74,3 +74,29 @@ def test_autograd_takes_the_fused_kernel(cuda, monkeypatch):
     torch.nn.functional.conv3d(xr, wr, None, stride=2, padding=1).backward(dy.double())
     assert _rel(xd.grad.cpu().double(), xr.grad) < 5e-6
     assert _rel(wd.grad.cpu().double(), wr.grad) < 5e-6
+
+
+def test_fused_pair_against_the_c_oracle(cuda):
+    """Forward and backward-data of the layer against the fp64-accumulated C oracle (oracle/c), on
+    a shape with whole and ragged bricks."""
+    import numpy as np
+
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+    from oracle import cops
+
+    rng = np.random.default_rng(5)
+    size = (12, 20, 18)
+    x = rng.standard_normal((1, 32, *size)).astype(np.float32)
+    x[:, ::3] *= 1e-3
+    w = (rng.standard_normal((32, 32, 3, 3, 3)) / np.sqrt(32 * 27)).astype(np.float32)
+    b = rng.standard_normal(32).astype(np.float32)
+    dy = (rng.standard_normal((1, 32, 6, 10, 9)) * 1e-4).astype(np.float32)
+    y_ref = cops.conv3d(x, w, b, 2, 1)
+    dx_ref, _, _ = cops.conv3d_bwd(x, w, dy, 2, 1)
+    wd = torch.from_numpy(w).to(cuda)
+    y, _ = ops.conv3d_fwd(ops.ndhwc(torch.from_numpy(x).to(cuda)), HF._packed(wd, 0),
+                          torch.from_numpy(b).to(cuda), 32, 3, 2, 1)
+    dx = ops.conv3d_bwd_data_s2_fused(ops.ndhwc(torch.from_numpy(dy).to(cuda)), HF._packed(wd, 1), size)
+    assert float(np.abs(y.cpu().numpy() - y_ref).max() / np.abs(y_ref).max()) < 5e-6
+    assert float(np.abs(dx.cpu().numpy() - dx_ref).max() / np.abs(dx_ref).max()) < 5e-6
