@@ -589,8 +589,10 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
   size_t lds;
   int rc = adell_plan_f16(a, N, &t, &lds);
   if (rc != ADELL_OK) return rc;
+  // (the f16x3 kernel's 16-byte halo loads address a batch item with 32-bit byte offsets)
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
-           (((uintptr_t)a.x1 & 15) == 0);
+           (((uintptr_t)a.x1 & 15) == 0) &&
+           (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30);
   a.vecw = 1;
   e.dbg = g_adell_tune.igemm_dbg;
   const long nsp = (long)a.ntx * a.nty * a.ntz;

@@ -126,19 +126,13 @@ __global__ __launch_bounds__(256, 1) void adell_dgrad_s2_fused_kernel(DgradS2Arg
   // ---- the split weight, once: global row (tap' * 32 + n) * 2 + chunk -> [tap'][chunk][n] ----
   // (27 x 256 slots of 16 bytes, nine loads in flight per thread)
   if (!(DBG & 4)) {
-#pragma unroll 1
-    for (int b = 0; b < 3; ++b) {
-      float4 v[9];
-#pragma unroll
-      for (int u = 0; u < 9; ++u)
-        v[u] = *reinterpret_cast<const float4*>(a.wpack + (size_t)(tid + 256 * (9 * b + u)) * 16);
-#pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int it = tid + 256 * (9 * b + u);
-        const int slot = it & 3, row = it >> 2;
-        const int ch = row & 1, n = (row >> 1) & 31, tap = row >> 6;
-        *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v[u];
-      }
+    // (a plain strided loop: a register array of nine rows per pass ended up in scratch memory)
+#pragma unroll 9
+    for (int it = tid; it < 27 * 256; it += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(a.wpack + (size_t)it * 16);
+      const int slot = it & 3, row = it >> 2;
+      const int ch = row & 1, n = (row >> 1) & 31, tap = row >> 6;
+      *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v;
     }
   }
 
@@ -179,9 +173,13 @@ __global__ __launch_bounds__(256, 1) void adell_dgrad_s2_fused_kernel(DgradS2Arg
     const float scaleA = __int_as_float((kA + 127) << 23);
     const float oscale = __int_as_float((127 - kA) << 23) * wsc;
     // ---- split to (hi, lo) halves and store: row = 64 B per (chunk, voxel) --------------------
+    // (the LDS row addresses do not depend on the brick either: recomputed per brick on purpose,
+    // hoisted they are 13 more spilled registers)
+    int ts = tid;
+    asm volatile("" : "+v"(ts));
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
-      const int it = tid + 256 * u;
+      const int it = ts + 256 * u;
       if (it < kItems && !(DBG & 8)) {
         const int hv = it >> 3;
         const float v[4] = {f[u].x * scaleA, f[u].y * scaleA, f[u].z * scaleA, f[u].w * scaleA};
@@ -191,8 +189,9 @@ __global__ __launch_bounds__(256, 1) void adell_dgrad_s2_fused_kernel(DgradS2Arg
           h[j] = (_Float16)v[j];
           l[j] = (_Float16)(v[j] - (float)h[j]);
         }
-        const int sw = (hv >> 2) & 3, slot = (q & 3) >> 1;
-        char* row = sA + (q >> 2) * (kHV * 64) + hv * 64 + (q & 1) * 8;
+        const int qs = ts & 7;
+        const int sw = (hv >> 2) & 3, slot = (qs & 3) >> 1;
+        char* row = sA + (qs >> 2) * (kHV * 64) + hv * 64 + (qs & 1) * 8;
         *reinterpret_cast<half4*>(row + ((slot ^ sw) << 4)) = h;
         *reinterpret_cast<half4*>(row + (((2 + slot) ^ sw) << 4)) = l;
       }
@@ -240,6 +239,10 @@ __global__ __launch_bounds__(256, 1) void adell_dgrad_s2_fused_kernel(DgradS2Arg
       return (unsigned)pz * eZ + (unsigned)(8 * mt + py + 2 * (r >> 2)) * eY +
              (unsigned)(px + 2 * (r & 3)) * 32u;
     };
+    // (opaque per brick: otherwise the 64 fragment addresses of the 8 offsets x 2 m-tiles x 2 chunks x
+    // (hi, lo) are hoisted out of the brick loop and spilled)
+    int arow_b[2] = {arow[0], arow[1]};
+    asm volatile("" : "+v"(arow_b[0]), "+v"(arow_b[1]));
     float rv[2][16];
     auto fetch_add0 = [&](const int c) __attribute__((always_inline)) {
       if constexpr (FULL && ADD) {
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void adell_dgrad_s2_fused_kernel(DgradS2Arg
           half8 ah[2], al[2];
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) {
-            const int hv = arow[mt] + (dz * kHY + dy_) * kHX + dx_;
+            const int hv = arow_b[mt] + (dz * kHY + dy_) * kHX + dx_;
             const int sw = (hv >> 2) & 3;
             const char* row = sAc + hv * 64;
             ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));

@@ -127,19 +127,13 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
   };
 
   // ---- the split weight, once: global row (tap * 32 + n) * 2 + chunk -> [tap][chunk][n] ---------
-#pragma unroll 1
-  for (int b = 0; b < 3; ++b) {
-    float4 v[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u)
-      v[u] = *reinterpret_cast<const float4*>(a.wpack + (size_t)(tid + 256 * (9 * b + u)) * 16);
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-      const int it = tid + 256 * (9 * b + u);
-      const int slot = it & 3, row = it >> 2;
-      const int ch = row & 1, n = (row >> 1) & 31, tap = row >> 6;
-      *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v[u];
-    }
+  // (a plain strided loop: a register array of nine rows per pass ended up in scratch memory)
+#pragma unroll 9
+  for (int it = tid; it < 27 * 256; it += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(a.wpack + (size_t)it * 16);
+    const int slot = it & 3, row = it >> 2;
+    const int ch = row & 1, n = (row >> 1) & 31, tap = row >> 6;
+    *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v;
   }
 
   // A rows of this lane at offset (0, 0, 0): wave w = output plane z = w; m-tile mt: y = 4 mt .. + 3

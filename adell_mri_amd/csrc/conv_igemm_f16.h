@@ -196,16 +196,18 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     }
     const size_t gv = (size_t)gvi;
     if (a.vecx) {
+      // (vecx also says that a batch item spans < 2^32 bytes: uniform base + 32-bit byte offset per
+      // load instead of a 64-bit pointer per load, which the compiler hoists and spills)
+      const ADELL_GLOBAL char* b0 = adell_uniform_ptr(x0n);
+      const ADELL_GLOBAL char* b1 = adell_uniform_ptr(x1n);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = c0 + 4 * q;
-        const float* p = nullptr;
-        if (c < a.C0)
-          p = x0n + gv * a.C0 + c;
-        else if (c < a.Cin)
-          p = x1n + gv * a.C1 + (c - a.C0);
-        if (p) {
-          const float4 f = *reinterpret_cast<const float4*>(p);
+        if (c < a.Cin) {
+          const bool first = c < a.C0;
+          const unsigned off = first ? ((unsigned)gvi * (unsigned)a.C0 + (unsigned)c) * 4u
+                                     : ((unsigned)gvi * (unsigned)a.C1 + (unsigned)(c - a.C0)) * 4u;
+          const float4 f = adell_gload4((first ? b0 : b1) + off);
           v[4 * q + 0] = f.x;
           v[4 * q + 1] = f.y;
           v[4 * q + 2] = f.z;
@@ -230,7 +232,10 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   // (generic single-tile instances have registers to spare: 6 voxels per thread keep the
   // 17 x 9 x 9 halo of a stride-2 3^3 layer out of the two-pass loop below, whose loads are
   // issued one dependent round at a time -- 2 x 64^3 x 32 -> 32 stride 2: 0.76 ms before)
-  constexpr int KEEP = SPEC ? ((SPEC == 3 ? 1000 : 600) + NTHR - 1) / NTHR : (MT * NT == 1 ? 6 : 3);
+  // (six voxels only on the two-wave instance, which runs those layers: on the four-wave single-tile
+  // instances the 96 registers spilled)
+  constexpr int KEEP = SPEC ? ((SPEC == 3 ? 1000 : 600) + NTHR - 1) / NTHR
+                            : (MT * NT == 1 && NW == 2 ? 6 : 3);
   const bool resident = SPEC || HV <= KEEP * NTHR;
   float keep[KEEP][CC];
   int gvk[KEEP];
@@ -244,7 +249,9 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   // slots = 4.5 (BN 32) / 9 (BN 64) x 256 slots of 16 bytes).
   // (the 256-column transposed-conv instance, WN = 4, has one tap per group)
   constexpr int WPF = ((WN == 4 ? 1 : GT) * BN * 4 + NTHR - 1) / NTHR;  // a kz plane of a 3^3 kernel
-  const bool wpipe = SPEC || GKH * KW * BN * 4 <= WPF * NTHR;
+  // (not on the generic 2x2-tile instance: with 64 accumulators and one fragment set the 36 prefetch
+  // registers spilled; it stages its weight slices straight from global memory)
+  const bool wpipe = SPEC || ((MT * NT < 4 || WN == 4) && GKH * KW * BN * 4 <= WPF * NTHR);
   float4 wreg[WPF];
   const int ngroups = SPEC ? NGRP : KD * ngy;
   // SPEC: slot index it = tid + u * NTHR means column (tid >> 2) % BN, tap u * TPU + (tid >> 2) / BN

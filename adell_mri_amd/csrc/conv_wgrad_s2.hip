@@ -163,11 +163,22 @@ __global__ __launch_bounds__(kThreads, 2) void adell_conv_wgrad_s2_kernel(WgradS
   const int abase = (lh * kHX + tq) * 64 + colb;   // + plane / row pair / tap offsets (halo rows)
   const int bbase = (lh * 8 + tq) * 64 + colb;     // + plane / row pair (brick rows)
 
-  f32x16 acc[7];
+  // seven named accumulators, selected at compile time (an indexed array of them ends up in
+  // scratch memory: the compiler sinks the identical MFMA chains of the tap branches into one block
+  // with the slot as a phi, and 448 bytes of dynamically indexed private memory are not promoted)
+  f32x16 acc0, acc1, acc2, acc3, acc4, acc5, acc6;
 #pragma unroll
-  for (int s = 0; s < 7; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = acc3[r] = acc4[r] = acc5[r] = acc6[r] = 0.f;
+  auto accref = [&](auto S) -> f32x16& {
+    constexpr int s = decltype(S)::value;
+    if constexpr (s == 0) return acc0;
+    else if constexpr (s == 1) return acc1;
+    else if constexpr (s == 2) return acc2;
+    else if constexpr (s == 3) return acc3;
+    else if constexpr (s == 4) return acc4;
+    else if constexpr (s == 5) return acc5;
+    else return acc6;
+  };
 
   const int c4 = tid & 7;
   auto brick_origin = [&](int t, int& nb, int& ox0, int& oy0, int& oz0) {
@@ -252,9 +263,10 @@ __global__ __launch_bounds__(kThreads, 2) void adell_conv_wgrad_s2_kernel(WgradS
                 const int yo = bbase + ((z * 8 + yp) * 8) * 64;
                 const ws2_half8 ah = tr_frag(sXh + xo), al = tr_frag(sXl + xo);
                 const ws2_half8 bh = tr_frag(sYh + yo), bl = tr_frag(sYl + yo);
-                acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[slot], 0, 0, 0);
-                acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[slot], 0, 0, 0);
-                acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[slot], 0, 0, 0);
+                f32x16& ac = accref(std::integral_constant<int, slot>{});
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, ac, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, ac, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, ac, 0, 0, 0);
               }
             }
           });
@@ -317,7 +329,8 @@ __global__ __launch_bounds__(kThreads, 2) void adell_conv_wgrad_s2_kernel(WgradS
       if (w4 == tap_owner(c, j)) {
         float* base = a.ws + (((size_t)region * 27 + tap) * 32 + 4 * lh) * 32 + co;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) base[(size_t)((r & 3) + 8 * (r >> 2)) * 32] = acc[slot][r] * unscale;
+        for (int r = 0; r < 16; ++r)
+          base[(size_t)((r & 3) + 8 * (r >> 2)) * 32] = accref(std::integral_constant<int, slot>{})[r] * unscale;
       }
     });
   });

@@ -16,8 +16,6 @@ import torch
 import torch.nn.functional as F
 
 from ... import functional as HF
-from ...optim import (FusedAdagrad, FusedAdam, FusedAdamax, FusedAdamW, FusedNAdam, FusedRAdam,
-                      FusedRMSprop, FusedSGD)
 from ..learning_rate import CosineAnnealingWithWarmupLR
 from .unet import BrUNet, UNet
 from .unetpp import UNetPlusPlus
@@ -31,16 +29,10 @@ except Exception:  # noqa: BLE001
     _Base = torch.nn.Module
 
 
-OPTIMIZER_MATCH = {"adam": FusedAdam, "adamw": FusedAdamW, "adamax": FusedAdamax, "sgd": FusedSGD,
-                   "adagrad": FusedAdagrad, "nadam": FusedNAdam, "radam": FusedRAdam,
-                   "rmsprop": FusedRMSprop}
-
-
-def get_optimizer(optimizer_str: str, *args, **kwargs):
-    """adell_mri/utils/optimizer_factory.py:17-30 on the fused flat-buffer optimisers: the same
-    eight names; as there, an unknown name returns None."""
-    if optimizer_str in OPTIMIZER_MATCH:
-        return OPTIMIZER_MATCH[optimizer_str](*args, **kwargs)
+# the factory lives where the reference keeps it (utils/optimizer_factory.py); re-exported here
+# because round-2 code imported it from this module
+from ...utils.optimizer_factory import (OPTIMIZER_MATCH, get_optimizer,  # noqa: E402,F401
+                                        optimizer_eps_from_precision)
 
 
 class UNetBasePL(_Base):

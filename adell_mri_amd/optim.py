@@ -25,11 +25,14 @@ from . import ops
 class FlatParameters:
     """Flatten ``params`` (leaf fp32 Parameters on one CUDA device)."""
 
-    def __init__(self, params):
+    def __init__(self, params, device=None):
+        # An empty list is legal (a parameter group whose parameters are all frozen, e.g. the SSL
+        # encoder handed to the U-Net with lr_encoder == 0: entrypoints/segmentation/train.py:718-724):
+        # zero-length buffers on ``device``; every loop below then has nothing to do.
         self.params = list(params)
-        if not self.params:
-            raise ValueError("FlatParameters: empty parameter list")
-        dev = self.params[0].device
+        if not self.params and device is None:
+            raise ValueError("FlatParameters: an empty parameter list needs a device")
+        dev = self.params[0].device if self.params else torch.device(device)
         self.offsets = []
         n = 0
         for p in self.params:
@@ -41,6 +44,9 @@ class FlatParameters:
         self.ends = self.offsets[1:] + [n]   # padded end of every slice
         self.data = torch.zeros(n, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        # parallel.GradSync: the slot holds this step's (reduced) gradient although ``p.grad`` is
+        # detached from it while the collective runs
+        self.reduced = [False] * len(self.params)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 view = self.data[o:o + p.numel()].view(p.shape)
@@ -154,7 +160,8 @@ class _FusedBase(torch.optim.Optimizer):
             # frozen parameters (e.g. an EMA shadow) never receive gradients: torch.optim skips
             # them, so they stay out of the flat buffer
             group = self.param_groups[gi]
-            flat = FlatParameters([p for p in group["params"] if p.requires_grad])
+            dev = next((p.device for g in self.param_groups for p in g["params"]), None)
+            flat = FlatParameters([p for p in group["params"] if p.requires_grad], device=dev)
             self._flats[gi] = flat
             self._flat_state[gi] = {"steps": np.zeros(len(flat.params), dtype=np.int64)}
         return flat

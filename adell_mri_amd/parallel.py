@@ -83,13 +83,18 @@ def plan_buckets(sizes, n_buckets=4, min_elems=1 << 20):
 
 
 class _Bucket:
-    __slots__ = ("flat", "lo", "hi", "e0", "e1", "pending", "sent")
+    __slots__ = ("flat", "lo", "hi", "e0", "e1", "pending", "sent", "handle", "again")
 
     def __init__(self, flat, lo, hi):
         self.flat, self.lo, self.hi = flat, lo, hi
         self.e0, self.e1 = flat.offsets[lo], flat.ends[hi - 1]
-        self.pending = hi - lo
-        self.sent = False
+        self.reset()
+
+    def reset(self):
+        self.pending = self.hi - self.lo   # parameters whose gradient has not arrived yet
+        self.sent = False                  # the slice went out in this step
+        self.handle = None                 # ... and this is its collective
+        self.again = False                 # a later backward of the same step brought more
 
 
 class GradSync:
@@ -97,41 +102,86 @@ class GradSync:
 
     ``overlap`` (default: on when the world size is > 1, ``ADELL_DDP_OVERLAP=0`` turns it off)
     issues the collectives bucket by bucket from backward hooks; otherwise the whole buffer
-    goes out in ``chunk_mb`` messages when ``all_reduce()`` is called.
+    goes out in ``chunk_mb`` messages when ``all_reduce()`` is called. The bucket count grows
+    with the message: ``n_buckets`` (default 4, ``ADELL_DDP_BUCKETS``) is a minimum, and a flat
+    buffer is cut into at least one bucket per ``max_bucket_mb`` (default 32 MB: the 135-167 MB
+    of gradients of the ViT / ConvNeXt / ResNet-encoder configurations go out in 5-6 pieces
+    that start while backward still runs, instead of four 40 MB ones).
+
+    A step is everything between two ``all_reduce()`` calls (``optimizer.zero_grad()`` also
+    closes one: a step abandoned after a NaN leaves no stale state). Several backward passes
+    per step are legal:
+
+    * inside ``no_sync()`` nothing is sent: gradients accumulate locally, exactly as under
+      ``DistributedDataParallel.no_sync()`` (Lightning's ``accumulate_grad_batches``);
+    * without it, a bucket that already went out is not touched by the later backward: once
+      sent, its parameters are detached from the flat slice (their next gradients arrive as
+      fresh tensors), and ``all_reduce()`` reduces that second contribution separately and adds
+      it to the first -- the result is the sum over ranks of ALL local gradients either way.
+
+    ``find_unused_parameters``: a parameter that got no gradient on this rank but did on
+    another still has to be stepped here, or the replicas drift (torch DDP writes the reduced
+    gradient on every rank). With the flag on, ``all_reduce()`` also MAX-reduces a has-gradient
+    bitmap and attaches the reduced slot to such parameters; it costs one host synchronisation
+    per step, so it is off unless the model has rank-dependent control flow (DDP's own flag).
     """
 
     def __init__(self, optimizer, chunk_mb=64, async_op=False, overlap=None, n_buckets=None,
-                 min_bucket_elems=None):
+                 min_bucket_elems=None, max_bucket_mb=32, find_unused_parameters=False,
+                 _force_overlap=False):
         self.optimizer = optimizer
         self.chunk = int(chunk_mb * 1024 * 1024 // 4)
         self.async_op = async_op
         self.world = world_size()
+        self.find_unused = bool(find_unused_parameters)
         for g in optimizer.param_groups:
             g["grad_scale"] = 1.0 / self.world
         if overlap is None:
             overlap = self.world > 1 and os.environ.get("ADELL_DDP_OVERLAP", "1") != "0"
-        self.overlap = bool(overlap) and self.world > 1
-        self.buckets, self._handles, self._hooks = [], [], []
+        # (_force_overlap: the single-rank RCCL test runs the hook -> async all-reduce -> wait path
+        # on a one-process group; a production world of 1 has nothing to exchange)
+        self.overlap = bool(overlap) and (self.world > 1 or (_force_overlap and dist.is_initialized()))
+        self.buckets, self._hooks = [], []
+        self._sync = True
         if self.overlap:
             nb = int(os.environ.get("ADELL_DDP_BUCKETS", "4")) if n_buckets is None else n_buckets
             me = (1 << 20) if min_bucket_elems is None else min_bucket_elems
-            self._install(nb, me)
+            self._install(nb, me, int(max_bucket_mb * 1024 * 1024 // 4))
+            self._wrap_zero_grad()
 
     # ---- bucketed, overlapped path --------------------------------------------------------
-    def _install(self, n_buckets, min_elems):
+    def _install(self, n_buckets, min_elems, max_elems):
         for flat in self.optimizer.flat_groups:
+            if not flat.params:          # a group of frozen parameters: nothing to exchange
+                continue
             sizes = [e - o for o, e in zip(flat.offsets, flat.ends)]
-            for lo, hi in plan_buckets(sizes, n_buckets, min_elems):
+            nb = max(int(n_buckets), -(-int(sum(sizes)) // max(max_elems, 1)))
+            for lo, hi in plan_buckets(sizes, nb, min_elems):
                 b = _Bucket(flat, lo, hi)
                 self.buckets.append(b)
                 for i in range(lo, hi):
                     self._hooks.append(
                         flat.params[i].register_post_accumulate_grad_hook(self._make_hook(b)))
 
+    def _wrap_zero_grad(self):
+        """``optimizer.zero_grad()`` starts a new step: drop whatever an abandoned one left."""
+        inner = self.optimizer.zero_grad
+
+        def zero_grad(*args, **kwargs):
+            self.reset()
+            return inner(*args, **kwargs)
+
+        self.optimizer.zero_grad = zero_grad
+
     def _make_hook(self, bucket):
         def hook(_param):
+            if not self._sync:
+                return
+            if bucket.sent:              # a second backward in this step (see the class notes)
+                bucket.again = True
+                return
             bucket.pending -= 1
-            if bucket.pending == 0 and not bucket.sent:
+            if bucket.pending == 0:
                 self._send(bucket)
         return hook
 
@@ -139,8 +189,60 @@ class GradSync:
         b.flat.collect(range(b.lo, b.hi))
         b.sent = True
         if b.e1 > b.e0:
-            self._handles.append(dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
-                                                 async_op=True))
+            b.handle = dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
+                                       async_op=True)
+        # detach the parameters from the slice while the collective may be running: a later
+        # backward must not accumulate in place into memory the collective reads and writes
+        for i in range(b.lo, b.hi):
+            p = b.flat.params[i]
+            if p.grad is not None:
+                b.flat.reduced[i] = True
+                p.grad = None
+
+    def _finish(self, b):
+        """After the bucket's collective: fold in what a later backward of the step produced,
+        then hand the parameters their reduced gradients."""
+        if b.handle is not None:
+            b.handle.wait()
+            b.handle = None
+        flat = b.flat
+        late = [i for i in range(b.lo, b.hi) if flat.params[i].grad is not None]
+        if late:
+            first = flat.grad[b.e0:b.e1].clone()      # sum over ranks of the first contribution
+            flat.grad[b.e0:b.e1].zero_()
+            flat.collect(late)
+            if self.world > 1 or dist.is_initialized():
+                dist.all_reduce(flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM)
+            flat.grad[b.e0:b.e1].add_(first)
+        for i in range(b.lo, b.hi):
+            if flat.reduced[i] or flat.params[i].grad is not None:
+                flat.params[i].grad = flat.slot(i)
+            flat.reduced[i] = False
+
+    def reset(self):
+        """Forget the current step (waits for collectives still in flight)."""
+        for b in self.buckets:
+            if b.handle is not None:
+                b.handle.wait()
+            for i in range(b.lo, b.hi):
+                b.flat.reduced[i] = False
+            b.reset()
+
+    def no_sync(self):
+        """Context manager: backward passes inside it exchange nothing (their gradients
+        accumulate locally and go out with the first backward outside it, or at
+        ``all_reduce()``)."""
+        outer = self
+
+        class _NoSync:
+            def __enter__(self):
+                self.prev, outer._sync = outer._sync, False
+
+            def __exit__(self, *exc):
+                outer._sync = self.prev
+                return False
+
+        return _NoSync()
 
     def remove_hooks(self):
         for h in self._hooks:
@@ -155,7 +257,8 @@ class GradSync:
         if self.world == 1:
             return
         for flat in self.optimizer.flat_groups:
-            dist.broadcast(flat.data, src=src)
+            if flat.data.numel() > 0:
+                dist.broadcast(flat.data, src=src)
         if module is not None:
             flat_ids = {id(p) for f in self.optimizer.flat_groups for p in f.params}
             for t in list(module.parameters()) + list(module.buffers()):
@@ -165,23 +268,43 @@ class GradSync:
 
         ops._weights_changed()
 
+    def _attach_remote_grads(self):
+        """find_unused_parameters: a parameter another rank produced a gradient for gets its
+        (reduced) slot here too."""
+        flats = [f for f in self.optimizer.flat_groups if f.params]
+        if not flats:
+            return
+        dev = flats[0].grad.device
+        have = torch.tensor([p.grad is not None for f in flats for p in f.params],
+                            dtype=torch.int32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MAX)
+        have = have.cpu().tolist()
+        k = 0
+        for f in flats:
+            for i, p in enumerate(f.params):
+                if have[k] and p.grad is None:
+                    p.grad = f.slot(i)
+                k += 1
+
     def all_reduce(self):
         """Complete the gradient exchange of this step: after it returns (stream-ordered), every
-        flat gradient buffer holds the sum over ranks."""
+        flat gradient buffer holds the sum over ranks and every parameter that produced a
+        gradient has ``p.grad`` pointing at its slice of it."""
         if self.overlap:
-            for b in self.buckets:           # buckets that a gradient-less parameter held back
-                if not b.sent:
+            for b in self.buckets:           # buckets that a gradient-less parameter (or
+                if not b.sent:               # no_sync) held back
                     self._send(b)
-            for h in self._handles:
-                h.wait()
-            self._handles = []
             for b in self.buckets:
-                b.pending, b.sent = b.hi - b.lo, False
-            return
-        collect = getattr(self.optimizer, "collect_grads", None)
-        if collect is not None:
-            collect()
-        all_reduce_flat([f.grad for f in self.optimizer.flat_groups], self.chunk, self.async_op)
+                self._finish(b)
+                b.reset()
+        else:
+            collect = getattr(self.optimizer, "collect_grads", None)
+            if collect is not None:
+                collect()
+            all_reduce_flat([f.grad for f in self.optimizer.flat_groups], self.chunk,
+                            self.async_op)
+        if self.find_unused and (self.world > 1):
+            self._attach_remote_grads()
 
 
 def reduce_max(value, device):

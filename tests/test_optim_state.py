@@ -118,7 +118,16 @@ def test_step_after_load_and_gradientless_parameters_match_torch(cuda, kind):
 
 
 def test_get_optimizer_covers_the_reference_factory_names():
-    from adell_mri_amd.modules.segmentation.pl import OPTIMIZER_MATCH, get_optimizer
+    # the module path of the reference (utils/optimizer_factory.py:5-54), its three public names
+    from adell_mri_amd.modules.segmentation import pl
+    from adell_mri_amd.utils.optimizer_factory import (OPTIMIZER_EPS_DEFAULT, OPTIMIZER_MATCH,
+                                                       get_optimizer,
+                                                       optimizer_eps_from_precision)
+
+    assert pl.get_optimizer is get_optimizer and pl.OPTIMIZER_MATCH is OPTIMIZER_MATCH
+    assert optimizer_eps_from_precision("16-true") == 1e-4
+    for prec in (None, "32", "16", "16-mixed", "bf16", "bf16-mixed", 32):
+        assert optimizer_eps_from_precision(prec) == OPTIMIZER_EPS_DEFAULT == 1e-8
 
     assert sorted(OPTIMIZER_MATCH) == sorted(["adam", "adamw", "adamax", "sgd", "adagrad", "nadam",
                                               "radam", "rmsprop"])
