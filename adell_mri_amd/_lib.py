@@ -41,6 +41,14 @@ class NormActDesc(ctypes.Structure):
     ]
 
 
+class AdnSite(ctypes.Structure):
+    """adell_adn_site (include/adell_hip.h): a norm -> dropout -> activation site whose backward
+    is fused into the backward-data kernel that produces the gradient of its output."""
+    _fields_ = [("y", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("keep_mask", ctypes.c_void_p), ("drop_p", ctypes.c_float),
+                ("act_p", ctypes.c_float), ("act", ctypes.c_int32)]
+
+
 _vp, _i, _l, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 
 # name -> (restype, argtypes); every symbol include/adell_hip.h declares.
@@ -88,6 +96,13 @@ SIGNATURES = {
     "adell_channel_partials_ntiles": (_i, [_l]),
     "adell_channel_partials": (_i, [_vp, _i, _l, _i, _vp, _vp]),
     "adell_norm_act_fwd": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "adell_norm_act_mask_bytes": (_l, [ctypes.POINTER(NormActDesc)]),
+    "adell_norm_act_fwd_mask": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 9),
+    "adell_norm_act_bwd_from_dt": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 5 + [_i, _i, _i, _vp, _vp,
+                                                                              ctypes.c_size_t, _vp]),
+    "adell_conv3d_bwd_data_f16x3_adn_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_bwd_data_f16x3_adn": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7
+                                        + [ctypes.POINTER(AdnSite), ctypes.POINTER(AdnSite), _vp, _vp]),
     "adell_norm_act_bwd_workspace": (_l, [ctypes.POINTER(NormActDesc)]),
     "adell_norm_act_bwd": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 11 + [ctypes.c_size_t, _vp]),
     "adell_dice_focal_workspace": (_l, [_i, _l]),

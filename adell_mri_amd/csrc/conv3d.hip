@@ -344,11 +344,11 @@ extern "C" int adell_pack_weight(const float* w, float* out, int mode, int dim0,
 // ---------------------------------------------------------------------------
 // f16x3 path (conv_igemm_f16.h): fp32 tensors in and out, 3 f16 MFMAs per K-block.
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int SPEC>
+template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0>
 static int adell_launch_conv_f16(const ConvArgs& a, const ConvF16Extra& e, dim3 grid, size_t lds,
                                  hipStream_t st) {
   static bool attr_done = false;
-  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN, SPEC>;
+  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN, SPEC, EPI>;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -583,12 +583,15 @@ static int adell_splitk_shares(const ConvArgs& a, const ConvTile& t, int N) {
   return adell_cdiv(nchunk, cpk);
 }
 
+// adn: 0 plain; 1 launch the EPI = 1 instance (fused norm / dropout / activation backward in the
+// epilogue: ConvF16Extra::adn), failing when the plan does not allow it; -1 only answer whether it
+// would (returns the number of bricks per batch item = rows of the partial-sum buffer, 0 = no).
 static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_t st,
-                                   void* ws = nullptr, size_t ws_bytes = 0) {
+                                   void* ws = nullptr, size_t ws_bytes = 0, int adn = 0) {
   ConvTile t;
   size_t lds;
   int rc = adell_plan_f16(a, N, &t, &lds);
-  if (rc != ADELL_OK) return rc;
+  if (rc != ADELL_OK) return adn < 0 ? 0 : rc;
   // (the f16x3 kernel's 16-byte halo loads address a batch item with 32-bit byte offsets)
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
            (((uintptr_t)a.x1 & 15) == 0) &&
@@ -629,6 +632,25 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
                     !g_adell_tune.igemm_nospec;
+  if (adn != 0) {
+    // the fused epilogue lives in the interior-brick path of the specialised instances: every brick
+    // whole, every 32-column sub-tile whole and on one side of ysplit, no split-K, no
+    // wave-specialised form
+    const int bz = t.cfg == 4 ? 8 : 4;
+    const bool ok = ((t.cfg <= 1 && spec) || t.cfg == 4) && shares == 1 && (a.shuffle & 16) == 0 &&
+                    a.Wo % 8 == 0 && a.Ho % 8 == 0 && a.Do % bz == 0 && a.Cout % t.BN == 0 &&
+                    a.ysplit % 32 == 0 && a.bias == nullptr && nsp * (long)a.Cout < (1L << 30);
+    if (adn < 0) return ok ? (int)nsp : 0;
+    if (!ok) {
+      adell_set_error("conv_bwd_data_f16x3_adn: this problem does not take the fused epilogue");
+      return ADELL_E_UNSUPPORTED;
+    }
+    switch (t.cfg) {
+      case 0: return adell_launch_conv_f16<2, 2, 4, 1, 1, 1>(a, e, grid, lds, st);
+      case 4: return adell_launch_conv_f16<4, 1, 4, 1, 3, 1>(a, e, grid, lds, st);
+      default: return adell_launch_conv_f16<2, 1, 4, 1, 1, 1>(a, e, grid, lds, st);
+    }
+  }
   int rc2 = ADELL_OK;
   // large 3x3x3 stride-1 layers, opt-in ("igemm_ws"): the persistent wave-specialised instance
   // (conv_igemm_ws.h), one block per CU walking >= ws_min_items / CUs bricks. Measured on MI355X
@@ -731,7 +753,7 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
   int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
@@ -763,7 +785,7 @@ extern "C" int adell_conv3d_fwd_f16x3_ws(const adell_conv3d_desc* d, const float
   int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -776,7 +798,7 @@ extern "C" int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const 
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
 }
 
@@ -794,8 +816,65 @@ extern "C" int adell_conv3d_bwd_data_f16x3_add(const adell_conv3d_desc* d, const
   ADELL_REQUIRE(w_split_bwd && wscale && add0, "conv_bwd_data_f16x3_add: null pointer");
   ADELL_REQUIRE(d->C1 == 0, "conv_bwd_data_f16x3_add: one destination only");
   a.res = add0;
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, workspace, workspace_bytes);
+}
+
+// Backward-data whose destination(s) are gradients with respect to the OUTPUT of a fused
+// norm -> dropout -> activation site (adn_fn.py:140-152): the epilogue applies the site's
+// activation / dropout derivative and reduces the two per-channel sums the normalisation's backward
+// needs, so the site's own backward is left with ONE elementwise pass (adell_norm_act_bwd_from_dt).
+// site0 / site1 (either may be null: plain destination) describe the sites behind dx0 / dx1;
+// partials: [N][ntiles][C0 + C1][2] floats, ntiles = adell_conv3d_bwd_data_f16x3_adn_ntiles(d)
+// (0: this problem does not take the fused epilogue -- small / ragged / split-K launches).
+extern "C" int adell_conv3d_bwd_data_f16x3_adn_ntiles(const adell_conv3d_desc* d) {
+  if (!d) return 0;
+  ConvArgs a;
+  alignas(16) static float dummy[4];   // (the plan looks at pointer alignment)
+  if (adell_fill_bwd_data(a, d, dummy, dummy, d->C1 > 0 ? dummy : nullptr) != ADELL_OK) return 0;
+  ConvF16Extra e = {};
+  // the plan of the real call (which passes the split-K workspace when there is one)
+  static float ws_probe;
+  const long wsb = adell_conv3d_splitk_workspace(d, 1);
+  return adell_conv_dispatch_f16(a, e, d->N, nullptr, wsb > 0 ? &ws_probe : nullptr,
+                                 wsb > 0 ? (size_t)wsb : 0, -1);
+}
+
+extern "C" int adell_conv3d_bwd_data_f16x3_adn(const adell_conv3d_desc* d, const float* dy,
+                                               const void* w_split_bwd, const float* wscale,
+                                               const float* add0, float* dx0, float* dx1,
+                                               uint32_t* dy_absmax, const adell_adn_site* site0,
+                                               const adell_adn_site* site1, float* partials,
+                                               void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(w_split_bwd && wscale && partials, "conv_bwd_data_f16x3_adn: null pointer");
+  ADELL_REQUIRE(site0 || site1, "conv_bwd_data_f16x3_adn: no site");
+  ADELL_REQUIRE(!add0 || d->C1 == 0, "conv_bwd_data_f16x3_adn: add0 needs one destination");
+  a.res = add0;
+  a.part = partials;
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr};
+  const adell_adn_site* sites[2] = {site0, site1};
+  const long V = (long)a.Do * a.Ho * a.Wo;
+  for (int k = 0; k < 2; ++k) {
+    const adell_adn_site* s = sites[k];
+    if (!s) continue;
+    const int C = k == 0 ? a.ysplit : a.Cout - a.ysplit;
+    ADELL_REQUIRE(C > 0 && s->y && s->mean && s->rstd, "conv_bwd_data_f16x3_adn: bad site %d", k);
+    ADELL_REQUIRE(s->drop_p >= 0.f && s->drop_p < 1.f && (s->drop_p == 0.f || s->keep_mask),
+                  "conv_bwd_data_f16x3_adn: dropout needs the forward's keep mask");
+    ADELL_REQUIRE(s->act == ADELL_ACT_IDENTITY || s->act == ADELL_ACT_SILU ||
+                      s->act == ADELL_ACT_RELU || s->act == ADELL_ACT_LEAKY_RELU,
+                  "conv_bwd_data_f16x3_adn: activation %d has no fused derivative", s->act);
+    e.adn[k].y = s->y; e.adn[k].mean = s->mean; e.adn[k].rstd = s->rstd;
+    e.adn[k].mask = s->drop_p > 0.f ? (const unsigned*)s->keep_mask : nullptr;
+    e.adn[k].keep_scale = 1.0f / (1.0f - s->drop_p);
+    e.adn[k].act_p = s->act_p;
+    e.adn[k].act = s->act;
+    e.adn[k].groups = (int)((V * C + 255) / 256);
+  }
+  return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream, nullptr, 0, 1);
 }
 
 // Backward-data of a stride-2 conv by parity classes. dX[2i + p] (p in {0,1}^3) only receives the
@@ -843,7 +922,7 @@ static int adell_bwd_data_s2_classes(const adell_conv3d_desc* d, const float* dy
     a.ysplit = a.Cout; a.Cs = a.Cout;
     a.shuffle = 8 | 7 | (add0 ? 16 : 0);         // rows on the stride-2 lattice, sub-position 0
     ConvF16Extra e = {(const _Float16*)w_split[c], wscale[c], c == 0 ? dy_absmax : nullptr,
-                      nullptr, nullptr, nullptr, 0};
+                      nullptr, nullptr, nullptr};
     rc = adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
     if (rc != ADELL_OK) return rc;
   }
@@ -889,7 +968,7 @@ extern "C" int adell_convtranspose3d_fwd_f16x3(int N, int D, int H, int W, int C
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.Cs = Cout;
   a.shuffle = 8 | (FW - 1) | ((FH - 1) << 1) | ((FD - 1) << 2);
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
 }
 
@@ -909,7 +988,7 @@ extern "C" int adell_convtranspose3d_bwd_data_f16x3(int N, int D, int H, int W, 
   a.UPS = a.UPSY = a.UPSZ = 1;
   a.Do = D; a.Ho = H; a.Wo = W;
   a.ysplit = a.Cout; a.shuffle = 0; a.Cs = a.Cout;
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, N, (hipStream_t)stream);
 }
 
@@ -921,7 +1000,7 @@ extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const flo
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split_bwd && wscale, "conv_bwd_data_f16x3: null weights");
-  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr, 0};
+  ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 

@@ -56,6 +56,22 @@ struct ConvF16Extra {
   const char* xs0;
   const char* xs1;
   const int* xk;
+  // Backward of a norm -> dropout -> activation site fused into this (backward-data) launch
+  // (EPI = 1 instances): destination d (0: columns [0, ysplit), 1: the rest) is the gradient with
+  // respect to the OUTPUT of such a site whose pre-norm input is adn[d].y (same shape as the
+  // destination). The epilogue then stores dt = dout * act'(u) * keep / (1 - p) instead of dout and
+  // emits the per-brick partial sums (sum dt, sum dt * xhat) through ConvArgs::part: the first of the
+  // two elementwise backward passes of the site (norm_act.hip) is gone. adn[d].y == null: plain store.
+  struct Adn {
+    const float* y;
+    const float* mean;       // [N][C of the destination]
+    const float* rstd;
+    const unsigned* mask;    // keep bits written by the site's forward (norm_act.hip), or null
+    float keep_scale;        // 1 / (1 - p)
+    float act_p;
+    int act;                 // ADELL_ACT_*
+    int groups;              // 256-element groups per batch item in `mask`
+  } adn[2];
   int dbg;               // timing experiments (-DADELL_DEBUG builds only: ADELL_IGEMM_DBG,
                          // tools/igemm_dbg.py): results are wrong when nonzero. 1: halo staged for chunk 0 only; 2: weights staged
                          // for the first tap group only; 8: no MFMAs; 16: no output stores
@@ -76,7 +92,9 @@ __device__ __forceinline__ void adell_split8(const float* v, float scale, half8*
 // counts, plain store. Every index of the halo, tap and epilogue arithmetic is then a
 // compile-time constant (no integer divisions in the loops, tap loop fully unrolled).
 // SPEC = 0 takes all of them from ConvArgs.
-template <int MT, int NT, int WM, int WN, int SPEC>
+// EPI = 1 (SPEC instances, launches whose bricks are all whole): the fused ADN backward of
+// ConvF16Extra::adn in the epilogue.
+template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : WM * WN / 2)
 void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
@@ -652,6 +670,38 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
         resptr[nt] = res_like_y ? a.res + (colptr[nt] - a.y0) : a.res + rrow0 * a.Cout + n;
     }
   }
+  // EPI = 1: per 32-column sub-tile, the site behind its destination (a sub-tile never straddles
+  // ysplit: the host takes the fused path only when ysplit is a multiple of 32)
+  const float* adn_y[NT];
+  const unsigned* adn_mk[NT];
+  float adn_m[NT], adn_r[NT], adn_ks[NT], adn_ap[NT];
+  int adn_act[NT];
+  unsigned adn_e0[NT];
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wn * NT + nt) * 32 + li;
+      const int dst = n < a.ysplit ? 0 : 1;
+      const int cl = n - (dst ? a.ysplit : 0), cs = rowmul[nt];
+      const ConvF16Extra::Adn& s = e.adn[dst];
+      adn_y[nt] = nullptr;
+      adn_mk[nt] = nullptr;
+      adn_m[nt] = 0.f; adn_r[nt] = 1.f; adn_ks[nt] = 1.f; adn_ap[nt] = 0.f;
+      adn_act[nt] = 0;
+      adn_e0[nt] = 0;
+      if (s.y != nullptr && nok[nt]) {
+        adn_y[nt] = s.y + (colptr[nt] - (dst ? a.y1 : a.y0));
+        adn_m[nt] = s.mean[(size_t)nb * cs + cl];
+        adn_r[nt] = s.rstd[(size_t)nb * cs + cl];
+        adn_ks[nt] = s.keep_scale;
+        adn_ap[nt] = s.act_p;
+        adn_act[nt] = s.act;
+        // element index, inside the batch item, of this lane's column in the brick's origin voxel
+        adn_e0[nt] = (unsigned)(row0 - (size_t)nb * a.Do * a.Ho * a.Wo) * (unsigned)cs + (unsigned)cl;
+        if (s.mask != nullptr) adn_mk[nt] = s.mask + (size_t)nb * s.groups * 8;
+      }
+    }
+  }
   bool stored = false;
   if constexpr (SPEC) {
     // interior brick, all columns valid: rows of an m-tile are 4 x-neighbours (r & 3) in 4
@@ -682,6 +732,52 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
           for (int nt = 0; nt < NT; ++nt) {
             float* p = colptr[nt] + (size_t)rbase * rowmul[nt];
             const unsigned dY = a.Wo * rowmul[nt], dX = rowmul[nt];
+            if constexpr (EPI == 1) {
+              if (adn_y[nt] != nullptr) {
+                // ---- dt and its two sums instead of dout (see ConvF16Extra::Adn) --------------
+                const float* yp = adn_y[nt] + (size_t)rbase * rowmul[nt];
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = yp[(r >> 2) * dY + (r & 3) * dX];
+                unsigned kw[16];
+                const unsigned ebase = adn_e0[nt] + rbase * (unsigned)rowmul[nt];
+                if (adn_mk[nt] != nullptr) {
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) {
+                    // element el of the item -> bit (el >> 2) & 63 of 64-bit word (el >> 8) * 4 + (el & 3)
+                    const unsigned el = ebase + (r >> 2) * dY + (r & 3) * dX;
+                    kw[r] = adn_mk[nt][((el >> 8) * 4u + (el & 3u)) * 2u + ((el >> 7) & 1u)];
+                  }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                  float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];
+                  if constexpr (has_res.value) v += resv[nt][r];
+                  const float hn = (yv[r] - adn_m[nt]) * adn_r[nt];
+                  bool keep = true;
+                  if (adn_mk[nt] != nullptr) {
+                    const unsigned el = ebase + (r >> 2) * dY + (r & 3) * dX;
+                    keep = (kw[r] >> ((el >> 2) & 31u)) & 1u;
+                  }
+                  const float u = keep ? hn * adn_ks[nt] : 0.f;
+                  float g = 1.f;
+                  if (adn_act[nt] == ADELL_ACT_SILU) {
+                    const float sg = adell_sigmoidf(u);
+                    g = sg * (1.0f + u * (1.0f - sg));
+                  } else if (adn_act[nt] == ADELL_ACT_RELU) {
+                    g = u > 0.f ? 1.f : 0.f;
+                  } else if (adn_act[nt] == ADELL_ACT_LEAKY_RELU) {
+                    g = u > 0.f ? 1.f : adn_ap[nt];
+                  }
+                  const float du = v * g;
+                  const float dt = keep ? du * adn_ks[nt] : 0.f;
+                  p[(r >> 2) * dY + (r & 3) * dX] = dt;
+                  s1[nt] += dt;
+                  s2[nt] += dt * hn;
+                }
+                continue;
+              }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               float v = acc[mt][nt][r] * oscale[nt] + bcol[nt];

@@ -231,6 +231,8 @@ struct NormActArgs {
   uint32_t seed_lo, seed_hi;
   uint32_t rng_offset;
   int vec;             // C % 4 == 0: float4 path covers everything
+  unsigned long long* mask;  // fast kernel: keep bits of the dropout (adell_norm_act_fwd_mask) or null
+  long groups;               // 256-element groups per batch item in `mask`
 };
 
 // hat = (x-mean)*rstd*gamma+beta ; u = dropout(hat) ; out = act(u)
@@ -363,13 +365,21 @@ static int adell_ew_blocks(long n4) {
   return (int)b;
 }
 
-extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
-                                  const float* mean, const float* rstd,
-                                  const float* gamma, const float* beta,
-                                  const float* act_w, float* out, void* stream) {
+extern "C" long adell_norm_act_mask_bytes(const adell_norm_act_desc* d) {
+  if (!d || d->N <= 0 || d->V <= 0 || d->C <= 0) return ADELL_E_BADARG;
+  return d->N * ((d->V * d->C + 255) / 256) * 32;
+}
+
+static int adell_norm_act_fwd_impl(const adell_norm_act_desc* d, const float* x,
+                                   const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta,
+                                   const float* act_w, float* out, void* keep_mask,
+                                   void* stream) {
   NormActArgs a = {};
   int rc = adell_na_fill(&a, d);
   if (rc != ADELL_OK) return rc;
+  a.mask = (unsigned long long*)keep_mask;
+  a.groups = (a.VC + 255) / 256;
   ADELL_REQUIRE(x && out, "norm_act_fwd: null pointer");
   ADELL_REQUIRE((mean == nullptr) == (rstd == nullptr), "norm_act_fwd: mean/rstd mismatch");
   ADELL_REQUIRE(d->C % 4 == 0 || a.total < (1L << 31),
@@ -386,11 +396,32 @@ extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
     ADELL_CHECK_HIP(hipGetLastError());
     return ADELL_OK;
   }
+  if (keep_mask != nullptr) {
+    adell_set_error("norm_act_fwd_mask: needs a power-of-two C <= 1024 and 16-byte aligned tensors");
+    return ADELL_E_UNSUPPORTED;
+  }
   hipLaunchKernelGGL(adell_norm_act_fwd_kernel,
                      dim3(adell_ew_blocks(a.vec ? (a.total >> 2) : a.total)), dim3(256), 0,
                      (hipStream_t)stream, a);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
+}
+
+extern "C" int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
+                                  const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta,
+                                  const float* act_w, float* out, void* stream) {
+  return adell_norm_act_fwd_impl(d, x, mean, rstd, gamma, beta, act_w, out, nullptr, stream);
+}
+
+extern "C" int adell_norm_act_fwd_mask(const adell_norm_act_desc* d, const float* x,
+                                       const float* mean, const float* rstd,
+                                       const float* gamma, const float* beta,
+                                       const float* act_w, float* out, void* keep_mask,
+                                       void* stream) {
+  ADELL_REQUIRE(d && (d->drop_p == 0.f || keep_mask), "norm_act_fwd_mask: null mask");
+  return adell_norm_act_fwd_impl(d, x, mean, rstd, gamma, beta, act_w, out,
+                                 d->drop_p > 0.f ? keep_mask : nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -570,9 +601,12 @@ __global__ __launch_bounds__(1024) void adell_na_bwd_finalize_kernel(
 // The per-item case without affine-parameter gradients (every InstanceNorm of the U-Nets): one
 // block per (8 channels, item) instead of one block walking all items (15 us -> a few us, 35 times
 // per training step). Same fixed-order fp64 fold: tile lanes, then a tree over the 32 lanes.
+// (pstride / poff: the partials of a site may be columns [poff, poff + C) of rows pstride wide --
+// what the fused backward-data epilogue of a two-destination conv writes)
 __global__ __launch_bounds__(256) void adell_na_bwd_finalize_item_kernel(
     const float* __restrict__ part, int ntiles, int C, double count,
-    const float* __restrict__ gamma, float* __restrict__ c1, float* __restrict__ c2) {
+    const float* __restrict__ gamma, float* __restrict__ c1, float* __restrict__ c2,
+    int pstride, int poff) {
   __shared__ double sh[32][8][2];
   const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl, n = blockIdx.y;
@@ -580,14 +614,16 @@ __global__ __launch_bounds__(256) void adell_na_bwd_finalize_item_kernel(
   if (c < C) {
     int t = sl;
     for (; t + 32 < ntiles; t += 64) {
-      const float2 u = *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
-      const float2 v =
-          *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t + 32) * C + c) * 2);
+      const float2 u =
+          *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * pstride + poff + c) * 2);
+      const float2 v = *reinterpret_cast<const float2*>(
+          part + (((size_t)n * ntiles + t + 32) * pstride + poff + c) * 2);
       a0 += (double)u.x; b0 += (double)u.y;
       a1 += (double)v.x; b1 += (double)v.y;
     }
     for (; t < ntiles; t += 32) {
-      const float2 u = *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
+      const float2 u =
+          *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * pstride + poff + c) * 2);
       a0 += (double)u.x; b0 += (double)u.y;
     }
   }
@@ -727,7 +763,7 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
     if (d->stats_per_item && !dgamma && !dbeta && d->N <= 65535)
       hipLaunchKernelGGL(adell_na_bwd_finalize_item_kernel,
                          dim3(adell_cdiv(d->C, 8), (unsigned)d->N), dim3(256), 0, st,
-                         (const float*)part, a.ntiles, d->C, (double)d->V, gamma, c1, c2);
+                         (const float*)part, a.ntiles, d->C, (double)d->V, gamma, c1, c2, d->C, 0);
     else
       hipLaunchKernelGGL(adell_na_bwd_finalize_kernel, dim3(adell_cdiv(d->C, 32)), dim3(1024), 0,
                          st, (const float*)part, (int)d->N, a.ntiles, d->C, (double)d->V,
@@ -807,16 +843,29 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
                                       a.seed_lo, a.seed_hi);
         rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
       }
+      bool kept[4] = {true, true, true, true};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float t = ((h[q] - k.m[q]) * k.r[q]) * k.g[q] + k.b[q];
         if (a.drop_p > 0.f) {
           const float uu = (float)(rr[q] >> 8) * (1.0f / 16777216.0f);
-          t = (uu >= a.drop_p) ? t * keep_scale : 0.f;
+          kept[q] = uu >= a.drop_p;
+          t = kept[q] ? t * keep_scale : 0.f;
         }
         h[q] = adell_act_fwd(ACT, t, k.p[q]);
       }
       yout[jj] = make_float4(h[0], h[1], h[2], h[3]);
+      if (a.mask != nullptr) {
+        // the 64 lanes of a wave hold 64 consecutive float4 = one 256-element group: word q of
+        // the group = the keep bits of sub-element q, bit = lane (lanes past the end: 0)
+        unsigned long long b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = __ballot(kept[q]);
+        const int ln = threadIdx.x & 63;
+        if (ln < 4)
+          a.mask[((long)n * a.groups + (jj >> 6)) * 4 + ln] =
+              ln == 0 ? b[0] : (ln == 1 ? b[1] : (ln == 2 ? b[2] : b[3]));
+      }
     }
   }
 }
@@ -934,6 +983,81 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
   }
 }
 
+
+// Second half of a site's backward when dout already carries the activation / dropout derivative
+// (dt, written by the fused backward-data epilogue of conv_igemm_f16.h):
+//   dx = rstd * (dt - c1 - xhat * c2),  xhat = (x - mean) * rstd
+// -- no transcendental, no Philox: reads x and dt once, writes dx once (dx may alias dt).
+__global__ __launch_bounds__(256) void adell_na_bwd_apply_dt_kernel(NormActBwdArgs a) {
+  const int n = blockIdx.y;
+  const long n4 = a.VC >> 2;
+  ADELL_EW_RANGE(n4);
+  const int c = (int)((j0 << 2) & (a.C - 1));
+  NaConst k;
+  adell_na_consts(k, a.mean, a.rstd, nullptr, nullptr, nullptr, 0, 0.f, a.c1, a.c2,
+                  (long)n * a.stat_stride_n, c);
+  const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
+  const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
+  float4* dxo = reinterpret_cast<float4*>(a.dx) + (long)n * n4;
+  for (long j = j0; j < jend; j += stride * ADELL_EW_UNROLL) {
+    float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u)
+      if (j + u * stride < jend) {
+        xv[u] = xin[j + u * stride];
+        gv[u] = gin[j + u * stride];
+      }
+#pragma unroll
+    for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
+      const long jj = j + u * stride;
+      if (jj >= jend) break;
+      const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+      const float gs[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float hn = (xs[q] - k.m[q]) * k.r[q];
+        o[q] = k.r[q] * (gs[q] - k.c1[q] - hn * k.c2[q]);
+      }
+      dxo[jj] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+extern "C" int adell_norm_act_bwd_from_dt(const adell_norm_act_desc* d, const float* x,
+                                          const float* dt, const float* mean, const float* rstd,
+                                          const float* partials, int ntiles, int pstride, int poff,
+                                          float* dx, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  NormActBwdArgs a = {};
+  int rc = adell_nab_fill(&a, d);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(x && dt && dx && mean && rstd && partials && workspace,
+                "norm_act_bwd_from_dt: null pointer");
+  ADELL_REQUIRE(d->stats_per_item == 1 && d->N <= 65535,
+                "norm_act_bwd_from_dt: instance statistics only");
+  ADELL_REQUIRE(ntiles > 0 && pstride >= d->C && poff >= 0 && poff + d->C <= pstride,
+                "norm_act_bwd_from_dt: bad partials layout");
+  ADELL_REQUIRE(adell_is_pow2(d->C) && d->C % 4 == 0 && d->C <= 1024 &&
+                    (((uintptr_t)x | (uintptr_t)dt | (uintptr_t)dx) & 15) == 0,
+                "norm_act_bwd_from_dt: needs a power-of-two C in 4..1024 and aligned tensors");
+  ADELL_REQUIRE(workspace_bytes >= sizeof(float) * 2 * (size_t)d->N * d->C,
+                "norm_act_bwd_from_dt: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float* c1 = (float*)workspace;
+  float* c2 = c1 + (size_t)d->N * d->C;
+  hipLaunchKernelGGL(adell_na_bwd_finalize_item_kernel, dim3(adell_cdiv(d->C, 8), (unsigned)d->N),
+                     dim3(256), 0, st, partials, ntiles, d->C, (double)d->V, (const float*)nullptr,
+                     c1, c2, pstride, poff);
+  a.x = x; a.dout = dt; a.mean = mean; a.rstd = rstd; a.c1 = c1; a.c2 = c2; a.dx = dx;
+  long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
+  if (bx > ADELL_EW_MAXBLOCKS) bx = ADELL_EW_MAXBLOCKS;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(adell_na_bwd_apply_dt_kernel, dim3((unsigned)bx, (unsigned)d->N), dim3(256), 0,
+                     st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
 
 // ---------------------------------------------------------------------------
 // PReLU weight gradient (torch.nn.PReLU, the reference's default activation_fn:

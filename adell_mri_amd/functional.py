@@ -31,7 +31,9 @@ CONV_PRECISION = os.environ.get("ADELL_CONV_PRECISION", "f16x3")
 # of the x taps of <= 4-channel inputs into the 16-channel MFMA chunk
 FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_s2class": bool(os.environ.get("ADELL_NO_S2CLASS")),
-         "no_fold": bool(os.environ.get("ADELL_NO_FOLD"))}
+         "no_fold": bool(os.environ.get("ADELL_NO_FOLD")),
+         # norm / dropout / activation backward left to its own two passes (no fused epilogue)
+         "no_adn_fuse": bool(os.environ.get("ADELL_NO_ADN_FUSE"))}
 
 
 def set_conv_precision(mode):
@@ -200,7 +202,7 @@ class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         (stride, padding, want_stats, wref, ctx.carry_in, ctx.carry_out, ctx.carry_x0,
-         ctx.carry_cat) = conf
+         ctx.carry_cat, ctx.adn) = conf
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
         # the statistics partials are a non-differentiable by-product: without this autograd
         # materialises a zero gradient for them in every backward (a 2 MB fill per conv site)
@@ -271,8 +273,9 @@ class _Conv3dFn(torch.autograd.Function):
         x0, x1, weight = ctx.saved_tensors
         k, stride, padding, has_bias, has_res, wref = ctx.conf
         need = ctx.needs_input_grad
-        if dy is None:   # the output took no part in the loss
-            return None, None, None, None, None, None, None
+        if dy is None:   # the output took no part in the loss: only a parked gradient passes through
+            add0 = ctx.carry_in.take() if ctx.carry_in is not None else None
+            return (add0 if need[0] else None), None, None, None, None, None, None
         dy = ops.ndhwc(dy)
         dx0 = dx1 = dw = db = dres = None
         add0 = ctx.carry_in.take() if ctx.carry_in is not None else None
@@ -321,6 +324,23 @@ class _Conv3dFn(torch.autograd.Function):
                                          tuple(x0.shape[2:]), C0, padding, amax=dy_amax,
                                          add0=add0)
             add0 = None
+        elif (ctx.adn is not None and need[0] and (x1 is None or need[1])
+              and (add0 is None or C1 == 0) and isinstance(_packed(wref.obj, 1), ops.SplitWeight)):
+            # the input(s) are outputs of norm -> dropout -> activation sites read by this conv
+            # only: their activation / dropout derivative and the two sums of the norm's backward
+            # come out of this kernel's epilogue (AdnSite)
+            site0, site1, ntiles = ctx.adn
+            wpb = _packed(wref.obj, 1)
+            if amax is not None:
+                dy_amax = amax[1:2]
+            dx0, dx1, part = ops.conv3d_bwd_data_adn(dy, wpb, tuple(x0.shape[2:]), C0, C1, k,
+                                                     stride, padding, ntiles, site0=site0,
+                                                     site1=site1, amax=dy_amax, add0=add0)
+            add0 = None
+            if site0 is not None:
+                site0.fused, site0.part, site0.poff = True, part, 0
+            if site1 is not None:
+                site1.fused, site1.part, site1.poff = True, part, C0
         elif need[0] or (x1 is not None and need[1]):
             wpb = _packed(wref.obj, 1)
             if amax is not None and isinstance(wpb, ops.SplitWeight):
@@ -368,6 +388,15 @@ def _park_input_grads(ctx, dx0, dx1):
     return dx0, dx1
 
 
+def grad_observed(t):
+    """True when someone watches the gradient of ``t`` (tensor hooks, ``retain_grad()``): a
+    GradCarry routes part of that gradient around autograd, so the watcher would see a partial
+    value -- callers then leave the fork to autograd's own accumulation. ``ADELL_NO_GRAD_CARRY=1``
+    switches the carries off altogether (gradient-inspection tools, partial
+    ``torch.autograd.grad(inputs=...)`` calls that run the parking conv but not the taking one)."""
+    return bool(getattr(t, "_backward_hooks", None)) or bool(getattr(t, "retains_grad", False))
+
+
 class GradCarry:
     """Hands a gradient from one consumer of a tensor to another consumer of the SAME tensor whose
     backward runs later and whose backward-data kernel adds it in its epilogue -- one full-size
@@ -390,12 +419,64 @@ class GradCarry:
         return g
 
 
+class AdnSite:
+    """A norm -> dropout -> activation site as the backward-data kernel of its consumer needs it
+    (ops.conv3d_bwd_data_adn): the site's input ``x``, its instance statistics, the keep bits its
+    forward stored and the activation. The consumer's backward sets ``fused`` / ``part`` / ``poff``
+    when its epilogue produced dt and the partial sums; the site's own backward then runs ONE
+    elementwise pass (ops.norm_act_bwd_from_dt) instead of two."""
+
+    __slots__ = ("x", "mean", "rstd", "mask", "drop_p", "act", "act_p", "fused", "part", "poff")
+
+    def __init__(self, x, mean, rstd, mask, drop_p, act, act_p):
+        self.x, self.mean, self.rstd, self.mask = x, mean, rstd, mask
+        self.drop_p, self.act, self.act_p = drop_p, act, act_p
+        self.fused, self.part, self.poff = False, None, 0
+
+
+def single_use(t):
+    """Module code declares: the next ``conv3d`` that reads ``t`` (as x0 or x1) is the ONLY
+    consumer of ``t``. Only then may that conv's backward-data kernel hand the site behind ``t``
+    a pre-multiplied gradient (AdnSite): a second consumer would add a plain gradient to it."""
+    if t is not None and getattr(t, "_adell_site", None) is not None:
+        t._adell_single = True
+    return t
+
+
+_ADN_PLAN = {}
+
+
+def _adn_sites_of(x0, x1, weight, stride, padding):
+    """(site0, site1, ntiles) when x0 / x1 carry single-use ADN sites and the backward-data
+    launch of this conv takes the fused epilogue, else None."""
+    s0 = getattr(x0, "_adell_site", None) if getattr(x0, "_adell_single", False) else None
+    s1 = (getattr(x1, "_adell_site", None)
+          if x1 is not None and getattr(x1, "_adell_single", False) else None)
+    if (s0 is None and s1 is None) or CONV_PRECISION != "f16x3" or FLAGS["no_adn_fuse"] \
+            or weight.dim() != 5 or not torch.is_grad_enabled():
+        return None
+    C0 = x0.shape[1]
+    C1 = 0 if x1 is None else x1.shape[1]
+    key = (tuple(x0.shape), C1, tuple(weight.shape), stride, padding)
+    nt = _ADN_PLAN.get(key)
+    if nt is None:
+        nt = ops.conv3d_bwd_data_adn_ntiles(tuple(x0.shape[2:]), x0.shape[0], C0, C1,
+                                            weight.shape[0], tuple(weight.shape[2:]), stride,
+                                            padding)
+        _ADN_PLAN[key] = nt
+    if nt <= 0:
+        return None
+    return (s0, s1, nt)
+
+
 def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True,
            carry_in=None, carry_out=None, carry_x0=None, carry_cat=None):
     """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual). ``carry_in`` /
     ``carry_out`` / ``carry_x0`` / ``carry_cat``: see GradCarry."""
     stride, padding = ops._triple(stride), ops._triple(padding)
-    conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out, carry_x0, carry_cat)
+    adn = _adn_sites_of(x0, x1, weight, stride, padding)
+    conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out, carry_x0, carry_cat,
+            adn)
     Cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
     small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
     if small1:
@@ -464,10 +545,16 @@ conv_transpose3d_k2s2 = conv_transpose3d
 class _NormDropActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mean, rstd, gamma, beta, act_w, conf):
-        act, act_p, per_item, drop_p, seed, offset = conf
-        out = ops.norm_act_fwd(x, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w,
-                               act_p=act_p, stats_per_item=per_item, drop_p=drop_p, seed=seed,
-                               rng_offset=offset)
+        act, act_p, per_item, drop_p, seed, offset, site = conf
+        if site is not None:
+            out, mask = ops.norm_act_fwd(x, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w,
+                                         act_p=act_p, stats_per_item=per_item, drop_p=drop_p,
+                                         seed=seed, rng_offset=offset, want_mask=True)
+            site.x, site.mean, site.rstd, site.mask = x, mean, rstd, mask
+        else:
+            out = ops.norm_act_fwd(x, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w,
+                                   act_p=act_p, stats_per_item=per_item, drop_p=drop_p, seed=seed,
+                                   rng_offset=offset)
         ctx.save_for_backward(x, mean, rstd, gamma, beta, act_w)
         ctx.conf = conf
         return out
@@ -475,7 +562,15 @@ class _NormDropActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, mean, rstd, gamma, beta, act_w = ctx.saved_tensors
-        act, act_p, per_item, drop_p, seed, offset = ctx.conf
+        act, act_p, per_item, drop_p, seed, offset, site = ctx.conf
+        if site is not None:
+            fused, part, poff = site.fused, site.part, site.poff
+            site.fused, site.part = False, None
+            if fused:
+                # dout is dt: the consumer's backward-data epilogue applied act' / dropout and
+                # left the two sums of the normalisation's backward in `part`
+                dx = ops.norm_act_bwd_from_dt(x, ops.ndhwc(dout), mean, rstd, part, poff)
+                return dx, None, None, None, None, None, None
         dact_w = None
         if act_w is not None and ctx.needs_input_grad[5]:
             dact_w = ops.prelu_wgrad(x, dout, mean, rstd, act_w, gamma=gamma, beta=beta,
@@ -540,8 +635,20 @@ def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=No
     if p > 0.0:
         seed = torch.initial_seed()
         offset = next(_dropout_counter)
-    conf = (act, float(act_p), per_item, p, seed, offset)
-    return _NormDropActFn.apply(x, mean, rstd, gamma, beta, act_w, conf)
+    # a site whose only consumer is a conv can leave half of its backward to that conv's
+    # backward-data kernel (AdnSite): instance statistics, no affine parameters, an activation the
+    # epilogue knows; the forward then also stores its keep bits
+    site = None
+    if (norm == "instance" and gamma is None and beta is None and act_w is None
+            and act in ("identity", "swish", "silu", "relu", "leaky_relu") and x.requires_grad
+            and torch.is_grad_enabled() and not FLAGS["no_adn_fuse"] and CONV_PRECISION == "f16x3"
+            and ops.norm_act_mask_ok(x)):
+        site = AdnSite(None, None, None, None, p, act, float(act_p))
+    conf = (act, float(act_p), per_item, p, seed, offset, site)
+    out = _NormDropActFn.apply(x, mean, rstd, gamma, beta, act_w, conf)
+    if site is not None:
+        out._adell_site = site
+    return out
 
 
 # ---- token-sequence functions (ViT encoder of UNETR) -------------------------------------

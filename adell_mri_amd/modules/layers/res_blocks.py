@@ -9,6 +9,7 @@ import torch
 
 from ... import functional as HF
 from ... import ops
+from .adn_fn import ActDropNorm
 from .conv import Conv2d, Conv3d
 from .linear_blocks import LayerNorm as RowLayerNorm
 from .linear_blocks import Linear
@@ -53,10 +54,14 @@ class ResidualBlock3d(torch.nn.Module):
         # the link's gradient rides the head conv's backward-data epilogue (functional.GradCarry)
         carry = (HF.GradCarry() if (self._conv is Conv3d and X.requires_grad
                                     and torch.is_grad_enabled()
-                                    and not ops.FLAGS["no_grad_carry"]) else None)
+                                    and not ops.FLAGS["no_grad_carry"]
+                                    and not HF.grad_observed(X)) else None)
         h = mods[0](X, carry_in=carry, carry_x0=fork) if carry is not None else mods[0](X)
-        for mod in mods[1:-1]:
+        for i, mod in enumerate(mods[1:-1], 1):
             h = mod(h)
+            # an ADN output read by the next conv only (functional.single_use)
+            if isinstance(mod, ActDropNorm) and type(mods[i + 1]) is self._conv and h.dim() == 5:
+                h = HF.single_use(h)
         out = self.final_op(mods[-1](h, residual=X, carry_out=carry) if carry is not None
                             else mods[-1](h, residual=X))
         skip = skip_activation if skip_activation is not None else self.skip_activation

@@ -46,9 +46,18 @@ class ConcatConvBlock(torch.nn.Sequential):
             h = mods[0](X, X_cat=X_cat, carry_cat=carry_cat)
         else:
             h = mods[0](X, X_cat=X_cat) if X_cat is not None else mods[0](X)
-        for mod in mods[1:]:
-            h = mod(h)
-        return h
+        return _run_rest(mods[1:], h)
+
+
+def _run_rest(mods, h):
+    """The remaining modules of a Sequential in turn. An ADN output that goes straight into a
+    Conv3d has that conv as its only reader: functional.single_use lets the conv's backward-data
+    kernel take over half of the site's backward."""
+    for i, mod in enumerate(mods):
+        h = mod(h)
+        if isinstance(mod, ActDropNorm) and i + 1 < len(mods) and type(mods[i + 1]) is Conv3d:
+            h = HF.single_use(h)
+    return h
 
 
 def _takes_carry(module):
@@ -380,7 +389,8 @@ class UNet(torch.nn.Module):
             encoding_out.append(curr)
             fork, down = None, None
             if (curr.dim() == 5 and curr.requires_grad and torch.is_grad_enabled()
-                    and not ops.FLAGS["no_grad_carry"] and not ops.FLAGS["no_skip_fork"]):
+                    and not ops.FLAGS["no_grad_carry"] and not ops.FLAGS["no_skip_fork"]
+                    and not HF.grad_observed(curr)):
                 fork = HF.GradCarry()
                 down = _head_with_carry(downsample, curr, carry_in=fork)
             if down is None:
@@ -426,6 +436,10 @@ class UNet(torch.nn.Module):
             if fork is not None and encoded is encoding_out[-i - 2] and isinstance(op, _DecoderOp):
                 curr = op(curr, X_cat=encoded, carry_cat=fork)
             else:
+                # the link op's own output (not an encoder level: those fork) is read by the
+                # decoder conv alone
+                if not isinstance(link_op, torch.nn.Identity) and encoded is not encoding_out[-i - 2]:
+                    encoded = HF.single_use(encoded)
                 curr = op(curr, X_cat=encoded)
             deep_outputs.append(curr)
         return curr, deep_outputs
@@ -436,6 +450,8 @@ class UNet(torch.nn.Module):
         code closes BrUNet.forward, :1209-1253)."""
         curr, deep_outputs = self._run_decoder(encoding_out, bottleneck, X_skip_layer,
                                                X_feature_conditioning)
+        if return_features is not True and self.deep_supervision is not True:
+            curr = HF.single_use(curr)      # the head's first conv is its only reader
         head = self._final(self.final_layer, curr, return_logits)
         return self._outputs(head, curr, bottleneck, deep_outputs, return_features)
 

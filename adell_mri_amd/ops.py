@@ -516,6 +516,47 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, 
     return dx0, dx1
 
 
+def conv3d_bwd_data_adn_ntiles(in_size, N, C0, C1, Cout, kernel, stride, padding):
+    """Bricks per batch item when the backward-data of this conv takes the fused ADN epilogue
+    (adell_conv3d_bwd_data_f16x3_adn), else 0."""
+    d = make_conv_desc(N, tuple(in_size), C0, C1, Cout, kernel, stride, padding)
+    return int(_lib.lib().adell_conv3d_bwd_data_f16x3_adn_ntiles(ctypes.byref(d)))
+
+
+def _adn_site_struct(site):
+    if site is None:
+        return None
+    return _lib.AdnSite(_ptr(site.x), _ptr(site.mean), _ptr(site.rstd), _ptr(site.mask),
+                        float(site.drop_p), float(site.act_p), ACT_IDS[site.act])
+
+
+def conv3d_bwd_data_adn(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, ntiles,
+                        site0=None, site1=None, amax=None, add0=None):
+    """Backward-data whose destinations are gradients of the outputs of norm -> dropout ->
+    activation sites (``site0`` for dx0, ``site1`` for dx1; objects with x, mean, rstd, mask,
+    drop_p, act, act_p): returns (dt0 or dx0, dt1 or dx1, partials [N, ntiles, C0 + C1, 2])."""
+    _require_cuda(dy, add0)
+    dy = ndhwc(dy)
+    N, Cout = dy.shape[:2]
+    d = make_conv_desc(N, tuple(in_size), C0, C1, Cout, kernel, stride, padding)
+    assert (d.Do, d.Ho, d.Wo) == tuple(dy.shape[2:])
+    if add0 is not None:
+        add0 = ndhwc(add0)
+    dx0 = new_act(N, C0, *in_size, dy.device)
+    dx1 = new_act(N, C1, *in_size, dy.device) if C1 > 0 else None
+    part = torch.empty((N, ntiles, C0 + C1, 2), device=dy.device, dtype=torch.float32)
+    s0, s1 = _adn_site_struct(site0), _adn_site_struct(site1)
+    extra = sum(4.0 * t.numel() for t, s in ((dx0, site0), (dx1, site1)) if s is not None)
+    check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
+                 lambda: _lib.lib().adell_conv3d_bwd_data_f16x3_adn(
+                     ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs), _ptr(w_packed_bwd.scale),
+                     _ptr(add0), _ptr(dx0), _ptr(dx1), _ptr(amax),
+                     None if s0 is None else ctypes.byref(s0),
+                     None if s1 is None else ctypes.byref(s1), _ptr(part), _stream()),
+                 _conv_tag(d, "dgrad"), _conv_bytes(d, add0 is not None) + extra))
+    return dx0, dx1, part
+
+
 def conv3d_bwd_data_s2(dy, class_weights, in_size, C0, padding, amax=None, add0=None):
     """Backward-data of a stride-2 k = 3 conv by parity classes; ``class_weights``: 8 SplitWeights
     (c = 4 pz + 2 py + px) of the sub-kernels packed with mode 1. ``add0`` (dX-shaped) is added in
@@ -799,18 +840,54 @@ def make_na_desc(x, act, stats_per_item=1, act_p=0.0, act_w_n=0, drop_p=0.0, see
                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_offset) & 0xFFFFFFFF)
 
 
+def norm_act_mask_ok(x):
+    """The forward can store its dropout keep bits (the bandwidth-tuned kernel runs: power-of-two
+    channel count, 16-byte aligned NDHWC tensor)."""
+    C = x.shape[1]
+    return x.dim() == 5 and C % 4 == 0 and C <= 1024 and (C & (C - 1)) == 0
+
+
 def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.0,
-                 stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0):
+                 stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0, want_mask=False):
+    """``want_mask`` (drop_p > 0): also returns the keep bits as an int64 tensor (1 bit per
+    element) for the fused backward (conv3d_bwd_data_adn)."""
     _require_cuda(x, mean, rstd, gamma, beta, act_w)
     x = ndhwc(x)
     d = make_na_desc(x, act, stats_per_item, act_p, 0 if act_w is None else act_w.numel(),
                      drop_p, seed, rng_offset)
     out = new_act(*x.shape, x.device)
+    mask = None
+    if want_mask and drop_p > 0.0:
+        nbytes = _lib.lib().adell_norm_act_mask_bytes(ctypes.byref(d))
+        if nbytes < 0:
+            check(int(nbytes))
+        mask = torch.empty((nbytes // 8,), device=x.device, dtype=torch.int64)
     # HBM-bound family of the roofline report: algorithmic bytes = read x + write out
-    check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_fwd(
-        ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(act_w),
-        _ptr(out), _stream()), "fwd", 8.0 * x.numel()))
-    return out
+    if mask is not None:
+        check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_fwd_mask(
+            ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(act_w),
+            _ptr(out), _ptr(mask), _stream()), "fwd", 8.0 * x.numel()))
+    else:
+        check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_fwd(
+            ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(act_w),
+            _ptr(out), _stream()), "fwd", 8.0 * x.numel()))
+    return (out, mask) if want_mask else out
+
+
+def norm_act_bwd_from_dt(x, dt, mean, rstd, partials, poff=0):
+    """dx of an instance-norm site from dt = dout * act'(u) * keep / (1 - p) and the per-brick
+    sums the fused backward-data epilogue left in ``partials`` [N, ntiles, pstride, 2] (the site's
+    channels at columns [poff, poff + C)). Written in place over ``dt``."""
+    _require_cuda(x, dt, mean, rstd, partials)
+    x, dt = ndhwc(x), ndhwc(dt)
+    d = make_na_desc(x, "identity", 1)
+    N, C = x.shape[:2]
+    ws = _workspace(8 * N * C, x.device)
+    check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_bwd_from_dt(
+        ctypes.byref(d), _ptr(x), _ptr(dt), _ptr(mean), _ptr(rstd), _ptr(partials),
+        int(partials.shape[1]), int(partials.shape[2]), int(poff), _ptr(dt), _ptr(ws),
+        ws.numel() * 4, _stream()), "bwd", 12.0 * x.numel()))
+    return dt
 
 
 def prelu_wgrad(x, dout, mean, rstd, act_w, gamma=None, beta=None, stats_per_item=1, drop_p=0.0,

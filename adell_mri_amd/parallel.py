@@ -165,7 +165,9 @@ class GradSync:
 
     def _wrap_zero_grad(self):
         """``optimizer.zero_grad()`` starts a new step: drop whatever an abandoned one left."""
-        inner = self.optimizer.zero_grad
+        inner = getattr(self.optimizer, "zero_grad", None)
+        if inner is None:
+            return
 
         def zero_grad(*args, **kwargs):
             self.reset()

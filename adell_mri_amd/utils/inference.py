@@ -133,7 +133,13 @@ class SlidingWindowSegmentation:
             yield self.extract_patch(X, coords), coords
 
     def extract_patch(self, X, coords):
+        """The window of every tensor of the structure; entries that are not tensors (file names,
+        metadata) are dropped, as the reference does (:562-599)."""
         index = (Ellipsis,) + tuple(slice(lo, hi) for lo, hi in coords)
+        if isinstance(X, dict):
+            return {k: v[index] for k, v in X.items() if isinstance(v, torch.Tensor)}
+        if isinstance(X, (tuple, list)):
+            return [v[index] for v in X if isinstance(v, torch.Tensor)]
         return _map(X, lambda t: t[index])
 
     def __call__(self, X, *args, **kwargs):

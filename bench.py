@@ -52,7 +52,9 @@ HBM_PEAK_TBS = 8.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100,
+                    help="timed steps (default 100: ~3.5 s of GPU work, long enough for a driver-side "
+                         "utilisation sampler to see the GPU busy)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--shape", type=str, default=None,
@@ -66,6 +68,8 @@ def parse_args():
                          "(1: every step; each event pair idles the stream ~6 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-MFMA secondary figure")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other north_star workloads (256x256x128 and batch-1 128^3)")
     ap.add_argument("--cpu-size", type=int, default=128,
                     help="edge of the volume the CPU oracle is timed on with all cores")
     return ap.parse_args()
@@ -323,11 +327,45 @@ def main():
                      "ms_per_step": 1e3 * dt32 / n32, "steps": n32,
                      "dtype": "f32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains)"}
 
+    # the other workloads north_star names, on the same module (every rank runs them: the gradient
+    # exchange inside a step is collective): 256 x 256 x 128 volumes and batch-1 128^3, 2 warm-up +
+    # 5 timed steps each with the dominant kernel family event-timed on every step
+    secondary = {}
+    if not args.no_secondary and args.shape is None and args.size == 128 and args.batch is None:
+        for key, sshape, sbatch in (("256x256x128_batch1", (256, 256, 128), 1),
+                                    ("128^3_batch1", (128, 128, 128), 1)):
+            sb = synthetic_batch(sbatch, sshape, device, 142 + rank)
+            for _ in range(2):
+                runner.train_step(sb)
+            barrier()
+            ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
+            sdt, _, sper = timed_steps(runner, sb, 5, barrier, timer=ops.KERNEL_TIMER, event_every=1)
+            stimer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+            sdt = reduce_max(sdt, device)
+            sec = {"value": sbatch * world * 5 / sdt, "unit": "volumes/s",
+                   "ms_per_step": 1e3 * sdt / 5, "median_ms_per_step": statistics.median(sper),
+                   "steps": 5, "warmup": 2, "per_gpu_batch": sbatch, "size": list(sshape)}
+            sdom = stimer.dominant()
+            if sdom is not None:
+                sname, sflops, sms, slaunches = sdom
+                speak = (F16X3_ALGORITHMIC_PEAK_TFLOPS if "f16" in sname else FP32_MFMA_PEAK_TFLOPS)
+                sec["roofline"] = {"bound": "mfma", "kernel": sname,
+                                   "achieved": sflops / (sms * 1e-3) / 1e12, "peak": speak,
+                                   "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / speak,
+                                   "launches": slaunches, "avg_launch_ms": sms / slaunches}
+            secondary[key] = sec
+            del sb
+        torch.cuda.empty_cache()
+
     if rank != 0:
         return
     vols = per_gpu_batch * world * args.steps
-    workload = (f"BASELINE configs[1]: u-net-3d-resnet.yaml U-Net, 2x{shape_str}, "
-                f"batch {per_gpu_batch}/GPU, {'+'.join(loss_keys)}, SGD-Nesterov")
+    yaml_name = os.path.basename(args.config)
+    opt_str = getattr(net, "optimizer_str", "sgd")
+    opt_desc = "SGD-Nesterov" if opt_str == "sgd" else opt_str
+    baseline_cfg = "BASELINE configs[1]: " if os.path.abspath(args.config) == CONFIG else ""
+    workload = (f"{baseline_cfg}{yaml_name} {type(net).__name__}, 2x{shape_str}, "
+                f"batch {per_gpu_batch}/GPU, {'+'.join(loss_keys)}, {opt_desc}")
     out = {
         "metric": f"volumes/sec 3D U-Net {shape_str} 2-ch seg (train step: fwd+loss+bwd+SGD)",
         "value": vols / dt, "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
@@ -350,6 +388,8 @@ def main():
         out["value_median"] = per_gpu_batch * world / (med * 1e-3)
     if fp32_line is not None:
         out["fp32_mfma"] = fp32_line
+    if secondary:
+        out["secondary"] = secondary
     dom = timer.dominant()
     if dom is not None:
         name, flops, ms, launches = dom

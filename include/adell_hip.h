@@ -177,6 +177,30 @@ int adell_conv3d_bwd_data_f16x3_add(const adell_conv3d_desc* d, const float* dy,
                                     const float* add0, float* dx0, uint32_t* dy_absmax,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Backward-data fused with the backward of the norm -> dropout -> activation site(s) whose OUTPUT
+ * the destination(s) are gradients of (reference: the autograd chain Conv3d <- activation <- Dropout
+ * <- InstanceNorm3d of adn_fn.py:140-152 feeding unet.py:260-273 / res_blocks.py:150-178). site0 /
+ * site1 describe the sites behind dx0 / dx1 (NULL: plain destination); their destinations receive
+ *   dt = dout * act'(u) * keep / (1 - p),   u = dropout((y - mean) * rstd)
+ * instead of dout, and `partials` ([N][ntiles][C0 + C1][2]) the per-brick sums (sum dt, sum dt xhat)
+ * that adell_norm_act_bwd_from_dt folds. ntiles = adell_conv3d_bwd_data_f16x3_adn_ntiles(d); 0 means
+ * the problem does not take the fused epilogue (the caller then uses the plain entry points). */
+typedef struct adell_adn_site {
+  const float* y;         /* the site's input, [N][D][H][W][C] like the destination */
+  const float* mean;      /* [N][C] instance statistics of y */
+  const float* rstd;
+  const void* keep_mask;  /* keep bits written by adell_norm_act_fwd_mask; NULL iff drop_p == 0 */
+  float drop_p;
+  float act_p;            /* LeakyReLU slope */
+  int32_t act;            /* ADELL_ACT_IDENTITY / _SILU / _RELU / _LEAKY_RELU */
+} adell_adn_site;
+int adell_conv3d_bwd_data_f16x3_adn_ntiles(const adell_conv3d_desc* d);
+int adell_conv3d_bwd_data_f16x3_adn(const adell_conv3d_desc* d, const float* dy,
+                                    const void* w_split_bwd, const float* wscale,
+                                    const float* add0, float* dx0, float* dx1,
+                                    uint32_t* dy_absmax, const adell_adn_site* site0,
+                                    const adell_adn_site* site1, float* partials, void* stream);
+
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
  * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias
  * gradient db[Cout] = sum over voxels of dy from the same pass. workspace:
@@ -280,6 +304,24 @@ int adell_norm_act_fwd(const adell_norm_act_desc* d, const float* x,
                        const float* mean, const float* rstd, const float* gamma,
                        const float* beta, const float* act_w, float* out,
                        void* stream);
+
+/* The same, also writing the dropout keep bits (drop_p > 0): element el of batch item n is bit
+ * (el >> 2) & 63 of 64-bit word (n * groups + (el >> 8)) * 4 + (el & 3), groups = ceil(V C / 256);
+ * adell_norm_act_mask_bytes(d) bytes. Needs C % 4 == 0 and a power-of-two C <= 1024 (returns
+ * ADELL_E_UNSUPPORTED otherwise: the caller then keeps the regenerating backward). */
+long adell_norm_act_mask_bytes(const adell_norm_act_desc* d);
+int adell_norm_act_fwd_mask(const adell_norm_act_desc* d, const float* x, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta,
+                            const float* act_w, float* out, void* keep_mask, void* stream);
+/* Second half of the site's backward when the producer of dout already applied the activation /
+ * dropout derivative (adell_conv3d_bwd_data_f16x3_adn): dx = rstd * (dt - c1 - xhat * c2) with
+ * c1 / c2 the means of the partial sums. partials: [N][ntiles][pstride][2], the site's channels
+ * at columns [poff, poff + C). dx may alias dt. Instance statistics, no affine parameters.
+ * workspace: 2 * N * C floats. */
+int adell_norm_act_bwd_from_dt(const adell_norm_act_desc* d, const float* x, const float* dt,
+                               const float* mean, const float* rstd, const float* partials,
+                               int ntiles, int pstride, int poff, float* dx, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* dx (and optionally dgamma / dbeta [C]) of adell_norm_act_fwd; the dropout
  * mask is regenerated from (seed, rng_offset). workspace >=

@@ -3,9 +3,11 @@ inference arithmetic, used to check `adell_mri_amd/utils/inference.py`.
 
 Follows `adell_mri/utils/inference.py`: window enumeration and edge adjustment :439-457 and
 :633-668, sum / denominator accumulation :690-724, final division :783, flip averaging :382-391.
-The reference module imports MONAI at the top (`:11`), which is not installed here, so it cannot
-be imported; its own tests (`testing/test_segmentation_inference_pl.py:21-52`) pin the identity
-round trip, shapes and value range, which tests/test_inference.py repeats on both implementations.
+PINNED (round 3): tests/golden/inference_ops.npz holds outputs of the REAL reference operators
+(oracle/make_golden_inference.py: the module imports with a stub `monai.data.meta_tensor`, its only
+MONAI use being `isinstance(x, MetaTensor)`); tests/test_inference.py checks this restatement and the
+mirror against them. The reference's own tests (`testing/test_segmentation_inference_pl.py:21-52`:
+identity round trip, shapes, value range) are repeated there on both implementations as well.
 """
 import numpy as np
 

@@ -119,3 +119,48 @@ SEMISL_CASES = {
                           dropout_param=0.0, activation_fn="swish", in_channels=1, n_classes=2,
                           depth=[8, 16], kernel_sizes=[3] * 2, strides=[2] * 2),
 }
+
+
+# ---- whole-volume inference operators (utils/inference.py:262-990) ---------------------------------
+def inference_net(n_out):
+    """A closed-form 'network' for the inference fixtures (tests/golden/inference_ops.npz, written
+    by oracle/make_golden_inference.py from the REAL reference operators): it depends on the
+    position inside the patch (ramps) and on the patch as a whole (its mean), so overlapping,
+    edge-adjusted and flipped windows all give different values. Takes a tensor or a dict with
+    "image"; [B, C, *spatial] -> [B, n_out, *spatial]."""
+    import torch
+
+    def net(X):
+        x = X["image"] if isinstance(X, dict) else X
+        nd = x.dim() - 2
+        ramp = 0.0
+        for a in range(nd):
+            shape = [1] * x.dim()
+            shape[2 + a] = x.shape[2 + a]
+            ramp = ramp + (a + 1) * torch.linspace(0.0, 1.0, x.shape[2 + a]).view(shape)
+        mean = x.mean(dim=tuple(range(1, x.dim())), keepdim=True)
+        s = x.sum(1, keepdim=True)
+        return torch.cat([torch.sigmoid(0.5 * (k + 1) * s + 0.3 * ramp - mean)
+                          for k in range(n_out)], 1)
+
+    return net
+
+
+INFERENCE_CASES = {
+    # name: (input shape, kind, arguments)
+    "sw3d_ragged_b1": ((1, 2, 20, 18, 14), "sliding", dict(window=(8, 8, 8), stride=(5, 6, 4),
+                                                          n_classes=1, batch=1)),
+    "sw3d_ragged_b3": ((1, 2, 20, 18, 14), "sliding", dict(window=(8, 8, 8), stride=(5, 6, 4),
+                                                          n_classes=1, batch=3)),
+    "sw3d_dict_2class": ((1, 3, 17, 16, 12), "sliding", dict(window=(8, 8, 8), stride=(6, 8, 5),
+                                                            n_classes=2, batch=2, as_dict=True)),
+    "sw3d_default_stride": ((1, 1, 16, 24, 16), "sliding", dict(window=(8, 8, 8), stride=None,
+                                                               n_classes=1, batch=4)),
+    "sw2d_overlap": ((1, 1, 30, 26), "sliding", dict(window=(16, 16), stride=(8, 8), n_classes=1,
+                                                    batch=1)),
+    "flip_tensor": ((1, 2, 6, 7, 8), "flip", dict(flips=[(2,), (4,), (2, 3)], n_out=1)),
+    "flip_dict_keys": ((1, 2, 6, 7, 8), "flip", dict(flips=[(2,), (3, 4)], n_out=2, as_dict=True,
+                                                   flip_keys=["image"])),
+    "seg_inference_flip": ((1, 2, 20, 18, 14), "segmentation",
+                           dict(window=[8, 8, 8], stride=0.5, n_classes=2, batch=2, flip=True)),
+}

@@ -1,0 +1,156 @@
+"""Backward of a norm -> dropout -> activation site fused into the backward-data kernel of the conv
+that reads it (adn_fn.py:140-152 feeding unet.py:260-273 / res_blocks.py:150-178): the epilogue of
+adell_conv3d_bwd_data_f16x3_adn stores dt = dout * act'(u) * keep / (1 - p) and the two per-channel
+sums, adell_norm_act_bwd_from_dt finishes the site. Checked against the unfused kernels (backward-
+data, then the two-pass site backward with the regenerated Philox mask) and, through a module, against
+torch autograd on the CPU."""
+import itertools
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+class _Site:
+    def __init__(self, x, mean, rstd, mask, drop_p, act, act_p=0.0):
+        self.x, self.mean, self.rstd, self.mask = x, mean, rstd, mask
+        self.drop_p, self.act, self.act_p = drop_p, act, act_p
+
+
+def _site(cuda, g, n, c, size, act, p, seed):
+    from adell_mri_amd import ops
+
+    y = ops.ndhwc((torch.randn(n, c, *size, generator=g) * 1.7 + 0.3).to(cuda))
+    mean, rstd = ops.instance_stats(y)
+    out, mask = ops.norm_act_fwd(y, mean, rstd, act, act_p=0.2 if act == "leaky_relu" else 0.0,
+                                 drop_p=p, seed=seed, rng_offset=7, want_mask=True)
+    return _Site(y, mean, rstd, mask, p, act, 0.2 if act == "leaky_relu" else 0.0), out
+
+
+@pytest.mark.parametrize("n,c0,c1,cout,size", [(2, 32, 0, 32, (16, 16, 16)),     # 8x8x8 bricks
+                                               (2, 32, 0, 48, (32, 32, 32)),     # 8x8x4 bricks
+                                               (1, 64, 0, 32, (64, 64, 32)),     # 64-column tile
+                                               (1, 32, 32, 64, (32, 64, 64))])   # two destinations
+@pytest.mark.parametrize("act,p", [("swish", 0.15), ("relu", 0.0), ("leaky_relu", 0.3),
+                                   ("identity", 0.5)])
+def test_fused_epilogue_equals_the_two_pass_backward(cuda, n, c0, c1, cout, size, act, p):
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(c0 + 3 * c1 + cout)
+    k, st, pad = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    nt = ops.conv3d_bwd_data_adn_ntiles(size, n, c0, c1, cout, k, st, pad)
+    assert nt > 0, "this shape must take the fused epilogue"
+    w = (torch.randn(cout, c0 + c1, 3, 3, 3, generator=g) * 0.05).to(cuda)
+    wpb = HF._packed(w, 1)
+    dy = ops.ndhwc(torch.randn(n, cout, *size, generator=g).to(cuda))
+    s0, _ = _site(cuda, g, n, c0, size, act, p, 11)
+    s1 = _site(cuda, g, n, c1, size, act, p, 12)[0] if c1 else None
+    add0 = ops.ndhwc(torch.randn(n, c0, *size, generator=g).to(cuda)) if c1 == 0 else None
+
+    for first_only in ((False, True) if c1 else (False,)):
+        sites = (None, s1) if first_only else (s0, s1)       # a plain first destination as well
+        dt0, dt1, part = ops.conv3d_bwd_data_adn(dy, wpb, size, c0, c1, k, st, pad, nt,
+                                                 site0=sites[0], site1=sites[1], add0=add0)
+        da0, da1 = ops.conv3d_bwd_data(dy, wpb, size, c0, c1, k, st, pad)
+        if add0 is not None:
+            da0 = da0 + add0
+        for site, dt, da, poff in ((sites[0], dt0, da0, 0), (sites[1], dt1, da1, c0)):
+            if site is None:
+                if da is not None:
+                    assert _rel(dt, da) <= 2e-6       # plain destination: the gradient itself
+                continue
+            want, _, _ = ops.norm_act_bwd(site.x, da, site.mean, site.rstd, site.act,
+                                          act_p=site.act_p, drop_p=p,
+                                          seed=11 if site is s0 else 12, rng_offset=7)
+            got = ops.norm_act_bwd_from_dt(site.x, dt, site.mean, site.rstd, part, poff)
+            assert _rel(got, want) <= 2e-5, (act, p, poff)
+
+
+def test_keep_bits_are_the_forward_mask(cuda):
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x = ops.ndhwc((torch.rand(2, 32, 8, 8, 12, generator=g) + 0.5).to(cuda))     # never zero
+    out, mask = ops.norm_act_fwd(x, None, None, "identity", drop_p=0.3, seed=3, rng_offset=2,
+                                 want_mask=True)
+    kept = (out.permute(0, 2, 3, 4, 1).reshape(2, -1) != 0).cpu()               # [N, V * C]
+    words = mask.cpu().view(2, -1, 4)                                           # [N, groups, 4]
+    el = torch.arange(kept.shape[1])
+    bits = (words[:, el >> 8, el & 3] >> ((el >> 2) & 63)) & 1
+    assert torch.equal(bits.bool(), kept)
+    assert 0.25 < 1.0 - kept.float().mean().item() < 0.35
+
+
+def _block(cuda, c, act="swish", p=0.15):
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.layers.res_blocks import ResidualBlock3d
+
+    torch.manual_seed(1)
+    return ResidualBlock3d(c, 3, out_channels=c,
+                           adn_fn=get_adn_fn(3, "instance", act, p)).to(cuda).train()
+
+
+def _run_block(blk, x, r):
+    from adell_mri_amd import functional as HF
+
+    HF._dropout_counter = itertools.count(1)       # the same dropout masks in both runs
+    blk.zero_grad()
+    xg = x.clone().requires_grad_(True)
+    y = blk(xg)
+    (y * r).sum().backward()
+    return y.detach(), xg.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()}
+
+
+def test_residual_block_gradients_do_not_depend_on_the_fusion(cuda, monkeypatch):
+    """conv -> ADN -> conv (+ link) -> ADN with dropout: the inner site hands half of its backward
+    to the second conv's backward-data kernel; same gradients as with the switch off."""
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+
+    blk = _block(cuda, 32)
+    x = torch.randn(2, 32, 16, 16, 16, device=cuda)
+    r = torch.randn(2, 32, 16, 16, 16, device=cuda)
+    calls = []
+    real = ops.conv3d_bwd_data_adn
+    monkeypatch.setattr(ops, "conv3d_bwd_data_adn", lambda *a, **k: calls.append(1) or real(*a, **k))
+    y_f, gx_f, gw_f = _run_block(blk, x, r)
+    assert calls, "the fused epilogue did not run"
+    monkeypatch.setitem(HF.FLAGS, "no_adn_fuse", True)
+    y_p, gx_p, gw_p = _run_block(blk, x, r)
+    assert len(calls) == 1
+    assert torch.equal(y_f, y_p)
+    assert _rel(gx_f, gx_p) <= 2e-5
+    for k in gw_p:
+        assert _rel(gw_f[k], gw_p[k]) <= 5e-5, k
+
+
+def test_residual_block_matches_torch_autograd(cuda, monkeypatch):
+    """The fused path against stock torch (fp64, CPU; no dropout: torch's mask stream differs)."""
+    from adell_mri_amd import ops
+
+    blk = _block(cuda, 32, act="swish", p=0.0)
+    x = torch.randn(2, 32, 16, 16, 16, device=cuda)
+    r = torch.randn(2, 32, 16, 16, 16, device=cuda)
+    calls = []
+    real = ops.conv3d_bwd_data_adn
+    monkeypatch.setattr(ops, "conv3d_bwd_data_adn", lambda *a, **k: calls.append(1) or real(*a, **k))
+    _, gx, gw = _run_block(blk, x, r)
+    assert calls, "the fused epilogue did not run"
+    sd = {k: v.detach().cpu().double() for k, v in blk.state_dict().items()}
+    xc = x.cpu().double().requires_grad_(True)
+    ws = [sd[k].requires_grad_(True) for k in ("op.0.weight", "op.2.weight")]
+    F = torch.nn.functional
+    h = F.conv3d(xc, ws[0], sd["op.0.bias"], padding=1)
+    h = F.silu(F.instance_norm(h, eps=1e-5))
+    h = F.conv3d(h, ws[1], sd["op.2.bias"], padding=1) + xc
+    out = F.silu(F.instance_norm(h, eps=1e-5))
+    (out * r.cpu().double()).sum().backward()
+    assert _rel(gx.cpu().double(), xc.grad) <= 1e-4
+    assert _rel(gw["op.0.weight"].cpu().double(), ws[0].grad) <= 1e-4
+    assert _rel(gw["op.2.weight"].cpu().double(), ws[1].grad) <= 1e-4

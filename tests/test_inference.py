@@ -1,6 +1,8 @@
 """Whole-volume inference operators: the reference's own tests
 (testing/test_segmentation_inference_pl.py:21-52: identity round trip, shapes, value range) on
-the mirror, and the mirror against the plain restatement in oracle/inference_ref.py."""
+the mirror, the mirror and the plain restatement (oracle/inference_ref.py) against outputs of the
+REAL reference operators (tests/golden/inference_ops.npz), and the HIP U-Net through the operators
+against the restatement."""
 import numpy as np
 import pytest
 import torch
@@ -100,6 +102,90 @@ def test_unbatched_input_and_stride_fraction():
     assert sli.stride == [4, 4, 4]
     out = sli(x)
     assert list(out.shape) == [1, 16, 16, 16] and torch.allclose(out, x)
+
+
+# ---- pinned to outputs of the REAL reference operators (oracle/make_golden_inference.py) -------------
+def _golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "inference_ops.npz"))
+
+
+def _build(kind, kw, net_factory):
+    if kind == "sliding":
+        return SlidingWindowSegmentation(kw["window"], net_factory(kw["n_classes"]),
+                                         kw["n_classes"], kw["stride"], kw["batch"])
+    if kind == "flip":
+        return FlippedInference(net_factory(kw["n_out"]), flips=kw["flips"],
+                                flip_keys=kw.get("flip_keys"))
+    return SegmentationInference(base_inference_function=net_factory(1),
+                                 sliding_window_size=kw["window"], stride=kw["stride"],
+                                 inference_batch_size=kw["batch"], n_classes=kw["n_classes"],
+                                 flip=kw["flip"])
+
+
+def test_mirror_matches_reference_outputs():
+    """SlidingWindowSegmentation (ragged overlapping windows, window batches 1 / 2 / 3 / 4, dict
+    input with a non-tensor entry, 2 classes, default stride, 2-D), FlippedInference (tensor, dict +
+    flip_keys) and SegmentationInference (fractional stride + flip) against what the reference's own
+    classes returned for the same inputs and the same closed-form network."""
+    from cases import INFERENCE_CASES, inference_net
+
+    g = _golden()
+    for name, (shape, kind, kw) in INFERENCE_CASES.items():
+        x = torch.from_numpy(g[name + "/x"])
+        assert tuple(x.shape) == shape
+        X = {"image": x, "meta": "not a tensor"} if kw.get("as_dict") else x
+        y = _build(kind, kw, inference_net)(X)
+        want = torch.from_numpy(g[name + "/y"])
+        assert y.shape == want.shape, name
+        assert torch.allclose(y, want, rtol=1e-6, atol=1e-6), (name, float((y - want).abs().max()))
+
+
+def test_restatement_matches_reference_outputs():
+    """oracle/inference_ref.py (the checker of the GPU parity test below) against the same
+    fixtures: its 3-D sliding window and its flip averaging."""
+    from cases import INFERENCE_CASES, inference_net
+
+    g = _golden()
+
+    def as_np(net):
+        return lambda a: net(torch.from_numpy(np.ascontiguousarray(a)).float()).numpy()
+
+    for name in ("sw3d_ragged_b1", "sw3d_ragged_b3", "sw3d_default_stride"):
+        kw = INFERENCE_CASES[name][2]
+        stride = kw["stride"] if kw["stride"] is not None else kw["window"]
+        ref = inference_ref.sliding_window_3d(g[name + "/x"].astype(np.float64),
+                                              as_np(inference_net(kw["n_classes"])), kw["window"],
+                                              stride, kw["n_classes"])
+        np.testing.assert_allclose(ref, g[name + "/y"], rtol=1e-5, atol=1e-6)
+    kw = INFERENCE_CASES["flip_tensor"][2]
+    ref = inference_ref.flipped(g["flip_tensor/x"].astype(np.float64),
+                                as_np(inference_net(kw["n_out"])), kw["flips"])
+    np.testing.assert_allclose(ref, g["flip_tensor/y"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_device_inputs_match_reference_outputs(cuda):
+    """The same operators with the volume, the windows and the accumulators on the GPU."""
+    from cases import INFERENCE_CASES, inference_net
+
+    def net_on_device(n_out):
+        net = inference_net(n_out)
+
+        def fn(X):   # the closed-form network is host arithmetic; its inputs / outputs live on the GPU
+            host = ({k: v.cpu() for k, v in X.items()} if isinstance(X, dict) else X.cpu())
+            return net(host).to(cuda)
+        return fn
+
+    g = _golden()
+    for name, (shape, kind, kw) in INFERENCE_CASES.items():
+        x = torch.from_numpy(g[name + "/x"]).to(cuda)
+        X = {"image": x, "meta": "not a tensor"} if kw.get("as_dict") else x
+        y = _build(kind, kw, net_on_device)(X)
+        assert y.is_cuda
+        want = torch.from_numpy(g[name + "/y"])
+        assert torch.allclose(y.cpu(), want, rtol=1e-6, atol=1e-6), name
 
 
 @pytest.mark.gpu

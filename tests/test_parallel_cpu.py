@@ -100,6 +100,7 @@ class _CpuFlat:
             v.copy_(p.data)
             p.data = v
         self.collected = []
+        self.reduced = [False] * len(self.params)
 
     def slot(self, i):
         p, o = self.params[i], self.offsets[i]
@@ -179,8 +180,13 @@ def _overlap_worker(rank, world, port, out):
         loss.backward()
         sent_during_backward.append(sum(b.sent for b in sync.buckets))
         sync.all_reduce()
-        assert not sync._handles and all(not b.sent and b.pending == b.hi - b.lo
-                                         for b in sync.buckets)
+        assert all(b.handle is None and not b.sent and b.pending == b.hi - b.lo
+                   for b in sync.buckets)
+        # every parameter that produced a gradient reads its reduced slice again
+        f = opt._flat
+        assert all(p.grad is None or p.grad.data_ptr() == f.slot(i).data_ptr()
+                   for i, p in enumerate(f.params))
+        assert sum(p.grad is not None for p in f.params) == len(f.params) - 1
         if step == 0:
             grads = opt._flat.grad.clone() * opt.param_groups[0]["grad_scale"]
         opt.step()
@@ -223,6 +229,64 @@ def test_bucketed_overlap_equals_single_process_batch(tmp_path):
     assert torch.equal(res[0]["data"], res[1]["data"])
     # the unused parameter was left alone (no weight decay on a gradient-less parameter)
     assert torch.equal(net.unused.data, torch.ones(5))
+
+
+def _accum_worker(rank, world, port, out, mode):
+    """Two backward passes per step (gradient accumulation): ``plain`` = no
+    precaution at all, ``no_sync`` = the first backward inside GradSync.no_sync(), ``abandon`` =
+    a step given up after its backward (zero_grad without all_reduce), then a normal one."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo")
+    net = _net()
+    opt = _CpuSGD(net.parameters(), 0.1, 0.9, 0.01)
+    opt.zero_grad = opt._flat.zero_grad          # what a step starts with (GradSync wraps it)
+    sync = parallel.GradSync(opt, n_buckets=3, min_bucket_elems=1)
+    sync.broadcast_parameters(module=net)
+    x, y = _data()
+    xs, ys = x[rank:rank + 1], y[rank:rank + 1]
+    for step in range(2):
+        opt.zero_grad()
+        if mode == "abandon" and step == 0:
+            ((net(xs) - ys) ** 2).mean().backward()
+            assert any(b.sent for b in sync.buckets)
+            continue                              # e.g. a NaN loss: no all_reduce, no step
+        if mode == "no_sync":
+            with sync.no_sync():
+                ((net(xs) - ys) ** 2).mean().backward()
+                assert not any(b.sent for b in sync.buckets)
+        elif mode == "plain":
+            ((net(xs) - ys) ** 2).mean().backward()
+        (0.5 * (net(xs * 2.0) - ys) ** 2).mean().backward()
+        sync.all_reduce()
+        assert all(b.handle is None and not b.sent and not b.again for b in sync.buckets)
+        opt.step()
+    torch.save({"data": opt._flat.data.clone()}, f"{out}/a{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("mode", ["plain", "no_sync", "abandon"])
+def test_two_backward_passes_per_step(tmp_path, mode):
+    world, port = 2, _free_port()
+    mp.spawn(_accum_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"a{r}.pt") for r in range(world)]
+    net = _net()
+    opt = _CpuSGD(net.parameters(), 0.1, 0.9, 0.01)
+    x, y = _data()
+    for step in range(2):
+        opt._flat.zero_grad()
+        if mode == "abandon" and step == 0:
+            continue
+        if mode != "abandon":
+            ((net(x) - y) ** 2).mean().backward()
+        (0.5 * (net(x * 2.0) - y) ** 2).mean().backward()
+        opt.collect_grads()
+        opt.step()
+    for r in range(world):
+        assert torch.allclose(res[r]["data"], opt._flat.data, rtol=1e-5, atol=1e-7), mode
+    assert torch.equal(res[0]["data"], res[1]["data"])
 
 
 def test_plan_buckets():

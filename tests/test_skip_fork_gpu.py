@@ -127,3 +127,33 @@ def _step_trainable(net, x, r):
     (y * r).sum().backward()
     return (y.detach(), xg.grad.clone(),
             {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+
+
+def test_hook_on_a_level_output_sees_the_whole_gradient(cuda, monkeypatch):
+    """a tensor hook on a forked level output must see the SUM of its readers'
+    gradients. A watched tensor (hooks / retain_grad) gets no carry: autograd accumulates."""
+    from adell_mri_amd import ops
+
+    net = _unet("residual", cuda)
+    x = torch.randn(1, 2, 32, 32, 32, device=cuda)
+    r = torch.randn(1, 1, 32, 32, 32, device=cuda)
+    seen = {}
+
+    def watch(name):
+        def fwd_hook(_mod, _inp, out):
+            out.register_hook(lambda g: seen.__setitem__(name, g.detach().clone()))
+        return fwd_hook
+
+    handles = [net.encoding_operations[i][0].register_forward_hook(watch(i)) for i in (0, 1)]
+    _, gx_h, gw_h = _step(net, x, r)
+    with_hooks = dict(seen)
+    seen.clear()
+    monkeypatch.setitem(ops.FLAGS, "no_grad_carry", True)       # plain autograd everywhere
+    _, gx_p, gw_p = _step(net, x, r)
+    for i in (0, 1):
+        assert _rel(with_hooks[i], seen[i]) <= 1e-6
+    for h in handles:
+        h.remove()
+    assert _rel(gx_h, gx_p) <= 1e-5
+    for k in gw_p:
+        assert _rel(gw_h[k], gw_p[k]) <= 1e-4, k

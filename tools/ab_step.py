@@ -26,18 +26,21 @@ net.train()
 opt = net.configure_optimizers()["optimizer"]
 runner = StepRunner(net, opt, GradSync(opt))
 batch = bench.synthetic_batch(int(net.batch_size), (128, 128, 128), dev, 42)
-PY = switch.startswith("py:")       # "py:no_cinfold": a Python-level dispatch flag (ops.FLAGS)
+PY = switch.startswith(("py:", "hf:"))   # "py:no_cinfold": a dispatch flag of ops.FLAGS; "hf:no_adn_fuse": of functional.FLAGS
 if PY:
+    from adell_mri_amd import functional as HF  # noqa: E402
     from adell_mri_amd import ops  # noqa: E402
+
+    FLAGSET = HF.FLAGS if switch.startswith("hf:") else ops.FLAGS
 
 
 def get_switch():
-    return int(bool(ops.FLAGS[switch[3:]])) if PY else _lib.lib().adell_get_tuning(switch.encode())
+    return int(bool(FLAGSET[switch[3:]])) if PY else _lib.lib().adell_get_tuning(switch.encode())
 
 
 def set_switch(v):
     if PY:
-        ops.FLAGS[switch[3:]] = bool(v)
+        FLAGSET[switch[3:]] = bool(v)
     else:
         _lib.lib().adell_set_tuning(switch.encode(), v)
 
