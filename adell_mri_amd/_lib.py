@@ -177,6 +177,10 @@ SIGNATURES = {
     "adell_conv_cin_small_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
     "adell_conv_cin_small_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),
     "adell_multi_copy": (_i, [_vp, _i, _vp, _vp]),
+    "adell_item_stats_workspace": (_l, [_i, _l]),
+    "adell_item_stats": (_i, [_vp, _i, _l, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_aug_intensity": (_i, [_vp, _vp, _i, _l, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp]),
+    "adell_affine_sample": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_fwd": (_i, [_vp, _l, _i, _i, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_bwd_workspace": (_l, [_l, _i]),

@@ -26,6 +26,7 @@ struct AdellTuning {
   int igemm_no2wave;              // strided / k == stride layers: not the two-wave 64-voxel instance
   int attn_nomfma;                // attention: vector-ALU kernels even for MFMA-eligible head dims
   int igemm_ws, ws_min_items;   // persistent wave-specialised conv instance: opt-in / size gate
+  int igemm_wide8;                // 64-column tile of the large 3^3 layers on 8x8x8 bricks, 8 waves
   int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;

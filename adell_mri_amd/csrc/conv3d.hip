@@ -193,10 +193,9 @@ static int adell_fill_bwd_data(ConvArgs& a, const adell_conv3d_desc* d, const fl
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(dy && dx0, "conv_bwd_data: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || dx1, "conv_bwd_data: C1 > 0 needs dx1");
-  if (d->PD > d->KD - 1 || d->PH > d->KH - 1 || d->PW > d->KW - 1) {
-    adell_set_error("conv_bwd_data: pad > k-1 unsupported");
-    return ADELL_E_UNSUPPORTED;
-  }
+  // (pad > k - 1 -- the padded 1x1 convs of the depthwise U-Net blocks, unet.py:292-307 -- makes
+  // the padding of this stride-1 conv over dY negative: the halo origin moves INSIDE dY, which the
+  // generic halo arithmetic handles as it stands)
   a = ConvArgs{};
   a.x0 = dy; a.x1 = nullptr; a.w = nullptr; a.bias = nullptr; a.res = nullptr;
   a.y0 = dx0; a.y1 = dx1; a.part = nullptr;
@@ -392,7 +391,7 @@ static int adell_launch_conv_ws(const ConvArgs& a, const ConvF16Extra& e, int it
 
 // Tile plan of the f16x3 kernel: the heuristic brick, or (when its halo does not fit
 // LDS, i.e. stride 2) the small-brick configuration of the same channel width.
-static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
+static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, bool no_wide8 = false) {
   ConvTile t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, g_conv_force_cfg);
   // kernel == stride > 1 (transposed-conv backward-data): every staged voxel feeds one tap, so
   // the launch is bound by staging, not MFMA. 64-voxel bricks (32 KB of LDS, 4 blocks per CU)
@@ -477,6 +476,23 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     a.HZ = 10;
     a.VP = a.HX * a.HY * a.HZ;
     lds = (size_t)1000 * 64 + (size_t)7 * 32 * 64 + 64;
+  }
+  // EXPERIMENT ("igemm_wide8", off by default): the same brick for the 64-column tile, eight waves
+  // of 2 x 2 tiles in ONE block per CU (92 KB of LDS): a sixth less halo and half the weight staging
+  // per output, but both waves of a SIMD then meet every barrier together
+  if (t.cfg == 0 && g_adell_tune.igemm_wide8 && !no_wide8 && a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 &&
+      a.SH == 1 && a.SW == 1 && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.shuffle == 0 &&
+      a.lTX == 3 && a.lTY == 3 && a.lTZ == 2 && a.Do >= 8 && a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
+      (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
+      g_conv_force_cfg < 0 && !g_adell_tune.igemm_nospec) {
+    t.cfg = 7;
+    t.BM = 512;
+    t.lTZ = 3;
+    a.lTZ = 3;
+    a.ntz = adell_cdiv(a.Do, 8);
+    a.HZ = 10;
+    a.VP = a.HX * a.HY * a.HZ;
+    lds = (size_t)1000 * 64 + (size_t)7 * 64 * 64 + 64;
   }
   // transposed-conv forward (1 tap, F * Cs columns with a pixel-shuffle store): one block takes a
   // 64-voxel brick and up to 256 columns (cfg 5), so the input brick is staged once instead of
@@ -590,7 +606,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                                    void* ws = nullptr, size_t ws_bytes = 0, int adn = 0) {
   ConvTile t;
   size_t lds;
-  int rc = adell_plan_f16(a, N, &t, &lds);
+  int rc = adell_plan_f16(a, N, &t, &lds, adn != 0);
   if (rc != ADELL_OK) return adn < 0 ? 0 : rc;
   // (the f16x3 kernel's 16-byte halo loads address a batch item with 32-bit byte offsets)
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
@@ -679,6 +695,13 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
         return ADELL_E_BADARG;
       }
       rc2 = adell_launch_conv_f16<4, 1, 4, 1, 3>(a, e, grid, lds, st);
+      break;
+    case 7:   // experiment: 8x8x8 bricks x 64 columns, eight waves (adell_plan_f16)
+      if (!a.vecx) {
+        adell_set_error("conv f16x3: input pointers must be 16-byte aligned");
+        return ADELL_E_BADARG;
+      }
+      rc2 = adell_launch_conv_f16<2, 2, 8, 1, 3>(a, e, grid, lds, st);
       break;
     case 1:
       rc2 = spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)

@@ -95,7 +95,7 @@ __device__ __forceinline__ void adell_split8(const float* v, float scale, half8*
 // EPI = 1 (SPEC instances, launches whose bricks are all whole): the fused ADN backward of
 // ConvF16Extra::adn in the epilogue.
 template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0>
-__global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : WM * WN / 2)
+__global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : (WM * WN >= 8 ? 2 : WM * WN / 2))
 void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
   // SPEC = 2: the same with the 27 taps staged in 4 linear groups of <= 7 (not per kz plane):
@@ -712,6 +712,27 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     if (full) {
       stored = true;
       auto fast = [&](auto has_res) {
+        // EPI = 1: the site inputs of ALL this wave's tiles are fetched before the first store (the
+        // stores of one m-tile may alias the loads of the next as far as the compiler knows: left
+        // inside the m-tile loop every tile paid its own memory round trip)
+        float yall[EPI == 1 ? MT : 1][EPI == 1 ? NT : 1][16];
+        if constexpr (EPI == 1) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int tile = wm * MT + mt;
+            const unsigned rbase = (unsigned)(tile >> 1) * (unsigned)(a.Ho * a.Wo) +
+                                   (unsigned)((tile & 1) * 4 * a.Wo) + 4 * lh;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const float* yp = (adn_y[nt] != nullptr ? adn_y[nt] : colptr[nt]) +
+                                (size_t)rbase * rowmul[nt];
+              const unsigned dY = a.Wo * rowmul[nt], dX = rowmul[nt];
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                yall[mt][nt][r] = adn_y[nt] != nullptr ? yp[(r >> 2) * dY + (r & 3) * dX] : 0.f;
+            }
+          }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int tile = wm * MT + mt;
@@ -735,18 +756,26 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
             if constexpr (EPI == 1) {
               if (adn_y[nt] != nullptr) {
                 // ---- dt and its two sums instead of dout (see ConvF16Extra::Adn) --------------
-                const float* yp = adn_y[nt] + (size_t)rbase * rowmul[nt];
-                float yv[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) yv[r] = yp[(r >> 2) * dY + (r & 3) * dX];
+                const float* yv = yall[mt][nt];
                 unsigned kw[16];
                 const unsigned ebase = adn_e0[nt] + rbase * (unsigned)rowmul[nt];
                 if (adn_mk[nt] != nullptr) {
+                  // element el of the item -> bit (el >> 2) & 63 of 64-bit word (el >> 8) * 4 + (el & 3)
+                  if (rowmul[nt] == 32) {
+                    // 32 channels: the four x-neighbours of a brick row share one 32-bit word
+                    // (el >> 7 = voxel >> 2, and x = 4 lh + (r & 3) with the brick 8-aligned)
 #pragma unroll
-                  for (int r = 0; r < 16; ++r) {
-                    // element el of the item -> bit (el >> 2) & 63 of 64-bit word (el >> 8) * 4 + (el & 3)
-                    const unsigned el = ebase + (r >> 2) * dY + (r & 3) * dX;
-                    kw[r] = adn_mk[nt][((el >> 8) * 4u + (el & 3u)) * 2u + ((el >> 7) & 1u)];
+                    for (int j = 0; j < 4; ++j) {
+                      const unsigned el = ebase + j * dY;
+                      const unsigned w = adn_mk[nt][((el >> 8) * 4u + (el & 3u)) * 2u + ((el >> 7) & 1u)];
+                      kw[4 * j] = kw[4 * j + 1] = kw[4 * j + 2] = kw[4 * j + 3] = w;
+                    }
+                  } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                      const unsigned el = ebase + (r >> 2) * dY + (r & 3) * dX;
+                      kw[r] = adn_mk[nt][((el >> 8) * 4u + (el & 3u)) * 2u + ((el >> 7) & 1u)];
+                    }
                   }
                 }
 #pragma unroll

@@ -101,6 +101,55 @@ class DepthwiseConv2d(torch.nn.Conv2d):
         return HF.dwconv3d(X.unsqueeze(2), self.weight.unsqueeze(2), self.bias).squeeze(2)
 
 
+class DepthwiseConvNd(torch.nn.Module):
+    """Mixin of the depthwise convolutions of the U-Net's ``conv_type="depthwise"`` blocks
+    (unet.py:276-307: ``Conv(in, in, k, stride, padding, groups=in)``): the stencil kernel computes the
+    stride-1 "same" convolution and the requested output is the lattice
+    ``same[(k // 2 - p) + stride * o]`` of it -- a strided view, materialised by the consumer's
+    NDHWC copy. Needs an odd kernel and padding <= k // 2 per axis (padding "same" included)."""
+
+    def _lattice(self, same, k, stride, pad):
+        index = [slice(None), slice(None)]
+        for n, kk, st, p in zip(same.shape[2:], k, stride, pad):
+            if kk % 2 == 0 or p > kk // 2:
+                raise NotImplementedError("HIP depthwise conv: odd kernels, padding <= k // 2")
+            out = (n + 2 * p - kk) // st + 1
+            lo = kk // 2 - p
+            index.append(slice(lo, lo + st * (out - 1) + 1, st))
+        if all(sl == slice(0, n, 1) for sl, n in zip(index[2:], same.shape[2:])):
+            return same
+        return same[tuple(index)]
+
+
+class DepthwiseConv3dStrided(torch.nn.Conv3d, DepthwiseConvNd):
+    """torch.nn.Conv3d(c, c, k, stride, padding, groups=c) of the depthwise U-Net block."""
+
+    def forward(self, X, X_cat=None):
+        if self.groups != self.in_channels or self.in_channels != self.out_channels \
+                or tuple(self.dilation) != (1, 1, 1):
+            raise NotImplementedError("HIP DepthwiseConv3dStrided: groups == channels, dilation 1")
+        if X_cat is not None:
+            X = HF.cat_channels([X, X_cat])
+        k = tuple(self.kernel_size)
+        pad = tuple(kk // 2 for kk in k) if self.padding == "same" else tuple(self.padding)
+        return self._lattice(HF.dwconv3d(X, self.weight, self.bias), k, tuple(self.stride), pad)
+
+
+class DepthwiseConv2dStrided(torch.nn.Conv2d, DepthwiseConvNd):
+    """The 2-D form on depth-1 volumes."""
+
+    def forward(self, X, X_cat=None):
+        if self.groups != self.in_channels or self.in_channels != self.out_channels \
+                or tuple(self.dilation) != (1, 1):
+            raise NotImplementedError("HIP DepthwiseConv2dStrided: groups == channels, dilation 1")
+        if X_cat is not None:
+            X = HF.cat_channels([X.unsqueeze(2), X_cat.unsqueeze(2)]).squeeze(2)
+        k = tuple(self.kernel_size)
+        pad = tuple(kk // 2 for kk in k) if self.padding == "same" else tuple(self.padding)
+        same = HF.dwconv3d(X.unsqueeze(2), self.weight.unsqueeze(2), self.bias).squeeze(2)
+        return self._lattice(same, k, tuple(self.stride), pad)
+
+
 class ConvNeXtBlock3d(torch.nn.Module):
     """ConvNeXt block (adell_mri/modules/layers/res_blocks.py:516-604): depthwise conv ->
     LayerNorm over channels -> Linear -> GELU -> Linear -> layer scale -> + input

@@ -27,7 +27,8 @@ from ..layers.conv import (Conv2d, Conv3d, ConvTranspose2d, ConvTranspose3d, Max
                            MaxPool3d, Upsample)
 from ..layers.linear_blocks import Linear
 from ..layers.regularization import UOut
-from ..layers.res_blocks import ResidualBlock2d, ResidualBlock3d
+from ..layers.res_blocks import (DepthwiseConv2dStrided, DepthwiseConv3dStrided, ResidualBlock2d,
+                                 ResidualBlock3d)
 from ..layers.utils import crop_to_size
 
 
@@ -175,6 +176,9 @@ class UNet(torch.nn.Module):
         if self.conv_type == "regular":
             self.conv_op_enc = self.conv_block
             self.conv_op_dec = self.conv_block
+        elif self.conv_type == "depthwise":
+            self.conv_op_enc = self.depthwise_conv_block
+            self.conv_op_dec = self.depthwise_conv_block
         elif self.conv_type == "resnet":
             self.conv_op_enc = self.res_block_conv_3d
             self.conv_op_dec = self.conv_block
@@ -200,6 +204,20 @@ class UNet(torch.nn.Module):
     # the reference names (unet.py:245,260) stay available
     conv_block_2d = conv_block
     conv_block_3d = conv_block
+
+    def depthwise_conv_block(self, in_d, out_d, kernel_size, stride=None, padding=None):
+        """conv(in->in, k, stride, groups=in) -> ADN(in) -> conv(in->out, 1): unet.py:276-307. As
+        in the reference the 1x1 conv receives the SAME ``padding`` argument: with an integer
+        padding p > 0 (every downsampling block: p = k // 2, unet.py:563-567) its output is the
+        input grown by p voxels of bias on every side, and the decoder crops the skip tensors."""
+        padding = 0 if padding is None else padding
+        stride = 1 if stride is None else stride
+        dw = DepthwiseConv3dStrided if self.spatial_dimensions == 3 else DepthwiseConv2dStrided
+        return ConcatConvBlock(dw(in_d, in_d, kernel_size, stride, padding, groups=in_d),
+                               self.adn_fn(in_d), self._conv(in_d, out_d, 1, 1, padding))
+
+    depthwise_conv_block_2d = depthwise_conv_block
+    depthwise_conv_block_3d = depthwise_conv_block
 
     def res_block_conv_3d(self, in_d, out_d, kernel_size, stride=None, padding=None):
         """ResidualBlock3d / 2d (+ max pooling when strided): unet.py:309-379."""

@@ -1632,3 +1632,43 @@ def optim_step(kind, param, grad, s1, s2, weight_decay, eps, grad_scale, c5):
                                       _ptr(s2), param.numel(), weight_decay, eps, grad_scale, arr,
                                       _stream()))
     _weights_changed()
+
+
+# ---- device-side batch augmentation (csrc/augment.hip) -------------------------------------------
+def item_stats(x):
+    """[N, 4] = (min, max, mean, population std) of every batch item of ``x`` (any layout: the
+    statistics are over all elements of the item)."""
+    _require_cuda(x)
+    N = x.shape[0]
+    per = x.numel() // N
+    assert x.is_contiguous() or ndhwc(x).data_ptr() == x.data_ptr()
+    out = torch.empty((N, 4), device=x.device, dtype=torch.float32)
+    ws = _workspace(_lib.lib().adell_item_stats_workspace(N, per), x.device)
+    check(_lib.lib().adell_item_stats(_ptr(x), N, per, _ptr(out), _ptr(ws), ws.numel() * 4, _stream()))
+    return out
+
+
+def aug_intensity(x, params, seed=0, rng_offset=0):
+    """Gamma contrast -> std shift -> Rician noise of every item in one pass; ``params`` [N, 8]
+    device rows {min, range, gamma, shift, noise std, 0, 0, 0} (adell_aug_intensity)."""
+    _require_cuda(x, params)
+    N = x.shape[0]
+    out = torch.empty_like(x)
+    check(_lib.lib().adell_aug_intensity(_ptr(x), _ptr(out), N, x.numel() // N, _ptr(params),
+                                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(rng_offset) & 0xFFFFFFFF,
+                                         _stream()))
+    return out
+
+
+def affine_sample(x, theta, linear=True, pad_mode="reflection"):
+    """Affine resampling of [N, C, D, H, W] (NDHWC memory) volumes about their centres; ``theta``
+    [N, 12] device rows of the 3 x 4 voxel-space matrices (adell_affine_sample)."""
+    _require_cuda(x, theta)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    out = new_act(N, C, D, H, W, x.device)
+    check(_lib.lib().adell_affine_sample(_ptr(x), _ptr(out), N, D, H, W, C, _ptr(theta),
+                                         1 if linear else 0,
+                                         {"zeros": 0, "border": 1, "reflection": 2}[pad_mode],
+                                         _stream()))
+    return out

@@ -725,6 +725,28 @@ void adell_debug_force_conv_cfg(int cfg);
 int adell_set_tuning(const char* name, int value);
 int adell_get_tuning(const char* name);
 
+/* ------------------------------------------------------------------------
+ * Device-side batch augmentation (csrc/augment.hip): the arithmetic of the MONAI transforms the
+ * reference composes in transform_factory/augmentations.py:19-178 (get_augmentations_unet) on
+ * volumes resident in HBM. The random draws are the caller's; these are the per-element passes.
+ * ---------------------------------------------------------------------- */
+/* out[N][4] = (min, max, mean, population std) of each item of per_item contiguous floats
+ * (what RandAdjustContrast / RandStdShiftIntensity need of an image) */
+long adell_item_stats_workspace(int N, long per_item);
+int adell_item_stats(const float* x, int N, long per_item, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* One pass: gamma contrast -> std shift -> Rician noise. params[N][8] per item:
+ * {min, max - min, gamma (<= 0: skip), shift, noise std (<= 0: skip), unused x 3}:
+ *   v = ((x - min) / (range + 1e-7))^gamma * range + min;  v += shift;
+ *   v = sqrt((v + n1)^2 + n2^2), n1, n2 ~ N(0, std) from Philox(seed, rng_offset, element). */
+int adell_aug_intensity(const float* x, float* out, int N, long per_item, const float* params,
+                        uint64_t seed, uint32_t rng_offset, void* stream);
+/* Affine resampling of NDHWC volumes: out[n][v] = sample(x[n], theta[n] (v - centre) + centre) in
+ * voxel coordinates (theta[N][12]: rows of a 3 x 4 matrix over (z, y, x)); linear: 1 trilinear,
+ * 0 nearest; pad_mode: 0 zeros, 1 border, 2 reflection (about -0.5 / size - 0.5). */
+int adell_affine_sample(const float* x, float* out, int N, int D, int H, int W, int C,
+                        const float* theta, int linear, int pad_mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,24 @@ UNET_CASES = {
 }
 
 
+DEPTHWISE_CASES = {
+    # conv_type="depthwise" (unet.py:292-307): Conv(groups = channels, k, stride) -> ADN -> 1x1 conv.
+    # The constructor default padding="same" (the 1x1 conv takes the SAME padding argument, so an
+    # integer padding > 0 would grow every tensor by 2 p per block in the reference)
+    "unet3d_depthwise": (dict(spatial_dimensions=3, conv_type="depthwise", link_type="identity",
+                              upscale_type="transpose", norm_type="instance", padding="same",
+                              dropout_param=0.0, activation_fn="swish", in_channels=2,
+                              n_classes=2, depth=[8, 16, 32], kernel_sizes=[3] * 3,
+                              strides=[2] * 3), (2, 2, 16, 16, 16), "normal"),
+    # 2-D: the same block on Conv2d (depthwise_conv_block_2d, unet.py:276-290)
+    "unet2d_depthwise": (dict(spatial_dimensions=2, conv_type="depthwise", link_type="identity",
+                              upscale_type="transpose", norm_type="instance", padding="same",
+                              dropout_param=0.0, activation_fn="relu", in_channels=1, n_classes=2,
+                              depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                         (2, 1, 32, 48), "uniform"),
+}
+
+
 UNET2D_CASES = {
     # BASELINE configs[0]: the 2-D U-Net of the reference's own testing/test_unet.py:63-72 with
     # the constructor defaults (BatchNorm2d, PReLU), 140 748 parameters. train() for batch
@@ -561,6 +579,46 @@ def gen_full(name, kw, shape, with_grads):
           "logit stats", out["logit_stats"])
 
 
+def gen_full_fp64(name, kw, shape):
+    """The same network, inputs and loss as gen_full in DOUBLE precision: the yardstick that tells
+    the reference's own fp32 summation noise (over 2 M voxels per channel) from an error of the HIP
+    path. Writes <name>_fp64.npz: per parameter the gradient's L2 norm / absolute maximum and the
+    entries at the SAME sampled positions as the fp32 fixture, plus the logit statistics."""
+    import time
+    torch.manual_seed(0)
+    x, y = full_inputs(shape)
+    net = make_unet(kw).eval().double()
+    t0 = time.time()
+    logits = net(x.double(), return_logits=True)[0]
+    print(name, "fp64 forward", round(time.time() - t0, 1), "s")
+    lg = logits.detach()
+    flat = lg.reshape(-1)
+    pos = sample_positions(flat.numel(), 64, 1)
+    out = {"logit_stats": np.array([float(lg.mean()), float(lg.std()), float(lg.min()),
+                                    float(lg.max()), float(lg.abs().mean())]),
+           "logit_pos": pos, "logit_val": flat[pos].numpy().copy()}
+    prob = torch.sigmoid(logits)
+    d = binary_generalized_dice_loss(prob, y.double(), smooth=1e-5, eps=1e-6)
+    f = binary_focal_loss(prob, y.double(), gamma=1.0, eps=1e-6)
+    loss = torch.stack([d.mean(), f.mean()]).mean()
+    out["loss"] = loss.detach().numpy()
+    t0 = time.time()
+    loss.backward()
+    print(name, "fp64 backward", round(time.time() - t0, 1), "s")
+    keys = []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        gflat = p.grad.reshape(-1)
+        gp = sample_positions(gflat.numel(), 16, zlib_crc(k))
+        out["gnorm:" + k] = np.array([float(gflat.norm()), float(gflat.abs().max())])
+        out["gpos:" + k], out["gval:" + k] = gp, gflat[gp].numpy().copy()
+        keys.append(k)
+    out["grad_keys"] = np.array(keys)
+    np.savez_compressed(os.path.join(OUT, name + "_fp64.npz"), **out)
+    print(name, "fp64 loss", float(loss))
+
+
 SURFACE_CASES = {
     # name: (net_type, sample YAML, image size the entrypoint would pass, number of image keys)
     "unet": ("unet", "u-net-3d-resnet.yaml", None, 2),
@@ -864,6 +922,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         gen_surface()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "full64":
+        gen_full_fp64("unet3d_cfg2_full", *FULL_CASES["unet3d_cfg2_full"][:2])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         for name, (kw, shape, wg) in FULL_CASES.items():
             if len(sys.argv) > 2 and sys.argv[2] != name:
@@ -872,6 +933,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ssl":
         gen_ssl()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "depthwise":
+        for name, (kw, shape, dist) in DEPTHWISE_CASES.items():
+            gen_unet(name, kw, shape, dist)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "unet2d":
         for name, (kw, shape, dist) in UNET2D_CASES.items():

@@ -23,6 +23,18 @@ UNET_CASES = {
                                    strides=[2] * 3),
 }
 
+# conv_type="depthwise" (unet.py:276-307); fixtures: `python oracle/make_golden.py depthwise`
+DEPTHWISE_CASES = {
+    "unet3d_depthwise": dict(spatial_dimensions=3, conv_type="depthwise", link_type="identity",
+                             upscale_type="transpose", norm_type="instance", padding="same",
+                             dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                             depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+    "unet2d_depthwise": dict(spatial_dimensions=2, conv_type="depthwise", link_type="identity",
+                             upscale_type="transpose", norm_type="instance", padding="same",
+                             dropout_param=0.0, activation_fn="relu", in_channels=1, n_classes=2,
+                             depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+}
+
 UNETR_CASES = {
     "unetr3d_small": dict(image_size=[32, 32, 32], patch_size=[8, 8, 8], number_of_blocks=4,
                           return_at=[1, 2], embedding_size=64, attention_dim=64, hidden_dim=64,

@@ -126,8 +126,13 @@ def test_residual_block_gradients_do_not_depend_on_the_fusion(cuda, monkeypatch)
     assert len(calls) == 1
     assert torch.equal(y_f, y_p)
     assert _rel(gx_f, gx_p) <= 2e-5
+    scale = max(float(v.abs().max()) for v in gw_p.values())
     for k in gw_p:
-        assert _rel(gw_f[k], gw_p[k]) <= 5e-5, k
+        if k.endswith("bias"):
+            # a bias in front of an instance norm has gradient zero: both runs hold rounding noise
+            assert float((gw_f[k] - gw_p[k]).abs().max()) <= 1e-5 * scale, k
+        else:
+            assert _rel(gw_f[k], gw_p[k]) <= 5e-5, k
 
 
 def test_residual_block_matches_torch_autograd(cuda, monkeypatch):

@@ -105,26 +105,47 @@ def test_cfg2_128_cubed_matches_reference(cuda, precision):
     loss = compound_loss(prob, yd)
     np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4)
     loss.backward()
-    worst_norm = worst_entry = 0.0
-    top = max(float(g["gnorm:" + str(k)][1]) for k in g["grad_keys"])
+    # The yardstick is the reference network in DOUBLE precision (unet3d_cfg2_full_fp64.npz, same
+    # inputs / weights / sampled positions: `python oracle/make_golden.py full64`). The reference's
+    # own fp32 gradients deviate from it by its summation noise over 2 M voxels per channel; the HIP
+    # gradients must be as close to fp64 as the reference's fp32 ones are (x 3), or within 1e-4.
+    g64 = np.load(os.path.join(GOLD, "unet3d_cfg2_full_fp64.npz"))
+    worst = {"hip_norm": (0.0, ""), "ref_norm": (0.0, ""), "hip_entry": (0.0, ""),
+             "ref_entry": (0.0, "")}
+    top = max(float(g64["gnorm:" + str(k)][1]) for k in g64["grad_keys"])
+    rows = []
     for k, p in net.named_parameters():
         if ("gnorm:" + k) not in g.files:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
         gr = p.grad.detach().float().cpu().reshape(-1)
         ref_norm, ref_max = (float(v) for v in g["gnorm:" + k])
-        scale = _grad_scale(g, k, ref_max, top)
+        n64, m64 = (float(v) for v in g64["gnorm:" + k])
+        scale = _grad_scale(g64, k, m64, top)
         pos = sample_positions(gr.numel(), 16, zlib_crc(k))
-        assert np.array_equal(pos, g["gpos:" + k])
-        e_entry = float(np.abs(gr[pos].numpy() - g["gval:" + k]).max()) / scale
-        worst_entry = max(worst_entry, e_entry)
-        assert e_entry < 2e-3, (k, e_entry)
-        if ref_max > 5e-4 * top:
-            e_norm = abs(float(gr.double().norm()) - ref_norm) / ref_norm
-            worst_norm = max(worst_norm, e_norm)
-            assert e_norm < 1e-3, (k, e_norm)
-    print(f"cfg2 128^3 [{precision}]: worst gradient-norm error {worst_norm:.2e}, worst sampled "
-          f"entry error {worst_entry:.2e} of the gradient's max")
+        assert np.array_equal(pos, g["gpos:" + k]) and np.array_equal(pos, g64["gpos:" + k])
+        e_hip = float(np.abs(gr[pos].numpy() - g64["gval:" + k]).max()) / scale
+        e_ref = float(np.abs(g["gval:" + k] - g64["gval:" + k]).max()) / scale
+        rows.append((k, e_hip, e_ref))
+        for name, v in (("hip_entry", e_hip), ("ref_entry", e_ref)):
+            if v > worst[name][0]:
+                worst[name] = (v, k)
+        assert e_hip < max(3.0 * e_ref, 1e-4), (k, e_hip, e_ref)
+        if m64 > 5e-4 * top:
+            n_hip = abs(float(gr.double().norm()) - n64) / n64
+            n_ref = abs(ref_norm - n64) / n64
+            for name, v in (("hip_norm", n_hip), ("ref_norm", n_ref)):
+                if v > worst[name][0]:
+                    worst[name] = (v, k)
+            assert n_hip < max(3.0 * n_ref, 1e-4), (k, n_hip, n_ref)
+    rows.sort(key=lambda r: -r[2])
+    print(f"cfg2 128^3 [{precision}] against the fp64 reference: worst gradient-norm error HIP "
+          f"{worst['hip_norm'][0]:.2e} ({worst['hip_norm'][1]}) / reference fp32 "
+          f"{worst['ref_norm'][0]:.2e} ({worst['ref_norm'][1]}); worst sampled entry HIP "
+          f"{worst['hip_entry'][0]:.2e} ({worst['hip_entry'][1]}) / reference fp32 "
+          f"{worst['ref_entry'][0]:.2e} ({worst['ref_entry'][1]})")
+    for k, e_hip, e_ref in rows[:5]:
+        print(f"    {k}: HIP {e_hip:.2e}, reference fp32 {e_ref:.2e} of the gradient's max")
 
 
 def test_cfg2_256x256x128_matches_reference(cuda):

@@ -174,7 +174,8 @@ def test_device_inputs_match_reference_outputs(cuda):
         net = inference_net(n_out)
 
         def fn(X):   # the closed-form network is host arithmetic; its inputs / outputs live on the GPU
-            host = ({k: v.cpu() for k, v in X.items()} if isinstance(X, dict) else X.cpu())
+            host = ({k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in X.items()}
+                    if isinstance(X, dict) else X.cpu())
             return net(host).to(cuda)
         return fn
 

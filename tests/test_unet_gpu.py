@@ -9,7 +9,7 @@ import torch
 
 from adell_mri_amd.modules.activations import activation_factory
 from adell_mri_amd.modules.segmentation.unet import UNet
-from cases import UNET_CASES, grad_rel_err
+from cases import DEPTHWISE_CASES, UNET_CASES, grad_rel_err
 from oracle.torch_ref.unet import compound_loss
 from oracle.weights import tensor_for
 
@@ -83,3 +83,36 @@ def test_train_mode_dropout_runs_and_is_seeded(cuda):
     assert torch.isfinite(a).all() and not torch.equal(a, b)
     a.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+# ---- conv_type="depthwise" (unet.py:276-307): depthwise stencil kernels + 1x1 convs, including the
+# reference's padded 1x1 conv of every downsampling block (its output grows by 2 voxels per axis and
+# the decoder crops the skip tensors) --------------------------------------------------------------
+@pytest.mark.parametrize("name", list(DEPTHWISE_CASES))
+def test_depthwise_unet_matches_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(DEPTHWISE_CASES[name], cuda).eval()
+    x = torch.from_numpy(g["x"]).to(cuda)
+    y = torch.from_numpy(g["y"]).to(cuda)
+    with torch.no_grad():
+        logits, _ = net(x, return_logits=True)
+    ref = g["logits"]
+    assert tuple(logits.shape) == ref.shape
+    rel = np.abs(logits.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert rel < 1e-4, rel
+    prob, _ = net(x)
+    loss = compound_loss(prob, y)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    # a 1x1 conv on ONE input channel in front of an instance norm (the 2-D case's first block) has a
+    # mathematically zero weight gradient too: the scale of a key is floored by 1e-3 of the largest
+    # gradient of the network
+    gmax = max(float(np.abs(g[f]).max()) for f in g.files if f.startswith("grad:"))
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        ref, got = g["grad:" + k], p.grad.cpu().numpy()
+        if float(np.abs(ref).max()) < 1e-3 * gmax:
+            # (both sides hold rounding noise of a zero gradient: an absolute bar)
+            assert float(np.abs(got - ref).max()) < 1e-4 * gmax, k
+        else:
+            assert grad_rel_err(g, k, got) < 2e-3, k

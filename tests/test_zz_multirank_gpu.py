@@ -71,3 +71,28 @@ def test_two_rank_unet_equals_single_process_batch(cuda, tmp_path):
             assert torch.allclose(res[r]["params"][k], p, rtol=1e-4, atol=2e-6), k
     for k in params:
         assert torch.equal(res[0]["params"][k], res[1]["params"][k]), k
+
+
+@pytest.mark.gpu
+def test_single_rank_rccl_overlap_path(cuda, tmp_path):
+    """RCCL itself (backend "nccl", one rank on the one card) under the overlapped GradSync path:
+    hooks -> gather launch -> async all-reduce on the collective stream -> wait -> fused SGD. Two
+    steps of the small U-Net must reproduce the no-exchange run bit for bit; two backward passes in
+    one step must give twice the single-pass gradient (tests/rccl_worker.py)."""
+    import torch
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = ["timeout", "-k", "10", "300", sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"),
+           str(tmp_path)]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = torch.load(tmp_path / "rccl.pt")
+    assert res["losses"] == res["plain_losses"]
+    for k, p in res["plain"].items():
+        assert torch.equal(res["params"][k], p), k
+    scale = float(res["once"].abs().max())
+    assert float((res["twice"] - 2.0 * res["once"]).abs().max()) <= 1e-6 * scale
