@@ -712,27 +712,6 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     if (full) {
       stored = true;
       auto fast = [&](auto has_res) {
-        // EPI = 1: the site inputs of ALL this wave's tiles are fetched before the first store (the
-        // stores of one m-tile may alias the loads of the next as far as the compiler knows: left
-        // inside the m-tile loop every tile paid its own memory round trip)
-        float yall[EPI == 1 ? MT : 1][EPI == 1 ? NT : 1][16];
-        if constexpr (EPI == 1) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            const int tile = wm * MT + mt;
-            const unsigned rbase = (unsigned)(tile >> 1) * (unsigned)(a.Ho * a.Wo) +
-                                   (unsigned)((tile & 1) * 4 * a.Wo) + 4 * lh;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const float* yp = (adn_y[nt] != nullptr ? adn_y[nt] : colptr[nt]) +
-                                (size_t)rbase * rowmul[nt];
-              const unsigned dY = a.Wo * rowmul[nt], dX = rowmul[nt];
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                yall[mt][nt][r] = adn_y[nt] != nullptr ? yp[(r >> 2) * dY + (r & 3) * dX] : 0.f;
-            }
-          }
-        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int tile = wm * MT + mt;
@@ -756,7 +735,12 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
             if constexpr (EPI == 1) {
               if (adn_y[nt] != nullptr) {
                 // ---- dt and its two sums instead of dout (see ConvF16Extra::Adn) --------------
-                const float* yv = yall[mt][nt];
+                // (fetching the site inputs of ALL the wave's tiles ahead of the first store was
+                // measured and lost: 64 more live registers, step +0.15 ms)
+                const float* yp = adn_y[nt] + (size_t)rbase * rowmul[nt];
+                float yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yv[r] = yp[(r >> 2) * dY + (r & 3) * dX];
                 unsigned kw[16];
                 const unsigned ebase = adn_e0[nt] + rbase * (unsigned)rowmul[nt];
                 if (adn_mk[nt] != nullptr) {
@@ -916,9 +900,15 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
 // mode 0: conv [Cout=A][Cin=B][taps] -> column n = cout, k = cin, tap order kept
 // mode 1: same source -> column n = cin, k = cout, taps flipped (backward-data)
 // ---------------------------------------------------------------------------
+// (the column's taps x K source values are read ONCE, tap-fastest -- runs of `taps` contiguous floats,
+// the canonical layout's innermost axis -- into LDS when they fit, and both passes (absmax, split)
+// index the LDS copy; reading them k-fastest from global memory touched every 128-byte line ~27
+// times: 323 MB fetched per step to repack 33 MB of weights)
+constexpr int kPackLds = 8192;   // floats: 27 taps x 256 channels and 343 taps x 16 fit
 __device__ __forceinline__ void adell_pack_weight_f16_column(
     const float* __restrict__ w, _Float16* __restrict__ out, float* __restrict__ wscale,
     int mode, int A, int B, int taps, int n, float* smx) {
+  __shared__ float scol[kPackLds];
   const int N = mode == 0 ? A : B;   // GEMM columns
   const int K = mode == 0 ? B : A;   // GEMM depth
   const int nchunk = (K + 15) / 16;
@@ -926,8 +916,19 @@ __device__ __forceinline__ void adell_pack_weight_f16_column(
     return mode == 0 ? ((long)n * B + k) * taps + tap
                      : ((long)k * B + n) * taps + (taps - 1 - tap);
   };
+  const bool staged = taps * K <= kPackLds;
   float mx = 0.f;
-  for (int i = threadIdx.x; i < taps * K; i += 256) mx = fmaxf(mx, fabsf(w[src(i / K, i % K)]));
+  if (staged) {
+    // scol[k * taps + t] = w[...][t] (t = source tap index, before the flip of mode 1)
+    for (int i = threadIdx.x; i < taps * K; i += 256) {
+      const int k = i / taps, t = i - k * taps;
+      const float v = w[mode == 0 ? ((long)n * B + k) * taps + t : ((long)k * B + n) * taps + t];
+      scol[i] = v;
+      mx = fmaxf(mx, fabsf(v));
+    }
+  } else {
+    for (int i = threadIdx.x; i < taps * K; i += 256) mx = fmaxf(mx, fabsf(w[src(i / K, i % K)]));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
@@ -946,7 +947,9 @@ __device__ __forceinline__ void adell_pack_weight_f16_column(
     const int ch = (i >> 4) % nchunk;
     const int tap = (i >> 4) / nchunk;
     const int k = ch * 16 + j;
-    const float tsc = (k < K ? w[src(tap, k)] : 0.f) * scale;
+    float v = 0.f;
+    if (k < K) v = staged ? scol[k * taps + (mode == 0 ? tap : taps - 1 - tap)] : w[src(tap, k)];
+    const float tsc = v * scale;
     const _Float16 h = (_Float16)tsc;
     _Float16* o = out + (((long)tap * N + n) * nchunk + ch) * 32;
     o[j] = h;

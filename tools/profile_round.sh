@@ -1,10 +1,27 @@
+# Round profile of the bench workload (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r03a').
+# Four rocprofv3 runs of the SAME command, each with the program directly after `--`:
+#   1. --kernel-trace --stats        per-kernel time
+#   2. --pmc FETCH_SIZE              HBM read bytes   (separate passes: the TCC block cannot hold both)
+#   3. --pmc WRITE_SIZE              HBM write bytes
+#   4. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE   matrix-pipe busy + clock
+# then the plain (un-profiled) default bench line. Summaries: tools/rocpd_stats.py,
+# tools/pmc_traffic.py, tools/pmc_mfma.py -> copy into profiles/<tag>_*.
 set -e
+TAG=${1:-r03a}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/r02e
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r02e/stats -- python3 $R/bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-fp32 > $R/gpurun_out/r02e/bench_line.json 2> $R/gpurun_out/r02e/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r02e/pmcF -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 > $R/gpurun_out/r02e/pmcF.json 2> $R/gpurun_out/r02e/pmcF.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/r02e/pmcW -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 > $R/gpurun_out/r02e/pmcW.json 2> $R/gpurun_out/r02e/pmcW.err
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+ARGS="--steps 7 --warmup 3 --no-cpu-baseline --no-fp32 --no-secondary"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $ARGS > $O/bench_line.json 2> $O/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcF -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary > $O/pmcF.json 2> $O/pmcF.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcW -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary > $O/pmcW.json 2> $O/pmcW.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcM -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary > $O/pmcM.json 2> $O/pmcM.err
 cd $R
-python3 bench.py > gpurun_out/r02e/bench_plain.json 2> gpurun_out/r02e/bench_plain.err
-ls gpurun_out/r02e; find gpurun_out/r02e -name "*.csv" | head; du -sh gpurun_out/r02e
+python3 tools/rocpd_stats.py $O/stats > $O/kernel_stats.txt 2>&1 || true
+python3 tools/pmc_traffic.py $O/pmcF $O/pmcW $O/pmc_traffic.json $O/bench_line.json > /dev/null 2>&1 || true
+python3 tools/pmc_mfma.py $O/pmcM > $O/pmc_mfma_utilisation.txt 2>&1 || true
+python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+# keep the merge small: the raw traces stay on the box
+find $O -name "*.csv" -size +3M -delete
+ls $O; du -sh $O
