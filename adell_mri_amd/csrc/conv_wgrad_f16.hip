@@ -91,8 +91,10 @@ __global__ __launch_bounds__(256, MINB) void adell_conv_wgrad_f16_kernel(WgradF1
   char* sXl = sXh + xplane;
   char* sYh = sXl + xplane;
   char* sYl = sYh + yplane;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lh = lane >> 5;
+  // (the wave index is uniform: pinned to a scalar register so that the roles derived from it --
+  // sub-tile, tap group, k-group -- cost no vector registers)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lh = lane >> 5;
   const int region = blockIdx.x;
   const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
   const int ci0 = cit * a.TCI, co0 = cot * a.TCO;
@@ -392,12 +394,18 @@ __global__ __launch_bounds__(256, MINB) void adell_conv_wgrad_f16_kernel(WgradF1
   // ---- partial slab (undo the operand scales) --------------------------------
   const float unscale = __int_as_float((127 - kX - kY) << 23);
   const int ntap = a.KD * a.KH * a.KW;
-  const int co = co0 + cos * 32 + li;
+  // (the lane / wave roles are derived again from an opaque copy of the thread index: kept live
+  // across the region loop of the nine-accumulator instance they were spilled to scratch memory)
+  int tid_e = threadIdx.x;
+  asm volatile("" : "+v"(tid_e));
+  const int li_e = tid_e & 31, lh_e = (tid_e >> 5) & 1, sub_e = (tid_e >> 6) % nsub;
+  const int cis_e = sub_e % sci, cos_e = sub_e / sci;
+  const int co = co0 + cos_e * 32 + li_e;
 #pragma unroll
   for (int q = 0; q < MAXJ; ++q) {
     const int tl = tfirst + tstride * q;
     const int tap = (kz * a.KH + ky0) * a.KW + tl;
-    const int cib = ci0 + cis * 32 + 4 * lh;
+    const int cib = ci0 + cis_e * 32 + 4 * lh_e;
     float* base = a.ws + (((size_t)region * ntap + tap) * a.Cin + cib) * a.Cout + co;
     if (jok[q] && co < a.Cout) {
 #pragma unroll

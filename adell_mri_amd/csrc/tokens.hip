@@ -235,6 +235,12 @@ struct AttArgs {
   uint32_t seed_lo, seed_hi, rng_offset;
 };
 
+// word `i` (0..3) of a Philox block by selects (indexing a local array with a run-time index puts the
+// array in scratch memory)
+__device__ __forceinline__ uint32_t adell_word4(const uint4& r, unsigned i) {
+  return i == 0 ? r.x : (i == 1 ? r.y : (i == 2 ? r.z : r.w));
+}
+
 // Keep decision of probability (bh, qrow, kcol): a pure function of the seed, so the two
 // backward kernels regenerate the mask the forward applied.
 __device__ __forceinline__ bool adell_att_keep(const AttArgs& a, int bh, int qrow, int kcol) {
@@ -242,8 +248,7 @@ __device__ __forceinline__ bool adell_att_keep(const AttArgs& a, int bh, int qro
   const uint64_t e = ((uint64_t)bh * a.T + qrow) * a.T + kcol;
   const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34), a.rng_offset, 2u,
                                 a.seed_lo, a.seed_hi);
-  const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
-  return (float)(rr[e & 3] >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
+  return (float)(adell_word4(r, (unsigned)(e & 3)) >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
 }
 
 // The same decisions for the four consecutive keys kcol0 .. kcol0 + 3 of one query: element
@@ -259,11 +264,13 @@ __device__ __forceinline__ void adell_att_keep4(const AttArgs& a, int bh, int qr
   uint4 r1 = r0;
   if (b1 != b0)
     r1 = adell_philox4((uint32_t)b1, (uint32_t)(b1 >> 32), a.rng_offset, 2u, a.seed_lo, a.seed_hi);
-  const uint32_t w0[4] = {r0.x, r0.y, r0.z, r0.w}, w1[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint64_t e = e0 + j;
-    const uint32_t w = (e >> 2) == b0 ? w0[e & 3] : w1[e & 3];
+    const bool first = (e >> 2) == b0;      // (component-wise: a select of the structs goes
+    const unsigned i = (unsigned)(e & 3);   // through memory)
+    const uint32_t w = i == 0 ? (first ? r0.x : r1.x) : (i == 1 ? (first ? r0.y : r1.y) :
+                       (i == 2 ? (first ? r0.z : r1.z) : (first ? r0.w : r1.w)));
     keep[j] = (float)(w >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
   }
 }

@@ -24,12 +24,15 @@ _FIELDS = {"vgpr": r"VGPRs", "agpr": r"AGPRs", "sgpr": r"SGPRs",
 
 
 def demangle(names):
-    try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names),
-                             capture_output=True, text=True, check=True).stdout.splitlines()
-        return out if len(out) == len(names) else names
-    except Exception:
-        return names
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True,
+                                 check=True).stdout.splitlines()
+            if len(out) == len(names):
+                return out
+        except Exception:
+            continue
+    return names
 
 
 def parse(text):
