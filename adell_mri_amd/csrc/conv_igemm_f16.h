@@ -712,12 +712,34 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     if (full) {
       stored = true;
       auto fast = [&](auto has_res) {
+        // EPI = 1, one column tile per wave (the 32-column instances): the site inputs of m-tile
+        // mt + 1 are fetched BEFORE the stores of m-tile mt (which may alias them as far as the
+        // compiler knows), so each tile's memory round trip runs under the arithmetic of the
+        // previous one. 16 more live registers (all the wave's tiles at once -- 64 -- lost).
+        constexpr bool YPIPE = EPI == 1 && NT == 1;
+        float ynext[16];
+        auto fetch_y = [&](int mt_) {
+          const int tile_ = wm * MT + mt_;
+          const unsigned rb = (unsigned)(tile_ >> 1) * (unsigned)(a.Ho * a.Wo) +
+                              (unsigned)((tile_ & 1) * 4 * a.Wo) + 4 * lh;
+          const float* yp = (adn_y[0] != nullptr ? adn_y[0] : colptr[0]) + (size_t)rb * rowmul[0];
+          const unsigned dY = a.Wo * rowmul[0], dX = rowmul[0];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ynext[r] = yp[(r >> 2) * dY + (r & 3) * dX];
+        };
+        if constexpr (YPIPE) fetch_y(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int tile = wm * MT + mt;
           const unsigned rbase =
               (unsigned)(tile >> 1) * (unsigned)(a.Ho * a.Wo) + (unsigned)((tile & 1) * 4 * a.Wo) +
               4 * lh;
+          float ycur[16];
+          if constexpr (YPIPE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ycur[r] = ynext[r];
+            if (mt + 1 < MT) fetch_y(mt + 1);
+          }
           float resv[NT][16];
           if constexpr (has_res.value) {
 #pragma unroll
@@ -735,12 +757,15 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
             if constexpr (EPI == 1) {
               if (adn_y[nt] != nullptr) {
                 // ---- dt and its two sums instead of dout (see ConvF16Extra::Adn) --------------
-                // (fetching the site inputs of ALL the wave's tiles ahead of the first store was
-                // measured and lost: 64 more live registers, step +0.15 ms)
-                const float* yp = adn_y[nt] + (size_t)rbase * rowmul[nt];
                 float yv[16];
+                if constexpr (YPIPE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) yv[r] = yp[(r >> 2) * dY + (r & 3) * dX];
+                  for (int r = 0; r < 16; ++r) yv[r] = ycur[r];
+                } else {
+                  const float* yp = adn_y[nt] + (size_t)rbase * rowmul[nt];
+#pragma unroll
+                  for (int r = 0; r < 16; ++r) yv[r] = yp[(r >> 2) * dY + (r & 3) * dX];
+                }
                 unsigned kw[16];
                 const unsigned ebase = adn_e0[nt] + rbase * (unsigned)rowmul[nt];
                 if (adn_mk[nt] != nullptr) {

@@ -48,9 +48,11 @@ __global__ __launch_bounds__(256) void adell_stats_finalize_kernel(
 // First level of the two-level reduction used when there are many tiles: block
 // (cgroup, n, z) folds tiles [256 z, 256 z + 256) into one row of `out`
 // ([N][Z][C][2] floats, summed in fp64).
+// (pstride / poff: the channels may be columns [poff, poff + C) of rows pstride wide)
 __global__ __launch_bounds__(256) void adell_stats_fold_kernel(const float* __restrict__ part,
                                                                int ntiles, int C, int Z,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out,
+                                                               int pstride, int poff) {
   __shared__ double sh[8][32][2];
   const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl, n = blockIdx.y, z = blockIdx.z;
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(256) void adell_stats_fold_kernel(const float* __re
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
     for (int t = t0 + sl; t < t1; t += 8) {
-      const float2 v =
-          *reinterpret_cast<const float2*>(part + (((size_t)n * ntiles + t) * C + c) * 2);
+      const float2 v = *reinterpret_cast<const float2*>(
+          part + (((size_t)n * ntiles + t) * pstride + poff + c) * 2);
       s1 += (double)v.x;
       s2 += (double)v.y;
     }
@@ -99,7 +101,7 @@ extern "C" int adell_stats_finalize(const float* partials, int N, int ntiles, in
                   "stats_finalize: workspace too small");
     const int Z = (ntiles + 255) / 256;
     hipLaunchKernelGGL(adell_stats_fold_kernel, dim3(adell_cdiv(C, 32), N, Z), dim3(256), 0, st,
-                       partials, ntiles, C, Z, (float*)workspace);
+                       partials, ntiles, C, Z, (float*)workspace, C, 0);
     partials = (const float*)workspace;
     ntiles = Z;
   }
@@ -1041,11 +1043,23 @@ extern "C" int adell_norm_act_bwd_from_dt(const adell_norm_act_desc* d, const fl
   ADELL_REQUIRE(adell_is_pow2(d->C) && d->C % 4 == 0 && d->C <= 1024 &&
                     (((uintptr_t)x | (uintptr_t)dt | (uintptr_t)dx) & 15) == 0,
                 "norm_act_bwd_from_dt: needs a power-of-two C in 4..1024 and aligned tensors");
-  ADELL_REQUIRE(workspace_bytes >= sizeof(float) * 2 * (size_t)d->N * d->C,
+  // the fused epilogue leaves one row per BRICK (thousands per item): fold them 256 at a time
+  // first, on a grid that fills the chip (a single-level fold runs on C / 8 x N blocks: 80 us)
+  const int Z = ntiles > 512 ? (ntiles + 255) / 256 : 0;
+  ADELL_REQUIRE(workspace_bytes >= sizeof(float) * (2 + 2 * (size_t)Z) * d->N * d->C,
                 "norm_act_bwd_from_dt: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   float* c1 = (float*)workspace;
   float* c2 = c1 + (size_t)d->N * d->C;
+  if (Z > 0) {
+    float* folded = c2 + (size_t)d->N * d->C;
+    hipLaunchKernelGGL(adell_stats_fold_kernel, dim3(adell_cdiv(d->C, 32), (unsigned)d->N, Z),
+                       dim3(256), 0, st, partials, ntiles, d->C, Z, folded, pstride, poff);
+    partials = folded;
+    ntiles = Z;
+    pstride = d->C;
+    poff = 0;
+  }
   hipLaunchKernelGGL(adell_na_bwd_finalize_item_kernel, dim3(adell_cdiv(d->C, 8), (unsigned)d->N),
                      dim3(256), 0, st, partials, ntiles, d->C, (double)d->V, (const float*)nullptr,
                      c1, c2, pstride, poff);

@@ -882,7 +882,7 @@ def norm_act_bwd_from_dt(x, dt, mean, rstd, partials, poff=0):
     x, dt = ndhwc(x), ndhwc(dt)
     d = make_na_desc(x, "identity", 1)
     N, C = x.shape[:2]
-    ws = _workspace(8 * N * C, x.device)
+    ws = _workspace(4 * (2 + 2 * ((int(partials.shape[1]) + 255) // 256)) * N * C, x.device)
     check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_bwd_from_dt(
         ctypes.byref(d), _ptr(x), _ptr(dt), _ptr(mean), _ptr(rstd), _ptr(partials),
         int(partials.shape[1]), int(partials.shape[2]), int(poff), _ptr(dt), _ptr(ws),

@@ -317,7 +317,7 @@ int adell_norm_act_fwd_mask(const adell_norm_act_desc* d, const float* x, const 
  * dropout derivative (adell_conv3d_bwd_data_f16x3_adn): dx = rstd * (dt - c1 - xhat * c2) with
  * c1 / c2 the means of the partial sums. partials: [N][ntiles][pstride][2], the site's channels
  * at columns [poff, poff + C). dx may alias dt. Instance statistics, no affine parameters.
- * workspace: 2 * N * C floats. */
+ * workspace: (2 + 2 * ceil(ntiles / 256)) * N * C floats. */
 int adell_norm_act_bwd_from_dt(const adell_norm_act_desc* d, const float* x, const float* dt,
                                const float* mean, const float* rstd, const float* partials,
                                int ntiles, int pstride, int poff, float* dx, void* workspace,
