@@ -152,11 +152,13 @@ SIGNATURES = {
     "adell_conv_cinfold_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
+    "adell_conv_cinfold_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
     "adell_conv_cinfold_wgrad_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_bwd_weight": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5
                                       + [ctypes.c_size_t, _vp]),
     "adell_conv_cinfold_dx_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),
+    "adell_conv_cinfold_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),
     "adell_pair_loss_scratch_floats": (_l, [_i, _i]),
     "adell_pair_loss_fwd": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp]),
     "adell_pair_loss_bwd": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),

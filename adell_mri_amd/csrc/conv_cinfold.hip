@@ -179,6 +179,237 @@ __global__ __launch_bounds__(256) void adell_cinfold_fwd_kernel(CinFoldArgs a, i
   }
 }
 
+// ---------------------------------------------------------------------------
+// The forward for TWO input channels on the f16 MFMA (f16x3 splits, conv_igemm_f16.h): in the
+// [z][y][x][2 ch] halo image the six im2col values of one (kz, ky) pair -- (kx, ci) = (0,0) (0,1)
+// (1,0) (1,1) (2,0) (2,1) -- are three consecutive half2 words, so with the contraction ordered
+// (kz, ky) major an 8-half MFMA fragment is ONE pair (+ two zero-weight slots): K = 9 pairs x 8 =
+// 72, padded to 80 = five v_mfma_f32_32x32x16_f16 steps x 3 split products = 15 MFMAs of 32 cycles
+// per 32 voxels where the fp32 MFMA form above issues 27 of 64. The image holds split halves
+// (hi | lo planes of half2 words) scaled by a power of two from the brick's own absmax (one more
+// barrier per brick); the weights sit in registers as split fragments with a per-column scale.
+// ---------------------------------------------------------------------------
+typedef _Float16 cf_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cf_half2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int cf_scale_exp(float mx) {
+  const int ebits = (__float_as_int(mx) >> 23) & 0xff;
+  int k = 0;
+  if (ebits > 0 && ebits < 255) k = 13 - (ebits - 127);   // max lands in [2^13, 2^14)
+  if (k > 96) k = 96;
+  if (k < -96) k = -96;
+  return k;
+}
+
+__global__ __launch_bounds__(256) void adell_cinfold2_fwd_f16_kernel(CinFoldArgs a, int total_bricks,
+                                                                     int per) {
+  constexpr int HV = 600, HP = 608;                 // halo voxels, padded plane (reads run 1 word past a row)
+  __shared__ uint32_t xhi[2][HP], xlo[2][HP];       // half2 (ch 0, ch 1) per voxel
+  __shared__ float red[2][4][32][2];
+  __shared__ float smax[2][4];
+  // per-wave transpose tile of the epilogue: the MFMA result holds ONE column per lane (a dword per
+  // lane and row: 256 B per store instruction, in two pieces); through this tile a lane stores four
+  // consecutive columns of a voxel, a wave 8 voxels x 128 B = 1 KB per instruction
+  __shared__ __attribute__((aligned(16))) float tile[4][32][36];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32, col = n0 + li;
+  const bool colok = col < a.Cout;
+  const int nsp = a.ntx * a.nty * a.ntz;
+  const int b0 = blockIdx.x * per;
+  const int b1 = (b0 + per) < total_bricks ? (b0 + per) : total_bricks;
+  if (b0 >= b1) return;
+  // ---- this lane's weights: column `col`, pairs p = 2 s + lh, split with the column's scale -----
+  const float* wc = a.w + (size_t)(colok ? col : 0) * 54;      // [ci][27]
+  // (this lane's 30 values, all loads in flight at once: a rolled loop of dependent round trips
+  // took ~25 us per block; the two lane halves hold the even / odd pairs, i.e. all 54 between them)
+  float wv[5][6];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int p = 2 * s + lh;                         // (kz, ky) pair; p = 9 is padding
+#pragma unroll
+    for (int j = 0; j < 6; ++j)                       // (kx = j >> 1, ci = j & 1)
+      wv[s][j] = (p < 9 && colok) ? wc[(j & 1) * 27 + (p < 9 ? p : 0) * 3 + (j >> 1)] : 0.f;
+  }
+  float wmax = 0.f;
+#pragma unroll
+  for (int s = 0; s < 5; ++s)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wmax = fmaxf(wmax, fabsf(wv[s][j]));
+  wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+  const int kw = cf_scale_exp(wmax);
+  const float wsc = __int_as_float((kw + 127) << 23);
+  cf_half8 bh[5], bl[5];
+  int aoff[5];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int p = 2 * s + lh;
+    aoff[s] = p < 9 ? ((p / 3) * 10 + (p % 3)) * 10 : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = j < 6 ? wv[s][j] * wsc : 0.f;
+      const _Float16 h = (_Float16)v;
+      bh[s][j] = h;
+      bl[s][j] = (_Float16)(v - (float)h);
+    }
+  }
+  int abase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) abase[j] = (wave * 10 + 4 * j + (li >> 3)) * 10 + (li & 7);
+  const float bcol = (a.bias && colok) ? a.bias[col] : 0.f;
+  const float wun = __int_as_float((127 - kw) << 23);
+
+  float2 hv[3];                                       // this thread's halo voxels tid, tid + 256, tid + 512
+  auto fetch = [&](const CinFoldBrick& k) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = tid + 256 * u;
+      const int hx = i % 10, hy = (i / 10) % 10, hz = i / 100;
+      const int x = k.ox0 - a.PW + hx, y = k.oy0 - a.PH + hy, z = k.oz0 - a.PD + hz;
+      const bool ok = i < HV && x >= 0 && x < a.W && y >= 0 && y < a.H && z >= 0 && z < a.D;
+      const size_t off = ok ? ((((size_t)k.nb * a.D + z) * a.H + y) * a.W + x) * 2 : 0;
+      const float2 t = *reinterpret_cast<const float2*>(a.x + off);
+      hv[u] = ok ? t : make_float2(0.f, 0.f);
+    }
+  };
+  // block-wide absmax of the fetched halo -> its power-of-two scale (all threads return the same)
+  auto halo_scale = [&](int buf) -> int {
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) mx = fmaxf(mx, fmaxf(fabsf(hv[u].x), fabsf(hv[u].y)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) smax[buf][wave] = mx;
+    __syncthreads();
+    return cf_scale_exp(fmaxf(fmaxf(smax[buf][0], smax[buf][1]), fmaxf(smax[buf][2], smax[buf][3])));
+  };
+  auto put = [&](int buf, int kx) {
+    const float sc = __int_as_float((kx + 127) << 23);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = tid + 256 * u;
+      if (i < HV) {
+        const float t0 = hv[u].x * sc, t1 = hv[u].y * sc;
+        cf_half2 h, l;
+        h[0] = (_Float16)t0; h[1] = (_Float16)t1;
+        l[0] = (_Float16)(t0 - (float)h[0]); l[1] = (_Float16)(t1 - (float)h[1]);
+        xhi[buf][i] = *reinterpret_cast<uint32_t*>(&h);
+        xlo[buf][i] = *reinterpret_cast<uint32_t*>(&l);
+      }
+    }
+  };
+  if (tid < HP - HV) {   // the padding words are read (against zero weights): keep them finite
+    xhi[0][HV + tid] = xhi[1][HV + tid] = xlo[0][HV + tid] = xlo[1][HV + tid] = 0u;
+  }
+  CinFoldBrick cur = adell_cinfold_brick(a, b0, nsp);
+  fetch(cur);
+  int kcur = halo_scale(0);
+  put(0, kcur);
+  __syncthreads();
+  for (int b = b0; b < b1; ++b) {
+    const int buf = (b - b0) & 1;
+    CinFoldBrick nxt = cur;
+    const bool more = b + 1 < b1;
+    if (more) {
+      nxt = adell_cinfold_brick(a, b + 1, nsp);
+      fetch(nxt);                                       // in flight during the MFMAs below
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const uint32_t* ph = xhi[buf];
+    const uint32_t* pl = xlo[buf];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int o = abase[j] + aoff[s];
+        uint32_t wh[4], wl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          wh[q] = ph[o + q];
+          wl[q] = pl[o + q];
+        }
+        const cf_half8 ah = *reinterpret_cast<const cf_half8*>(wh);
+        const cf_half8 al = *reinterpret_cast<const cf_half8*>(wl);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[j], 0, 0, 0);
+      }
+    }
+    const float oscale = __int_as_float((127 - kcur) << 23) * wun;
+    float s1 = 0.f, s2 = 0.f;
+    const int oz = cur.oz0 + wave;
+    // whole 8 x 8 slice inside the volume and a whole, 16-byte aligned column tile: wide stores
+    const bool wide = cur.ox0 + 8 <= a.Wo && cur.oy0 + 8 <= a.Ho && oz < a.Do &&
+                      n0 + 32 <= a.Cout && (a.Cout & 3) == 0;
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float v = acc[j][r] * oscale + bcol;
+          tile[wave][row][li] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+        // rows 8 i .. 8 i + 7 are the eight x-neighbours of brick row y = 4 j + i
+        float* ybase = a.y + ((((size_t)cur.nb * a.Do + oz) * a.Ho + cur.oy0 + 4 * j) * a.Wo + cur.ox0) *
+                                 a.Cout + n0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 q = *reinterpret_cast<const float4*>(&tile[wave][8 * i + (lane >> 3)][4 * (lane & 7)]);
+          *reinterpret_cast<float4*>(ybase + ((size_t)i * a.Wo + (lane >> 3)) * a.Cout + 4 * (lane & 7)) = q;
+        }
+      }
+    } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // voxel of the M tile
+        const int ox = cur.ox0 + (row & 7), oy = cur.oy0 + 4 * j + (row >> 3);
+        if (colok && ox < a.Wo && oy < a.Ho && oz < a.Do) {
+          const float v = acc[j][r] * oscale + bcol;
+          a.y[((((size_t)cur.nb * a.Do + oz) * a.Ho + oy) * a.Wo + ox) * a.Cout + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    }
+    if (a.part) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lh == 0) {
+        red[buf][wave][li][0] = s1;
+        red[buf][wave][li][1] = s2;
+      }
+    }
+    int knext = kcur;
+    if (more) {           // (block-uniform)
+      knext = halo_scale(buf ^ 1);
+      put(buf ^ 1, knext);
+    }
+    __syncthreads();   // next halo image complete, this brick's statistics visible
+    if (a.part && tid < 32 && n0 + tid < a.Cout) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        t1 += red[buf][w][tid][0];
+        t2 += red[buf][w][tid][1];
+      }
+      float* p = a.part + (((size_t)cur.nb * nsp + cur.tile) * a.Cout + n0 + tid) * 2;
+      p[0] = t1;
+      p[1] = t2;
+    }
+    cur = nxt;
+    kcur = knext;
+  }
+}
+
 // Weight gradient. grid (blocks, ceil(Cout / 32)); a block walks bricks b = blockIdx.x,
 // blockIdx.x + gridDim.x, ... over all batch items and keeps dW[32 co][KP] in accumulators;
 // wave w takes the z = w slice of each brick (32 K steps of two voxels). The input halo image is
@@ -332,9 +563,28 @@ extern "C" int adell_conv_cinfold_ntiles(const adell_conv3d_desc* d) {
   return adell_cdiv(d->Wo, 8) * adell_cdiv(d->Ho, 8) * adell_cdiv(d->Do, 4);
 }
 
+static int adell_cinfold_fwd_impl(const adell_conv3d_desc* d, const float* x, const float* w,
+                                  const float* bias, float* y, float* stat_partials,
+                                  int f16x3, void* stream);
+
 extern "C" int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
                                       const float* bias, float* y, float* stat_partials,
                                       void* stream) {
+  return adell_cinfold_fwd_impl(d, x, w, bias, y, stat_partials, 0, stream);
+}
+
+// The same on the f16 MFMA with error-compensated splits (~2^-22 per product, the precision of
+// the other f16x3 conv entry points) for two input channels; other channel counts run the exact
+// fp32-MFMA kernel.
+extern "C" int adell_conv_cinfold_fwd_f16x3(const adell_conv3d_desc* d, const float* x,
+                                            const float* w, const float* bias, float* y,
+                                            float* stat_partials, void* stream) {
+  return adell_cinfold_fwd_impl(d, x, w, bias, y, stat_partials, 1, stream);
+}
+
+static int adell_cinfold_fwd_impl(const adell_conv3d_desc* d, const float* x, const float* w,
+                                  const float* bias, float* y, float* stat_partials,
+                                  int f16x3, void* stream) {
   ADELL_REQUIRE(x && w && y && adell_cinfold_ok(d),
                 "conv_cinfold_fwd: 3x3x3 stride-1 conv with 1..4 input channels expected");
   CinFoldArgs a = {};
@@ -349,6 +599,11 @@ extern "C" int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x
   if (per > 16) per = 16;
   dim3 grid((unsigned)((total + per - 1) / per), (unsigned)adell_cdiv(d->Cout, 32));
   hipStream_t st = (hipStream_t)stream;
+  if (f16x3 && d->C0 == 2 && (((uintptr_t)x & 7) == 0)) {
+    hipLaunchKernelGGL(adell_cinfold2_fwd_f16_kernel, grid, dim3(256), 0, st, a, (int)total, per);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   switch (d->C0) {
     case 1: hipLaunchKernelGGL(adell_cinfold_fwd_kernel<1>, grid, dim3(256), 0, st, a, (int)total, per); break;
     case 2: hipLaunchKernelGGL(adell_cinfold_fwd_kernel<2>, grid, dim3(256), 0, st, a, (int)total, per); break;
@@ -540,13 +795,211 @@ __global__ __launch_bounds__(256, 2) void adell_cinfold_dx_kernel(CinFoldDxArgs 
   }
 }
 
+// The same kernel with the per-voxel GEMM T = dY W on the f16 MFMA (f16x3 splits): the dY plane
+// image holds the 64-byte rows of conv_igemm_f16.h ([voxel][hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] per
+// 16-channel chunk, slots XOR-swizzled by (row >> 2) & 3), scaled by a power of two from the
+// PLANE's absmax (the reduction rides the barrier that already separates the steps); the weights
+// sit in registers as split fragments with one power-of-two scale per column (tap, ci).
+// K = Cout = 32: 2 chunks x 3 products x NTL tiles = 12 MFMAs of 32 cycles per 32 voxels where the
+// fp32 form issues 32 of 64 (the profile had this kernel at 63 % matrix-pipe busy).
+template <int CIN, int CO>
+__global__ __launch_bounds__(256, 2) void adell_cinfold_dx_f16_kernel(CinFoldDxArgs a) {
+  constexpr int KT = 27 * CIN, NTL = (KT + 31) / 32, KP = NTL * 32, NCH = CO / 16;
+  constexpr int TS = KP + 1;         // row stride of a T plane
+  extern __shared__ float smem[];
+  char* sdy = reinterpret_cast<char*>(smem);                       // [NCH][128 rows][64 B]
+  float* sT = smem + NCH * 128 * 16;                               // [128][TS]
+  float* smax = sT + 128 * TS;                                     // [2][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  int t = blockIdx.x;
+  const int tx = t % a.ntx;
+  t /= a.ntx;
+  const int ty = t % a.nty, seg = t / a.nty;
+  const int nb = blockIdx.y;
+  const int x0 = tx * 8, y0 = ty * 8;
+  const int z_beg = seg * a.seglen;
+  const int z_end = (z_beg + a.seglen) < a.D ? (z_beg + a.seglen) : a.D;
+  // weights of this lane: column j = nt * 32 + li = (tap, ci); fragment (chunk c): co 16 c + 8 lh + q
+  cf_half8 bh[NTL][NCH], bl[NTL][NCH];
+  float wun[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt) {
+    const int k = nt * 32 + li;
+    const int tap = k < KT ? k / CIN : 0, ci = k < KT ? k - tap * CIN : 0;
+    float wv[NCH][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int co = 16 * c + 8 * lh + q;
+        const bool ok = k < KT && co < a.Cout;
+        const float v = a.w[((size_t)(ok ? co : 0) * CIN + ci) * 27 + tap];
+        wv[c][q] = ok ? v : 0.f;
+        mx = fmaxf(mx, fabsf(wv[c][q]));
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));       // the column's other eight-channel halves
+    const int kw = cf_scale_exp(mx);
+    const float wsc = __int_as_float((kw + 127) << 23);
+    wun[nt] = __int_as_float((127 - kw) << 23);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v = wv[c][q] * wsc;
+        const _Float16 h = (_Float16)v;
+        bh[nt][c][q] = h;
+        bl[nt][c][q] = (_Float16)(v - (float)h);
+      }
+  }
+  constexpr int C4 = CO / 4, PIECES = (100 * C4 + 255) / 256;
+  float4 pre[PIECES];
+  auto fetch_plane = [&](int p) {
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) {
+      const int i = tid + 256 * u;
+      const int c4 = i % C4, r = i / C4;
+      const int hy = r / 10, hx = r - hy * 10;
+      const int yy = y0 + a.PH - 2 + hy, xx = x0 + a.PW - 2 + hx;   // dY coordinates
+      const bool ok = r < 100 && p >= 0 && p < a.Do && yy >= 0 && yy < a.Ho && xx >= 0 &&
+                      xx < a.Wo && 4 * c4 < a.Cout;
+      const size_t off =
+          ok ? ((((size_t)nb * a.Do + p) * a.Ho + yy) * a.Wo + xx) * a.Cout + 4 * c4 : 0;
+      const float4 f = *reinterpret_cast<const float4*>(a.dy + off);
+      pre[u] = ok ? f : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto plane_max = [&](int slot) {
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u)
+      mx = fmaxf(fmaxf(fmaxf(mx, fabsf(pre[u].x)), fmaxf(fabsf(pre[u].y), fabsf(pre[u].z))),
+                 fabsf(pre[u].w));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) smax[slot * 4 + wave] = mx;
+  };
+  auto put_plane = [&](float sc) {
+#pragma unroll
+    for (int u = 0; u < PIECES; ++u) {
+      const int i = tid + 256 * u;
+      const int c4 = i % C4, r = i / C4;
+      if (r < 100) {
+        // channels 4 c4 .. + 3 of row r: chunk c4 >> 2, halfs (c4 & 3) * 4 inside the chunk
+        const float v[4] = {pre[u].x * sc, pre[u].y * sc, pre[u].z * sc, pre[u].w * sc};
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 h, l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          h[q] = (_Float16)v[q];
+          l[q] = (_Float16)(v[q] - (float)h[q]);
+        }
+        const int sw = (r >> 2) & 3, slot = (c4 & 3) >> 1;
+        char* row = sdy + ((size_t)(c4 >> 2) * 128 + r) * 64 + (c4 & 1) * 8;
+        *reinterpret_cast<h4*>(row + ((slot ^ sw) << 4)) = h;
+        *reinterpret_cast<h4*>(row + (((2 + slot) ^ sw) << 4)) = l;
+      }
+    }
+  };
+  // rows 100..127 of the image are never written: zero them once (their T rows are never read)
+  for (int i = tid; i < NCH * 28 * 16; i += 256) {
+    const int c = i / (28 * 16), w = i - c * 28 * 16;
+    reinterpret_cast<float*>(sdy)[(c * 128 + 100) * 16 + w] = 0.f;
+  }
+  const int p_first = z_beg + a.PD - 2, p_last = z_end - 1 + a.PD;
+  float run[3] = {0.f, 0.f, 0.f};
+  fetch_plane(p_first);
+  int it = 0;
+  for (int p = p_first; p <= p_last; ++p, ++it) {
+    plane_max(it & 1);
+    __syncthreads();            // previous step's readers of sdy and of T are done; maxima visible
+    const float* sm = smax + (it & 1) * 4;
+    const int kd = cf_scale_exp(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])));
+    put_plane(__int_as_float((kd + 127) << 23));
+    __syncthreads();
+    if (p + 1 <= p_last) fetch_plane(p + 1);   // in flight during the MFMAs
+    f32x16 acc[NTL];
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const int rowi = wave * 32 + li;
+    const int sw = (rowi >> 2) & 3;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const char* row = sdy + ((size_t)c * 128 + rowi) * 64;
+      const cf_half8 ah = *reinterpret_cast<const cf_half8*>(row + ((lh ^ sw) << 4));
+      const cf_half8 al = *reinterpret_cast<const cf_half8*>(row + (((2 + lh) ^ sw) << 4));
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) {
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt][c], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt][c], acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt][c], acc[nt], 0, 0, 0);
+      }
+    }
+    const float dun = __int_as_float((127 - kd) << 23);
+#pragma unroll
+    for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sT[row * TS + nt * 32 + li] = acc[nt][r] * (dun * wun[nt]);
+      }
+    __syncthreads();
+    if (tid < 64 * CIN) {
+      const int ci = tid % CIN, v = tid / CIN, vy = v >> 3, vx = v & 7;
+#pragma unroll
+      for (int kz = 0; kz < 3; ++kz) {
+        float t9 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int r = (vy + 2 - ky) * 10 + (vx + 2 - kx);
+            t9 += sT[r * TS + ((kz * 3 + ky) * 3 + kx) * CIN + ci];
+          }
+        run[kz] += t9;
+      }
+      const int z = p - a.PD, yy = y0 + vy, xx = x0 + vx;
+      if (z >= z_beg && z < z_end && yy < a.H && xx < a.W)
+        a.dx[((((size_t)nb * a.D + z) * a.H + yy) * a.W + xx) * CIN + ci] = run[0];
+      run[0] = run[1];
+      run[1] = run[2];
+      run[2] = 0.f;
+    }
+  }
+}
+
 extern "C" int adell_conv_cinfold_dx_applicable(const adell_conv3d_desc* d) {
   return (adell_cinfold_ok(d) && d->Cout <= 64 && d->Cout % 4 == 0) ? 1 : 0;
 }
 
-template <int CIN>
-static void adell_cinfold_dx_launch(const CinFoldDxArgs& a, dim3 grid, hipStream_t st) {
+template <int CIN, int CO>
+static void adell_cinfold_dx_f16_launch(const CinFoldDxArgs& a, dim3 grid, hipStream_t st) {
   constexpr int KP = ((27 * CIN + 31) / 32) * 32;
+  const size_t lds = (size_t)((CO / 16) * 128 * 16 + 128 * (KP + 1) + 8) * sizeof(float);
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(adell_cinfold_dx_f16_kernel<CIN, CO>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    done = true;
+  }
+  hipLaunchKernelGGL((adell_cinfold_dx_f16_kernel<CIN, CO>), grid, dim3(256), lds, st, a);
+}
+
+template <int CIN>
+static void adell_cinfold_dx_launch(const CinFoldDxArgs& a, dim3 grid, hipStream_t st, int f16x3) {
+  constexpr int KP = ((27 * CIN + 31) / 32) * 32;
+  if (f16x3 && a.Cout <= 32) {
+    adell_cinfold_dx_f16_launch<CIN, 32>(a, grid, st);
+    return;
+  }
+  if constexpr (CIN < 4) {   // (4 channels x 64 columns: the split fragments do not fit 256 registers)
+    if (f16x3) {
+      adell_cinfold_dx_f16_launch<CIN, 64>(a, grid, st);
+      return;
+    }
+  }
   if (a.Cout <= 32) {
     const size_t lds = (size_t)(128 * 33 + 128 * (KP + 1)) * sizeof(float);
     static bool done = false;
@@ -568,8 +1021,22 @@ static void adell_cinfold_dx_launch(const CinFoldDxArgs& a, dim3 grid, hipStream
   }
 }
 
+static int adell_cinfold_bwd_data_impl(const adell_conv3d_desc* d, const float* dy, const float* w,
+                                       float* dx, int f16x3, void* stream);
+
 extern "C" int adell_conv_cinfold_bwd_data(const adell_conv3d_desc* d, const float* dy,
                                            const float* w, float* dx, void* stream) {
+  return adell_cinfold_bwd_data_impl(d, dy, w, dx, 0, stream);
+}
+
+// the same with the per-voxel GEMM on the f16 MFMA (error-compensated splits, ~2^-22 per product)
+extern "C" int adell_conv_cinfold_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
+                                                 const float* w, float* dx, void* stream) {
+  return adell_cinfold_bwd_data_impl(d, dy, w, dx, 1, stream);
+}
+
+static int adell_cinfold_bwd_data_impl(const adell_conv3d_desc* d, const float* dy, const float* w,
+                                       float* dx, int f16x3, void* stream) {
   ADELL_REQUIRE(dy && w && dx && adell_conv_cinfold_dx_applicable(d),
                 "conv_cinfold_bwd_data: 3x3x3 stride-1 conv, 1..4 input channels, Cout <= 64 "
                 "(multiple of 4) expected");
@@ -592,10 +1059,10 @@ extern "C" int adell_conv_cinfold_bwd_data(const adell_conv3d_desc* d, const flo
   dim3 grid((unsigned)(a.ntx * a.nty * a.nseg), (unsigned)d->N);
   hipStream_t st = (hipStream_t)stream;
   switch (d->C0) {
-    case 1: adell_cinfold_dx_launch<1>(a, grid, st); break;
-    case 2: adell_cinfold_dx_launch<2>(a, grid, st); break;
-    case 3: adell_cinfold_dx_launch<3>(a, grid, st); break;
-    default: adell_cinfold_dx_launch<4>(a, grid, st); break;
+    case 1: adell_cinfold_dx_launch<1>(a, grid, st, f16x3); break;
+    case 2: adell_cinfold_dx_launch<2>(a, grid, st, f16x3); break;
+    case 3: adell_cinfold_dx_launch<3>(a, grid, st, f16x3); break;
+    default: adell_cinfold_dx_launch<4>(a, grid, st, f16x3); break;
   }
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;

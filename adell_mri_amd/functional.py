@@ -210,7 +210,8 @@ class _Conv3dFn(torch.autograd.Function):
         ctx.cin_small = wp == "cin_small"
         ctx.cinfold = wp == "cinfold"
         if ctx.cinfold:
-            y, part = ops.conv_cinfold_fwd(x0, weight, bias, padding, want_stats)
+            y, part = ops.conv_cinfold_fwd(x0, weight, bias, padding, want_stats,
+                                           f16x3=CONV_PRECISION == "f16x3")
             ctx.small1 = False
             ctx.amax = None
             ctx.save_for_backward(x0, x1, weight)
@@ -296,7 +297,8 @@ class _Conv3dFn(torch.autograd.Function):
         amax = ctx.amax
         dy_amax = None
         if getattr(ctx, "cinfold", False) and need[0]:
-            dx0 = ops.conv_cinfold_bwd_data(dy, weight, tuple(x0.shape[2:]), padding)
+            dx0 = ops.conv_cinfold_bwd_data(dy, weight, tuple(x0.shape[2:]), padding,
+                                            f16x3=CONV_PRECISION == "f16x3")
         if dx0 is not None:
             pass
         elif ctx.cin_small and need[0] and dy.shape[1] % 4 == 0:

@@ -350,7 +350,8 @@ def conv_cinfold_ok(weight, x0, x1, stride, padding, residual):
             and all(0 <= p <= 1 for p in padding))
 
 
-def conv_cinfold_fwd(x, weight, bias, padding, want_stats):
+def conv_cinfold_fwd(x, weight, bias, padding, want_stats, f16x3=False):
+    """``f16x3``: the split-f16 MFMA kernel (two input channels) instead of the exact fp32 one."""
     _require_cuda(x, weight, bias)
     x = ndhwc(x)
     N, Cin, D, H, W = x.shape
@@ -364,10 +365,10 @@ def conv_cinfold_fwd(x, weight, bias, padding, want_stats):
         if nt < 0:
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x.device, dtype=torch.float32)
+    fn = _lib.lib().adell_conv_cinfold_fwd_f16x3 if f16x3 else _lib.lib().adell_conv_cinfold_fwd
     check(_timed("adell_cinfold_kernel", _conv_flops(d),
-                 lambda: _lib.lib().adell_conv_cinfold_fwd(
-                     ctypes.byref(d), _ptr(x), _ptr(wc), _ptr(bias), _ptr(y), _ptr(part),
-                     _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
+                 lambda: fn(ctypes.byref(d), _ptr(x), _ptr(wc), _ptr(bias), _ptr(y), _ptr(part),
+                            _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
     return y, part
 
 
@@ -391,7 +392,7 @@ def conv_cinfold_bwd_weight(x, dy, padding, want_db):
     return dw, db
 
 
-def conv_cinfold_bwd_data(dy, weight, in_size, padding):
+def conv_cinfold_bwd_data(dy, weight, in_size, padding, f16x3=False):
     """dx [N, Cin, *in_size] of a narrow-input conv, or None when the kernel does not take the
     shape (Cout > 64 or not a multiple of 4: the caller falls to the implicit-GEMM kernel)."""
     _require_cuda(dy, weight)
@@ -404,9 +405,10 @@ def conv_cinfold_bwd_data(dy, weight, in_size, padding):
         return None
     dx = new_act(N, Cin, *in_size, dy.device)
     wc = weight.contiguous()
+    fn = (_lib.lib().adell_conv_cinfold_bwd_data_f16x3 if f16x3
+          else _lib.lib().adell_conv_cinfold_bwd_data)
     check(_timed("adell_cinfold_kernel", _conv_flops(d),
-                 lambda: _lib.lib().adell_conv_cinfold_bwd_data(
-                     ctypes.byref(d), _ptr(dy), _ptr(wc), _ptr(dx), _stream()),
+                 lambda: fn(ctypes.byref(d), _ptr(dy), _ptr(wc), _ptr(dx), _stream()),
                  _conv_tag(d, "dgrad"), _conv_bytes(d)))
     return dx
 

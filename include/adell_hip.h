@@ -576,6 +576,10 @@ int adell_conv_cinfold_applicable(const adell_conv3d_desc* d);
 int adell_conv_cinfold_ntiles(const adell_conv3d_desc* d);
 int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
                            const float* bias, float* y, float* stat_partials, void* stream);
+/* the same arithmetic on the f16 MFMA with error-compensated operand splits (two input channels;
+ * other channel counts run the exact kernel above) */
+int adell_conv_cinfold_fwd_f16x3(const adell_conv3d_desc* d, const float* x, const float* w,
+                                 const float* bias, float* y, float* stat_partials, void* stream);
 long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d);
 int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x, const float* dy,
                                   float* dw, float* db, void* workspace, size_t workspace_bytes,
@@ -586,6 +590,9 @@ int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x, co
 int adell_conv_cinfold_dx_applicable(const adell_conv3d_desc* d);
 int adell_conv_cinfold_bwd_data(const adell_conv3d_desc* d, const float* dy, const float* w,
                                 float* dx, void* stream);
+/* the same with the per-voxel GEMM on the f16 MFMA with error-compensated operand splits */
+int adell_conv_cinfold_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy, const float* w,
+                                      float* dx, void* stream);
 
 /* 1x1x1 convolution with Cout <= 4 (the logits head, unet.py:712-731) on canonical weights
  * w [Cout][C0+C1]: one HBM-bound pass each way. `applicable` tells whether a descriptor takes

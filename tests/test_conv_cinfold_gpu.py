@@ -37,6 +37,19 @@ def test_cinfold_forward_and_weight_gradient_match_oracle(cuda, N, Cin, size, Co
     assert ops.conv_cinfold_ok(wd, xd, None, (1, 1, 1), (pad,) * 3, None) == (Cout > 4)
     y, part = ops.conv_cinfold_fwd(xd, wd, bd, (pad,) * 3, True)
     assert _rel(y.cpu().numpy(), ref) < 2e-6
+    # the split-f16 MFMA form (two input channels; the others run the same exact kernel): ~2^-22 per
+    # product, and statistics partials of what it wrote
+    y16, part16 = ops.conv_cinfold_fwd(xd, wd, bd, (pad,) * 3, True, f16x3=True)
+    assert _rel(y16.cpu().numpy(), ref) < 3e-6
+    m16, r16 = ops.stats_finalize(part16, int(np.prod(ref.shape[2:])), 1e-5)
+    np.testing.assert_allclose(m16.cpu().numpy(), ref.reshape(N, Cout, -1).mean(-1), rtol=1e-3,
+                               atol=1e-4)
+    if Cin == 2:    # a large dynamic range inside one tensor: the per-brick scale keeps 22 bits
+        big = xd * torch.logspace(-6, 6, xd.shape[2], device=cuda).view(1, 1, -1, 1, 1)
+        refb = cops.conv3d(big.cpu().numpy(), w, b, 1, pad)
+        yb, _ = ops.conv_cinfold_fwd(ops.ndhwc(big), wd, bd, (pad,) * 3, False, f16x3=True)
+        plane = np.abs(refb).max(axis=(0, 1, 3, 4), keepdims=True) + 1e-30
+        assert float((np.abs(yb.cpu().numpy() - refb) / plane).max()) < 2e-5
     V = int(np.prod(ref.shape[2:]))
     mean, rstd = ops.stats_finalize(part, V, 1e-5)
     np.testing.assert_allclose(mean.cpu().numpy(), ref.reshape(N, Cout, -1).mean(-1), rtol=1e-3,
@@ -48,10 +61,12 @@ def test_cinfold_forward_and_weight_gradient_match_oracle(cuda, N, Cin, size, Co
     assert _rel(dw.cpu().numpy(), dw_ref) < 5e-6
     assert _rel(db.cpu().numpy(), db_ref) < 5e-6
     dx = ops.conv_cinfold_bwd_data(dyd, wd, size, (pad,) * 3)
+    dx16 = ops.conv_cinfold_bwd_data(dyd, wd, size, (pad,) * 3, f16x3=True)   # split-f16 GEMM
     if Cout <= 64 and Cout % 4 == 0:
         assert _rel(dx.cpu().numpy(), dx_ref) < 5e-6
+        assert _rel(dx16.cpu().numpy(), dx_ref) < 5e-6
     else:
-        assert dx is None
+        assert dx is None and dx16 is None
     dw2, none = ops.conv_cinfold_bwd_weight(xd, dyd, (pad,) * 3, False)
     assert none is None and torch.equal(dw, dw2)      # deterministic fold order
 

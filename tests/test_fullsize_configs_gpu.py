@@ -91,7 +91,8 @@ def test_config5_swin_unet_full_size(cuda):
 
 
 def test_config4_vicreg_convnext_full_size(cuda):
-    """ssl-3d-convnext.yaml (cfg 4): two views of 16 crops of 64^3, VICReg, AdamW."""
+    """ssl-3d-convnext.yaml (cfg 4): two views of 32 crops of 64^3 (B = 32 per GPU),
+    VICReg, AdamW."""
     _, cfg = parse_config_ssl(os.path.join(CONFIGS, "ssl-3d-convnext.yaml"), 0.0, 1)
     cfg.pop("batch_size", None)
     cfg["vic_reg_loss_params"] = {}
@@ -103,7 +104,7 @@ def test_config4_vicreg_convnext_full_size(cuda):
     assert sum(p.numel() for p in net.parameters()) == 33862368
     assert (net.learning_rate, net.weight_decay) == (0.005, 0.001)
     g = torch.Generator().manual_seed(1)
-    x1 = torch.randn((16, 1, 64, 64, 64), generator=g).to(cuda)
+    x1 = torch.randn((32, 1, 64, 64, 64), generator=g).to(cuda)
     x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g).to(cuda)).flip(2)
     batch = {"augmented_image_1": x1, "augmented_image_2": x2}
     net.train()

@@ -71,6 +71,16 @@ dy2 = ops.ndhwc(torch.randn(batch, 32, *size, device=dev, generator=g))
 b2 = torch.randn(32, device=dev, generator=g)
 thin = big // 16
 put("cin2_fwd", timed(lambda: ops.conv_cinfold_fwd(x2, w2, b2, (1, 1, 1), True)), big + thin)
+try:
+    put("cin2_fwd_f16x3", timed(lambda: ops.conv_cinfold_fwd(x2, w2, b2, (1, 1, 1), True, f16x3=True)),
+        big + thin)
+except (TypeError, AttributeError):
+    pass     # an older build / binding without the split-f16 forward
 put("cin2_wgrad", timed(lambda: ops.conv_cinfold_bwd_weight(x2, dy2, (1, 1, 1), True)), big + thin)
 put("cin2_dx", timed(lambda: ops.conv_cinfold_bwd_data(dy2, w2, size, (1, 1, 1))), big + thin)
+try:
+    put("cin2_dx_f16x3", timed(lambda: ops.conv_cinfold_bwd_data(dy2, w2, size, (1, 1, 1), f16x3=True)),
+        big + thin)
+except (TypeError, AttributeError):
+    pass
 print(json.dumps(out))
