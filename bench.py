@@ -24,6 +24,8 @@ timed K steps, plus
 * ``cpu_baseline``: the stock-torch CPU oracle (rank 0, N = 1 only), 1 warm-up + 3 timed
   training steps on the host's physical cores, and a one-thread figure on a 64^3 volume;
 * ``fp32_mfma``: the same step on the bit-exact fp32-MFMA kernels (secondary figure);
+* ``secondary``: north_star's other workloads on the same module -- batch-1 128^3 and 256 x 256 x 128
+  volumes (3 warm-up + 5 timed steps each, with their own ``roofline.frac``);
 * ``median_ms_per_step``: median of per-step HIP-event times; ``value`` keeps
   the contract's definition (all K steps between two barriers).
 """
@@ -328,14 +330,16 @@ def main():
                      "dtype": "f32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains)"}
 
     # the other workloads north_star names, on the same module (every rank runs them: the gradient
-    # exchange inside a step is collective): 256 x 256 x 128 volumes and batch-1 128^3, 2 warm-up +
+    # exchange inside a step is collective): 256 x 256 x 128 volumes and batch-1 128^3, 3 warm-up +
     # 5 timed steps each with the dominant kernel family event-timed on every step
     secondary = {}
     if not args.no_secondary and args.shape is None and args.size == 128 and args.batch is None:
-        for key, sshape, sbatch in (("256x256x128_batch1", (256, 256, 128), 1),
-                                    ("128^3_batch1", (128, 128, 128), 1)):
+        # (the smaller workload first: it reuses the main run's memory pool; 3 warm-up steps, a new
+        # shape's first steps grow the pool and repack nothing else)
+        for key, sshape, sbatch in (("128^3_batch1", (128, 128, 128), 1),
+                                    ("256x256x128_batch1", (256, 256, 128), 1)):
             sb = synthetic_batch(sbatch, sshape, device, 142 + rank)
-            for _ in range(2):
+            for _ in range(3):
                 runner.train_step(sb)
             barrier()
             ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
@@ -344,7 +348,7 @@ def main():
             sdt = reduce_max(sdt, device)
             sec = {"value": sbatch * world * 5 / sdt, "unit": "volumes/s",
                    "ms_per_step": 1e3 * sdt / 5, "median_ms_per_step": statistics.median(sper),
-                   "steps": 5, "warmup": 2, "per_gpu_batch": sbatch, "size": list(sshape)}
+                   "steps": 5, "warmup": 3, "per_gpu_batch": sbatch, "size": list(sshape)}
             sdom = stimer.dominant()
             if sdom is not None:
                 sname, sflops, sms, slaunches = sdom
