@@ -38,6 +38,7 @@ static AdellTuning adell_tuning_from_env() {
   t.attn_nomfma = adell_env_set("ADELL_ATTN_NOMFMA");
   t.ws_min_items = adell_env_int("ADELL_WS_MIN_ITEMS", 1024);
   t.igemm_wide8 = adell_env_int("ADELL_IGEMM_WIDE8", 0);
+  t.ew_reverse = adell_env_int("ADELL_EW_REVERSE", 0);
 #ifdef ADELL_DEBUG
   t.igemm_dbg = adell_env_int("ADELL_IGEMM_DBG", 0);
   t.zr_dbg = adell_env_int("ADELL_ZR_DBG", 0);
@@ -63,6 +64,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "attn_nomfma")) return &g_adell_tune.attn_nomfma;
   if (!strcmp(name, "ws_min_items")) return &g_adell_tune.ws_min_items;
   if (!strcmp(name, "igemm_wide8")) return &g_adell_tune.igemm_wide8;
+  if (!strcmp(name, "ew_reverse")) return &g_adell_tune.ew_reverse;
 #ifdef ADELL_DEBUG
   if (!strcmp(name, "igemm_dbg")) return &g_adell_tune.igemm_dbg;
   if (!strcmp(name, "zr_dbg")) return &g_adell_tune.zr_dbg;

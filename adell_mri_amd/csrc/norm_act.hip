@@ -235,6 +235,7 @@ struct NormActArgs {
   int vec;             // C % 4 == 0: float4 path covers everything
   unsigned long long* mask;  // fast kernel: keep bits of the dropout (adell_norm_act_fwd_mask) or null
   long groups;               // 256-element groups per batch item in `mask`
+  int rev;                   // experiment: reversed block order (adell_ew_block)
 };
 
 // hat = (x-mean)*rstd*gamma+beta ; u = dropout(hat) ; out = act(u)
@@ -323,10 +324,19 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
 #ifndef ADELL_EW_CONTIG
 #define ADELL_EW_CONTIG 1
 #endif
+// EXPERIMENT ("ew_reverse" switch): visit the tensor in the reverse of the order the producing conv
+// wrote it (its blocks advance through eight XCD ranges at once, later batch items last), so that
+// the first reads find the most recently written lines still in the 256 MB Infinity Cache.
+__device__ __forceinline__ unsigned adell_ew_block(int rev) {
+  if (!rev) return blockIdx.x;
+  const unsigned nb = gridDim.x, per = nb >> 3;
+  if (per == 0 || (nb & 7)) return nb - 1 - blockIdx.x;
+  return (blockIdx.x & 7) * per + (per - 1 - (blockIdx.x >> 3));
+}
 #if ADELL_EW_CONTIG
 #define ADELL_EW_RANGE(n4)                                                                   \
   const long chunk_ = (((n4) + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;            \
-  const long jbeg = (long)blockIdx.x * chunk_;                                               \
+  const long jbeg = (long)adell_ew_block(a.rev) * chunk_;                         \
   const long jend = jbeg + chunk_ < (n4) ? jbeg + chunk_ : (n4);                             \
   const long j0 = jbeg + threadIdx.x;                                                        \
   const long stride = 256
@@ -357,6 +367,7 @@ static int adell_na_fill(NormActArgs* a, const adell_norm_act_desc* d) {
   a->seed_lo = (uint32_t)(d->seed & 0xffffffffu);
   a->seed_hi = (uint32_t)(d->seed >> 32);
   a->rng_offset = d->rng_offset;
+  a->rev = g_adell_tune.ew_reverse;
   return ADELL_OK;
 }
 
@@ -450,6 +461,7 @@ struct NormActBwdArgs {
   int C, stat_stride_n, act, act_w_n, ntiles;
   float act_p, drop_p;
   uint32_t seed_lo, seed_hi, rng_offset;
+  int rev;             // experiment: reversed block order (adell_ew_block)
 };
 
 __device__ __forceinline__ void adell_na_bwd_elem(const NormActBwdArgs& a, float x, float dout,
@@ -818,7 +830,7 @@ __device__ __forceinline__ void adell_na_consts(NaConst& k, const float* mean, c
 
 template <int ACT>
 __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArgs a) {
-  const int n = blockIdx.y;
+  const int n = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
   const long n4 = a.VC >> 2;  // float4 per item
   ADELL_EW_RANGE(n4);
   const int c = (int)((j0 << 2) & (a.C - 1));
