@@ -105,6 +105,8 @@ SIGNATURES = {
                                         + [ctypes.POINTER(AdnSite), ctypes.POINTER(AdnSite), _vp, _vp]),
     "adell_norm_act_bwd_workspace": (_l, [ctypes.POINTER(NormActDesc)]),
     "adell_norm_act_bwd": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 11 + [ctypes.c_size_t, _vp]),
+    "adell_norm_act_bwd_lowrank": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                        _vp, ctypes.c_size_t, _vp]),
     "adell_dice_focal_workspace": (_l, [_i, _l]),
     "adell_dice_focal_fwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_dice_focal_bwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _f, _f, _vp, _vp]),

@@ -315,6 +315,19 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
     case 7: hipLaunchKernelGGL(KERN<7>, grid, dim3(256), 0, st, args); break;                 \
     default: hipLaunchKernelGGL(KERN<8>, grid, dim3(256), 0, st, args); break;                \
   }
+// the same for the <ACT, true> instances (low-rank upstream gradient)
+#define ADELL_ACT_DISPATCH_LR(KERN, act, grid, st, args)                                      \
+  switch (act) {                                                                              \
+    case 0: hipLaunchKernelGGL((KERN<0, true>), grid, dim3(256), 0, st, args); break;         \
+    case 1: hipLaunchKernelGGL((KERN<1, true>), grid, dim3(256), 0, st, args); break;         \
+    case 2: hipLaunchKernelGGL((KERN<2, true>), grid, dim3(256), 0, st, args); break;         \
+    case 3: hipLaunchKernelGGL((KERN<3, true>), grid, dim3(256), 0, st, args); break;         \
+    case 4: hipLaunchKernelGGL((KERN<4, true>), grid, dim3(256), 0, st, args); break;         \
+    case 5: hipLaunchKernelGGL((KERN<5, true>), grid, dim3(256), 0, st, args); break;         \
+    case 6: hipLaunchKernelGGL((KERN<6, true>), grid, dim3(256), 0, st, args); break;         \
+    case 7: hipLaunchKernelGGL((KERN<7, true>), grid, dim3(256), 0, st, args); break;         \
+    default: hipLaunchKernelGGL((KERN<8, true>), grid, dim3(256), 0, st, args); break;        \
+  }
 #ifndef ADELL_EW_MAXBLOCKS
 #define ADELL_EW_MAXBLOCKS 65535
 #endif
@@ -462,6 +475,12 @@ struct NormActBwdArgs {
   float act_p, drop_p;
   uint32_t seed_lo, seed_hi, rng_offset;
   int rev;             // experiment: reversed block order (adell_ew_block)
+  // low-rank upstream gradient (fast kernels): dout[v][c] = sum_o lr_g[v][o] lr_w[o][c], o < lr_co
+  // <= 4 -- the backward-data of a 1x1x1 conv with <= 4 output channels (the logits head,
+  // unet.py:626-655) folded into the site's backward: dout is never materialised
+  const float* lr_g;   // [N][V][lr_co] or null
+  const float* lr_w;   // [lr_co][C]
+  int lr_co, lr_shift; // lr_shift = log2(C) - 2: float4 index -> voxel
 };
 
 __device__ __forceinline__ void adell_na_bwd_elem(const NormActBwdArgs& a, float x, float dout,
@@ -700,8 +719,8 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_kernel(NormActBwdArgs 
   }
 }
 
-template <int ACT> __global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
-template <int ACT> __global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
+template <int ACT, bool LR = false> __global__ void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a);
+template <int ACT, bool LR = false> __global__ void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a);
 // blocks per item of the grid-strided partials kernel (each covers >= 1024 float4)
 static long adell_na_fast_blocks(long V, int C) {
   long bx = ((V * C >> 2) + 256 * 4 - 1) / (256 * 4);
@@ -740,14 +759,51 @@ extern "C" long adell_norm_act_bwd_workspace(const adell_norm_act_desc* d) {
   return (long)sizeof(float) * (d->N * nt * d->C * 2 + 2 * d->N * d->C);
 }
 
+static int adell_norm_act_bwd_impl(const adell_norm_act_desc* d, const float* x,
+                                   const float* dout, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const float* act_w,
+                                   float* dx, float* dgamma, float* dbeta, void* workspace,
+                                   size_t workspace_bytes, void* stream, const float* lr_g,
+                                   const float* lr_w, int lr_co);
+
 extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
                                   const float* dout, const float* mean, const float* rstd,
                                   const float* gamma, const float* beta, const float* act_w,
                                   float* dx, float* dgamma, float* dbeta, void* workspace,
                                   size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(dout, "norm_act_bwd: null pointer");
+  return adell_norm_act_bwd_impl(d, x, dout, mean, rstd, gamma, beta, act_w, dx, dgamma, dbeta,
+                                 workspace, workspace_bytes, stream, nullptr, nullptr, 0);
+}
+
+// The same with a LOW-RANK upstream gradient dout[v][c] = sum_o g[v][o] w[o][c] (g: [N][V][co],
+// w: [co][C], co <= 4): the site in front of a 1x1x1 conv with <= 4 output channels (the logits
+// head: Conv3d -> ADN -> Conv3d(C -> 1, k = 1), unet.py:626-655) takes that conv's dY and weight
+// and never sees -- nor does anyone write -- its full-size backward-data result. Needs the
+// bandwidth-tuned kernels (power-of-two C in 4..1024, aligned tensors).
+extern "C" int adell_norm_act_bwd_lowrank(const adell_norm_act_desc* d, const float* x,
+                                          const float* g, const float* w, int co,
+                                          const float* mean, const float* rstd, float* dx,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(d && g && w && co >= 1 && co <= 4, "norm_act_bwd_lowrank: 1..4 factors expected");
+  ADELL_REQUIRE(adell_is_pow2(d->C) && d->C >= 4 && d->C <= 1024 &&
+                    (((uintptr_t)x | (uintptr_t)dx) & 15) == 0,
+                "norm_act_bwd_lowrank: needs a power-of-two C in 4..1024 and aligned tensors");
+  return adell_norm_act_bwd_impl(d, x, x, mean, rstd, nullptr, nullptr, nullptr, dx, nullptr,
+                                 nullptr, workspace, workspace_bytes, stream, g, w, co);
+}
+
+static int adell_norm_act_bwd_impl(const adell_norm_act_desc* d, const float* x,
+                                   const float* dout, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, const float* act_w,
+                                   float* dx, float* dgamma, float* dbeta, void* workspace,
+                                   size_t workspace_bytes, void* stream, const float* lr_g,
+                                   const float* lr_w, int lr_co) {
   NormActBwdArgs a = {};
   int rc = adell_nab_fill(&a, d);
   if (rc != ADELL_OK) return rc;
+  a.lr_g = lr_g; a.lr_w = lr_w; a.lr_co = lr_co;
+  a.lr_shift = adell_ilog2(d->C) - 2;
   ADELL_REQUIRE(x && dout && dx, "norm_act_bwd: null pointer");
   ADELL_REQUIRE((mean == nullptr) == (rstd == nullptr), "norm_act_bwd: mean/rstd mismatch");
   hipStream_t st = (hipStream_t)stream;
@@ -768,8 +824,13 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
     dim3 grid(a.ntiles, (unsigned)d->N);
     if (fast) {
       a.ntiles = (int)adell_na_fast_blocks(d->V, d->C);
-      ADELL_ACT_DISPATCH(adell_na_bwd_partials_fast_kernel, d->act,
-                         dim3(a.ntiles, (unsigned)d->N), st, a);
+      if (lr_g) {
+        ADELL_ACT_DISPATCH_LR(adell_na_bwd_partials_fast_kernel, d->act,
+                              dim3(a.ntiles, (unsigned)d->N), st, a);
+      } else {
+        ADELL_ACT_DISPATCH(adell_na_bwd_partials_fast_kernel, d->act,
+                           dim3(a.ntiles, (unsigned)d->N), st, a);
+      }
     } else if (vec)
       hipLaunchKernelGGL(adell_na_bwd_partials_kernel<true>, grid, dim3(256), 0, st, a);
     else
@@ -788,8 +849,13 @@ extern "C" int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x,
     long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
     if (bx > ADELL_EW_MAXBLOCKS) bx = ADELL_EW_MAXBLOCKS;
     if (bx < 1) bx = 1;
-    ADELL_ACT_DISPATCH(adell_na_bwd_apply_fast_kernel, d->act, dim3((unsigned)bx, (unsigned)d->N),
-                       st, a);
+    if (lr_g) {
+      ADELL_ACT_DISPATCH_LR(adell_na_bwd_apply_fast_kernel, d->act,
+                            dim3((unsigned)bx, (unsigned)d->N), st, a);
+    } else {
+      ADELL_ACT_DISPATCH(adell_na_bwd_apply_fast_kernel, d->act,
+                         dim3((unsigned)bx, (unsigned)d->N), st, a);
+    }
   } else if (vec)
     hipLaunchKernelGGL(adell_na_bwd_apply_kernel<true>, dim3(adell_ew_blocks(nw)), dim3(256), 0,
                        st, a);
@@ -826,6 +892,32 @@ __device__ __forceinline__ void adell_na_consts(NaConst& k, const float* mean, c
     k.c1[j] = c1 ? c1[sbase + c + j] : 0.f;
     k.c2[j] = c2 ? c2[sbase + c + j] : 0.f;
   }
+}
+
+// this thread's rows of the low-rank weight: w[o][c .. c + 3]
+struct NaLowRank {
+  float w[4][4];
+};
+__device__ __forceinline__ void adell_na_lr_load(NaLowRank& l, const NormActBwdArgs& a, int c) {
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      l.w[o][q] = o < a.lr_co ? a.lr_w[o * a.C + c + q] : 0.f;
+}
+// dout quad jj of item n from the low-rank factors (voxel = jj >> lr_shift)
+__device__ __forceinline__ float4 adell_na_lr_dout(const NaLowRank& l, const NormActBwdArgs& a,
+                                                   int n, long jj) {
+  const float* g = a.lr_g + ((long)n * a.V + (jj >> a.lr_shift)) * a.lr_co;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+    if (o < a.lr_co) {
+      const float gv = g[o];
+      r.x = fmaf(gv, l.w[o][0], r.x); r.y = fmaf(gv, l.w[o][1], r.y);
+      r.z = fmaf(gv, l.w[o][2], r.z); r.w = fmaf(gv, l.w[o][3], r.w);
+    }
+  return r;
 }
 
 template <int ACT>
@@ -884,7 +976,7 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
   }
 }
 
-template <int ACT>
+template <int ACT, bool LR>
 __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwdArgs a) {
   const int n = blockIdx.y;
   const long n4 = a.VC >> 2;
@@ -898,13 +990,15 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
   float4* dxo = reinterpret_cast<float4*>(a.dx) + (long)n * n4;
   const bool norm = a.mean != nullptr;
+  NaLowRank lr;
+  if (LR) adell_na_lr_load(lr, a, c);
   for (long j = j0; j < jend; j += stride * ADELL_EW_UNROLL) {
     float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u)
       if (j + u * stride < jend) {
         xv[u] = xin[j + u * stride];
-        gv[u] = gin[j + u * stride];
+        gv[u] = LR ? adell_na_lr_dout(lr, a, n, j + u * stride) : gin[j + u * stride];
       }
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u) {
@@ -934,7 +1028,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
 // grid (blocks per item, N), grid-strided like the apply kernel: a thread keeps one channel
 // quad, accumulates (sum dt, sum dt*xhat) over its whole share in registers, and the block
 // folds its 256 / (C/4) threads per quad once at the end (fixed order).
-template <int ACT>
+template <int ACT, bool LR>
 __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormActBwdArgs a) {
   __shared__ float sh[8][256];
   const int n = blockIdx.y;
@@ -948,13 +1042,15 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
   float A[4] = {0.f, 0.f, 0.f, 0.f}, B[4] = {0.f, 0.f, 0.f, 0.f};
+  NaLowRank lr;
+  if (LR) adell_na_lr_load(lr, a, c);
   for (long j = j0; j < jend; j += stride * ADELL_EW_UNROLL) {
     float4 xv[ADELL_EW_UNROLL], gv[ADELL_EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u)
       if (j + u * stride < jend) {
         xv[u] = xin[j + u * stride];
-        gv[u] = gin[j + u * stride];
+        gv[u] = LR ? adell_na_lr_dout(lr, a, n, j + u * stride) : gin[j + u * stride];
       }
 #pragma unroll
     for (int u = 0; u < ADELL_EW_UNROLL; ++u) {

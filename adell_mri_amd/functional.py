@@ -33,7 +33,9 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_s2class": bool(os.environ.get("ADELL_NO_S2CLASS")),
          "no_fold": bool(os.environ.get("ADELL_NO_FOLD")),
          # norm / dropout / activation backward left to its own two passes (no fused epilogue)
-         "no_adn_fuse": bool(os.environ.get("ADELL_NO_ADN_FUSE"))}
+         "no_adn_fuse": bool(os.environ.get("ADELL_NO_ADN_FUSE")),
+         # the logits head's backward-data tensor is formed (no factored site backward)
+         "no_lowrank": bool(os.environ.get("ADELL_NO_LOWRANK"))}
 
 
 def set_conv_precision(mode):
@@ -283,7 +285,11 @@ class _Conv3dFn(torch.autograd.Function):
         C0 = x0.shape[1]
         C1 = 0 if x1 is None else x1.shape[1]
         if ctx.small1:
-            if need[0] or (x1 is not None and need[1]):
+            if ctx.adn is not None and need[0]:
+                # dX = dy (x) weight stays factored: a stride-0 placeholder goes down the graph
+                ctx.adn[1].lowrank = (dy, weight.detach())
+                dx0 = dy.new_zeros(()).expand(x0.shape)
+            elif need[0] or (x1 is not None and need[1]):
                 dx0, dx1 = ops.conv1_small_bwd_data(dy, weight, tuple(x0.shape[2:]), C0, C1)
                 dx0 = dx0 if need[0] else None
                 dx1 = dx1 if (x1 is not None and need[1]) else None
@@ -428,12 +434,16 @@ class AdnSite:
     when its epilogue produced dt and the partial sums; the site's own backward then runs ONE
     elementwise pass (ops.norm_act_bwd_from_dt) instead of two."""
 
-    __slots__ = ("x", "mean", "rstd", "mask", "drop_p", "act", "act_p", "fused", "part", "poff")
+    __slots__ = ("x", "mean", "rstd", "mask", "drop_p", "act", "act_p", "fused", "part", "poff",
+                 "lowrank")
 
     def __init__(self, x, mean, rstd, mask, drop_p, act, act_p):
         self.x, self.mean, self.rstd, self.mask = x, mean, rstd, mask
         self.drop_p, self.act, self.act_p = drop_p, act, act_p
         self.fused, self.part, self.poff = False, None, 0
+        # (dy, weight) of a 1x1x1 consumer with <= 4 output channels: its backward-data result is
+        # never formed, the site's backward reads the two factors (ops.norm_act_bwd_lowrank)
+        self.lowrank = None
 
 
 def single_use(t):
@@ -483,6 +493,12 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
     if small1:
         wp = None
+        # the logits head behind a single-use site: the site's backward takes (dy, weight)
+        site = getattr(x0, "_adell_site", None) if getattr(x0, "_adell_single", False) else None
+        if (site is not None and x1 is None and carry_in is None and carry_x0 is None
+                and not FLAGS["no_adn_fuse"] and not FLAGS["no_lowrank"]
+                and torch.is_grad_enabled() and ops.norm_act_lowrank_ok(x0, weight.shape[0])):
+            conf = conf[:-1] + (("lowrank", site),)
     elif ops.conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
         wp = "cin_small"
     elif ops.conv_cinfold_ok(weight, x0, x1, stride, padding, residual):
@@ -568,6 +584,12 @@ class _NormDropActFn(torch.autograd.Function):
         if site is not None:
             fused, part, poff = site.fused, site.part, site.poff
             site.fused, site.part = False, None
+            lowrank, site.lowrank = site.lowrank, None
+            if lowrank is not None:
+                dx = ops.norm_act_bwd_lowrank(x, lowrank[0], lowrank[1], mean, rstd, act,
+                                              act_p=act_p, drop_p=drop_p, seed=seed,
+                                              rng_offset=offset)
+                return dx, None, None, None, None, None, None
             if fused:
                 # dout is dt: the consumer's backward-data epilogue applied act' / dropout and
                 # left the two sums of the normalisation's backward in `part`

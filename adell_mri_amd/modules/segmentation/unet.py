@@ -367,8 +367,7 @@ class UNet(torch.nn.Module):
     # ---- forward (unet.py:751-843) --------------------------------------------
     def _final(self, layer, X, return_logits):
         mods = list(layer)
-        for mod in mods[:-1]:
-            X = mod(X)
+        X = _run_rest(mods[:-1], X)
         if return_logits is True:
             return X
         if isinstance(mods[-1], torch.nn.Sigmoid):

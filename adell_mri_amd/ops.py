@@ -930,6 +930,32 @@ def norm_act_bwd(x, dout, mean, rstd, act, gamma=None, beta=None, act_w=None, ac
     return dx, dgamma, dbeta
 
 
+def norm_act_lowrank_ok(x, co):
+    """Whether norm_act_bwd_lowrank takes this site: power-of-two channels, <= 4 factors."""
+    C = x.shape[1]
+    return 1 <= co <= 4 and 4 <= C <= 1024 and (C & (C - 1)) == 0
+
+
+def norm_act_bwd_lowrank(x, g, w, mean, rstd, act, act_p=0.0, drop_p=0.0, seed=0, rng_offset=0):
+    """dx of norm_act_fwd when the upstream gradient is g (x) w: g [N, co, ...] the gradient of a
+    1x1x1 conv's output, w [co, C] its weight -- that conv's backward-data result is never formed
+    (adell_norm_act_bwd_lowrank)."""
+    _require_cuda(x, g, w, mean, rstd)
+    x, g = ndhwc(x), ndhwc(g)
+    co = g.shape[1]
+    w = w.reshape(co, x.shape[1]).contiguous()
+    assert g.shape[0] == x.shape[0] and g.shape[2:] == x.shape[2:]
+    d = make_na_desc(x, act, 1, act_p, 0, drop_p, seed, rng_offset)
+    dx = new_act(*x.shape, x.device)
+    ws = _workspace(_lib.lib().adell_norm_act_bwd_workspace(ctypes.byref(d)), x.device)
+    # algorithmic bytes: read x and g once, write dx once
+    nb = 8.0 * x.numel() + 4.0 * g.numel()
+    check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_bwd_lowrank(
+        ctypes.byref(d), _ptr(x), _ptr(g), _ptr(w), co, _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(ws),
+        ws.numel() * 4, _stream()), "bwd", nb))
+    return dx
+
+
 def dice_focal_fwd(prob, target, smooth, dice_eps, gamma, focal_eps):
     """Per-item (dice[B], focal[B]) and the sums the backward needs. prob/target: [B, ...]."""
     _require_cuda(prob, target)

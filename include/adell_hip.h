@@ -333,6 +333,16 @@ int adell_norm_act_bwd(const adell_norm_act_desc* d, const float* x, const float
                        const float* beta, const float* act_w, float* dx, float* dgamma,
                        float* dbeta, void* workspace, size_t workspace_bytes,
                        void* stream);
+/* adell_norm_act_bwd with a LOW-RANK upstream gradient dout[v][c] = sum_o g[v][o] * w[o][c]
+ * (g: [N][V][co] channels-last, w: [co][C], 1 <= co <= 4): the site in front of a 1x1x1 conv with
+ * few output channels -- the logits head Conv3d -> ADN -> Conv3d(C -> n_classes, k = 1) of
+ * lib/modules/segmentation/unet.py:626-655 -- takes that conv's dY and weight, and the conv's
+ * backward-data tensor is neither written nor read. Instance statistics without affine
+ * parameters; power-of-two C in 4..1024, 16-byte aligned x / dx; workspace as for
+ * adell_norm_act_bwd. */
+int adell_norm_act_bwd_lowrank(const adell_norm_act_desc* d, const float* x, const float* g,
+                               const float* w, int co, const float* mean, const float* rstd,
+                               float* dx, void* workspace, size_t workspace_bytes, void* stream);
 /* Gradient of the PReLU weight(s) of the same fused op (torch.nn.PReLU is the reference's
  * default activation_fn): dact_w[act_w_n] with act_w_n = 1 or C; operands as above. */
 long adell_prelu_wgrad_workspace(const adell_norm_act_desc* d);

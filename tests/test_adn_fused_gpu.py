@@ -159,3 +159,89 @@ def test_residual_block_matches_torch_autograd(cuda, monkeypatch):
     assert _rel(gx.cpu().double(), xc.grad) <= 1e-4
     assert _rel(gw["op.0.weight"].cpu().double(), ws[0].grad) <= 1e-4
     assert _rel(gw["op.2.weight"].cpu().double(), ws[1].grad) <= 1e-4
+
+
+@pytest.mark.parametrize("n,c,co,size", [(2, 32, 1, (16, 16, 24)), (1, 16, 3, (8, 12, 20)),
+                                         (2, 64, 4, (8, 8, 8)), (1, 32, 2, (40, 24, 8))])
+@pytest.mark.parametrize("act,p", [("swish", 0.1), ("relu", 0.0), ("leaky_relu", 0.25)])
+def test_lowrank_site_backward_equals_conv_backward_data_then_site(cuda, n, c, co, size, act, p):
+    """The site in front of the 1x1x1 logits conv (unet.py:626-655): its backward from (dy, w)
+    against the 1x1x1 backward-data kernel followed by the ordinary site backward."""
+    from adell_mri_amd import ops
+
+    g = torch.Generator().manual_seed(c + 7 * co)
+    site, _ = _site(cuda, g, n, c, size, act, p, 21)
+    w = (torch.randn(co, c, 1, 1, 1, generator=g) * 0.3).to(cuda)
+    dy = ops.ndhwc(torch.randn(n, co, *size, generator=g).to(cuda))
+    assert ops.norm_act_lowrank_ok(site.x, co)
+    da, _ = ops.conv1_small_bwd_data(dy, w, size, c, 0)
+    want, _, _ = ops.norm_act_bwd(site.x, da, site.mean, site.rstd, act, act_p=site.act_p,
+                                  drop_p=p, seed=21, rng_offset=7)
+    got = ops.norm_act_bwd_lowrank(site.x, dy, w, site.mean, site.rstd, act, act_p=site.act_p,
+                                   drop_p=p, seed=21, rng_offset=7)
+    assert _rel(got, want) <= 2e-6
+    # without a normalisation in the site: the elementwise pass alone
+    want, _, _ = ops.norm_act_bwd(site.x, da, None, None, act, act_p=site.act_p, drop_p=p,
+                                  seed=21, rng_offset=7)
+    got = ops.norm_act_bwd_lowrank(site.x, dy, w, None, None, act, act_p=site.act_p, drop_p=p,
+                                   seed=21, rng_offset=7)
+    assert _rel(got, want) <= 2e-6
+
+
+def test_lowrank_rejects_what_the_kernels_do_not_cover(cuda):
+    from adell_mri_amd import ops
+    from adell_mri_amd._lib import AdellHipError
+
+    x = ops.ndhwc(torch.randn(1, 24, 4, 4, 4).to(cuda))        # 24 channels: not a power of two
+    mean, rstd = ops.instance_stats(x)
+    assert not ops.norm_act_lowrank_ok(x, 1)
+    with pytest.raises(AdellHipError):
+        ops.norm_act_bwd_lowrank(x, ops.ndhwc(torch.randn(1, 1, 4, 4, 4).to(cuda)),
+                                 torch.randn(1, 24, 1, 1, 1).to(cuda), mean, rstd, "swish")
+    x = ops.ndhwc(torch.randn(1, 32, 4, 4, 4).to(cuda))
+    assert not ops.norm_act_lowrank_ok(x, 5)
+
+
+def test_head_gradients_do_not_depend_on_the_lowrank_site(cuda, monkeypatch):
+    """conv -> ADN -> conv 1x1x1 (C -> 1) -> sigmoid as the U-Net builds its final layer: the same
+    parameter and input gradients with the switch off, and the 1x1x1 backward-data kernel does not
+    run with it on."""
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+    from adell_mri_amd.modules.segmentation.unet import UNet
+
+    torch.manual_seed(3)
+    from adell_mri_amd.modules.layers.adn_fn import activation_factory
+    net = UNet(spatial_dimensions=3, upscale_type="transpose", norm_type="instance", padding=1,
+               dropout_param=0.1, activation_fn=activation_factory["swish"], in_channels=2,
+               n_classes=2, depth=[16, 32], kernel_sizes=[3, 3], strides=[2, 2]).to(cuda)
+    x = torch.randn(2, 2, 16, 16, 16, device=cuda)
+    t = (torch.rand(2, 1, 16, 16, 16, device=cuda) > 0.5).float()
+    calls = []
+    real = ops.conv1_small_bwd_data
+    monkeypatch.setattr(ops, "conv1_small_bwd_data", lambda *a, **k: calls.append(1) or real(*a, **k))
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        xx = x.clone().requires_grad_(True)
+        out = net(xx)
+        prob = out[0] if isinstance(out, tuple) else out
+        loss = ((prob - t) ** 2).mean()
+        loss.backward()
+        return prob.detach(), xx.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()
+                                                if p.grad is not None}
+
+    net.train()
+    import itertools as it
+    monkeypatch.setattr(HF, "_dropout_counter", it.count(100))
+    y_f, gx_f, gw_f = run()
+    assert not calls, "the 1x1x1 backward-data kernel ran although the site takes (dy, w)"
+    monkeypatch.setitem(HF.FLAGS, "no_adn_fuse", True)
+    monkeypatch.setattr(HF, "_dropout_counter", it.count(100))
+    y_p, gx_p, gw_p = run()
+    assert calls
+    assert torch.equal(y_f, y_p)
+    scale = max(float(v.abs().max()) for v in gw_p.values())
+    assert _rel(gx_f, gx_p) <= 5e-5
+    for k in gw_p:
+        assert float((gw_f[k] - gw_p[k]).abs().max()) <= 5e-5 * scale, k
