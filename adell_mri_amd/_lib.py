@@ -62,6 +62,7 @@ SIGNATURES = {
     "adell_pack_weight_f16x3_bytes": (_l, [_i, _i, _i, _i]),
     "adell_pack_weight_f16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "adell_conv3d_fwd_ntiles_f16x3": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_fwd_ntiles_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10),
     "adell_conv3d_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
     "adell_pack_weight_f16x3_multi": (_i, [_vp, _i, _l, _vp]),

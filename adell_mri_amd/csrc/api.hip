@@ -39,6 +39,7 @@ static AdellTuning adell_tuning_from_env() {
   t.ws_min_items = adell_env_int("ADELL_WS_MIN_ITEMS", 1024);
   t.igemm_wide8 = adell_env_int("ADELL_IGEMM_WIDE8", 0);
   t.ew_reverse = adell_env_int("ADELL_EW_REVERSE", 0);
+  t.fold_coarse = adell_env_int("ADELL_FOLD_COARSE", 0);
 #ifdef ADELL_DEBUG
   t.igemm_dbg = adell_env_int("ADELL_IGEMM_DBG", 0);
   t.zr_dbg = adell_env_int("ADELL_ZR_DBG", 0);
@@ -65,6 +66,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "ws_min_items")) return &g_adell_tune.ws_min_items;
   if (!strcmp(name, "igemm_wide8")) return &g_adell_tune.igemm_wide8;
   if (!strcmp(name, "ew_reverse")) return &g_adell_tune.ew_reverse;
+  if (!strcmp(name, "fold_coarse")) return &g_adell_tune.fold_coarse;
 #ifdef ADELL_DEBUG
   if (!strcmp(name, "igemm_dbg")) return &g_adell_tune.igemm_dbg;
   if (!strcmp(name, "zr_dbg")) return &g_adell_tune.zr_dbg;

@@ -28,6 +28,7 @@ struct AdellTuning {
   int igemm_ws, ws_min_items;   // persistent wave-specialised conv instance: opt-in / size gate
   int igemm_wide8;                // 64-column tile of the large 3^3 layers on 8x8x8 bricks, 8 waves
   int ew_reverse;                 // norm / activation forward: reverse of the producer's write order
+  int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)
   int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;

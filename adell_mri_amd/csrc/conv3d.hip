@@ -584,6 +584,20 @@ __global__ __launch_bounds__(256) void adell_conv_splitk_fold_kernel(ConvFoldArg
   }
 }
 
+// Voxel ranges (= blocks per batch item, = statistics partial rows per item) of the fold over the K
+// shares: the conv that needs split-K has few bricks (16 per item at 16^3), and a fold on that many
+// blocks streamed its 4 x 4 MB of slabs at a twentieth of the chip's bandwidth (20-53 us per call,
+// 24 calls per step) -- the fold gets its own, finer partition: ~512 blocks in all.
+static int adell_fold_tiles(long vox, int N, int Cout, long bricks) {
+  if (g_adell_tune.fold_coarse) return (int)bricks;
+  const int rstep = 256 / (Cout / 4);          // voxel rows a block covers per pass
+  long tiles = adell_cdiv(512, N);
+  const long most = adell_cdiv(vox, rstep);
+  if (tiles > most) tiles = most;
+  if (tiles < 1) tiles = 1;
+  return (int)tiles;
+}
+
 // number of K shares for this problem (1 = no split) given the planned tile
 static int adell_splitk_shares(const ConvArgs& a, const ConvTile& t, int N) {
   if (g_adell_tune.no_splitk) return 1;
@@ -635,7 +649,13 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
   ConvArgs full = a;
   int shares = ws ? adell_splitk_shares(a, t, N) : 1;
   const long slab = (long)N * a.Do * a.Ho * a.Wo * a.Cout;
-  if (shares > 1 && (size_t)shares * slab * sizeof(float) > ws_bytes) shares = 1;
+  if (shares > 1 && (size_t)shares * slab * sizeof(float) > ws_bytes) {
+    // (the statistics rows of the split form are the fold's, adell_conv3d_fwd_ntiles_f16x3_ws:
+    // falling back to one share here would write a different number of rows)
+    adell_set_error("conv f16x3: split-K workspace too small (%zu bytes, adell_conv3d_splitk_workspace)",
+                    ws_bytes);
+    return ADELL_E_BADARG;
+  }
   a.ksplit = shares;
   a.slab = slab;
   if (shares > 1) a.y0 = (float*)ws;
@@ -715,9 +735,9 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
   ConvFoldArgs f = {};
   f.slabs = (const float*)ws; f.bias = full.bias; f.res = full.res; f.y0 = full.y0; f.y1 = full.y1;
   f.part = full.part; f.vox = (long)a.Do * a.Ho * a.Wo; f.slab = slab; f.ksplit = shares;
-  f.Cout = a.Cout; f.ysplit = full.ysplit; f.ntiles = (int)nsp;
-  hipLaunchKernelGGL(adell_conv_splitk_fold_kernel, dim3((unsigned)nsp, (unsigned)N), dim3(256), 0,
-                     st, f);
+  f.Cout = a.Cout; f.ysplit = full.ysplit; f.ntiles = adell_fold_tiles(f.vox, N, a.Cout, nsp);
+  hipLaunchKernelGGL(adell_conv_splitk_fold_kernel, dim3((unsigned)f.ntiles, (unsigned)N), dim3(256),
+                     0, st, f);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
@@ -730,6 +750,22 @@ extern "C" int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d) {
   ConvTile t;
   size_t lds;
   if (adell_plan_f16(a, d->N, &t, &lds) != ADELL_OK) return ADELL_E_UNSUPPORTED;
+  return a.ntx * a.nty * a.ntz;
+}
+
+// Statistics partial rows per batch item that adell_conv3d_fwd_f16x3_ws writes (called with the
+// workspace adell_conv3d_splitk_workspace asks for): the fold's voxel ranges when the layer runs
+// split-K, else the bricks.
+extern "C" int adell_conv3d_fwd_ntiles_f16x3_ws(const adell_conv3d_desc* d) {
+  ConvArgs a;
+  float dummy;
+  if (adell_fill_fwd(a, d, &dummy, &dummy, nullptr, nullptr, &dummy, nullptr) != ADELL_OK)
+    return ADELL_E_BADARG;
+  ConvTile t;
+  size_t lds;
+  if (adell_plan_f16(a, d->N, &t, &lds) != ADELL_OK) return ADELL_E_UNSUPPORTED;
+  if (adell_splitk_shares(a, t, d->N) > 1)
+    return adell_fold_tiles((long)a.Do * a.Ho * a.Wo, d->N, a.Cout, (long)a.ntx * a.nty * a.ntz);
   return a.ntx * a.nty * a.ntz;
 }
 

@@ -10,7 +10,9 @@
 // output brick is a 9 x 9 x 5 halo of 51 KB -- where the halo of the whole brick (17 x 17 x 9
 // voxels, 333 KB) fits no LDS, which is why the implicit-GEMM kernel runs this layer on 64-voxel
 // bricks at one wave per SIMD (0.56 ms at 2 x 128^3 for 0.1 ms of MFMA work and 0.13 ms of HBM).
-// Here a persistent block (one per CU, 4 waves)
+// Here a persistent block (one per CU, 8 waves: a wave alone on its SIMD issues one vector
+// instruction per 4 cycles, two waves one per 2 -- and the staging arithmetic, not memory, was what
+// the four-wave form spent its time on)
 //   * keeps the whole split weight (27 x 32 x 32 x (hi, lo) = 108 KB) in LDS for its lifetime,
 //   * walks the eight sub-lattices of a brick: stage + split one 51 KB halo, run its taps into the
 //     SAME 2 x 16 accumulator registers per wave, while the halos of the next TWO sub-lattices are
@@ -32,10 +34,12 @@ namespace {
 constexpr int kHX = 9, kHY = 9, kHZ = 5, kHV = kHX * kHY * kHZ;
 constexpr int kWBytes = 27 * 2 * 32 * 64;
 constexpr int kABytes = kHV * 128;
-constexpr int kRedFloats = 4 * 32 * 2;                       // statistics fold: [wave][channel][2]
-constexpr int kLds = kWBytes + kABytes + 32 + kRedFloats * 4;
+constexpr int kThreads = 512, kWaves = kThreads / 64;
+constexpr int kRedFloats = 4 * 32 * 2;                       // statistics fold: [plane][channel][2]
+constexpr int kLds = kWBytes + kABytes + 64 + kRedFloats * 4;
+static_assert(kLds <= 160 * 1024, "one block per CU: weights + one halo image");
 constexpr int kItems = kHV * 8;
-constexpr int kPer = (kItems + 255) / 256;
+constexpr int kPer = (kItems + kThreads - 1) / kThreads;
 
 template <typename T>
 __device__ __forceinline__ ADELL_GLOBAL T* uniform_ptr(T* p) {
@@ -72,12 +76,12 @@ struct FwdS2Args {
 // DBG: timing experiments (-DADELL_DEBUG builds only; results are wrong when nonzero): 1 no MFMAs,
 // 2 no y stores / statistics, 8 no halo split / LDS stores, 16 no halo loads after the first phase
 template <int DBG>
-__global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a) {
+__global__ __launch_bounds__(kThreads, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a) {
   extern __shared__ char smem[];
   char* sW = smem;
   char* sA = smem + kWBytes;
   float* sMax = reinterpret_cast<float*>(sA + kABytes);
-  float* sRed = sMax + 8;
+  float* sRed = sMax + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int q = tid & 7;
@@ -100,46 +104,85 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
   // one-tap sub-lattice runs 12 MFMAs per wave: far less than a memory round trip)
   float4 fbuf[2][kPer];
   unsigned okbuf[2] = {0u, 0u};
+  // Per-item constants of this thread, computed ONCE (the staging arithmetic -- two divisions, six
+  // comparisons, the swizzled LDS address per 16 bytes -- was what the kernel spent its time on, not
+  // memory): position of item u in the halo, its element offset from the halo origin in x, its
+  // LDS byte address (hi half; the lo half is that ^ 32).
+  unsigned hpos[kPer], reloff[kPer], ldsoff[kPer];
+  unsigned okstatic = 0;
+#pragma unroll
+  for (int u = 0; u < kPer; ++u) {
+    const int it = tid + kThreads * u;
+    const bool in = it < kItems;
+    const int hv = in ? it >> 3 : 0;
+    const int hz = hv / (kHX * kHY), rem = hv - hz * (kHX * kHY);
+    const int hy = rem / kHX, hx = rem - hy * kHX;
+    hpos[u] = (unsigned)(hx | (hy << 8) | (hz << 16));
+    reloff[u] = (unsigned)((2 * hz * a.H + 2 * hy) * a.W + 2 * hx) * 32u + 4u * q;
+    const int sw = (hv >> 2) & 3, slot = (q & 3) >> 1;
+    ldsoff[u] = (unsigned)((q >> 2) * (kHV * 64) + hv * 64 + (q & 1) * 8 + ((slot ^ sw) << 4));
+    okstatic |= in ? (1u << u) : 0u;
+  }
+  // origin of the brick whose sub-lattices are being fetched (moves on with sub-lattice 0)
+  int pf_nb = 0, pf_ox0 = 0, pf_oy0 = 0, pf_oz0 = 0;
   auto prefetch = [&](int phase, float4 (&f)[kPer], unsigned& okbits) {
-    const int t = blockIdx.x + (phase >> 3) * gridDim.x, cls = phase & 7;
-    int nb, tile, ox0, oy0, oz0;
-    brick_origin(t, nb, tile, ox0, oy0, oz0);
+    const int cls = phase & 7;
+    if (cls == 0) {
+      int tile;
+      brick_origin(blockIdx.x + (phase >> 3) * gridDim.x, pf_nb, tile, pf_ox0, pf_oy0, pf_oz0);
+      pf_nb = __builtin_amdgcn_readfirstlane(pf_nb);
+      pf_ox0 = __builtin_amdgcn_readfirstlane(pf_ox0);
+      pf_oy0 = __builtin_amdgcn_readfirstlane(pf_oy0);
+      pf_oz0 = __builtin_amdgcn_readfirstlane(pf_oz0);
+    }
     const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-    const int bz = 2 * (oz0 - 1) + pz, by = 2 * (oy0 - 1) + py, bx = 2 * (ox0 - 1) + px;
-    const ADELL_GLOBAL float* src = uniform_ptr(a.x + (size_t)nb * a.D * a.H * a.W * 32);
-    int tt = tid;
-    asm volatile("" : "+v"(tt));   // (keeps the per-item arithmetic inside the loop: see conv_dgrad_s2.hip)
-    okbits = 0;
+    const int bz = 2 * (pf_oz0 - 1) + pz, by = 2 * (pf_oy0 - 1) + py, bx = 2 * (pf_ox0 - 1) + px;
+    const ADELL_GLOBAL float* src = uniform_ptr(a.x + (size_t)pf_nb * a.D * a.H * a.W * 32);
+    // a halo that lies inside the volume (72 % of the bricks at 128^3): origin + constant offsets
+    const bool inside = (bz >= 0) & (by >= 0) & (bx >= 0) & (bz + 2 * (kHZ - 1) < a.D) &
+                        (by + 2 * (kHY - 1) < a.H) & (bx + 2 * (kHX - 1) < a.W);
+    unsigned rel[kPer];
+    if (inside) {
+      const unsigned base = (unsigned)((bz * a.H + by) * a.W + bx) * 32u;
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) rel[u] = base + reloff[u];
+      okbits = okstatic | 0x80000000u;      // (bit 31: nothing to mask)
+    } else {
+      const int base = ((bz * a.H + by) * a.W + bx) * 32;
+      okbits = 0;
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        const int hx = hpos[u] & 255, hy = (hpos[u] >> 8) & 255, hz = hpos[u] >> 16;
+        const int iz = bz + 2 * hz, iy = by + 2 * hy, ix = bx + 2 * hx;
+        const bool ok = ((okstatic >> u) & 1u) & (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) &
+                        (ix >= 0) & (ix < a.W);
+        rel[u] = ok ? (unsigned)(base + (int)reloff[u]) : 0u;
+        okbits |= ok ? (1u << u) : 0u;
+      }
+    }
+    // ONE fetch site for both cases (two sites meeting in a phi made the register copies wait
+    // for the loads)
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
-      const int it = tt + 256 * u;
-      const int hv = it >> 3;
-      const int hz = hv / (kHX * kHY), rem = hv - hz * (kHX * kHY);
-      const int hy = rem / kHX, hx = rem - hy * kHX;
-      const int iz = bz + 2 * hz, iy = by + 2 * hy, ix = bx + 2 * hx;
-      const bool ok = (it < kItems) & (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) & (ix >= 0) &
-                      (ix < a.W);
-      const unsigned rel = ok ? (unsigned)((iz * a.H + iy) * a.W + ix) * 32u + 4u * q : 0u;
-      const f32x4 v = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(src + rel);
+      const f32x4 v = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(src + rel[u]);
       f[u] = make_float4(v.x, v.y, v.z, v.w);
-      okbits |= ok ? (1u << u) : 0u;
     }
   };
 
   // ---- the split weight, once: global row (tap * 32 + n) * 2 + chunk -> [tap][chunk][n] ---------
   // (a plain strided loop: a register array of nine rows per pass ended up in scratch memory)
-#pragma unroll 9
-  for (int it = tid; it < 27 * 256; it += 256) {
+#pragma unroll 7
+  for (int it = tid; it < 27 * 256; it += kThreads) {
     const float4 v = *reinterpret_cast<const float4*>(a.wpack + (size_t)it * 16);
     const int slot = it & 3, row = it >> 2;
     const int ch = row & 1, n = (row >> 1) & 31, tap = row >> 6;
     *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v;
   }
 
-  // A rows of this lane at offset (0, 0, 0): wave w = output plane z = w; m-tile mt: y = 4 mt .. + 3
-  int arow[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) arow[mt] = (wave * kHY + (li >> 3) + 4 * mt) * kHX + (li & 7);
+  // A rows of this lane at offset (0, 0, 0): wave w = output plane z = w & 3, rows y = 4 wm .. + 3
+  // with wm = w >> 2 (one 32-voxel m-tile per wave)
+  const int wz = wave & 3, wm = wave >> 2;
+  const int arow = (wz * kHY + (li >> 3) + 4 * wm) * kHX + (li & 7);
   const int bsw = (li >> 2) & 3;
   const int boffh = li * 64 + ((lh ^ bsw) << 4), boffl = li * 64 + (((2 + lh) ^ bsw) << 4);
   const float wsc = a.wscale[li];
@@ -149,7 +192,7 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
   const int my_bricks = ((int)blockIdx.x < a.nbricks)
                             ? (a.nbricks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int nphases = my_bricks * 8;
-  f32x16 acc[2];
+  f32x16 acc;
   int kprev = 0;
   // one phase = one sub-lattice of one brick.
   // iteration ph: issue the loads of phase ph (into register image ph & 1), run the MFMAs of phase
@@ -177,57 +220,55 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
                 constexpr int tz = pz ? 2 * sz : 1, ty = py ? 2 * sy : 1, tx = px ? 2 * sx : 1;
                 constexpr int dz = pz ? sz : 1, dy = py ? sy : 1, dx = px ? sx : 1;
                 constexpr int tap = (tz * 3 + ty) * 3 + tx;
-                half8 ah[2], al[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                  const int hv = arow[mt] + (dz * kHY + dy) * kHX + dx;
-                  const int sw = (hv >> 2) & 3;
-                  const char* row = sAc + hv * 64;
-                  ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
-                  al[mt] = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
-                }
+                const int hv = arow + (dz * kHY + dy) * kHX + dx;
+                const int sw = (hv >> 2) & 3;
+                const char* row = sAc + hv * 64;
+                const half8 ah = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
+                const half8 al = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
                 const char* bt = sW + (tap * 2 + ch) * (32 * 64);
                 const half8 bh = *reinterpret_cast<const half8*>(bt + boffh);
                 const half8 bl = *reinterpret_cast<const half8*>(bt + boffl);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                  acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt], 0, 0, 0);
-                  acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt], 0, 0, 0);
-                  acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt], 0, 0, 0);
-                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
               }
             });
           });
         }
       });
       if (cls == 7) {
-        // ---- epilogue of the brick: C row r of m-tile mt = output (x = (r & 3) + 4 lh, y = (r >> 2) + 4 mt)
+        // ---- epilogue of the brick: C row r = output (x = (r & 3) + 4 lh, y = (r >> 2) + 4 wm)
         const int t = blockIdx.x + ((ph - 2) >> 3) * gridDim.x;
         int nb, tile, ox0, oy0, oz0;
         brick_origin(t, nb, tile, ox0, oy0, oz0);
         const float oscale = __int_as_float((127 - kprev) << 23) * wsc;
-        const int z = oz0 + wave;
+        const int z = oz0 + wz;
         float s1 = 0.f, s2 = 0.f;
         if (z < a.Do && !(DBG & 2)) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int x = ox0 + (r & 3) + 4 * lh, yy = oy0 + (r >> 2) + 4 * mt;
-              if (x < a.Wo && yy < a.Ho) {
-                const float v = acc[mt][r] * oscale + bcol;
-                a.y[((((size_t)nb * a.Do + z) * a.Ho + yy) * a.Wo + x) * 32 + li] = v;
-                s1 += v;
-                s2 += v * v;
-              }
+          for (int r = 0; r < 16; ++r) {
+            const int x = ox0 + (r & 3) + 4 * lh, yy = oy0 + (r >> 2) + 4 * wm;
+            if (x < a.Wo && yy < a.Ho) {
+              const float v = acc[r] * oscale + bcol;
+              a.y[((((size_t)nb * a.Do + z) * a.Ho + yy) * a.Wo + x) * 32 + li] = v;
+              s1 += v;
+              s2 += v * v;
             }
+          }
         }
         if (a.part) {
+          // fold in a fixed order: lane halves, then the two row groups of a plane (waves w + 4
+          // hand theirs to waves w through sRed), then the four planes
           s1 += __shfl_xor(s1, 32, 64);
           s2 += __shfl_xor(s2, 32, 64);
-          if (lh == 0) {
-            sRed[(wave * 32 + li) * 2 + 0] = s1;
-            sRed[(wave * 32 + li) * 2 + 1] = s2;
+          if (lh == 0 && wm == 1) {
+            sRed[(wz * 32 + li) * 2 + 0] = s1;
+            sRed[(wz * 32 + li) * 2 + 1] = s2;
+          }
+          __syncthreads();
+          if (lh == 0 && wm == 0) {
+            sRed[(wz * 32 + li) * 2 + 0] += s1;
+            sRed[(wz * 32 + li) * 2 + 1] += s2;
           }
           __syncthreads();
           if (tid < 32) {
@@ -248,22 +289,29 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
       float4 (&f)[kPer] = fbuf[1 - B];
       const unsigned okbits = okbuf[1 - B];
       // ---- mask, absmax -> power-of-two scale of this sub-lattice halo ----------------------------
+      // (an image fetched from inside the volume needs no mask: the items past the end of the
+      // halo were read from its first voxel and change no maximum)
       float mx = 0.f;
+      if (!(okbits >> 31)) {
 #pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        const bool ok = (okbits >> u) & 1u;
-        f[u] = make_float4(ok ? f[u].x : 0.f, ok ? f[u].y : 0.f, ok ? f[u].z : 0.f, ok ? f[u].w : 0.f);
-        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f[u].x)), fmaxf(fabsf(f[u].y), fabsf(f[u].z))), fabsf(f[u].w));
+        for (int u = 0; u < kPer; ++u) {
+          const bool ok = (okbits >> u) & 1u;
+          f[u] = make_float4(ok ? f[u].x : 0.f, ok ? f[u].y : 0.f, ok ? f[u].z : 0.f, ok ? f[u].w : 0.f);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < kPer; ++u)
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f[u].x)), fmaxf(fabsf(f[u].y), fabsf(f[u].z))), fabsf(f[u].w));
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
       // (two sMax rows used in turn: a row is rewritten two phases after it was read, with a
       // barrier in between, so one barrier serves "fragments of phase ph - 2 are read" and "the
       // four wave maxima are visible")
-      float* sm = sMax + 4 * (ph & 1);
+      float* sm = sMax + kWaves * (ph & 1);
       if (lane == 0) sm[wave] = mx;
       __syncthreads();
-      mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      mx = fmaxf(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])),
+                 fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7])));
       block_max = fmaxf(block_max, mx);
       int kA = 0;
       {
@@ -275,23 +323,17 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
       }
       if (((ph - 1) & 7) == 0) {   // first sub-lattice of a brick: fresh accumulators
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       } else if (kA != kprev) {
         const float fix = __int_as_float((kA - kprev + 127) << 23);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mt][r] *= fix;
+        for (int r = 0; r < 16; ++r) acc[r] *= fix;
       }
       kprev = kA;
       const float scaleA = __int_as_float((kA + 127) << 23);
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
-        const int it = tid + 256 * u;
-        if (it < kItems && !(DBG & 8)) {
-          const int hv = it >> 3;
+        if (((okstatic >> u) & 1u) && !(DBG & 8)) {
           const float v[4] = {f[u].x * scaleA, f[u].y * scaleA, f[u].z * scaleA, f[u].w * scaleA};
           half4 h, l;
 #pragma unroll
@@ -299,10 +341,8 @@ __global__ __launch_bounds__(256, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a)
             h[j] = (_Float16)v[j];
             l[j] = (_Float16)(v[j] - (float)h[j]);
           }
-          const int sw = (hv >> 2) & 3, slot = (q & 3) >> 1;
-          char* row = sA + (q >> 2) * (kHV * 64) + hv * 64 + (q & 1) * 8;
-          *reinterpret_cast<half4*>(row + ((slot ^ sw) << 4)) = h;
-          *reinterpret_cast<half4*>(row + (((2 + slot) ^ sw) << 4)) = l;
+          *reinterpret_cast<half4*>(sA + ldsoff[u]) = h;
+          *reinterpret_cast<half4*>(sA + (ldsoff[u] ^ 32u)) = l;
         }
       }
       __syncthreads();
@@ -379,7 +419,7 @@ extern "C" int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float
   auto launch = [&](auto kern) -> int {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), kLds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), kLds, (hipStream_t)stream, a);
     return ADELL_OK;
   };
   int rc = ADELL_OK;

@@ -261,7 +261,7 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
                and bool(_lib.lib().adell_conv3d_fwd_s2_fused_applicable(ctypes.byref(d))))
     if want_stats:
         fn = (_lib.lib().adell_conv3d_fwd_s2_fused_ntiles if s2fused
-              else _lib.lib().adell_conv3d_fwd_ntiles_f16x3 if split
+              else _lib.lib().adell_conv3d_fwd_ntiles_f16x3_ws if split
               else _lib.lib().adell_conv3d_fwd_ntiles)
         nt = fn(ctypes.byref(d))
         if nt < 0:

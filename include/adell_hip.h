@@ -110,6 +110,9 @@ int adell_pack_weight_f16x3(const float* w, void* out, float* wscale, int mode, 
  * mode 1); total_blocks = that sum over all rows. */
 int adell_pack_weight_f16x3_multi(const long* table, int entries, long total_blocks, void* stream);
 int adell_conv3d_fwd_ntiles_f16x3(const adell_conv3d_desc* d);
+/* the same for adell_conv3d_fwd_f16x3_ws (the split-K layers write one row per voxel range of
+ * their fold, not per brick) */
+int adell_conv3d_fwd_ntiles_f16x3_ws(const adell_conv3d_desc* d);
 /* in_absmax / dy_absmax (optional, one zero-initialised uint32 on the device): receive
  * the bit pattern of the absmax of the kernel's input tensor(s) as a by-product;
  * adell_conv3d_bwd_weight_f16x3 takes them as its operand scales. */
