@@ -35,7 +35,10 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          # norm / dropout / activation backward left to its own two passes (no fused epilogue)
          "no_adn_fuse": bool(os.environ.get("ADELL_NO_ADN_FUSE")),
          # the logits head's backward-data tensor is formed (no factored site backward)
-         "no_lowrank": bool(os.environ.get("ADELL_NO_LOWRANK"))}
+         "no_lowrank": bool(os.environ.get("ADELL_NO_LOWRANK")),
+         # weight gradients of the convolutions / linear layers on a second HIP stream (side_run);
+         # ADELL_WGRAD_STREAM=0 keeps every launch on the caller's stream
+         "wgrad_stream": os.environ.get("ADELL_WGRAD_STREAM", "1") != "0"}
 
 
 def set_conv_precision(mode):
@@ -200,6 +203,93 @@ def _amax_pair(device):
     return pair
 
 
+# ---- the weight-gradient branch on a second HIP stream --------------------------------------------
+# dW of a conv depends on (x, dY) only and nothing in the backward pass waits for it: on its own
+# stream the MFMA-bound weight-gradient kernels (and their small partial-slab folds) run beside the
+# HBM-bound norm / dropout / activation passes and the launch tails of the backward-data chain.
+# Ordering: the side stream waits for everything queued on the main stream so far (dY, the absmax
+# slots); the main stream waits for the side stream when the backward pass ends (engine callback)
+# and wherever a gradient is read before that (join_side_stream: GradSync buckets, the optimiser).
+_SIDE = {"stream": None, "pending": False, "callback": False}
+
+
+def _side_join_callback():
+    _SIDE["callback"] = False
+    join_side_stream()
+
+
+def join_side_stream():
+    """Make the current stream wait for the weight gradients still running on the side stream."""
+    if _SIDE["pending"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"] = False
+
+
+def side_run(fn, reads):
+    """``fn()`` with its launches on the side stream; ``reads``: the tensors it reads (kept from
+    the allocator until the side stream is done with them)."""
+    main = torch.cuda.current_stream()
+    side = _SIDE["stream"]
+    if side is None or side.device != main.device:
+        side = _SIDE["stream"] = torch.cuda.Stream(device=main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in reads:
+        if t is not None:
+            t.record_stream(side)
+    _SIDE["pending"] = True
+    if not _SIDE["callback"]:
+        _SIDE["callback"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_side_join_callback)
+    return out
+
+
+def _note_use(weight):
+    """Forward side of _side_ok: counts the graph nodes that hold this weight. Two nodes in one
+    graph (the semi-supervised step runs the network twice) have their gradients added by the
+    autograd engine on the main stream, which knows nothing of the side stream."""
+    if torch.is_grad_enabled() and weight.requires_grad:
+        n = getattr(weight, "_adell_uses", 0) + 1
+        weight._adell_uses = n
+        if n > 1:
+            weight._adell_multi = True
+
+
+def reset_uses(params):
+    """A new step: forget graph nodes that never ran their backward (FlatParameters.zero_grad)."""
+    for p in params:
+        if getattr(p, "_adell_uses", 0):
+            p._adell_uses = 0
+            p._adell_multi = False
+
+
+def _side_ok(weight, *params):
+    """Whether the gradients of these leaf parameters may be produced off the main stream: nothing
+    on the main stream reads them before the join (one graph node per weight, no accumulation into
+    an existing .grad, no tensor hooks, no further autograd nodes). Called once per backward node."""
+    uses = getattr(weight, "_adell_uses", 0)
+    multi = getattr(weight, "_adell_multi", False)
+    if uses > 0:
+        weight._adell_uses = uses - 1
+        if uses == 1:
+            weight._adell_multi = False
+    if uses != 1 or multi:
+        return False
+    if not FLAGS["wgrad_stream"] or torch.is_grad_enabled():     # (create_graph: dW feeds a graph)
+        return False
+    for p in (weight,) + params:
+        if p is None:
+            continue
+        if not p.is_leaf or p.grad is not None or p._backward_hooks:
+            return False
+        # post-accumulate hooks read the gradient on the main stream: only GradSync's own (which
+        # join first, FlatParameters.collect) are known to be safe
+        if getattr(p, "_post_accumulate_grad_hooks", None) and not getattr(p, "_adell_gradsync", False):
+            return False
+    return True
+
+
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
@@ -209,6 +299,7 @@ class _Conv3dFn(torch.autograd.Function):
         # the statistics partials are a non-differentiable by-product: without this autograd
         # materialises a zero gradient for them in every backward (a 2 MB fill per conv site)
         ctx.set_materialize_grads(False)
+        ctx.bias_ref = _Ref(bias)
         ctx.cin_small = wp == "cin_small"
         ctx.cinfold = wp == "cinfold"
         if ctx.cinfold:
@@ -277,6 +368,7 @@ class _Conv3dFn(torch.autograd.Function):
         k, stride, padding, has_bias, has_res, wref = ctx.conf
         need = ctx.needs_input_grad
         if dy is None:   # the output took no part in the loss: only a parked gradient passes through
+            _side_ok(wref.obj)      # (bookkeeping: this node is done)
             add0 = ctx.carry_in.take() if ctx.carry_in is not None else None
             return (add0 if need[0] else None), None, None, None, None, None, None
         dy = ops.ndhwc(dy)
@@ -294,7 +386,11 @@ class _Conv3dFn(torch.autograd.Function):
                 dx0 = dx0 if need[0] else None
                 dx1 = dx1 if (x1 is not None and need[1]) else None
             if need[2] or (has_bias and need[3]):
-                dw, db = ops.conv1_small_bwd_weight(x0, x1, dy, has_bias and need[3])
+                if _side_ok(wref.obj, ctx.bias_ref.obj):
+                    dw, db = side_run(lambda: ops.conv1_small_bwd_weight(
+                        x0, x1, dy, has_bias and need[3]), (x0, x1, dy))
+                else:
+                    dw, db = ops.conv1_small_bwd_weight(x0, x1, dy, has_bias and need[3])
                 dw = dw.view(weight.shape) if need[2] else None
             if add0 is not None and dx0 is not None:
                 dx0 = dx0 + add0
@@ -363,19 +459,28 @@ class _Conv3dFn(torch.autograd.Function):
             if x1 is None or not need[1]:
                 dx1 = None
         want_db = has_bias and need[3]
-        if need[2] and getattr(ctx, "cinfold", False):
-            dw, db = ops.conv_cinfold_bwd_weight(x0, dy, padding, want_db)
-            dw = dw.view(weight.shape)
-        elif need[2]:
-            dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db,
-                                       f16x3=(CONV_PRECISION == "f16x3"),
-                                       x_amax=None if amax is None else amax[0:1],
-                                       dy_amax=dy_amax)
-            if want_db:
-                dw, db = dw
-            dw = dw.view(weight.shape)
-        elif want_db:
-            db = ops.bias_grad(dy)
+
+        def weight_grads():
+            dw = db = None
+            if need[2] and getattr(ctx, "cinfold", False):
+                dw, db = ops.conv_cinfold_bwd_weight(x0, dy, padding, want_db)
+                dw = dw.view(weight.shape)
+            elif need[2]:
+                dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db,
+                                           f16x3=(CONV_PRECISION == "f16x3"),
+                                           x_amax=None if amax is None else amax[0:1],
+                                           dy_amax=dy_amax)
+                if want_db:
+                    dw, db = dw
+                dw = dw.view(weight.shape)
+            elif want_db:
+                db = ops.bias_grad(dy)
+            return dw, db
+
+        if (need[2] or want_db) and _side_ok(wref.obj, ctx.bias_ref.obj):
+            dw, db = side_run(weight_grads, (x0, x1, dy))
+        else:
+            dw, db = weight_grads()
         if add0 is not None and dx0 is not None:   # a path without the fused add
             dx0 = dx0 + add0
         dx0, dx1 = _park_input_grads(ctx, dx0, dx1)
@@ -486,6 +591,7 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     """Conv3d over the virtual concatenation [x0, x1] (+ bias + residual). ``carry_in`` /
     ``carry_out`` / ``carry_x0`` / ``carry_cat``: see GradCarry."""
     stride, padding = ops._triple(stride), ops._triple(padding)
+    _note_use(weight)
     adn = _adn_sites_of(x0, x1, weight, stride, padding)
     conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out, carry_x0, carry_cat,
             adn)
@@ -526,6 +632,7 @@ class _ConvT3dFn(torch.autograd.Function):
             y = ops.convtranspose3d_fwd(x, wp, bias, weight.shape[1], factors)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = _Ref(bias)
         ctx.wref = wref
         ctx.factors = factors
         return y
@@ -541,19 +648,29 @@ class _ConvT3dFn(torch.autograd.Function):
                   ops.convtranspose3d_bwd_data(dy, _packed(ctx.wref.obj, 3), weight.shape[0],
                                                ctx.factors))
         want_db = ctx.has_bias and need[2]
-        if need[1] and ctx.k2 and want_db:
-            dw, db = ops.convt_k2_bwd_weight(x, dy, want_db=True)   # db from the same pass over dy
-        elif need[1]:
-            dw = (ops.convt_k2_bwd_weight(x, dy) if ctx.k2 else
-                  ops.convtranspose3d_bwd_weight(x, dy, ctx.factors))
-        if want_db and db is None:
-            db = ops.bias_grad(dy)
+
+        def weight_grads():
+            dw = db = None
+            if need[1] and ctx.k2 and want_db:
+                dw, db = ops.convt_k2_bwd_weight(x, dy, want_db=True)   # db from the same pass over dy
+            elif need[1]:
+                dw = (ops.convt_k2_bwd_weight(x, dy) if ctx.k2 else
+                      ops.convtranspose3d_bwd_weight(x, dy, ctx.factors))
+            if want_db and db is None:
+                db = ops.bias_grad(dy)
+            return dw, db
+
+        if (need[1] or want_db) and _side_ok(ctx.wref.obj, ctx.bias_ref.obj):
+            dw, db = side_run(weight_grads, (x, dy))
+        else:
+            dw, db = weight_grads()
         return dx, dw, db, None, None
 
 
 def conv_transpose3d(x, weight, bias=None):
     """ConvTranspose3d whose kernel equals its stride (each 1 or 2 per dim), padding 0."""
     wp = None if (x.dim() == 5 and ops.convt_k2_ok(x.shape, weight)) else _packed(weight, 2)
+    _note_use(weight)
     return _ConvT3dFn.apply(x, weight, bias, wp, _Ref(weight))
 
 
@@ -709,6 +826,7 @@ class _LinearFn(torch.autograd.Function):
             y = ops.gemm(rows, N, K, x2, K, True, w, K, True, bias=bias, residual=res2)
         ctx.save_for_backward(x2, w)
         ctx.split = split
+        ctx.refs = (_Ref(weight), _Ref(bias))
         ctx.meta = (x.shape, bias is not None, residual is not None and residual.shape)
         return y.view(*x.shape[:-1], N)
 
@@ -728,13 +846,21 @@ class _LinearFn(torch.autograd.Function):
             else:
                 dx = ops.gemm(rows, K, N, dy2, N, True, w, K, False)
             dx = dx.view(xshape)
-        if need[1]:
-            if split and ops.gemm_f16x3_ok(N, K, rows, dy2, N, False, x2, K, False):
-                dw = ops.gemm_f16x3(N, K, rows, dy2, N, False, x2, K, False)
-            else:
-                dw = ops.gemm(N, K, rows, dy2, N, False, x2, K, False)
-        if has_bias and need[2]:
-            db = ops.bias_grad(_rows_as_volume(dy2))
+        def weight_grads():
+            dw = db = None
+            if need[1]:
+                if split and ops.gemm_f16x3_ok(N, K, rows, dy2, N, False, x2, K, False):
+                    dw = ops.gemm_f16x3(N, K, rows, dy2, N, False, x2, K, False)
+                else:
+                    dw = ops.gemm(N, K, rows, dy2, N, False, x2, K, False)
+            if has_bias and need[2]:
+                db = ops.bias_grad(_rows_as_volume(dy2))
+            return dw, db
+
+        if (need[1] or (has_bias and need[2])) and _side_ok(ctx.refs[0].obj, ctx.refs[1].obj):
+            dw, db = side_run(weight_grads, (x2, dy2))
+        else:
+            dw, db = weight_grads()
         if res_shape and need[3]:
             dres = dy2.view(res_shape)
         return dx, dw, db, dres
@@ -742,6 +868,7 @@ class _LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, residual=None):
     """torch.nn.functional.linear on the MFMA GEMMs (+ fused bias / residual add)."""
+    _note_use(weight)
     return _LinearFn.apply(x, weight, bias, residual)
 
 

@@ -65,9 +65,11 @@ class FlatParameters:
         parameters from it: autograd then hands each parameter its freshly computed gradient
         tensor (no per-parameter accumulate kernels) and ``collect()`` gathers them into the
         flat buffer with one launch. Otherwise ``p.grad`` stays a view of the flat buffer."""
+        from . import functional as HF
         self.grad.zero_()
         for i, p in enumerate(self.params):
             p.grad = None if set_to_none else self.slot(i)
+        HF.reset_uses(self.params)
 
     def _upload_and_copy(self, rows):
         """Stage the (pointer, offset, count) table through a small ring of pinned host buffers
@@ -94,6 +96,8 @@ class FlatParameters:
         view of the flat buffer into its slot (one multi-copy launch), then point ``p.grad`` at
         the slots. Returns nothing; parameters without a gradient keep ``grad is None`` and a
         zero slot."""
+        from . import functional as HF
+        HF.join_side_stream()     # weight gradients still running on the side stream
         base = self.grad.data_ptr()
         todo, keep = [], []
         idx = range(len(self.params)) if indices is None else indices

@@ -162,6 +162,9 @@ class GradSync:
                 for i in range(lo, hi):
                     self._hooks.append(
                         flat.params[i].register_post_accumulate_grad_hook(self._make_hook(b)))
+                    # (functional.side_run: these hooks join the weight-gradient stream before
+                    # they read a gradient)
+                    flat.params[i]._adell_gradsync = True
 
     def _wrap_zero_grad(self):
         """``optimizer.zero_grad()`` starts a new step: drop whatever an abandoned one left."""
@@ -250,6 +253,10 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for flat in self.optimizer.flat_groups:
+            for p in flat.params:
+                if getattr(p, "_adell_gradsync", False):
+                    del p._adell_gradsync
 
     # ---- public ---------------------------------------------------------------------------
     def broadcast_parameters(self, src=0, module=None):

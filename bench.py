@@ -65,7 +65,7 @@ def parse_args():
                     help="volumes per GPU per step (default: batch_size of the YAML = 2; "
                          "SURVEY.md 8(d): B per GPU in {1, 2})")
     ap.add_argument("--config", type=str, default=CONFIG)
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=10,
                     help="event-time the dominant kernel family on every M-th timed step "
                          "(1: every step; each event pair idles the stream ~6 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -227,8 +227,14 @@ def cpu_training_steps(cfg_kwargs, size, threads, warmup, steps):
 def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None, event_every=1):
     """K training steps between two barriers. ``timer``: the per-launch event timer of the
     dominant kernel family, switched on for every ``event_every``-th step only (each event pair
-    idles the stream ~6 us; sampling keeps the instrument from slowing what it measures)."""
+    idles the stream ~6 us; sampling keeps the instrument from slowing what it measures). The
+    instrumented steps keep every launch on ONE stream (functional.FLAGS['wgrad_stream'] off): a
+    launch duration taken while the weight-gradient stream shares the chip says nothing about the
+    kernel -- so the timed region mixes overlapped steps with a few slower serial ones."""
     import torch
+
+    from adell_mri_amd import functional as HF
+    overlap = HF.FLAGS["wgrad_stream"]
 
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step_events else None
     t0 = time.perf_counter()
@@ -238,7 +244,9 @@ def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None,
             evs[i].record()
         if timer is not None:
             timer.active = event_every > 0 and i % event_every == 0
+            HF.FLAGS["wgrad_stream"] = overlap and not timer.active
         loss = runner.train_step(batch)
+    HF.FLAGS["wgrad_stream"] = overlap
     if timer is not None:
         timer.active = True
     if evs:
@@ -287,11 +295,20 @@ def main():
     # warm-up (untimed): every instrumented kernel family is event-timed to find the dominant
     # MFMA one; the timed region then carries events for that family and the HBM-bound
     # norm/activation family only (fewer markers in the stream)
+    # (instrumented steps keep every launch on one stream, see timed_steps; a few plain steps
+    # after them warm the weight-gradient stream and its memory pool)
     ops.KERNEL_TIMER = ops.KernelTimer()
+    overlap = HF.FLAGS["wgrad_stream"]
+    HF.FLAGS["wgrad_stream"] = False
     for _ in range(args.warmup):
         runner.train_step(batch)
     barrier()
     warm, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    HF.FLAGS["wgrad_stream"] = overlap
+    warm_extra = min(3, args.warmup) if overlap else 0
+    for _ in range(warm_extra):
+        runner.train_step(batch)
+    barrier()
     dom_warm = warm.dominant() if args.warmup > 0 else None
     warm_summary = warm.summary() if args.warmup > 0 else {}
     ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
@@ -306,10 +323,19 @@ def main():
     # not sit inside the region `value` is measured over
     hbm_steps = 2 if args.warmup > 0 else 0
     ops.KERNEL_TIMER = ops.KernelTimer(only={ops.NORM_ACT_FAMILY})
+    overlap = HF.FLAGS["wgrad_stream"]
+    HF.FLAGS["wgrad_stream"] = False          # (instrumented steps: one stream, see timed_steps)
     for _ in range(hbm_steps):
         runner.train_step(batch)
     barrier()
     hbm_timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    # the same step with every launch on one stream, for the record (a few steps)
+    serial_ms = None
+    if overlap and args.warmup > 0:
+        nser = max(3, min(args.steps, 8))
+        dts, _, _ = timed_steps(runner, batch, nser, barrier, per_step_events=False)
+        serial_ms = 1e3 * reduce_max(dts, device) / nser
+    HF.FLAGS["wgrad_stream"] = overlap
     dt = reduce_max(dt, device)
     loss_value = float(loss.detach().cpu())
 
@@ -331,7 +357,7 @@ def main():
 
     # the other workloads north_star names, on the same module (every rank runs them: the gradient
     # exchange inside a step is collective): 256 x 256 x 128 volumes and batch-1 128^3, 3 warm-up +
-    # 5 timed steps each with the dominant kernel family event-timed on every step
+    # 5 timed steps each, then two instrumented steps for the dominant kernel family's roofline
     secondary = {}
     if not args.no_secondary and args.shape is None and args.size == 128 and args.batch is None:
         # (the smaller workload first: it reuses the main run's memory pool; 3 warm-up steps, a new
@@ -342,10 +368,13 @@ def main():
             for _ in range(3):
                 runner.train_step(sb)
             barrier()
-            ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
-            sdt, _, sper = timed_steps(runner, sb, 5, barrier, timer=ops.KERNEL_TIMER, event_every=1)
-            stimer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+            sdt, _, sper = timed_steps(runner, sb, 5, barrier)
             sdt = reduce_max(sdt, device)
+            # its roofline: two instrumented (one-stream) steps after the timed ones
+            ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
+            timed_steps(runner, sb, 2, barrier, per_step_events=False, timer=ops.KERNEL_TIMER,
+                        event_every=1)
+            stimer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
             sec = {"value": sbatch * world * 5 / sdt, "unit": "volumes/s",
                    "ms_per_step": 1e3 * sdt / 5, "median_ms_per_step": statistics.median(sper),
                    "steps": 5, "warmup": 3, "per_gpu_batch": sbatch, "size": list(sshape)}
@@ -390,6 +419,11 @@ def main():
         med = statistics.median(per_step)
         out["median_ms_per_step"] = med
         out["value_median"] = per_gpu_batch * world / (med * 1e-3)
+    out["streams"] = {"weight_gradient_stream": bool(overlap),
+                      "ms_per_step_one_stream": serial_ms,
+                      "untimed_steps_after_warmup": warm_extra,
+                      "note": "the weight-gradient kernels run on a second HIP stream beside the "
+                              "backward-data chain; the event-timed steps (roofline) keep one stream"}
     if fp32_line is not None:
         out["fp32_mfma"] = fp32_line
     if secondary:

@@ -13,12 +13,21 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 ARGS="--steps 7 --warmup 3 --no-cpu-baseline --no-fp32 --no-secondary"
+# (per-kernel passes with every launch on ONE stream -- ADELL_WGRAD_STREAM=0, exported, not `env`
+# after `--` -- so that a kernel's duration and counters are its own; bench.py's event-timed steps
+# do the same. Pass 1b is the default two-stream step, for the record of what overlaps.)
+export ADELL_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py $ARGS > $O/bench_line.json 2> $O/stats.err
+export ADELL_WGRAD_STREAM=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py $ARGS > $O/bench_line_two_streams.json 2> $O/stats2.err
+export ADELL_WGRAD_STREAM=0
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcF -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary > $O/pmcF.json 2> $O/pmcF.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcW -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary > $O/pmcW.json 2> $O/pmcW.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmcM -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-fp32 --no-secondary > $O/pmcM.json 2> $O/pmcM.err
 cd $R
-python3 tools/rocpd_stats.py $O/stats > $O/kernel_stats.txt 2>&1 || true
+unset ADELL_WGRAD_STREAM
+python3 tools/trace_stats.py $O/stats > $O/kernel_stats.txt 2>&1 || true
+python3 tools/trace_stats.py $O/stats2 > $O/kernel_stats_two_streams.txt 2>&1 || true
 python3 tools/pmc_traffic.py $O/pmcF $O/pmcW $O/pmc_traffic.json $O/bench_line.json > /dev/null 2>&1 || true
 python3 tools/pmc_mfma.py $O/pmcM > $O/pmc_mfma_utilisation.txt 2>&1 || true
 python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
