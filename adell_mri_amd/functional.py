@@ -231,6 +231,8 @@ def side_run(fn, reads):
     main = torch.cuda.current_stream()
     side = _SIDE["stream"]
     if side is None or side.device != main.device:
+        # (a LOW-priority stream -- hipStreamCreateWithPriority, torch only hands out normal / high --
+        # was measured: the main stream ends 0.3 ms earlier and waits that much longer at the join)
         side = _SIDE["stream"] = torch.cuda.Stream(device=main.device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
