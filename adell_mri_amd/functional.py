@@ -210,7 +210,7 @@ def _amax_pair(device):
 # Ordering: the side stream waits for everything queued on the main stream so far (dY, the absmax
 # slots); the main stream waits for the side stream when the backward pass ends (engine callback)
 # and wherever a gradient is read before that (join_side_stream: GradSync buckets, the optimiser).
-_SIDE = {"stream": None, "pending": False, "callback": False}
+_SIDE = {"stream": None, "pending": False, "callback": False, "mains": []}
 
 
 def _side_join_callback():
@@ -219,9 +219,17 @@ def _side_join_callback():
 
 
 def join_side_stream():
-    """Make the current stream wait for the weight gradients still running on the side stream."""
+    """Make the current stream -- and every stream a backward node handed work over from (the
+    engine's final callbacks need not run under the stream of the forward pass) -- wait for the
+    weight gradients still running on the side stream."""
     if _SIDE["pending"]:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        side = _SIDE["stream"]
+        cur = torch.cuda.current_stream(side.device)
+        cur.wait_stream(side)
+        for m in _SIDE["mains"]:
+            if m != cur:
+                m.wait_stream(side)
+        _SIDE["mains"] = []
         _SIDE["pending"] = False
 
 
@@ -241,6 +249,8 @@ def side_run(fn, reads):
         if t is not None:
             t.record_stream(side)
     _SIDE["pending"] = True
+    if main not in _SIDE["mains"]:
+        _SIDE["mains"].append(main)
     if not _SIDE["callback"]:
         _SIDE["callback"] = True
         torch.autograd.Variable._execution_engine.queue_callback(_side_join_callback)

@@ -145,3 +145,27 @@ def test_shared_weight_and_accumulation_stay_on_the_main_stream(cuda, monkeypatc
     conv(x).sum().backward()
     assert len(calls) == 2
     assert torch.equal(conv.weight.grad, g1)
+
+
+@pytest.mark.gpu
+def test_forward_on_a_non_default_stream_is_joined_on_that_stream(cuda, monkeypatch):
+    """The backward nodes run on the stream of their forward; the gradient must be complete for
+    work queued on THAT stream after backward() returns, whatever stream the engine's final
+    callback runs under."""
+    from adell_mri_amd.modules.layers.conv import Conv3d
+
+    monkeypatch.setitem(HF.FLAGS, "wgrad_stream", True)
+    torch.manual_seed(2)
+    conv = Conv3d(32, 32, 3, padding=1).to(cuda)
+    x = torch.randn(2, 32, 48, 48, 48, device=cuda)
+    conv(x).sum().backward()
+    torch.cuda.synchronize()
+    want = conv.weight.grad.clone()
+    conv.zero_grad(set_to_none=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        conv(x).sum().backward()
+        got = conv.weight.grad.clone()       # queued on s right behind the backward pass
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -43,6 +43,11 @@ def set_switch(v):
         FLAGSET[switch[3:]] = bool(v)
     else:
         _lib.lib().adell_set_tuning(switch.encode(), v)
+    # launch plans cached on the Python side (partial-row counts of the fused site epilogue) belong
+    # to the switch they were made under: a stale row count is an out-of-bounds write
+    from adell_mri_amd import functional as _HF
+    torch.cuda.synchronize()
+    _HF._ADN_PLAN.clear()
 
 
 base = get_switch()
