@@ -233,6 +233,16 @@ def join_side_stream():
         _SIDE["pending"] = False
 
 
+def side_stream_behind(main):
+    """The weight-gradient stream, made to wait for ``main``, when it holds work of the running
+    backward pass -- for consumers that would rather queue behind the gradients than stall the
+    main stream for them (GradSync's bucket gathers); else None."""
+    if not _SIDE["pending"] or _SIDE["stream"] is None or _SIDE["stream"].device != main.device:
+        return None
+    _SIDE["stream"].wait_stream(main)
+    return _SIDE["stream"]
+
+
 def side_run(fn, reads):
     """``fn()`` with its launches on the side stream; ``reads``: the tensors it reads (kept from
     the allocator until the side stream is done with them)."""

@@ -91,13 +91,16 @@ class FlatParameters:
         ev.record()
         ops.multi_copy(dev, n, self.grad)
 
-    def collect(self, indices=None):
+    def collect(self, indices=None, on_side_stream=False):
         """Copy every parameter gradient (of ``indices``, default all) that is not already a
         view of the flat buffer into its slot (one multi-copy launch), then point ``p.grad`` at
         the slots. Returns nothing; parameters without a gradient keep ``grad is None`` and a
-        zero slot."""
+        zero slot. ``on_side_stream``: the caller runs this on the weight-gradient stream itself
+        (GradSync's buckets: in order behind the gradients, without stalling the main stream);
+        otherwise the current stream first waits for that stream."""
         from . import functional as HF
-        HF.join_side_stream()     # weight gradients still running on the side stream
+        if not on_side_stream:
+            HF.join_side_stream()     # weight gradients still running on the side stream
         base = self.grad.data_ptr()
         todo, keep = [], []
         idx = range(len(self.params)) if indices is None else indices
@@ -109,6 +112,8 @@ class FlatParameters:
             if g.dtype != torch.float32 or g.device != self.grad.device:
                 raise ValueError("FlatParameters.collect: gradients must be fp32 on the GPU")
             g = g.contiguous()
+            if on_side_stream:       # (may have been produced, and be freed, on another stream)
+                g.record_stream(torch.cuda.current_stream(g.device))
             keep.append(g)
             todo.append((g.data_ptr(), o, g.numel()))
         if todo:

@@ -191,11 +191,25 @@ class GradSync:
         return hook
 
     def _send(self, b):
-        b.flat.collect(range(b.lo, b.hi))
+        # With weight gradients in flight on their own stream (functional.side_run) the gather and
+        # the collective queue BEHIND them on that stream: the main stream -- the backward-data
+        # chain -- is not held up for a bucket (it waits for the handle before the optimiser).
+        side = None
+        if b.flat.grad.is_cuda and os.environ.get("ADELL_DDP_SEND_MAIN") is None:
+            from . import functional as HF
+            side = HF.side_stream_behind(torch.cuda.current_stream(b.flat.grad.device))
+        if side is not None:
+            with torch.cuda.stream(side):
+                b.flat.collect(range(b.lo, b.hi), on_side_stream=True)
+                if b.e1 > b.e0:
+                    b.handle = dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
+                                               async_op=True)
+        else:
+            b.flat.collect(range(b.lo, b.hi))
+            if b.e1 > b.e0:
+                b.handle = dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
+                                           async_op=True)
         b.sent = True
-        if b.e1 > b.e0:
-            b.handle = dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
-                                       async_op=True)
         # detach the parameters from the slice while the collective may be running: a later
         # backward must not accumulate in place into memory the collective reads and writes
         for i in range(b.lo, b.hi):
