@@ -65,7 +65,7 @@ def parse_args():
                     help="volumes per GPU per step (default: batch_size of the YAML = 2; "
                          "SURVEY.md 8(d): B per GPU in {1, 2})")
     ap.add_argument("--config", type=str, default=CONFIG)
-    ap.add_argument("--event-every", type=int, default=10,
+    ap.add_argument("--event-every", type=int, default=20,
                     help="event-time the dominant kernel family on every M-th timed step "
                          "(1: every step; each event pair idles the stream ~6 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
