@@ -17,13 +17,27 @@ __global__ __launch_bounds__(256) void adell_stats_finalize_kernel(
   const int nbeg = per_item ? blockIdx.y : 0, nend = per_item ? blockIdx.y + 1 : N;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    for (int n = nbeg; n < nend; ++n)
-      for (int t = sl; t < ntiles; t += 8) {
-        const float2 v = *reinterpret_cast<const float2*>(
-            part + (((size_t)n * ntiles + t) * C + c) * 2);
+    for (int n = nbeg; n < nend; ++n) {
+      // eight rows in flight, added in row order (the launch is latency-bound: 2-16 blocks)
+      const float* p = part + ((size_t)n * ntiles * C + c) * 2;
+      int t = sl;
+      for (; t + 56 < ntiles; t += 64) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          v[u] = *reinterpret_cast<const float2*>(p + (size_t)(t + 8 * u) * C * 2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          s1 += (double)v[u].x;
+          s2 += (double)v[u].y;
+        }
+      }
+      for (; t < ntiles; t += 8) {
+        const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * C * 2);
         s1 += (double)v.x;
         s2 += (double)v.y;
       }
+    }
   }
   sh[sl][cl][0] = s1;
   sh[sl][cl][1] = s2;
@@ -59,13 +73,27 @@ __global__ __launch_bounds__(256) void adell_stats_fold_kernel(const float* __re
   const int t0 = z * 256;
   const int t1 = t0 + 256 < ntiles ? t0 + 256 : ntiles;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int t = t0 + sl; t < t1; t += 8) {
-      const float2 v = *reinterpret_cast<const float2*>(
-          part + (((size_t)n * ntiles + t) * pstride + poff + c) * 2);
+  if (c < C) {
+    // eight rows in flight, added in row order
+    const float* p = part + ((size_t)n * ntiles * pstride + poff + c) * 2;
+    int t = t0 + sl;
+    for (; t + 56 < t1; t += 64) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        v[u] = *reinterpret_cast<const float2*>(p + (size_t)(t + 8 * u) * pstride * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s1 += (double)v[u].x;
+        s2 += (double)v[u].y;
+      }
+    }
+    for (; t < t1; t += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(p + (size_t)t * pstride * 2);
       s1 += (double)v.x;
       s2 += (double)v.y;
     }
+  }
   sh[sl][cl][0] = s1;
   sh[sl][cl][1] = s2;
   __syncthreads();
