@@ -210,7 +210,7 @@ def _amax_pair(device):
 # Ordering: the side stream waits for everything queued on the main stream so far (dY, the absmax
 # slots); the main stream waits for the side stream when the backward pass ends (engine callback)
 # and wherever a gradient is read before that (join_side_stream: GradSync buckets, the optimiser).
-_SIDE = {"stream": None, "pending": False, "callback": False, "mains": []}
+_SIDE = {"stream": None, "pending": False, "callback": False, "mains": [], "keep": []}
 
 
 def _side_join_callback():
@@ -231,6 +231,9 @@ def join_side_stream():
                 m.wait_stream(side)
         _SIDE["mains"] = []
         _SIDE["pending"] = False
+        # the tensors the side stream read may go back to the allocator now: whatever stream
+        # reuses their memory does so behind the wait just queued
+        _SIDE["keep"].clear()
 
 
 def side_stream_behind(main):
@@ -243,9 +246,16 @@ def side_stream_behind(main):
     return _SIDE["stream"]
 
 
+def side_keep(t):
+    """Keep ``t`` alive until the side stream has been joined (for work a caller queued on it)."""
+    _SIDE["keep"].append(t)
+
+
 def side_run(fn, reads):
-    """``fn()`` with its launches on the side stream; ``reads``: the tensors it reads (kept from
-    the allocator until the side stream is done with them)."""
+    """``fn()`` with its launches on the side stream; ``reads``: the tensors it reads. They are
+    kept alive until the join (not ``record_stream``-ed: that defers the reuse of every such block
+    behind an allocator event, and with the host a step ahead of the GPU the pools kept growing
+    through fresh device allocations -- sporadic 0.3 s stalls in the first steps of a process)."""
     main = torch.cuda.current_stream()
     side = _SIDE["stream"]
     if side is None or side.device != main.device:
@@ -255,9 +265,7 @@ def side_run(fn, reads):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         out = fn()
-    for t in reads:
-        if t is not None:
-            t.record_stream(side)
+    _SIDE["keep"].extend(t for t in reads if t is not None)
     _SIDE["pending"] = True
     if main not in _SIDE["mains"]:
         _SIDE["mains"].append(main)

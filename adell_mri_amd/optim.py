@@ -112,8 +112,8 @@ class FlatParameters:
             if g.dtype != torch.float32 or g.device != self.grad.device:
                 raise ValueError("FlatParameters.collect: gradients must be fp32 on the GPU")
             g = g.contiguous()
-            if on_side_stream:       # (may have been produced, and be freed, on another stream)
-                g.record_stream(torch.cuda.current_stream(g.device))
+            if on_side_stream:       # (may have been produced on another stream: alive till the join)
+                HF.side_keep(g)
             keep.append(g)
             todo.append((g.data_ptr(), o, g.numel()))
         if todo:

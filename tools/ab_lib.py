@@ -33,7 +33,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         runner.train_step(batch)
     e1.record()
     torch.cuda.synchronize()
-    print("MS_PER_STEP", e0.elapsed_time(e1) / steps)
+    st = torch.cuda.memory_stats()
+    print("MS_PER_STEP", e0.elapsed_time(e1) / steps, "device_allocs", st.get("num_device_alloc"),
+          "retries", st.get("num_alloc_retries"), "reserved_GB",
+          round(torch.cuda.memory_reserved() / 2 ** 30, 1))
     sys.exit(0)
 
 libs = [os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])]
