@@ -377,6 +377,7 @@ def main():
             stimer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
             sec = {"value": sbatch * world * 5 / sdt, "unit": "volumes/s",
                    "ms_per_step": 1e3 * sdt / 5, "median_ms_per_step": statistics.median(sper),
+                   "per_step_ms": [round(v, 2) for v in sper],
                    "steps": 5, "warmup": 3, "per_gpu_batch": sbatch, "size": list(sshape)}
             sdom = stimer.dominant()
             if sdom is not None:
