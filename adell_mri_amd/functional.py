@@ -1191,6 +1191,15 @@ def cat_channels(tensors):
     return _CatFn.apply(*tensors)
 
 
+def cat_tokens(a, b):
+    """torch.cat([a, b], 1) for token tensors [B, T, E] (class token / registers in front of the
+    patch tokens, vit.py:871-880): per item the rows are contiguous, so it is the channel concat of
+    depth-1 volumes with T * E "channels"."""
+    B, E = a.shape[0], a.shape[2]
+    y = _CatFn.apply(a.reshape(B, -1, 1, 1, 1), b.reshape(B, -1, 1, 1, 1))
+    return y.reshape(B, a.shape[1] + b.shape[1], E)
+
+
 class _NearestFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, size):

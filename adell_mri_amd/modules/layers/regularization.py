@@ -42,6 +42,28 @@ class UOut(torch.nn.Module):
         return HF.scale_per_item_channel(X, 1.0 + r)
 
 
+class ChannelDropout(torch.nn.Module):
+    """Drops whole channels (axis 1) per batch item, without rescaling
+    (adell_mri/modules/layers/regularization.py:230-261; the ViT's patch erasing applies it to
+    [B, tokens, features]). The mask is drawn on the host exactly as the reference draws it
+    (``torch.rand([B, C])``), so a seeded run erases the same channels."""
+
+    def __init__(self, dropout_prob: float, channel_axis: int = 1):
+        super().__init__()
+        self.dropout_prob = dropout_prob
+        self.channel_axis = channel_axis
+        if channel_axis != 1:
+            raise NotImplementedError("HIP ChannelDropout: channel_axis 1 only")
+
+    def forward(self, X):
+        if not (self.dropout_prob > 0 and self.training is True):
+            return X
+        from ... import functional as HF
+
+        keep = (torch.rand([X.shape[0], X.shape[1]]) > self.dropout_prob).float().to(X.device)
+        return HF.scale_per_item_channel(X, keep)
+
+
 class LayerNorm(torch.nn.Module):
     """LayerNorm over the channel axis for channels_last ([..., C]) or channels_first
     ([N, C, ...]) tensors (adell_mri/modules/layers/regularization.py:60-92; weight and

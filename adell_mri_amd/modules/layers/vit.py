@@ -16,6 +16,7 @@ import torch
 from ... import functional as HF
 from .adn_fn import get_adn_fn
 from .linear_blocks import MLP, LayerNorm, Linear, MultiHeadSelfAttention
+from .regularization import ChannelDropout
 
 
 class LinearEmbedding(torch.nn.Module):
@@ -42,9 +43,10 @@ class LinearEmbedding(torch.nn.Module):
         assert len(self.image_size) == len(self.patch_size), "image_size and patch_size must have the same length"
         self.n_dims = len(self.image_size)
         self.windowed = window_size is not None
-        if use_class_token or n_registers > 0 or channel_to_token or not learnable_embedding:
-            raise NotImplementedError("HIP LinearEmbedding: no class token / registers / "
-                                      "channel tokens / sinusoidal embedding")
+        if channel_to_token:
+            raise NotImplementedError("HIP LinearEmbedding: no channel tokens")
+        if (use_class_token or n_registers > 0) and window_size is not None:
+            raise NotImplementedError("HIP windowed LinearEmbedding: no class token / registers")
         if self.windowed:
             # SWIN configuration (vit.py:553-571): tokens are the patches of one window
             if not channels_last or self.n_dims != 3:
@@ -71,10 +73,22 @@ class LinearEmbedding(torch.nn.Module):
                                                       Linear(self.n_features, self.out_dim))
             self.map_to_in = Linear(self.out_dim, self.n_features)
         self.drop_op = torch.nn.Dropout(self.dropout_rate)
+        # (parameter order of vit.py:489-495: class token, registers, positional embedding)
+        if self.use_class_token is True:
+            self.class_token = torch.nn.Parameter(torch.zeros([1, 1, self.true_n_features]))
+        if self.n_registers > 0:
+            self.registers = torch.nn.Parameter(
+                torch.zeros([1, self.n_registers, self.true_n_features]))
         if self.use_pos_embed:
-            self.positional_embedding = torch.nn.Parameter(
-                torch.rand(1, self.n_patches, self.true_n_features))
-            torch.nn.init.trunc_normal_(self.positional_embedding, std=0.02)
+            if self.learnable_embedding is True:
+                self.positional_embedding = torch.nn.Parameter(
+                    torch.rand(1, self.n_patches, self.true_n_features))
+                torch.nn.init.trunc_normal_(self.positional_embedding, std=0.02)
+            else:       # fixed sinusoidal table (vit.py:210-218, 600-607)
+                sin_embed = sinusoidal_positional_encoding(
+                    self.n_patches, self.true_n_features)[np.newaxis, :, :]
+                self.positional_embedding = torch.nn.Parameter(
+                    torch.as_tensor(sin_embed, dtype=torch.float32), requires_grad=False)
         self.linearized_dim = [-1, self.n_patches, self.n_features]
 
     @property
@@ -163,9 +177,31 @@ class LinearEmbedding(torch.nn.Module):
         X = self.rearrange(X)
         if (no_pos_embed is False) and (self.use_pos_embed is True):
             X = HF.add_bcast(X, self.positional_embedding)
+        # class token, then registers, in front of the patch tokens (vit.py:871-880)
+        if self.use_class_token is True:
+            X = self._prepend(self.class_token, X)
+        if self.n_registers > 0:
+            X = self._prepend(self.registers, X)
         if self.dropout_rate > 0 and self.training:
             X = HF.elementwise(X, drop_p=self.dropout_rate, training=True)
         return X
+
+    @staticmethod
+    def _prepend(tokens, X):
+        """[1, n, E] parameter rows repeated per batch item in front of X [B, T, E]."""
+        rows = HF.add_bcast(X.new_zeros((X.shape[0], tokens.shape[1], tokens.shape[2])), tokens)
+        return HF.cat_tokens(rows, X.contiguous())
+
+
+def sinusoidal_positional_encoding(n_tokens, dim_size):
+    """vit.py:210-218."""
+    token_range = np.arange(0, n_tokens)[:, np.newaxis]
+    dim_range = np.arange(0, dim_size)[np.newaxis, :]
+    radians = token_range / (10000 ** (2 * dim_range / dim_size))
+    output = np.zeros((n_tokens, dim_size))
+    output[:, ::2] = np.sin(radians)[:, ::2]
+    output[:, 1::2] = np.cos(radians)[:, 1::2]
+    return output
 
 
 class TransformerBlock(torch.nn.Module):
@@ -288,8 +324,6 @@ class ViT(torch.nn.Module):
         self.learnable_embedding = learnable_embedding
         self.channel_to_token = channel_to_token
         self.patch_erasing = patch_erasing
-        if patch_erasing is not None:
-            raise NotImplementedError("patch erasing is outside the HIP path built so far")
         self.embedding = LinearEmbedding(
             image_size=image_size, patch_size=patch_size, in_channels=in_channels,
             window_size=window_size, out_dim=embedding_size, embed_method=embed_method,
@@ -297,7 +331,13 @@ class ViT(torch.nn.Module):
             use_class_token=use_class_token, n_registers=n_registers,
             learnable_embedding=learnable_embedding, channel_to_token=channel_to_token)
         self.input_dim_primary = self.embedding.true_n_features
-        self.patch_erasing_op = None
+        # patch erasing (vit.py:1731-1736): whole tokens zeroed per item, or the caller's own module
+        if self.patch_erasing is None:
+            self.patch_erasing_op = None
+        elif callable(self.patch_erasing):
+            self.patch_erasing_op = self.patch_erasing
+        else:
+            self.patch_erasing_op = ChannelDropout(self.patch_erasing)
         if isinstance(self.mlp_structure, float):
             self.mlp_structure = [int(self.input_dim_primary * self.mlp_structure)]
         idp = embedding_size if embedding_size is not None else self.input_dim_primary
@@ -313,6 +353,8 @@ class ViT(torch.nn.Module):
             assert max(return_at) < self.number_of_blocks, \
                 "max(return_at) should be smaller than self.number_of_blocks"
         embeded_X = self.embedding(X)
+        if self.patch_erasing_op is not None:
+            embeded_X = self.patch_erasing_op(embeded_X)
         if return_at == "end" or return_at is None:
             return_at = []
         outputs = []

@@ -425,6 +425,51 @@ def gen_blocks():
     print("blocks ok")
 
 
+VIT_TOKEN_KW = dict(image_size=[16, 16, 16], patch_size=[8, 8, 8], in_channels=2, number_of_blocks=2,
+                    attention_dim=32, hidden_dim=32, embedding_size=32, n_heads=4, dropout_rate=0.0,
+                    mlp_structure=[64])
+
+
+def gen_vit_tokens():
+    """ViT with the LinearEmbedding options of vit.py:389-881 that UNETR does not use: class token,
+    registers, the fixed sinusoidal table (learnable_embedding False) and patch erasing
+    (vit.py:1731-1736, 1793-1794): outputs, every parameter gradient, the initial table, and a
+    seeded training-mode forward with erased patches (all other dropouts off, so the erasing mask
+    is the only consumer of the host generator)."""
+    from adell_mri.modules.layers.vit import ViT
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((2, 2, 16, 16, 16), generator=g)
+    adn = get_adn_fn(1, "identity", "gelu", 0.0)
+    out = {"x": x.numpy()}
+    net = ViT(**VIT_TOKEN_KW, adn_fn=adn, use_class_token=True, n_registers=2,
+              learnable_embedding=False).eval()
+    out["pos_init"] = net.embedding.positional_embedding.detach().numpy().copy()
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    out["state_keys"] = np.array(list(net.state_dict().keys()))
+    y, hidden = net(x, return_at=[0])
+    wgt = torch.from_numpy(np.asarray(
+        np.random.default_rng(3).uniform(-1, 1, size=tuple(y.shape)), dtype=np.float32))
+    (y * wgt).sum().backward()
+    out["y"], out["hidden0"], out["wgt"] = y.detach().numpy(), hidden[0].detach().numpy(), wgt.numpy()
+    keys = []
+    for k, p_ in net.named_parameters():
+        if p_.grad is not None:
+            out["grad:" + k] = p_.grad.numpy()
+            keys.append(k)
+    out["grad_keys"] = np.array(keys)
+    # patch erasing, learnable table, class token only
+    net2 = ViT(**VIT_TOKEN_KW, adn_fn=adn, use_class_token=True, patch_erasing=0.4).train()
+    net2.load_state_dict(fill_state_dict(net2.state_dict()))
+    torch.manual_seed(5)
+    y2, _ = net2(x)
+    out["y_erased"] = y2.detach().numpy()
+    torch.manual_seed(5)
+    out["erase_mask"] = (torch.rand([2, 9]) > 0.4).numpy()
+    np.savez_compressed(os.path.join(OUT, "vit_tokens.npz"), **out)
+    print("vit_tokens ok", y.shape, float(y.abs().mean()), out["erase_mask"].mean())
+
+
 SSL_CASE = dict(
     backbone_args=dict(spatial_dim=3, in_channels=1, structure=[[8, 16, 3, 2], [16, 32, 7, 2]],
                        maxpool_structure=[2, 2]),
@@ -933,6 +978,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ssl":
         gen_ssl()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vit":
+        gen_vit_tokens()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "depthwise":
         for name, (kw, shape, dist) in DEPTHWISE_CASES.items():
