@@ -441,7 +441,11 @@ static int adell_norm_act_fwd_impl(const adell_norm_act_desc* d, const float* x,
   a.x = x; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
   a.act_w = act_w; a.out = out;
   a.vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)out & 15) == 0);
-  if (a.vec && adell_is_pow2(d->C) && d->C <= 1024 && (a.VC >> 2) < (1L << 40)) {
+  // (1 / 2 channels -- the 2-channel input block, the sigmoid head -- take the bandwidth-tuned
+  // kernels too: a float4 is then 4 / C voxels)
+  const bool narrow = d->C < 4 && a.VC % 4 == 0 && keep_mask == nullptr &&
+                      (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+  if ((a.vec || narrow) && adell_is_pow2(d->C) && d->C <= 1024 && (a.VC >> 2) < (1L << 40)) {
     long bx = ((a.VC >> 2) + 256 * ADELL_EW_UNROLL - 1) / (256 * ADELL_EW_UNROLL);
     if (bx > ADELL_EW_MAXBLOCKS) bx = ADELL_EW_MAXBLOCKS;
     if (bx < 1) bx = 1;
@@ -839,7 +843,9 @@ static int adell_norm_act_bwd_impl(const adell_norm_act_desc* d, const float* x,
   a.act_w = act_w; a.dx = dx;
   const bool vec = (d->C % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
                    (((uintptr_t)dout & 15) == 0) && (((uintptr_t)dx & 15) == 0);
-  const bool fast = vec && adell_is_pow2(d->C) && d->C <= 1024;
+  const bool narrow = d->C < 4 && a.VC % 4 == 0 && !lr_g && (((uintptr_t)x & 15) == 0) &&
+                      (((uintptr_t)dout & 15) == 0) && (((uintptr_t)dx & 15) == 0);
+  const bool fast = (vec || narrow) && adell_is_pow2(d->C) && d->C <= 1024;
   if (mean || dgamma || dbeta) {
     ADELL_REQUIRE(workspace && (long)workspace_bytes >= adell_norm_act_bwd_workspace(d),
                   "norm_act_bwd: workspace too small");
@@ -909,16 +915,18 @@ __device__ __forceinline__ void adell_na_consts(NaConst& k, const float* mean, c
                                                 const float* gamma, const float* beta,
                                                 const float* act_w, int act_w_n, float act_p,
                                                 const float* c1, const float* c2, long sbase,
-                                                int c) {
+                                                int c, int cmask) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    k.m[j] = mean ? mean[sbase + c + j] : 0.f;
-    k.r[j] = rstd ? rstd[sbase + c + j] : 1.f;
-    k.g[j] = gamma ? gamma[c + j] : 1.f;
-    k.b[j] = beta ? beta[c + j] : 0.f;
-    k.p[j] = act_w ? act_w[act_w_n > 1 ? c + j : 0] : act_p;
-    k.c1[j] = c1 ? c1[sbase + c + j] : 0.f;
-    k.c2[j] = c2 ? c2[sbase + c + j] : 0.f;
+    // (1 or 2 channels: the four lanes of a float4 are 4 / C voxels, channels (c + j) mod C)
+    const int cj = (c + j) & cmask;
+    k.m[j] = mean ? mean[sbase + cj] : 0.f;
+    k.r[j] = rstd ? rstd[sbase + cj] : 1.f;
+    k.g[j] = gamma ? gamma[cj] : 1.f;
+    k.b[j] = beta ? beta[cj] : 0.f;
+    k.p[j] = act_w ? act_w[act_w_n > 1 ? cj : 0] : act_p;
+    k.c1[j] = c1 ? c1[sbase + cj] : 0.f;
+    k.c2[j] = c2 ? c2[sbase + cj] : 0.f;
   }
 }
 
@@ -956,7 +964,7 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
-                  nullptr, (long)n * a.stat_stride_n, c);
+                  nullptr, (long)n * a.stat_stride_n, c, a.C - 1);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   float4* yout = reinterpret_cast<float4*>(a.out) + (long)n * n4;
@@ -1012,7 +1020,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_fast_kernel(NormActBwd
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, a.c1, a.c2,
-                  (long)n * a.stat_stride_n, c);
+                  (long)n * a.stat_stride_n, c, a.C - 1);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, a.gamma, a.beta, a.act_w, a.act_w_n, a.act_p, nullptr,
-                  nullptr, (long)n * a.stat_stride_n, c);
+                  nullptr, (long)n * a.stat_stride_n, c, a.C - 1);
   const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
@@ -1106,6 +1114,18 @@ __global__ __launch_bounds__(256) void adell_na_bwd_partials_fast_kernel(NormAct
     sh[4 + q][threadIdx.x] = B[q];
   }
   __syncthreads();
+  if (a.C < 4) {
+    // 1 or 2 channels: every thread holds the same "quad" (channels q mod C): fold the lanes of
+    // a channel, then the 256 threads in index order (wave shuffles would do; this runs once)
+    if (threadIdx.x < 2 * a.C) {
+      const int ch = threadIdx.x % a.C, which = threadIdx.x / a.C;
+      float s1 = 0.f;
+      for (int kk = 0; kk < 256; ++kk)
+        for (int q = ch; q < 4; q += a.C) s1 += sh[which * 4 + q][kk];
+      a.part[(((size_t)n * a.ntiles + blockIdx.x) * a.C + ch) * 2 + which] = s1;
+    }
+    return;
+  }
   // threads of one block that share a channel quad are CG = C/4 apart
   const int CG = a.C >> 2;
   const int VL = CG >= 256 ? 1 : 256 / CG;
@@ -1133,7 +1153,7 @@ __global__ __launch_bounds__(256) void adell_na_bwd_apply_dt_kernel(NormActBwdAr
   const int c = (int)((j0 << 2) & (a.C - 1));
   NaConst k;
   adell_na_consts(k, a.mean, a.rstd, nullptr, nullptr, nullptr, 0, 0.f, a.c1, a.c2,
-                  (long)n * a.stat_stride_n, c);
+                  (long)n * a.stat_stride_n, c, a.C - 1);
   const float4* xin = reinterpret_cast<const float4*>(a.x) + (long)n * n4;
   const float4* gin = reinterpret_cast<const float4*>(a.dout) + (long)n * n4;
   float4* dxo = reinterpret_cast<float4*>(a.dx) + (long)n * n4;
