@@ -222,6 +222,8 @@ def join_side_stream():
     """Make the current stream -- and every stream a backward node handed work over from (the
     engine's final callbacks need not run under the stream of the forward pass) -- wait for the
     weight gradients still running on the side stream."""
+    # (also re-arms the end-of-backward callback: a backward pass that raised never ran it)
+    _SIDE["callback"] = False
     if _SIDE["pending"]:
         side = _SIDE["stream"]
         cur = torch.cuda.current_stream(side.device)
@@ -288,6 +290,8 @@ def _note_use(weight):
 
 def reset_uses(params):
     """A new step: forget graph nodes that never ran their backward (FlatParameters.zero_grad)."""
+    if torch.cuda.is_available() and _SIDE["pending"]:
+        join_side_stream()
     for p in params:
         if getattr(p, "_adell_uses", 0):
             p._adell_uses = 0
