@@ -445,11 +445,15 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       half8 h0, l0, h1, l1;
       adell_split8(v, scaleA, &h0, &l0);
       adell_split8(v + 8, scaleA, &h1, &l1);
-      // SPEC: slot permutation by the halo row's y. The 16-lane groups of a ds_read_b128 hold
-      // 4 x-neighbours in each of 4 consecutive y (8x8 brick faces), so rows of one y differ in
-      // the bank quarter and the 4 y's in the slot: conflict-free fragment reads (the generic
-      // permutation costs 3x the LDS cycles on this brick).
-      const int sw = SPEC ? ((hv / 10) % 10) & 3 : (hv >> 2) & 3;
+      // SPEC: slot permutation by the halo voxel's x pair, (x >> 1) & 3. The 16-lane groups of a
+      // ds_read_b128 hold 4 x-neighbours in each of 4 consecutive y (8x8 brick faces): with the
+      // row's bank quarter (2 y + x) mod 4 every lane of a group lands in its own (quarter, slot)
+      // cell for all 27 taps -- conflict-free fragment reads (the generic permutation costs 3x
+      // the LDS cycles on this brick) -- and the eight consecutive voxels of a ds_write_b128 group
+      // of the staging stores spread over the four slots as well (a permutation by y alone, round
+      // 2, left them 4-way conflicted: 12-17 % of the kernel's LDS-active cycles;
+      // searched exhaustively over the linear forms of (y, x)).
+      const int sw = SPEC ? ((hv % 10) >> 1) & 3 : (hv >> 2) & 3;
       char* row = sA + (size_t)hv * 64;
       *reinterpret_cast<half8*>(row + ((0 ^ sw) << 4)) = h0;
       *reinterpret_cast<half8*>(row + ((1 ^ sw) << 4)) = h1;
@@ -462,7 +466,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       for (int u = 0; u < KEEP; ++u) {
         const int hv = tid + NTHR * u;
         if (hv < HV) {
-          const int sw = ((hv / 10) % 10) & 3;
+          const int sw = ((hv % 10) >> 1) & 3;
           char* row = sA + (size_t)hv * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q)
@@ -548,8 +552,8 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int hv = arow[mt] + aoff;
-          // SPEC: y of the halo row = (li >> 3) + 4 * (m-tile & 1) + ky  (no carries: x + kx < 10)
-          const int sw = SPEC ? ((li >> 3) + kyl) & 3 : ((hv + (kz * HY + ky0) * HX) >> 2) & 3;
+          // SPEC: x of the halo voxel = (li & 7) + kx  (no carries: x + kx < 10)
+          const int sw = SPEC ? (((li & 7) + kx) >> 1) & 3 : ((hv + (kz * HY + ky0) * HX) >> 2) & 3;
           const char* row = sAg + (size_t)hv * 64;
           ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
           al[mt] = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));

@@ -175,7 +175,7 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
           half8 h0, l0, h1, l1;
           adell_split8(keep[u], scaleA, &h0, &l0);
           adell_split8(keep[u] + 8, scaleA, &h1, &l1);
-          const int sw = ((hv / 10) % 10) & 3;   // slot permutation by the halo row's y
+          const int sw = ((hv % 10) >> 1) & 3;   // slot permutation by the voxel's x pair (conv_igemm_f16.h)
           char* row = base + (size_t)hv * 64;
           *reinterpret_cast<half8*>(row + ((0 ^ sw) << 4)) = h0;
           *reinterpret_cast<half8*>(row + ((1 ^ sw) << 4)) = h1;
@@ -373,8 +373,8 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
           const int aoff = (kz * HY + ky) * HX + kx;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            // y of the halo row = (li >> 3) + 4 * (m-tile & 1) + ky: slot permutation by y & 3
-            const int sw = ((li >> 3) + ky) & 3;
+            // x of the halo voxel = (li & 7) + kx: slot permutation by the x pair
+            const int sw = (((li & 7) + kx) >> 1) & 3;
             const char* row = sAc + (size_t)(arow[mt] + aoff) * 64;
             ah[mt] = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
             al[mt] = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
