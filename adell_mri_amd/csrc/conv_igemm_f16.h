@@ -74,7 +74,7 @@ struct ConvF16Extra {
   } adn[2];
   int dbg;               // timing experiments (-DADELL_DEBUG builds only: ADELL_IGEMM_DBG,
                          // tools/igemm_dbg.py): results are wrong when nonzero. 1: halo staged for chunk 0 only; 2: weights staged
-                         // for the first tap group only; 8: no MFMAs; 16: no output stores
+                         // for the first tap group only; 8: no MFMAs; 16: no output stores; 32: no weight-group barriers
 };
 
 __device__ __forceinline__ void adell_split8(const float* v, float scale, half8* hi, half8* lo) {
@@ -496,7 +496,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       const int gkh = (KH - ky0) < GKH ? (KH - ky0) : GKH;
       const int tpg = SPEC >= 2 ? ((27 - grp * GT) < GT ? (27 - grp * GT) : GT) : gkh * KW;
       const int tap0 = SPEC >= 2 ? grp * GT : (kz * KH + ky0) * KW;
-      if (grp > 0) __syncthreads();  // previous tap group consumed
+      if (grp > 0 && !(ADELL_DBG(e.dbg) & 32)) __syncthreads();  // previous tap group consumed
       // ---- stage the weight slice of this tap group: [tpg][BN][4 slots] -----
       const bool skipB = (ADELL_DBG(e.dbg) & 2) && (ch > 0 || grp > 0);
       if (skipB) {
@@ -531,7 +531,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
           *reinterpret_cast<float4*>(sB + ((size_t)(tl * BN + n) * 4 + (slot ^ ((n >> 2) & 3))) * 16) = f;
         }
       }
-      __syncthreads();
+      if (!(ADELL_DBG(e.dbg) & 32) || grp == 0) __syncthreads();   // (DBG 32: timing without the weight-group barriers)
       if (wpipe && !skipB) {
         // ONE fetch site: with two (next group / first group of the next chunk) the prefetch
         // registers meet in a phi, the copies behind it read them, and the wait for those copies
