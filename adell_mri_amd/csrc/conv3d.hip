@@ -4,6 +4,15 @@
 #include "conv_igemm_f16.h"
 #include "conv_igemm_ws.h"
 
+#ifdef ADELL_DEBUG
+// phase stamps of the f16x3 implicit-GEMM kernel (conv_igemm_f16.h, tools/igemm_stamps.py)
+__device__ unsigned long long* adell_g_stamps = nullptr;
+extern "C" int adell_debug_set_stamps(void* device_buffer) {
+  ADELL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(adell_g_stamps), &device_buffer, sizeof(void*)));
+  return ADELL_OK;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // Tile selection. BM voxels are laid out as a TX x TY x TZ brick (powers of 2).
 // ---------------------------------------------------------------------------

@@ -94,6 +94,21 @@ __device__ __forceinline__ void adell_split8(const float* v, float scale, half8*
 // SPEC = 0 takes all of them from ConvArgs.
 // EPI = 1 (SPEC instances, launches whose bricks are all whole): the fused ADN backward of
 // ConvF16Extra::adn in the epilogue.
+// In-kernel stamps (debug build only, tools/igemm_stamps.py): thread 0 of every block writes
+// s_memtime at the phase boundaries of its life into adell_g_stamps[block][24] when that pointer
+// is set (adell_debug_set_stamps); no stamp executes in the product build.
+#ifdef ADELL_DEBUG
+extern __device__ unsigned long long* adell_g_stamps;
+#define ADELL_STAMP(i)                                                                          \
+  do {                                                                                          \
+    if (adell_g_stamps != nullptr && threadIdx.x == 0)                                          \
+      adell_g_stamps[((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 24 + (i)] = \
+          __builtin_amdgcn_s_memtime();                                                         \
+  } while (0)
+#else
+#define ADELL_STAMP(i) do { } while (0)
+#endif
+
 template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0>
 __global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : (WM * WN >= 8 ? 2 : WM * WN / 2))
 void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
@@ -324,8 +339,10 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     a.part = nullptr;
   }
   if (wpipe && c_beg < c_end) wfetch(c_beg, 0);
+  ADELL_STAMP(0);
   for (int ch = c_beg; ch < c_end; ++ch) {
     const int c0 = ch * CC;
+    if (ch - c_beg < 4) ADELL_STAMP(1 + 4 * (ch - c_beg));
     float mx = 0.f;
     const bool skipA = (ADELL_DBG(e.dbg) & 1) && ch > 0;
 #ifdef ADELL_EXPERIMENTS
@@ -441,6 +458,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
           for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
     }
     kA_prev = kA;
+    if (ch - c_beg < 4) ADELL_STAMP(2 + 4 * (ch - c_beg));
     auto store_split = [&](int hv, const float* v) {
       half8 h0, l0, h1, l1;
       adell_split8(v, scaleA, &h0, &l0);
@@ -488,6 +506,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
         store_split(hv, v);
       }
     }
+    if (ch - c_beg < 4) ADELL_STAMP(3 + 4 * (ch - c_beg));
 #pragma unroll SPEC >= 2 ? NGRP : 1
     for (int grp = 0; grp < ngroups; ++grp) {
       // SPEC 1: group = kz plane; SPEC 2: group = taps [GT * grp, GT * grp + tpg) in (kz, ky, kx)
@@ -623,6 +642,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     }
   }
 
+  ADELL_STAMP(20);
   // ---- epilogue (same contract as the fp32 kernel) ---------------------------
   // A row of the output is addressed as (64-bit block base, per lane and column tile) +
   // (32-bit offset of the row inside the brick); the brick spans < 2^31 elements (checked on
@@ -892,6 +912,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     }
   }
   }
+  ADELL_STAMP(21);
   if (a.part) {
     __syncthreads();
     float* red = smem;  // [WM][BN][2]
@@ -921,6 +942,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
       }
     }
   }
+  ADELL_STAMP(22);
 }
 
 // ---------------------------------------------------------------------------
