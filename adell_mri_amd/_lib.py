@@ -57,24 +57,26 @@ SIGNATURES = {
     "adell_last_error": (ctypes.c_char_p, []),
     "adell_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "adell_conv3d_fwd_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "adell_plan_epoch": (_l, []),
+    "adell_conv3d_fwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "adell_conv3d_bwd_data": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "adell_pack_weight_f16x3_bytes": (_l, [_i, _i, _i, _i]),
     "adell_pack_weight_f16x3": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "adell_conv3d_fwd_ntiles_f16x3": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_fwd_ntiles_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv3d_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10),
+    "adell_conv3d_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 8 + [_i, _vp, _vp]),
     "adell_conv3d_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
     "adell_pack_weight_f16x3_multi": (_i, [_vp, _i, _l, _vp]),
     "adell_conv3d_bwd_data_s2_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
     "adell_conv3d_bwd_data_s2_f16x3_add": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
     "adell_conv3d_fwd_s2_fused_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_fwd_s2_fused_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv3d_fwd_s2_fused": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 8),
+    "adell_conv3d_fwd_s2_fused": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6 + [_i, _vp, _vp]),
     "adell_conv3d_bwd_data_s2_fused_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_bwd_data_s2_fused": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7),
     "adell_conv3d_splitk_workspace": (_l, [ctypes.POINTER(ConvDesc), _i]),
-    "adell_conv3d_fwd_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10 + [ctypes.c_size_t, _vp]),
+    "adell_conv3d_fwd_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 8 + [_i, _vp, _vp,
+                                                                         ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_data_f16x3_ws": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7 + [ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_data_f16x3_add": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7
                                         + [ctypes.c_size_t, _vp]),
@@ -103,7 +105,7 @@ SIGNATURES = {
                                                                               ctypes.c_size_t, _vp]),
     "adell_conv3d_bwd_data_f16x3_adn_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv3d_bwd_data_f16x3_adn": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 7
-                                        + [ctypes.POINTER(AdnSite), ctypes.POINTER(AdnSite), _vp, _vp]),
+                                        + [ctypes.POINTER(AdnSite), ctypes.POINTER(AdnSite), _vp, _i, _vp]),
     "adell_norm_act_bwd_workspace": (_l, [ctypes.POINTER(NormActDesc)]),
     "adell_norm_act_bwd": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 11 + [ctypes.c_size_t, _vp]),
     "adell_norm_act_bwd_lowrank": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp,
@@ -154,8 +156,8 @@ SIGNATURES = {
     "adell_convt_k2_bwd_weight": (_i, [_i] * 6 + [_vp] * 5 + [ctypes.c_size_t, _vp]),
     "adell_conv_cinfold_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv_cinfold_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
-    "adell_conv_cinfold_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
+    "adell_conv_cinfold_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5 + [_i, _vp]),
+    "adell_conv_cinfold_fwd_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5 + [_i, _vp]),
     "adell_conv_cinfold_wgrad_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_bwd_weight": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5
                                       + [ctypes.c_size_t, _vp]),
@@ -179,7 +181,7 @@ SIGNATURES = {
     "adell_conv1_small_bwd_weight": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6 + [ctypes.c_size_t, _vp]),
     "adell_conv_cin_small_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cin_small_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
-    "adell_conv_cin_small_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 6),
+    "adell_conv_cin_small_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5 + [_i, _vp]),
     "adell_conv_cin_small_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),
     "adell_multi_copy": (_i, [_vp, _i, _vp, _vp]),
     "adell_item_stats_workspace": (_l, [_i, _l]),

@@ -50,6 +50,8 @@ static AdellTuning adell_tuning_from_env() {
   return t;
 }
 AdellTuning g_adell_tune = adell_tuning_from_env();
+long g_adell_plan_epoch = 0;
+extern "C" long adell_plan_epoch(void) { return g_adell_plan_epoch; }
 
 static int* adell_tuning_slot(const char* name) {
   if (!name) return nullptr;
@@ -80,6 +82,7 @@ extern "C" int adell_set_tuning(const char* name, int value) {
     adell_set_error("adell_set_tuning: unknown switch '%s'", name ? name : "(null)");
     return ADELL_E_BADARG;
   }
+  if (*slot != value) ++g_adell_plan_epoch;
   *slot = value;
   return ADELL_OK;
 }

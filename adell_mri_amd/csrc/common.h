@@ -32,6 +32,17 @@ struct AdellTuning {
   int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;
+// Bumped by every adell_set_tuning / adell_debug_force_conv_cfg that changes the launch plan:
+// anything a caller sized from an *_ntiles / *_workspace query is valid for one epoch only.
+extern long g_adell_plan_epoch;
+// A statistics / partial-sum buffer the caller sized for `have` rows per batch item, against the
+// `need` rows the plan of THIS launch writes (the row count is also the buffer's stride, so more
+// rows are as wrong as fewer): refuse before anything is launched.
+#define ADELL_REQUIRE_ROWS(ptr, have, need, what)                                              \
+  ADELL_REQUIRE((ptr) == nullptr || (long)(have) == (long)(need),                              \
+                "%s: partial-sum buffer sized for %ld rows per item, the current launch plan "  \
+                "writes %ld (query the matching *_ntiles again after adell_set_tuning)",        \
+                what, (long)(have), (long)(need))
 // Kernel-side timing experiments make results WRONG; they exist only in -DADELL_DEBUG builds.
 #ifdef ADELL_DEBUG
 #define ADELL_DBG(bits) (bits)

@@ -74,7 +74,10 @@ static ConvTile adell_pick_tile(int N, int Do, int Ho, int Wo, int Cout,
 }
 
 static int g_conv_force_cfg = -1;
-extern "C" void adell_debug_force_conv_cfg(int cfg) { g_conv_force_cfg = cfg; }
+extern "C" void adell_debug_force_conv_cfg(int cfg) {
+  if (g_conv_force_cfg != cfg) ++g_adell_plan_epoch;
+  g_conv_force_cfg = cfg;
+}
 
 template <int MT, int NT, int WM, int WN>
 static int adell_launch_conv(const ConvArgs& a, dim3 grid, size_t lds,
@@ -124,6 +127,7 @@ static int adell_conv_dispatch(ConvArgs a, int N, hipStream_t st) {
     adell_set_error("conv: grid too large");
     return ADELL_E_UNSUPPORTED;
   }
+  ADELL_REQUIRE_ROWS(a.part, a.part_rows, nsp, "conv (fp32 MFMA)");
   dim3 grid((unsigned)nsp, (unsigned)adell_cdiv(a.Cout, t.BN), (unsigned)N);
   switch (t.cfg) {
     case 0: return adell_launch_conv<2, 2, 4, 1>(a, grid, lds, st);
@@ -161,14 +165,14 @@ extern "C" int adell_conv3d_fwd_ntiles(const adell_conv3d_desc* d) {
 
 static int adell_fill_fwd(ConvArgs& a, const adell_conv3d_desc* d, const float* x0,
                           const float* x1, const float* bias, const float* residual, float* y,
-                          float* stat_partials) {
+                          float* stat_partials, int partial_rows = 0) {
   int rc = adell_check_desc(d);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(x0 && y, "conv_fwd: null pointer");
   ADELL_REQUIRE(d->C1 == 0 || x1, "conv_fwd: C1 > 0 needs x1");
   a = ConvArgs{};
   a.x0 = x0; a.x1 = x1; a.w = nullptr; a.bias = bias; a.res = residual;
-  a.y0 = y; a.y1 = nullptr; a.part = stat_partials;
+  a.y0 = y; a.y1 = nullptr; a.part = stat_partials; a.part_rows = partial_rows;
   a.D = d->D; a.H = d->H; a.W = d->W;
   a.C0 = d->C0; a.C1 = d->C1; a.Cin = d->C0 + d->C1; a.Cout = d->Cout;
   a.KD = d->KD; a.KH = d->KH; a.KW = d->KW;
@@ -183,9 +187,9 @@ static int adell_fill_fwd(ConvArgs& a, const adell_conv3d_desc* d, const float* 
 extern "C" int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0,
                                 const float* x1, const float* w_packed,
                                 const float* bias, const float* residual,
-                                float* y, float* stat_partials, void* stream) {
+                                float* y, float* stat_partials, int partial_rows, void* stream) {
   ConvArgs a;
-  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
+  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials, partial_rows);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_packed, "conv_fwd: null weights");
   a.w = w_packed;
@@ -677,6 +681,10 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
                     !g_adell_tune.igemm_nospec;
+  if (adn >= 0)
+    ADELL_REQUIRE_ROWS(a.part, a.part_rows,
+                       shares > 1 ? adell_fold_tiles((long)a.Do * a.Ho * a.Wo, N, a.Cout, nsp) : nsp,
+                       "conv f16x3");
   if (adn != 0) {
     // the fused epilogue lives in the interior-brick path of the specialised instances: every brick
     // whole, every 32-column sub-tile whole and on one side of ysplit, no split-K, no
@@ -816,9 +824,9 @@ extern "C" int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x
                                       const float* x1, const void* w_split,
                                       const float* wscale, const float* bias,
                                       const float* residual, float* y, float* stat_partials,
-                                      uint32_t* in_absmax, void* stream) {
+                                      int partial_rows, uint32_t* in_absmax, void* stream) {
   ConvArgs a;
-  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
+  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials, partial_rows);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
   ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr};
@@ -847,10 +855,10 @@ extern "C" int adell_conv3d_fwd_f16x3_ws(const adell_conv3d_desc* d, const float
                                          const float* x1, const void* w_split,
                                          const float* wscale, const float* bias,
                                          const float* residual, float* y, float* stat_partials,
-                                         uint32_t* in_absmax, void* workspace,
+                                         int partial_rows, uint32_t* in_absmax, void* workspace,
                                          size_t workspace_bytes, void* stream) {
   ConvArgs a;
-  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials);
+  int rc = adell_fill_fwd(a, d, x0, x1, bias, residual, y, stat_partials, partial_rows);
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3: null weights");
   ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax, nullptr, nullptr, nullptr};
@@ -913,7 +921,7 @@ extern "C" int adell_conv3d_bwd_data_f16x3_adn(const adell_conv3d_desc* d, const
                                                const float* add0, float* dx0, float* dx1,
                                                uint32_t* dy_absmax, const adell_adn_site* site0,
                                                const adell_adn_site* site1, float* partials,
-                                               void* stream) {
+                                               int partial_rows, void* stream) {
   ConvArgs a;
   int rc = adell_fill_bwd_data(a, d, dy, dx0, dx1);
   if (rc != ADELL_OK) return rc;
@@ -922,6 +930,7 @@ extern "C" int adell_conv3d_bwd_data_f16x3_adn(const adell_conv3d_desc* d, const
   ADELL_REQUIRE(!add0 || d->C1 == 0, "conv_bwd_data_f16x3_adn: add0 needs one destination");
   a.res = add0;
   a.part = partials;
+  a.part_rows = partial_rows;
   ConvF16Extra e = {(const _Float16*)w_split_bwd, wscale, dy_absmax, nullptr, nullptr, nullptr};
   const adell_adn_site* sites[2] = {site0, site1};
   const long V = (long)a.Do * a.Ho * a.Wo;

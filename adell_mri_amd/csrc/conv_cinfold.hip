@@ -565,12 +565,12 @@ extern "C" int adell_conv_cinfold_ntiles(const adell_conv3d_desc* d) {
 
 static int adell_cinfold_fwd_impl(const adell_conv3d_desc* d, const float* x, const float* w,
                                   const float* bias, float* y, float* stat_partials,
-                                  int f16x3, void* stream);
+                                  int partial_rows, int f16x3, void* stream);
 
 extern "C" int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
                                       const float* bias, float* y, float* stat_partials,
-                                      void* stream) {
-  return adell_cinfold_fwd_impl(d, x, w, bias, y, stat_partials, 0, stream);
+                                      int partial_rows, void* stream) {
+  return adell_cinfold_fwd_impl(d, x, w, bias, y, stat_partials, partial_rows, 0, stream);
 }
 
 // The same on the f16 MFMA with error-compensated splits (~2^-22 per product, the precision of
@@ -578,17 +578,19 @@ extern "C" int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x
 // fp32-MFMA kernel.
 extern "C" int adell_conv_cinfold_fwd_f16x3(const adell_conv3d_desc* d, const float* x,
                                             const float* w, const float* bias, float* y,
-                                            float* stat_partials, void* stream) {
-  return adell_cinfold_fwd_impl(d, x, w, bias, y, stat_partials, 1, stream);
+                                            float* stat_partials, int partial_rows,
+                                            void* stream) {
+  return adell_cinfold_fwd_impl(d, x, w, bias, y, stat_partials, partial_rows, 1, stream);
 }
 
 static int adell_cinfold_fwd_impl(const adell_conv3d_desc* d, const float* x, const float* w,
                                   const float* bias, float* y, float* stat_partials,
-                                  int f16x3, void* stream) {
+                                  int partial_rows, int f16x3, void* stream) {
   ADELL_REQUIRE(x && w && y && adell_cinfold_ok(d),
                 "conv_cinfold_fwd: 3x3x3 stride-1 conv with 1..4 input channels expected");
   CinFoldArgs a = {};
   adell_cinfold_fill(&a, d);
+  ADELL_REQUIRE_ROWS(stat_partials, partial_rows, (long)a.ntx * a.nty * a.ntz, "conv_cinfold_fwd");
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.part = stat_partials;
   const long total = (long)d->N * a.ntx * a.nty * a.ntz;
   ADELL_REQUIRE(total < 0x7fffffffL, "conv_cinfold_fwd: too many bricks");

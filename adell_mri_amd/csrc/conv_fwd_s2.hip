@@ -395,9 +395,12 @@ extern "C" int adell_conv3d_fwd_s2_fused_ntiles(const adell_conv3d_desc* d) {
 extern "C" int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float* x,
                                          const void* w_split, const float* wscale,
                                          const float* bias, float* y, float* stat_partials,
-                                         uint32_t* in_absmax, void* stream) {
+                                         int partial_rows, uint32_t* in_absmax, void* stream) {
   ADELL_REQUIRE(fwd_s2_fused_ok(d),
                 "conv_fwd_s2_fused: needs 32 -> 32 channels, k = 3, stride 2, padding 1, even dims");
+  ADELL_REQUIRE_ROWS(stat_partials, partial_rows,
+                     (long)adell_cdiv(d->Wo, 8) * adell_cdiv(d->Ho, 8) * adell_cdiv(d->Do, 4),
+                     "conv_fwd_s2_fused");
   ADELL_REQUIRE(x && w_split && wscale && y, "conv_fwd_s2_fused: null pointer");
   ADELL_REQUIRE(((uintptr_t)x & 15) == 0, "conv_fwd_s2_fused: x must be 16-byte aligned");
   FwdS2Args a;

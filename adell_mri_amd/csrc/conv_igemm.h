@@ -43,6 +43,8 @@ struct ConvArgs {
   int vecx, vecw;     // 16-byte global loads legal for input / weights
   int ksplit;         // f16 kernel: > 1 = blockIdx.z also indexes a share of the channel chunks
   long slab;          // ... whose partial outputs go to y0 + share * slab (plain [N][vox][Cout])
+  int part_rows;      // host side: rows per batch item the caller sized `part` for (checked against
+                      // the launch plan before anything is launched)
 };
 
 template <int MT, int NT, int WM, int WN>

@@ -960,8 +960,9 @@ static int adell_cin_small_fwd_launch(const CinSmallArgs& a, int Cin, dim3 grid,
 
 extern "C" int adell_conv_cin_small_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
                                         const float* bias, float* y, float* stat_partials,
-                                        void* stream) {
+                                        int partial_rows, void* stream) {
   ADELL_REQUIRE(d && x && w && y && adell_cin_small_ok(d), "conv_cin_small_fwd: bad arguments");
+  ADELL_REQUIRE_ROWS(stat_partials, partial_rows, adell_conv_cin_small_ntiles(d), "conv_cin_small_fwd");
   ADELL_REQUIRE(d->N <= 65535, "conv_cin_small_fwd: batch too large");
   CinSmallArgs a = {};
   a.x = x; a.w = w; a.bias = bias; a.y = y; a.part = stat_partials;

@@ -60,8 +60,26 @@ class _Ref:
 # Conv weights packed for the f16x3 kernels (modes 0 / 1) are registered here so that, after an
 # optimiser step has rewritten the parameters, ALL of them are repacked by one launch
 # (adell_pack_weight_f16x3_multi) instead of one ~6 us launch per weight and mode.
-_PACK_REG = {}      # (id(weight), mode) -> [weakref(weight), mode, SplitWeight, tag]
+_PACK_REG = {}      # (id(weight), mode) -> [weakref(weight), mode, SplitWeight, tag, fence]
 _PACK_BATCH = {"epoch": -1, "sig": None, "table": None, "blocks": 0}
+
+
+class _PackFence:
+    """Where a pack was launched: a consumer on ANOTHER stream waits for the event first (the
+    packed copies and the absmax arena used to assume that one stream drives every forward /
+    backward-data launch of the process; two micro-batches on two streams read half-written
+    packs -- round 3's diverged A/B run)."""
+
+    __slots__ = ("stream", "event")
+
+    def __init__(self):
+        self.stream = ops._stream().value
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def order(self):
+        if ops._stream().value != self.stream:
+            torch.cuda.current_stream().wait_event(self.event)
 
 
 def _pack_tag(w):
@@ -93,8 +111,10 @@ def _repack_registered():
         _PACK_BATCH["sig"] = sig
         _PACK_BATCH["blocks"] = first
     ops.pack_weight_f16x3_multi(_PACK_BATCH["table"], len(rows), _PACK_BATCH["blocks"])
+    fence = _PackFence()
     for w, ent in live:
         ent[3] = _pack_tag(w)
+        ent[4] = fence
     _PACK_BATCH["epoch"] = ops.WEIGHT_EPOCH
     return True
 
@@ -111,12 +131,14 @@ def _packed(w, mode):
             ent = None
         if ent is not None:
             if ent[3] == _pack_tag(w):
+                ent[4].order()
                 return ent[2]
             if _PACK_BATCH["epoch"] != ops.WEIGHT_EPOCH and _repack_registered() \
                     and ent[3] == _pack_tag(w):
+                ent[4].order()
                 return ent[2]
         p = ops.pack_weight_f16x3(w.detach(), mode)
-        _PACK_REG[key] = [weakref.ref(w), mode, p, _pack_tag(w)]
+        _PACK_REG[key] = [weakref.ref(w), mode, p, _pack_tag(w), _PackFence()]
         return p
     cache = getattr(w, "_adell_packs", None)
     if cache is None:
@@ -126,6 +148,8 @@ def _packed(w, mode):
     hit = cache.get(key)
     tag = (w._version, w.data_ptr(), ops.WEIGHT_EPOCH)
     if hit is not None and hit[0] == tag:
+        if w.is_cuda:
+            hit[2].order()
         return hit[1]
     wd = w.detach()
     if wd.dim() == 2:  # torch.nn.Linear weight == 1x1x1 convolution weight
@@ -139,7 +163,7 @@ def _packed(w, mode):
         p = ops.pack_weight_f16x3(wd, 0)
     else:
         p = ops.pack_weight_f16x3(wd, mode) if split else ops.pack_weight(wd, mode)
-    cache[key] = (tag, p)
+    cache[key] = (tag, p, _PackFence() if w.is_cuda else None)
     return p
 
 
@@ -154,6 +178,7 @@ def _packed_s2_classes(w, padding):
     key = ("s2", tuple(padding))
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
+        hit[2].order()
         return hit[1]
     wd = w.detach()
     packs = []
@@ -162,7 +187,7 @@ def _packed_s2_classes(w, padding):
         t0 = [(par[a] + padding[a]) & 1 for a in range(3)]
         sub = wd[:, :, t0[0]::2, t0[1]::2, t0[2]::2].contiguous()
         packs.append(ops.pack_weight_f16x3(sub, 1))
-    cache[key] = (tag, packs)
+    cache[key] = (tag, packs, _PackFence())
     return packs
 
 
@@ -176,6 +201,7 @@ def _packed_folded(w):
     tag = _pack_tag(w)
     hit = cache.get("fold")
     if hit is not None and hit[0] == tag:
+        hit[2].order()
         return hit[1]
     wd = w.detach()
     co, ci, kd, kh, kw = wd.shape
@@ -183,19 +209,24 @@ def _packed_folded(w):
     if kw * ci < 16:
         wf = torch.cat([wf, wf.new_zeros(co, 16 - kw * ci, kd, kh, 1)], 1)
     p = ops.pack_weight_f16x3(wf.contiguous(), 0)
-    cache["fold"] = (tag, p)
+    cache["fold"] = (tag, p, _PackFence())
     return p
 
 
 # absmax by-product slots ([0]: input(s) of a conv, [1]: its dy), zeroed in bulk: every slot is
 # handed out once and never reused, so a slot stays valid as long as the graph that holds it --
 # one fill per 256 conv calls instead of one per call
-_AMAX_ARENA = {"buf": None, "next": 0}
+# (one arena per launching stream: the bulk fill is ordered before the kernels that use its slots
+# only on the stream it was issued on)
+_AMAX_ARENAS = {}
 
 
 def _amax_pair(device):
-    a = _AMAX_ARENA
-    if a["buf"] is None or a["buf"].device != device or a["next"] + 2 > a["buf"].numel():
+    key = (device, ops._stream().value)
+    a = _AMAX_ARENAS.get(key)
+    if a is None:
+        a = _AMAX_ARENAS[key] = {"buf": None, "next": 0}
+    if a["buf"] is None or a["next"] + 2 > a["buf"].numel():
         a["buf"] = torch.zeros(512, device=device, dtype=torch.int32)
         a["next"] = 0
     pair = a["buf"][a["next"]:a["next"] + 2]
@@ -210,7 +241,22 @@ def _amax_pair(device):
 # Ordering: the side stream waits for everything queued on the main stream so far (dY, the absmax
 # slots); the main stream waits for the side stream when the backward pass ends (engine callback)
 # and wherever a gradient is read before that (join_side_stream: GradSync buckets, the optimiser).
-_SIDE = {"stream": None, "pending": False, "callback": False, "mains": [], "keep": []}
+_SIDE = {"stream": None, "pending": False, "callback": False, "mains": [], "keep": [],
+         "bytes": 0, "task": -1}
+# the tensors the side stream reads are kept alive until the join: past this many bytes the main
+# stream joins early (mid-backward) and lets them go -- bounds what the overlap adds to the
+# step's peak memory (default: 1/8 of the device; ADELL_SIDE_KEEP_GB overrides)
+_SIDE_KEEP_LIMIT = {"bytes": None}
+
+
+def _side_keep_limit(device):
+    if _SIDE_KEEP_LIMIT["bytes"] is None:
+        env = os.environ.get("ADELL_SIDE_KEEP_GB")
+        if env is not None:
+            _SIDE_KEEP_LIMIT["bytes"] = int(float(env) * (1 << 30))
+        else:
+            _SIDE_KEEP_LIMIT["bytes"] = torch.cuda.get_device_properties(device).total_memory // 8
+    return _SIDE_KEEP_LIMIT["bytes"]
 
 
 def _side_join_callback():
@@ -236,6 +282,7 @@ def join_side_stream():
         # the tensors the side stream read may go back to the allocator now: whatever stream
         # reuses their memory does so behind the wait just queued
         _SIDE["keep"].clear()
+        _SIDE["bytes"] = 0
 
 
 def side_stream_behind(main):
@@ -267,13 +314,21 @@ def side_run(fn, reads):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         out = fn()
-    _SIDE["keep"].extend(t for t in reads if t is not None)
+    for t in reads:
+        if t is not None:
+            _SIDE["keep"].append(t)
+            _SIDE["bytes"] += t.numel() * t.element_size()
     _SIDE["pending"] = True
     if main not in _SIDE["mains"]:
         _SIDE["mains"].append(main)
-    if not _SIDE["callback"]:
-        _SIDE["callback"] = True
+    # one end-of-backward join per GraphTask: a backward pass that raised after a side_run never
+    # ran its callback, and the next pass must queue its own (the flag alone would suppress it)
+    task = torch._C._current_graph_task_id()
+    if not _SIDE["callback"] or _SIDE["task"] != task:
+        _SIDE["callback"], _SIDE["task"] = True, task
         torch.autograd.Variable._execution_engine.queue_callback(_side_join_callback)
+    if _SIDE["bytes"] > _side_keep_limit(main.device):
+        join_side_stream()      # early join: the kept tensors go back to the allocator
     return out
 
 
@@ -284,8 +339,19 @@ def _note_use(weight):
     if torch.is_grad_enabled() and weight.requires_grad:
         n = getattr(weight, "_adell_uses", 0) + 1
         weight._adell_uses = n
-        if n > 1:
+        if n > 1 or _inside_torch_ddp():
             weight._adell_multi = True
+
+
+def _inside_torch_ddp():
+    """True while a torch DistributedDataParallel wrapper runs the forward pass: its Reducer reads
+    every gradient from a C++ hook on the AccumulateGrad node, on the main stream, as soon as the
+    node returns -- invisible to _side_ok's hook checks, so such weights stay on the main stream."""
+    try:
+        from torch.nn.parallel import DistributedDataParallel as _DDP
+        return getattr(_DDP, "_active_ddp_module", None) is not None
+    except Exception:       # torch built without distributed
+        return False
 
 
 def reset_uses(params):
@@ -312,10 +378,21 @@ def _side_ok(weight, *params):
         return False
     if not FLAGS["wgrad_stream"] or torch.is_grad_enabled():     # (create_graph: dW feeds a graph)
         return False
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     for p in (weight,) + params:
         if p is None:
             continue
         if not p.is_leaf or p.grad is not None or p._backward_hooks:
+            return False
+        # OPT-IN: the gradient's consumer must be known to join the side stream before it reads.
+        # That is optim.FlatParameters (collect / zero_grad join) on one process, and with a
+        # process group up additionally parallel.GradSync (its hooks and its all_reduce() go
+        # through collect). Anything else -- a torch optimiser, torch DDP's Reducer (a C++ hook on
+        # the AccumulateGrad node that copies dW into its bucket on the main stream the moment the
+        # node returns) -- gets its gradients on the main stream.
+        if not getattr(p, "_adell_flat", False):
+            return False
+        if dist_on and not getattr(p, "_adell_gradsync", False):
             return False
         # post-accumulate hooks read the gradient on the main stream: only GradSync's own (which
         # join first, FlatParameters.collect) are known to be safe
@@ -467,18 +544,33 @@ class _Conv3dFn(torch.autograd.Function):
             # the input(s) are outputs of norm -> dropout -> activation sites read by this conv
             # only: their activation / dropout derivative and the two sums of the norm's backward
             # come out of this kernel's epilogue (AdnSite)
-            site0, site1, ntiles = ctx.adn
+            site0, site1, ntiles, epoch = ctx.adn
             wpb = _packed(wref.obj, 1)
             if amax is not None:
                 dy_amax = amax[1:2]
-            dx0, dx1, part = ops.conv3d_bwd_data_adn(dy, wpb, tuple(x0.shape[2:]), C0, C1, k,
-                                                     stride, padding, ntiles, site0=site0,
-                                                     site1=site1, amax=dy_amax, add0=add0)
-            add0 = None
-            if site0 is not None:
-                site0.fused, site0.part, site0.poff = True, part, 0
-            if site1 is not None:
-                site1.fused, site1.part, site1.poff = True, part, C0
+            if epoch != ops.plan_epoch():
+                # the launch plan changed between forward and backward (adell_set_tuning): the row
+                # count of the partial-sum buffer is the CURRENT plan's, or the plain path if that
+                # plan has no fused epilogue (the sites then run their own two passes)
+                ntiles = ops.conv3d_bwd_data_adn_ntiles(tuple(x0.shape[2:]), x0.shape[0], C0, C1,
+                                                        dy.shape[1], k, stride, padding)
+            if ntiles > 0:
+                dx0, dx1, part = ops.conv3d_bwd_data_adn(dy, wpb, tuple(x0.shape[2:]), C0, C1, k,
+                                                         stride, padding, ntiles, site0=site0,
+                                                         site1=site1, amax=dy_amax, add0=add0)
+                add0 = None
+                if site0 is not None:
+                    site0.fused, site0.part, site0.poff = True, part, 0
+                if site1 is not None:
+                    site1.fused, site1.part, site1.poff = True, part, C0
+            else:
+                fused = add0 is not None and C1 == 0
+                dx0, dx1 = ops.conv3d_bwd_data(dy, wpb, tuple(x0.shape[2:]), C0, C1, k, stride,
+                                               padding, amax=dy_amax, add0=add0 if fused else None)
+                if fused:
+                    add0 = None
+                if x1 is None or not need[1]:
+                    dx1 = None
         elif need[0] or (x1 is not None and need[1]):
             wpb = _packed(wref.obj, 1)
             if amax is not None and isinstance(wpb, ops.SplitWeight):
@@ -608,7 +700,9 @@ def _adn_sites_of(x0, x1, weight, stride, padding):
         return None
     C0 = x0.shape[1]
     C1 = 0 if x1 is None else x1.shape[1]
-    key = (tuple(x0.shape), C1, tuple(weight.shape), stride, padding)
+    # (the row count is a property of the library's launch plan, which process-wide switches --
+    # adell_set_tuning -- change: one answer per plan epoch)
+    key = (tuple(x0.shape), C1, tuple(weight.shape), stride, padding, ops.plan_epoch())
     nt = _ADN_PLAN.get(key)
     if nt is None:
         nt = ops.conv3d_bwd_data_adn_ntiles(tuple(x0.shape[2:]), x0.shape[0], C0, C1,
@@ -617,7 +711,7 @@ def _adn_sites_of(x0, x1, weight, stride, padding):
         _ADN_PLAN[key] = nt
     if nt <= 0:
         return None
-    return (s0, s1, nt)
+    return (s0, s1, nt, key[-1])
 
 
 def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, want_stats=True,
@@ -736,6 +830,8 @@ class _NormDropActFn(torch.autograd.Function):
             fused, part, poff = site.fused, site.part, site.poff
             site.fused, site.part = False, None
             lowrank, site.lowrank = site.lowrank, None
+            # the site is done: do not pin x / statistics / mask until the graph is freed
+            site.x = site.mean = site.rstd = site.mask = None
             if lowrank is not None:
                 dx = ops.norm_act_bwd_lowrank(x, lowrank[0], lowrank[1], mean, rstd, act,
                                               act_p=act_p, drop_p=drop_p, seed=seed,

@@ -267,11 +267,12 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
         if nt < 0:
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
+    rows = 0 if part is None else part.shape[1]    # checked by the library against its launch plan
     if s2fused:
         check(_timed("adell_fwd_s2_fused_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_fwd_s2_fused(
                          ctypes.byref(d), _ptr(x0), _ptr(w_packed.halfs), _ptr(w_packed.scale),
-                         _ptr(bias), _ptr(y), _ptr(part), _ptr(amax), _stream()),
+                         _ptr(bias), _ptr(y), _ptr(part), rows, _ptr(amax), _stream()),
                      _conv_tag(d, "fwd"), _conv_bytes(d)))
     elif split:
         ws, wsb = _splitk_workspace(d, 0, x0.device)
@@ -279,12 +280,13 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
                      lambda: _lib.lib().adell_conv3d_fwd_f16x3_ws(
                          ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed.halfs),
                          _ptr(w_packed.scale), _ptr(bias), _ptr(residual), _ptr(y), _ptr(part),
-                         _ptr(amax), _ptr(ws), wsb, _stream()), _conv_tag(d, "fwd"),
+                         rows, _ptr(amax), _ptr(ws), wsb, _stream()), _conv_tag(d, "fwd"),
                      _conv_bytes(d, residual is not None)))
     else:
         check(_timed("adell_conv_igemm_kernel", _conv_flops(d), lambda: _lib.lib().adell_conv3d_fwd(
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(w_packed), _ptr(bias), _ptr(residual),
-            _ptr(y), _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d, residual is not None)))
+            _ptr(y), _ptr(part), rows, _stream()), _conv_tag(d, "fwd"),
+            _conv_bytes(d, residual is not None)))
     return y, part
 
 
@@ -319,7 +321,8 @@ def conv_cin_small_fwd(x, weight, bias, padding, want_stats):
     check(_timed("adell_cin_small_kernel", _conv_flops(d),
                  lambda: _lib.lib().adell_conv_cin_small_fwd(
                      ctypes.byref(d), _ptr(x), _ptr(wc), _ptr(bias), _ptr(y),
-                     _ptr(part), _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
+                     _ptr(part), 0 if part is None else part.shape[1], _stream()),
+                 _conv_tag(d, "fwd"), _conv_bytes(d)))
     return y, part
 
 
@@ -368,7 +371,8 @@ def conv_cinfold_fwd(x, weight, bias, padding, want_stats, f16x3=False):
     fn = _lib.lib().adell_conv_cinfold_fwd_f16x3 if f16x3 else _lib.lib().adell_conv_cinfold_fwd
     check(_timed("adell_cinfold_kernel", _conv_flops(d),
                  lambda: fn(ctypes.byref(d), _ptr(x), _ptr(wc), _ptr(bias), _ptr(y), _ptr(part),
-                            _stream()), _conv_tag(d, "fwd"), _conv_bytes(d)))
+                            0 if part is None else part.shape[1], _stream()),
+                 _conv_tag(d, "fwd"), _conv_bytes(d)))
     return y, part
 
 
@@ -518,6 +522,12 @@ def conv3d_bwd_data(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, padding, 
     return dx0, dx1
 
 
+def plan_epoch():
+    """The library's launch-plan epoch (adell_plan_epoch): changes with every adell_set_tuning flip;
+    row counts taken from the *_ntiles queries are valid within one epoch."""
+    return int(_lib.lib().adell_plan_epoch())
+
+
 def conv3d_bwd_data_adn_ntiles(in_size, N, C0, C1, Cout, kernel, stride, padding):
     """Bricks per batch item when the backward-data of this conv takes the fused ADN epilogue
     (adell_conv3d_bwd_data_f16x3_adn), else 0."""
@@ -554,7 +564,8 @@ def conv3d_bwd_data_adn(dy, w_packed_bwd, in_size, C0, C1, kernel, stride, paddi
                      ctypes.byref(d), _ptr(dy), _ptr(w_packed_bwd.halfs), _ptr(w_packed_bwd.scale),
                      _ptr(add0), _ptr(dx0), _ptr(dx1), _ptr(amax),
                      None if s0 is None else ctypes.byref(s0),
-                     None if s1 is None else ctypes.byref(s1), _ptr(part), _stream()),
+                     None if s1 is None else ctypes.byref(s1), _ptr(part), int(ntiles),
+                     _stream()),
                  _conv_tag(d, "dgrad"), _conv_bytes(d, add0 is not None) + extra))
     return dx0, dx1, part
 

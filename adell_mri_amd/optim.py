@@ -53,6 +53,9 @@ class FlatParameters:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                # functional._side_ok: gradients of these parameters are read only through
+                # collect() / zero_grad(), which join the weight-gradient stream first
+                p._adell_flat = True
 
     CHUNK = 16384
 

@@ -143,6 +143,12 @@ class GradSync:
         self.overlap = bool(overlap) and (self.world > 1 or (_force_overlap and dist.is_initialized()))
         self.buckets, self._hooks = [], []
         self._sync = True
+        # functional._side_ok: with a process group up, weight gradients may be produced on the
+        # side stream only for parameters whose exchange goes through this object (every read of a
+        # gradient here is behind FlatParameters.collect, which joins that stream)
+        for flat in getattr(optimizer, "flat_groups", ()):
+            for p in getattr(flat, "params", ()):
+                p._adell_gradsync = True
         if self.overlap:
             nb = int(os.environ.get("ADELL_DDP_BUCKETS", "4")) if n_buckets is None else n_buckets
             me = (1 << 20) if min_bucket_elems is None else min_bucket_elems

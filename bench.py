@@ -30,6 +30,7 @@ timed K steps, plus
   the contract's definition (all K steps between two barriers).
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -224,6 +225,31 @@ def cpu_training_steps(cfg_kwargs, size, threads, warmup, steps):
     return statistics.median(times), torch.get_num_threads()
 
 
+# per-step deltas of the last timed_steps(per_step_events=True) call: (host s, device allocs, device
+# frees, allocator retries, reserved bytes after the step, gc gen0 / gen1 / gen2 passes)
+LAST_DIAG = []
+
+
+def step_record(per, diag):
+    """Self-describing per-step record of a timed region: every step's GPU time, where the slowest
+    one sits and what the host saw during it."""
+    if not per:
+        return None
+    srt = sorted(per)
+    worst = max(range(len(per)), key=lambda i: per[i])
+    rec = {"per_step_ms": [round(v, 2) for v in per], "max_ms": round(srt[-1], 2),
+           "p95_ms": round(srt[min(len(srt) - 1, int(0.95 * len(srt)))], 2), "argmax": worst,
+           "excess_over_median_ms": round(sum(per) - statistics.median(per) * len(per), 2)}
+    if diag and len(diag) == len(per):
+        rec["host_ms"] = [round(1e3 * d[0], 2) for d in diag]
+        rec["device_allocs"] = [d[1] for d in diag]
+        rec["device_frees"] = [d[2] for d in diag]
+        rec["alloc_retries"] = [d[3] for d in diag]
+        rec["reserved_GB"] = [round(d[4] / 2**30, 2) for d in diag]
+        rec["gc_passes"] = [list(d[5:8]) for d in diag]
+    return rec
+
+
 def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None, event_every=1):
     """K training steps between two barriers. ``timer``: the per-launch event timer of the
     dominant kernel family, switched on for every ``event_every``-th step only (each event pair
@@ -237,11 +263,24 @@ def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None,
     overlap = HF.FLAGS["wgrad_stream"]
 
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step_events else None
+    # per-step host-side record (cheap: the host runs ~15 ms ahead of the GPU): host time of the
+    # step's enqueue, the allocator's device-allocation / retry counters, reserved bytes, and the
+    # cyclic collector's pass counts -- what a stalled step is attributed with
+    diag = [] if per_step_events else None
+
+    def probe():
+        st = torch.cuda.memory_stats()
+        g = gc.get_stats()
+        return (time.perf_counter(), st.get("num_device_alloc", 0), st.get("num_device_free", 0),
+                st.get("num_alloc_retries", 0), st.get("reserved_bytes.all.current", 0),
+                g[0]["collections"], g[1]["collections"], g[2]["collections"])
+
     t0 = time.perf_counter()
     loss = None
     for i in range(steps):
         if evs:
             evs[i].record()
+            diag.append(probe())
         if timer is not None:
             timer.active = event_every > 0 and i % event_every == 0
             HF.FLAGS["wgrad_stream"] = overlap and not timer.active
@@ -251,9 +290,13 @@ def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None,
         timer.active = True
     if evs:
         evs[steps].record()
+        diag.append(probe())
     barrier()
     dt = time.perf_counter() - t0
     per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)] if evs else []
+    if diag:
+        LAST_DIAG[:] = [tuple(b[j] - a[j] if j != 4 else b[j] for j in range(8))
+                        for a, b in zip(diag[:-1], diag[1:])]
     return dt, loss, per
 
 
@@ -309,6 +352,9 @@ def main():
     for _ in range(warm_extra):
         runner.train_step(batch)
     barrier()
+    # no device allocation inside a timed region: the pools get their head-room now (round 3's
+    # driver record had a 64 ms and a 112 ms step where the pools grew by 4.3 / 7 GB)
+    reserved_extra = runner.reserve_memory() if args.warmup > 0 else (0, 0)
     dom_warm = warm.dominant() if args.warmup > 0 else None
     warm_summary = warm.summary() if args.warmup > 0 else {}
     ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
@@ -317,6 +363,7 @@ def main():
     barrier()
     dt, loss, per_step = timed_steps(runner, batch, args.steps, barrier, timer=ops.KERNEL_TIMER,
                                      event_every=every)
+    main_record = step_record(per_step, list(LAST_DIAG))
     timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     # the HBM-bound norm / dropout / activation family: its own instrumented steps right after the
     # timed region (clocks still in their loaded state), so that its ~140 event pairs per step do
@@ -368,7 +415,9 @@ def main():
             for _ in range(3):
                 runner.train_step(sb)
             barrier()
+            runner.reserve_memory()
             sdt, _, sper = timed_steps(runner, sb, 5, barrier)
+            srec = step_record(sper, list(LAST_DIAG))
             sdt = reduce_max(sdt, device)
             # its roofline: two instrumented (one-stream) steps after the timed ones
             ops.KERNEL_TIMER = ops.KernelTimer(only=None if dom_warm is None else {dom_warm[0]})
@@ -377,7 +426,7 @@ def main():
             stimer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
             sec = {"value": sbatch * world * 5 / sdt, "unit": "volumes/s",
                    "ms_per_step": 1e3 * sdt / 5, "median_ms_per_step": statistics.median(sper),
-                   "per_step_ms": [round(v, 2) for v in sper],
+                   "step_record": srec,
                    "steps": 5, "warmup": 3, "per_gpu_batch": sbatch, "size": list(sshape)}
             sdom = stimer.dominant()
             if sdom is not None:
@@ -420,9 +469,11 @@ def main():
         med = statistics.median(per_step)
         out["median_ms_per_step"] = med
         out["value_median"] = per_gpu_batch * world / (med * 1e-3)
+        out["step_record"] = main_record
     out["streams"] = {"weight_gradient_stream": bool(overlap),
                       "ms_per_step_one_stream": serial_ms,
                       "untimed_steps_after_warmup": warm_extra,
+                      "pool_headroom_bytes": list(reserved_extra),
                       "note": "the weight-gradient kernels run on a second HIP stream beside the "
                               "backward-data chain; the event-timed steps (roofline) keep one stream"}
     if fp32_line is not None:

@@ -34,7 +34,7 @@ extern "C" {
 #define ADELL_E_HIP (-3)
 #define ADELL_E_NOMEM (-4)
 
-#define ADELL_ABI_VERSION 1
+#define ADELL_ABI_VERSION 2
 
 /* activation ids (reference: adell_mri/modules/activations.py:6-31) */
 enum {
@@ -51,6 +51,16 @@ enum {
 
 int adell_abi_version(void);
 const char* adell_last_error(void);
+
+/* Launch-plan epoch. Every entry point that writes per-block partial sums (`stat_partials`,
+ * `partials`) lays them out as [N][rows][C][2] with `rows` decided by the launch plan, and the
+ * plan depends on process-wide switches (adell_set_tuning). ABI version 2: each such entry point
+ * takes `partial_rows` = the rows per batch item the caller sized the buffer for (from the matching
+ * *_ntiles query) and returns ADELL_E_BADARG -- before anything is launched -- when the plan of the
+ * call would write a different number. adell_plan_epoch() changes whenever a switch changes, so a
+ * caller may cache an *_ntiles answer per epoch. (Round 3 had a fault here: a row count cached on
+ * the host across an adell_set_tuning flip made a kernel write twice the rows it had been given.) */
+long adell_plan_epoch(void);
 
 /* ------------------------------------------------------------------------
  * 3D convolution. Replaces torch.nn.Conv3d at unet.py:260-273 (conv_block_3d),
@@ -87,7 +97,7 @@ int adell_conv3d_fwd_ntiles(const adell_conv3d_desc* d);
 int adell_conv3d_fwd(const adell_conv3d_desc* d, const float* x0, const float* x1,
                      const float* w_packed, const float* bias,
                      const float* residual, float* y, float* stat_partials,
-                     void* stream);
+                     int partial_rows, void* stream);
 
 /* dX of the convolution above (autograd mirror of the same call sites).
  * dx0 receives channels [0,C0), dx1 channels [C0,C0+C1). */
@@ -119,7 +129,7 @@ int adell_conv3d_fwd_ntiles_f16x3_ws(const adell_conv3d_desc* d);
 int adell_conv3d_fwd_f16x3(const adell_conv3d_desc* d, const float* x0, const float* x1,
                            const void* w_split, const float* wscale, const float* bias,
                            const float* residual, float* y, float* stat_partials,
-                           uint32_t* in_absmax, void* stream);
+                           int partial_rows, uint32_t* in_absmax, void* stream);
 int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                 const void* w_split_bwd, const float* wscale, float* dx0,
                                 float* dx1, uint32_t* dy_absmax, void* stream);
@@ -153,7 +163,8 @@ int adell_conv3d_fwd_s2_fused_applicable(const adell_conv3d_desc* d);
 int adell_conv3d_fwd_s2_fused_ntiles(const adell_conv3d_desc* d);
 int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float* x, const void* w_split,
                               const float* wscale, const float* bias, float* y,
-                              float* stat_partials, uint32_t* in_absmax, void* stream);
+                              float* stat_partials, int partial_rows, uint32_t* in_absmax,
+                              void* stream);
 int adell_conv3d_bwd_data_s2_fused(const adell_conv3d_desc* d, const float* dy,
                                    const void* w_split_bwd, const float* wscale,
                                    const float* add0, float* dx, uint32_t* dy_absmax, void* stream);
@@ -167,8 +178,8 @@ long adell_conv3d_splitk_workspace(const adell_conv3d_desc* d, int backward_data
 int adell_conv3d_fwd_f16x3_ws(const adell_conv3d_desc* d, const float* x0, const float* x1,
                               const void* w_split, const float* wscale, const float* bias,
                               const float* residual, float* y, float* stat_partials,
-                              uint32_t* in_absmax, void* workspace, size_t workspace_bytes,
-                              void* stream);
+                              int partial_rows, uint32_t* in_absmax, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int adell_conv3d_bwd_data_f16x3_ws(const adell_conv3d_desc* d, const float* dy,
                                    const void* w_split_bwd, const float* wscale, float* dx0,
                                    float* dx1, uint32_t* dy_absmax, void* workspace,
@@ -202,7 +213,8 @@ int adell_conv3d_bwd_data_f16x3_adn(const adell_conv3d_desc* d, const float* dy,
                                     const void* w_split_bwd, const float* wscale,
                                     const float* add0, float* dx0, float* dx1,
                                     uint32_t* dy_absmax, const adell_adn_site* site0,
-                                    const adell_adn_site* site1, float* partials, void* stream);
+                                    const adell_adn_site* site1, float* partials,
+                                    int partial_rows, void* stream);
 
 /* dW in torch's canonical [Cout][Cin][kD][kH][kW] layout (split-K over voxel
  * bricks, fixed-order reduction: deterministic) and, when db != NULL, the bias
@@ -588,11 +600,13 @@ int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, con
 int adell_conv_cinfold_applicable(const adell_conv3d_desc* d);
 int adell_conv_cinfold_ntiles(const adell_conv3d_desc* d);
 int adell_conv_cinfold_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
-                           const float* bias, float* y, float* stat_partials, void* stream);
+                           const float* bias, float* y, float* stat_partials, int partial_rows,
+                           void* stream);
 /* the same arithmetic on the f16 MFMA with error-compensated operand splits (two input channels;
  * other channel counts run the exact kernel above) */
 int adell_conv_cinfold_fwd_f16x3(const adell_conv3d_desc* d, const float* x, const float* w,
-                                 const float* bias, float* y, float* stat_partials, void* stream);
+                                 const float* bias, float* y, float* stat_partials, int partial_rows,
+                           void* stream);
 long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d);
 int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x, const float* dy,
                                   float* dw, float* db, void* workspace, size_t workspace_bytes,
@@ -628,7 +642,8 @@ int adell_conv1_small_bwd_weight(const adell_conv3d_desc* d, const float* x0, co
 int adell_conv_cin_small_applicable(const adell_conv3d_desc* d);
 int adell_conv_cin_small_ntiles(const adell_conv3d_desc* d);
 int adell_conv_cin_small_fwd(const adell_conv3d_desc* d, const float* x, const float* w,
-                             const float* bias, float* y, float* stat_partials, void* stream);
+                             const float* bias, float* y, float* stat_partials, int partial_rows,
+                           void* stream);
 int adell_conv_cin_small_bwd_data(const adell_conv3d_desc* d, const float* dy, const float* w,
                                   float* dx, void* stream);
 

@@ -29,6 +29,41 @@ def steps(net, batch, n, **sync_kw):
     return sync, losses, {k: p.detach().cpu().clone() for k, p in net.named_parameters()}
 
 
+def ddp_steps(device, batch, side_stream):
+    """Two steps of the small U-Net wrapped in torch DistributedDataParallel (the reference's
+    Lightning strategy="ddp" route) with the fused optimiser: DDP's Reducer copies every gradient
+    into its bucket from a C++ hook on the main stream as soon as the node returns, so no weight
+    gradient of a DDP-managed module may be produced on the side stream (functional._side_ok).
+    Returns (losses, parameters, number of side_run calls)."""
+    import ddp_worker
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    from adell_mri_amd import functional as HF
+
+    HF.FLAGS["wgrad_stream"] = side_stream
+    calls = []
+    real = HF.side_run
+    HF.side_run = lambda fn, reads: calls.append(1) or real(fn, reads)
+    try:
+        net = ddp_worker.build(device)
+        opt = net.configure_optimizers()["optimizer"]
+        ddp = DDP(net, device_ids=[0])
+        losses = []
+        for _ in range(2):
+            opt.zero_grad()
+            out = ddp(batch["image"])
+            prob = out[0] if isinstance(out, tuple) else out
+            loss = ((prob - batch["mask"]) ** 2).mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+    finally:
+        HF.side_run = real
+        HF.FLAGS["wgrad_stream"] = True
+    return losses, {k: p.detach().cpu().clone() for k, p in net.named_parameters()}, len(calls)
+
+
 def main():
     import ddp_worker
 
@@ -65,8 +100,11 @@ def main():
     net3.training_step(batch, 0).backward()
     opt3.collect_grads()
     once = opt3.flat_groups[0].grad.detach().cpu().clone()
+    ddp_on = ddp_steps(device, batch, True)
+    ddp_off = ddp_steps(device, batch, False)
     torch.save({"params": params, "plain": plain, "losses": losses, "plain_losses": plain_losses,
-                "twice": twice, "once": once}, os.path.join(out, "rccl.pt"))
+                "twice": twice, "once": once, "ddp_on": ddp_on, "ddp_off": ddp_off},
+               os.path.join(out, "rccl.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

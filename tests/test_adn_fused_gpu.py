@@ -135,6 +135,46 @@ def test_residual_block_gradients_do_not_depend_on_the_fusion(cuda, monkeypatch)
             assert _rel(gw_f[k], gw_p[k]) <= 5e-5, k
 
 
+def test_launch_plan_flipped_between_forward_and_backward(cuda):
+    """adell_set_tuning between the forward and the backward of a block whose inner site rides the
+    second conv's backward-data epilogue: the partial-sum rows are the CURRENT plan's (the forward
+    planned 8x8x8 bricks, the backward runs 8x8x4 ones: twice the rows), never a count cached from
+    the forward -- the gradients equal the unflipped run, and the C entry refuses a stale count
+    outright (round 3's A/B fault; include/adell_hip.h, ABI version 2). Run once."""
+    from adell_mri_amd import _lib
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+
+    blk = _block(cuda, 32)
+    x = torch.randn(2, 32, 32, 32, 32, device=cuda)
+    r = torch.randn(2, 32, 32, 32, 32, device=cuda)
+    y0, gx0, gw0 = _run_block(blk, x, r)
+
+    HF._dropout_counter = itertools.count(1)
+    blk.zero_grad()
+    xg = x.clone().requires_grad_(True)
+    y = blk(xg)                                   # planned under the default switches
+    size, k, st, pad = (32, 32, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    rows_fwd = ops.conv3d_bwd_data_adn_ntiles(size, 2, 32, 0, 32, k, st, pad)
+    with _lib.tuning(igemm_no8=1):
+        rows_bwd = ops.conv3d_bwd_data_adn_ntiles(size, 2, 32, 0, 32, k, st, pad)
+        assert rows_bwd not in (0, rows_fwd)
+        # the stale count is refused before anything is launched
+        w = blk.op[2].weight if hasattr(blk, "op") else next(blk.parameters())
+        dy = ops.ndhwc(torch.randn(2, w.shape[0], *size, device=cuda))
+        site = _site(cuda, torch.Generator().manual_seed(3), 2, 32, size, "swish", 0.0, 5)[0]
+        with pytest.raises(_lib.AdellHipError, match="rows"):
+            ops.conv3d_bwd_data_adn(dy, HF._packed(w, 1), size, 32, 0, k, st, pad, rows_fwd,
+                                    site0=site)
+        (y * r).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(y.detach(), y0)
+    assert _rel(xg.grad, gx0) <= 2e-5
+    scale = max(float(v.abs().max()) for v in gw0.values())
+    for name, v in blk.named_parameters():
+        assert float((v.grad - gw0[name]).abs().max()) <= 5e-5 * scale, name
+
+
 def test_residual_block_matches_torch_autograd(cuda, monkeypatch):
     """The fused path against stock torch (fp64, CPU; no dropout: torch's mask stream differs)."""
     from adell_mri_amd import ops

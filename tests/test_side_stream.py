@@ -12,6 +12,17 @@ def test_use_counting_decides_when_the_side_stream_is_safe(monkeypatch):
     monkeypatch.setitem(HF.FLAGS, "wgrad_stream", True)
     w = torch.nn.Parameter(torch.zeros(4, 4))
     b = torch.nn.Parameter(torch.zeros(4))
+    # opt-in: only parameters owned by optim.FlatParameters (whose collect / zero_grad join the side
+    # stream before a gradient is read) may have their gradients produced off the main stream
+    HF._note_use(w)
+    with torch.no_grad():
+        assert not HF._side_ok(w, b, None)      # a plain parameter (torch optimiser, DDP, ...)
+    w._adell_flat = b._adell_flat = True        # what FlatParameters.__init__ sets
+    HF._note_use(w)
+    with torch.no_grad():
+        b._adell_flat = False
+        assert not HF._side_ok(w, b)            # every parameter of the node must qualify
+        b._adell_flat = True
     with torch.no_grad():                       # (a backward pass runs with grad mode off)
         HF._note_use(w)                         # no graph is being built: not counted
         assert getattr(w, "_adell_uses", 0) == 0
@@ -32,6 +43,7 @@ def test_use_counting_decides_when_the_side_stream_is_safe(monkeypatch):
     # an existing gradient (accumulation), a tensor hook, a foreign post-accumulate hook
     for spoil in ("grad", "hook", "post"):
         w2 = torch.nn.Parameter(torch.zeros(4, 4))
+        w2._adell_flat = True
         HF._note_use(w2)
         if spoil == "grad":
             w2.grad = torch.zeros(4, 4)
@@ -53,6 +65,25 @@ def test_use_counting_decides_when_the_side_stream_is_safe(monkeypatch):
     HF._note_use(w)
     with torch.no_grad():
         assert not HF._side_ok(w, b)
+    monkeypatch.setitem(HF.FLAGS, "wgrad_stream", True)
+    # a forward pass under torch DistributedDataParallel marks its weights: main stream
+    monkeypatch.setattr(HF, "_inside_torch_ddp", lambda: True)
+    HF._note_use(w)
+    with torch.no_grad():
+        assert not HF._side_ok(w, b)
+    monkeypatch.setattr(HF, "_inside_torch_ddp", lambda: False)
+    HF._note_use(w)
+    with torch.no_grad():
+        assert HF._side_ok(w, b)
+    # with a process group up, only parameters whose exchange goes through parallel.GradSync
+    monkeypatch.setattr(torch.distributed, "is_initialized", lambda: True)
+    HF._note_use(w)
+    with torch.no_grad():
+        assert not HF._side_ok(w, b)
+    w._adell_gradsync = b._adell_gradsync = True
+    HF._note_use(w)
+    with torch.no_grad():
+        assert HF._side_ok(w, b)
 
 
 def _small_unet(cuda, seed=0):
@@ -123,6 +154,9 @@ def test_shared_weight_and_accumulation_stay_on_the_main_stream(cuda, monkeypatc
     monkeypatch.setattr(HF, "side_run", lambda fn, reads: calls.append(1) or real(fn, reads))
     torch.manual_seed(1)
     conv = Conv3d(16, 16, 3, padding=1).to(cuda)
+    for p in conv.parameters():
+        p._adell_flat = True     # (as optim.FlatParameters marks its parameters; the test joins by
+                                 # the end-of-backward callback)
     x = torch.randn(1, 16, 8, 8, 8, device=cuda)
     # one use: side stream; the gradient is complete when backward() returns (engine callback)
     conv(x).sum().backward()
@@ -157,6 +191,8 @@ def test_forward_on_a_non_default_stream_is_joined_on_that_stream(cuda, monkeypa
     monkeypatch.setitem(HF.FLAGS, "wgrad_stream", True)
     torch.manual_seed(2)
     conv = Conv3d(32, 32, 3, padding=1).to(cuda)
+    for p in conv.parameters():
+        p._adell_flat = True
     x = torch.randn(2, 32, 48, 48, 48, device=cuda)
     conv(x).sum().backward()
     torch.cuda.synchronize()

@@ -96,3 +96,12 @@ def test_single_rank_rccl_overlap_path(cuda, tmp_path):
         assert torch.equal(res["params"][k], p), k
     scale = float(res["once"].abs().max())
     assert float((res["twice"] - 2.0 * res["once"]).abs().max()) <= 1e-6 * scale
+    # the same network under torch DistributedDataParallel (Lightning's strategy="ddp"): no weight
+    # gradient leaves the main stream (DDP's Reducer reads it from a C++ hook the moment the node
+    # returns), and the steps are bit-identical with the side stream switched off
+    l_on, p_on, calls_on = res["ddp_on"]
+    l_off, p_off, calls_off = res["ddp_off"]
+    assert calls_on == 0 and calls_off == 0
+    assert l_on == l_off
+    for k, p in p_off.items():
+        assert torch.equal(p_on[k], p), k

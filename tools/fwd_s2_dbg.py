@@ -30,7 +30,7 @@ stream = torch.cuda.current_stream().cuda_stream
 
 def launch():
     rc = L.adell_conv3d_fwd_s2_fused(ctypes.addressof(d), x.data_ptr(), pack.halfs.data_ptr(),
-                                     pack.scale.data_ptr(), None, y.data_ptr(), None, None, stream)
+                                     pack.scale.data_ptr(), None, y.data_ptr(), None, 0, None, stream)
     assert rc == 0, rc
 
 
