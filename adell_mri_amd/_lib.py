@@ -100,6 +100,14 @@ SIGNATURES = {
     "adell_channel_partials": (_i, [_vp, _i, _l, _i, _vp, _vp]),
     "adell_norm_act_fwd": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "adell_norm_act_mask_bytes": (_l, [ctypes.POINTER(NormActDesc)]),
+    "adell_norm_act_fwd_split": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 7 + [_i, _vp, _vp]),
+    "adell_split_rows_from_f32": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp]),
+    "adell_split_rows_to_f32": (_i, [_vp, _i, _l, _i, _vp, _vp, _vp]),
+    "adell_conv3d_f16x3_rows_ok": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_bwd_weight_f16x3_rows_ok": (_i, [ctypes.POINTER(ConvDesc)]),
+    "adell_conv3d_bwd_weight_f16x3_rows": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10
+                                           + [ctypes.c_size_t, _vp]),
+    "adell_conv3d_fwd_f16x3_rows": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 10 + [_i, _vp, _vp]),
     "adell_norm_act_fwd_mask": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 9),
     "adell_norm_act_bwd_from_dt": (_i, [ctypes.POINTER(NormActDesc)] + [_vp] * 5 + [_i, _i, _i, _vp, _vp,
                                                                               ctypes.c_size_t, _vp]),

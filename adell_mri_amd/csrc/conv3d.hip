@@ -356,11 +356,11 @@ extern "C" int adell_pack_weight(const float* w, float* out, int mode, int dim0,
 // ---------------------------------------------------------------------------
 // f16x3 path (conv_igemm_f16.h): fp32 tensors in and out, 3 f16 MFMAs per K-block.
 // ---------------------------------------------------------------------------
-template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0>
+template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0, int ROWS = 0>
 static int adell_launch_conv_f16(const ConvArgs& a, const ConvF16Extra& e, dim3 grid, size_t lds,
                                  hipStream_t st) {
   static bool attr_done = false;
-  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN, SPEC, EPI>;
+  auto kern = adell_conv_igemm_f16_kernel<MT, NT, WM, WN, SPEC, EPI, ROWS>;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -633,7 +633,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                                    void* ws = nullptr, size_t ws_bytes = 0, int adn = 0) {
   ConvTile t;
   size_t lds;
-  int rc = adell_plan_f16(a, N, &t, &lds, adn != 0);
+  int rc = adell_plan_f16(a, N, &t, &lds, adn == 1 || adn == -1);
   if (rc != ADELL_OK) return adn < 0 ? 0 : rc;
   // (the f16x3 kernel's 16-byte halo loads address a batch item with 32-bit byte offsets)
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
@@ -681,6 +681,15 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
                     (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
                     !g_adell_tune.igemm_nospec;
+  // split-row sources are staged by the specialised instances only (no split-K: a share would have
+  // to know the rows' exponent of chunks it does not own... it could; it is simply not built)
+  const bool rows_ok = shares == 1 && ((t.cfg <= 1 && spec) || t.cfg == 4);
+  if (adn == -2) return rows_ok ? 1 : 0;
+  if ((e.xs0 != nullptr || e.xs1 != nullptr) && !rows_ok) {
+    adell_set_error("conv f16x3: this problem's launch plan does not take split-row sources "
+                    "(adell_conv3d_f16x3_rows_ok)");
+    return ADELL_E_UNSUPPORTED;
+  }
   if (adn >= 0)
     ADELL_REQUIRE_ROWS(a.part, a.part_rows,
                        shares > 1 ? adell_fold_tiles((long)a.Do * a.Ho * a.Wo, N, a.Cout, nsp) : nsp,
@@ -705,13 +714,29 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
     }
   }
   int rc2 = ADELL_OK;
+  if (e.xs0 != nullptr || e.xs1 != nullptr) {
+    // split-row sources (rows_ok above): the instance without the fp32 staging path when every
+    // source is rows, else the one that decides per source
+    const bool all_rows = e.xs0 != nullptr && (a.C1 == 0 || e.xs1 != nullptr);
+    switch (t.cfg) {
+      case 0:
+        return all_rows ? adell_launch_conv_f16<2, 2, 4, 1, 1, 0, 2>(a, e, grid, lds, st)
+                        : adell_launch_conv_f16<2, 2, 4, 1, 1, 0, 1>(a, e, grid, lds, st);
+      case 4:
+        return all_rows ? adell_launch_conv_f16<4, 1, 4, 1, 3, 0, 2>(a, e, grid, lds, st)
+                        : adell_launch_conv_f16<4, 1, 4, 1, 3, 0, 1>(a, e, grid, lds, st);
+      default:
+        return all_rows ? adell_launch_conv_f16<2, 1, 4, 1, 1, 0, 2>(a, e, grid, lds, st)
+                        : adell_launch_conv_f16<2, 1, 4, 1, 1, 0, 1>(a, e, grid, lds, st);
+    }
+  }
   // large 3x3x3 stride-1 layers, opt-in ("igemm_ws"): the persistent wave-specialised instance
   // (conv_igemm_ws.h), one block per CU walking >= ws_min_items / CUs bricks. Measured on MI355X
   // (round 2): +5-9 % over the one-brick-per-block instances when a layer is timed alone
   // (64->64 @ 2 x 128^3: 2.62 vs 2.87 ms), -3 % inside the training step (41.0 vs 39.9 ms), where
   // the chip holds a lower clock under the denser MFMA issue; not the default.
-  if (shares == 1 && g_adell_tune.igemm_ws && a.Cin % 16 == 0 &&
-      ((t.cfg == 0 && spec) || t.cfg == 4)) {
+  if (shares == 1 && g_adell_tune.igemm_ws && a.Cin % 16 == 0 && e.xs0 == nullptr &&
+      e.xs1 == nullptr && ((t.cfg == 0 && spec) || t.cfg == 4)) {
     const int nct = adell_cdiv(a.Cout, t.BN);
     const long items = (long)N * nsp * nct;
     if (items >= g_adell_tune.ws_min_items && items < 0x7fffffffL)
@@ -1092,76 +1117,42 @@ extern "C" int adell_debug_ws_prof(unsigned long long* out) {
 }
 #endif
 
-#ifdef ADELL_EXPERIMENTS
 // ---------------------------------------------------------------------------
-// EXPERIMENT (tools/presplit_exp.py): activations stored pre-split.
-// adell_presplit rewrites an NDHWC fp32 tensor as the 64-byte rows the f16x3 kernels stage into
-// LDS (same bytes per element), scaled per (item, 16-channel chunk) by 2^xk; the forward below
-// takes such tensors, so that its halo staging is a copy. Not part of include/adell_hip.h and
-// not in the shipped library: `make -C adell_mri_amd/csrc EXPERIMENTS=1`. Measured (round 2,
-// 2 x 128^3): 32 -> 32 +10 %, 64 -> 64 +3 %, 32+32 -> 32 +11 % -- less than the extra 4 B / element
-// the norm / activation kernels would have to write, so the format change was not made.
+// Split-row sources (round 4): the forward of a 3x3x3 stride-1 layer whose input(s) the producer
+// already wrote as the 64-byte hi | lo rows of the kernels' LDS image (adell_norm_act_fwd_split;
+// ConvF16Extra::xs0 / xs1). xk0 / xk1 non-null: that source is rows with exponents
+// xk[N][C / 16]; null: fp32 as in adell_conv3d_fwd_f16x3. _rows_ok: 1 when the forward plan of
+// `d` stages rows (the specialised instances; never split-K).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adell_presplit_kernel(const float* __restrict__ x,
-                                                             const int* __restrict__ xk,
-                                                             char* __restrict__ xs, long V, int C,
-                                                             long total) {
-  const int nch = C >> 4;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    const int ch = (int)(i % nch);
-    const long v = i / nch;                    // voxel over the whole batch
-    const int n = (int)(v / V);
-    const float scale = __int_as_float((xk[n * nch + ch] + 127) << 23);
-    const float4* p = reinterpret_cast<const float4*>(x + v * C + ch * 16);
-    float f[16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 t = p[q];
-      f[4 * q] = t.x; f[4 * q + 1] = t.y; f[4 * q + 2] = t.z; f[4 * q + 3] = t.w;
-    }
-    half8 h0, l0, h1, l1;
-    adell_split8(f, scale, &h0, &l0);
-    adell_split8(f + 8, scale, &h1, &l1);
-    half8* o = reinterpret_cast<half8*>(xs + i * 64);
-    o[0] = h0; o[1] = h1; o[2] = l0; o[3] = l1;
-  }
-}
-
-extern "C" int adell_presplit(const float* x, int N, long V, int C, const int* xk, void* xs,
-                              void* stream) {
-  ADELL_REQUIRE(x && xk && xs && N > 0 && V > 0 && C >= 16 && C % 16 == 0, "presplit: bad arguments");
-  const long total = (long)N * V * (C >> 4);
-  long blocks = (total + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(adell_presplit_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                     (hipStream_t)stream, x, xk, (char*)xs, V, C, total);
-  ADELL_CHECK_HIP(hipGetLastError());
-  return ADELL_OK;
-}
-
-extern "C" int adell_conv3d_fwd_f16x3_presplit(const adell_conv3d_desc* d, const void* xs0,
-                                               const void* xs1, const int* xk,
-                                               const void* w_split, const float* wscale,
-                                               const float* bias, const float* residual, float* y,
-                                               float* stat_partials, void* stream) {
+extern "C" int adell_conv3d_f16x3_rows_ok(const adell_conv3d_desc* d) {
   ConvArgs a;
-  // the fp32 pointers are never dereferenced on this path; they carry alignment checks only
-  int rc = adell_fill_fwd(a, d, (const float*)xs0, (const float*)xs1, bias, residual, y,
-                          stat_partials);
+  alignas(16) static float dummy[4];
+  if (adell_fill_fwd(a, d, dummy, d && d->C1 > 0 ? dummy : nullptr, nullptr, nullptr, dummy,
+                     nullptr) != ADELL_OK)
+    return 0;
+  ConvF16Extra e = {};
+  // (the plan of adell_conv3d_fwd_f16x3_ws, which the caller would otherwise use: a layer that
+  // runs split-K there is too small to gain from rows)
+  static float ws_probe;
+  const long wsb = adell_conv3d_splitk_workspace(d, 0);
+  return adell_conv_dispatch_f16(a, e, d->N, nullptr, wsb > 0 ? &ws_probe : nullptr,
+                                 wsb > 0 ? (size_t)wsb : 0, -2);
+}
+
+extern "C" int adell_conv3d_fwd_f16x3_rows(const adell_conv3d_desc* d, const void* x0,
+                                           const int* xk0, const void* x1, const int* xk1,
+                                           const void* w_split, const float* wscale,
+                                           const float* bias, const float* residual, float* y,
+                                           float* stat_partials, int partial_rows,
+                                           uint32_t* in_absmax, void* stream) {
+  ConvArgs a;
+  int rc = adell_fill_fwd(a, d, (const float*)x0, (const float*)x1, bias, residual, y,
+                          stat_partials, partial_rows);
   if (rc != ADELL_OK) return rc;
-  ADELL_REQUIRE(w_split && wscale && xs0 && xk, "conv_fwd_f16x3_presplit: null pointer");
-  ADELL_REQUIRE(d->KD == 3 && d->KH == 3 && d->KW == 3 && d->SD == 1 && d->SH == 1 && d->SW == 1 &&
-                    d->C0 % 16 == 0 && d->C1 % 16 == 0,
-                "conv_fwd_f16x3_presplit: 3x3x3 stride-1 layers with 16-channel-aligned sources");
-  ConvF16Extra e = {(const _Float16*)w_split, wscale, nullptr, (const char*)xs0,
-                    (const char*)xs1, xk, 0};
-  ConvTile t;
-  size_t lds;
-  ConvArgs probe = a;
-  rc = adell_plan_f16(probe, d->N, &t, &lds);
-  if (rc != ADELL_OK) return rc;
-  ADELL_REQUIRE(t.cfg == 4 || t.cfg == 0,
-                "conv_fwd_f16x3_presplit: this shape does not take a specialised instance");
+  ADELL_REQUIRE(w_split && wscale, "conv_fwd_f16x3_rows: null weights");
+  ADELL_REQUIRE(xk0 || xk1, "conv_fwd_f16x3_rows: no split-row source (use adell_conv3d_fwd_f16x3)");
+  ADELL_REQUIRE(!xk1 || x1, "conv_fwd_f16x3_rows: xk1 without x1");
+  ConvF16Extra e = {(const _Float16*)w_split, wscale, in_absmax,
+                    xk0 ? (const char*)x0 : nullptr, xk1 ? (const char*)x1 : nullptr, xk0, xk1};
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
-#endif  // ADELL_EXPERIMENTS

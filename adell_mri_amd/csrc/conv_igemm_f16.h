@@ -49,13 +49,15 @@ struct ConvF16Extra {
   const _Float16* wh;    // packed split weights [tap][Cout][nchunk][32 halfs]
   const float* wscale;   // [Cout] 2^-kw[n]: undoes the per-output-channel weight scale
   unsigned* amax_out;    // optional: receives the absmax (float bits) of the input tensor(s)
-  // pre-split activations (optional): the input tensor(s) already hold, per voxel and 16-channel
-  // chunk, the 64-byte row [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] of the LDS image, scaled by
-  // 2^xk[item * nchunk + chunk] (same bytes per element as fp32). Staging is then a copy: no
-  // block-wide absmax, no conversion VALU work.
+  // Split-row sources (optional, per source; SPEC instances): the tensor holds, per voxel and
+  // 16-channel chunk, the 64-byte row [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] of the LDS image, scaled
+  // by 2^xk[item * (C / 16) + chunk] (same bytes per element as fp32; written by the producer:
+  // adell_norm_act_fwd_split). Staging is then a copy: no block-wide absmax, no conversion VALU
+  // work. xs0 / xs1 null: that source is fp32 (a.x0 / a.x1).
   const char* xs0;
   const char* xs1;
-  const int* xk;
+  const int* xk0;
+  const int* xk1;
   // Backward of a norm -> dropout -> activation site fused into this (backward-data) launch
   // (EPI = 1 instances): destination d (0: columns [0, ysplit), 1: the rest) is the gradient with
   // respect to the OUTPUT of such a site whose pre-norm input is adn[d].y (same shape as the
@@ -109,7 +111,10 @@ extern __device__ unsigned long long* adell_g_stamps;
 #define ADELL_STAMP(i) do { } while (0)
 #endif
 
-template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0>
+// ROWS (SPEC instances): 0 = fp32 sources; 2 = every source holds split rows (ConvF16Extra::xs0 /
+// xs1: staging is a copy, the fp32 staging path is not compiled in); 1 = decided per source at run
+// time (the two halves of a virtual concat in different formats: both paths compiled in).
+template <int MT, int NT, int WM, int WN, int SPEC, int EPI = 0, int ROWS = 0>
 __global__ __launch_bounds__(WM * WN * 64, SPEC == 2 ? 3 : (WM * WN >= 8 ? 2 : WM * WN / 2))
 void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   constexpr int BN = WN * NT * 32, CC = 16;
@@ -345,11 +350,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     if (ch - c_beg < 4) ADELL_STAMP(1 + 4 * (ch - c_beg));
     float mx = 0.f;
     const bool skipA = (ADELL_DBG(e.dbg) & 1) && ch > 0;
-#ifdef ADELL_EXPERIMENTS
-    const bool presplit = SPEC && e.xs0 != nullptr;
-#else
-    constexpr bool presplit = false;   // tools/presplit_exp.py: `make EXPERIMENTS=1` builds
-#endif
+    const bool presplit = SPEC != 0 && (ROWS == 2 || (ROWS == 1 && (c0 < a.C0 ? e.xs0 : e.xs1) != nullptr));
     if (skipA) {
     } else if (presplit) {
       if constexpr (SPEC) {
@@ -426,7 +427,8 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
     int kA = 0;
     if (presplit) {
       __syncthreads();  // previous chunk's MFMAs are done: LDS may be overwritten
-      kA = e.xk[nb * nchunk + ch];
+      kA = c0 < a.C0 ? e.xk0[nb * (a.C0 >> 4) + (c0 >> 4)]
+                     : e.xk1[nb * (a.C1 >> 4) + ((c0 - a.C0) >> 4)];
     } else {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));

@@ -454,7 +454,8 @@ extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int 
                                         int C1, const float* x0, const float* x1, int Cout, int Do,
                                         int Ho, int Wo, const float* dy, int PD, int PH, int PW,
                                         float* slabs, float* wsdb, const unsigned* xmax,
-                                        const unsigned* ymax, hipStream_t st);
+                                        const unsigned* ymax, hipStream_t st,
+                                        const int* xk0 = nullptr, const int* xk1 = nullptr);
 
 struct WgradF16Plan {
   int lTY, HX, HY, TCI, TCO, nci, nco, maxj, R, ntx, nty, GKH, NGY, ksplit;
@@ -537,12 +538,17 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
                                 const float* dy, int KD, int KH, int KW, int SD, int SH, int SW,
                                 int PD, int PH, int PW, float* out, float* db,
                                 const uint32_t* xmax_in, const uint32_t* ymax_in, void* ws,
-                                size_t ws_bytes, hipStream_t st) {
+                                size_t ws_bytes, hipStream_t st, const int* xk0 = nullptr,
+                                const int* xk1 = nullptr) {
   const int Cin = C0 + C1;
   WgradF16Plan p = {};
   WgradZrPlan zp;
   const bool zring = adell_wgrad_zring_plan(N, D, H, W, C0, C1, Cout, KD, KH, KW, SD, SH, SW, Do, Ho,
                                             Wo, &zp) != 0;
+  // split-row sources: the z-ring kernel only, and no 32-channel tile across the two sources
+  ADELL_REQUIRE((!xk0 && !xk1) || (zring && (C1 == 0 || C0 % 32 == 0)),
+                "wgrad f16x3: this problem does not take split-row sources "
+                "(adell_conv3d_bwd_weight_f16x3_rows_ok)");
   WgradS2Plan sp;
   const bool s2 = !zring && adell_wgrad_s2_plan(N, D, H, W, C0, C1, Cout, KD, KH, KW, SD, SH, SW, PD,
                                                 PH, PW, Do, Ho, Wo, &sp) != 0;
@@ -567,9 +573,10 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   const long ny = (long)N * Do * Ho * Wo * Cout;
   auto blocks_for = [](long n) { long b = (n / 4 + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); };
   if (!xmax_in || !ymax_in) ADELL_CHECK_HIP(hipMemsetAsync(amax, 0, 4 * sizeof(unsigned), st));
-  if (!xmax_in) {
-    hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx0)), dim3(256), 0, st, x0, nx0, amax);
-    if (C1 > 0)
+  if (!xmax_in) {   // (a split-row source carries its own exponent: its bytes are not fp32 values)
+    if (!xk0)
+      hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx0)), dim3(256), 0, st, x0, nx0, amax);
+    if (C1 > 0 && !xk1)
       hipLaunchKernelGGL(adell_absmax2_kernel, dim3(blocks_for(nx1)), dim3(256), 0, st, x1, nx1, amax);
   }
   if (!ymax_in)
@@ -577,7 +584,7 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   if (zring) {
     rc = adell_wgrad_zring_launch(&zp, N, D, H, W, C0, C1, x0, x1, Cout, Do, Ho, Wo, dy, PD, PH, PW,
                                   slabs, db ? wsdb : nullptr, xmax_in ? xmax_in : amax,
-                                  ymax_in ? ymax_in : amax + 1, st);
+                                  ymax_in ? ymax_in : amax + 1, st, xk0, xk1);
     if (rc != ADELL_OK) return rc;
     return adell_wgrad_reduce_launch(slabs, out, zp.R, ntap, Cin, Cout, db ? wsdb : nullptr, db, st);
   }
@@ -672,4 +679,33 @@ extern "C" int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const f
                               d->Ho, d->Wo, dy, d->KD, d->KH, d->KW, d->SD, d->SH, d->SW, d->PD,
                               d->PH, d->PW, dw, db, x_absmax, dy_absmax, workspace, workspace_bytes,
                               (hipStream_t)stream);
+}
+
+// The same with split-row sources of X (adell_norm_act_fwd_split; include/adell_hip.h): xk0 / xk1
+// non-null = that source holds rows (ONE exponent per tensor: xk[0]). _rows_ok: 1 when this problem
+// runs on the z-ring kernel with every 32-channel tile inside one source.
+extern "C" int adell_conv3d_bwd_weight_f16x3_rows_ok(const adell_conv3d_desc* d) {
+  if (!d || adell_wgrad_small_workspace(d) > 0) return 0;
+  WgradZrPlan zp;
+  if (!adell_wgrad_zring_plan(d->N, d->D, d->H, d->W, d->C0, d->C1, d->Cout, d->KD, d->KH, d->KW,
+                              d->SD, d->SH, d->SW, d->Do, d->Ho, d->Wo, &zp))
+    return 0;
+  return (d->C1 == 0 || d->C0 % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int adell_conv3d_bwd_weight_f16x3_rows(const adell_conv3d_desc* d, const void* x0,
+                                                  const int* xk0, const void* x1, const int* xk1,
+                                                  const float* dy, float* dw, float* db,
+                                                  const uint32_t* x_absmax,
+                                                  const uint32_t* dy_absmax, void* workspace,
+                                                  size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(d && x0 && dy && dw, "conv_bwd_weight_f16x3_rows: null pointer");
+  ADELL_REQUIRE(d->C1 == 0 || x1, "conv_bwd_weight_f16x3_rows: C1 > 0 needs x1");
+  ADELL_REQUIRE(xk0 || xk1, "conv_bwd_weight_f16x3_rows: no split-row source");
+  ADELL_REQUIRE(adell_conv3d_bwd_weight_f16x3_rows_ok(d),
+                "conv_bwd_weight_f16x3_rows: this problem does not take split-row sources");
+  return adell_wgrad_f16_core(d->N, d->D, d->H, d->W, d->C0, d->C1, (const float*)x0,
+                              (const float*)x1, d->Cout, d->Do, d->Ho, d->Wo, dy, d->KD, d->KH,
+                              d->KW, d->SD, d->SH, d->SW, d->PD, d->PH, d->PW, dw, db, x_absmax,
+                              dy_absmax, workspace, workspace_bytes, (hipStream_t)stream, xk0, xk1);
 }

@@ -37,6 +37,12 @@ struct WgradZrArgs {
   float* wsdb;           // [R][Cout] or null
   const unsigned* xmax;  // device absmax (float bits) of X and dY
   const unsigned* ymax;
+  // split-row sources (adell_norm_act_fwd_split): xk0 / xk1 non-null = that source of X holds the
+  // 64-byte hi | lo rows of 16-channel chunks scaled by 2^xk[0] (ONE exponent per tensor: the
+  // accumulators of a block sum over batch items). A row occupies the bytes of its fp32 chunk, so
+  // the loads are the fp32 path's; staging stores the 16-byte pieces as they are.
+  const int* xk0;
+  const int* xk1;
   int N, D, H, W;
   int C0, C1, Cin, Cout;
   int PD, PH, PW;
@@ -107,7 +113,12 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
   const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
   const int ci0 = cit * 32, co0 = cot * 32;
 
-  const int kX = adell_zr_scale_exp(a.xmax[0]), kY = adell_zr_scale_exp(a.ymax[0]);
+  // (the tile's source decides the format: the host keeps tiles that straddle two sources off
+  // this path when either holds rows)
+  const int* xkt = ci0 < a.C0 ? a.xk0 : a.xk1;
+  const bool xrows = xkt != nullptr;
+  const int kX = xrows ? xkt[0] : adell_zr_scale_exp(a.xmax[0]);
+  const int kY = adell_zr_scale_exp(a.ymax[0]);
   const float sX = __int_as_float((kX + 127) << 23), sY = __int_as_float((kY + 127) << 23);
 
   // Whole tile inside one source (every 32-channel-aligned layer): one wave-uniform base per
@@ -214,6 +225,19 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
       }
     };
     auto store_x = [&](int slot) {
+      if (xrows) {
+        // piece c4 of the tile's 128 bytes: chunk c4 >> 2, pieces 0, 1 = hi halves (channels 0-7,
+        // 8-15 of the chunk), 2, 3 = lo halves
+        char* plane = (c4 & 2) ? sXl : sXh;
+        const unsigned po = (unsigned)((c4 >> 2) * 32 + (c4 & 1) * 16);
+#pragma unroll
+        for (int u = 0; u < ZR_NX; ++u) {
+          const int hv = row0 + 32 * u;
+          if (hv < ZR_HV)
+            *reinterpret_cast<float4*>(plane + slot * ZR_PLANE + hv * 64 + po) = xr[u];
+        }
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < ZR_NX; ++u) {
         const int hv = row0 + 32 * u;
@@ -381,9 +405,11 @@ extern "C" int adell_wgrad_zring_launch(const WgradZrPlan* p, int N, int D, int 
                                         int C1, const float* x0, const float* x1, int Cout, int Do,
                                         int Ho, int Wo, const float* dy, int PD, int PH, int PW,
                                         float* slabs, float* wsdb, const unsigned* xmax,
-                                        const unsigned* ymax, hipStream_t st) {
+                                        const unsigned* ymax, hipStream_t st,
+                                        const int* xk0 = nullptr, const int* xk1 = nullptr) {
   WgradZrArgs a = {};
   a.x0 = x0; a.x1 = x1; a.dy = dy; a.ws = slabs; a.wsdb = wsdb; a.xmax = xmax; a.ymax = ymax;
+  a.xk0 = xk0; a.xk1 = xk1;
   a.N = N; a.D = D; a.H = H; a.W = W; a.C0 = C0; a.C1 = C1; a.Cin = C0 + C1; a.Cout = Cout;
   a.PD = PD; a.PH = PH; a.PW = PW; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.ntx = p->ntx; a.nty = p->nty; a.nseg = p->nseg; a.seglen = p->seglen;

@@ -264,6 +264,12 @@ struct NormActArgs {
   unsigned long long* mask;  // fast kernel: keep bits of the dropout (adell_norm_act_fwd_mask) or null
   long groups;               // 256-element groups per batch item in `mask`
   int rev;                   // experiment: reversed block order (adell_ew_block)
+  // fast kernel, split-row output (adell_norm_act_fwd_split): `out` receives, per voxel and
+  // 16-channel chunk, the 64-byte row [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of fp16 values of
+  // out * 2^split_exp -- the LDS row image of the f16x3 convolution kernels (conv_igemm_f16.h),
+  // same bytes per element as fp32 -- instead of fp32 values
+  int split;
+  float split_scale;
 };
 
 // hat = (x-mean)*rstd*gamma+beta ; u = dropout(hat) ; out = act(u)
@@ -428,10 +434,12 @@ static int adell_norm_act_fwd_impl(const adell_norm_act_desc* d, const float* x,
                                    const float* mean, const float* rstd,
                                    const float* gamma, const float* beta,
                                    const float* act_w, float* out, void* keep_mask,
-                                   void* stream) {
+                                   void* stream, int split = 0, int split_exp = 0) {
   NormActArgs a = {};
   int rc = adell_na_fill(&a, d);
   if (rc != ADELL_OK) return rc;
+  a.split = split;
+  a.split_scale = __builtin_ldexpf(1.0f, split_exp);
   a.mask = (unsigned long long*)keep_mask;
   a.groups = (a.VC + 255) / 256;
   ADELL_REQUIRE(x && out, "norm_act_fwd: null pointer");
@@ -454,8 +462,8 @@ static int adell_norm_act_fwd_impl(const adell_norm_act_desc* d, const float* x,
     ADELL_CHECK_HIP(hipGetLastError());
     return ADELL_OK;
   }
-  if (keep_mask != nullptr) {
-    adell_set_error("norm_act_fwd_mask: needs a power-of-two C <= 1024 and 16-byte aligned tensors");
+  if (keep_mask != nullptr || split) {
+    adell_set_error("norm_act_fwd_mask / _split: needs a power-of-two C <= 1024 and 16-byte aligned tensors");
     return ADELL_E_UNSUPPORTED;
   }
   hipLaunchKernelGGL(adell_norm_act_fwd_kernel,
@@ -480,6 +488,104 @@ extern "C" int adell_norm_act_fwd_mask(const adell_norm_act_desc* d, const float
   ADELL_REQUIRE(d && (d->drop_p == 0.f || keep_mask), "norm_act_fwd_mask: null mask");
   return adell_norm_act_fwd_impl(d, x, mean, rstd, gamma, beta, act_w, out,
                                  d->drop_p > 0.f ? keep_mask : nullptr, stream);
+}
+
+// Split-row output (see NormActArgs::split): `out_rows` has the byte size of the fp32 output and holds
+// [N][V][C / 16] rows of 64 bytes, every value scaled by 2^split_exp. C: a power of two, 16..1024.
+// keep_mask as in adell_norm_act_fwd_mask (may be null when drop_p == 0 or no mask is wanted).
+extern "C" int adell_norm_act_fwd_split(const adell_norm_act_desc* d, const float* x,
+                                        const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta,
+                                        const float* act_w, void* out_rows, int split_exp,
+                                        void* keep_mask, void* stream) {
+  ADELL_REQUIRE(d && d->C >= 16 && d->C % 16 == 0 && adell_is_pow2(d->C) && d->C <= 1024,
+                "norm_act_fwd_split: C must be a power of two in 16..1024");
+  ADELL_REQUIRE(split_exp >= -100 && split_exp <= 100, "norm_act_fwd_split: bad exponent");
+  ADELL_REQUIRE((((uintptr_t)x | (uintptr_t)out_rows) & 15) == 0,
+                "norm_act_fwd_split: 16-byte aligned tensors");
+  return adell_norm_act_fwd_impl(d, x, mean, rstd, gamma, beta, act_w, (float*)out_rows,
+                                 d->drop_p > 0.f ? keep_mask : nullptr, stream, 1, split_exp);
+}
+
+// fp32 [N][V][C] -> split rows with per-(item, chunk) exponents xk[N][C / 16] (any tensor whose
+// range the caller knows), and back: x = (hi + lo) * 2^-xk. The producer-side fusion above is the
+// product path; these two serve consumers that cannot read rows and the tests.
+typedef _Float16 na_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 na_half4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void adell_rows_from_f32_kernel(const float* __restrict__ x,
+                                                                  const int* __restrict__ xk,
+                                                                  char* __restrict__ rows, long V,
+                                                                  int C, long total) {
+  const int nch = C >> 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int ch = (int)(i % nch);
+    const long v = i / nch;                    // voxel over the whole batch
+    const int n = (int)(v / V);
+    const float scale = __int_as_float((xk[n * nch + ch] + 127) << 23);
+    const float4* p = reinterpret_cast<const float4*>(x + v * C + ch * 16);
+    na_half8 o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 t4 = p[q];
+      const float t[4] = {t4.x * scale, t4.y * scale, t4.z * scale, t4.w * scale};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const _Float16 h = (_Float16)t[j];
+        o[q >> 1][(q & 1) * 4 + j] = h;
+        o[2 + (q >> 1)][(q & 1) * 4 + j] = (_Float16)(t[j] - (float)h);
+      }
+    }
+    na_half8* dst = reinterpret_cast<na_half8*>(rows + i * 64);
+    dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
+  }
+}
+__global__ __launch_bounds__(256) void adell_rows_to_f32_kernel(const char* __restrict__ rows,
+                                                                const int* __restrict__ xk,
+                                                                float* __restrict__ x, long V, int C,
+                                                                long total) {
+  const int nch = C >> 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+    const int ch = (int)(i % nch);
+    const long v = i / nch;
+    const int n = (int)(v / V);
+    const float inv = __int_as_float((127 - xk[n * nch + ch]) << 23);
+    const na_half8* src = reinterpret_cast<const na_half8*>(rows + i * 64);
+    const na_half8 h0 = src[0], h1 = src[1], l0 = src[2], l1 = src[3];
+    float4* p = reinterpret_cast<float4*>(x + v * C + ch * 16);
+    p[0] = make_float4(((float)h0[0] + (float)l0[0]) * inv, ((float)h0[1] + (float)l0[1]) * inv,
+                       ((float)h0[2] + (float)l0[2]) * inv, ((float)h0[3] + (float)l0[3]) * inv);
+    p[1] = make_float4(((float)h0[4] + (float)l0[4]) * inv, ((float)h0[5] + (float)l0[5]) * inv,
+                       ((float)h0[6] + (float)l0[6]) * inv, ((float)h0[7] + (float)l0[7]) * inv);
+    p[2] = make_float4(((float)h1[0] + (float)l1[0]) * inv, ((float)h1[1] + (float)l1[1]) * inv,
+                       ((float)h1[2] + (float)l1[2]) * inv, ((float)h1[3] + (float)l1[3]) * inv);
+    p[3] = make_float4(((float)h1[4] + (float)l1[4]) * inv, ((float)h1[5] + (float)l1[5]) * inv,
+                       ((float)h1[6] + (float)l1[6]) * inv, ((float)h1[7] + (float)l1[7]) * inv);
+  }
+}
+static int adell_rows_convert(const void* src, void* dst, int N, long V, int C, const int* xk,
+                              int to_rows, void* stream) {
+  ADELL_REQUIRE(src && dst && xk && N > 0 && V > 0 && C >= 16 && C % 16 == 0,
+                "split rows: bad arguments (C must be a multiple of 16)");
+  ADELL_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "split rows: 16-byte aligned tensors");
+  const long total = (long)N * V * (C >> 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (to_rows)
+    hipLaunchKernelGGL(adell_rows_from_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, (const float*)src, xk, (char*)dst, V, C, total);
+  else
+    hipLaunchKernelGGL(adell_rows_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                       (hipStream_t)stream, (const char*)src, xk, (float*)dst, V, C, total);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+extern "C" int adell_split_rows_from_f32(const float* x, int N, long V, int C, const int* xk,
+                                         void* rows, void* stream) {
+  return adell_rows_convert(x, rows, N, V, C, xk, 1, stream);
+}
+extern "C" int adell_split_rows_to_f32(const void* rows, int N, long V, int C, const int* xk,
+                                       float* x, void* stream) {
+  return adell_rows_convert(rows, x, N, V, C, xk, 0, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -996,7 +1102,24 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
         }
         h[q] = adell_act_fwd(ACT, t, k.p[q]);
       }
-      yout[jj] = make_float4(h[0], h[1], h[2], h[3]);
+      if (a.split) {
+        // this thread's four channels of a 16-channel chunk: 8 bytes of the row's hi half and 8 of
+        // its lo half; the four lanes of a chunk fill the 64-byte row between them
+        na_half4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float t = h[q] * a.split_scale;
+          const _Float16 hh = (_Float16)t;
+          hi[q] = hh;
+          lo[q] = (_Float16)(t - (float)hh);
+        }
+        const int within = (int)((jj << 2) & 15);
+        char* row = reinterpret_cast<char*>(a.out) + 4 * ((long)n * a.VC + (jj << 2) - within);
+        *reinterpret_cast<na_half4*>(row + within * 2) = hi;
+        *reinterpret_cast<na_half4*>(row + 32 + within * 2) = lo;
+      } else {
+        yout[jj] = make_float4(h[0], h[1], h[2], h[3]);
+      }
       if (a.mask != nullptr) {
         // the 64 lanes of a wave hold 64 consecutive float4 = one 256-element group: word q of
         // the group = the keep bits of sub-element q, bit = lane (lanes past the end: 0)

@@ -38,7 +38,10 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_lowrank": bool(os.environ.get("ADELL_NO_LOWRANK")),
          # weight gradients of the convolutions / linear layers on a second HIP stream (side_run);
          # ADELL_WGRAD_STREAM=0 keeps every launch on the caller's stream
-         "wgrad_stream": os.environ.get("ADELL_WGRAD_STREAM", "1") != "0"}
+         "wgrad_stream": os.environ.get("ADELL_WGRAD_STREAM", "1") != "0",
+         # an ADN output whose only reader is a 3x3x3 stride-1 conv is written as SPLIT ROWS (the
+         # conv kernels' LDS row image: ops.SplitRows) instead of fp32; ADELL_NO_ROWS=1: always fp32
+         "no_rows": bool(os.environ.get("ADELL_NO_ROWS"))}
 
 
 def set_conv_precision(mode):
@@ -401,11 +404,94 @@ def _side_ok(weight, *params):
     return True
 
 
+# ---- split rows between an ADN site and the conv that is its only reader -----------------------------
+# Module code that knows "the output of THIS ActDropNorm is read by THAT Conv3d and by nothing else"
+# says so before it runs the ADN (expect_rows); the ADN's forward takes the note (take_rows_reader)
+# and, when the conv's kernels stage split rows for this shape, writes rows instead of fp32 values
+# (same bytes). The note is keyed by the ADN module: no other norm_drop_act call can pick it up.
+_ROWS_EXPECT = {}
+_ROWS_PLAN = {}
+
+
+def expect_rows(adn_module, conv, as_x1=False):
+    """``conv``: a modules.layers.conv.Conv3d; ``as_x1``: the tensor will be the conv's X_cat."""
+    spec = conv.rows_spec() if (not FLAGS["no_rows"] and hasattr(conv, "rows_spec")) else None
+    if spec is None:
+        _ROWS_EXPECT.pop(id(adn_module), None)
+    else:
+        _ROWS_EXPECT[id(adn_module)] = spec + (bool(as_x1),)
+
+
+def clear_row_expectations():
+    """A new top-level forward: notes left by a pass that never reached its ADN are void."""
+    if _ROWS_EXPECT:
+        _ROWS_EXPECT.clear()
+
+
+def take_rows_reader(adn_module):
+    return _ROWS_EXPECT.pop(id(adn_module), None) if _ROWS_EXPECT else None
+
+
+def _rows_exponent(x, reader, norm, gamma, beta, act, act_p, act_w, p):
+    """Exponent for a split-row output of this site, or None when it must stay fp32: instance
+    statistics without affine parameters bound the normalised value by sqrt(V), dropout scales by
+    1 / (1 - p), and |act(u)| <= |u| for the activations listed -- so 2^exp is chosen on the host,
+    without a pass over the data, with the largest possible value at 2^14 (fp16 tops out at 2^16;
+    typical values sit ~2^10 below the bound, where hi + lo still carry 22 bits and the absolute
+    error floor is 2^-25 of the scaled unit)."""
+    if (reader is None or FLAGS["no_rows"] or CONV_PRECISION != "f16x3" or norm != "instance"
+            or gamma is not None or beta is not None or act_w is not None or x.dim() != 5
+            or act not in ("identity", "swish", "silu", "relu", "leaky_relu", "gelu")
+            or (act == "leaky_relu" and abs(act_p) > 1.0)):
+        return None
+    weight, stride, padding, as_x1 = reader
+    N, C = x.shape[:2]
+    spatial = tuple(x.shape[2:])
+    other = weight.shape[1] - C
+    if weight.dim() != 5 or other < 0 or C < 16 or (C & (C - 1)) or C > 1024:
+        return None
+    C0, C1 = (other, C) if as_x1 else (C, other)
+    if C0 == 0:
+        C0, C1 = C1, 0
+    grad = torch.is_grad_enabled() and weight.requires_grad
+    key = (N, spatial, C0, C1, tuple(weight.shape), stride, padding, grad, ops.plan_epoch())
+    ok = _ROWS_PLAN.get(key)
+    if ok is None:
+        k = tuple(weight.shape[2:])
+        ok = ops.conv3d_rows_ok(N, spatial, C0, C1, weight.shape[0], k, stride, padding)
+        if ok and grad:
+            ok = ops.conv3d_bwd_weight_rows_ok(N, spatial, C0, C1, weight.shape[0], k, stride,
+                                               padding)
+        _ROWS_PLAN[key] = ok
+    if not ok:
+        return None
+    V = spatial[0] * spatial[1] * spatial[2]
+    bound = float(np.sqrt(V)) / (1.0 - p)
+    return 14 - int(np.ceil(np.log2(max(bound, 1.0))))
+
+
+def materialize(t):
+    """``t`` as plain fp32 values (a split-row tensor converted back; anything else unchanged). For
+    the rare reader that is not the conv the rows were written for. Not differentiable: use on
+    tensors whose gradient does not matter or inside an autograd.Function."""
+    rows = getattr(t, "_adell_rows", None)
+    return t if rows is None else ops.rows_to_f32(t.detach(), rows)
+
+
 class _Conv3dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, residual, wp, conf):
         (stride, padding, want_stats, wref, ctx.carry_in, ctx.carry_out, ctx.carry_x0,
-         ctx.carry_cat, ctx.adn) = conf
+         ctx.carry_cat, ctx.adn, rows0, rows1) = conf
+        if (rows0 is not None or rows1 is not None) and not isinstance(wp, ops.SplitWeight):
+            # a reader other than the f16x3 implicit-GEMM path: it gets fp32 values (and so does
+            # its backward: the converted tensors are the ones saved)
+            ops.ROWS_FALLBACKS[0] += 1
+            if rows0 is not None:
+                x0, rows0 = ops.rows_to_f32(x0, rows0), None
+            if rows1 is not None:
+                x1, rows1 = ops.rows_to_f32(x1, rows1), None
+        ctx.rows = (rows0, rows1)
         k = tuple(weight.shape[2:]) if weight.dim() == 5 else (1, 1, 1)
         # the statistics partials are a non-differentiable by-product: without this autograd
         # materialises a zero gradient for them in every backward (a 2 MB fill per conv site)
@@ -464,7 +550,7 @@ class _Conv3dFn(torch.autograd.Function):
             amax = _amax_pair(x0.device)
         y, part = ops.conv3d_fwd(x0, wp, bias, weight.shape[0], k, stride, padding, x1=x1,
                                  residual=residual, want_stats=want_stats,
-                                 amax=None if amax is None else amax[0:1])
+                                 amax=None if amax is None else amax[0:1], rows0=rows0, rows1=rows1)
         ctx.amax = amax
         ctx.save_for_backward(x0, x1, weight)
         ctx.conf = (k, stride, padding, bias is not None, residual is not None, wref)
@@ -592,10 +678,11 @@ class _Conv3dFn(torch.autograd.Function):
                 dw, db = ops.conv_cinfold_bwd_weight(x0, dy, padding, want_db)
                 dw = dw.view(weight.shape)
             elif need[2]:
+                rows0, rows1 = getattr(ctx, "rows", (None, None))
                 dw = ops.conv3d_bwd_weight(x0, dy, k, stride, padding, x1=x1, want_db=want_db,
                                            f16x3=(CONV_PRECISION == "f16x3"),
                                            x_amax=None if amax is None else amax[0:1],
-                                           dy_amax=dy_amax)
+                                           dy_amax=dy_amax, rows0=rows0, rows1=rows1)
                 if want_db:
                     dw, db = dw
                 dw = dw.view(weight.shape)
@@ -721,8 +808,10 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     stride, padding = ops._triple(stride), ops._triple(padding)
     _note_use(weight)
     adn = _adn_sites_of(x0, x1, weight, stride, padding)
+    rows0 = getattr(x0, "_adell_rows", None)
+    rows1 = getattr(x1, "_adell_rows", None) if x1 is not None else None
     conf = (stride, padding, want_stats, _Ref(weight), carry_in, carry_out, carry_x0, carry_cat,
-            adn)
+            adn, rows0, rows1)
     Cin = x0.shape[1] + (0 if x1 is None else x1.shape[1])
     small1 = ops.conv1_small_ok(weight, Cin, stride, padding, residual)
     if small1:
@@ -732,7 +821,7 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
         if (site is not None and x1 is None and carry_in is None and carry_x0 is None
                 and not FLAGS["no_adn_fuse"] and not FLAGS["no_lowrank"]
                 and torch.is_grad_enabled() and ops.norm_act_lowrank_ok(x0, weight.shape[0])):
-            conf = conf[:-1] + (("lowrank", site),)
+            conf = conf[:8] + (("lowrank", site),) + conf[9:]
     elif ops.conv_cin_small_ok(weight, x0, x1, stride, padding, residual):
         wp = "cin_small"
     elif ops.conv_cinfold_ok(weight, x0, x1, stride, padding, residual):
@@ -808,16 +897,17 @@ conv_transpose3d_k2s2 = conv_transpose3d
 class _NormDropActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mean, rstd, gamma, beta, act_w, conf):
-        act, act_p, per_item, drop_p, seed, offset, site = conf
+        act, act_p, per_item, drop_p, seed, offset, site, split_exp = conf
         if site is not None:
             out, mask = ops.norm_act_fwd(x, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w,
                                          act_p=act_p, stats_per_item=per_item, drop_p=drop_p,
-                                         seed=seed, rng_offset=offset, want_mask=True)
+                                         seed=seed, rng_offset=offset, want_mask=True,
+                                         split_exp=split_exp)
             site.x, site.mean, site.rstd, site.mask = x, mean, rstd, mask
         else:
             out = ops.norm_act_fwd(x, mean, rstd, act, gamma=gamma, beta=beta, act_w=act_w,
                                    act_p=act_p, stats_per_item=per_item, drop_p=drop_p, seed=seed,
-                                   rng_offset=offset)
+                                   rng_offset=offset, split_exp=split_exp)
         ctx.save_for_backward(x, mean, rstd, gamma, beta, act_w)
         ctx.conf = conf
         return out
@@ -825,7 +915,7 @@ class _NormDropActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, mean, rstd, gamma, beta, act_w = ctx.saved_tensors
-        act, act_p, per_item, drop_p, seed, offset, site = ctx.conf
+        act, act_p, per_item, drop_p, seed, offset, site, _split_exp = ctx.conf
         if site is not None:
             fused, part, poff = site.fused, site.part, site.poff
             site.fused, site.part = False, None
@@ -859,7 +949,7 @@ class _NormDropActFn(torch.autograd.Function):
 
 def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=None,
                   momentum=0.1, act="identity", act_p=0.0, act_w=None, drop_p=0.0,
-                  training=False):
+                  training=False, rows_reader=None):
     """Fused Norm -> Dropout -> Activation.
 
     norm: "none" | "instance" | "batch". ``running`` = (running_mean, running_var,
@@ -915,10 +1005,14 @@ def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=No
             and torch.is_grad_enabled() and not FLAGS["no_adn_fuse"] and CONV_PRECISION == "f16x3"
             and ops.norm_act_mask_ok(x)):
         site = AdnSite(None, None, None, None, p, act, float(act_p))
-    conf = (act, float(act_p), per_item, p, seed, offset, site)
+    # (rows_reader: the conv that is the ONLY reader of the output, take_rows_reader)
+    split_exp = _rows_exponent(x, rows_reader, norm, gamma, beta, act, float(act_p), act_w, p)
+    conf = (act, float(act_p), per_item, p, seed, offset, site, split_exp)
     out = _NormDropActFn.apply(x, mean, rstd, gamma, beta, act_w, conf)
     if site is not None:
         out._adell_site = site
+    if split_exp is not None:
+        out._adell_rows = ops.SplitRows(split_exp, ops.split_exponents(N, C, split_exp, x.device))
     return out
 
 

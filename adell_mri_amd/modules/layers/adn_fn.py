@@ -88,7 +88,7 @@ class ActDropNorm(torch.nn.Module):
             self._stages[-1][k] = self.name_dict[k]
             last = _RANK[k]
 
-    def _run_stage(self, X, stage):
+    def _run_stage(self, X, stage, reader=None):
         kw = {"training": self.training}
         if "N" in stage:
             m = self.op_list[stage["N"]]
@@ -143,11 +143,17 @@ class ActDropNorm(torch.nn.Module):
         X5, back = _as5d(X)
         if hasattr(X, "_adell_partials") and X5 is not X:
             X5._adell_partials = X._adell_partials
+        if reader is not None and X5 is X:
+            kw["rows_reader"] = reader
         return back(HF.norm_drop_act(X5, **kw))
 
     def forward(self, X: torch.Tensor) -> torch.Tensor:
-        for stage in self._stages:
-            X = self._run_stage(X, stage)
+        # the conv that module code announced as the only reader of this output
+        # (functional.expect_rows): the last stage may then write split rows instead of fp32
+        reader = HF.take_rows_reader(self)
+        last = len(self._stages) - 1
+        for i, stage in enumerate(self._stages):
+            X = self._run_stage(X, stage, reader if i == last else None)
         return X
 
 

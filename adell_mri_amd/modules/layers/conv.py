@@ -33,6 +33,15 @@ class Conv3d(torch.nn.Conv3d):
         pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
         return not (k == st and max(k) > 2 and tuple(pad) == (0, 0, 0))
 
+    def rows_spec(self):
+        """(weight, stride, padding) for functional.expect_rows when this conv may read its input
+        as split rows (3x3x3, stride 1: the layers that carry the FLOPs of a U-Net), else None."""
+        if (self.groups != 1 or any(d != 1 for d in self.dilation) or self.padding_mode != "zeros"
+                or tuple(self.kernel_size) != (3, 3, 3) or tuple(self.stride) != (1, 1, 1)):
+            return None
+        pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
+        return (self.weight, (1, 1, 1), tuple(pad))
+
     def forward(self, X, X_cat=None, residual=None, carry_in=None, carry_out=None,
                 carry_x0=None, carry_cat=None):
         """``X_cat``: second source of a virtual channel concat; ``residual``: tensor

@@ -58,9 +58,13 @@ class ResidualBlock3d(torch.nn.Module):
                                     and not HF.grad_observed(X)) else None)
         h = mods[0](X, carry_in=carry, carry_x0=fork) if carry is not None else mods[0](X)
         for i, mod in enumerate(mods[1:-1], 1):
+            # an ADN output read by the next conv only (functional.single_use; it may be written
+            # as split rows: functional.expect_rows)
+            only_reader = isinstance(mod, ActDropNorm) and type(mods[i + 1]) is self._conv and h.dim() == 5
+            if only_reader and self._conv is Conv3d:
+                HF.expect_rows(mod, mods[i + 1])
             h = mod(h)
-            # an ADN output read by the next conv only (functional.single_use)
-            if isinstance(mod, ActDropNorm) and type(mods[i + 1]) is self._conv and h.dim() == 5:
+            if only_reader:
                 h = HF.single_use(h)
         out = self.final_op(mods[-1](h, residual=X, carry_out=carry) if carry is not None
                             else mods[-1](h, residual=X))

@@ -14,4 +14,10 @@ def crop_to_size(X: torch.Tensor, output_size: List[int]) -> torch.Tensor:
     for cur, out in zip(X.shape[2:], output_size):
         a = (cur - out) // 2
         sl.append(slice(a, a + out))
-    return X[tuple(sl)]
+    out = X[tuple(sl)]
+    # a spatial crop of a split-row tensor (functional.expect_rows) keeps whole voxels, i.e. whole
+    # rows: still a split-row tensor
+    rows = getattr(X, "_adell_rows", None)
+    if rows is not None and out is not X:
+        out._adell_rows = rows
+    return out

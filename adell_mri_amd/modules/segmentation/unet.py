@@ -55,10 +55,32 @@ def _run_rest(mods, h):
     Conv3d has that conv as its only reader: functional.single_use lets the conv's backward-data
     kernel take over half of the site's backward."""
     for i, mod in enumerate(mods):
+        only_reader = (isinstance(mod, ActDropNorm) and i + 1 < len(mods)
+                       and type(mods[i + 1]) is Conv3d)
+        if only_reader:
+            HF.expect_rows(mod, mods[i + 1])     # ... which may take its input as split rows
         h = mod(h)
-        if isinstance(mod, ActDropNorm) and i + 1 < len(mods) and type(mods[i + 1]) is Conv3d:
+        if only_reader:
             h = HF.single_use(h)
     return h
+
+
+def _last_adn(module):
+    """The ActDropNorm whose output is the output of ``module`` (a decoder op, a residual link
+    block), or None."""
+    if isinstance(module, ResidualBlock3d):
+        adn = getattr(module, "adn_op", None)
+        return adn if isinstance(adn, ActDropNorm) and module.skip_activation is not True else None
+    if isinstance(module, _DecoderOp) and len(module) > 0 and isinstance(module[-1], ActDropNorm):
+        return module[-1]
+    return None
+
+
+def _first_conv(module):
+    """The Conv3d that reads the input of ``module`` first (through nested Sequentials), or None."""
+    while isinstance(module, torch.nn.Sequential) and len(module) > 0:
+        module = module[0]
+    return module if type(module) is Conv3d else None
 
 
 def _takes_carry(module):
@@ -381,6 +403,7 @@ class UNet(torch.nn.Module):
                 return_bottleneck=False, return_logits=False):
         if not X.is_cuda:
             raise AdellHipError("adell_mri_amd.UNet runs on MI355X only (no CPU fallback)")
+        HF.clear_row_expectations()
         encoding_out, bottleneck, X_skip_layer, X_feature_conditioning = self._encode(
             X, X_skip_layer, X_feature_conditioning)
         if return_bottleneck is True:
@@ -432,6 +455,14 @@ class UNet(torch.nn.Module):
                 S = link_in.shape[2:]
                 link_in = _cat_channels(link_in, _nearest(X_skip_layer, S))
                 fork = None
+            # the link block's output is read by the decoder conv alone (as the second half of its
+            # channel concat): its last ADN may write split rows
+            link_adn = _last_adn(link_op)
+            if (link_adn is not None and X_feature_conditioning is None
+                    and isinstance(op, _DecoderOp) and isinstance(op[0], ConcatConvBlock)):
+                reader = _first_conv(op[0])
+                if reader is not None:
+                    HF.expect_rows(link_adn, reader, as_x1=True)
             encoded = None
             if fork is not None and isinstance(link_op, ResidualBlock3d):
                 encoded, fork = link_op(link_in, fork=fork), None
@@ -465,9 +496,15 @@ class UNet(torch.nn.Module):
                 return_features, return_logits):
         """Decoder, head, bottleneck classifier and deep supervision (unet.py:790-843; the same
         code closes BrUNet.forward, :1209-1253)."""
+        head_only = return_features is not True and self.deep_supervision is not True
+        if head_only and len(self.decoding_operations) > 0:
+            # the last decoder op's ADN output is read by the head's first conv alone
+            adn, reader = _last_adn(self.decoding_operations[-1]), _first_conv(self.final_layer)
+            if adn is not None and reader is not None:
+                HF.expect_rows(adn, reader)
         curr, deep_outputs = self._run_decoder(encoding_out, bottleneck, X_skip_layer,
                                                X_feature_conditioning)
-        if return_features is not True and self.deep_supervision is not True:
+        if head_only:
             curr = HF.single_use(curr)      # the head's first conv is its only reader
         head = self._final(self.final_layer, curr, return_logits)
         return self._outputs(head, curr, bottleneck, deep_outputs, return_features)

@@ -227,6 +227,10 @@ def pack_weight_f16x3_multi(table, entries, total_blocks):
                                                    _stream()))
 
 
+# conv launches that had to convert a split-row source back to fp32 (a plan that cannot stage rows)
+ROWS_FALLBACKS = [0]
+
+
 def _splitk_workspace(d, backward, device):
     """(workspace tensor or None, bytes) for the split-K path of the small (8^3 - 16^3) layers."""
     nbytes = _lib.lib().adell_conv3d_splitk_workspace(ctypes.byref(d), backward)
@@ -236,10 +240,23 @@ def _splitk_workspace(d, backward, device):
 
 
 def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, residual=None,
-               want_stats=False, amax=None):
+               want_stats=False, amax=None, rows0=None, rows1=None):
     """y = conv(cat(x0, x1)) + bias + residual ; optional (sum, sumsq) partials.
-    ``w_packed``: fp32 GEMM-B tensor (exact fp32 MFMA) or a SplitWeight (f16x3 MFMA)."""
+    ``w_packed``: fp32 GEMM-B tensor (exact fp32 MFMA) or a SplitWeight (f16x3 MFMA).
+    ``rows0`` / ``rows1`` (SplitRows): that source holds split rows; a launch plan that cannot
+    stage rows gets the fp32 tensor back first (rows_to_f32: one extra pass, counted in
+    ROWS_FALLBACKS)."""
     split = isinstance(w_packed, SplitWeight)
+    if rows0 is not None or rows1 is not None:
+        N_, C0_ = x0.shape[:2]
+        C1_ = 0 if x1 is None else x1.shape[1]
+        if not (split and conv3d_rows_ok(N_, tuple(x0.shape[2:]), C0_, C1_, Cout, kernel, stride,
+                                         padding)):
+            ROWS_FALLBACKS[0] += 1
+            if rows0 is not None:
+                x0, rows0 = rows_to_f32(x0, rows0), None
+            if rows1 is not None:
+                x1, rows1 = rows_to_f32(x1, rows1), None
     if not split:
         _require_cuda(w_packed)
     _require_cuda(x0, x1, bias, residual)
@@ -259,8 +276,11 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
     # the 32 -> 32 stride-2 downsampling layer: one persistent launch (csrc/conv_fwd_s2.hip)
     s2fused = (split and x1 is None and residual is None and not FLAGS["no_s2fused"]
                and bool(_lib.lib().adell_conv3d_fwd_s2_fused_applicable(ctypes.byref(d))))
+    if rows0 is not None or rows1 is not None:
+        s2fused = False
     if want_stats:
         fn = (_lib.lib().adell_conv3d_fwd_s2_fused_ntiles if s2fused
+              else _lib.lib().adell_conv3d_fwd_ntiles_f16x3 if (rows0 is not None or rows1 is not None)
               else _lib.lib().adell_conv3d_fwd_ntiles_f16x3_ws if split
               else _lib.lib().adell_conv3d_fwd_ntiles)
         nt = fn(ctypes.byref(d))
@@ -268,6 +288,15 @@ def conv3d_fwd(x0, w_packed, bias, Cout, kernel, stride, padding, x1=None, resid
             check(nt)
         part = torch.empty((N, nt, Cout, 2), device=x0.device, dtype=torch.float32)
     rows = 0 if part is None else part.shape[1]    # checked by the library against its launch plan
+    if rows0 is not None or rows1 is not None:
+        check(_timed("adell_conv_igemm_f16_kernel", _conv_flops(d),
+                     lambda: _lib.lib().adell_conv3d_fwd_f16x3_rows(
+                         ctypes.byref(d), _ptr(x0), None if rows0 is None else _ptr(rows0.xk),
+                         _ptr(x1), None if rows1 is None else _ptr(rows1.xk),
+                         _ptr(w_packed.halfs), _ptr(w_packed.scale), _ptr(bias), _ptr(residual),
+                         _ptr(y), _ptr(part), rows, _ptr(amax), _stream()), _conv_tag(d, "fwd"),
+                     _conv_bytes(d, residual is not None)))
+        return y, part
     if s2fused:
         check(_timed("adell_fwd_s2_fused_kernel", _conv_flops(d),
                      lambda: _lib.lib().adell_conv3d_fwd_s2_fused(
@@ -627,11 +656,29 @@ def _workspace(nbytes, device):
     return torch.empty((max(int(nbytes), 4) + 3) // 4, device=device, dtype=torch.float32)
 
 
+def conv3d_bwd_weight_rows_ok(N, in_size, C0, C1, Cout, kernel, stride, padding):
+    """The weight gradient of this conv reads split-row sources (z-ring kernel)."""
+    d = make_conv_desc(N, tuple(in_size), C0, C1, Cout, kernel, stride, padding)
+    return bool(_lib.lib().adell_conv3d_bwd_weight_f16x3_rows_ok(ctypes.byref(d)))
+
+
 def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f16x3=False,
-                      x_amax=None, dy_amax=None):
+                      x_amax=None, dy_amax=None, rows0=None, rows1=None):
     """dW in torch's canonical [Cout, Cin, kD, kH, kW] layout (and db when want_db).
-    f16x3: error-compensated f16 MFMA instead of the fp32 MFMA."""
+    f16x3: error-compensated f16 MFMA instead of the fp32 MFMA. ``rows0`` / ``rows1``
+    (SplitRows): that source holds split rows (converted back when the kernel that serves the
+    problem cannot read them: ROWS_FALLBACKS)."""
     _require_cuda(x0, x1, dy)
+    if rows0 is not None or rows1 is not None:
+        ok = f16x3 and conv3d_bwd_weight_rows_ok(
+            x0.shape[0], tuple(x0.shape[2:]), x0.shape[1], 0 if x1 is None else x1.shape[1],
+            dy.shape[1], kernel, stride, padding)
+        if not ok:
+            ROWS_FALLBACKS[0] += 1
+            if rows0 is not None:
+                x0, rows0 = rows_to_f32(x0, rows0), None
+            if rows1 is not None:
+                x1, rows1 = rows_to_f32(x1, rows1), None
     x0, dy = ndhwc(x0), ndhwc(dy)
     N, C0, D, H, W = x0.shape
     C1 = 0
@@ -653,7 +700,14 @@ def conv3d_bwd_weight(x0, dy, kernel, stride, padding, x1=None, want_db=False, f
     ws = _workspace(nbytes, x0.device)
     dw = torch.empty((Cout, C0 + C1, *k), device=x0.device, dtype=torch.float32)
     db = torch.empty((Cout,), device=x0.device, dtype=torch.float32) if want_db else None
-    if f16x3:
+    if rows0 is not None or rows1 is not None:
+        # (x_amax: the forward's by-product covers the fp32 source only, as this call needs it)
+        check(_timed(name, _conv_flops(d), lambda: L.adell_conv3d_bwd_weight_f16x3_rows(
+            ctypes.byref(d), _ptr(x0), None if rows0 is None else _ptr(rows0.xk), _ptr(x1),
+            None if rows1 is None else _ptr(rows1.xk), _ptr(dy), _ptr(dw), _ptr(db), _ptr(x_amax),
+            _ptr(dy_amax), _ptr(ws), ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"),
+                     _conv_bytes(d)))
+    elif f16x3:
         check(_timed(name, _conv_flops(d), lambda: fn(
             ctypes.byref(d), _ptr(x0), _ptr(x1), _ptr(dy), _ptr(dw), _ptr(db), _ptr(x_amax),
             _ptr(dy_amax), _ptr(ws), ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"),
@@ -860,10 +914,70 @@ def norm_act_mask_ok(x):
     return x.dim() == 5 and C % 4 == 0 and C <= 1024 and (C & (C - 1)) == 0
 
 
+# ---- split rows: activations stored as the f16x3 kernels' LDS row image ------------------------------
+class SplitRows:
+    """Marks a tensor whose MEMORY holds, per voxel and 16-channel chunk, the 64-byte row
+    [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15] of fp16 values of x * 2^exp (conv_igemm_f16.h) instead
+    of fp32 values -- same logical shape [N, C, D, H, W], dtype and byte count. ``xk``: int32 device
+    tensor [N, C / 16] of exponents (one value per tensor for the producers built so far: ``exp``)."""
+
+    __slots__ = ("exp", "xk")
+
+    def __init__(self, exp, xk):
+        self.exp, self.xk = int(exp), xk
+
+
+_XK_CACHE = {}
+
+
+def split_exponents(N, C, exp, device):
+    """Constant exponent table [N, C / 16] (cached: a handful of distinct (N, C, exp) per model)."""
+    key = (device, int(N) * (int(C) // 16), int(exp))
+    t = _XK_CACHE.get(key)
+    if t is None:
+        t = _XK_CACHE[key] = torch.full((key[1],), int(exp), device=device, dtype=torch.int32)
+    return t
+
+
+def rows_from_f32(x, exp):
+    """fp32 NDHWC activation -> (tensor of split rows, SplitRows); |x| * 2^exp must stay below 2^15."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C = x.shape[:2]
+    V = x.numel() // (N * C)
+    xk = split_exponents(N, C, exp, x.device)
+    out = new_act(*x.shape, x.device)
+    check(_lib.lib().adell_split_rows_from_f32(_ptr(x), N, V, C, _ptr(xk), _ptr(out), _stream()))
+    return out, SplitRows(exp, xk)
+
+
+def rows_to_f32(rows, sr):
+    """The fp32 tensor a split-row tensor stands for ((hi + lo) * 2^-exp: 22 mantissa bits)."""
+    _require_cuda(rows)
+    rows = ndhwc(rows)
+    N, C = rows.shape[:2]
+    V = rows.numel() // (N * C)
+    out = new_act(*rows.shape, rows.device)
+    check(_lib.lib().adell_split_rows_to_f32(_ptr(rows), N, V, C, _ptr(sr.xk), _ptr(out), _stream()))
+    return out
+
+
+def conv3d_rows_ok(N, in_size, C0, C1, Cout, kernel, stride, padding):
+    """The forward of this conv stages split-row sources (specialised f16x3 instances)."""
+    k, st = _triple(kernel), _triple(stride)
+    if k != (3, 3, 3) or st != (1, 1, 1) or C0 % 16 or C1 % 16:
+        return False
+    d = make_conv_desc(N, tuple(in_size), C0, C1, Cout, kernel, stride, padding)
+    return bool(_lib.lib().adell_conv3d_f16x3_rows_ok(ctypes.byref(d)))
+
+
 def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.0,
-                 stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0, want_mask=False):
+                 stats_per_item=1, drop_p=0.0, seed=0, rng_offset=0, want_mask=False,
+                 split_exp=None):
     """``want_mask`` (drop_p > 0): also returns the keep bits as an int64 tensor (1 bit per
-    element) for the fused backward (conv3d_bwd_data_adn)."""
+    element) for the fused backward (conv3d_bwd_data_adn). ``split_exp``: the output is written as
+    SPLIT ROWS scaled by 2^split_exp (SplitRows below) instead of fp32 values -- same shape, dtype
+    and bytes, readable only by consumers that take rows (conv3d_fwd / conv3d_bwd_weight)."""
     _require_cuda(x, mean, rstd, gamma, beta, act_w)
     x = ndhwc(x)
     d = make_na_desc(x, act, stats_per_item, act_p, 0 if act_w is None else act_w.numel(),
@@ -876,7 +990,11 @@ def norm_act_fwd(x, mean, rstd, act, gamma=None, beta=None, act_w=None, act_p=0.
             check(int(nbytes))
         mask = torch.empty((nbytes // 8,), device=x.device, dtype=torch.int64)
     # HBM-bound family of the roofline report: algorithmic bytes = read x + write out
-    if mask is not None:
+    if split_exp is not None:
+        check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_fwd_split(
+            ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(act_w),
+            _ptr(out), int(split_exp), _ptr(mask), _stream()), "fwd", 8.0 * x.numel()))
+    elif mask is not None:
         check(_timed(NORM_ACT_FAMILY, 0.0, lambda: _lib.lib().adell_norm_act_fwd_mask(
             ctypes.byref(d), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(act_w),
             _ptr(out), _ptr(mask), _stream()), "fwd", 8.0 * x.numel()))

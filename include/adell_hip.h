@@ -134,6 +134,17 @@ int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const float* dy,
                                 const void* w_split_bwd, const float* wscale, float* dx0,
                                 float* dx1, uint32_t* dy_absmax, void* stream);
 
+/* adell_conv3d_fwd_f16x3 with split-row sources (see adell_norm_act_fwd_split): xk0 / xk1 non-NULL
+ * = that source is rows with exponents xk[N][C / 16], NULL = fp32. 3x3x3 stride-1 layers whose
+ * launch plan is a specialised instance: adell_conv3d_f16x3_rows_ok(d) == 1 (else
+ * ADELL_E_UNSUPPORTED). stat_partials rows: adell_conv3d_fwd_ntiles_f16x3(d). */
+int adell_conv3d_f16x3_rows_ok(const adell_conv3d_desc* d);
+int adell_conv3d_fwd_f16x3_rows(const adell_conv3d_desc* d, const void* x0, const int* xk0,
+                                const void* x1, const int* xk1, const void* w_split,
+                                const float* wscale, const float* bias, const float* residual,
+                                float* y, float* stat_partials, int partial_rows,
+                                uint32_t* in_absmax, void* stream);
+
 /* Backward-data of a stride-2, k = 3 convolution by parity classes: dX[2i + p], p in {0,1}^3, is a
  * stride-1 convolution of dY with the sub-kernel w[:, :, t0z::2, t0y::2, t0x::2] (t0 = (p + P) mod 2
  * per axis), written onto the stride-2 lattice of dX. w_split[c] / wscale[c] (c = 4 pz + 2 py + px):
@@ -233,6 +244,16 @@ int adell_conv3d_bwd_weight_f16x3(const adell_conv3d_desc* d, const float* x0,
                                   const float* x1, const float* dy, float* dw, float* db,
                                   const uint32_t* x_absmax, const uint32_t* dy_absmax,
                                   void* workspace, size_t workspace_bytes, void* stream);
+/* The same with split-row sources of X (see adell_norm_act_fwd_split): xk0 / xk1 non-NULL = that
+ * source holds rows, ONE exponent per tensor (xk[0]); x_absmax then covers the fp32 source only.
+ * _rows_ok(d) == 1: the z-ring kernel serves the problem and no 32-channel tile straddles the two
+ * sources. Workspace: adell_conv3d_bwd_weight_f16x3_workspace(d). */
+int adell_conv3d_bwd_weight_f16x3_rows_ok(const adell_conv3d_desc* d);
+int adell_conv3d_bwd_weight_f16x3_rows(const adell_conv3d_desc* d, const void* x0, const int* xk0,
+                                       const void* x1, const int* xk1, const float* dy, float* dw,
+                                       float* db, const uint32_t* x_absmax,
+                                       const uint32_t* dy_absmax, void* workspace,
+                                       size_t workspace_bytes, void* stream);
 
 /* db[c] = sum over rows of dy[rows][C] (torch's bias gradient of Conv3d /
  * ConvTranspose3d). workspace >= adell_bias_grad_workspace(rows, C) bytes. */
@@ -328,6 +349,27 @@ long adell_norm_act_mask_bytes(const adell_norm_act_desc* d);
 int adell_norm_act_fwd_mask(const adell_norm_act_desc* d, const float* x, const float* mean,
                             const float* rstd, const float* gamma, const float* beta,
                             const float* act_w, float* out, void* keep_mask, void* stream);
+/* Split rows (round 4): an activation stored as the LDS row image of the f16x3 convolution kernels
+ * instead of fp32 values -- per voxel and 16-channel chunk one 64-byte row
+ *   [hi c0-7 | hi c8-15 | lo c0-7 | lo c8-15]   fp16, hi = fp16(x 2^k), lo = fp16(x 2^k - hi)
+ * (same bytes per element; 22 of the 24 mantissa bits, exactly what those kernels keep of an fp32
+ * operand), with exponents xk[N][C / 16]. The consumer then stages its halo as a copy: no
+ * block-wide absmax, no conversion on the vector ALU. Replaces the fp32 tensor between
+ * `ActDropNorm` and the `Conv3d` that is its only reader (unet.py:260-273, res_blocks.py:150-178).
+ *
+ * adell_norm_act_fwd_split: adell_norm_act_fwd(_mask) writing rows scaled by 2^split_exp (the
+ * caller knows a bound: an instance-normalised value is at most sqrt(V) in magnitude, dropout
+ * scales by 1 / (1 - p), and |act(u)| <= |u| for the activations it is used with); C a power of two
+ * in 16..1024; keep_mask as adell_norm_act_fwd_mask or NULL.
+ * adell_split_rows_from_f32 / _to_f32: the conversions for any tensor with known exponents. */
+int adell_norm_act_fwd_split(const adell_norm_act_desc* d, const float* x, const float* mean,
+                             const float* rstd, const float* gamma, const float* beta,
+                             const float* act_w, void* out_rows, int split_exp, void* keep_mask,
+                             void* stream);
+int adell_split_rows_from_f32(const float* x, int N, long V, int C, const int* xk, void* rows,
+                              void* stream);
+int adell_split_rows_to_f32(const void* rows, int N, long V, int C, const int* xk, float* x,
+                            void* stream);
 /* Second half of the site's backward when the producer of dout already applied the activation /
  * dropout derivative (adell_conv3d_bwd_data_f16x3_adn): dx = rstd * (dt - c1 - xhat * c2) with
  * c1 / c2 the means of the partial sums. partials: [N][ntiles][pstride][2], the site's channels

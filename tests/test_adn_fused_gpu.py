@@ -146,15 +146,15 @@ def test_launch_plan_flipped_between_forward_and_backward(cuda):
     from adell_mri_amd import ops
 
     blk = _block(cuda, 32)
-    x = torch.randn(2, 32, 32, 32, 32, device=cuda)
-    r = torch.randn(2, 32, 32, 32, 32, device=cuda)
+    x = torch.randn(2, 32, 64, 64, 64, device=cuda)
+    r = torch.randn(2, 32, 64, 64, 64, device=cuda)
     y0, gx0, gw0 = _run_block(blk, x, r)
 
     HF._dropout_counter = itertools.count(1)
     blk.zero_grad()
     xg = x.clone().requires_grad_(True)
     y = blk(xg)                                   # planned under the default switches
-    size, k, st, pad = (32, 32, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    size, k, st, pad = (64, 64, 64), (3, 3, 3), (1, 1, 1), (1, 1, 1)
     rows_fwd = ops.conv3d_bwd_data_adn_ntiles(size, 2, 32, 0, 32, k, st, pad)
     with _lib.tuning(igemm_no8=1):
         rows_bwd = ops.conv3d_bwd_data_adn_ntiles(size, 2, 32, 0, 32, k, st, pad)

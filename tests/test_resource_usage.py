@@ -20,6 +20,8 @@ import resource_usage as ru  # noqa: E402
 ALLOWED = {
     "adell_conv_igemm_ws_kernel<2, 2, 4>": (356, "opt-in wave-specialised experiment (igemm_ws)"),
     "adell_conv_igemm_ws_kernel<4, 1, 8>": (672, "opt-in wave-specialised experiment (igemm_ws)"),
+    "adell_conv_igemm_f16_kernel<4, 1, 4, 1, 3, 0, 1>": (
+        12, "split rows in ONE half of a concat on a 32-column tile: no BASELINE config"),
     "adell_cinfold_wgrad_kernel<3>": (340, "3-channel inputs: no BASELINE config"),
     "adell_cinfold_wgrad_kernel<4>": (568, "4-channel inputs: no BASELINE config"),
     "adell_cinfold_dx_kernel<4, 64>": (92, "4-channel inputs: no BASELINE config"),
@@ -78,7 +80,10 @@ def test_step_kernels_are_spill_free():
     for n in names:
         if n.startswith("_Z"):
             continue
-        cands = [k for k in table if k == n or k.startswith(n + "<") or k.startswith(n + "(")]
+        # (a template that gained trailing defaulted parameters since the profile was taken: the
+        # profile's "<a, b>" names the instances "<a, b, 0...>")
+        cands = [k for k in table if k == n or k.startswith(n + "<") or k.startswith(n + "(")
+                 or (n.endswith(">") and k.startswith(n[:-1] + ", 0"))]
         if not cands:
             missing.append(n)
             continue
