@@ -73,6 +73,9 @@ def parse_args():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32-MFMA secondary figure")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the other north_star workloads (256x256x128 and batch-1 128^3)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip BASELINE configs 3-5 (UNETR 96^3, VICReg ConvNeXt 64^3, SWIN-UNet "
+                         "256x256x128) in the `secondary` object")
     ap.add_argument("--cpu-size", type=int, default=128,
                     help="edge of the volume the CPU oracle is timed on with all cores")
     return ap.parse_args()
@@ -300,6 +303,127 @@ def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None,
     return dt, loss, per
 
 
+
+CONFIGS_DIR = os.path.join(ROOT, "configs")
+
+
+def other_config_runs(device, rank, world, barrier, reduce_max):
+    """BASELINE configs 3, 4 and 5 at the sizes SURVEY.md 8(d) gives them, each built from its YAML
+    through the factory the entrypoint uses (as tests/test_fullsize_configs_gpu.py does): 3 warm-up
+    steps, pool head-room, 5 timed steps with the per-step record, then one instrumented step for
+    the dominant FLOP-carrying kernel family of THAT workload (its own roofline)."""
+    import torch
+
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+    from adell_mri_amd.modules.config_parsing import parse_config_ssl, parse_config_unet
+    from adell_mri_amd.parallel import GradSync
+    from adell_mri_amd.trainer import StepRunner
+    from adell_mri_amd.utils.network_factories import get_segmentation_network
+
+    def seg(net_type, yaml_name, keys, size, patch=None):
+        cfg, _ = parse_config_unet(os.path.join(CONFIGS_DIR, yaml_name), len(keys), 2)
+        if patch is not None:
+            cfg["patch_size"] = patch
+        torch.manual_seed(0)
+        return get_segmentation_network(net_type, cfg, False, [], [], None, None, None, 100, [None],
+                                        False, None, None, None, False, 2, keys,
+                                        random_crop_size=size)
+
+    def seg_batch(n, c, size, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand((n, c, *size), generator=g).to(device)
+        y = (torch.rand((n, 1, *size), generator=g) > 0.9).float().to(device)
+        return {"image": x, "mask": y}
+
+    def build_cfg3():
+        net = seg("unetr", "unetr.yaml", ["image"], [96, 96, 96], patch=[16, 16, 16])
+        return net, seg_batch(4, 1, (96, 96, 96), 342 + rank), 4, "volumes/s", \
+            "BASELINE configs[2]: unetr.yaml UNETRPL, 1x96^3, patch 16^3, batch 4/GPU"
+
+    def build_cfg4():
+        from adell_mri_amd.modules.self_supervised.pl import SelfSLConvNeXtPL
+        _, cfg = parse_config_ssl(os.path.join(CONFIGS_DIR, "ssl-3d-convnext.yaml"), 0.0, 1)
+        cfg.pop("batch_size", None)
+        cfg["vic_reg_loss_params"] = {}
+        cfg["backbone_args"] = {k: v for k, v in cfg["backbone_args"].items() if k != "res_type"}
+        torch.manual_seed(0)
+        net = SelfSLConvNeXtPL(aug_image_key_1="augmented_image_1",
+                               aug_image_key_2="augmented_image_2", ssl_method="vicreg",
+                               stop_gradient=False, n_epochs=100, **cfg)
+        g = torch.Generator().manual_seed(442 + rank)
+        x1 = torch.randn((32, 1, 64, 64, 64), generator=g).to(device)
+        x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g).to(device)).flip(2)
+        return net, {"augmented_image_1": x1, "augmented_image_2": x2}, 32, "crops/s", \
+            "BASELINE configs[3]: ssl-3d-convnext.yaml SelfSLConvNeXtPL (VICReg), 2 views x 32 crops of 64^3 per GPU, AdamW"
+
+    def build_cfg5():
+        net = seg("swin", "unet-swin.yaml", ["image", "image_1"], [256, 256, 128])
+        return net, seg_batch(1, 2, (256, 256, 128), 542 + rank), 1, "volumes/s", \
+            "BASELINE configs[4]: unet-swin.yaml SWINUNetPL, 2x256x256x128, batch 1/GPU"
+
+    out = {}
+    for key, build in (("cfg3_unetr_96", build_cfg3), ("cfg4_vicreg_convnext_64", build_cfg4),
+                       ("cfg5_swinunet_256x256x128", build_cfg5)):
+        try:
+            net, batch, units, unit, workload = build()
+            net = net.to(device).train()
+            opt = net.configure_optimizers()["optimizer"]
+            runner = StepRunner(net, opt, GradSync(opt))
+            for _ in range(3):
+                runner.train_step(batch)
+            barrier()
+            runner.reserve_memory()
+            dt, loss, per = timed_steps(runner, batch, 5, barrier)
+            rec = step_record(per, list(LAST_DIAG))
+            dt = reduce_max(dt, device)
+            ops.KERNEL_TIMER = ops.KernelTimer()
+            overlap = HF.FLAGS["wgrad_stream"]
+            HF.FLAGS["wgrad_stream"] = False       # (instrumented step: one stream, see timed_steps)
+            runner.train_step(batch)
+            barrier()
+            HF.FLAGS["wgrad_stream"] = overlap
+            timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+            entry = {"workload": workload, "value": units * world * 5 / dt, "unit": unit,
+                     "ms_per_step": 1e3 * dt / 5, "median_ms_per_step": statistics.median(per),
+                     "steps": 5, "warmup": 3, "final_loss": float(loss.detach().cpu()),
+                     "step_record": rec,
+                     "params": sum(p.numel() for p in net.parameters())}
+            dom = timer.dominant()
+            if dom is not None:
+                name, flops, ms, launches = dom
+                f16 = "f16" in name
+                peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
+                ach = flops / (ms * 1e-3) / 1e12
+                summ = timer.summary()
+                entry["roofline"] = {
+                    "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s", "frac": ach / peak, "launches": launches,
+                    "avg_launch_ms": ms / launches,
+                    "kernel_time_share_of_step": ms / (1e3 * dt / 5),
+                    "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product" if f16
+                                   else "fp32 matrix peak"),
+                    "families_ms_per_step": {k: round(v["ms"], 3) for k, v in summ.items()}}
+            out[key] = entry
+            del runner, opt, net, batch
+        except Exception as exc:      # a secondary workload must not take the headline line down
+            out[key] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_cfg1_step(threads):
+    """BASELINE configs[0]: the 2-D U-Net of the reference's testing/test_unet.py:63-72 (depth
+    16 / 32 / 64, transposed upscaling, 140 748 parameters) on the stock-torch CPU oracle: median of
+    3 training steps on a batch of 4 x 1 x 128 x 128, seconds per step."""
+    import torch
+
+    from oracle.torch_ref import unet2d as o2
+
+    torch.set_num_threads(threads)
+    return o2.training_step_seconds(batch=4, size=128, steps=3, warmup=1)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -439,6 +563,14 @@ def main():
             secondary[key] = sec
             del sb
         torch.cuda.empty_cache()
+    other = {}
+    if (not args.no_secondary and not args.no_other_configs and args.shape is None
+            and args.size == 128 and args.batch is None and os.path.abspath(args.config) == CONFIG):
+        # release the headline model's pools first: cfg 5 alone reserves ~45 GB
+        del batch
+        torch.cuda.empty_cache()
+        other = other_config_runs(device, rank, world, barrier, reduce_max)
+        secondary.update(other)
 
     if rank != 0:
         return
@@ -547,6 +679,15 @@ def main():
             "one_thread": {"value": (small ** 3 / vox) / t_one, "unit": "volumes/s", "cores": 1,
                            "sample": f"1 training step on one {small}^3 volume ({t_one:.2f} s), "
                                      f"scaled by voxel count to {shape_str}"}}
+        # "... at cfg 2 (B = 1) and cfg 1" -- BASELINE configs[0], the reference's
+        # own CPU-runnable case (testing/test_unet.py:63-72), on the same host cores
+        t_cfg1 = cpu_cfg1_step(physical)
+        out["cpu_baseline"]["cfg1"] = {
+            "value": 4.0 / t_cfg1, "unit": "images/s", "cores": used, "kind": "port",
+            "sample": f"BASELINE configs[0]: 2-D U-Net 128x128 1-ch (140 748 parameters, BatchNorm2d "
+                      f"+ PReLU), stock-torch CPU oracle (oracle/torch_ref/unet2d.py, pinned to the "
+                      f"reference fixture unet2d_cfg1): 1 warm-up + 3 timed training steps on a "
+                      f"batch of 4, median {1e3 * t_cfg1:.1f} ms/step"}
     print(json.dumps(out))
 
 

@@ -54,9 +54,9 @@ def test_fused_producer_writes_the_rows_of_the_fp32_output(cuda, act, p, C, size
 CASES = [  # N, C0, C1, Cout, size
     (2, 32, 0, 32, (16, 16, 16)),      # 8x8x4 bricks
     (2, 32, 0, 32, (64, 64, 64)),      # 8x8x8 bricks
-    (1, 64, 0, 32, (40, 24, 36)),      # ragged bricks, two chunks
-    (1, 64, 0, 64, (32, 32, 32)),      # 64-column tile
-    (1, 32, 32, 64, (32, 32, 32)),     # virtual concat
+    (1, 64, 0, 32, (76, 44, 68)),      # ragged bricks, four chunks
+    (2, 64, 0, 64, (32, 32, 32)),      # 64-column tile
+    (1, 32, 32, 64, (48, 48, 44)),     # virtual concat, ragged in z
     (2, 16, 0, 16, (32, 32, 32)),      # one chunk, half-empty column tile
 ]
 
