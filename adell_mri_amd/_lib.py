@@ -196,6 +196,11 @@ SIGNATURES = {
     "adell_item_stats": (_i, [_vp, _i, _l, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_aug_intensity": (_i, [_vp, _vp, _i, _l, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp]),
     "adell_affine_sample": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "adell_axis_filter": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "adell_bias_field": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "adell_axis_lut_sample": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "adell_gibbs_workspace": (_l, [_i, _i, _i, _i, _i]),
+    "adell_gibbs_lowpass": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_fwd": (_i, [_vp, _l, _i, _i, _l, _l, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "adell_layernorm_rows_bwd_workspace": (_l, [_l, _i]),

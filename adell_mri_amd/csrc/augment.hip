@@ -244,3 +244,292 @@ extern "C" int adell_affine_sample(const float* x, float* out, int N, int D, int
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// =====================================================================================================
+// Round 4: the remaining members of get_augmentations_unet (transform_factory/augmentations.py:52-127):
+// RandGaussianSmoothd ("blur"), RandBiasFieldd ("rbf"), RandGridDistortiond ("distort"),
+// RandGibbsNoised (the k-space half of "noise"); RandSimulateLowResolutiond ("lowres") is composed on
+// the host side from the resize kernels of layout.hip. All HBM-bound single passes over [N][D][H][W][C].
+// =====================================================================================================
+
+// ---- 1-D filter along one spatial axis, zero padding (one pass per axis of a separable Gaussian) ----
+// taps [N][2 R + 1]: the item's filter (an item that is not smoothed gets the unit impulse).
+__global__ __launch_bounds__(256) void adell_axis_filter_kernel(
+    const float* __restrict__ x, float* __restrict__ out, int D, int H, int W, int C, int axis,
+    const float* __restrict__ taps, int R) {
+  const int n = blockIdx.y;
+  const long V = (long)D * H * W, E = V * C;
+  const float* t = taps + (size_t)n * (2 * R + 1);
+  const float* xi = x + (size_t)n * E;
+  float* oi = out + (size_t)n * E;
+  const int L = axis == 0 ? D : (axis == 1 ? H : W);
+  const long stride = (axis == 0 ? (long)H * W : (axis == 1 ? (long)W : 1L)) * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
+    const long v = e / C;
+    const int pos = axis == 0 ? (int)(v / ((long)H * W)) : (axis == 1 ? (int)((v / W) % H) : (int)(v % W));
+    float acc = 0.f;
+    for (int k = -R; k <= R; ++k) {
+      const int q = pos + k;
+      if (q >= 0 && q < L) acc = fmaf(t[k + R], xi[e + (long)k * stride], acc);
+    }
+    oi[e] = acc;
+  }
+}
+
+extern "C" int adell_axis_filter(const float* x, float* out, int N, int D, int H, int W, int C,
+                                 int axis, const float* taps, int radius, void* stream) {
+  ADELL_REQUIRE(x && out && taps && x != out, "axis_filter: null or aliased pointer");
+  ADELL_REQUIRE(N > 0 && N <= 65535 && D > 0 && H > 0 && W > 0 && C > 0, "axis_filter: bad dims");
+  ADELL_REQUIRE(axis >= 0 && axis <= 2 && radius >= 0 && radius <= 64, "axis_filter: bad axis / radius");
+  long b = ((long)D * H * W * C + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(adell_axis_filter_kernel, dim3((unsigned)b, N), dim3(256), 0,
+                     (hipStream_t)stream, x, out, D, H, W, C, axis, taps, radius);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---- multiplicative polynomial bias field: out = x * exp(sum_ijk c[i][j][k] P_i(z) P_j(y) P_k(x)) ----
+// coef [N][64] = the dense 4 x 4 x 4 Legendre coefficient cube of the item (degree <= 3; entries
+// with i + j + k > 3 are zero in MONAI's field), coordinates linspace(-1, 1, size) per axis.
+__device__ __forceinline__ void adell_legendre4(float u, float* p) {
+  p[0] = 1.f;
+  p[1] = u;
+  p[2] = 0.5f * (3.f * u * u - 1.f);
+  p[3] = 0.5f * (5.f * u * u * u - 3.f * u);
+}
+
+__global__ __launch_bounds__(256) void adell_bias_field_kernel(
+    const float* __restrict__ x, float* __restrict__ out, int D, int H, int W, int C,
+    const float* __restrict__ coef) {
+  const int n = blockIdx.y;
+  const long V = (long)D * H * W;
+  __shared__ float c[64];
+  if (threadIdx.x < 64) c[threadIdx.x] = coef[(size_t)n * 64 + threadIdx.x];
+  __syncthreads();
+  const float* xi = x + (size_t)n * V * C;
+  float* oi = out + (size_t)n * V * C;
+  const float sz = D > 1 ? 2.f / (D - 1) : 0.f, sy = H > 1 ? 2.f / (H - 1) : 0.f,
+              sx = W > 1 ? 2.f / (W - 1) : 0.f;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    const int ox = (int)(v % W), oy = (int)((v / W) % H), oz = (int)(v / ((long)W * H));
+    float pz[4], py[4], px[4];
+    adell_legendre4(-1.f + sz * oz, pz);
+    adell_legendre4(-1.f + sy * oy, py);
+    adell_legendre4(-1.f + sx * ox, px);
+    float f = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = fmaf(c[(i * 4 + j) * 4 + k], px[k], s);
+        f = fmaf(pz[i] * py[j], s, f);
+      }
+    const float g = expf(f);
+    for (int ch = 0; ch < C; ++ch) oi[v * C + ch] = xi[v * C + ch] * g;
+  }
+}
+
+extern "C" int adell_bias_field(const float* x, float* out, int N, int D, int H, int W, int C,
+                                const float* coef, void* stream) {
+  ADELL_REQUIRE(x && out && coef, "bias_field: null pointer");
+  ADELL_REQUIRE(N > 0 && N <= 65535 && D > 0 && H > 0 && W > 0 && C > 0, "bias_field: bad dims");
+  long b = ((long)D * H * W + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(adell_bias_field_kernel, dim3((unsigned)b, N), dim3(256), 0,
+                     (hipStream_t)stream, x, out, D, H, W, C, coef);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---- resampling through per-axis coordinate tables (grid distortion): border padding ----------------
+// lut [N][D + H + W]: for output index o along an axis, the input coordinate in voxels.
+__global__ __launch_bounds__(256) void adell_axis_lut_sample_kernel(
+    const float* __restrict__ x, float* __restrict__ out, int D, int H, int W, int C,
+    const float* __restrict__ lut, int linear) {
+  const int n = blockIdx.y;
+  const long V = (long)D * H * W;
+  const float* lz = lut + (size_t)n * (D + H + W);
+  const float* ly = lz + D;
+  const float* lx = ly + H;
+  const float* xi = x + (size_t)n * V * C;
+  float* oi = out + (size_t)n * V * C;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    const int ox = (int)(v % W), oy = (int)((v / W) % H), oz = (int)(v / ((long)W * H));
+    const float sz = fminf(fmaxf(lz[oz], 0.f), (float)(D - 1));
+    const float sy = fminf(fmaxf(ly[oy], 0.f), (float)(H - 1));
+    const float sx = fminf(fmaxf(lx[ox], 0.f), (float)(W - 1));
+    float* o = oi + v * C;
+    if (!linear) {
+      const int iz = (int)nearbyintf(sz), iy = (int)nearbyintf(sy), ix = (int)nearbyintf(sx);
+      const float* s = xi + (((long)iz * H + iy) * W + ix) * C;
+      for (int c = 0; c < C; ++c) o[c] = s[c];
+      continue;
+    }
+    const float fz = floorf(sz), fy = floorf(sy), fx = floorf(sx);
+    const int z0 = (int)fz, y0 = (int)fy, x0 = (int)fx;
+    const float az = sz - fz, ay = sy - fy, ax = sx - fx;
+    for (int c = 0; c < C; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = min(z0 + (k >> 2), D - 1), yy = min(y0 + ((k >> 1) & 1), H - 1),
+                xx = min(x0 + (k & 1), W - 1);
+      const float w = ((k >> 2) ? az : 1.f - az) * (((k >> 1) & 1) ? ay : 1.f - ay) *
+                      ((k & 1) ? ax : 1.f - ax);
+      if (w == 0.f) continue;
+      const float* s = xi + (((long)zz * H + yy) * W + xx) * C;
+      for (int c = 0; c < C; ++c) o[c] += w * s[c];
+    }
+  }
+}
+
+extern "C" int adell_axis_lut_sample(const float* x, float* out, int N, int D, int H, int W, int C,
+                                     const float* lut, int linear, void* stream) {
+  ADELL_REQUIRE(x && out && lut && x != out, "axis_lut_sample: null or aliased pointer");
+  ADELL_REQUIRE(N > 0 && N <= 65535 && D > 0 && H > 0 && W > 0 && C > 0, "axis_lut_sample: bad dims");
+  long b = ((long)D * H * W + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(adell_axis_lut_sample_kernel, dim3((unsigned)b, N), dim3(256), 0,
+                     (hipStream_t)stream, x, out, D, H, W, C, lut, linear);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---- k-space low-pass (Gibbs ringing): DFT along each spatial axis of a complex copy, a spherical
+// mask about the centre of the SHIFTED spectrum, inverse DFTs, real part --------------------------------
+// The transform is a direct O(L^2) DFT per line out of LDS (any length up to 1024, e.g. the 96 of
+// BASELINE config 3: no power-of-two restriction); G adjacent lines per block so that the strided
+// axes still read whole 64-byte runs. buf: [N][D][H][W][C] float2.
+constexpr int kDftMaxL = 1024;
+__global__ __launch_bounds__(256) void adell_dft_axis_kernel(float2* __restrict__ buf, long lines,
+                                                             int L, long S, int G, int inverse) {
+  extern __shared__ float2 sdft[];            // [G][L] data, then [L] twiddles
+  float2* tw = sdft + (size_t)G * L;
+  const int tid = threadIdx.x;
+  for (int k = tid; k < L; k += 256) {
+    const float a = (inverse ? 6.283185307179586f : -6.283185307179586f) * (float)k / (float)L;
+    float sn, cs;
+    sincosf(a, &sn, &cs);
+    tw[k] = make_float2(cs, sn);
+  }
+  const long groups = (lines + G - 1) / G;
+  for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+    __syncthreads();
+    // line id -> (outer, inner): element (outer * L + k) * S + inner; a group = G consecutive inner
+    const long line0 = g * G;
+    for (int i = tid; i < G * L; i += 256) {
+      const int k = i / G, j = i - k * G;
+      const long line = line0 + j;
+      float2 v = make_float2(0.f, 0.f);
+      if (line < lines) {
+        const long outer = line / S, inner = line - outer * S;
+        v = buf[(outer * L + k) * S + inner];
+      }
+      sdft[(size_t)j * L + k] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < G * L; i += 256) {
+      const int k = i / G, j = i - k * G;
+      const long line = line0 + j;
+      if (line >= lines) continue;
+      const float2* xl = sdft + (size_t)j * L;
+      float re = 0.f, im = 0.f;
+      int idx = 0;
+      for (int m = 0; m < L; ++m) {
+        const float2 w = tw[idx], v = xl[m];
+        re = fmaf(v.x, w.x, fmaf(-v.y, w.y, re));
+        im = fmaf(v.x, w.y, fmaf(v.y, w.x, im));
+        idx += k;
+        if (idx >= L) idx -= L;
+      }
+      const long outer = line / S, inner = line - outer * S;
+      // (written after every read of the group: the second barrier above orders the reads of the
+      // NEXT group; this group's inputs are all in LDS)
+      buf[(outer * L + k) * S + inner] = make_float2(re, im);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_kspace_kernel(const float* __restrict__ x,
+                                                           float2* __restrict__ buf,
+                                                           float* __restrict__ out, int D, int H,
+                                                           int W, int C,
+                                                           const float* __restrict__ radius,
+                                                           int phase) {
+  // phase 0: buf = x (complex); phase 1: zero the coefficients outside the item's sphere;
+  // phase 2: out = Re(buf) / (D H W)
+  const int n = blockIdx.y;
+  const long V = (long)D * H * W;
+  const float r2 = phase == 1 ? radius[n] * radius[n] : 0.f;
+  const float cz = 0.5f * (D - 1), cy = 0.5f * (H - 1), cx = 0.5f * (W - 1);
+  const float inv = 1.0f / (float)V;
+  for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < V; v += (long)gridDim.x * 256) {
+    const size_t e0 = ((size_t)n * V + v) * C;
+    if (phase == 0) {
+      for (int c = 0; c < C; ++c) buf[e0 + c] = make_float2(x[e0 + c], 0.f);
+    } else if (phase == 2) {
+      for (int c = 0; c < C; ++c) out[e0 + c] = buf[e0 + c].x * inv;
+    } else {
+      const int kx = (int)(v % W), ky = (int)((v / W) % H), kz = (int)(v / ((long)W * H));
+      // fftshift: coefficient k sits at position (k + L / 2) mod L of the shifted spectrum
+      const float dz = (float)((kz + D / 2) % D) - cz, dy = (float)((ky + H / 2) % H) - cy,
+                  dx = (float)((kx + W / 2) % W) - cx;
+      if (dz * dz + dy * dy + dx * dx > r2)
+        for (int c = 0; c < C; ++c) buf[e0 + c] = make_float2(0.f, 0.f);
+    }
+  }
+}
+
+extern "C" long adell_gibbs_workspace(int N, int D, int H, int W, int C) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return ADELL_E_BADARG;
+  return (long)N * D * H * W * C * 8;
+}
+
+// out = Re(ifftn(ifftshift(fftshift(fftn(x)) * [dist from centre <= radius[n]]))) per item and
+// channel over the three spatial axes (an item with radius >= the spectrum's half diagonal is unchanged
+// up to rounding). workspace: adell_gibbs_workspace bytes.
+extern "C" int adell_gibbs_lowpass(const float* x, float* out, int N, int D, int H, int W, int C,
+                                   const float* radius, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  ADELL_REQUIRE(x && out && radius && workspace, "gibbs_lowpass: null pointer");
+  ADELL_REQUIRE(N > 0 && N <= 65535 && D > 0 && H > 0 && W > 0 && C > 0, "gibbs_lowpass: bad dims");
+  ADELL_REQUIRE(D <= kDftMaxL && H <= kDftMaxL && W <= kDftMaxL, "gibbs_lowpass: axis longer than 1024");
+  ADELL_REQUIRE(workspace_bytes >= (size_t)adell_gibbs_workspace(N, D, H, W, C),
+                "gibbs_lowpass: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  float2* buf = (float2*)workspace;
+  long b = ((long)D * H * W + 255) / 256;
+  if (b > 8192) b = 8192;
+  auto pass = [&](int phase) {
+    hipLaunchKernelGGL(adell_kspace_kernel, dim3((unsigned)b, N), dim3(256), 0, st, x, buf, out, D, H,
+                       W, C, radius, phase);
+  };
+  static bool attr_done = false;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_dft_axis_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  auto dft = [&](int axis, int inverse) {
+    const int L = axis == 0 ? D : (axis == 1 ? H : W);
+    if (L == 1) return;
+    const long S = (axis == 0 ? (long)H * W : (axis == 1 ? (long)W : 1L)) * C;
+    const long total = (long)N * D * H * W * C;
+    const long lines = total / L;        // outer * S with outer = N * (dims before the axis)
+    int G = 8;
+    while (G > 1 && (S % G != 0 || (size_t)(G + 1) * L * 8 > 96 * 1024)) G >>= 1;
+    long groups = (lines + G - 1) / G;
+    if (groups > 65535 * 4) groups = 65535 * 4;
+    hipLaunchKernelGGL(adell_dft_axis_kernel, dim3((unsigned)groups), dim3(256),
+                       (size_t)(G + 1) * L * sizeof(float2), st, buf, lines, L, S, G, inverse);
+  };
+  pass(0);
+  for (int a = 0; a < 3; ++a) dft(a, 0);
+  pass(1);
+  for (int a = 0; a < 3; ++a) dft(a, 1);
+  pass(2);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

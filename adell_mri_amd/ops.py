@@ -1829,3 +1829,63 @@ def affine_sample(x, theta, linear=True, pad_mode="reflection"):
                                          {"zeros": 0, "border": 1, "reflection": 2}[pad_mode],
                                          _stream()))
     return out
+
+
+def axis_filter(x, taps, axis):
+    """1-D filter along spatial axis 0 / 1 / 2 (zero padding); ``taps`` [N, 2 R + 1] device rows."""
+    _require_cuda(x, taps)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    out = new_act(N, C, D, H, W, x.device)
+    check(_lib.lib().adell_axis_filter(_ptr(x), _ptr(out), N, D, H, W, C, int(axis), _ptr(taps),
+                                       (taps.shape[1] - 1) // 2, _stream()))
+    return out
+
+
+def bias_field(x, coef):
+    """x * exp(Legendre polynomial field); ``coef`` [N, 64] device rows (dense 4 x 4 x 4 cube)."""
+    _require_cuda(x, coef)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    out = new_act(N, C, D, H, W, x.device)
+    check(_lib.lib().adell_bias_field(_ptr(x), _ptr(out), N, D, H, W, C, _ptr(coef), _stream()))
+    return out
+
+
+def axis_lut_sample(x, lut, linear=True):
+    """Resampling through per-axis coordinate tables ``lut`` [N, D + H + W] (border padding)."""
+    _require_cuda(x, lut)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    out = new_act(N, C, D, H, W, x.device)
+    check(_lib.lib().adell_axis_lut_sample(_ptr(x), _ptr(out), N, D, H, W, C, _ptr(lut),
+                                           1 if linear else 0, _stream()))
+    return out
+
+
+def gibbs_lowpass(x, radius):
+    """k-space low-pass per item: spectrum zeroed outside ``radius`` [N] (device) about the centre of
+    the shifted spectrum."""
+    _require_cuda(x, radius)
+    x = ndhwc(x)
+    N, C, D, H, W = x.shape
+    out = new_act(N, C, D, H, W, x.device)
+    nbytes = _lib.lib().adell_gibbs_workspace(N, D, H, W, C)
+    if nbytes < 0:
+        check(int(nbytes))
+    ws = _workspace(nbytes, x.device)
+    check(_lib.lib().adell_gibbs_lowpass(_ptr(x), _ptr(out), N, D, H, W, C, _ptr(radius), _ptr(ws),
+                                         ws.numel() * 4, _stream()))
+    return out
+
+
+def resize_linear(x, size):
+    """F.interpolate(x, size=size, mode="trilinear", align_corners=False) on [N, C, D, H, W]."""
+    _require_cuda(x)
+    x = ndhwc(x)
+    N, C, Di, Hi, Wi = x.shape
+    Do, Ho, Wo = (int(v) for v in size)
+    y = new_act(N, C, Do, Ho, Wo, x.device)
+    check(_lib.lib().adell_interp_linear_fwd(_ptr(x), _ptr(y), N, C, Di, Hi, Wi, Do, Ho, Wo,
+                                             Do / Di, Ho / Hi, Wo / Wi, 0, _stream()))
+    return y

@@ -354,7 +354,7 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
         g = torch.Generator().manual_seed(442 + rank)
         x1 = torch.randn((32, 1, 64, 64, 64), generator=g).to(device)
         x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g).to(device)).flip(2)
-        return net, {"augmented_image_1": x1, "augmented_image_2": x2}, 32, "crops/s", \
+        return net, {"augmented_image_1": x1, "augmented_image_2": x2}, 64, "crops/s", \
             "BASELINE configs[3]: ssl-3d-convnext.yaml SelfSLConvNeXtPL (VICReg), 2 views x 32 crops of 64^3 per GPU, AdamW"
 
     def build_cfg5():
@@ -370,7 +370,7 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             net = net.to(device).train()
             opt = net.configure_optimizers()["optimizer"]
             runner = StepRunner(net, opt, GradSync(opt))
-            for _ in range(3):
+            for _ in range(4):
                 runner.train_step(batch)
             barrier()
             runner.reserve_memory()
@@ -386,7 +386,7 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
             entry = {"workload": workload, "value": units * world * 5 / dt, "unit": unit,
                      "ms_per_step": 1e3 * dt / 5, "median_ms_per_step": statistics.median(per),
-                     "steps": 5, "warmup": 3, "final_loss": float(loss.detach().cpu()),
+                     "steps": 5, "warmup": 4, "final_loss": float(loss.detach().cpu()),
                      "step_record": rec,
                      "params": sum(p.numel() for p in net.parameters())}
             dom = timer.dominant()

@@ -823,6 +823,26 @@ int adell_aug_intensity(const float* x, float* out, int N, long per_item, const 
  * 0 nearest; pad_mode: 0 zeros, 1 border, 2 reflection (about -0.5 / size - 0.5). */
 int adell_affine_sample(const float* x, float* out, int N, int D, int H, int W, int C,
                         const float* theta, int linear, int pad_mode, void* stream);
+/* Round 4, the rest of get_augmentations_unet (augmentations.py:52-127). All on NDHWC volumes.
+ * adell_axis_filter: 1-D filter along spatial axis 0 / 1 / 2 with zero padding, taps[N][2 R + 1]
+ *   per item (three calls = the separable Gaussian of RandGaussianSmoothd, "blur").
+ * adell_bias_field: out = x * exp(sum c[i][j][k] P_i(z) P_j(y) P_k(x)), Legendre polynomials over
+ *   linspace(-1, 1, size), coef[N][64] = dense 4 x 4 x 4 cube (RandBiasFieldd degree 3, "rbf").
+ * adell_axis_lut_sample: resampling through per-axis coordinate tables lut[N][D + H + W] (input
+ *   voxel coordinate per output index), trilinear / nearest, border padding (RandGridDistortiond,
+ *   "distort").
+ * adell_gibbs_lowpass: per item the spectrum (three-axis DFT, any axis length <= 1024) is zeroed
+ *   outside the sphere of radius[n] about the centre of the SHIFTED spectrum and transformed back
+ *   (RandGibbsNoised, the k-space half of "noise"); workspace adell_gibbs_workspace bytes. */
+int adell_axis_filter(const float* x, float* out, int N, int D, int H, int W, int C, int axis,
+                      const float* taps, int radius, void* stream);
+int adell_bias_field(const float* x, float* out, int N, int D, int H, int W, int C,
+                     const float* coef, void* stream);
+int adell_axis_lut_sample(const float* x, float* out, int N, int D, int H, int W, int C,
+                          const float* lut, int linear, void* stream);
+long adell_gibbs_workspace(int N, int D, int H, int W, int C);
+int adell_gibbs_lowpass(const float* x, float* out, int N, int D, int H, int W, int C,
+                        const float* radius, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

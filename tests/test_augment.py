@@ -12,10 +12,21 @@ from oracle.torch_ref import augment_ref as ref
 def test_factory_vocabulary_and_plan_statistics():
     with pytest.raises(NotImplementedError):
         DeviceAugmenter(["sharpen"], ["image"], ["image"])
-    for word in ("blur", "distort", "lowres"):
-        with pytest.raises(NotImplementedError):
-            DeviceAugmenter([word], ["image"], ["image"])
-    DeviceAugmenter(["rbf"], ["image"], ["image"])           # no T2 keys: the factory adds nothing
+    for word in ("blur", "distort", "lowres", "rbf"):         # the whole vocabulary is built (round 4)
+        DeviceAugmenter([word], ["image"], ["image"])
+    assert DeviceAugmenter(["rbf"], ["image"], ["image"])._transforms() == []   # no T2 keys: nothing
+    full = DeviceAugmenter(["intensity", "noise", "rbf", "affine", "shear", "blur", "distort",
+                            "lowres"], ["image"], ["image"], t2_keys=["image"], seed=5)
+    # the order of augmentations.py:52-127
+    assert full._transforms() == ["distort", "contrast", "stdshift", "blur", "rician", "gibbs",
+                                  "rbf", "affine", "shear", "lowres"]
+    plan = full.plan(4000)
+    frac = lambda key: np.mean([key in it for it in plan])  # noqa: E731
+    for key in ("distort", "gibbs_alpha", "rbf", "lowres"):
+        assert 0.17 < frac(key) < 0.23, key
+    assert 0.07 < frac("blur") < 0.13                        # MONAI's default prob of 0.1
+    al = [it["gibbs_alpha"] for it in plan if "gibbs_alpha" in it]
+    assert 0.3 <= min(al) and max(al) <= 0.6
     aug = DeviceAugmenter(["intensity", "noise", "affine", "shear", "flip"], ["image", "mask"],
                           ["image"], seed=1)
     plan = aug.plan(4000)
@@ -130,3 +141,81 @@ def test_augmenter_composes_the_passes(cuda):
     wm = ref.affine_resample(m[0:1], th, linear=False, pad_mode="reflection").flip(3)
     assert float((out["mask"][0].cpu() != wm[0]).float().mean()) < 5e-3
     assert set(np.unique(out["mask"].cpu().numpy())) <= {0.0, 1.0}   # labels stay labels
+
+
+@pytest.mark.gpu
+def test_blur_bias_distort_gibbs_lowres_match_restatement(cuda):
+    """Round 4: the remaining transforms of the factory against the torch-CPU restatement of the MONAI
+    definitions (parity unpinned: MONAI absent), on a ragged non-power-of-two volume."""
+    from adell_mri_amd import ops
+    from adell_mri_amd.utils.augment import (bias_coefficients, distortion_table, gaussian_taps)
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand((2, 2, 12, 20, 18), generator=g)
+    xd = ops.ndhwc(x.to(cuda))
+    # blur: item 0 smoothed with three sigmas, item 1 untouched (unit impulse)
+    sig = (0.4, 1.5, 0.9)
+    y = xd
+    for axis in range(3):
+        t = gaussian_taps(sig[axis])
+        R = (len(t) - 1) // 2
+        rows = np.zeros((2, 2 * R + 1), dtype=np.float32)
+        rows[0] = t
+        rows[1, R] = 1.0
+        y = ops.axis_filter(y, torch.from_numpy(rows).to(cuda), axis)
+    want = ref.gaussian_blur(x[0], [gaussian_taps(s) for s in sig])
+    assert float((y[0].cpu() - want).abs().max()) < 1e-5
+    assert torch.equal(y[1].cpu(), x[1])
+    # bias field
+    cube = bias_coefficients(np.linspace(0.01, 0.1, 20))
+    rows = np.zeros((2, 64), dtype=np.float32)
+    rows[0] = cube.reshape(-1)
+    y = ops.bias_field(xd, torch.from_numpy(rows).to(cuda))
+    assert float((y[0].cpu() - ref.bias_field(x[0], cube)).abs().max()) < 2e-5
+    assert torch.equal(y[1].cpu(), x[1])
+    # grid distortion, both interpolation modes
+    steps = [[1.03, 0.96, 1.0, 1.05, 0.95, 1.0], [0.97, 1.02, 1.04, 0.98, 1.0, 1.0],
+             [1.0, 1.05, 0.95, 1.02, 0.99, 1.0]]
+    luts = [distortion_table(n, st) for n, st in zip((12, 20, 18), steps)]
+    ident = [np.arange(n, dtype=np.float32) for n in (12, 20, 18)]
+    rows = np.stack([np.concatenate(luts), np.concatenate(ident)])
+    for linear in (True, False):
+        y = ops.axis_lut_sample(xd, torch.from_numpy(rows).to(cuda), linear=linear)
+        want = ref.lut_resample(x[0], luts, linear=linear)
+        if linear:
+            assert float((y[0].cpu() - want).abs().max()) < 2e-5
+        else:       # ties of the rounding may fall either way on a handful of voxels
+            assert float((y[0].cpu() != want).float().mean()) < 5e-3
+        assert torch.equal(y[1].cpu(), x[1])
+    # Gibbs: a k-space low-pass on one item, the other keeps its whole spectrum
+    alpha = 0.45
+    rad = torch.tensor([(1 - alpha) * 20 * np.sqrt(2) / 2, 40.0], device=cuda)
+    y = ops.gibbs_lowpass(xd, rad)
+    assert float((y[0].cpu() - ref.gibbs(x[0], alpha)).abs().max()) < 2e-5
+    assert float((y[1].cpu() - x[1]).abs().max()) < 2e-5
+    # low resolution
+    for zoom in (0.8, 1.17):
+        small = tuple(int(round(n * zoom)) for n in (12, 20, 18))
+        y = ops.resize_linear(ops.interp_nearest(xd[:1], small), (12, 20, 18))
+        assert float((y[0].cpu() - ref.low_resolution(x[0], zoom)).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_augmenter_runs_the_whole_vocabulary(cuda):
+    g = torch.Generator().manual_seed(1)
+    batch = {"image": torch.rand((3, 1, 16, 24, 20), generator=g).to(cuda),
+             "mask": (torch.rand((3, 1, 16, 24, 20), generator=g) > 0.8).float().to(cuda)}
+    aug = DeviceAugmenter(["intensity", "noise", "rbf", "affine", "shear", "flip", "blur",
+                           "distort", "lowres"], ["image", "mask"], ["image"], t2_keys=["image"],
+                          seed=9)
+    seen = set()
+    for _ in range(12):
+        out = aug(batch)
+        assert out["image"].shape == batch["image"].shape and torch.isfinite(out["image"]).all()
+        assert set(out["mask"].unique().tolist()) <= {0.0, 1.0}      # labels stay labels
+        for it in aug.last_plan:
+            seen.update(k for k in it if k != "flips")
+    assert {"distort", "gamma", "gibbs_alpha", "rbf", "lowres", "affine"} <= seen
+    tri = DeviceAugmenter(["trivial", "blur", "noise", "lowres"], ["image"], ["image"], seed=2)
+    out = tri({"image": batch["image"]})
+    assert torch.isfinite(out["image"]).all()
