@@ -189,7 +189,7 @@ def test_blur_bias_distort_gibbs_lowres_match_restatement(cuda):
         assert torch.equal(y[1].cpu(), x[1])
     # Gibbs: a k-space low-pass on one item, the other keeps its whole spectrum
     alpha = 0.45
-    rad = torch.tensor([(1 - alpha) * 20 * np.sqrt(2) / 2, 40.0], device=cuda)
+    rad = torch.tensor([(1 - alpha) * 20 * np.sqrt(2) / 2, 40.0], dtype=torch.float32, device=cuda)
     y = ops.gibbs_lowpass(xd, rad)
     assert float((y[0].cpu() - ref.gibbs(x[0], alpha)).abs().max()) < 2e-5
     assert float((y[1].cpu() - x[1]).abs().max()) < 2e-5
