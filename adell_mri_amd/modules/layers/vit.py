@@ -44,7 +44,11 @@ class LinearEmbedding(torch.nn.Module):
         self.n_dims = len(self.image_size)
         self.windowed = window_size is not None
         if channel_to_token:
-            raise NotImplementedError("HIP LinearEmbedding: no channel tokens")
+            # every channel of a patch is its own token (vit.py:484-487, 566-571)
+            assert self.embed_method == "linear", \
+                "embed_method must be 'linear' if channel_to_token == True"
+            if window_size is not None:
+                raise NotImplementedError("HIP windowed LinearEmbedding: no channel tokens")
         if (use_class_token or n_registers > 0) and window_size is not None:
             raise NotImplementedError("HIP windowed LinearEmbedding: no class token / registers")
         if self.windowed:
@@ -59,8 +63,10 @@ class LinearEmbedding(torch.nn.Module):
                 raise NotImplementedError("HIP LinearEmbedding without windows covers the UNETR "
                                           "configuration only (linear embedding, channels first)")
             self.n_patches_split = [x // y for x, y in zip(self.image_size, self.patch_size)]
-        self.n_patches = int(np.prod(self.n_patches_split))
-        self.n_features = int(np.prod(self.patch_size) * self.in_channels)
+        extra_patches, extra_features = ((self.in_channels, 1) if self.channel_to_token
+                                         else (1, self.in_channels))
+        self.n_patches = int(np.prod(self.n_patches_split) * extra_patches)
+        self.n_features = int(np.prod(self.patch_size) * extra_features)
         if self.embed_method == "convolutional":
             # parameter container only: the patch convolution runs as gather + GEMM
             self.conv = torch.nn.Conv3d(self.in_channels, self.true_n_features, self.patch_size,
@@ -106,7 +112,12 @@ class LinearEmbedding(torch.nn.Module):
         X = X.reshape(shape)
         grid_axes = [2 + 2 * i for i in range(n)]
         patch_axes = [3 + 2 * i for i in range(n)]
-        X = X.permute(0, *grid_axes, *patch_axes, 1)
+        if self.channel_to_token:
+            # "b c (h x) (w y) (d z) -> b (h w c d) (x y z)": the reference's token order puts the
+            # channel index after w -- in front of d in three dimensions (vit.py:622-645)
+            X = X.permute(0, *grid_axes[:2], 1, *grid_axes[2:], *patch_axes)
+        else:
+            X = X.permute(0, *grid_axes, *patch_axes, 1)
         return X.reshape(b, self.n_patches, self.n_features)
 
     def rearrange(self, X):
@@ -147,6 +158,21 @@ class LinearEmbedding(torch.nn.Module):
         n = self.n_dims
         hs = self.n_patches_split
         ps = [p // s for p, s in zip(self.patch_size, scale)]
+        if self.channel_to_token:
+            # "b (h w c d) (x s1 y s2 z s3) -> b (c s1 s2 s3) (h x) (w y) (d z)"
+            shape = [b, *hs[:2], self.in_channels, *hs[2:]]
+            for p, sc in zip(ps, scale):
+                shape += [p, sc]
+            X = X.reshape(shape)
+            g_ax = [1, 2] + ([4] if n == 3 else [])      # grid axes h, w (, d)
+            c_ax = 3
+            first = 4 + (1 if n == 3 else 0)             # first (x, s1) pair
+            perm = [0, c_ax] + [first + 2 * i + 1 for i in range(n)]
+            for i in range(n):
+                perm += [g_ax[i], first + 2 * i]
+            X = X.permute(perm)
+            out_c = self.in_channels * int(np.prod(scale))
+            return X.reshape(b, out_c, *[h * p for h, p in zip(hs, ps)])
         shape = [b, *hs]
         for p, s in zip(ps, scale):
             shape += [p, s]

@@ -466,8 +466,25 @@ def gen_vit_tokens():
     out["y_erased"] = y2.detach().numpy()
     torch.manual_seed(5)
     out["erase_mask"] = (torch.rand([2, 9]) > 0.4).numpy()
+    # channel tokens (vit.py:484-487, 566-571, 622-645): every channel of a patch is a token
+    net3 = ViT(**VIT_TOKEN_KW, adn_fn=adn, channel_to_token=True).eval()
+    net3.load_state_dict(fill_state_dict(net3.state_dict()))
+    out["c2t_state_keys"] = np.array(list(net3.state_dict().keys()))
+    y3, _ = net3(x)
+    w3 = torch.from_numpy(np.asarray(
+        np.random.default_rng(4).uniform(-1, 1, size=tuple(y3.shape)), dtype=np.float32))
+    net3.zero_grad()
+    (y3 * w3).sum().backward()
+    out["c2t_y"], out["c2t_w"] = y3.detach().numpy(), w3.numpy()
+    keys3 = []
+    for k, p_ in net3.named_parameters():
+        if p_.grad is not None:
+            out["c2t_grad:" + k] = p_.grad.numpy()
+            keys3.append(k)
+    out["c2t_grad_keys"] = np.array(keys3)
     np.savez_compressed(os.path.join(OUT, "vit_tokens.npz"), **out)
-    print("vit_tokens ok", y.shape, float(y.abs().mean()), out["erase_mask"].mean())
+    print("vit_tokens ok", y.shape, float(y.abs().mean()), out["erase_mask"].mean(), "channel tokens",
+          tuple(y3.shape))
 
 
 SSL_CASE = dict(
@@ -566,7 +583,7 @@ FULL_CASES = {
 from oracle.fullsize import FULL_SEED, full_inputs, sample_positions, zlib_crc  # noqa: E402
 
 
-def gen_full(name, kw, shape, with_grads):
+def gen_full(name, kw, shape, with_grads, net=None):
     """Reference UNet.forward (unet.py:751-843) + dice/focal + backward at the benchmark's size,
     eval() (dropout off; instance norm is mode-independent). Stores statistics and sampled values
     only: logits mean/std/min/max + 64 sampled voxels + a 128-entry line, loss terms, and for
@@ -574,7 +591,7 @@ def gen_full(name, kw, shape, with_grads):
     import time
     torch.manual_seed(0)
     x, y = full_inputs(shape)
-    net = make_unet(kw).eval()
+    net = (make_unet(kw) if net is None else net).eval()
     out = {"seed": np.array(FULL_SEED), "shape": np.array(shape),
            "x_checksum": np.array([float(x.double().sum()), float(y.double().sum())])}
     t0 = time.time()
@@ -622,6 +639,99 @@ def gen_full(name, kw, shape, with_grads):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "params", sum(p.numel() for p in net.parameters()), "loss", float(loss),
           "logit stats", out["logit_stats"])
+
+
+# BASELINE configs 3 and 5 at their full sizes (round 4): the REAL reference classes built with the
+# keyword arguments the factory splats (as gen_surface does), name-keyed weights, the gen_full record.
+FULL_SEG_CASES = {
+    # name: (net_type, sample YAML, image size, image keys, input shape, gradients?, patch override)
+    "unetr_cfg3_full": ("unetr", "unetr.yaml", [96, 96, 96], 1, (1, 1, 96, 96, 96), True,
+                        [16, 16, 16]),
+    # forward only: the eager reference's backward at this size does not fit the build container
+    "swinunet_cfg5_full": ("swin", "unet-swin.yaml", [256, 256, 128], 2, (1, 2, 256, 256, 128),
+                           False, None),
+}
+
+
+def reference_seg_network(net_type, fname, size, n_keys, patch=None):
+    import yaml
+    classes = {"unet": UNet, "unetpp": UNetPlusPlus, "unetr": UNETR, "swin": SWINUNet}
+    with open(os.path.join(REF, "sample_configs", fname)) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["in_channels"] = n_keys * cfg.pop("n_channels")
+    cfg["activation_fn"] = activation_factory[cfg["activation_fn"]]
+    cfg.setdefault("spatial_dimensions", 3)
+    for k in ("learning_rate", "batch_size", "weight_decay", "loss_fn"):
+        cfg.pop(k)
+    model_kw = dict(n_classes=2, bottleneck_classification=False, skip_conditioning=0,
+                    feature_conditioning=0, feature_conditioning_params=None,
+                    deep_supervision=False)
+    cfg["image_size"] = size[:cfg["spatial_dimensions"]]
+    if net_type == "unetr":
+        cfg["patch_size"] = (patch or cfg["patch_size"])[:cfg["spatial_dimensions"]]
+    torch.manual_seed(0)
+    net = classes[net_type](**model_kw, **cfg)
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    return net
+
+
+def gen_full_seg(name):
+    net_type, fname, size, n_keys, shape, wg, patch = FULL_SEG_CASES[name]
+    gen_full(name, None, shape, wg, net=reference_seg_network(net_type, fname, size, n_keys, patch))
+
+
+def gen_full_convnext():
+    """BASELINE config 4 at full width: the reference ConvNeXt of configs/ssl-3d-convnext.yaml (= its
+    sample_configs/ssl-2d-convnext.yaml lifted to three dimensions) on four 64^3
+    crops per view: representation, both heads, the three VICReg terms and per parameter the
+    gradient norm / maximum / 16 sampled entries."""
+    import time
+    import yaml
+    with open(os.path.join(ROOT, "configs", "ssl-3d-convnext.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    adn3 = get_adn_fn(3, cfg["norm_fn"], cfg["act_fn"], 0.0)
+    adn1 = get_adn_fn(1, cfg["norm_fn"], cfg["act_fn"], 0.0)
+    bb = {k: v for k, v in cfg["backbone_args"].items() if k != "res_type"}
+    bb["adn_fn"] = adn3
+    kw = dict(backbone_args=bb,
+              projection_head_args=dict(cfg["projection_head_args"], adn_fn=adn1),
+              prediction_head_args=dict(cfg["prediction_head_args"], adn_fn=adn1))
+    torch.manual_seed(0)
+    net = ConvNeXt(**kw)
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    net.train()
+    zz, yy, xx = torch.meshgrid(*[torch.arange(64.0)] * 3, indexing="ij")
+    g = torch.Generator().manual_seed(FULL_SEED)
+    x1 = torch.stack([torch.sin((b + 1) * 0.21 * zz) * torch.cos((b + 2) * 0.13 * yy)
+                      + 0.02 * (b - 1.5) * xx for b in range(4)])[:, None]
+    x1 = x1 + 0.2 * torch.rand(x1.shape, generator=g)
+    x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=g)).flip(2)
+    out = {"x_checksum": np.array([float(x1.double().sum()), float(x2.double().sum())])}
+    t0 = time.time()
+    with torch.no_grad():
+        out["representation"] = net(x1, ret="representation").numpy()
+    y1 = net(x1, ret="prediction")
+    y2 = net(x2, ret="projection")
+    out["y1"], out["y2"] = y1.detach().numpy(), y2.detach().numpy()
+    losses = VICRegLoss()(y1, y2)
+    loss = sum(losses)
+    out["losses"] = torch.stack(losses).detach().numpy()
+    loss.backward()
+    print("convnext_cfg4_full fwd+bwd", round(time.time() - t0, 1), "s")
+    keys = []
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        gflat = p.grad.reshape(-1)
+        gp = sample_positions(gflat.numel(), 16, zlib_crc(k))
+        out["gnorm:" + k] = np.array([float(gflat.double().norm()), float(gflat.abs().max())])
+        out["gpos:" + k], out["gval:" + k] = gp, gflat[gp].numpy().copy()
+        keys.append(k)
+    out["grad_keys"] = np.array(keys)
+    out["param_keys"] = np.array([k for k, _ in net.named_parameters()])
+    np.savez_compressed(os.path.join(OUT, "convnext_cfg4_full.npz"), **out)
+    print("convnext_cfg4_full params", sum(p.numel() for p in net.parameters()), "losses",
+          out["losses"], "y1 std over batch", float(y1.detach().std(0).mean()))
 
 
 def gen_full_fp64(name, kw, shape):
@@ -969,6 +1079,15 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full64":
         gen_full_fp64("unet3d_cfg2_full", *FULL_CASES["unet3d_cfg2_full"][:2])
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullseg":
+        for name in FULL_SEG_CASES:
+            if len(sys.argv) > 2 and sys.argv[2] != name:
+                continue
+            gen_full_seg(name)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fullssl":
+        gen_full_convnext()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "full":
         for name, (kw, shape, wg) in FULL_CASES.items():

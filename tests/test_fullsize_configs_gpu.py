@@ -125,3 +125,130 @@ def test_config4_vicreg_convnext_full_size(cuda):
     xb = {"aug_image_1": torch.randn(6, 1, 16, 16, 16, device=cuda),
           "aug_image_2": torch.randn(6, 1, 16, 16, 16, device=cuda)}
     assert torch.isfinite(StepRunner(r).train_step(xb))
+
+
+# ---- round 4: VALUES at full size against the REAL reference ------------------------------------------
+# tests/golden/{unetr_cfg3_full, convnext_cfg4_full, swinunet_cfg5_full}.npz were written by
+# `python oracle/make_golden.py fullseg` / `fullssl` from the imported reference classes (name-keyed
+# weights, seeded inputs regenerated here): logit statistics, 64 sampled voxels, a line and the eight
+# corners, the loss terms, and for every parameter gradient its L2 norm, maximum and 16 sampled entries.
+import numpy as np  # noqa: E402
+
+from oracle.fullsize import full_inputs  # noqa: E402
+from oracle.weights import fill_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _check_logits(g, logits, tag, bar=1e-4):
+    lg = logits.detach().float().cpu()
+    stats = g["logit_stats"]
+    rng = float(stats[3] - stats[2])
+    flat = lg.reshape(-1)
+    got = [float(lg.double().mean()), float(lg.double().std()), float(lg.min()), float(lg.max()),
+           float(lg.double().abs().mean())]
+    err = {"sampled": float(np.abs(flat[g["logit_pos"]].numpy() - g["logit_val"]).max()) / rng,
+           "line": float(np.abs(lg[0, 0, lg.shape[2] // 2, lg.shape[3] // 2, :].numpy()
+                                - g["logit_line"]).max()) / rng,
+           "corners": float(np.abs(lg[0, 0][::lg.shape[2] - 1, ::lg.shape[3] - 1,
+                                            ::lg.shape[4] - 1].numpy() - g["logit_corners"]).max()) / rng,
+           "stats": float(np.abs(np.array(got) - stats).max()) / rng}
+    print(f"{tag}: full-size logits vs reference, error / logit range: {err}")
+    assert max(err.values()) < bar, err
+
+
+def _check_grads(g, net, tag, norm_bar=2e-3, entry_bar=3e-3):
+    top = max(float(g["gnorm:" + str(k)][1]) for k in g["grad_keys"])
+    worst = (0.0, "")
+    for k, p in net.named_parameters():
+        if ("gnorm:" + k) not in g.files:
+            continue
+        assert p.grad is not None, k
+        ref_norm, ref_max = (float(v) for v in g["gnorm:" + k])
+        scale = max(ref_max, 5e-4 * top)
+        if k.endswith(".bias") and ("gnorm:" + k[:-5] + ".weight") in g.files:
+            # (a bias in front of a norm has a mathematically zero gradient: rounding noise)
+            scale = max(scale, 1e-1 * float(g["gnorm:" + k[:-5] + ".weight"][1]))
+        got = p.grad.detach().reshape(-1)
+        e = float(np.abs(got[g["gpos:" + k]].cpu().numpy() - g["gval:" + k]).max()) / scale
+        worst = max(worst, (e, k))
+        assert e < entry_bar, (k, e)
+        n = float(got.double().norm())
+        assert abs(n - ref_norm) <= norm_bar * max(ref_norm, scale * np.sqrt(got.numel()) * 1e-2), \
+            (k, n, ref_norm)
+    print(f"{tag}: worst sampled gradient entry error / scale {worst}")
+
+
+def test_config3_unetr_values_match_reference(cuda):
+    g = np.load(os.path.join(GOLD, "unetr_cfg3_full.npz"))
+    shape = tuple(int(v) for v in g["shape"])
+    x, y = full_inputs(shape, int(g["seed"]))
+    assert abs(float(x.double().sum()) - g["x_checksum"][0]) < 1e-6 * g["x_checksum"][0]
+    net = _seg("unetr", "unetr.yaml", ["image"], [96, 96, 96], patch=[16, 16, 16])
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    net = net.to(cuda).eval()
+    logits = net(x.to(cuda), return_logits=True)[0]
+    _check_logits(g, logits, "cfg3 UNETR 96^3")
+    from oracle.torch_ref.unet import compound_loss
+    prob = net(x.to(cuda))[0]
+    loss = compound_loss(prob, y.to(cuda))
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4)
+    loss.backward()
+    _check_grads(g, net, "cfg3 UNETR 96^3")
+
+
+def test_config5_swinunet_forward_values_match_reference(cuda):
+    g = np.load(os.path.join(GOLD, "swinunet_cfg5_full.npz"))
+    shape = tuple(int(v) for v in g["shape"])
+    x, _ = full_inputs(shape, int(g["seed"]))
+    assert abs(float(x.double().sum()) - g["x_checksum"][0]) < 1e-6 * g["x_checksum"][0]
+    net = _seg("swin", "unet-swin.yaml", ["image", "image_1"], [256, 256, 128])
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    net = net.to(cuda).eval()
+    with torch.no_grad():
+        logits = net(x.to(cuda), return_logits=True)[0]
+    _check_logits(g, logits, "cfg5 SWIN-UNet 256x256x128")
+
+
+def test_config4_convnext_values_match_reference(cuda):
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.layers.conv_next import ConvNeXt
+    from adell_mri_amd.modules.self_supervised.losses.vicreg import VICRegLoss
+    import yaml
+
+    g = np.load(os.path.join(GOLD, "convnext_cfg4_full.npz"))
+    with open(os.path.join(CONFIGS, "ssl-3d-convnext.yaml")) as fh:
+        cfg = yaml.safe_load(fh)
+    adn3 = get_adn_fn(3, cfg["norm_fn"], cfg["act_fn"], 0.0)
+    adn1 = get_adn_fn(1, cfg["norm_fn"], cfg["act_fn"], 0.0)
+    bb = {k: v for k, v in cfg["backbone_args"].items() if k != "res_type"}
+    bb["adn_fn"] = adn3
+    net = ConvNeXt(backbone_args=bb,
+                   projection_head_args=dict(cfg["projection_head_args"], adn_fn=adn1),
+                   prediction_head_args=dict(cfg["prediction_head_args"], adn_fn=adn1))
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=3.0))
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    net = net.to(cuda).train()
+    zz, yy, xx = torch.meshgrid(*[torch.arange(64.0)] * 3, indexing="ij")
+    gen = torch.Generator().manual_seed(20260128)
+    x1 = torch.stack([torch.sin((b + 1) * 0.21 * zz) * torch.cos((b + 2) * 0.13 * yy)
+                      + 0.02 * (b - 1.5) * xx for b in range(4)])[:, None]
+    x1 = x1 + 0.2 * torch.rand(x1.shape, generator=gen)
+    x2 = (x1 + 0.3 * torch.randn(x1.shape, generator=gen)).flip(2)
+    assert abs(float(x1.double().sum()) - g["x_checksum"][0]) < 1e-6 * abs(g["x_checksum"][0])
+    x1, x2 = x1.to(cuda), x2.to(cuda)
+    with torch.no_grad():
+        rep = net(x1, ret="representation")
+    scale = float(np.abs(g["representation"]).max())
+    assert float(np.abs(rep.cpu().numpy() - g["representation"]).max()) < 1e-4 * scale
+    y1, y2 = net(x1, ret="prediction"), net(x2, ret="projection")
+    for got, key in ((y1, "y1"), (y2, "y2")):
+        s = float(np.abs(g[key]).max())
+        assert float(np.abs(got.detach().cpu().numpy() - g[key]).max()) < 2e-4 * s, key
+    losses = VICRegLoss()(y1, y2)
+    np.testing.assert_allclose(torch.stack(list(losses)).detach().cpu().numpy(), g["losses"],
+                               rtol=2e-3, atol=1e-6)
+    sum(losses).backward()
+    _check_grads(g, net, "cfg4 ConvNeXt 64^3", norm_bar=5e-3, entry_bar=5e-3)

@@ -88,3 +88,27 @@ def test_patch_erasing_draws_the_reference_mask(cuda):
     assert torch.equal(z != 0, keep[:, :, None].expand_as(z))
     assert torch.equal(z[keep], t[keep])
     assert op.eval()(t) is t
+
+
+def test_channel_tokens_parameter_tree_matches_the_reference():
+    g = np.load(GOLD)
+    net = _vit(channel_to_token=True)
+    assert list(net.state_dict().keys()) == list(g["c2t_state_keys"])
+    # 8 patches x 2 channels = 16 tokens of 8^3 features
+    assert net.embedding.n_patches == 16 and net.embedding.n_features == 512
+
+
+@pytest.mark.gpu
+def test_channel_tokens_forward_and_gradients(cuda):
+    """LinearEmbedding(channel_to_token=True) (vit.py:424-467, 566-571, 622-645): every channel of
+    a patch is a token, ordered (h w c d) as the reference's rearrangement orders them."""
+    g = np.load(GOLD)
+    net = _load(_vit(channel_to_token=True)).to(cuda).eval()
+    x = torch.from_numpy(g["x"]).to(cuda)
+    y, _ = net(x)
+    assert tuple(y.shape) == (2, 16, 32)
+    _close(y, g["c2t_y"], 1e-4, "y")
+    (y * torch.from_numpy(g["c2t_w"]).to(cuda)).sum().backward()
+    grads = dict(net.named_parameters())
+    for k in g["c2t_grad_keys"]:
+        _close(grads[str(k)].grad, g["c2t_grad:" + str(k)], 2e-3, str(k))
