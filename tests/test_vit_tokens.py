@@ -110,5 +110,9 @@ def test_channel_tokens_forward_and_gradients(cuda):
     _close(y, g["c2t_y"], 1e-4, "y")
     (y * torch.from_numpy(g["c2t_w"]).to(cuda)).sum().backward()
     grads = dict(net.named_parameters())
-    for k in g["c2t_grad_keys"]:
-        _close(grads[str(k)].grad, g["c2t_grad:" + str(k)], 2e-3, str(k))
+    keys = [str(k) for k in g["c2t_grad_keys"]]
+    scale = max(np.abs(g["c2t_grad:" + k]).max() for k in keys)
+    for k in keys:       # (a k-norm bias has a mathematically zero gradient: floor by the largest)
+        ref = g["c2t_grad:" + k]
+        err = np.abs(grads[k].grad.cpu().numpy() - ref).max()
+        assert err <= 2e-4 * max(np.abs(ref).max(), 1e-3 * scale), (k, err)
