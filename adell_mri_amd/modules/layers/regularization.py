@@ -19,8 +19,10 @@ class LayerNormChannelsFirst(torch.nn.Module):
         from ... import functional as HF
         from ... import ops
 
+        if x.dim() == 4:       # 2-D activation: a depth-1 volume
+            return self.forward(x.unsqueeze(2)).squeeze(2)
         if x.dim() != 5:
-            raise NotImplementedError("HIP LayerNormChannelsFirst: 5-D activations only")
+            raise NotImplementedError("HIP LayerNormChannelsFirst: 4-D / 5-D activations only")
         rows = ops.ndhwc(x).permute(0, 2, 3, 4, 1)            # [N, D, H, W, C], contiguous
         return HF.layer_norm(rows, self.weight, self.bias, self.eps).permute(0, 4, 1, 2, 3)
 

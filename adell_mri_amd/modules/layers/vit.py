@@ -53,11 +53,16 @@ class LinearEmbedding(torch.nn.Module):
             raise NotImplementedError("HIP windowed LinearEmbedding: no class token / registers")
         if self.windowed:
             # SWIN configuration (vit.py:553-571): tokens are the patches of one window
-            if not channels_last or self.n_dims != 3:
-                raise NotImplementedError("HIP windowed LinearEmbedding: 3-D, channels_last=True")
+            if not channels_last or self.n_dims not in (2, 3):
+                raise NotImplementedError("HIP windowed LinearEmbedding: channels_last=True")
             self.n_windows = [x // y for x, y in zip(self.image_size, self.window_size)]
             self.n_patches_split = [x // z // y for x, y, z in
                                     zip(self.image_size, self.patch_size, self.n_windows)]
+            # two dimensions run as depth-1 volumes [b, 1, H, W, c] on the same gather kernels: the
+            # einops patterns of vit.py:622-676 with a leading singleton factor per group
+            lift = [1] * (3 - self.n_dims)
+            self._win3 = (lift + self.n_windows, lift + self.n_patches_split,
+                          lift + self.patch_size, lift + self.image_size)
         else:
             if embed_method != "linear" or channels_last:
                 raise NotImplementedError("HIP LinearEmbedding without windows covers the UNETR "
@@ -69,8 +74,9 @@ class LinearEmbedding(torch.nn.Module):
         self.n_features = int(np.prod(self.patch_size) * extra_features)
         if self.embed_method == "convolutional":
             # parameter container only: the patch convolution runs as gather + GEMM
-            self.conv = torch.nn.Conv3d(self.in_channels, self.true_n_features, self.patch_size,
-                                        stride=self.patch_size)
+            conv_cls = torch.nn.Conv2d if self.n_dims == 2 else torch.nn.Conv3d
+            self.conv = conv_cls(self.in_channels, self.true_n_features, self.patch_size,
+                                 stride=self.patch_size)
         self.map_to_out = torch.nn.Identity()
         self.map_to_in = torch.nn.Identity()
         if self.out_dim is not None and self.out_dim != self.n_features:
@@ -129,10 +135,11 @@ class LinearEmbedding(torch.nn.Module):
         """Embedding of torch.roll(X, -shift) for X [b, *image_size, c]: window partition
         (one gather), then LayerNorm + Linear ("linear") or the patch convolution as a GEMM
         over (x y z c) features ("convolutional"), + positional embedding, dropout."""
-        tokens = HF.window_partition(X, self.n_windows, self.n_patches_split, self.patch_size,
-                                     shift)
+        nwin, ppw, patch, _ = self._win3
+        tokens = HF.window_partition(X, nwin, ppw, patch, shift)
         if self.embed_method == "convolutional":
-            w = self.conv.weight.permute(0, 2, 3, 4, 1).reshape(self.true_n_features, -1)
+            perm = (0, 2, 3, 1) if self.n_dims == 2 else (0, 2, 3, 4, 1)
+            w = self.conv.weight.permute(*perm).reshape(self.true_n_features, -1)
             tokens = HF.linear(tokens, w, self.conv.bias)
         else:
             tokens = self.map_to_out(tokens)
@@ -146,9 +153,9 @@ class LinearEmbedding(torch.nn.Module):
         """rearrange_inverse / rearrange_inverse_basic of the windowed embedding
         (vit.py:777-811): map_to_in, then tokens back to [b, *image_size, c]."""
         tokens = self.map_to_in(tokens)
-        shape = (tokens.shape[0], *self.image_size, self.in_channels)
-        return HF.window_merge(tokens, shape, self.n_windows, self.n_patches_split,
-                               self.patch_size)
+        nwin, ppw, patch, image = self._win3
+        shape = (tokens.shape[0], *image, self.in_channels)
+        return HF.window_merge(tokens, shape, nwin, ppw, patch)
 
     def _from_tokens(self, X, scale):
         """inverse rearrangement with the per-axis factor ``scale`` moved from the patch
@@ -402,11 +409,14 @@ def move_axis(X: torch.Tensor, axis1: int, axis2: int) -> torch.Tensor:
 
 
 def einops_rescale(X: torch.Tensor, scale) -> torch.Tensor:
-    """'b c (h p1) (w p2) (d p3) -> b (c p1 p2 p3) h w d' (vit.py:33-45) as one gather."""
+    """'b c (h p1) (w p2) (d p3) -> b (c p1 p2 p3) h w d' (vit.py:33-45) as one gather; a 4-D input
+    ('b c (h p1) (w p2) -> b (c p1 p2) h w') runs as a depth-1 volume."""
     if isinstance(scale, int):
         scale = [scale] * (X.dim() - 2)
     if all(int(s) == 1 for s in scale):
         return X
+    if X.dim() == 4:
+        return HF.space_to_depth(X.unsqueeze(2), [1] + [int(s) for s in scale]).squeeze(2)
     return HF.space_to_depth(X, [int(s) for s in scale])
 
 
@@ -526,6 +536,9 @@ class SWINTransformerBlock(torch.nn.Module):
     def forward(self, X: torch.Tensor, scale=None) -> torch.Tensor:
         from ... import ops
 
+        two_d = X.dim() == 4
+        if two_d:                                      # [b, c, H, W] as the volume [b, c, 1, H, W]
+            X = X.unsqueeze(2)
         X = ops.ndhwc(X).permute(0, 2, 3, 4, 1)        # move_axis(X, 1, -1): a view of NDHWC
         shortcut = X
         if scale is not None and isinstance(scale, int):
@@ -533,8 +546,11 @@ class SWINTransformerBlock(torch.nn.Module):
         ss = self.shift_size
         if isinstance(ss, int):
             ss = [ss] * len(self.patch_size)
-        # torch.roll(X, [-s...], dims=[2, 3, 4]) on [b, X, Y, Z, c]
-        embedded = self.embedding.window_tokens(X, (0, ss[0], ss[1], ss[2]))
+        # torch.roll(X, [-s...], dims=[2, 3, ...]) on the channels-last tensor (vit.py:1151-1163: the
+        # dims start at 2): Y, Z and the channel axis of [b, X, Y, Z, c]; W and the channel axis of
+        # [b, H, W, c] -- in the lifted frame [b, 1, H, W, c] that is (0, 0, s0, s1)
+        shift = (0, 0, ss[0], ss[1]) if two_d else (0, ss[0], ss[1], ss[2])
+        embedded = self.embedding.window_tokens(X, shift)
         attention = self.mha(self.norm_op_1(embedded), mask=self._mask(X.device))
         shifted = self.embedding.window_image(attention)
         drop = self.training and self.dropout_rate > 0
@@ -544,6 +560,8 @@ class SWINTransformerBlock(torch.nn.Module):
         else:
             X = self.mlp(self.norm_op_2(X), residual=X)
         X = X.permute(0, 4, 1, 2, 3)                      # move_axis(X, -1, 1)
+        if two_d:
+            X = X.squeeze(2)
         if scale is not None:
             X = einops_rescale(X, scale)
         return X

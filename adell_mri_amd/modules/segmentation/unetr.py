@@ -185,8 +185,8 @@ class SWINUNet(UNet, torch.nn.Module):
         _keep_arguments(self, arguments)
         self.encoder_only = False
         self.number_of_blocks = len(self.depth)
-        if self.spatial_dimensions != 3:
-            raise NotImplementedError("HIP SWINUNet is 3-D (the BASELINE configuration)")
+        if self.spatial_dimensions not in (2, 3):
+            raise NotImplementedError("SWINUNet: 2 or 3 spatial dimensions")
         self.arg_compliance()
         self.get_norm_op()
         self.get_drop_op()
@@ -306,6 +306,9 @@ class SWINUNet(UNet, torch.nn.Module):
         for mod in mods[1:-1]:
             head = mod(head)
         if return_logits is not True:
-            head = (HF.norm_drop_act(head, act="sigmoid")
-                    if isinstance(mods[-1], torch.nn.Sigmoid) else mods[-1](head))
+            if isinstance(mods[-1], torch.nn.Sigmoid):
+                head = (HF.norm_drop_act(head.unsqueeze(2), act="sigmoid").squeeze(2)
+                        if head.dim() == 4 else HF.norm_drop_act(head, act="sigmoid"))
+            else:
+                head = mods[-1](head)
         return self._outputs(head, curr, bottleneck, deep_outputs, return_features)

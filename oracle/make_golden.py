@@ -210,6 +210,17 @@ SWIN_CASES = {
                               n_classes=2, depth=[8, 16, 32], kernel_sizes=[3, 3, 3],
                               strides=[[2, 2, 1], 2, 2], _cls="swin"),
                          (2, 2, 32, 32, 16), "uniform"),
+    # the 2-D SWIN-UNet the reference's own tests build (testing/test_swin_unet.py:15, 43-161):
+    # linear embedding, 8 x 8 windows of 4 x 4 patches, anisotropic first stride
+    "swinunet2d_small": (dict(image_size=[32, 64], patch_size=[4, 4], window_size=[8, 8],
+                              shift_sizes=[[0, 1], [0, 1], [0, 1]], embedding_size=[16, 32, 64],
+                              n_heads=4, dropout_rate=0.0, embed_method="linear",
+                              mlp_structure=4.0, spatial_dimensions=2, conv_type="regular",
+                              link_type="conv", upscale_type="transpose", norm_type="instance",
+                              padding="same", dropout_param=0.0, activation_fn="leaky_relu",
+                              in_channels=2, n_classes=2, depth=[8, 16, 32],
+                              kernel_sizes=[3, 3, 3], strides=[[2, 1], 2, 2], _cls="swin"),
+                         (2, 2, 32, 64), "uniform"),
 }
 
 
@@ -1115,6 +1126,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         for name, (kw, shape, dist) in SWIN_CASES.items():
+            if len(sys.argv) > 2 and sys.argv[2] != name:
+                continue
             gen_unet(name, kw, shape, dist)
         sys.exit(0)
     for name, (kw, shape, dist) in {**UNET_CASES, **UNET2D_CASES, **UNETR_CASES, **UNETPP_CASES,

@@ -78,6 +78,14 @@ SWIN_CASES = {
                              padding="same", dropout_param=0.0, activation_fn="leaky_relu",
                              in_channels=2, n_classes=2, depth=[8, 16, 32],
                              kernel_sizes=[3, 3, 3], strides=[[2, 2, 1], 2, 2]),
+    "swinunet2d_small": dict(image_size=[32, 64], patch_size=[4, 4], window_size=[8, 8],
+                             shift_sizes=[[0, 1], [0, 1], [0, 1]], embedding_size=[16, 32, 64],
+                             n_heads=4, dropout_rate=0.0, embed_method="linear",
+                             mlp_structure=4.0, spatial_dimensions=2, conv_type="regular",
+                             link_type="conv", upscale_type="transpose", norm_type="instance",
+                             padding="same", dropout_param=0.0, activation_fn="leaky_relu",
+                             in_channels=2, n_classes=2, depth=[8, 16, 32],
+                             kernel_sizes=[3, 3, 3], strides=[[2, 1], 2, 2]),
 }
 
 

@@ -18,8 +18,8 @@ from oracle.weights import fill_state_dict
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def build(**over):
-    kw = copy.deepcopy(SWIN_CASES["swinunet3d_small"])
+def build(name="swinunet3d_small", **over):
+    kw = copy.deepcopy(SWIN_CASES[name])
     kw.update(over)
     kw["activation_fn"] = activation_factory[kw["activation_fn"]]
     net = SWINUNet(**kw)
@@ -120,3 +120,45 @@ def test_swinunet_training_mode_with_dropout_runs_and_learns(cuda):
         opt.step()
         losses.append(loss.item())
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+# ---- two dimensions (unetr.py:635-1033 with spatial_dimensions=2; the reference's own tests build it:
+# testing/test_swin_unet.py:15, 43-161): depth-1 volumes on the same kernels --------------------------
+def test_swinunet2d_state_dict_keys_and_shapes_equal_reference():
+    g = np.load(os.path.join(GOLD, "swinunet2d_small.npz"))
+    net = build("swinunet2d_small")
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    shapes = {str(k): tuple(int(i) for i in str(s).split(",")) for k, s in
+              zip(g["param_keys"], g["param_shapes"])}
+    for k, p in net.named_parameters():
+        assert tuple(p.shape) == shapes[k], k
+    m = generate_mask([8, 16], [2, 2], 1)
+    assert m.shape == (4 * 8, 4, 4) and set(np.unique(m.numpy())) <= {-100.0, 0.0}
+
+
+@pytest.mark.gpu
+def test_swinunet2d_logits_and_gradients_match_reference(cuda):
+    g = np.load(os.path.join(GOLD, "swinunet2d_small.npz"))
+    net = build("swinunet2d_small").to(cuda).eval()
+    x = torch.from_numpy(g["x"]).to(cuda)
+    with torch.no_grad():
+        logits, _ = net(x, return_logits=True)
+    ref = g["logits"]
+    assert logits.shape == ref.shape
+    err = np.abs(logits.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < 1e-4, err
+    prob, _ = net(x)
+    loss = compound_loss(prob, torch.from_numpy(g["y"]).to(cuda))
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    for k, p in net.named_parameters():
+        if ("grad:" + k) not in g.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref32, ref64 = g["grad:" + k], g["grad64:" + k]
+        scale = np.abs(ref64).max()
+        if k.endswith(".bias") and ("grad64:" + k[:-5] + ".weight") in g.files:
+            scale = max(scale, 1e-1 * np.abs(g["grad64:" + k[:-5] + ".weight"]).max())
+        noise = np.abs(ref32 - ref64).max() / (scale + 1e-12)
+        err = np.abs(p.grad.cpu().numpy() - ref64).max() / (scale + 1e-12)
+        assert err < max(3e-3, 2 * noise), (k, err, noise)
