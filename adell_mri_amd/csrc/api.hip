@@ -37,6 +37,7 @@ static AdellTuning adell_tuning_from_env() {
   t.igemm_ws = adell_env_set("ADELL_IGEMM_WS");
   t.attn_nomfma = adell_env_set("ADELL_ATTN_NOMFMA");
   t.ws_min_items = adell_env_int("ADELL_WS_MIN_ITEMS", 1024);
+  t.igemm_ws_rows = adell_env_int("ADELL_IGEMM_WS_ROWS", 0);
   t.igemm_wide8 = adell_env_int("ADELL_IGEMM_WIDE8", 0);
   t.ew_reverse = adell_env_int("ADELL_EW_REVERSE", 0);
   t.fold_coarse = adell_env_int("ADELL_FOLD_COARSE", 0);
@@ -66,6 +67,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "igemm_ws")) return &g_adell_tune.igemm_ws;
   if (!strcmp(name, "attn_nomfma")) return &g_adell_tune.attn_nomfma;
   if (!strcmp(name, "ws_min_items")) return &g_adell_tune.ws_min_items;
+  if (!strcmp(name, "igemm_ws_rows")) return &g_adell_tune.igemm_ws_rows;
   if (!strcmp(name, "igemm_wide8")) return &g_adell_tune.igemm_wide8;
   if (!strcmp(name, "ew_reverse")) return &g_adell_tune.ew_reverse;
   if (!strcmp(name, "fold_coarse")) return &g_adell_tune.fold_coarse;

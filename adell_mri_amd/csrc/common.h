@@ -26,6 +26,7 @@ struct AdellTuning {
   int igemm_no2wave;              // strided / k == stride layers: not the two-wave 64-voxel instance
   int attn_nomfma;                // attention: vector-ALU kernels even for MFMA-eligible head dims
   int igemm_ws, ws_min_items;   // persistent wave-specialised conv instance: opt-in / size gate
+  int igemm_ws_rows;              // ... its DMA-only-loader form for launches whose sources are split rows
   int igemm_wide8;                // 64-column tile of the large 3^3 layers on 8x8x8 bricks, 8 waves
   int ew_reverse;                 // norm / activation forward: reverse of the producer's write order
   int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)

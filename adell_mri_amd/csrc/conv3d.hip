@@ -383,18 +383,36 @@ static int adell_cu_count() {
   return cus;
 }
 
-template <int MT, int NT, int BZ>
-static int adell_launch_conv_ws(const ConvArgs& a, const ConvF16Extra& e, int items, int nct,
+// 256 zero bytes in device memory (the rows instance of the wave-specialised kernel reads them for
+// halo rows outside the tensor); allocated once per process, never freed
+static const char* adell_zero_page() {
+  static char* page = nullptr;
+  if (page == nullptr) {
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
+    page = p;
+  }
+  return page;
+}
+
+template <int MT, int NT, int BZ, int ROWS = 0>
+static int adell_launch_conv_ws(const ConvArgs& a, ConvF16Extra e, int items, int nct,
                                 hipStream_t st) {
   static bool attr_done = false;
-  auto kern = adell_conv_igemm_ws_kernel<MT, NT, BZ>;
+  auto kern = adell_conv_igemm_ws_kernel<MT, NT, BZ, ROWS>;
   if (!attr_done) {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
   constexpr int BN = NT * 32, HV = 100 * (BZ + 2), GT = BZ == 8 ? 7 : 9;
-  const size_t lds = (size_t)2 * HV * 64 + (size_t)2 * GT * BN * 64 + 16 + 8 + (size_t)4 * BN * 2 * 4;
+  constexpr size_t A_BYTES = ROWS ? (size_t)((HV + 15) / 16) * 1024 : (size_t)HV * 64;
+  if (ROWS) {
+    e.zeros = adell_zero_page();
+    ADELL_REQUIRE(e.zeros != nullptr, "conv f16x3 (wave-specialised rows): no zero page");
+  }
+  const size_t lds = 2 * A_BYTES + (size_t)2 * GT * BN * 64 + 16 + 8 + (size_t)4 * BN * 2 * 4;
   int blocks = adell_cu_count() & ~7;   // one block per CU, dealt to the 8 XCDs in equal shares
   if (blocks < 8) blocks = 8;
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, e, items, nct);
@@ -718,6 +736,14 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
     // split-row sources (rows_ok above): the instance without the fp32 staging path when every
     // source is rows, else the one that decides per source
     const bool all_rows = e.xs0 != nullptr && (a.C1 == 0 || e.xs1 != nullptr);
+    // ("igemm_ws_rows": the persistent wave-specialised instance with DMA-only loaders)
+    if (all_rows && g_adell_tune.igemm_ws_rows && (t.cfg == 0 || t.cfg == 4)) {
+      const int nct = adell_cdiv(a.Cout, t.BN);
+      const long items = (long)N * nsp * nct;
+      if (items >= g_adell_tune.ws_min_items && items < 0x7fffffffL)
+        return t.cfg == 0 ? adell_launch_conv_ws<2, 2, 4, 1>(a, e, (int)items, nct, st)
+                          : adell_launch_conv_ws<4, 1, 8, 1>(a, e, (int)items, nct, st);
+    }
     switch (t.cfg) {
       case 0:
         return all_rows ? adell_launch_conv_f16<2, 2, 4, 1, 1, 0, 2>(a, e, grid, lds, st)

@@ -45,7 +45,14 @@ struct ConvWsItem {
   int nb, ncol, tile, ox0, oy0, oz0;
 };
 
-template <int MT, int NT, int BZ>
+// ROWS = 1 (round 4): every source holds SPLIT ROWS (ConvF16Extra::xs0 / xs1: the 64-byte hi | lo rows
+// of this very LDS image, written by the producer, adell_norm_act_fwd_split). The loaders then
+// have no arithmetic at all: the halo of the next chunk arrives by LDS-DMA like the weights -- a
+// wave-instruction fills 16 rows, the slot permutation and the zero padding ride on each lane's
+// SOURCE address (rows outside the tensor read e.zeros) -- no halo registers, no absmax, no split, no
+// ds_write. (Round 2 measured the register-staged halo path of the loaders as what costs this design
+// its lead: compute waves alone 453-470 TF, with that path 345 TF.)
+template <int MT, int NT, int BZ, int ROWS = 0>
 __global__ __launch_bounds__(512, 2)
 void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct) {
   constexpr int BN = NT * 32, CC = 16;
@@ -54,8 +61,12 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
   constexpr int NGRP = (27 + GT - 1) / GT;            // stages per chunk (3 or 4)
   constexpr int LTZ = BZ == 8 ? 3 : 2;
   constexpr int NLD = 256;                            // loader threads
-  constexpr int KEEP = (HV + NLD - 1) / NLD;          // halo voxels per loader thread
-  constexpr size_t A_BYTES = (size_t)HV * 64, B_BYTES = (size_t)GT * BN * 64;
+  constexpr int KEEP = ROWS ? 1 : (HV + NLD - 1) / NLD;   // halo voxels per loader thread (fp32 path)
+  // (ROWS: the halo image is padded to whole 1 KB DMA pieces; the pad rows read the zero page)
+  constexpr int HPIECES = (HV + 15) / 16;             // 16-row pieces of a halo image
+  constexpr int HP = (HPIECES + 3) / 4;               // ... per loader wave
+  constexpr size_t A_BYTES = ROWS ? (size_t)HPIECES * 1024 : (size_t)HV * 64,
+                   B_BYTES = (size_t)GT * BN * 64;
   static_assert(NGRP >= 3, "the halo of the next chunk is staged over three stages");
 
   extern __shared__ float smem[];
@@ -100,6 +111,144 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
   if (wave >= 4) {
     // =============================== loader waves ==============================================
     const int t = tid - 256;
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef const __attribute__((address_space(1))) char glb_char;
+    if constexpr (ROWS != 0) {
+      // ============================ loaders, split-row sources: DMA only ==========================
+      constexpr int PIECES = (GT * BN / 16 + 3) / 4;      // weight pieces per loader wave
+      const int lw = wave - 4;
+      // per piece of this wave: byte offset of this lane's 16 bytes inside the batch item's chunk-0
+      // rows (voxel * C * 4 + slot * 16; the chunk adds 64 per chunk), or -1: zero page
+      int voff[HP];
+      auto set_item = [&](const ConvWsItem& it) {
+        const int lx0 = it.ox0 - a.PW, ly0 = it.oy0 - a.PH, lz0 = it.oz0 - a.PD;
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+          const int hv = (lw + 4 * j) * 16 + (lane >> 2);
+          int off = -1;
+          if (hv < HV) {
+            const int hz = hv / (HX * HY), rem = hv - hz * (HX * HY);
+            const int hy = rem / HX, hx = rem - hy * HX;
+            const int rx = lx0 + hx, ry = ly0 + hy, rz = lz0 + hz;
+            if ((rx >= 0) & (ry >= 0) & (rz >= 0) & (rx < a.W) & (ry < a.H) & (rz < a.D)) {
+              // physical slot lane & 3 of the row holds logical piece slot ^ sw (conv_igemm_f16.h)
+              const int sw = (hx >> 1) & 3;
+              off = ((rz * a.H + ry) * a.W + rx);          // voxel index: scaled by the source below
+              off = off * 4 + ((lane & 3) ^ sw);           // (voxel, logical piece)
+            }
+          }
+          voff[j] = off;
+        }
+      };
+      // halo pieces [j0, j1) of this wave for chunk ch of item `it` -> halo buffer `buf`
+      auto dma_halo = [&](const ConvWsItem& it, int ch, int buf, int j0, int j1) {
+        const int c0 = ch * CC;
+        const bool firstsrc = c0 < a.C0;
+        const size_t vox0 = (size_t)it.nb * a.D * a.H * a.W;
+        const unsigned cs = firstsrc ? a.C0 : a.C1;       // channels of the source: cs * 4 bytes per voxel
+        const char* src = firstsrc ? e.xs0 + vox0 * a.C0 * 4 + (size_t)c0 * 4
+                                   : e.xs1 + vox0 * a.C1 * 4 + (size_t)(c0 - a.C0) * 4;
+        const ADELL_GLOBAL char* base = adell_uniform_ptr(src);
+        const ADELL_GLOBAL char* zero = adell_uniform_ptr(e.zeros);
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+          if (j < j0 || j >= j1) continue;
+          const int piece = lw + 4 * j;
+          if (piece < HPIECES) {    // wave-uniform
+            const int o = voff[j];
+            const ADELL_GLOBAL char* p =
+                o >= 0 ? base + ((unsigned)(o >> 2) * cs * 4u + (unsigned)(o & 3) * 16u)
+                       : zero + (lane & 3) * 16;
+            const unsigned off = __builtin_amdgcn_readfirstlane(
+                (unsigned)(buf * A_BYTES + piece * 1024));
+            __builtin_amdgcn_global_load_lds((glb_char*)p, (lds_char*)smem + off, 16, 0, 0);
+          }
+        }
+      };
+      auto dma_weights = [&](int ch, int grp, int ncol, int buf) {
+        const int n0 = ncol * BN;
+        const int tpg = (27 - grp * GT) < GT ? (27 - grp * GT) : GT;
+        const int rows = tpg * BN;
+        const char* wbase = reinterpret_cast<const char*>(e.wh) +
+                            ((size_t)(grp * GT) * a.Cout * nchunk + ch) * 64;
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) {
+          const int piece = k * 4 + lw;
+          if (piece * 16 < rows) {   // wave-uniform
+            const int row = piece * 16 + (lane >> 2);
+            const int tl = row / BN, n = row % BN;
+            int col = n0 + n;
+            if (col >= a.Cout) col = a.Cout - 1;
+            const int lslot = (lane & 3) ^ ((n >> 2) & 3);
+            const char* src = wbase + ((size_t)tl * a.Cout + col) * nchunk * 64 + lslot * 16;
+            const unsigned off = __builtin_amdgcn_readfirstlane(
+                (unsigned)(2 * A_BYTES + buf * B_BYTES + piece * 1024));
+            __builtin_amdgcn_global_load_lds((glb_char*)src, (lds_char*)smem + off, 16, 0, 0);
+          }
+        }
+      };
+      auto chunk_exp = [&](const ConvWsItem& it, int ch) -> int {
+        const int c0 = ch * CC;
+        return c0 < a.C0 ? e.xk0[it.nb * (a.C0 >> 4) + (c0 >> 4)]
+                         : e.xk1[it.nb * (a.C1 >> 4) + ((c0 - a.C0) >> 4)];
+      };
+      auto flush_stats = [&](const ConvWsItem& it) {
+        if (a.part == nullptr || t >= BN) return;
+        const int n = it.ncol * BN + t;
+        if (n >= a.Cout) return;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          t1 += sRed[(w * BN + t) * 2 + 0];
+          t2 += sRed[(w * BN + t) * 2 + 1];
+        }
+        float* p = a.part + (((size_t)it.nb * nsp + it.tile) * a.Cout + n) * 2;
+        p[0] = t1;
+        p[1] = t2;
+      };
+      ConvWsItem cur = item_at(first);
+      set_item(cur);
+      dma_halo(cur, 0, 0, 0, HP);
+      dma_weights(0, 0, cur.ncol, 0);
+      if (t == 0) sK[0] = chunk_exp(cur, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      adell_ws_barrier();                       // P1
+      adell_ws_barrier();                       // P2
+      int stage = 0, cidx = 0;
+      for (int i = 0; i < count; ++i) {
+        const bool has_next_item = i + 1 < count;
+        ConvWsItem nxt = cur;
+        if (has_next_item) nxt = item_at(first + i + 1);
+        for (int ch = 0; ch < nchunk; ++ch, ++cidx) {
+          const bool last_chunk = ch + 1 == nchunk;
+          const bool stage_next = !last_chunk || has_next_item;
+#pragma unroll
+          for (int g = 0; g < NGRP; ++g, ++stage) {
+            if (g == 0 && ch == 0 && i > 0) flush_stats(item_at(first + i - 1));
+            // weights of stage s + 1 (buffer released by the barrier that ended stage s - 1)
+            if (g + 1 < NGRP)
+              dma_weights(ch, g + 1, cur.ncol, (stage + 1) & 1);
+            else if (!last_chunk)
+              dma_weights(ch + 1, 0, cur.ncol, (stage + 1) & 1);
+            else if (has_next_item)
+              dma_weights(0, 0, nxt.ncol, (stage + 1) & 1);
+            // a share of the next chunk's halo (its buffer is idle for the whole of this chunk)
+            if (stage_next) {
+              if (g == 0 && last_chunk) set_item(nxt);
+              const int j0 = (HP * g) / NGRP, j1 = (HP * (g + 1)) / NGRP;
+              dma_halo(last_chunk ? nxt : cur, last_chunk ? 0 : ch + 1, (cidx + 1) & 1, j0, j1);
+              if (g == 0 && t == 0)
+                sK[(cidx + 1) & 1] = chunk_exp(last_chunk ? nxt : cur, last_chunk ? 0 : ch + 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            adell_ws_barrier();
+          }
+        }
+        cur = nxt;
+      }
+      flush_stats(item_at(first + count - 1));
+      return;
+    }
     float keep[KEEP][CC];
     int gvk[KEEP];
 
@@ -189,8 +338,6 @@ void adell_conv_igemm_ws_kernel(ConvArgs a, ConvF16Extra e, int n_items, int nct
     // the hi | lo halves the LDS image wants. One wave-instruction fills 1 KB = 16 rows of 64 B in
     // lane order, so the per-row slot permutation is applied to each lane's SOURCE address.
     // Columns past Cout (ragged last tile) read a clamped column: their outputs are never stored.
-    typedef __attribute__((address_space(3))) char lds_char;
-    typedef const __attribute__((address_space(1))) char glb_char;
     constexpr int PIECES = (GT * BN / 16 + 3) / 4;      // 1 KB pieces per loader wave
     auto dma_weights = [&](int ch, int grp, int ncol, int buf) {
       const int n0 = ncol * BN;
