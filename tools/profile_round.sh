@@ -31,6 +31,19 @@ python3 tools/trace_stats.py $O/stats2 > $O/kernel_stats_two_streams.txt 2>&1 ||
 python3 tools/pmc_traffic.py $O/pmcF $O/pmcW $O/pmc_traffic.json $O/bench_line.json > /dev/null 2>&1 || true
 python3 tools/pmc_mfma.py $O/pmcM > $O/pmc_mfma_utilisation.txt 2>&1 || true
 python3 bench.py > $O/bench_plain.json 2> $O/bench_plain.err
+# the driver's exact command as well (20 timed steps)
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+# BASELINE configs 3 / 4 / 5: kernel summaries of their own step (one stream), program directly after `--`
+cd /tmp
+export ADELL_WGRAD_STREAM=0
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/unetr -- python3 $R/tools/bench_unetr.py --steps 6 --warmup 2 > $O/unetr_line.json 2> $O/unetr.err || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ssl -- python3 $R/tools/bench_ssl.py --batch 32 --steps 6 --warmup 2 > $O/ssl_line.json 2> $O/ssl.err || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/swin -- python3 $R/tools/bench_swin.py --steps 4 --warmup 2 > $O/swin_line.json 2> $O/swin.err || true
+unset ADELL_WGRAD_STREAM
+cd $R
+python3 tools/trace_stats.py $O/unetr > $O/unetr_kernel_stats.txt 2>&1 || true
+python3 tools/trace_stats.py $O/ssl > $O/ssl_convnext_kernel_stats.txt 2>&1 || true
+python3 tools/trace_stats.py $O/swin > $O/swinunet_kernel_stats.txt 2>&1 || true
 # keep the merge small: the raw traces stay on the box
 find $O -name "*.csv" -size +3M -delete
 ls $O; du -sh $O
