@@ -104,3 +104,66 @@ class ConcurrentSqueezeAndExcite2d(_ConcurrentSqueezeAndExcite):
 class ConcurrentSqueezeAndExcite3d(_ConcurrentSqueezeAndExcite):
     """self_attention.py:127-149."""
     _spatial = SpatialSqueezeAndExcite3d
+
+
+
+class SelfAttentionBlock(torch.nn.Module):
+    """Self-attention over the patches of an image / volume (self_attention.py:152-239; the U-Net's
+    ``link_type="attention"`` skip links, unet.py:473-481): patches of ``patch_size`` become tokens
+    of (x y z c) features -- "n c (h x) (w y) (d z) -> n (h w d) (x y z c)" -- one
+    MultiHeadSelfAttention (QK-norm, 4 heads) maps them back to the same width, and the inverse
+    rearrangement restores the tensor. Same sub-module tree / ``state_dict`` keys
+    (``attention_op.qkv.weight``, ...). The rearrangements are index permutations (a view plus one
+    copy); the arithmetic is the MHSA kernels."""
+
+    def __init__(self, ndim: int, input_dim: int, attention_dim: int, patch_size=(16, 16, 8)):
+        super().__init__()
+        import numpy as np
+
+        from .linear_blocks import MultiHeadSelfAttention
+
+        self.ndim = ndim
+        self.input_dim = input_dim
+        self.attention_dim = attention_dim
+        self.patch_size = patch_size
+        self.input_dim_att = int(np.prod(patch_size[:ndim]) * input_dim)
+        self.attention_op = MultiHeadSelfAttention(
+            input_dim=self.input_dim_att, attention_dim=attention_dim, hidden_dim=attention_dim,
+            output_dim=self.input_dim_att)
+
+    def _grid(self, shape):
+        ps = list(self.patch_size[:self.ndim])
+        for n, p in zip(shape[2:], ps):
+            if n % p:
+                raise ValueError(f"SelfAttentionBlock: size {tuple(shape[2:])} is not a multiple "
+                                 f"of the patch size {tuple(ps)}")
+        return [n // p for n, p in zip(shape[2:], ps)], ps
+
+    def embed(self, X: torch.Tensor) -> torch.Tensor:
+        n, c = X.shape[:2]
+        hs, ps = self._grid(X.shape)
+        shape = [n, c]
+        for h, p in zip(hs, ps):
+            shape += [h, p]
+        nd = self.ndim
+        grid_axes = [2 + 2 * i for i in range(nd)]
+        patch_axes = [3 + 2 * i for i in range(nd)]
+        tokens = X.reshape(shape).permute(0, *grid_axes, *patch_axes, 1)
+        t = 1
+        for h in hs:
+            t *= h
+        return tokens.reshape(n, t, self.input_dim_att)
+
+    def unembed(self, X: torch.Tensor, sh) -> torch.Tensor:
+        n, c = sh[:2]
+        hs, ps = self._grid(sh)
+        nd = self.ndim
+        X = X.reshape([n, *hs, *ps, c])
+        # axes: 0 n | 1..nd grid | nd+1..2nd patch | last c  ->  n c (h x) (w y) (d z)
+        perm = [0, 1 + 2 * nd]
+        for i in range(nd):
+            perm += [1 + i, 1 + nd + i]
+        return X.permute(perm).reshape(sh)
+
+    def forward(self, X: torch.Tensor) -> torch.Tensor:
+        return self.unembed(self.attention_op(self.embed(X)), tuple(X.shape))

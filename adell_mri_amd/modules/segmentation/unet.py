@@ -290,6 +290,11 @@ class UNet(torch.nn.Module):
             block = ResidualBlock3d if self.spatial_dimensions == 3 else ResidualBlock2d
             self.link_ops = torch.nn.ModuleList([
                 block(d + ex, 3, out_channels=d, adn_fn=self.adn_fn) for d in rev_depth])
+        elif self.link_type == "attention":     # unet.py:473-481
+            from ..layers.self_attention import SelfAttentionBlock
+            self.link_ops = torch.nn.ModuleList([
+                SelfAttentionBlock(self.spatial_dimensions, d, d, [16, 16, 1])
+                for d in self.depth[-2::-1]])
         else:
             raise NotImplementedError(f"link_type={self.link_type!r} is outside the HIP path")
 

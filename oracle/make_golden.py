@@ -81,6 +81,24 @@ UNET_CASES = {
 }
 
 
+ATTENTION_LINK_CASES = {
+    # link_type="attention" (unet.py:473-481: SelfAttentionBlock over [16, 16, 1] patches of every
+    # skip tensor; the reference tests it for shapes only, testing/test_unet.py:204-235)
+    "unet3d_attention_links": (dict(spatial_dimensions=3, conv_type="regular",
+                                    link_type="attention", upscale_type="transpose",
+                                    norm_type="instance", padding="same", dropout_param=0.0,
+                                    activation_fn="swish", in_channels=1, n_classes=2,
+                                    depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                               (2, 1, 64, 64, 8), "uniform"),
+    "unet2d_attention_links": (dict(spatial_dimensions=2, conv_type="regular",
+                                    link_type="attention", upscale_type="transpose",
+                                    norm_type="instance", padding="same", dropout_param=0.0,
+                                    activation_fn="relu", in_channels=2, n_classes=2,
+                                    depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                               (2, 2, 64, 96), "uniform"),
+}
+
+
 DEPTHWISE_CASES = {
     # conv_type="depthwise" (unet.py:292-307): Conv(groups = channels, k, stride) -> ADN -> 1x1 conv.
     # The constructor default padding="same" (the 1x1 conv takes the SAME padding argument, so an
@@ -1123,6 +1141,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "brunet":
         for name, (kw, shape, missing) in BRUNET_CASES.items():
             gen_brunet(name, kw, shape, missing)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "attention":
+        for name, (kw, shape, dist) in ATTENTION_LINK_CASES.items():
+            gen_unet(name, kw, shape, dist)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "swin":
         for name, (kw, shape, dist) in SWIN_CASES.items():

@@ -35,6 +35,20 @@ DEPTHWISE_CASES = {
                              depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
 }
 
+# link_type="attention" (unet.py:473-481); fixtures: `python oracle/make_golden.py attention`
+ATTENTION_LINK_CASES = {
+    "unet3d_attention_links": dict(spatial_dimensions=3, conv_type="regular", link_type="attention",
+                                   upscale_type="transpose", norm_type="instance", padding="same",
+                                   dropout_param=0.0, activation_fn="swish", in_channels=1,
+                                   n_classes=2, depth=[8, 16, 32], kernel_sizes=[3] * 3,
+                                   strides=[2] * 3),
+    "unet2d_attention_links": dict(spatial_dimensions=2, conv_type="regular", link_type="attention",
+                                   upscale_type="transpose", norm_type="instance", padding="same",
+                                   dropout_param=0.0, activation_fn="relu", in_channels=2,
+                                   n_classes=2, depth=[8, 16, 32], kernel_sizes=[3] * 3,
+                                   strides=[2] * 3),
+}
+
 UNETR_CASES = {
     "unetr3d_small": dict(image_size=[32, 32, 32], patch_size=[8, 8, 8], number_of_blocks=4,
                           return_at=[1, 2], embedding_size=64, attention_dim=64, hidden_dim=64,

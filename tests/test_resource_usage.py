@@ -5,7 +5,7 @@ the Makefile rule; tools/resource_usage.py parses it) and this test reads it. Ro
 slabs are 57 MB): accumulators behind a phi of addresses, invisible in every timing.
 
 Every kernel must report ScratchSize 0 except the ones listed below, none of which runs in the
-benchmark step (profiles/r03*_bench_kernel_stats.txt); their budgets may shrink, never grow."""
+benchmark step (profiles/r04*_bench_kernel_stats.txt); their budgets may shrink, never grow."""
 import glob
 import os
 import sys
@@ -64,8 +64,8 @@ def test_no_scratch_outside_the_allow_list():
 
 
 def test_step_kernels_are_spill_free():
-    """The kernels of the benchmark step by name (profiles/r03d_bench_kernel_stats.txt)."""
-    path = os.path.join(ROOT, "profiles", "r03d_bench_kernel_stats.txt")
+    """The kernels of the benchmark step by name (profiles/r04a_bench_kernel_stats.txt)."""
+    path = os.path.join(ROOT, "profiles", "r04a_bench_kernel_stats.txt")
     names = set()
     with open(path) as fh:
         for line in fh:
