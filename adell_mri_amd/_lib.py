@@ -119,9 +119,12 @@ SIGNATURES = {
     "adell_norm_act_bwd_lowrank": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                         _vp, ctypes.c_size_t, _vp]),
     "adell_dice_focal_workspace": (_l, [_i, _l]),
-    "adell_dice_focal_fwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
-    "adell_dice_focal_bwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _f, _f, _vp, _vp]),
-    "adell_dice_focal_bwd_dev": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_dice_focal_fwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_dice_focal_bwd": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _f, _vp, _f, _f, _vp, _vp]),
+    "adell_dice_focal_bwd_dev": (_i, [_vp, _vp, _i, _l, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "adell_class_sums_workspace": (_l, [_i, _l, _i]),
+    "adell_class_sums_fwd": (_i, [_vp, _vp, _i, _l, _i, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_class_sums_bwd": (_i, [_vp, _vp, _i, _l, _i, _vp, _vp]),
     "adell_sgd_step": (_i, [_vp, _vp, _vp, _l, _f, _f, _f, _i, _i, _f, _vp]),
     "adell_adamw_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),
     "adell_adam_step": (_i, [_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _l, _f, _vp]),

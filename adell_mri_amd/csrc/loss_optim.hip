@@ -13,6 +13,7 @@ struct LossArgs {
   const float* t;  // targets [B][S]
   float* part;     // [B][nblk][3]
   const float* sums;  // [B][3] (num, den, fl) for the backward
+  float falpha;       // weight of the positive-class term of the focal loss (losses.py:112-164 `alpha`)
   float* dp;
   long S;
   int nblk;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void adell_dice_focal_partials_kernel(LossArgs
     const float pc = fmaxf(pi, a.focal_eps);
     const float qc = fmaxf(1.0f - pc, a.focal_eps);
     const float tb = ti > 0.5f ? 1.f : 0.f;
-    fl += adell_powg(pc, a.gamma) * logf(pc) * tb +
+    fl += a.falpha * adell_powg(pc, a.gamma) * logf(pc) * tb +
           adell_powg(qc, a.gamma) * logf(qc) * (1.f - tb);
   }
   num = adell_wave_sum(num);
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void adell_dice_focal_bwd_kernel(LossArgs a) {
     if (pi > a.focal_eps) {
       const float g1 = a.gamma - 1.0f;
       const float pg = g1 == 0.f ? 1.f : adell_powg(pi, g1);
-      gf += tb * (a.gamma * pg * logf(pi) + pg);
+      gf += a.falpha * tb * (a.gamma * pg * logf(pi) + pg);
       const float q = 1.0f - pi;
       if (q > a.focal_eps) {
         const float qg = g1 == 0.f ? 1.f : adell_powg(q, g1);
@@ -123,7 +124,7 @@ extern "C" long adell_dice_focal_workspace(int B, long S) {
 
 // dice[B], focal[B] per-item losses; sums[B][3] is kept for the backward.
 extern "C" int adell_dice_focal_fwd(const float* prob, const float* target, int B, long S,
-                                    float smooth, float dice_eps, float gamma,
+                                    float smooth, float dice_eps, float gamma, float focal_alpha,
                                     float focal_eps, float* dice, float* focal, float* sums,
                                     void* workspace, size_t workspace_bytes, void* stream) {
   ADELL_REQUIRE(prob && target && dice && focal && sums && workspace,
@@ -135,6 +136,7 @@ extern "C" int adell_dice_focal_fwd(const float* prob, const float* target, int 
   a.p = prob; a.t = target; a.part = (float*)workspace; a.S = S;
   a.nblk = (int)((S + ADELL_LOSS_SLAB - 1) / ADELL_LOSS_SLAB);
   a.smooth = smooth; a.dice_eps = dice_eps; a.gamma = gamma; a.focal_eps = focal_eps;
+  a.falpha = focal_alpha;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adell_dice_focal_partials_kernel, dim3(a.nblk, B), dim3(256), 0, st, a);
   hipLaunchKernelGGL(adell_dice_focal_finalize_kernel, dim3(B), dim3(64), 0, st,
@@ -145,7 +147,7 @@ extern "C" int adell_dice_focal_fwd(const float* prob, const float* target, int 
 
 // dprob = gdice * d dice_b/dp + gfocal * d focal_b/dp  (per item b).
 extern "C" int adell_dice_focal_bwd(const float* prob, const float* target, int B, long S,
-                                    float smooth, float dice_eps, float gamma,
+                                    float smooth, float dice_eps, float gamma, float focal_alpha,
                                     float focal_eps, const float* sums, float gdice,
                                     float gfocal, float* dprob, void* stream) {
   ADELL_REQUIRE(prob && target && sums && dprob, "dice_focal_bwd: null pointer");
@@ -153,6 +155,7 @@ extern "C" int adell_dice_focal_bwd(const float* prob, const float* target, int 
   LossArgs a = {};
   a.p = prob; a.t = target; a.sums = sums; a.dp = dprob; a.S = S;
   a.smooth = smooth; a.dice_eps = dice_eps; a.gamma = gamma; a.focal_eps = focal_eps;
+  a.falpha = focal_alpha;
   a.gdice = gdice; a.gfocal = gfocal;
   long blocks = (S + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
@@ -166,18 +169,120 @@ extern "C" int adell_dice_focal_bwd(const float* prob, const float* target, int 
 // may be NULL = 0): no host read-back of the autograd inputs.
 extern "C" int adell_dice_focal_bwd_dev(const float* prob, const float* target, int B, long S,
                                         float smooth, float dice_eps, float gamma,
-                                        float focal_eps, const float* sums, const float* gdice,
-                                        const float* gfocal, float* dprob, void* stream) {
+                                        float focal_alpha, float focal_eps, const float* sums,
+                                        const float* gdice, const float* gfocal, float* dprob,
+                                        void* stream) {
   ADELL_REQUIRE(prob && target && sums && dprob, "dice_focal_bwd: null pointer");
   ADELL_REQUIRE(B > 0 && S > 0, "dice_focal_bwd: bad dims");
   LossArgs a = {};
   a.p = prob; a.t = target; a.sums = sums; a.dp = dprob; a.S = S;
   a.smooth = smooth; a.dice_eps = dice_eps; a.gamma = gamma; a.focal_eps = focal_eps;
+  a.falpha = focal_alpha;
   a.gdice = 0.f; a.gfocal = 0.f; a.gdice_dev = gdice; a.gfocal_dev = gfocal;
   long blocks = (S + 1023) / 1024;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adell_dice_focal_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0,
                      (hipStream_t)stream, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Per-(item, class) sums over the voxels of probabilities p and targets t, [B][V][C]:
+//   sums[b][c] = (sum p t, sum p, sum t)
+// -- what the Tversky-type losses are made of (losses.py:295-337, 656-698: tp = sum p t,
+// "fn" = sum p (1 - t) = sum p - sum p t, "fp" = sum (1 - p) t = sum t - sum p t). Deterministic:
+// per-slab partials, fixed-order fp64 fold. Backward: dp[b][v][c] = g[b][c][0] t + g[b][c][1].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_class_sums_partials_kernel(
+    const float* __restrict__ p, const float* __restrict__ t, float* __restrict__ part, long V,
+    int C, int nblk) {
+  __shared__ float sh[4][3];
+  const int blk = blockIdx.x, b = blockIdx.y, c = blockIdx.z;
+  const long i0 = (long)blk * ADELL_LOSS_SLAB;
+  long i1 = i0 + ADELL_LOSS_SLAB;
+  if (i1 > V) i1 = V;
+  const float* pb = p + (size_t)b * V * C + c;
+  const float* tb = t + (size_t)b * V * C + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float pi = pb[i * C], ti = tb[i * C];
+    s0 += pi * ti;
+    s1 += pi;
+    s2 += ti;
+  }
+  s0 = adell_wave_sum(s0);
+  s1 = adell_wave_sum(s1);
+  s2 = adell_wave_sum(s2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[w][0] = s0; sh[w][1] = s1; sh[w][2] = s2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    part[(((size_t)b * C + c) * nblk + blk) * 3 + threadIdx.x] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ void adell_class_sums_finalize_kernel(const float* __restrict__ part, int nblk,
+                                                 float* __restrict__ sums) {
+  const int bc = blockIdx.x;
+  __shared__ double sh[64][3];
+  double acc[3] = {0.0, 0.0, 0.0};
+  for (int k = threadIdx.x; k < nblk; k += 64)
+    for (int j = 0; j < 3; ++j) acc[j] += (double)part[((size_t)bc * nblk + k) * 3 + j];
+  for (int j = 0; j < 3; ++j) sh[threadIdx.x][j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double s = 0.0;
+    for (int k = 0; k < 64; ++k) s += sh[k][threadIdx.x];
+    sums[bc * 3 + threadIdx.x] = (float)s;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_class_sums_bwd_kernel(
+    const float* __restrict__ t, const float* __restrict__ g, float* __restrict__ dp, long VC,
+    int C) {
+  const int b = blockIdx.y;
+  const float* tb = t + (size_t)b * VC;
+  float* db = dp + (size_t)b * VC;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < VC; e += (long)gridDim.x * 256L) {
+    const int c = (int)(e % C);
+    const float* gc = g + ((size_t)b * C + c) * 3;
+    db[e] = gc[0] * tb[e] + gc[1];
+  }
+}
+
+extern "C" long adell_class_sums_workspace(int B, long V, int C) {
+  const long nblk = (V + ADELL_LOSS_SLAB - 1) / ADELL_LOSS_SLAB;
+  return (long)sizeof(float) * B * C * nblk * 3;
+}
+
+extern "C" int adell_class_sums_fwd(const float* p, const float* t, int B, long V, int C,
+                                    float* sums, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  ADELL_REQUIRE(p && t && sums && workspace, "class_sums_fwd: null pointer");
+  ADELL_REQUIRE(B > 0 && B <= 65535 && V > 0 && C > 0 && C <= 65535, "class_sums_fwd: bad dims");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_class_sums_workspace(B, V, C),
+                "class_sums_fwd: workspace too small");
+  const int nblk = (int)((V + ADELL_LOSS_SLAB - 1) / ADELL_LOSS_SLAB);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adell_class_sums_partials_kernel, dim3(nblk, B, C), dim3(256), 0, st, p, t,
+                     (float*)workspace, V, C, nblk);
+  hipLaunchKernelGGL(adell_class_sums_finalize_kernel, dim3(B * C), dim3(64), 0, st,
+                     (const float*)workspace, nblk, sums);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_class_sums_bwd(const float* t, const float* gsums, int B, long V, int C,
+                                    float* dp, void* stream) {
+  ADELL_REQUIRE(t && gsums && dp, "class_sums_bwd: null pointer");
+  ADELL_REQUIRE(B > 0 && B <= 65535 && V > 0 && C > 0, "class_sums_bwd: bad dims");
+  long blocks = (V * C + 1023) / 1024;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adell_class_sums_bwd_kernel, dim3((unsigned)blocks, B), dim3(256), 0,
+                     (hipStream_t)stream, t, gsums, dp, V * C, C);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }

@@ -18,21 +18,22 @@ class DiceFocalFn(torch.autograd.Function):
     """(dice[B], focal[B]) of probabilities ``pred`` against ``target``."""
 
     @staticmethod
-    def forward(ctx, pred, target, smooth, dice_eps, gamma, focal_eps):
+    def forward(ctx, pred, target, smooth, dice_eps, gamma, focal_eps, focal_alpha=1.0):
         pred, target = pred.contiguous(), target.contiguous().to(torch.float32)
-        dice, focal, sums = ops.dice_focal_fwd(pred, target, smooth, dice_eps, gamma, focal_eps)
+        dice, focal, sums = ops.dice_focal_fwd(pred, target, smooth, dice_eps, gamma, focal_eps,
+                                               focal_alpha)
         ctx.save_for_backward(pred, target, sums)
-        ctx.conf = (smooth, dice_eps, gamma, focal_eps)
+        ctx.conf = (smooth, dice_eps, gamma, focal_eps, focal_alpha)
         return dice, focal
 
     @staticmethod
     def backward(ctx, gdice, gfocal):
         pred, target, sums = ctx.saved_tensors
-        smooth, dice_eps, gamma, focal_eps = ctx.conf
+        smooth, dice_eps, gamma, focal_eps, focal_alpha = ctx.conf
         # per-item upstream gradients stay on the device (no host read-back / sync)
         dp = ops.dice_focal_bwd_dev(pred, target, sums, smooth, dice_eps, gamma, focal_eps,
-                                    gdice, gfocal)
-        return dp, None, None, None, None, None
+                                    gdice, gfocal, focal_alpha)
+        return dp, None, None, None, None, None, None
 
 
 def _check_binary(pred, target, **unsupported):
@@ -43,18 +44,103 @@ def _check_binary(pred, target, **unsupported):
             raise NotImplementedError(f"{k}={v!r} is outside the HIP path built so far")
 
 
+def _scalar(v):
+    return float(v.reshape(-1)[0]) if torch.is_tensor(v) else float(v)
+
+
 def binary_generalized_dice_loss(pred, target, weight: float = 1.0, smooth: float = 1.0,
                                  scale: float = 1.0, eps: float = eps) -> torch.Tensor:
-    _check_binary(pred, target, weight=(weight, 1.0), scale=(scale, 1.0))
+    # (a scalar `weight` multiplies numerator and denominator of generalised_dice_score alike,
+    # losses.py:14-54: it cancels, so any value gives the weight-1 result)
+    _check_binary(pred, target, scale=(scale, 1.0))
+    if torch.is_tensor(weight) and weight.numel() > 1:
+        raise NotImplementedError("binary dice: a per-class weight vector is outside the HIP path")
     return DiceFocalFn.apply(pred, target, float(smooth), float(eps), 1.0, 1e-6)[0]
 
 
 def binary_focal_loss(pred, target, gamma: float, alpha: float = 1.0, threshold: float = 0.5,
                       scale: float = 1.0, label_smoothing: float = 0.0,
                       eps: float = eps) -> torch.Tensor:
-    _check_binary(pred, target, alpha=(alpha, 1.0), threshold=(threshold, 0.5),
-                  scale=(scale, 1.0), label_smoothing=(label_smoothing, 0.0))
-    return DiceFocalFn.apply(pred, target, 0.0, 1e-6, float(gamma), float(eps))[1]
+    """losses.py:112-164: -mean((alpha p^gamma log p) t + (q^gamma log q) (1 - t)) * scale."""
+    _check_binary(pred, target, threshold=(threshold, 0.5), label_smoothing=(label_smoothing, 0.0))
+    out = DiceFocalFn.apply(pred, target, 0.0, 1e-6, _scalar(gamma), float(eps), _scalar(alpha))[1]
+    return out if float(scale) == 1.0 else out * float(scale)
+
+
+def _focal_b1(*args, **kwargs):
+    """binary_focal_loss in the reference's own output shape [B, 1] (losses.py:152-163 flattens
+    from dim 2 and averages the last axis): the composite losses add it to [B] terms, which
+    broadcasts to [B, B] there -- reproduced, so that every reduction a caller applies (CompoundLoss
+    takes the mean, losses.py:862-885) sees the same numbers."""
+    return binary_focal_loss(*args, **kwargs).reshape(-1, 1)
+
+
+class _ClassSumsFn(torch.autograd.Function):
+    """sums[B, C, 3] = (sum p t, sum p, sum t) over the voxels of [B, V, C] tensors
+    (ops.class_sums_fwd); differentiable in p."""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = p.contiguous(), t.contiguous().to(torch.float32)
+        ctx.save_for_backward(t)
+        return ops.class_sums_fwd(p, t)
+
+    @staticmethod
+    def backward(ctx, gsums):
+        (t,) = ctx.saved_tensors
+        return ops.class_sums_bwd(t, gsums), None
+
+
+def _tversky_terms(pred, target):
+    """(tp, "fn", "fp") as the reference names them (losses.py:325-330, 690-696):
+    sum p t, sum p (1 - t), sum (1 - p) t per (item, class)."""
+    s = _ClassSumsFn.apply(_as_bvc(pred), _as_bvc(target))
+    tp = s[..., 0]
+    return tp, s[..., 1] - tp, s[..., 2] - tp
+
+
+def binary_focal_tversky_loss(pred, target, alpha: float, beta: float,
+                              gamma: float = 1) -> torch.Tensor:
+    """losses.py:295-337: 1 - ((tp + 1) / (tp + alpha fn + beta fp + 1))^gamma per item."""
+    if pred.shape != target.shape:
+        raise ValueError("binary_focal_tversky_loss: pred and target shapes differ")
+    B = pred.shape[0]
+    tp, fn, fp = _tversky_terms(pred.reshape(B, 1, -1), target.reshape(B, 1, -1))
+    nd = (tp + 1) / (tp + _scalar(alpha) * fn + _scalar(beta) * fp + 1)
+    return (1 - nd ** _scalar(gamma)).reshape(B)
+
+
+def combo_loss(pred, target, alpha: float = 0.5, weight: float = 1, gamma: float = 1.0,
+               scale: float = 1.0, eps: float = eps) -> torch.Tensor:
+    """losses.py:339-383 (as written there: the dice term is called positionally, so `eps` lands
+    in its `smooth` argument)."""
+    bdl = binary_generalized_dice_loss(pred, target, weight, eps) * scale
+    bce = _focal_b1(pred=pred, target=target, alpha=weight, gamma=gamma, scale=scale)
+    return _scalar(alpha) * bce + (1 - _scalar(alpha)) * bdl
+
+
+def hybrid_focal_loss(pred, target, lam: float = 0.5, focal_params: dict = {},
+                      tversky_params: dict = {}) -> torch.Tensor:
+    """losses.py:386-418: lam * focal + (1 - lam) * focal Tversky (a numeric / None focal alpha
+    is replaced by 1, as the reference does)."""
+    focal_params = dict(focal_params)
+    a = focal_params.get("alpha")
+    if a is None or isinstance(a, (int, float)):
+        focal_params["alpha"] = 1.0
+    bfl = _focal_b1(pred, target, **focal_params)
+    bftl = binary_focal_tversky_loss(pred, target, **tversky_params)
+    return lam * bfl + (1 - lam) * bftl
+
+
+def unified_focal_loss(pred, target, weight: float, gamma: float, lam: float = 0.5,
+                       threshold: float = 0.5, scale: float = 1.0) -> torch.Tensor:
+    """losses.py:421-461, argument for argument: the focal term is called positionally as
+    binary_focal_loss(pred, target, weight, 1 - gamma, threshold, scale), i.e. its `gamma` is
+    `weight` and its `alpha` is `1 - gamma`."""
+    w, g = _scalar(weight), _scalar(gamma)
+    bfl = _focal_b1(pred, target, w, 1 - g, threshold, scale)
+    bftl = binary_focal_tversky_loss(pred, target, w, 1 - w, g)
+    return lam * bfl + (1 - lam) * bftl
 
 
 class _SegLossFn(torch.autograd.Function):
@@ -153,6 +239,47 @@ def mc_generalized_dice_loss(pred, target, weight=1.0, smooth: float = 1.0, scal
     target = _mc_target(pred, target)
     conf = (ops.SEG_LOSS_KINDS["mc_dice"], float(eps), float(scale), 0.0, 0.0, float(smooth), 1.0)
     return _SegLossFn.apply(pred, target, _class_vector(weight, pred.shape[1], pred), conf)
+
+
+def mc_focal_tversky_loss(pred, target, alpha, beta, gamma=1.0) -> torch.Tensor:
+    """losses.py:656-698: n = tp + 1, d = n + alpha fn + beta fp + 1 (the second + 1 as written
+    there), mean over the classes of 1 - (n / d)^gamma."""
+    target = _mc_target(pred, target)
+    tp, fn, fp = _tversky_terms(pred, target)
+    C = pred.shape[1]
+    n = tp + 1
+    d = n + _class_vector(alpha, C, pred) * fn + _class_vector(beta, C, pred) * fp + 1
+    g = _class_vector(gamma, C, pred)
+    return torch.mean(1 - torch.pow(n / d, g), dim=-1)
+
+
+def mc_combo_loss(pred, target, alpha: float = 0.5, weight=1, scale: float = 1.0) -> torch.Tensor:
+    """losses.py:701-734 (positional calls as written: `scale` lands in the dice loss's `smooth`)."""
+    bdl = mc_generalized_dice_loss(pred, target, weight, scale)
+    bce = cat_cross_entropy(pred, target, weight, scale)
+    return _scalar(alpha) * bce + (1 - _scalar(alpha)) * bdl
+
+
+def mc_hybrid_focal_loss(pred, target, lam: float = 1.0, focal_params: dict = {},
+                         tversky_params: dict = {}) -> torch.Tensor:
+    """losses.py:737-769."""
+    focal_params = dict(focal_params)
+    a = focal_params.get("alpha")
+    if a is None or isinstance(a, (int, float)):
+        focal_params["alpha"] = 1.0
+    fl = mc_focal_loss(pred, target, **focal_params)
+    ftl = mc_focal_tversky_loss(pred, target, **tversky_params)
+    return lam * fl + (1 - lam) * ftl
+
+
+def mc_unified_focal_loss(pred, target, delta, gamma, lam: float, scale: float = 1.0) -> torch.Tensor:
+    """losses.py:772-808: mc_focal_loss(pred, target, delta, 1 - gamma, scale) and
+    mc_focal_tversky_loss(pred, target, delta, 1 - delta, gamma)."""
+    C = pred.shape[1]
+    dvec = _class_vector(delta, C, pred)
+    fl = mc_focal_loss(pred, target, dvec, 1 - _scalar(gamma), scale)
+    ftl = mc_focal_tversky_loss(pred, target, dvec, 1 - dvec, gamma)
+    return lam * fl + (1 - lam) * ftl
 
 
 class CompoundLoss(torch.nn.Module):

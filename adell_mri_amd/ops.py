@@ -1085,7 +1085,7 @@ def norm_act_bwd_lowrank(x, g, w, mean, rstd, act, act_p=0.0, drop_p=0.0, seed=0
     return dx
 
 
-def dice_focal_fwd(prob, target, smooth, dice_eps, gamma, focal_eps):
+def dice_focal_fwd(prob, target, smooth, dice_eps, gamma, focal_eps, focal_alpha=1.0):
     """Per-item (dice[B], focal[B]) and the sums the backward needs. prob/target: [B, ...]."""
     _require_cuda(prob, target)
     prob, target = prob.contiguous(), target.contiguous()
@@ -1097,23 +1097,27 @@ def dice_focal_fwd(prob, target, smooth, dice_eps, gamma, focal_eps):
     focal = torch.empty_like(dice)
     sums = torch.empty((B, 3), device=prob.device, dtype=torch.float32)
     check(_lib.lib().adell_dice_focal_fwd(_ptr(prob), _ptr(target), B, S, smooth, dice_eps, gamma,
-                                          focal_eps, _ptr(dice), _ptr(focal), _ptr(sums),
+                                          float(focal_alpha), focal_eps, _ptr(dice), _ptr(focal),
+                                          _ptr(sums),
                                           _ptr(ws), ws.numel() * 4, _stream()))
     return dice, focal, sums
 
 
-def dice_focal_bwd(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice, gfocal):
+def dice_focal_bwd(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice, gfocal,
+                   focal_alpha=1.0):
     prob, target = prob.contiguous(), target.contiguous()
     B = prob.shape[0]
     S = prob.numel() // B
     dprob = torch.empty_like(prob)
     check(_lib.lib().adell_dice_focal_bwd(_ptr(prob), _ptr(target), B, S, smooth, dice_eps, gamma,
-                                          focal_eps, _ptr(sums), float(gdice), float(gfocal),
+                                          float(focal_alpha), focal_eps, _ptr(sums), float(gdice),
+                                          float(gfocal),
                                           _ptr(dprob), _stream()))
     return dprob
 
 
-def dice_focal_bwd_dev(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice, gfocal):
+def dice_focal_bwd_dev(prob, target, sums, smooth, dice_eps, gamma, focal_eps, gdice, gfocal,
+                       focal_alpha=1.0):
     """gdice / gfocal: per-item upstream gradients as CUDA tensors [B] (or None)."""
     prob, target = prob.contiguous(), target.contiguous()
     B = prob.shape[0]
@@ -1122,9 +1126,31 @@ def dice_focal_bwd_dev(prob, target, sums, smooth, dice_eps, gamma, focal_eps, g
     gd = None if gdice is None else gdice.contiguous().float()
     gf = None if gfocal is None else gfocal.contiguous().float()
     check(_lib.lib().adell_dice_focal_bwd_dev(_ptr(prob), _ptr(target), B, S, smooth, dice_eps,
-                                              gamma, focal_eps, _ptr(sums), _ptr(gd), _ptr(gf),
-                                              _ptr(dprob), _stream()))
+                                              gamma, float(focal_alpha), focal_eps, _ptr(sums),
+                                              _ptr(gd), _ptr(gf), _ptr(dprob), _stream()))
     return dprob
+
+
+def class_sums_fwd(p, t):
+    """p, t: [B, V, C] contiguous -> sums [B, C, 3] = (sum p t, sum p, sum t) over the voxels."""
+    _require_cuda(p, t)
+    B, V, C = p.shape
+    nbytes = _lib.lib().adell_class_sums_workspace(B, V, C)
+    ws = _workspace(nbytes, p.device)
+    sums = torch.empty((B, C, 3), device=p.device, dtype=torch.float32)
+    check(_lib.lib().adell_class_sums_fwd(_ptr(p), _ptr(t), B, V, C, _ptr(sums), _ptr(ws),
+                                          ws.numel() * 4, _stream()))
+    return sums
+
+
+def class_sums_bwd(t, gsums):
+    """dp [B, V, C] = gsums[..., 0] * t + gsums[..., 1]."""
+    _require_cuda(t, gsums)
+    B, V, C = t.shape
+    dp = torch.empty_like(t)
+    g = gsums.contiguous()
+    check(_lib.lib().adell_class_sums_bwd(_ptr(t), _ptr(g), B, V, C, _ptr(dp), _stream()))
+    return dp
 
 
 # Bumped whenever a HIP kernel rewrites parameters in place (torch's version

@@ -33,19 +33,19 @@ loss_factory = {
         "cross_entropy": _seg_losses.binary_cross_entropy,
         "focal": _seg_losses.binary_focal_loss,
         "dice": _seg_losses.binary_generalized_dice_loss,
-        "tversky_focal": _not_built("binary_focal_tversky_loss"),
-        "combo": _not_built("combo_loss"),
-        "hybrid_focal": _not_built("hybrid_focal_loss"),
-        "unified_focal": _not_built("unified_focal_loss"),
+        "tversky_focal": _seg_losses.binary_focal_tversky_loss,
+        "combo": _seg_losses.combo_loss,
+        "hybrid_focal": _seg_losses.hybrid_focal_loss,
+        "unified_focal": _seg_losses.unified_focal_loss,
     },
     "categorical": {
         "cross_entropy": _seg_losses.cat_cross_entropy,
         "focal": _seg_losses.mc_focal_loss,
         "dice": _seg_losses.mc_generalized_dice_loss,
-        "tversky_focal": _not_built("mc_focal_tversky_loss"),
-        "combo": _not_built("mc_combo_loss"),
-        "hybrid_focal": _not_built("mc_hybrid_focal_loss"),
-        "unified_focal": _not_built("mc_unified_focal_loss"),
+        "tversky_focal": _seg_losses.mc_focal_tversky_loss,
+        "combo": _seg_losses.mc_combo_loss,
+        "hybrid_focal": _seg_losses.mc_hybrid_focal_loss,
+        "unified_focal": _seg_losses.mc_unified_focal_loss,
     },
 }
 

@@ -417,19 +417,30 @@ int adell_prelu_wgrad(const adell_norm_act_desc* d, const float* x, const float*
  * ---------------------------------------------------------------------- */
 long adell_dice_focal_workspace(int B, long S);
 int adell_dice_focal_fwd(const float* prob, const float* target, int B, long S,
-                         float smooth, float dice_eps, float gamma, float focal_eps,
+                         float smooth, float dice_eps, float gamma, float focal_alpha, float focal_eps,
                          float* dice, float* focal, float* sums, void* workspace,
                          size_t workspace_bytes, void* stream);
 /* dprob = gdice * d(dice_b)/dprob + gfocal * d(focal_b)/dprob */
 int adell_dice_focal_bwd(const float* prob, const float* target, int B, long S,
-                         float smooth, float dice_eps, float gamma, float focal_eps,
+                         float smooth, float dice_eps, float gamma, float focal_alpha, float focal_eps,
                          const float* sums, float gdice, float gfocal, float* dprob,
                          void* stream);
 /* the same with per-item upstream gradients on the device (gdice[B], gfocal[B], NULL = 0) */
 int adell_dice_focal_bwd_dev(const float* prob, const float* target, int B, long S, float smooth,
-                             float dice_eps, float gamma, float focal_eps, const float* sums,
-                             const float* gdice, const float* gfocal, float* dprob,
-                             void* stream);
+                             float dice_eps, float gamma, float focal_alpha, float focal_eps,
+                             const float* sums, const float* gdice, const float* gfocal,
+                             float* dprob, void* stream);
+/* (focal_alpha: weight of the positive-class term, `alpha` of binary_focal_loss, losses.py:112-164)
+ *
+ * Per-(item, class) sums (sum p t, sum p, sum t) of probabilities / targets laid out [B][V][C]: the
+ * building block of the Tversky-type losses (binary_focal_tversky_loss losses.py:295-337,
+ * mc_focal_tversky_loss :656-698 and, through them, hybrid_focal / unified_focal :386-462, 737-808).
+ * Backward: dp[b][v][c] = gsums[b][c][0] * t[b][v][c] + gsums[b][c][1]. */
+long adell_class_sums_workspace(int B, long V, int C);
+int adell_class_sums_fwd(const float* p, const float* t, int B, long V, int C, float* sums,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int adell_class_sums_bwd(const float* t, const float* gsums, int B, long V, int C, float* dp,
+                         void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimiser / EMA updates over flat fp32 buffers (16-byte aligned).

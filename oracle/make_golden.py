@@ -876,7 +876,8 @@ def gen_losses():
         else:
             p = torch.softmax(logits, 1).detach().requires_grad_(True)
             t = onehot if kind == "onehot" else cls
-        val = getattr(L, fn)(p, t, **kw)
+        import copy
+        val = getattr(L, fn)(p, t, **copy.deepcopy(kw))   # (the hybrid losses write into their dicts)
         (val * r).sum().backward()
         out[name + ":value"], out[name + ":grad"] = val.detach().numpy(), p.grad.numpy().copy()
         print(name, val.detach().numpy())

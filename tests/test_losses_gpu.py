@@ -15,10 +15,12 @@ from oracle.torch_ref import losses as RL
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-HIP = {"binary_cross_entropy": HL.binary_cross_entropy, "cat_cross_entropy": HL.cat_cross_entropy,
-       "mc_focal_loss": HL.mc_focal_loss, "mc_generalized_dice_loss": HL.mc_generalized_dice_loss}
-REF = {"binary_cross_entropy": RL.binary_cross_entropy, "cat_cross_entropy": RL.cat_cross_entropy,
-       "mc_focal_loss": RL.mc_focal_loss, "mc_generalized_dice_loss": RL.mc_generalized_dice_loss}
+_NAMES = ("binary_cross_entropy", "cat_cross_entropy", "mc_focal_loss", "mc_generalized_dice_loss",
+          "binary_focal_loss", "binary_focal_tversky_loss", "combo_loss", "hybrid_focal_loss",
+          "unified_focal_loss", "mc_focal_tversky_loss", "mc_combo_loss", "mc_hybrid_focal_loss",
+          "mc_unified_focal_loss")
+HIP = {n: getattr(HL, n) for n in _NAMES}
+REF = {n: getattr(RL, n) for n in _NAMES}
 
 
 @pytest.mark.parametrize("name", list(LOSS_CASES))
@@ -45,6 +47,10 @@ def test_loss_matches_reference_fixture(cuda, name):
     ("mc_generalized_dice_loss", dict(weight=[1.0, 3.0, 0.2, 1.0, 1.0, 2.0, 1.0], smooth=0.1, scale=2.0), 7,
      (2, 20, 24, 28)),
     ("binary_cross_entropy", dict(weight=0.7, scale=2.0), 1, (4, 50, 60, 10)),
+    ("binary_focal_tversky_loss", dict(alpha=0.2, beta=0.8, gamma=2.0), 1, (3, 41, 37, 9)),
+    ("unified_focal_loss", dict(weight=0.7, gamma=0.4, lam=0.6), 1, (2, 30, 50, 20)),
+    ("mc_focal_tversky_loss", dict(alpha=[0.3, 0.5, 0.7, 0.4, 0.6], beta=0.5, gamma=1.2), 5, (2, 25, 31, 7)),
+    ("mc_unified_focal_loss", dict(delta=[0.6, 0.5, 0.7, 0.4], gamma=0.6, lam=0.5), 4, (3, 19, 23)),
 ])
 def test_loss_matches_cpu_restatement_on_ragged_shapes(cuda, fn, kw, C, shape):
     g = torch.Generator().manual_seed(C)

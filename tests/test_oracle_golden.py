@@ -132,8 +132,7 @@ def test_loss_restatements_match_reference_fixture():
     logits, cls = torch.from_numpy(g["logits"]), torch.from_numpy(g["cls"])
     onehot = torch.nn.functional.one_hot(cls, 3).permute(0, 4, 1, 2, 3).float()
     r = torch.from_numpy(g["r"])
-    fns = {"binary_cross_entropy": L.binary_cross_entropy, "cat_cross_entropy": L.cat_cross_entropy,
-           "mc_focal_loss": L.mc_focal_loss, "mc_generalized_dice_loss": L.mc_generalized_dice_loss}
+    fns = {fn: getattr(L, fn) for fn, _, _ in LOSS_CASES.values()}
     for name, (fn, kw, kind) in LOSS_CASES.items():
         if kind == "binary":
             p, t = torch.from_numpy(g["pb"]).requires_grad_(True), torch.from_numpy(g["tb"])
