@@ -94,7 +94,7 @@ ATTENTION_LINK_CASES = {
     "unet2d_attention_links": (dict(spatial_dimensions=2, conv_type="regular",
                                     link_type="attention", upscale_type="transpose",
                                     norm_type="instance", padding="same", dropout_param=0.0,
-                                    activation_fn="relu", in_channels=2, n_classes=2,
+                                    activation_fn="gelu", in_channels=2, n_classes=2,
                                     depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3,
                                     _grad64=True),
                                (2, 2, 64, 96), "uniform"),

@@ -1,7 +1,12 @@
 """``link_type="attention"`` (unet.py:473-481: SelfAttentionBlock over [16, 16, 1] patches of every
 skip tensor, self_attention.py:152-239; the reference tests it for shapes only,
 testing/test_unet.py:204-235) against fixtures generated from the real reference
-(`python oracle/make_golden.py attention`): logits 1e-4, loss, every parameter gradient."""
+(`python oracle/make_golden.py attention`): logits 1e-4, loss, every parameter gradient.
+
+(The 2-D case uses a smooth activation on purpose: with ReLU its first draft had ONE bottleneck
+pre-activation within 2e-7 of zero, whose mask flipped between the f16x3 and the fp32 forward --
+at 2 x 16 x 24 bottleneck voxels a single flipped element moves the encoder's weight gradients by
+~1 %, in either direction, reference included; traced with tools/dbg_att.py, round 4.)"""
 import os
 
 import numpy as np
