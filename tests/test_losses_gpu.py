@@ -35,14 +35,14 @@ def test_loss_matches_reference_fixture(cuda, name):
         t = torch.nn.functional.one_hot(cls, 3).permute(0, 4, 1, 2, 3).float() if kind == "onehot" else cls
     pd = p.to(cuda).requires_grad_(True)
     val = HIP[fn](pd, t.to(cuda), **kw)
-    (val * torch.from_numpy(g["r"]).to(cuda)).sum().backward()
     want = g[name + ":value"]
-    got = val.detach().cpu().numpy()
-    if got.shape != want.shape and got.size == want.size:
+    if tuple(val.shape) != want.shape and val.numel() == want.size:
         # (binary_focal_loss: the reference returns [B, 1], this package [B]; the composite losses
-        # reproduce the reference's [B, B] broadcast, see losses._focal_b1)
-        got = got.reshape(want.shape)
-    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7)
+        # reproduce the reference's [B, B] broadcast, see losses._focal_b1. The fixture's gradient
+        # was taken through the same broadcast against r [B].)
+        val = val.reshape(want.shape)
+    (val * torch.from_numpy(g["r"]).to(cuda)).sum().backward()
+    np.testing.assert_allclose(val.detach().cpu().numpy(), want, rtol=2e-5, atol=1e-7)
     ref = g[name + ":grad"]
     assert np.abs(pd.grad.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max() + 1e-9
 
