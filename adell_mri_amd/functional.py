@@ -779,9 +779,13 @@ _ADN_PLAN = {}
 def _adn_sites_of(x0, x1, weight, stride, padding):
     """(site0, site1, ntiles) when x0 / x1 carry single-use ADN sites and the backward-data
     launch of this conv takes the fused epilogue, else None."""
-    s0 = getattr(x0, "_adell_site", None) if getattr(x0, "_adell_single", False) else None
+    # (someone watching the gradient of the site's output -- a tensor hook, retain_grad() -- must see
+    # the true gradient, not dt: such a site keeps its own two-pass backward)
+    s0 = (getattr(x0, "_adell_site", None)
+          if getattr(x0, "_adell_single", False) and not grad_observed(x0) else None)
     s1 = (getattr(x1, "_adell_site", None)
-          if x1 is not None and getattr(x1, "_adell_single", False) else None)
+          if x1 is not None and getattr(x1, "_adell_single", False) and not grad_observed(x1)
+          else None)
     if (s0 is None and s1 is None) or CONV_PRECISION != "f16x3" or FLAGS["no_adn_fuse"] \
             or weight.dim() != 5 or not torch.is_grad_enabled():
         return None
@@ -819,6 +823,7 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
         # the logits head behind a single-use site: the site's backward takes (dy, weight)
         site = getattr(x0, "_adell_site", None) if getattr(x0, "_adell_single", False) else None
         if (site is not None and x1 is None and carry_in is None and carry_x0 is None
+                and not grad_observed(x0)
                 and not FLAGS["no_adn_fuse"] and not FLAGS["no_lowrank"]
                 and torch.is_grad_enabled() and ops.norm_act_lowrank_ok(x0, weight.shape[0])):
             conf = conf[:8] + (("lowrank", site),) + conf[9:]

@@ -285,3 +285,36 @@ def test_head_gradients_do_not_depend_on_the_lowrank_site(cuda, monkeypatch):
     assert _rel(gx_f, gx_p) <= 5e-5
     for k in gw_p:
         assert float((gw_f[k] - gw_p[k]).abs().max()) <= 5e-5 * scale, k
+
+
+def test_a_hook_on_a_site_output_sees_the_true_gradient(cuda):
+    """A tensor hook (or retain_grad) on an ADN output that a fused site epilogue or the low-rank head
+    path would otherwise serve with dt / a placeholder: the site then keeps its own backward and the
+    watcher sees d loss / d output."""
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd.modules.layers.conv import Conv3d
+
+    torch.manual_seed(0)
+    conv = Conv3d(32, 32, 3, padding=1).to(cuda)
+    x = torch.randn(2, 32, 16, 16, 16, device=cuda, requires_grad=True)
+    r = torch.randn(2, 32, 16, 16, 16, device=cuda)
+
+    def run(watch):
+        HF._dropout_counter = itertools.count(1)
+        conv.zero_grad()
+        x.grad = None
+        h = HF.norm_drop_act(x, norm="instance", act="swish", drop_p=0.0, training=True)
+        seen = []
+        if watch:
+            h.register_hook(lambda g: seen.append(g.detach().clone()))
+        h = HF.single_use(h)
+        (conv(h) * r).sum().backward()
+        return x.grad.clone(), seen
+
+    gx_plain, _ = run(False)
+    gx_watch, seen = run(True)
+    assert len(seen) == 1
+    assert _rel(gx_watch, gx_plain) <= 2e-5
+    # the watcher's tensor is the gradient with respect to the ADN OUTPUT: conv backward-data of r
+    want = torch.nn.grad.conv3d_input(x.shape, conv.weight.detach().cpu(), r.cpu(), padding=1)
+    assert _rel(seen[0].cpu(), want) <= 1e-4
