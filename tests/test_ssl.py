@@ -329,6 +329,30 @@ def test_selfsl_unet_vicreg_step(cuda):
     got = [float(t.detach()) for t in net.last_losses]
     np.testing.assert_allclose(got, [float(t) for t in want], rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(float(loss.detach()), sum(got), rtol=1e-6)
+    # ... and INDEPENDENTLY of the HIP path: the stock-torch CPU oracle of the U-Net encoder
+    # (oracle/torch_ref/unet.py, pinned to the reference fixtures) on the same weights and inputs
+    # gives the bottlenecks, the three terms and every parameter gradient
+    from oracle.torch_ref.unet import UNetOracle
+    ref = UNetOracle({k: v.detach().cpu() for k, v in net.state_dict().items()},
+                     dict(depth=[8, 16, 32], kernel_sizes=[3, 3, 3], strides=[2, 2, 2], padding=1,
+                          norm_type="instance", activation="swish")).requires_grad_(True)
+    b1 = ref.encode("encoding_operations", x1)[1]
+    b2 = ref.encode("encoding_operations", x2)[1]
+    scale = float(b1.detach().abs().max())
+    assert float((y1.detach().cpu() - b1.detach()).abs().max()) < 1e-4 * scale
+    terms = vicreg_loss(b1.flatten(2).mean(-1), b2.flatten(2).mean(-1))
+    np.testing.assert_allclose(got, [float(t) for t in terms], rtol=5e-4, atol=1e-6)
+    sum(terms).backward()
+    net.zero_grad()
+    net.training_step(batch, 0).backward()
+    top = max(float(v.grad.abs().max()) for v in ref.sd.values() if v.grad is not None)
+    for k, p in net.named_parameters():
+        rg = ref.sd[k].grad
+        if rg is None:
+            continue
+        err = float((p.grad.detach().cpu() - rg).abs().max())
+        assert err <= 3e-3 * max(float(rg.abs().max()), 1e-2 * top), (k, err)
+    net.zero_grad()
     before = {k: p.detach().clone() for k, p in net.named_parameters()}
     StepRunner(net).train_step(batch)
     moved = sum(not torch.equal(before[k], p.detach()) for k, p in net.named_parameters())
