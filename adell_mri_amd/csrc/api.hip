@@ -41,6 +41,9 @@ static AdellTuning adell_tuning_from_env() {
   t.igemm_wide8 = adell_env_int("ADELL_IGEMM_WIDE8", 0);
   t.ew_reverse = adell_env_int("ADELL_EW_REVERSE", 0);
   t.fold_coarse = adell_env_int("ADELL_FOLD_COARSE", 0);
+  t.wgrad_no16 = adell_env_int("ADELL_WGRAD_NO16", 0);
+  t.zr_oldseg = adell_env_int("ADELL_ZR_OLDSEG", 0);
+  t.igemm_no16 = adell_env_int("ADELL_IGEMM_NO16", 0);
 #ifdef ADELL_DEBUG
   t.igemm_dbg = adell_env_int("ADELL_IGEMM_DBG", 0);
   t.zr_dbg = adell_env_int("ADELL_ZR_DBG", 0);
@@ -71,6 +74,9 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "igemm_wide8")) return &g_adell_tune.igemm_wide8;
   if (!strcmp(name, "ew_reverse")) return &g_adell_tune.ew_reverse;
   if (!strcmp(name, "fold_coarse")) return &g_adell_tune.fold_coarse;
+  if (!strcmp(name, "wgrad_no16")) return &g_adell_tune.wgrad_no16;
+  if (!strcmp(name, "zr_oldseg")) return &g_adell_tune.zr_oldseg;
+  if (!strcmp(name, "igemm_no16")) return &g_adell_tune.igemm_no16;
 #ifdef ADELL_DEBUG
   if (!strcmp(name, "igemm_dbg")) return &g_adell_tune.igemm_dbg;
   if (!strcmp(name, "zr_dbg")) return &g_adell_tune.zr_dbg;

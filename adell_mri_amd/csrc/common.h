@@ -30,6 +30,9 @@ struct AdellTuning {
   int igemm_wide8;                // 64-column tile of the large 3^3 layers on 8x8x8 bricks, 8 waves
   int ew_reverse;                 // norm / activation forward: reverse of the producer's write order
   int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)
+  int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)
+  int wgrad_no16;                 // z-ring weight gradient: 32 x 32 tiles even for 16-channel layers
+  int igemm_no16;                 // (reserved) forward / backward-data: no 16-column instance
   int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;

@@ -433,7 +433,7 @@ extern "C" int adell_wgrad_reduce_launch(const float* ws, float* out, int R, int
 
 // z-ring kernel for 3^3 stride-1 convolutions (conv_wgrad_zring.hip)
 struct WgradZrPlan {
-  int ntx, nty, nseg, seglen, nci, nco, R;
+  int ntx, nty, nseg, seglen, nci, nco, R, t16;
 };
 extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
                                       int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,

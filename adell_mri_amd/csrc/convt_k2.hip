@@ -1,4 +1,4 @@
-// ConvTranspose3d with kernel = stride = 2 on every axis and 32 / 64 channels on both sides (the
+// ConvTranspose3d with kernel = stride = 2 on every axis, 32 / 64 input and 16 / 32 / 64 output channels (the
 // decoder upscaling of the high-resolution U-Net levels, unet.py:445-458) as streaming GEMMs on the
 // fp32 MFMA (exact fp32 products). Every input voxel v feeds exactly the 8 output voxels 2 v + f:
 //
@@ -73,6 +73,48 @@ __device__ __forceinline__ void adell_ctk2_put(float* tile, int ld, int lane,
     const int i = lane + 64 * u, r = i / W4, c4 = i - r * W4;
     float* q = tile + r * ld + 4 * c4;
     q[0] = g.f[u].x; q[1] = g.f[u].y; q[2] = g.f[u].z; q[3] = g.f[u].w;
+  }
+}
+
+// ---- forward, 16 output channels (UNETR's full-resolution upscaling): the 32 MFMA columns are
+// (fx, co) -- the two fine-grid voxels of a coarse voxel are 32 contiguous floats -- one tile -------
+template <int CIN>
+__global__ __launch_bounds__(256) void adell_convt_k2_fwd16_kernel(ConvTK2Args a) {
+  constexpr int LD = CIN + 1, KS = CIN / 2;
+  __shared__ float sx[4][32 * LD];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int fz = wave >> 1, fy = wave & 1, fx = li >> 4, co = li & 15;
+  float bw[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+    bw[s] = a.w[((size_t)(2 * s + lh) * 16 + co) * 8 + (fz * 2 + fy) * 2 + fx];
+  const float bcol = a.bias ? a.bias[co] : 0.f;
+  float* tile = sx[wave];
+  CtK2Regs<CIN> regs;
+  auto fetch = [&](int t) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    adell_ctk2_fetch<CIN>(regs, valid, lane, a.x + (size_t)v0 * CIN, (size_t)li * CIN);
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    adell_ctk2_put<CIN>(tile, LD, lane, regs);
+    const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) : 0;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done
+    if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[li * LD + 2 * s + lh], bw[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < valid) a.y[adell_ctk2_shfl(yrow, row) * 16 + li] = acc[r] + bcol;
+    }
   }
 }
 
@@ -265,6 +307,98 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
   }
 }
 
+// ---- weight gradient, 16 output channels: N = (fx, co), one tile per (fz, fy) wave ---------------
+// partials [blocks][Cin / 32][4 (fz, fy)][32 ci][32 (fx, co)]
+__global__ __launch_bounds__(256) void adell_convt_k2_dw16_kernel(ConvTK2Args a) {
+  constexpr int LDX = 33, LDY = 33;
+  __shared__ float sx[4][32 * LDX];
+  __shared__ float sy[4][32 * LDY];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+  const int fz = wave >> 1, fy = wave & 1;
+  const int ci0 = blockIdx.y * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float* tx = sx[wave];
+  float* tyl = sy[wave];
+  CtK2Regs<32> rx, ry;
+  const bool do_db = a.wsdb != nullptr && ci0 == 0;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int t) {
+    const long v0 = (long)t * 32;
+    const int valid = (a.V - v0) < 32 ? (int)(a.V - v0) : 32;
+    const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) * 16 : 0;
+    adell_ctk2_fetch<32>(rx, valid, lane, a.x + (size_t)v0 * a.Cin + ci0, (size_t)li * a.Cin);
+    adell_ctk2_fetch<32>(ry, valid, lane, a.dy, yrow);   // both fx: 32 contiguous floats
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    adell_ctk2_put<32>(tx, LDX, lane, rx);
+    adell_ctk2_put<32>(tyl, LDY, lane, ry);
+    if (do_db) {
+#pragma unroll
+      for (int u = 0; u < CtK2Regs<32>::PER; ++u) {
+        dbacc.x += ry.f[u].x; dbacc.y += ry.f[u].y; dbacc.z += ry.f[u].z; dbacc.w += ry.f[u].w;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int v = 2 * s + lh;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tx[v * LDX + li], tyl[v * LDY + li], acc, 0, 0, 0);
+    }
+  }
+  float* out = a.ws + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 4 + (fz * 2 + fy)) * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // ci
+    out[row * 32 + li] = acc[r];
+  }
+  if (do_db) {
+    // this lane's pieces are always floats 4 (lane & 7) .. + 3 of the (fx, co) row: channels
+    // 4 (lane & 3) .. + 3 -- fold over lane bits 2 (fx), 3, 4, 5
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) {
+      dbacc.x += __shfl_xor(dbacc.x, o, 64);
+      dbacc.y += __shfl_xor(dbacc.y, o, 64);
+      dbacc.z += __shfl_xor(dbacc.z, o, 64);
+      dbacc.w += __shfl_xor(dbacc.w, o, 64);
+    }
+    if (lane < 4) {
+      float* o = a.wsdb + ((size_t)blockIdx.x * 4 + wave) * 16 + 4 * lane;
+      o[0] = dbacc.x; o[1] = dbacc.y; o[2] = dbacc.z; o[3] = dbacc.w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_convt_k2_dw16_reduce_kernel(
+    const float* __restrict__ ws, int blocks, int Cin, float* __restrict__ dw,
+    const float* __restrict__ wsdb, float* __restrict__ db) {
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const long ndw = (long)Cin * 16 * 8;
+  if (i >= ndw) {
+    const long co = i - ndw;
+    if (db == nullptr || co >= 16) return;
+    float s = 0.f;
+    for (int r = lane; r < blocks * 4; r += 64) s += wsdb[(size_t)r * 16 + co];
+    s = adell_wave_sum(s);
+    if (lane == 0) db[co] = s;
+    return;
+  }
+  const int f = (int)(i & 7);
+  const long cc = i >> 3;
+  const int co = (int)(cc & 15), ci = (int)(cc >> 4);
+  const int pairs = Cin / 32;
+  const float* p = ws + ((size_t)(ci >> 5) * 4 + (f >> 1)) * 1024 + (ci & 31) * 32 + (f & 1) * 16 + co;
+  const size_t stride = (size_t)pairs * 4 * 1024;
+  float s = 0.f;
+  for (int b = lane; b < blocks; b += 64) s += p[(size_t)b * stride];
+  s = adell_wave_sum(s);
+  if (lane == 0) dw[i] = s;
+}
+
 // dw[ci][co][f] = sum over blocks: one wave per value (lane l adds blocks l, l + 64, ...)
 __global__ __launch_bounds__(256) void adell_convt_k2_dw_reduce_kernel(
     const float* __restrict__ ws, int blocks, int Cin, int Cout, float* __restrict__ dw,
@@ -295,8 +429,9 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_reduce_kernel(
 }
 
 static bool adell_convt_k2_ok(int N, int D, int H, int W, int Cin, int Cout) {
+  // (Cout == 16: the (fx, co) column forms above)
   return N >= 1 && D >= 1 && H >= 1 && W >= 1 && (Cin == 32 || Cin == 64) &&
-         (Cout == 32 || Cout == 64) && (long)N * D * H * W >= 32768 &&
+         (Cout == 16 || Cout == 32 || Cout == 64) && (long)N * D * H * W >= 32768 &&
          (long)N * D * H * W < 0x7fffffe0L;
 }
 
@@ -318,13 +453,17 @@ static int adell_ctk2_blocks(const ConvTK2Args& a, int per_cu) {
 extern "C" int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
                                   const float* w, const float* bias, float* y, void* stream) {
   ADELL_REQUIRE(x && w && y && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
-                "convt_k2_fwd: factor-2 transposed conv with 32 / 64 channels expected");
+                "convt_k2_fwd: factor-2 transposed conv with 32 / 64 -> 16 / 32 / 64 channels expected");
   ADELL_REQUIRE(((uintptr_t)x & 15) == 0, "convt_k2_fwd: x must be 16-byte aligned");
   ConvTK2Args a = {};
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
-  dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cout / 32));
-  if (Cin == 32)
+  dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cout == 16 ? 1 : Cout / 32));
+  if (Cout == 16 && Cin == 32)
+    hipLaunchKernelGGL(adell_convt_k2_fwd16_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (Cout == 16)
+    hipLaunchKernelGGL(adell_convt_k2_fwd16_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else if (Cin == 32)
     hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -348,7 +487,9 @@ extern "C" int adell_convt_k2_bwd_data(int N, int D, int H, int W, int Cin, int 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_done = true;
   }
-  if (Cout == 32)
+  if (Cout == 16)
+    hipLaunchKernelGGL(adell_convt_k2_dx_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  else if (Cout == 32)
     hipLaunchKernelGGL(adell_convt_k2_dx_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(adell_convt_k2_dx_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -361,6 +502,7 @@ extern "C" long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int C
   ConvTK2Args a = {};
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
   const long blocks = adell_ctk2_blocks(a, 2);
+  if (Cout == 16) return (long)sizeof(float) * (blocks * (Cin / 32) * 4 * 1024 + blocks * 4 * 16);
   return (long)sizeof(float) * (blocks * (Cin / 32) * (Cout / 32) * 8 * 1024 + blocks * 4 * Cout);
 }
 
@@ -378,9 +520,19 @@ extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, in
   adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
   a.x = x; a.dy = dy; a.ws = (float*)workspace;
   const int blocks = adell_ctk2_blocks(a, 2);
+  hipStream_t st = (hipStream_t)stream;
+  if (Cout == 16) {
+    a.wsdb = db ? a.ws + (size_t)blocks * (Cin / 32) * 4 * 1024 : nullptr;
+    hipLaunchKernelGGL(adell_convt_k2_dw16_kernel, dim3((unsigned)blocks, (unsigned)(Cin / 32)), dim3(256),
+                       0, st, a);
+    const long outs16 = (long)Cin * 16 * 8 + (db ? 16 : 0);
+    hipLaunchKernelGGL(adell_convt_k2_dw16_reduce_kernel, dim3((unsigned)((outs16 + 3) / 4)), dim3(256),
+                       0, st, (const float*)workspace, blocks, Cin, dw, (const float*)a.wsdb, db);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   a.wsdb = db ? a.ws + (size_t)blocks * (Cin / 32) * (Cout / 32) * 8 * 1024 : nullptr;
   dim3 grid((unsigned)blocks, (unsigned)((Cin / 32) * (Cout / 32)));
-  hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adell_convt_k2_dw_kernel, grid, dim3(256), 0, st, a);
   const long outs = (long)Cin * Cout * 8 + (db ? Cout : 0);
   hipLaunchKernelGGL(adell_convt_k2_dw_reduce_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0,

@@ -18,7 +18,9 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("n,cin,cout,size", [(1, 32, 32, (32, 32, 32)), (2, 64, 32, (20, 33, 25)),
-                                              (1, 32, 64, (17, 40, 49)), (1, 64, 64, (32, 32, 33))])
+                                              (1, 32, 64, (17, 40, 49)), (1, 64, 64, (32, 32, 33)),
+                                              # 16 output channels: the (fx, co) column forms
+                                              (2, 32, 16, (20, 33, 25)), (1, 64, 16, (32, 32, 33))])
 def test_convt_k2_matches_torch_cpu(cuda, n, cin, cout, size):
     g = torch.Generator().manual_seed(cin + cout + size[0])
     x = torch.randn(n, cin, *size, generator=g).requires_grad_(True)

@@ -58,6 +58,7 @@ CASES = [  # N, C0, C1, Cout, size
     (2, 64, 0, 64, (32, 32, 32)),      # 64-column tile
     (1, 32, 32, 64, (48, 48, 44)),     # virtual concat, ragged in z
     (2, 16, 0, 16, (32, 32, 32)),      # one chunk, half-empty column tile
+    (1, 32, 0, 16, (24, 24, 24)),      # 16 x 16 weight-gradient tiles over a two-chunk rows source
 ]
 
 
