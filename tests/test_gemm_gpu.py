@@ -16,7 +16,9 @@ def rel(a, r):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (16, 1024, 768), (33, 130, 50),
                                    (128, 768, 3072), (300, 96, 384), (1024, 384, 1536),
-                                   (4099, 97, 96), (2, 2, 70000), (65, 257, 129)])
+                                   (4099, 97, 96), (2, 2, 70000), (65, 257, 129),
+                                   # ViT of UNETR (64 x 64 tiles, no split) / 128 x 128 tiles
+                                   (864, 512, 512), (864, 1536, 512), (4100, 520, 72)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_layouts_match_float64(cuda, M, N, K, layout):
     rng = np.random.default_rng(M * 131 + N * 17 + K)
