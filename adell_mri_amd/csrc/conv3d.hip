@@ -420,10 +420,36 @@ static int adell_launch_conv_ws(const ConvArgs& a, ConvF16Extra e, int items, in
   return ADELL_OK;
 }
 
+// 16 -> 16 channel layers: the z-marching 16-column kernel (conv_zring16.hip)
+extern "C" int adell_conv_zring16_ok(const ConvArgs* a);
+extern "C" void adell_conv_zring16_segments(int N, int Do, int Ho, int Wo, int* seglen, int* nseg);
+extern "C" int adell_conv_zring16_launch(const ConvArgs* a, const ConvF16Extra* e, int N, int seglen,
+                                         int nseg, hipStream_t st);
+
 // Tile plan of the f16x3 kernel: the heuristic brick, or (when its halo does not fit
 // LDS, i.e. stride 2) the small-brick configuration of the same channel width.
 static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, bool no_wide8 = false) {
   ConvTile t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, g_conv_force_cfg);
+  if (g_conv_force_cfg < 0 && adell_conv_zring16_ok(&a)) {
+    // cfg 8: units = 8 x 8 columns x z segments (ntz = segments, HZ = steps per segment); the
+    // statistics rows per item are ntx * nty * ntz like every other plan's
+    int seglen = 0, nseg = 0;
+    adell_conv_zring16_segments(N, a.Do, a.Ho, a.Wo, &seglen, &nseg);
+    t.cfg = 8;
+    t.BM = 64;
+    t.BN = 16;
+    t.lTX = 3; t.lTY = 3; t.lTZ = 0;
+    a.lTX = 3; a.lTY = 3; a.lTZ = 0;
+    a.ntx = adell_cdiv(a.Wo, 8);
+    a.nty = adell_cdiv(a.Ho, 8);
+    a.ntz = nseg;
+    a.HX = 10; a.HY = 10; a.HZ = seglen;
+    a.VP = 100;
+    a.GKH = 3;
+    *tile = t;
+    *lds_out = 0;
+    return ADELL_OK;
+  }
   // kernel == stride > 1 (transposed-conv backward-data): every staged voxel feeds one tap, so
   // the launch is bound by staging, not MFMA. 64-voxel bricks (32 KB of LDS, 4 blocks per CU)
   // overlap the staging of one block with the MFMAs of another (measured, 2 x 64^3 x 32 ->
@@ -701,7 +727,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                     !g_adell_tune.igemm_nospec;
   // split-row sources are staged by the specialised instances only (no split-K: a share would have
   // to know the rows' exponent of chunks it does not own... it could; it is simply not built)
-  const bool rows_ok = shares == 1 && ((t.cfg <= 1 && spec) || t.cfg == 4);
+  const bool rows_ok = shares == 1 && ((t.cfg <= 1 && spec) || t.cfg == 4 || t.cfg == 8);
   if (adn == -2) return rows_ok ? 1 : 0;
   if ((e.xs0 != nullptr || e.xs1 != nullptr) && !rows_ok) {
     adell_set_error("conv f16x3: this problem's launch plan does not take split-row sources "
@@ -731,6 +757,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
       default: return adell_launch_conv_f16<2, 1, 4, 1, 1, 1>(a, e, grid, lds, st);
     }
   }
+  if (t.cfg == 8) return adell_conv_zring16_launch(&a, &e, N, a.HZ, a.ntz, st);
   int rc2 = ADELL_OK;
   if (e.xs0 != nullptr || e.xs1 != nullptr) {
     // split-row sources (rows_ok above): the instance without the fp32 staging path when every

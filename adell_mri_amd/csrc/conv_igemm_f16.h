@@ -948,6 +948,7 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
   ADELL_STAMP(22);
 }
 
+#ifndef ADELL_NO_PACK_KERNELS   // (non-template kernels: defined once, in conv3d.hip's unit)
 // ---------------------------------------------------------------------------
 // Weight packing for the f16x3 kernel. One block per GEMM column n (an output
 // channel): absmax over that column's taps x K -> power-of-two scale -> hi/lo split.
@@ -1038,3 +1039,4 @@ __global__ __launch_bounds__(256) void adell_pack_weight_f16_multi_kernel(
                                (int)t[3], (int)t[4], (int)t[5], (int)t[6],
                                (int)((long)blockIdx.x - t[7]), smx);
 }
+#endif  // ADELL_NO_PACK_KERNELS

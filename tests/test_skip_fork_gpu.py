@@ -80,10 +80,17 @@ def test_fork_gradient_rides_the_downsampling_conv(cuda, monkeypatch, link_type,
     monkeypatch.setitem(ops.FLAGS, "no_skip_fork", True)
     taken.clear()
     y_a, gx_a, gw_a = _step(net, x, r)
-    assert torch.equal(y_f, y_a)
+    # (the forward is the same computation either way, but a level output with ONE reader may be
+    # handed over as split rows and with two as fp32: a conv that reads rows and one that reads the
+    # fp32 tensor agree to an ulp, not to the bit -- tools/dbg_rows16.py)
+    assert _rel(y_f, y_a) <= 1e-6
     assert _rel(gx_f, gx_a) <= 2e-5
+    # (a conv bias in front of an instance norm has a mathematically zero gradient: what is left is
+    # rounding noise of the forward, floored by the largest gradient of the net)
+    top = max(float(g.abs().max()) for g in gw_a.values())
     for k, g in gw_a.items():
-        assert _rel(gw_f[k], g) <= 2e-5, k
+        err = float((gw_f[k] - g).abs().max())
+        assert err <= max(2e-5 * float(g.abs().max()), 1e-6 * top), k
 
 
 def test_fork_is_off_under_no_grad(cuda):
@@ -116,8 +123,12 @@ def test_frozen_downsampling_conv_still_delivers_the_fork(cuda):
     finally:
         ops.FLAGS["no_skip_fork"] = False
     assert _rel(gx_f, gx_a) <= 2e-5
+    # (a conv bias in front of an instance norm has a mathematically zero gradient: what is left is
+    # rounding noise of the forward, floored by the largest gradient of the net)
+    top = max(float(g.abs().max()) for g in gw_a.values())
     for k, g in gw_a.items():
-        assert _rel(gw_f[k], g) <= 2e-5, k
+        err = float((gw_f[k] - g).abs().max())
+        assert err <= max(2e-5 * float(g.abs().max()), 1e-6 * top), k
 
 
 def _step_trainable(net, x, r):
