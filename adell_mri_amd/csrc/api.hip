@@ -44,6 +44,7 @@ static AdellTuning adell_tuning_from_env() {
   t.wgrad_no16 = adell_env_int("ADELL_WGRAD_NO16", 0);
   t.zr_oldseg = adell_env_int("ADELL_ZR_OLDSEG", 0);
   t.igemm_no16 = adell_env_int("ADELL_IGEMM_NO16", 0);
+  t.zr16_overhead = adell_env_int("ADELL_ZR16_OVERHEAD", 6);
 #ifdef ADELL_DEBUG
   t.igemm_dbg = adell_env_int("ADELL_IGEMM_DBG", 0);
   t.zr_dbg = adell_env_int("ADELL_ZR_DBG", 0);
@@ -77,6 +78,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "wgrad_no16")) return &g_adell_tune.wgrad_no16;
   if (!strcmp(name, "zr_oldseg")) return &g_adell_tune.zr_oldseg;
   if (!strcmp(name, "igemm_no16")) return &g_adell_tune.igemm_no16;
+  if (!strcmp(name, "zr16_overhead")) return &g_adell_tune.zr16_overhead;
 #ifdef ADELL_DEBUG
   if (!strcmp(name, "igemm_dbg")) return &g_adell_tune.igemm_dbg;
   if (!strcmp(name, "zr_dbg")) return &g_adell_tune.zr_dbg;

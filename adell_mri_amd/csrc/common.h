@@ -32,7 +32,8 @@ struct AdellTuning {
   int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)
   int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)
   int wgrad_no16;                 // z-ring weight gradient: 32 x 32 tiles even for 16-channel layers
-  int igemm_no16;                 // (reserved) forward / backward-data: no 16-column instance
+  int igemm_no16;                 // forward / backward-data of 16 -> 16 layers: not the z-ring 16-column kernel
+  int zr16_overhead;              // ... its segment rule: steps a unit costs besides its planes
   int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;

@@ -18,7 +18,8 @@
 // two MFMAs per tap and 16 voxels, one ds_read_b128 per A fragment (slots XOR-ed with hx & 3:
 // conflict-free for all 9 in-plane shifts, searched exhaustively). The four waves split the 27 taps
 // (their B fragments stay in registers for the whole launch) and fold their partial planes through
-// LDS in wave order. fp32 sources: one power-of-two scale per staged plane (block-wide absmax,
+// LDS in wave order (double-buffered: the fold of a plane runs after the next step's barrier, so a
+// step has ONE barrier). fp32 sources: one power-of-two scale per staged plane (block-wide absmax,
 // published one step ahead, so no extra barrier); the three kz groups of a step accumulate
 // separately and are combined with their planes' scales. Split-row sources carry their exponent.
 // Loads run CZ_PF planes ahead in registers.
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_zring16_kernel(ConvZr16Args
   const ConvF16Extra& e = args.e;
   extern __shared__ float smem[];
   char* sX = reinterpret_cast<char*>(smem);                       // [4 ring slots][100 rows][64 B]
-  float* sRed = reinterpret_cast<float*>(sX + 4 * CZ_PLANE);       // [4 waves][64 voxels][16 co]
-  float* sMax = sRed + 4 * 64 * 16;                                // [4 slots][4 waves]
+  float* sRed = reinterpret_cast<float*>(sX + 4 * CZ_PLANE);       // [2 steps][4 waves][64 voxels][16 co]
+  float* sMax = sRed + 2 * 4 * 64 * 16;                            // [4 slots][4 waves]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r = lane & 15;
 
@@ -185,6 +186,24 @@ __global__ __launch_bounds__(256, 2) void adell_conv_zring16_kernel(ConvZr16Args
   if (a.bias) bias4 = *reinterpret_cast<const float4*>(a.bias + ec);
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
 
+  // fold in wave order, weight scale, bias, residual, store, statistics. Runs one step LATE, after
+  // the next step's barrier (the partial planes are double-buffered): one barrier per step.
+  auto epilogue = [&](int z, float4 res4, const float* red) {
+    const float4 u0 = *reinterpret_cast<const float4*>(red + (0 * 64 + ev) * 16 + ec);
+    const float4 u1 = *reinterpret_cast<const float4*>(red + (1 * 64 + ev) * 16 + ec);
+    const float4 u2 = *reinterpret_cast<const float4*>(red + (2 * 64 + ev) * 16 + ec);
+    const float4 u3 = *reinterpret_cast<const float4*>(red + (3 * 64 + ev) * 16 + ec);
+    float4 v;
+    v.x = (((u0.x + u1.x) + u2.x) + u3.x) * wsc.x + bias4.x + res4.x;
+    v.y = (((u0.y + u1.y) + u2.y) + u3.y) * wsc.y + bias4.y + res4.y;
+    v.z = (((u0.z + u1.z) + u2.z) + u3.z) * wsc.z + bias4.z + res4.z;
+    v.w = (((u0.w + u1.w) + u2.w) + u3.w) * wsc.w + bias4.w + res4.w;
+    if (eok) {
+      *reinterpret_cast<float4*>(a.y0 + (erow0 + (size_t)z * a.Ho * a.Wo) * 16 + ec) = v;
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+      s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+  };
   // ---- pipeline: step i stages plane p0 + i into slot i & 3 and (i >= 2) produces plane z0 + i - 2 --
   const int nsteps = (z1 - z0) + 2;
 #pragma unroll
@@ -192,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void adell_conv_zring16_kernel(ConvZr16Args
   publish_max(xr[0], p0, 0);
   __syncthreads();
   int kA0 = 0, kA1 = 0, kA2 = 0;    // exponents of the planes of taps kz = 0, 1, 2 of the current step
+  float4 res_prev = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int ib = 0; ib < nsteps; ib += CZ_PF) {
 #pragma unroll
     for (int j = 0; j < CZ_PF; ++j) {
@@ -209,6 +229,8 @@ __global__ __launch_bounds__(256, 2) void adell_conv_zring16_kernel(ConvZr16Args
       if (i >= 2 && a.res != nullptr && eok)
         res4 = *reinterpret_cast<const float4*>(a.res + (erow0 + (size_t)z * a.Ho * a.Wo) * 16 + ec);
       __syncthreads();
+      if (i >= 3) epilogue(z - 1, res_prev, sRed + ((j + 1) & 1) * (4 * 64 * 16));   // plane of step i - 1
+      res_prev = res4;
       if (i < 2) continue;
       // ---- MFMAs: this wave's taps x 4 m-tiles (16 voxels = two rows of the plane) --------------
       f32x4 acc[3][4];
@@ -256,29 +278,13 @@ __global__ __launch_bounds__(256, 2) void adell_conv_zring16_kernel(ConvZr16Args
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr)
-          sRed[(wave * 64 + 16 * mt + 4 * g + rr) * 16 + r] =
+          sRed[(j & 1) * (4 * 64 * 16) + (wave * 64 + 16 * mt + 4 * g + rr) * 16 + r] =
               (acc[0][mt][rr] * f0 + acc[1][mt][rr] * f1) + acc[2][mt][rr] * f2;
-      __syncthreads();
-      // ---- fold in wave order, weight scale, bias, residual, store, statistics --------------------
-      {
-        const float4 u0 = *reinterpret_cast<const float4*>(sRed + (0 * 64 + ev) * 16 + ec);
-        const float4 u1 = *reinterpret_cast<const float4*>(sRed + (1 * 64 + ev) * 16 + ec);
-        const float4 u2 = *reinterpret_cast<const float4*>(sRed + (2 * 64 + ev) * 16 + ec);
-        const float4 u3 = *reinterpret_cast<const float4*>(sRed + (3 * 64 + ev) * 16 + ec);
-        float4 v;
-        v.x = (((u0.x + u1.x) + u2.x) + u3.x) * wsc.x + bias4.x + res4.x;
-        v.y = (((u0.y + u1.y) + u2.y) + u3.y) * wsc.y + bias4.y + res4.y;
-        v.z = (((u0.z + u1.z) + u2.z) + u3.z) * wsc.z + bias4.z + res4.z;
-        v.w = (((u0.w + u1.w) + u2.w) + u3.w) * wsc.w + bias4.w + res4.w;
-        if (eok) {
-          *reinterpret_cast<float4*>(a.y0 + (erow0 + (size_t)z * a.Ho * a.Wo) * 16 + ec) = v;
-          s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-          s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
-        }
-      }
-      // (the next step's barrier orders these reads of sRed before its writes)
+      // (its epilogue runs after the next step's barrier; that buffer is written again two steps on)
     }
   }
+  __syncthreads();
+  epilogue(z1 - 1, res_prev, sRed + ((nsteps - 1) & 1) * (4 * 64 * 16));   // the last plane
   if (!ROWS && e.amax_out != nullptr && tid == 0) atomicMax(e.amax_out, __float_as_uint(blockmax));
   if (a.part) {
     __syncthreads();
@@ -326,7 +332,7 @@ extern "C" void adell_conv_zring16_segments(int N, int Do, int Ho, int Wo, int* 
     if (ns != cand) continue;
     const long units = ncols * ns;
     const long blocks = units < target ? units : target;
-    const long cost = adell_cdiv((int)units, (int)blocks) * (sl + 6);
+    const long cost = adell_cdiv((int)units, (int)blocks) * (sl + g_adell_tune.zr16_overhead);
     if (best < 0 || cost < best) { best = cost; pick = cand; }
   }
   *seglen = adell_cdiv(Do, (int)pick);
@@ -342,7 +348,7 @@ extern "C" int adell_conv_zring16_launch(const ConvArgs* a, const ConvF16Extra* 
   args.e = *e;
   args.seglen = seglen;
   args.nseg = nseg;
-  const size_t lds = 4 * (size_t)CZ_PLANE + (size_t)4 * 64 * 16 * 4 + 16 * 4;
+  const size_t lds = 4 * (size_t)CZ_PLANE + (size_t)2 * 4 * 64 * 16 * 4 + 16 * 4;
   const int per_item = a->ntx * a->nty * nseg;
   dim3 grid((unsigned)(8 * ((per_item + 7) / 8)), (unsigned)N);
   if (e->xs0 != nullptr)
