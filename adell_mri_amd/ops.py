@@ -89,9 +89,15 @@ FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          "no_grad_carry": bool(os.environ.get("ADELL_NO_GRAD_CARRY")),
          "no_skip_fork": bool(os.environ.get("ADELL_NO_SKIP_FORK")),
          "no_s2fused": bool(os.environ.get("ADELL_NO_S2FUSED")),
-         # opt-in: Linear layers on the f16x3 GEMM (1.2-2x the fp32-MFMA GEMM per launch; per step
-         # -5 % VICReg ConvNeXt, -1 % UNETR, +2 % SWIN-UNet: DESIGN.md section 8)
-         "gemm_f16x3": bool(os.environ.get("ADELL_GEMM_F16X3")),
+         # Linear layers on the f16x3 GEMM (1.2-2x the fp32-MFMA GEMM per launch) when both output
+         # sides are >= 64: measured per step (bench.py secondary, alternating runs on one box) UNETR
+         # 22.6 -> 21.8 ms, VICReg ConvNeXt 27.7 -> 24.8 ms, SWIN-UNet 198 -> 197.5 ms; with every
+         # size SWIN's narrow projections (24 ... 48 wide) lose 1 %. ADELL_GEMM_F16X3=0: fp32-MFMA
+         # GEMMs everywhere; =1: every applicable size (ADELL_GEMM_F16X3_MIN_K / _MIN_MN: knobs).
+         "gemm_f16x3": os.environ.get("ADELL_GEMM_F16X3", "auto") != "0",
+         "gemm_f16x3_min_k": int(os.environ.get("ADELL_GEMM_F16X3_MIN_K", "0")),
+         "gemm_f16x3_min_mn": int(os.environ.get(
+             "ADELL_GEMM_F16X3_MIN_MN", "64" if os.environ.get("ADELL_GEMM_F16X3", "auto") == "auto" else "0")),
          "no_cin_small": bool(os.environ.get("ADELL_NO_CIN_SMALL")),
          "cin_small_all": bool(os.environ.get("ADELL_CIN_SMALL_ALL"))}
 NORM_ACT_FAMILY = "adell_norm_act_kernels"   # norm -> dropout -> activation, forward + backward
@@ -1610,7 +1616,7 @@ def absmax_word(x):
 
 
 def gemm_f16x3_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc):
-    if not FLAGS["gemm_f16x3"]:
+    if not FLAGS["gemm_f16x3"] or K < FLAGS["gemm_f16x3_min_k"] or min(M, N) < FLAGS["gemm_f16x3_min_mn"]:
         return False
     return bool(_lib.lib().adell_gemm_f16x3_applicable(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb,
                                                        int(b_kc)))

@@ -1,7 +1,8 @@
 """f16x3 GEMM (csrc/gemm_f16x3.hip): the three operand layouts of a Linear layer (forward X W^T,
 backward-data dY W, backward-weight dY^T X), ragged tiles, split-K, bias / residual epilogue and
-extreme operand scales, against fp64; HF.linear takes it when ops.FLAGS["gemm_f16x3"] is set (opt-in) and
-falls back to the fp32-MFMA GEMM when the operands do not qualify."""
+extreme operand scales, against fp64; HF.linear takes it when ops.FLAGS["gemm_f16x3"] is set (the
+default, for outputs of at least 64 x 64: ops.FLAGS["gemm_f16x3_min_mn"]) and falls back to the
+fp32-MFMA GEMM when the operands do not qualify."""
 import pytest
 import torch
 
@@ -13,6 +14,8 @@ def _opt_in(monkeypatch):
     from adell_mri_amd import ops
 
     monkeypatch.setitem(ops.FLAGS, "gemm_f16x3", True)
+    monkeypatch.setitem(ops.FLAGS, "gemm_f16x3_min_mn", 0)     # every size: the kernel is under test
+    monkeypatch.setitem(ops.FLAGS, "gemm_f16x3_min_k", 0)
 
 
 def _rel(a, b):
@@ -119,7 +122,13 @@ def test_linear_takes_the_f16x3_gemm_and_matches_torch(cuda, monkeypatch):
     w5 = torch.randn(12, 5, generator=g).to(cuda).requires_grad_(True)
     HF.linear(x5, w5).sum().backward()
     assert calls == [] and x5.grad is not None and w5.grad is not None
-    # and not at all without the opt-in
+    # the default size rule: narrow outputs (SWIN's 24 ... 48-wide projections) stay on the fp32 GEMM
+    monkeypatch.setitem(ops.FLAGS, "gemm_f16x3_min_mn", 64)
+    xn = torch.randn(3, 40, 96, generator=g).to(cuda).requires_grad_(True)
+    wn = (torch.randn(48, 96, generator=g) / 10).to(cuda).requires_grad_(True)
+    HF.linear(xn, wn).sum().backward()
+    assert calls == []          # (the forward's shape decides for the layer's three GEMMs)
+    # and not at all when switched off
     monkeypatch.setitem(ops.FLAGS, "gemm_f16x3", False)
     HF.linear(xd, wd, bd).sum().backward()
     assert calls == []
