@@ -196,28 +196,47 @@ __global__ __launch_bounds__(256) void adell_dw_tile_kernel(DwTileArgs a) {
                                           tid);
   __syncthreads();
   const int c = tid & 15, row = tid >> 4, rz = row >> 2, ry = row & 3;
-  float acc[WT];
+  // Packed fp32 FMAs (v_pk_fma_f32, two outputs per issue: the kernel is bound by vector-ALU issue,
+  // 2 K^3 flops per output). Output pair m = (2m, 2m + 1) and tap shift s = kx - P read the input
+  // pair starting at 2m + s: an even-aligned pair E for even s, an odd-aligned pair O for odd s --
+  // both sets are assembled once per (kz, ky) and shared by the K taps along x.
+  typedef float dw_f2 __attribute__((ext_vector_type(2)));
+  static_assert(WT % 2 == 0, "x segment in output pairs");
+  dw_f2 acc2[WT / 2];
   const float bias = (a.b && c0 + c < t.C) ? a.b[c0 + c] : 0.f;
 #pragma unroll
-  for (int j = 0; j < WT; ++j) acc[j] = bias;
+  for (int m = 0; m < WT / 2; ++m) acc2[m] = dw_f2{bias, bias};
 #pragma unroll 1
   for (int kz = 0; kz < K; ++kz) {
 #pragma unroll 1
     for (int ky = 0; ky < K; ++ky) {
-      float in[WT], wk[K];
       const float* xr = xt + ((rz + kz) * Cf::HY + ry + ky) * Cf::RS + c;
       const float* wr = wt + (kz * K + ky) * K * 16 + c;
+      // both pair sets straight from LDS (two dwords per ds_read2_b32): assembling the odd pairs
+      // from the even ones cost six v_mov per packed FMA
+      dw_f2 E[WT / 2], O[WT / 2 + 1];      // E[i] = (in[2i], in[2i+1]); O[i] = (in[2i-1], in[2i])
+      float wk[K];
 #pragma unroll
-      for (int j = 0; j < WT; ++j) in[j] = xr[j * 16];
+      for (int i = 0; i < WT / 2; ++i) E[i] = dw_f2{xr[(2 * i) * 16], xr[(2 * i + 1) * 16]};
+#pragma unroll
+      for (int i = 0; i <= WT / 2; ++i)
+        O[i] = dw_f2{i > 0 ? xr[(2 * i - 1) * 16] : 0.f, i < WT / 2 ? xr[(2 * i) * 16] : 0.f};
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) wk[kx] = wr[kx * 16];
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx)
+      for (int kx = 0; kx < K; ++kx) {
+        const dw_f2 w2 = dw_f2{wk[kx], wk[kx]};
+        const int sft = kx - Cf::P;
 #pragma unroll
-        for (int j = 0; j < WT; ++j) {
-          const int jj = j + kx - Cf::P;
-          if (jj >= 0 && jj < WT) acc[j] = fmaf(wk[kx], in[jj], acc[j]);
+        for (int m = 0; m < WT / 2; ++m) {
+          const int start = 2 * m + sft;           // first input of the pair (compile-time)
+          if (start < -1 || start > WT - 1) continue;   // both inputs outside the row
+          if ((start & 1) == 0)
+            acc2[m] = __builtin_elementwise_fma(w2, E[start / 2], acc2[m]);
+          else
+            acc2[m] = __builtin_elementwise_fma(w2, O[(start + 1) / 2], acc2[m]);
         }
+      }
     }
   }
   const int z = z0 + rz, y = y0 + ry;
@@ -227,7 +246,8 @@ __global__ __launch_bounds__(256) void adell_dw_tile_kernel(DwTileArgs a) {
 #pragma unroll
     for (int j = 0; j < WT; ++j) {
       const int x = xin0 + j;
-      if (j >= jlo && j < jlo + t.seg && x < t.W) out[(size_t)x * t.C] = acc[j];
+      if (j >= jlo && j < jlo + t.seg && x < t.W)
+        out[(size_t)x * t.C] = (j & 1) ? acc2[j / 2].y : acc2[j / 2].x;
     }
   }
 }
@@ -608,6 +628,108 @@ __global__ __launch_bounds__(1024) void adell_vicreg_fwd_kernel(
   }
 }
 
+// ---- the same forward on many blocks (B <= 64): a block owns a chunk of 128 feature columns ------
+// (the one-block kernel above took 1.0 ms of the VICReg ConvNeXt step at B = 32: B^2 D products on
+// one CU). Pass 1: per chunk and view the column means / variances, the centred chunk in LDS and its
+// B x B partial Gram matrix; pass 2 (one block) folds the partials in block order (deterministic).
+// scratch (after the 4 D + 2 B^2 floats the backward reads): [2 views][nblk][B^2] partial Gram
+// matrices, then [nblk][4] partial (hinge, var^2, inv, -).
+constexpr int VIC_CH = 128, VIC_MAXB = 64;
+__global__ __launch_bounds__(256) void adell_vicreg_fwd_chunk_kernel(
+    const float* __restrict__ x1, const float* __restrict__ x2, int B, int D, float min_var,
+    float eps, float* __restrict__ scratch) {
+  extern __shared__ float vsm[];            // [B][VIC_CH + 1] centred values of the chunk
+  __shared__ float sh[16];
+  const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
+  const int j0 = blk * VIC_CH, j = j0 + tid;
+  const bool col = tid < VIC_CH && j < D;
+  const float* xs[2] = {x1, x2};
+  float* gpart = scratch + 4L * D + 2L * B * B;
+  float* part = gpart + 2L * nblk * B * B + (long)blk * 4;
+  float hinge = 0.f, var2 = 0.f, inv = 0.f;
+  for (int view = 0; view < 2; ++view) {
+    const float* x = xs[view];
+    float* mean = scratch + view * 2 * D;
+    float* var = mean + D;
+    if (tid < VIC_CH) {
+      float m = 0.f, v = 0.f;
+      if (col) {
+        for (int b = 0; b < B; ++b) m += x[(size_t)b * D + j];
+        m /= (float)B;
+        for (int b = 0; b < B; ++b) {
+          const float d = x[(size_t)b * D + j] - m;
+          v += d * d;
+          vsm[b * (VIC_CH + 1) + tid] = d;
+        }
+        v /= (float)(B - 1);
+        mean[j] = m;
+        var[j] = v;
+        hinge += fmaxf(min_var - sqrtf(v + eps), 0.f);
+        var2 += v * v;
+      } else {
+        for (int b = 0; b < B; ++b) vsm[b * (VIC_CH + 1) + tid] = 0.f;
+      }
+    }
+    __syncthreads();
+    float* G = gpart + ((long)view * nblk + blk) * B * B;
+    for (int p = tid; p < B * B; p += 256) {
+      const int a = p / B, b = p - a * B;
+      const float* ra = vsm + a * (VIC_CH + 1);
+      const float* rb = vsm + b * (VIC_CH + 1);
+      float g = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < VIC_CH; ++q) g += ra[q] * rb[q];
+      G[p] = g;
+    }
+    __syncthreads();
+  }
+  if (col)
+    for (int b = 0; b < B; ++b) {
+      const float d = x1[(size_t)b * D + j] - x2[(size_t)b * D + j];
+      inv += d * d;
+    }
+  hinge = adell_block_sum(hinge, sh);
+  var2 = adell_block_sum(var2, sh);
+  inv = adell_block_sum(inv, sh);
+  if (tid == 0) {
+    part[0] = hinge;
+    part[1] = var2;
+    part[2] = inv;
+    part[3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void adell_vicreg_fwd_fold_kernel(int B, int D, int nblk,
+                                                                    float* __restrict__ scratch,
+                                                                    float* __restrict__ out) {
+  __shared__ float sh[16];
+  const float* gpart = scratch + 4L * D + 2L * B * B;
+  const float* part = gpart + 2L * nblk * B * B;
+  float g2 = 0.f;
+  for (int view = 0; view < 2; ++view) {
+    float* G = scratch + 4 * D + (size_t)view * B * B;
+    for (int p = threadIdx.x; p < B * B; p += blockDim.x) {
+      float g = 0.f;
+      for (int k = 0; k < nblk; ++k) g += gpart[((long)view * nblk + k) * B * B + p];
+      G[p] = g;
+      g2 += g * g;
+    }
+  }
+  g2 = adell_block_sum(g2, sh);
+  if (threadIdx.x == 0) {
+    float hinge = 0.f, var2 = 0.f, inv = 0.f;
+    for (int k = 0; k < nblk; ++k) {
+      hinge += part[4 * k];
+      var2 += part[4 * k + 1];
+      inv += part[4 * k + 2];
+    }
+    const float bm1 = (float)(B - 1);
+    out[0] = inv / ((float)B * (float)D);
+    out[1] = 0.5f * hinge / (float)D;
+    out[2] = 0.5f * (g2 / (bm1 * bm1) - var2) / (float)D;
+  }
+}
+
 // dX_v = g_inv * d inv/dX_v + g_var * d var/dX_v + g_cov * d cov/dX_v
 __global__ __launch_bounds__(256) void adell_vicreg_bwd_kernel(
     const float* __restrict__ x1, const float* __restrict__ x2, int B, int D, float min_var,
@@ -638,12 +760,29 @@ __global__ __launch_bounds__(256) void adell_vicreg_bwd_kernel(
   }
 }
 
-extern "C" long adell_vicreg_scratch_floats(int B, int D) { return 4L * D + 2L * B * B; }
+static int adell_vicreg_chunks(int B, int D) {
+  return (B <= VIC_MAXB && D >= 2 * VIC_CH) ? (D + VIC_CH - 1) / VIC_CH : 0;   // 0: the one-block kernel
+}
+
+extern "C" long adell_vicreg_scratch_floats(int B, int D) {
+  const long nblk = adell_vicreg_chunks(B, D);
+  return 4L * D + 2L * B * B + nblk * (2L * B * B + 4);
+}
 
 extern "C" int adell_vicreg_fwd(const float* x1, const float* x2, int B, int D, float min_var,
                                 float eps, float* scratch, float* out3, void* stream) {
   ADELL_REQUIRE(x1 && x2 && scratch && out3, "vicreg_fwd: null pointer");
   ADELL_REQUIRE(B > 1 && D > 0, "vicreg_fwd: need B > 1, D > 0");
+  const int nblk = adell_vicreg_chunks(B, D);
+  if (nblk > 0) {
+    const size_t lds = (size_t)B * (VIC_CH + 1) * sizeof(float);
+    hipLaunchKernelGGL(adell_vicreg_fwd_chunk_kernel, dim3((unsigned)nblk), dim3(256), lds,
+                       (hipStream_t)stream, x1, x2, B, D, min_var, eps, scratch);
+    hipLaunchKernelGGL(adell_vicreg_fwd_fold_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, D,
+                       nblk, scratch, out3);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   hipLaunchKernelGGL(adell_vicreg_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x1, x2, B,
                      D, min_var, eps, scratch, out3);
   ADELL_CHECK_HIP(hipGetLastError());

@@ -163,7 +163,8 @@ def test_vicreg_loss_terms_and_grads_match_reference(cuda):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,D", [(2, 7), (16, 1024), (5, 300)])
+# (B <= 64 and D >= 256: the forward on one block per 128 feature columns + a fold; else one block)
+@pytest.mark.parametrize("B,D", [(2, 7), (16, 1024), (5, 300), (32, 2048), (64, 520), (65, 512)])
 def test_vicreg_loss_matches_oracle_at_other_sizes(cuda, B, D):
     from adell_mri_amd.modules.self_supervised.losses import VICRegLoss
 

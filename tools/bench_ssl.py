@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ema", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="per (kernel, shape) table instead of the JSON line")
     args = ap.parse_args()
     from adell_mri_amd import ops
     from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
@@ -57,6 +58,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    if args.layers:
+        tags = timer.by_tag()
+        tot = sum(v["ms"] for v in tags.values())
+        print(f"{1e3 * dt / args.steps:.2f} ms/step, timed kernels {tot / args.steps:.2f} ms/step")
+        for (name, tag), v in sorted(tags.items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            print(f"{v['ms'] / args.steps:7.3f} ms {100 * v['ms'] / tot:5.1f}% {v['tflops']:7.1f} TF "
+                  f"x{v['launches'] // args.steps:3d}  {name.replace('adell_', '')}  {tag}")
+        return
     print(json.dumps({"workload": f"VICReg ConvNeXt-3D {args.size}^3 batch {args.batch}",
                       "params": sum(p.numel() for p in net.parameters() if p.requires_grad),
                       "ms_per_step": 1e3 * dt / args.steps,
