@@ -221,6 +221,108 @@ __global__ __launch_bounds__(256) void adell_gemm_reduce_flat_kernel(GemmArgs a)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Linear layers with a handful of features over millions of rows (SWIN-UNet's per-voxel 2 -> 8 -> 2
+// and 8 -> 32 layers at 256 x 256 x 128: 8.4 M rows). They are streaming operations -- 335 MB for
+// 2 -> 8 at 8.4 M rows -- that ran 0.7-1.0 ms each on 128-wide MFMA tiles (0.3-0.5 TB/s).
+//   rows kernel:  C[m][n] = sum_k A[m][k] B(k, n)   K, N <= 32, A row-major: a thread per row,
+//                 the weights in LDS (broadcast reads), 16-byte loads / stores when K / N allow;
+//   tall kernel:  C[m][n] = sum_k A[k][m] B[k][n]   M, N <= 32, K rows long (the weight gradient):
+//                 lane = (m, row group), N accumulators per lane, block partials folded in block
+//                 order by adell_gemm_reduce_kernel (deterministic).
+constexpr int GEMM_SMALL = 32;
+
+template <bool BKC>
+__global__ __launch_bounds__(256) void adell_gemm_rows_small_kernel(GemmArgs a) {
+  // a thread per OUTPUT element (m, n): the N lanes of a row read the same K inputs (one
+  // transaction, broadcast) and store N contiguous floats; weights [n][k] and bias in LDS
+  __shared__ float sw[GEMM_SMALL * GEMM_SMALL + GEMM_SMALL];
+  const int K = a.K, N = a.N;
+  for (int i = threadIdx.x; i < N * K; i += 256) {
+    const int n = i / K, k = i - n * K;
+    sw[i] = BKC ? a.B[(long)n * a.ldb + k] : a.B[(long)k * a.ldb + n];
+  }
+  for (int i = threadIdx.x; i < N; i += 256) sw[GEMM_SMALL * GEMM_SMALL + i] = a.bias ? a.bias[i] : 0.f;
+  __syncthreads();
+  const bool vk = a.a_vec && (K & 3) == 0;
+  const long total = (long)a.M * N;
+  for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+    const long m = e / N;
+    const int n = (int)(e - m * N);
+    const float* ar = a.A + m * a.lda;
+    const float* wr = sw + n * K;
+    float s = sw[GEMM_SMALL * GEMM_SMALL + n];
+    if (vk) {
+      for (int k = 0; k < K; k += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ar + k);
+        s = fmaf(v.x, wr[k], s);
+        s = fmaf(v.y, wr[k + 1], s);
+        s = fmaf(v.z, wr[k + 2], s);
+        s = fmaf(v.w, wr[k + 3], s);
+      }
+    } else {
+      for (int k = 0; k < K; ++k) s = fmaf(ar[k], wr[k], s);
+    }
+    if (a.residual) s += a.residual[m * a.ldr + n];
+    a.C[m * a.ldc + n] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_gemm_tall_small_kernel(GemmArgs a) {
+  __shared__ float red[256 * GEMM_SMALL];
+  const int M = a.M, N = a.N;
+  const int groups = 256 / M;                 // row groups of a block (lanes past groups * M idle)
+  const int m = threadIdx.x % M, grp = threadIdx.x / M;
+  const bool active = grp < groups;
+  float acc[GEMM_SMALL];
+#pragma unroll
+  for (int n = 0; n < GEMM_SMALL; ++n) acc[n] = 0.f;
+  // rows of this block: a contiguous range (k0 .. k1), dealt to the row groups in turn
+  const long per = ((long)a.K + gridDim.x - 1) / gridDim.x;
+  const long k0 = (long)blockIdx.x * per, k1 = (k0 + per) < a.K ? (k0 + per) : a.K;
+  const bool vn = a.b_vec && (N & 3) == 0;
+  if (active)
+#pragma unroll 4
+    for (long k = k0 + grp; k < k1; k += groups) {
+      const float av = a.A[k * a.lda + m];
+      const float* br = a.B + k * a.ldb;
+      if (vn) {
+#pragma unroll
+        for (int q = 0; q < GEMM_SMALL / 4; ++q)
+          if (4 * q < N) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(br + 4 * q);
+            acc[4 * q] = fmaf(av, v.x, acc[4 * q]);
+            acc[4 * q + 1] = fmaf(av, v.y, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(av, v.z, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(av, v.w, acc[4 * q + 3]);
+          }
+      } else {
+#pragma unroll
+        for (int n = 0; n < GEMM_SMALL; ++n)
+          if (n < N) acc[n] = fmaf(av, br[n], acc[n]);
+      }
+    }
+#pragma unroll
+  for (int n = 0; n < GEMM_SMALL; ++n)
+    if (n < N) red[threadIdx.x * GEMM_SMALL + n] = active ? acc[n] : 0.f;
+  __syncthreads();
+  // fold the row groups in order; one partial [M][N] per block
+  for (int i = threadIdx.x; i < M * N; i += 256) {
+    const int mm = i / N, n = i - mm * N;
+    float s = 0.f;
+    for (int g = 0; g < groups; ++g) s += red[(g * M + mm) * GEMM_SMALL + n];
+    a.slab[((long)blockIdx.x * M + mm) * N + n] = s;
+  }
+}
+
+static int adell_gemm_tall_blocks(int M, int N, int K) {
+  if (M > GEMM_SMALL || N > GEMM_SMALL || K < 16384) return 0;
+  long b = K / 512;
+  if (b > 1024) b = 1024;
+  if (b < 2) b = 2;
+  return (int)b;
+}
+
 struct GemmPlan {
   int skinny;  // 32 x 128 tile instead of 128 x 128
   int BM, BN, splits, ksteps_per_split;
@@ -251,7 +353,10 @@ static GemmPlan adell_gemm_plan(int M, int N, int K) {
 extern "C" long adell_gemm_f32_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const GemmPlan p = adell_gemm_plan(M, N, K);
-  return p.splits > 1 ? (long)p.splits * M * N : 0;
+  long need = p.splits > 1 ? (long)p.splits * M * N : 0;
+  // (the layout decides at launch whether the tall small-output kernel runs: room for either)
+  const long tall = (long)adell_gemm_tall_blocks(M, N, K) * M * N;
+  return need > tall ? need : tall;
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -281,7 +386,13 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   ADELL_REQUIRE(lda >= (a_kc ? K : M) && ldb >= (b_kc ? K : N) && ldc >= N, "gemm: bad strides");
   ADELL_REQUIRE(!residual || ldr >= N, "gemm: bad residual stride");
   const GemmPlan p = adell_gemm_plan(M, N, K);
-  ADELL_REQUIRE(p.splits == 1 || workspace, "gemm: workspace required for this shape");
+  const int tall = (!a_kc && !b_kc && !g_adell_tune.gemm_nosmall) ? adell_gemm_tall_blocks(M, N, K) : 0;
+  // (measured on SWIN-UNet's shapes: 10x / 5x for 8 -> 2 / 2 -> 8 features at 8.4 M rows; from
+  // N K = 256 on the MFMA tiles are as fast or faster, 32 x 8 at 2 M rows 180 vs 250 us)
+  const bool rows_small = a_kc && K <= GEMM_SMALL && N <= GEMM_SMALL && (long)N * K <= 64 && M >= 65536 &&
+                          !g_adell_tune.gemm_nosmall;
+  ADELL_REQUIRE(rows_small || (tall ? workspace != nullptr : (p.splits == 1 || workspace)),
+                "gemm: workspace required for this shape");
   GemmArgs a;
   a.A = A; a.B = B; a.C = C; a.bias = bias; a.residual = residual; a.slab = workspace;
   a.M = M; a.N = N; a.K = K;
@@ -291,6 +402,24 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   a.a_vec = ((uintptr_t)A % 16 == 0) && (lda % 4 == 0);
   a.b_vec = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0);
   hipStream_t st = (hipStream_t)stream;
+  if (rows_small) {
+    long blocks = ((long)M * N + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (b_kc)
+      hipLaunchKernelGGL(adell_gemm_rows_small_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL(adell_gemm_rows_small_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
+  if (tall) {
+    a.splits = tall;
+    hipLaunchKernelGGL(adell_gemm_tall_small_kernel, dim3((unsigned)tall), dim3(256), 0, st, a);
+    const long blocks = ((long)M * N + 63) / 64;
+    hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   dim3 grid(adell_cdiv(M, p.BM), adell_cdiv(N, p.BN), p.splits);
   ADELL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm: grid too large");
   int rc = p.skinny ? adell_gemm_launch<1, 4, 1, 1>(a, a_kc, b_kc, grid, st)

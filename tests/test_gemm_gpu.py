@@ -18,7 +18,10 @@ def rel(a, r):
                                    (128, 768, 3072), (300, 96, 384), (1024, 384, 1536),
                                    (4099, 97, 96), (2, 2, 70000), (65, 257, 129),
                                    # ViT of UNETR (64 x 64 tiles, no split) / 128 x 128 tiles
-                                   (864, 512, 512), (864, 1536, 512), (4100, 520, 72)])
+                                   (864, 512, 512), (864, 1536, 512), (4100, 520, 72),
+                                   # a handful of features over many rows: the streaming kernels
+                                   (70000, 8, 2), (70001, 2, 8), (66000, 32, 8), (65540, 12, 5),
+                                   (2, 8, 70000), (8, 32, 20000), (32, 32, 16400), (5, 3, 33000)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_layouts_match_float64(cuda, M, N, K, layout):
     rng = np.random.default_rng(M * 131 + N * 17 + K)

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--layers", action="store_true", help="per (kernel, shape) table instead of the JSON line")
     args = ap.parse_args()
     from adell_mri_amd import ops
     from adell_mri_amd.modules.activations import activation_factory
@@ -63,6 +64,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+    if args.layers:
+        tags = timer.by_tag()
+        tot = sum(v["ms"] for v in tags.values())
+        print(f"timed kernels {tot / args.steps:.2f} ms/step")
+        for (name, tag), v in sorted(tags.items(), key=lambda kv: -kv[1]["ms"])[:45]:
+            print(f"{v['ms'] / args.steps:7.3f} ms {100 * v['ms'] / tot:5.1f}% {v['tflops']:7.1f} TF "
+                  f"x{v['launches'] // args.steps:3d}  {name.replace('adell_', '')}  {tag}")
+        return
     print(json.dumps({"workload": f"SWIN-UNet {args.size} batch {args.batch}",
                       "params": sum(p.numel() for p in net.parameters()),
                       "ms_per_step": 1e3 * dt / args.steps,
