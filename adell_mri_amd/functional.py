@@ -42,7 +42,7 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          # an ADN output whose only reader is a 3x3x3 stride-1 conv is written as SPLIT ROWS (the
          # conv kernels' LDS row image: ops.SplitRows) instead of fp32; ADELL_NO_ROWS=1: always fp32
          "no_rows": bool(os.environ.get("ADELL_NO_ROWS")),
-         # 1x1x1 stride-1 convolutions with >= 64 channels on both sides stay on the implicit-GEMM
+         # 1x1x1 stride-1 convolutions with >= 64 channels on one side (>= 8 on the other) stay on the implicit-GEMM
          # conv kernels instead of the Linear-layer GEMMs (conv3d)
          "no_pointwise_gemm": bool(os.environ.get("ADELL_NO_POINTWISE_GEMM"))}
 
@@ -821,8 +821,8 @@ def conv3d(x0, weight, bias=None, stride=1, padding=0, x1=None, residual=None, w
     if (weight.dim() == 5 and tuple(weight.shape[2:]) == (1, 1, 1) and stride == (1, 1, 1)
             and padding == (0, 0, 0) and x1 is None and residual is None and carry_in is None
             and carry_out is None and carry_x0 is None and carry_cat is None and x0.dim() == 5
-            and getattr(x0, "_adell_rows", None) is None and min(weight.shape[:2]) >= 64
-            and not FLAGS["no_pointwise_gemm"]):
+            and getattr(x0, "_adell_rows", None) is None and max(weight.shape[:2]) >= 64
+            and min(weight.shape[:2]) >= 8 and not FLAGS["no_pointwise_gemm"]):
         xr = ops.ndhwc(x0)
         N, C, D, H, W = xr.shape
         y2 = linear(xr.permute(0, 2, 3, 4, 1).reshape(-1, C), weight.view(weight.shape[0], C), bias)
