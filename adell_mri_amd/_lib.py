@@ -165,6 +165,11 @@ SIGNATURES = {
     "adell_convt_k2_bwd_data": (_i, [_i] * 6 + [_vp] * 4),
     "adell_convt_k2_wgrad_workspace": (_l, [_i] * 6),
     "adell_convt_k2_bwd_weight": (_i, [_i] * 6 + [_vp] * 5 + [ctypes.c_size_t, _vp]),
+    "adell_convt_k221_applicable": (_i, [_i] * 6),
+    "adell_convt_k221_fwd": (_i, [_i] * 6 + [_vp] * 5),
+    "adell_convt_k221_bwd_data": (_i, [_i] * 6 + [_vp] * 4),
+    "adell_convt_k221_wgrad_workspace": (_l, [_i] * 6),
+    "adell_convt_k221_bwd_weight": (_i, [_i] * 6 + [_vp] * 5 + [ctypes.c_size_t, _vp]),
     "adell_conv_cinfold_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_ntiles": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_fwd": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5 + [_i, _vp]),

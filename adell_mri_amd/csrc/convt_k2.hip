@@ -24,6 +24,7 @@ struct ConvTK2Args {
   float* ws;          // dW partials [blocks][pairs][8 f][32 ci][32 co]
   float* wsdb;        // db partials [blocks][4 waves][Cout] or null
   int N, D, H, W, Cin, Cout;
+  int FX;             // factor along x: 2, or 1 (factors (2, 2, 1): the fine grid keeps W)
   long V;             // N D H W
   int ntiles;         // ceil(V / 32)
 };
@@ -35,7 +36,7 @@ __device__ __forceinline__ size_t adell_ctk2_fine(const ConvTK2Args& a, long v64
   const unsigned t1 = v / W, x = v - t1 * W;
   const unsigned t2 = t1 / H, y = t1 - t2 * H;
   const unsigned n = t2 / D, z = t2 - n * D;
-  return (((size_t)n * 2 * D + 2 * z + fz) * 2 * H + 2 * y + fy) * 2 * W + 2 * x;
+  return (((size_t)n * 2 * D + 2 * z + fz) * 2 * H + 2 * y + fy) * (size_t)(a.FX * W) + (size_t)a.FX * x;
 }
 
 __device__ __forceinline__ size_t adell_ctk2_shfl(size_t v, int src) {
@@ -118,19 +119,19 @@ __global__ __launch_bounds__(256) void adell_convt_k2_fwd16_kernel(ConvTK2Args a
   }
 }
 
-// ---- forward: grid (blocks, Cout / 32); wave w = (fz, fy), both fx ------------------------------
-template <int CIN>
+// ---- forward: grid (blocks, Cout / 32); wave w = (fz, fy), both fx (FX = 1: the one) -----------
+template <int CIN, int FX = 2>
 __global__ __launch_bounds__(256) void adell_convt_k2_fwd_kernel(ConvTK2Args a) {
-  constexpr int LD = CIN + 1, KS = CIN / 2;
+  constexpr int LD = CIN + 1, KS = CIN / 2, F = 4 * FX;
   __shared__ float sx[4][32 * LD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const int fz = wave >> 1, fy = wave & 1, n0 = blockIdx.y * 32, col = n0 + li;
-  float bw[2][KS];
+  float bw[FX][KS];
 #pragma unroll
-  for (int fx = 0; fx < 2; ++fx)
+  for (int fx = 0; fx < FX; ++fx)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      bw[fx][s] = a.w[((size_t)(2 * s + lh) * a.Cout + col) * 8 + (fz * 2 + fy) * 2 + fx];
+      bw[fx][s] = a.w[((size_t)(2 * s + lh) * a.Cout + col) * F + (fz * 2 + fy) * FX + fx];
   const float bcol = a.bias ? a.bias[col] : 0.f;
   float* tile = sx[wave];
   CtK2Regs<CIN> regs;
@@ -147,16 +148,16 @@ __global__ __launch_bounds__(256) void adell_convt_k2_fwd_kernel(ConvTK2Args a) 
     const size_t yrow = li < valid ? adell_ctk2_fine(a, v0 + li, fz, fy) : 0;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done
     if (t + (int)gridDim.x < a.ntiles) fetch(t + gridDim.x);   // in flight under the MFMAs / stores
-    f32x16 acc[2];
+    f32x16 acc[FX];
 #pragma unroll
-    for (int fx = 0; fx < 2; ++fx)
+    for (int fx = 0; fx < FX; ++fx)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[fx][r] = 0.f;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const float av = tile[li * LD + 2 * s + lh];
 #pragma unroll
-      for (int fx = 0; fx < 2; ++fx)
+      for (int fx = 0; fx < FX; ++fx)
         acc[fx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[fx][s], acc[fx], 0, 0, 0);
     }
 #pragma unroll
@@ -165,16 +166,16 @@ __global__ __launch_bounds__(256) void adell_convt_k2_fwd_kernel(ConvTK2Args a) 
       if (row < valid) {
         float* o = a.y + adell_ctk2_shfl(yrow, row) * a.Cout + col;
         o[0] = acc[0][r] + bcol;
-        o[a.Cout] = acc[1][r] + bcol;
+        if constexpr (FX == 2) o[a.Cout] = acc[1][r] + bcol;
       }
     }
   }
 }
 
 // ---- backward-data: grid (blocks, Cin / 32); wave w = (fz, fy) owns a K slice of 2 Cout ---------
-template <int COUT>
+template <int COUT, int FX = 2>
 __global__ __launch_bounds__(256) void adell_convt_k2_dx_kernel(ConvTK2Args a) {
-  constexpr int KW = 2 * COUT, LD = KW + 1, KS = KW / 2;
+  constexpr int KW = FX * COUT, LD = KW + 1, KS = KW / 2, F = 4 * FX;
   extern __shared__ float smem[];
   float* sred = smem + 4 * 32 * LD;   // [3][32][33] partial tiles of waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dx_kernel(ConvTK2Args a) {
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int k = 2 * s + lh, fx = k / COUT, co = k - fx * COUT;
-    bw[s] = a.w[((size_t)ci * COUT + co) * 8 + (fz * 2 + fy) * 2 + fx];
+    bw[s] = a.w[((size_t)ci * COUT + co) * F + (fz * 2 + fy) * FX + fx];
   }
   float* tile = smem + wave * 32 * LD;
   CtK2Regs<KW> regs;
@@ -228,6 +229,7 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dx_kernel(ConvTK2Args a) {
 }
 
 // ---- weight gradient: grid (blocks, (Cin / 32) (Cout / 32)); wave w = (fz, fy), both fx --------
+template <int FX = 2>
 __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
   constexpr int LDX = 33, LDY = 65;
   __shared__ float sx[4][32 * LDX];
@@ -235,9 +237,9 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
   const int fz = wave >> 1, fy = wave & 1;
   const int nct = a.Cout / 32, ci0 = (blockIdx.y / nct) * 32, co0 = (blockIdx.y % nct) * 32;
-  f32x16 acc[2];
+  f32x16 acc[FX];
 #pragma unroll
-  for (int fx = 0; fx < 2; ++fx)
+  for (int fx = 0; fx < FX; ++fx)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[fx][r] = 0.f;
   float* tx = sx[wave];
@@ -254,20 +256,20 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
     adell_ctk2_fetch<32>(rx, valid, lane, a.x + (size_t)v0 * a.Cin + ci0, (size_t)li * a.Cin);
     // the two fine-grid voxels (fx = 0, 1) of a coarse voxel are adjacent rows of Cout floats
     adell_ctk2_fetch<32>(ry0, valid, lane, a.dy, yrow, co0);
-    adell_ctk2_fetch<32>(ry1, valid, lane, a.dy, yrow, a.Cout + co0);
+    if constexpr (FX == 2) adell_ctk2_fetch<32>(ry1, valid, lane, a.dy, yrow, a.Cout + co0);
   };
   if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     adell_ctk2_put<32>(tx, LDX, lane, rx);
     adell_ctk2_put<32>(tyl, LDY, lane, ry0);
-    adell_ctk2_put<32>(tyl + 32, LDY, lane, ry1);
+    if constexpr (FX == 2) adell_ctk2_put<32>(tyl + 32, LDY, lane, ry1);
     if (do_db) {
 #pragma unroll
       for (int u = 0; u < CtK2Regs<32>::PER; ++u) {
-        dbacc.x += ry0.f[u].x + ry1.f[u].x;
-        dbacc.y += ry0.f[u].y + ry1.f[u].y;
-        dbacc.z += ry0.f[u].z + ry1.f[u].z;
-        dbacc.w += ry0.f[u].w + ry1.f[u].w;
+        dbacc.x += ry0.f[u].x; dbacc.y += ry0.f[u].y; dbacc.z += ry0.f[u].z; dbacc.w += ry0.f[u].w;
+        if constexpr (FX == 2) {
+          dbacc.x += ry1.f[u].x; dbacc.y += ry1.f[u].y; dbacc.z += ry1.f[u].z; dbacc.w += ry1.f[u].w;
+        }
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -277,19 +279,19 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_kernel(ConvTK2Args a) {
       const int v = 2 * s + lh;
       const float av = tx[v * LDX + li];                 // A[i = ci][k = v]
 #pragma unroll
-      for (int fx = 0; fx < 2; ++fx)
+      for (int fx = 0; fx < FX; ++fx)
         acc[fx] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tyl[v * LDY + fx * 32 + li], acc[fx],
                                                         0, 0, 0);
     }
   }
-  // every wave owns its own two f: no fold inside the block
-  float* out = a.ws + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8) * 1024;
+  // every wave owns its own FX sub-positions: no fold inside the block
+  float* out = a.ws + (((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (4 * FX)) * 1024;
 #pragma unroll
-  for (int fx = 0; fx < 2; ++fx)
+  for (int fx = 0; fx < FX; ++fx)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;   // ci
-      out[(size_t)((fz * 2 + fy) * 2 + fx) * 1024 + row * 32 + li] = acc[fx][r];
+      out[(size_t)((fz * 2 + fy) * FX + fx) * 1024 + row * 32 + li] = acc[fx][r];
     }
   if (do_db) {
     // lanes with the same lane & 7 hold the same four channels: fold over lane bits 3, 4, 5
@@ -402,10 +404,10 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw16_reduce_kernel(
 // dw[ci][co][f] = sum over blocks: one wave per value (lane l adds blocks l, l + 64, ...)
 __global__ __launch_bounds__(256) void adell_convt_k2_dw_reduce_kernel(
     const float* __restrict__ ws, int blocks, int Cin, int Cout, float* __restrict__ dw,
-    const float* __restrict__ wsdb, float* __restrict__ db) {
+    const float* __restrict__ wsdb, float* __restrict__ db, int F) {
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const long ndw = (long)Cin * Cout * 8;
+  const long ndw = (long)Cin * Cout * F;
   if (i >= ndw) {   // whole wave: the waves past dW fold the bias-gradient rows, one channel each
     const long co = i - ndw;
     if (db == nullptr || co >= Cout) return;
@@ -415,23 +417,23 @@ __global__ __launch_bounds__(256) void adell_convt_k2_dw_reduce_kernel(
     if (lane == 0) db[co] = s;
     return;
   }
-  const int f = (int)(i & 7);
-  const long cc = i >> 3;
+  const int f = (int)(i % F);
+  const long cc = i / F;
   const int co = (int)(cc % Cout), ci = (int)(cc / Cout);
   const int nct = Cout / 32, pairs = (Cin / 32) * nct;
   const int pair = (ci >> 5) * nct + (co >> 5);
-  const float* p = ws + ((size_t)pair * 8 + f) * 1024 + (ci & 31) * 32 + (co & 31);
-  const size_t stride = (size_t)pairs * 8 * 1024;
+  const float* p = ws + ((size_t)pair * F + f) * 1024 + (ci & 31) * 32 + (co & 31);
+  const size_t stride = (size_t)pairs * F * 1024;
   float s = 0.f;
   for (int b = lane; b < blocks; b += 64) s += p[(size_t)b * stride];
   s = adell_wave_sum(s);
   if (lane == 0) dw[i] = s;
 }
 
-static bool adell_convt_k2_ok(int N, int D, int H, int W, int Cin, int Cout) {
-  // (Cout == 16: the (fx, co) column forms above)
-  return N >= 1 && D >= 1 && H >= 1 && W >= 1 && (Cin == 32 || Cin == 64) &&
-         (Cout == 16 || Cout == 32 || Cout == 64) && (long)N * D * H * W >= 32768 &&
+static bool adell_convt_k2_ok(int N, int D, int H, int W, int Cin, int Cout, int FX = 2) {
+  // (Cout == 16: the (fx, co) column forms above, factors 2 x 2 x 2 only)
+  return N >= 1 && D >= 1 && H >= 1 && W >= 1 && (FX == 1 || FX == 2) && (Cin == 32 || Cin == 64) &&
+         ((Cout == 16 && FX == 2) || Cout == 32 || Cout == 64) && (long)N * D * H * W >= 32768 &&
          (long)N * D * H * W < 0x7fffffe0L;
 }
 
@@ -439,9 +441,14 @@ static bool adell_convt_k2_ok(int N, int D, int H, int W, int Cin, int Cout) {
 extern "C" int adell_convt_k2_applicable(int N, int D, int H, int W, int Cin, int Cout) {
   return adell_convt_k2_ok(N, D, H, W, Cin, Cout) ? 1 : 0;
 }
+// ... factors (2, 2, 1): depth and height doubled, width kept (SWIN-UNet's anisotropic upscaling)
+extern "C" int adell_convt_k221_applicable(int N, int D, int H, int W, int Cin, int Cout) {
+  return adell_convt_k2_ok(N, D, H, W, Cin, Cout, 1) ? 1 : 0;
+}
 
-static void adell_ctk2_fill(ConvTK2Args* a, int N, int D, int H, int W, int Cin, int Cout) {
+static void adell_ctk2_fill(ConvTK2Args* a, int N, int D, int H, int W, int Cin, int Cout, int FX = 2) {
   a->N = N; a->D = D; a->H = H; a->W = W; a->Cin = Cin; a->Cout = Cout;
+  a->FX = FX;
   a->V = (long)N * D * H * W;
   a->ntiles = (int)((a->V + 31) / 32);
 }
@@ -450,74 +457,112 @@ static int adell_ctk2_blocks(const ConvTK2Args& a, int per_cu) {
   return a.ntiles < want ? a.ntiles : want;
 }
 
-extern "C" int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
-                                  const float* w, const float* bias, float* y, void* stream) {
-  ADELL_REQUIRE(x && w && y && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
+static int adell_convt_k2_fwd_impl(int N, int D, int H, int W, int Cin, int Cout, int FX, const float* x,
+                                   const float* w, const float* bias, float* y, void* stream) {
+  ADELL_REQUIRE(x && w && y && adell_convt_k2_ok(N, D, H, W, Cin, Cout, FX),
                 "convt_k2_fwd: factor-2 transposed conv with 32 / 64 -> 16 / 32 / 64 channels expected");
   ADELL_REQUIRE(((uintptr_t)x & 15) == 0, "convt_k2_fwd: x must be 16-byte aligned");
   ConvTK2Args a = {};
-  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout, FX);
   a.x = x; a.w = w; a.bias = bias; a.y = y;
   dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cout == 16 ? 1 : Cout / 32));
+  hipStream_t st = (hipStream_t)stream;
   if (Cout == 16 && Cin == 32)
-    hipLaunchKernelGGL(adell_convt_k2_fwd16_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adell_convt_k2_fwd16_kernel<32>, grid, dim3(256), 0, st, a);
   else if (Cout == 16)
-    hipLaunchKernelGGL(adell_convt_k2_fwd16_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(adell_convt_k2_fwd16_kernel<64>, grid, dim3(256), 0, st, a);
+  else if (Cin == 32 && FX == 2)
+    hipLaunchKernelGGL((adell_convt_k2_fwd_kernel<32, 2>), grid, dim3(256), 0, st, a);
+  else if (FX == 2)
+    hipLaunchKernelGGL((adell_convt_k2_fwd_kernel<64, 2>), grid, dim3(256), 0, st, a);
   else if (Cin == 32)
-    hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((adell_convt_k2_fwd_kernel<32, 1>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL(adell_convt_k2_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((adell_convt_k2_fwd_kernel<64, 1>), grid, dim3(256), 0, st, a);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
+}
+
+extern "C" int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                                  const float* w, const float* bias, float* y, void* stream) {
+  return adell_convt_k2_fwd_impl(N, D, H, W, Cin, Cout, 2, x, w, bias, y, stream);
+}
+extern "C" int adell_convt_k221_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                                    const float* w, const float* bias, float* y, void* stream) {
+  return adell_convt_k2_fwd_impl(N, D, H, W, Cin, Cout, 1, x, w, bias, y, stream);
+}
+
+template <int COUT, int FX>
+static int adell_ctk2_launch_dx(const ConvTK2Args& a, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  auto kern = adell_convt_k2_dx_kernel<COUT, FX>;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+static int adell_convt_k2_bwd_data_impl(int N, int D, int H, int W, int Cin, int Cout, int FX,
+                                        const float* dy, const float* w, float* dx, void* stream) {
+  ADELL_REQUIRE(dy && w && dx && adell_convt_k2_ok(N, D, H, W, Cin, Cout, FX),
+                "convt_k2_bwd_data: factor-2 transposed conv with 32 / 64 channels expected");
+  ADELL_REQUIRE(((uintptr_t)dy & 15) == 0, "convt_k2_bwd_data: dy must be 16-byte aligned");
+  ConvTK2Args a = {};
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout, FX);
+  a.dy = dy; a.w = w; a.dx = dx;
+  const size_t lds = (size_t)(4 * 32 * (FX * Cout + 1) + 3 * 32 * 33) * sizeof(float);
+  dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cin / 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (FX == 2) {
+    if (Cout == 16) return adell_ctk2_launch_dx<16, 2>(a, grid, lds, st);
+    if (Cout == 32) return adell_ctk2_launch_dx<32, 2>(a, grid, lds, st);
+    return adell_ctk2_launch_dx<64, 2>(a, grid, lds, st);
+  }
+  if (Cout == 32) return adell_ctk2_launch_dx<32, 1>(a, grid, lds, st);
+  return adell_ctk2_launch_dx<64, 1>(a, grid, lds, st);
 }
 
 extern "C" int adell_convt_k2_bwd_data(int N, int D, int H, int W, int Cin, int Cout,
                                        const float* dy, const float* w, float* dx, void* stream) {
-  ADELL_REQUIRE(dy && w && dx && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
-                "convt_k2_bwd_data: factor-2 transposed conv with 32 / 64 channels expected");
-  ADELL_REQUIRE(((uintptr_t)dy & 15) == 0, "convt_k2_bwd_data: dy must be 16-byte aligned");
-  ConvTK2Args a = {};
-  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
-  a.dy = dy; a.w = w; a.dx = dx;
-  const size_t lds = (size_t)(4 * 32 * (2 * Cout + 1) + 3 * 32 * 33) * sizeof(float);
-  dim3 grid((unsigned)adell_ctk2_blocks(a, 2), (unsigned)(Cin / 32));
-  static bool attr_done = false;
-  if (!attr_done) {
-    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_convt_k2_dx_kernel<64>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_done = true;
-  }
-  if (Cout == 16)
-    hipLaunchKernelGGL(adell_convt_k2_dx_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  else if (Cout == 32)
-    hipLaunchKernelGGL(adell_convt_k2_dx_kernel<32>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(adell_convt_k2_dx_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
-  ADELL_CHECK_HIP(hipGetLastError());
-  return ADELL_OK;
+  return adell_convt_k2_bwd_data_impl(N, D, H, W, Cin, Cout, 2, dy, w, dx, stream);
+}
+extern "C" int adell_convt_k221_bwd_data(int N, int D, int H, int W, int Cin, int Cout,
+                                         const float* dy, const float* w, float* dx, void* stream) {
+  return adell_convt_k2_bwd_data_impl(N, D, H, W, Cin, Cout, 1, dy, w, dx, stream);
 }
 
-extern "C" long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
-  if (!adell_convt_k2_ok(N, D, H, W, Cin, Cout)) return ADELL_E_BADARG;
+static long adell_convt_k2_wgrad_ws_impl(int N, int D, int H, int W, int Cin, int Cout, int FX) {
+  if (!adell_convt_k2_ok(N, D, H, W, Cin, Cout, FX)) return ADELL_E_BADARG;
   ConvTK2Args a = {};
-  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout, FX);
   const long blocks = adell_ctk2_blocks(a, 2);
   if (Cout == 16) return (long)sizeof(float) * (blocks * (Cin / 32) * 4 * 1024 + blocks * 4 * 16);
-  return (long)sizeof(float) * (blocks * (Cin / 32) * (Cout / 32) * 8 * 1024 + blocks * 4 * Cout);
+  return (long)sizeof(float) *
+         (blocks * (Cin / 32) * (Cout / 32) * (4 * FX) * 1024 + blocks * 4 * Cout);
+}
+extern "C" long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+  return adell_convt_k2_wgrad_ws_impl(N, D, H, W, Cin, Cout, 2);
+}
+extern "C" long adell_convt_k221_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout) {
+  return adell_convt_k2_wgrad_ws_impl(N, D, H, W, Cin, Cout, 1);
 }
 
 // db (optional): the bias gradient sum_v dy[v][co], a by-product of the same pass over dy.
-extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout,
-                                         const float* x, const float* dy, float* dw, float* db,
-                                         void* workspace, size_t workspace_bytes, void* stream) {
-  ADELL_REQUIRE(x && dy && dw && workspace && adell_convt_k2_ok(N, D, H, W, Cin, Cout),
+static int adell_convt_k2_bwd_weight_impl(int N, int D, int H, int W, int Cin, int Cout, int FX,
+                                          const float* x, const float* dy, float* dw, float* db,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  ADELL_REQUIRE(x && dy && dw && workspace && adell_convt_k2_ok(N, D, H, W, Cin, Cout, FX),
                 "convt_k2_bwd_weight: factor-2 transposed conv with 32 / 64 channels expected");
   ADELL_REQUIRE((((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
                 "convt_k2_bwd_weight: x and dy must be 16-byte aligned");
-  ADELL_REQUIRE((long)workspace_bytes >= adell_convt_k2_wgrad_workspace(N, D, H, W, Cin, Cout),
+  ADELL_REQUIRE((long)workspace_bytes >= adell_convt_k2_wgrad_ws_impl(N, D, H, W, Cin, Cout, FX),
                 "convt_k2_bwd_weight: workspace too small");
   ConvTK2Args a = {};
-  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout);
+  adell_ctk2_fill(&a, N, D, H, W, Cin, Cout, FX);
   a.x = x; a.dy = dy; a.ws = (float*)workspace;
   const int blocks = adell_ctk2_blocks(a, 2);
   hipStream_t st = (hipStream_t)stream;
@@ -531,12 +576,29 @@ extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, in
     ADELL_CHECK_HIP(hipGetLastError());
     return ADELL_OK;
   }
-  a.wsdb = db ? a.ws + (size_t)blocks * (Cin / 32) * (Cout / 32) * 8 * 1024 : nullptr;
+  const int F = 4 * FX;
+  a.wsdb = db ? a.ws + (size_t)blocks * (Cin / 32) * (Cout / 32) * F * 1024 : nullptr;
   dim3 grid((unsigned)blocks, (unsigned)((Cin / 32) * (Cout / 32)));
-  hipLaunchKernelGGL(adell_convt_k2_dw_kernel, grid, dim3(256), 0, st, a);
-  const long outs = (long)Cin * Cout * 8 + (db ? Cout : 0);
+  if (FX == 2)
+    hipLaunchKernelGGL(adell_convt_k2_dw_kernel<2>, grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(adell_convt_k2_dw_kernel<1>, grid, dim3(256), 0, st, a);
+  const long outs = (long)Cin * Cout * F + (db ? Cout : 0);
   hipLaunchKernelGGL(adell_convt_k2_dw_reduce_kernel, dim3((unsigned)((outs + 3) / 4)), dim3(256), 0,
-                     st, (const float*)workspace, blocks, Cin, Cout, dw, (const float*)a.wsdb, db);
+                     st, (const float*)workspace, blocks, Cin, Cout, dw, (const float*)a.wsdb, db, F);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
+}
+
+extern "C" int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout,
+                                         const float* x, const float* dy, float* dw, float* db,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return adell_convt_k2_bwd_weight_impl(N, D, H, W, Cin, Cout, 2, x, dy, dw, db, workspace,
+                                        workspace_bytes, stream);
+}
+extern "C" int adell_convt_k221_bwd_weight(int N, int D, int H, int W, int Cin, int Cout,
+                                           const float* x, const float* dy, float* dw, float* db,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  return adell_convt_k2_bwd_weight_impl(N, D, H, W, Cin, Cout, 1, x, dy, dw, db, workspace,
+                                        workspace_bytes, stream);
 }

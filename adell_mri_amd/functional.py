@@ -891,9 +891,9 @@ class _ConvT3dFn(torch.autograd.Function):
         def weight_grads():
             dw = db = None
             if need[1] and ctx.k2 and want_db:
-                dw, db = ops.convt_k2_bwd_weight(x, dy, want_db=True)   # db from the same pass over dy
+                dw, db = ops.convt_k2_bwd_weight(x, dy, want_db=True, factors=ctx.factors)   # db from the same pass over dy
             elif need[1]:
-                dw = (ops.convt_k2_bwd_weight(x, dy) if ctx.k2 else
+                dw = (ops.convt_k2_bwd_weight(x, dy, factors=ctx.factors) if ctx.k2 else
                       ops.convtranspose3d_bwd_weight(x, dy, ctx.factors))
             if want_db and db is None:
                 db = ops.bias_grad(dy)

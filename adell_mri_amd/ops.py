@@ -758,12 +758,27 @@ def convtranspose3d_bwd_weight(x, dy, factors=(2, 2, 2)):
 
 
 # ---- factor-2 transposed conv with 32 / 64 channels: streaming GEMMs, canonical weights ----------
+def _convt_k2_fns(factors):
+    L = _lib.lib()
+    if tuple(factors) == (2, 2, 2):
+        return (L.adell_convt_k2_applicable, L.adell_convt_k2_fwd, L.adell_convt_k2_bwd_data,
+                L.adell_convt_k2_wgrad_workspace, L.adell_convt_k2_bwd_weight)
+    if tuple(factors) == (2, 2, 1):
+        return (L.adell_convt_k221_applicable, L.adell_convt_k221_fwd, L.adell_convt_k221_bwd_data,
+                L.adell_convt_k221_wgrad_workspace, L.adell_convt_k221_bwd_weight)
+    return None
+
+
 def convt_k2_ok(x_shape, weight):
-    """True when csrc/convt_k2.hip takes ConvTranspose3d(x) with this weight [Cin, Cout, 2, 2, 2]."""
-    if FLAGS.get("no_convt_k2") or weight.dim() != 5 or tuple(weight.shape[2:]) != (2, 2, 2):
+    """True when csrc/convt_k2.hip takes ConvTranspose3d(x) with this weight [Cin, Cout, 2, 2, 2]
+    (or [Cin, Cout, 2, 2, 1]: depth and height doubled, width kept)."""
+    if FLAGS.get("no_convt_k2") or weight.dim() != 5:
+        return False
+    fns = _convt_k2_fns(weight.shape[2:])
+    if fns is None:
         return False
     N, _, D, H, W = x_shape
-    return bool(_lib.lib().adell_convt_k2_applicable(N, D, H, W, weight.shape[0], weight.shape[1]))
+    return bool(fns[0](N, D, H, W, weight.shape[0], weight.shape[1]))
 
 
 def convt_k2_fwd(x, weight, bias):
@@ -771,12 +786,15 @@ def convt_k2_fwd(x, weight, bias):
     x = ndhwc(x)
     N, Cin, D, H, W = x.shape
     Cout = weight.shape[1]
-    y = new_act(N, Cout, 2 * D, 2 * H, 2 * W, x.device)
+    f = tuple(weight.shape[2:])
+    y = new_act(N, Cout, f[0] * D, f[1] * H, f[2] * W, x.device)
     wc = weight.contiguous()   # bound to a local: must outlive the launch
-    check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
-                 lambda: _lib.lib().adell_convt_k2_fwd(N, D, H, W, Cin, Cout, _ptr(x), _ptr(wc),
-                                                       _ptr(bias), _ptr(y), _stream()),
-                 f"convT fwd {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (x.numel() + y.numel())))
+    fn = _convt_k2_fns(f)[1]
+    nf = f[0] * f[1] * f[2]
+    check(_timed("adell_convt_k2_kernel", 2.0 * nf * N * D * H * W * Cin * Cout,
+                 lambda: fn(N, D, H, W, Cin, Cout, _ptr(x), _ptr(wc), _ptr(bias), _ptr(y), _stream()),
+                 f"convT fwd {Cin}->{Cout} in {D}x{H}x{W} f{f[0]}{f[1]}{f[2]}",
+                 4.0 * (x.numel() + y.numel())))
     return y
 
 
@@ -785,32 +803,38 @@ def convt_k2_bwd_data(dy, weight):
     dy = ndhwc(dy)
     N, Cout, D2, H2, W2 = dy.shape
     Cin = weight.shape[0]
-    D, H, W = D2 // 2, H2 // 2, W2 // 2
+    f = tuple(weight.shape[2:])
+    D, H, W = D2 // f[0], H2 // f[1], W2 // f[2]
     dx = new_act(N, Cin, D, H, W, dy.device)
     wc = weight.contiguous()
-    check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
-                 lambda: _lib.lib().adell_convt_k2_bwd_data(N, D, H, W, Cin, Cout, _ptr(dy),
-                                                            _ptr(wc), _ptr(dx), _stream()),
-                 f"convT dgrad {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (dy.numel() + dx.numel())))
+    fn = _convt_k2_fns(f)[2]
+    nf = f[0] * f[1] * f[2]
+    check(_timed("adell_convt_k2_kernel", 2.0 * nf * N * D * H * W * Cin * Cout,
+                 lambda: fn(N, D, H, W, Cin, Cout, _ptr(dy), _ptr(wc), _ptr(dx), _stream()),
+                 f"convT dgrad {Cin}->{Cout} in {D}x{H}x{W} f{f[0]}{f[1]}{f[2]}",
+                 4.0 * (dy.numel() + dx.numel())))
     return dx
 
 
-def convt_k2_bwd_weight(x, dy, want_db=False):
+def convt_k2_bwd_weight(x, dy, want_db=False, factors=(2, 2, 2)):
     """dW (and, with want_db, the bias gradient from the same pass over dy: returns (dw, db))."""
     _require_cuda(x, dy)
     x, dy = ndhwc(x), ndhwc(dy)
     N, Cin, D, H, W = x.shape
     Cout = dy.shape[1]
-    nbytes = _lib.lib().adell_convt_k2_wgrad_workspace(N, D, H, W, Cin, Cout)
+    f = tuple(factors)
+    fns = _convt_k2_fns(f)
+    nbytes = fns[3](N, D, H, W, Cin, Cout)
     check(min(nbytes, 0))
     ws = _workspace(nbytes, x.device)
-    dw = torch.empty((Cin, Cout, 2, 2, 2), device=x.device, dtype=torch.float32)
+    dw = torch.empty((Cin, Cout, *f), device=x.device, dtype=torch.float32)
     db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_db else None
-    check(_timed("adell_convt_k2_kernel", 16.0 * N * D * H * W * Cin * Cout,
-                 lambda: _lib.lib().adell_convt_k2_bwd_weight(
-                     N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
-                     ws.numel() * 4, _stream()),
-                 f"convT wgrad {Cin}->{Cout} in {D}x{H}x{W} f222", 4.0 * (x.numel() + dy.numel())))
+    nf = f[0] * f[1] * f[2]
+    check(_timed("adell_convt_k2_kernel", 2.0 * nf * N * D * H * W * Cin * Cout,
+                 lambda: fns[4](N, D, H, W, Cin, Cout, _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+                                ws.numel() * 4, _stream()),
+                 f"convT wgrad {Cin}->{Cout} in {D}x{H}x{W} f{f[0]}{f[1]}{f[2]}",
+                 4.0 * (x.numel() + dy.numel())))
     return (dw, db) if want_db else dw
 
 

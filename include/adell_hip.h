@@ -631,8 +631,11 @@ int adell_loco_loss_bwd(const float* f1, const float* f2, const float* gloss, in
  * (unet.py:445-458, the upscaling of the high-resolution decoder levels) as streaming GEMMs on the
  * fp32 MFMA: every input voxel feeds exactly its 8 output voxels, so nothing needs a halo or a
  * packed weight. w / dw: torch's canonical [Cin][Cout][2][2][2]. `applicable`: factors 2x2x2,
- * channels in {32, 64}, at least 32 768 input voxels (below that the implicit-GEMM entry points
- * above stay in use). x / dy 16-byte aligned. */
+ * 32 / 64 input and 16 / 32 / 64 output channels, at least 32 768 input voxels (below that the
+ * implicit-GEMM entry points above stay in use). x / dy 16-byte aligned.
+ * adell_convt_k221_*: the same for factors (2, 2, 1) -- depth and height doubled, width kept
+ * (SWIN-UNet's anisotropic upscaling, unetr.py:902-925); w / dw [Cin][Cout][2][2][1], 32 / 64
+ * channels on both sides. */
 int adell_convt_k2_applicable(int N, int D, int H, int W, int Cin, int Cout);
 int adell_convt_k2_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
                        const float* w, const float* bias, float* y, void* stream);
@@ -643,6 +646,15 @@ long adell_convt_k2_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cou
 int adell_convt_k2_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, const float* x,
                               const float* dy, float* dw, float* db, void* workspace,
                               size_t workspace_bytes, void* stream);
+int adell_convt_k221_applicable(int N, int D, int H, int W, int Cin, int Cout);
+int adell_convt_k221_fwd(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                         const float* w, const float* bias, float* y, void* stream);
+int adell_convt_k221_bwd_data(int N, int D, int H, int W, int Cin, int Cout, const float* dy,
+                              const float* w, float* dx, void* stream);
+long adell_convt_k221_wgrad_workspace(int N, int D, int H, int W, int Cin, int Cout);
+int adell_convt_k221_bwd_weight(int N, int D, int H, int W, int Cin, int Cout, const float* x,
+                                const float* dy, float* dw, float* db, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 /* 3x3x3 stride-1 convolution with 1..4 input channels and a wide output (the 2 -> 32 conv of the
  * U-Net input block, unet.py:260-273; UNETR's first encoder, unetr.py:225-237) as one small GEMM per
