@@ -86,9 +86,9 @@ def test_step_kernels_are_spill_free():
         if n.startswith("_Z"):
             continue
         # (a template that gained trailing defaulted parameters since the profile was taken: the
-        # profile's "<a, b>" names the instances "<a, b, 0...>")
+        # profile's "<a, b>" names the instances "<a, b, ...>")
         cands = [k for k in table if k == n or k.startswith(n + "<") or k.startswith(n + "(")
-                 or (n.endswith(">") and k.startswith(n[:-1] + ", 0"))]
+                 or (n.endswith(">") and k.startswith(n[:-1] + ", "))]
         if not cands:
             missing.append(n)
             continue
