@@ -30,6 +30,7 @@ struct AdellTuning {
   int igemm_wide8;                // 64-column tile of the large 3^3 layers on 8x8x8 bricks, 8 waves
   int ew_reverse;                 // norm / activation forward: reverse of the producer's write order
   int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)
+  int dw_nozring;                 // depthwise 7^3: the 4 x 4 tile kernel instead of the z-marching one
   int gemm_nosmall;               // fp32 GEMM: no streaming kernels for Linear layers with <= 32 features
   int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)
   int wgrad_no16;                 // z-ring weight gradient: 32 x 32 tiles even for 16-channel layers

@@ -351,6 +351,191 @@ static int adell_dw_check(int N, int C, int D, int H, int W, int KD, int KH, int
   return ADELL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Depthwise 7^3 marching along z (rows of 9 ... 16 voxels: ConvNeXt's first stage, 64 crops x 16^3 x
+// 96 channels). The tile kernel above needs a 10 x 10 halo of rows for its 4 x 4 (z, y) outputs --
+// 6.25x the input bytes, 109 KB of LDS, ONE block per CU whose staging (~12 us of L2 reads) and
+// stencil (~9.5 us) run one after the other: 546 us per launch where the tensors move in 50.
+// Here a block owns 16 channels x 8 output rows (y) x the whole x row and walks z: a ring of 8
+// planes of 14 rows in LDS (7 live + the one being written: one barrier per step), one new plane
+// staged per output plane -- halo only in y (1.75x) -- and its loads issued two steps ahead, under
+// the stencil. Thread = (channel, row, x half): 8 outputs as 4 packed pairs, 28 v_pk_fma_f32 per
+// (kz, ky).
+constexpr int DZ_K = 7, DZ_P = 3, DZ_WT = 16, DZ_TY = 8, DZ_HY = DZ_TY + DZ_K - 1;
+constexpr int DZ_RS = DZ_WT * 16 + 16, DZ_PLANE = DZ_HY * DZ_RS, DZ_SLOTS = 8, DZ_K3 = 343;
+constexpr int DZ_QUADS = DZ_HY * DZ_WT * 4, DZ_PER = (DZ_QUADS + 255) / 256;
+
+struct DwZrArgs {
+  const float* x;
+  const float* w;
+  const float* b;
+  float* y;
+  int N, C, D, H, W, flip;
+  int tilesY, chanBlocks, nseg, seglen, vec;
+};
+
+template <int XH>
+__device__ __forceinline__ void adell_dz_stencil(const float* __restrict__ ring, const float* __restrict__ wt,
+                                                 int first_slot, int row, int c,
+                                                 float (&acc)[8]) {
+  typedef float dz_f2 __attribute__((ext_vector_type(2)));
+  dz_f2 acc2[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) acc2[m] = dz_f2{acc[2 * m], acc[2 * m + 1]};
+#pragma unroll 1
+  for (int kz = 0; kz < DZ_K; ++kz) {
+    const float* pl = ring + ((first_slot + kz) & (DZ_SLOTS - 1)) * DZ_PLANE;
+    // (ky NOT unrolled: measured 457 -> 759 us per launch with the seven rows unrolled)
+#pragma unroll 1
+    for (int ky = 0; ky < DZ_K; ++ky) {
+      // inputs t = 0 .. 13 are x = 8 XH - 3 + t; outside [0, 16) they are zero (compile time)
+      const float* xr = pl + (row + ky) * DZ_RS + (8 * XH - DZ_P) * 16 + c;
+      const float* wr = wt + (kz * DZ_K + ky) * DZ_K * 16 + c;
+      float in[14];
+#pragma unroll
+      for (int t = 0; t < 14; ++t) {
+        const int x = 8 * XH - DZ_P + t;
+        in[t] = (x >= 0 && x < DZ_WT) ? xr[t * 16] : 0.f;
+      }
+      dz_f2 E[7], O[6];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) E[i] = dz_f2{in[2 * i], in[2 * i + 1]};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) O[i] = dz_f2{in[2 * i + 1], in[2 * i + 2]};
+#pragma unroll
+      for (int kx = 0; kx < DZ_K; ++kx) {
+        const float wv = wr[kx * 16];
+        const dz_f2 w2 = dz_f2{wv, wv};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int start = 2 * m + kx;
+          if ((start & 1) == 0)
+            acc2[m] = __builtin_elementwise_fma(w2, E[start / 2], acc2[m]);
+          else
+            acc2[m] = __builtin_elementwise_fma(w2, O[(start - 1) / 2], acc2[m]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    acc[2 * m] = acc2[m].x;
+    acc[2 * m + 1] = acc2[m].y;
+  }
+}
+
+__global__ __launch_bounds__(256) void adell_dw_zring_kernel(DwZrArgs a) {
+  extern __shared__ float smem[];
+  float* ring = smem;                            // [8 slots][14 rows][16 x][16 ch] (+16 pad per row)
+  float* wt = smem + DZ_SLOTS * DZ_PLANE;        // [343 taps][16 ch]
+  const int tid = threadIdx.x;
+  const int c = tid & 15, q = tid >> 4, row = q & 7, xh = q >> 3;
+  int item = blockIdx.x;
+  const int cb = item % a.chanBlocks; item /= a.chanBlocks;   // channel blocks of a tile run together
+  const int seg = item % a.nseg; item /= a.nseg;
+  const int ty = item % a.tilesY;
+  const int n = item / a.tilesY;
+  const int c0 = cb * 16, y0 = ty * DZ_TY;
+  const int z0 = seg * a.seglen;
+  const int z1 = (z0 + a.seglen < a.D) ? z0 + a.seglen : a.D;
+  for (int i = tid; i < 16 * DZ_K3; i += 256) {
+    const int cc = i / DZ_K3, tap = i - cc * DZ_K3;
+    const int src = a.flip ? DZ_K3 - 1 - tap : tap;
+    wt[tap * 16 + cc] = (c0 + cc < a.C) ? a.w[(size_t)(c0 + cc) * DZ_K3 + src] : 0.f;
+  }
+  // staging roles: quads idx = tid + 256 u of the plane's 14 x 16 x 4
+  unsigned goff[DZ_PER], loff[DZ_PER];
+  bool gok[DZ_PER];
+#pragma unroll
+  for (int u = 0; u < DZ_PER; ++u) {
+    const int idx = tid + 256 * u;
+    const int qd = idx & 3, j = (idx >> 2) % DZ_WT, r = (idx >> 2) / DZ_WT;
+    const int yy = y0 - DZ_P + r, cc = c0 + 4 * qd;
+    gok[u] = idx < DZ_QUADS && yy >= 0 && yy < a.H && j < a.W && cc < a.C;
+    goff[u] = gok[u] ? (unsigned)((yy * a.W + j) * a.C + cc) : 0u;
+    loff[u] = (unsigned)(r * DZ_RS + j * 16 + 4 * qd);
+  }
+  const float* xn = a.x + (size_t)n * a.D * a.H * a.W * a.C;
+  f32x4 pre[2][DZ_PER];
+  auto fetch = [&](f32x4* v, int p) {
+    const bool pok = p >= 0 && p < a.D;
+    const float* base = xn + (size_t)(pok ? p : 0) * a.H * a.W * a.C;
+#pragma unroll
+    for (int u = 0; u < DZ_PER; ++u) {
+      f32x4 f = {0.f, 0.f, 0.f, 0.f};
+      if (pok && gok[u]) f = adell_dw_load_quad(base + goff[u], a.C - (c0 + 4 * ((tid + 256 * u) & 3)), a.vec);
+      v[u] = f;
+    }
+  };
+  auto put = [&](int slot, const f32x4* v) {
+    float* dst = ring + slot * DZ_PLANE;
+#pragma unroll
+    for (int u = 0; u < DZ_PER; ++u)
+      if (tid + 256 * u < DZ_QUADS) *reinterpret_cast<f32x4*>(dst + loff[u]) = v[u];
+  };
+  const float bias = (a.b && c0 + c < a.C) ? a.b[c0 + c] : 0.f;
+  const int p0 = z0 - DZ_P;
+  const int nsteps = (z1 - z0) + DZ_K - 1;
+  fetch(pre[0], p0);
+  fetch(pre[1], p0 + 1);
+  for (int ib = 0; ib < nsteps; ib += 2) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const int i = ib + jb;
+      if (i >= nsteps) break;
+      put(i & (DZ_SLOTS - 1), pre[jb]);
+      fetch(pre[jb], p0 + i + 2);        // under the stencils of this step and the next
+      __syncthreads();
+      if (i < DZ_K - 1) continue;
+      const int z = z0 + i - (DZ_K - 1);
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = bias;
+      if (xh == 0)
+        adell_dz_stencil<0>(ring, wt, i - (DZ_K - 1), row, c, acc);
+      else
+        adell_dz_stencil<1>(ring, wt, i - (DZ_K - 1), row, c, acc);
+      const int y = y0 + row;
+      if (y < a.H && c0 + c < a.C) {
+        float* out = a.y + ((((size_t)n * a.D + z) * a.H + y) * a.W + 8 * xh) * a.C + c0 + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (8 * xh + j < a.W) out[(size_t)j * a.C] = acc[j];
+      }
+    }
+  }
+}
+
+// 1 when the z-marching kernel takes the problem; fills the launch geometry
+static int adell_dw_zring_plan(int N, int C, int D, int H, int W, int KD, int KH, int KW, DwZrArgs* z) {
+  if (KD != 7 || KH != 7 || KW != 7 || W > DZ_WT || W <= 8 || D < 4 || g_adell_tune.dw_nozring) return 0;
+  z->N = N; z->C = C; z->D = D; z->H = H; z->W = W;
+  z->tilesY = adell_cdiv(H, DZ_TY);
+  z->chanBlocks = adell_cdiv(C, 16);
+  const long base = (long)N * z->tilesY * z->chanBlocks;
+  // segments: fill ~2 x the CUs when the batch alone does not, at least 8 planes each (6 priming planes)
+  long nseg = 1;
+  while (base * nseg < 512 && D / (nseg + 1) >= 8) ++nseg;
+  z->seglen = adell_cdiv(D, (int)nseg);
+  z->nseg = adell_cdiv(D, z->seglen);
+  if (base * z->nseg > 0x7fffffffL) return 0;
+  return 1;
+}
+
+static int adell_dw_zring_launch(DwZrArgs z, hipStream_t st) {
+  static bool attr_done = false;
+  const size_t lds = (size_t)(DZ_SLOTS * DZ_PLANE + 16 * DZ_K3) * sizeof(float);
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_dw_zring_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  const long blocks = (long)z.N * z.tilesY * z.chanBlocks * z.nseg;
+  hipLaunchKernelGGL(adell_dw_zring_kernel, dim3((unsigned)blocks), dim3(256), lds, st, z);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
 // tiled path: cubic K in {3,5,7}. Returns the x-row width WT (4 / 8 / 16) or 0.
 static int adell_dw_plan(int N, int C, int D, int H, int W, int KD, int KH, int KW, DwTile* t) {
   if (KD != KH || KH != KW || (KD != 3 && KD != 5 && KD != 7)) return 0;
@@ -406,6 +591,12 @@ static int adell_dw_tile_launch(const DwTileArgs& a, hipStream_t st) {
   } while (0)
 
 static int adell_dw_launch(DwArgs a, hipStream_t st) {
+  DwZrArgs zr = {};
+  if (adell_dw_zring_plan(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, &zr)) {
+    zr.x = a.x; zr.w = a.w; zr.b = a.b; zr.y = a.y; zr.flip = a.flip;
+    zr.vec = (a.C % 4 == 0) && ((uintptr_t)a.x % 16 == 0);
+    return adell_dw_zring_launch(zr, st);
+  }
   DwTileArgs ta;
   const int WT = adell_dw_plan(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, &ta.t);
   if (WT) {

@@ -123,7 +123,10 @@ def test_loss_selection_follows_the_reference():
                                         (2, 24, (4, 5, 3), 7), (1, 130, (2, 2, 2), 3),
                                         (1, 8, (7, 6, 9), (3, 1, 5)),
                                         (1, 20, (5, 9, 21), 7), (1, 16, (6, 6, 37), 3),
-                                        (2, 8, (9, 10, 11), 5), (1, 33, (3, 17, 16), 5)])
+                                        (2, 8, (9, 10, 11), 5), (1, 33, (3, 17, 16), 5),
+                                        # 7^3 with rows of 9 ... 16 voxels: the z-marching kernel (ragged
+                                        # channels / rows, several z segments)
+                                        (3, 24, (10, 11, 13), 7), (1, 16, (40, 9, 16), 7)])
 def test_depthwise_conv3d_fwd_bwd(cuda, N, C, size, k):
     from adell_mri_amd import functional as HF
     from adell_mri_amd import ops
