@@ -183,6 +183,54 @@ __global__ __launch_bounds__(256) void adell_channel_partials_kernel(
   }
 }
 
+// The same with 16-byte loads (C % 4 == 0): thread = (channel quad, voxel lane), four voxels in
+// flight per thread. The scalar form above walked a slab with one dependent 4-byte load per
+// iteration: 226 MB (16 channels at 4 x 96^3) took 532 us.
+__global__ __launch_bounds__(256) void adell_channel_partials_vec_kernel(
+    const float* __restrict__ x, long V, int C, float* __restrict__ part, int ntiles) {
+  __shared__ f32x4 sh[256][2];
+  const int n = blockIdx.y, tile = blockIdx.x;
+  const long v0 = (long)tile * ADELL_STATS_SLAB;
+  long v1 = v0 + ADELL_STATS_SLAB;
+  if (v1 > V) v1 = V;
+  const int CQ = C >> 2;
+  const int QG = CQ < 256 ? CQ : 256;          // quads handled per pass
+  const int VL = 256 / QG;
+  const int ql = threadIdx.x % QG, vl = threadIdx.x / QG;
+  for (int qb = 0; qb < CQ; qb += QG) {
+    const int q = qb + ql;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (vl < VL && q < CQ) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(x + ((size_t)n * V) * C) + q;
+      long v = v0 + vl;
+      for (; v + 3L * VL < v1; v += 4L * VL) {
+        const f32x4 a = p[v * CQ], b = p[(v + VL) * CQ], c = p[(v + 2L * VL) * CQ],
+                    d = p[(v + 3L * VL) * CQ];
+        s1 += (a + b) + (c + d);
+        s2 += (a * a + b * b) + (c * c + d * d);
+      }
+      for (; v < v1; v += VL) {
+        const f32x4 a = p[v * CQ];
+        s1 += a;
+        s2 += a * a;
+      }
+    }
+    sh[threadIdx.x][0] = s1;
+    sh[threadIdx.x][1] = s2;
+    __syncthreads();
+    if (vl == 0 && q < CQ) {
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      for (int k = 0; k < VL; ++k) {
+        a += sh[k * QG + ql][0];
+        b += sh[k * QG + ql][1];
+      }
+      float* o = part + (((size_t)n * ntiles + tile) * C + 4 * q) * 2;
+      o[0] = a.x; o[1] = b.x; o[2] = a.y; o[3] = b.y; o[4] = a.z; o[5] = b.z; o[6] = a.w; o[7] = b.w;
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int adell_channel_partials_ntiles(long V) {
   return (int)((V + ADELL_STATS_SLAB - 1) / ADELL_STATS_SLAB);
 }
@@ -192,8 +240,12 @@ extern "C" int adell_channel_partials(const float* x, int N, long V, int C,
   ADELL_REQUIRE(x && partials, "channel_partials: null pointer");
   ADELL_REQUIRE(N > 0 && V > 0 && C > 0, "channel_partials: bad dims");
   const int nt = adell_channel_partials_ntiles(V);
-  hipLaunchKernelGGL(adell_channel_partials_kernel, dim3(nt, N), dim3(256), 0,
-                     (hipStream_t)stream, x, V, C, partials, nt);
+  if ((C & 3) == 0 && (((uintptr_t)x) & 15) == 0)
+    hipLaunchKernelGGL(adell_channel_partials_vec_kernel, dim3(nt, N), dim3(256), 0,
+                       (hipStream_t)stream, x, V, C, partials, nt);
+  else
+    hipLaunchKernelGGL(adell_channel_partials_kernel, dim3(nt, N), dim3(256), 0,
+                       (hipStream_t)stream, x, V, C, partials, nt);
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
