@@ -386,7 +386,9 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
   }
 }
 
+#ifndef ADELL_EW_UNROLL
 #define ADELL_EW_UNROLL 4
+#endif
 // the bandwidth-tuned kernels are compiled once per activation (the runtime switch inside
 // the element loop made one 40 KB kernel out of nine small ones)
 #define ADELL_ACT_DISPATCH(KERN, act, grid, st, args)                                         \
