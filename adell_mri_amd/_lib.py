@@ -177,6 +177,8 @@ SIGNATURES = {
     "adell_conv_cinfold_wgrad_workspace": (_l, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_bwd_weight": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5
                                       + [ctypes.c_size_t, _vp]),
+    "adell_conv_cinfold_bwd_weight_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 5
+                                            + [ctypes.c_size_t, _vp]),
     "adell_conv_cinfold_dx_applicable": (_i, [ctypes.POINTER(ConvDesc)]),
     "adell_conv_cinfold_bwd_data": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),
     "adell_conv_cinfold_bwd_data_f16x3": (_i, [ctypes.POINTER(ConvDesc)] + [_vp] * 4),

@@ -14,6 +14,7 @@
 // (forward: the 27 Cin / 2 weight values of this lane's output channel; weight gradient: dY rows
 // read straight from global memory, 128 contiguous bytes per half-wave). Both directions are then
 // bound by the one pass over the wide tensor (y or dY).
+#include <type_traits>
 #include "common.h"
 
 struct CinFoldArgs {
@@ -510,6 +511,272 @@ __global__ __launch_bounds__(256, 2) void adell_cinfold_wgrad_kernel(CinFoldArgs
   for (int i = tid; i < 32 * (KP + 1); i += 256) out[i] = (&red[0][0])[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same weight gradient on the f16 MFMA with the error-compensated split (f16x3): the fp32-MFMA
+// kernel above is bound by its 2 x 32 MFMAs of 64 cycles per 64 voxels (0.36 ms at 2 x 128^3, 2 -> 32,
+// where dY moves in 0.13 ms). GEMM view: M = co (32), N = im2col columns k = (tap, ci), K = voxels.
+//   A (dY): the wave's 64-voxel z slice, split to fp16 hi / lo planes [voxel][32 co] in wave-private
+//           LDS, read transposed (ds_read_b64_tr_b16) like the dY operand of conv_wgrad_zring.hip;
+//           one power-of-two scale per slice (its absmax), the accumulators rescaled by the exact
+//           ratio when it changes.
+//   B (x):  the brick's 6 x 10 x 10 halo split once (scale from the tensor's absmax, a pre-pass over
+//           the narrow input) into THREE x-shifted copies [kx][ci][z][y][8 x] so that the eight
+//           consecutive voxels of a k-block are one aligned 16-byte read for every tap.
+// 12 / 24 MFMAs of 32 cycles per wave and brick instead of 64 of 64: HBM-bound.
+typedef _Float16 cf_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cf_half4 __attribute__((ext_vector_type(4)));
+typedef __fp16 cf_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ cf_half8 adell_cf_trfrag(const char* p) {
+  typedef __attribute__((address_space(3))) cf_fp16x4* lds_p;
+  const cf_fp16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_p)(p));
+  const cf_fp16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_p)(p + 4 * 64));
+  cf_half8 r;
+  r[0] = (_Float16)lo4[0]; r[1] = (_Float16)lo4[1]; r[2] = (_Float16)lo4[2]; r[3] = (_Float16)lo4[3];
+  r[4] = (_Float16)hi4[0]; r[5] = (_Float16)hi4[1]; r[6] = (_Float16)hi4[2]; r[7] = (_Float16)hi4[3];
+  return r;
+}
+
+__device__ __forceinline__ int adell_cf_exp(float mx) {
+  const int ebits = (__float_as_int(mx) >> 23) & 0xff;
+  int k = 0;
+  if (ebits > 0 && ebits < 255) k = 8 * ((13 - (ebits - 127)) >> 3);
+  if (k > 96) k = 96;
+  if (k < -96) k = -96;
+  return k;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void adell_cinfold_wgrad_f16_kernel(CinFoldArgs a, int total_bricks,
+                                                                         const unsigned* xmax) {
+  constexpr int KT = 27 * CIN, NTL = (KT + 31) / 32, KP = NTL * 32;
+  constexpr int XCOPY = CIN * 6 * 10 * 8;                 // halfs of one shifted copy
+  constexpr int XIMG = 3 * XCOPY * 2 + 16;                // bytes-in-halfs of (hi | lo) + a zero row
+  __shared__ __attribute__((aligned(16))) _Float16 xs[2][XIMG];   // [buf][hi 3 copies | lo 3 copies | 8 zeros]
+  __shared__ __attribute__((aligned(16))) char dys[4][2][64 * 64];  // [wave][hi | lo][64 voxels][32 co]
+  __shared__ float red[32][KP + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32;
+  const int nsp = a.ntx * a.nty * a.ntz;
+  const int kX = adell_cf_exp(__uint_as_float(xmax[0]));
+  const float sX = __int_as_float((kX + 127) << 23);
+  // B fragment addresses (halfs) of this lane's im2col column in every N tile: brick row 0 of slice z
+  int boff[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt) {
+    const int k = nt * 32 + li;
+    if (k < KT) {
+      const int tap = k / CIN, ci = k - tap * CIN;
+      const int kz = tap / 9, ky = (tap - 9 * kz) / 3, kx = tap - 9 * kz - 3 * ky;
+      boff[nt] = (((kx * CIN + ci) * 6 + (wave + kz)) * 10 + ky) * 8;
+    } else {
+      boff[nt] = -1;
+    }
+  }
+  // A fragment (transposed read of the wave's dY planes): lane roles of conv_wgrad_zring.hip
+  const int cg = (lane >> 4) & 1, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int abase = (lh * 8 + tq) * 64 + (16 * cg + 4 * tp) * 2;
+  f32x16 acc[NTL];
+#pragma unroll
+  for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  float4 dbacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int kprev = 0;
+  bool first = true;
+  // dY slice of a brick: lane = (row lane >> 3 + 8 u, channel quad lane & 7). TWO bricks of loads in
+  // flight (register sets 0 / 1): with one, an iteration lasted a memory round trip under load
+  // (~10 us per brick and block: 1.7 TB/s, the same as the fp32-MFMA kernel it replaces).
+  float4 yr[2][8];
+  // (voxel v = (lane >> 3) + 8 u of the 8 x 8 slice: x = lane >> 3, y = u -- one 64-bit base per
+  // brick and a uniform row stride instead of eight per-lane offsets)
+  const int vx = lane >> 3, cq = n0 + 4 * (lane & 7);
+  const bool cok = cq < a.Cout;
+  const bool yvec = (a.Cout & 3) == 0;
+  auto fetch_dy = [&](const CinFoldBrick& k, float4* y) {
+    const int oz = k.oz0 + wave;
+    const bool ok0 = cok && (k.ox0 + vx < a.Wo) && oz < a.Do;
+    const float* base = a.dy + ((((size_t)k.nb * a.Do + (oz < a.Do ? oz : 0)) * a.Ho + k.oy0) * a.Wo +
+                                (k.ox0 + vx < a.Wo ? k.ox0 + vx : 0)) * a.Cout + (cok ? cq : 0);
+    const size_t rstride = (size_t)a.Wo * a.Cout;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = ok0 && (k.oy0 + u < a.Ho);
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float* p = base + u * rstride;
+        if (yvec) {
+          f = *reinterpret_cast<const float4*>(p);
+        } else {
+          f.x = p[0];
+          if (cq + 1 < a.Cout) f.y = p[1];
+          if (cq + 2 < a.Cout) f.z = p[2];
+          if (cq + 3 < a.Cout) f.w = p[3];
+        }
+      }
+      y[u] = f;
+    }
+  };
+  // registers -> the wave's hi / lo planes; returns the slice's exponent
+  auto put_dy = [&](const float4* y) -> int {
+    float mx = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(y[u].x), fabsf(y[u].y)), fmaxf(fabsf(y[u].z), fabsf(y[u].w))));
+      dbacc.x += y[u].x; dbacc.y += y[u].y; dbacc.z += y[u].z; dbacc.w += y[u].w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const int kY = adell_cf_exp(mx);
+    const float sY = __int_as_float((kY + 127) << 23);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = (lane >> 3) + 8 * u;
+      const float t[4] = {y[u].x * sY, y[u].y * sY, y[u].z * sY, y[u].w * sY};
+      cf_half4 h, l;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        h[jj] = (_Float16)t[jj];
+        l[jj] = (_Float16)(t[jj] - (float)h[jj]);
+      }
+      *reinterpret_cast<cf_half4*>(dys[wave][0] + v * 64 + (lane & 7) * 8) = h;
+      *reinterpret_cast<cf_half4*>(dys[wave][1] + v * 64 + (lane & 7) * 8) = l;
+    }
+    return kY;
+  };
+  // halo registers -> the three shifted hi / lo copies of buffer `buf`
+  CinFoldHalo<CIN> halo[2];
+  auto put_x = [&](int buf, const CinFoldHalo<CIN>& hreg) {
+    _Float16* hi = xs[buf];
+    _Float16* lo = xs[buf] + 3 * XCOPY;
+#pragma unroll
+    for (int u = 0; u < CinFoldHalo<CIN>::PER; ++u) {
+      const int i2 = tid + 256 * u;
+      if (i2 < 600 * CIN) {
+        const int ci = i2 % CIN, hv = i2 / CIN;
+        const int hx = hv % 10, hy = (hv / 10) % 10, hz = hv / 100;
+        const float t = hreg.v[u] * sX;
+        const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
+#pragma unroll
+        for (int sh = 0; sh < 3; ++sh) {
+          const int xq = hx - sh;
+          if (xq >= 0 && xq < 8) {
+            const int o = (((sh * CIN + ci) * 6 + hz) * 10 + hy) * 8 + xq;
+            hi[o] = h;
+            lo[o] = l;
+          }
+        }
+      }
+    }
+    if (tid < 8) xs[buf][6 * XCOPY + tid] = (_Float16)0.f;     // the zero row of columns >= KT
+  };
+  const int stride = (int)gridDim.x;
+  if (blockIdx.x < total_bricks) {
+    const CinFoldBrick k0 = adell_cinfold_brick(a, blockIdx.x, nsp);
+    halo[0].fetch(a, k0.nb, k0.ox0, k0.oy0, k0.oz0);
+    fetch_dy(k0, yr[0]);
+    if ((int)blockIdx.x + stride < total_bricks) {
+      const CinFoldBrick k1 = adell_cinfold_brick(a, blockIdx.x + stride, nsp);
+      halo[1].fetch(a, k1.nb, k1.ox0, k1.oy0, k1.oz0);
+      fetch_dy(k1, yr[1]);
+    }
+    put_x(0, halo[0]);
+  }
+  __syncthreads();
+  // iteration `it` (register set S = it & 1): brick it out of LDS, brick it + 2 into set S, the
+  // halo of brick it + 1 (set S ^ 1) into the other image
+  auto iteration = [&](int b, int it, auto S) {
+    constexpr int s0 = decltype(S)::value, s1 = s0 ^ 1;
+    const int buf = it & 1;
+    const int kY = put_dy(yr[s0]);
+    const int ksum = kX + kY;
+    if (!first && ksum != kprev) {
+      const float f = __int_as_float((ksum - kprev + 127) << 23);
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] *= f;
+    }
+    kprev = ksum;
+    first = false;
+    if (b + 2 * stride < total_bricks) {
+      const CinFoldBrick kn = adell_cinfold_brick(a, b + 2 * stride, nsp);
+      halo[s0].fetch(a, kn.nb, kn.ox0, kn.oy0, kn.oz0);
+      fetch_dy(kn, yr[s0]);
+    }
+    const _Float16* xh = xs[buf];
+    const _Float16* xl = xs[buf] + 3 * XCOPY;
+    const _Float16* zero = xs[buf] + 6 * XCOPY;
+    // 4 k-steps of 16 voxels (two brick rows): lane half lh takes row 2 s + lh
+    // (two at a time: all four in flight spilled next to the two prefetched bricks)
+#pragma unroll 2
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const cf_half8 ah = adell_cf_trfrag(dys[wave][0] + abase + s4 * 16 * 64);
+      const cf_half8 al = adell_cf_trfrag(dys[wave][1] + abase + s4 * 16 * 64);
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt) {
+        const int o = boff[nt] + (2 * s4 + lh) * 8;
+        const cf_half8 bh = *reinterpret_cast<const cf_half8*>(boff[nt] >= 0 ? xh + o : zero);
+        const cf_half8 bl = *reinterpret_cast<const cf_half8*>(boff[nt] >= 0 ? xl + o : zero);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[nt], 0, 0, 0);
+      }
+    }
+    if (b + stride < total_bricks) put_x(buf ^ 1, halo[s1]);
+    __syncthreads();
+  };
+  {
+    int it = 0;
+    for (int b = blockIdx.x; b < total_bricks; b += 2 * stride, it += 2) {
+      iteration(b, it, std::integral_constant<int, 0>{});
+      if (b + stride < total_bricks) iteration(b + stride, it + 1, std::integral_constant<int, 1>{});
+    }
+  }
+  // undo the scales, fold the four waves in wave order, one partial row set per block
+  const float unscale = __int_as_float((127 - kprev) << 23);
+  // db: lanes with the same lane & 7 hold the same channel quad
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    dbacc.x += __shfl_xor(dbacc.x, o, 64);
+    dbacc.y += __shfl_xor(dbacc.y, o, 64);
+    dbacc.z += __shfl_xor(dbacc.z, o, 64);
+    dbacc.w += __shfl_xor(dbacc.w, o, 64);
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int nt = 0; nt < NTL; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;      // output channel of the tile
+          float* q = &red[row][nt * 32 + li];
+          const float v = first ? 0.f : acc[nt][r] * unscale;
+          *q = w == 0 ? v : *q + v;
+        }
+      if (lane < 8) {
+        float* q = &red[4 * lane][KP];
+        const float d4[4] = {dbacc.x, dbacc.y, dbacc.z, dbacc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j * (KP + 1)] = w == 0 ? d4[j] : q[j * (KP + 1)] + d4[j];
+      }
+    }
+    __syncthreads();
+  }
+  float* out = a.ws + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 32 * (KP + 1);
+  for (int i = tid; i < 32 * (KP + 1); i += 256) out[i] = (&red[0][0])[i];
+}
+
+__global__ __launch_bounds__(256) void adell_cinfold_absmax_kernel(const float* __restrict__ x, long n,
+                                                                   unsigned* __restrict__ out) {
+  float mx = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
+    mx = fmaxf(mx, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));
+}
+
 // dw[co][ci][tap] (and db[co]) = sum over the blocks' partials: one wave per output value, lane l
 // adds blocks l, l + 64, ... and the wave folds its 64 sums with the fixed xor-shuffle tree (a
 // thread per value walking 1024 strided partials in turn took longer than the MFMA kernel).
@@ -624,7 +891,7 @@ static int adell_cinfold_wgrad_blocks(const adell_conv3d_desc* d) {
 extern "C" long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d) {
   if (!adell_cinfold_ok(d)) return ADELL_E_BADARG;
   const int KP = adell_cdiv(27 * d->C0, 32) * 32;
-  return (long)sizeof(float) * adell_cinfold_wgrad_blocks(d) * adell_cdiv(d->Cout, 32) * 32 * (KP + 1);
+  return (long)sizeof(float) * ((long)adell_cinfold_wgrad_blocks(d) * adell_cdiv(d->Cout, 32) * 32 * (KP + 1) + 4);
 }
 
 extern "C" int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x,
@@ -650,6 +917,44 @@ extern "C" int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const f
     default: hipLaunchKernelGGL(adell_cinfold_wgrad_kernel<4>, grid, dim3(256), 0, st, a, (int)total); break;
   }
   const int KP = adell_cdiv(27 * d->C0, 32) * 32;
+  const int outs = d->Cout * (27 * d->C0 + 1);
+  hipLaunchKernelGGL(adell_cinfold_wgrad_reduce_kernel, dim3(adell_cdiv(outs, 4)), dim3(256), 0, st,
+                     (const float*)workspace, blocks, ntile, KP, d->C0, d->Cout, dw, db);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+// The same on the f16 MFMA with the error-compensated split (adell_cinfold_wgrad_f16_kernel): same
+// arguments, same workspace.
+extern "C" int adell_conv_cinfold_bwd_weight_f16x3(const adell_conv3d_desc* d, const float* x,
+                                                   const float* dy, float* dw, float* db,
+                                                   void* workspace, size_t workspace_bytes,
+                                                   void* stream) {
+  ADELL_REQUIRE(x && dy && dw && workspace && adell_cinfold_ok(d),
+                "conv_cinfold_bwd_weight_f16x3: 3x3x3 stride-1 conv with 1..4 input channels expected");
+  ADELL_REQUIRE((long)workspace_bytes >= adell_conv_cinfold_wgrad_workspace(d),
+                "conv_cinfold_bwd_weight_f16x3: workspace too small");
+  CinFoldArgs a = {};
+  adell_cinfold_fill(&a, d);
+  a.x = x; a.dy = dy; a.ws = (float*)workspace;
+  const long total = (long)d->N * a.ntx * a.nty * a.ntz;
+  ADELL_REQUIRE(total < 0x7fffffffL, "conv_cinfold_bwd_weight_f16x3: too many bricks");
+  const int blocks = adell_cinfold_wgrad_blocks(d), ntile = adell_cdiv(d->Cout, 32);
+  const int KP = adell_cdiv(27 * d->C0, 32) * 32;
+  unsigned* xmax = reinterpret_cast<unsigned*>(a.ws + (size_t)blocks * ntile * 32 * (KP + 1));
+  hipStream_t st = (hipStream_t)stream;
+  ADELL_CHECK_HIP(hipMemsetAsync(xmax, 0, 4 * sizeof(unsigned), st));
+  const long nx = (long)d->N * d->D * d->H * d->W * d->C0;
+  long ab = (nx + 255) / 256;
+  if (ab > 2048) ab = 2048;
+  hipLaunchKernelGGL(adell_cinfold_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, x, nx, xmax);
+  dim3 grid((unsigned)blocks, (unsigned)ntile);
+  switch (d->C0) {
+    case 1: hipLaunchKernelGGL(adell_cinfold_wgrad_f16_kernel<1>, grid, dim3(256), 0, st, a, (int)total, xmax); break;
+    case 2: hipLaunchKernelGGL(adell_cinfold_wgrad_f16_kernel<2>, grid, dim3(256), 0, st, a, (int)total, xmax); break;
+    case 3: hipLaunchKernelGGL(adell_cinfold_wgrad_f16_kernel<3>, grid, dim3(256), 0, st, a, (int)total, xmax); break;
+    default: hipLaunchKernelGGL(adell_cinfold_wgrad_f16_kernel<4>, grid, dim3(256), 0, st, a, (int)total, xmax); break;
+  }
   const int outs = d->Cout * (27 * d->C0 + 1);
   hipLaunchKernelGGL(adell_cinfold_wgrad_reduce_kernel, dim3(adell_cdiv(outs, 4)), dim3(256), 0, st,
                      (const float*)workspace, blocks, ntile, KP, d->C0, d->Cout, dw, db);

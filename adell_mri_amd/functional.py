@@ -44,7 +44,9 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_rows": bool(os.environ.get("ADELL_NO_ROWS")),
          # 1x1x1 stride-1 convolutions with >= 64 channels on one side (>= 8 on the other) stay on the implicit-GEMM
          # conv kernels instead of the Linear-layer GEMMs (conv3d)
-         "no_pointwise_gemm": bool(os.environ.get("ADELL_NO_POINTWISE_GEMM"))}
+         "no_pointwise_gemm": bool(os.environ.get("ADELL_NO_POINTWISE_GEMM")),
+         # weight gradient of the narrow-input convs on the exact fp32-MFMA kernel (A/B)
+         "no_cinfold_wgrad_f16": bool(os.environ.get("ADELL_NO_CINFOLD_WGRAD_F16"))}
 
 
 def set_conv_precision(mode):
@@ -678,7 +680,13 @@ class _Conv3dFn(torch.autograd.Function):
         def weight_grads():
             dw = db = None
             if need[2] and getattr(ctx, "cinfold", False):
-                dw, db = ops.conv_cinfold_bwd_weight(x0, dy, padding, want_db)
+                dw, db = ops.conv_cinfold_bwd_weight(
+                    x0, dy, padding, want_db,
+                    # (two input channels: 0.300 vs 0.339 ms at 2 x 128^3; one channel and single
+                    # volumes are 7-17 % faster on the fp32-MFMA kernel -- both are bound by the
+                    # instructions of their staging code, not by HBM: tools/cinfold_wgrad_time.py)
+                    f16x3=(CONV_PRECISION == "f16x3" and x0.shape[1] == 2 and x0.shape[0] > 1
+                           and not FLAGS["no_cinfold_wgrad_f16"]))
                 dw = dw.view(weight.shape)
             elif need[2]:
                 rows0, rows1 = getattr(ctx, "rows", (None, None))

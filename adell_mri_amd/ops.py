@@ -411,8 +411,9 @@ def conv_cinfold_fwd(x, weight, bias, padding, want_stats, f16x3=False):
     return y, part
 
 
-def conv_cinfold_bwd_weight(x, dy, padding, want_db):
-    """(dw [Cout, Cin, 3, 3, 3], db or None)."""
+def conv_cinfold_bwd_weight(x, dy, padding, want_db, f16x3=False):
+    """(dw [Cout, Cin, 3, 3, 3], db or None). ``f16x3``: the split-f16 MFMA kernel (bound by the one
+    pass over dy) instead of the exact fp32-MFMA one."""
     _require_cuda(x, dy)
     x, dy = ndhwc(x), ndhwc(dy)
     N, Cin, D, H, W = x.shape
@@ -424,10 +425,11 @@ def conv_cinfold_bwd_weight(x, dy, padding, want_db):
     ws = _workspace(nbytes, x.device)
     dw = torch.empty((Cout, Cin, 3, 3, 3), device=x.device, dtype=torch.float32)
     db = torch.empty(Cout, device=x.device, dtype=torch.float32) if want_db else None
+    fn = (_lib.lib().adell_conv_cinfold_bwd_weight_f16x3 if f16x3
+          else _lib.lib().adell_conv_cinfold_bwd_weight)
     check(_timed("adell_cinfold_kernel", _conv_flops(d),
-                 lambda: _lib.lib().adell_conv_cinfold_bwd_weight(
-                     ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
-                     ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"), _conv_bytes(d)))
+                 lambda: fn(ctypes.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(db), _ptr(ws),
+                            ws.numel() * 4, _stream()), _conv_tag(d, "wgrad"), _conv_bytes(d)))
     return dw, db
 
 

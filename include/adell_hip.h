@@ -676,6 +676,11 @@ long adell_conv_cinfold_wgrad_workspace(const adell_conv3d_desc* d);
 int adell_conv_cinfold_bwd_weight(const adell_conv3d_desc* d, const float* x, const float* dy,
                                   float* dw, float* db, void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* the same on the f16 MFMA with error-compensated operand splits (every channel count 1..4; same
+ * workspace): bound by the one pass over dy instead of by the fp32 MFMA */
+int adell_conv_cinfold_bwd_weight_f16x3(const adell_conv3d_desc* d, const float* x, const float* dy,
+                                        float* dw, float* db, void* workspace,
+                                        size_t workspace_bytes, void* stream);
 /* backward-data of the same convs (dx has 1..4 channels): one GEMM per dY voxel over K = Cout
  * (Cout <= 64, multiple of 4) into the 27 Cin (tap, channel) columns, gathered into dx along a
  * z march. dy 16-byte aligned. */

@@ -69,6 +69,15 @@ def test_cinfold_forward_and_weight_gradient_match_oracle(cuda, N, Cin, size, Co
         assert dx is None and dx16 is None
     dw2, none = ops.conv_cinfold_bwd_weight(xd, dyd, (pad,) * 3, False)
     assert none is None and torch.equal(dw, dw2)      # deterministic fold order
+    # the split-f16 MFMA weight gradient (every channel count): ~2^-22 per product, the bias gradient
+    # is the same fp32 sum; badly scaled operands (the per-slice / per-tensor scales carry them)
+    dw16, db16 = ops.conv_cinfold_bwd_weight(xd, dyd, (pad,) * 3, True, f16x3=True)
+    assert _rel(dw16.cpu().numpy(), dw_ref) < 5e-6
+    assert _rel(db16.cpu().numpy(), db_ref) < 5e-6
+    dw16b, _ = ops.conv_cinfold_bwd_weight(xd, dyd, (pad,) * 3, False, f16x3=True)
+    assert torch.equal(dw16, dw16b)
+    dws, _ = ops.conv_cinfold_bwd_weight(xd * 3e4, dyd * 2e-5, (pad,) * 3, False, f16x3=True)
+    assert _rel(dws.cpu().numpy() / (3e4 * 2e-5), dw_ref) < 5e-6
 
 
 def test_layer_takes_the_cinfold_path_and_matches_the_fold_path(cuda):

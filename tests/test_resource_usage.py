@@ -28,6 +28,7 @@ ALLOWED = {
     "adell_conv_igemm_f16_kernel<4, 1, 4, 1, 3, 0, 1>": (
         12, "split rows in ONE half of a concat on a 32-column tile: no BASELINE config"),
     "adell_cinfold_wgrad_kernel<3>": (340, "3-channel inputs: no BASELINE config"),
+    "adell_cinfold_wgrad_f16_kernel<3>": (192, "3-channel inputs: no BASELINE config (and not dispatched)"),
     "adell_cinfold_wgrad_kernel<4>": (568, "4-channel inputs: no BASELINE config"),
     "adell_cinfold_dx_kernel<4, 64>": (92, "4-channel inputs: no BASELINE config"),
     "adell_wgrad_small_kernel<7, 4>": (128, "7^3 stem with 4 input channels: no BASELINE config"),
