@@ -103,16 +103,23 @@ __device__ __forceinline__ float adell_sigmoidf(float x) {
   return __frcp_rn(1.0f + __expf(-x));
 }
 
-// Philox-4x32-10 counter RNG: one call -> 4 uniform 32-bit words. The dropout
-// mask of element e of a tensor is a pure function of (seed, offset, e), so
-// forward and backward regenerate it instead of storing it.
+// Philox-4x32 counter RNG, 7 rounds (Salmon et al., SC'11: the fewest rounds of this generator that
+// pass BigCrush; 10 is the library default with a safety margin): one call -> 4 uniform 32-bit
+// words. The dropout mask of element e of a tensor is a pure function of (seed, offset, e), so
+// forward and backward regenerate it instead of storing it. The 32-bit multiplies are quarter-rate
+// instructions: at 10 rounds the generator was 640 of the ~880 vector-ALU cycles the fused norm ->
+// dropout -> activation forward spends per 64 float4, i.e. that HBM-bound-looking pass was bound by
+// its RNG (4.1 TB/s in the step, 5.0 alone, 5.8 without dropout).
+#ifndef ADELL_PHILOX_ROUNDS
+#define ADELL_PHILOX_ROUNDS 7
+#endif
 __device__ __forceinline__ uint4 adell_philox4(uint32_t c0, uint32_t c1,
                                                uint32_t c2, uint32_t c3,
                                                uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < ADELL_PHILOX_ROUNDS; ++r) {
     uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
     uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
