@@ -769,9 +769,24 @@ __global__ __launch_bounds__(256, 2) void adell_cinfold_wgrad_f16_kernel(CinFold
 
 __global__ __launch_bounds__(256) void adell_cinfold_absmax_kernel(const float* __restrict__ x, long n,
                                                                    unsigned* __restrict__ out) {
+  // 16-byte loads, four in flight per thread (the scalar grid-stride form took 100 us for 33 MB)
   float mx = 0.f;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
-    mx = fmaxf(mx, fabsf(x[i]));
+  const long n4 = ((((uintptr_t)x) & 15) == 0) ? (n >> 2) : 0;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const long stride = (long)gridDim.x * 256L;
+  long i = blockIdx.x * 256L + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    const f32x4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
+                         fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))),
+                         fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+  }
+  for (; i < n4; i += stride) {
+    const f32x4 a = x4[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+  }
+  for (long j = 4 * n4 + blockIdx.x * 256L + threadIdx.x; j < n; j += stride) mx = fmaxf(mx, fabsf(x[j]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(mx));
@@ -945,8 +960,9 @@ extern "C" int adell_conv_cinfold_bwd_weight_f16x3(const adell_conv3d_desc* d, c
   hipStream_t st = (hipStream_t)stream;
   ADELL_CHECK_HIP(hipMemsetAsync(xmax, 0, 4 * sizeof(unsigned), st));
   const long nx = (long)d->N * d->D * d->H * d->W * d->C0;
-  long ab = (nx + 255) / 256;
+  long ab = (nx / 4 + 1023) / 1024;
   if (ab > 2048) ab = 2048;
+  if (ab < 1) ab = 1;
   hipLaunchKernelGGL(adell_cinfold_absmax_kernel, dim3((unsigned)ab), dim3(256), 0, st, x, nx, xmax);
   dim3 grid((unsigned)blocks, (unsigned)ntile);
   switch (d->C0) {

@@ -682,11 +682,9 @@ class _Conv3dFn(torch.autograd.Function):
             if need[2] and getattr(ctx, "cinfold", False):
                 dw, db = ops.conv_cinfold_bwd_weight(
                     x0, dy, padding, want_db,
-                    # (two input channels: 0.300 vs 0.339 ms at 2 x 128^3; one channel and single
-                    # volumes are 7-17 % faster on the fp32-MFMA kernel -- both are bound by the
-                    # instructions of their staging code, not by HBM: tools/cinfold_wgrad_time.py)
-                    f16x3=(CONV_PRECISION == "f16x3" and x0.shape[1] == 2 and x0.shape[0] > 1
-                           and not FLAGS["no_cinfold_wgrad_f16"]))
+                    # (0.297 vs 0.339 ms for 2 -> 32 at 2 x 128^3, 0.167 vs 0.207 ms for 1 -> 16 at
+                    # 4 x 96^3: tools/cinfold_wgrad_time.py)
+                    f16x3=(CONV_PRECISION == "f16x3" and not FLAGS["no_cinfold_wgrad_f16"]))
                 dw = dw.view(weight.shape)
             elif need[2]:
                 rows0, rows1 = getattr(ctx, "rows", (None, None))
