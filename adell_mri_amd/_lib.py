@@ -138,6 +138,12 @@ SIGNATURES = {
                                  ctypes.c_uint, _vp, _vp, _vp]),
     "adell_attention_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f,
                                  ctypes.c_ulonglong, ctypes.c_uint, _vp, _vp, _vp, _vp]),
+    "adell_attention_strided_ok": (_i, [_i, _i, _i]),
+    "adell_attention_fwd_strided": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _f, _f,
+                                         ctypes.c_ulonglong, ctypes.c_uint, _vp, _vp, _vp]),
+    "adell_attention_bwd_strided": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                         _vp, _f, _f, ctypes.c_ulonglong, ctypes.c_uint, _vp, _vp,
+                                         _vp, _vp]),
     "adell_copy_channels": (_i, [_vp, _vp, _l, _i, _i, _i, _i, _vp]),
     "adell_interp_nearest_fwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),
     "adell_interp_nearest_bwd": (_i, [_vp, _vp] + [_i] * 8 + [_vp]),

@@ -377,16 +377,53 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
 #endif
 }
 
-// fixed-order fold of the split-K slabs (+ bias, residual): one thread per output
-__global__ __launch_bounds__(256) void adell_gemm_f16x3_fold_kernel(GemmHArgs a) {
+// fixed-order fold of the split-K slabs (+ bias, residual). A block takes 64 consecutive outputs
+// (x V floats each) and spreads the slabs over its 16 waves, four independent loads in flight per
+// thread: wave q sums slabs q, q + 16, ... in that order, the 16 wave sums are added in wave order
+// -- one fixed tree, whatever the launch. (One thread per output walking all the slabs took 120 us
+// for 171 slabs of 96 x 384: 25 MB behind 144 blocks' worth of load latency.)
+template <int V>
+__global__ __launch_bounds__(1024) void adell_gemm_f16x3_fold_kernel(GemmHArgs a) {
+  __shared__ float sh[16][64 * V];
   const long total = (long)a.M * a.N;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-    float s = 0.f;
-    for (int sp = 0; sp < a.splits; ++sp) s += a.slab[(long)sp * total + i];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long i = ((long)blockIdx.x * 64 + e) * V;
+  float acc[4][V];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[u][v] = 0.f;
+  auto add = [&](int u, int sp) {
+    const float* src = a.slab + (long)sp * total + i;
+    if constexpr (V == 4) {
+      const float4 f = *reinterpret_cast<const float4*>(src);
+      acc[u][0] += f.x; acc[u][1] += f.y; acc[u][2] += f.z; acc[u][3] += f.w;
+    } else {
+      acc[u][0] += *src;
+    }
+  };
+  if (i < total) {
+    int sp = q;
+    for (; sp + 3 * 16 < a.splits; sp += 4 * 16) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) add(u, sp + 16 * u);
+    }
+    for (; sp < a.splits; sp += 16) add(0, sp);
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) sh[q][e * V + v] = (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
+  __syncthreads();
+  if (q == 0 && i < total) {
     const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
-    if (a.bias) s += a.bias[col];
-    if (a.residual) s += a.residual[(long)row * a.ldr + col];
-    a.C[(long)row * a.ldc + col] = s;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) s += sh[k][e * V + v];
+      if (a.bias) s += a.bias[col + v];
+      if (a.residual) s += a.residual[(long)row * a.ldr + col + v];
+      a.C[(long)row * a.ldc + col + v] = s;
+    }
   }
 }
 
@@ -527,9 +564,13 @@ extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, i
     rc = launch(adell_gemm_f16x3_kernel<false, true>);
   if (rc != ADELL_OK) return rc;
   if (p.splits > 1) {
-    long blocks = ((long)M * N + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(adell_gemm_f16x3_fold_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    const long total = (long)M * N;
+    if (N % 4 == 0 && (((uintptr_t)a.slab) & 15) == 0)
+      hipLaunchKernelGGL(adell_gemm_f16x3_fold_kernel<4>, dim3((unsigned)((total / 4 + 63) / 64)),
+                         dim3(1024), 0, st, a);
+    else
+      hipLaunchKernelGGL(adell_gemm_f16x3_fold_kernel<1>, dim3((unsigned)((total + 63) / 64)),
+                         dim3(1024), 0, st, a);
     ADELL_CHECK_HIP(hipGetLastError());
   }
   return ADELL_OK;

@@ -216,6 +216,8 @@ extern "C" int adell_sum_bcast(const float* g, float* db, long n, long period, v
 #define ATT_TK 64
 #define ATT_ROWS 16  // query rows per block (4 waves x 4 rows)
 
+struct AttStride { long b, h, r; };
+
 struct AttArgs {
   const float* q;
   const float* k;
@@ -233,7 +235,16 @@ struct AttArgs {
   float scale;
   float drop_p;      // attention-probability dropout (0 = off)
   uint32_t seed_lo, seed_hi, rng_offset;
+  // MFMA kernels: element strides of sequence bh = b * H + h (item b, head h) and of its token
+  // rows, so that Q / K / V can be read inside a packed [B][T][H][q | k | v] projection and O,
+  // dQ, dK, dV land in token-major buffers (contiguous [BH][T][*]: H = 1, {T * C, 0, C})
+  int H;
+  AttStride sq, sk, sv, so, sg, sdq, sdk, sdv;
 };
+
+__device__ __forceinline__ size_t att_base(const AttArgs& a, const AttStride& s, int bh) {
+  return (size_t)(bh / a.H) * s.b + (size_t)(bh % a.H) * s.h;
+}
 
 // word `i` (0..3) of a Philox block by selects (indexing a local array with a run-time index puts the
 // array in scratch memory)
@@ -596,14 +607,14 @@ __device__ __forceinline__ int am_row(int r, int h) { return (r & 3) + 8 * (r >>
 // clamped row indices (a select on the loaded value, not a branch around the load: hipcc would
 // otherwise wait for every load in turn -- dependent L2 round trips).
 template <int C>
-__device__ __forceinline__ void am_stage32(float* dst, const float* src, int r0, int T, int tid) {
+__device__ __forceinline__ void am_stage32(float* dst, const float* src, long rs, int r0, int T, int tid) {
   constexpr int N4 = 32 * C / 4 / 256;   // float4 per thread for a 32-row tile
   float4 v[N4];
 #pragma unroll
   for (int u = 0; u < N4; ++u) {
     const int i = tid + 256 * u, r = i / (C / 4), c4 = i - r * (C / 4);
     const int row = r0 + r < T ? r0 + r : T - 1;
-    v[u] = *reinterpret_cast<const float4*>(src + (size_t)row * C + 4 * c4);
+    v[u] = *reinterpret_cast<const float4*>(src + (size_t)row * rs + 4 * c4);
   }
 #pragma unroll
   for (int u = 0; u < N4; ++u) {
@@ -619,7 +630,7 @@ __device__ __forceinline__ void am_stage32(float* dst, const float* src, int r0,
 // the whole [T][C] matrix, padded to a multiple of 32 rows (resident variants): the loads of
 // four tiles are in flight together
 template <int C>
-__device__ __forceinline__ void am_stage_all(float* dst, const float* src, int T, int tid) {
+__device__ __forceinline__ void am_stage_all(float* dst, const float* src, long rs, int T, int tid) {
   constexpr int N4 = 32 * C / 4 / 256, G = 4;
   const int tiles = (T + 31) / 32;
   for (int t0 = 0; t0 < tiles; t0 += G) {
@@ -631,7 +642,7 @@ __device__ __forceinline__ void am_stage_all(float* dst, const float* src, int T
         const int i = tid + 256 * u, r = i / (C / 4), c4 = i - r * (C / 4);
         int row = (t0 + g) * 32 + r;
         row = row < T ? row : T - 1;
-        v[g][u] = *reinterpret_cast<const float4*>(src + (size_t)row * C + 4 * c4);
+        v[g][u] = *reinterpret_cast<const float4*>(src + (size_t)row * rs + 4 * c4);
       }
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -686,16 +697,16 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_fwd_kernel(AttArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + li;
   const bool qok = qrow < a.T, active = q0 < a.T;   // `active` is wave-uniform
-  const float* qb = a.q + (size_t)bh * a.T * A;
-  const float* kb = a.k + (size_t)bh * a.T * A;
-  const float* vb = a.v + (size_t)bh * a.T * Dv;
+  const float* qb = a.q + att_base(a, a.sq, bh);
+  const float* kb = a.k + att_base(a, a.sk, bh);
+  const float* vb = a.v + att_base(a, a.sv, bh);
   const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
   float qreg[A / 2];
 #pragma unroll
-  for (int ss = 0; ss < A / 2; ++ss) qreg[ss] = qok ? qb[(size_t)qrow * A + 2 * ss + h] : 0.f;
+  for (int ss = 0; ss < A / 2; ++ss) qreg[ss] = qok ? qb[(size_t)qrow * a.sq.r + 2 * ss + h] : 0.f;
   if (RES) {
-    am_stage_all<A>(sK, kb, a.T, tid);
-    am_stage_all<Dv>(sV, vb, a.T, tid);
+    am_stage_all<A>(sK, kb, a.sk.r, a.T, tid);
+    am_stage_all<Dv>(sV, vb, a.sv.r, a.T, tid);
     __syncthreads();
   }
   // pass 1: log-sum-exp of this lane's query
@@ -703,7 +714,7 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_fwd_kernel(AttArgs a) {
   for (int k0 = 0; k0 < a.T; k0 += 32) {
     if (!RES) {
       __syncthreads();
-      am_stage32<A>(sK, kb, k0, a.T, tid);
+      am_stage32<A>(sK, kb, a.sk.r, k0, a.T, tid);
       __syncthreads();
     }
     if (!active) continue;
@@ -732,8 +743,8 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_fwd_kernel(AttArgs a) {
   for (int k0 = 0; k0 < a.T; k0 += 32) {
     if (!RES) {
       __syncthreads();
-      am_stage32<A>(sK, kb, k0, a.T, tid);
-      am_stage32<Dv>(sV, vb, k0, a.T, tid);
+      am_stage32<A>(sK, kb, a.sk.r, k0, a.T, tid);
+      am_stage32<Dv>(sV, vb, a.sv.r, k0, a.T, tid);
       __syncthreads();
     }
     if (!active) continue;
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_fwd_kernel(AttArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = q0 + am_row(r, h);
-      if (row < a.T) a.out[((size_t)bh * a.T + row) * Dv + dt * 32 + li] = o[dt][r];
+      if (row < a.T) a.out[att_base(a, a.so, bh) + (size_t)row * a.so.r + dt * 32 + li] = o[dt][r];
     }
   if (h == 0 && qok) a.lse_out[(size_t)bh * a.T + qrow] = lse;
 }
@@ -780,20 +791,20 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_q_kernel(AttArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, q0 = (blockIdx.x * 4 + wave) * 32, qrow = q0 + li;
   const bool qok = qrow < a.T, active = q0 < a.T;
-  const float* qb = a.q + (size_t)bh * a.T * A;
-  const float* kb = a.k + (size_t)bh * a.T * A;
-  const float* vb = a.v + (size_t)bh * a.T * Dv;
-  const float* ob = a.o + (size_t)bh * a.T * Dv;
-  const float* gb = a.dout + (size_t)bh * a.T * Dv;
+  const float* qb = a.q + att_base(a, a.sq, bh);
+  const float* kb = a.k + att_base(a, a.sk, bh);
+  const float* vb = a.v + att_base(a, a.sv, bh);
+  const float* ob = a.o + att_base(a, a.so, bh);
+  const float* gb = a.dout + att_base(a, a.sg, bh);
   const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
   float qreg[A / 2], doreg[Dv / 2];
   float D = 0.f;
 #pragma unroll
-  for (int ss = 0; ss < A / 2; ++ss) qreg[ss] = qok ? qb[(size_t)qrow * A + 2 * ss + h] : 0.f;
+  for (int ss = 0; ss < A / 2; ++ss) qreg[ss] = qok ? qb[(size_t)qrow * a.sq.r + 2 * ss + h] : 0.f;
 #pragma unroll
   for (int ss = 0; ss < Dv / 2; ++ss) {
-    doreg[ss] = qok ? gb[(size_t)qrow * Dv + 2 * ss + h] : 0.f;
-    D += qok ? doreg[ss] * ob[(size_t)qrow * Dv + 2 * ss + h] : 0.f;
+    doreg[ss] = qok ? gb[(size_t)qrow * a.sg.r + 2 * ss + h] : 0.f;
+    D += qok ? doreg[ss] * ob[(size_t)qrow * a.so.r + 2 * ss + h] : 0.f;
   }
   D += __shfl_xor(D, 32, 64);
   const float lse = qok ? a.lse[(size_t)bh * a.T + qrow] : 0.f;
@@ -804,15 +815,15 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_q_kernel(AttArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[at][r] = 0.f;
   if (RES) {
-    am_stage_all<A>(sK, kb, a.T, tid);
-    am_stage_all<Dv>(sV, vb, a.T, tid);
+    am_stage_all<A>(sK, kb, a.sk.r, a.T, tid);
+    am_stage_all<Dv>(sV, vb, a.sv.r, a.T, tid);
     __syncthreads();
   }
   for (int k0 = 0; k0 < a.T; k0 += 32) {
     if (!RES) {
       __syncthreads();
-      am_stage32<A>(sK, kb, k0, a.T, tid);
-      am_stage32<Dv>(sV, vb, k0, a.T, tid);
+      am_stage32<A>(sK, kb, a.sk.r, k0, a.T, tid);
+      am_stage32<Dv>(sV, vb, a.sv.r, k0, a.T, tid);
       __syncthreads();
     }
     if (!active) continue;
@@ -851,7 +862,7 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_q_kernel(AttArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = q0 + am_row(r, h);
-      if (row < a.T) a.dq[((size_t)bh * a.T + row) * A + at * 32 + li] = dq[at][r] * a.scale;
+      if (row < a.T) a.dq[att_base(a, a.sdq, bh) + (size_t)row * a.sdq.r + at * 32 + li] = dq[at][r] * a.scale;
     }
 }
 
@@ -870,17 +881,17 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_kv_kernel(AttArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h = lane >> 5;
   const int bh = blockIdx.y, k0 = (blockIdx.x * 4 + wave) * 32, krow = k0 + li;
   const bool kok = krow < a.T, active = k0 < a.T;
-  const float* qb = a.q + (size_t)bh * a.T * A;
-  const float* kb = a.k + (size_t)bh * a.T * A;
-  const float* vb = a.v + (size_t)bh * a.T * Dv;
-  const float* ob = a.o + (size_t)bh * a.T * Dv;
-  const float* gb = a.dout + (size_t)bh * a.T * Dv;
+  const float* qb = a.q + att_base(a, a.sq, bh);
+  const float* kb = a.k + att_base(a, a.sk, bh);
+  const float* vb = a.v + att_base(a, a.sv, bh);
+  const float* ob = a.o + att_base(a, a.so, bh);
+  const float* gb = a.dout + att_base(a, a.sg, bh);
   const float* biasb = a.bias ? a.bias + (size_t)(bh % a.nbias) * a.T * a.T : nullptr;
   float kreg[A / 2], vreg[Dv / 2];
 #pragma unroll
-  for (int ss = 0; ss < A / 2; ++ss) kreg[ss] = kok ? kb[(size_t)krow * A + 2 * ss + h] : 0.f;
+  for (int ss = 0; ss < A / 2; ++ss) kreg[ss] = kok ? kb[(size_t)krow * a.sk.r + 2 * ss + h] : 0.f;
 #pragma unroll
-  for (int ss = 0; ss < Dv / 2; ++ss) vreg[ss] = kok ? vb[(size_t)krow * Dv + 2 * ss + h] : 0.f;
+  for (int ss = 0; ss < Dv / 2; ++ss) vreg[ss] = kok ? vb[(size_t)krow * a.sv.r + 2 * ss + h] : 0.f;
   const float keep_scale = a.drop_p > 0.f ? 1.f / (1.f - a.drop_p) : 1.f;
   f32x16 dv[DT], dk[AT];
 #pragma unroll
@@ -898,8 +909,8 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_kv_kernel(AttArgs a) 
       float d = 0.f;
       if (qr < a.T)
         for (int c = (tid & 7) * 4; c < Dv; c += 32) {
-          const float4 g4 = *reinterpret_cast<const float4*>(gb + (size_t)qr * Dv + c);
-          const float4 o4 = *reinterpret_cast<const float4*>(ob + (size_t)qr * Dv + c);
+          const float4 g4 = *reinterpret_cast<const float4*>(gb + (size_t)qr * a.sg.r + c);
+          const float4 o4 = *reinterpret_cast<const float4*>(ob + (size_t)qr * a.so.r + c);
           d += g4.x * o4.x + g4.y * o4.y + g4.z * o4.z + g4.w * o4.w;
         }
       d += __shfl_xor(d, 1, 64);
@@ -912,16 +923,16 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_kv_kernel(AttArgs a) 
     }
   };
   if (RES) {
-    am_stage_all<A>(sQ, qb, a.T, tid);
-    am_stage_all<Dv>(sG, gb, a.T, tid);
+    am_stage_all<A>(sQ, qb, a.sq.r, a.T, tid);
+    am_stage_all<Dv>(sG, gb, a.sg.r, a.T, tid);
     stage_stats(0, Tpad, sD, sL);
     __syncthreads();
   }
   for (int q0 = 0; q0 < a.T; q0 += 32) {
     if (!RES) {
       __syncthreads();
-      am_stage32<A>(sQ, qb, q0, a.T, tid);
-      am_stage32<Dv>(sG, gb, q0, a.T, tid);
+      am_stage32<A>(sQ, qb, a.sq.r, q0, a.T, tid);
+      am_stage32<Dv>(sG, gb, a.sg.r, q0, a.T, tid);
       stage_stats(q0, 32, sD, sL);
       __syncthreads();
     }
@@ -971,14 +982,14 @@ __global__ __launch_bounds__(256) void adell_attn_mfma_bwd_kv_kernel(AttArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = k0 + am_row(r, h);
-      if (row < a.T) a.dv[((size_t)bh * a.T + row) * Dv + t * 32 + li] = dv[t][r];
+      if (row < a.T) a.dv[att_base(a, a.sdv, bh) + (size_t)row * a.sdv.r + t * 32 + li] = dv[t][r];
     }
 #pragma unroll
   for (int t = 0; t < AT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = k0 + am_row(r, h);
-      if (row < a.T) a.dk[((size_t)bh * a.T + row) * A + t * 32 + li] = dk[t][r] * a.scale;
+      if (row < a.T) a.dk[att_base(a, a.sdk, bh) + (size_t)row * a.sdk.r + t * 32 + li] = dk[t][r] * a.scale;
     }
 }
 
@@ -1046,6 +1057,23 @@ static int adell_att_launch(K kern, const AttArgs& a, int BH, size_t lds, hipStr
   return ADELL_OK;
 }
 
+// contiguous [BH][T][A | Dv] operands as strides
+static void adell_att_contiguous(AttArgs* a) {
+  const AttStride sa = {(long)a->T * a->A, 0, a->A}, sd = {(long)a->T * a->Dv, 0, a->Dv};
+  a->H = 1;
+  a->sq = a->sk = a->sdq = a->sdk = sa;
+  a->sv = a->so = a->sg = a->sdv = sd;
+}
+
+static int adell_att_stride(const char* what, const void* p, const long* s, int C, AttStride* out) {
+  ADELL_REQUIRE(p && (((uintptr_t)p) & 15) == 0, "attention (strided): %s must be 16-byte aligned", what);
+  ADELL_REQUIRE(s[0] >= 0 && s[1] >= 0 && s[2] >= C && s[0] % 4 == 0 && s[1] % 4 == 0 && s[2] % 4 == 0,
+                "attention (strided): %s strides (%ld, %ld, %ld) must be multiples of 4 elements, "
+                "rows at least %d apart", what, s[0], s[1], s[2], C);
+  out->b = s[0]; out->h = s[1]; out->r = s[2];
+  return ADELL_OK;
+}
+
 extern "C" int adell_attention_fwd(const float* q, const float* k, const float* v,
                                    const float* bias, int nbias, int BH, int T, int A, int Dv,
                                    float scale, float drop_p, unsigned long long seed,
@@ -1060,8 +1088,10 @@ extern "C" int adell_attention_fwd(const float* q, const float* k, const float* 
   ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
   a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   a.rng_offset = rng_offset;
-  if (adell_att_mfma_ok(T, A, Dv) && !g_adell_tune.attn_nomfma)
+  if (adell_att_mfma_ok(T, A, Dv) && !g_adell_tune.attn_nomfma) {
+    adell_att_contiguous(&a);
     return adell_att_mfma_launch(0, a, BH, (hipStream_t)stream);
+  }
   const size_t lds = sizeof(float) * ((size_t)ATT_TK * (A + 1) + (size_t)ATT_TK * Dv +
                                       (size_t)ATT_ROWS * A + 4 * ATT_TK);
   return adell_att_launch(adell_attention_fwd_kernel, a, BH, lds, (hipStream_t)stream);
@@ -1084,6 +1114,7 @@ extern "C" int adell_attention_bwd(const float* q, const float* k, const float* 
   a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
   a.rng_offset = rng_offset;
   if (adell_att_mfma_ok(T, A, Dv) && !g_adell_tune.attn_nomfma) {
+    adell_att_contiguous(&a);
     rc = adell_att_mfma_launch(1, a, BH, (hipStream_t)stream);
     if (rc != ADELL_OK) return rc;
     return adell_att_mfma_launch(2, a, BH, (hipStream_t)stream);
@@ -1096,4 +1127,73 @@ extern "C" int adell_attention_bwd(const float* q, const float* k, const float* 
                                          (size_t)ATT_ROWS * A + (size_t)ATT_ROWS * Dv +
                                          8 * ATT_TK + 2 * ATT_TK);
   return adell_att_launch(adell_attention_bwd_kv_kernel, a, BH, lds_kv, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same attention with every operand addressed by (item, head, token row) element strides:
+// sequence bh = b * H + h. Q / K / V can stay inside the packed [B][T][H][q | k | v] projection
+// output, O / dO are read and written as [B][T][H * Dv] token rows, dQ / dK / dV land where the
+// caller's next kernel wants them -- none of the permute / slice copies of
+// linear_blocks.py:372-417 exist as launches. MFMA-shaped heads only (adell_attention_strided_ok).
+// ---------------------------------------------------------------------------------------------
+extern "C" int adell_attention_strided_ok(int T, int A, int Dv) {
+  return adell_att_mfma_ok(T, A, Dv) && !g_adell_tune.attn_nomfma ? 1 : 0;
+}
+
+extern "C" int adell_attention_fwd_strided(const float* q, const float* k, const float* v,
+                                           const float* bias, int nbias, int B, int H, int T,
+                                           int A, int Dv, const long* strides, float scale,
+                                           float drop_p, unsigned long long seed,
+                                           unsigned int rng_offset, float* out, float* lse,
+                                           void* stream) {
+  ADELL_REQUIRE(B > 0 && H > 0 && strides, "attention_fwd_strided: bad dims");
+  int rc = adell_att_check(B * H, T, A, Dv, nbias, bias);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(adell_attention_strided_ok(T, A, Dv),
+                "attention_fwd_strided: head dims (%d, %d) at %d tokens have no MFMA instance", A, Dv, T);
+  ADELL_REQUIRE(lse, "attention_fwd_strided: null pointer");
+  AttArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.bias = bias; a.out = out; a.lse_out = lse;
+  a.T = T; a.A = A; a.Dv = Dv; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale; a.H = H;
+  ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
+  a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  a.rng_offset = rng_offset;
+  if ((rc = adell_att_stride("q", q, strides, A, &a.sq)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("k", k, strides + 3, A, &a.sk)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("v", v, strides + 6, Dv, &a.sv)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("out", out, strides + 9, Dv, &a.so)) != ADELL_OK) return rc;
+  return adell_att_mfma_launch(0, a, B * H, (hipStream_t)stream);
+}
+
+extern "C" int adell_attention_bwd_strided(const float* q, const float* k, const float* v,
+                                           const float* bias, int nbias, const float* out,
+                                           const float* dout, const float* lse, int B, int H,
+                                           int T, int A, int Dv, const long* strides, float scale,
+                                           float drop_p, unsigned long long seed,
+                                           unsigned int rng_offset, float* dq, float* dk,
+                                           float* dv, void* stream) {
+  ADELL_REQUIRE(B > 0 && H > 0 && strides, "attention_bwd_strided: bad dims");
+  int rc = adell_att_check(B * H, T, A, Dv, nbias, bias);
+  if (rc != ADELL_OK) return rc;
+  ADELL_REQUIRE(adell_attention_strided_ok(T, A, Dv),
+                "attention_bwd_strided: head dims (%d, %d) at %d tokens have no MFMA instance", A, Dv, T);
+  ADELL_REQUIRE(lse, "attention_bwd_strided: null pointer");
+  AttArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.bias = bias; a.o = out; a.dout = dout; a.lse = lse;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.T = T; a.A = A; a.Dv = Dv; a.nbias = nbias > 0 ? nbias : 1; a.scale = scale; a.H = H;
+  ADELL_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention: bad dropout probability");
+  a.drop_p = drop_p; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32);
+  a.rng_offset = rng_offset;
+  if ((rc = adell_att_stride("q", q, strides, A, &a.sq)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("k", k, strides + 3, A, &a.sk)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("v", v, strides + 6, Dv, &a.sv)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("out", out, strides + 9, Dv, &a.so)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("dout", dout, strides + 12, Dv, &a.sg)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("dq", dq, strides + 15, A, &a.sdq)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("dk", dk, strides + 18, A, &a.sdk)) != ADELL_OK) return rc;
+  if ((rc = adell_att_stride("dv", dv, strides + 21, Dv, &a.sdv)) != ADELL_OK) return rc;
+  rc = adell_att_mfma_launch(1, a, B * H, (hipStream_t)stream);
+  if (rc != ADELL_OK) return rc;
+  return adell_att_mfma_launch(2, a, B * H, (hipStream_t)stream);
 }

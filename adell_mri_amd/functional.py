@@ -45,6 +45,8 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          # 1x1x1 stride-1 convolutions with >= 64 channels on one side (>= 8 on the other) stay on the implicit-GEMM
          # conv kernels instead of the Linear-layer GEMMs (conv3d)
          "no_pointwise_gemm": bool(os.environ.get("ADELL_NO_POINTWISE_GEMM")),
+         # full-sequence attention by slices + copies around the kernels (the pre-round-4 form)
+         "no_seq_attention": bool(os.environ.get("ADELL_NO_SEQ_ATTENTION")),
          # weight gradient of the narrow-input convs on the exact fp32-MFMA kernel (A/B)
          "no_cinfold_wgrad_f16": bool(os.environ.get("ADELL_NO_CINFOLD_WGRAD_F16"))}
 
@@ -1342,6 +1344,84 @@ def window_attention(qkv, q_gamma, q_beta, k_gamma, k_beta, n_windows, n_heads, 
     return _WindowAttnFn.apply(qkv.contiguous(), q_gamma, q_beta, k_gamma, k_beta, rel, mask, conf)
 
 
+class _SeqAttnFn(torch.autograd.Function):
+    """q-norm, k-norm and full-sequence attention on the projection output [B*T, H*(2a+hd)]
+    whose heads are laid out q | k | v (linear_blocks.py:372-417), for the MFMA-shaped heads.
+    As in the windowed form nothing is sliced or permuted: the LayerNorm kernel reads the q / k
+    slices in place (token-major outputs), the attention kernels address every operand by
+    (item, head, row) strides -- V inside the projection, O as [B, T, H*hd] token rows -- and the
+    backward writes the three gradients straight into dQKV."""
+
+    @staticmethod
+    def _strides(T, H, a, hd):
+        per = 2 * a + hd
+        tok = (T * H * a, a, H * a)            # [B, T, H, a] token-major q / k (and dq / dk)
+        pak = (T * H * per, per, H * per)      # rows inside the packed projection
+        out = (T * H * hd, hd, H * hd)         # [B, T, H * hd]
+        return tok, pak, out
+
+    @staticmethod
+    def forward(ctx, qkv, qg, qb, kg, kb, bias, conf):
+        B, H, T, a, hd, scale, drop_p, seed, offset, eps = conf
+        per = 2 * a + hd
+        flat = qkv.view(-1)
+        rows = B * T * H
+        qn, qm, qr = ops.layernorm_rows_fwd(flat, rows, a, 1, per, 0, qg, qb, eps)
+        kn, km, kr = ops.layernorm_rows_fwd(flat[a:], rows, a, 1, per, 0, kg, kb, eps)
+        tok, pak, out = _SeqAttnFn._strides(T, H, a, hd)
+        o = torch.empty((B * T, H * hd), device=qkv.device, dtype=torch.float32)
+        lse = ops.attention_fwd_strided(qn, kn, flat[2 * a:], o, tok + tok + pak + out, bias, B, H, T,
+                                        a, hd, scale, drop_p, seed, offset)
+        ctx.save_for_backward(qkv, qg, kg, qn, kn, qm, qr, km, kr, o, lse, bias)
+        ctx.conf = conf
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, qg, kg, qn, kn, qm, qr, km, kr, o, lse, bias = ctx.saved_tensors
+        B, H, T, a, hd, scale, drop_p, seed, offset, eps = ctx.conf
+        if bias is not None and ctx.needs_input_grad[5]:
+            raise NotImplementedError("attention bias gradient of the full-sequence form")
+        per = 2 * a + hd
+        rows = B * T * H
+        need = ctx.needs_input_grad
+        flat = qkv.view(-1)
+        dqkv = torch.empty_like(qkv)
+        dflat = dqkv.view(-1)
+        dqn, dkn = torch.empty_like(qn), torch.empty_like(kn)
+        tok, pak, out = _SeqAttnFn._strides(T, H, a, hd)
+        ops.attention_bwd_strided(qn, kn, flat[2 * a:], o, do.contiguous(), lse, dqn, dkn,
+                                  dflat[2 * a:], tok + tok + pak + out + out + tok + tok + pak, bias,
+                                  B, H, T, a, hd, scale, drop_p, seed, offset)
+        dqg, dqb = ops.layernorm_rows_bwd(flat, dqn, qg, qm, qr, rows, a, 1, per, 0, dflat, per, 0,
+                                          need[1] or need[2])
+        dkg, dkb = ops.layernorm_rows_bwd(flat[a:], dkn, kg, km, kr, rows, a, 1, per, 0, dflat[a:],
+                                          per, 0, need[3] or need[4])
+        return dqkv, dqg, dqb, dkg, dkb, None, None
+
+
+def seq_attention_ok(tokens, a, hd):
+    """Whether ``seq_attention`` covers these head sizes (otherwise: slices + ``attention``)."""
+    return (not FLAGS["no_seq_attention"] and a % 4 == 0 and hd % 4 == 0
+            and ops.attention_strided_ok(tokens, a, hd))
+
+
+def seq_attention(qkv, q_gamma, q_beta, k_gamma, k_beta, batch, n_heads, tokens, a, hd, bias=None,
+                  drop_p=0.0, training=False, eps=1e-5):
+    """qkv: [batch * tokens, n_heads * (2a + hd)] -> [batch * tokens, n_heads * hd]; bias
+    [nbias, tokens, tokens] or None is added to the scores of sequence (b, h) as
+    bias[(b * n_heads + h) % nbias]."""
+    p = float(drop_p) if training else 0.0
+    seed, offset = 0, 0
+    if p > 0.0:
+        seed = torch.initial_seed()
+        offset = next(_dropout_counter)
+    conf = (int(batch), int(n_heads), int(tokens), int(a), int(hd), 1.0 / (a ** 0.5), p, seed,
+            offset, float(eps))
+    bias = None if bias is None else bias.contiguous()
+    return _SeqAttnFn.apply(qkv.contiguous(), q_gamma, q_beta, k_gamma, k_beta, bias, conf)
+
+
 class _AddBcastFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
@@ -1366,6 +1446,10 @@ class _AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, bias, scale, drop):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        if bias is not None:
+            # an expanded mask ([1, 1, T, T] -> heads) reshapes to a stride-0 VIEW: the backward
+            # must see the same materialised rows the forward used
+            bias = bias.contiguous()
         out, lse = ops.attention_fwd(q, k, v, bias, scale, *drop)
         ctx.save_for_backward(q, k, v, bias, out, lse)
         ctx.scale, ctx.drop = scale, drop

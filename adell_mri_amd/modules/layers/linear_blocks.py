@@ -145,16 +145,24 @@ class MultiHeadSelfAttention(torch.nn.Module):
             return self.output_layer(O.view(*b, t, self.hidden_dim), residual=residual)
         if self.window_size:
             raise NotImplementedError("windowed attention beyond 64 tokens per window")
+        bias = None
+        if mask is not None:
+            m = mask.to(device=X.device, dtype=torch.float32)
+            if m.ndim == 3:
+                m = m.unsqueeze(1)
+            bias = m.expand(nb, self.n_heads, t, t).reshape(nb * self.n_heads, t, t)
+        if self.q_norm.weight is not None and HF.seq_attention_ok(t, a, h):
+            # q-norm, k-norm and attention on the projection output in place: no slices, no
+            # permutes (functional._SeqAttnFn)
+            O = HF.seq_attention(self.qkv(X).reshape(nb * t, self.qkv_dim), self.q_norm.weight,
+                                 self.q_norm.bias, self.k_norm.weight, self.k_norm.bias, nb,
+                                 self.n_heads, t, a, h, bias=bias, drop_p=self.dropout_rate,
+                                 training=self.training, eps=self.q_norm.eps)
+            return self.output_layer(O.view(*b, t, self.hidden_dim), residual=residual)
         QKV = self.qkv(X).reshape(nb, t, self.n_heads, 2 * a + h).permute(0, 2, 1, 3)
         Q = self.q_norm(QKV[..., :a].contiguous())      # per-head interleaved q | k | v
         K = self.k_norm(QKV[..., a:2 * a].contiguous())
         V = QKV[..., 2 * a:].contiguous()
-        bias = None
-        if mask is not None:
-            m = mask.to(Q)
-            if m.ndim == 3:
-                m = m.unsqueeze(1)
-            bias = m.expand(nb, self.n_heads, t, t).reshape(nb * self.n_heads, t, t)
         O = HF.attention(Q.reshape(nb * self.n_heads, t, a), K.reshape(nb * self.n_heads, t, a),
                          V.reshape(nb * self.n_heads, t, h), bias, drop_p=self.dropout_rate,
                          training=self.training)

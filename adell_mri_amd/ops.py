@@ -1300,6 +1300,8 @@ def attention_bwd(q, k, v, bias, out, dout, lse, scale, drop_p=0.0, seed=0, offs
     Dv = v.shape[-1]
     dout = dout.contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if bias is not None:
+        bias = bias.contiguous()
     nb = 0 if bias is None else bias.numel() // (T * T)
     check(_lib.lib().adell_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, _ptr(out),
                                          _ptr(dout), _ptr(lse), BH, T, A, Dv, float(scale),
@@ -1556,6 +1558,39 @@ def gather_nd(x, dims, axes, out=None):
         LongD(*[int(d[2]) for d in dims]), na, LongA(*[int(a[0]) for a in axes]),
         LongA(*[int(a[1]) for a in axes]), LongA(*[int(a[2]) for a in axes]), _stream()))
     return out
+
+
+def attention_strided_ok(T, A, Dv):
+    return bool(_lib.lib().adell_attention_strided_ok(int(T), int(A), int(Dv)))
+
+
+def attention_fwd_strided(q, k, v, out, strides, bias, B, H, T, A, Dv, scale, drop_p=0.0, seed=0,
+                          offset=0):
+    """q, k, v, out: tensors whose data pointers are the first rows of sequence 0 (flat views
+    into packed buffers are fine); strides: 12 element strides, (item, head, row) for each of
+    q, k, v, out. Writes ``out``; returns lse [B*H, T]."""
+    _require_cuda(q, k, v, out, bias)
+    bias = None if bias is None else bias.contiguous()
+    lse = torch.empty((B * H, T), device=q.device, dtype=torch.float32)
+    nb = 0 if bias is None else bias.numel() // (T * T)
+    st = (ctypes.c_long * 12)(*[int(x) for x in strides])
+    check(_lib.lib().adell_attention_fwd_strided(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, B, H, T, A, Dv, st, float(scale), float(drop_p),
+        int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF, _ptr(out), _ptr(lse), _stream()))
+    return lse
+
+
+def attention_bwd_strided(q, k, v, out, dout, lse, dq, dk, dv, strides, bias, B, H, T, A, Dv, scale,
+                          drop_p=0.0, seed=0, offset=0):
+    """strides: 24 element strides, (item, head, row) for q, k, v, out, dout, dq, dk, dv."""
+    _require_cuda(q, k, v, out, dout, lse, dq, dk, dv, bias)
+    bias = None if bias is None else bias.contiguous()
+    nb = 0 if bias is None else bias.numel() // (T * T)
+    st = (ctypes.c_long * 24)(*[int(x) for x in strides])
+    check(_lib.lib().adell_attention_bwd_strided(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(bias), nb, _ptr(out), _ptr(dout), _ptr(lse), B, H, T, A, Dv,
+        st, float(scale), float(drop_p), int(seed) & 0xFFFFFFFFFFFFFFFF, int(offset) & 0xFFFFFFFF,
+        _ptr(dq), _ptr(dk), _ptr(dv), _stream()))
 
 
 def layernorm_rows_fwd(x, rows, C, inner, so, si, gamma, beta, eps):

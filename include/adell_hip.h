@@ -506,6 +506,25 @@ int adell_attention_bwd(const float* q, const float* k, const float* v, const fl
                         int BH, int T, int A, int Dv, float scale, float drop_p,
                         unsigned long long seed, unsigned int rng_offset, float* dq, float* dk,
                         float* dv, void* stream);
+/* The same attention with every operand addressed by element strides: sequence bh = b * H + h,
+ * `strides` holds (item b, head h, token row) triples in the order q, k, v, out (forward: 12
+ * values) and q, k, v, out, dout, dq, dk, dv (backward: 24). Q / K / V may stay inside the packed
+ * [B][T][H][q | k | v] projection output of linear_blocks.py:372-385, O / dO are [B][T][H * Dv]
+ * token rows, dV can land inside the packed gradient: the slice / permute copies around
+ * F.scaled_dot_product_attention (linear_blocks.py:380-417) are not launches. Strides are
+ * multiples of 4 elements, pointers 16-byte aligned; MFMA-shaped heads only
+ * (adell_attention_strided_ok: A, Dv in {32, 64, 128}, T >= 16), ADELL_E_BADARG otherwise. */
+int adell_attention_strided_ok(int T, int A, int Dv);
+int adell_attention_fwd_strided(const float* q, const float* k, const float* v, const float* bias,
+                                int nbias, int B, int H, int T, int A, int Dv, const long* strides,
+                                float scale, float drop_p, unsigned long long seed,
+                                unsigned int rng_offset, float* out, float* lse, void* stream);
+int adell_attention_bwd_strided(const float* q, const float* k, const float* v, const float* bias,
+                                int nbias, const float* out, const float* dout, const float* lse,
+                                int B, int H, int T, int A, int Dv, const long* strides,
+                                float scale, float drop_p, unsigned long long seed,
+                                unsigned int rng_offset, float* dq, float* dk, float* dv,
+                                void* stream);
 
 /* ------------------------------------------------------------------------
  * Data movement for the U-Net++ dense links (standard_blocks.py:365-371):

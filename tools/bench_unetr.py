@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", action="store_true", help="per (kernel, shape) table instead of the JSON line")
+    ap.add_argument("--ab", default=None, help="functional.FLAGS name: alternate blocks of steps with the flag "
+                                               "off / on in this one process and print both medians")
     args = ap.parse_args()
     from adell_mri_amd import ops
     from adell_mri_amd.modules.activations import activation_factory
@@ -56,6 +58,26 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    if args.ab:
+        import statistics
+        from adell_mri_amd import functional as HF
+        res = {False: [], True: []}
+        for _ in range(6):
+            for flag in (False, True):
+                HF.FLAGS[args.ab] = flag
+                step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                res[flag].append(1e3 * (time.perf_counter() - t0) / args.steps)
+        HF.FLAGS[args.ab] = False
+        print(json.dumps({"flag": args.ab, "ms_per_step_off": round(statistics.median(res[False]), 3),
+                          "ms_per_step_on": round(statistics.median(res[True]), 3),
+                          "blocks_off": [round(v, 2) for v in res[False]],
+                          "blocks_on": [round(v, 2) for v in res[True]]}))
+        return
     ops.KERNEL_TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
