@@ -377,17 +377,20 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
 #endif
 }
 
-// fixed-order fold of the split-K slabs (+ bias, residual). A block takes 64 consecutive outputs
-// (x V floats each) and spreads the slabs over its 16 waves, four independent loads in flight per
-// thread: wave q sums slabs q, q + 16, ... in that order, the 16 wave sums are added in wave order
-// -- one fixed tree, whatever the launch. (One thread per output walking all the slabs took 120 us
-// for 171 slabs of 96 x 384: 25 MB behind 144 blocks' worth of load latency.)
-template <int V>
-__global__ __launch_bounds__(1024) void adell_gemm_f16x3_fold_kernel(GemmHArgs a) {
-  __shared__ float sh[16][64 * V];
+// fixed-order fold of the split-K slabs (+ bias, residual). A block takes OPB consecutive outputs
+// (x V floats each) and spreads the slabs over G thread groups of OPB threads, four independent
+// loads in flight per thread: group q sums slabs q, q + G, ... in that
+// order, the G group sums are added in group order -- one fixed tree per (splits, shape). G follows
+// the slab count (1 / 4 / 16): one thread per output walking all the slabs took 120 us for 171
+// slabs of 96 x 384 (25 MB behind 144 blocks' worth of load latency), 16 groups on a two-slab
+// fold cost 10 us instead of 5.
+template <int V, int G>
+__global__ __launch_bounds__(G == 16 ? 1024 : 256) void adell_gemm_f16x3_fold_kernel(GemmHArgs a) {
+  constexpr int NT = G == 16 ? 1024 : 256, OPB = NT / G;
+  __shared__ float sh[G][OPB * V];
   const long total = (long)a.M * a.N;
-  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const long i = ((long)blockIdx.x * 64 + e) * V;
+  const int e = threadIdx.x % OPB, q = threadIdx.x / OPB;
+  const long i = ((long)blockIdx.x * OPB + e) * V;
   float acc[4][V];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -404,27 +407,50 @@ __global__ __launch_bounds__(1024) void adell_gemm_f16x3_fold_kernel(GemmHArgs a
   };
   if (i < total) {
     int sp = q;
-    for (; sp + 3 * 16 < a.splits; sp += 4 * 16) {
+    for (; sp + 3 * G < a.splits; sp += 4 * G) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) add(u, sp + 16 * u);
+      for (int u = 0; u < 4; ++u) add(u, sp + G * u);
     }
-    for (; sp < a.splits; sp += 16) add(0, sp);
+    for (; sp < a.splits; sp += G) add(0, sp);
   }
+  float t[V];
 #pragma unroll
-  for (int v = 0; v < V; ++v) sh[q][e * V + v] = (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
-  __syncthreads();
-  if (q == 0 && i < total) {
-    const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+  for (int v = 0; v < V; ++v) t[v] = (acc[0][v] + acc[1][v]) + (acc[2][v] + acc[3][v]);
+  if constexpr (G > 1) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) sh[q][e * V + v] = t[v];
+    __syncthreads();
+    if (q != 0) return;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      float s = 0.f;
+      t[v] = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) s += sh[k][e * V + v];
-      if (a.bias) s += a.bias[col + v];
-      if (a.residual) s += a.residual[(long)row * a.ldr + col + v];
-      a.C[(long)row * a.ldc + col + v] = s;
+      for (int k = 0; k < G; ++k) t[v] += sh[k][e * V + v];
     }
   }
+  if (i >= total) return;
+  const int row = (int)(i / a.N), col = (int)(i - (long)row * a.N);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    float s = t[v];
+    if (a.bias) s += a.bias[col + v];
+    if (a.residual) s += a.residual[(long)row * a.ldr + col + v];
+    a.C[(long)row * a.ldc + col + v] = s;
+  }
+}
+
+template <int V>
+static void adell_gemm_f16x3_fold(const GemmHArgs& a, hipStream_t st) {
+  const long units = ((long)a.M * a.N + V - 1) / V;
+  if (a.splits >= 32)
+    hipLaunchKernelGGL((adell_gemm_f16x3_fold_kernel<V, 16>), dim3((unsigned)((units + 63) / 64)),
+                       dim3(1024), 0, st, a);
+  else if (a.splits >= 8)
+    hipLaunchKernelGGL((adell_gemm_f16x3_fold_kernel<V, 4>), dim3((unsigned)((units + 63) / 64)),
+                       dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((adell_gemm_f16x3_fold_kernel<V, 1>), dim3((unsigned)((units + 255) / 256)),
+                       dim3(256), 0, st, a);
 }
 
 // absmax (float bits, atomicMax into a zero-initialised word) of n floats
@@ -564,13 +590,10 @@ extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, i
     rc = launch(adell_gemm_f16x3_kernel<false, true>);
   if (rc != ADELL_OK) return rc;
   if (p.splits > 1) {
-    const long total = (long)M * N;
     if (N % 4 == 0 && (((uintptr_t)a.slab) & 15) == 0)
-      hipLaunchKernelGGL(adell_gemm_f16x3_fold_kernel<4>, dim3((unsigned)((total / 4 + 63) / 64)),
-                         dim3(1024), 0, st, a);
+      adell_gemm_f16x3_fold<4>(a, st);
     else
-      hipLaunchKernelGGL(adell_gemm_f16x3_fold_kernel<1>, dim3((unsigned)((total + 63) / 64)),
-                         dim3(1024), 0, st, a);
+      adell_gemm_f16x3_fold<1>(a, st);
     ADELL_CHECK_HIP(hipGetLastError());
   }
   return ADELL_OK;

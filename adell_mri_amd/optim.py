@@ -47,12 +47,19 @@ class FlatParameters:
         # parallel.GradSync: the slot holds this step's (reduced) gradient although ``p.grad`` is
         # detached from it while the collective runs
         self.reduced = [False] * len(self.params)
+        # the per-step loops below run once per parameter on the host (a few hundred parameters:
+        # a millisecond of a 20 ms step if they slice, view and compare tensors): slot views,
+        # slot addresses and the "has a gradient" mask are made once / once per collect
+        self._slots = [self.grad[o:o + p.numel()].view(p.shape)
+                       for p, o in zip(self.params, self.offsets)]
+        self._slot_ptr = [self.grad.data_ptr() + 4 * o for o in self.offsets]
+        self._has = None
         with torch.no_grad():
-            for p, o in zip(self.params, self.offsets):
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 view = self.data[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                p.grad = self._slots[i]
                 # functional._side_ok: gradients of these parameters are read only through
                 # collect() / zero_grad(), which join the weight-gradient stream first
                 p._adell_flat = True
@@ -60,8 +67,7 @@ class FlatParameters:
     CHUNK = 16384
 
     def slot(self, i):
-        p, o = self.params[i], self.offsets[i]
-        return self.grad[o:o + p.numel()].view(p.shape)
+        return self._slots[i]
 
     def zero_grad(self, set_to_none=True):
         """Zero the flat gradient. ``set_to_none`` (torch's default) also detaches the
@@ -70,8 +76,13 @@ class FlatParameters:
         flat buffer with one launch. Otherwise ``p.grad`` stays a view of the flat buffer."""
         from . import functional as HF
         self.grad.zero_()
-        for i, p in enumerate(self.params):
-            p.grad = None if set_to_none else self.slot(i)
+        self._has = None
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+        else:
+            for p, v in zip(self.params, self._slots):
+                p.grad = v
         HF.reset_uses(self.params)
 
     def _upload_and_copy(self, rows):
@@ -104,21 +115,32 @@ class FlatParameters:
         from . import functional as HF
         if not on_side_stream:
             HF.join_side_stream()     # weight gradients still running on the side stream
-        base = self.grad.data_ptr()
         todo, keep = [], []
-        idx = range(len(self.params)) if indices is None else indices
+        params, offsets, slots, slot_ptr = self.params, self.offsets, self._slots, self._slot_ptr
+        idx = range(len(params)) if indices is None else indices
+        dev, f32 = self.grad.device, torch.float32
+        has = np.zeros(len(params), dtype=bool) if indices is None else None
         for i in idx:
-            p, o = self.params[i], self.offsets[i]
-            g = p.grad
-            if g is None or g.data_ptr() == base + 4 * o or g.numel() == 0:
+            g = params[i].grad
+            if g is None:
                 continue
-            if g.dtype != torch.float32 or g.device != self.grad.device:
+            if has is not None:
+                has[i] = True
+            ptr = g.data_ptr()
+            if ptr == slot_ptr[i]:
+                continue
+            n = g.numel()
+            if n == 0:
+                continue
+            if g.dtype != f32 or g.device != dev:
                 raise ValueError("FlatParameters.collect: gradients must be fp32 on the GPU")
-            g = g.contiguous()
+            if not g.is_contiguous():
+                g = g.contiguous()
+                ptr = g.data_ptr()
             if on_side_stream:       # (may have been produced on another stream: alive till the join)
                 HF.side_keep(g)
             keep.append(g)
-            todo.append((g.data_ptr(), o, g.numel()))
+            todo.append((ptr, offsets[i], n))
         if todo:
             # one row per CHUNK-element piece of every gradient, built without a Python loop
             ptr, off, num = np.array(todo, dtype=np.int64).T
@@ -129,11 +151,16 @@ class FlatParameters:
                              np.minimum(self.CHUNK, num[ix] - start)], 1)
             self._upload_and_copy(rows)
         for i in idx:
-            p = self.params[i]
+            p = params[i]
             if p.grad is not None:
-                p.grad = self.slot(i)
+                p.grad = slots[i]
+        self._has = has
 
     def has_grad(self):
+        """Which parameters hold a gradient (after a full ``collect()``: the mask it made; a
+        ``.grad`` set or cleared by hand since then is not seen -- ``zero_grad`` resets it)."""
+        if self._has is not None:
+            return self._has.copy()
         return np.fromiter((p.grad is not None for p in self.params), dtype=bool,
                            count=len(self.params))
 
@@ -142,6 +169,11 @@ class FlatParameters:
         [(first index, element offset, element end)], ends padded so that a run is one
         contiguous 16-byte-aligned slice of the flat buffers."""
         out, i, n = [], 0, len(self.params)
+        active = np.asarray(active)
+        if n and active.all() and self.numel > 0:       # the usual step: ONE run, no scan
+            k = None if key is None else np.asarray(key)
+            if k is None or (k == k[0]).all():
+                return [(0, self.offsets[0], self.ends[-1])]
         while i < n:
             if not active[i]:
                 i += 1

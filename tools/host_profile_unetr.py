@@ -53,3 +53,12 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(34)
+# who issues the device-to-device copies / host uploads (rocclr copyBuffer in the kernel trace)
+st.print_callers("copy_|contiguous|clone|'to' of|tensor|zeros|full")
+# one step under the torch profiler: memcpy / memset records with the op that issued them
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    step()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=40, max_name_column_width=60))
+
