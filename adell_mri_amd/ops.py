@@ -153,8 +153,22 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_CHECK_DENSE = bool(os.environ.get("ADELL_CHECK_DENSE"))
+
+
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device address of ``t``. The kernels index dense memory (row-major, or NDHWC for 5-D / NHWC
+    for 4-D activations): with ADELL_CHECK_DENSE=1 a tensor that is neither -- an expanded
+    stride-0 view, a slice with gaps -- raises here instead of being read past its storage (the test
+    suite is run once per round with the check on)."""
+    if t is None:
+        return None
+    if _CHECK_DENSE and not (t.is_contiguous()
+                             or (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d))
+                             or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
+        raise _lib.AdellHipError(f"non-dense tensor handed to a kernel: shape {tuple(t.shape)}, "
+                                 f"strides {t.stride()}")
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def _require_cuda(*ts):
