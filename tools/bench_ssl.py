@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--ema", action="store_true")
     ap.add_argument("--layers", action="store_true", help="per (kernel, shape) table instead of the JSON line")
+    ap.add_argument("--ab", default=None, help="launch-plan switch of adell_set_tuning (or hf:<flag> of functional.FLAGS): "
+                                               "alternate blocks of steps with it off / on in this process")
     args = ap.parse_args()
     from adell_mri_amd import ops
     from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
@@ -51,6 +53,35 @@ def main():
     for _ in range(args.warmup):
         runner.train_step(batch)
     torch.cuda.synchronize()
+    if args.ab:
+        import statistics
+        from adell_mri_amd import _lib, functional as HF
+
+        def set_switch(v):
+            if args.ab.startswith("hf:"):
+                HF.FLAGS[args.ab[3:]] = bool(v)
+            else:
+                _lib.lib().adell_set_tuning(args.ab.encode(), int(v))
+            torch.cuda.synchronize()
+            HF._ADN_PLAN.clear()
+
+        res = {0: [], 1: []}
+        for _ in range(6):
+            for v in (0, 1):
+                set_switch(v)
+                runner.train_step(batch)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    runner.train_step(batch)
+                torch.cuda.synchronize()
+                res[v].append(1e3 * (time.perf_counter() - t0) / args.steps)
+        set_switch(0)
+        print(json.dumps({"switch": args.ab, "ms_per_step_off": round(statistics.median(res[0]), 3),
+                          "ms_per_step_on": round(statistics.median(res[1]), 3),
+                          "blocks_off": [round(v, 2) for v in res[0]],
+                          "blocks_on": [round(v, 2) for v in res[1]]}))
+        return
     ops.KERNEL_TIMER = ops.KernelTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
