@@ -233,6 +233,8 @@ SIGNATURES = {
     "adell_gemm_f16x3_workspace_floats": (_l, [_i, _i, _i]),
     "adell_gemm_f16x3": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _l, _vp, _vp,
                               _vp, _vp]),
+    "adell_gemm_f16x3_act": (_i, [_i, _i, _i, _vp, _l, _i, _vp, _l, _i, _vp, _l, _vp, _vp, _l, _vp,
+                                  _vp, _vp, _i, _f, _vp, _vp, _vp]),
     "adell_optim_step": (_i, [_i, _vp, _vp, _vp, _vp, _l, _f, _f, _f, ctypes.POINTER(ctypes.c_float),
                               _vp]),
     "adell_seg_loss_workspace": (_l, [_i, _l, _i]),

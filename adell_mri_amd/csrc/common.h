@@ -32,6 +32,7 @@ struct AdellTuning {
   int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)
   int dw_nozring;                 // depthwise 7^3: the 4 x 4 tile kernel instead of the z-marching one
   int gemm_nosmall;               // fp32 GEMM: no streaming kernels for Linear layers with <= 32 features
+  int gemm_nowide;                // f16x3 GEMM: scalar epilogue stores from the MFMA layout (no LDS pass)
   int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)
   int wgrad_no16;                 // z-ring weight gradient: 32 x 32 tiles even for 16-channel layers
   int igemm_no16;                 // forward / backward-data of 16 -> 16 layers: not the z-ring 16-column kernel
@@ -101,6 +102,50 @@ __device__ __forceinline__ double adell_wave_sum_d(double v) {
 // kernels VALU-bound at ~2.5 TB/s.
 __device__ __forceinline__ float adell_sigmoidf(float x) {
   return __frcp_rn(1.0f + __expf(-x));
+}
+
+// ---------------------------------------------------------------------------
+// Activations
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float adell_act_fwd(int act, float x, float p) {
+  switch (act) {
+    case ADELL_ACT_SILU: return x * adell_sigmoidf(x);
+    case ADELL_ACT_RELU: return x > 0.f ? x : 0.f;
+    case ADELL_ACT_LEAKY_RELU: return x > 0.f ? x : p * x;
+    case ADELL_ACT_PRELU: return x > 0.f ? x : p * x;
+    case ADELL_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    case ADELL_ACT_SIGMOID: return adell_sigmoidf(x);
+    case ADELL_ACT_TANH: return tanhf(x);
+    case ADELL_ACT_ELU: return x > 0.f ? x : p * (expf(x) - 1.0f);
+    default: return x;
+  }
+}
+// d act(x) / dx
+__device__ __forceinline__ float adell_act_grad(int act, float x, float p) {
+  switch (act) {
+    case ADELL_ACT_SILU: {
+      const float s = adell_sigmoidf(x);
+      return s * (1.0f + x * (1.0f - s));
+    }
+    case ADELL_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case ADELL_ACT_LEAKY_RELU: return x > 0.f ? 1.f : p;
+    case ADELL_ACT_PRELU: return x > 0.f ? 1.f : p;
+    case ADELL_ACT_GELU: {
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+      const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+      return cdf + x * pdf;
+    }
+    case ADELL_ACT_SIGMOID: {
+      const float s = adell_sigmoidf(x);
+      return s * (1.0f - s);
+    }
+    case ADELL_ACT_TANH: {
+      const float t = tanhf(x);
+      return 1.0f - t * t;
+    }
+    case ADELL_ACT_ELU: return x > 0.f ? 1.f : p * expf(x);
+    default: return 1.f;
+  }
 }
 
 // Philox-4x32 counter RNG, 7 rounds (Salmon et al., SC'11: the fewest rounds of this generator that

@@ -44,6 +44,11 @@ struct GemmHArgs {
   int M, N, K;
   long lda, ldb, ldc, ldr;
   int splits, stages_per_split;
+  // wide epilogue / the fold: an activation around the output (ld = ldc for both tensors)
+  float* act_out;        // also store act(C) here (Linear -> activation: both tensors in one pass)
+  const float* dact_in;  // multiply the output by act'(dact_in) (the backward of that pair)
+  int act;
+  float act_p;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64, NCH = BK / 16;
@@ -157,7 +162,7 @@ __device__ __forceinline__ void gemm_h_put(char* tile, const float4 (&f)[8], flo
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [A | B] 64 KB + 8 floats
   float* sMax = reinterpret_cast<float*>(smem + 2 * kTileBytes);
@@ -353,6 +358,61 @@ __global__ __launch_bounds__(256, 2) void adell_gemm_f16x3_kernel(GemmHArgs a) {
           }
         }
 #else
+  if constexpr (WIDE) {
+    // Wide epilogue (N and the leading dimensions multiples of 4): the tile goes through the LDS
+    // image (free after the last stage: 128 x 128 floats = 64 KB) and ONE rolled loop applies bias /
+    // residual / activation to 16-byte row pieces -- 16 stores of 16 B per thread instead of 64 of
+    // 4 B (VICReg ConvNeXt step -0.5 ms). The activation lives only here: inlined into the 64
+    // unrolled stores of the scalar epilogue it made the kernel 190 KB of code (9 activations x 64
+    // sites) and the step 3 ms SLOWER than the element-wise passes it replaced -- instruction-cache
+    // misses.
+    __syncthreads();
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wn * 64 + j * 32 + li] =
+              acc[i][j][r] * oscale;
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < BM * BN / 4 / 256; ++it) {
+      const int idx = it * 256 + tid, rl = idx >> 5, cl = (idx & 31) * 4;
+      const int row = m0 + rl, col = n0 + cl;
+      if (row >= a.M || col >= a.N) continue;
+      float4 v4 = *reinterpret_cast<const float4*>(sC + rl * BN + cl);
+      if (!direct) {   // split K: this block's slab (bias / residual / activation ride the fold)
+        *reinterpret_cast<float4*>(a.slab + ((long)split * a.M + row) * a.N + col) = v4;
+        continue;
+      }
+      float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      const long o = (long)row * a.ldc + col;
+      if (a.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + col);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (a.residual) {
+        const float4 r4 = *reinterpret_cast<const float4*>(a.residual + (long)row * a.ldr + col);
+        v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+      }
+      if (a.dact_in) {
+        const float4 d4 = *reinterpret_cast<const float4*>(a.dact_in + o);
+        const float d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) v[q] *= adell_act_grad(a.act, d[q], a.act_p);
+      }
+      *reinterpret_cast<float4*>(a.C + o) = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.act_out) {
+        float g[4];
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) g[q] = adell_act_fwd(a.act, v[q], a.act_p);
+        *reinterpret_cast<float4*>(a.act_out + o) = make_float4(g[0], g[1], g[2], g[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -435,6 +495,8 @@ __global__ __launch_bounds__(G == 16 ? 1024 : 256) void adell_gemm_f16x3_fold_ke
     float s = t[v];
     if (a.bias) s += a.bias[col + v];
     if (a.residual) s += a.residual[(long)row * a.ldr + col + v];
+    if (a.dact_in) s *= adell_act_grad(a.act, a.dact_in[(long)row * a.ldc + col + v], a.act_p);
+    if (a.act_out) a.act_out[(long)row * a.ldc + col + v] = adell_act_fwd(a.act, s, a.act_p);
     a.C[(long)row * a.ldc + col + v] = s;
   }
 }
@@ -544,11 +606,12 @@ extern "C" long adell_gemm_f16x3_workspace_floats(int M, int N, int K) {
 // Same contract as adell_gemm_f32 + a_absmax / b_absmax: both NULL (operand scales chosen per block
 // and 64-k stage inside the kernel), or device words holding the float bits of the absmax of the
 // A / B tensors (adell_absmax_f32, or any upper bound within a factor of 2^10): one scale per tensor.
-extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, int a_kc,
-                                const float* B, long ldb, int b_kc, float* C, long ldc,
-                                const float* bias, const float* residual, long ldr,
-                                const uint32_t* a_absmax, const uint32_t* b_absmax,
-                                float* workspace, void* stream) {
+static int gemm_h_run(int M, int N, int K, const float* A, long lda, int a_kc,
+                      const float* B, long ldb, int b_kc, float* C, long ldc,
+                      const float* bias, const float* residual, long ldr,
+                      const uint32_t* a_absmax, const uint32_t* b_absmax,
+                      float* workspace, void* stream, int act, float act_p, float* act_out,
+                      const float* dact_in) {
   ADELL_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f16x3: bad dims");
   ADELL_REQUIRE(A && B && C, "gemm_f16x3: null pointer");
   ADELL_REQUIRE((a_absmax == nullptr) == (b_absmax == nullptr),
@@ -568,6 +631,8 @@ extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, i
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr;
   a.splits = p.splits;
   a.stages_per_split = p.stages_per_split;
+  a.act = act; a.act_p = act_p; a.act_out = act_out; a.dact_in = dact_in;
+  const bool epi = act_out || dact_in;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(adell_cdiv(M, BM), adell_cdiv(N, BN), p.splits);
   ADELL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "gemm_f16x3: grid too large");
@@ -580,7 +645,20 @@ extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, i
     return ADELL_OK;
   };
   int rc;
-  if (a_kc && b_kc)
+  const bool wide = N % 4 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0) &&
+                    ((((uintptr_t)C) | ((uintptr_t)bias) | ((uintptr_t)residual) |
+                      ((uintptr_t)workspace)) & 15) == 0 && (epi || !g_adell_tune.gemm_nowide);
+  ADELL_REQUIRE(wide || !epi, "gemm_f16x3_act: operands do not qualify for the wide epilogue");
+  if (wide) {
+    if (a_kc && b_kc)
+      rc = launch(adell_gemm_f16x3_kernel<true, true, true>);
+    else if (a_kc && !b_kc)
+      rc = launch(adell_gemm_f16x3_kernel<true, false, true>);
+    else if (!a_kc && !b_kc)
+      rc = launch(adell_gemm_f16x3_kernel<false, false, true>);
+    else
+      rc = launch(adell_gemm_f16x3_kernel<false, true, true>);
+  } else if (a_kc && b_kc)
     rc = launch(adell_gemm_f16x3_kernel<true, true>);
   else if (a_kc && !b_kc)
     rc = launch(adell_gemm_f16x3_kernel<true, false>);
@@ -597,4 +675,37 @@ extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, i
     ADELL_CHECK_HIP(hipGetLastError());
   }
   return ADELL_OK;
+}
+
+extern "C" int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, int a_kc,
+                                const float* B, long ldb, int b_kc, float* C, long ldc,
+                                const float* bias, const float* residual, long ldr,
+                                const uint32_t* a_absmax, const uint32_t* b_absmax,
+                                float* workspace, void* stream) {
+  return gemm_h_run(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, residual, ldr, a_absmax,
+                    b_absmax, workspace, stream, 0, 0.f, nullptr, nullptr);
+}
+
+// The same GEMM with an activation in its epilogue -- Linear -> activation pairs without an
+// element-wise pass (ConvNeXt's pwconv1 -> GELU -> pwconv2, res_blocks.py:559-566):
+//   act_out != NULL: C = A B^T + bias (+ residual) and act_out = act(C), both [M][ldc];
+//   dact_in != NULL: C = (A B^T ...) * act'(dact_in)  (dact_in = the saved pre-activation):
+//                    the gradient of the pair's input side in the GEMM that produces it.
+// A must be K-contiguous (forward and dX of a Linear layer).
+extern "C" int adell_gemm_f16x3_act(int M, int N, int K, const float* A, long lda, int a_kc,
+                                    const float* B, long ldb, int b_kc, float* C, long ldc,
+                                    const float* bias, const float* residual, long ldr,
+                                    const uint32_t* a_absmax, const uint32_t* b_absmax,
+                                    float* workspace, int act, float act_p, float* act_out,
+                                    const float* dact_in, void* stream) {
+  ADELL_REQUIRE(act_out || dact_in, "gemm_f16x3_act: give act_out or dact_in");
+  ADELL_REQUIRE(act >= 0 && act <= ADELL_ACT_ELU, "gemm_f16x3_act: unknown activation %d", act);
+  ADELL_REQUIRE(a_kc, "gemm_f16x3_act: A must be K-contiguous");
+  ADELL_REQUIRE(N % 4 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0),
+                "gemm_f16x3_act: N and the leading dimensions must be multiples of 4");
+  ADELL_REQUIRE(((((uintptr_t)C) | ((uintptr_t)act_out) | ((uintptr_t)dact_in) | ((uintptr_t)bias) |
+                  ((uintptr_t)residual)) & 15) == 0,
+                "gemm_f16x3_act: C, act_out, dact_in, bias and residual must be 16-byte aligned");
+  return gemm_h_run(M, N, K, A, lda, a_kc, B, ldb, b_kc, C, ldc, bias, residual, ldr, a_absmax,
+                    b_absmax, workspace, stream, act, act_p, act_out, dact_in);
 }

@@ -250,49 +250,7 @@ extern "C" int adell_channel_partials(const float* x, int N, long V, int C,
   return ADELL_OK;
 }
 
-// ---------------------------------------------------------------------------
-// Activations
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float adell_act_fwd(int act, float x, float p) {
-  switch (act) {
-    case ADELL_ACT_SILU: return x * adell_sigmoidf(x);
-    case ADELL_ACT_RELU: return x > 0.f ? x : 0.f;
-    case ADELL_ACT_LEAKY_RELU: return x > 0.f ? x : p * x;
-    case ADELL_ACT_PRELU: return x > 0.f ? x : p * x;
-    case ADELL_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    case ADELL_ACT_SIGMOID: return adell_sigmoidf(x);
-    case ADELL_ACT_TANH: return tanhf(x);
-    case ADELL_ACT_ELU: return x > 0.f ? x : p * (expf(x) - 1.0f);
-    default: return x;
-  }
-}
-// d act(x) / dx
-__device__ __forceinline__ float adell_act_grad(int act, float x, float p) {
-  switch (act) {
-    case ADELL_ACT_SILU: {
-      const float s = adell_sigmoidf(x);
-      return s * (1.0f + x * (1.0f - s));
-    }
-    case ADELL_ACT_RELU: return x > 0.f ? 1.f : 0.f;
-    case ADELL_ACT_LEAKY_RELU: return x > 0.f ? 1.f : p;
-    case ADELL_ACT_PRELU: return x > 0.f ? 1.f : p;
-    case ADELL_ACT_GELU: {
-      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-      const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
-      return cdf + x * pdf;
-    }
-    case ADELL_ACT_SIGMOID: {
-      const float s = adell_sigmoidf(x);
-      return s * (1.0f - s);
-    }
-    case ADELL_ACT_TANH: {
-      const float t = tanhf(x);
-      return 1.0f - t * t;
-    }
-    case ADELL_ACT_ELU: return x > 0.f ? 1.f : p * expf(x);
-    default: return 1.f;
-  }
-}
+// (activations: adell_act_fwd / adell_act_grad in common.h)
 
 struct NormActArgs {
   const float* x;

@@ -47,6 +47,8 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_pointwise_gemm": bool(os.environ.get("ADELL_NO_POINTWISE_GEMM")),
          # full-sequence attention by slices + copies around the kernels (the pre-round-4 form)
          "no_seq_attention": bool(os.environ.get("ADELL_NO_SEQ_ATTENTION")),
+         # Linear -> activation -> Linear as separate layers with an element-wise pass between them
+         "no_mlp_fuse": bool(os.environ.get("ADELL_NO_MLP_FUSE")),
          # weight gradient of the narrow-input convs on the exact fp32-MFMA kernel (A/B)
          "no_cinfold_wgrad_f16": bool(os.environ.get("ADELL_NO_CINFOLD_WGRAD_F16"))}
 
@@ -1118,6 +1120,98 @@ class _LinearFn(torch.autograd.Function):
         if res_shape and need[3]:
             dres = dy2.view(res_shape)
         return dx, dw, db, dres
+
+
+class _MlpFn(torch.autograd.Function):
+    """Linear -> activation -> Linear (+ residual) as three + four GEMMs and NO element-wise pass
+    (ConvNeXt's pwconv1 -> GELU -> pwconv2 -> + input, res_blocks.py:559-566): the first GEMM's
+    epilogue stores the pre-activation (for the backward) and the activation (for the second GEMM)
+    in one pass, and the backward's dY W2 GEMM multiplies by act'(pre-activation) in its epilogue,
+    so the gradient of the hidden layer is written once. f16x3 GEMMs only (the caller checks
+    ``mlp_ok``)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, act):
+        H, K = w1.shape
+        N = w2.shape[0]
+        x2 = x.reshape(-1, K).contiguous()
+        rows = x2.shape[0]
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        res2 = None if residual is None else residual.reshape(rows, N).contiguous()
+        h, g = ops.gemm_f16x3_act(rows, H, K, x2, K, True, w1c, K, True, act, bias=b1, want_act=True)
+        y = ops.gemm_f16x3(rows, N, H, g, H, True, w2c, H, True, bias=b2, residual=res2)
+        ctx.save_for_backward(x2, w1c, w2c, h, g)
+        ctx.act = act
+        ctx.refs = (_Ref(w1), _Ref(b1), _Ref(w2), _Ref(b2))
+        ctx.meta = (x.shape, b1 is not None, b2 is not None,
+                    residual is not None and residual.shape)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, h, g = ctx.saved_tensors
+        xshape, has_b1, has_b2, res_shape = ctx.meta
+        H, K = w1.shape
+        N = w2.shape[0]
+        rows = x2.shape[0]
+        need = ctx.needs_input_grad
+        dy2 = dy.reshape(rows, N).contiguous()
+        # dh = (dy W2) * act'(h): the activation's backward rides the GEMM epilogue
+        dh, _ = ops.gemm_f16x3_act(rows, H, N, dy2, N, True, w2, H, False, ctx.act, dact_in=h)
+        dx = None
+        if need[0]:
+            dx = ops.gemm_f16x3(rows, K, H, dh, H, True, w1, K, False).view(xshape)
+
+        def grads2():
+            dw2 = db2 = None
+            if need[3]:
+                dw2 = ops.gemm_f16x3(N, H, rows, dy2, N, False, g, H, False)
+            if has_b2 and need[4]:
+                db2 = ops.bias_grad(_rows_as_volume(dy2))
+            return dw2, db2
+
+        def grads1():
+            dw1 = db1 = None
+            if need[1]:
+                dw1 = ops.gemm_f16x3(H, K, rows, dh, H, False, x2, K, False)
+            if has_b1 and need[2]:
+                db1 = ops.bias_grad(_rows_as_volume(dh))
+            return dw1, db1
+
+        r1, rb1, r2, rb2 = ctx.refs
+        if (need[3] or (has_b2 and need[4])) and _side_ok(r2.obj, rb2.obj):
+            dw2, db2 = side_run(grads2, (dy2, g))
+        else:
+            dw2, db2 = grads2()
+        if (need[1] or (has_b1 and need[2])) and _side_ok(r1.obj, rb1.obj):
+            dw1, db1 = side_run(grads1, (dh, x2))
+        else:
+            dw1, db1 = grads1()
+        dres = dy2.view(res_shape) if (res_shape and need[5]) else None
+        return dx, dw1, db1, dw2, db2, dres, None
+
+
+def mlp_ok(x, w1, w2):
+    """Whether ``mlp`` can take Linear(w1) -> act -> Linear(w2) on rows ``x``: all seven GEMMs on the
+    f16x3 kernels."""
+    if FLAGS["no_mlp_fuse"] or CONV_PRECISION != "f16x3" or not x.is_cuda:
+        return False
+    H, K = w1.shape
+    N = w2.shape[0]
+    rows = x.numel() // K
+    x2 = x.reshape(-1, K)
+    ok = ops.gemm_f16x3_ok
+    return (w2.shape[1] == H and x2.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
+            and ok(rows, H, K, x2, K, True, w1, K, True) and ok(rows, N, H, x2, H, True, w2, H, True)
+            and ok(rows, K, H, x2, H, True, w1, K, False) and ok(rows, H, N, x2, N, True, w2, H, False)
+            and ok(N, H, rows, x2, N, False, x2, H, False) and ok(H, K, rows, x2, H, False, x2, K, False))
+
+
+def mlp(x, w1, b1, w2, b2, act="gelu", residual=None):
+    """act(x W1^T + b1) W2^T + b2 (+ residual) with the activation inside the GEMM epilogues."""
+    _note_use(w1)
+    _note_use(w2)
+    return _MlpFn.apply(x, w1, b1, w2, b2, residual, act)
 
 
 def linear(x, weight, bias=None, residual=None):

@@ -200,7 +200,6 @@ class ConvNeXtBlock3d(torch.nn.Module):
         h = HF.dwconv3d(inp, w if w.dim() == 5 else w.unsqueeze(2), self.dwconv.bias)
         rows = ops.ndhwc(h).permute(0, 2, 3, 4, 1)          # [N, D, H, W, C], contiguous
         rows = self.norm(rows)
-        rows = HF.elementwise(self.pwconv1(rows), act="gelu")
         # pwconv2 -> layer scale -> + input as ONE GEMM: gamma * (h W^T + b) = h (gamma W)^T +
         # gamma b, so the scale is folded into the [C, 4C] weight (parameter algebra on a tiny
         # tensor; autograd carries dgamma / dW back through it) and the residual add rides the
@@ -210,7 +209,14 @@ class ConvNeXtBlock3d(torch.nn.Module):
         else:
             w2 = self.gamma.unsqueeze(1) * self.pwconv2.weight
             b2 = self.gamma * self.pwconv2.bias
-        rows = HF.linear(rows, w2, b2, residual=inp.permute(0, 2, 3, 4, 1))
+        res = inp.permute(0, 2, 3, 4, 1)
+        if HF.mlp_ok(rows, self.pwconv1.weight, w2):
+            # GELU inside the epilogues of pwconv1 (forward) and of the dY W2 GEMM (backward): no
+            # element-wise pass over the 4 C-wide hidden layer
+            rows = HF.mlp(rows, self.pwconv1.weight, self.pwconv1.bias, w2, b2, act="gelu",
+                          residual=res)
+        else:
+            rows = HF.linear(HF.elementwise(self.pwconv1(rows), act="gelu"), w2, b2, residual=res)
         out = rows.permute(0, 4, 1, 2, 3)
         if self.out_layer is not None:
             proj = self.out_layer[0]

@@ -1720,6 +1720,27 @@ def gemm_f16x3(M, N, K, A, lda, a_kc, B, ldb, b_kc, a_amax=None, b_amax=None, ou
     return out
 
 
+def gemm_f16x3_act(M, N, K, A, lda, a_kc, B, ldb, b_kc, act, act_p=0.0, bias=None, residual=None,
+                   want_act=False, dact_in=None):
+    """``gemm_f16x3`` with an activation in the epilogue (csrc/gemm_f16x3.hip,
+    adell_gemm_f16x3_act): ``want_act`` -> returns (C, act(C)); ``dact_in`` [M, N] (a saved
+    pre-activation) -> returns (C * act'(dact_in), None)."""
+    _require_cuda(A, B, bias, residual, dact_in)
+    out = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    act_out = torch.empty_like(out) if want_act else None
+    nws = _lib.lib().adell_gemm_f16x3_workspace_floats(M, N, K)
+    ws = _workspace(nws * 4, A.device) if nws else None
+    ldr = 0 if residual is None else N
+
+    def run():
+        check(_lib.lib().adell_gemm_f16x3_act(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb,
+                                              int(b_kc), _ptr(out), N, _ptr(bias), _ptr(residual),
+                                              ldr, None, None, _ptr(ws), _lib.ACT_IDS[act],
+                                              float(act_p), _ptr(act_out), _ptr(dact_in), _stream()))
+    _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run)
+    return out, act_out
+
+
 def vicreg_fwd(x1, x2, min_var, eps):
     _require_cuda(x1, x2)
     x1, x2 = x1.contiguous(), x2.contiguous()

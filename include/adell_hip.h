@@ -802,6 +802,18 @@ int adell_gemm_f16x3(int M, int N, int K, const float* A, long lda, int a_kc, co
                      long ldb, int b_kc, float* C, long ldc, const float* bias,
                      const float* residual, long ldr, const uint32_t* a_absmax,
                      const uint32_t* b_absmax, float* workspace, void* stream);
+/* The same GEMM with an activation (ADELL_ACT_*) in its epilogue: a Linear -> activation pair
+ * without an element-wise pass over the 4 C-wide intermediate (res_blocks.py:559-566: pwconv1 ->
+ * GELU -> pwconv2; linear_blocks.py MLP). act_out != NULL: C = A B^T + bias (+ residual) and
+ * act_out = act(C), both [M][ldc] (the backward needs the pre-activation, the next layer the
+ * activation: one GEMM writes both). dact_in != NULL: C = (A B^T + ...) * act'(dact_in), with
+ * dact_in [M][ldc] the saved pre-activation -- the gradient through the activation, applied by the
+ * GEMM that produces the gradient of the activation's output. A must be K-contiguous (a_kc = 1). */
+int adell_gemm_f16x3_act(int M, int N, int K, const float* A, long lda, int a_kc, const float* B,
+                         long ldb, int b_kc, float* C, long ldc, const float* bias,
+                         const float* residual, long ldr, const uint32_t* a_absmax,
+                         const uint32_t* b_absmax, float* workspace, int act, float act_p,
+                         float* act_out, const float* dact_in, void* stream);
 
 /* Element-wise segmentation losses beyond the fused binary dice + focal pair, on probabilities
  * p[B][V][C] (NDHWC; C = 1 for the binary family) against targets of the same layout:

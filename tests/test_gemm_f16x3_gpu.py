@@ -132,3 +132,49 @@ def test_linear_takes_the_f16x3_gemm_and_matches_torch(cuda, monkeypatch):
     monkeypatch.setitem(ops.FLAGS, "gemm_f16x3", False)
     HF.linear(xd, wd, bd).sum().backward()
     assert calls == []
+
+
+@pytest.mark.parametrize("rows,k,hid,n,act", [(4096, 96, 384, 96, "gelu"), (300, 192, 768, 192, "gelu"),
+                                               (128, 2048, 128, 64, "swish"),      # split K: the fold applies it
+                                               (1000, 64, 256, 128, "swish")])
+def test_mlp_with_the_activation_in_the_gemm_epilogues(cuda, rows, k, hid, n, act):
+    """functional.mlp (Linear -> act -> Linear + residual, activation and its backward inside GEMM
+    epilogues) against the layer-by-layer form and torch fp64 on the CPU."""
+    import torch.nn.functional as F
+    from adell_mri_amd import functional as HF
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn(rows, k, generator=g).to(cuda).requires_grad_(True)
+    w1 = (torch.randn(hid, k, generator=g) * k ** -0.5).to(cuda).requires_grad_(True)
+    b1 = (torch.randn(hid, generator=g) * 0.3).to(cuda).requires_grad_(True)
+    w2 = (torch.randn(n, hid, generator=g) * hid ** -0.5).to(cuda).requires_grad_(True)
+    b2 = torch.randn(n, generator=g).to(cuda).requires_grad_(True)
+    res = torch.randn(rows, n, generator=g).to(cuda).requires_grad_(True)
+    dy = torch.randn(rows, n, generator=g).to(cuda)
+    leaves = [x, w1, b1, w2, b2, res]
+    assert HF.mlp_ok(x, w1, w2)
+
+    def run(fused):
+        for t in leaves:
+            t.grad = None
+        if fused:
+            y = HF.mlp(x, w1, b1, w2, b2, act=act, residual=res)
+        else:
+            hdn = HF.elementwise(HF.linear(x, w1, b1), act=act)
+            y = HF.linear(hdn, w2, b2, residual=res)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        return [y.detach().clone()] + [t.grad.clone() for t in leaves]
+
+    new, old = run(True), run(False)
+    fn = {"gelu": F.gelu, "swish": F.silu}[act]
+    ld = [t.detach().cpu().double().requires_grad_(True) for t in leaves]
+    yd = fn(ld[0] @ ld[1].T + ld[2]) @ ld[3].T + ld[4] + ld[5]
+    yd.backward(dy.cpu().double())
+    ref = [yd.detach()] + [t.grad for t in ld]
+    for name, u, v, r in zip(["y", "dx", "dw1", "db1", "dw2", "db2", "dres"], new, old, ref):
+        scale = float(r.abs().max())
+        assert float((u.cpu().double() - r).abs().max()) < 2e-5 * scale, name
+        assert float((v.cpu().double() - r).abs().max()) < 2e-5 * scale, name
+    # deterministic
+    again = run(True)
+    assert all(torch.equal(a, b) for a, b in zip(new, again))
