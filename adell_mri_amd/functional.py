@@ -49,6 +49,9 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_seq_attention": bool(os.environ.get("ADELL_NO_SEQ_ATTENTION")),
          # Linear -> activation -> Linear as separate layers with an element-wise pass between them
          "no_mlp_fuse": bool(os.environ.get("ADELL_NO_MLP_FUSE")),
+         # ... from this many hidden elements on (UNETR's 864-token MLPs: 21.6 vs 21.3 ms with it,
+         # nothing to save on a 3.5 MB intermediate; ConvNeXt's 262 144 x 384: -0.33 ms per step)
+         "mlp_min_elems": int(os.environ.get("ADELL_MLP_MIN_ELEMS", str(1 << 20))),
          # weight gradient of the narrow-input convs on the exact fp32-MFMA kernel (A/B)
          "no_cinfold_wgrad_f16": bool(os.environ.get("ADELL_NO_CINFOLD_WGRAD_F16"))}
 
@@ -1131,17 +1134,18 @@ class _MlpFn(torch.autograd.Function):
     ``mlp_ok``)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, act):
+    def forward(ctx, x, w1, b1, w2, b2, residual, act, act_p):
         H, K = w1.shape
         N = w2.shape[0]
         x2 = x.reshape(-1, K).contiguous()
         rows = x2.shape[0]
         w1c, w2c = w1.contiguous(), w2.contiguous()
         res2 = None if residual is None else residual.reshape(rows, N).contiguous()
-        h, g = ops.gemm_f16x3_act(rows, H, K, x2, K, True, w1c, K, True, act, bias=b1, want_act=True)
+        h, g = ops.gemm_f16x3_act(rows, H, K, x2, K, True, w1c, K, True, act, act_p, bias=b1,
+                                  want_act=True)
         y = ops.gemm_f16x3(rows, N, H, g, H, True, w2c, H, True, bias=b2, residual=res2)
         ctx.save_for_backward(x2, w1c, w2c, h, g)
-        ctx.act = act
+        ctx.act = (act, act_p)
         ctx.refs = (_Ref(w1), _Ref(b1), _Ref(w2), _Ref(b2))
         ctx.meta = (x.shape, b1 is not None, b2 is not None,
                     residual is not None and residual.shape)
@@ -1157,7 +1161,7 @@ class _MlpFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dy2 = dy.reshape(rows, N).contiguous()
         # dh = (dy W2) * act'(h): the activation's backward rides the GEMM epilogue
-        dh, _ = ops.gemm_f16x3_act(rows, H, N, dy2, N, True, w2, H, False, ctx.act, dact_in=h)
+        dh, _ = ops.gemm_f16x3_act(rows, H, N, dy2, N, True, w2, H, False, *ctx.act, dact_in=h)
         dx = None
         if need[0]:
             dx = ops.gemm_f16x3(rows, K, H, dh, H, True, w1, K, False).view(xshape)
@@ -1188,7 +1192,7 @@ class _MlpFn(torch.autograd.Function):
         else:
             dw1, db1 = grads1()
         dres = dy2.view(res_shape) if (res_shape and need[5]) else None
-        return dx, dw1, db1, dw2, db2, dres, None
+        return dx, dw1, db1, dw2, db2, dres, None, None
 
 
 def mlp_ok(x, w1, w2):
@@ -1199,6 +1203,8 @@ def mlp_ok(x, w1, w2):
     H, K = w1.shape
     N = w2.shape[0]
     rows = x.numel() // K
+    if rows * H < FLAGS["mlp_min_elems"]:
+        return False
     x2 = x.reshape(-1, K)
     ok = ops.gemm_f16x3_ok
     return (w2.shape[1] == H and x2.is_contiguous() and w1.is_contiguous() and w2.is_contiguous()
@@ -1207,11 +1213,12 @@ def mlp_ok(x, w1, w2):
             and ok(N, H, rows, x2, N, False, x2, H, False) and ok(H, K, rows, x2, H, False, x2, K, False))
 
 
-def mlp(x, w1, b1, w2, b2, act="gelu", residual=None):
-    """act(x W1^T + b1) W2^T + b2 (+ residual) with the activation inside the GEMM epilogues."""
+def mlp(x, w1, b1, w2, b2, act="gelu", act_p=0.0, residual=None):
+    """act(x W1^T + b1) W2^T + b2 (+ residual) with the activation inside the GEMM epilogues
+    (``act_p``: the slope / alpha of leaky_relu / elu)."""
     _note_use(w1)
     _note_use(w2)
-    return _MlpFn.apply(x, w1, b1, w2, b2, residual, act)
+    return _MlpFn.apply(x, w1, b1, w2, b2, residual, act, float(act_p))
 
 
 def linear(x, weight, bias=None, residual=None):

@@ -147,6 +147,24 @@ class ActDropNorm(torch.nn.Module):
             kw["rows_reader"] = reader
         return back(HF.norm_drop_act(X5, **kw))
 
+    def pure_activation(self):
+        """(name, parameter) when this module is nothing but a parameter-free element-wise
+        activation right now (identity norm, dropout absent / zero / in eval mode) -- what
+        ``functional.mlp`` can carry in a GEMM epilogue -- else None."""
+        name = None
+        for k in self.ordering:
+            m = self.op_list[self.name_dict[k]]
+            if k == "N" and not isinstance(m, torch.nn.Identity):
+                return None
+            if k == "D" and not isinstance(m, torch.nn.Identity):
+                if not isinstance(m, torch.nn.Dropout) or (self.training and m.p > 0.0):
+                    return None
+            if k == "A":
+                name, p, w = act_spec(m)
+                if w is not None:
+                    return None
+        return None if name is None else (name, p)
+
     def forward(self, X: torch.Tensor) -> torch.Tensor:
         # the conv that module code announced as the only reader of this output
         # (functional.expect_rows): the last stage may then write split rows instead of fp32

@@ -72,6 +72,13 @@ class MLP(torch.nn.Module):
 
     def forward(self, X: torch.Tensor, residual: torch.Tensor = None) -> torch.Tensor:
         mods = list(self.op)
+        if (len(mods) == 3 and isinstance(mods[0], Linear) and isinstance(mods[2], Linear)
+                and hasattr(mods[1], "pure_activation")):
+            # Linear -> activation -> Linear: the activation and its backward inside GEMM epilogues
+            spec = mods[1].pure_activation()
+            if spec is not None and HF.mlp_ok(X, mods[0].weight, mods[2].weight):
+                return HF.mlp(X, mods[0].weight, mods[0].bias, mods[2].weight, mods[2].bias,
+                              act=spec[0], act_p=spec[1], residual=residual)
         for mod in mods[:-1]:
             X = mod(X)
         return mods[-1](X, residual=residual) if residual is not None else mods[-1](X)

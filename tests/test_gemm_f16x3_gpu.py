@@ -136,8 +136,8 @@ def test_linear_takes_the_f16x3_gemm_and_matches_torch(cuda, monkeypatch):
 
 @pytest.mark.parametrize("rows,k,hid,n,act", [(4096, 96, 384, 96, "gelu"), (300, 192, 768, 192, "gelu"),
                                                (128, 2048, 128, 64, "swish"),      # split K: the fold applies it
-                                               (1000, 64, 256, 128, "swish")])
-def test_mlp_with_the_activation_in_the_gemm_epilogues(cuda, rows, k, hid, n, act):
+                                               (1000, 64, 256, 128, "leaky_relu")])
+def test_mlp_with_the_activation_in_the_gemm_epilogues(cuda, monkeypatch, rows, k, hid, n, act):
     """functional.mlp (Linear -> act -> Linear + residual, activation and its backward inside GEMM
     epilogues) against the layer-by-layer form and torch fp64 on the CPU."""
     import torch.nn.functional as F
@@ -151,22 +151,25 @@ def test_mlp_with_the_activation_in_the_gemm_epilogues(cuda, rows, k, hid, n, ac
     res = torch.randn(rows, n, generator=g).to(cuda).requires_grad_(True)
     dy = torch.randn(rows, n, generator=g).to(cuda)
     leaves = [x, w1, b1, w2, b2, res]
+    slope = 0.02 if act == "leaky_relu" else 0.0
+    assert HF.mlp_ok(x, w1, w2) == (rows * hid >= HF.FLAGS["mlp_min_elems"])   # the dispatch rule
+    monkeypatch.setitem(HF.FLAGS, "mlp_min_elems", 0)
     assert HF.mlp_ok(x, w1, w2)
 
     def run(fused):
         for t in leaves:
             t.grad = None
         if fused:
-            y = HF.mlp(x, w1, b1, w2, b2, act=act, residual=res)
+            y = HF.mlp(x, w1, b1, w2, b2, act=act, act_p=slope, residual=res)
         else:
-            hdn = HF.elementwise(HF.linear(x, w1, b1), act=act)
+            hdn = HF.elementwise(HF.linear(x, w1, b1), act=act, act_p=slope)
             y = HF.linear(hdn, w2, b2, residual=res)
         y.backward(dy)
         torch.cuda.synchronize()
         return [y.detach().clone()] + [t.grad.clone() for t in leaves]
 
     new, old = run(True), run(False)
-    fn = {"gelu": F.gelu, "swish": F.silu}[act]
+    fn = {"gelu": F.gelu, "swish": F.silu, "leaky_relu": lambda t: F.leaky_relu(t, slope)}[act]
     ld = [t.detach().cpu().double().requires_grad_(True) for t in leaves]
     yd = fn(ld[0] @ ld[1].T + ld[2]) @ ld[3].T + ld[4] + ld[5]
     yd.backward(dy.cpu().double())
@@ -178,3 +181,44 @@ def test_mlp_with_the_activation_in_the_gemm_epilogues(cuda, rows, k, hid, n, ac
     # deterministic
     again = run(True)
     assert all(torch.equal(a, b) for a, b in zip(new, again))
+
+
+def test_mlp_module_takes_the_fused_path_only_without_norm_or_dropout(cuda, monkeypatch):
+    """linear_blocks.MLP: Linear -> ADN -> Linear runs on functional.mlp when the ADN is a bare
+    activation; a LayerNorm or an active dropout inside it keeps the layer-by-layer form."""
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
+    from adell_mri_amd.modules.layers.linear_blocks import MLP
+    monkeypatch.setitem(HF.FLAGS, "mlp_min_elems", 0)
+    calls = []
+    orig = HF.mlp
+    monkeypatch.setattr(HF, "mlp", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    torch.manual_seed(3)
+    x = torch.randn(2, 200, 64, device=cuda, requires_grad=True)
+    gy = torch.randn(2, 200, 64, device=cuda)
+    for norm, drop, fused in (("identity", 0.0, True), ("layer", 0.0, False), ("identity", 0.3, False)):
+        m = MLP(64, 64, [256], adn_fn=get_adn_fn(1, norm, "gelu", drop)).to(cuda).train()
+        calls.clear()
+        y = m(x, residual=x)
+        assert bool(calls) == fused, (norm, drop)
+        if not fused or drop:
+            continue
+        y.backward(gy)
+        got = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+        x.grad = None
+        for p in m.parameters():
+            p.grad = None
+        monkeypatch.setitem(HF.FLAGS, "no_mlp_fuse", True)
+        y2 = m(x, residual=x)
+        y2.backward(gy)
+        monkeypatch.setitem(HF.FLAGS, "no_mlp_fuse", False)
+        want = [y2.detach(), x.grad] + [p.grad for p in m.parameters()]
+        for u, v in zip(got, want):
+            assert float((u - v).abs().max()) < 2e-5 * float(v.abs().max())
+        x.grad = None
+    # in eval mode the dropout is inactive: bare activation again
+    m = MLP(64, 64, [256], adn_fn=get_adn_fn(1, "identity", "gelu", 0.3)).to(cuda).eval()
+    calls.clear()
+    with torch.no_grad():
+        m(x)
+    assert calls
