@@ -47,10 +47,13 @@ FLAGS = {"s2class_always": bool(os.environ.get("ADELL_S2CLASS_ALWAYS")),
          "no_pointwise_gemm": bool(os.environ.get("ADELL_NO_POINTWISE_GEMM")),
          # full-sequence attention by slices + copies around the kernels (the pre-round-4 form)
          "no_seq_attention": bool(os.environ.get("ADELL_NO_SEQ_ATTENTION")),
-         # Linear -> activation -> Linear as separate layers with an element-wise pass between them
-         "no_mlp_fuse": bool(os.environ.get("ADELL_NO_MLP_FUSE")),
-         # ... from this many hidden elements on (UNETR's 864-token MLPs: 21.6 vs 21.3 ms with it,
-         # nothing to save on a 3.5 MB intermediate; ConvNeXt's 262 144 x 384: -0.33 ms per step)
+         # Linear -> activation -> Linear as separate layers with an element-wise pass between them.
+         # The DEFAULT: with the wide epilogue on every GEMM the fused form (functional.mlp,
+         # ADELL_MLP_FUSE=1) measured 20.03 against 19.71 ms on the VICReg ConvNeXt step -- the erf of
+         # 100 M hidden elements costs more inside a GEMM epilogue than in two passes that run at the
+         # HBM rate -- and 21.6 against 21.3 ms on UNETR.
+         "no_mlp_fuse": not bool(os.environ.get("ADELL_MLP_FUSE")),
+         # (fused form only from this many hidden elements on)
          "mlp_min_elems": int(os.environ.get("ADELL_MLP_MIN_ELEMS", str(1 << 20))),
          # weight gradient of the narrow-input convs on the exact fp32-MFMA kernel (A/B)
          "no_cinfold_wgrad_f16": bool(os.environ.get("ADELL_NO_CINFOLD_WGRAD_F16"))}

@@ -152,7 +152,9 @@ def test_mlp_with_the_activation_in_the_gemm_epilogues(cuda, monkeypatch, rows, 
     dy = torch.randn(rows, n, generator=g).to(cuda)
     leaves = [x, w1, b1, w2, b2, res]
     slope = 0.02 if act == "leaky_relu" else 0.0
-    assert HF.mlp_ok(x, w1, w2) == (rows * hid >= HF.FLAGS["mlp_min_elems"])   # the dispatch rule
+    assert not HF.mlp_ok(x, w1, w2)                       # opt-in (measured slower per step)
+    monkeypatch.setitem(HF.FLAGS, "no_mlp_fuse", False)
+    assert HF.mlp_ok(x, w1, w2) == (rows * hid >= HF.FLAGS["mlp_min_elems"])   # the size rule
     monkeypatch.setitem(HF.FLAGS, "mlp_min_elems", 0)
     assert HF.mlp_ok(x, w1, w2)
 
@@ -190,6 +192,7 @@ def test_mlp_module_takes_the_fused_path_only_without_norm_or_dropout(cuda, monk
     from adell_mri_amd.modules.layers.adn_fn import get_adn_fn
     from adell_mri_amd.modules.layers.linear_blocks import MLP
     monkeypatch.setitem(HF.FLAGS, "mlp_min_elems", 0)
+    monkeypatch.setitem(HF.FLAGS, "no_mlp_fuse", False)
     calls = []
     orig = HF.mlp
     monkeypatch.setattr(HF, "mlp", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
