@@ -590,7 +590,15 @@ static int adell_dw_tile_launch(const DwTileArgs& a, hipStream_t st) {
     return FN<7, 16>(__VA_ARGS__);                                         \
   } while (0)
 
+extern "C" int adell_dw_mfma_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW,
+                                const float* x, const float* y);
+extern "C" int adell_dw_mfma_launch(const float* x, const float* w, const float* b, float* y, int N,
+                                    int C, int D, int H, int W, int flip, void* stream);
+
 static int adell_dw_launch(DwArgs a, hipStream_t st) {
+  // 7^3 taps on rows of 9 .. 16 voxels: the Toeplitz form on the f16x3 MFMA (csrc/dw_mfma.hip)
+  if (adell_dw_mfma_ok(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, a.x, a.y))
+    return adell_dw_mfma_launch(a.x, a.w, a.b, a.y, a.N, a.C, a.D, a.H, a.W, a.flip, st);
   DwZrArgs zr = {};
   if (adell_dw_zring_plan(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, &zr)) {
     zr.x = a.x; zr.w = a.w; zr.b = a.b; zr.y = a.y; zr.flip = a.flip;

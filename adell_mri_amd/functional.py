@@ -64,6 +64,19 @@ def set_conv_precision(mode):
     if mode not in ("f16x3", "fp32"):
         raise ValueError("conv precision must be 'f16x3' or 'fp32'")
     CONV_PRECISION = mode
+    _sync_dw_precision()
+
+
+def _sync_dw_precision():
+    """The depthwise 7^3 kernels choose their arithmetic inside the library (csrc/dw_mfma.hip: the
+    f16x3 Toeplitz form on the MFMA): "fp32" keeps them on the exact fp32-FMA kernels too."""
+    from . import _lib
+    if os.path.exists(_lib.LIB_PATH) and not os.environ.get("ADELL_DW_NOMFMA"):
+        _lib.lib().adell_set_tuning(b"dw_nomfma", 1 if CONV_PRECISION == "fp32" else 0)
+
+
+if CONV_PRECISION == "fp32":
+    _sync_dw_precision()
 
 
 class _Ref:

@@ -1,0 +1,74 @@
+"""Depthwise 7^3 convolution as Toeplitz products on the f16x3 MFMA (csrc/dw_mfma.hip): forward and
+backward-data against torch fp64 on the CPU and against the vector-ALU kernels it replaces, with
+ragged planes, both column forms (register column for D <= 16, streamed otherwise), badly scaled
+operands (the per-(item, channel) power-of-two scales have to carry them) and the dispatch limits."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from adell_mri_amd import _lib, functional as HF, ops
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # N, C, (D, H, W)
+    (2, 8, (16, 16, 16)),
+    (3, 12, (10, 11, 13)),      # ragged rows and columns, D not a multiple of the group of 4
+    (1, 4, (21, 9, 16)),        # streamed column (D > 16), last group ragged
+    (1, 20, (3, 16, 9)),        # fewer planes than taps
+    (2, 4, (40, 12, 12)),
+]
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("N,C,size", CASES)
+@pytest.mark.parametrize("scale", [1.0, 2e4, 3e-5])
+def test_forward_and_backward_data_against_fp64(cuda, N, C, size, scale):
+    g = torch.Generator().manual_seed(C + size[0])
+    x = torch.randn(N, C, *size, generator=g, dtype=torch.float64) * scale
+    x[:, 1] *= 300.0                       # channels of one block far apart: per-channel scales
+    x[0, :, size[0] // 2] *= 50.0          # one plane far above the others
+    w = torch.randn(C, 1, 7, 7, 7, generator=g, dtype=torch.float64) * 0.05
+    w[2] *= 1e-3
+    b = torch.randn(C, generator=g, dtype=torch.float64) * scale
+    xr = x.clone().requires_grad_(True)
+    y = F.conv3d(xr, w, b, padding=3, groups=C)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xd, wd, bd = ops.ndhwc(x.float().to(cuda)), w.float().to(cuda), b.float().to(cuda)
+    dyd = ops.ndhwc(dy.float().to(cuda))
+    assert _lib.lib().adell_dw_mfma_ok(N, C, *size, 7, 7, 7, xd.data_ptr(), xd.data_ptr())
+    got_y = ops.dwconv3d_fwd(xd, wd, bd)
+    got_dx = ops.dwconv3d_bwd_data(dyd, wd)
+    # per channel: the split carries 22 bits relative to the channel's own largest value
+    for c in range(C):
+        assert _rel(got_y[:, c].cpu().double(), y[:, c].detach()) < 2e-6, c
+        assert _rel(got_dx[:, c].cpu().double(), xr.grad[:, c]) < 2e-6, c
+    with _lib.tuning(dw_nomfma=1):
+        old_y = ops.dwconv3d_fwd(xd, wd, bd)
+        old_dx = ops.dwconv3d_bwd_data(dyd, wd)
+    assert _rel(got_y, old_y) < 2e-6 and _rel(got_dx, old_dx) < 2e-6
+    # deterministic
+    assert torch.equal(got_y, ops.dwconv3d_fwd(xd, wd, bd))
+
+
+def test_dispatch_limits_and_the_fp32_mode(cuda):
+    ok = _lib.lib().adell_dw_mfma_ok
+    p = torch.zeros(64, device=cuda).data_ptr()
+    assert ok(2, 96, 16, 16, 16, 7, 7, 7, p, p)
+    assert not ok(2, 96, 16, 16, 16, 5, 5, 5, p, p)       # other stencils: vector-ALU kernels
+    assert not ok(2, 96, 16, 8, 8, 7, 7, 7, p, p)         # rows of <= 8 voxels: a quarter of the tile
+    assert not ok(2, 96, 16, 16, 17, 7, 7, 7, p, p)       # a row must fit the 16 columns
+    assert not ok(2, 98, 16, 16, 16, 7, 7, 7, p, p)       # channels in fours
+    assert not ok(2, 96, 16, 16, 16, 7, 7, 7, p + 4, p)   # 16-byte aligned tensors
+    # "fp32" precision keeps the depthwise convs on exact fp32 FMAs too
+    old = HF.CONV_PRECISION
+    try:
+        HF.set_conv_precision("fp32")
+        assert not ok(2, 96, 16, 16, 16, 7, 7, 7, p, p)
+        HF.set_conv_precision("f16x3")
+        assert ok(2, 96, 16, 16, 16, 7, 7, 7, p, p)
+    finally:
+        HF.set_conv_precision(old)
