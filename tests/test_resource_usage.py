@@ -70,8 +70,8 @@ def test_no_scratch_outside_the_allow_list():
 
 
 def test_step_kernels_are_spill_free():
-    """The kernels of the benchmark step by name (profiles/r04e_bench_kernel_stats.txt)."""
-    path = os.path.join(ROOT, "profiles", "r04e_bench_kernel_stats.txt")
+    """The kernels of the benchmark step by name (profiles/r04f_bench_kernel_stats.txt)."""
+    path = os.path.join(ROOT, "profiles", "r04f_bench_kernel_stats.txt")
     names = set()
     with open(path) as fh:
         for line in fh:
