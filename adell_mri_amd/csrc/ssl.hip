@@ -713,16 +713,26 @@ static int adell_dw_wgrad_dispatch(int K, int WT, const DwWgradArgs& a, int spli
   ADELL_DW_DISPATCH(adell_dw_wgrad_tile_launch, K, WT, a, splits, st);
 }
 
+extern "C" int adell_dw_wgrad_mfma_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW,
+                                      const float* x, const float* dy);
+extern "C" long adell_dw_wgrad_mfma_workspace_floats(int N, int C);
+extern "C" int adell_dw_wgrad_mfma_launch(const float* x, const float* dy, float* workspace, int N,
+                                          int C, int D, int H, int W, int* chunks_out, void* stream);
+
 // floats of workspace adell_dwconv3d_bwd_weight needs (0: none)
 extern "C" long adell_dwconv3d_bwd_weight_workspace_floats(int N, int C, int D, int H, int W,
                                                            int KD, int KH, int KW) {
   DwTile t;
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-  if (!adell_dw_plan(N, C, D, H, W, KD, KH, KW, &t)) return 0;
+  long need = 0;
+  // (the MFMA form is chosen per call from the operands' alignment: size for either)
+  if (KD == 7 && KH == 7 && KW == 7 && C % 4 == 0) need = adell_dw_wgrad_mfma_workspace_floats(N, C);
+  if (!adell_dw_plan(N, C, D, H, W, KD, KH, KW, &t)) return need;
   long items;
   int ips;
   const int splits = adell_dw_wgrad_splits(t, &items, &ips);
-  return (long)splits * t.chanBlocks * 16 * ((long)KD * KH * KW + 1);
+  const long tile = (long)splits * t.chanBlocks * 16 * ((long)KD * KH * KW + 1);
+  return tile > need ? tile : need;
 }
 
 extern "C" int adell_dwconv3d_bwd_weight(int N, int C, int D, int H, int W, int KD, int KH,
@@ -732,6 +742,21 @@ extern "C" int adell_dwconv3d_bwd_weight(int N, int C, int D, int H, int W, int 
   if (rc != ADELL_OK) return rc;
   ADELL_REQUIRE(x && dy && dw, "dwconv_bwd_weight: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  // 7^3 taps on rows of 9 .. 16 voxels: rows as the reduction dimension of f16x3 MFMA products
+  // (csrc/dw_wgrad_mfma.hip), per-chunk partial sums folded by the reduce kernel below
+  if (adell_dw_wgrad_mfma_ok(N, C, D, H, W, KD, KH, KW, x, dy)) {
+    ADELL_REQUIRE(workspace, "dwconv_bwd_weight: workspace of "
+                             "adell_dwconv3d_bwd_weight_workspace_floats() floats required");
+    int chunks = 0;
+    rc = adell_dw_wgrad_mfma_launch(x, dy, workspace, N, C, D, H, W, &chunks, stream);
+    if (rc != ADELL_OK) return rc;
+    long blocks = ((long)C * 344 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adell_dw_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st,
+                       workspace, chunks, C, C, 343, dw, db);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   DwWgradArgs a;
   const int WT = adell_dw_plan(N, C, D, H, W, KD, KH, KW, &a.t);
   if (WT) {

@@ -72,3 +72,30 @@ def test_dispatch_limits_and_the_fp32_mode(cuda):
         assert ok(2, 96, 16, 16, 16, 7, 7, 7, p, p)
     finally:
         HF.set_conv_precision(old)
+
+
+@pytest.mark.parametrize("N,C,size", CASES + [(9, 8, (6, 16, 16))])   # several items per chunk, D < 7
+@pytest.mark.parametrize("scale", [1.0, 2e4, 3e-5])
+def test_weight_and_bias_gradient_against_fp64(cuda, N, C, size, scale):
+    """csrc/dw_wgrad_mfma.hip: rows as the reduction dimension of f16x3 MFMA products, one power-of-two
+    scale per tensor -- against torch fp64 and the vector-ALU tile kernel."""
+    g = torch.Generator().manual_seed(C + size[1])
+    x = torch.randn(N, C, *size, generator=g, dtype=torch.float64) * scale
+    x[0, :, size[0] // 2] *= 30.0
+    dy = torch.randn(N, C, *size, generator=g, dtype=torch.float64) / scale
+    dy[:, 1] *= 20.0
+    w = torch.zeros(C, 1, 7, 7, 7, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(C, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, w, b, padding=3, groups=C).backward(dy)
+    xd, dyd = ops.ndhwc(x.float().to(cuda)), ops.ndhwc(dy.float().to(cuda))
+    assert _lib.lib().adell_dw_wgrad_mfma_ok(N, C, *size, 7, 7, 7, xd.data_ptr(), dyd.data_ptr())
+    dw, db = ops.dwconv3d_bwd_weight(xd, dyd, (7, 7, 7), True)
+    assert _rel(dw.cpu().double(), w.grad) < 3e-6
+    assert _rel(db.cpu().double(), b.grad) < 3e-6
+    with _lib.tuning(dw_wgrad_nomfma=1):
+        dw_old, db_old = ops.dwconv3d_bwd_weight(xd, dyd, (7, 7, 7), True)
+    assert _rel(dw, dw_old) < 3e-6 and _rel(db, db_old) < 3e-6
+    dw2, db2 = ops.dwconv3d_bwd_weight(xd, dyd, (7, 7, 7), True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)      # deterministic: chunk order fold
+    dw3, _ = ops.dwconv3d_bwd_weight(xd, dyd, (7, 7, 7), False)
+    assert torch.equal(dw, dw3)

@@ -24,5 +24,20 @@ for N, C, D, H, W in shapes:
             e1.record()
             torch.cuda.synchronize()
             res[nomfma] = e0.elapsed_time(e1) / 20 * 1e3
+    dy = ops.ndhwc(torch.randn(N, C, D, H, W, device=dev))
+    wres = {}
+    for nomfma in (0, 1):
+        with _lib.tuning(dw_wgrad_nomfma=nomfma):
+            for _ in range(3):
+                ops.dwconv3d_bwd_weight(x, dy, (7, 7, 7), True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.dwconv3d_bwd_weight(x, dy, (7, 7, 7), True)
+            e1.record()
+            torch.cuda.synchronize()
+            wres[nomfma] = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"{(N, C, D, H, W)}: weight gradient MFMA {wres[0]:7.1f} us   vector ALU {wres[1]:7.1f} us")
     gf = 2.0 * N * C * D * H * W * 343 / 1e9
     print(f"{(N, C, D, H, W)}: MFMA {res[0]:7.1f} us ({gf / res[0] * 1e-3:5.1f} TF)   vector ALU {res[1]:7.1f} us ({gf / res[1] * 1e-3:5.1f} TF)")
