@@ -595,7 +595,15 @@ extern "C" int adell_dw_mfma_ok(int N, int C, int D, int H, int W, int KD, int K
 extern "C" int adell_dw_mfma_launch(const float* x, const float* w, const float* b, float* y, int N,
                                     int C, int D, int H, int W, int flip, void* stream);
 
+extern "C" int adell_dw_dense_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW,
+                                 const float* x, const float* y);
+extern "C" int adell_dw_dense_launch(const float* x, const float* w, const float* b, float* y, int N,
+                                     int C, int D, int H, int W, int flip, void* stream);
+
 static int adell_dw_launch(DwArgs a, hipStream_t st) {
+  // 7^3 taps on volumes of at most 4^3 voxels: a dense per-channel matrix (csrc/dw_dense.hip)
+  if (adell_dw_dense_ok(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, a.x, a.y))
+    return adell_dw_dense_launch(a.x, a.w, a.b, a.y, a.N, a.C, a.D, a.H, a.W, a.flip, st);
   // 7^3 taps on rows of 9 .. 16 voxels: the Toeplitz form on the f16x3 MFMA (csrc/dw_mfma.hip)
   if (adell_dw_mfma_ok(a.N, a.C, a.D, a.H, a.W, a.KD, a.KH, a.KW, a.x, a.y))
     return adell_dw_mfma_launch(a.x, a.w, a.b, a.y, a.N, a.C, a.D, a.H, a.W, a.flip, st);

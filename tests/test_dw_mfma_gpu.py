@@ -99,3 +99,35 @@ def test_weight_and_bias_gradient_against_fp64(cuda, N, C, size, scale):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)      # deterministic: chunk order fold
     dw3, _ = ops.dwconv3d_bwd_weight(xd, dyd, (7, 7, 7), False)
     assert torch.equal(dw, dw3)
+
+
+@pytest.mark.parametrize("N,C,size", [(64, 8, (4, 4, 4)), (5, 12, (4, 4, 4)), (17, 4, (3, 4, 2)), (33, 8, (4, 2, 4))])
+@pytest.mark.parametrize("scale", [1.0, 2e4, 3e-5])
+def test_small_volumes_as_a_dense_matrix(cuda, N, C, size, scale):
+    """csrc/dw_dense.hip: volumes of at most 4^3 voxels -- every output sees every input -- as a
+    [items] x [64] x [64] product per channel; forward and backward-data against fp64 and the
+    vector-ALU kernels, ragged item tiles and ragged volumes."""
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn(N, C, *size, generator=g, dtype=torch.float64) * scale
+    x[:, 1] *= 300.0
+    w = torch.randn(C, 1, 7, 7, 7, generator=g, dtype=torch.float64) * 0.05
+    b = torch.randn(C, generator=g, dtype=torch.float64) * scale
+    xr = x.clone().requires_grad_(True)
+    y = F.conv3d(xr, w, b, padding=3, groups=C)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    xd, wd, bd = ops.ndhwc(x.float().to(cuda)), w.float().to(cuda), b.float().to(cuda)
+    dyd = ops.ndhwc(dy.float().to(cuda))
+    assert _lib.lib().adell_dw_dense_ok(N, C, *size, 7, 7, 7, xd.data_ptr(), xd.data_ptr())
+    got_y, got_dx = ops.dwconv3d_fwd(xd, wd, bd), ops.dwconv3d_bwd_data(dyd, wd)
+    for c in range(C):
+        assert _rel(got_y[:, c].cpu().double(), y[:, c].detach()) < 2e-6, c
+        assert _rel(got_dx[:, c].cpu().double(), xr.grad[:, c]) < 2e-6, c
+    with _lib.tuning(dw_nomfma=1):
+        old_y, old_dx = ops.dwconv3d_fwd(xd, wd, bd), ops.dwconv3d_bwd_data(dyd, wd)
+    assert _rel(got_y, old_y) < 2e-6 and _rel(got_dx, old_dx) < 2e-6
+    assert torch.equal(got_y, ops.dwconv3d_fwd(xd, wd, bd))
+    # 2^3 and 5 x 4 x 4 volumes are not this kernel's
+    p = xd.data_ptr()
+    assert not _lib.lib().adell_dw_dense_ok(N, C, 2, 2, 2, 7, 7, 7, p, p)
+    assert not _lib.lib().adell_dw_dense_ok(N, C, 5, 4, 4, 7, 7, 7, p, p)

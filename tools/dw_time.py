@@ -6,7 +6,7 @@ import torch
 from adell_mri_amd import _lib, ops
 
 dev = torch.device("cuda:0")
-shapes = [(64, 96, 16, 16, 16), (64, 96, 16, 12, 12), (16, 96, 32, 16, 16)]
+shapes = [(64, 96, 16, 16, 16), (64, 384, 4, 4, 4), (16, 96, 32, 16, 16)]
 for N, C, D, H, W in shapes:
     x = ops.ndhwc(torch.randn(N, C, D, H, W, device=dev))
     w = torch.randn(C, 1, 7, 7, 7, device=dev) * 0.05
