@@ -7,7 +7,7 @@
 // form walks 343 taps per output (21 952, five sixths of them on the zero padding). Forward, and
 // backward-data as the same kernel on the flipped taps.
 //
-// Block = (16 items, 4 channels), wave = channel. The wave builds its 8 B fragment pairs (2 k-steps x
+// Block = (16 items, 16 or 4 channels), wave = channel. The wave builds its 8 B fragment pairs (2 k-steps x
 // 4 output tiles, hi and lo) once from the channel's 343 taps and keeps them in registers; the 16 x 64
 // inputs of its channel are staged split in LDS (a thread's float4 is the four channels of one
 // voxel, all of a block's loads in flight together); 24 MFMAs per wave; the four channels of an
@@ -20,12 +20,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int DD_CG = 4, DD_IT = 16;           // channels (waves) and items per block
+constexpr int DD_IT = 16;                      // items per block (one M tile)
 constexpr int DD_AROW = 272;                   // bytes per (channel, item): 64 halfs hi | 64 halfs lo | 16 pad
 constexpr int DD_AB = DD_IT * DD_AROW;         // per channel
 constexpr int DD_TAPW = 344;                   // packed (hi | lo << 16) tap words per channel (+ 1 zero)
-constexpr int DD_OUTROW = 64 * 4 + 4;          // floats per item of the output staging: [o][channel] + pad
-constexpr int DD_LDS = DD_CG * DD_AB + DD_CG * DD_TAPW * 4 + DD_IT * DD_OUTROW * 4 + 128;   // + 32 floats of reduction scratch
+// CG channels (= waves) per block: 4, or 16 (a voxel's 16 channels are a 64-byte run shared by four
+// lanes of a load, where four channels are 16 bytes of a line per lane -- measured slower at the
+// shapes in hand, see the launch)
+template <int CG> constexpr int dd_outrow() { return 64 * CG + 4; }   // floats per item of the output staging
+template <int CG> constexpr int dd_lds() {
+  // the output staging [item][o][channel] reuses the input region (16 x dd_outrow floats <= CG x DD_AB for CG = 16)
+  return (CG * DD_AB > DD_IT * dd_outrow<CG>() * 4 ? CG * DD_AB : DD_IT * dd_outrow<CG>() * 4) +
+         CG * DD_TAPW * 4 + (CG * (CG / 4) * 4 + CG) * 4 + 64;
+}
 
 struct DwDenseArgs {
   const float* x;
@@ -45,23 +52,27 @@ __device__ __forceinline__ int dd_scale_exp(float amax) {
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void adell_dw_dense_kernel(DwDenseArgs a) {
+template <int CG>
+__global__ __launch_bounds__(64 * CG) void adell_dw_dense_kernel(DwDenseArgs a) {
+  constexpr int Q = CG / 4, NT = 64 * CG;
+  constexpr int AREG = CG * DD_AB > DD_IT * dd_outrow<CG>() * 4 ? CG * DD_AB : DD_IT * dd_outrow<CG>() * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* sTap = reinterpret_cast<uint32_t*>(smem + DD_CG * DD_AB);
-  float* sOut = reinterpret_cast<float*>(smem + DD_CG * DD_AB + DD_CG * DD_TAPW * 4);
-  float* sRed = sOut + DD_IT * DD_OUTROW;
+  uint32_t* sTap = reinterpret_cast<uint32_t*>(smem + AREG);
+  float* sRed = reinterpret_cast<float*>(smem + AREG + CG * DD_TAPW * 4);   // [wave][quad][4], then [wave] exponents
+  float* sOut = reinterpret_cast<float*>(smem);                            // after the MFMAs: over the inputs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = blockIdx.x * DD_CG, n0 = blockIdx.y * DD_IT;
+  const int c0 = blockIdx.x * CG, n0 = blockIdx.y * DD_IT;
   const int V = a.D * a.H * a.W;                 // <= 64
 
-  // ---- loads: thread t owns (item t >> 6 ... in four passes, voxel t & 63) -----------------------
+  // ---- loads: four float4 per thread over [item][voxel][channel quad], quads fastest ------------
   float4 f[4];
+  const int quad = tid % Q;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int it = (tid >> 6) + 4 * u, v = tid & 63;
+    const int idx = tid + u * NT, v = (idx / Q) & 63, it = idx / (64 * Q);
     const bool ok = v < V && n0 + it < a.N;
     const float4 g = *reinterpret_cast<const float4*>(
-        ok ? a.x + ((size_t)(n0 + it) * V + v) * a.C + c0 : a.x);
+        ok ? a.x + ((size_t)(n0 + it) * V + v) * a.C + c0 + 4 * quad : a.x);
     f[u] = make_float4(ok ? g.x : 0.f, ok ? g.y : 0.f, ok ? g.z : 0.f, ok ? g.w : 0.f);
   }
   // ---- this wave's channel: taps split, scaled, packed (flipped for backward-data) --------------
@@ -90,9 +101,9 @@ __global__ __launch_bounds__(256) void adell_dw_dense_kernel(DwDenseArgs a) {
                                    ((uint32_t)__builtin_bit_cast(unsigned short, l) << 16);
       }
     }
-    if (lane == 0) sRed[16 + wave] = __int_as_float(kw);   // (bit pattern of the exponent)
+    if (lane == 0) sRed[CG * Q * 4 + wave] = __int_as_float(kw);   // (bit pattern of the exponent)
   }
-  // ---- operand scale per channel: absmax of the block's inputs ----------------------------------
+  // ---- operand scale per channel: absmax of the block's inputs (lanes of one quad together) -----
   float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -100,31 +111,36 @@ __global__ __launch_bounds__(256) void adell_dw_dense_kernel(DwDenseArgs a) {
     mx.z = fmaxf(mx.z, fabsf(f[u].z)); mx.w = fmaxf(mx.w, fabsf(f[u].w));
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = 32; o >= Q; o >>= 1) {
     mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
     mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
   }
-  if (lane == 0) {
-    sRed[wave * 4 + 0] = mx.x; sRed[wave * 4 + 1] = mx.y;
-    sRed[wave * 4 + 2] = mx.z; sRed[wave * 4 + 3] = mx.w;
+  if (lane < Q) {
+    float* r = sRed + (wave * Q + lane) * 4;
+    r[0] = mx.x; r[1] = mx.y; r[2] = mx.z; r[3] = mx.w;
   }
   __syncthreads();
+  auto chan_exp = [&](int ch) {     // channel ch = 4 quad + j of the block
+    float m = 0.f;
+    for (int w = 0; w < CG; ++w) m = fmaxf(m, sRed[(w * Q + (ch >> 2)) * 4 + (ch & 3)]);
+    return dd_scale_exp(m);
+  };
   int kx4[4];
 #pragma unroll
-  for (int ch = 0; ch < 4; ++ch)
-    kx4[ch] = dd_scale_exp(fmaxf(fmaxf(sRed[ch], sRed[4 + ch]), fmaxf(sRed[8 + ch], sRed[12 + ch])));
+  for (int j = 0; j < 4; ++j) kx4[j] = chan_exp(4 * quad + j);
+  const int kx_w = chan_exp(wave);
   // ---- stage the inputs: [channel][item][hi 64 | lo 64] ------------------------------------------
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int it = (tid >> 6) + 4 * u, v = tid & 63;
+    const int idx = tid + u * NT, v = (idx / Q) & 63, it = idx / (64 * Q);
     const float vals[4] = {f[u].x, f[u].y, f[u].z, f[u].w};
-    char* p = smem + it * DD_AROW + v * 2;
+    char* p = smem + (4 * quad) * DD_AB + it * DD_AROW + v * 2;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      const float s = vals[ch] * __int_as_float((kx4[ch] + 127) << 23);
+    for (int j = 0; j < 4; ++j) {
+      const float s = vals[j] * __int_as_float((kx4[j] + 127) << 23);
       const _Float16 h = (_Float16)s;
-      *reinterpret_cast<_Float16*>(p + ch * DD_AB) = h;
-      *reinterpret_cast<_Float16*>(p + ch * DD_AB + 128) = (_Float16)(s - (float)h);
+      *reinterpret_cast<_Float16*>(p + j * DD_AB) = h;
+      *reinterpret_cast<_Float16*>(p + j * DD_AB + 128) = (_Float16)(s - (float)h);
     }
   }
   __syncthreads();
@@ -176,21 +192,23 @@ __global__ __launch_bounds__(256) void adell_dw_dense_kernel(DwDenseArgs a) {
     for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks][nt], acc[nt], 0, 0, 0);
   }
   // ---- outputs: D[item = 4 kq + r][o = 16 nt + col] -> [item][o][channel] in LDS -> 16-byte stores --
-  const int kw = __float_as_int(sRed[16 + wave]);
-  const float oscale = __int_as_float((127 - (kx4[wave] + kw)) << 23);
+  const int kw = __float_as_int(sRed[CG * Q * 4 + wave]);
+  const float oscale = __int_as_float((127 - (kx_w + kw)) << 23);
   const float bias = a.b ? a.b[ch_w] : 0.f;
+  __syncthreads();     // every wave has read its A fragments: the staging may overwrite the inputs
+  constexpr int OUTROW = dd_outrow<CG>();
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      sOut[(4 * kq + r) * DD_OUTROW + (nt * 16 + col) * 4 + wave] = acc[nt][r] * oscale + bias;
+      sOut[(4 * kq + r) * OUTROW + (nt * 16 + col) * CG + wave] = acc[nt][r] * oscale + bias;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int it = (tid >> 6) + 4 * u, v = tid & 63;
+    const int idx = tid + u * NT, v = (idx / Q) & 63, it = idx / (64 * Q);
     if (v < V && n0 + it < a.N)
-      *reinterpret_cast<float4*>(a.y + ((size_t)(n0 + it) * V + v) * a.C + c0) =
-          *reinterpret_cast<const float4*>(sOut + it * DD_OUTROW + v * 4);
+      *reinterpret_cast<float4*>(a.y + ((size_t)(n0 + it) * V + v) * a.C + c0 + 4 * quad) =
+          *reinterpret_cast<const float4*>(sOut + it * OUTROW + v * CG + 4 * quad);
   }
 }
 
@@ -198,22 +216,30 @@ __global__ __launch_bounds__(256) void adell_dw_dense_kernel(DwDenseArgs a) {
 extern "C" int adell_dw_dense_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW,
                                  const float* x, const float* y) {
   return KD == 7 && KH == 7 && KW == 7 && D <= 4 && H <= 4 && W <= 4 && D * H * W > 16 &&
-         C % DD_CG == 0 && (N + DD_IT - 1) / DD_IT <= 65535 &&
+         C % 4 == 0 && (N + DD_IT - 1) / DD_IT <= 65535 &&
          ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && !g_adell_tune.dw_nomfma;
+}
+
+template <int CG>
+static int adell_dw_dense_go(const DwDenseArgs& a, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_dw_dense_kernel<CG>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(adell_dw_dense_kernel<CG>, dim3(a.C / CG, (a.N + DD_IT - 1) / DD_IT), dim3(64 * CG),
+                     dd_lds<CG>(), st, a);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
 }
 
 extern "C" int adell_dw_dense_launch(const float* x, const float* w, const float* b, float* y, int N,
                                      int C, int D, int H, int W, int flip, void* stream) {
   ADELL_REQUIRE(adell_dw_dense_ok(N, C, D, H, W, 7, 7, 7, x, y), "dw_dense: shape not covered");
-  static bool attr_done = false;
-  if (!attr_done) {
-    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(adell_dw_dense_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
   DwDenseArgs a = {x, w, b, y, N, C, D, H, W, flip};
-  hipLaunchKernelGGL(adell_dw_dense_kernel, dim3(C / DD_CG, (N + DD_IT - 1) / DD_IT), dim3(256), DD_LDS,
-                     (hipStream_t)stream, a);
-  ADELL_CHECK_HIP(hipGetLastError());
-  return ADELL_OK;
+  // (16 channels per block quarter the line requests but leave 96 blocks of 1 024 threads for 256 CUs at
+  // ConvNeXt's 64 crops x 384 channels: 30.4 us against 24.4 -- A/B switch only)
+  if (C % 16 == 0 && g_adell_tune.dw_dense16) return adell_dw_dense_go<16>(a, (hipStream_t)stream);
+  return adell_dw_dense_go<4>(a, (hipStream_t)stream);
 }
