@@ -46,6 +46,7 @@ static AdellTuning adell_tuning_from_env() {
   t.gemm_nosmall = adell_env_int("ADELL_GEMM_NOSMALL", 0);
   t.dw_nomfma = adell_env_int("ADELL_DW_NOMFMA", 0);
   t.dw_wgrad_nomfma = adell_env_int("ADELL_DW_WGRAD_NOMFMA", 0);
+  t.dw_nopersist = adell_env_int("ADELL_DW_NOPERSIST", 0);
   t.dw_dense16 = adell_env_int("ADELL_DW_DENSE16", 0);
   t.gemm_nowide = adell_env_int("ADELL_GEMM_NOWIDE", 0);
   t.dw_nozring = adell_env_int("ADELL_DW_NOZRING", 0);
@@ -86,6 +87,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "gemm_nosmall")) return &g_adell_tune.gemm_nosmall;
   if (!strcmp(name, "dw_nomfma")) return &g_adell_tune.dw_nomfma;
   if (!strcmp(name, "dw_wgrad_nomfma")) return &g_adell_tune.dw_wgrad_nomfma;
+  if (!strcmp(name, "dw_nopersist")) return &g_adell_tune.dw_nopersist;
   if (!strcmp(name, "dw_dense16")) return &g_adell_tune.dw_dense16;
   if (!strcmp(name, "gemm_nowide")) return &g_adell_tune.gemm_nowide;
   if (!strcmp(name, "dw_nozring")) return &g_adell_tune.dw_nozring;

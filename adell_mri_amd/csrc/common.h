@@ -34,6 +34,7 @@ struct AdellTuning {
   int gemm_nosmall;               // fp32 GEMM: no streaming kernels for Linear layers with <= 32 features
   int dw_nomfma;                  // depthwise 7^3: vector-ALU kernels only (exact fp32 FMAs) instead of the f16x3 Toeplitz MFMA form
   int dw_wgrad_nomfma;            // depthwise 7^3 weight gradient: vector-ALU tile kernel instead of the MFMA form
+  int dw_nopersist;               // depthwise MFMA forward: one block per work item instead of persistent blocks (A/B)
   int dw_dense16;                 // dense small-volume depthwise kernel: 16 channels per block when 16 divide C (A/B: slower)
   int gemm_nowide;                // f16x3 GEMM: scalar epilogue stores from the MFMA layout (no LDS pass)
   int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)

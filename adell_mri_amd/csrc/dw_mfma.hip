@@ -51,6 +51,7 @@ struct DwMfmaArgs {
   const float* b;   // [C] or null
   float* y;
   int N, C, D, H, W, flip;
+  int total;        // work items = N * (C / 4): item n = work / (C / 4), channels 4 (work % (C / 4)) ..
 };
 
 __device__ __forceinline__ int dm_scale_exp(float amax) {
@@ -75,16 +76,17 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
   float* sOut = reinterpret_cast<float*>(smem + DM_CG * DM_CHB);   // [plane][y][x][channel], rows padded
   float* sRed = reinterpret_cast<float*>(smem + DM_CG * DM_CHB + DM_OUTB);   // [4 waves][4 channels]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = blockIdx.y, c0 = blockIdx.x * DM_CG;
   const int vy = tid >> 4, vx = tid & 15;            // the voxel of a plane this thread stages
   const bool vok = vy < a.H && vx < a.W;
-  const size_t item = (size_t)n * a.D * a.H * a.W;
-  const float* xin = a.x + (item + (size_t)vy * a.W + vx) * a.C + c0;
+  const int groups = a.C / DM_CG;
   const size_t zstride = (size_t)a.H * a.W * a.C;
-  auto load_plane = [&](int z) -> float4 {
+  // this thread's voxel of plane z of work item `work` (zeros outside the volume / past the last item)
+  auto load_plane = [&](int work, int z) -> float4 {
     // (a select on the loaded value, not a branch around the load: the loads of a group stay in flight together)
-    const bool ok = vok && z >= 0 && z < a.D;
-    const float4 f = *reinterpret_cast<const float4*>(ok ? xin + (size_t)z * zstride : a.x);
+    const bool ok = vok && z >= 0 && z < a.D && work < a.total;
+    const int wn = work / groups, wc0 = (work - wn * groups) * DM_CG;
+    const float4 f = *reinterpret_cast<const float4*>(
+        ok ? a.x + ((size_t)wn * a.D * a.H * a.W + (size_t)vy * a.W + vx) * a.C + wc0 + (size_t)z * zstride : a.x);
     return make_float4(ok ? f.x : 0.f, ok ? f.y : 0.f, ok ? f.z : 0.f, ok ? f.w : 0.f);
   };
 
@@ -92,12 +94,26 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
   for (int i = tid; i < DM_CG * DM_CHB / 16; i += 256)
     reinterpret_cast<float4*>(smem)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // REGCOL: persistent blocks -- the column of the NEXT work item is loaded into a second register
+  // set under this item's MFMAs (a column's 16 loads per thread are 4 096 line requests per block:
+  // ~17 us that nothing overlapped when every block loaded its own column first)
+  float4 colnext[REGCOL ? 16 : 1];
+  if constexpr (REGCOL) {
+#pragma unroll
+    for (int z = 0; z < 16; ++z) colnext[z] = load_plane((int)blockIdx.x, z);
+  }
+  for (int work = blockIdx.x; work < a.total; work += gridDim.x) {
+  const int n = work / groups, c0 = (work - n * groups) * DM_CG;
+  const size_t item = (size_t)n * a.D * a.H * a.W;
+
   // ---- operand scale per channel: absmax of this block's 4-channel column of the item ----------
   float4 mx = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 col[REGCOL ? 16 : 1];
   if constexpr (REGCOL) {
 #pragma unroll
-    for (int z = 0; z < 16; ++z) col[z] = load_plane(z);
+    for (int z = 0; z < 16; ++z) col[z] = colnext[z];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) colnext[z] = load_plane(work + (int)gridDim.x, z);
 #pragma unroll
     for (int z = 0; z < 16; ++z) {
       mx.x = fmaxf(mx.x, fabsf(col[z].x)); mx.y = fmaxf(mx.y, fabsf(col[z].y));
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
     for (int z0 = 0; z0 < a.D; z0 += 8) {
       float4 f[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) f[u] = load_plane(z0 + u);
+      for (int u = 0; u < 8; ++u) f[u] = load_plane(work, z0 + u);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         mx.x = fmaxf(mx.x, fabsf(f[u].x)); mx.y = fmaxf(mx.y, fabsf(f[u].y));
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
     mx.x = fmaxf(mx.x, __shfl_xor(mx.x, o, 64)); mx.y = fmaxf(mx.y, __shfl_xor(mx.y, o, 64));
     mx.z = fmaxf(mx.z, __shfl_xor(mx.z, o, 64)); mx.w = fmaxf(mx.w, __shfl_xor(mx.w, o, 64));
   }
-  __syncthreads();   // the zero fill is complete (sRed lies inside the zeroed range's tail? no: beyond it)
+  __syncthreads();   // the zero fill is complete / the previous item's last group is consumed
   if (lane == 0) {
     sRed[wave * 4 + 0] = mx.x; sRed[wave * 4 + 1] = mx.y;
     sRed[wave * 4 + 2] = mx.z; sRed[wave * 4 + 3] = mx.w;
@@ -176,14 +192,17 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
     }
   };
 
-  // ---- prime the ring: input planes -3 .. 6 into slots 0 .. 9 (planes < 0 stay zero) ------------
+  // ---- prime the ring: input planes -3 .. 6 into slots 0 .. 9 (planes < 0: zeros, over whatever
+  // the previous work item left in those slots) -----------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < 3; ++u) store_plane(u, make_float4(0.f, 0.f, 0.f, 0.f));
   if constexpr (REGCOL) {
 #pragma unroll
     for (int u = 0; u < 7; ++u) store_plane(3 + u, col[u]);
   } else {
     float4 f[7];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) f[u] = load_plane(u);
+    for (int u = 0; u < 7; ++u) f[u] = load_plane(work, u);
 #pragma unroll
     for (int u = 0; u < 7; ++u) store_plane(3 + u, f[u]);
   }
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
         constexpr int z = 4 * decltype(gq)::value + 7;
         pf[u] = (z + u < 16) ? col[(z + u) & 15] : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
-        pf[u] = load_plane(4 * g + 7 + u);
+        pf[u] = load_plane(work, 4 * g + 7 + u);
       }
     }
 
@@ -313,6 +332,7 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
   } else {
     for (int g = 0; g < ngroups; ++g) do_group(g);
   }
+  }   // work items
 }
 
 // K = 7 cubic, rows of 9 .. 16 voxels in x and y, channels in fours, 16-byte aligned tensors
@@ -334,13 +354,25 @@ extern "C" int adell_dw_mfma_launch(const float* x, const float* w, const float*
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  DwMfmaArgs a = {x, w, b, y, N, C, D, H, W, flip};
-  if (D <= 16)
-    hipLaunchKernelGGL(adell_dw_mfma_kernel<true>, dim3(C / DM_CG, N), dim3(256), DM_LDS,
+  const long total = (long)N * (C / DM_CG);
+  ADELL_REQUIRE(total <= 0x7fffffffL - 4096, "dw_mfma: too many work items");
+  DwMfmaArgs a = {x, w, b, y, N, C, D, H, W, flip, (int)total};
+  if (D <= 16) {
+    // one block per CU (LDS): persistent blocks, each prefetching its next column
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      ADELL_CHECK_HIP(hipGetDevice(&dev));
+      ADELL_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+      cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = total < cus || g_adell_tune.dw_nopersist ? (int)total : cus;
+    hipLaunchKernelGGL(adell_dw_mfma_kernel<true>, dim3(grid), dim3(256), DM_LDS, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(adell_dw_mfma_kernel<false>, dim3((unsigned)total), dim3(256), DM_LDS,
                        (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(adell_dw_mfma_kernel<false>, dim3(C / DM_CG, N), dim3(256), DM_LDS,
-                       (hipStream_t)stream, a);
+  }
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
