@@ -193,7 +193,9 @@ __global__ __launch_bounds__(64 * CG) void adell_dw_dense_kernel(DwDenseArgs a) 
   }
   // ---- outputs: D[item = 4 kq + r][o = 16 nt + col] -> [item][o][channel] in LDS -> 16-byte stores --
   const int kw = __float_as_int(sRed[CG * Q * 4 + wave]);
-  const float oscale = __int_as_float((127 - (kx_w + kw)) << 23);
+  // the two scales undone one after the other: each exponent is clamped to +-100, their sum
+  // can pass the exponent range of a float (tiny dY times near-zero taps)
+  const float oscale = __int_as_float((127 - kx_w) << 23), oscale2 = __int_as_float((127 - kw) << 23);
   const float bias = a.b ? a.b[ch_w] : 0.f;
   __syncthreads();     // every wave has read its A fragments: the staging may overwrite the inputs
   constexpr int OUTROW = dd_outrow<CG>();
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(64 * CG) void adell_dw_dense_kernel(DwDenseArgs a) 
   for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      sOut[(4 * kq + r) * OUTROW + (nt * 16 + col) * CG + wave] = acc[nt][r] * oscale + bias;
+      sOut[(4 * kq + r) * OUTROW + (nt * 16 + col) * CG + wave] = acc[nt][r] * oscale * oscale2 + bias;
   __syncthreads();
 #pragma unroll
   for (int u = 0; u < 4; ++u) {

@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
     off[i] = d + 1;
   }
   const char* arow = R + mrow * DM_ROWB + kq * 16;   // A[m = y][k-group]: + slot, + ky rows
-  const float oscale = __int_as_float((127 - (kx4[wave] + kw)) << 23);
+  // the two scales undone one after the other: each exponent is clamped to +-100, their sum
+  // can pass the exponent range of a float (tiny dY times near-zero taps)
+  const float oscale = __int_as_float((127 - kx4[wave]) << 23), oscale2 = __int_as_float((127 - kw) << 23);
   const float bias = a.b ? a.b[ch_w] : 0.f;
 
   const int ngroups = (a.D + DM_G - 1) / DM_G;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void adell_dw_mfma_kernel(DwMfmaArgs a) {
     for (int j = 0; j < DM_G; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        sOut[(j * 16 + 4 * kq + r) * DM_OUTROW + mrow * 4 + wave] = acc[j][r] * oscale + bias;
+        sOut[(j * 16 + 4 * kq + r) * DM_OUTROW + mrow * 4 + wave] = acc[j][r] * oscale * oscale2 + bias;
     __syncthreads();     // the staging is complete, and every wave has read the four oldest planes
     if (vok) {
 #pragma unroll

@@ -48,7 +48,10 @@ __device__ __forceinline__ int wm_scale_exp(uint32_t bits) {
   const int ebits = (bits >> 23) & 0xff;
   int k = 0;
   if (ebits > 0 && ebits < 255) k = 13 - (ebits - 127);
-  return k > 100 ? 100 : (k < -100 ? -100 : k);
+  // +-63: the two tensors' exponents are undone as ONE factor 2^-(kx + kd), whose exponent field
+  // must stay inside a float's (a tensor whose absmax is below 2^-50 keeps fewer bits: it is zero
+  // for every purpose of a gradient)
+  return k > 63 ? 63 : (k < -63 ? -63 : k);
 }
 
 }  // namespace

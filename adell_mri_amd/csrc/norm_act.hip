@@ -1120,7 +1120,9 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
         na_half4 hi, lo;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float t = h[q] * a.split_scale;
+          // saturate at fp16's largest finite value: the exponent is a host-side bound (functional.
+          // _rows_exponent) that assumes exact statistics; an overshoot must not become inf -> NaN
+          const float t = __builtin_amdgcn_fmed3f(h[q] * a.split_scale, -65504.f, 65504.f);
           const _Float16 hh = (_Float16)t;
           hi[q] = hh;
           lo[q] = (_Float16)(t - (float)hh);

@@ -13,6 +13,7 @@ Statistics produced by the conv epilogue ride on the output tensor as
 """
 import itertools
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -437,17 +438,41 @@ def _side_ok(weight, *params):
 # says so before it runs the ADN (expect_rows); the ADN's forward takes the note (take_rows_reader)
 # and, when the conv's kernels stage split rows for this shape, writes rows instead of fp32 values
 # (same bytes). The note is keyed by the ADN module: no other norm_drop_act call can pick it up.
-_ROWS_EXPECT = {}
+_ROWS_EXPECT = weakref.WeakKeyDictionary()   # keyed by the ADN module itself (an id() can be reused)
 _ROWS_PLAN = {}
 
 
-def expect_rows(adn_module, conv, as_x1=False):
-    """``conv``: a modules.layers.conv.Conv3d; ``as_x1``: the tensor will be the conv's X_cat."""
+def _hooked(producers, readers):
+    """Could anything but the announced conv see the tensor? Forward hooks on a module whose output
+    it is (the ADN, the link / decoder block around it, anything inside), forward pre-hooks on a
+    module whose input it is, or global module hooks (feature extraction, Grad-CAM, profilers):
+    they would be handed fp32-typed memory holding fp16 row pairs."""
+    gm = torch.nn.modules.module
+    if gm._global_forward_hooks or gm._global_forward_pre_hooks:
+        return True
+    for top in producers:
+        for m in top.modules():
+            if m._forward_hooks:
+                return True
+    for top in readers:
+        for m in top.modules():
+            if m._forward_pre_hooks:
+                return True
+    return False
+
+
+def expect_rows(adn_module, conv, as_x1=False, producers=(), readers=()):
+    """``conv``: a modules.layers.conv.Conv3d; ``as_x1``: the tensor will be the conv's X_cat.
+    ``producers`` / ``readers``: the enclosing modules that return / receive the same tensor (the
+    link block and the decoder block of a skip hand-over); with the ADN and the conv themselves
+    they are searched for hooks that would observe the tensor (``_hooked``): then it stays fp32."""
     spec = conv.rows_spec() if (not FLAGS["no_rows"] and hasattr(conv, "rows_spec")) else None
+    if spec is not None and _hooked((adn_module,) + tuple(producers), (conv,) + tuple(readers)):
+        spec = None
     if spec is None:
-        _ROWS_EXPECT.pop(id(adn_module), None)
+        _ROWS_EXPECT.pop(adn_module, None)
     else:
-        _ROWS_EXPECT[id(adn_module)] = spec + (bool(as_x1),)
+        _ROWS_EXPECT[adn_module] = spec + (bool(as_x1),)
 
 
 def clear_row_expectations():
@@ -457,7 +482,7 @@ def clear_row_expectations():
 
 
 def take_rows_reader(adn_module):
-    return _ROWS_EXPECT.pop(id(adn_module), None) if _ROWS_EXPECT else None
+    return _ROWS_EXPECT.pop(adn_module, None) if _ROWS_EXPECT else None
 
 
 def _rows_exponent(x, reader, norm, gamma, beta, act, act_p, act_w, p):
@@ -468,6 +493,7 @@ def _rows_exponent(x, reader, norm, gamma, beta, act, act_p, act_w, p):
     typical values sit ~2^10 below the bound, where hi + lo still carry 22 bits and the absolute
     error floor is 2^-25 of the scaled unit)."""
     if (reader is None or FLAGS["no_rows"] or CONV_PRECISION != "f16x3" or norm != "instance"
+            or p >= 1.0
             or gamma is not None or beta is not None or act_w is not None or x.dim() != 5
             or act not in ("identity", "swish", "silu", "relu", "leaky_relu", "gelu")
             or (act == "leaky_relu" and abs(act_p) > 1.0)):

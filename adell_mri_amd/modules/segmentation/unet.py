@@ -467,7 +467,8 @@ class UNet(torch.nn.Module):
                     and isinstance(op, _DecoderOp) and isinstance(op[0], ConcatConvBlock)):
                 reader = _first_conv(op[0])
                 if reader is not None:
-                    HF.expect_rows(link_adn, reader, as_x1=True)
+                    HF.expect_rows(link_adn, reader, as_x1=True, producers=(link_op,),
+                                   readers=(op,))
             encoded = None
             if fork is not None and isinstance(link_op, ResidualBlock3d):
                 encoded, fork = link_op(link_in, fork=fork), None
@@ -506,7 +507,8 @@ class UNet(torch.nn.Module):
             # the last decoder op's ADN output is read by the head's first conv alone
             adn, reader = _last_adn(self.decoding_operations[-1]), _first_conv(self.final_layer)
             if adn is not None and reader is not None:
-                HF.expect_rows(adn, reader)
+                HF.expect_rows(adn, reader, producers=(self.decoding_operations[-1],),
+                               readers=(self.final_layer,))
         curr, deep_outputs = self._run_decoder(encoding_out, bottleneck, X_skip_layer,
                                                X_feature_conditioning)
         if head_only:

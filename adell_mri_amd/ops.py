@@ -158,16 +158,23 @@ _CHECK_DENSE = bool(os.environ.get("ADELL_CHECK_DENSE"))
 
 def _ptr(t):
     """Device address of ``t``. The kernels index dense memory (row-major, or NDHWC for 5-D / NHWC
-    for 4-D activations): with ADELL_CHECK_DENSE=1 a tensor that is neither -- an expanded
-    stride-0 view, a slice with gaps -- raises here instead of being read past its storage (the test
-    suite is run once per round with the check on)."""
+    for 4-D activations). Always checked: an expanded view (a stride-0 dimension of size > 1) raises
+    -- a kernel would read ``numel`` elements from a storage that holds fewer (the masked-attention
+    backward at batch 1 did, round 4). With ADELL_CHECK_DENSE=1 (tests/conftest.py sets it) every
+    other non-dense layout -- a slice with gaps, a permuted view -- raises too."""
     if t is None:
         return None
+    st = t.stride()
+    if 0 in st:
+        for s, n in zip(st, t.shape):
+            if s == 0 and n > 1:
+                raise _lib.AdellHipError(f"expanded (stride-0) tensor handed to a kernel: shape "
+                                         f"{tuple(t.shape)}, strides {st}")
     if _CHECK_DENSE and not (t.is_contiguous()
                              or (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d))
                              or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))):
         raise _lib.AdellHipError(f"non-dense tensor handed to a kernel: shape {tuple(t.shape)}, "
-                                 f"strides {t.stride()}")
+                                 f"strides {st}")
     return ctypes.c_void_p(t.data_ptr())
 
 

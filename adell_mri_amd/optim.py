@@ -157,10 +157,17 @@ class FlatParameters:
         self._has = has
 
     def has_grad(self):
-        """Which parameters hold a gradient (after a full ``collect()``: the mask it made; a
-        ``.grad`` set or cleared by hand since then is not seen -- ``zero_grad`` resets it)."""
+        """Which parameters hold a gradient. After a full ``collect()`` its mask is the starting
+        point, and every entry it marked is looked at again: a ``.grad`` set to None since then (a
+        parameter frozen for this step, gradient filtering between the all-reduce and the step) is
+        skipped, as ``torch.optim`` would skip it -- its slot still holds the stale gradient. A
+        gradient ASSIGNED by hand after ``collect()`` needs another ``collect()`` anyway."""
         if self._has is not None:
-            return self._has.copy()
+            has, params = self._has.copy(), self.params
+            for i in np.flatnonzero(has):
+                if params[i].grad is None:
+                    has[i] = False
+            return has
         return np.fromiter((p.grad is not None for p in self.params), dtype=bool,
                            count=len(self.params))
 

@@ -730,7 +730,9 @@ def gen_full_convnext():
               prediction_head_args=dict(cfg["prediction_head_args"], adn_fn=adn1))
     torch.manual_seed(0)
     net = ConvNeXt(**kw)
-    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN))
+    # norm scales centred at 1: a NON-collapsed state (batch std of y1 0.15, covariance term 0.03;
+    # with the plain filler: 0.004 and 5e-8, i.e. the covariance term and its gradient untested)
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=SSL_GAIN, norm_weight_offset=1.0))
     net.train()
     zz, yy, xx = torch.meshgrid(*[torch.arange(64.0)] * 3, indexing="ij")
     g = torch.Generator().manual_seed(FULL_SEED)

@@ -54,6 +54,27 @@ def test_forward_and_backward_data_against_fp64(cuda, N, C, size, scale):
     assert torch.equal(got_y, ops.dwconv3d_fwd(xd, wd, bd))
 
 
+def test_tiny_operands_give_tiny_results_not_garbage(cuda):
+    """Operands of 1e-30: the power-of-two scales of the two operands are undone one after the
+    other (their sum leaves the exponent range of a float: 2^-(kx + kw) built as ONE bit pattern
+    wrapped into garbage / NaN). Forward, backward-data, weight gradient and the dense small-volume
+    form: finite, and equal to fp64 within the split's 22 bits wherever fp32 can hold the value."""
+    g = torch.Generator().manual_seed(5)
+    for size, N in (((16, 16, 16), 2), ((4, 4, 4), 8)):
+        x = torch.randn(N, 8, *size, generator=g, dtype=torch.float64) * 1e-30
+        w = torch.randn(8, 1, 7, 7, 7, generator=g, dtype=torch.float64) * 1e-6
+        y = F.conv3d(x, w, None, padding=3, groups=8)           # ~1e-35: a normal fp32 number
+        xd, wd = ops.ndhwc(x.float().to(cuda)), w.float().to(cuda)
+        got = ops.dwconv3d_fwd(xd, wd, None)
+        assert torch.isfinite(got).all()
+        assert _rel(got.cpu().double(), y) < 1e-4
+        got_dx = ops.dwconv3d_bwd_data(xd, wd)                    # the same product, flipped taps
+        assert torch.isfinite(got_dx).all() and float(got_dx.abs().max()) < 1e-30
+    x = torch.randn(2, 8, 16, 16, 16, generator=g) * 1e-30
+    dw, db = ops.dwconv3d_bwd_weight(ops.ndhwc(x.to(cuda)), ops.ndhwc((x * 1e-5).to(cuda)), (7, 7, 7), True)
+    assert torch.isfinite(dw).all() and torch.isfinite(db).all() and float(dw.abs().max()) < 1e-30
+
+
 def test_dispatch_limits_and_the_fp32_mode(cuda):
     ok = _lib.lib().adell_dw_mfma_ok
     p = torch.zeros(64, device=cuda).data_ptr()

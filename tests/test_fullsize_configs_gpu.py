@@ -231,8 +231,10 @@ def test_config4_convnext_values_match_reference(cuda):
     net = ConvNeXt(backbone_args=bb,
                    projection_head_args=dict(cfg["projection_head_args"], adn_fn=adn1),
                    prediction_head_args=dict(cfg["prediction_head_args"], adn_fn=adn1))
-    net.load_state_dict(fill_state_dict(net.state_dict(), gain=3.0))
+    net.load_state_dict(fill_state_dict(net.state_dict(), gain=3.0, norm_weight_offset=1.0))
     assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    # a non-collapsed state: all three VICReg terms carry weight (the covariance term was 5e-8)
+    assert g["losses"][2] > 1e-2 and float(np.std(g["y1"], axis=0).mean()) > 0.05
     net = net.to(cuda).train()
     zz, yy, xx = torch.meshgrid(*[torch.arange(64.0)] * 3, indexing="ij")
     gen = torch.Generator().manual_seed(20260128)

@@ -237,6 +237,81 @@ def test_dropout_mask_statistics_and_determinism(cuda):
     assert torch.allclose(vals, torch.tensor([0.0, 1.0 / 0.85], device=cuda))
 
 
+def _chi2_2x2(a, b):
+    """Pearson chi-square (1 degree of freedom) of two boolean arrays' 2x2 contingency table."""
+    a = a.reshape(-1).astype(np.float64)
+    b = b.reshape(-1).astype(np.float64)
+    n = a.size
+    n11 = float((a * b).sum())
+    n1_, n_1 = float(a.sum()), float(b.sum())
+    tab = np.array([[n11, n1_ - n11], [n_1 - n11, n - n1_ - n_1 + n11]])
+    exp = np.outer([n1_, n - n1_], [n_1, n - n_1]) / n
+    return float(((tab - exp) ** 2 / exp).sum())
+
+
+def test_dropout_per_channel_rates_and_independence(cuda):
+    """The 7-round Philox mask (csrc/common.h): keep rate of every one of 64 channels, independence
+    of x-neighbours, of neighbouring channels and of the masks of offsets o and o + 1 (2x2 contingency
+    tables: chi-square with 1 degree of freedom, 99.99 % point = 15.1 -- a lost round of the
+    generator shows up as a statistic in the thousands on 0.5 M pairs)."""
+    p = 0.15
+    x = ops.ndhwc(torch.ones((2, 64, 16, 16, 16), device=cuda))
+    keep = []
+    for off in (5, 6):
+        out = ops.norm_act_fwd(x, None, None, "identity", drop_p=p, seed=1234, rng_offset=off)
+        keep.append((_np(out) != 0))
+    k0, k1 = keep
+    nper = k0[:, 0].size
+    rates = k0.mean(axis=(0, 2, 3, 4))
+    sigma = np.sqrt(p * (1 - p) / nper)
+    assert np.abs(rates - (1 - p)).max() < 5 * sigma, (rates.min(), rates.max(), sigma)
+    assert abs(k0.mean() - (1 - p)) < 5 * np.sqrt(p * (1 - p) / k0.size)
+    assert _chi2_2x2(k0[..., :-1], k0[..., 1:]) < 15.1          # neighbours along W
+    assert _chi2_2x2(k0[:, :, :, :-1], k0[:, :, :, 1:]) < 15.1  # along H
+    assert _chi2_2x2(k0[:, :-1], k0[:, 1:]) < 15.1              # neighbouring channels (same float4 or next)
+    assert _chi2_2x2(k0[:, 0::4], k0[:, 3::4]) < 15.1           # first and last word of one Philox call
+    assert _chi2_2x2(k0, k1) < 15.1                              # offsets o and o + 1
+    assert _chi2_2x2(k0[0], k0[1]) < 15.1                        # batch items
+
+
+@pytest.mark.parametrize("act,norm", [("swish", True), ("identity", False)])
+def test_dropout_forward_backward_mask_identity_p015(cuda, act, norm):
+    """Forward and backward regenerate the SAME mask at the configuration's p = 0.15: dx is zero
+    exactly where the forward output was dropped, and nowhere else (generic inputs)."""
+    g = torch.Generator(device=cuda).manual_seed(3)
+    x = ops.ndhwc(torch.randn((2, 32, 12, 10, 9), device=cuda, generator=g) + 0.3)
+    gy = ops.ndhwc(torch.randn((2, 32, 12, 10, 9), device=cuda, generator=g))
+    mean = rstd = None
+    if norm:
+        mean, rstd = ops.instance_stats(x, 1e-5)
+    out = ops.norm_act_fwd(x, mean, rstd, act, drop_p=0.15, seed=77, rng_offset=11)
+    ref = ops.norm_act_fwd(x, mean, rstd, act, drop_p=0.0, seed=77, rng_offset=11)
+    dropped = (out == 0) & (ref != 0)
+    assert abs(dropped.float().mean().item() - 0.15) < 0.01
+    assert torch.allclose(out[~dropped], ref[~dropped] / 0.85, rtol=1e-6, atol=1e-7)
+    if not norm:
+        # without the normalisation dx is elementwise: g * act'(x) * mask / (1 - p)
+        dx, _, _ = ops.norm_act_bwd(x, gy, None, None, act, drop_p=0.15, seed=77, rng_offset=11)
+        dx0, _, _ = ops.norm_act_bwd(x, gy, None, None, act, drop_p=0.0, seed=77, rng_offset=11)
+        assert torch.equal(dx == 0, dropped | (dx0 == 0))
+        assert torch.allclose(dx[~dropped], dx0[~dropped] / 0.85, rtol=1e-6, atol=1e-7)
+    else:
+        # with it, feed the masked gradient by hand: backward(p = 0.15, g) == backward(p = 0, g * mask / 0.85)
+        mask = (~dropped).float() / 0.85
+        dx, _, _ = ops.norm_act_bwd(x, gy, mean, rstd, act, drop_p=0.15, seed=77, rng_offset=11)
+        dx0, _, _ = ops.norm_act_bwd(x, gy * mask, mean, rstd, act, drop_p=0.0, seed=77, rng_offset=11)
+        assert torch.allclose(dx, dx0, rtol=1e-5, atol=1e-6)
+
+
+def test_expanded_view_is_refused(cuda):
+    """ops._ptr, always on: a stride-0 dimension of size > 1 never reaches a kernel (the masked
+    attention backward of round 4 read B*H*T*T floats from a T*T storage this way)."""
+    x = torch.ones((1, 32, 4, 4, 4), device=cuda).expand(2, 32, 4, 4, 4)
+    with pytest.raises(_lib.AdellHipError, match="stride-0"):
+        ops._ptr(x)
+    assert ops._ptr(torch.ones((1, 1, 4), device=cuda).expand(1, 1, 4)) is not None
+
+
 def test_cpu_tensor_is_refused():
     with pytest.raises(_lib.AdellHipError):
         ops.norm_act_fwd(torch.zeros(1, 4, 2, 2, 2), None, None, "relu")

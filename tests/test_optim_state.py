@@ -117,6 +117,29 @@ def test_step_after_load_and_gradientless_parameters_match_torch(cuda, kind):
         assert torch.allclose(a, b.cpu(), rtol=2e-5, atol=1e-6), k
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+def test_a_gradient_cleared_after_collect_is_skipped_as_torch_skips_it(cuda, kind):
+    """``p.grad = None`` between ``collect()`` (GradSync.all_reduce runs it) and ``step()``: the
+    parameter is left alone, like torch.optim leaves it -- not stepped with the stale slot."""
+    tcls, fcls, kw = KINDS[kind]
+    m = _model()
+    m2 = copy.deepcopy(m).to(cuda)
+    topt, fused = tcls(m.parameters(), **kw), fcls(m2.parameters())
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(3))
+    for step in range(2):
+        for mm, opt in ((m, topt), (m2, fused)):
+            opt.zero_grad()
+            mm(x.to(next(mm.parameters()).device)).pow(2).mean().backward()
+            if opt is fused:
+                fused.collect_grads()
+            if step == 1:
+                mm[0].bias.grad = None
+            opt.step()
+    for (k, a), b in zip(m.named_parameters(), m2.parameters()):
+        assert torch.allclose(a, b.cpu(), rtol=2e-5, atol=1e-6), k
+
+
 def test_get_optimizer_covers_the_reference_factory_names():
     # the module path of the reference (utils/optimizer_factory.py:5-54), its three public names
     from adell_mri_amd.modules.segmentation import pl

@@ -193,6 +193,80 @@ def test_residual_block_with_and_without_rows(cuda, monkeypatch):
         assert float((gw_r[k] - gw_f[k]).abs().max()) <= 5e-5 * scale, k
 
 
+def _unet(cuda):
+    from adell_mri_amd.modules.activations import activation_factory
+    from adell_mri_amd.modules.segmentation.unet import UNet
+
+    torch.manual_seed(2)
+    return UNet(spatial_dimensions=3, conv_type="regular", link_type="residual",
+                upscale_type="transpose", norm_type="instance", padding=1, dropout_param=0.0,
+                activation_fn=activation_factory["swish"], in_channels=2, n_classes=2,
+                depth=[16, 32, 32], kernel_sizes=[3] * 3, strides=[2] * 3).to(cuda).train()
+
+
+@pytest.mark.parametrize("where", ["decoder_output", "link_output", "adn_output", "conv_pre_hook", "global"])
+def test_a_forward_hook_never_sees_split_rows(cuda, monkeypatch, where):
+    """A tensor in split-row format is fp32-typed memory holding fp16 row pairs: only the conv it
+    was written for may read it. Any hook that could observe it -- on the ADN, on the link / decoder
+    block around it, a pre-hook on the reading conv, a global module hook -- keeps the site in fp32
+    (functional._hooked); hook-free sites keep their rows; logits agree with the hook-free run."""
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd import ops
+    from adell_mri_amd.modules.layers.adn_fn import ActDropNorm
+
+    net = _unet(cuda)
+    x = torch.rand(1, 2, 32, 32, 32, device=cuda)
+    made = []
+    real = ops.norm_act_fwd
+    monkeypatch.setattr(ops, "norm_act_fwd",
+                        lambda *a, **k: made.append(k.get("split_exp")) or real(*a, **k))
+    ref = net(x, return_logits=True)[0].detach()
+    plain_rows = sum(e is not None for e in made)
+    assert plain_rows >= 3, made           # link -> decoder, decoder -> head and inner sites write rows
+    seen = []
+
+    def look(_m, _inp, out):
+        seen.append(out)
+
+    def look_pre(_m, inp):
+        seen.extend(t for t in inp if torch.is_tensor(t))
+
+    if where == "decoder_output":
+        h = net.decoding_operations[-1].register_forward_hook(look)
+    elif where == "link_output":
+        h = net.link_ops[-1].register_forward_hook(look)
+    elif where == "adn_output":
+        adn = [m for m in net.decoding_operations[-1].modules() if isinstance(m, ActDropNorm)][-1]
+        h = adn.register_forward_hook(look)
+    elif where == "conv_pre_hook":
+        from adell_mri_amd.modules.segmentation.unet import _first_conv
+        h = _first_conv(net.final_layer).register_forward_pre_hook(look_pre)
+    else:
+        h = torch.nn.modules.module.register_module_forward_hook(look)
+    try:
+        made.clear()
+        got = net(x, return_logits=True)[0].detach()
+    finally:
+        h.remove()
+    assert seen, "the hook did not run"
+    for t in seen:
+        if torch.is_tensor(t):
+            assert getattr(t, "_adell_rows", None) is None
+    hooked_rows = sum(e is not None for e in made)
+    assert hooked_rows < plain_rows
+    if where == "global":
+        assert hooked_rows == 0
+    # the hooked tensor holds the values: feeding it to the head by hand reproduces the logits
+    if where in ("decoder_output", "adn_output"):
+        feat = [t for t in seen if torch.is_tensor(t)][-1]
+        assert feat.shape[1] == 16 and torch.isfinite(feat).all() and float(feat.abs().max()) < 1e3
+    assert _rel(got, ref) <= 5e-6
+    # and once the hook is gone the rows are back
+    made.clear()
+    net(x, return_logits=True)
+    assert sum(e is not None for e in made) == plain_rows
+
+
 @pytest.mark.parametrize("N,C0,C1,Cout,size", [
     (2, 32, 0, 32, (64, 64, 64)),      # 8x8x8 bricks, two chunks
     (1, 64, 0, 32, (76, 44, 68)),      # ragged bricks, four chunks, faces outside the tensor
