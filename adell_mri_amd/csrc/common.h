@@ -169,8 +169,12 @@ __device__ __forceinline__ uint4 adell_philox4(uint32_t c0, uint32_t c1,
   const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int r = 0; r < ADELL_PHILOX_ROUNDS; ++r) {
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    // one 32 x 32 -> 64 bit multiply per word pair (v_mad_u64_u32) instead of a mul_hi and a mul_lo:
+    // both are quarter-rate instructions, and the generator is what these passes spend their
+    // vector-ALU time on
+    const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += W0; k1 += W1;

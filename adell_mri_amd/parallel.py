@@ -19,6 +19,8 @@ group (``optim.FlatParameters``), so a bucket is a contiguous slice of that buff
   (``grad_scale``), not a separate pass.
 """
 import os
+import statistics
+import time
 
 import torch
 import torch.distributed as dist
@@ -83,7 +85,7 @@ def plan_buckets(sizes, n_buckets=4, min_elems=1 << 20):
 
 
 class _Bucket:
-    __slots__ = ("flat", "lo", "hi", "e0", "e1", "pending", "sent", "handle", "again")
+    __slots__ = ("flat", "lo", "hi", "e0", "e1", "pending", "sent", "handle", "again", "issued")
 
     def __init__(self, flat, lo, hi):
         self.flat, self.lo, self.hi = flat, lo, hi
@@ -95,6 +97,7 @@ class _Bucket:
         self.sent = False                  # the slice went out in this step
         self.handle = None                 # ... and this is its collective
         self.again = False                 # a later backward of the same step brought more
+        self.issued = None                 # GradSync.profile: (event at the collective's issue, host time)
 
 
 class GradSync:
@@ -143,6 +146,11 @@ class GradSync:
         self.overlap = bool(overlap) and (self.world > 1 or (_force_overlap and dist.is_initialized()))
         self.buckets, self._hooks = [], []
         self._sync = True
+        # exchange profile (bench.py's N > 1 line): with ``profile`` on, every step records when
+        # each bucket's collective was issued and how long ``all_reduce()`` kept the main stream
+        # waiting for handles -- see ``exchange_stats()``
+        self.profile = False
+        self._prof = []
         # functional._side_ok: with a process group up, weight gradients may be produced on the
         # side stream only for parameters whose exchange goes through this object (every read of a
         # gradient here is behind FlatParameters.collect, which joins that stream)
@@ -215,6 +223,12 @@ class GradSync:
             if b.e1 > b.e0:
                 b.handle = dist.all_reduce(b.flat.grad[b.e0:b.e1], op=dist.ReduceOp.SUM,
                                            async_op=True)
+        if self.profile:
+            ev = None
+            if b.flat.grad.is_cuda:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(side if side is not None else torch.cuda.current_stream(b.flat.grad.device))
+            b.issued = (ev, time.perf_counter())
         b.sent = True
         # detach the parameters from the slice while the collective may be running: a later
         # backward must not accumulate in place into memory the collective reads and writes
@@ -319,21 +333,96 @@ class GradSync:
         """Complete the gradient exchange of this step: after it returns (stream-ordered), every
         flat gradient buffer holds the sum over ranks and every parameter that produced a
         gradient has ``p.grad`` pointing at its slice of it."""
+        prof = self._profile_begin() if self.profile else None
         if self.overlap:
+            late = 0
             for b in self.buckets:           # buckets that a gradient-less parameter (or
                 if not b.sent:               # no_sync) held back
                     self._send(b)
+                    late += 1
+            issued = [b.issued for b in self.buckets]
             for b in self.buckets:
                 self._finish(b)
                 b.reset()
+            if prof is not None:
+                self._profile_end(prof, issued, late)
         else:
             collect = getattr(self.optimizer, "collect_grads", None)
             if collect is not None:
                 collect()
             all_reduce_flat([f.grad for f in self.optimizer.flat_groups], self.chunk,
                             self.async_op)
+            if prof is not None:
+                self._profile_end(prof, [], 0)
         if self.find_unused and (self.world > 1):
             self._attach_remote_grads()
+
+
+    # ---- exchange profile ---------------------------------------------------------------------
+    def _profile_begin(self):
+        """End of backward as the MAIN stream sees it (an event) and as the host sees it."""
+        dev = next((f.grad.device for f in self.optimizer.flat_groups if f.grad.numel()), None)
+        ev = None
+        if dev is not None and dev.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(dev))
+        return dev, ev, time.perf_counter()
+
+    def _profile_end(self, begin, issued, late):
+        dev, ev0, t0 = begin
+        ev1 = None
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream(dev))
+        self._prof.append((ev0, ev1, t0, time.perf_counter(), issued, late))
+
+    def exchange_stats(self):
+        """What the profiled steps saw (medians over steps; call after a device synchronisation):
+        ``exposed_comm_ms`` -- how long ``all_reduce()`` held the main stream between the end of
+        backward and the optimiser (HIP events on that stream: waits for bucket handles, late
+        sends, the second-contribution fold), ``exposed_comm_host_ms`` -- the same interval on the
+        host clock (a blocking backend such as gloo shows here), ``bucket_mb`` -- message sizes
+        in issue order of the flat buffer, ``issue_before_backward_end_ms`` -- per bucket, how long
+        before the end of backward its collective was issued on the device time line (negative:
+        it went out from ``all_reduce()`` itself, nothing left to hide behind) and
+        ``buckets_sent_late`` -- buckets no hook completed."""
+        if not self._prof:
+            return None
+        exp_dev, exp_host, lead, late = [], [], [], []
+        for ev0, ev1, t0, t1, issued, nlate in self._prof:
+            exp_host.append(1e3 * (t1 - t0))
+            late.append(nlate)
+            if ev0 is not None and ev1 is not None:
+                ev1.synchronize()
+                exp_dev.append(ev0.elapsed_time(ev1))
+            row = []
+            for it in issued:
+                if it is None:
+                    row.append(None)
+                elif it[0] is not None and ev0 is not None:
+                    it[0].synchronize()
+                    row.append(it[0].elapsed_time(ev0))
+                else:
+                    row.append(1e3 * (t0 - it[1]))
+            lead.append(row)
+        med = statistics.median
+        nb = max((len(r) for r in lead), default=0)
+        out = {"steps_profiled": len(self._prof),
+               "overlap": bool(self.overlap),
+               "exposed_comm_ms": None if not exp_dev else round(med(exp_dev), 4),
+               "exposed_comm_host_ms": round(med(exp_host), 4),
+               "bucket_mb": [round(4.0 * (b.e1 - b.e0) / 2 ** 20, 3) for b in self.buckets],
+               "issue_before_backward_end_ms": [
+                   (lambda v: None if not v else round(med(v), 4))(
+                       [r[k] for r in lead if len(r) > k and r[k] is not None]) for k in range(nb)],
+               "buckets_sent_late": med(late) if late else 0}
+        if not self.overlap:
+            out["bucket_mb"] = [round(4.0 * f.grad.numel() / 2 ** 20, 3)
+                                for f in self.optimizer.flat_groups]
+        return out
+
+    def clear_profile(self):
+        self._prof = []
 
 
 def reduce_max(value, device):

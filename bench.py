@@ -507,6 +507,16 @@ def main():
         dts, _, _ = timed_steps(runner, batch, nser, barrier, per_step_events=False)
         serial_ms = 1e3 * reduce_max(dts, device) / nser
     HF.FLAGS["wgrad_stream"] = overlap
+    # N > 1: what the gradient exchange costs the step, on a few profiled steps after the timed
+    # region (GradSync.exchange_stats: exposed wait of the main stream, bucket sizes, how long before
+    # the end of backward each bucket went out) -- the line that explains a scaling curve
+    exchange = None
+    if world > 1 and args.warmup > 0:
+        sync.profile = True
+        timed_steps(runner, batch, 3, barrier, per_step_events=False)
+        sync.profile = False
+        exchange = sync.exchange_stats()
+        sync.clear_profile()
     dt = reduce_max(dt, device)
     loss_value = float(loss.detach().cpu())
 
@@ -608,6 +618,14 @@ def main():
                       "pool_headroom_bytes": list(reserved_extra),
                       "note": "the weight-gradient kernels run on a second HIP stream beside the "
                               "backward-data chain; the event-timed steps (roofline) keep one stream"}
+    if exchange is not None:
+        exchange["gradient_mb"] = round(sum(exchange["bucket_mb"]), 3)
+        exchange["exposed_share_of_step"] = (
+            None if exchange["exposed_comm_ms"] is None
+            else exchange["exposed_comm_ms"] / (1e3 * dt / args.steps))
+        exchange["backend"] = torch.distributed.get_backend()
+        exchange["measured"] = "3 profiled steps on rank 0 directly after the timed region"
+        out["gradient_exchange"] = exchange
     if fp32_line is not None:
         out["fp32_mfma"] = fp32_line
     if secondary:

@@ -274,33 +274,40 @@ def test_dropout_per_channel_rates_and_independence(cuda):
     assert _chi2_2x2(k0[0], k0[1]) < 15.1                        # batch items
 
 
-@pytest.mark.parametrize("act,norm", [("swish", True), ("identity", False)])
+@pytest.mark.parametrize("act", ["swish", "identity"])
+@pytest.mark.parametrize("norm", [True, False])
 def test_dropout_forward_backward_mask_identity_p015(cuda, act, norm):
-    """Forward and backward regenerate the SAME mask at the configuration's p = 0.15: dx is zero
-    exactly where the forward output was dropped, and nowhere else (generic inputs)."""
+    """Forward and backward regenerate the SAME mask at the configuration's p = 0.15 (ordering
+    norm -> dropout -> activation, adn_fn.py:140-152): the mask is read off an identity-activation
+    forward, the forward with the activation equals act(u * mask / 0.85), and the backward equals
+    the p = 0 backward of a gradient masked by hand (through the activation's derivative at the
+    dropped-out value, computed here with torch)."""
     g = torch.Generator(device=cuda).manual_seed(3)
     x = ops.ndhwc(torch.randn((2, 32, 12, 10, 9), device=cuda, generator=g) + 0.3)
     gy = ops.ndhwc(torch.randn((2, 32, 12, 10, 9), device=cuda, generator=g))
     mean = rstd = None
     if norm:
         mean, rstd = ops.instance_stats(x, 1e-5)
-    out = ops.norm_act_fwd(x, mean, rstd, act, drop_p=0.15, seed=77, rng_offset=11)
-    ref = ops.norm_act_fwd(x, mean, rstd, act, drop_p=0.0, seed=77, rng_offset=11)
-    dropped = (out == 0) & (ref != 0)
-    assert abs(dropped.float().mean().item() - 0.15) < 0.01
-    assert torch.allclose(out[~dropped], ref[~dropped] / 0.85, rtol=1e-6, atol=1e-7)
+    kw = dict(seed=77, rng_offset=11)
+    u = ops.norm_act_fwd(x, mean, rstd, "identity", drop_p=0.0, **kw)            # normalised values
+    ud = ops.norm_act_fwd(x, mean, rstd, "identity", drop_p=0.15, **kw)
+    keep = (ud != 0)
+    assert abs(keep.float().mean().item() - 0.85) < 0.01
+    m = keep.float() / 0.85
+    assert torch.allclose(ud, u * m, rtol=1e-6, atol=1e-7)
+    fn = torch.nn.functional.silu if act == "swish" else (lambda t: t)
+    out = ops.norm_act_fwd(x, mean, rstd, act, drop_p=0.15, **kw)
+    assert torch.allclose(out, fn(u * m), rtol=2e-6, atol=1e-6)
+    # backward: dt = g * act'(u m) * m, then the normalisation's backward (p = 0, identity)
+    um = (u * m).detach().requires_grad_(True)
+    fn(um).backward(gy)
+    dt = (um.grad * m).contiguous(memory_format=torch.channels_last_3d)
+    dx, _, _ = ops.norm_act_bwd(x, gy, mean, rstd, act, drop_p=0.15, **kw)
+    dx0, _, _ = ops.norm_act_bwd(x, dt, mean, rstd, "identity", drop_p=0.0, **kw)
+    scale = float(dx0.abs().max())
+    assert float((dx - dx0).abs().max()) <= 2e-5 * scale
     if not norm:
-        # without the normalisation dx is elementwise: g * act'(x) * mask / (1 - p)
-        dx, _, _ = ops.norm_act_bwd(x, gy, None, None, act, drop_p=0.15, seed=77, rng_offset=11)
-        dx0, _, _ = ops.norm_act_bwd(x, gy, None, None, act, drop_p=0.0, seed=77, rng_offset=11)
-        assert torch.equal(dx == 0, dropped | (dx0 == 0))
-        assert torch.allclose(dx[~dropped], dx0[~dropped] / 0.85, rtol=1e-6, atol=1e-7)
-    else:
-        # with it, feed the masked gradient by hand: backward(p = 0.15, g) == backward(p = 0, g * mask / 0.85)
-        mask = (~dropped).float() / 0.85
-        dx, _, _ = ops.norm_act_bwd(x, gy, mean, rstd, act, drop_p=0.15, seed=77, rng_offset=11)
-        dx0, _, _ = ops.norm_act_bwd(x, gy * mask, mean, rstd, act, drop_p=0.0, seed=77, rng_offset=11)
-        assert torch.allclose(dx, dx0, rtol=1e-5, atol=1e-6)
+        assert torch.equal(dx == 0, ~keep | (dx0 == 0))
 
 
 def test_expanded_view_is_refused(cuda):

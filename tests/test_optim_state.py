@@ -125,7 +125,7 @@ def test_a_gradient_cleared_after_collect_is_skipped_as_torch_skips_it(cuda, kin
     tcls, fcls, kw = KINDS[kind]
     m = _model()
     m2 = copy.deepcopy(m).to(cuda)
-    topt, fused = tcls(m.parameters(), **kw), fcls(m2.parameters())
+    topt, fused = tcls(m.parameters(), **kw), fcls(m2.parameters(), **kw)
     x = torch.randn(4, 6, generator=torch.Generator().manual_seed(3))
     for step in range(2):
         for mm, opt in ((m, topt), (m2, fused)):

@@ -35,6 +35,14 @@ def test_two_rank_bench_prints_one_contract_line(cuda):
     # whole-job throughput: both ranks' volumes over the slowest rank's time
     assert abs(d["value"] - 2 * 1 * 2 / (2 * d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["frac"] > 0 and d["final_loss"] == d["final_loss"]
+    # the line explains its own exchange: exposed wait, bucket sizes, issue times against backward
+    ex = d["gradient_exchange"]
+    assert ex["overlap"] and ex["steps_profiled"] == 3 and ex["backend"] == "gloo"
+    assert ex["exposed_comm_ms"] is not None and ex["exposed_comm_ms"] >= 0
+    assert ex["exposed_comm_host_ms"] >= 0 and 0 <= ex["exposed_share_of_step"] < 1
+    assert len(ex["bucket_mb"]) == len(ex["issue_before_backward_end_ms"]) >= 1
+    assert abs(sum(ex["bucket_mb"]) - ex["gradient_mb"]) < 1e-2 and ex["gradient_mb"] > 30   # 33 MB
+    assert all(v is not None for v in ex["issue_before_backward_end_ms"])
 
 
 @pytest.mark.gpu
