@@ -49,6 +49,7 @@ static AdellTuning adell_tuning_from_env() {
   t.dw_nopersist = adell_env_int("ADELL_DW_NOPERSIST", 0);
   t.dw_dense16 = adell_env_int("ADELL_DW_DENSE16", 0);
   t.gemm_nowide = adell_env_int("ADELL_GEMM_NOWIDE", 0);
+  t.gemm_norows = adell_env_int("ADELL_GEMM_NOROWS", 0);
   t.dw_nozring = adell_env_int("ADELL_DW_NOZRING", 0);
   t.igemm_no16 = adell_env_int("ADELL_IGEMM_NO16", 0);
   t.zr16_overhead = adell_env_int("ADELL_ZR16_OVERHEAD", 6);
@@ -90,6 +91,7 @@ static int* adell_tuning_slot(const char* name) {
   if (!strcmp(name, "dw_nopersist")) return &g_adell_tune.dw_nopersist;
   if (!strcmp(name, "dw_dense16")) return &g_adell_tune.dw_dense16;
   if (!strcmp(name, "gemm_nowide")) return &g_adell_tune.gemm_nowide;
+  if (!strcmp(name, "gemm_norows")) return &g_adell_tune.gemm_norows;
   if (!strcmp(name, "dw_nozring")) return &g_adell_tune.dw_nozring;
   if (!strcmp(name, "igemm_no16")) return &g_adell_tune.igemm_no16;
   if (!strcmp(name, "zr16_overhead")) return &g_adell_tune.zr16_overhead;

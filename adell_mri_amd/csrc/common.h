@@ -37,6 +37,7 @@ struct AdellTuning {
   int dw_nopersist;               // depthwise MFMA forward: one block per work item instead of persistent blocks (A/B)
   int dw_dense16;                 // dense small-volume depthwise kernel: 16 channels per block when 16 divide C (A/B: slower)
   int gemm_nowide;                // f16x3 GEMM: scalar epilogue stores from the MFMA layout (no LDS pass)
+  int gemm_norows;                // f16x3 GEMM: never the streaming kernel for many-row Linear layers (gemm_rows.hip)
   int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)
   int wgrad_no16;                 // z-ring weight gradient: 32 x 32 tiles even for 16-channel layers
   int igemm_no16;                 // forward / backward-data of 16 -> 16 layers: not the z-ring 16-column kernel

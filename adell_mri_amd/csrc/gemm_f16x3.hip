@@ -541,6 +541,15 @@ __global__ __launch_bounds__(256) void adell_absmax_f32_kernel(const float* __re
   }
 }
 
+// the streaming kernel for many-row Linear layers (gemm_rows.hip)
+bool adell_gemm_rows_ok(int M, int N, int K, const float* A, long lda, int a_kc, const float* B, long ldb,
+                        int act, bool epi, bool dact);
+long adell_gemm_rows_workspace_floats(int M, int N, int K);
+int adell_gemm_rows_run(int M, int N, int K, const float* A, long lda, const float* B, long ldb, int b_kc,
+                        float* C, long ldc, const float* bias, const float* residual, long ldr,
+                        float* workspace, hipStream_t st, int act, float act_p, float* act_out,
+                        const float* dact_in);
+
 namespace {
 
 struct GemmHPlan {
@@ -600,7 +609,14 @@ extern "C" int adell_gemm_f16x3_applicable(int M, int N, int K, const float* A, 
 extern "C" long adell_gemm_f16x3_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const GemmHPlan p = gemm_h_plan(M, N, K);
-  return p.splits > 1 ? (long)p.splits * M * N : 0;
+  long need = p.splits > 1 ? (long)p.splits * M * N : 0;
+  // the streaming kernel packs its weight operand into the workspace (shape-eligible problems only;
+  // the pointer conditions are checked at the call)
+  if (adell_gemm_rows_ok(M, N, K, nullptr, 0, 1, nullptr, 0, ADELL_ACT_GELU, false, false)) {
+    const long rows = adell_gemm_rows_workspace_floats(M, N, K);
+    need = need > rows ? need : rows;
+  }
+  return need;
 }
 
 // Same contract as adell_gemm_f32 + a_absmax / b_absmax: both NULL (operand scales chosen per block
@@ -622,6 +638,10 @@ static int gemm_h_run(int M, int N, int K, const float* A, long lda, int a_kc,
     adell_set_error("gemm_f16x3: operands need 16-byte alignment, leading dimensions / K multiples of 4");
     return ADELL_E_UNSUPPORTED;
   }
+  if (workspace && (((uintptr_t)workspace) & 15) == 0 && (((uintptr_t)C) & 3) == 0 &&
+      adell_gemm_rows_ok(M, N, K, A, lda, a_kc, B, ldb, act, act_out || dact_in, dact_in != nullptr))
+    return adell_gemm_rows_run(M, N, K, A, lda, B, ldb, b_kc, C, ldc, bias, residual, ldr, workspace,
+                               (hipStream_t)stream, act, act_p, act_out, dact_in);
   const GemmHPlan p = gemm_h_plan(M, N, K);
   ADELL_REQUIRE(p.splits == 1 || workspace, "gemm_f16x3: workspace required for this shape");
   GemmHArgs a;

@@ -1723,7 +1723,8 @@ def gemm_f16x3(M, N, K, A, lda, a_kc, B, ldb, b_kc, a_amax=None, b_amax=None, ou
         check(_lib.lib().adell_gemm_f16x3(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb, int(b_kc),
                                           _ptr(out), N, _ptr(bias), _ptr(residual), ldr,
                                           _ptr(a_amax), _ptr(b_amax), _ptr(ws), _stream()))
-    _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run)
+    _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run,
+           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'}")
     return out
 
 
@@ -1744,7 +1745,8 @@ def gemm_f16x3_act(M, N, K, A, lda, a_kc, B, ldb, b_kc, act, act_p=0.0, bias=Non
                                               int(b_kc), _ptr(out), N, _ptr(bias), _ptr(residual),
                                               ldr, None, None, _ptr(ws), _lib.ACT_IDS[act],
                                               float(act_p), _ptr(act_out), _ptr(dact_in), _stream()))
-    _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run)
+    _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run,
+           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'} act")
     return out, act_out
 
 

@@ -225,3 +225,91 @@ def test_mlp_module_takes_the_fused_path_only_without_norm_or_dropout(cuda, monk
     with torch.no_grad():
         m(x)
     assert calls
+
+
+# ---- the streaming kernel for many-row Linear layers (csrc/gemm_rows.hip) --------------------------
+ROWS_CASES = [  # M, N, K: persistent blocks over (128-row tile, 128-column slice) pairs
+    (65536, 384, 96),       # ConvNeXt pwconv1 (a quarter of config 4's rows): 3 slices x 3 stages
+    (65536, 96, 384),       # pwconv2: one slice of 3 column tiles, 12 stages
+    (66000, 200, 64),       # ragged last row tile, last slice of 72 columns (a partial column tile)
+    (70001, 36, 32),        # N < one slice, odd M, a single stage
+    (40000, 1536, 384),     # 12 slices
+]
+
+
+@pytest.mark.parametrize("M,N,K", ROWS_CASES)
+@pytest.mark.parametrize("b_kc", [True, False])
+def test_rows_kernel_against_fp64_and_the_tile_kernel(cuda, M, N, K, b_kc):
+    from adell_mri_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(M % 1000 + N + K)
+    A = torch.randn(M, K, generator=g)
+    A[:, : K // 2] *= 40.0                      # block exponents differ between k stages
+    A[M // 3] *= 3000.0                         # and between row blocks
+    B = torch.randn(K, N, generator=g) * torch.logspace(-3, 2, N)[None, :]   # per-column scales matter
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g)
+    Ad, Bd = A.to(cuda), (B.t() if b_kc else B).contiguous().to(cuda)
+    ldb = K if b_kc else N
+    assert _lib.lib().adell_gemm_f16x3_workspace_floats(M, N, K) >= 128 * ((N + 127) // 128) * (K + 1)
+    got = ops.gemm_f16x3(M, N, K, Ad, K, True, Bd, ldb, b_kc, bias=bias.to(cuda), residual=res.to(cuda))
+    with _lib.tuning(gemm_norows=1):
+        old = ops.gemm_f16x3(M, N, K, Ad, K, True, Bd, ldb, b_kc, bias=bias.to(cuda), residual=res.to(cuda))
+    # row by row against fp64 in chunks (the whole fp64 product of the largest case is 0.5 GB)
+    worst, worst_old = 0.0, 0.0
+    Bd64, absB = B.double(), B.double().abs()
+    for lo in range(0, M, 16384):
+        a64 = A[lo:lo + 16384].double()
+        want = a64 @ Bd64 + bias.double() + res[lo:lo + 16384].double()
+        scale = (a64.abs() @ absB).clamp_min(1e-30)             # per element: sum |a||b|
+        worst = max(worst, float(((got[lo:lo + 16384].cpu().double() - want).abs() / scale).max()))
+        worst_old = max(worst_old, float(((old[lo:lo + 16384].cpu().double() - want).abs() / scale).max()))
+    assert worst < 2e-6, (worst, worst_old)
+    assert torch.equal(got, ops.gemm_f16x3(M, N, K, Ad, K, True, Bd, ldb, b_kc, bias=bias.to(cuda),
+                                           residual=res.to(cuda)))            # deterministic
+
+
+def test_rows_kernel_activation_pair(cuda):
+    """Linear -> GELU with both tensors from one launch, and the backward of the pair (C * act'(saved))
+    on the streaming kernel, against torch fp64 and the tile kernel's epilogue."""
+    from adell_mri_amd import _lib, ops
+
+    M, K, N = 50000, 96, 384
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(cuda)
+    W = (torch.randn(N, K, generator=g) * 0.1).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda)
+    pre, post = ops.gemm_f16x3_act(M, N, K, A, K, True, W, K, True, "gelu", bias=b, want_act=True)
+    want = A.cpu().double() @ W.cpu().double().t() + b.cpu().double()
+    assert _rel(pre, want) < 2e-6
+    assert _rel(post, torch.nn.functional.gelu(want)) < 2e-6
+    # backward of the pair: dX = (dY W2) * gelu'(pre), A = dY [M, K2], W2 [K2, N] outer-contiguous
+    K2 = 96
+    dY = torch.randn(M, K2, generator=g).to(cuda)
+    W2 = (torch.randn(K2, N, generator=g) * 0.1).to(cuda)
+    dh, _ = ops.gemm_f16x3_act(M, N, K2, dY, K2, True, W2, N, False, "gelu", dact_in=pre)
+    x = want.clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(dY.cpu().double() @ W2.cpu().double())
+    assert _rel(dh, x.grad) < 3e-6
+    with _lib.tuning(gemm_norows=1):
+        pre_o, post_o = ops.gemm_f16x3_act(M, N, K, A, K, True, W, K, True, "gelu", bias=b, want_act=True)
+    assert _rel(pre, pre_o.cpu().double()) < 2e-6 and _rel(post, post_o.cpu().double()) < 2e-6
+
+
+def test_rows_kernel_limits(cuda):
+    """Shapes the streaming kernel leaves to the tile kernel: few rows, K not a multiple of 32, an
+    activation it has no instance of, outer-contiguous A -- the results do not depend on the choice."""
+    from adell_mri_amd import _lib, ops
+
+    g = torch.Generator().manual_seed(2)
+    for M, N, K in ((1024, 384, 96), (65536, 96, 48)):
+        A, W = torch.randn(M, K, generator=g).to(cuda), torch.randn(N, K, generator=g).to(cuda)
+        a = ops.gemm_f16x3(M, N, K, A, K, True, W, K, True)
+        with _lib.tuning(gemm_norows=1):
+            b = ops.gemm_f16x3(M, N, K, A, K, True, W, K, True)
+        assert torch.equal(a, b)
+    A, W = torch.randn(65536, 96, generator=g).to(cuda), torch.randn(128, 96, generator=g).to(cuda)
+    s1, _ = ops.gemm_f16x3_act(65536, 128, 96, A, 96, True, W, 96, True, "swish", want_act=True)
+    with _lib.tuning(gemm_norows=1):
+        s2, _ = ops.gemm_f16x3_act(65536, 128, 96, A, 96, True, W, 96, True, "swish", want_act=True)
+    assert torch.equal(s1, s2)
