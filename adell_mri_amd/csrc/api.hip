@@ -29,30 +29,13 @@ static AdellTuning adell_tuning_from_env() {
   t.igemm_nospec = adell_env_set("ADELL_IGEMM_NOSPEC");
   t.igemm_no8 = adell_env_set("ADELL_IGEMM_NO8");
   t.no_splitk = adell_env_set("ADELL_NO_SPLITK");
-  t.no_wgrad_tiny = adell_env_set("ADELL_NO_WGRAD_TINY");
   t.wgrad_nozring = adell_env_set("ADELL_WGRAD_NOZRING");
-  t.zr_minseg = adell_env_int("ADELL_ZR_MINSEG", 4);
-  t.igemm_no2wave = adell_env_set("ADELL_IGEMM_NO2WAVE");
-  t.igemm_oldtile = adell_env_set("ADELL_IGEMM_OLDTILE");
-  t.igemm_ws = adell_env_set("ADELL_IGEMM_WS");
   t.attn_nomfma = adell_env_set("ADELL_ATTN_NOMFMA");
-  t.ws_min_items = adell_env_int("ADELL_WS_MIN_ITEMS", 1024);
-  t.igemm_ws_rows = adell_env_int("ADELL_IGEMM_WS_ROWS", 0);
-  t.igemm_wide8 = adell_env_int("ADELL_IGEMM_WIDE8", 0);
-  t.ew_reverse = adell_env_int("ADELL_EW_REVERSE", 0);
-  t.fold_coarse = adell_env_int("ADELL_FOLD_COARSE", 0);
-  t.wgrad_no16 = adell_env_int("ADELL_WGRAD_NO16", 0);
-  t.zr_oldseg = adell_env_int("ADELL_ZR_OLDSEG", 0);
-  t.gemm_nosmall = adell_env_int("ADELL_GEMM_NOSMALL", 0);
   t.dw_nomfma = adell_env_int("ADELL_DW_NOMFMA", 0);
   t.dw_wgrad_nomfma = adell_env_int("ADELL_DW_WGRAD_NOMFMA", 0);
-  t.dw_nopersist = adell_env_int("ADELL_DW_NOPERSIST", 0);
-  t.dw_dense16 = adell_env_int("ADELL_DW_DENSE16", 0);
-  t.gemm_nowide = adell_env_int("ADELL_GEMM_NOWIDE", 0);
-  t.gemm_norows = adell_env_int("ADELL_GEMM_NOROWS", 0);
-  t.dw_nozring = adell_env_int("ADELL_DW_NOZRING", 0);
+  t.wgrad_no16 = adell_env_int("ADELL_WGRAD_NO16", 0);
   t.igemm_no16 = adell_env_int("ADELL_IGEMM_NO16", 0);
-  t.zr16_overhead = adell_env_int("ADELL_ZR16_OVERHEAD", 6);
+  t.gemm_norows = adell_env_int("ADELL_GEMM_NOROWS", 0);
 #ifdef ADELL_DEBUG
   t.igemm_dbg = adell_env_int("ADELL_IGEMM_DBG", 0);
   t.zr_dbg = adell_env_int("ADELL_ZR_DBG", 0);
@@ -66,35 +49,20 @@ AdellTuning g_adell_tune = adell_tuning_from_env();
 long g_adell_plan_epoch = 0;
 extern "C" long adell_plan_epoch(void) { return g_adell_plan_epoch; }
 
+// ten switches, each selecting another built path that the parity tests compare with the default
+// (variants that lost their A/B measurements are in the history, not in the library)
 static int* adell_tuning_slot(const char* name) {
   if (!name) return nullptr;
   if (!strcmp(name, "igemm_nospec")) return &g_adell_tune.igemm_nospec;
   if (!strcmp(name, "igemm_no8")) return &g_adell_tune.igemm_no8;
   if (!strcmp(name, "no_splitk")) return &g_adell_tune.no_splitk;
-  if (!strcmp(name, "no_wgrad_tiny")) return &g_adell_tune.no_wgrad_tiny;
   if (!strcmp(name, "wgrad_nozring")) return &g_adell_tune.wgrad_nozring;
-  if (!strcmp(name, "zr_minseg")) return &g_adell_tune.zr_minseg;
-  if (!strcmp(name, "igemm_no2wave")) return &g_adell_tune.igemm_no2wave;
-  if (!strcmp(name, "igemm_oldtile")) return &g_adell_tune.igemm_oldtile;
-  if (!strcmp(name, "igemm_ws")) return &g_adell_tune.igemm_ws;
   if (!strcmp(name, "attn_nomfma")) return &g_adell_tune.attn_nomfma;
-  if (!strcmp(name, "ws_min_items")) return &g_adell_tune.ws_min_items;
-  if (!strcmp(name, "igemm_ws_rows")) return &g_adell_tune.igemm_ws_rows;
-  if (!strcmp(name, "igemm_wide8")) return &g_adell_tune.igemm_wide8;
-  if (!strcmp(name, "ew_reverse")) return &g_adell_tune.ew_reverse;
-  if (!strcmp(name, "fold_coarse")) return &g_adell_tune.fold_coarse;
-  if (!strcmp(name, "wgrad_no16")) return &g_adell_tune.wgrad_no16;
-  if (!strcmp(name, "zr_oldseg")) return &g_adell_tune.zr_oldseg;
-  if (!strcmp(name, "gemm_nosmall")) return &g_adell_tune.gemm_nosmall;
   if (!strcmp(name, "dw_nomfma")) return &g_adell_tune.dw_nomfma;
   if (!strcmp(name, "dw_wgrad_nomfma")) return &g_adell_tune.dw_wgrad_nomfma;
-  if (!strcmp(name, "dw_nopersist")) return &g_adell_tune.dw_nopersist;
-  if (!strcmp(name, "dw_dense16")) return &g_adell_tune.dw_dense16;
-  if (!strcmp(name, "gemm_nowide")) return &g_adell_tune.gemm_nowide;
-  if (!strcmp(name, "gemm_norows")) return &g_adell_tune.gemm_norows;
-  if (!strcmp(name, "dw_nozring")) return &g_adell_tune.dw_nozring;
+  if (!strcmp(name, "wgrad_no16")) return &g_adell_tune.wgrad_no16;
   if (!strcmp(name, "igemm_no16")) return &g_adell_tune.igemm_no16;
-  if (!strcmp(name, "zr16_overhead")) return &g_adell_tune.zr16_overhead;
+  if (!strcmp(name, "gemm_norows")) return &g_adell_tune.gemm_norows;
 #ifdef ADELL_DEBUG
   if (!strcmp(name, "igemm_dbg")) return &g_adell_tune.igemm_dbg;
   if (!strcmp(name, "zr_dbg")) return &g_adell_tune.zr_dbg;

@@ -21,28 +21,18 @@ void adell_set_error(const char* fmt, ...);
 // ADELL_WGRAD_NOZRING, ADELL_ZR_MINSEG, ADELL_IGEMM_WS, ADELL_WS_MIN_ITEMS); afterwards only adell_set_tuning() changes them, so
 // the per-launch host path never calls getenv().
 struct AdellTuning {
-  int igemm_nospec, igemm_no8, no_splitk, no_wgrad_tiny, wgrad_nozring, zr_minseg;
-  int igemm_oldtile;              // low-resolution wide layers: the round-1 tile rule
-  int igemm_no2wave;              // strided / k == stride layers: not the two-wave 64-voxel instance
+  // launch-plan switches that select another BUILT path (the parity tests compare the two sides):
+  int igemm_nospec;               // 3^3 stride-1 convs on the generic f16x3 instance, not the specialised ones
+  int igemm_no8;                  // 32-column layers on 8x8x4 bricks, not the 8x8x8-brick instance
+  int no_splitk;                  // 8^3 .. 16^3 levels without split-K
+  int wgrad_nozring;              // weight gradients on the per-plane kernel, not the z-ring (nor the stride-2 sub-lattice kernel)
   int attn_nomfma;                // attention: vector-ALU kernels even for MFMA-eligible head dims
-  int igemm_ws, ws_min_items;   // persistent wave-specialised conv instance: opt-in / size gate
-  int igemm_ws_rows;              // ... its DMA-only-loader form for launches whose sources are split rows
-  int igemm_wide8;                // 64-column tile of the large 3^3 layers on 8x8x8 bricks, 8 waves
-  int ew_reverse;                 // norm / activation forward: reverse of the producer's write order
-  int fold_coarse;                // split-K fold on one block per brick (the round-2 partition)
-  int dw_nozring;                 // depthwise 7^3: the 4 x 4 tile kernel instead of the z-marching one
-  int gemm_nosmall;               // fp32 GEMM: no streaming kernels for Linear layers with <= 32 features
   int dw_nomfma;                  // depthwise 7^3: vector-ALU kernels only (exact fp32 FMAs) instead of the f16x3 Toeplitz MFMA form
   int dw_wgrad_nomfma;            // depthwise 7^3 weight gradient: vector-ALU tile kernel instead of the MFMA form
-  int dw_nopersist;               // depthwise MFMA forward: one block per work item instead of persistent blocks (A/B)
-  int dw_dense16;                 // dense small-volume depthwise kernel: 16 channels per block when 16 divide C (A/B: slower)
-  int gemm_nowide;                // f16x3 GEMM: scalar epilogue stores from the MFMA layout (no LDS pass)
-  int gemm_norows;                // f16x3 GEMM: never the streaming kernel for many-row Linear layers (gemm_rows.hip)
-  int zr_oldseg;                  // z-ring weight gradient: the round-2 segment rule (units may share out unevenly)
   int wgrad_no16;                 // z-ring weight gradient: 32 x 32 tiles even for 16-channel layers
   int igemm_no16;                 // forward / backward-data of 16 -> 16 layers: not the z-ring 16-column kernel
-  int zr16_overhead;              // ... its segment rule: steps a unit costs besides its planes
-  int igemm_dbg, zr_dbg;   // timing experiments: always 0 unless built with -DADELL_DEBUG
+  int gemm_norows;                // f16x3 GEMM: never the streaming kernel for many-row Linear layers (gemm_rows.hip)
+  int igemm_dbg, zr_dbg;          // timing experiments: always 0 unless built with -DADELL_DEBUG
 };
 extern AdellTuning g_adell_tune;
 // Bumped by every adell_set_tuning / adell_debug_force_conv_cfg that changes the launch plan:

@@ -2,7 +2,6 @@
 // the kernel). Everything here is NDHWC fp32 on raw device pointers.
 #include "conv_igemm.h"
 #include "conv_igemm_f16.h"
-#include "conv_igemm_ws.h"
 
 #ifdef ADELL_DEBUG
 // phase stamps of the f16x3 implicit-GEMM kernel (conv_igemm_f16.h, tools/igemm_stamps.py)
@@ -383,43 +382,6 @@ static int adell_cu_count() {
   return cus;
 }
 
-// 256 zero bytes in device memory (the rows instance of the wave-specialised kernel reads them for
-// halo rows outside the tensor); allocated once per process, never freed
-static const char* adell_zero_page() {
-  static char* page = nullptr;
-  if (page == nullptr) {
-    char* p = nullptr;
-    if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, 256) != hipSuccess) return nullptr;
-    page = p;
-  }
-  return page;
-}
-
-template <int MT, int NT, int BZ, int ROWS = 0>
-static int adell_launch_conv_ws(const ConvArgs& a, ConvF16Extra e, int items, int nct,
-                                hipStream_t st) {
-  static bool attr_done = false;
-  auto kern = adell_conv_igemm_ws_kernel<MT, NT, BZ, ROWS>;
-  if (!attr_done) {
-    ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
-  constexpr int BN = NT * 32, HV = 100 * (BZ + 2), GT = BZ == 8 ? 7 : 9;
-  constexpr size_t A_BYTES = ROWS ? (size_t)((HV + 15) / 16) * 1024 : (size_t)HV * 64;
-  if (ROWS) {
-    e.zeros = adell_zero_page();
-    ADELL_REQUIRE(e.zeros != nullptr, "conv f16x3 (wave-specialised rows): no zero page");
-  }
-  const size_t lds = 2 * A_BYTES + (size_t)2 * GT * BN * 64 + 16 + 8 + (size_t)4 * BN * 2 * 4;
-  int blocks = adell_cu_count() & ~7;   // one block per CU, dealt to the 8 XCDs in equal shares
-  if (blocks < 8) blocks = 8;
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a, e, items, nct);
-  ADELL_CHECK_HIP(hipGetLastError());
-  return ADELL_OK;
-}
-
 // 16 -> 16 channel layers: the z-marching 16-column kernel (conv_zring16.hip)
 extern "C" int adell_conv_zring16_ok(const ConvArgs* a);
 extern "C" void adell_conv_zring16_segments(int N, int Do, int Ho, int Wo, int* seglen, int* nseg);
@@ -428,7 +390,7 @@ extern "C" int adell_conv_zring16_launch(const ConvArgs* a, const ConvF16Extra* 
 
 // Tile plan of the f16x3 kernel: the heuristic brick, or (when its halo does not fit
 // LDS, i.e. stride 2) the small-brick configuration of the same channel width.
-static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, bool no_wide8 = false) {
+static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   ConvTile t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, g_conv_force_cfg);
   if (g_conv_force_cfg < 0 && adell_conv_zring16_ok(&a)) {
     // cfg 8: units = 8 x 8 columns x z segments (ntz = segments, HZ = steps per segment); the
@@ -457,14 +419,13 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, b
   if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.KD == a.SD && a.KH == a.SH && a.KW == a.SW &&
       a.KD * a.KH * a.KW > 1 && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1)
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout,
-                        a.Cout <= 32 && !g_adell_tune.igemm_no2wave ? 6 : 2);
+                        a.Cout <= 32 ? 6 : 2);
   // strided k > stride layers with <= 32 output channels (the 3^3 stride-2 downsampling convs):
   // the halo of a 128-voxel brick is 17 x 9 x 9 voxels = 88 KB, one block per CU, and nothing
   // overlaps its staging (measured 2 x 128^3 -> 64^3, 32 -> 32: 0.73 ms at 40 TF). 64-voxel bricks
   // on two-wave blocks (46 KB halo) keep two to three blocks per CU in different phases.
   else if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.Cout <= 32 &&
-           (a.SD > 1 || a.SH > 1 || a.SW > 1) && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 &&
-           !g_adell_tune.igemm_no2wave)
+           (a.SD > 1 || a.SH > 1 || a.SW > 1) && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1)
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 6);
   // Low-resolution 3x3x3 stride-1 levels with wide outputs (measured with warm clocks,
   // tools/cfg_exp.py, batch 2): the 64-voxel x 64-column bricks of the "small problem" rule make
@@ -472,7 +433,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, b
   // 0.9 GB of weight reads, 214 us); 256-voxel x 32-column bricks + split-K read a quarter of
   // that (139 us). 8^3 levels: 64-voxel x 32-column two-wave bricks (256 -> 256: 89 -> 68 us).
   bool retiled = false;
-  if (g_conv_force_cfg < 0 && !g_adell_tune.igemm_oldtile && a.shuffle == 0 && a.KD == 3 &&
+  if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.KD == 3 &&
       a.KH == 3 && a.KW == 3 && a.SD == 1 && a.SH == 1 && a.SW == 1 && a.UPS == 1 &&
       a.UPSY == 1 && a.UPSZ == 1) {
     const long vox = (long)N * a.Do * a.Ho * a.Wo;
@@ -509,7 +470,7 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, b
     const size_t red = (size_t)8 * t.BN * 2 * sizeof(float);
     if (lds < red) lds = red;
     if (lds <= 160 * 1024) break;
-    const int next = t.BN == 64 ? 2 : (t.cfg == 3 && !g_adell_tune.igemm_no2wave ? 6 : 3);
+    const int next = t.BN == 64 ? 2 : (t.cfg == 3 ? 6 : 3);
     if (t.cfg == next || g_conv_force_cfg >= 0) break;
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, next);
   }
@@ -533,23 +494,6 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out, b
     a.HZ = 10;
     a.VP = a.HX * a.HY * a.HZ;
     lds = (size_t)1000 * 64 + (size_t)7 * 32 * 64 + 64;
-  }
-  // EXPERIMENT ("igemm_wide8", off by default): the same brick for the 64-column tile, eight waves
-  // of 2 x 2 tiles in ONE block per CU (92 KB of LDS): a sixth less halo and half the weight staging
-  // per output, but both waves of a SIMD then meet every barrier together
-  if (t.cfg == 0 && g_adell_tune.igemm_wide8 && !no_wide8 && a.KD == 3 && a.KH == 3 && a.KW == 3 && a.SD == 1 &&
-      a.SH == 1 && a.SW == 1 && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 && a.shuffle == 0 &&
-      a.lTX == 3 && a.lTY == 3 && a.lTZ == 2 && a.Do >= 8 && a.C0 % 16 == 0 && a.C1 % 16 == 0 &&
-      (size_t)a.D * a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) < ((size_t)1 << 30) &&
-      g_conv_force_cfg < 0 && !g_adell_tune.igemm_nospec) {
-    t.cfg = 7;
-    t.BM = 512;
-    t.lTZ = 3;
-    a.lTZ = 3;
-    a.ntz = adell_cdiv(a.Do, 8);
-    a.HZ = 10;
-    a.VP = a.HX * a.HY * a.HZ;
-    lds = (size_t)1000 * 64 + (size_t)7 * 64 * 64 + 64;
   }
   // transposed-conv forward (1 tap, F * Cs columns with a pixel-shuffle store): one block takes a
   // 64-voxel brick and up to 256 columns (cfg 5), so the input brick is staged once instead of
@@ -646,7 +590,6 @@ __global__ __launch_bounds__(256) void adell_conv_splitk_fold_kernel(ConvFoldArg
 // blocks streamed its 4 x 4 MB of slabs at a twentieth of the chip's bandwidth (20-53 us per call,
 // 24 calls per step) -- the fold gets its own, finer partition: ~512 blocks in all.
 static int adell_fold_tiles(long vox, int N, int Cout, long bricks) {
-  if (g_adell_tune.fold_coarse) return (int)bricks;
   const int rstep = 256 / (Cout / 4);          // voxel rows a block covers per pass
   long tiles = adell_cdiv(512, N);
   const long most = adell_cdiv(vox, rstep);
@@ -677,7 +620,7 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
                                    void* ws = nullptr, size_t ws_bytes = 0, int adn = 0) {
   ConvTile t;
   size_t lds;
-  int rc = adell_plan_f16(a, N, &t, &lds, adn == 1 || adn == -1);
+  int rc = adell_plan_f16(a, N, &t, &lds);
   if (rc != ADELL_OK) return adn < 0 ? 0 : rc;
   // (the f16x3 kernel's 16-byte halo loads address a batch item with 32-bit byte offsets)
   a.vecx = (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && (((uintptr_t)a.x0 & 15) == 0) &&
@@ -763,14 +706,6 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
     // split-row sources (rows_ok above): the instance without the fp32 staging path when every
     // source is rows, else the one that decides per source
     const bool all_rows = e.xs0 != nullptr && (a.C1 == 0 || e.xs1 != nullptr);
-    // ("igemm_ws_rows": the persistent wave-specialised instance with DMA-only loaders)
-    if (all_rows && g_adell_tune.igemm_ws_rows && (t.cfg == 0 || t.cfg == 4)) {
-      const int nct = adell_cdiv(a.Cout, t.BN);
-      const long items = (long)N * nsp * nct;
-      if (items >= g_adell_tune.ws_min_items && items < 0x7fffffffL)
-        return t.cfg == 0 ? adell_launch_conv_ws<2, 2, 4, 1>(a, e, (int)items, nct, st)
-                          : adell_launch_conv_ws<4, 1, 8, 1>(a, e, (int)items, nct, st);
-    }
     switch (t.cfg) {
       case 0:
         return all_rows ? adell_launch_conv_f16<2, 2, 4, 1, 1, 0, 2>(a, e, grid, lds, st)
@@ -782,19 +717,6 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
         return all_rows ? adell_launch_conv_f16<2, 1, 4, 1, 1, 0, 2>(a, e, grid, lds, st)
                         : adell_launch_conv_f16<2, 1, 4, 1, 1, 0, 1>(a, e, grid, lds, st);
     }
-  }
-  // large 3x3x3 stride-1 layers, opt-in ("igemm_ws"): the persistent wave-specialised instance
-  // (conv_igemm_ws.h), one block per CU walking >= ws_min_items / CUs bricks. Measured on MI355X
-  // (round 2): +5-9 % over the one-brick-per-block instances when a layer is timed alone
-  // (64->64 @ 2 x 128^3: 2.62 vs 2.87 ms), -3 % inside the training step (41.0 vs 39.9 ms), where
-  // the chip holds a lower clock under the denser MFMA issue; not the default.
-  if (shares == 1 && g_adell_tune.igemm_ws && a.Cin % 16 == 0 && e.xs0 == nullptr &&
-      e.xs1 == nullptr && ((t.cfg == 0 && spec) || t.cfg == 4)) {
-    const int nct = adell_cdiv(a.Cout, t.BN);
-    const long items = (long)N * nsp * nct;
-    if (items >= g_adell_tune.ws_min_items && items < 0x7fffffffL)
-      return t.cfg == 0 ? adell_launch_conv_ws<2, 2, 4>(a, e, (int)items, nct, st)
-                        : adell_launch_conv_ws<4, 1, 8>(a, e, (int)items, nct, st);
   }
   switch (t.cfg) {
     case 0:
@@ -810,13 +732,6 @@ static int adell_conv_dispatch_f16(ConvArgs a, ConvF16Extra e, int N, hipStream_
         return ADELL_E_BADARG;
       }
       rc2 = adell_launch_conv_f16<4, 1, 4, 1, 3>(a, e, grid, lds, st);
-      break;
-    case 7:   // experiment: 8x8x8 bricks x 64 columns, eight waves (adell_plan_f16)
-      if (!a.vecx) {
-        adell_set_error("conv f16x3: input pointers must be 16-byte aligned");
-        return ADELL_E_BADARG;
-      }
-      rc2 = adell_launch_conv_f16<2, 2, 8, 1, 3>(a, e, grid, lds, st);
       break;
     case 1:
       rc2 = spec ? adell_launch_conv_f16<2, 1, 4, 1, 1>(a, e, grid, lds, st)
@@ -1159,16 +1074,6 @@ extern "C" int adell_conv3d_bwd_data_f16x3(const adell_conv3d_desc* d, const flo
   return adell_conv_dispatch_f16(a, e, d->N, (hipStream_t)stream);
 }
 
-#ifdef ADELL_WS_CENSUS
-// census builds only: read and clear the role cycle census of the wave-specialised conv kernel
-extern "C" int adell_debug_ws_prof(unsigned long long* out) {
-  ADELL_CHECK_HIP(hipDeviceSynchronize());
-  ADELL_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ws_prof), 16 * sizeof(unsigned long long)));
-  unsigned long long z[16] = {0};
-  ADELL_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_prof), z, sizeof(z)));
-  return ADELL_OK;
-}
-#endif
 
 // ---------------------------------------------------------------------------
 // Split-row sources (round 4): the forward of a 3x3x3 stride-1 layer whose input(s) the producer

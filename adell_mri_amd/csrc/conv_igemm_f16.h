@@ -58,7 +58,6 @@ struct ConvF16Extra {
   const char* xs1;
   const int* xk0;
   const int* xk1;
-  const char* zeros;     // >= 64 zero bytes (wave-specialised rows instance: halo rows outside the tensor)
   // Backward of a norm -> dropout -> activation site fused into this (backward-data) launch
   // (EPI = 1 instances): destination d (0: columns [0, ysplit), 1: the rest) is the gradient with
   // respect to the OUTPUT of such a site whose pre-norm input is adn[d].y (same shape as the

@@ -311,8 +311,7 @@ static void adell_wgrad_tiny_launch(const WgSmallArgs& a, int blocks, int nbrick
 }
 
 static bool adell_wgrad_tiny_ok(const adell_conv3d_desc* d) {
-  return d->C1 == 0 && d->C0 <= 2 && d->Cout <= 2 && d->KD == 3 && d->KH == 3 && d->KW == 3 &&
-         !g_adell_tune.no_wgrad_tiny;
+  return d->C1 == 0 && d->C0 <= 2 && d->Cout <= 2 && d->KD == 3 && d->KH == 3 && d->KW == 3;
 }
 
 static bool adell_wgrad_small_ok(const adell_conv3d_desc* d) {

@@ -632,20 +632,16 @@ extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1
   // two (three: the 16-channel form) blocks per CU over all channel tiles
   long target = (p->t16 ? 768 : 512) / chan_blocks;
   if (target < 8) target = 8;
-  // z segments: at least `zr_minseg` steps each (2 priming planes), enough units to fill the target,
+  // z segments: at least 4 steps each (2 priming planes), enough units to fill the target,
   // and -- round 4 -- a unit count the blocks share out evenly: units are dealt round-robin, so the
   // launch lasts ceil(units / blocks) units of (seglen + priming) steps. 4 x 96^3 has 576 columns:
   // as 576 units on 512 blocks an eighth of the blocks ran two whole columns while the rest idled
   // (makespan 2 x 98 steps; 8 segments: 9 x 14). Columns that fill the target exactly (2 x 128^3:
   // 512) keep one segment.
-  const int minseg = g_adell_tune.zr_minseg;
+  const int minseg = 4;
   const long maxseg = Do / minseg > 0 ? Do / minseg : 1;
   long nseg = 1;
-  if (g_adell_tune.zr_oldseg) {
-    nseg = (target + ncols - 1) / ncols;
-    if (nseg > maxseg) nseg = maxseg;
-    if (nseg < 1) nseg = 1;
-  } else {
+  {
     long best = -1;
     for (long cand = 1; cand <= maxseg; ++cand) {
       const long sl = adell_cdiv(Do, (int)cand), ns = adell_cdiv(Do, (int)sl);

@@ -332,7 +332,7 @@ extern "C" void adell_conv_zring16_segments(int N, int Do, int Ho, int Wo, int* 
     if (ns != cand) continue;
     const long units = ncols * ns;
     const long blocks = units < target ? units : target;
-    const long cost = adell_cdiv((int)units, (int)blocks) * (sl + g_adell_tune.zr16_overhead);
+    const long cost = adell_cdiv((int)units, (int)blocks) * (sl + 6);   // 6: steps a unit costs besides its planes (priming, epilogue)
     if (best < 0 || cost < best) { best = cost; pick = cand; }
   }
   *seglen = adell_cdiv(Do, (int)pick);

@@ -242,6 +242,5 @@ extern "C" int adell_dw_dense_launch(const float* x, const float* w, const float
   DwDenseArgs a = {x, w, b, y, N, C, D, H, W, flip};
   // (16 channels per block quarter the line requests but leave 96 blocks of 1 024 threads for 256 CUs at
   // ConvNeXt's 64 crops x 384 channels: 30.4 us against 24.4 -- A/B switch only)
-  if (C % 16 == 0 && g_adell_tune.dw_dense16) return adell_dw_dense_go<16>(a, (hipStream_t)stream);
   return adell_dw_dense_go<4>(a, (hipStream_t)stream);
 }

@@ -369,7 +369,7 @@ extern "C" int adell_dw_mfma_launch(const float* x, const float* w, const float*
       ADELL_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
       cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const int grid = total < cus || g_adell_tune.dw_nopersist ? (int)total : cus;
+    const int grid = total < cus ? (int)total : cus;
     hipLaunchKernelGGL(adell_dw_mfma_kernel<true>, dim3(grid), dim3(256), DM_LDS, (hipStream_t)stream, a);
   } else {
     hipLaunchKernelGGL(adell_dw_mfma_kernel<false>, dim3((unsigned)total), dim3(256), DM_LDS,

@@ -386,11 +386,10 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   ADELL_REQUIRE(lda >= (a_kc ? K : M) && ldb >= (b_kc ? K : N) && ldc >= N, "gemm: bad strides");
   ADELL_REQUIRE(!residual || ldr >= N, "gemm: bad residual stride");
   const GemmPlan p = adell_gemm_plan(M, N, K);
-  const int tall = (!a_kc && !b_kc && !g_adell_tune.gemm_nosmall) ? adell_gemm_tall_blocks(M, N, K) : 0;
+  const int tall = (!a_kc && !b_kc) ? adell_gemm_tall_blocks(M, N, K) : 0;
   // (measured on SWIN-UNet's shapes: 10x / 5x for 8 -> 2 / 2 -> 8 features at 8.4 M rows; from
   // N K = 256 on the MFMA tiles are as fast or faster, 32 x 8 at 2 M rows 180 vs 250 us)
-  const bool rows_small = a_kc && K <= GEMM_SMALL && N <= GEMM_SMALL && (long)N * K <= 64 && M >= 65536 &&
-                          !g_adell_tune.gemm_nosmall;
+  const bool rows_small = a_kc && K <= GEMM_SMALL && N <= GEMM_SMALL && (long)N * K <= 64 && M >= 65536;
   ADELL_REQUIRE(rows_small || (tall ? workspace != nullptr : (p.splits == 1 || workspace)),
                 "gemm: workspace required for this shape");
   GemmArgs a;

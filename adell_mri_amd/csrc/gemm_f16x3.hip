@@ -667,7 +667,7 @@ static int gemm_h_run(int M, int N, int K, const float* A, long lda, int a_kc,
   int rc;
   const bool wide = N % 4 == 0 && ldc % 4 == 0 && (!residual || ldr % 4 == 0) &&
                     ((((uintptr_t)C) | ((uintptr_t)bias) | ((uintptr_t)residual) |
-                      ((uintptr_t)workspace)) & 15) == 0 && (epi || !g_adell_tune.gemm_nowide);
+                      ((uintptr_t)workspace)) & 15) == 0;
   ADELL_REQUIRE(wide || !epi, "gemm_f16x3_act: operands do not qualify for the wide epilogue");
   if (wide) {
     if (a_kc && b_kc)

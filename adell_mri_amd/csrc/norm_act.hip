@@ -426,7 +426,7 @@ static int adell_na_fill(NormActArgs* a, const adell_norm_act_desc* d) {
   a->seed_lo = (uint32_t)(d->seed & 0xffffffffu);
   a->seed_hi = (uint32_t)(d->seed >> 32);
   a->rng_offset = d->rng_offset;
-  a->rev = g_adell_tune.ew_reverse;
+  a->rev = 0;
   return ADELL_OK;
 }
 

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void adell_dw_zring_kernel(DwZrArgs a) {
 
 // 1 when the z-marching kernel takes the problem; fills the launch geometry
 static int adell_dw_zring_plan(int N, int C, int D, int H, int W, int KD, int KH, int KW, DwZrArgs* z) {
-  if (KD != 7 || KH != 7 || KW != 7 || W > DZ_WT || W <= 8 || D < 4 || g_adell_tune.dw_nozring) return 0;
+  if (KD != 7 || KH != 7 || KW != 7 || W > DZ_WT || W <= 8 || D < 4) return 0;
   z->N = N; z->C = C; z->D = D; z->H = H; z->W = W;
   z->tilesY = adell_cdiv(H, DZ_TY);
   z->chanBlocks = adell_cdiv(C, 16);

@@ -1683,7 +1683,8 @@ def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, out=None, bias=None, residual=None
         check(_lib.lib().adell_gemm_f32(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb, int(b_kc),
                                         _ptr(out), N, _ptr(bias), _ptr(residual), ldr, _ptr(ws),
                                         _stream()))
-    _timed("adell_gemm_f32_kernel", 2.0 * M * N * K, run)
+    _timed("adell_gemm_f32_kernel", 2.0 * M * N * K, run, None,
+           4.0 * (M * K + K * N + M * N * (2 if residual is not None else 1)))
     return out
 
 
@@ -1723,8 +1724,10 @@ def gemm_f16x3(M, N, K, A, lda, a_kc, B, ldb, b_kc, a_amax=None, b_amax=None, ou
         check(_lib.lib().adell_gemm_f16x3(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb, int(b_kc),
                                           _ptr(out), N, _ptr(bias), _ptr(residual), ldr,
                                           _ptr(a_amax), _ptr(b_amax), _ptr(ws), _stream()))
+    # algorithmic bytes: each operand and the output once (+ the residual)
     _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run,
-           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'}")
+           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'}",
+           4.0 * (M * K + K * N + M * N * (2 if residual is not None else 1)))
     return out
 
 
@@ -1745,8 +1748,10 @@ def gemm_f16x3_act(M, N, K, A, lda, a_kc, B, ldb, b_kc, act, act_p=0.0, bias=Non
                                               int(b_kc), _ptr(out), N, _ptr(bias), _ptr(residual),
                                               ldr, None, None, _ptr(ws), _lib.ACT_IDS[act],
                                               float(act_p), _ptr(act_out), _ptr(dact_in), _stream()))
+    extra = (1 if residual is not None else 0) + (1 if want_act else 0) + (1 if dact_in is not None else 0)
     _timed("adell_gemm_f16x3_kernel", 2.0 * M * N * K, run,
-           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'} act")
+           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'} act",
+           4.0 * (M * K + K * N + M * N * (1 + extra)))
     return out, act_out
 
 

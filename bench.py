@@ -97,6 +97,30 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def roofline_entry(name, flops, ms, launches, nbytes):
+    """The roofline object of one kernel family: the bound is the side of the ridge its arithmetic
+    intensity (algorithmic FLOPs / algorithmic bytes over the family's launches) falls on --
+    f16x3 MFMA: 833 TFLOP/s / 8 TB/s = 104 FLOP/B, fp32 MFMA: 157.3 / 8 = 20 FLOP/B -- and
+    `achieved` / `peak` / `frac` are quoted against THAT ceiling."""
+    f16 = "f16" in name
+    peak_tf = F16X3_ALGORITHMIC_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
+    ridge = peak_tf / HBM_PEAK_TBS                    # FLOP per byte
+    tf = flops / (ms * 1e-3) / 1e12
+    out = {"kernel": name, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+           "arithmetic_intensity": None if not nbytes else flops / nbytes,
+           "ridge_flop_per_byte": ridge, "mfma_tflops": tf, "mfma_frac": tf / peak_tf,
+           "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product" if f16
+                          else "fp32 matrix peak")}
+    if nbytes and flops / nbytes < ridge:
+        tbs = nbytes / (ms * 1e-3) / 1e12
+        out.update({"bound": "hbm", "achieved": tbs * 1e3, "peak": HBM_PEAK_TBS * 1e3,
+                    "unit": "GB/s", "frac": tbs / HBM_PEAK_TBS})
+    else:
+        out.update({"bound": "mfma", "achieved": tf, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": tf / peak_tf})
+    return out
+
+
 def _shape(size):
     return (size, size, size) if isinstance(size, int) else tuple(size)
 
@@ -121,6 +145,35 @@ def build_module(device, config=CONFIG):
         res_config_file=None, deep_supervision=False, n_classes=2, keys=KEYS,
         optimizer_str="sgd")
     return net.to(device), loss_keys
+
+
+def build_cfg2b(device=None, config=CONFIG):
+    """BASELINE config 2b: the same YAML with the ResNet of configs/ssl-resnet.yaml (the reference's
+    sample_configs/ssl-resnet.yaml) as encoder -- `--res_config_file`, assembled as
+    entrypoints/segmentation/train.py:672-734 does: parse_config_ssl -> ResNet -> depth / strides
+    from the backbone, stem / stages / pools as encoding_operations (utils/handoff.py) ->
+    get_segmentation_network. 41.8 M parameters, 7.3 TFLOP forward per 128^3 volume; the padded
+    max-pools give odd 65^3 / 33x33x65 / 17x17x65 / 9x9x33 maps, so crop_to_size runs in every
+    decoder level."""
+    import torch
+
+    from adell_mri_amd.modules.config_parsing import parse_config_ssl, parse_config_unet
+    from adell_mri_amd.utils.handoff import unet_encoder_from_ssl
+    from adell_mri_amd.utils.network_factories import get_segmentation_network
+
+    res_config = os.path.join(ROOT, "configs", "ssl-resnet.yaml")
+    cfg, loss_keys = parse_config_unet(config, len(KEYS), 2)
+    _, cfg_ssl = parse_config_ssl(res_config, 0.0, len(KEYS))
+    torch.manual_seed(0)
+    cfg, enc, _ = unet_encoder_from_ssl(cfg, cfg_ssl)
+    net = get_segmentation_network(
+        net_type="unet", network_config=cfg, bottleneck_classification=False,
+        clinical_feature_keys=[], all_aux_keys=[], clinical_feature_params=None,
+        clinical_feature_key_net=None, aux_key_net=None, max_epochs=100,
+        encoding_operations=enc, picai_eval=False, lr_encoder=None, encoder_checkpoint=None,
+        res_config_file=res_config, deep_supervision=False, n_classes=2, keys=KEYS,
+        optimizer_str="sgd")
+    return (net if device is None else net.to(device)), loss_keys
 
 
 def synthetic_batch(batch, size, device, seed):
@@ -336,6 +389,12 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
         y = (torch.rand((n, 1, *size), generator=g) > 0.9).float().to(device)
         return {"image": x, "mask": y}
 
+    def build_cfg2b_entry():
+        net, _ = build_cfg2b()
+        return net, seg_batch(1, 2, (128, 128, 128), 242 + rank), 1, "volumes/s", \
+            "BASELINE config 2b: u-net-3d-resnet.yaml + --res_config_file ssl-resnet.yaml (ResNet-backbone " \
+            "encoder, 41.8 M parameters, odd 65^3 .. 9x9x33 maps), UNetPL, 2x128^3, batch 1/GPU"
+
     def build_cfg3():
         net = seg("unetr", "unetr.yaml", ["image"], [96, 96, 96], patch=[16, 16, 16])
         return net, seg_batch(4, 1, (96, 96, 96), 342 + rank), 4, "volumes/s", \
@@ -363,7 +422,8 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             "BASELINE configs[4]: unet-swin.yaml SWINUNetPL, 2x256x256x128, batch 1/GPU"
 
     out = {}
-    for key, build in (("cfg3_unetr_96", build_cfg3), ("cfg4_vicreg_convnext_64", build_cfg4),
+    for key, build in (("cfg2b_resnet_backbone_128", build_cfg2b_entry),
+                       ("cfg3_unetr_96", build_cfg3), ("cfg4_vicreg_convnext_64", build_cfg4),
                        ("cfg5_swinunet_256x256x128", build_cfg5)):
         try:
             net, batch, units, unit, workload = build()
@@ -392,18 +452,11 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             dom = timer.dominant()
             if dom is not None:
                 name, flops, ms, launches = dom
-                f16 = "f16" in name
-                peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if f16 else FP32_MFMA_PEAK_TFLOPS
-                ach = flops / (ms * 1e-3) / 1e12
                 summ = timer.summary()
-                entry["roofline"] = {
-                    "bound": "mfma", "kernel": name, "achieved": ach, "peak": peak,
-                    "unit": "TFLOP/s", "frac": ach / peak, "launches": launches,
-                    "avg_launch_ms": ms / launches,
-                    "kernel_time_share_of_step": ms / (1e3 * dt / 5),
-                    "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product" if f16
-                                   else "fp32 matrix peak"),
-                    "families_ms_per_step": {k: round(v["ms"], 3) for k, v in summ.items()}}
+                roof = roofline_entry(name, flops, ms, launches, summ[name]["algorithmic_bytes"])
+                roof["kernel_time_share_of_step"] = ms / (1e3 * dt / 5)
+                roof["families_ms_per_step"] = {k: round(v["ms"], 3) for k, v in summ.items()}
+                entry["roofline"] = roof
             out[key] = entry
             del runner, opt, net, batch
         except Exception as exc:      # a secondary workload must not take the headline line down
@@ -565,11 +618,8 @@ def main():
             sdom = stimer.dominant()
             if sdom is not None:
                 sname, sflops, sms, slaunches = sdom
-                speak = (F16X3_ALGORITHMIC_PEAK_TFLOPS if "f16" in sname else FP32_MFMA_PEAK_TFLOPS)
-                sec["roofline"] = {"bound": "mfma", "kernel": sname,
-                                   "achieved": sflops / (sms * 1e-3) / 1e12, "peak": speak,
-                                   "unit": "TFLOP/s", "frac": sflops / (sms * 1e-3) / 1e12 / speak,
-                                   "launches": slaunches, "avg_launch_ms": sms / slaunches}
+                sec["roofline"] = roofline_entry(sname, sflops, sms, slaunches,
+                                                 stimer.summary()[sname]["algorithmic_bytes"])
             secondary[key] = sec
             del sb
         torch.cuda.empty_cache()
@@ -633,26 +683,22 @@ def main():
     dom = timer.dominant()
     if dom is not None:
         name, flops, ms, launches = dom
-        achieved = flops / (ms * 1e-3) / 1e12
         kf16 = "f16" in name
         peak = F16X3_ALGORITHMIC_PEAK_TFLOPS if kf16 else FP32_MFMA_PEAK_TFLOPS
         traffic = pmc_traffic(name, workload)
-        roof = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": peak,
-                "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": None if traffic is None else traffic[0],
-                "traffic_source": None if traffic is None else
-                f"offline rocprofv3 PMC passes of this workload (profiles/{traffic[1]}): mean bytes "
-                f"per launch, 2*FETCH_SIZE + WRITE_SIZE",
-                "algorithmic_bytes_per_launch":
-                    timer.summary()[name]["algorithmic_bytes"] / launches,
-                "peak_basis": ("2.5 PFLOP/s dense f16 MFMA / 3 MFMAs per fp32 product"
-                               if kf16 else "fp32 matrix peak"),
-                "executed_mfma_tflops": achieved * (3.0 if kf16 else 1.0),
-                "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
-                "launches": launches, "avg_launch_ms": ms / launches,
-                "event_timed_steps": f"{sampled} of the {args.steps} timed steps (every "
-                                     f"{every}{'st' if every == 1 else 'th'})",
-                "kernel_time_share": timer.share(name, 1e3 * dt * sampled / args.steps)}
+        roof = roofline_entry(name, flops, ms, launches, timer.summary()[name]["algorithmic_bytes"])
+        achieved = roof["mfma_tflops"]
+        roof.update({
+            "traffic": None if traffic is None else traffic[0],
+            "traffic_source": None if traffic is None else
+            f"offline rocprofv3 PMC passes of this workload (profiles/{traffic[1]}): mean bytes "
+            f"per launch, 2*FETCH_SIZE + WRITE_SIZE",
+            "algorithmic_bytes_per_launch": timer.summary()[name]["algorithmic_bytes"] / launches,
+            "executed_mfma_tflops": achieved * (3.0 if kf16 else 1.0),
+            "fp32_mfma_peak": FP32_MFMA_PEAK_TFLOPS,
+            "event_timed_steps": f"{sampled} of the {args.steps} timed steps (every "
+                                 f"{every}{'st' if every == 1 else 'th'})",
+            "kernel_time_share": timer.share(name, 1e3 * dt * sampled / args.steps)})
         # whole step: algorithmic FLOPs of every instrumented MFMA / conv family (from the
         # warm-up census, per step) over the measured step time, against the same ceiling
         if args.warmup > 0:

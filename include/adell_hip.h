@@ -27,6 +27,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header
+ * are exported (their definitions inherit the visibility of these declarations). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define ADELL_OK 0
 #define ADELL_E_BADARG (-1)
@@ -849,15 +854,15 @@ int adell_channel_max_bwd(const float* dout, const int* arg, float* dx, int N, l
 /* test hook: force one conv tile configuration (0..3), -1 = heuristic */
 void adell_debug_force_conv_cfg(int cfg);
 
-/* Launch-plan switches for A/B tests of kernel instances: "igemm_nospec", "igemm_no8",
- * "igemm_no2wave" (strided layers back on the four-wave bricks), "igemm_oldtile" (low-resolution
- * wide layers back on 64 x 64 bricks), "no_splitk", "no_wgrad_tiny", "wgrad_nozring", "igemm_ws" (0 / 1; the last one opts INTO the
- * persistent wave-specialised conv instance for layers of >= "ws_min_items" bricks) and
- * "zr_minseg" (planes). Initialised
- * once at load from the environment variables of the same names (ADELL_ prefix, upper case);
- * the launch path itself never reads the environment. The kernel timing experiments
- * ("igemm_dbg", "zr_dbg": results become WRONG) exist only in -DADELL_DEBUG builds of the
- * library. adell_set_tuning returns ADELL_E_BADARG for an unknown name; adell_get_tuning -1. */
+/* Launch-plan switches (ten): each selects another BUILT path that the parity tests compare with
+ * the default -- "igemm_nospec" (3^3 convs on the generic f16x3 instance), "igemm_no8" (no 8x8x8
+ * bricks), "no_splitk", "wgrad_nozring", "wgrad_no16", "igemm_no16" (16-channel layers off their
+ * 16-column kernels), "attn_nomfma", "dw_nomfma", "dw_wgrad_nomfma" (depthwise 7^3 on the
+ * vector-ALU kernels), "gemm_norows" (Linear layers never on the streaming GEMM). Initialised once
+ * at load from the environment variables of the same names (ADELL_ prefix, upper case); the launch
+ * path itself never reads the environment. The kernel timing experiments ("igemm_dbg", "zr_dbg":
+ * results become WRONG) exist only in -DADELL_DEBUG builds of the library. adell_set_tuning
+ * returns ADELL_E_BADARG for an unknown name; adell_get_tuning -1. */
 int adell_set_tuning(const char* name, int value);
 int adell_get_tuning(const char* name);
 
@@ -899,10 +904,26 @@ int adell_bias_field(const float* x, float* out, int N, int D, int H, int W, int
                      const float* coef, void* stream);
 int adell_axis_lut_sample(const float* x, float* out, int N, int D, int H, int W, int C,
                           const float* lut, int linear, void* stream);
+/* ------------------------------------------------------------------------
+ * Dispatch queries of the depthwise 7^3 kernels (csrc/dw_mfma.hip, dw_dense.hip, dw_wgrad_mfma.hip):
+ * 1 when adell_dwconv3d_fwd / _bwd_data / _bwd_weight run this problem on the f16x3 MFMA forms
+ * (planes of 9 .. 16 rows and columns, channels in fours, 16-byte aligned tensors, the "dw_nomfma" /
+ * "dw_wgrad_nomfma" switches off), resp. on the dense small-volume form (volumes of <= 4^3 voxels).
+ * x / y: the two tensors of the launch (alignment is part of the answer). */
+int adell_dw_mfma_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW, const float* x,
+                     const float* y);
+int adell_dw_dense_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW, const float* x,
+                      const float* y);
+int adell_dw_wgrad_mfma_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW, const float* x,
+                           const float* dy);
+
 long adell_gibbs_workspace(int N, int D, int H, int W, int C);
 int adell_gibbs_lowpass(const float* x, float* out, int N, int D, int H, int W, int C,
                         const float* radius, void* workspace, size_t workspace_bytes, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

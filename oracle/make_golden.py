@@ -611,6 +611,18 @@ FULL_CASES = {
     # north_star's 256x256x128 variant: forward only (the eager reference's backward at this
     # size did not finish in 15 minutes / 2 CPU-hours in the build container and was stopped)
     "unet3d_cfg2_full_256x256x128": (FULL_CFG2, (1, 2, 256, 256, 128), False),
+    # BASELINE config 2b (SURVEY.md 8(a) row a12, 8(d) "measure it second"): the same YAML with the
+    # ResNet of sample_configs/ssl-resnet.yaml:5-6 as encoder, assembled as
+    # entrypoints/segmentation/train.py:672-734 does (make_backbone_unet): 41.8 M parameters, odd
+    # 65^3 / 33x33x65 / 17x17x65 / 9x9x33 maps from the padded max-pools, crop_to_size live in every
+    # decoder level; logits, loss and every parameter gradient at 1 x 2 x 128^3
+    "unet3d_cfg2b_full": (dict({k: v for k, v in FULL_CFG2.items()
+                                if k not in ("depth", "kernel_sizes", "strides")},
+                               _cls="backbone",
+                               _structure=[[64, 64, 5, 2], [128, 128, 3, 2], [256, 256, 3, 2],
+                                           [512, 512, 3, 2]],
+                               _maxpool=[[2, 2, 1], [2, 2, 1], [2, 2, 2], [2, 2, 2]]),
+                          (1, 2, 128, 128, 128), True),
 }
 from oracle.fullsize import FULL_SEED, full_inputs, sample_positions, zlib_crc  # noqa: E402
 

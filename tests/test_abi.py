@@ -30,6 +30,17 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in adell_hip.h but not exported: {missing}"
 
 
+def test_library_exports_nothing_but_the_declared_symbols():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table of the library is the header,
+    no internal helper, no kernel stub (nm -D minus header = empty)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True,
+                         check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.strip()})
+    assert exported == _declared_symbols(), sorted(set(exported) ^ set(_declared_symbols()))
+
+
 def test_binding_table_matches_header():
     assert sorted(_lib.SIGNATURES) == _declared_symbols()
 

@@ -123,7 +123,6 @@ def test_weight_and_bias_gradient_against_fp64(cuda, N, C, size, scale):
 
 
 @pytest.mark.parametrize("N,C,size", [(64, 8, (4, 4, 4)), (5, 12, (4, 4, 4)), (17, 4, (3, 4, 2)), (33, 8, (4, 2, 4)),
-                                      # (also run on the 16-channels-per-block form)
                                       (40, 32, (4, 4, 4)), (3, 16, (3, 3, 4))])
 @pytest.mark.parametrize("scale", [1.0, 2e4, 3e-5])
 def test_small_volumes_as_a_dense_matrix(cuda, N, C, size, scale):
@@ -150,9 +149,6 @@ def test_small_volumes_as_a_dense_matrix(cuda, N, C, size, scale):
         old_y, old_dx = ops.dwconv3d_fwd(xd, wd, bd), ops.dwconv3d_bwd_data(dyd, wd)
     assert _rel(got_y, old_y) < 2e-6 and _rel(got_dx, old_dx) < 2e-6
     assert torch.equal(got_y, ops.dwconv3d_fwd(xd, wd, bd))
-    if C % 16 == 0:      # the 16-channel blocks (A/B form) compute the same sums in the same order
-        with _lib.tuning(dw_dense16=1):
-            assert torch.equal(got_y, ops.dwconv3d_fwd(xd, wd, bd))
     # 2^3 and 5 x 4 x 4 volumes are not this kernel's
     p = xd.data_ptr()
     assert not _lib.lib().adell_dw_dense_ok(N, C, 2, 2, 2, 7, 7, 7, p, p)

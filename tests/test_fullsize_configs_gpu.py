@@ -257,3 +257,31 @@ def test_config4_convnext_values_match_reference(cuda):
                                rtol=2e-3, atol=1e-6)
     sum(losses).backward()
     _check_grads(g, net, "cfg4 ConvNeXt 64^3", norm_bar=5e-3, entry_bar=5e-3)
+
+
+def test_config2b_resnet_backbone_values_match_reference(cuda):
+    """BASELINE config 2b at 1 x 2 x 128^3 ("measure it second"): the U-Net with the
+    ResNet-backbone encoder, built through the factory path the entrypoint takes (bench.build_cfg2b:
+    parse_config_ssl -> handoff -> get_segmentation_network), against tests/golden/unet3d_cfg2b_full.npz
+    (`python oracle/make_golden.py full unet3d_cfg2b_full`: the REAL reference classes assembled as
+    train.py:672-734 assembles them): logits within 1e-4 of the logit range on the odd-sized maps whose
+    crop_to_size path is live (65^3 / 33x33x65 / 17x17x65 / 9x9x33), loss, every parameter gradient."""
+    import bench
+
+    g = np.load(os.path.join(GOLD, "unet3d_cfg2b_full.npz"))
+    shape = tuple(int(v) for v in g["shape"])
+    x, y = full_inputs(shape, int(g["seed"]))
+    assert abs(float(x.double().sum()) - g["x_checksum"][0]) < 1e-6 * g["x_checksum"][0]
+    net, _ = bench.build_cfg2b()
+    assert sum(p.numel() for p in net.parameters()) == 41819841           # BASELINE.md section 2
+    net.load_state_dict(fill_state_dict(net.state_dict()))
+    assert [k for k, _ in net.named_parameters()] == [str(k) for k in g["param_keys"]]
+    net = net.to(cuda).eval()
+    logits = net(x.to(cuda), return_logits=True)[0]
+    _check_logits(g, logits, "cfg2b ResNet-backbone U-Net 128^3")
+    from oracle.torch_ref.unet import compound_loss
+    prob = net(x.to(cuda))[0]
+    loss = compound_loss(prob, y.to(cuda))
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4)
+    loss.backward()
+    _check_grads(g, net, "cfg2b ResNet-backbone U-Net 128^3")

@@ -18,13 +18,6 @@ import resource_usage as ru  # noqa: E402
 
 # substring of the demangled name -> (bytes per lane allowed, why it is outside the step)
 ALLOWED = {
-    # (opt-in wave-specialised instances, igemm_ws / igemm_ws_rows. The scratch is a per-lane table
-    # written once in the prologue and read in the ragged-brick epilogue; no scratch access sits in
-    # the MFMA loops -- checked in the ISA)
-    "adell_conv_igemm_ws_kernel<2, 2, 4, 0>": (356, "opt-in wave-specialised experiment (igemm_ws)"),
-    "adell_conv_igemm_ws_kernel<4, 1, 8, 0>": (672, "opt-in wave-specialised experiment (igemm_ws)"),
-    "adell_conv_igemm_ws_kernel<2, 2, 4, 1>": (356, "opt-in wave-specialised rows instance (igemm_ws_rows)"),
-    "adell_conv_igemm_ws_kernel<4, 1, 8, 1>": (672, "opt-in wave-specialised rows instance (igemm_ws_rows)"),
     "adell_conv_igemm_f16_kernel<4, 1, 4, 1, 3, 0, 1>": (
         12, "split rows in ONE half of a concat on a 32-column tile: no BASELINE config"),
     "adell_cinfold_wgrad_kernel<3>": (340, "3-channel inputs: no BASELINE config"),

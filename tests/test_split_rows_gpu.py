@@ -268,35 +268,3 @@ def test_a_forward_hook_never_sees_split_rows(cuda, monkeypatch, where):
     made.clear()
     net(x, return_logits=True)
     assert sum(e is not None for e in made) == plain_rows
-
-
-@pytest.mark.parametrize("N,C0,C1,Cout,size", [
-    (2, 32, 0, 32, (64, 64, 64)),      # 8x8x8 bricks, two chunks
-    (1, 64, 0, 32, (76, 44, 68)),      # ragged bricks, four chunks, faces outside the tensor
-    (2, 64, 0, 64, (32, 32, 32)),      # 64-column tile (8x8x4 bricks)
-    (1, 32, 32, 64, (48, 48, 44)),     # two row sources
-    (2, 16, 0, 16, (32, 32, 32)),      # one chunk per item
-])
-def test_wave_specialised_rows_instance_equals_the_block_instance(cuda, N, C0, C1, Cout, size):
-    """igemm_ws_rows: the persistent wave-specialised instance whose loaders only issue LDS-DMA (halo
-    rows and weights; rows outside the tensor read a zero page). Same MFMA stream, same epilogue:
-    bit-identical outputs and statistics to the one-brick-per-block rows instance."""
-    from adell_mri_amd import _lib, ops
-
-    if not ops.conv3d_rows_ok(N, size, C0, C1, Cout, 3, 1, 1):
-        pytest.skip("this shape's launch plan does not stage rows")
-    x0, x1, w, b = _operands(cuda, N, C0, C1, Cout, size, 7)
-    wp = ops.pack_weight_f16x3(w, 0)
-    r0, s0 = ops.rows_from_f32(x0, 9)
-    r1 = s1 = None
-    if x1 is not None:
-        r1, s1 = ops.rows_from_f32(x1, 10)
-    res = torch.randn(N, Cout, *size, device=cuda)
-    y_ref, part_ref = ops.conv3d_fwd(r0, wp, b, Cout, 3, 1, 1, x1=r1, residual=res,
-                                     want_stats=True, rows0=s0, rows1=s1)
-    with _lib.tuning(igemm_ws_rows=1, ws_min_items=1):
-        y, part = ops.conv3d_fwd(r0, wp, b, Cout, 3, 1, 1, x1=r1, residual=res, want_stats=True,
-                                 rows0=s0, rows1=s1)
-    torch.cuda.synchronize()
-    assert torch.equal(y, y_ref)
-    assert torch.equal(part, part_ref)

@@ -39,17 +39,5 @@ for N, C, D, H, W in shapes:
             torch.cuda.synchronize()
             wres[nomfma] = e0.elapsed_time(e1) / 20 * 1e3
     print(f"{(N, C, D, H, W)}: weight gradient MFMA {wres[0]:7.1f} us   vector ALU {wres[1]:7.1f} us")
-    if D <= 4:
-        with _lib.tuning(dw_dense16=1):
-            for _ in range(3):
-                ops.dwconv3d_fwd(x, w, b)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                ops.dwconv3d_fwd(x, w, b)
-            e1.record()
-            torch.cuda.synchronize()
-            print(f"{(N, C, D, H, W)}: dense kernel with 16 channels per block {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us")
     gf = 2.0 * N * C * D * H * W * 343 / 1e9
     print(f"{(N, C, D, H, W)}: MFMA {res[0]:7.1f} us ({gf / res[0] * 1e-3:5.1f} TF)   vector ALU {res[1]:7.1f} us ({gf / res[1] * 1e-3:5.1f} TF)")
