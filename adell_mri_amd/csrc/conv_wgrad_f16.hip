@@ -437,7 +437,7 @@ struct WgradZrPlan {
 };
 extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
                                       int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,
-                                      WgradZrPlan* p);
+                                      int* plan);   // plan: the eight ints of a WgradZrPlan
 extern "C" size_t adell_wgrad_zring_ws_floats(const WgradZrPlan* p, int Cin, int Cout);
 // the 32 -> 32 stride-2 downsampling layer (conv_wgrad_s2.hip)
 struct WgradS2Plan {
@@ -544,7 +544,7 @@ static int adell_wgrad_f16_core(int N, int D, int H, int W, int C0, int C1, cons
   WgradF16Plan p = {};
   WgradZrPlan zp;
   const bool zring = adell_wgrad_zring_plan(N, D, H, W, C0, C1, Cout, KD, KH, KW, SD, SH, SW, Do, Ho,
-                                            Wo, &zp) != 0;
+                                            Wo, reinterpret_cast<int*>(&zp)) != 0;
   // split-row sources: the z-ring kernel only, and no 32-channel tile across the two sources
   ADELL_REQUIRE((!xk0 && !xk1) || (zring && (C1 == 0 || C0 % 32 == 0)),
                 "wgrad f16x3: this problem does not take split-row sources "
@@ -648,7 +648,7 @@ extern "C" long adell_conv3d_bwd_weight_f16x3_workspace(const adell_conv3d_desc*
   WgradZrPlan zp;
   const int Cin = d->C0 + d->C1;
   if (adell_wgrad_zring_plan(d->N, d->D, d->H, d->W, d->C0, d->C1, d->Cout, d->KD, d->KH, d->KW,
-                             d->SD, d->SH, d->SW, d->Do, d->Ho, d->Wo, &zp)) {
+                             d->SD, d->SH, d->SW, d->Do, d->Ho, d->Wo, reinterpret_cast<int*>(&zp))) {
     // the larger of the two plans, so that a later call may take either kernel
     WgradF16Plan q = {};
     if (adell_wgrad_f16_plan(d->N, Cin, d->Cout, d->KD, d->KH, d->KW, d->SH, d->SW, d->Do, d->Ho,
@@ -688,7 +688,7 @@ extern "C" int adell_conv3d_bwd_weight_f16x3_rows_ok(const adell_conv3d_desc* d)
   if (!d || adell_wgrad_small_workspace(d) > 0) return 0;
   WgradZrPlan zp;
   if (!adell_wgrad_zring_plan(d->N, d->D, d->H, d->W, d->C0, d->C1, d->Cout, d->KD, d->KH, d->KW,
-                              d->SD, d->SH, d->SW, d->Do, d->Ho, d->Wo, &zp))
+                              d->SD, d->SH, d->SW, d->Do, d->Ho, d->Wo, reinterpret_cast<int*>(&zp)))
     return 0;
   return (d->C1 == 0 || d->C0 % 32 == 0) ? 1 : 0;
 }

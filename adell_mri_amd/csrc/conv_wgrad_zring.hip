@@ -608,7 +608,9 @@ struct WgradZrPlan {
 // 1 when the z-ring kernel serves this problem (3^3 taps, stride 1, channel counts in whole 16s)
 extern "C" int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD,
                                       int KH, int KW, int SD, int SH, int SW, int Do, int Ho, int Wo,
-                                      WgradZrPlan* p) {
+                                      int* plan) {
+  static_assert(sizeof(WgradZrPlan) == 8 * sizeof(int), "plan[8] of include/adell_hip.h");
+  WgradZrPlan* p = reinterpret_cast<WgradZrPlan*>(plan);
   const int Cin = C0 + C1;
   if (KD != 3 || KH != 3 || KW != 3 || SD != 1 || SH != 1 || SW != 1) return 0;
   // whole 16-channel pieces: tiles are 32 x 32 channels, a ragged last tile or one that straddles

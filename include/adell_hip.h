@@ -917,6 +917,13 @@ int adell_dw_dense_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW,
 int adell_dw_wgrad_mfma_ok(int N, int C, int D, int H, int W, int KD, int KH, int KW, const float* x,
                            const float* dy);
 
+/* Launch plan of the z-ring weight-gradient kernel (csrc/conv_wgrad_zring.hip) for a conv of these
+ * extents: returns 1 and fills plan[8] = {column tiles x, y, z segments, planes per segment, input /
+ * output channel tiles, resident blocks, 1 when the 16 x 16 tile form (16-channel layers) runs}, or 0
+ * when adell_conv3d_bwd_weight_f16x3 runs the layer on the per-plane kernel instead. */
+int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD, int KH,
+                           int KW, int SD, int SH, int SW, int Do, int Ho, int Wo, int* plan);
+
 long adell_gibbs_workspace(int N, int D, int H, int W, int C);
 int adell_gibbs_lowpass(const float* x, float* out, int N, int D, int H, int W, int C,
                         const float* radius, void* workspace, size_t workspace_bytes, void* stream);
