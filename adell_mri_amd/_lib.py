@@ -252,6 +252,7 @@ SIGNATURES = {
     "adell_channel_max_bwd": (_i, [_vp, _vp, _vp, _i, _l, _i, _vp]),
     "adell_debug_force_conv_cfg": (None, [_i]),
     "adell_set_tuning": (_i, [ctypes.c_char_p, _i]),
+    "adell_rng_advance": (_i, [ctypes.c_uint32, _i, _vp]),
     "adell_get_tuning": (_i, [ctypes.c_char_p]),
 }
 

@@ -85,3 +85,17 @@ extern "C" int adell_get_tuning(const char* name) {
   int* slot = adell_tuning_slot(name);
   return slot ? *slot : -1;
 }
+
+// ---- replay counter of the dropout offsets (common.h: ADELL_RNG_STEP_DEFINE) ------------------------
+int adell_rng_advance_norm_act(unsigned delta, int set, hipStream_t st);
+int adell_rng_advance_tokens(unsigned delta, int set, hipStream_t st);
+int adell_rng_advance_window(unsigned delta, int set, hipStream_t st);
+
+extern "C" int adell_rng_advance(uint32_t delta, int set, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = adell_rng_advance_norm_act(delta, set, st);
+  if (rc == ADELL_OK) rc = adell_rng_advance_tokens(delta, set, st);
+  if (rc == ADELL_OK) rc = adell_rng_advance_window(delta, set, st);
+  if (rc != ADELL_OK) adell_set_error("adell_rng_advance: launch failed");
+  return rc;
+}

@@ -143,6 +143,23 @@ __device__ __forceinline__ float adell_act_grad(int act, float x, float p) {
   }
 }
 
+// Replay counter of the dropout offsets. A kernel's (seed, offset) words are launch arguments: in a
+// captured HIP graph they are frozen, and every replay would draw the masks of the captured step. Each
+// translation unit with a dropout kernel therefore keeps ONE device word that is ADDED to the offset
+// argument (0 unless a graph advances it: eager launches are unchanged), and the graph ends with the
+// one-thread kernel that advances it by the number of offsets a step draws -- replay r of a step
+// captured with offsets c .. c + K - 1 uses c + r K .. , exactly what eager step r would have drawn
+// (adell_rng_advance, include/adell_hip.h; trainer.StepRunner.enable_graph).
+#define ADELL_RNG_STEP_DEFINE(tu)                                                                \
+  static __device__ unsigned g_adell_rng_step = 0;                                                \
+  __global__ void adell_rng_advance_kernel_##tu(unsigned delta, int set) {                        \
+    g_adell_rng_step = set ? delta : g_adell_rng_step + delta;                                    \
+  }                                                                                               \
+  int adell_rng_advance_##tu(unsigned delta, int set, hipStream_t st) {                           \
+    hipLaunchKernelGGL(adell_rng_advance_kernel_##tu, dim3(1), dim3(1), 0, st, delta, set);      \
+    return hipGetLastError() == hipSuccess ? ADELL_OK : ADELL_E_HIP;                              \
+  }
+
 // Philox-4x32 counter RNG, 7 rounds (Salmon et al., SC'11: the fewest rounds of this generator that
 // pass BigCrush; 10 is the library default with a safety margin): one call -> 4 uniform 32-bit
 // words. The dropout mask of element e of a tensor is a pure function of (seed, offset, e), so

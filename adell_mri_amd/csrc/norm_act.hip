@@ -4,6 +4,8 @@
 // NDHWC fp32; reductions use wavefront shuffles and fixed-order fp64 combines.
 #include "common.h"
 
+ADELL_RNG_STEP_DEFINE(norm_act)
+
 // ---------------------------------------------------------------------------
 // Per-(n,c) statistics from per-block partials [N][ntiles][C][2] (sum, sumsq)
 // written by the conv epilogue or by adell_channel_partials_kernel.
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
     float h[4] = {v.x, v.y, v.z, v.w};
     uint4 r = make_uint4(0, 0, 0, 0);
     if (a.drop_p > 0.f)
-      r = adell_philox4((uint32_t)i, (uint32_t)(i >> 32), a.rng_offset, 0u, a.seed_lo,
+      r = adell_philox4((uint32_t)i, (uint32_t)(i >> 32), a.rng_offset + g_adell_rng_step, 0u, a.seed_lo,
                         a.seed_hi);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_kernel(NormActArgs a) 
     if (a.beta) t = t + a.beta[cj];
     if (a.drop_p > 0.f) {
       const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34),
-                                    a.rng_offset, 0u, a.seed_lo, a.seed_hi);
+                                    a.rng_offset + g_adell_rng_step, 0u, a.seed_lo, a.seed_hi);
       const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
       const float u = (float)(rr[e & 3] >> 8) * (1.0f / 16777216.0f);
       t = (u >= a.drop_p) ? t * keep_scale : 0.f;
@@ -655,7 +657,7 @@ __device__ __forceinline__ void adell_na_bwd_elem(const NormActBwdArgs& a, float
 __device__ __forceinline__ void adell_na_keep4(const NormActBwdArgs& a, long e4, bool keep[4]) {
   keep[0] = keep[1] = keep[2] = keep[3] = true;
   if (a.drop_p > 0.f) {
-    const uint4 r = adell_philox4((uint32_t)e4, (uint32_t)(e4 >> 32), a.rng_offset, 0u,
+    const uint4 r = adell_philox4((uint32_t)e4, (uint32_t)(e4 >> 32), a.rng_offset + g_adell_rng_step, 0u,
                                   a.seed_lo, a.seed_hi);
     const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -1099,7 +1101,7 @@ __global__ __launch_bounds__(256) void adell_norm_act_fwd_fast_kernel(NormActArg
       uint32_t rr[4] = {0, 0, 0, 0};
       if (a.drop_p > 0.f) {
         const long gi = (long)n * n4 + jj;  // same counter as the generic kernel
-        const uint4 r = adell_philox4((uint32_t)gi, (uint32_t)(gi >> 32), a.rng_offset, 0u,
+        const uint4 r = adell_philox4((uint32_t)gi, (uint32_t)(gi >> 32), a.rng_offset + g_adell_rng_step, 0u,
                                       a.seed_lo, a.seed_hi);
         rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
       }

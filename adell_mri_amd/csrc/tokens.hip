@@ -10,6 +10,8 @@
 // reductions, fixed summation order.
 #include "common.h"
 
+ADELL_RNG_STEP_DEFINE(tokens)
+
 // ---------------------------------------------------------------------------
 // LayerNorm: y = (x - mean) * rstd * gamma + beta over rows of length C.
 // One wave per row. mean/rstd are saved for the backward.
@@ -257,7 +259,7 @@ __device__ __forceinline__ uint32_t adell_word4(const uint4& r, unsigned i) {
 __device__ __forceinline__ bool adell_att_keep(const AttArgs& a, int bh, int qrow, int kcol) {
   if (a.drop_p <= 0.f) return true;
   const uint64_t e = ((uint64_t)bh * a.T + qrow) * a.T + kcol;
-  const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34), a.rng_offset, 2u,
+  const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34), a.rng_offset + g_adell_rng_step, 2u,
                                 a.seed_lo, a.seed_hi);
   return (float)(adell_word4(r, (unsigned)(e & 3)) >> 8) * (1.0f / 16777216.0f) >= a.drop_p;
 }
@@ -270,11 +272,11 @@ __device__ __forceinline__ void adell_att_keep4(const AttArgs& a, int bh, int qr
   if (a.drop_p <= 0.f) return;
   const uint64_t e0 = ((uint64_t)bh * a.T + qrow) * a.T + kcol0;
   const uint64_t b0 = e0 >> 2, b1 = (e0 + 3) >> 2;
-  const uint4 r0 = adell_philox4((uint32_t)b0, (uint32_t)(b0 >> 32), a.rng_offset, 2u, a.seed_lo,
+  const uint4 r0 = adell_philox4((uint32_t)b0, (uint32_t)(b0 >> 32), a.rng_offset + g_adell_rng_step, 2u, a.seed_lo,
                                  a.seed_hi);
   uint4 r1 = r0;
   if (b1 != b0)
-    r1 = adell_philox4((uint32_t)b1, (uint32_t)(b1 >> 32), a.rng_offset, 2u, a.seed_lo, a.seed_hi);
+    r1 = adell_philox4((uint32_t)b1, (uint32_t)(b1 >> 32), a.rng_offset + g_adell_rng_step, 2u, a.seed_lo, a.seed_hi);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const uint64_t e = e0 + j;

@@ -11,6 +11,8 @@
 //     (window, head, query row); HBM/latency bound (QK^T is 2*T*A flops per row).
 #include "common.h"
 
+ADELL_RNG_STEP_DEFINE(window)
+
 // ---------------------------------------------------------------------------
 // out (contiguous over sizes[0..nd)) = in[offset(coords)]. Each out dim d feeds input axis
 // axis[d] with multiplier mult[d]; input axis a has extent / stride / cyclic shift:
@@ -374,7 +376,7 @@ struct WinAttnArgs {
 __device__ __forceinline__ bool adell_wa_keep(const WinAttnArgs& a, long seq, int i, int j) {
   if (a.drop_p <= 0.f) return true;
   const unsigned long e = ((unsigned long)seq * a.T + i) * a.T + j;
-  const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34), a.rng_offset, 1u,
+  const uint4 r = adell_philox4((uint32_t)(e >> 2), (uint32_t)(e >> 34), a.rng_offset + g_adell_rng_step, 1u,
                                 a.seed_lo, a.seed_hi);
   const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
   return (float)(rr[e & 3] >> 8) * (1.0f / 16777216.0f) >= a.drop_p;

@@ -138,6 +138,11 @@ def _repack_registered():
                      d1, taps, first))
         first += d0 if ent[1] == 0 else d1
     sig = tuple(rows)
+    if _PACK_BATCH["sig"] != sig and torch.cuda.is_current_stream_capturing():
+        # the set of live weights changed inside a graph capture (another module died since the
+        # warm-up step): the table upload is a pageable host copy, which a capture cannot hold --
+        # the caller packs weight by weight (captured launches of the single-weight kernel)
+        return False
     if _PACK_BATCH["sig"] != sig:
         _PACK_BATCH["table"] = torch.tensor(rows, dtype=torch.int64, device=live[0][0].device)
         _PACK_BATCH["sig"] = sig

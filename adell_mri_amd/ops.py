@@ -187,6 +187,13 @@ def _require_cuda(*ts):
             raise _lib.AdellHipError(f"adell_mri_amd kernels are fp32; got {t.dtype}")
 
 
+def rng_advance(delta, set_value=False):
+    """The library's replay counter of the dropout offsets (adell_rng_advance): add ``delta`` to the
+    device word every dropout kernel adds to its offset argument, or set it. Stream-ordered; the
+    last node of a captured training step (trainer.StepRunner.enable_graph)."""
+    check(_lib.lib().adell_rng_advance(int(delta) & 0xFFFFFFFF, 1 if set_value else 0, _stream()))
+
+
 def ndhwc(x):
     """Return a tensor sharing x's logical NCDHW shape whose memory is dense NDHWC."""
     if x.dim() != 5:

@@ -90,6 +90,22 @@ class FlatParameters:
         (asynchronous upload, no host synchronisation unless the ring wraps onto a copy that is
         still in flight) and launch the multi-copy."""
         n = len(rows)
+        if self.grad.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a graph capture (trainer.StepRunner.enable_graph): the table is a node's static
+            # input. Nothing may be allocated on the host here (pinning memory invalidates the
+            # capture): one entry of the ring the eager steps built is taken out of it for good --
+            # kept alive with the graph, never written again, no event to wait on later
+            ring = getattr(self, "_ring", None)
+            if ring is None or ring[0][0].shape[0] < n or len(ring) < 2:
+                raise RuntimeError("FlatParameters.collect inside a graph capture: run eager steps "
+                                   "first (they size the pinned staging ring)")
+            host, dev, _ev = ring.pop(self._ring_pos % len(ring))
+            self._ring_pos = self._ring_pos % len(ring)
+            host[:n] = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int64))
+            dev[:n].copy_(host[:n], non_blocking=True)
+            self._graph_tables = getattr(self, "_graph_tables", []) + [(host, dev)]
+            ops.multi_copy(dev, n, self.grad)
+            return
         ring = getattr(self, "_ring", None)
         if ring is None or ring[0][0].shape[0] < n:
             cap = max(2 * n, 1024)

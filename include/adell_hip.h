@@ -864,6 +864,13 @@ void adell_debug_force_conv_cfg(int cfg);
  * results become WRONG) exist only in -DADELL_DEBUG builds of the library. adell_set_tuning
  * returns ADELL_E_BADARG for an unknown name; adell_get_tuning -1. */
 int adell_set_tuning(const char* name, int value);
+/* Replay counter of the dropout offsets: a device word (0 after load) that every dropout kernel of
+ * the library ADDS to its `rng_offset` argument. Eager callers never touch it. A caller that
+ * captures a training step in a HIP graph enqueues adell_rng_advance(K, 0, stream) as the LAST
+ * node, K = the number of offsets the step draws: replay r then uses offsets c + r K .. where the
+ * capture drew c .., i.e. the masks eager step r would have drawn. set != 0: the word is set to
+ * `delta` instead (0 when the caller goes back to eager launches). Stream-ordered. */
+int adell_rng_advance(uint32_t delta, int set, void* stream);
 int adell_get_tuning(const char* name);
 
 /* ------------------------------------------------------------------------
