@@ -17,17 +17,8 @@ from .. import ops
 from ..modules.segmentation import losses as _seg_losses
 
 
-def _not_built(name):
-    def raiser(*args, **kwargs):
-        raise NotImplementedError(f"loss {name!r} has no HIP kernel yet (built: binary cross-entropy / dice "
-                                  f"/ focal, categorical cross-entropy / dice / focal)")
-    raiser.__name__ = name
-    return raiser
-
-
-# adell_mri/utils/utils.py:39-59: name -> loss function, per target family. Entries without a
-# HIP implementation raise on call (no eager-torch fallback) but keep the key set, so that
-# configuration files are validated the same way.
+# adell_mri/utils/utils.py:39-59: name -> loss function, per target family (every entry is a HIP
+# kernel: cross-entropy / focal / dice and the Tversky / combo / hybrid / unified focal family).
 loss_factory = {
     "binary": {
         "cross_entropy": _seg_losses.binary_cross_entropy,
