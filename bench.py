@@ -422,12 +422,15 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             "BASELINE configs[4]: unet-swin.yaml SWINUNetPL, 2x256x256x128, batch 1/GPU"
 
     out = {}
-    # config 3 is ~800 launches of 10-60 us per step: eager, the host's enqueue time IS the step time
-    # (round 4's driver record: host 24.9 ms of a 26.8 ms step). Its timed steps replay one captured
-    # HIP graph (StepRunner.enable_graph: forward + loss + backward + gradient gather; the optimiser
-    # launch stays eager) -- single rank only: under DDP the bucketed all-reduce is issued from
-    # backward hooks, which a replay does not run. (Config 4 stays eager: hipStreamEndCapture of its
-    # step crashes inside the runtime on this ROCm build -- DESIGN.md, known gaps.)
+    # config 3 is ~800 launches of 10-60 us per step: eager, the host's enqueue time is as long as the
+    # step (round 4's driver record: host 24.9 ms of a 26.8 ms step). After its eager timed steps the
+    # same step is replayed from ONE captured HIP graph (StepRunner.enable_graph: forward + loss +
+    # backward + gradient gather; the optimiser launch stays eager) and recorded as
+    # `hip_graph_replay`: 2 ms of host time per step, ~1 ms MORE GPU time than an eager step the host
+    # keeps up with (measured on one box, alternating: 21.3 vs 20.1-20.4 ms) -- so `value` stays the
+    # eager figure. Single rank only: under DDP the bucketed all-reduce is issued from backward
+    # hooks, which a replay does not run. (Config 4: hipStreamEndCapture of its step crashes inside
+    # the runtime on this ROCm build -- DESIGN.md, known gaps.)
     graphed = {"cfg3_unetr_96"} if world == 1 and not os.environ.get("ADELL_BENCH_NO_GRAPH") else set()
     for key, build in (("cfg2b_resnet_backbone_128", build_cfg2b_entry),
                        ("cfg3_unetr_96", build_cfg3), ("cfg4_vicreg_convnext_64", build_cfg4),
@@ -444,14 +447,22 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
                 runner.train_step(batch)
             barrier()
             runner.reserve_memory()
+            dt, loss, per = timed_steps(runner, batch, 5, barrier)
+            rec = step_record(per, list(LAST_DIAG))
+            dt = reduce_max(dt, device)
+            replay = None
             if key in graphed:
                 runner.enable_graph(batch, warmup=1)
                 barrier()
-            dt, loss, per = timed_steps(runner, batch, 5, barrier)
-            rec = step_record(per, list(LAST_DIAG))
-            if key in graphed:
+                gdt, _, gper = timed_steps(runner, batch, 5, barrier)
+                grec = step_record(gper, list(LAST_DIAG))
                 runner.disable_graph()
-            dt = reduce_max(dt, device)
+                barrier()
+                replay = {"ms_per_step": 1e3 * gdt / 5, "median_ms_per_step": statistics.median(gper),
+                          "value": units * world * 5 / gdt, "unit": unit,
+                          "host_ms": grec.get("host_ms"), "per_step_ms": grec.get("per_step_ms"),
+                          "captured": "zero_grad + training_step + backward + gradient gather; the "
+                                      "optimiser launch stays eager"}
             ops.KERNEL_TIMER = ops.KernelTimer()
             overlap = HF.FLAGS["wgrad_stream"]
             HF.FLAGS["wgrad_stream"] = False       # (instrumented step: one stream, see timed_steps)
@@ -462,8 +473,10 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             entry = {"workload": workload, "value": units * world * 5 / dt, "unit": unit,
                      "ms_per_step": 1e3 * dt / 5, "median_ms_per_step": statistics.median(per),
                      "steps": 5, "warmup": 4, "final_loss": float(loss.detach().cpu()),
-                     "step_record": rec, "hip_graph": key in graphed,
+                     "step_record": rec,
                      "params": sum(p.numel() for p in net.parameters())}
+            if replay is not None:
+                entry["hip_graph_replay"] = replay
             dom = timer.dominant()
             if dom is not None:
                 name, flops, ms, launches = dom
