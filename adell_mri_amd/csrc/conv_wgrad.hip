@@ -609,6 +609,49 @@ __global__ __launch_bounds__(1024) void adell_colsum_final_kernel(
   out[c] = (float)s;
 }
 
+// Narrow tensors (C a power of two <= 64: the 2 .. 32-channel per-voxel layers of SWIN / U-Net heads):
+// the kernel above keeps C of its 64 column lanes busy (C = 2: 8 threads of 256, 63 us for a 67 MB
+// tensor). Here dy is a flat stream of float4: the grid stride is a multiple of C elements, so a
+// thread's four lanes stay on the same four columns; block fold = a fixed tree over the threads that
+// share columns. part[block][C] as above.
+__global__ __launch_bounds__(256) void adell_colsum_flat_kernel(const f32x4* __restrict__ x4, long n4,
+                                                                int C, float* __restrict__ part) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x;
+  const long stride = (long)gridDim.x * 256L;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  long i = blockIdx.x * 256L + tid;
+  for (; i + 3 * stride < n4; i += 4 * stride) {       // four 16-byte loads in flight
+    const f32x4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+  }
+  for (; i < n4; i += stride) a0 += x4[i];
+  sh[tid] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  const int q = C >= 4 ? C >> 2 : 1;                      // threads per period of the column pattern
+  for (int s = 128; s >= q; s >>= 1) {
+    if (tid < s) sh[tid] += sh[tid + s];
+    __syncthreads();
+  }
+  if (tid < C) {
+    float v;
+    if (C >= 4) v = sh[tid >> 2][tid & 3];
+    else if (C == 2) v = sh[0][tid] + sh[0][tid + 2];
+    else v = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    part[(size_t)blockIdx.x * C + tid] = v;
+  }
+}
+
+static bool adell_colsum_flat_ok(const float* dy, long rows, int C) {
+  return C >= 1 && C <= 64 && (C & (C - 1)) == 0 && ((rows * C) & 3) == 0 && rows * (long)C >= 4096 &&
+         (((uintptr_t)dy) & 15) == 0;
+}
+static int adell_colsum_flat_blocks(long rows, int C) {
+  long nb = (rows * C / 4 + 1023) / 1024;                // >= 4 float4 per thread
+  if (nb > 1024) nb = 1024;
+  return (int)(nb < 1 ? 1 : nb);
+}
+
 // rows per block: about 2048 blocks in total, at least 16 rows each
 static int adell_bias_grad_chunk(long rows, int C) {
   const long colgroups = adell_cdiv(C, 64);
@@ -624,7 +667,10 @@ static int adell_bias_grad_chunk(long rows, int C) {
 extern "C" long adell_bias_grad_workspace(long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
   const int chunk = adell_bias_grad_chunk(rows, C);
-  return (long)((rows + chunk - 1) / chunk) * C * (long)sizeof(float);
+  long nb = (rows + chunk - 1) / chunk;
+  if (C <= 64 && (C & (C - 1)) == 0 && adell_colsum_flat_blocks(rows, C) > nb)
+    nb = adell_colsum_flat_blocks(rows, C);              // either kernel may run (alignment decides)
+  return nb * C * (long)sizeof(float);
 }
 
 extern "C" int adell_bias_grad(const float* dy, long rows, int C, float* db, void* workspace,
@@ -634,9 +680,15 @@ extern "C" int adell_bias_grad(const float* dy, long rows, int C, float* db, voi
   ADELL_REQUIRE((long)workspace_bytes >= adell_bias_grad_workspace(rows, C),
                 "bias_grad: workspace too small");
   const int chunk = adell_bias_grad_chunk(rows, C);
-  const int nb = (int)((rows + chunk - 1) / chunk);
-  hipLaunchKernelGGL(adell_colsum_partial_kernel, dim3(nb, adell_cdiv(C, 64)), dim3(256), 0,
-                     (hipStream_t)stream, dy, rows, C, chunk, (float*)workspace);
+  int nb = (int)((rows + chunk - 1) / chunk);
+  if (adell_colsum_flat_ok(dy, rows, C)) {
+    nb = adell_colsum_flat_blocks(rows, C);
+    hipLaunchKernelGGL(adell_colsum_flat_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(dy), rows * C / 4, C, (float*)workspace);
+  } else {
+    hipLaunchKernelGGL(adell_colsum_partial_kernel, dim3(nb, adell_cdiv(C, 64)), dim3(256), 0,
+                       (hipStream_t)stream, dy, rows, C, chunk, (float*)workspace);
+  }
   hipLaunchKernelGGL(adell_colsum_final_kernel, dim3(adell_cdiv(C, 64)), dim3(1024), 0,
                      (hipStream_t)stream, (const float*)workspace, nb, C, db);
   ADELL_CHECK_HIP(hipGetLastError());

@@ -66,6 +66,140 @@ __global__ __launch_bounds__(256) void adell_gather_nd_kernel(GatherArgs a) {
   }
 }
 
+// The same gather in 32-bit arithmetic (every problem of the SWIN path: < 2^31 elements on either
+// side). The generic kernel above spends ~60 instructions per 64-bit division and 12 selects per
+// dimension on coordinates it rarely needs (0.66 TB/s on the 2-channel window partition of config 5):
+//   * divisions by the (launch-constant) sizes are multiply-high + shift (host-made magic numbers);
+//   * a dimension that feeds an UNSHIFTED input axis contributes coordinate * (mult * stride)
+//     straight to the offset -- no per-axis coordinate; only the (at most four) cyclically shifted
+//     axes keep one, wrapped by one conditional subtraction (0 <= shift < extent);
+//   * adjacent unshifted dimensions whose offsets nest (lin[d] == size[d+1] * lin[d+1]) are merged on
+//     the host, so 'z c' runs of a channels-last volume move as 16- or 8-byte pieces.
+typedef float g_f32x2 __attribute__((ext_vector_type(2)));
+struct Gather32Args {
+  const float* in;
+  float* out;
+  int nd, ns;
+  unsigned size[ADELL_GATHER_MAX], magic[ADELL_GATHER_MAX], shr[ADELL_GATHER_MAX];
+  unsigned lin[ADELL_GATHER_MAX];       // offset per coordinate (unshifted axes), else 0
+  int sidx[ADELL_GATHER_MAX];           // shifted axis this dimension feeds, or -1
+  unsigned smult[ADELL_GATHER_MAX];
+  unsigned sext[4], sshift[4], sstride[4];
+  unsigned total;                       // in units of `vec` elements
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void adell_gather_nd32_kernel(Gather32Args a) {
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < a.total; i += gridDim.x * 256u) {
+    unsigned rem = i * VEC, off = 0, sc[4] = {0u, 0u, 0u, 0u};
+    for (int d = a.nd - 1; d >= 0; --d) {
+      const unsigned q = (__umulhi(rem, a.magic[d]) + rem) >> a.shr[d];
+      const unsigned c = rem - q * a.size[d];
+      rem = q;
+      const int sx = a.sidx[d];                     // launch constants: scalar branches
+      if (sx < 0) {
+        off += c * a.lin[d];
+      } else {
+        const unsigned v = c * a.smult[d];
+        sc[0] += sx == 0 ? v : 0u;
+        sc[1] += sx == 1 ? v : 0u;
+        sc[2] += sx == 2 ? v : 0u;
+        sc[3] += sx == 3 ? v : 0u;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < a.ns) {
+        unsigned c = sc[q] + a.sshift[q];
+        c = c >= a.sext[q] ? c - a.sext[q] : c;
+        off += c * a.sstride[q];
+      }
+    if constexpr (VEC == 4)
+      reinterpret_cast<f32x4*>(a.out)[i] = *reinterpret_cast<const f32x4*>(a.in + off);
+    else if constexpr (VEC == 2)
+      reinterpret_cast<g_f32x2*>(a.out)[i] = *reinterpret_cast<const g_f32x2*>(a.in + off);
+    else
+      a.out[i] = a.in[off];
+  }
+}
+
+// plans the 32-bit form; false when the problem does not fit it
+static bool adell_gather32_plan(const float* in, float* out, int nd, const int* sizes, const int* axis,
+                                const long* mult, int na, const long* extent, const long* stride,
+                                const long* shift, Gather32Args* a, int* vec_out) {
+  long total = 1, in_span = 1;
+  for (int d = 0; d < nd; ++d) total *= sizes[d];
+  for (int q = 0; q < na; ++q) in_span += (extent[q] - 1) * (stride[q] < 0 ? -stride[q] : stride[q]);
+  if (total >= (1L << 31) || in_span >= (1L << 31)) return false;
+  // shifted axes (shift normalised into [0, extent)); at most four; negative strides not taken
+  int smap[ADELL_GATHER_MAX];
+  a->ns = 0;
+  for (int q = 0; q < na; ++q) {
+    smap[q] = -1;
+    if (stride[q] < 0) return false;
+    long sh = shift[q] % extent[q];
+    if (sh < 0) sh += extent[q];
+    if (sh != 0) {
+      if (a->ns == 4) return false;
+      // the wrap is ONE conditional subtraction: the axis coordinate must stay below its extent
+      long mx = 0;
+      for (int d = 0; d < nd; ++d)
+        if (axis[d] == q) { if (mult[d] < 0) return false; mx += (long)(sizes[d] - 1) * mult[d]; }
+      if (mx >= extent[q]) return false;
+      smap[q] = a->ns;
+      a->sext[a->ns] = (unsigned)extent[q];
+      a->sshift[a->ns] = (unsigned)sh;
+      a->sstride[a->ns] = (unsigned)stride[q];
+      ++a->ns;
+    }
+  }
+  for (int q = a->ns; q < 4; ++q) a->sext[q] = 1u, a->sshift[q] = 0u, a->sstride[q] = 0u;
+  // dimensions, innermost last; merge nested unshifted neighbours
+  long sz[ADELL_GATHER_MAX], lin[ADELL_GATHER_MAX], sm[ADELL_GATHER_MAX];
+  int sx[ADELL_GATHER_MAX], n = 0;
+  for (int d = 0; d < nd; ++d) {
+    const int ax = axis[d];
+    const long l = smap[ax] < 0 ? mult[d] * stride[ax] : 0;
+    if (smap[ax] < 0 && l < 0) return false;
+    if (sizes[d] == 1) continue;
+    if (n > 0 && smap[ax] < 0 && sx[n - 1] < 0 && lin[n - 1] == (long)sizes[d] * l) {
+      sz[n - 1] *= sizes[d];
+      lin[n - 1] = l;
+      continue;
+    }
+    sz[n] = sizes[d]; lin[n] = l; sx[n] = smap[ax]; sm[n] = smap[ax] < 0 ? 0 : mult[d];
+    ++n;
+  }
+  if (n == 0) { sz[0] = 1; lin[0] = 0; sx[0] = -1; sm[0] = 0; n = 1; }
+  // vector width: the innermost dimension walks unit-stride, unshifted memory
+  int vec = 1;
+  if (sx[n - 1] < 0 && lin[n - 1] == 1) {
+    for (int v = 4; v >= 2 && vec == 1; v >>= 1) {
+      bool ok = sz[n - 1] % v == 0 && ((uintptr_t)in % (4 * v)) == 0 && ((uintptr_t)out % (4 * v)) == 0;
+      for (int d = 0; d + 1 < n && ok; ++d)
+        if (sx[d] < 0 && lin[d] % v != 0) ok = false;
+      for (int q = 0; q < a->ns && ok; ++q)
+        if (a->sstride[q] % v != 0) ok = false;
+      if (ok) vec = v;
+    }
+  }
+  a->in = in; a->out = out; a->nd = n;
+  for (int d = 0; d < ADELL_GATHER_MAX; ++d) {
+    const unsigned dv = d < n ? (unsigned)sz[d] : 1u;
+    int l = 0;
+    while ((1ul << l) < dv) ++l;
+    a->size[d] = dv;
+    a->magic[d] = (unsigned)(((1ul << 32) * ((1ul << l) - dv)) / dv + 1);
+    a->shr[d] = (unsigned)l;
+    a->lin[d] = d < n ? (unsigned)lin[d] : 0u;
+    a->sidx[d] = d < n ? sx[d] : -1;
+    a->smult[d] = d < n ? (unsigned)sm[d] : 0u;
+  }
+  a->total = (unsigned)(total / vec);
+  *vec_out = vec;
+  return true;
+}
+
 extern "C" int adell_gather_nd(const float* in, float* out, int nd, const int* sizes,
                                const int* axis, const long* mult, int na, const long* extent,
                                const long* stride, const long* shift, void* stream) {
@@ -94,6 +228,22 @@ extern "C" int adell_gather_nd(const float* in, float* out, int nd, const int* s
     for (int d = 0; d < nd; ++d)
       if (axis[d] == q) mx += (long)(sizes[d] - 1) * mult[d];
     ADELL_REQUIRE(extent[q] > 0 && mx < extent[q], "gather_nd: coordinates exceed the input axis");
+  }
+  // the 32-bit form (fast divisions, merged runs) whenever the problem fits it
+  {
+    Gather32Args g;
+    int v = 1;
+    if (adell_gather32_plan(in, out, nd, sizes, axis, mult, na, extent, stride, shift, &g, &v)) {
+      unsigned blocks = (g.total + 255u) / 256u;
+      if (blocks > 16384u) blocks = 16384u;
+      if (blocks < 1u) blocks = 1u;
+      hipStream_t st = (hipStream_t)stream;
+      if (v == 4) hipLaunchKernelGGL(adell_gather_nd32_kernel<4>, dim3(blocks), dim3(256), 0, st, g);
+      else if (v == 2) hipLaunchKernelGGL(adell_gather_nd32_kernel<2>, dim3(blocks), dim3(256), 0, st, g);
+      else hipLaunchKernelGGL(adell_gather_nd32_kernel<1>, dim3(blocks), dim3(256), 0, st, g);
+      ADELL_CHECK_HIP(hipGetLastError());
+      return ADELL_OK;
+    }
   }
   // 16-byte path: innermost out dim walks a unit-stride, unshifted axis of its own
   const int last = nd - 1, la = axis[last];

@@ -170,3 +170,49 @@ def test_window_attention_dropout_mask_is_consistent(cuda):
     out_eval = HF.window_attention(qkv.detach(), ones, zeros, ones, zeros, W, H, T, a, hd,
                                    drop_p=p_drop, training=False)
     assert torch.equal(out_eval, ref)
+
+
+GATHER_CASES = [
+    # (input axes [(extent, stride, shift)], out dims [(size, axis, mult)]): the shapes of the SWIN path
+    # and the corners of the 32-bit planner (csrc/window.hip: merged runs, 16 / 8 / 4-byte pieces,
+    # cyclic shifts on up to four axes, size-1 dims, a non-power-of-two extent)
+    # window partition of [2, 16, 16, 8, 2]: windows 2x2x1 of 2x2x2 patches of 4x4x4 voxels, no shift
+    ([(2, 4096, 0), (16, 256, 0), (16, 16, 0), (8, 2, 0), (2, 1, 0)],
+     [(2, 0, 1), (2, 1, 8), (2, 2, 8), (1, 3, 8), (2, 1, 4), (2, 2, 4), (2, 3, 4), (4, 1, 1), (4, 2, 1),
+      (4, 3, 1), (2, 4, 1)]),
+    # the same with the reference's roll: Y, Z and the channel axis shifted
+    ([(2, 4096, 0), (16, 256, 0), (16, 16, 3), (8, 2, 5), (2, 1, 1)],
+     [(2, 0, 1), (2, 1, 8), (2, 2, 8), (1, 3, 8), (2, 1, 4), (2, 2, 4), (2, 3, 4), (4, 1, 1), (4, 2, 1),
+      (4, 3, 1), (2, 4, 1)]),
+    # space-to-depth of [1, 12, 10, 6, 6]: (2, 2, 3) blocks, 6 channels innermost -> 8-byte pieces
+    ([(1, 4320, 0), (12, 360, 0), (10, 36, 0), (6, 6, 0), (6, 1, 0)],
+     [(1, 0, 1), (6, 1, 2), (5, 2, 2), (2, 3, 3), (6, 4, 1), (2, 1, 1), (2, 2, 1), (3, 3, 1)]),
+    # a transpose (nothing merges, nothing vectorises) and a negative shift on a prime extent
+    ([(7, 1, -2), (5, 7, 0)], [(5, 1, 1), (7, 0, 1)]),
+    # four shifted axes, strides with gaps (a view into a larger buffer)
+    ([(3, 1000, 1), (5, 150, 2), (6, 20, 5), (4, 4, 3)],
+     [(3, 0, 1), (5, 1, 1), (3, 2, 2), (2, 2, 1), (4, 3, 1)]),
+]
+
+
+@pytest.mark.parametrize("axes,dims", GATHER_CASES)
+def test_gather_nd_against_index_arithmetic(cuda, axes, dims):
+    """ops.gather_nd against the definition: out[coords] = in[sum_axis ((sum_d c_d mult_d + shift) mod
+    extent) stride]."""
+    import numpy as np
+
+    span = 1 + sum((e - 1) * s for e, s, _ in axes)
+    rng = np.random.default_rng(len(dims))
+    src = rng.standard_normal(span).astype(np.float32)
+    sizes = [d[0] for d in dims]
+    coords = np.indices(sizes).reshape(len(dims), -1)
+    off = np.zeros(coords.shape[1], dtype=np.int64)
+    for q, (ext, stride, shift) in enumerate(axes):
+        c = np.zeros(coords.shape[1], dtype=np.int64)
+        for d, (_, ax, mult) in enumerate(dims):
+            if ax == q:
+                c += coords[d] * mult
+        off += ((c + shift) % ext) * stride
+    want = src[off]
+    got = ops.gather_nd(torch.from_numpy(src).to(cuda), dims, axes)
+    assert torch.equal(got.cpu(), torch.from_numpy(want))
