@@ -560,7 +560,9 @@ GemmHPlan gemm_h_plan(int M, int N, int K) {
   GemmHPlan p;
   const long tiles = (long)adell_cdiv(M, BM) * adell_cdiv(N, BN);
   const int stages = adell_cdiv(K, BK);
-  long s = adell_cdiv(512, (int)(tiles < 512 ? tiles : 512));   // two resident blocks per CU
+  // two resident blocks per CU, and never one block more than that: 3 tiles x 171 shares = 513 blocks
+  // left the last block alone on the chip for a second round (dW of 262 144 x 96 / 384: 194 us)
+  long s = 512 / (tiles < 512 ? tiles : 512);
   if (s > stages / 4) s = stages / 4;                          // at least four stages per split
   const long slab_cap = (16L << 20) / ((long)M * N);           // slabs capped at 64 MB
   if (s > slab_cap) s = slab_cap;
