@@ -303,6 +303,108 @@ __global__ __launch_bounds__(256) void adell_wgrad_tiny_kernel(WgSmallArgs a, in
   }
 }
 
+// The same weight gradient for 2 input channels and rows of a multiple of four voxels (the 2 -> 2
+// conv at 128^3): a thread owns FOUR consecutive voxels of a row and reads its taps straight from
+// global memory as 16-byte pieces (the six voxels x - 1 .. x + 4 of a (kz, ky) row: 4 loads, 2 bounds
+// checks, shared by 24 products each) -- no LDS halo, no barrier per brick, grid-stride over the
+// volume with the next group's dY in flight. Partial rows as adell_wgrad_tiny_kernel writes them.
+template <int COUT>
+__global__ __launch_bounds__(256) void adell_wgrad_cin2_rows_kernel(WgSmallArgs a, long groups) {
+  __shared__ float sred[4][27 * 2 * COUT + COUT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[27][2][COUT];
+  float sb[COUT];
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) acc[t][c][o] = 0.f;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) sb[o] = 0.f;
+  const int W = a.W, H = a.H, D = a.D;
+  const long vox = (long)D * H * W, gpi = vox >> 2;            // groups of four voxels per item
+  for (long gi = blockIdx.x * 256L + tid; gi < groups; gi += gridDim.x * 256L) {
+    const int n = (int)(gi / gpi);
+    const long v0 = (gi - (long)n * gpi) << 2;
+    const int x0 = (int)(v0 % W), y = (int)((v0 / W) % H), z = (int)(v0 / ((long)W * H));
+    const float* xb = a.x0 + (size_t)n * vox * 2;
+    const float* gp = a.dy + ((size_t)n * vox + v0) * COUT;
+    float g[4][COUT];
+    if (COUT == 2) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+      g[0][0] = g0.x; g[0][COUT - 1] = g0.y; g[1][0] = g0.z; g[1][COUT - 1] = g0.w;
+      g[2][0] = g1.x; g[2][COUT - 1] = g1.y; g[3][0] = g1.z; g[3][COUT - 1] = g1.w;
+    } else {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp);
+      g[0][0] = g0.x; g[1][0] = g0.y; g[2][0] = g0.z; g[3][0] = g0.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) sb[o] += g[q][o];
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const int iz = z - 1 + kz;
+      if (iz < 0 || iz >= D) continue;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+        const float* row = xb + ((size_t)(iz * H + iy) * W) * 2;
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + (size_t)x0 * 2);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 2) * 2);
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (x0 > 0) lo = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 - 2) * 2);
+        if (x0 + 4 < W) hi = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 4) * 2);
+        const float in[6][2] = {{lo.z, lo.w}, {m0.x, m0.y}, {m0.z, m0.w}, {m1.x, m1.y}, {m1.z, m1.w},
+                                {hi.x, hi.y}};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+              for (int o = 0; o < COUT; ++o)
+                acc[(kz * 3 + ky) * 3 + kx][c][o] = fmaf(in[q + kx][c], g[q][o], acc[(kz * 3 + ky) * 3 + kx][c][o]);
+      }
+    }
+  }
+  // wave fold (fixed butterfly order), then the four waves through LDS
+#pragma unroll
+  for (int t = 0; t < 27; ++t)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        float v = acc[t][c][o];
+        for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh, 64);
+        if (lane == 0) sred[wave][(t * 2 + c) * COUT + o] = v;
+      }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    float v = sb[o];
+    for (int sh = 32; sh > 0; sh >>= 1) v += __shfl_xor(v, sh, 64);
+    if (lane == 0) sred[wave][27 * 2 * COUT + o] = v;
+  }
+  __syncthreads();
+  constexpr int NV = 27 * 2 * COUT + COUT;
+  if (tid < NV) {
+    const float v = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+    int co, col;
+    if (tid < 27 * 2 * COUT) {
+      const int o = tid % COUT, c = (tid / COUT) % 2, t = tid / (COUT * 2);
+      co = o;
+      col = c * 27 + t;
+    } else {
+      co = tid - 27 * 2 * COUT;
+      col = 4 * 27;
+    }
+    a.part[((size_t)blockIdx.x * 16 + co) * (4 * 27 + 1) + col] = v;
+  }
+}
+
 template <int CIN, int COUT>
 static void adell_wgrad_tiny_launch(const WgSmallArgs& a, int blocks, int nbricks, int ntx, int nty,
                                     int ntz, hipStream_t st) {
@@ -365,6 +467,17 @@ extern "C" int adell_wgrad_small(const adell_conv3d_desc* d, const float* x0, co
     // three resident blocks per CU (159 registers at 2 x 2 channels): one round of blocks
     int nb = splits < 768 ? splits : 768;            // the workspace holds `splits` partial rows
     if (nb > bricks) nb = (int)bricks;
+    // rows of a multiple of four voxels, padding 1, 16-byte aligned tensors: four voxels per thread
+    if (d->C0 == 2 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->W % 4 == 0 && d->Do == d->D &&
+        d->Ho == d->H && d->Wo == d->W && ((((uintptr_t)x0) | ((uintptr_t)dy)) & 15) == 0) {
+      const long groups = (long)d->N * d->D * d->H * d->W / 4;
+      long gb = (groups + 255) / 256;
+      if (gb < nb) nb = (int)gb;
+      if (d->Cout == 2)
+        hipLaunchKernelGGL(adell_wgrad_cin2_rows_kernel<2>, dim3((unsigned)nb), dim3(256), 0, st, a, groups);
+      else
+        hipLaunchKernelGGL(adell_wgrad_cin2_rows_kernel<1>, dim3((unsigned)nb), dim3(256), 0, st, a, groups);
+    } else
     if (d->C0 == 2 && d->Cout == 2) adell_wgrad_tiny_launch<2, 2>(a, nb, (int)bricks, ntx, nty, ntz, st);
     else if (d->C0 == 2) adell_wgrad_tiny_launch<2, 1>(a, nb, (int)bricks, ntx, nty, ntz, st);
     else if (d->Cout == 2) adell_wgrad_tiny_launch<1, 2>(a, nb, (int)bricks, ntx, nty, ntz, st);
@@ -865,6 +978,112 @@ __global__ __launch_bounds__(256) void adell_cin_small_fwd_kernel(CinSmallArgs a
   }
 }
 
+// Two input channels, at most two output channels, 3x3x3, rows of a multiple of four voxels (the
+// Conv3d(2 -> 2) of the U-Net input block, unet.py:260-273: 67 MB at 2 x 128^3). The kernel above
+// gives it one voxel per thread: 27 bounds-checked 8-byte loads per voxel and a block that stages the
+// weights, folds its statistics and writes a partial row for 256 voxels -- 131 us, 0.06 of HBM time.
+// Here a thread owns FOUR consecutive voxels of a row: per (kz, ky) it loads the six voxels x - 1 ..
+// x + 4 as 16-byte pieces (36 loads per four voxels instead of 108), keeps them in registers across
+// the three kx taps, reads the 108 weights as LDS broadcasts and stores its 4 x Cout outputs as
+// 16-byte pieces; a block covers 1024 voxels (= one partial row of the statistics).
+template <int COUT>
+__global__ __launch_bounds__(256) void adell_cin2_rows_fwd_kernel(CinSmallArgs a) {
+  __shared__ __attribute__((aligned(16))) float sw[27 * 2 * 2];    // [tap][ci][co], co padded to 2
+  __shared__ float sred[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = blockIdx.z;
+  if (tid < 108) {
+    const int co = tid & 1, ci = (tid >> 1) & 1, tap = tid >> 2;
+    sw[tid] = co < COUT ? a.w[((size_t)co * 2 + ci) * 27 + tap] : 0.f;
+  }
+  __syncthreads();
+  const long vox = (long)a.Do * a.Ho * a.Wo;            // == D H W (stride 1, "same" padding)
+  const long v0 = ((long)blockIdx.x * 256 + tid) * 4;
+  const bool vok = v0 < vox;
+  const int W = a.W, H = a.H, D = a.D;
+  const int x0 = (int)(v0 % W), y = (int)((v0 / W) % H), z = (int)(v0 / ((long)W * H));
+  const float* xb = a.x + (size_t)nb * vox * 2;
+  float acc[4][2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = 0.f;
+  if (vok) {
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+      const int iz = z - 1 + kz;
+      if (iz < 0 || iz >= D) continue;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = y - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+        const float* row = xb + ((size_t)(iz * H + iy) * W) * 2;
+        // voxels x0 - 2 .. x0 + 5 as four 16-byte pieces (x0 is a multiple of 4: the middle two
+        // always lie inside the row)
+        float in[8][2];
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + (size_t)x0 * 2);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 2) * 2);
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (x0 > 0) lo = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 - 2) * 2);
+        if (x0 + 4 < W) hi = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 4) * 2);
+        in[1][0] = lo.z; in[1][1] = lo.w;
+        in[2][0] = m0.x; in[2][1] = m0.y; in[3][0] = m0.z; in[3][1] = m0.w;
+        in[4][0] = m1.x; in[4][1] = m1.y; in[5][0] = m1.z; in[5][1] = m1.w;
+        in[6][0] = hi.x; in[6][1] = hi.y;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + ((kz * 3 + ky) * 3 + kx) * 4);  // [ci][co]
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float i0 = in[1 + q + kx][0], i1 = in[1 + q + kx][1];
+            acc[q][0] = fmaf(i0, wv.x, fmaf(i1, wv.z, acc[q][0]));
+            if (COUT > 1) acc[q][1] = fmaf(i0, wv.y, fmaf(i1, wv.w, acc[q][1]));
+          }
+        }
+      }
+    }
+  }
+  const float b0 = a.bias ? a.bias[0] : 0.f, b1 = (a.bias && COUT > 1) ? a.bias[1] : 0.f;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  if (vok) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[q][0] += b0;
+      acc[q][1] += b1;
+      s1[0] += acc[q][0]; s2[0] += acc[q][0] * acc[q][0];
+      s1[1] += acc[q][1]; s2[1] += acc[q][1] * acc[q][1];
+    }
+    float* yp = a.y + ((size_t)nb * vox + v0) * COUT;
+    if (COUT == 2) {
+      *reinterpret_cast<f32x4*>(yp) = f32x4{acc[0][0], acc[0][1], acc[1][0], acc[1][1]};
+      *reinterpret_cast<f32x4*>(yp + 4) = f32x4{acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+    } else {
+      *reinterpret_cast<f32x4*>(yp) = f32x4{acc[0][0], acc[1][0], acc[2][0], acc[3][0]};
+    }
+  }
+  if (a.part) {
+    float r[4] = {s1[0], s2[0], s1[1], s2[1]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      for (int o = 32; o > 0; o >>= 1) r[k] += __shfl_xor(r[k], o, 64);
+    if (lane == 0) {
+      sred[wave][0] = r[0]; sred[wave][1] = r[1]; sred[wave][2] = r[2]; sred[wave][3] = r[3];
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      float* p = a.part + (((size_t)nb * a.tiles + blockIdx.x) * COUT + tid) * 2;
+      p[0] = (sred[0][2 * tid] + sred[1][2 * tid]) + (sred[2][2 * tid] + sred[3][2 * tid]);
+      p[1] = (sred[0][2 * tid + 1] + sred[1][2 * tid + 1]) + (sred[2][2 * tid + 1] + sred[3][2 * tid + 1]);
+    }
+  }
+}
+
+// the rows form takes: 2 input channels, <= 2 output channels, 3x3x3 taps with padding 1 (output =
+// input extents), rows of a multiple of 4 voxels, 16-byte aligned tensors (checked at the call)
+static bool adell_cin2_rows_ok(const adell_conv3d_desc* d) {
+  return d->C0 == 2 && d->C1 == 0 && d->Cout >= 1 && d->Cout <= 2 && d->KD == 3 && d->KH == 3 &&
+         d->KW == 3 && d->PD == 1 && d->PH == 1 && d->PW == 1 && d->SD == 1 && d->SH == 1 &&
+         d->SW == 1 && d->W % 4 == 0 && d->Do == d->D && d->Ho == d->H && d->Wo == d->W;
+}
+
 template <int CIN, int KD>
 __global__ __launch_bounds__(256) void adell_cin_small_bwd_data_kernel(CinSmallArgs a, int lpv) {
   constexpr int NTAP = KD * 9;
@@ -940,6 +1159,7 @@ static int adell_cin_small_lpv(int Cout) {
 
 extern "C" int adell_conv_cin_small_ntiles(const adell_conv3d_desc* d) {
   if (!d || !adell_cin_small_ok(d)) return ADELL_E_BADARG;
+  if (adell_cin2_rows_ok(d)) return (int)(((long)d->Do * d->Ho * d->Wo + 1023) / 1024);
   const int vpb = 256 / adell_cin_small_lpv(d->Cout);
   return (int)(((long)d->Do * d->Ho * d->Wo + vpb - 1) / vpb);
 }
@@ -968,6 +1188,19 @@ extern "C" int adell_conv_cin_small_fwd(const adell_conv3d_desc* d, const float*
   a.N = d->N; a.D = d->D; a.H = d->H; a.W = d->W; a.Cout = d->Cout;
   a.Do = d->Do; a.Ho = d->Ho; a.Wo = d->Wo; a.PD = d->PD; a.PH = d->PH; a.PW = d->PW;
   a.tiles = adell_conv_cin_small_ntiles(d);
+  if (adell_cin2_rows_ok(d)) {
+    // (the plan -- and with it the statistics rows -- depends on the shape only; the operands of
+    // this path are whole NDHWC tensors from the allocator: 16-byte aligned or refused)
+    ADELL_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0,
+                  "conv_cin_small_fwd: x and y must be 16-byte aligned");
+    dim3 g((unsigned)a.tiles, 1, (unsigned)d->N);
+    if (d->Cout == 2)
+      hipLaunchKernelGGL(adell_cin2_rows_fwd_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(adell_cin2_rows_fwd_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, a);
+    ADELL_CHECK_HIP(hipGetLastError());
+    return ADELL_OK;
+  }
   const int lpv = adell_cin_small_lpv(d->Cout);
   dim3 grid((unsigned)a.tiles, (unsigned)adell_cdiv(d->Cout, 64), (unsigned)d->N);
   return d->KD == 1 ? adell_cin_small_fwd_launch<1>(a, d->C0, grid, lpv, (hipStream_t)stream)

@@ -14,6 +14,12 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("n,cin,cout,size,kd,pad,bias", [(1, 2, 2, (9, 17, 21), 3, 1, True),
+                                                         # rows of a multiple of 4 voxels: the
+                                                         # four-voxels-per-thread forward (2 -> 2, 2 -> 1)
+                                                         (2, 2, 2, (9, 17, 20), 3, 1, True),
+                                                         (1, 2, 1, (6, 5, 8), 3, 1, False),
+                                                         (1, 2, 2, (5, 7, 4), 3, 1, True),
+                                                         (1, 2, 2, (40, 36, 64), 3, 1, True),
                                                          (2, 2, 32, (8, 12, 19), 3, 1, True),
                                                          (1, 1, 16, (1, 33, 30), 1, (0, 1, 1), True),
                                                          (1, 3, 40, (7, 9, 11), 3, 0, False),

@@ -328,6 +328,8 @@ def test_cpu_tensor_is_refused():
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C0,C1,size,Cout,k,p", [
     (1, 2, 0, (20, 18, 33), 32, 3, 1), (2, 2, 0, (9, 7, 5), 2, 3, 1), (1, 1, 2, (8, 8, 17), 5, 3, 1),
+    # rows of a multiple of four voxels: the four-voxels-per-thread kernel (2 -> 2, 2 -> 1)
+    (2, 2, 0, (9, 7, 8), 2, 3, 1), (1, 2, 0, (5, 6, 4), 1, 3, 1), (2, 2, 0, (24, 20, 64), 2, 3, 1),
     (1, 4, 0, (6, 6, 6), 19, 3, 1), (1, 3, 0, (7, 5, 9), 8, 1, 0), (1, 2, 0, (8, 8, 8), 16, 3, 0)])
 @pytest.mark.parametrize("prec", ["f16x3", "fp32"])
 def test_small_cin_weight_gradient(cuda, prec, N, C0, C1, size, Cout, k, p):
