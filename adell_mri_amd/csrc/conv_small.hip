@@ -1007,23 +1007,34 @@ __global__ __launch_bounds__(256) void adell_cin2_rows_fwd_kernel(CinSmallArgs a
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = 0.f;
   if (vok) {
+    // all 36 loads of the nine (kz, ky) rows first, branch-free (rows / end pieces outside the
+    // volume read a clamped address and are zeroed by a select): loads behind a branch per row
+    // waited for each other -- nine memory round trips per group of four voxels
+    f32x4 pc[9][4];
+    float rowok[9];
+    const float lok = x0 > 0 ? 1.f : 0.f, hok = x0 + 4 < W ? 1.f : 0.f;
+    const int xl = x0 > 0 ? x0 - 2 : x0, xh = x0 + 4 < W ? x0 + 4 : x0;
 #pragma unroll
-    for (int kz = 0; kz < 3; ++kz) {
-      const int iz = z - 1 + kz;
-      if (iz < 0 || iz >= D) continue;
+    for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        const int iy = y - 1 + ky;
-        if (iy < 0 || iy >= H) continue;
-        const float* row = xb + ((size_t)(iz * H + iy) * W) * 2;
-        // voxels x0 - 2 .. x0 + 5 as four 16-byte pieces (x0 is a multiple of 4: the middle two
-        // always lie inside the row)
+        const int iz = z - 1 + kz, iy = y - 1 + ky;
+        const bool ok = (iz >= 0) & (iz < D) & (iy >= 0) & (iy < H);
+        const float* row = xb + ((size_t)((ok ? iz : z) * H + (ok ? iy : y)) * W) * 2;
+        rowok[kz * 3 + ky] = ok ? 1.f : 0.f;
+        pc[kz * 3 + ky][0] = *reinterpret_cast<const f32x4*>(row + (size_t)xl * 2);
+        pc[kz * 3 + ky][1] = *reinterpret_cast<const f32x4*>(row + (size_t)x0 * 2);
+        pc[kz * 3 + ky][2] = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 2) * 2);
+        pc[kz * 3 + ky][3] = *reinterpret_cast<const f32x4*>(row + (size_t)xh * 2);
+      }
+#pragma unroll
+    for (int kz = 0; kz < 3; ++kz) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const float rk = rowok[kz * 3 + ky];
+        const f32x4 lo = pc[kz * 3 + ky][0] * (rk * lok), m0 = pc[kz * 3 + ky][1] * rk,
+                    m1 = pc[kz * 3 + ky][2] * rk, hi = pc[kz * 3 + ky][3] * (rk * hok);
         float in[8][2];
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(row + (size_t)x0 * 2);
-        const f32x4 m1 = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 2) * 2);
-        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        if (x0 > 0) lo = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 - 2) * 2);
-        if (x0 + 4 < W) hi = *reinterpret_cast<const f32x4*>(row + (size_t)(x0 + 4) * 2);
         in[1][0] = lo.z; in[1][1] = lo.w;
         in[2][0] = m0.x; in[2][1] = m0.y; in[3][0] = m0.z; in[3][1] = m0.w;
         in[4][0] = m1.x; in[4][1] = m1.y; in[5][0] = m1.z; in[5][1] = m1.w;
