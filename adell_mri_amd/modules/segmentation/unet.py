@@ -116,12 +116,22 @@ def _nearest(x, size):
     return HF.interpolate_nearest(x, size)
 
 
+class SaeBlock(torch.nn.Sequential):
+    """``Sequential(conv_block, ConcurrentSqueezeAndExcite)`` of ``conv_type="sae"``
+    (unet.py:375-397): same children / keys; the concat operand of a decoder level goes to the conv
+    block's first conv as two sources."""
+
+    def forward(self, X, X_cat=None, carry_cat=None):
+        h = self[0](X, X_cat=X_cat, carry_cat=carry_cat) if X_cat is not None else self[0](X)
+        return self[1](h)
+
+
 class _DecoderOp(torch.nn.Sequential):
     """``Sequential(conv_block, adn)`` forwarding the concat operand."""
 
     def forward(self, X, X_cat=None, carry_cat=None):
         mods = list(self)
-        if X_cat is not None and isinstance(mods[0], ConcatConvBlock):
+        if X_cat is not None and isinstance(mods[0], (ConcatConvBlock, SaeBlock)):
             h = mods[0](X, X_cat=X_cat, carry_cat=carry_cat)
         else:
             h = mods[0](X if X_cat is None else _cat_channels(X, X_cat))
@@ -204,7 +214,12 @@ class UNet(torch.nn.Module):
         elif self.conv_type == "resnet":
             self.conv_op_enc = self.res_block_conv_3d
             self.conv_op_dec = self.conv_block
+        elif self.conv_type == "sae":
+            self.conv_op_enc = self.sae_block
+            self.conv_op_dec = self.sae_block
         else:
+            # ("asp": atrous spatial pyramid pooling -- dilated convolutions, which the conv
+            # kernels do not have)
             raise NotImplementedError(
                 f"conv_type={self.conv_type!r} (spatial_dimensions={self.spatial_dimensions}) "
                 "is outside the HIP path built so far")
@@ -240,6 +255,18 @@ class UNet(torch.nn.Module):
 
     depthwise_conv_block_2d = depthwise_conv_block
     depthwise_conv_block_3d = depthwise_conv_block
+
+    def sae_block(self, in_d, out_d, kernel_size, stride=None, padding=None):
+        """conv block -> concurrent (spatial + channel) squeeze-and-excite: unet.py:375-397,
+        self_attention.py:40-149. The gate pass is one kernel (``adell_cse_apply``, the BrUNet
+        merge kernel with a single branch)."""
+        from ..layers.self_attention import (ConcurrentSqueezeAndExcite2d,
+                                             ConcurrentSqueezeAndExcite3d)
+        cse = ConcurrentSqueezeAndExcite3d if self.spatial_dimensions == 3 else ConcurrentSqueezeAndExcite2d
+        return SaeBlock(self.conv_block(in_d, out_d, kernel_size, stride, padding), cse(out_d))
+
+    sae_2d = sae_block
+    sae_3d = sae_block
 
     def res_block_conv_3d(self, in_d, out_d, kernel_size, stride=None, padding=None):
         """ResidualBlock3d / 2d (+ max pooling when strided): unet.py:309-379."""

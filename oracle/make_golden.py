@@ -101,6 +101,19 @@ ATTENTION_LINK_CASES = {
 }
 
 
+SAE_CASES = {
+    # conv_type="sae" (unet.py:375-397): conv block + ConcurrentSqueezeAndExcite in every level
+    "unet3d_sae": (dict(spatial_dimensions=3, conv_type="sae", link_type="identity",
+                        upscale_type="transpose", norm_type="instance", padding=1,
+                        dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                        depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                   (2, 2, 16, 16, 16), "uniform"),
+    "unet2d_sae": (dict(spatial_dimensions=2, conv_type="sae", link_type="conv",
+                        upscale_type="transpose", norm_type="instance", padding=1,
+                        dropout_param=0.0, activation_fn="relu", in_channels=1, n_classes=2,
+                        depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                   (2, 1, 32, 32), "normal"),
+}
 DEPTHWISE_CASES = {
     # conv_type="depthwise" (unet.py:292-307): Conv(groups = channels, k, stride) -> ADN -> 1x1 conv.
     # The constructor default padding="same" (the 1x1 conv takes the SAME padding argument, so an
@@ -1159,6 +1172,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "brunet":
         for name, (kw, shape, missing) in BRUNET_CASES.items():
             gen_brunet(name, kw, shape, missing)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "sae":
+        for name, (kw, shape, dist) in SAE_CASES.items():
+            gen_unet(name, kw, shape, dist)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attention":
         for name, (kw, shape, dist) in ATTENTION_LINK_CASES.items():

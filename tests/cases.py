@@ -35,6 +35,19 @@ DEPTHWISE_CASES = {
                              depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
 }
 
+# conv_type="sae" (unet.py:375-397: conv block + concurrent squeeze-and-excite); fixtures:
+# `python oracle/make_golden.py sae`
+SAE_CASES = {
+    "unet3d_sae": dict(spatial_dimensions=3, conv_type="sae", link_type="identity",
+                       upscale_type="transpose", norm_type="instance", padding=1,
+                       dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                       depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+    "unet2d_sae": dict(spatial_dimensions=2, conv_type="sae", link_type="conv",
+                       upscale_type="transpose", norm_type="instance", padding=1,
+                       dropout_param=0.0, activation_fn="relu", in_channels=1, n_classes=2,
+                       depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+}
+
 # link_type="attention" (unet.py:473-481); fixtures: `python oracle/make_golden.py attention`
 ATTENTION_LINK_CASES = {
     "unet3d_attention_links": dict(spatial_dimensions=3, conv_type="regular", link_type="attention",

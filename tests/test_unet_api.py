@@ -10,7 +10,7 @@ import torch
 from adell_mri_amd._lib import AdellHipError
 from adell_mri_amd.modules.activations import activation_factory
 from adell_mri_amd.modules.segmentation.unet import UNet
-from cases import DEPTHWISE_CASES, UNET_CASES
+from cases import DEPTHWISE_CASES, SAE_CASES, UNET_CASES
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -21,10 +21,10 @@ def build(kw):
     return UNet(**kw)
 
 
-@pytest.mark.parametrize("name", list(UNET_CASES) + list(DEPTHWISE_CASES))
+@pytest.mark.parametrize("name", list(UNET_CASES) + list(DEPTHWISE_CASES) + list(SAE_CASES))
 def test_state_dict_keys_and_shapes_equal_reference(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    net = build({**UNET_CASES, **DEPTHWISE_CASES}[name])
+    net = build({**UNET_CASES, **DEPTHWISE_CASES, **SAE_CASES}[name])
     sd = net.state_dict()
     assert list(sd.keys()) == [str(k) for k in g["param_keys"]]
     for k, v in sd.items():

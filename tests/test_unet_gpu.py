@@ -9,7 +9,7 @@ import torch
 
 from adell_mri_amd.modules.activations import activation_factory
 from adell_mri_amd.modules.segmentation.unet import UNet
-from cases import DEPTHWISE_CASES, UNET_CASES, grad_rel_err
+from cases import DEPTHWISE_CASES, SAE_CASES, UNET_CASES, grad_rel_err
 from oracle.torch_ref.unet import compound_loss
 from oracle.weights import tensor_for
 
@@ -116,3 +116,30 @@ def test_depthwise_unet_matches_reference(cuda, name):
             assert float(np.abs(got - ref).max()) < 1e-4 * gmax, k
         else:
             assert grad_rel_err(g, k, got) < 2e-3, k
+
+
+# ---- conv_type="sae" (unet.py:375-397): every conv block followed by a concurrent (spatial + channel)
+# squeeze-and-excite, 3-D and 2-D, against fixtures from the real reference classes ------------------
+@pytest.mark.parametrize("name", list(SAE_CASES))
+def test_sae_unet_matches_reference(cuda, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    net = build(SAE_CASES[name], cuda).eval()
+    assert [k for k, _ in net.named_parameters()] == [f[5:] for f in g.files if f.startswith("grad:")]
+    x = torch.from_numpy(g["x"]).to(cuda)
+    y = torch.from_numpy(g["y"]).to(cuda)
+    with torch.no_grad():
+        logits, _ = net(x, return_logits=True)
+    ref = g["logits"]
+    assert tuple(logits.shape) == ref.shape
+    rel = np.abs(logits.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert rel < 1e-4, rel
+    prob, _ = net(x)
+    loss = compound_loss(prob, y)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    gmax = max(float(np.abs(g[f]).max()) for f in g.files if f.startswith("grad:"))
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        ref, got = g["grad:" + k], p.grad.cpu().numpy()
+        scale = max(float(np.abs(ref).max()), 1e-3 * gmax)
+        assert float(np.abs(got - ref).max()) < 2e-3 * scale, k
