@@ -219,6 +219,8 @@ SIGNATURES = {
     "adell_dw_dense_ok": (_i, [_i] * 8 + [_vp, _vp]),
     "adell_dw_wgrad_mfma_ok": (_i, [_i] * 8 + [_vp, _vp]),
     "adell_wgrad_zring_plan": (_i, [_i] * 16 + [_vp]),
+    "adell_rowscale_fwd": (_i, [_vp] * 5 + [_i, _i, _vp]),
+    "adell_rowscale_bwd": (_i, [_vp] * 8 + [_i, _i, _vp]),
     "adell_gibbs_workspace": (_l, [_i, _i, _i, _i, _i]),
     "adell_gibbs_lowpass": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

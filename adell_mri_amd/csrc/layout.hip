@@ -869,3 +869,69 @@ extern "C" int adell_channel_max_bwd(const float* dout, const int* arg, float* d
   ADELL_CHECK_HIP(hipGetLastError());
   return ADELL_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Layer scale folded into a Linear layer (ConvNeXtBlock3d, res_blocks.py:588-604: gamma * pwconv2(h)
+// = h (gamma W)^T + gamma b): W2[c][k] = gamma[c] W[c][k], b2[c] = gamma[c] b[c] and the backward of
+// that parameter algebra -- one launch each way instead of ~10 element-wise / reduction launches of
+// a tensor library per block (15 blocks per ConvNeXt step). One block per output row c.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adell_rowscale_fwd_kernel(const float* __restrict__ gamma,
+                                                                 const float* __restrict__ W,
+                                                                 const float* __restrict__ b,
+                                                                 float* __restrict__ W2,
+                                                                 float* __restrict__ b2, int K) {
+  const int c = blockIdx.x;
+  const float g = gamma[c];
+  for (int k = threadIdx.x; k < K; k += 256) W2[(size_t)c * K + k] = g * W[(size_t)c * K + k];
+  if (threadIdx.x == 0 && b != nullptr) b2[c] = g * b[c];
+}
+
+__global__ __launch_bounds__(256) void adell_rowscale_bwd_kernel(
+    const float* __restrict__ gamma, const float* __restrict__ W, const float* __restrict__ b,
+    const float* __restrict__ dW2, const float* __restrict__ db2, float* __restrict__ dgamma,
+    float* __restrict__ dW, float* __restrict__ db, int K) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x;
+  const float g = gamma[c];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {      // fixed order per thread, fixed tree below
+    const float d = dW2[(size_t)c * K + k];
+    s = fmaf(d, W[(size_t)c * K + k], s);
+    dW[(size_t)c * K + k] = g * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (b != nullptr) {
+      t = fmaf(db2[c], b[c], t);
+      db[c] = g * db2[c];
+    }
+    dgamma[c] = t;
+  }
+}
+
+extern "C" int adell_rowscale_fwd(const float* gamma, const float* W, const float* b, float* W2,
+                                  float* b2, int C, int K, void* stream) {
+  ADELL_REQUIRE(gamma && W && W2 && C > 0 && K > 0 && (b == nullptr || b2 != nullptr),
+                "rowscale_fwd: bad arguments");
+  hipLaunchKernelGGL(adell_rowscale_fwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                     gamma, W, b, W2, b2, K);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}
+
+extern "C" int adell_rowscale_bwd(const float* gamma, const float* W, const float* b, const float* dW2,
+                                  const float* db2, float* dgamma, float* dW, float* db, int C, int K,
+                                  void* stream) {
+  ADELL_REQUIRE(gamma && W && dW2 && dgamma && dW && C > 0 && K > 0 &&
+                    (b == nullptr || (db2 != nullptr && db != nullptr)),
+                "rowscale_bwd: bad arguments");
+  hipLaunchKernelGGL(adell_rowscale_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream,
+                     gamma, W, b, dW2, db2, dgamma, dW, db, K);
+  ADELL_CHECK_HIP(hipGetLastError());
+  return ADELL_OK;
+}

@@ -18,7 +18,7 @@ import weakref
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 
 _dropout_counter = itertools.count(1)
 
@@ -1708,6 +1708,42 @@ def resize_linear_aligned(x, size):
     if nd == 2:
         return ops.interp_linear(x.unsqueeze(2), None, size=(1, *size)).squeeze(2)
     return ops.interp_linear(x[:, :, None, None], None, size=(1, 1, *size))[:, :, 0, 0]
+
+
+class _RowScaleFn(torch.autograd.Function):
+    """(gamma[:, None] * W, gamma * b) with its backward, one launch each way (adell_rowscale_*)."""
+
+    @staticmethod
+    def forward(ctx, gamma, W, b):
+        gamma, W = gamma.contiguous(), W.contiguous()
+        C, K = W.shape
+        W2 = torch.empty_like(W)
+        b2 = None if b is None else torch.empty_like(b)
+        ops.check(_lib.lib().adell_rowscale_fwd(ops._ptr(gamma), ops._ptr(W), ops._ptr(b), ops._ptr(W2),
+                                                ops._ptr(b2), C, K, ops._stream()))
+        ctx.save_for_backward(gamma, W, b)
+        return W2, b2
+
+    @staticmethod
+    def backward(ctx, dW2, db2):
+        gamma, W, b = ctx.saved_tensors
+        C, K = W.shape
+        dW2 = dW2.contiguous()
+        if b is not None and db2 is None:
+            db2 = torch.zeros_like(b)
+        dgamma, dW = torch.empty_like(gamma), torch.empty_like(W)
+        db = None if b is None else torch.empty_like(b)
+        ops.check(_lib.lib().adell_rowscale_bwd(
+            ops._ptr(gamma), ops._ptr(W), ops._ptr(b), ops._ptr(dW2),
+            None if db2 is None else ops._ptr(db2.contiguous()), ops._ptr(dgamma), ops._ptr(dW),
+            ops._ptr(db), C, K, ops._stream()))
+        return dgamma, dW, db
+
+
+def rowscale(gamma, W, b=None):
+    """Layer scale folded into a Linear layer: (gamma[:, None] * W, gamma * b) for W [C, K]."""
+    ops._require_cuda(gamma, W, b)
+    return _RowScaleFn.apply(gamma, W, b)
 
 
 class _ScaleBcFn(torch.autograd.Function):

@@ -207,8 +207,7 @@ class ConvNeXtBlock3d(torch.nn.Module):
         if self.gamma is None:
             w2, b2 = self.pwconv2.weight, self.pwconv2.bias
         else:
-            w2 = self.gamma.unsqueeze(1) * self.pwconv2.weight
-            b2 = self.gamma * self.pwconv2.bias
+            w2, b2 = HF.rowscale(self.gamma, self.pwconv2.weight, self.pwconv2.bias)
         res = inp.permute(0, 2, 3, 4, 1)
         if HF.mlp_ok(rows, self.pwconv1.weight, w2):
             # GELU inside the epilogues of pwconv1 (forward) and of the dY W2 GEMM (backward): no

@@ -931,6 +931,16 @@ int adell_dw_wgrad_mfma_ok(int N, int C, int D, int H, int W, int KD, int KH, in
 int adell_wgrad_zring_plan(int N, int D, int H, int W, int C0, int C1, int Cout, int KD, int KH,
                            int KW, int SD, int SH, int SW, int Do, int Ho, int Wo, int* plan);
 
+/* Layer scale folded into a Linear layer's parameters (ConvNeXtBlock3d, res_blocks.py:588-604:
+ * gamma * (h W^T + b) = h (gamma W)^T + gamma b): W2[c][k] = gamma[c] W[c][k], b2[c] = gamma[c] b[c]
+ * (b / b2 may be NULL), and the backward of that algebra: dW = gamma dW2, db = gamma db2,
+ * dgamma[c] = sum_k dW2[c][k] W[c][k] + db2[c] b[c]. W, W2, dW2, dW: [C][K] row-major. */
+int adell_rowscale_fwd(const float* gamma, const float* W, const float* b, float* W2, float* b2, int C,
+                       int K, void* stream);
+int adell_rowscale_bwd(const float* gamma, const float* W, const float* b, const float* dW2,
+                       const float* db2, float* dgamma, float* dW, float* db, int C, int K,
+                       void* stream);
+
 long adell_gibbs_workspace(int N, int D, int H, int W, int C);
 int adell_gibbs_lowpass(const float* x, float* out, int N, int D, int H, int W, int C,
                         const float* radius, void* workspace, size_t workspace_bytes, void* stream);

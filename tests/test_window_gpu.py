@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from adell_mri_amd import functional as HF
+from adell_mri_amd import ops
 
 
 def rel(a, r):
@@ -195,6 +196,7 @@ GATHER_CASES = [
 ]
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("axes,dims", GATHER_CASES)
 def test_gather_nd_against_index_arithmetic(cuda, axes, dims):
     """ops.gather_nd against the definition: out[coords] = in[sum_axis ((sum_d c_d mult_d + shift) mod
