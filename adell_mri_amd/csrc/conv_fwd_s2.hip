@@ -10,17 +10,26 @@
 // output brick is a 9 x 9 x 5 halo of 51 KB -- where the halo of the whole brick (17 x 17 x 9
 // voxels, 333 KB) fits no LDS, which is why the implicit-GEMM kernel runs this layer on 64-voxel
 // bricks at one wave per SIMD (0.56 ms at 2 x 128^3 for 0.1 ms of MFMA work and 0.13 ms of HBM).
-// Here a persistent block (one per CU, 8 waves: a wave alone on its SIMD issues one vector
-// instruction per 4 cycles, two waves one per 2 -- and the staging arithmetic, not memory, was what
-// the four-wave form spent its time on)
+// Here a persistent block (one per CU) of FOUR CONSUMER and FOUR PRODUCER waves (one of each per
+// SIMD, so the MFMA pipe and the vector ALU / memory pipes of a SIMD are fed by different waves --
+// the lock-step form of rounds 2-4, every wave fetching, splitting and multiplying in turn, cost
+// the SUM of its phases: loads 67 + split 37 + y stores 38 + MFMAs 25 + skeleton 50 us of 231 us
+// at 2 x 128^3, tools/fwd_s2_dbg.py):
 //   * keeps the whole split weight (27 x 32 x 32 x (hi, lo) = 108 KB) in LDS for its lifetime,
-//   * walks the eight sub-lattices of a brick: stage + split one 51 KB halo, run its taps into the
-//     SAME 2 x 16 accumulator registers per wave, while the halos of the next TWO sub-lattices are
-//     in flight in registers (a sub-lattice voxel is a full 128-byte line of x),
-//   * takes the operand scale per (brick, sub-lattice) from the block-wide absmax of the staged
-//     halo and rescales the accumulators by the exact power of two when it changes,
+//   * walks the eight sub-lattices of a brick in two half-phases each (channels 0-15, 16-31): the
+//     producers split one 26 KB half image into LDS while the consumers run the taps of the OTHER
+//     half image into 2 x 16 accumulator registers per wave (a wave owns one z plane of the brick:
+//     two 32-voxel m-tiles sharing their B fragments); one s_barrier per half-phase, no other
+//     synchronisation; the fp32 halos of the next TWO sub-lattices are in flight in the producers'
+//     registers (a sub-lattice voxel is a full 128-byte line of x),
+//   * takes the operand scale per (brick, sub-lattice) from the producers' absmax of the halo,
+//     published one barrier ahead, and rescales the accumulators by the exact power of two when it
+//     changes,
 //   * emits bias, the per-channel (sum, sum of squares) partials of the following norm and the
-//     absmax of x (for the weight-gradient kernel) like the implicit-GEMM epilogue.
+//     absmax of x (for the weight-gradient kernel) like the implicit-GEMM epilogue -- from the
+//     consumers, while the producers are already staging the next brick,
+//   * bricks are dealt in contiguous ranges per XCD (blockIdx & 7) so that neighbouring halos meet in
+//     one L2.
 // Roofline: HBM (x read once: 537 MB at 2 x 128^3, y 67 MB).
 #include <type_traits>
 #include <utility>
@@ -33,13 +42,14 @@ namespace {
 
 constexpr int kHX = 9, kHY = 9, kHZ = 5, kHV = kHX * kHY * kHZ;
 constexpr int kWBytes = 27 * 2 * 32 * 64;
-constexpr int kABytes = kHV * 128;
-constexpr int kThreads = 512, kWaves = kThreads / 64;
-constexpr int kRedFloats = 4 * 32 * 2;                       // statistics fold: [plane][channel][2]
-constexpr int kLds = kWBytes + kABytes + 64 + kRedFloats * 4;
-static_assert(kLds <= 160 * 1024, "one block per CU: weights + one halo image");
-constexpr int kItems = kHV * 8;
-constexpr int kPer = (kItems + kThreads - 1) / kThreads;
+constexpr int kImg = kHV * 64;                               // one 16-channel half image
+constexpr int kCW = 4, kPW = 4;                              // consumer / producer waves
+constexpr int kThreads = (kCW + kPW) * 64, kPThreads = kPW * 64;
+constexpr int kRedFloats = kCW * 32 * 2;                     // statistics fold: [plane][channel][2]
+constexpr int kLds = kWBytes + 2 * kImg + 64 + kRedFloats * 4;
+static_assert(kLds <= 160 * 1024, "one block per CU: weights + two half images");
+constexpr int kItems = kHV * 4;                              // 16-byte pieces of a half image
+constexpr int kPer = (kItems + kPThreads - 1) / kPThreads;   // 7 per producer thread
 
 template <typename T>
 __device__ __forceinline__ ADELL_GLOBAL T* uniform_ptr(T* p) {
@@ -74,18 +84,64 @@ struct FwdS2Args {
 }  // namespace
 
 // DBG: timing experiments (-DADELL_DEBUG builds only; results are wrong when nonzero): 1 no MFMAs,
-// 2 no y stores / statistics, 8 no halo split / LDS stores, 16 no halo loads after the first phase
+// 2 no y stores / statistics, 8 no halo split / LDS stores, 16 no halo loads after the first phases
+#define ADELL_S2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// power-of-two operand scale of a halo whose absmax is mx: multiples of 8 (the maximum lands in
+// [2^6, 2^14)), so that it rarely changes inside a brick
+__device__ __forceinline__ int fwd_s2_scale_exp(float mx) {
+  int kA = 0;
+  const int ebits = (__float_as_int(mx) >> 23) & 0xff;
+  if (ebits > 0 && ebits < 255) kA = 8 * ((13 - (ebits - 127)) >> 3);
+  if (kA > 96) kA = 96;
+  if (kA < -96) kA = -96;
+  return kA;
+}
+
+// wave-wide maximum on the DPP network (quad permutes, row mirrors, row broadcasts, one readlane):
+// __shfl_xor is a ds_bpermute per step -- six dependent LDS latencies per phase
+__device__ __forceinline__ float fwd_s2_wave_max(float v) {
+  auto step = [&](auto CTRL, auto ROWS) {
+    const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(CTRL)::value,
+                                              decltype(ROWS)::value, 0xf, false);
+    v = fmaxf(v, __int_as_float(o));
+  };
+  step(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+  step(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+  step(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+  step(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror
+  step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 -> rows 1, 3
+  step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <int DBG>
 __global__ __launch_bounds__(kThreads, 1) void adell_fwd_s2_fused_kernel(FwdS2Args a) {
   extern __shared__ char smem[];
   char* sW = smem;
-  char* sA = smem + kWBytes;
-  float* sMax = reinterpret_cast<float*>(sA + kABytes);
-  float* sRed = sMax + 16;
+  char* sA = smem + kWBytes;                                  // [2 halves][kHV][64 B]
+  float* sMax = reinterpret_cast<float*>(sA + 2 * kImg);      // [2 phases][kPW]
+  float* sRed = sMax + 16;                                    // [kCW][32][2]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int q = tid & 7;
   const int nsp = a.ntx * a.nty * a.ntz;
+
+  // bricks of this block: first, first + stride, ... (count of them); blocks b, b + 8, ... run on one
+  // XCD and share one contiguous eighth of the bricks
+  int first, stride, count;
+  if (gridDim.x >= 8) {
+    const int xcd = blockIdx.x & 7, per = (a.nbricks + 7) >> 3;
+    const int lo = xcd * per, hi = (lo + per < a.nbricks) ? lo + per : a.nbricks;
+    stride = gridDim.x >> 3;
+    first = lo + (blockIdx.x >> 3);
+    count = first < hi ? (hi - 1 - first) / stride + 1 : 0;
+  } else {
+    stride = gridDim.x;
+    first = blockIdx.x;
+    count = first < a.nbricks ? (a.nbricks - 1 - first) / stride + 1 : 0;
+  }
+  if (count == 0) return;                                 // (whole block: no barrier is skipped)
+  const int nphases = count * 8;
 
   auto brick_origin = [&](int t, int& nb, int& tile, int& ox0, int& oy0, int& oz0) {
     tile = t % nsp;
@@ -99,75 +155,6 @@ __global__ __launch_bounds__(kThreads, 1) void adell_fwd_s2_fused_kernel(FwdS2Ar
     oy0 = ty * 8;
     oz0 = tz * 4;
   };
-  // halo of sub-lattice (pz, py, px) behind brick t: halo voxel h <-> x index 2 (o0 - 1 + h) + p per axis
-  // two register images: the loads of a phase are issued two phases ahead of their use (a
-  // one-tap sub-lattice runs 12 MFMAs per wave: far less than a memory round trip)
-  float4 fbuf[2][kPer];
-  unsigned okbuf[2] = {0u, 0u};
-  // Per-item constants of this thread, computed ONCE (the staging arithmetic -- two divisions, six
-  // comparisons, the swizzled LDS address per 16 bytes -- was what the kernel spent its time on, not
-  // memory): position of item u in the halo, its element offset from the halo origin in x, its
-  // LDS byte address (hi half; the lo half is that ^ 32).
-  unsigned hpos[kPer], reloff[kPer], ldsoff[kPer];
-  unsigned okstatic = 0;
-#pragma unroll
-  for (int u = 0; u < kPer; ++u) {
-    const int it = tid + kThreads * u;
-    const bool in = it < kItems;
-    const int hv = in ? it >> 3 : 0;
-    const int hz = hv / (kHX * kHY), rem = hv - hz * (kHX * kHY);
-    const int hy = rem / kHX, hx = rem - hy * kHX;
-    hpos[u] = (unsigned)(hx | (hy << 8) | (hz << 16));
-    reloff[u] = (unsigned)((2 * hz * a.H + 2 * hy) * a.W + 2 * hx) * 32u + 4u * q;
-    const int sw = (hv >> 2) & 3, slot = (q & 3) >> 1;
-    ldsoff[u] = (unsigned)((q >> 2) * (kHV * 64) + hv * 64 + (q & 1) * 8 + ((slot ^ sw) << 4));
-    okstatic |= in ? (1u << u) : 0u;
-  }
-  // origin of the brick whose sub-lattices are being fetched (moves on with sub-lattice 0)
-  int pf_nb = 0, pf_ox0 = 0, pf_oy0 = 0, pf_oz0 = 0;
-  auto prefetch = [&](int phase, float4 (&f)[kPer], unsigned& okbits) {
-    const int cls = phase & 7;
-    if (cls == 0) {
-      int tile;
-      brick_origin(blockIdx.x + (phase >> 3) * gridDim.x, pf_nb, tile, pf_ox0, pf_oy0, pf_oz0);
-      pf_nb = __builtin_amdgcn_readfirstlane(pf_nb);
-      pf_ox0 = __builtin_amdgcn_readfirstlane(pf_ox0);
-      pf_oy0 = __builtin_amdgcn_readfirstlane(pf_oy0);
-      pf_oz0 = __builtin_amdgcn_readfirstlane(pf_oz0);
-    }
-    const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
-    const int bz = 2 * (pf_oz0 - 1) + pz, by = 2 * (pf_oy0 - 1) + py, bx = 2 * (pf_ox0 - 1) + px;
-    const ADELL_GLOBAL float* src = uniform_ptr(a.x + (size_t)pf_nb * a.D * a.H * a.W * 32);
-    // a halo that lies inside the volume (72 % of the bricks at 128^3): origin + constant offsets
-    const bool inside = (bz >= 0) & (by >= 0) & (bx >= 0) & (bz + 2 * (kHZ - 1) < a.D) &
-                        (by + 2 * (kHY - 1) < a.H) & (bx + 2 * (kHX - 1) < a.W);
-    unsigned rel[kPer];
-    if (inside) {
-      const unsigned base = (unsigned)((bz * a.H + by) * a.W + bx) * 32u;
-#pragma unroll
-      for (int u = 0; u < kPer; ++u) rel[u] = base + reloff[u];
-      okbits = okstatic | 0x80000000u;      // (bit 31: nothing to mask)
-    } else {
-      const int base = ((bz * a.H + by) * a.W + bx) * 32;
-      okbits = 0;
-#pragma unroll
-      for (int u = 0; u < kPer; ++u) {
-        const int hx = hpos[u] & 255, hy = (hpos[u] >> 8) & 255, hz = hpos[u] >> 16;
-        const int iz = bz + 2 * hz, iy = by + 2 * hy, ix = bx + 2 * hx;
-        const bool ok = ((okstatic >> u) & 1u) & (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) &
-                        (ix >= 0) & (ix < a.W);
-        rel[u] = ok ? (unsigned)(base + (int)reloff[u]) : 0u;
-        okbits |= ok ? (1u << u) : 0u;
-      }
-    }
-    // ONE fetch site for both cases (two sites meeting in a phi made the register copies wait
-    // for the loads)
-#pragma unroll
-    for (int u = 0; u < kPer; ++u) {
-      const f32x4 v = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(src + rel[u]);
-      f[u] = make_float4(v.x, v.y, v.z, v.w);
-    }
-  };
 
   // ---- the split weight, once: global row (tap * 32 + n) * 2 + chunk -> [tap][chunk][n] ---------
   // (a plain strided loop: a register array of nine rows per pass ended up in scratch memory)
@@ -179,161 +166,106 @@ __global__ __launch_bounds__(kThreads, 1) void adell_fwd_s2_fused_kernel(FwdS2Ar
     *reinterpret_cast<float4*>(sW + ((tap * 2 + ch) * 32 + n) * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v;
   }
 
-  // A rows of this lane at offset (0, 0, 0): wave w = output plane z = w & 3, rows y = 4 wm .. + 3
-  // with wm = w >> 2 (one 32-voxel m-tile per wave)
-  const int wz = wave & 3, wm = wave >> 2;
-  const int arow = (wz * kHY + (li >> 3) + 4 * wm) * kHX + (li & 7);
-  const int bsw = (li >> 2) & 3;
-  const int boffh = li * 64 + ((lh ^ bsw) << 4), boffl = li * 64 + (((2 + lh) ^ bsw) << 4);
-  const float wsc = a.wscale[li];
-  const float bcol = a.bias ? a.bias[li] : 0.f;
-  float block_max = 0.f;
-
-  const int my_bricks = ((int)blockIdx.x < a.nbricks)
-                            ? (a.nbricks - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int nphases = my_bricks * 8;
-  f32x16 acc;
-  int kprev = 0;
-  // one phase = one sub-lattice of one brick.
-  // iteration ph: issue the loads of phase ph (into register image ph & 1), run the MFMAs of phase
-  // ph - 2 out of LDS (and close its brick after the eighth sub-lattice), move phase ph - 1 from
-  // its register image to LDS. Unrolled by two so that each image has ONE fetch site.
-  auto step = [&](int ph, auto BUF) __attribute__((always_inline)) {
-    constexpr int B = decltype(BUF)::value;
-    if (ph < nphases && !((DBG & 16) && ph > 1)) prefetch(ph, fbuf[B], okbuf[B]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ph > 1) {
-      const int cls = (ph - 2) & 7;
-      // ---- taps of sub-lattice cls: per axis parity 0 -> tap 1 at offset 1; parity 1 -> tap 0 at
-      // offset 0 and tap 2 at offset 1 (offsets in the halo whose origin is o0 - 1)
-      static_for<8>([&](auto CLS) {
-        constexpr int c = decltype(CLS)::value;
-        if (cls == c) {
-          constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
-          static_for<2>([&](auto CH) {
-            constexpr int ch = decltype(CH)::value;
-            const char* sAc = sA + ch * (kHV * 64);
-            static_for<8>([&](auto T) {
-              constexpr int tb = decltype(T)::value;   // bit a: the second tap of axis a (parity 1 only)
-              constexpr int sz = tb >> 2, sy = (tb >> 1) & 1, sx = tb & 1;
-              if constexpr ((sz <= pz) && (sy <= py) && (sx <= px) && !(DBG & 1)) {
-                constexpr int tz = pz ? 2 * sz : 1, ty = py ? 2 * sy : 1, tx = px ? 2 * sx : 1;
-                constexpr int dz = pz ? sz : 1, dy = py ? sy : 1, dx = px ? sx : 1;
-                constexpr int tap = (tz * 3 + ty) * 3 + tx;
-                const int hv = arow + (dz * kHY + dy) * kHX + dx;
-                const int sw = (hv >> 2) & 3;
-                const char* row = sAc + hv * 64;
-                const half8 ah = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
-                const half8 al = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
-                const char* bt = sW + (tap * 2 + ch) * (32 * 64);
-                const half8 bh = *reinterpret_cast<const half8*>(bt + boffh);
-                const half8 bl = *reinterpret_cast<const half8*>(bt + boffl);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-              }
-            });
-          });
-        }
-      });
-      if (cls == 7) {
-        // ---- epilogue of the brick: C row r = output (x = (r & 3) + 4 lh, y = (r >> 2) + 4 wm)
-        const int t = blockIdx.x + ((ph - 2) >> 3) * gridDim.x;
-        int nb, tile, ox0, oy0, oz0;
-        brick_origin(t, nb, tile, ox0, oy0, oz0);
-        const float oscale = __int_as_float((127 - kprev) << 23) * wsc;
-        const int z = oz0 + wz;
-        float s1 = 0.f, s2 = 0.f;
-        if (z < a.Do && !(DBG & 2)) {
+  if (wave >= kCW) {
+    // =================================== producers ==============================================
+    const int ptid = tid - kCW * 64, pw = wave - kCW;
+    // Per-item constants of this thread, computed ONCE: position of item u in the halo (item = one
+    // 16-byte piece of a half row: voxel j >> 2, channels 4 (j & 3) ... of the half), its element
+    // offset from the halo origin in x, its LDS byte address (hi half; the lo half is that ^ 32).
+    // A thread past the end of the half image (items 1620 .. 1791 of its last round) repeats items
+    // 0 .. 171: the same bytes to the same LDS address as their owner -- no per-item branch.
+    // (ldsoff: bits 0-15 the LDS address, 16-19 / 20-23 / 24-27 the halo position x / y / z)
+    unsigned reloff[kPer], ldsoff[kPer];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int x = ox0 + (r & 3) + 4 * lh, yy = oy0 + (r >> 2) + 4 * wm;
-            if (x < a.Wo && yy < a.Ho) {
-              const float v = acc[r] * oscale + bcol;
-              a.y[((((size_t)nb * a.Do + z) * a.Ho + yy) * a.Wo + x) * 32 + li] = v;
-              s1 += v;
-              s2 += v * v;
-            }
-          }
-        }
-        if (a.part) {
-          // fold in a fixed order: lane halves, then the two row groups of a plane (waves w + 4
-          // hand theirs to waves w through sRed), then the four planes
-          s1 += __shfl_xor(s1, 32, 64);
-          s2 += __shfl_xor(s2, 32, 64);
-          if (lh == 0 && wm == 1) {
-            sRed[(wz * 32 + li) * 2 + 0] = s1;
-            sRed[(wz * 32 + li) * 2 + 1] = s2;
-          }
-          __syncthreads();
-          if (lh == 0 && wm == 0) {
-            sRed[(wz * 32 + li) * 2 + 0] += s1;
-            sRed[(wz * 32 + li) * 2 + 1] += s2;
-          }
-          __syncthreads();
-          if (tid < 32) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              t1 += sRed[(w * 32 + tid) * 2 + 0];
-              t2 += sRed[(w * 32 + tid) * 2 + 1];
-            }
-            float* p = a.part + (((size_t)nb * nsp + tile) * 32 + tid) * 2;
-            p[0] = t1;
-            p[1] = t2;
-          }
-        }
-      }
+    for (int u = 0; u < kPer; ++u) {
+      int j = ptid + kPThreads * u;
+      j = j < kItems ? j : j - kItems;
+      const int hv = j >> 2, q4 = j & 3;
+      const int hz = hv / (kHX * kHY), rem = hv - hz * (kHX * kHY);
+      const int hy = rem / kHX, hx = rem - hy * kHX;
+      reloff[u] = (unsigned)((2 * hz * a.H + 2 * hy) * a.W + 2 * hx) * 32u + 4u * q4;
+      const int sw = (hv >> 2) & 3;
+      ldsoff[u] = (unsigned)(hv * 64 + (q4 & 1) * 8 + (((q4 >> 1) ^ sw) << 4)) |
+                  (unsigned)((hx << 16) | (hy << 20) | (hz << 24));
     }
-    if (ph > 0 && ph - 1 < nphases) {
-      float4 (&f)[kPer] = fbuf[1 - B];
-      const unsigned okbits = okbuf[1 - B];
-      // ---- mask, absmax -> power-of-two scale of this sub-lattice halo ----------------------------
-      // (an image fetched from inside the volume needs no mask: the items past the end of the
-      // halo were read from its first voxel and change no maximum)
-      float mx = 0.f;
-      if (!(okbits >> 31)) {
+    // two register images (phases p and p + 1), each as two halves of kPer pieces
+    float4 raw[2][2][kPer];
+    unsigned okbuf[2] = {0u, 0u};
+    int pf_nb = 0, pf_ox0 = 0, pf_oy0 = 0, pf_oz0 = 0;
+    // loads of phase p into f (both halves of a 128-byte line by neighbouring instructions: issued
+    // half a phase apart the second half missed the vector cache again); moves the brick origin
+    // with sub-lattice 0 and sets okbits
+    auto issue = [&](int p, float4 (&f)[2][kPer], unsigned& okbits) {
+      const int cls = p & 7;
+      if (cls == 0) {
+        int tile;
+        brick_origin(first + (p >> 3) * stride, pf_nb, tile, pf_ox0, pf_oy0, pf_oz0);
+        pf_nb = __builtin_amdgcn_readfirstlane(pf_nb);
+        pf_ox0 = __builtin_amdgcn_readfirstlane(pf_ox0);
+        pf_oy0 = __builtin_amdgcn_readfirstlane(pf_oy0);
+        pf_oz0 = __builtin_amdgcn_readfirstlane(pf_oz0);
+      }
+      const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+      const int bz = 2 * (pf_oz0 - 1) + pz, by = 2 * (pf_oy0 - 1) + py, bx = 2 * (pf_ox0 - 1) + px;
+      const ADELL_GLOBAL float* src = uniform_ptr(a.x + (size_t)pf_nb * a.D * a.H * a.W * 32);
+      // a halo that lies inside the volume (72 % of the bricks at 128^3): origin + constant offsets
+      const bool inside = (bz >= 0) & (by >= 0) & (bx >= 0) & (bz + 2 * (kHZ - 1) < a.D) &
+                          (by + 2 * (kHY - 1) < a.H) & (bx + 2 * (kHX - 1) < a.W);
+      unsigned rel[kPer];
+      unsigned ok = 0;
+      if (inside) {
+        const unsigned base = (unsigned)((bz * a.H + by) * a.W + bx) * 32u;
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) rel[u] = base + reloff[u];
+        ok = 0x80000000u;                 // (bit 31: nothing to mask)
+      } else {
+        const int base = ((bz * a.H + by) * a.W + bx) * 32;
 #pragma unroll
         for (int u = 0; u < kPer; ++u) {
-          const bool ok = (okbits >> u) & 1u;
-          f[u] = make_float4(ok ? f[u].x : 0.f, ok ? f[u].y : 0.f, ok ? f[u].z : 0.f, ok ? f[u].w : 0.f);
+          const int hx = (ldsoff[u] >> 16) & 15, hy = (ldsoff[u] >> 20) & 15, hz = ldsoff[u] >> 24;
+          const int iz = bz + 2 * hz, iy = by + 2 * hy, ix = bx + 2 * hx;
+          const bool v = (iz >= 0) & (iz < a.D) & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);
+          rel[u] = v ? (unsigned)(base + (int)reloff[u]) : 0u;
+          ok |= v ? (1u << u) : 0u;
         }
       }
-#pragma unroll
-      for (int u = 0; u < kPer; ++u)
-        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f[u].x)), fmaxf(fabsf(f[u].y), fabsf(f[u].z))), fabsf(f[u].w));
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      // (two sMax rows used in turn: a row is rewritten two phases after it was read, with a
-      // barrier in between, so one barrier serves "fragments of phase ph - 2 are read" and "the
-      // four wave maxima are visible")
-      float* sm = sMax + kWaves * (ph & 1);
-      if (lane == 0) sm[wave] = mx;
-      __syncthreads();
-      mx = fmaxf(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])),
-                 fmaxf(fmaxf(sm[4], sm[5]), fmaxf(sm[6], sm[7])));
-      block_max = fmaxf(block_max, mx);
-      int kA = 0;
-      {
-        const int ebits = (__float_as_int(mx) >> 23) & 0xff;
-        // multiples of 8 (max lands in [2^6, 2^14)): the scale rarely changes inside a brick
-        if (ebits > 0 && ebits < 255) kA = 8 * ((13 - (ebits - 127)) >> 3);
-        if (kA > 96) kA = 96;
-        if (kA < -96) kA = -96;
-      }
-      if (((ph - 1) & 7) == 0) {   // first sub-lattice of a brick: fresh accumulators
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      } else if (kA != kprev) {
-        const float fix = __int_as_float((kA - kprev + 127) << 23);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= fix;
-      }
-      kprev = kA;
-      const float scaleA = __int_as_float((kA + 127) << 23);
+      okbits = ok;
+      // ONE fetch site for both cases (two sites meeting in a phi made the register copies wait
+      // for the loads)
 #pragma unroll
       for (int u = 0; u < kPer; ++u) {
-        if (((okstatic >> u) & 1u) && !(DBG & 8)) {
+        const f32x4 v0 = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(src + rel[u]);
+        const f32x4 v1 = *reinterpret_cast<const ADELL_GLOBAL f32x4*>(src + rel[u] + 16);
+        f[0][u] = make_float4(v0.x, v0.y, v0.z, v0.w);
+        f[1][u] = make_float4(v1.x, v1.y, v1.z, v1.w);
+      }
+    };
+    // mask (in place) and absmax of a landed register image -> this wave's slot of sMax row `row`
+    // (an image fetched from inside the volume needs no mask)
+    auto publish_max = [&](float4 (&f)[2][kPer], unsigned okbits, int row) {
+      float mx = 0.f;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (!(okbits >> 31)) {
+#pragma unroll
+          for (int u = 0; u < kPer; ++u) {
+            const bool ok = (okbits >> u) & 1u;
+            f[c][u] = make_float4(ok ? f[c][u].x : 0.f, ok ? f[c][u].y : 0.f, ok ? f[c][u].z : 0.f,
+                                  ok ? f[c][u].w : 0.f);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u)
+          mx = fmaxf(fmaxf(fmaxf(mx, fabsf(f[c][u].x)), fmaxf(fabsf(f[c][u].y), fabsf(f[c][u].z))),
+                     fabsf(f[c][u].w));
+      }
+      mx = fwd_s2_wave_max(mx);
+      if (lane == 0) sMax[row * kPW + pw] = mx;
+    };
+    auto convert = [&](const float4 (&f)[kPer], float scaleA, char* img) {
+#pragma unroll
+      for (int u = 0; u < kPer; ++u) {
+        if (!(DBG & 8)) {
           const float v[4] = {f[u].x * scaleA, f[u].y * scaleA, f[u].z * scaleA, f[u].w * scaleA};
           half4 h, l;
 #pragma unroll
@@ -341,18 +273,173 @@ __global__ __launch_bounds__(kThreads, 1) void adell_fwd_s2_fused_kernel(FwdS2Ar
             h[j] = (_Float16)v[j];
             l[j] = (_Float16)(v[j] - (float)h[j]);
           }
-          *reinterpret_cast<half4*>(sA + ldsoff[u]) = h;
-          *reinterpret_cast<half4*>(sA + (ldsoff[u] ^ 32u)) = l;
+          const unsigned off = ldsoff[u] & 0xffffu;
+          *reinterpret_cast<half4*>(img + off) = h;
+          *reinterpret_cast<half4*>(img + (off ^ 32u)) = l;
         }
       }
-      __syncthreads();
+    };
+
+    float block_max = 0.f;
+    // (every load of the loop is issued unconditionally -- past the last phase it fetches the last
+    // phase again -- so that the counted waits the compiler derives hold on every path: a
+    // conditional issue made every wait a vmcnt(0) and left no load in flight across the barriers)
+    issue(0, raw[0], okbuf[0]);
+    issue(1, raw[1], okbuf[1]);
+    publish_max(raw[0], okbuf[0], 0);
+    ADELL_S2_BARRIER();                                   // weights + the first absmax are in LDS
+    // iteration p: halves of phase p from register image p & 1 to LDS (a barrier after each), the
+    // loads of phase p + 2 into the registers just freed, the absmax of phase p + 1
+    auto pstep = [&](int p, auto BUF) __attribute__((always_inline)) {
+      constexpr int B = decltype(BUF)::value;
+      const float* sm = sMax + kPW * (p & 1);
+      const float mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      block_max = fmaxf(block_max, mx);
+      const float scaleA = __int_as_float((fwd_s2_scale_exp(mx) + 127) << 23);
+      const int pn = p + 2 < nphases ? p + 2 : nphases - 1;
+      convert(raw[B][0], scaleA, sA);
+      ADELL_S2_BARRIER();
+      convert(raw[B][1], scaleA, sA + kImg);
+      if (!((DBG & 16) && p > 1)) issue(pn, raw[B], okbuf[B]);
+      publish_max(raw[1 - B], okbuf[1 - B], (p + 1) & 1);
+      ADELL_S2_BARRIER();
+    };
+    for (int p = 0; p < nphases; p += 2) {                // (nphases is a multiple of 8)
+      pstep(p, std::integral_constant<int, 0>{});
+      pstep(p + 1, std::integral_constant<int, 1>{});
+    }
+    ADELL_S2_BARRIER();                                   // the consumers' last statistics rows
+    if (a.amax_out != nullptr && ptid == 0) atomicMax(a.amax_out, __float_as_uint(block_max));
+    return;
+  }
+
+  // ===================================== consumers ================================================
+  // wave w = output plane z = w of the brick: m-tile mt = rows y = 4 mt .. 4 mt + 3 (32 voxels)
+  const int wz = wave;
+  int arow[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) arow[mt] = (wz * kHY + (li >> 3) + 4 * mt) * kHX + (li & 7);
+  const int bsw = (li >> 2) & 3;
+  const int boffh = li * 64 + ((lh ^ bsw) << 4), boffl = li * 64 + (((2 + lh) ^ bsw) << 4);
+  const float wsc = a.wscale[li];
+  const float bcol = a.bias ? a.bias[li] : 0.f;
+  f32x16 acc[2];
+  int kprev = 0;
+
+  // taps of sub-lattice cls on half image CH: per axis parity 0 -> tap 1 at offset 1; parity 1 ->
+  // tap 0 at offset 0 and tap 2 at offset 1 (offsets in the halo whose origin is o0 - 1)
+  auto taps = [&](int cls, auto CHT) __attribute__((always_inline)) {
+    constexpr int ch = decltype(CHT)::value;
+    const char* sAc = sA + ch * kImg;
+    static_for<8>([&](auto CLS) {
+      constexpr int c = decltype(CLS)::value;
+      if (cls == c) {
+        constexpr int pz = c >> 2, py = (c >> 1) & 1, px = c & 1;
+        static_for<8>([&](auto T) {
+          constexpr int tb = decltype(T)::value;   // bit a: the second tap of axis a (parity 1 only)
+          constexpr int sz = tb >> 2, sy = (tb >> 1) & 1, sx = tb & 1;
+          if constexpr ((sz <= pz) && (sy <= py) && (sx <= px) && !(DBG & 1)) {
+            constexpr int tz = pz ? 2 * sz : 1, ty = py ? 2 * sy : 1, tx = px ? 2 * sx : 1;
+            constexpr int dz = pz ? sz : 1, dy = py ? sy : 1, dx = px ? sx : 1;
+            constexpr int tap = (tz * 3 + ty) * 3 + tx;
+            const char* bt = sW + (tap * 2 + ch) * (32 * 64);
+            const half8 bh = *reinterpret_cast<const half8*>(bt + boffh);
+            const half8 bl = *reinterpret_cast<const half8*>(bt + boffl);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+              const int hv = arow[mt] + (dz * kHY + dy) * kHX + dx;
+              const int sw = (hv >> 2) & 3;
+              const char* row = sAc + hv * 64;
+              const half8 ah = *reinterpret_cast<const half8*>(row + ((lh ^ sw) << 4));
+              const half8 al = *reinterpret_cast<const half8*>(row + (((2 + lh) ^ sw) << 4));
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mt], 0, 0, 0);
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mt], 0, 0, 0);
+            }
+          }
+        });
+      }
+    });
+  };
+  // statistics rows of brick i: the four planes' sums (sRed, written by the epilogue before the last
+  // barrier) folded in plane order by the first 32 lanes of consumer wave 0
+  auto fold_stats = [&](int i) {
+    if (a.part && tid < 32 && !(DBG & 2)) {
+      int nb, tile, ox0, oy0, oz0;
+      brick_origin(first + i * stride, nb, tile, ox0, oy0, oz0);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < kCW; ++w) {
+        t1 += sRed[(w * 32 + tid) * 2 + 0];
+        t2 += sRed[(w * 32 + tid) * 2 + 1];
+      }
+      float* p = a.part + (((size_t)nb * nsp + tile) * 32 + tid) * 2;
+      p[0] = t1;
+      p[1] = t2;
     }
   };
-  for (int ph = 0; ph <= nphases + 1; ph += 2) {
-    step(ph, std::integral_constant<int, 0>{});
-    step(ph + 1, std::integral_constant<int, 1>{});
+
+  ADELL_S2_BARRIER();                                     // weights + the first absmax are in LDS
+  for (int p = 0; p < nphases; ++p) {
+    const int cls = p & 7;
+    {
+      const float* sm = sMax + kPW * (p & 1);
+      const float mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+      const int kA = fwd_s2_scale_exp(mx);
+      if (cls == 0) {   // first sub-lattice of a brick: fresh accumulators
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      } else if (kA != kprev) {
+        const float fix = __int_as_float((kA - kprev + 127) << 23);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][r] *= fix;
+      }
+      kprev = kA;
+    }
+    ADELL_S2_BARRIER();                                   // half image 0 of phase p is in LDS
+    if (cls == 0 && p > 0) fold_stats((p >> 3) - 1);
+    taps(cls, std::integral_constant<int, 0>{});
+    ADELL_S2_BARRIER();                                   // half image 1
+    taps(cls, std::integral_constant<int, 1>{});
+    if (cls == 7) {
+      // ---- epilogue of the brick: C row r of m-tile mt = output (x = (r & 3) + 4 lh,
+      // y = (r >> 2) + 4 mt) of plane wz
+      int nb, tile, ox0, oy0, oz0;
+      brick_origin(first + (p >> 3) * stride, nb, tile, ox0, oy0, oz0);
+      const float oscale = __int_as_float((127 - kprev) << 23) * wsc;
+      const int z = oz0 + wz;
+      float s1 = 0.f, s2 = 0.f;
+      if (z < a.Do && !(DBG & 2)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int x = ox0 + (r & 3) + 4 * lh, yy = oy0 + (r >> 2) + 4 * mt;
+            if (x < a.Wo && yy < a.Ho) {
+              const float v = acc[mt][r] * oscale + bcol;
+              a.y[((((size_t)nb * a.Do + z) * a.Ho + yy) * a.Wo + x) * 32 + li] = v;
+              s1 += v;
+              s2 += v * v;
+            }
+          }
+      }
+      if (a.part) {
+        // fixed order: rows of a lane (m-tile 0 then 1), lane halves, then (fold_stats) the planes
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lh == 0) {
+          sRed[(wz * 32 + li) * 2 + 0] = s1;
+          sRed[(wz * 32 + li) * 2 + 1] = s2;
+        }
+      }
+    }
   }
-  if (a.amax_out != nullptr && tid == 0) atomicMax(a.amax_out, __float_as_uint(block_max));
+  ADELL_S2_BARRIER();                                     // the last brick's statistics rows
+  if (count > 0) fold_stats(count - 1);
 }
 
 namespace {
@@ -418,7 +505,8 @@ extern "C" int adell_conv3d_fwd_s2_fused(const adell_conv3d_desc* d, const float
   const long nbricks = (long)d->N * a.ntx * a.nty * a.ntz;
   ADELL_REQUIRE(nbricks < 0x0fffffffL, "conv_fwd_s2_fused: too many bricks");
   a.nbricks = (int)nbricks;
-  const int grid = (int)(nbricks < cu_count() ? nbricks : cu_count());   // one block per CU
+  int grid = (int)(nbricks < cu_count() ? nbricks : cu_count());   // one block per CU
+  if (grid >= 8) grid &= ~7;                                       // whole blocks per XCD
   auto launch = [&](auto kern) -> int {
     ADELL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds));

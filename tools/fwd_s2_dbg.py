@@ -1,7 +1,6 @@
 """Where the one-launch stride-2 forward kernel spends its time: the -DADELL_DEBUG build of
-csrc/conv_fwd_s2.hip (adell_mri_amd/csrc/_dbg/libfs2dbg.so: `hipcc -O3 -DADELL_DEBUG -std=c++17 -fPIC
---offload-arch=gfx950 -shared api.hip conv_fwd_s2.hip`) with phases switched off (results are wrong
-then). bits: 1 no MFMAs, 2 no y stores, 8 no halo split, 16 no halo loads after the first phases."""
+csrc/conv_fwd_s2.hip (adell_mri_amd/libadellhip_dbg.so, `bash tools/build_dbg.sh`) with phases
+switched off (results are wrong then). bits: 1 no MFMAs, 2 no y stores, 8 no halo split, 16 no halo loads after the first phases."""
 import ctypes
 import json
 import os
@@ -16,8 +15,8 @@ from adell_mri_amd import ops  # noqa: E402
 edge = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 here = os.path.dirname(os.path.abspath(__file__))
-L = ctypes.CDLL(os.path.join(here, "..", "adell_mri_amd", "csrc", "_dbg", "libfs2dbg.so"))
-L.adell_conv3d_fwd_s2_fused.argtypes = [ctypes.c_void_p] * 9
+L = ctypes.CDLL(os.path.join(here, "..", "adell_mri_amd", "libadellhip_dbg.so"))
+L.adell_conv3d_fwd_s2_fused.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int] + [ctypes.c_void_p] * 2
 dev = torch.device("cuda:0")
 size = (edge,) * 3
 w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
