@@ -96,6 +96,7 @@ SIGNATURES = {
     "adell_convtranspose3d_k2s2_bwd_data": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "adell_stats_finalize_workspace": (_l, [_i, _i, _i]),
     "adell_stats_finalize": (_i, [_vp, _i, _i, _i, _l, _f, _i, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "adell_bn_running_update": (_i, [_vp] * 5 + [_i, _l, _f, _f, _vp]),
     "adell_channel_partials_ntiles": (_i, [_l]),
     "adell_channel_partials": (_i, [_vp, _i, _l, _i, _vp, _vp]),
     "adell_norm_act_fwd": (_i, [ctypes.POINTER(NormActDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -221,6 +222,7 @@ SIGNATURES = {
     "adell_wgrad_zring_plan": (_i, [_i] * 16 + [_vp]),
     "adell_rowscale_fwd": (_i, [_vp] * 5 + [_i, _i, _vp]),
     "adell_rowscale_bwd": (_i, [_vp] * 8 + [_i, _i, _vp]),
+    "adell_window_ndhwc": (_i, [_vp, _vp] + [_i] * 11 + [_vp]),
     "adell_gibbs_workspace": (_l, [_i, _i, _i, _i, _i]),
     "adell_gibbs_lowpass": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, ctypes.c_size_t, _vp]),
     "adell_gather_nd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -1054,15 +1054,10 @@ def norm_drop_act(x, *, norm="none", eps=1e-5, gamma=None, beta=None, running=No
                 part = ops.channel_partials(x.detach())
             mean, rstd = ops.stats_finalize(part, V, eps, per_item=False)
             if training and running is not None and running[0] is not None:
-                with torch.no_grad():
-                    rm, rv, nbt = running
-                    n = N * V
-                    var = (1.0 / (rstd * rstd) - eps) * (n / max(n - 1, 1))
-                    if nbt is not None:
-                        nbt += 1
-                    mom = momentum if momentum is not None else 1.0 / float(nbt)
-                    rm.mul_(1 - mom).add_(mean, alpha=mom)
-                    rv.mul_(1 - mom).add_(var, alpha=mom)
+                rm, rv, nbt = running
+                if nbt is None and momentum is None:
+                    raise ValueError("BatchNorm with momentum=None needs num_batches_tracked")
+                ops.bn_running_update(mean, rstd, rm, rv, nbt, N * V, eps, momentum)
         else:
             # running statistics are constants, not functions of x: fold them into the affine
             # pair (y = x * (rstd gamma) + (beta - mean rstd gamma)) so that the backward is the
@@ -1738,6 +1733,30 @@ class _RowScaleFn(torch.autograd.Function):
             None if db2 is None else ops._ptr(db2.contiguous()), ops._ptr(dgamma), ops._ptr(dW),
             ops._ptr(db), C, K, ops._stream()))
         return dgamma, dW, db
+
+
+class _CropFn(torch.autograd.Function):
+    """Centre window of a volume as a dense tensor, and a zero frame around the gradient: one launch
+    each way (adell_window_ndhwc) where slicing + ``contiguous`` + ``slice_backward`` ran a strided
+    copy, three zero-fills and four more strided copies."""
+
+    @staticmethod
+    def forward(ctx, x, out_size, offset):
+        x = ops.ndhwc(x)
+        ctx.in_size, ctx.offset = tuple(x.shape[2:]), tuple(offset)
+        return ops.window_ndhwc(x, out_size, offset)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = ops.ndhwc(dy)
+        return ops.window_ndhwc(dy, ctx.in_size, tuple(-o for o in ctx.offset)), None, None
+
+
+def crop3d(x, out_size):
+    """crop_to_size of a [N, C, D, H, W] volume (layers/utils.py:30-52: offset ``diff // 2`` per axis)."""
+    ops._require_cuda(x)
+    offset = [(cur - out) // 2 for cur, out in zip(x.shape[2:], out_size)]
+    return _CropFn.apply(x, tuple(int(v) for v in out_size), tuple(offset))
 
 
 def rowscale(gamma, W, b=None):

@@ -10,6 +10,12 @@ def crop_to_size(X: torch.Tensor, output_size: List[int]) -> torch.Tensor:
     Same window as adell_mri/modules/layers/utils.py:30-52 (offset ``diff // 2``),
     expressed as a strided view instead of ``index_select`` copies.
     """
+    rows = getattr(X, "_adell_rows", None)
+    if (X.dim() == 5 and X.is_cuda and rows is None and X.dtype == torch.float32
+            and tuple(X.shape[2:]) != tuple(output_size)):
+        from ... import functional as HF
+
+        return HF.crop3d(X, output_size)        # one kernel each way instead of a strided view
     sl = [slice(None), slice(None)]
     for cur, out in zip(X.shape[2:], output_size):
         a = (cur - out) // 2
@@ -17,7 +23,6 @@ def crop_to_size(X: torch.Tensor, output_size: List[int]) -> torch.Tensor:
     out = X[tuple(sl)]
     # a spatial crop of a split-row tensor (functional.expect_rows) keeps whole voxels, i.e. whole
     # rows: still a split-row tensor
-    rows = getattr(X, "_adell_rows", None)
     if rows is not None and out is not X:
         out._adell_rows = rows
     return out

@@ -204,6 +204,33 @@ def ndhwc(x):
     return xp.permute(0, 4, 1, 2, 3)
 
 
+def bn_running_update(mean, rstd, running_mean, running_var, num_batches_tracked, count, eps,
+                      momentum):
+    """torch.nn.BatchNorm running statistics in training, in place, from the batch (mean, rstd) of
+    stats_finalize(per_item=False) over ``count`` elements per channel (csrc/norm_act.hip)."""
+    _require_cuda(mean, rstd, running_mean, running_var)
+    nbt = num_batches_tracked
+    if nbt is not None and (not nbt.is_cuda or nbt.dtype != torch.int64):
+        raise _lib.AdellHipError("num_batches_tracked must be an int64 device tensor")
+    check(_lib.lib().adell_bn_running_update(
+        _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+        None if nbt is None else ctypes.c_void_p(nbt.data_ptr()), int(mean.numel()), int(count),
+        float(eps), -1.0 if momentum is None else float(momentum), _stream()))
+
+
+def window_ndhwc(x, out_size, offset):
+    """out[n, :, d, h, w] = x[n, :, d + od, h + oh, w + ow] where that voxel exists, zeros elsewhere
+    (csrc/layout.hip): ``x`` a dense-NDHWC [N, C, D, H, W] tensor; returns a dense-NDHWC tensor of the
+    spatial size ``out_size``. Crop (positive offsets) and its gradient (negative offsets)."""
+    _require_cuda(x)
+    N, C, D, H, W = x.shape
+    Do, Ho, Wo = (int(v) for v in out_size)
+    out = new_act(N, C, Do, Ho, Wo, x.device)
+    check(_lib.lib().adell_window_ndhwc(_ptr(x), _ptr(out), N, C, D, H, W, Do, Ho, Wo,
+                                        int(offset[0]), int(offset[1]), int(offset[2]), _stream()))
+    return out
+
+
 def new_act(N, C, D, H, W, device):
     return torch.empty((N, D, H, W, C), device=device, dtype=torch.float32).permute(0, 4, 1, 2, 3)
 

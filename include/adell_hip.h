@@ -322,6 +322,14 @@ int adell_stats_finalize(const float* partials, int N, int ntiles, int C,
                          long count, float eps, int per_item, float* mean,
                          float* rstd, void* workspace, size_t workspace_bytes,
                          void* stream);
+
+/* Running statistics of a BatchNorm site in training, from the batch (mean, rstd) of
+ * adell_stats_finalize(per_item = 0) over `count` elements per channel (torch.nn.BatchNorm3d:
+ * running = (1 - m) running + m batch, with the unbiased variance; num_batches_tracked (int64, may be
+ * NULL) += 1; momentum < 0: the cumulative average m = 1 / num_batches_tracked). One launch. */
+int adell_bn_running_update(const float* mean, const float* rstd, float* running_mean,
+                            float* running_var, long long* num_batches_tracked, int C, long count,
+                            float eps, float momentum, void* stream);
 /* Partials of an arbitrary tensor x [N][V][C] (same buffer format). */
 int adell_channel_partials_ntiles(long V);
 int adell_channel_partials(const float* x, int N, long V, int C, float* partials,
@@ -940,6 +948,13 @@ int adell_rowscale_fwd(const float* gamma, const float* W, const float* b, float
 int adell_rowscale_bwd(const float* gamma, const float* W, const float* b, const float* dW2,
                        const float* db2, float* dgamma, float* dW, float* db, int C, int K,
                        void* stream);
+
+/* Spatial window of a dense channels-last volume: out[n][d][h][w][:] = in[n][d + od][h + oh][w + ow][:]
+ * where that voxel exists, zeros elsewhere (in [N][Di][Hi][Wi][C], out [N][Do][Ho][Wo][C]). Positive
+ * offsets and a smaller output: crop_to_size (adell_mri/modules/layers/utils.py:30-52); negative
+ * offsets and a larger output: its gradient (a zero frame around dY). */
+int adell_window_ndhwc(const float* in, float* out, int N, int C, int Di, int Hi, int Wi, int Do, int Ho,
+                       int Wo, int od, int oh, int ow, void* stream);
 
 long adell_gibbs_workspace(int N, int D, int H, int W, int C);
 int adell_gibbs_lowpass(const float* x, float* out, int N, int D, int H, int W, int C,

@@ -416,3 +416,54 @@ def test_residual_block_link_gradient_rides_the_head_conv(cuda):
         # no gradient wanted for X: no carry, the block still runs
         with torch.no_grad():
             assert torch.equal(blk(x0), out["carry"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,size,out", [(64, (10, 12, 14), (8, 9, 14)), (6, (7, 7, 9), (6, 5, 5)),
+                                        (3, (5, 6, 7), (4, 6, 6)), (32, (9, 9, 9), (9, 9, 9))])
+def test_crop3d_against_slicing(cuda, C, size, out):
+    """functional.crop3d (adell_window_ndhwc both ways) against the strided view of crop_to_size
+    (layers/utils.py:30-52): values and the zero-framed gradient, bit for bit."""
+    from adell_mri_amd import functional as HF
+    from adell_mri_amd.modules.layers.utils import crop_to_size
+
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn((2, C, *size), generator=g)
+    sl = [slice(None), slice(None)] + [slice((c - o) // 2, (c - o) // 2 + o) for c, o in zip(size, out)]
+    xr = x.clone().requires_grad_(True)
+    ref = xr[tuple(sl)]
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    xg = ops.ndhwc(x.to(cuda)).requires_grad_(True)
+    got = crop_to_size(xg, list(out))
+    if tuple(size) != tuple(out):
+        assert got.permute(0, 2, 3, 4, 1).is_contiguous()
+    (got * w.to(cuda)).sum().backward()
+    assert torch.equal(got.detach().cpu(), ref.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+    assert torch.equal(HF.crop3d(xg.detach(), out).cpu(), ref.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("momentum", [0.1, None])
+def test_batchnorm_running_statistics_against_torch(cuda, momentum):
+    """Two training passes through functional.norm_drop_act(norm="batch") update running_mean /
+    running_var / num_batches_tracked as torch.nn.BatchNorm3d does (adell_bn_running_update: one
+    launch per site), with momentum 0.1 and with the cumulative average (momentum=None)."""
+    from adell_mri_amd import functional as HF
+
+    C = 6
+    ref = torch.nn.BatchNorm3d(C, momentum=momentum)
+    ref.train()
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    nbt = torch.zeros((), dtype=torch.int64, device=cuda)
+    g = torch.Generator().manual_seed(3)
+    for step in range(2):
+        x = torch.randn((2, C, 5, 6, 7), generator=g) * (1.0 + step) + 0.5 * step
+        want = ref(x)
+        got = HF.norm_drop_act(ops.ndhwc(x.to(cuda)), norm="batch", eps=ref.eps, running=(rm, rv, nbt),
+                               momentum=momentum, training=True)
+        assert _relerr(_np(got), _np(want.detach())) < 2e-6
+    assert int(nbt) == 2 and int(ref.num_batches_tracked) == 2
+    assert _relerr(_np(rm), _np(ref.running_mean)) < 1e-6
+    assert _relerr(_np(rv), _np(ref.running_var)) < 1e-6

@@ -39,8 +39,12 @@ export ADELL_WGRAD_STREAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/unetr -- python3 $R/tools/bench_unetr.py --steps 6 --warmup 2 > $O/unetr_line.json 2> $O/unetr.err || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ssl -- python3 $R/tools/bench_ssl.py --batch 32 --steps 6 --warmup 2 > $O/ssl_line.json 2> $O/ssl.err || true
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/swin -- python3 $R/tools/bench_swin.py --steps 4 --warmup 2 > $O/swin_line.json 2> $O/swin.err || true
+export ADELL_BENCH_ONLY=cfg2b_resnet_backbone_128
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg2b -- python3 $R/tools/secondary_only.py > $O/cfg2b_line.txt 2> $O/cfg2b.err || true
+unset ADELL_BENCH_ONLY
 unset ADELL_WGRAD_STREAM
 cd $R
+python3 tools/trace_stats.py $O/cfg2b > $O/backbone_unet_kernel_stats.txt 2>&1 || true
 python3 tools/trace_stats.py $O/unetr > $O/unetr_kernel_stats.txt 2>&1 || true
 python3 tools/trace_stats.py $O/ssl > $O/ssl_convnext_kernel_stats.txt 2>&1 || true
 python3 tools/trace_stats.py $O/swin > $O/swinunet_kernel_stats.txt 2>&1 || true
