@@ -92,9 +92,15 @@ def test_nearest_resample_and_concat_match_torch(cuda, insz, outsz):
 @pytest.mark.parametrize("size,k,s,p", [((8, 8, 8), 2, 2, 1), ((9, 7, 5), 3, 2, 1),
                                         ((8, 8, 8), 2, 2, 0), ((6, 6, 5), (2, 2, 1), (2, 2, 1), (1, 1, 0)),
                                         ((5, 5, 5), 3, 1, 1)])
-def test_maxpool3d_fwd_bwd_matches_torch(cuda, size, k, s, p):
+@pytest.mark.parametrize("C,ties", [(6, False), (8, False), (8, True)])
+def test_maxpool3d_fwd_bwd_matches_torch(cuda, size, k, s, p, C, ties):
+    """(C = 8 with kernel == stride: the 16-bytes-of-channels row kernels; ties: integer-valued
+    inputs, the first maximum in scan order takes the gradient as in torch)"""
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 6, *size, generator=g).requires_grad_(True)
+    x = torch.randn(2, C, *size, generator=g)
+    if ties:
+        x = torch.round(x)
+    x.requires_grad_(True)
     ref = torch.nn.functional.max_pool3d(x, k, s, p)
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
