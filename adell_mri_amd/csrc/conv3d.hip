@@ -443,7 +443,9 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
       // layers leave half the chip without a block: 32 -> 32 at 2 x 32^3 30 -> 20 us)
       if (vox >= 4096 && vox < 262144) pick = 1;
     } else if (vox < 4096)
-      pick = 6;
+      // (512 -> 512 at 9 x 9 x 33, the bottom level of the ResNet-backbone U-Net: every 64-voxel
+      // brick streams 1.8 MB of weights per 32 columns -- 851 us; 256-voxel x 64-column bricks 279 us)
+      pick = (a.Cin >= 512 && vox >= 2048) ? 0 : 6;
     else if (vox < 32768)
       pick = a.Cin >= 256 ? 1 : 3;
     else if (vox < 262144 && a.Cout <= 64)

@@ -360,6 +360,11 @@ def timed_steps(runner, batch, steps, barrier, per_step_events=True, timer=None,
 CONFIGS_DIR = os.path.join(ROOT, "configs")
 
 
+# tools/native_ops.py: a callable (key, runner, batch) -> entry run INSTEAD of the timed steps of a
+# secondary workload (after its warm-up steps)
+PROBE = None
+
+
 def other_config_runs(device, rank, world, barrier, reduce_max):
     """BASELINE configs 3, 4 and 5 at the sizes SURVEY.md 8(d) gives them, each built from its YAML
     through the factory the entrypoint uses (as tests/test_fullsize_configs_gpu.py does): 3 warm-up
@@ -446,6 +451,11 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
             for _ in range(4):
                 runner.train_step(batch)
             barrier()
+            if PROBE is not None:
+                out[key] = PROBE(key, runner, batch)
+                del runner, opt, net, batch
+                torch.cuda.empty_cache()
+                continue
             runner.reserve_memory()
             dt, loss, per = timed_steps(runner, batch, 5, barrier)
             rec = step_record(per, list(LAST_DIAG))

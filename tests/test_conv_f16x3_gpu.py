@@ -68,6 +68,33 @@ def test_conv3d_fwd_f16x3(cuda, N, Cin, size, Cout, k, s, p, cfg, xs, ws):
                                atol=1e-4 * xs * ws)
 
 
+@pytest.mark.gpu
+def test_wide_bottom_level_plan_against_torch(cuda):
+    """512 input channels on 2 048 .. 4 095 voxels (the 9 x 9 x 33 bottom level of the ResNet-backbone
+    U-Net, csrc/conv3d.hip adell_plan_f16: 256-voxel x 64-column bricks instead of the two-wave
+    64 x 32 ones): forward with statistics and backward-data against torch's fp64 convolution."""
+    g = torch.Generator().manual_seed(5)
+    N, Cin, size, Cout = 1, 512, (9, 9, 26), 64
+    x = torch.randn((N, Cin, *size), generator=g)
+    w = torch.randn((Cout, Cin, 3, 3, 3), generator=g) / np.sqrt(Cin * 27)
+    b = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv3d(x.double(), w.double(), b.double(), 1, 1)
+    wp = ops.pack_weight_f16x3(w.to(cuda), 0)
+    y, part = ops.conv3d_fwd(ops.ndhwc(x.to(cuda)), wp, b.to(cuda), Cout, 3, 1, 1, want_stats=True)
+    assert _relerr(_np(y), ref.detach().numpy()) < 5e-6
+    mean, _ = ops.stats_finalize(part, int(np.prod(size)), 1e-5)
+    np.testing.assert_allclose(_np(mean), ref.detach().reshape(N, Cout, -1).mean(-1).numpy(), rtol=1e-3,
+                               atol=1e-4)
+    # backward-data of a 64 -> 512 conv: the gradient operand has the 512 channels
+    w2 = torch.randn((Cin, Cout, 3, 3, 3), generator=g) / np.sqrt(Cin * 27)
+    dy = torch.randn((N, Cin, *size), generator=g)
+    xd = torch.zeros((N, Cout, *size), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(xd, w2.double(), None, 1, 1).backward(dy.double())
+    wpb = ops.pack_weight_f16x3(w2.to(cuda), 1)
+    dx, _ = ops.conv3d_bwd_data(ops.ndhwc(dy.to(cuda)), wpb, size, Cout, 0, 3, 1, 1)
+    assert _relerr(_np(dx), xd.grad.numpy()) < 5e-6
+
+
 @pytest.mark.parametrize("N,Cin,size,Cout,k,s,p,gs", [
     (1, 32, (8, 8, 8), 32, 3, 1, 1, 1.0), (1, 16, (16, 16, 16), 24, 3, 2, 1, 1e-8),
     (1, 8, (9, 9, 9), 8, 3, 2, 1, 1.0), (2, 2, (8, 8, 8), 32, 3, 1, 1, 1e-7)])

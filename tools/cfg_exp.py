@@ -1,18 +1,20 @@
 """Forward time of one conv shape under each forced tile configuration (adell_debug_force_conv_cfg).
-usage: cfg_exp.py Cin Cout size batch [k] [stride]"""
+usage: cfg_exp.py Cin Cout size|DxHxW batch [k] [stride]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from adell_mri_amd import _lib, ops
-cin, cout, sz, batch = (int(v) for v in sys.argv[1:5])
+cin, cout, batch = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[4])
+dims = [int(v) for v in sys.argv[3].split("x")]
+dims = dims * 3 if len(dims) == 1 else dims
 k = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 s = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 dev = torch.device("cuda:0")
-x = ops.ndhwc(torch.randn(batch, cin, sz, sz, sz, device=dev))
+x = ops.ndhwc(torch.randn(batch, cin, *dims, device=dev))
 w = torch.randn(cout, cin, k, k, k, device=dev) * 0.05
 b = torch.randn(cout, device=dev)
 wp = ops.pack_weight_f16x3(w, 0)
-flops = 2.0 * batch * (sz // s) ** 3 * cin * cout * k ** 3
+flops = 2.0 * batch * (dims[0] // s) * (dims[1] // s) * (dims[2] // s) * cin * cout * k ** 3
 for _ in range(300):   # clock ramp: the first ~100 ms of load run slow
     ops.conv3d_fwd(x, wp, b, cout, k, s, k // 2, want_stats=True)
 torch.cuda.synchronize()
