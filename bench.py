@@ -428,15 +428,17 @@ def other_config_runs(device, rank, world, barrier, reduce_max):
 
     out = {}
     # config 3 is ~800 launches of 10-60 us per step: eager, the host's enqueue time is as long as the
-    # step (round 4's driver record: host 24.9 ms of a 26.8 ms step). After its eager timed steps the
-    # same step is replayed from ONE captured HIP graph (StepRunner.enable_graph: forward + loss +
-    # backward + gradient gather; the optimiser launch stays eager) and recorded as
-    # `hip_graph_replay`: 2 ms of host time per step, ~1 ms MORE GPU time than an eager step the host
-    # keeps up with (measured on one box, alternating: 21.3 vs 20.1-20.4 ms) -- so `value` stays the
-    # eager figure. Single rank only: under DDP the bucketed all-reduce is issued from backward
-    # hooks, which a replay does not run. (Config 4: hipStreamEndCapture of its step crashes inside
-    # the runtime on this ROCm build -- DESIGN.md, known gaps.)
-    graphed = {"cfg3_unetr_96"} if world == 1 and not os.environ.get("ADELL_BENCH_NO_GRAPH") else set()
+    # step (round 4's driver record: host 24.9 ms of a 26.8 ms step). With ADELL_BENCH_GRAPH=1 the same
+    # step is also replayed from ONE captured HIP graph after its eager timed steps
+    # (StepRunner.enable_graph: forward + loss + backward + gradient gather; the optimiser launch stays
+    # eager) and recorded as `hip_graph_replay`: 2 ms of host time per step, ~1 ms MORE GPU time than an
+    # eager step the host keeps up with (21.3 vs 20.1-20.4 ms, profiles/r05a_bench_line.json) -- `value`
+    # is the eager figure either way. NOT run by default: hipStreamEndCapture of a whole training step
+    # segfaults inside the ROCm runtime on some boxes of this pool (config 4's step always; config 3's
+    # replayed fine all morning and crashed on four boxes in a row in the afternoon, on the very commit
+    # that had recorded it), and a segfault would take the headline line down with it.
+    graphed = ({"cfg3_unetr_96"} if world == 1 and os.environ.get("ADELL_BENCH_GRAPH")
+               and not os.environ.get("ADELL_BENCH_NO_GRAPH") else set())
     for key, build in (("cfg2b_resnet_backbone_128", build_cfg2b_entry),
                        ("cfg3_unetr_96", build_cfg3), ("cfg4_vicreg_convnext_64", build_cfg4),
                        ("cfg5_swinunet_256x256x128", build_cfg5)):

@@ -5,11 +5,31 @@ inputs, and back to eager steps afterwards. Reference loop: lightning.Trainer.fi
 ops (adell_mri/entrypoints/segmentation/train.py:799-819)."""
 import copy
 import itertools
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# hipStreamEndCapture of a whole training step segfaults INSIDE the ROCm runtime on some boxes of
+# this pool (config 4's step always, config 3's on some days: the same commit and binary replayed
+# fine in the morning and crashed in the afternoon -- DESIGN.md, known gaps). A segfault would take
+# the whole test process down, so every capture runs in a child process: a child that dies inside
+# capture_end skips the test with that reason; any other failure fails it.
+
+
+def _in_child(name, *args):
+    env = dict(os.environ, ADELL_CHECK_DENSE="1")
+    r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__), name, *map(str, args)],
+                       capture_output=True, text=True, timeout=600, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if r.returncode < 0 and "capture_end" in r.stderr:
+        pytest.skip("hipStreamEndCapture crashed inside the ROCm runtime on this box (signal "
+                    f"{-r.returncode}); the replay path could not be exercised here")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def _unetr(cuda, dropout_rate):
@@ -40,6 +60,10 @@ def _batches(cuda, n):
 
 @pytest.mark.parametrize("dropout_rate", [0.1, 0.0])
 def test_replayed_steps_equal_eager_steps_bit_for_bit(cuda, dropout_rate):
+    _in_child("replayed_steps_equal_eager_steps", dropout_rate)
+
+
+def replayed_steps_equal_eager_steps(cuda, dropout_rate):
     from adell_mri_amd import functional as HF
     from adell_mri_amd import ops
     from adell_mri_amd.parallel import GradSync
@@ -100,3 +124,8 @@ def test_graph_mode_refuses_hooked_gradient_buckets(cuda):
     sync.overlap = True          # what a world of > 1 ranks sets up
     with pytest.raises(RuntimeError, match="backward hooks"):
         StepRunner(net, opt, sync).enable_graph(_batches(cuda, 1)[0])
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    globals()[sys.argv[1]](torch.device("cuda:0"), *[float(v) for v in sys.argv[2:]])
