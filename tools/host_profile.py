@@ -1,7 +1,7 @@
-#!/usr/bin/env python
-"""cProfile of the host side of the headline training step (where the ~18 ms of enqueue time
-per step go)."""
+"""Host-side cost of a secondary config's training step by Python function (cProfile over 5 steps
+after bench.py's warm-up): ADELL_BENCH_ONLY=cfg3_unetr_96 python tools/host_profile.py"""
 import cProfile
+import io
 import os
 import pstats
 import sys
@@ -10,23 +10,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from adell_mri_amd.parallel import GradSync  # noqa: E402
-from adell_mri_amd.trainer import StepRunner  # noqa: E402
 
-dev = torch.device("cuda", 0)
-net = bench.build_module(dev, 128)
-net.train()
-opt = net.configure_optimizers()["optimizer"]
-runner = StepRunner(net, opt, GradSync(opt))
-batch = bench.synthetic_batch(2, 128, dev, 42)
-for _ in range(3):
-    runner.train_step(batch)
-torch.cuda.synchronize()
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(5):
-    runner.train_step(batch)
-pr.disable()
-torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+
+def probe(key, runner, batch):
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        runner.train_step(batch)
+    pr.disable()
+    torch.cuda.synchronize()
+    out = io.StringIO()
+    st = pstats.Stats(pr, stream=out)
+    st.sort_stats("tottime").print_stats(45)
+    print(f"==== {key} (5 steps)")
+    print(out.getvalue()[:9000])
+    return {}
+
+
+bench.PROBE = probe
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+bench.other_config_runs(dev, 0, 1, torch.cuda.synchronize, lambda v, d: float(v))
