@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256, 2) void adell_conv_wgrad_zring_kernel(WgradZrA
   char* sYl = sYh + 2 * 64 * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int region = blockIdx.x;
+  // consecutive blocks go round-robin to the 8 XCDs (one L2 each): an XCD takes a contiguous eighth
+  // of the regions, i.e. neighbouring columns, whose 10 x 10 input halos then meet in one L2 (the
+  // blocks of one region over the channel tiles share an XCD already: R is a multiple of 8)
+  const int region = (a.R & 7) == 0 ? (int)((blockIdx.x & 7) * (a.R >> 3) + (blockIdx.x >> 3))
+                                    : (int)blockIdx.x;
   const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
   const int ci0 = cit * 32, co0 = cot * 32;
 
@@ -395,7 +399,8 @@ __global__ __launch_bounds__(256, 3) void adell_conv_wgrad_zring16_kernel(WgradZ
   char* sYh = sXl + ZR_SLOTS * Z16_XPLANE;            // [2 steps][8 x 12 rows][16 halfs]
   char* sYl = sYh + 2 * Z16_YPLANE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int region = blockIdx.x;
+  const int region = (a.R & 7) == 0 ? (int)((blockIdx.x & 7) * (a.R >> 3) + (blockIdx.x >> 3))
+                                    : (int)blockIdx.x;   // (XCD-contiguous regions, see above)
   const int cit = blockIdx.y % a.nci, cot = blockIdx.y / a.nci;
   const int ci0 = cit * 16, co0 = cot * 16;
 

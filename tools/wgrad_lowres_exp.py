@@ -25,9 +25,10 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for C, size in ((512, (9, 9, 33)), (512, (17, 17, 65)), (256, (17, 17, 65)), (128, (33, 33, 65)),
+for C, size in ((32, (128, 128, 128)), (64, (128, 128, 128)), (64, (64, 64, 64)), (128, (32, 32, 32)),
+                (512, (9, 9, 33)), (512, (17, 17, 65)), (256, (17, 17, 65)), (128, (33, 33, 65)),
                 (128, (65, 65, 65)), (256, (8, 8, 8)), (128, (16, 16, 16))):
-    N = 2 if size[0] in (8, 16) else 1
+    N = 2 if size[0] in (8, 16, 32, 64, 128) else 1
     x = ops.ndhwc(torch.randn(N, C, *size, device=dev))
     dy = ops.ndhwc(torch.randn(N, C, *size, device=dev))
     flops = 2.0 * N * size[0] * size[1] * size[2] * C * C * 27
