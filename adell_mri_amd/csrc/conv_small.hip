@@ -163,7 +163,15 @@ __global__ __launch_bounds__(1024) void adell_wgrad_small_reduce_kernel(
     co = (int)(i / (Cin * K3 + 1));
     e = (int)(i % (Cin * K3 + 1));
     const int col = e < Cin * K3 ? e : 4 * K3;   // (ci, tap) slots are laid out ci-major
-    for (int sp = vl; sp < splits; sp += 16) s += (double)part[((size_t)sp * coPad + co) * rowlen + col];
+    int sp = vl;
+    for (; sp + 7 * 16 < splits; sp += 8 * 16) {       // eight loads in flight, same order of additions
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[((size_t)(sp + 16 * u) * coPad + co) * rowlen + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; sp < splits; sp += 16) s += (double)part[((size_t)sp * coPad + co) * rowlen + col];
   }
   sh[vl][cl] = s;
   __syncthreads();
@@ -752,8 +760,19 @@ __global__ __launch_bounds__(1024) void adell_conv1_small_wgrad_fold_kernel(
   const int n = Cout * (Cin + 1);
   const int e = blockIdx.x * 64 + cl;
   double s = 0.0;
-  if (e < n)
-    for (int b = vl; b < nb; b += 16) s += (double)part[(size_t)b * n + e];
+  if (e < n) {
+    // (eight independent loads in flight, added in the same order: 128 dependent round trips made
+    // this fold of 33 values 43 us long)
+    int b = vl;
+    for (; b + 7 * 16 < nb; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 16 * u) * n + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < nb; b += 16) s += (double)part[(size_t)b * n + e];
+  }
   sh[vl][cl] = s;
   __syncthreads();
   if (vl != 0 || e >= n) return;

@@ -598,8 +598,17 @@ __global__ __launch_bounds__(1024) void adell_colsum_final_kernel(
   const int cl = threadIdx.x & 63, vl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   double s = 0.0;
-  if (c < C)
-    for (int b = vl; b < nb; b += 16) s += (double)part[(size_t)b * C + c];
+  if (c < C) {
+    int b = vl;
+    for (; b + 7 * 16 < nb; b += 8 * 16) {             // eight loads in flight, same order of additions
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 16 * u) * C + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < nb; b += 16) s += (double)part[(size_t)b * C + c];
+  }
   sh[vl][cl] = s;
   __syncthreads();
   if (vl != 0 || c >= C) return;
