@@ -958,7 +958,9 @@ void adell_conv_igemm_f16_kernel(ConvArgs a, ConvF16Extra e) {
 // the canonical layout's innermost axis -- into LDS when they fit, and both passes (absmax, split)
 // index the LDS copy; reading them k-fastest from global memory touched every 128-byte line ~27
 // times: 323 MB fetched per step to repack 33 MB of weights)
-constexpr int kPackLds = 8192;   // floats: 27 taps x 256 channels and 343 taps x 16 fit
+// (27 taps x 512 channels: the 512-channel layers of the ResNet-backbone U-Net fell off the staged
+// path at 8192 floats and their repack took 0.98 ms of every config-2b step)
+constexpr int kPackLds = 14336;  // floats (56 KB): 27 taps x 512 channels, 125 x 64 and 343 x 16 fit
 __device__ __forceinline__ void adell_pack_weight_f16_column(
     const float* __restrict__ w, _Float16* __restrict__ out, float* __restrict__ wscale,
     int mode, int A, int B, int taps, int n, float* smx) {
