@@ -232,33 +232,42 @@ __global__ __launch_bounds__(256) void adell_gemm_reduce_flat_kernel(GemmArgs a)
 //                 order by adell_gemm_reduce_kernel (deterministic).
 constexpr int GEMM_SMALL = 32;
 
+constexpr int GEMM_ROWS_K = 64;       // rows kernel: K <= 64, N <= 32, N K <= 512
+
 template <bool BKC>
 __global__ __launch_bounds__(256) void adell_gemm_rows_small_kernel(GemmArgs a) {
   // a thread per OUTPUT element (m, n): the N lanes of a row read the same K inputs (one
-  // transaction, broadcast) and store N contiguous floats; weights [n][k] and bias in LDS
-  __shared__ float sw[GEMM_SMALL * GEMM_SMALL + GEMM_SMALL];
-  const int K = a.K, N = a.N;
+  // transaction, broadcast) and store N contiguous floats; weights [n][k] (rows padded by four
+  // floats: a stride of 32 floats put every n on one bank) and bias in LDS
+  __shared__ __attribute__((aligned(16))) float sw[GEMM_SMALL * (GEMM_ROWS_K + 4) + GEMM_SMALL];
+  const int K = a.K, N = a.N, KP = K + 4;
   for (int i = threadIdx.x; i < N * K; i += 256) {
     const int n = i / K, k = i - n * K;
-    sw[i] = BKC ? a.B[(long)n * a.ldb + k] : a.B[(long)k * a.ldb + n];
+    sw[n * KP + k] = BKC ? a.B[(long)n * a.ldb + k] : a.B[(long)k * a.ldb + n];
   }
-  for (int i = threadIdx.x; i < N; i += 256) sw[GEMM_SMALL * GEMM_SMALL + i] = a.bias ? a.bias[i] : 0.f;
+  float* sb = sw + GEMM_SMALL * (GEMM_ROWS_K + 4);
+  for (int i = threadIdx.x; i < N; i += 256) sb[i] = a.bias ? a.bias[i] : 0.f;
   __syncthreads();
   const bool vk = a.a_vec && (K & 3) == 0;
   const long total = (long)a.M * N;
+  // (N a power of two -- every caller's is --: shift and mask instead of a 64-bit division per
+  // output, which cost more than the whole dot product of a 2- or 8-feature row)
+  const bool pow2 = (N & (N - 1)) == 0;
+  const int nshift = __ffs(N) - 1;
   for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
-    const long m = e / N;
-    const int n = (int)(e - m * N);
+    const long m = pow2 ? (e >> nshift) : e / N;
+    const int n = pow2 ? (int)(e & (N - 1)) : (int)(e - m * N);
     const float* ar = a.A + m * a.lda;
-    const float* wr = sw + n * K;
-    float s = sw[GEMM_SMALL * GEMM_SMALL + n];
+    const float* wr = sw + n * KP;
+    float s = sb[n];
     if (vk) {
       for (int k = 0; k < K; k += 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(ar + k);
-        s = fmaf(v.x, wr[k], s);
-        s = fmaf(v.y, wr[k + 1], s);
-        s = fmaf(v.z, wr[k + 2], s);
-        s = fmaf(v.w, wr[k + 3], s);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+        s = fmaf(v.x, w.x, s);
+        s = fmaf(v.y, w.y, s);
+        s = fmaf(v.z, w.z, s);
+        s = fmaf(v.w, w.w, s);
       }
     } else {
       for (int k = 0; k < K; ++k) s = fmaf(ar[k], wr[k], s);
@@ -389,7 +398,9 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   const int tall = (!a_kc && !b_kc) ? adell_gemm_tall_blocks(M, N, K) : 0;
   // (measured on SWIN-UNet's shapes: 10x / 5x for 8 -> 2 / 2 -> 8 features at 8.4 M rows; from
   // N K = 256 on the MFMA tiles are as fast or faster, 32 x 8 at 2 M rows 180 vs 250 us)
-  const bool rows_small = a_kc && K <= GEMM_SMALL && N <= GEMM_SMALL && (long)N * K <= 64 && M >= 65536;
+  // (round 5: without the 64-bit division per output the thread-per-output kernel wins up to
+  // N K = 512 -- 2 097 152 x 8 x 32: 249 us on the tiles)
+  const bool rows_small = a_kc && K <= GEMM_ROWS_K && N <= GEMM_SMALL && (long)N * K <= 512 && M >= 65536;
   ADELL_REQUIRE(rows_small || (tall ? workspace != nullptr : (p.splits == 1 || workspace)),
                 "gemm: workspace required for this shape");
   GemmArgs a;

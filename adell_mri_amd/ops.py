@@ -92,7 +92,8 @@ FLAGS = {"no_cinfold": bool(os.environ.get("ADELL_NO_CINFOLD")),
          # Linear layers on the f16x3 GEMM (1.2-2x the fp32-MFMA GEMM per launch) when both output
          # sides are >= 64: measured per step (bench.py secondary, alternating runs on one box) UNETR
          # 22.6 -> 21.8 ms, VICReg ConvNeXt 27.7 -> 24.8 ms, SWIN-UNet 198 -> 197.5 ms; with every
-         # size SWIN's narrow projections (24 ... 48 wide) lose 1 %. ADELL_GEMM_F16X3=0: fp32-MFMA
+         # size SWIN's narrow projections (24 ... 48 wide) lose 1 % (round 3; round 5: 32-wide layers
+         # over >= 64 k rows are streaming problems and take it too, gemm_f16x3_ok). ADELL_GEMM_F16X3=0: fp32-MFMA
          # GEMMs everywhere; =1: every applicable size (ADELL_GEMM_F16X3_MIN_K / _MIN_MN: knobs).
          "gemm_f16x3": os.environ.get("ADELL_GEMM_F16X3", "auto") != "0",
          "gemm_f16x3_min_k": int(os.environ.get("ADELL_GEMM_F16X3_MIN_K", "0")),
@@ -1721,7 +1722,8 @@ def gemm(M, N, K, A, lda, a_kc, B, ldb, b_kc, out=None, bias=None, residual=None
         check(_lib.lib().adell_gemm_f32(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb, int(b_kc),
                                         _ptr(out), N, _ptr(bias), _ptr(residual), ldr, _ptr(ws),
                                         _stream()))
-    _timed("adell_gemm_f32_kernel", 2.0 * M * N * K, run, None,
+    _timed("adell_gemm_f32_kernel", 2.0 * M * N * K, run,
+           lambda: f"{M}x{N}x{K} {'kc' if a_kc else 'outer'}/{'kc' if b_kc else 'outer'}",
            4.0 * (M * K + K * N + M * N * (2 if residual is not None else 1)))
     return out
 
@@ -1737,7 +1739,16 @@ def absmax_word(x):
 
 
 def gemm_f16x3_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc):
-    if not FLAGS["gemm_f16x3"] or K < FLAGS["gemm_f16x3_min_k"] or min(M, N) < FLAGS["gemm_f16x3_min_mn"]:
+    if not FLAGS["gemm_f16x3"] or K < FLAGS["gemm_f16x3_min_k"]:
+        return False
+    if min(M, N) < FLAGS["gemm_f16x3_min_mn"]:
+        # below the threshold only the streaming regime: >= 32 on both output sides and >= 64 k rows
+        # along M or K (524 288 x 32 x 128: 178 -> 66 us on the rows kernel; its dW 188 -> 103 us)
+        if FLAGS["gemm_f16x3_min_mn"] != 64 or min(M, N) < 32 or max(M, K) < 65536:
+            return False
+    # a handful of features over >= 64 k rows: the thread-per-output kernel of adell_gemm_f32
+    # (csrc/gemm.hip, rows_small) streams them; 128-wide MFMA tiles run 2 097 152 x 32 x 8 at 1.3 TB/s
+    if a_kc and K <= 64 and N <= 32 and N * K <= 512 and M >= 65536:
         return False
     return bool(_lib.lib().adell_gemm_f16x3_applicable(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb,
                                                        int(b_kc)))
