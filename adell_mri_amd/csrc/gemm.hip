@@ -232,23 +232,63 @@ __global__ __launch_bounds__(256) void adell_gemm_reduce_flat_kernel(GemmArgs a)
 //                 order by adell_gemm_reduce_kernel (deterministic).
 constexpr int GEMM_SMALL = 32;
 
-constexpr int GEMM_ROWS_K = 64;       // rows kernel: K <= 64, N <= 32, N K <= 512
+constexpr int GEMM_ROWS_K = 64, GEMM_ROWS_N = 64;   // rows kernel: K <= 64, N <= 64, N K <= 512
+constexpr int GEMM_ROWS_W = 512 + 4 * GEMM_ROWS_N;    // weight image: N rows of K + 4 floats
 
 template <bool BKC>
 __global__ __launch_bounds__(256) void adell_gemm_rows_small_kernel(GemmArgs a) {
   // a thread per OUTPUT element (m, n): the N lanes of a row read the same K inputs (one
   // transaction, broadcast) and store N contiguous floats; weights [n][k] (rows padded by four
   // floats: a stride of 32 floats put every n on one bank) and bias in LDS
-  __shared__ __attribute__((aligned(16))) float sw[GEMM_SMALL * (GEMM_ROWS_K + 4) + GEMM_SMALL];
+  __shared__ __attribute__((aligned(16))) float sw[GEMM_ROWS_W + GEMM_ROWS_N];
   const int K = a.K, N = a.N, KP = K + 4;
   for (int i = threadIdx.x; i < N * K; i += 256) {
     const int n = i / K, k = i - n * K;
     sw[n * KP + k] = BKC ? a.B[(long)n * a.ldb + k] : a.B[(long)k * a.ldb + n];
   }
-  float* sb = sw + GEMM_SMALL * (GEMM_ROWS_K + 4);
+  float* sb = sw + GEMM_ROWS_W;
   for (int i = threadIdx.x; i < N; i += 256) sb[i] = a.bias ? a.bias[i] : 0.f;
   __syncthreads();
   const bool vk = a.a_vec && (K & 3) == 0;
+  // N in fours: a thread per (row, four outputs) -- a quarter of the row loads and 16-byte stores
+  // (8 388 608 x 8 x 2 spent its time on 4-byte stores and two loads per output)
+  if ((N & 3) == 0 && (N & (N - 1)) == 0 && (a.ldc & 3) == 0 && (((uintptr_t)a.C) & 15) == 0 &&
+      (!a.residual || ((a.ldr & 3) == 0 && (((uintptr_t)a.residual) & 15) == 0))) {
+    const int qshift = __ffs(N) - 3;                  // log2(N / 4)
+    const long total4 = (long)a.M << qshift;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total4; e += (long)gridDim.x * 256L) {
+      const long m = e >> qshift;
+      const int n = (int)(e & ((N >> 2) - 1)) << 2;
+      const float* ar = a.A + m * a.lda;
+      const float* w0 = sw + n * KP;
+      f32x4 s = {sb[n], sb[n + 1], sb[n + 2], sb[n + 3]};
+      if (vk) {
+        for (int k = 0; k < K; k += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ar + k);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(w0 + j * KP + k);
+            s[j] = fmaf(v.x, w.x, s[j]);
+            s[j] = fmaf(v.y, w.y, s[j]);
+            s[j] = fmaf(v.z, w.z, s[j]);
+            s[j] = fmaf(v.w, w.w, s[j]);
+          }
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          const float v = ar[k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s[j] = fmaf(v, w0[j * KP + k], s[j]);
+        }
+      }
+      if (a.residual) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(a.residual + m * a.ldr + n);
+        s[0] += r.x; s[1] += r.y; s[2] += r.z; s[3] += r.w;
+      }
+      *reinterpret_cast<f32x4*>(a.C + m * a.ldc + n) = s;
+    }
+    return;
+  }
   const long total = (long)a.M * N;
   // (N a power of two -- every caller's is --: shift and mask instead of a 64-bit division per
   // output, which cost more than the whole dot product of a 2- or 8-feature row)
@@ -400,7 +440,7 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   // N K = 256 on the MFMA tiles are as fast or faster, 32 x 8 at 2 M rows 180 vs 250 us)
   // (round 5: without the 64-bit division per output the thread-per-output kernel wins up to
   // N K = 512 -- 2 097 152 x 8 x 32: 249 us on the tiles)
-  const bool rows_small = a_kc && K <= GEMM_ROWS_K && N <= GEMM_SMALL && (long)N * K <= 512 && M >= 65536;
+  const bool rows_small = a_kc && K <= GEMM_ROWS_K && N <= GEMM_ROWS_N && (long)N * K <= 512 && M >= 65536;
   ADELL_REQUIRE(rows_small || (tall ? workspace != nullptr : (p.splits == 1 || workspace)),
                 "gemm: workspace required for this shape");
   GemmArgs a;

@@ -1748,7 +1748,7 @@ def gemm_f16x3_ok(M, N, K, A, lda, a_kc, B, ldb, b_kc):
             return False
     # a handful of features over >= 64 k rows: the thread-per-output kernel of adell_gemm_f32
     # (csrc/gemm.hip, rows_small) streams them; 128-wide MFMA tiles run 2 097 152 x 32 x 8 at 1.3 TB/s
-    if a_kc and K <= 64 and N <= 32 and N * K <= 512 and M >= 65536:
+    if a_kc and K <= 64 and N <= 64 and N * K <= 512 and M >= 65536:
         return False
     return bool(_lib.lib().adell_gemm_f16x3_applicable(M, N, K, _ptr(A), lda, int(a_kc), _ptr(B), ldb,
                                                        int(b_kc)))
