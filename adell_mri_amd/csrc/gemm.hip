@@ -364,6 +364,98 @@ __global__ __launch_bounds__(256) void adell_gemm_tall_small_kernel(GemmArgs a) 
   }
 }
 
+// The same product for dense operands (lda == M, ldb == N, 16-byte aligned) and power-of-two M, N
+// up to 64 with M N <= 512: a block walks a contiguous range of rows in chunks; a chunk of both
+// operands is copied to LDS as one flat stream of 16-byte pieces (the kernel above reads 4-byte
+// pieces, a few per lane in flight: 1.3 TB/s on 8 x 2 over 8.4 M rows, and 64 x 8 fell to the
+// 128-wide MFMA tiles at 0.9 TB/s); thread = (m, NB outputs n, row group g) sums the rows
+// r = g (mod groups) of the chunk from LDS; groups folded in order, one partial [M][N] per block.
+constexpr int GEMM_TALL_LDS_FLOATS = 8192;      // 32 KB of operands per chunk
+
+__global__ __launch_bounds__(256) void adell_gemm_tall_lds_kernel(GemmArgs a, int R, int NB) {
+  __shared__ __attribute__((aligned(16))) float sAB[GEMM_TALL_LDS_FLOATS];
+  __shared__ float red[256 * 8];
+  const int M = a.M, N = a.N;
+  float* sA = sAB;                 // [R][M]
+  float* sB = sAB + R * M;         // [R][N]
+  const int nq = N / NB;           // output groups per m
+  const int P = M * nq;            // threads per row slice
+  const int groups = 256 / P;
+  const int p = threadIdx.x % P, g = threadIdx.x / P;
+  const int m = p / nq, n0 = (p - m * nq) * NB;
+  const bool active = g < groups;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const long nchunks = ((long)a.K + R - 1) / R;
+  const long per = (nchunks + gridDim.x - 1) / gridDim.x;
+  const long c0 = (long)blockIdx.x * per, c1 = (c0 + per) < nchunks ? (c0 + per) : nchunks;
+  for (long c = c0; c < c1; ++c) {
+    const long k0 = c * R;
+    const int rows = (int)(((long)a.K - k0) < R ? ((long)a.K - k0) : R);
+    const f32x4* gA = reinterpret_cast<const f32x4*>(a.A + k0 * M);
+    const f32x4* gB = reinterpret_cast<const f32x4*>(a.B + k0 * N);
+    const int nA = rows * M / 4, nB = rows * N / 4;       // (rows % 4 == 0: the chunk length is a
+    __syncthreads();                                      //  multiple of 64 and K of 4)
+    for (int i = threadIdx.x; i < nA; i += 256) reinterpret_cast<f32x4*>(sA)[i] = gA[i];
+    for (int i = threadIdx.x; i < nB; i += 256) reinterpret_cast<f32x4*>(sB)[i] = gB[i];
+    __syncthreads();
+    if (active) {
+      if (NB == 8) {                                      // (n0 and N in eights: 16-byte reads)
+        for (int r = g; r < rows; r += groups) {
+          const float av = sA[r * M + m];
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB + r * N + n0);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB + r * N + n0 + 4);
+          acc[0] = fmaf(av, b0.x, acc[0]); acc[1] = fmaf(av, b0.y, acc[1]);
+          acc[2] = fmaf(av, b0.z, acc[2]); acc[3] = fmaf(av, b0.w, acc[3]);
+          acc[4] = fmaf(av, b1.x, acc[4]); acc[5] = fmaf(av, b1.y, acc[5]);
+          acc[6] = fmaf(av, b1.z, acc[6]); acc[7] = fmaf(av, b1.w, acc[7]);
+        }
+      } else {
+        for (int r = g; r < rows; r += groups) {
+          const float av = sA[r * M + m];
+          const float* br = sB + r * N + n0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (j < NB) acc[j] = fmaf(av, br[j], acc[j]);
+        }
+      }
+    }
+  }
+  // fold the row groups in order
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = active ? acc[j] : 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < M * N; i += 256) {
+    const int mm = i / N, n = i - mm * N;
+    const int pp = mm * nq + n / NB, j = n % NB;
+    float sum = 0.f;
+    for (int gg = 0; gg < groups; ++gg) sum += red[(gg * P + pp) * 8 + j];
+    a.slab[((long)blockIdx.x * M + mm) * N + n] = sum;
+  }
+}
+
+// chunk rows / outputs per thread / blocks of the LDS-staged form, or 0 when it does not apply
+static int adell_gemm_tall_lds_plan(int M, int N, int K, long lda, long ldb, const float* A,
+                                    const float* B, int* R, int* NB) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  if (!pow2(M) || !pow2(N) || M > 64 || N > 64 || M * N > 512 || M * N < 8 || K < 16384 || (K & 3)) return 0;
+  if (A != nullptr && (lda != M || ldb != N || (((uintptr_t)A | (uintptr_t)B) & 15))) return 0;
+  int nb = N < 8 ? N : 8;
+  while (M * (N / nb) > 256) nb *= 2;           // (M N <= 512, nb <= 8: never needed beyond 8)
+  if (nb > 8) return 0;
+  int r = GEMM_TALL_LDS_FLOATS / (M + N);
+  r &= ~63;
+  if (r < 64) return 0;
+  *R = r;
+  *NB = nb;
+  long b = ((long)K + r - 1) / r;               // chunks
+  b = (b + 3) / 4;                              // at least four chunks per block
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 static int adell_gemm_tall_blocks(int M, int N, int K) {
   if (M > GEMM_SMALL || N > GEMM_SMALL || K < 16384) return 0;
   long b = K / 512;
@@ -404,7 +496,10 @@ extern "C" long adell_gemm_f32_workspace_floats(int M, int N, int K) {
   const GemmPlan p = adell_gemm_plan(M, N, K);
   long need = p.splits > 1 ? (long)p.splits * M * N : 0;
   // (the layout decides at launch whether the tall small-output kernel runs: room for either)
-  const long tall = (long)adell_gemm_tall_blocks(M, N, K) * M * N;
+  long tall = (long)adell_gemm_tall_blocks(M, N, K) * M * N;
+  int r_ = 0, nb_ = 0;
+  const long tall2 = (long)adell_gemm_tall_lds_plan(M, N, K, 0, 0, nullptr, nullptr, &r_, &nb_) * M * N;
+  if (tall2 > tall) tall = tall2;
   return need > tall ? need : tall;
 }
 
@@ -435,7 +530,9 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   ADELL_REQUIRE(lda >= (a_kc ? K : M) && ldb >= (b_kc ? K : N) && ldc >= N, "gemm: bad strides");
   ADELL_REQUIRE(!residual || ldr >= N, "gemm: bad residual stride");
   const GemmPlan p = adell_gemm_plan(M, N, K);
-  const int tall = (!a_kc && !b_kc) ? adell_gemm_tall_blocks(M, N, K) : 0;
+  int tallR = 0, tallNB = 0;
+  const int tall_lds = (!a_kc && !b_kc) ? adell_gemm_tall_lds_plan(M, N, K, lda, ldb, A, B, &tallR, &tallNB) : 0;
+  const int tall = tall_lds ? tall_lds : ((!a_kc && !b_kc) ? adell_gemm_tall_blocks(M, N, K) : 0);
   // (measured on SWIN-UNet's shapes: 10x / 5x for 8 -> 2 / 2 -> 8 features at 8.4 M rows; from
   // N K = 256 on the MFMA tiles are as fast or faster, 32 x 8 at 2 M rows 180 vs 250 us)
   // (round 5: without the 64-bit division per output the thread-per-output kernel wins up to
@@ -464,7 +561,10 @@ extern "C" int adell_gemm_f32(int M, int N, int K, const float* A, long lda, int
   }
   if (tall) {
     a.splits = tall;
-    hipLaunchKernelGGL(adell_gemm_tall_small_kernel, dim3((unsigned)tall), dim3(256), 0, st, a);
+    if (tall_lds)
+      hipLaunchKernelGGL(adell_gemm_tall_lds_kernel, dim3((unsigned)tall), dim3(256), 0, st, a, tallR, tallNB);
+    else
+      hipLaunchKernelGGL(adell_gemm_tall_small_kernel, dim3((unsigned)tall), dim3(256), 0, st, a);
     const long blocks = ((long)M * N + 63) / 64;
     hipLaunchKernelGGL(adell_gemm_reduce_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, a);
     ADELL_CHECK_HIP(hipGetLastError());

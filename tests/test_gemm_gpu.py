@@ -21,7 +21,12 @@ def rel(a, r):
                                    (864, 512, 512), (864, 1536, 512), (4100, 520, 72),
                                    # a handful of features over many rows: the streaming kernels
                                    (70000, 8, 2), (70001, 2, 8), (66000, 32, 8), (65540, 12, 5),
-                                   (2, 8, 70000), (8, 32, 20000), (32, 32, 16400), (5, 3, 33000)])
+                                   (2, 8, 70000), (8, 32, 20000), (32, 32, 16400), (5, 3, 33000),
+                                   # round 5: four outputs per thread / N K up to 512 (rows kernel);
+                                   # the LDS-staged weight-gradient form (dense power-of-two M, N)
+                                   (70000, 8, 32), (66000, 64, 8), (65540, 8, 64), (70000, 16, 32),
+                                   (8, 2, 70000), (64, 8, 16388), (8, 64, 65600), (32, 8, 100000),
+                                   (16, 16, 16384), (2, 4, 16388)])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_layouts_match_float64(cuda, M, N, K, layout):
     rng = np.random.default_rng(M * 131 + N * 17 + K)
