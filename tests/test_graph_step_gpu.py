@@ -21,8 +21,8 @@ pytestmark = pytest.mark.gpu
 # capture_end skips the test with that reason; any other failure fails it.
 
 
-def _in_child(name, *args):
-    env = dict(os.environ, ADELL_CHECK_DENSE="1")
+def _in_child(name, *args, extra_env=None):
+    env = dict(os.environ, ADELL_CHECK_DENSE="1", **(extra_env or {}))
     r = subprocess.run([sys.executable, "-X", "faulthandler", os.path.abspath(__file__), name, *map(str, args)],
                        capture_output=True, text=True, timeout=600, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -61,6 +61,15 @@ def _batches(cuda, n):
 @pytest.mark.parametrize("dropout_rate", [0.1, 0.0])
 def test_replayed_steps_equal_eager_steps_bit_for_bit(cuda, dropout_rate):
     _in_child("replayed_steps_equal_eager_steps", dropout_rate)
+
+
+def test_a_child_that_dies_inside_capture_end_skips_and_any_other_death_fails(cuda):
+    """The guard itself: a child killed by a signal inside a frame called capture_end is a skip with
+    the reason spelled out; a child that dies anywhere else is a failure."""
+    with pytest.raises(pytest.skip.Exception, match="hipStreamEndCapture"):
+        _in_child("replayed_steps_equal_eager_steps", 0.0, extra_env={"ADELL_TEST_FAKE_CRASH": "capture_end"})
+    with pytest.raises(AssertionError):
+        _in_child("replayed_steps_equal_eager_steps", 0.0, extra_env={"ADELL_TEST_FAKE_CRASH": "elsewhere"})
 
 
 def replayed_steps_equal_eager_steps(cuda, dropout_rate):
@@ -126,6 +135,22 @@ def test_graph_mode_refuses_hooked_gradient_buckets(cuda):
         StepRunner(net, opt, sync).enable_graph(_batches(cuda, 1)[0])
 
 
+def capture_end():          # (the frame name the guard looks for, for the guard's own test)
+    import signal
+
+    os.kill(os.getpid(), signal.SIGSEGV)
+
+
+def _elsewhere():
+    import signal
+
+    os.kill(os.getpid(), signal.SIGSEGV)
+
+
 if __name__ == "__main__":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if os.environ.get("ADELL_TEST_FAKE_CRASH") == "capture_end":
+        capture_end()
+    elif os.environ.get("ADELL_TEST_FAKE_CRASH"):
+        _elsewhere()
     globals()[sys.argv[1]](torch.device("cuda:0"), *[float(v) for v in sys.argv[2:]])
