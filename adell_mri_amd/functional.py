@@ -1435,6 +1435,49 @@ def space_to_depth(x, scale):
     return out.permute(0, 4, 1, 2, 3)
 
 
+def conv3d_dilated(x, weight, bias, rate):
+    """``Conv3d(kernel_size=3, dilation=rate, padding="same")`` (stride 1) -- the dilated convs of the
+    atrous pyramid (multi_resolution.py:392-403). A tap of a dilated kernel reads
+    ``x[o + (t - 1) rate]``: output voxel ``o = rate q + p`` only ever meets the sub-lattice of voxels
+    congruent to ``p`` (per axis), on which the operation is the PLAIN 3x3x3 convolution with
+    padding 1. So: one gather (space-to-batch: the rate^3 sub-lattices become batch items), the
+    ordinary conv kernels on a batch of N rate^3 volumes, one inverse gather. Extents that are not
+    multiples of ``rate`` are zero-framed at the far end first (``adell_window_ndhwc``; the frame is
+    what the conv's own zero padding would be) and the result is cropped back."""
+    rate = tuple(int(r) for r in ops._triple(rate))
+    x = ops.ndhwc(x)
+    if rate == (1, 1, 1):
+        return conv3d(x, weight, bias, 1, 1)
+    if tuple(weight.shape[2:]) != (3, 3, 3):
+        raise NotImplementedError("dilated convolutions: 3x3x3 kernels only")
+    N, C, D, H, W = x.shape
+    full = tuple(-(-n // r) * r for n, r in zip((D, H, W), rate))
+    if full != (D, H, W):
+        x = _CropFn.apply(x, full, (0, 0, 0))
+    De, He, We = full
+    sub = tuple(n // r for n, r in zip(full, rate))
+
+    def spec(ch):
+        axes = [(N, De * He * We * ch, 0), (De, He * We * ch, 0), (He, We * ch, 0), (We, ch, 0), (ch, 1, 0)]
+        dims = [(N, 0, 1)]
+        dims += [(r, a + 1, 1) for a, r in enumerate(rate) if r > 1]                       # the phases
+        dims += [(n, a + 1, r) for a, (n, r) in enumerate(zip(sub, rate))] + [(ch, 4, 1)]  # the sub-lattice
+        return dims, axes
+
+    phases = rate[0] * rate[1] * rate[2]
+    dims, axes = spec(C)
+    xb = _GatherFn.apply(x.permute(0, 2, 3, 4, 1), dims, axes, (N * phases, *sub, C))
+    yb = conv3d(xb.permute(0, 4, 1, 2, 3), weight, bias, 1, 1, want_stats=False)
+    Cout = weight.shape[0]
+    odims, oaxes = spec(Cout)
+    inv_dims, inv_axes, _ = _inverse_gather(odims, oaxes)
+    y = _GatherFn.apply(ops.ndhwc(yb).permute(0, 2, 3, 4, 1).contiguous(), inv_dims, inv_axes,
+                        (N, De, He, We, Cout)).permute(0, 4, 1, 2, 3)
+    if full != (D, H, W):
+        y = _CropFn.apply(y, (D, H, W), (0, 0, 0))
+    return y
+
+
 class _WindowAttnFn(torch.autograd.Function):
     """q-norm, k-norm and windowed attention on a QKV buffer [tokens, H*(2a+hd)] whose heads
     are laid out q | k | v (linear_blocks.py:369-417). Nothing is sliced or permuted: the

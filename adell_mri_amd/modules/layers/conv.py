@@ -22,16 +22,23 @@ def _resolve_padding(padding, kernel_size, stride, dilation):
 
 
 class Conv3d(torch.nn.Conv3d):
+    def _dilated(self):
+        """kernel 3, stride 1, padding "same", dilation > 1 (the atrous pyramid's convs)."""
+        return (any(d != 1 for d in self.dilation) and tuple(self.kernel_size) == (3, 3, 3)
+                and tuple(self.stride) == (1, 1, 1) and self.padding == "same")
+
     def _check(self):
-        if self.groups != 1 or any(d != 1 for d in self.dilation) or self.padding_mode != "zeros":
-            raise AdellHipError("HIP Conv3d supports groups=1, dilation=1, zero padding only")
+        if self.groups != 1 or self.padding_mode != "zeros" or (
+                any(d != 1 for d in self.dilation) and not self._dilated()):
+            raise AdellHipError("HIP Conv3d supports groups=1, zero padding, dilation=1 (or kernel 3, "
+                                "stride 1, padding='same' with a dilation)")
 
     def takes_carry(self):
         """Whether forward() hands GradCarry arguments to the conv kernels (the space-to-depth
         stem path does not)."""
         k, st = tuple(self.kernel_size), tuple(self.stride)
         pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
-        return not (k == st and max(k) > 2 and tuple(pad) == (0, 0, 0))
+        return not (k == st and max(k) > 2 and tuple(pad) == (0, 0, 0)) and not self._dilated()
 
     def rows_spec(self):
         """(weight, stride, padding) for functional.expect_rows when this conv may read its input
@@ -48,6 +55,11 @@ class Conv3d(torch.nn.Conv3d):
         added to the output inside the kernel epilogue; ``carry_in`` / ``carry_out`` /
         ``carry_x0`` / ``carry_cat``: functional.GradCarry (residual link, skip fork)."""
         self._check()
+        if self._dilated():
+            if X_cat is not None or residual is not None or carry_in is not None \
+                    or carry_out is not None or carry_x0 is not None or carry_cat is not None:
+                raise AdellHipError("HIP Conv3d: a dilated conv takes one source and no fused epilogue")
+            return HF.conv3d_dilated(X, self.weight, self.bias, self.dilation)
         pad = _resolve_padding(self.padding, self.kernel_size, self.stride, self.dilation)
         k, st = tuple(self.kernel_size), tuple(self.stride)
         if k == st and max(k) > 2 and tuple(pad) == (0, 0, 0) and X_cat is None:

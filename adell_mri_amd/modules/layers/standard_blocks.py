@@ -58,3 +58,31 @@ class DenseBlock(torch.nn.Module):
             out = adn(out)
             outputs.append(out)
         return outputs if self.return_all is True else outputs[-1]
+
+
+class DepthWiseSeparableConvolution3d(torch.nn.Module):
+    """Depthwise ``Conv3d(c, c, k, padding, groups=c)`` -> pointwise ``Conv3d(c, out, 1)`` -> ADN
+    (adell_mri/modules/layers/standard_blocks.py:93-144): the stencil kernel and the 1x1x1 conv on the
+    GEMM / implicit-GEMM kernels. Same attribute names (``depthwise_op``, ``pointwise_op``,
+    ``act_op``) and parameter shapes."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, padding=1,
+                 adn_fn=torch.nn.Identity):
+        super().__init__()
+        from .res_blocks import DepthwiseConv3d
+
+        self.input_channels = in_channels
+        self.output_channels = out_channels
+        self.kernel_size = kernel_size
+        self.padding = padding
+        self.adn_fn = adn_fn
+        if padding != "same" and tuple(torch.nn.modules.utils._triple(padding)) != \
+                tuple(k // 2 for k in torch.nn.modules.utils._triple(kernel_size)):
+            raise NotImplementedError("HIP DepthWiseSeparableConvolution3d: padding 'same' (or k // 2)")
+        self.depthwise_op = DepthwiseConv3d(in_channels, in_channels, kernel_size=kernel_size,
+                                            padding="same", groups=in_channels)
+        self.pointwise_op = Conv3d(in_channels, out_channels, kernel_size=1)
+        self.act_op = adn_fn(out_channels)
+
+    def forward(self, X: torch.Tensor) -> torch.Tensor:
+        return self.act_op(self.pointwise_op(self.depthwise_op(X)))

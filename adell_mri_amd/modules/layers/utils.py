@@ -4,6 +4,15 @@ from typing import List
 import torch
 
 
+def split_int_into_n(i: int, n: int) -> List[int]:
+    """``i`` divided into ``n`` slots as equally as possible, the remainder to the first slots
+    (adell_mri/modules/layers/utils.py:8-27)."""
+    out = [i // n] * n
+    for idx in range(i % n):
+        out[idx] += 1
+    return out
+
+
 def crop_to_size(X: torch.Tensor, output_size: List[int]) -> torch.Tensor:
     """Centre-crop the spatial dims of ``X`` ([N, C, ...]) to ``output_size``.
 

@@ -217,9 +217,10 @@ class UNet(torch.nn.Module):
         elif self.conv_type == "sae":
             self.conv_op_enc = self.sae_block
             self.conv_op_dec = self.sae_block
+        elif self.conv_type == "asp":
+            self.conv_op_enc = self.asp_block
+            self.conv_op_dec = self.sae_block
         else:
-            # ("asp": atrous spatial pyramid pooling -- dilated convolutions, which the conv
-            # kernels do not have)
             raise NotImplementedError(
                 f"conv_type={self.conv_type!r} (spatial_dimensions={self.spatial_dimensions}) "
                 "is outside the HIP path built so far")
@@ -267,6 +268,20 @@ class UNet(torch.nn.Module):
 
     sae_2d = sae_block
     sae_3d = sae_block
+
+    def asp_block(self, in_d, out_d, kernel_size, stride=None, padding=None):
+        """Atrous spatial pyramid with rates (1, 2) and an instance-norm ADN of its own, whatever
+        ``norm_type`` says; ``kernel_size`` / ``stride`` / ``padding`` are ignored as in the reference
+        (unet.py:399-413) -- an "asp" encoder never downsamples and the decoder crops."""
+        from ..layers.adn_fn import get_adn_fn
+        from ..layers.multi_resolution import (AtrousSpatialPyramidPooling2d,
+                                               AtrousSpatialPyramidPooling3d)
+        asp = AtrousSpatialPyramidPooling3d if self.spatial_dimensions == 3 else AtrousSpatialPyramidPooling2d
+        return asp(in_d, out_d, [1, 2],
+                   get_adn_fn(self.spatial_dimensions, "instance", self.activation_fn, self.dropout_param))
+
+    asp_2d = asp_block
+    asp_3d = asp_block
 
     def res_block_conv_3d(self, in_d, out_d, kernel_size, stride=None, padding=None):
         """ResidualBlock3d / 2d (+ max pooling when strided): unet.py:309-379."""

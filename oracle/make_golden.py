@@ -114,6 +114,19 @@ SAE_CASES = {
                         depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
                    (2, 1, 32, 32), "normal"),
 }
+ASP_CASES = {
+    # conv_type="asp" (unet.py:399-413, multi_resolution.py:291-416): every encoder op is an atrous
+    # spatial pyramid (rates 1 and 2: dilated conv -> ADN -> depthwise-separable conv -> ADN per
+    # rate, outputs concatenated) that IGNORES kernel size, stride and padding -- the encoder never
+    # downsamples and the decoder crops its upsampled tensors to the skips; decoder ops are "sae"
+    "unet3d_asp": (dict(spatial_dimensions=3, conv_type="asp", link_type="identity",
+                        upscale_type="transpose", norm_type="instance", padding=1,
+                        dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                        depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+                   (2, 2, 12, 10, 9), "uniform"),
+    # (no 2-D case: AtrousSpatialPyramidPooling2d cannot be constructed -- standard_blocks.py:78
+    # reads self.paddign)
+}
 DEPTHWISE_CASES = {
     # conv_type="depthwise" (unet.py:292-307): Conv(groups = channels, k, stride) -> ADN -> 1x1 conv.
     # The constructor default padding="same" (the 1x1 conv takes the SAME padding argument, so an
@@ -1175,6 +1188,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "sae":
         for name, (kw, shape, dist) in SAE_CASES.items():
+            gen_unet(name, kw, shape, dist)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "asp":
+        for name, (kw, shape, dist) in ASP_CASES.items():
             gen_unet(name, kw, shape, dist)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "attention":

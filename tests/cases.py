@@ -48,6 +48,16 @@ SAE_CASES = {
                        depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
 }
 
+# conv_type="asp" (unet.py:399-413: atrous pyramid encoder ops that ignore stride, "sae" decoder ops);
+# 3-D only -- the reference's 2-D pyramid cannot be constructed (standard_blocks.py:78 reads
+# self.paddign); fixtures: `python oracle/make_golden.py asp`
+ASP_CASES = {
+    "unet3d_asp": dict(spatial_dimensions=3, conv_type="asp", link_type="identity",
+                       upscale_type="transpose", norm_type="instance", padding=1,
+                       dropout_param=0.0, activation_fn="swish", in_channels=2, n_classes=2,
+                       depth=[8, 16, 32], kernel_sizes=[3] * 3, strides=[2] * 3),
+}
+
 # link_type="attention" (unet.py:473-481); fixtures: `python oracle/make_golden.py attention`
 ATTENTION_LINK_CASES = {
     "unet3d_attention_links": dict(spatial_dimensions=3, conv_type="regular", link_type="attention",

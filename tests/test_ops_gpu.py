@@ -467,3 +467,31 @@ def test_batchnorm_running_statistics_against_torch(cuda, momentum):
     assert int(nbt) == 2 and int(ref.num_batches_tracked) == 2
     assert _relerr(_np(rm), _np(ref.running_mean)) < 1e-6
     assert _relerr(_np(rv), _np(ref.running_var)) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,size,rate", [(8, 16, (10, 12, 8), 2), (4, 6, (9, 7, 11), 2),
+                                                (16, 8, (9, 9, 10), 3), (8, 8, (7, 8, 9), (2, 1, 2))])
+def test_dilated_conv_against_torch(cuda, cin, cout, size, rate):
+    """functional.conv3d_dilated (space-to-batch gather + the plain conv kernels on the rate^3
+    sub-lattices + inverse gather; zero frame for extents that are not multiples of the rate) against
+    torch's dilated conv in fp64: values and the gradients of input, weight and bias."""
+    from adell_mri_amd import functional as HF
+
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn((2, cin, *size), generator=g, dtype=torch.float64).requires_grad_(True)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g, dtype=torch.float64) / np.sqrt(27 * cin)).requires_grad_(True)
+    b = torch.randn(cout, generator=g, dtype=torch.float64).requires_grad_(True)
+    ref = torch.nn.functional.conv3d(x, w, b, padding=rate, dilation=rate)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    xd = ops.ndhwc(x.detach().float().to(cuda)).requires_grad_(True)
+    wd = w.detach().float().to(cuda).requires_grad_(True)
+    bd = b.detach().float().to(cuda).requires_grad_(True)
+    out = HF.conv3d_dilated(xd, wd, bd, rate)
+    assert tuple(out.shape) == tuple(ref.shape)
+    out.backward(dy.float().to(cuda))
+    assert _relerr(_np(out).astype(np.float64), ref.detach().numpy()) < 5e-6
+    assert _relerr(_np(xd.grad).astype(np.float64), x.grad.numpy()) < 5e-6
+    assert _relerr(_np(wd.grad).astype(np.float64), w.grad.numpy()) < 2e-5
+    assert _relerr(_np(bd.grad).astype(np.float64), b.grad.numpy()) < 2e-5

@@ -10,7 +10,7 @@ import torch
 from adell_mri_amd._lib import AdellHipError
 from adell_mri_amd.modules.activations import activation_factory
 from adell_mri_amd.modules.segmentation.unet import UNet
-from cases import DEPTHWISE_CASES, SAE_CASES, UNET_CASES
+from cases import ASP_CASES, DEPTHWISE_CASES, SAE_CASES, UNET_CASES
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -21,10 +21,10 @@ def build(kw):
     return UNet(**kw)
 
 
-@pytest.mark.parametrize("name", list(UNET_CASES) + list(DEPTHWISE_CASES) + list(SAE_CASES))
+@pytest.mark.parametrize("name", list(UNET_CASES) + list(DEPTHWISE_CASES) + list(SAE_CASES) + list(ASP_CASES))
 def test_state_dict_keys_and_shapes_equal_reference(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    net = build({**UNET_CASES, **DEPTHWISE_CASES, **SAE_CASES}[name])
+    net = build({**UNET_CASES, **DEPTHWISE_CASES, **SAE_CASES, **ASP_CASES}[name])
     sd = net.state_dict()
     assert list(sd.keys()) == [str(k) for k in g["param_keys"]]
     for k, v in sd.items():
@@ -65,3 +65,12 @@ def test_no_cpu_fallback():
 def test_parent_class_builds_nothing():
     net = UNet(parent_class=True)
     assert len(list(net.parameters())) == 0
+
+
+def test_asp_2d_raises_like_the_reference_constructor():
+    """conv_type="asp" in 2-D: the reference's DepthWiseSeparableConvolution2d reads self.paddign
+    (standard_blocks.py:78) and raises at construction; the mirror refuses with that reason."""
+    with pytest.raises(NotImplementedError, match="paddign"):
+        build(dict(spatial_dimensions=2, conv_type="asp", link_type="identity", upscale_type="transpose",
+                   norm_type="instance", padding=1, dropout_param=0.0, activation_fn="relu",
+                   in_channels=1, n_classes=2, depth=[8, 16], kernel_sizes=[3] * 2, strides=[2] * 2))

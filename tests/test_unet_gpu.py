@@ -9,7 +9,7 @@ import torch
 
 from adell_mri_amd.modules.activations import activation_factory
 from adell_mri_amd.modules.segmentation.unet import UNet
-from cases import DEPTHWISE_CASES, SAE_CASES, UNET_CASES, grad_rel_err
+from cases import ASP_CASES, DEPTHWISE_CASES, SAE_CASES, UNET_CASES, grad_rel_err
 from oracle.torch_ref.unet import compound_loss
 from oracle.weights import tensor_for
 
@@ -120,10 +120,12 @@ def test_depthwise_unet_matches_reference(cuda, name):
 
 # ---- conv_type="sae" (unet.py:375-397): every conv block followed by a concurrent (spatial + channel)
 # squeeze-and-excite, 3-D and 2-D, against fixtures from the real reference classes ------------------
-@pytest.mark.parametrize("name", list(SAE_CASES))
+# conv_type="asp": atrous-pyramid encoder ops (dilated convs on the interleaved sub-lattices of their
+# input, functional.conv3d_dilated; odd extents 9 / 5 exercise the zero frame), "sae" decoder ops
+@pytest.mark.parametrize("name", list(SAE_CASES) + list(ASP_CASES))
 def test_sae_unet_matches_reference(cuda, name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    net = build(SAE_CASES[name], cuda).eval()
+    net = build({**SAE_CASES, **ASP_CASES}[name], cuda).eval()
     assert [k for k, _ in net.named_parameters()] == [f[5:] for f in g.files if f.startswith("grad:")]
     x = torch.from_numpy(g["x"]).to(cuda)
     y = torch.from_numpy(g["y"]).to(cuda)
