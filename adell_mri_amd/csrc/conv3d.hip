@@ -427,6 +427,13 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
   else if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.Cout <= 32 &&
            (a.SD > 1 || a.SH > 1 || a.SW > 1) && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1)
     t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 6);
+  // 5x5x5 stride-1 layers (the k = 5 bottleneck blocks of the ResNet backbone, 64 -> 64 at 65^3): a
+  // 256-voxel brick has a 12 x 12 x 8 halo (74 KB) and one block per CU; 128-voxel x 32-column bricks
+  // (49 KB halo, two blocks per CU): 1923 -> 1687 us (tools/cfg_exp.py 64 64 65 1 5)
+  else if (g_conv_force_cfg < 0 && a.shuffle == 0 && a.KD == 5 && a.KH == 5 && a.KW == 5 &&
+           a.SD == 1 && a.SH == 1 && a.SW == 1 && a.UPS == 1 && a.UPSY == 1 && a.UPSZ == 1 &&
+           (long)N * a.Do * a.Ho * a.Wo >= 65536)
+    t = adell_pick_tile(N, a.Do, a.Ho, a.Wo, a.Cout, 3);
   // Low-resolution 3x3x3 stride-1 levels with wide outputs (measured with warm clocks,
   // tools/cfg_exp.py, batch 2): the 64-voxel x 64-column bricks of the "small problem" rule make
   // every block stream the whole weight slice of its column tile from L2 (256 -> 256 at 16^3:
