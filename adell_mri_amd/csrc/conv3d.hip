@@ -454,7 +454,9 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
       // brick streams 1.8 MB of weights per 32 columns -- 851 us; 256-voxel x 64-column bricks 279 us)
       pick = (a.Cin >= 512 && vox >= 2048) ? 0 : 6;
     else if (vox < 32768)
-      pick = a.Cin >= 256 ? 1 : 3;
+      // (512 output channels: 64-column bricks -- 512 -> 512 at 17 x 17 x 65 1381 -> 1283 us,
+      // 256 -> 512 693 -> 657 us; 256 outputs stay on 32 columns: 765 vs 778 us)
+      pick = a.Cout >= 512 ? 0 : (a.Cin >= 256 ? 1 : 3);
     else if (vox < 262144 && a.Cout <= 64)
       pick = 1;
     if (pick >= 0) {
