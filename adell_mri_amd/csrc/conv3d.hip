@@ -452,11 +452,15 @@ static int adell_plan_f16(ConvArgs& a, int N, ConvTile* tile, size_t* lds_out) {
     } else if (vox < 4096)
       // (512 -> 512 at 9 x 9 x 33, the bottom level of the ResNet-backbone U-Net: every 64-voxel
       // brick streams 1.8 MB of weights per 32 columns -- 851 us; 256-voxel x 64-column bricks 279 us)
-      pick = (a.Cin >= 512 && vox >= 2048) ? 0 : 6;
+      // (round 5, tools/cfg_exp.py, batch 2 at 8^3: 64-voxel x 64-column four-wave bricks 41 us against
+      // 50 us on the two-wave ones for 256 -> 256, 25 / 31 for 128 -> 256, 72 / 86 for 512 -> 256)
+      pick = (a.Cin >= 512 && vox >= 2048) ? 0 : (vox >= 512 ? 2 : 6);
     else if (vox < 32768)
       // (512 output channels: 64-column bricks -- 512 -> 512 at 17 x 17 x 65 1381 -> 1283 us,
-      // 256 -> 512 693 -> 657 us; 256 outputs stay on 32 columns: 765 vs 778 us)
-      pick = a.Cout >= 512 ? 0 : (a.Cin >= 256 ? 1 : 3);
+      // 256 -> 512 693 -> 657 us; 256 outputs stay on 32 columns: 765 vs 778 us. Round 5: the
+      // 128-voxel bricks that Cin < 256 took lose to the 256-voxel ones + split-K at 2 x 16^3:
+      // 128 -> 128 55 -> 38 us, 64 -> 128 35 -> 29 us, 128 -> 64 35 -> 28 us)
+      pick = a.Cout >= 512 ? 0 : 1;
     else if (vox < 262144 && a.Cout <= 64)
       pick = 1;
     if (pick >= 0) {
